@@ -1,0 +1,125 @@
+"""Pins the oracle (oracle/rejit_oracle.c) -- CPU only.
+
+1. against the expectations written in the reference's own tools/tests/test.cc and the
+   outputs of the real reference (use_fast_forward=0) stored in tests/golden/;
+2. live against oracle/_ref/librejit_ref.so on fresh random inputs, when that prebuilt
+   library is present (it always is in the build container).
+"""
+import hashlib
+import random
+
+import pytest
+
+import vectors as V
+from checkers import Oracle, Ref, have_ref
+from rejit_amd import workloads as W
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return Oracle()
+
+
+def test_testcc_expectations(oracle):
+    """The numbers written in test.cc itself (count / bool / first-match limits)."""
+    n = 0
+    for v in V.testcc():
+        rx, tx = V.b(v["regex"]), V.b(v["text"])
+        allm = oracle.match_all(rx, tx)
+        assert isinstance(allm, list), (v, oracle.error())
+        if v["macro"] == "TEST":
+            mt = v["match_type"]
+            if mt == "kMatchAll":
+                assert len(allm) == v["expected"], v
+            elif mt == "kMatchFirst":
+                assert bool(allm) == bool(v["expected"]), v
+            else:
+                raise AssertionError(mt)
+        elif v["macro"] == "TEST_Full":
+            assert oracle.match_full(rx, tx) == v["expected_full"], v
+            if v["expected_full"]:  # TestFull also runs kMatchFirst and kMatchAll (test.cc:665-678)
+                assert len(allm) == 1, v
+        else:
+            assert len(allm) == v["expected_count"], v
+            if v["expected_count"]:
+                assert list(allm[0]) == v["expected_first"], v
+        n += 1
+    assert n > 1200
+
+
+def test_against_reference_outputs(oracle):
+    """Bit-exact MatchAll offsets and MatchFull vs the real reference (ff=0) fixtures."""
+    n = 0
+    for rx, tx, exp_all, exp_full in V.all_matchall_cases():
+        assert oracle.match_all(rx, tx) == exp_all, (rx, tx)
+        assert oracle.match_full(rx, tx) == exp_full, (rx, tx)
+        n += 1
+    assert n > 2500
+
+
+def test_parse_errors(oracle):
+    for e in V.semantics()["errors"]:
+        st = oracle.status(V.b(e["regex"]))
+        assert st == (Oracle.PARSE_ERROR if e["status"] == "ParserError" else Oracle.REJECTED), e
+
+
+def _digest(ms):
+    h = hashlib.sha256()
+    for b_, e_ in ms:
+        h.update(int(b_).to_bytes(8, "little"))
+        h.update(int(e_).to_bytes(8, "little"))
+    return h.hexdigest()
+
+
+def test_bench_regexes(oracle):
+    import numpy as np
+    for v in V.bench()["bench"]:
+        text = W.random_ascii_numpy(v["n"], v["seed"], ord(v["low"]), ord(v["high"]))
+        for k, o in enumerate(v["plant_offsets"]):
+            p = V.b(v["plants"][k % len(v["plants"])])
+            text[o:o + len(p)] = np.frombuffer(p, dtype=np.uint8)
+        tb = text.tobytes()
+        assert hashlib.sha256(tb).hexdigest() == v["text_sha256"]
+        assert oracle.match_all(V.b(v["regex"]), tb) == V.tup(v["ref_all"]), v["regex"]
+
+
+@pytest.mark.parametrize("nf", [1000, 50000])
+def test_regexdna(oracle, nf):
+    g = V.bench()["regexdna"][str(nf)]
+    raw = W.fasta_raw_numpy(nf).tobytes()
+    stripped = W.fasta_stripped_numpy(nf).tobytes()
+    assert (len(raw), len(stripped)) == (g["raw_size"], g["stripped_size"])
+    assert hashlib.sha256(raw).hexdigest() == g["raw_sha256"]
+    assert hashlib.sha256(stripped).hexdigest() == g["stripped_sha256"]
+    strip = oracle.match_all(V.b(g["strip"]["regex"]), raw)
+    assert len(strip) == g["strip"]["count"] and _digest(strip) == g["strip"]["digest"]
+    for p in g["patterns"]:
+        ms = oracle.match_all(V.b(p["regex"]), stripped)
+        assert len(ms) == p["count"] and _digest(ms) == p["digest"], p["regex"]
+    if nf == 50000:  # the canonical Benchmarks-Game regex-dna output
+        assert [p["count"] for p in g["patterns"]] == [3, 12, 43, 27, 58, 16, 15, 18, 20]
+        assert (g["raw_size"], g["stripped_size"], g["replaced_size"]) == (508411, 500000, 668262)
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref/librejit_ref.so not built")
+def test_live_differential_vs_reference(oracle):
+    """Fresh random patterns every run would not be reproducible; use a second seed than
+    the committed fuzz fixture and compare live.  The generator only emits constructs the
+    reference handles without aborting (see tests/golden/make_golden.py)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import RegexGen, ALPHABETS, RefProc
+    ref = RefProc()
+    rng = random.Random(777)
+    checked = 0
+    for _ in range(600):
+        alphabet = rng.choice(ALPHABETS)
+        rx = RegexGen(rng, alphabet).alt(2).encode("latin1")
+        text = "".join(rng.choice(alphabet) for _ in range(rng.choice([0, 2, 9, 31, 70]))).encode("latin1")
+        r = ref.call("all", rx, text, timeout=5.0)
+        if not isinstance(r, list):
+            continue
+        assert oracle.match_all(rx, text) == r, (rx, text)
+        assert oracle.match_full(rx, text) == ref.call("full", rx, text), (rx, text)
+        checked += 1
+    assert checked > 500
