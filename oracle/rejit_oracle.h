@@ -54,6 +54,12 @@ int ro_match_full(const ro_regex* re, const uint8_t* text, size_t n);
 long ro_match_all_re(const char* regexp, const uint8_t* text, size_t n, uint64_t* out, size_t cap);
 int ro_match_full_re(const char* regexp, const uint8_t* text, size_t n);
 
+/* The documented left-most-longest semantics computed without the ring dynamics
+ * (longest match from every start + greedy pick).  Differs from ro_match_all only on
+ * the reference artefact "Q8" (see rejit_oracle.c); used to classify such inputs. */
+long ro_match_all_spec(const ro_regex* re, const uint8_t* text, size_t n, uint64_t* out, size_t cap);
+long ro_match_all_spec_re(const char* regexp, const uint8_t* text, size_t n, uint64_t* out, size_t cap);
+
 /* Introspection used by tests. */
 int ro_n_states(const ro_regex* re);
 int ro_n_edges(const ro_regex* re);

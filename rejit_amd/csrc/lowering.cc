@@ -1,0 +1,517 @@
+// rejit_amd/csrc/lowering.cc -- AST -> NFA graph -> position automaton + scan plan.
+// See lowering.h for the map to the reference files this replaces.
+#include "lowering.h"
+
+#include <algorithm>
+#include <cstring>
+#include <functional>
+#include <set>
+
+namespace rejit_amd {
+
+// =============================================================================
+// NFA graph.  Same wiring as RegexpIndexer / RegexpLister (src/codegen.cc:91-324).
+namespace {
+
+class GraphBuilder {
+ public:
+  GraphBuilder(Graph* g, int max_states) : g_(g), max_states_(max_states) {}
+  bool failed() const { return failed_; }
+
+  int new_state() {
+    if (g_->n_states >= max_states_) {
+      failed_ = true;
+      return 0;
+    }
+    return g_->n_states++;
+  }
+
+  void control(int src, int dst, ControlKind k) { g_->control_edges.push_back({src, dst, k}); }
+
+  // `copied`: this sub-tree is one the reference obtains through DeepCopy()
+  // (codegen.cc:228-241); Bracket::DeepCopy drops the non_matching flag.
+  void emit(const Node& n, int entry, int exit, bool copied) {
+    if (failed_) return;
+    switch (n.kind) {
+      case NodeKind::Literal: {
+        ByteEdge e;
+        e.src = entry;
+        e.dst = exit;
+        e.bytes = n.bytes;
+        g_->byte_edges.push_back(std::move(e));
+        break;
+      }
+      case NodeKind::Any: {
+        ByteEdge e;
+        e.src = entry;
+        e.dst = exit;
+        ByteSet lb;
+        lb.add('\n');
+        lb.add('\r');
+        e.cls = lb.inverted();  // VisitPeriod, codegen-x64.cc:851-873
+        g_->byte_edges.push_back(std::move(e));
+        break;
+      }
+      case NodeKind::Class: {
+        ByteEdge e;
+        e.src = entry;
+        e.dst = exit;
+        e.cls = (n.negated && !copied) ? n.listed.inverted() : n.listed;
+        g_->byte_edges.push_back(std::move(e));
+        break;
+      }
+      case NodeKind::StartOfLine:
+        control(entry, exit, ControlKind::StartOfLine);
+        break;
+      case NodeKind::EndOfLine:
+        control(entry, exit, ControlKind::EndOfLine);
+        break;
+      case NodeKind::Concat: {
+        int cur = entry;
+        for (size_t i = 0; i < n.kids.size(); i++) {
+          int nxt = (i + 1 == n.kids.size()) ? exit : new_state();
+          emit(*n.kids[i], cur, nxt, copied);
+          cur = nxt;
+        }
+        break;
+      }
+      case NodeKind::Alternate:
+        for (const auto& k : n.kids) emit(*k, entry, exit, copied);
+        break;
+      case NodeKind::Repeat:
+        repeat(n, entry, exit, copied);
+        break;
+    }
+  }
+
+ private:
+  void repeat(const Node& n, int entry, int exit, bool copied) {
+    const Node& base = *n.kids[0];
+    const uint32_t lo = n.min, hi = n.max;
+    const bool bounded = hi != kUnbounded;
+    if (lo == 0 && hi == 0) {
+      control(entry, exit, ControlKind::Epsilon);
+      return;
+    }
+    const bool chain = lo > 1 || (hi > 1 && bounded);
+    const uint32_t copies = chain ? (bounded ? hi : lo) : 1;
+    int in = entry, out = exit;
+    if (!bounded) {
+      out = new_state();
+      if (lo <= 1) in = new_state();
+    }
+    std::vector<int> from(copies), to(copies);
+    int cur = in;
+    for (uint32_t i = 0; i < copies && !failed_; i++) {
+      int nxt = (i + 1 == copies) ? out : new_state();
+      from[i] = cur;
+      to[i] = nxt;
+      emit(base, cur, nxt, copied || i > 0);
+      cur = nxt;
+    }
+    if (failed_) return;
+    if (lo == 0) control(entry, exit, ControlKind::Epsilon);
+    if (bounded && hi > 1) {
+      for (uint32_t i = std::max(1u, lo) - 1; i + 1 < copies; i++) control(to[i], exit, ControlKind::Epsilon);
+    } else {
+      // unbounded repetitions AND bounded ones with max == 1 (x?, x{1}, x{0,1}): the
+      // reference wires a "repeat" epsilon from the last copy's exit back to its entry
+      // (codegen.cc:266-312) -- for max == 1 those are the repetition's own entry/exit
+      // states, shared with whatever surrounds it.
+      if (lo <= 1) control(entry, in, ControlKind::Epsilon);
+      control(out, exit, ControlKind::Epsilon);
+      control(to[copies - 1], from[copies - 1], ControlKind::Epsilon);
+    }
+  }
+
+  Graph* g_;
+  int max_states_;
+  bool failed_ = false;
+};
+
+}  // namespace
+
+bool build_graph(const Node& root, Graph* g, std::string* message, int max_states) {
+  g->n_states = 2;
+  g->entry = 0;
+  g->exit = 1;
+  GraphBuilder b(g, max_states);
+  b.emit(root, g->entry, g->exit, false);
+  if (b.failed()) {
+    if (message) *message = "pattern expands to too many states";
+    return false;
+  }
+  return true;
+}
+
+// =============================================================================
+// Position automaton.
+namespace {
+
+struct Bits {
+  std::vector<uint32_t> w;
+  explicit Bits(int words = 0) : w(static_cast<size_t>(words), 0u) {}
+  void set(int i) { w[static_cast<size_t>(i) >> 5] |= 1u << (i & 31); }
+  bool get(int i) const { return (w[static_cast<size_t>(i) >> 5] >> (i & 31)) & 1u; }
+  bool any() const {
+    for (uint32_t x : w)
+      if (x) return true;
+    return false;
+  }
+  void operator|=(const Bits& o) {
+    for (size_t i = 0; i < w.size(); i++) w[i] |= o.w[i];
+  }
+  bool operator==(const Bits& o) const { return w == o.w; }
+  int count() const {
+    int n = 0;
+    for (uint32_t x : w) n += __builtin_popcount(x);
+    return n;
+  }
+  template <class F>
+  void for_each(F f) const {
+    for (size_t k = 0; k < w.size(); k++) {
+      uint32_t x = w[k];
+      while (x) {
+        int b = __builtin_ctz(x);
+        x &= x - 1;
+        f(static_cast<int>(k * 32 + b));
+      }
+    }
+  }
+};
+
+struct Closure {
+  std::vector<int> states;
+  bool reaches_exit = false;
+};
+
+class Automaton {
+ public:
+  Automaton(const Graph& g, Program* p) : g_(g), p_(p) {}
+
+  bool build(std::string* message) {
+    // positions
+    edge_first_.resize(g_.byte_edges.size());
+    int n = 0;
+    for (size_t e = 0; e < g_.byte_edges.size(); e++) {
+      edge_first_[e] = n;
+      n += g_.byte_edges[e].bytes.empty() ? 1 : static_cast<int>(g_.byte_edges[e].bytes.size());
+    }
+    if (n > kMaxPositions) {
+      if (message) *message = "pattern has too many positions for the device automaton";
+      return false;
+    }
+    P_ = n;
+    W_ = std::max(1, (n + 31) / 32);
+    p_->n_pos = P_;
+    p_->n_words = W_;
+    out_edges_.assign(static_cast<size_t>(g_.n_states), {});
+    ctrl_.assign(static_cast<size_t>(g_.n_states), {});
+    for (size_t e = 0; e < g_.byte_edges.size(); e++) out_edges_[static_cast<size_t>(g_.byte_edges[e].src)].push_back(static_cast<int>(e));
+    for (const ControlEdge& c : g_.control_edges) {
+      ctrl_[static_cast<size_t>(c.src)].push_back(&c);
+      if (c.kind != ControlKind::Epsilon) p_->has_assertions = true;
+    }
+
+    // byte classes
+    p_->cls.assign(static_cast<size_t>(256) * W_, 0u);
+    for (size_t e = 0; e < g_.byte_edges.size(); e++) {
+      const ByteEdge& be = g_.byte_edges[e];
+      if (be.bytes.empty()) {
+        for (int b = 0; b < 256; b++)
+          if (be.cls.has(static_cast<uint8_t>(b))) set_bit(&p_->cls[static_cast<size_t>(b) * W_], edge_first_[e]);
+      } else {
+        for (size_t k = 0; k < be.bytes.size(); k++)
+          set_bit(&p_->cls[static_cast<size_t>(static_cast<uint8_t>(be.bytes[k])) * W_], edge_first_[e] + static_cast<int>(k));
+      }
+    }
+
+    // first / nullable
+    for (int ctx = 0; ctx < kNumCtx; ctx++) {
+      Closure c = closure(g_.entry, ctx);
+      p_->first[ctx].assign(static_cast<size_t>(W_), 0u);
+      p_->last[ctx].assign(static_cast<size_t>(W_), 0u);
+      starts_of(c, p_->first[ctx].data());
+      p_->nullable[ctx] = c.reaches_exit;
+      p_->any_nullable |= c.reaches_exit;
+    }
+
+    // follow of the LAST position of every edge; interior literal positions are linear
+    p_->linear.assign(static_cast<size_t>(W_), 0u);
+    p_->row_of.assign(static_cast<size_t>(std::max(P_, 1)), -1);
+    std::vector<std::vector<uint32_t>> rows[kNumCtx];
+    for (size_t e = 0; e < g_.byte_edges.size(); e++) {
+      const ByteEdge& be = g_.byte_edges[e];
+      int len = be.bytes.empty() ? 1 : static_cast<int>(be.bytes.size());
+      for (int k = 0; k + 1 < len; k++) set_bit(p_->linear.data(), edge_first_[e] + k);
+      int lastpos = edge_first_[e] + len - 1;
+      std::vector<uint32_t> f[kNumCtx];
+      bool lin = true;
+      for (int ctx = 0; ctx < kNumCtx; ctx++) {
+        Closure c = closure(be.dst, ctx);
+        f[ctx].assign(static_cast<size_t>(W_), 0u);
+        starts_of(c, f[ctx].data());
+        if (c.reaches_exit) set_bit(p_->last[ctx].data(), lastpos);
+        // linear iff follow == {lastpos + 1}
+        std::vector<uint32_t> want(static_cast<size_t>(W_), 0u);
+        if (lastpos + 1 < P_) set_bit(want.data(), lastpos + 1);
+        if (lastpos + 1 >= P_ || f[ctx] != want) lin = false;
+      }
+      if (lin) {
+        set_bit(p_->linear.data(), lastpos);
+      } else {
+        p_->row_of[static_cast<size_t>(lastpos)] = p_->n_rows++;
+        for (int ctx = 0; ctx < kNumCtx; ctx++) rows[ctx].push_back(std::move(f[ctx]));
+      }
+    }
+    for (int ctx = 0; ctx < kNumCtx; ctx++) {
+      p_->rows[ctx].assign(static_cast<size_t>(std::max(p_->n_rows, 1)) * W_, 0u);
+      for (int r = 0; r < p_->n_rows; r++)
+        std::copy(rows[ctx][static_cast<size_t>(r)].begin(), rows[ctx][static_cast<size_t>(r)].end(),
+                  p_->rows[ctx].begin() + static_cast<long>(r) * W_);
+    }
+
+    // bytes that can start a non-empty match
+    Bits first_any(W_);
+    for (int ctx = 0; ctx < kNumCtx; ctx++)
+      for (int k = 0; k < W_; k++) first_any.w[static_cast<size_t>(k)] |= p_->first[ctx][static_cast<size_t>(k)];
+    for (int b = 0; b < 256; b++) {
+      const uint32_t* row = &p_->cls[static_cast<size_t>(b) * W_];
+      for (int k = 0; k < W_; k++)
+        if (row[k] & first_any.w[static_cast<size_t>(k)]) {
+          p_->first_bytes.add(static_cast<uint8_t>(b));
+          break;
+        }
+    }
+    lengths(first_any);
+    plan(first_any);
+    return true;
+  }
+
+ private:
+  static void set_bit(uint32_t* w, int i) { w[i >> 5] |= 1u << (i & 31); }
+
+  // states reachable from q through control edges that hold in context ctx
+  Closure closure(int q, int ctx) {
+    Closure c;
+    std::vector<int> stack{q};
+    std::set<int> seen{q};
+    while (!stack.empty()) {
+      int s = stack.back();
+      stack.pop_back();
+      c.states.push_back(s);
+      if (s == g_.exit) c.reaches_exit = true;
+      for (const ControlEdge* e : ctrl_[static_cast<size_t>(s)]) {
+        bool ok = e->kind == ControlKind::Epsilon || (e->kind == ControlKind::StartOfLine && (ctx & 1)) ||
+                  (e->kind == ControlKind::EndOfLine && (ctx & 2));
+        if (ok && seen.insert(e->dst).second) stack.push_back(e->dst);
+      }
+    }
+    return c;
+  }
+
+  void starts_of(const Closure& c, uint32_t* out) {
+    for (int s : c.states)
+      for (int e : out_edges_[static_cast<size_t>(s)]) set_bit(out, edge_first_[static_cast<size_t>(e)]);
+  }
+
+  // follow set of position i, union over all contexts (an over-approximation used only
+  // for length bounds and for planning the scan, never for matching)
+  Bits follow_any(int i) const {
+    Bits f(W_);
+    if ((p_->linear[static_cast<size_t>(i) >> 5] >> (i & 31)) & 1u) {
+      f.set(i + 1);
+      return f;
+    }
+    int r = p_->row_of[static_cast<size_t>(i)];
+    for (int ctx = 0; ctx < kNumCtx; ctx++)
+      for (int k = 0; k < W_; k++) f.w[static_cast<size_t>(k)] |= p_->rows[ctx][static_cast<size_t>(r) * W_ + k];
+    return f;
+  }
+
+  Bits step_any(const Bits& s) const {
+    Bits out(W_);
+    s.for_each([&](int i) { out |= follow_any(i); });
+    return out;
+  }
+
+  bool is_last_any(int i) const {
+    for (int ctx = 0; ctx < kNumCtx; ctx++)
+      if ((p_->last[ctx][static_cast<size_t>(i) >> 5] >> (i & 31)) & 1u) return true;
+    return false;
+  }
+
+  void lengths(const Bits& first_any) {
+    // min_len: BFS by depth over position sets; max_len: longest path, unbounded on a cycle
+    if (p_->any_nullable) {
+      p_->min_len = 0;
+    } else {
+      Bits level = first_any, seen(W_);
+      uint64_t depth = 1;
+      bool found = false;
+      while (level.any() && !found) {
+        level.for_each([&](int i) { found |= is_last_any(i); });
+        if (found) break;
+        seen |= level;
+        Bits next = step_any(level);
+        for (int k = 0; k < W_; k++) next.w[static_cast<size_t>(k)] &= ~seen.w[static_cast<size_t>(k)];
+        level = next;
+        depth++;
+      }
+      p_->min_len = found ? depth : 0;
+      if (!found) p_->min_len = Program::kUnboundedLen;  // the pattern can never match
+    }
+    // longest path with DFS colouring
+    std::vector<int> colour(static_cast<size_t>(std::max(P_, 1)), 0);
+    std::vector<uint64_t> best(static_cast<size_t>(std::max(P_, 1)), 0);
+    bool cyclic = false;
+    std::function<void(int)> dfs = [&](int i) {
+      colour[static_cast<size_t>(i)] = 1;
+      uint64_t b = 1;
+      follow_any(i).for_each([&](int j) {
+        if (cyclic) return;
+        if (colour[static_cast<size_t>(j)] == 1) {
+          cyclic = true;
+          return;
+        }
+        if (colour[static_cast<size_t>(j)] == 0) dfs(j);
+        b = std::max(b, 1 + best[static_cast<size_t>(j)]);
+      });
+      best[static_cast<size_t>(i)] = b;
+      colour[static_cast<size_t>(i)] = 2;
+    };
+    uint64_t longest = 0;
+    first_any.for_each([&](int i) {
+      if (cyclic) return;
+      if (colour[static_cast<size_t>(i)] == 0) dfs(i);
+      longest = std::max(longest, best[static_cast<size_t>(i)]);
+    });
+    p_->max_len = cyclic ? Program::kUnboundedLen : longest;
+  }
+
+  // Scan plan (the GPU's answer to FF_finder, src/codegen.cc:327-557).  The reference
+  // picks literal NODES of the tree and needs a backward NFA pass when they are not at
+  // the start of the match.  Here: choose a byte offset d such that the set of 4-byte
+  // strings a match can contain at [d, d+4) is small (<= kMaxWindows); a candidate start
+  // is any s with one of those strings at s + d.  Every candidate is then verified by
+  // the forward automaton from s, so the window set only has to be a necessary condition.
+  void plan(const Bits& first_any) {
+    p_->mode = ScanMode::Dense;
+    p_->windows.clear();
+    if (p_->any_nullable || p_->min_len == 0 || p_->min_len == Program::kUnboundedLen) return;
+    const int wl = static_cast<int>(std::min<uint64_t>(4, p_->min_len));
+    const uint64_t max_d = std::min<uint64_t>(p_->min_len - static_cast<uint64_t>(wl), 56);
+    std::vector<std::string> best;
+    uint64_t best_d = 0;
+    Bits level = first_any;
+    for (uint64_t d = 0; d <= max_d; d++) {
+      std::set<std::string> found;
+      std::string cur;
+      bool overflow = false;
+      enumerate(level, wl, &cur, &found, &overflow);
+      if (!overflow && !found.empty() && (best.empty() || found.size() < best.size())) {
+        best.assign(found.begin(), found.end());
+        best_d = d;
+        if (best.size() == 1) break;
+      }
+      level = step_any(level);
+      if (!level.any()) break;
+    }
+    if (best.empty()) return;
+    p_->mode = ScanMode::Windows;
+    for (const std::string& s : best) {
+      FFWindow w;
+      w.offset = static_cast<uint32_t>(best_d);
+      w.value = 0;
+      w.mask = 0;
+      for (int k = 0; k < wl; k++) {
+        w.value |= static_cast<uint32_t>(static_cast<uint8_t>(s[static_cast<size_t>(k)])) << (8 * k);
+        w.mask |= 0xFFu << (8 * k);
+      }
+      p_->windows.push_back(w);
+    }
+  }
+
+  void enumerate(const Bits& level, int remaining, std::string* cur, std::set<std::string>* found, bool* overflow) {
+    if (*overflow) return;
+    if (remaining == 0) {
+      found->insert(*cur);
+      if (found->size() > static_cast<size_t>(kMaxWindows)) *overflow = true;
+      return;
+    }
+    int live = 0;
+    for (int b = 0; b < 256 && !*overflow; b++) {
+      const uint32_t* row = &p_->cls[static_cast<size_t>(b) * W_];
+      Bits hit(W_);
+      bool any = false;
+      for (int k = 0; k < W_; k++) {
+        hit.w[static_cast<size_t>(k)] = level.w[static_cast<size_t>(k)] & row[k];
+        any |= hit.w[static_cast<size_t>(k)] != 0;
+      }
+      if (!any) continue;
+      if (++live > kMaxWindows) {  // more byte values than windows at this depth
+        *overflow = true;
+        return;
+      }
+      cur->push_back(static_cast<char>(b));
+      Bits next = remaining > 1 ? step_any(hit) : hit;
+      if (remaining > 1 && !next.any()) {
+        // a match cannot be shorter than d + wl, so every path continues; an empty
+        // continuation can only come from the context over-approximation -- drop it
+        cur->pop_back();
+        continue;
+      }
+      enumerate(next, remaining - 1, cur, found, overflow);
+      cur->pop_back();
+    }
+  }
+
+  const Graph& g_;
+  Program* p_;
+  int P_ = 0, W_ = 1;
+  std::vector<int> edge_first_;
+  std::vector<std::vector<int>> out_edges_;
+  std::vector<std::vector<const ControlEdge*>> ctrl_;
+};
+
+void find_literal(const Node& n, std::string* out, bool* ok) {
+  if (!*ok) return;
+  if (n.kind == NodeKind::Literal) {
+    *out += n.bytes;
+  } else if (n.kind == NodeKind::Concat) {
+    for (const auto& k : n.kids) find_literal(*k, out, ok);
+  } else {
+    *ok = false;
+  }
+}
+
+}  // namespace
+
+LowerResult lower(const char* regexp) {
+  LowerResult r;
+  ParseResult pr = parse(regexp);
+  if (pr.status != kParseOk) {
+    r.status = pr.status;
+    r.message = pr.message;
+    return r;
+  }
+  Graph g;
+  if (!build_graph(*pr.root, &g, &r.message)) {
+    r.status = -2;
+    return r;
+  }
+  auto prog = std::make_unique<Program>();
+  Automaton a(g, prog.get());
+  if (!a.build(&r.message)) {
+    r.status = -2;
+    return r;
+  }
+  bool lit = true;
+  std::string bytes;
+  find_literal(*pr.root, &bytes, &lit);
+  if (lit) prog->literal = bytes;
+  r.program = std::move(prog);
+  return r;
+}
+
+}  // namespace rejit_amd

@@ -48,6 +48,8 @@ class Oracle:
         L = self.lib
         L.ro_match_all_re.restype = ctypes.c_long
         L.ro_match_all_re.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, _u64p, ctypes.c_size_t]
+        L.ro_match_all_spec_re.restype = ctypes.c_long
+        L.ro_match_all_spec_re.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, _u64p, ctypes.c_size_t]
         L.ro_match_full_re.restype = ctypes.c_int
         L.ro_match_full_re.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
         L.ro_error.restype = ctypes.c_char_p
@@ -69,6 +71,15 @@ class Oracle:
         cap = (len(text) + 2) if cap is None else cap
         buf = (ctypes.c_uint64 * (2 * max(cap, 1)))()
         n = self.lib.ro_match_all_re(regex, text, len(text), buf, cap)
+        if n < 0:
+            return int(n)
+        return _pairs(buf, min(n, cap))
+
+    def match_all_spec(self, regex: bytes, text: bytes):
+        """Documented left-most-longest semantics (differs from match_all only on Q8)."""
+        cap = len(text) + 2
+        buf = (ctypes.c_uint64 * (2 * cap))()
+        n = self.lib.ro_match_all_spec_re(regex, text, len(text), buf, cap)
         if n < 0:
             return int(n)
         return _pairs(buf, min(n, cap))

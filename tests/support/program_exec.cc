@@ -1,0 +1,200 @@
+// tests/support/program_exec.cc -- TEST-ONLY scalar executor of a lowered Program.
+//
+// Compiled by tests/test_lowering.py together with rejit_amd/csrc/{parser,lowering}.cc
+// into tests/support/libprogram_exec.so (g++, no HIP).  It restates, one position at a
+// time, exactly what the HIP kernels compute from the same tables (candidate filter ->
+// forward automaton -> left-most-longest selection), so the lowering can be checked
+// against the oracle on a machine without a GPU.  It is never linked into the product
+// library and the product never falls back to it.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../rejit_amd/csrc/lowering.h"
+
+using namespace rejit_amd;
+
+namespace {
+
+struct Span { uint64_t begin, end; };
+
+inline bool line_break(uint8_t c) { return c == '\n' || c == '\r'; }
+
+inline int context_at(const uint8_t* t, uint64_t n, uint64_t p) {
+  int ctx = 0;
+  if (p == 0 || line_break(t[p - 1])) ctx |= 1;
+  if (p == n || line_break(t[p])) ctx |= 2;
+  return ctx;
+}
+
+bool longest_at(const Program& P, const uint8_t* t, uint64_t n, uint64_t s, uint64_t* end) {
+  const int W = P.n_words;
+  bool found = false;
+  int ctx = context_at(t, n, s);
+  if (P.nullable[ctx]) {
+    found = true;
+    *end = s;
+  }
+  if (s >= n || P.n_pos == 0) return found;
+  std::vector<uint32_t> S(W), T(W);
+  const uint32_t* row = &P.cls[(size_t)t[s] * W];
+  bool any = false;
+  for (int k = 0; k < W; k++) {
+    S[k] = P.first[ctx][k] & row[k];
+    any |= S[k] != 0;
+  }
+  uint64_t p = s + 1;
+  while (any) {
+    ctx = context_at(t, n, p);
+    for (int k = 0; k < W; k++)
+      if (S[k] & P.last[ctx][k]) {
+        found = true;
+        *end = p;
+        break;
+      }
+    if (p == n) break;
+    // follow
+    uint32_t carry = 0;
+    for (int k = 0; k < W; k++) {
+      uint32_t lin = S[k] & P.linear[k];
+      T[k] = (lin << 1) | carry;
+      carry = lin >> 31;
+    }
+    for (int k = 0; k < W; k++) {
+      uint32_t sp = S[k] & ~P.linear[k];
+      while (sp) {
+        int b = __builtin_ctz(sp);
+        sp &= sp - 1;
+        int r = P.row_of[(size_t)k * 32 + b];
+        const uint32_t* fr = &P.rows[ctx][(size_t)r * W];
+        for (int j = 0; j < W; j++) T[j] |= fr[j];
+      }
+    }
+    row = &P.cls[(size_t)t[p] * W];
+    any = false;
+    for (int k = 0; k < W; k++) {
+      S[k] = T[k] & row[k];
+      any |= S[k] != 0;
+    }
+    p++;
+  }
+  return found;
+}
+
+bool candidate(const Program& P, const uint8_t* t, uint64_t n, uint64_t s) {
+  if (P.mode == ScanMode::Windows) {
+    for (const FFWindow& w : P.windows) {
+      int wl = w.mask == 0xFFFFFFFFu ? 4 : (w.mask == 0xFFFFFFu ? 3 : (w.mask == 0xFFFFu ? 2 : 1));
+      if (s + w.offset + wl > n) continue;
+      uint32_t v = 0;
+      for (int k = 0; k < wl; k++) v |= (uint32_t)t[s + w.offset + k] << (8 * k);
+      if ((v & w.mask) == w.value) return true;
+    }
+    return false;
+  }
+  if (P.any_nullable) {
+    if (P.nullable[context_at(t, n, s)]) return true;
+  }
+  return s < n && P.first_bytes.has(t[s]);
+}
+
+}  // namespace
+
+extern "C" {
+
+// returns count, or a negative status
+long pe_match_all(const char* re, const uint8_t* text, uint64_t n, uint64_t* out, uint64_t cap) {
+  LowerResult lr = lower(re);
+  if (lr.status != 0) return lr.status;
+  const Program& P = *lr.program;
+  std::vector<Span> sel;
+  uint64_t cur = 0;  // smallest allowed start
+  bool have_prev = false;
+  uint64_t prev_end = 0;
+  for (uint64_t s = 0; s <= n; s++) {
+    if (s < cur) continue;
+    if (!candidate(P, text, n, s)) continue;
+    uint64_t e;
+    if (!longest_at(P, text, n, s, &e)) continue;
+    cur = e > s ? e : s + 1;
+    if (e == s && have_prev && prev_end == s) {
+      // zero-length rule, src/codegen.cc:65-73
+    } else {
+      sel.push_back({s, e});
+    }
+    have_prev = true;
+    prev_end = e;
+  }
+  for (size_t i = 0; i < sel.size() && i < cap; i++) {
+    out[2 * i] = sel[i].begin;
+    out[2 * i + 1] = sel[i].end;
+  }
+  return (long)sel.size();
+}
+
+int pe_match_full(const char* re, const uint8_t* text, uint64_t n) {
+  LowerResult lr = lower(re);
+  if (lr.status != 0) return lr.status;
+  // anchored at 0, must end at n: simulate keeping only "accept at n"
+  const Program& P = *lr.program;
+  const int W = P.n_words;
+  int ctx = context_at(text, n, 0);
+  if (n == 0) return P.nullable[ctx] ? 1 : 0;
+  if (P.n_pos == 0) return 0;
+  std::vector<uint32_t> S(W), T(W);
+  const uint32_t* row = &P.cls[(size_t)text[0] * W];
+  bool any = false;
+  for (int k = 0; k < W; k++) {
+    S[k] = P.first[ctx][k] & row[k];
+    any |= S[k] != 0;
+  }
+  for (uint64_t p = 1; any; p++) {
+    ctx = context_at(text, n, p);
+    if (p == n) {
+      for (int k = 0; k < W; k++)
+        if (S[k] & P.last[ctx][k]) return 1;
+      return 0;
+    }
+    uint32_t carry = 0;
+    for (int k = 0; k < W; k++) {
+      uint32_t lin = S[k] & P.linear[k];
+      T[k] = (lin << 1) | carry;
+      carry = lin >> 31;
+    }
+    for (int k = 0; k < W; k++) {
+      uint32_t sp = S[k] & ~P.linear[k];
+      while (sp) {
+        int b = __builtin_ctz(sp);
+        sp &= sp - 1;
+        const uint32_t* fr = &P.rows[ctx][(size_t)P.row_of[(size_t)k * 32 + b] * W];
+        for (int j = 0; j < W; j++) T[j] |= fr[j];
+      }
+    }
+    row = &P.cls[(size_t)text[p] * W];
+    any = false;
+    for (int k = 0; k < W; k++) {
+      S[k] = T[k] & row[k];
+      any |= S[k] != 0;
+    }
+  }
+  return 0;
+}
+
+// plan introspection: mode (0 dense, 1 windows), window count, offset, P, min_len, max_len
+int pe_plan(const char* re, uint64_t* info, uint32_t* window_values) {
+  LowerResult lr = lower(re);
+  if (lr.status != 0) return lr.status;
+  const Program& P = *lr.program;
+  info[0] = P.mode == ScanMode::Windows;
+  info[1] = P.windows.size();
+  info[2] = P.windows.empty() ? 0 : P.windows[0].offset;
+  info[3] = (uint64_t)P.n_pos;
+  info[4] = P.min_len;
+  info[5] = P.max_len;
+  info[6] = (uint64_t)P.n_rows;
+  info[7] = P.literal.size();
+  for (size_t i = 0; i < P.windows.size(); i++) window_values[i] = P.windows[i].value;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+"""CPU tests of the host lowering (parser -> NFA graph -> position automaton -> scan plan).
+
+The lowered Program is executed by a TEST-ONLY scalar executor (tests/support/
+program_exec.cc, compiled here with g++) that applies exactly the tables the HIP kernels
+interpret, and the result is compared with the oracle on every golden vector.
+
+Known, documented divergence ("Q8"): on a handful of random vectors the
+reference's own no-fast-forward loop drops a thread that starts exactly at the end of a
+match; there the product implements the documented left-most-longest semantics
+(Oracle.match_all_spec) and the reference's default-flag build returns a third,
+overlapping answer.
+"""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+import vectors as V
+from checkers import Oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SO = os.path.join(HERE, "support", "libprogram_exec.so")
+SRCS = [os.path.join(HERE, "support", "program_exec.cc"),
+        os.path.join(ROOT, "rejit_amd", "csrc", "parser.cc"),
+        os.path.join(ROOT, "rejit_amd", "csrc", "lowering.cc")]
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+@pytest.fixture(scope="module")
+def pe():
+    deps = SRCS + [os.path.join(ROOT, "rejit_amd", "csrc", "lowering.h")]
+    if not os.path.exists(SO) or any(os.path.getmtime(SO) < os.path.getmtime(s) for s in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", SO] + SRCS)
+    lib = ctypes.CDLL(SO)
+    lib.pe_match_all.restype = ctypes.c_long
+    lib.pe_match_all.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, _u64p, ctypes.c_uint64]
+    lib.pe_match_full.restype = ctypes.c_int
+    lib.pe_match_full.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64]
+    lib.pe_plan.restype = ctypes.c_int
+    lib.pe_plan.argtypes = [ctypes.c_char_p, _u64p, ctypes.POINTER(ctypes.c_uint32)]
+    return lib
+
+
+def match_all(lib, rx, tx):
+    cap = len(tx) + 2
+    buf = (ctypes.c_uint64 * (2 * cap))()
+    n = lib.pe_match_all(rx, tx, len(tx), buf, cap)
+    if n < 0:
+        return int(n)
+    return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n)]
+
+
+def plan(lib, rx):
+    info = (ctypes.c_uint64 * 8)()
+    vals = (ctypes.c_uint32 * 8)()
+    st = lib.pe_plan(rx, info, vals)
+    assert st == 0
+    return dict(windows=bool(info[0]), n_windows=int(info[1]), offset=int(info[2]), n_pos=int(info[3]),
+                min_len=int(info[4]), max_len=int(info[5]), n_rows=int(info[6]), literal_len=int(info[7]),
+                values=[int(v) for v in vals[:info[1]]])
+
+
+def test_all_vectors_match_reference(pe):
+    oracle = Oracle()
+    n = q8 = 0
+    for rx, tx, exp_all, exp_full in V.all_matchall_cases():
+        got = match_all(pe, rx, tx)
+        if got != exp_all:
+            # only acceptable on the Q8 artefact, where documented semantics != reference ff=0
+            spec = oracle.match_all_spec(rx, tx)
+            assert spec != exp_all and got == spec, (rx, tx, got, exp_all)
+            q8 += 1
+        assert pe.pe_match_full(rx, tx, len(tx)) == exp_full, (rx, tx)
+        n += 1
+    assert n > 2500
+    assert q8 <= 19, q8   # 19 of 2500 fuzz vectors; none of the test.cc-derived vectors
+
+
+def test_parse_errors(pe):
+    for e in V.semantics()["errors"]:
+        buf = (ctypes.c_uint64 * 4)()
+        assert pe.pe_match_all(V.b(e["regex"]), b"abc", 3, buf, 2) == -1, e
+
+
+def test_scan_plans(pe):
+    p = plan(pe, b"regexp")
+    assert p["windows"] and p["n_windows"] == 1 and p["values"] == [int.from_bytes(b"rege", "little")]
+    assert p["literal_len"] == 6 and p["min_len"] == 6 and p["max_len"] == 6
+    for rx in V.bench()["regexdna"]["1000"]["patterns"]:
+        p = plan(pe, V.b(rx["regex"]))
+        assert p["windows"] and 2 <= p["n_windows"] <= 4, (rx["regex"], p)
+        assert p["min_len"] == 8 and p["max_len"] == 8 and p["n_pos"] == 16
+    p = plan(pe, b"x*")
+    assert not p["windows"] and p["min_len"] == 0 and p["max_len"] == 2 ** 64 - 1
+    p = plan(pe, b"([complex]|(regexp)){2,7}abcdefgh(at|the|[e-nd]as well)")
+    assert p["min_len"] == 12 and p["max_len"] == 58
+    p = plan(pe, b">.*\n|\n")
+    assert p["windows"] and p["n_windows"] == 2 and p["min_len"] == 1
