@@ -1,0 +1,108 @@
+/* include/rejit_hip.h -- the C ABI of librejit_hip.so: the drop-in boundary between a
+ * host program and the MI355X kernels.
+ *
+ * In the reference the boundary is a set of raw function pointers into JIT-generated x86
+ * code, one per match type (src/regexp.h:533-536):
+ *
+ *     bool     (*MatchFullFunc)    (const char* text, size_t size);
+ *     bool     (*MatchAnywhereFunc)(const char* text, size_t size);
+ *     bool     (*MatchFirstFunc)   (const char* text, size_t size, Match*);
+ *     unsigned (*MatchAllFunc)     (const char* text, size_t size, std::vector<Match>*);
+ *
+ * produced by Regej::Compile (src/rejit.cc:229-267) and called by Regej::Match*
+ * (src/rejit.cc:150-208).  The entry points below replace exactly those: rj_compile takes
+ * the place of Parser::Parse + Codegen::Compile, rj_match_* of the four generated
+ * functions.  Offsets are returned instead of pointers (the C++ wrapper in
+ * include/rejit.h converts).  Plain C types only; no HIP or torch types in signatures
+ * (streams are passed as void*).
+ *
+ * Errors never throw and never abort: every call returns a negative rj_status and
+ * rj_last_error() holds a message (thread-local).
+ */
+#ifndef REJIT_HIP_H_
+#define REJIT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  RJ_OK = 0,
+  RJ_PARSER_ERROR = -1,  /* == rejit::ParserError, include/rejit.h:98-102 of the reference */
+  RJ_TOO_LARGE = -2,     /* pattern expands beyond the device automaton limits */
+  RJ_DEVICE_ERROR = -3,  /* HIP failure (no GPU, out of memory, launch error, ...) */
+  RJ_BAD_ARGUMENT = -4
+} rj_status;
+
+typedef struct rj_program rj_program; /* a compiled pattern: immutable, shareable across threads */
+typedef struct rj_scan rj_scan;       /* per-caller device scratch + results; NOT thread-safe   */
+
+typedef struct {
+  int32_t n_positions;     /* automaton positions (one per pattern byte)            */
+  int32_t n_words;         /* 32-bit words of automaton state                       */
+  int32_t has_assertions;  /* pattern contains ^ or $                               */
+  int32_t scan_mode;       /* 0 dense (every position), 1 fast-forward windows       */
+  int32_t n_windows;       /* number of 4-byte window constants                     */
+  uint32_t window_offset;  /* byte offset of the windows inside a match             */
+  uint32_t window_len;     /* bytes compared per window                             */
+  uint64_t min_len;        /* shortest match                                         */
+  uint64_t max_len;        /* longest match, UINT64_MAX when unbounded               */
+} rj_info;
+
+typedef struct {
+  uint64_t n_hits;         /* candidate starts produced by the scan kernel           */
+  uint64_t n_candidates;   /* verified (begin,end) candidates before selection       */
+  uint64_t n_matches;      /* final left-most-longest, non-overlapping matches       */
+  float scan_ms;           /* HIP-event time of the scan kernel(s) on the run's stream */
+  float total_ms;          /* HIP-event time of the whole device pipeline            */
+  int32_t retries;         /* runs repeated because a device list had to grow        */
+  int32_t large_path;      /* 1 when the rocPRIM sort path was taken                 */
+} rj_stats;
+
+/* ---- compile (replaces Regej::Regej + Regej::Compile, src/rejit.cc:127-137,229-267) */
+int rj_compile(const char* regexp, rj_program** out);
+void rj_program_free(rj_program* prog);
+int rj_program_info(const rj_program* prog, rj_info* info);
+const char* rj_last_error(void);
+
+/* ---- host text: one call = H2D copy + device pipeline + D2H of the results.
+ * These four replace the four JIT function pointers above. */
+/* 1 = the whole text matches, 0 = it does not, <0 = rj_status */
+int rj_match_full(const rj_program* prog, const char* text, size_t n);
+/* 1 / 0 / <0 */
+int rj_match_anywhere(const rj_program* prog, const char* text, size_t n);
+/* 1 (begin/end offsets written) / 0 / <0; left-most longest match */
+int rj_match_first(const rj_program* prog, const char* text, size_t n, uint64_t* begin, uint64_t* end);
+/* number of matches (>= 0) or rj_status.  *spans receives a malloc'ed array of
+ * 2*count offsets (begin0,end0,begin1,...) to be released with rj_free_spans; pass NULL
+ * to only count. */
+int64_t rj_match_all(const rj_program* prog, const char* text, size_t n, uint64_t** spans);
+void rj_free_spans(uint64_t* spans);
+
+/* ---- device-resident text (what bench.py and the multi-GPU driver use; no copies).
+ * d_text must be 16-byte aligned device memory with bytes [0, n) readable.  Matches whose
+ * BEGIN lies in [own_begin, own_end) are reported (own_end may be n + 1 to include the
+ * empty match at the end of the text); the automaton may read up to n, so a shard passes
+ * its halo inside [0, n).  carry_cur / carry_prev_end / have_prev describe the last match
+ * selected before own_begin (0,0,0 for the first shard). */
+int rj_scan_create(const rj_program* prog, rj_scan** out);
+void rj_scan_destroy(rj_scan* scan);
+int64_t rj_scan_run(rj_scan* scan, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end,
+                    uint64_t carry_cur, uint64_t carry_prev_end, int have_prev, void* hip_stream);
+/* results of the last run: device pointer to 2*count uint64 offsets, or a host copy */
+const uint64_t* rj_scan_device_spans(const rj_scan* scan);
+int64_t rj_scan_copy_spans(const rj_scan* scan, uint64_t* host_spans, uint64_t cap);
+int rj_scan_stats(const rj_scan* scan, rj_stats* stats);
+/* 1 / 0 / <0: kMatchFull over device text */
+int rj_scan_match_full(rj_scan* scan, const void* d_text, uint64_t n, void* hip_stream);
+
+/* number of visible HIP devices (0 when there is none), for callers that want to probe */
+int rj_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REJIT_HIP_H_ */

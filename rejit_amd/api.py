@@ -1,0 +1,214 @@
+"""ctypes binding of include/rejit_hip.h + the in-tree build of librejit_hip.so."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import List, Optional, Tuple
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+SOURCES = ["kernels.hip", "engine.hip", "parser.cc", "lowering.cc", "rejit_api.cc"]
+HEADERS = ["kernels.h", "device_program.h", "lowering.h"]
+LIB = os.path.join(PKG, "librejit_hip.so")
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+class RejitError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"rejit_hip status {status}: {message}")
+        self.status = status
+        self.message = message
+
+
+def library_path() -> str:
+    return LIB
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    deps += [os.path.join(PKG, "..", "include", f) for f in ("rejit.h", "rejit_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP/C++ source for gfx950 into rejit_amd/librejit_hip.so (in-tree, so
+    the built library travels with the repo snapshot).  hipcc cross-compiles without a GPU."""
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB + ".tmp"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+class _Info(ctypes.Structure):
+    _fields_ = [("n_positions", ctypes.c_int32), ("n_words", ctypes.c_int32), ("has_assertions", ctypes.c_int32),
+                ("scan_mode", ctypes.c_int32), ("n_windows", ctypes.c_int32), ("window_offset", ctypes.c_uint32),
+                ("window_len", ctypes.c_uint32), ("min_len", ctypes.c_uint64), ("max_len", ctypes.c_uint64)]
+
+
+class _Stats(ctypes.Structure):
+    _fields_ = [("n_hits", ctypes.c_uint64), ("n_candidates", ctypes.c_uint64), ("n_matches", ctypes.c_uint64),
+                ("scan_ms", ctypes.c_float), ("total_ms", ctypes.c_float), ("retries", ctypes.c_int32),
+                ("large_path", ctypes.c_int32)]
+
+
+_lib = None
+
+# every symbol include/rejit_hip.h declares
+C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_error", "rj_match_full",
+                 "rj_match_anywhere", "rj_match_first", "rj_match_all", "rj_free_spans", "rj_scan_create",
+                 "rj_scan_destroy", "rj_scan_run", "rj_scan_device_spans", "rj_scan_copy_spans", "rj_scan_stats",
+                 "rj_scan_match_full", "rj_device_count"]
+
+
+def load_library():
+    """Load the product library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        raise FileNotFoundError(f"{LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = ctypes.CDLL(LIB)
+    vp, cp, sz, i64, u64 = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_uint64
+    L.rj_compile.restype = ctypes.c_int
+    L.rj_compile.argtypes = [cp, ctypes.POINTER(vp)]
+    L.rj_program_free.argtypes = [vp]
+    L.rj_program_info.argtypes = [vp, ctypes.POINTER(_Info)]
+    L.rj_last_error.restype = cp
+    L.rj_match_full.argtypes = [vp, cp, sz]
+    L.rj_match_anywhere.argtypes = [vp, cp, sz]
+    L.rj_match_first.argtypes = [vp, cp, sz, _u64p, _u64p]
+    L.rj_match_all.restype = i64
+    L.rj_match_all.argtypes = [vp, cp, sz, ctypes.POINTER(_u64p)]
+    L.rj_free_spans.argtypes = [_u64p]
+    L.rj_scan_create.argtypes = [vp, ctypes.POINTER(vp)]
+    L.rj_scan_destroy.argtypes = [vp]
+    L.rj_scan_run.restype = i64
+    L.rj_scan_run.argtypes = [vp, vp, u64, u64, u64, u64, u64, ctypes.c_int, vp]
+    L.rj_scan_device_spans.restype = vp
+    L.rj_scan_device_spans.argtypes = [vp]
+    L.rj_scan_copy_spans.restype = i64
+    L.rj_scan_copy_spans.argtypes = [vp, _u64p, u64]
+    L.rj_scan_stats.argtypes = [vp, ctypes.POINTER(_Stats)]
+    L.rj_scan_match_full.argtypes = [vp, vp, u64, vp]
+    L.rj_device_count.restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def device_count() -> int:
+    return int(load_library().rj_device_count())
+
+
+def _check(rc: int):
+    if rc < 0:
+        raise RejitError(int(rc), load_library().rj_last_error().decode("latin1"))
+    return rc
+
+
+class Program:
+    """A compiled pattern (rj_program)."""
+
+    def __init__(self, regexp):
+        self._lib = load_library()
+        if isinstance(regexp, str):
+            regexp = regexp.encode("latin1")
+        self.regexp = regexp
+        h = ctypes.c_void_p()
+        _check(self._lib.rj_compile(regexp, ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.rj_program_free(h)
+            self._h = None
+
+    def info(self) -> dict:
+        i = _Info()
+        _check(self._lib.rj_program_info(self._h, ctypes.byref(i)))
+        return {k: int(getattr(i, k)) for k, _ in _Info._fields_}
+
+    # host-text entry points (the four JIT function pointers of the reference)
+    def match_all(self, text: bytes) -> List[Tuple[int, int]]:
+        spans = _u64p()
+        n = _check(self._lib.rj_match_all(self._h, text, len(text), ctypes.byref(spans)))
+        out = [(int(spans[2 * i]), int(spans[2 * i + 1])) for i in range(n)]
+        if n:
+            self._lib.rj_free_spans(spans)
+        return out
+
+    def count(self, text: bytes) -> int:
+        return int(_check(self._lib.rj_match_all(self._h, text, len(text), None)))
+
+    def match_first(self, text: bytes) -> Optional[Tuple[int, int]]:
+        b, e = ctypes.c_uint64(), ctypes.c_uint64()
+        r = _check(self._lib.rj_match_first(self._h, text, len(text), ctypes.byref(b), ctypes.byref(e)))
+        return (int(b.value), int(e.value)) if r else None
+
+    def match_anywhere(self, text: bytes) -> bool:
+        return bool(_check(self._lib.rj_match_anywhere(self._h, text, len(text))))
+
+    def match_full(self, text: bytes) -> bool:
+        return bool(_check(self._lib.rj_match_full(self._h, text, len(text))))
+
+
+class Scan:
+    """Device-resident scanning (rj_scan): text stays in HBM, results stay in HBM."""
+
+    def __init__(self, program: Program):
+        self._lib = load_library()
+        self.program = program
+        h = ctypes.c_void_p()
+        _check(self._lib.rj_scan_create(program._h, ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.rj_scan_destroy(h)
+            self._h = None
+
+    def run(self, d_text_ptr: int, n: int, own_begin: int = 0, own_end: Optional[int] = None, carry_cur: int = 0,
+            carry_prev_end: int = 0, have_prev: bool = False, stream: int = 0) -> int:
+        if own_end is None:
+            own_end = n + 1
+        return int(_check(self._lib.rj_scan_run(self._h, ctypes.c_void_p(d_text_ptr), n, own_begin, own_end, carry_cur,
+                                                carry_prev_end, int(have_prev), ctypes.c_void_p(stream))))
+
+    def run_tensor(self, t, n: Optional[int] = None, stream=None, **kw) -> int:
+        """t: a contiguous uint8 torch tensor on the GPU."""
+        import torch
+
+        assert t.dtype == torch.uint8 and t.is_contiguous() and t.is_cuda
+        st = torch.cuda.current_stream(t.device).cuda_stream if stream is None else stream
+        return self.run(t.data_ptr(), int(t.numel() if n is None else n), stream=st, **kw)
+
+    def spans(self) -> List[Tuple[int, int]]:
+        n = int(_check(self._lib.rj_scan_copy_spans(self._h, None, 0)))
+        buf = (ctypes.c_uint64 * (2 * max(n, 1)))()
+        _check(self._lib.rj_scan_copy_spans(self._h, buf, n))
+        return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n)]
+
+    def device_spans_ptr(self) -> int:
+        return int(self._lib.rj_scan_device_spans(self._h) or 0)
+
+    def stats(self) -> dict:
+        s = _Stats()
+        _check(self._lib.rj_scan_stats(self._h, ctypes.byref(s)))
+        return {k: (float(getattr(s, k)) if k.endswith("_ms") else int(getattr(s, k))) for k, _ in _Stats._fields_}
+
+    def match_full(self, d_text_ptr: int, n: int, stream: int = 0) -> bool:
+        return bool(_check(self._lib.rj_scan_match_full(self._h, ctypes.c_void_p(d_text_ptr), n, ctypes.c_void_p(stream))))

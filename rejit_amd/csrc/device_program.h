@@ -1,0 +1,178 @@
+// rejit_amd/csrc/device_program.h -- the lowered program as the kernels see it (plain
+// data in HBM, passed to every kernel by value as a small descriptor of pointers), and
+// the per-lane automaton step shared by the verify / dense kernels.
+//
+// This header is deliberately free of HIP runtime calls so that the lane simulator can
+// also be compiled by g++ in the CPU unit tests (tests/support/) -- the SAME source the
+// kernels run, which is how the automaton logic is checked without a GPU.
+#ifndef REJIT_AMD_DEVICE_PROGRAM_H_
+#define REJIT_AMD_DEVICE_PROGRAM_H_
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RJ_HD __host__ __device__ __forceinline__
+#else
+#define RJ_HD inline
+#endif
+
+namespace rejit_amd {
+
+constexpr int kDevMaxWindows = 8;
+
+// Table layout (all uint32 words, W = n_words, C = n_ctx in {1,4}):
+//   first [C][W]   last [C][W]   linear [W]   row_of [P] (int32)   rows [C][n_rows][W]
+//   cls [256][W]
+struct DevProgram {
+  int32_t n_pos;
+  int32_t n_words;
+  int32_t n_ctx;        // 1 when the pattern has no ^ / $, else 4
+  int32_t n_rows;
+  uint32_t nullable;    // bit c: the empty string matches in context c (bits replicated when n_ctx == 1)
+  int32_t mode;         // 0 dense, 1 windows
+  int32_t n_windows;
+  uint32_t win_offset;
+  uint32_t win_len;     // bytes compared per window (1..4)
+  uint32_t win_value[kDevMaxWindows];
+  uint32_t win_mask;
+  uint32_t first_bytes[8];
+  uint64_t min_len;
+  const uint32_t* first;
+  const uint32_t* last;
+  const uint32_t* linear;
+  const int32_t* row_of;
+  const uint32_t* rows;
+  const uint32_t* cls;
+};
+
+RJ_HD bool rj_line_break(uint32_t c) { return c == '\n' || c == '\r'; }
+
+// Context at text position p: bit0 start-of-line, bit1 end-of-line
+// (MatchStartOrEndOfLine, reference src/x64/codegen-x64.cc:686-708).
+RJ_HD int rj_context(const uint8_t* t, uint64_t n, uint64_t p) {
+  int ctx = 0;
+  if (p == 0 || rj_line_break(t[p - 1])) ctx |= 1;
+  if (p == n || rj_line_break(t[p])) ctx |= 2;
+  return ctx;
+}
+
+// Longest match that starts exactly at s, automaton state held in NQ 64-bit words per
+// lane (P <= 64 * NQ).  Returns false when no match starts at s.
+// One step is S' = follow_ctx(S) & cls[byte]: the linear part is a shift, positions with
+// a non-trivial follow set OR in their row.
+template <int NQ>
+RJ_HD bool rj_lane_longest(const DevProgram& P, const uint8_t* t, uint64_t n, uint64_t s, uint64_t* end) {
+  const int W = P.n_words;  // 32-bit words; NQ*2 >= W
+  const bool ctxed = P.n_ctx > 1;
+  int ctx = ctxed ? rj_context(t, n, s) : 0;
+  bool found = false;
+  if ((P.nullable >> ctx) & 1u) {
+    found = true;
+    *end = s;
+  }
+  if (s >= n || P.n_pos == 0) return found;
+
+  uint64_t S[NQ], lin[NQ];
+  {
+    const uint32_t* fr = P.first + ctx * W;
+    const uint32_t* cr = P.cls + (uint32_t)t[s] * W;
+    for (int q = 0; q < NQ; q++) {
+      uint64_t f = 0, c = 0, l = 0;
+      if (2 * q < W) { f = fr[2 * q]; c = cr[2 * q]; l = P.linear[2 * q]; }
+      if (2 * q + 1 < W) {
+        f |= (uint64_t)fr[2 * q + 1] << 32;
+        c |= (uint64_t)cr[2 * q + 1] << 32;
+        l |= (uint64_t)P.linear[2 * q + 1] << 32;
+      }
+      S[q] = f & c;
+      lin[q] = l;
+    }
+  }
+  uint64_t p = s + 1;
+  for (;;) {
+    uint64_t alive = 0;
+    for (int q = 0; q < NQ; q++) alive |= S[q];
+    if (!alive) break;
+    ctx = ctxed ? rj_context(t, n, p) : 0;
+    {
+      const uint32_t* lr = P.last + ctx * W;
+      uint64_t acc = 0;
+      for (int q = 0; q < NQ; q++) {
+        uint64_t l = 0;
+        if (2 * q < W) l = lr[2 * q];
+        if (2 * q + 1 < W) l |= (uint64_t)lr[2 * q + 1] << 32;
+        acc |= S[q] & l;
+      }
+      if (acc) {
+        found = true;
+        *end = p;
+      }
+    }
+    if (p == n) break;
+    uint64_t T[NQ];
+    uint64_t carry = 0;
+    for (int q = 0; q < NQ; q++) {
+      uint64_t x = S[q] & lin[q];
+      T[q] = (x << 1) | carry;
+      carry = x >> 63;
+    }
+    for (int q = 0; q < NQ; q++) {
+      uint64_t sp = S[q] & ~lin[q];
+      while (sp) {
+        int b = __builtin_ctzll(sp);
+        sp &= sp - 1;
+        const uint32_t* row = P.rows + ((size_t)ctx * P.n_rows + P.row_of[q * 64 + b]) * W;
+        for (int j = 0; j < NQ; j++) {
+          uint64_t r = 0;
+          if (2 * j < W) r = row[2 * j];
+          if (2 * j + 1 < W) r |= (uint64_t)row[2 * j + 1] << 32;
+          T[j] |= r;
+        }
+      }
+    }
+    const uint32_t* cr = P.cls + (uint32_t)t[p] * W;
+    for (int q = 0; q < NQ; q++) {
+      uint64_t c = 0;
+      if (2 * q < W) c = cr[2 * q];
+      if (2 * q + 1 < W) c |= (uint64_t)cr[2 * q + 1] << 32;
+      S[q] = T[q] & c;
+    }
+    p++;
+  }
+  return found;
+}
+
+// Candidate test used by the dense scan: can a match start at s at all?
+RJ_HD bool rj_dense_candidate(const DevProgram& P, const uint8_t* t, uint64_t n, uint64_t s) {
+  if (P.nullable) {
+    int ctx = P.n_ctx > 1 ? rj_context(t, n, s) : 0;
+    if ((P.nullable >> ctx) & 1u) return true;
+  }
+  if (s >= n) return false;
+  uint32_t c = t[s];
+  return (P.first_bytes[c >> 5] >> (c & 31)) & 1u;
+}
+
+// Left-most-longest selection over candidates sorted by begin (one entry per begin):
+// the sequential definition (MatchAllAppendFilter + the non-overlap rule, reference
+// src/codegen.cc:36-86, codegen-x64.cc:448-460), used by the single-lane cluster walk.
+struct RjSelectState {
+  uint64_t cur;       // smallest begin the next match may have
+  uint64_t prev_end;
+  bool have_prev;
+};
+
+// returns true when (b,e) is to be emitted
+RJ_HD bool rj_select_step(RjSelectState* st, uint64_t b, uint64_t e, bool* taken) {
+  *taken = false;
+  if (b < st->cur) return false;
+  *taken = true;
+  st->cur = e > b ? e : b + 1;
+  bool drop = (e == b) && st->have_prev && st->prev_end == b;  // zero-length rule
+  st->have_prev = true;
+  st->prev_end = e;
+  return !drop;
+}
+
+}  // namespace rejit_amd
+#endif

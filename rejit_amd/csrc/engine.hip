@@ -1,0 +1,530 @@
+// rejit_amd/csrc/engine.hip -- host orchestration of the device pipeline and the C ABI
+// (include/rejit_hip.h).  Replaces the reference's API shim src/rejit.cc:150-267 (lazy
+// Compile + indirect call into JIT code) and its result sink src/codegen.cc:36-86.
+//
+//   rj_compile : parse -> lower -> upload the automaton tables to HBM once
+//   rj_scan_run: memset counters -> scan kernel(s) -> verify kernel -> finalize kernel
+//                -> ONE host synchronisation to read {hits, candidates, final count};
+//                lists that overflowed are grown and the run repeated; more than
+//                kFinalizeCap candidates take the rocPRIM radix-sort path.
+//
+// There is no CPU matching code in this library: without a working HIP device every
+// entry point fails with RJ_DEVICE_ERROR.
+#include <cstring>  // must precede rocprim (its texture iterator uses ::memset)
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rejit_hip.h"
+#include "device_program.h"
+#include "kernels.h"
+#include "lowering.h"
+
+using namespace rejit_amd;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+#define RJ_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(RJ_DEVICE_ERROR, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+struct DeviceBuffer {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DeviceBuffer() {
+    if (p) (void)hipFree(p);
+  }
+  // grow-only; contents are NOT preserved
+  hipError_t reserve(size_t want) {
+    if (want <= bytes) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) bytes = want;
+    return e;
+  }
+  template <class T>
+  T* as() const { return static_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct rj_program {
+  std::unique_ptr<Program> host;
+  DevProgram dev{};
+  DeviceBuffer tables;
+  int device = 0;
+  std::string pattern;
+};
+
+struct rj_scan {
+  const rj_program* prog = nullptr;
+  DeviceBuffer counters, hits, cands, out, keys_in, keys_out, vals_in, vals_out, sort_tmp, flag;
+  uint64_t hits_cap = 0, cands_cap = 0, out_cap = 0;
+  unsigned long long* host_counters = nullptr;  // pinned
+  int* host_flag = nullptr;                     // pinned
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  rj_stats stats{};
+  const uint64_t* result = nullptr;  // device pointer to the final pairs
+  uint64_t result_count = 0;
+  // host-text path
+  DeviceBuffer text;
+  hipStream_t own_stream = nullptr;
+};
+
+namespace {
+
+int upload_program(rj_program* rp) {
+  const Program& P = *rp->host;
+  const int W = P.n_words;
+  const int C = P.has_assertions ? kNumCtx : 1;
+  const int R = std::max(P.n_rows, 1);
+  const int Pn = std::max(P.n_pos, 1);
+  // layout in 32-bit words
+  size_t off_first = 0;
+  size_t off_last = off_first + static_cast<size_t>(C) * W;
+  size_t off_linear = off_last + static_cast<size_t>(C) * W;
+  size_t off_rowof = off_linear + W;
+  size_t off_rows = off_rowof + Pn;
+  size_t off_cls = off_rows + static_cast<size_t>(C) * R * W;
+  size_t total = off_cls + static_cast<size_t>(256) * W;
+  std::vector<uint32_t> blob(total, 0u);
+  for (int c = 0; c < C; c++) {
+    std::copy(P.first[c].begin(), P.first[c].end(), blob.begin() + off_first + static_cast<size_t>(c) * W);
+    std::copy(P.last[c].begin(), P.last[c].end(), blob.begin() + off_last + static_cast<size_t>(c) * W);
+    for (int r = 0; r < P.n_rows; r++)
+      std::copy(P.rows[c].begin() + static_cast<long>(r) * W, P.rows[c].begin() + static_cast<long>(r + 1) * W,
+                blob.begin() + off_rows + (static_cast<size_t>(c) * R + r) * W);
+  }
+  std::copy(P.linear.begin(), P.linear.end(), blob.begin() + off_linear);
+  for (int i = 0; i < P.n_pos; i++) blob[off_rowof + i] = static_cast<uint32_t>(P.row_of[static_cast<size_t>(i)]);
+  std::copy(P.cls.begin(), P.cls.end(), blob.begin() + off_cls);
+
+  RJ_HIP(hipGetDevice(&rp->device));
+  RJ_HIP(rp->tables.reserve(total * sizeof(uint32_t)));
+  RJ_HIP(hipMemcpy(rp->tables.p, blob.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice));
+  const uint32_t* base = rp->tables.as<uint32_t>();
+  DevProgram& D = rp->dev;
+  D.n_pos = P.n_pos;
+  D.n_words = W;
+  D.n_ctx = C;
+  D.n_rows = R;
+  D.nullable = 0;
+  for (int c = 0; c < kNumCtx; c++)
+    if (P.nullable[C == 1 ? 0 : c]) D.nullable |= 1u << c;
+  D.mode = P.mode == ScanMode::Windows ? 1 : 0;
+  D.n_windows = static_cast<int>(P.windows.size());
+  D.win_offset = P.windows.empty() ? 0 : P.windows[0].offset;
+  D.win_mask = P.windows.empty() ? 0 : P.windows[0].mask;
+  D.win_len = D.win_mask == 0xFFFFFFFFu ? 4 : D.win_mask == 0xFFFFFFu ? 3 : D.win_mask == 0xFFFFu ? 2 : 1;
+  for (int k = 0; k < kDevMaxWindows; k++)
+    D.win_value[k] = P.windows.empty() ? 0 : P.windows[std::min<size_t>(static_cast<size_t>(k), P.windows.size() - 1)].value;
+  for (int k = 0; k < 8; k++) D.first_bytes[k] = P.first_bytes.w[k];
+  D.min_len = P.min_len;
+  D.first = base + off_first;
+  D.last = base + off_last;
+  D.linear = base + off_linear;
+  D.row_of = reinterpret_cast<const int32_t*>(base + off_rowof);
+  D.rows = base + off_rows;
+  D.cls = base + off_cls;
+  return RJ_OK;
+}
+
+int ensure_lists(rj_scan* s, uint64_t hits_cap, uint64_t cands_cap) {
+  if (hits_cap > s->hits_cap) {
+    RJ_HIP(s->hits.reserve(hits_cap * sizeof(uint64_t)));
+    s->hits_cap = hits_cap;
+  }
+  if (cands_cap > s->cands_cap) {
+    RJ_HIP(s->cands.reserve(cands_cap * 2 * sizeof(uint64_t)));
+    RJ_HIP(s->out.reserve(cands_cap * 2 * sizeof(uint64_t)));
+    s->cands_cap = cands_cap;
+    s->out_cap = cands_cap;
+  }
+  return RJ_OK;
+}
+
+// Large path: more candidates than finalize_small sorts in LDS.
+int finalize_large(rj_scan* s, uint64_t n_cands, const FinalizeParams& fp, hipStream_t st) {
+  s->stats.large_path = 1;
+  RJ_HIP(s->keys_in.reserve(n_cands * sizeof(uint64_t)));
+  RJ_HIP(s->keys_out.reserve(n_cands * sizeof(uint64_t)));
+  RJ_HIP(s->vals_in.reserve(n_cands * sizeof(uint64_t)));
+  RJ_HIP(s->vals_out.reserve(n_cands * sizeof(uint64_t)));
+  launch_split_pairs(s->cands.as<uint64_t>(), n_cands, s->keys_in.as<uint64_t>(), s->vals_in.as<uint64_t>(), st);
+  size_t tmp_bytes = 0;
+  RJ_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, s->keys_in.as<uint64_t>(), s->keys_out.as<uint64_t>(),
+                                   s->vals_in.as<uint64_t>(), s->vals_out.as<uint64_t>(), n_cands, 0, 64, st));
+  RJ_HIP(s->sort_tmp.reserve(std::max<size_t>(tmp_bytes, 16)));
+  RJ_HIP(rocprim::radix_sort_pairs(s->sort_tmp.p, tmp_bytes, s->keys_in.as<uint64_t>(), s->keys_out.as<uint64_t>(),
+                                   s->vals_in.as<uint64_t>(), s->vals_out.as<uint64_t>(), n_cands, 0, 64, st));
+  // already a valid result (pairwise disjoint, no empties)?  then selection is the identity
+  *s->host_flag = 1;
+  RJ_HIP(hipMemcpyAsync(s->flag.p, s->host_flag, sizeof(int), hipMemcpyHostToDevice, st));
+  launch_check_disjoint(s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), n_cands, s->flag.as<int>(), st);
+  RJ_HIP(hipMemcpyAsync(s->host_flag, s->flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  RJ_HIP(hipStreamSynchronize(st));
+  uint64_t first_key = 0;
+  RJ_HIP(hipMemcpy(&first_key, s->keys_out.p, sizeof(uint64_t), hipMemcpyDeviceToHost));
+  if (*s->host_flag == 1 && first_key >= fp.carry_cur) {
+    launch_interleave_pairs(s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), n_cands, s->out.as<uint64_t>(),
+                            s->out_cap, st);
+    RJ_HIP(hipStreamSynchronize(st));
+    s->result_count = n_cands;
+    return RJ_OK;
+  }
+  launch_select_sorted(s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), n_cands, fp, st);
+  RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  RJ_HIP(hipStreamSynchronize(st));
+  s->result_count = s->host_counters[kCntFinal];
+  return RJ_OK;
+}
+
+int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, uint64_t carry_cur,
+                 uint64_t carry_prev_end, int have_prev, hipStream_t st) {
+  const rj_program* rp = s->prog;
+  const DevProgram& D = rp->dev;
+  if (se > n + 1) se = n + 1;
+  s->stats = rj_stats{};
+  s->result = s->out.as<uint64_t>();
+  s->result_count = 0;
+  if (sb >= se) return RJ_OK;
+  if ((reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) return fail(RJ_BAD_ARGUMENT, "device text must be 16-byte aligned");
+
+  // Dense mode produces a hit for a sizeable fraction of the bytes: walk the starts in
+  // segments so the hit list stays bounded.  Windows mode: one segment.
+  const bool windows = D.mode == 1;
+  const uint64_t seg = windows ? (se - sb) : std::min<uint64_t>(se - sb, 1ull << 27);
+  uint64_t want_hits = windows ? std::max<uint64_t>(1u << 16, (se - sb) / 512) : seg + 64;
+  uint64_t want_cands = std::max<uint64_t>(1u << 16, (se - sb) / 512);
+
+  for (int attempt = 0; attempt < 8; attempt++) {
+    int rc = ensure_lists(s, std::max(want_hits, s->hits_cap), std::max(want_cands, s->cands_cap));
+    if (rc != RJ_OK) return rc;
+    RJ_HIP(hipMemsetAsync(s->counters.p, 0, kCntSize * sizeof(unsigned long long), st));
+    RJ_HIP(hipEventRecord(s->ev[0], st));
+    float scan_ms_total = 0.f;
+    (void)scan_ms_total;
+    for (uint64_t lo = sb; lo < se; lo += seg) {
+      const uint64_t hi = std::min(se, lo + seg);
+      if (lo != sb) RJ_HIP(hipMemsetAsync(s->counters.as<unsigned long long>() + kCntHits, 0, sizeof(unsigned long long), st));
+      ScanParams sp{};
+      sp.text = d_text;
+      sp.n = n;
+      sp.sb = lo;
+      sp.se = hi;
+      sp.hits = s->hits.as<uint64_t>();
+      sp.hits_cap = s->hits_cap;
+      sp.counters = s->counters.as<unsigned long long>();
+      if (lo == sb) RJ_HIP(hipEventRecord(s->ev[1], st));
+      if (windows) {
+        WindowSet ws{};
+        for (int k = 0; k < kDevMaxWindows; k++) ws.value[k] = D.win_value[k];
+        ws.mask = D.win_mask;
+        ws.offset = D.win_offset;
+        sp.wlo = lo + D.win_offset;
+        // a window must fit into the text: w + win_len <= n
+        const uint64_t last_w = n >= D.win_len ? n - D.win_len + 1 : 0;
+        sp.whi = std::min(hi + D.win_offset, last_w);
+        launch_scan_windows(sp, ws, D.n_windows, st);
+      } else {
+        launch_scan_dense(sp, D, st);
+      }
+      if (hi == se) RJ_HIP(hipEventRecord(s->ev[2], st));
+      VerifyParams vp{};
+      vp.text = d_text;
+      vp.n = n;
+      vp.hits = s->hits.as<uint64_t>();
+      vp.hits_cap = s->hits_cap;
+      vp.cands = s->cands.as<uint64_t>();
+      vp.cands_cap = s->cands_cap;
+      vp.counters = s->counters.as<unsigned long long>();
+      launch_verify(vp, D, windows ? 65536 : (hi - lo) / 8 + 1, st);
+    }
+    FinalizeParams fp{};
+    fp.cands = s->cands.as<uint64_t>();
+    fp.cands_cap = s->cands_cap;
+    fp.hits_cap = s->hits_cap;
+    fp.out = s->out.as<uint64_t>();
+    fp.out_cap = s->out_cap;
+    fp.counters = s->counters.as<unsigned long long>();
+    fp.carry_cur = carry_cur;
+    fp.carry_prev_end = carry_prev_end;
+    fp.have_prev = have_prev;
+    launch_finalize_small(fp, st);
+    RJ_HIP(hipEventRecord(s->ev[3], st));
+    RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    RJ_HIP(hipStreamSynchronize(st));
+    RJ_HIP(hipGetLastError());
+    const unsigned long long n_hits = s->host_counters[kCntHits];
+    const unsigned long long n_cands = s->host_counters[kCntCands];
+    s->stats.n_hits = n_hits;
+    s->stats.n_candidates = n_cands;
+    (void)hipEventElapsedTime(&s->stats.scan_ms, s->ev[1], s->ev[2]);
+    (void)hipEventElapsedTime(&s->stats.total_ms, s->ev[0], s->ev[3]);
+    if (s->host_counters[kCntOverflow] != 0 || n_cands > s->cands_cap || n_hits > s->hits_cap) {
+      // grow whichever list overflowed and run again
+      s->stats.retries++;
+      want_hits = std::max<uint64_t>(s->hits_cap, std::min<uint64_t>(std::max<uint64_t>(n_hits, s->hits_cap * 4), seg + 64));
+      want_cands = std::max<uint64_t>(s->cands_cap, std::min<uint64_t>(std::max<uint64_t>(n_cands * 2, s->cands_cap * 4), (se - sb) + 64));
+      if (want_hits == s->hits_cap && want_cands == s->cands_cap) return fail(RJ_DEVICE_ERROR, "device lists cannot grow further");
+      continue;
+    }
+    if (s->host_counters[kCntFinal] == ~0ull) {
+      rc = finalize_large(s, n_cands, fp, st);
+      if (rc != RJ_OK) return rc;
+    } else {
+      s->result_count = s->host_counters[kCntFinal];
+    }
+    s->stats.n_matches = s->result_count;
+    return RJ_OK;
+  }
+  return fail(RJ_DEVICE_ERROR, "device lists kept overflowing");
+}
+
+int scan_init(rj_scan* s) {
+  RJ_HIP(s->counters.reserve(kCntSize * sizeof(unsigned long long)));
+  RJ_HIP(s->flag.reserve(16));
+  RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->host_counters), kCntSize * sizeof(unsigned long long)));
+  RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->host_flag), 16));
+  for (auto& e : s->ev) RJ_HIP(hipEventCreate(&e));
+  return RJ_OK;
+}
+
+// one scratch per (thread, program) for the host-text entry points
+struct HostScans {
+  std::vector<std::pair<const rj_program*, rj_scan*>> v;
+  ~HostScans() {
+    for (auto& p : v) rj_scan_destroy(p.second);
+  }
+};
+thread_local HostScans g_host_scans;
+
+int host_scan_for(const rj_program* prog, rj_scan** out) {
+  for (auto& p : g_host_scans.v)
+    if (p.first == prog) {
+      *out = p.second;
+      return RJ_OK;
+    }
+  rj_scan* s = nullptr;
+  int rc = rj_scan_create(prog, &s);
+  if (rc != RJ_OK) return rc;
+  if (hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    rj_scan_destroy(s);
+    return fail(RJ_DEVICE_ERROR, "hipStreamCreate failed");
+  }
+  if (g_host_scans.v.size() >= 16) {  // bound the cache
+    rj_scan_destroy(g_host_scans.v.front().second);
+    g_host_scans.v.erase(g_host_scans.v.begin());
+  }
+  g_host_scans.v.emplace_back(prog, s);
+  *out = s;
+  return RJ_OK;
+}
+
+int stage_text(rj_scan* s, const char* text, size_t n, const uint8_t** d_text) {
+  RJ_HIP(s->text.reserve(((n + 64 + 4095) / 4096) * 4096));
+  if (n) RJ_HIP(hipMemcpyAsync(s->text.p, text, n, hipMemcpyHostToDevice, s->own_stream));
+  *d_text = s->text.as<uint8_t>();
+  return RJ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rj_last_error(void) { return g_error.c_str(); }
+
+int rj_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int rj_compile(const char* regexp, rj_program** out) {
+  if (!regexp || !out) return fail(RJ_BAD_ARGUMENT, "null argument");
+  *out = nullptr;
+  g_error.clear();
+  LowerResult lr = lower(regexp);
+  if (lr.status != 0) {
+    g_error = lr.message;
+    return lr.status == kParseError ? RJ_PARSER_ERROR : RJ_TOO_LARGE;
+  }
+  auto rp = std::make_unique<rj_program>();
+  rp->host = std::move(lr.program);
+  rp->pattern = regexp;
+  int rc = upload_program(rp.get());
+  if (rc != RJ_OK) return rc;
+  *out = rp.release();
+  return RJ_OK;
+}
+
+void rj_program_free(rj_program* prog) {
+  if (!prog) return;
+  // drop cached host scans of this thread that refer to the program
+  auto& v = g_host_scans.v;
+  for (size_t i = 0; i < v.size();) {
+    if (v[i].first == prog) {
+      rj_scan_destroy(v[i].second);
+      v.erase(v.begin() + static_cast<long>(i));
+    } else {
+      i++;
+    }
+  }
+  delete prog;
+}
+
+int rj_program_info(const rj_program* prog, rj_info* info) {
+  if (!prog || !info) return fail(RJ_BAD_ARGUMENT, "null argument");
+  const Program& P = *prog->host;
+  info->n_positions = P.n_pos;
+  info->n_words = P.n_words;
+  info->has_assertions = P.has_assertions;
+  info->scan_mode = P.mode == ScanMode::Windows;
+  info->n_windows = static_cast<int32_t>(P.windows.size());
+  info->window_offset = prog->dev.win_offset;
+  info->window_len = prog->dev.win_len;
+  info->min_len = P.min_len;
+  info->max_len = P.max_len;
+  return RJ_OK;
+}
+
+int rj_scan_create(const rj_program* prog, rj_scan** out) {
+  if (!prog || !out) return fail(RJ_BAD_ARGUMENT, "null argument");
+  auto s = std::make_unique<rj_scan>();
+  s->prog = prog;
+  int rc = scan_init(s.get());
+  if (rc != RJ_OK) return rc;
+  *out = s.release();
+  return RJ_OK;
+}
+
+void rj_scan_destroy(rj_scan* s) {
+  if (!s) return;
+  if (s->host_counters) (void)hipHostFree(s->host_counters);
+  if (s->host_flag) (void)hipHostFree(s->host_flag);
+  for (auto& e : s->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
+  delete s;
+}
+
+int64_t rj_scan_run(rj_scan* s, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end,
+                    uint64_t carry_cur, uint64_t carry_prev_end, int have_prev, void* hip_stream) {
+  if (!s) return fail(RJ_BAD_ARGUMENT, "null scan");
+  int rc = run_pipeline(s, static_cast<const uint8_t*>(d_text), n, own_begin, own_end, carry_cur, carry_prev_end,
+                        have_prev, static_cast<hipStream_t>(hip_stream));
+  if (rc != RJ_OK) return rc;
+  return static_cast<int64_t>(s->result_count);
+}
+
+const uint64_t* rj_scan_device_spans(const rj_scan* s) { return s ? s->result : nullptr; }
+
+int64_t rj_scan_copy_spans(const rj_scan* s, uint64_t* host_spans, uint64_t cap) {
+  if (!s) return fail(RJ_BAD_ARGUMENT, "null scan");
+  const uint64_t k = std::min<uint64_t>(cap, s->result_count);
+  if (k) {
+    hipError_t e = hipMemcpy(host_spans, s->result, k * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(RJ_DEVICE_ERROR, "hipMemcpy failed: %s", hipGetErrorString(e));
+  }
+  return static_cast<int64_t>(s->result_count);
+}
+
+int rj_scan_stats(const rj_scan* s, rj_stats* stats) {
+  if (!s || !stats) return fail(RJ_BAD_ARGUMENT, "null argument");
+  *stats = s->stats;
+  return RJ_OK;
+}
+
+int rj_scan_match_full(rj_scan* s, const void* d_text, uint64_t n, void* hip_stream) {
+  if (!s) return fail(RJ_BAD_ARGUMENT, "null scan");
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  launch_match_full(static_cast<const uint8_t*>(d_text), n, s->prog->dev, s->flag.as<int>(), st);
+  RJ_HIP(hipMemcpyAsync(s->host_flag, s->flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  RJ_HIP(hipStreamSynchronize(st));
+  RJ_HIP(hipGetLastError());
+  return *s->host_flag ? 1 : 0;
+}
+
+int64_t rj_match_all(const rj_program* prog, const char* text, size_t n, uint64_t** spans) {
+  if (spans) *spans = nullptr;
+  if (!prog || (!text && n)) return fail(RJ_BAD_ARGUMENT, "null argument");
+  rj_scan* s = nullptr;
+  int rc = host_scan_for(prog, &s);
+  if (rc != RJ_OK) return rc;
+  const uint8_t* d_text = nullptr;
+  rc = stage_text(s, text, n, &d_text);
+  if (rc != RJ_OK) return rc;
+  rc = run_pipeline(s, d_text, n, 0, n + 1, 0, 0, 0, s->own_stream);
+  if (rc != RJ_OK) return rc;
+  if (spans && s->result_count) {
+    uint64_t* h = static_cast<uint64_t*>(malloc(s->result_count * 2 * sizeof(uint64_t)));
+    if (!h) return fail(RJ_DEVICE_ERROR, "out of host memory");
+    hipError_t e = hipMemcpy(h, s->result, s->result_count * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+      free(h);
+      return fail(RJ_DEVICE_ERROR, "hipMemcpy failed: %s", hipGetErrorString(e));
+    }
+    *spans = h;
+  }
+  return static_cast<int64_t>(s->result_count);
+}
+
+void rj_free_spans(uint64_t* spans) { free(spans); }
+
+int rj_match_first(const rj_program* prog, const char* text, size_t n, uint64_t* begin, uint64_t* end) {
+  // kMatchFirst == first element of kMatchAll (left-most longest); see DESIGN.md
+  uint64_t* spans = nullptr;
+  int64_t c = rj_match_all(prog, text, n, &spans);
+  if (c < 0) return static_cast<int>(c);
+  if (c > 0) {
+    if (begin) *begin = spans[0];
+    if (end) *end = spans[1];
+  }
+  rj_free_spans(spans);
+  return c > 0 ? 1 : 0;
+}
+
+int rj_match_anywhere(const rj_program* prog, const char* text, size_t n) {
+  int64_t c = rj_match_all(prog, text, n, nullptr);
+  if (c < 0) return static_cast<int>(c);
+  return c > 0 ? 1 : 0;
+}
+
+int rj_match_full(const rj_program* prog, const char* text, size_t n) {
+  if (!prog || (!text && n)) return fail(RJ_BAD_ARGUMENT, "null argument");
+  rj_scan* s = nullptr;
+  int rc = host_scan_for(prog, &s);
+  if (rc != RJ_OK) return rc;
+  const uint8_t* d_text = nullptr;
+  rc = stage_text(s, text, n, &d_text);
+  if (rc != RJ_OK) return rc;
+  return rj_scan_match_full(s, d_text, n, s->own_stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// rejit_amd/csrc/kernels.h -- parameter blocks and launchers of the HIP kernels.
+#ifndef REJIT_AMD_KERNELS_H_
+#define REJIT_AMD_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_program.h"
+
+namespace rejit_amd {
+
+// device counters (unsigned long long[kCntSize])
+enum { kCntHits = 0, kCntCands = 1, kCntFinal = 2, kCntOverflow = 3, kCntSize = 8 };
+
+constexpr int kFinalizeCap = 2048;  // candidates the single-workgroup finalize sorts in LDS
+
+struct ScanParams {
+  const uint8_t* text;   // 16-byte aligned; bytes [0, n) are readable
+  uint64_t n;
+  uint64_t sb, se;       // candidate starts lie in [sb, se), se <= n + 1
+  uint64_t wlo, whi;     // window positions scanned (windows mode): [wlo, whi)
+  uint64_t* hits;
+  uint64_t hits_cap;
+  unsigned long long* counters;
+};
+
+struct WindowSet {
+  uint32_t value[kDevMaxWindows];
+  uint32_t mask;
+  uint32_t offset;
+};
+
+struct VerifyParams {
+  const uint8_t* text;
+  uint64_t n;
+  const uint64_t* hits;
+  uint64_t hits_cap;
+  uint64_t* cands;       // (begin,end) pairs
+  uint64_t cands_cap;
+  unsigned long long* counters;
+};
+
+struct FinalizeParams {
+  const uint64_t* cands;
+  uint64_t cands_cap;
+  uint64_t hits_cap;
+  uint64_t* out;         // (begin,end) pairs, ordered
+  uint64_t out_cap;
+  unsigned long long* counters;
+  // state carried in from the text before this range (multi-GPU / segmented runs):
+  uint64_t carry_cur;       // smallest begin the first match may have
+  uint64_t carry_prev_end;  // end of the previous match (zero-length rule)
+  int have_prev;
+};
+
+void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows, hipStream_t st);
+void launch_scan_dense(const ScanParams& a, const DevProgram& P, hipStream_t st);
+void launch_verify(const VerifyParams& a, const DevProgram& P, uint64_t expected_hits, hipStream_t st);
+void launch_match_full(const uint8_t* text, uint64_t n, const DevProgram& P, int* result, hipStream_t st);
+void launch_finalize_small(const FinalizeParams& a, hipStream_t st);
+void launch_split_pairs(const uint64_t* pairs, uint64_t n, uint64_t* keys, uint64_t* vals, hipStream_t st);
+void launch_check_disjoint(const uint64_t* keys, const uint64_t* vals, uint64_t n, int* flag, hipStream_t st);
+void launch_interleave_pairs(const uint64_t* keys, const uint64_t* vals, uint64_t n, uint64_t* out, uint64_t cap,
+                             hipStream_t st);
+void launch_select_sorted(const uint64_t* keys, const uint64_t* vals, uint64_t n, const FinalizeParams& a,
+                          hipStream_t st);
+
+}  // namespace rejit_amd
+#endif
