@@ -211,7 +211,7 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
   const DevProgram& D = rp->dev;
   if (se > n + 1) se = n + 1;
   s->stats = rj_stats{};
-  s->result = s->out.as<uint64_t>();
+  s->result = nullptr;
   s->result_count = 0;
   if (sb >= se) return RJ_OK;
   if ((reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) return fail(RJ_BAD_ARGUMENT, "device text must be 16-byte aligned");
@@ -302,6 +302,7 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       s->result_count = s->host_counters[kCntFinal];
     }
     s->stats.n_matches = s->result_count;
+    s->result = s->out.as<uint64_t>();
     return RJ_OK;
   }
   return fail(RJ_DEVICE_ERROR, "device lists kept overflowing");
