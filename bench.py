@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline measurement (BASELINE.json: "GB/s text scanned + matches/s,
+regexdna 50M-line input, 1/2/4/8 MI355X").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One STEP = one pass of the hot path over one batch of synthetic input: the nine regex-dna
+patterns (reference sample/regexdna.cc:51-67), one MatchAllCount each, over the stripped
+50M-line FASTA text (500 MB per GPU), already resident in HBM when the timed region
+starts.  With N GPUs the text is N x 500 MB (weak scaling), cut into contiguous byte ranges
+with a halo of max_match_len-1 bytes; the only exchange is an RCCL all_reduce of the nine
+match counts per step.  Rank 0 prints ONE JSON line.
+
+Besides the contract fields the line carries
+  roofline      -- the dominant kernel (the fast-forward window scan): algorithmic bytes
+                   per launch (1 byte read per text byte per MatchAll call, SURVEY.md
+                   section 8d) / average launch duration from HIP events on the run's stream
+  cpu_baseline  -- the REAL reference (oracle/_ref, built from /root/reference) timed on
+                   one host core on a bounded sample of the same text, same convention
+  literal_scan  -- BASELINE configs[1]: literal `regexp` over 5 GB random ASCII, 1 GPU
+                   (the pure fast-forward scan of the north star), with its own roofline
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--fasta-n", type=int, default=50_000_000, help="FASTA size parameter per GPU (50M = 500 MB stripped)")
+    ap.add_argument("--literal-bytes", type=int, default=5_000_000_000)
+    ap.add_argument("--no-extra", action="store_true", help="skip the literal_scan extra")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-mib", type=int, default=64)
+    return ap.parse_args()
+
+
+def cpu_baseline(text_host: bytes, patterns, sample_desc: str):
+    """The reference's own x86 SIMD path on ONE host core (kind "reference"), or, when the
+    prebuilt oracle/_ref library is absent, our C restatement (kind "port")."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import checkers
+    n = len(text_host)
+    if checkers.have_ref():
+        # default flags except use_ff_reduce=0: the fast-forward configuration whose counts are
+        # correct; compile time excluded as in the reference harness
+        ref = checkers.Ref(use_ff=1, ff_early=1, ff_reduce=0, parser_opt=1)
+        counts = []
+        t0 = time.perf_counter()
+        for rx in patterns:
+            counts.append(int(ref.lib.ref_match_all_repeat(rx.encode(), text_host, n, 1)))
+        dt = time.perf_counter() - t0
+        return dict(value=len(patterns) * n / dt / 1e9, unit="GB/s", cores=1, kind="reference",
+                    sample=sample_desc + "; reference flags use_fast_forward=1 use_ff_reduce=0",
+                    seconds=round(dt, 3)), counts
+    oracle = checkers.Oracle()
+    n = min(n, 4 << 20)
+    t0 = time.perf_counter()
+    counts = [oracle.count(rx.encode(), text_host[:n]) for rx in patterns]
+    dt = time.perf_counter() - t0
+    return dict(value=len(patterns) * n / dt / 1e9, unit="GB/s", cores=1, kind="port",
+                sample=f"first {n} bytes of rank 0's text (oracle/_ref not present)", seconds=round(dt, 3)), None
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    import rejit_amd
+    from rejit_amd import sharding, workloads as W
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    rejit_amd.build()
+    patterns = W.REGEXDNA_PATTERNS
+    progs = [rejit_amd.Program(rx) for rx in patterns]
+    scans = [rejit_amd.Scan(p) for p in progs]
+    max_len = max(p.info()["max_len"] for p in progs)
+
+    # ---- input: N x (10 * fasta_n) bytes of stripped FASTA, rank r holds its range + halo
+    n_fa = args.fasta_n * world
+    n_total = W.fasta_stripped_size(n_fa)
+    ranges = sharding.partition(n_total, world)
+    own = ranges[rank]
+    vis_lo, vis_hi = sharding.visible_range(n_total, own, max_len)
+    text = W.fasta_stripped_torch(n_fa, dev, lo=vis_lo, hi=vis_hi)
+    n_local = int(text.numel())
+    own_lo, own_hi = own[0] - vis_lo, min(own[1], n_total + 1) - vis_lo
+    own_bytes = min(own[1], n_total) - own[0]
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    torch.cuda.synchronize(dev)
+
+    counts_dev = torch.zeros(len(patterns), dtype=torch.int64, device=dev)
+    scan_ms = []
+
+    def step(record: bool):
+        local = []
+        for sc in scans:
+            c = sc.run(text.data_ptr(), n_local, own_begin=own_lo, own_end=own_hi, stream=stream)
+            local.append(c)
+            if record:
+                scan_ms.append(sc.stats()["scan_ms"])
+        if world > 1:
+            counts_dev.copy_(torch.tensor(local, dtype=torch.int64), non_blocking=False)
+            dist.all_reduce(counts_dev)       # RCCL over xGMI: 9 x 8 bytes
+            return counts_dev.tolist()
+        return local
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counts = step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    total_matches = int(sum(counts))
+    scanned = len(patterns) * n_total * args.steps          # bytes of text scanned by the whole job
+    value = scanned / elapsed / 1e9
+    avg_scan_ms = sum(scan_ms) / max(len(scan_ms), 1)
+    achieved = own_bytes / (avg_scan_ms * 1e-3) / 1e9 if avg_scan_ms > 0 else 0.0
+
+    out = {
+        "metric": "GB/s text scanned (regexdna 9 patterns, 50M-line input); matches/s alongside",
+        "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "regexdna: 9 x MatchAllCount over the stripped 50M-line FASTA (BASELINE configs[2])",
+                   "fasta_n_per_gpu": args.fasta_n, "text_bytes_per_gpu": int(own_bytes), "patterns": len(patterns),
+                   "sharding": "contiguous byte ranges + %d-byte halo; all_reduce of 9 counts per step" % (max_len - 1)},
+        "matches_per_s": round(total_matches * args.steps / elapsed, 1),
+        "matches_per_pass": counts,
+        "roofline": {"bound": "hbm", "kernel": "scan_windows<K>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "avg_launch_ms": round(avg_scan_ms, 5), "bytes_per_launch": int(own_bytes),
+                     "launches_timed": len(scan_ms)},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # bounded sample taken from the lower-case (matching) part of the text: the first 20 %
+        # is the upper-case ALU repeat, which no pattern can match
+        sample = min(n_local, args.cpu_sample_mib << 20)
+        s0 = min(max(0, n_local - sample), (int(n_local * 0.6) // 4096) * 4096)
+        host = text[s0:s0 + sample].cpu().numpy().tobytes()
+        base, ref_counts = cpu_baseline(host, patterns, f"bytes [{s0}, {s0 + sample}) of the same text, 9 patterns, 1 pass")
+        out["cpu_baseline"] = base
+        if ref_counts is not None:
+            # in-run parity check against the real reference on the sample
+            gpu_counts = []
+            for sc in scans:
+                sc.run(text.data_ptr() + s0, sample, own_begin=0, own_end=sample + 1, stream=stream)
+                gpu_counts.append(sc.stats()["n_matches"])
+            assert gpu_counts == ref_counts, ("GPU and reference disagree on the sample", gpu_counts, ref_counts)
+            out["cpu_baseline"]["parity_on_sample"] = "GPU counts == reference counts: %s" % ref_counts
+
+    if rank == 0 and world == 1 and not args.no_extra:
+        del text
+        torch.cuda.empty_cache()
+        n = args.literal_bytes
+        t = W.random_ascii_torch(n, 0xC0FFEE, dev)
+        offs = W.plant_offsets(n, 6, 1000, seed=0xC0FFEE, boundaries=[16, 1024, 1 << 20, 1 << 30, n // 2])
+        W.plant(t, offs, b"regexp")
+        prog = rejit_amd.Program("regexp")
+        sc = rejit_amd.Scan(prog)
+        torch.cuda.synchronize(dev)
+        for _ in range(2):
+            sc.run(t.data_ptr(), n, stream=stream)
+        ms, tot = [], []
+        steps = max(5, min(args.steps, 20))
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            c = sc.run(t.data_ptr(), n, stream=stream)
+            st = sc.stats()
+            ms.append(st["scan_ms"])
+            tot.append(st["total_ms"])
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        found = [b for b, _ in sc.spans()]
+        assert set(offs) <= set(found), "a planted occurrence was missed"
+        a_ms = sum(ms) / len(ms)
+        ach = n / (a_ms * 1e-3) / 1e9
+        out["literal_scan"] = {
+            "workload": "literal 'regexp' MatchAll over %d bytes random ASCII ['0','z'), %d planted (BASELINE configs[1])" % (n, len(offs)),
+            "value": round(n * steps / dt / 1e9, 1), "unit": "GB/s", "matches": int(c), "latency_ms": round(dt / steps * 1e3, 4),
+            "roofline": {"bound": "hbm", "kernel": "scan_windows<1>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "avg_launch_ms": round(a_ms, 5), "bytes_per_launch": n},
+        }
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -953,6 +953,21 @@ long ro_match_all_spec_re(const char* regexp, const uint8_t* text, size_t n, uin
   return c;
 }
 
+/* ends[s] = end of the longest match that begins exactly at s, or -1 (s = 0..n).
+ * Test helper: lets the multi-rank selection protocol be checked against a plain
+ * per-start table. */
+int ro_longest_all_re(const char* regexp, const uint8_t* text, size_t n, int64_t* ends) {
+  ro_regex* R;
+  int st = ro_compile(regexp, &R);
+  if (st != RO_OK) return st;
+  for (size_t s = 0; s <= n; s++) {
+    size_t e;
+    ends[s] = longest_from(R, text, n, s, &e) ? (int64_t)e : -1;
+  }
+  ro_free(R);
+  return RO_OK;
+}
+
 long ro_match_all_re(const char* regexp, const uint8_t* text, size_t n, uint64_t* out, size_t cap) {
   ro_regex* R;
   int st = ro_compile(regexp, &R);

@@ -60,6 +60,8 @@ int ro_match_full_re(const char* regexp, const uint8_t* text, size_t n);
 long ro_match_all_spec(const ro_regex* re, const uint8_t* text, size_t n, uint64_t* out, size_t cap);
 long ro_match_all_spec_re(const char* regexp, const uint8_t* text, size_t n, uint64_t* out, size_t cap);
 
+int ro_longest_all_re(const char* regexp, const uint8_t* text, size_t n, int64_t* ends);
+
 /* Introspection used by tests. */
 int ro_n_states(const ro_regex* re);
 int ro_n_edges(const ro_regex* re);

@@ -32,9 +32,9 @@ struct DevProgram {
   int32_t mode;         // 0 dense, 1 windows
   int32_t n_windows;
   uint32_t win_offset;
-  uint32_t win_len;     // bytes compared per window (1..4)
-  uint32_t win_value[kDevMaxWindows];
-  uint32_t win_mask;
+  uint32_t win_len;     // pattern bytes covered by a window (1..8)
+  uint32_t win_value0[kDevMaxWindows], win_mask0[kDevMaxWindows];  // first dword of the window
+  uint32_t win_value1[kDevMaxWindows], win_mask1[kDevMaxWindows];  // second dword (win_len > 4)
   uint32_t first_bytes[8];
   uint64_t min_len;
   const uint32_t* first;

@@ -84,7 +84,8 @@ struct rj_program {
 
 struct rj_scan {
   const rj_program* prog = nullptr;
-  DeviceBuffer counters, hits, cands, out, keys_in, keys_out, vals_in, vals_out, sort_tmp, flag;
+  DeviceBuffer counters, hits, cand_begin, cand_end, out, keys_out, vals_out, sort_tmp, flag;
+  DeviceBuffer scan_a, scan_b, taken;  // large-path selection scratch
   uint64_t hits_cap = 0, cands_cap = 0, out_cap = 0;
   unsigned long long* host_counters = nullptr;  // pinned
   int* host_flag = nullptr;                     // pinned
@@ -140,10 +141,15 @@ int upload_program(rj_program* rp) {
   D.mode = P.mode == ScanMode::Windows ? 1 : 0;
   D.n_windows = static_cast<int>(P.windows.size());
   D.win_offset = P.windows.empty() ? 0 : P.windows[0].offset;
-  D.win_mask = P.windows.empty() ? 0 : P.windows[0].mask;
-  D.win_len = D.win_mask == 0xFFFFFFFFu ? 4 : D.win_mask == 0xFFFFFFu ? 3 : D.win_mask == 0xFFFFu ? 2 : 1;
-  for (int k = 0; k < kDevMaxWindows; k++)
-    D.win_value[k] = P.windows.empty() ? 0 : P.windows[std::min<size_t>(static_cast<size_t>(k), P.windows.size() - 1)].value;
+  D.win_len = P.windows.empty() ? 0 : P.windows[0].len;
+  for (int k = 0; k < kDevMaxWindows; k++) {
+    // unused slots repeat the last window, so kernels instantiated for a larger K stay exact
+    const FFWindow w = P.windows.empty() ? FFWindow{} : P.windows[std::min<size_t>(static_cast<size_t>(k), P.windows.size() - 1)];
+    D.win_value0[k] = w.value0;
+    D.win_mask0[k] = w.mask0;
+    D.win_value1[k] = w.value1;
+    D.win_mask1[k] = w.mask1;
+  }
   for (int k = 0; k < 8; k++) D.first_bytes[k] = P.first_bytes.w[k];
   D.min_len = P.min_len;
   D.first = base + off_first;
@@ -161,7 +167,8 @@ int ensure_lists(rj_scan* s, uint64_t hits_cap, uint64_t cands_cap) {
     s->hits_cap = hits_cap;
   }
   if (cands_cap > s->cands_cap) {
-    RJ_HIP(s->cands.reserve(cands_cap * 2 * sizeof(uint64_t)));
+    RJ_HIP(s->cand_begin.reserve(cands_cap * sizeof(uint64_t)));
+    RJ_HIP(s->cand_end.reserve(cands_cap * sizeof(uint64_t)));
     RJ_HIP(s->out.reserve(cands_cap * 2 * sizeof(uint64_t)));
     s->cands_cap = cands_cap;
     s->out_cap = cands_cap;
@@ -170,37 +177,73 @@ int ensure_lists(rj_scan* s, uint64_t hits_cap, uint64_t cands_cap) {
 }
 
 // Large path: more candidates than finalize_small sorts in LDS.
-int finalize_large(rj_scan* s, uint64_t n_cands, const FinalizeParams& fp, hipStream_t st) {
+int finalize_large(rj_scan* s, uint64_t n_cands, uint64_t text_len, const FinalizeParams& fp, hipStream_t st) {
   s->stats.large_path = 1;
-  RJ_HIP(s->keys_in.reserve(n_cands * sizeof(uint64_t)));
   RJ_HIP(s->keys_out.reserve(n_cands * sizeof(uint64_t)));
-  RJ_HIP(s->vals_in.reserve(n_cands * sizeof(uint64_t)));
   RJ_HIP(s->vals_out.reserve(n_cands * sizeof(uint64_t)));
-  launch_split_pairs(s->cands.as<uint64_t>(), n_cands, s->keys_in.as<uint64_t>(), s->vals_in.as<uint64_t>(), st);
+  uint64_t* kin = s->cand_begin.as<uint64_t>();
+  uint64_t* vin = s->cand_end.as<uint64_t>();
+  // begins are < 2^bits: sort only the bits that can differ
+  unsigned bits = 1;
+  while (bits < 64 && (text_len >> bits) != 0) bits++;
   size_t tmp_bytes = 0;
-  RJ_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, s->keys_in.as<uint64_t>(), s->keys_out.as<uint64_t>(),
-                                   s->vals_in.as<uint64_t>(), s->vals_out.as<uint64_t>(), n_cands, 0, 64, st));
+  RJ_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, s->keys_out.as<uint64_t>(), vin, s->vals_out.as<uint64_t>(),
+                                   n_cands, 0, bits, st));
   RJ_HIP(s->sort_tmp.reserve(std::max<size_t>(tmp_bytes, 16)));
-  RJ_HIP(rocprim::radix_sort_pairs(s->sort_tmp.p, tmp_bytes, s->keys_in.as<uint64_t>(), s->keys_out.as<uint64_t>(),
-                                   s->vals_in.as<uint64_t>(), s->vals_out.as<uint64_t>(), n_cands, 0, 64, st));
-  // already a valid result (pairwise disjoint, no empties)?  then selection is the identity
+  RJ_HIP(rocprim::radix_sort_pairs(s->sort_tmp.p, tmp_bytes, kin, s->keys_out.as<uint64_t>(), vin,
+                                   s->vals_out.as<uint64_t>(), n_cands, 0, bits, st));
+  // common case: the sorted candidates already are the result
   *s->host_flag = 1;
   RJ_HIP(hipMemcpyAsync(s->flag.p, s->host_flag, sizeof(int), hipMemcpyHostToDevice, st));
-  launch_check_disjoint(s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), n_cands, s->flag.as<int>(), st);
+  launch_check_and_interleave(s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), n_cands, fp.carry_cur,
+                              s->out.as<uint64_t>(), s->out_cap, s->flag.as<int>(), st);
   RJ_HIP(hipMemcpyAsync(s->host_flag, s->flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
   RJ_HIP(hipStreamSynchronize(st));
-  uint64_t first_key = 0;
-  RJ_HIP(hipMemcpy(&first_key, s->keys_out.p, sizeof(uint64_t), hipMemcpyDeviceToHost));
-  if (*s->host_flag == 1 && first_key >= fp.carry_cur) {
-    launch_interleave_pairs(s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), n_cands, s->out.as<uint64_t>(),
-                            s->out_cap, st);
-    RJ_HIP(hipStreamSynchronize(st));
+  RJ_HIP(hipGetLastError());
+  if (*s->host_flag == 1) {
     s->result_count = n_cands;
     return RJ_OK;
   }
-  launch_select_sorted(s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), n_cands, fp, st);
+  // general case: cluster-parallel selection
+  //   pmax  = exclusive prefix max of the ends           (scan_a)
+  //   taken = per-cluster sequential walk                 (taken)
+  //   last  = exclusive prefix max of (taken ? i+1 : 0)   (scan_b; cand_begin reused as scratch)
+  //   keep  = taken minus the zero-length rule            (scan_a)
+  //   pos   = exclusive prefix sum of keep                (scan_b)
+  RJ_HIP(s->scan_a.reserve(n_cands * sizeof(uint64_t)));
+  RJ_HIP(s->scan_b.reserve(n_cands * sizeof(uint64_t)));
+  RJ_HIP(s->taken.reserve(n_cands));
+  uint64_t* keys = s->keys_out.as<uint64_t>();
+  uint64_t* vals = s->vals_out.as<uint64_t>();
+  uint64_t* sa = s->scan_a.as<uint64_t>();
+  uint64_t* sb = s->scan_b.as<uint64_t>();
+  uint64_t* scratch = s->cand_begin.as<uint64_t>();  // free again after the sort
+  auto scan_max = [&](uint64_t* in, uint64_t* out) -> hipError_t {
+    size_t bytes = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, bytes, in, out, uint64_t{0}, n_cands, rocprim::maximum<uint64_t>(), st);
+    if (e != hipSuccess) return e;
+    e = s->sort_tmp.reserve(std::max<size_t>(bytes, 16));
+    if (e != hipSuccess) return e;
+    return rocprim::exclusive_scan(s->sort_tmp.p, bytes, in, out, uint64_t{0}, n_cands, rocprim::maximum<uint64_t>(), st);
+  };
+  auto scan_sum = [&](uint64_t* in, uint64_t* out) -> hipError_t {
+    size_t bytes = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, bytes, in, out, uint64_t{0}, n_cands, rocprim::plus<uint64_t>(), st);
+    if (e != hipSuccess) return e;
+    e = s->sort_tmp.reserve(std::max<size_t>(bytes, 16));
+    if (e != hipSuccess) return e;
+    return rocprim::exclusive_scan(s->sort_tmp.p, bytes, in, out, uint64_t{0}, n_cands, rocprim::plus<uint64_t>(), st);
+  };
+  RJ_HIP(scan_max(vals, sa));
+  launch_select_walk(keys, vals, sa, n_cands, fp.carry_cur, s->taken.as<uint8_t>(), st);
+  launch_taken_index(s->taken.as<uint8_t>(), n_cands, scratch, st);
+  RJ_HIP(scan_max(scratch, sb));
+  launch_zero_length_rule(keys, vals, s->taken.as<uint8_t>(), sb, n_cands, fp.carry_prev_end, fp.have_prev, sa, st);
+  RJ_HIP(scan_sum(sa, sb));
+  launch_compact_kept(keys, vals, sa, sb, n_cands, s->out.as<uint64_t>(), s->out_cap, s->counters.as<unsigned long long>(), st);
   RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   RJ_HIP(hipStreamSynchronize(st));
+  RJ_HIP(hipGetLastError());
   s->result_count = s->host_counters[kCntFinal];
   return RJ_OK;
 }
@@ -244,8 +287,16 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       if (lo == sb) RJ_HIP(hipEventRecord(s->ev[1], st));
       if (windows) {
         WindowSet ws{};
-        for (int k = 0; k < kDevMaxWindows; k++) ws.value[k] = D.win_value[k];
-        ws.mask = D.win_mask;
+        bool masked = false;
+        for (int k = 0; k < kDevMaxWindows; k++) {
+          ws.value0[k] = D.win_value0[k];
+          ws.mask0[k] = D.win_mask0[k];
+          ws.value1[k] = D.win_value1[k];
+          ws.mask1[k] = D.win_mask1[k];
+          masked |= D.win_mask0[k] != 0xFFFFFFFFu || (D.win_len > 4 && D.win_mask1[k] != 0xFFFFFFFFu);
+        }
+        ws.masked = masked;
+        ws.len = D.win_len;
         ws.offset = D.win_offset;
         sp.wlo = lo + D.win_offset;
         // a window must fit into the text: w + win_len <= n
@@ -261,13 +312,15 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       vp.n = n;
       vp.hits = s->hits.as<uint64_t>();
       vp.hits_cap = s->hits_cap;
-      vp.cands = s->cands.as<uint64_t>();
+      vp.cand_begin = s->cand_begin.as<uint64_t>();
+      vp.cand_end = s->cand_end.as<uint64_t>();
       vp.cands_cap = s->cands_cap;
       vp.counters = s->counters.as<unsigned long long>();
       launch_verify(vp, D, windows ? 65536 : (hi - lo) / 8 + 1, st);
     }
     FinalizeParams fp{};
-    fp.cands = s->cands.as<uint64_t>();
+    fp.cand_begin = s->cand_begin.as<uint64_t>();
+    fp.cand_end = s->cand_end.as<uint64_t>();
     fp.cands_cap = s->cands_cap;
     fp.hits_cap = s->hits_cap;
     fp.out = s->out.as<uint64_t>();
@@ -296,7 +349,7 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       continue;
     }
     if (s->host_counters[kCntFinal] == ~0ull) {
-      rc = finalize_large(s, n_cands, fp, st);
+      rc = finalize_large(s, n_cands, n + 1, fp, st);
       if (rc != RJ_OK) return rc;
     } else {
       s->result_count = s->host_counters[kCntFinal];

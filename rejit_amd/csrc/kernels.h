@@ -25,9 +25,11 @@ struct ScanParams {
 };
 
 struct WindowSet {
-  uint32_t value[kDevMaxWindows];
-  uint32_t mask;
+  uint32_t value0[kDevMaxWindows], mask0[kDevMaxWindows];
+  uint32_t value1[kDevMaxWindows], mask1[kDevMaxWindows];
   uint32_t offset;
+  uint32_t len;      // 1..8 bytes
+  uint32_t masked;   // some mask byte inside [0,len) is a wildcard / len is not 4 or 8
 };
 
 struct VerifyParams {
@@ -35,13 +37,15 @@ struct VerifyParams {
   uint64_t n;
   const uint64_t* hits;
   uint64_t hits_cap;
-  uint64_t* cands;       // (begin,end) pairs
+  uint64_t* cand_begin;  // candidates, structure of arrays
+  uint64_t* cand_end;
   uint64_t cands_cap;
   unsigned long long* counters;
 };
 
 struct FinalizeParams {
-  const uint64_t* cands;
+  const uint64_t* cand_begin;
+  const uint64_t* cand_end;
   uint64_t cands_cap;
   uint64_t hits_cap;
   uint64_t* out;         // (begin,end) pairs, ordered
@@ -58,12 +62,18 @@ void launch_scan_dense(const ScanParams& a, const DevProgram& P, hipStream_t st)
 void launch_verify(const VerifyParams& a, const DevProgram& P, uint64_t expected_hits, hipStream_t st);
 void launch_match_full(const uint8_t* text, uint64_t n, const DevProgram& P, int* result, hipStream_t st);
 void launch_finalize_small(const FinalizeParams& a, hipStream_t st);
-void launch_split_pairs(const uint64_t* pairs, uint64_t n, uint64_t* keys, uint64_t* vals, hipStream_t st);
-void launch_check_disjoint(const uint64_t* keys, const uint64_t* vals, uint64_t n, int* flag, hipStream_t st);
-void launch_interleave_pairs(const uint64_t* keys, const uint64_t* vals, uint64_t n, uint64_t* out, uint64_t cap,
-                             hipStream_t st);
-void launch_select_sorted(const uint64_t* keys, const uint64_t* vals, uint64_t n, const FinalizeParams& a,
-                          hipStream_t st);
+// writes the sorted candidates as (begin,end) pairs and clears *flag unless they already are a
+// valid result (pairwise disjoint, no empty match, first begin >= carry_cur)
+void launch_check_and_interleave(const uint64_t* keys, const uint64_t* vals, uint64_t n, uint64_t carry_cur,
+                                 uint64_t* out, uint64_t cap, int* flag, hipStream_t st);
+void launch_select_walk(const uint64_t* keys, const uint64_t* vals, const uint64_t* pmax, uint64_t n,
+                        uint64_t carry_cur, uint8_t* taken, hipStream_t st);
+void launch_taken_index(const uint8_t* taken, uint64_t n, uint64_t* idx, hipStream_t st);
+void launch_zero_length_rule(const uint64_t* keys, const uint64_t* vals, const uint8_t* taken,
+                             const uint64_t* last_taken, uint64_t n, uint64_t carry_prev_end, int have_prev,
+                             uint64_t* keep, hipStream_t st);
+void launch_compact_kept(const uint64_t* keys, const uint64_t* vals, const uint64_t* keep, const uint64_t* pos,
+                         uint64_t n, uint64_t* out, uint64_t out_cap, unsigned long long* counters, hipStream_t st);
 
 }  // namespace rejit_amd
 #endif

@@ -61,8 +61,8 @@ __device__ __forceinline__ void wave_append(bool pred, uint64_t mine, uint64_t* 
   }
 }
 
-__device__ __forceinline__ void wave_append_pair(bool pred, uint64_t b, uint64_t e, uint64_t* pairs,
-                                                 uint64_t cap, unsigned long long* counter) {
+__device__ __forceinline__ void wave_append_pair(bool pred, uint64_t b, uint64_t e, uint64_t* begins,
+                                                 uint64_t* ends, uint64_t cap, unsigned long long* counter) {
   const unsigned long long m = __ballot(pred);
   if (m == 0) return;
   const int lane = lane_id();
@@ -73,16 +73,99 @@ __device__ __forceinline__ void wave_append_pair(bool pred, uint64_t b, uint64_t
   if (pred) {
     const unsigned long long idx = base + __popcll(m & ((1ull << lane) - 1ull));
     if (idx < cap) {
-      pairs[2 * idx] = b;
-      pairs[2 * idx + 1] = e;
+      begins[idx] = b;
+      ends[idx] = e;
     }
   }
 }
 
-// 16 B of the lane + the 4 B that follow, guarded against the end of the text (tail chunk).
-__device__ __forceinline__ void load_guarded(const uint8_t* text, uint64_t n, uint64_t at, uint32_t d[5]) {
+// Append the positions of the set bits of `mask16` (bit j <-> position at + j - bias) of every
+// lane, in position order, with ONE atomic for the whole wave: wave prefix sum of the
+// per-lane popcounts, then each lane writes its own run.
+__device__ __forceinline__ void wave_append_bits(uint32_t mask16, uint64_t at, uint64_t bias, uint64_t* list,
+                                                 uint64_t cap, unsigned long long* counter) {
+  const int lane = lane_id();
+  const uint32_t cnt = __popc(mask16);
+  uint32_t inc = cnt;
 #pragma unroll
-  for (int q = 0; q < 5; q++) {
+  for (int o = 1; o < kWave; o <<= 1) {
+    const uint32_t v = __shfl_up(inc, o);
+    if (lane >= o) inc += v;
+  }
+  const uint32_t total = __shfl(inc, kWave - 1);
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(counter, static_cast<unsigned long long>(total));
+  base = __shfl(base, 0);
+  unsigned long long idx = base + inc - cnt;
+  while (mask16) {
+    const int j = __ffs(static_cast<int>(mask16)) - 1;
+    mask16 &= mask16 - 1;
+    if (idx < cap) list[idx] = at + j - bias;
+    idx++;
+  }
+}
+
+// Per-wave staging buffer in LDS for hit offsets.  A single device-wide counter sustains
+// only ~90 atomics/us (MI355X_MICROARCH.md "dequeue"), so appending chunk by chunk costs
+// ~11 ns per chunk-with-hits -- measured: the regexdna patterns with 20-60k hits per pass ran
+// at 0.7-2.3 TB/s instead of 4.8.  Hits are therefore collected per wave in LDS (position
+// order is kept inside a batch) and flushed with ONE atomic per kHitBuf/2.. hits.
+constexpr int kHitBuf = 256;  // entries per wave (2 KiB)
+
+struct WaveHits {
+  uint64_t* slots;      // LDS, kHitBuf entries of this wave
+  uint32_t count;       // wave-uniform
+  uint64_t* list;       // global hit list
+  uint64_t cap;
+  unsigned long long* counter;
+
+  __device__ __forceinline__ void flush() {
+    if (count == 0) return;
+    const int lane = lane_id();
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(counter, static_cast<unsigned long long>(count));
+    base = __shfl(base, 0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t i = lane; i < count; i += kWave) {
+      const unsigned long long idx = base + i;
+      if (idx < cap) list[idx] = slots[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    count = 0;
+  }
+
+  // bit j of mask16 <-> offset at + j - bias; appended in position order
+  __device__ __forceinline__ void push_bits(uint32_t mask16, uint64_t at, uint64_t bias) {
+    const int lane = lane_id();
+    const uint32_t cnt = __popc(mask16);
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const uint32_t v = __shfl_up(inc, o);
+      if (lane >= o) inc += v;
+    }
+    const uint32_t total = __shfl(inc, kWave - 1);
+    if (total == 0) return;
+    if (count + total > kHitBuf) flush();
+    if (total > kHitBuf) {  // a very dense chunk: straight to the global list
+      wave_append_bits(mask16, at, bias, list, cap, counter);
+      return;
+    }
+    uint32_t idx = count + inc - cnt;
+    while (mask16) {
+      const int j = __ffs(static_cast<int>(mask16)) - 1;
+      mask16 &= mask16 - 1;
+      slots[idx++] = at + j - bias;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    count += total;
+  }
+};
+
+// 16 B of the lane + the 8 B that follow, guarded against the end of the text (tail chunk).
+__device__ __forceinline__ void load_guarded(const uint8_t* text, uint64_t n, uint64_t at, uint32_t d[6]) {
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
     uint32_t v = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -98,67 +181,135 @@ __device__ __forceinline__ void load_guarded(const uint8_t* text, uint64_t n, ui
 // ---------------------------------------------------------------------------------------
 // Fast-forward window scan.
 //
-// Window position w is a hit iff (load32(text + w) & mask) == value[k] for some k < K; the
-// candidate start is s = w - offset and must lie in [sb, se).  Scanned w range: [wlo, whi).
-template <int K, bool MASKED>
+// Window position w is a hit iff for some k < K
+//     (load32(text + w) & mask0[k]) == value0[k]  and, when TWO,
+//     (load32(text + w + 4) & mask1[k]) == value1[k];
+// the candidate start is s = w - offset.  Scanned w range: [wlo, whi).
+// One chunk: d[0..3] = the lane's 16 bytes, d[4..5] = the 8 bytes that follow.
+template <int K, bool TWO, bool MASKED>
+__device__ __forceinline__ void windows_chunk(const uint32_t (&d)[6], uint64_t at, const ScanParams& a,
+                                              const WindowSet& ws, WaveHits& hits) {
+  constexpr int NX = TWO ? 20 : 16;  // windows needed: 16 positions (+4 for the second dword)
+  // the unaligned 4-byte windows of this lane: x[j] = bytes [at+j, at+j+4)
+  uint32_t x[NX];
+#pragma unroll
+  for (int q = 0; q < NX / 4; q++) {
+    x[4 * q] = d[q];
+    x[4 * q + 1] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1);
+    x[4 * q + 2] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2);
+    x[4 * q + 3] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 3);
+  }
+  // Streaming test, VALU only.  For window k at position j
+  //     t = ((x[j] ^ value0[k]) & mask0[k]) | ((x[j+4] ^ value1[k]) & mask1[k])
+  // is zero iff the window matches; the minimum over all (j,k) is zero iff the lane has a
+  // hit.  (The obvious form -- v_cmp per dword and s_and/s_or of the lane masks -- put ~130
+  // scalar instructions per chunk on the CU's single scalar unit and ran at 2.9 TB/s.)
+  uint32_t acc = 0xFFFFFFFFu;
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      uint32_t t = x[j] ^ ws.value0[k];
+      if (MASKED) t &= ws.mask0[k];
+      if (TWO) {
+        uint32_t u = x[j + 4] ^ ws.value1[k];
+        t = MASKED ? ((u & ws.mask1[k]) | t) : (u | t);  // v_and_or_b32
+      }
+      acc = acc < t ? acc : t;
+    }
+  }
+  const bool any = acc == 0;
+  if (__ballot(any) == 0) return;  // wave-uniform: the common case leaves here
+
+  // rare path: per-lane 16-bit hit mask, staged in the wave's LDS buffer
+  uint32_t hm = 0;
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    bool hit = false;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      bool h = ((MASKED ? (x[j] & ws.mask0[k]) : x[j]) == ws.value0[k]);
+      if (TWO) h = h && ((MASKED ? (x[j + 4] & ws.mask1[k]) : x[j + 4]) == ws.value1[k]);
+      hit |= h;
+    }
+    const uint64_t w = at + j;
+    hit = hit && w >= a.wlo && w < a.whi;
+    hm |= static_cast<uint32_t>(hit) << j;
+  }
+  hits.push_bits(hm, at, ws.offset);
+}
+
+template <bool TWO>
+__device__ __forceinline__ void load_chunk(const uint8_t* text, uint64_t at, uint32_t (&d)[6]) {
+  const uint4 v = *reinterpret_cast<const uint4*>(text + at);
+  d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  if (TWO) {  // the neighbour's first 8 bytes (same cache lines: L1 hits, no extra HBM traffic)
+    const uint2 h = *reinterpret_cast<const uint2*>(text + at + 16);
+    d[4] = h.x; d[5] = h.y;
+  } else {
+    d[4] = *reinterpret_cast<const uint32_t*>(text + at + 16);
+    d[5] = 0;
+  }
+}
+
+template <int K, bool TWO, bool MASKED>
 __global__ __launch_bounds__(256) void scan_windows(ScanParams a, WindowSet ws) {
+  __shared__ uint64_t hit_slots[4 * kHitBuf];
+  WaveHits hits{hit_slots + (threadIdx.x >> 6) * kHitBuf, 0u, a.hits, a.hits_cap, a.counters + kCntHits};
   const int lane = lane_id();
-  const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  // wave index as a scalar, so that chunk addresses and loop branches are wave-uniform
+  const uint64_t wave = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6));
   const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
   const uint64_t first_chunk = a.wlo / kChunk;
   const uint64_t end_chunk = (a.whi + kChunk - 1) / kChunk;
+  // chunks [first_chunk, fast_end) can be loaded without guards (16 B + 8 B halo stay < n)
+  uint64_t fast_end = a.n >= kChunk + 8 ? (a.n - 8) / kChunk : 0;
+  if (fast_end > end_chunk) fast_end = end_chunk;
+  if (fast_end < first_chunk) fast_end = first_chunk;
 
-  for (uint64_t c = first_chunk + wave; c < end_chunk; c += n_waves) {
-    const uint64_t base = c * kChunk;
-    const uint64_t at = base + static_cast<uint64_t>(lane) * 16;
-    uint32_t d[5];
-    if (base + kChunk + 4 <= a.n) {
-      const uint4 v = *reinterpret_cast<const uint4*>(a.text + at);
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-      d[4] = *reinterpret_cast<const uint32_t*>(a.text + at + 16);  // neighbour's first dword (L1 hit)
-    } else {
-      load_guarded(a.text, a.n, at, d);
-    }
-    // the 16 unaligned 4-byte windows of this lane
-    uint32_t x[16];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      x[4 * q] = d[q];
-      x[4 * q + 1] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1);
-      x[4 * q + 2] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2);
-      x[4 * q + 3] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 3);
-    }
-    bool any = false;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const uint32_t v = MASKED ? (x[j] & ws.mask) : x[j];
-#pragma unroll
-      for (int k = 0; k < K; k++) any |= (v == ws.value[k]);
-    }
-    if (__ballot(any) == 0) continue;  // wave-uniform: the common case leaves here
-
-    // rare path: per-lane 16-bit hit mask, then append the hit offsets in position order
-    uint32_t hm = 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const uint32_t v = MASKED ? (x[j] & ws.mask) : x[j];
-      bool hit = false;
-#pragma unroll
-      for (int k = 0; k < K; k++) hit |= (v == ws.value[k]);
-      const uint64_t w = at + j;
-      hit = hit && w >= a.wlo && w < a.whi;
-      hm |= static_cast<uint32_t>(hit) << j;
-    }
-#pragma unroll 1
-    for (int j = 0; j < 16; j++) {
-      wave_append((hm >> j) & 1u, at + j - ws.offset, a.hits, a.hits_cap, a.counters + kCntHits);
+  // Software-pipelined streaming loop, three register buffers deep: while chunk c is compared
+  // the loads of chunks c + stride and c + 2*stride are in flight (3 KiB per wave, ~96 KiB
+  // per CU at 8 waves/SIMD).  Prefetches are unconditional -- past the end they re-read the
+  // wave's last chunk -- so the number of loads in flight is static and the compiler can
+  // wait for exactly the buffer it needs (vmcnt(4)).
+  if (first_chunk + wave < fast_end) {
+    const uint64_t lane_off = static_cast<uint64_t>(lane) * 16;
+    uint64_t last = first_chunk + wave;  // last in-range chunk of this wave (clamp target)
+    last += (fast_end - 1 - last) / n_waves * n_waves;
+    uint32_t b0[6], b1[6], b2[6];
+    uint64_t c = first_chunk + wave;
+    auto clamp = [&](uint64_t x) { return x < fast_end ? x : last; };
+    load_chunk<TWO>(a.text, clamp(c) * kChunk + lane_off, b0);
+    load_chunk<TWO>(a.text, clamp(c + n_waves) * kChunk + lane_off, b1);
+    load_chunk<TWO>(a.text, clamp(c + 2 * n_waves) * kChunk + lane_off, b2);
+    for (; c < fast_end; c += 3 * n_waves) {
+      windows_chunk<K, TWO, MASKED>(b0, c * kChunk + lane_off, a, ws, hits);
+      load_chunk<TWO>(a.text, clamp(c + 3 * n_waves) * kChunk + lane_off, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + n_waves < fast_end) windows_chunk<K, TWO, MASKED>(b1, (c + n_waves) * kChunk + lane_off, a, ws, hits);
+      load_chunk<TWO>(a.text, clamp(c + 4 * n_waves) * kChunk + lane_off, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 2 * n_waves < fast_end) windows_chunk<K, TWO, MASKED>(b2, (c + 2 * n_waves) * kChunk + lane_off, a, ws, hits);
+      load_chunk<TWO>(a.text, clamp(c + 5 * n_waves) * kChunk + lane_off, b2);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+  // tail: the last chunk(s) touch the end of the text and use guarded byte loads
+  for (uint64_t t = fast_end + wave; t < end_chunk; t += n_waves) {
+    const uint64_t at = t * kChunk + static_cast<uint64_t>(lane) * 16;
+    uint32_t d[6];
+    load_guarded(a.text, a.n, at, d);
+    windows_chunk<K, TWO, MASKED>(d, at, a, ws, hits);
+  }
+  hits.flush();
 }
 
 // ---------------------------------------------------------------------------------------
 // Dense scan: every position s in [sb, se) that can start a match goes to the hit list.
 __global__ __launch_bounds__(256) void scan_dense(ScanParams a, DevProgram P) {
+  __shared__ uint64_t hit_slots[4 * kHitBuf];
+  WaveHits hits{hit_slots + (threadIdx.x >> 6) * kHitBuf, 0u, a.hits, a.hits_cap, a.counters + kCntHits};
   __shared__ uint32_t fb[8];
   if (threadIdx.x < 8) fb[threadIdx.x] = P.first_bytes[threadIdx.x];
   __syncthreads();
@@ -172,11 +323,10 @@ __global__ __launch_bounds__(256) void scan_dense(ScanParams a, DevProgram P) {
   for (uint64_t c = first_chunk + wave; c < end_chunk; c += n_waves) {
     const uint64_t base = c * kChunk;
     const uint64_t at = base + static_cast<uint64_t>(lane) * 16;
-    uint32_t d[5];
-    if (base + kChunk + 4 <= a.n) {
+    uint32_t d[6];
+    if (base + kChunk <= a.n) {
       const uint4 v = *reinterpret_cast<const uint4*>(a.text + at);
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-      d[4] = *reinterpret_cast<const uint32_t*>(a.text + at + 16);
     } else {
       load_guarded(a.text, a.n, at, d);
     }
@@ -202,11 +352,9 @@ __global__ __launch_bounds__(256) void scan_dense(ScanParams a, DevProgram P) {
       prev = cur;
     }
     if (__ballot(cand != 0) == 0) continue;
-#pragma unroll 1
-    for (int j = 0; j < 16; j++) {
-      wave_append((cand >> j) & 1u, at + j, a.hits, a.hits_cap, a.counters + kCntHits);
-    }
+    hits.push_bits(cand, at, 0);
   }
+  hits.flush();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -229,7 +377,7 @@ __global__ __launch_bounds__(256) void verify_lane(VerifyParams a, DevProgram P)
       s = a.hits[i];
       found = rj_lane_longest<NQ>(P, a.text, a.n, s, &e);
     }
-    wave_append_pair(found, s, e, a.cands, a.cands_cap, a.counters + kCntCands);
+    wave_append_pair(found, s, e, a.cand_begin, a.cand_end, a.cands_cap, a.counters + kCntCands);
   }
 }
 
@@ -342,8 +490,8 @@ __global__ __launch_bounds__(256) void verify_wave(VerifyParams a, DevProgram P)
     if (found && lane_id() == 0) {
       const unsigned long long idx = atomicAdd(a.counters + kCntCands, 1ull);
       if (idx < a.cands_cap) {
-        a.cands[2 * idx] = s;
-        a.cands[2 * idx + 1] = e;
+        a.cand_begin[idx] = s;
+        a.cand_end[idx] = e;
       }
     }
   }
@@ -380,8 +528,8 @@ __global__ __launch_bounds__(1024) void finalize_small(FinalizeParams a) {
   int m = 1;
   while (m < n) m <<= 1;
   for (int i = threadIdx.x; i < m; i += blockDim.x) {
-    key[i] = i < n ? a.cands[2 * i] : ~0ull;
-    val[i] = i < n ? a.cands[2 * i + 1] : ~0ull;
+    key[i] = i < n ? a.cand_begin[i] : ~0ull;
+    val[i] = i < n ? a.cand_end[i] : ~0ull;
   }
   if (threadIdx.x == 0) all_disjoint = 1;
   __syncthreads();
@@ -441,49 +589,86 @@ __global__ __launch_bounds__(1024) void finalize_small(FinalizeParams a) {
   }
 }
 
-// Selection over a sorted candidate list of any size (large path), one lane.
-// TODO(round 2): cluster-parallel version (prefix-max of ends -> independent clusters).
-__global__ void select_sorted(const uint64_t* keys, const uint64_t* vals, uint64_t n, FinalizeParams a) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  RjSelectState st;
-  st.cur = a.carry_cur;
-  st.prev_end = a.carry_prev_end;
-  st.have_prev = a.have_prev != 0;
-  unsigned long long out_n = 0;
-  for (uint64_t i = 0; i < n; i++) {
-    if (i > 0 && keys[i] == keys[i - 1]) continue;
-    bool taken;
-    if (rj_select_step(&st, keys[i], vals[i], &taken)) {
-      if (out_n < a.out_cap) {
-        a.out[2 * out_n] = keys[i];
-        a.out[2 * out_n + 1] = vals[i];
-      }
-      out_n++;
+// Selection over a sorted candidate list of any size (large path), cluster-parallel.
+//
+// With M[i] = max end of the candidates before i (exclusive prefix max, computed by the
+// caller) candidate i starts a CLUSTER iff begin[i] >= max(M[i], carry_cur): nothing before it
+// can overlap it, so whatever was selected earlier, i is selected.  Clusters are independent;
+// the thread of a cluster head walks its cluster with the sequential rule.  Clusters are a
+// handful of candidates in practice (overlapping or adjacent-empty matches).
+__global__ void select_walk(const uint64_t* keys, const uint64_t* vals, const uint64_t* pmax, uint64_t n,
+                            uint64_t carry_cur, uint8_t* taken) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t floor_i = pmax[i] > carry_cur ? pmax[i] : carry_cur;
+  const bool head = keys[i] >= floor_i;
+  if (!head && i != 0) return;  // index 0 also walks the candidates hidden by the carry
+  uint64_t cur = i == 0 ? carry_cur : 0;
+  for (uint64_t j = i; j < n; j++) {
+    if (j > i) {
+      const uint64_t fl = pmax[j] > carry_cur ? pmax[j] : carry_cur;
+      if (keys[j] >= fl) break;  // next cluster: its own thread takes over
+    }
+    const uint64_t b = keys[j], e = vals[j];
+    bool t = b >= cur && !(j > 0 && keys[j - 1] == b);  // duplicates of a begin: keep the first
+    if (t) cur = e > b ? e : b + 1;
+    taken[j] = t ? 1 : 0;
+  }
+}
+
+// idx[i] = i + 1 if candidate i was taken else 0 (input of the "last taken before i" max-scan)
+__global__ void taken_index(const uint8_t* taken, uint64_t n, uint64_t* idx) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) idx[i] = taken[i] ? i + 1 : 0;
+}
+
+// zero-length rule (reference src/codegen.cc:65-73): a taken empty match that begins where the
+// previously taken match ended is not reported.  keep[i] in {0,1} as uint64 for the sum-scan.
+__global__ void apply_zero_length_rule(const uint64_t* keys, const uint64_t* vals, const uint8_t* taken,
+                                       const uint64_t* last_taken, uint64_t n, uint64_t carry_prev_end,
+                                       int have_prev, uint64_t* keep) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool k = taken[i] != 0;
+  if (k && keys[i] == vals[i]) {
+    const uint64_t lt = last_taken[i];  // 1-based index of the last taken candidate before i
+    if (lt > 0) {
+      if (vals[lt - 1] == keys[i]) k = false;
+    } else if (have_prev && carry_prev_end == keys[i]) {
+      k = false;
     }
   }
-  a.counters[kCntFinal] = out_n;
+  keep[i] = k ? 1 : 0;
 }
 
-// Parallel check used by the large path: is the sorted list already a valid result?
-__global__ void check_disjoint(const uint64_t* keys, const uint64_t* vals, uint64_t n, int* flag) {
+__global__ void compact_kept(const uint64_t* keys, const uint64_t* vals, const uint64_t* keep, const uint64_t* pos,
+                             uint64_t n, uint64_t* out, uint64_t out_cap, unsigned long long* counters) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const bool ok = vals[i] > keys[i] && (i == 0 || keys[i] >= vals[i - 1]);
+  if (keep[i]) {
+    const uint64_t o = pos[i];
+    if (o < out_cap) {
+      out[2 * o] = keys[i];
+      out[2 * o + 1] = vals[i];
+    }
+  }
+  if (i == n - 1) counters[kCntFinal] = pos[i] + keep[i];
+}
+
+// Large path, common case in one kernel: emit the sorted candidates as pairs and find out
+// whether they already are the result (pairwise disjoint, no empty match, nothing hidden by
+// the carry); *flag is cleared otherwise and the cluster-parallel selection runs.
+__global__ void check_and_interleave(const uint64_t* keys, const uint64_t* vals, uint64_t n, uint64_t carry_cur,
+                                     uint64_t* out, uint64_t cap, int* flag) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t b = keys[i], e = vals[i];
+  const bool ok = e > b && (i == 0 ? b >= carry_cur : b >= vals[i - 1]);
   if (!ok) *flag = 0;
-}
-
-__global__ void interleave_pairs(const uint64_t* keys, const uint64_t* vals, uint64_t n, uint64_t* out, uint64_t cap) {
-  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n || i >= cap) return;
-  out[2 * i] = keys[i];
-  out[2 * i + 1] = vals[i];
-}
-
-__global__ void split_pairs(const uint64_t* pairs, uint64_t n, uint64_t* keys, uint64_t* vals) {
-  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  keys[i] = pairs[2 * i];
-  vals[i] = pairs[2 * i + 1];
+  if (i < cap) {
+    out[2 * i] = b;
+    out[2 * i + 1] = e;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -499,26 +684,29 @@ int grid_for_scan(uint64_t chunks) {
 }
 }  // namespace
 
-template <bool MASKED>
+template <bool TWO, bool MASKED>
 static void launch_windows_k(int k, const ScanParams& a, const WindowSet& ws, int grid, hipStream_t st) {
-  switch (k) {
-    case 1: hipLaunchKernelGGL((scan_windows<1, MASKED>), dim3(grid), dim3(256), 0, st, a, ws); break;
-    case 2: hipLaunchKernelGGL((scan_windows<2, MASKED>), dim3(grid), dim3(256), 0, st, a, ws); break;
-    case 3: hipLaunchKernelGGL((scan_windows<3, MASKED>), dim3(grid), dim3(256), 0, st, a, ws); break;
-    case 4: hipLaunchKernelGGL((scan_windows<4, MASKED>), dim3(grid), dim3(256), 0, st, a, ws); break;
-    case 5: hipLaunchKernelGGL((scan_windows<5, MASKED>), dim3(grid), dim3(256), 0, st, a, ws); break;
-    case 6: hipLaunchKernelGGL((scan_windows<6, MASKED>), dim3(grid), dim3(256), 0, st, a, ws); break;
-    case 7: hipLaunchKernelGGL((scan_windows<7, MASKED>), dim3(grid), dim3(256), 0, st, a, ws); break;
-    default: hipLaunchKernelGGL((scan_windows<8, MASKED>), dim3(grid), dim3(256), 0, st, a, ws); break;
-  }
+  // K is rounded up to an instantiated size; the host pads the window set with copies
+  if (k <= 1) hipLaunchKernelGGL((scan_windows<1, TWO, MASKED>), dim3(grid), dim3(256), 0, st, a, ws);
+  else if (k == 2) hipLaunchKernelGGL((scan_windows<2, TWO, MASKED>), dim3(grid), dim3(256), 0, st, a, ws);
+  else if (k == 3) hipLaunchKernelGGL((scan_windows<3, TWO, MASKED>), dim3(grid), dim3(256), 0, st, a, ws);
+  else if (k == 4) hipLaunchKernelGGL((scan_windows<4, TWO, MASKED>), dim3(grid), dim3(256), 0, st, a, ws);
+  else if (k <= 6) hipLaunchKernelGGL((scan_windows<6, TWO, MASKED>), dim3(grid), dim3(256), 0, st, a, ws);
+  else hipLaunchKernelGGL((scan_windows<8, TWO, MASKED>), dim3(grid), dim3(256), 0, st, a, ws);
 }
 
 void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows, hipStream_t st) {
   if (a.whi <= a.wlo) return;
   const uint64_t chunks = (a.whi + kChunk - 1) / kChunk - a.wlo / kChunk;
   const int grid = grid_for_scan(chunks);
-  if (ws.mask == 0xFFFFFFFFu) launch_windows_k<false>(n_windows, a, ws, grid, st);
-  else launch_windows_k<true>(n_windows, a, ws, grid, st);
+  const bool two = ws.len > 4;
+  if (two) {
+    if (ws.masked) launch_windows_k<true, true>(n_windows, a, ws, grid, st);
+    else launch_windows_k<true, false>(n_windows, a, ws, grid, st);
+  } else {
+    if (ws.masked) launch_windows_k<false, true>(n_windows, a, ws, grid, st);
+    else launch_windows_k<false, false>(n_windows, a, ws, grid, st);
+  }
 }
 
 void launch_scan_dense(const ScanParams& a, const DevProgram& P, hipStream_t st) {
@@ -557,25 +745,35 @@ void launch_finalize_small(const FinalizeParams& a, hipStream_t st) {
   hipLaunchKernelGGL(finalize_small, dim3(1), dim3(1024), 0, st, a);
 }
 
-void launch_split_pairs(const uint64_t* pairs, uint64_t n, uint64_t* keys, uint64_t* vals, hipStream_t st) {
+void launch_check_and_interleave(const uint64_t* keys, const uint64_t* vals, uint64_t n, uint64_t carry_cur,
+                                 uint64_t* out, uint64_t cap, int* flag, hipStream_t st) {
   if (n == 0) return;
-  hipLaunchKernelGGL(split_pairs, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, pairs, n, keys, vals);
+  hipLaunchKernelGGL(check_and_interleave, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, keys, vals, n,
+                     carry_cur, out, cap, flag);
 }
 
-void launch_check_disjoint(const uint64_t* keys, const uint64_t* vals, uint64_t n, int* flag, hipStream_t st) {
-  if (n == 0) return;
-  hipLaunchKernelGGL(check_disjoint, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, keys, vals, n, flag);
+static unsigned blocks_for(uint64_t n) { return static_cast<unsigned>((n + 255) / 256); }
+
+void launch_select_walk(const uint64_t* keys, const uint64_t* vals, const uint64_t* pmax, uint64_t n,
+                        uint64_t carry_cur, uint8_t* taken, hipStream_t st) {
+  hipLaunchKernelGGL(select_walk, dim3(blocks_for(n)), dim3(256), 0, st, keys, vals, pmax, n, carry_cur, taken);
 }
 
-void launch_interleave_pairs(const uint64_t* keys, const uint64_t* vals, uint64_t n, uint64_t* out, uint64_t cap,
-                             hipStream_t st) {
-  if (n == 0) return;
-  hipLaunchKernelGGL(interleave_pairs, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, keys, vals, n, out, cap);
+void launch_taken_index(const uint8_t* taken, uint64_t n, uint64_t* idx, hipStream_t st) {
+  hipLaunchKernelGGL(taken_index, dim3(blocks_for(n)), dim3(256), 0, st, taken, n, idx);
 }
 
-void launch_select_sorted(const uint64_t* keys, const uint64_t* vals, uint64_t n, const FinalizeParams& a,
-                          hipStream_t st) {
-  hipLaunchKernelGGL(select_sorted, dim3(1), dim3(64), 0, st, keys, vals, n, a);
+void launch_zero_length_rule(const uint64_t* keys, const uint64_t* vals, const uint8_t* taken,
+                             const uint64_t* last_taken, uint64_t n, uint64_t carry_prev_end, int have_prev,
+                             uint64_t* keep, hipStream_t st) {
+  hipLaunchKernelGGL(apply_zero_length_rule, dim3(blocks_for(n)), dim3(256), 0, st, keys, vals, taken, last_taken, n,
+                     carry_prev_end, have_prev, keep);
+}
+
+void launch_compact_kept(const uint64_t* keys, const uint64_t* vals, const uint64_t* keep, const uint64_t* pos,
+                         uint64_t n, uint64_t* out, uint64_t out_cap, unsigned long long* counters, hipStream_t st) {
+  hipLaunchKernelGGL(compact_kept, dim3(blocks_for(n)), dim3(256), 0, st, keys, vals, keep, pos, n, out, out_cap,
+                     counters);
 }
 
 }  // namespace rejit_amd

@@ -391,56 +391,130 @@ class Automaton {
 
   // Scan plan (the GPU's answer to FF_finder, src/codegen.cc:327-557).  The reference
   // picks literal NODES of the tree and needs a backward NFA pass when they are not at
-  // the start of the match.  Here: choose a byte offset d such that the set of 4-byte
-  // strings a match can contain at [d, d+4) is small (<= kMaxWindows); a candidate start
-  // is any s with one of those strings at s + d.  Every candidate is then verified by
-  // the forward automaton from s, so the window set only has to be a necessary condition.
+  // the start of the match.  Here: choose a byte offset d such that the set of up-to-8-byte
+  // strings a match can contain at [d, d+len) is small; strings that differ in one position
+  // (a class position) are merged into one window with a wildcard byte.  A candidate start
+  // is any s with one of the <= kMaxWindows windows at s + d.  Every candidate is then
+  // verified by the forward automaton from s, so the windows only have to be a necessary
+  // condition.
+  struct Pattern {
+    uint8_t byte[8];
+    bool wild[8];
+  };
+
+  static int distance(const Pattern& a, const Pattern& b, int len) {
+    int d = 0;
+    for (int k = 0; k < len; k++)
+      if (a.wild[k] != b.wild[k] || (!a.wild[k] && a.byte[k] != b.byte[k])) d++;
+    return d;
+  }
+
+  static int fixed_after_merge(const Pattern& a, const Pattern& b, int len) {
+    int fixed = 0;
+    for (int k = 0; k < len; k++)
+      if (!a.wild[k] && !b.wild[k] && a.byte[k] == b.byte[k]) fixed++;
+    return fixed;
+  }
+
+  // merge patterns that differ in few positions (wildcarding those positions) until at
+  // most `target` remain; returns the number of wildcards introduced, or -1
+  static int merge_patterns(std::vector<Pattern>* ps, int len, size_t target) {
+    int wilds = 0;
+    // distance-1 merges are always worth it (one class position)
+    for (int max_dist = 1; max_dist <= 2; max_dist++) {
+      bool merged = true;
+      while (merged && (max_dist == 1 || ps->size() > target)) {
+        merged = false;
+        for (size_t i = 0; i < ps->size() && !merged; i++)
+          for (size_t j = i + 1; j < ps->size() && !merged; j++) {
+            int dist = distance((*ps)[i], (*ps)[j], len);
+            if (dist == 0) {
+              ps->erase(ps->begin() + static_cast<long>(j));
+              merged = true;
+            } else if (dist <= max_dist && fixed_after_merge((*ps)[i], (*ps)[j], len) >= std::max(1, len - 2)) {
+              for (int k = 0; k < len; k++)
+                if ((*ps)[i].wild[k] != (*ps)[j].wild[k] || (*ps)[i].byte[k] != (*ps)[j].byte[k]) {
+                  if (!(*ps)[i].wild[k]) wilds++;
+                  (*ps)[i].wild[k] = true;
+                  (*ps)[i].byte[k] = 0;
+                }
+              ps->erase(ps->begin() + static_cast<long>(j));
+              merged = true;
+            }
+          }
+      }
+    }
+    return ps->size() <= target ? wilds : -1;
+  }
+
   void plan(const Bits& first_any) {
     p_->mode = ScanMode::Dense;
     p_->windows.clear();
     if (p_->any_nullable || p_->min_len == 0 || p_->min_len == Program::kUnboundedLen) return;
-    const int wl = static_cast<int>(std::min<uint64_t>(4, p_->min_len));
-    const uint64_t max_d = std::min<uint64_t>(p_->min_len - static_cast<uint64_t>(wl), 56);
-    std::vector<std::string> best;
+    const int wl = static_cast<int>(std::min<uint64_t>(8, p_->min_len));
+    const uint64_t max_d = std::min<uint64_t>(p_->min_len - static_cast<uint64_t>(wl), 48);
+    std::vector<Pattern> best;
+    int best_fixed = -1;  // exact (non-wildcard) bytes of the weakest window
     uint64_t best_d = 0;
     Bits level = first_any;
     for (uint64_t d = 0; d <= max_d; d++) {
-      std::set<std::string> found;
-      std::string cur;
+      std::vector<Pattern> ps;
+      Pattern cur{};
       bool overflow = false;
-      enumerate(level, wl, &cur, &found, &overflow);
-      if (!overflow && !found.empty() && (best.empty() || found.size() < best.size())) {
-        best.assign(found.begin(), found.end());
-        best_d = d;
-        if (best.size() == 1) break;
+      enumerate(level, 0, wl, &cur, &ps, &overflow);
+      if (!overflow && !ps.empty()) {
+        if (merge_patterns(&ps, wl, kMaxWindows) >= 0) {
+          int weakest = wl;
+          for (const Pattern& pt : ps) {
+            int fixed = 0;
+            for (int k = 0; k < wl; k++) fixed += !pt.wild[k];
+            weakest = std::min(weakest, fixed);
+          }
+          // prefer: more exact bytes in the weakest window, then fewer windows, then smaller d
+          bool better = best.empty() || weakest > best_fixed || (weakest == best_fixed && ps.size() < best.size());
+          if (weakest >= 1 && better) {
+            best = ps;
+            best_fixed = weakest;
+            best_d = d;
+          }
+        }
       }
       level = step_any(level);
       if (!level.any()) break;
     }
     if (best.empty()) return;
     p_->mode = ScanMode::Windows;
-    for (const std::string& s : best) {
-      FFWindow w;
+    for (const Pattern& pt : best) {
+      FFWindow w{};
       w.offset = static_cast<uint32_t>(best_d);
-      w.value = 0;
-      w.mask = 0;
+      w.len = static_cast<uint32_t>(wl);
       for (int k = 0; k < wl; k++) {
-        w.value |= static_cast<uint32_t>(static_cast<uint8_t>(s[static_cast<size_t>(k)])) << (8 * k);
-        w.mask |= 0xFFu << (8 * k);
+        if (pt.wild[k]) continue;
+        if (k < 4) {
+          w.value0 |= static_cast<uint32_t>(pt.byte[k]) << (8 * k);
+          w.mask0 |= 0xFFu << (8 * k);
+        } else {
+          w.value1 |= static_cast<uint32_t>(pt.byte[k]) << (8 * (k - 4));
+          w.mask1 |= 0xFFu << (8 * (k - 4));
+        }
       }
       p_->windows.push_back(w);
     }
   }
 
-  void enumerate(const Bits& level, int remaining, std::string* cur, std::set<std::string>* found, bool* overflow) {
+  // all byte patterns of `remaining` more positions readable from position set `level`
+  // (capped); a depth with more than 16 possible byte values becomes a wildcard
+  static constexpr size_t kMaxEnumerated = 256;
+
+  void enumerate(const Bits& level, int depth, int len, Pattern* cur, std::vector<Pattern>* found, bool* overflow) {
     if (*overflow) return;
-    if (remaining == 0) {
-      found->insert(*cur);
-      if (found->size() > static_cast<size_t>(kMaxWindows)) *overflow = true;
+    if (depth == len) {
+      found->push_back(*cur);
+      if (found->size() > kMaxEnumerated) *overflow = true;
       return;
     }
-    int live = 0;
-    for (int b = 0; b < 256 && !*overflow; b++) {
+    std::vector<std::pair<int, Bits>> branches;
+    for (int b = 0; b < 256; b++) {
       const uint32_t* row = &p_->cls[static_cast<size_t>(b) * W_];
       Bits hit(W_);
       bool any = false;
@@ -448,21 +522,25 @@ class Automaton {
         hit.w[static_cast<size_t>(k)] = level.w[static_cast<size_t>(k)] & row[k];
         any |= hit.w[static_cast<size_t>(k)] != 0;
       }
-      if (!any) continue;
-      if (++live > kMaxWindows) {  // more byte values than windows at this depth
-        *overflow = true;
-        return;
-      }
-      cur->push_back(static_cast<char>(b));
-      Bits next = remaining > 1 ? step_any(hit) : hit;
-      if (remaining > 1 && !next.any()) {
-        // a match cannot be shorter than d + wl, so every path continues; an empty
-        // continuation can only come from the context over-approximation -- drop it
-        cur->pop_back();
-        continue;
-      }
-      enumerate(next, remaining - 1, cur, found, overflow);
-      cur->pop_back();
+      if (any) branches.emplace_back(b, std::move(hit));
+    }
+    if (branches.size() > 16) {  // a wide class ('.', [a-z], ...): do not split on it
+      cur->byte[depth] = 0;
+      cur->wild[depth] = true;
+      Bits next = depth + 1 < len ? step_any(level) : level;
+      if (depth + 1 < len && !next.any()) return;
+      enumerate(next, depth + 1, len, cur, found, overflow);
+      return;
+    }
+    for (auto& br : branches) {
+      if (*overflow) return;
+      cur->byte[depth] = static_cast<uint8_t>(br.first);
+      cur->wild[depth] = false;
+      Bits next = depth + 1 < len ? step_any(br.second) : br.second;
+      // a match cannot be shorter than d + len, so every real path continues; an empty
+      // continuation can only come from the context over-approximation -- drop it
+      if (depth + 1 < len && !next.any()) continue;
+      enumerate(next, depth + 1, len, cur, found, overflow);
     }
   }
 

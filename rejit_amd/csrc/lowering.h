@@ -107,10 +107,15 @@ constexpr int kNumCtx = 4;
 
 constexpr int kMaxPositions = 8192;
 
-struct FFWindow {      // candidate start s  <=>  (load32(text + s + offset) & mask) == value
+// candidate start s  <=>  for some window:
+//   (load32(text + s + offset) & mask0) == value0  &&  (load32(text + s + offset + 4) & mask1) == value1
+// A window covers `len` (1..8) pattern bytes; a zero mask byte is a wildcard (a class
+// position, or a byte past `len`).
+struct FFWindow {
   uint32_t offset;
-  uint32_t value;
-  uint32_t mask;
+  uint32_t len;
+  uint32_t value0, mask0;
+  uint32_t value1, mask1;
 };
 
 enum class ScanMode {
@@ -142,7 +147,6 @@ struct Program {
   // fast-forward plan
   ScanMode mode = ScanMode::Dense;
   std::vector<FFWindow> windows;
-  bool windows_exact = false;            // a window hit IS a match of length min_len (pure literal <= 4.. no)
   std::string literal;                   // non-empty: the whole pattern is this literal
 };
 

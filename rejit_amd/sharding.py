@@ -1,0 +1,137 @@
+"""Sharding one text across ranks (one process per GPU, torch.distributed over RCCL/xGMI).
+
+The reference has no text-chunk parallelism at all (one sequential pass per MatchAll,
+src/x64/codegen-x64.cc:535-581); its samples only fan whole patterns / whole files over
+threads (sample/regexdna-multithread.cc:65-78, sample/jrep.cc:408-493).  Here one buffer is
+cut into contiguous byte ranges:
+
+  * rank r OWNS the match begins in [lo_r, hi_r); it sees the text [lo_r - left, hi_r + right)
+    where `right` = max match length - 1 (the automaton may read past hi_r) and `left` >= 1
+    (the start-of-line context needs one byte before lo_r);
+  * scanning needs no collective.  Only the left-most-longest, non-overlapping SELECTION has
+    a dependency across the cut: a match selected in rank r-1 that ends after lo_r suppresses
+    begins in rank r.  Ranks therefore first select with an empty carry, exchange their
+    carry-out (3 integers, all_gather), and a rank re-runs its (cheap) selection only if the
+    true carry-in reaches into its first match -- rarely, and never for the benchmark
+    patterns;
+  * the exchange step proper is tiny: all_reduce(sum) of match counts (8 B per pattern) and a
+    gather of (begin,end) pairs to rank 0 (16 B per match).  With xGMI being point-to-point
+    a direct gather is used; there is nothing to bucket.
+
+`local_scan` is injected so the protocol can be exercised on CPU with gloo (tests use the
+oracle as the local matcher; bench.py and the product use rejit_amd.Scan on the GPU).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+Span = Tuple[int, int]
+# local_scan(own_lo, own_hi, carry_cur, carry_prev_end, have_prev) -> ordered GLOBAL spans whose
+# begin lies in [own_lo, own_hi)
+LocalScan = Callable[[int, int, int, int, bool], List[Span]]
+
+
+def partition(n: int, world: int, align: int = 1024) -> List[Tuple[int, int]]:
+    """Contiguous ranges covering match begins 0..n (inclusive: the empty match at the end
+    of the text belongs to the last rank).  Cuts are multiples of `align`."""
+    cuts = [0]
+    for r in range(1, world):
+        c = (n * r // world) // align * align
+        cuts.append(max(c, cuts[-1]))
+    cuts.append(n + 1)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def visible_range(n: int, own: Tuple[int, int], max_len: Optional[int], left: int = 64) -> Tuple[int, int]:
+    """Bytes a rank must hold to decide every match that begins in `own`.  max_len None =
+    unbounded pattern: the rank needs the text up to its end."""
+    lo, hi = own
+    vis_lo = max(0, lo - left)
+    vis_hi = n if max_len is None else min(n, hi + max_len)
+    return vis_lo, vis_hi
+
+
+def carry_out(spans: Sequence[Span], carry_in: Tuple[int, int, bool]) -> Tuple[int, int, bool]:
+    """Selection state after a rank's matches: (smallest allowed next begin, end of the
+    previous match, whether there is a previous match)."""
+    if not spans:
+        return carry_in
+    b, e = spans[-1]
+    return (e if e > b else b + 1, e, True)
+
+
+def needs_rerun(first: Optional[Span], carry_in: Tuple[int, int, bool]) -> bool:
+    """Would the first match selected with an empty carry change under the true carry-in?"""
+    cur, prev_end, have = carry_in
+    if first is None:
+        return False
+    b, e = first
+    if b < cur:
+        return True
+    return bool(have and b == e and prev_end == b)  # zero-length rule, src/codegen.cc:65-73
+
+
+def sharded_match_all(local_scan: LocalScan, ranges: Sequence[Tuple[int, int]], rank: int, world: int,
+                      dist=None, gather_to_root: bool = True):
+    """Runs the protocol above.  Returns (total_count, spans_on_root_or_None, local_spans).
+    `dist` is torch.distributed (initialised) or None for world == 1."""
+    own = ranges[rank]
+    empty = (0, 0, False)
+    spans = local_scan(own[0], own[1], *empty)
+    used = empty
+    if world > 1:
+        import torch
+
+        dev = _device_for(dist)
+        for _ in range(world):
+            co = carry_out(spans, used)
+            mine = torch.tensor([co[0], co[1], int(co[2]), spans[0][0] if spans else -1,
+                                 spans[0][1] if spans else -1], dtype=torch.int64, device=dev)
+            allc = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allc, mine)
+            # true carry-in of this rank = carry-out of the nearest earlier rank that has a match
+            cin = empty
+            for r in range(rank):
+                c = allc[r].tolist()
+                if c[2]:
+                    cin = (c[0], c[1], True)
+            rerun = cin != used and needs_rerun(spans[0] if spans else None, cin)
+            flag = torch.tensor([int(rerun)], dtype=torch.int64, device=dev)
+            dist.all_reduce(flag)
+            if rerun:
+                spans = local_scan(own[0], own[1], *cin)
+                used = cin
+            if int(flag.item()) == 0:
+                break
+    total = len(spans)
+    gathered = list(spans) if rank == 0 else None
+    if world > 1:
+        import torch
+
+        dev = _device_for(dist)
+        cnt = torch.tensor([len(spans)], dtype=torch.int64, device=dev)
+        counts = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(counts, cnt)
+        counts = [int(c.item()) for c in counts]
+        total = sum(counts)
+        if gather_to_root:
+            # padded gather of (begin,end) pairs to rank 0: 16 B per match, direct peer->root
+            width = max(max(counts), 1)
+            buf = torch.zeros((width, 2), dtype=torch.int64, device=dev)
+            if spans:
+                buf[:len(spans)] = torch.tensor(spans, dtype=torch.int64, device=dev)
+            parts = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
+            dist.gather(buf, parts, dst=0)
+            if rank == 0:
+                gathered = []
+                for r in range(world):
+                    gathered += [tuple(x) for x in parts[r][:counts[r]].tolist()]
+    return total, gathered, spans
+
+
+def _device_for(dist):
+    import torch
+
+    if dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")

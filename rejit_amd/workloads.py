@@ -133,20 +133,25 @@ def fasta_raw_numpy(n: int) -> np.ndarray:
     return np.concatenate(parts)
 
 
-def fasta_stripped_torch(n: int, device, chunk: int = 1 << 28):
-    """Same bytes as fasta_stripped_numpy, built on `device` (uint8 tensor of 10n)."""
+def fasta_stripped_torch(n: int, device, chunk: int = 1 << 28, lo: int = 0, hi: int = None):
+    """Bytes [lo, hi) of fasta_stripped_numpy(n), built on `device` (uint8 tensor).  A rank
+    of a sharded run generates only its own range (+ halo) this way."""
     import torch
 
-    out = torch.empty(10 * n, dtype=torch.uint8, device=device)
+    total = 10 * n
+    hi = total if hi is None else hi
+    lo, hi = max(0, lo), min(total, hi)
+    out = torch.empty(max(hi - lo, 0), dtype=torch.uint8, device=device)
     alu = torch.from_numpy(np.frombuffer(ALU.encode(), dtype=np.uint8).copy()).to(device)
     iub = torch.from_numpy(_char_table(IUB).copy()).to(device)
     hs = torch.from_numpy(_char_table(HS).copy()).to(device)
     sections = [(0, 2 * n, alu, 0, len(ALU)), (2 * n, 3 * n, iub, 1, IM), (5 * n, 5 * n, hs, 1 + 3 * n, IM)]
     for base, count, table, off, mod in sections:
-        for lo in range(0, count, chunk):
-            hi = min(count, lo + chunk)
-            k = torch.arange(lo, hi, dtype=torch.int64, device=device)
-            out[base + lo:base + hi] = table[(k + off) % mod]
+        a, b = max(lo, base), min(hi, base + count)   # overlap of [lo,hi) with this section
+        for c0 in range(a, b, chunk):
+            c1 = min(b, c0 + chunk)
+            k = torch.arange(c0 - base, c1 - base, dtype=torch.int64, device=device)
+            out[c0 - lo:c1 - lo] = table[(k + off) % mod]
     return out
 
 

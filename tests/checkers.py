@@ -84,6 +84,15 @@ class Oracle:
             return int(n)
         return _pairs(buf, min(n, cap))
 
+    def longest_all(self, regex: bytes, text: bytes):
+        """ends[s] for s in 0..n: end of the longest match beginning at s, or -1."""
+        ends = (ctypes.c_int64 * (len(text) + 1))()
+        self.lib.ro_longest_all_re.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t,
+                                               ctypes.POINTER(ctypes.c_int64)]
+        st = self.lib.ro_longest_all_re(regex, text, len(text), ends)
+        assert st == 0, st
+        return list(ends)
+
     def count(self, regex: bytes, text: bytes) -> int:
         return int(self.lib.ro_match_all_re(regex, text, len(text), None, 0))
 

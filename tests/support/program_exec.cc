@@ -84,11 +84,14 @@ bool longest_at(const Program& P, const uint8_t* t, uint64_t n, uint64_t s, uint
 bool candidate(const Program& P, const uint8_t* t, uint64_t n, uint64_t s) {
   if (P.mode == ScanMode::Windows) {
     for (const FFWindow& w : P.windows) {
-      int wl = w.mask == 0xFFFFFFFFu ? 4 : (w.mask == 0xFFFFFFu ? 3 : (w.mask == 0xFFFFu ? 2 : 1));
-      if (s + w.offset + wl > n) continue;
-      uint32_t v = 0;
-      for (int k = 0; k < wl; k++) v |= (uint32_t)t[s + w.offset + k] << (8 * k);
-      if ((v & w.mask) == w.value) return true;
+      if (s + w.offset + w.len > n) continue;
+      uint32_t v0 = 0, v1 = 0;
+      for (uint32_t k = 0; k < w.len; k++) {
+        uint32_t c = t[s + w.offset + k];
+        if (k < 4) v0 |= c << (8 * k);
+        else v1 |= c << (8 * (k - 4));
+      }
+      if ((v0 & w.mask0) == w.value0 && (v1 & w.mask1) == w.value1) return true;
     }
     return false;
   }
@@ -193,7 +196,12 @@ int pe_plan(const char* re, uint64_t* info, uint32_t* window_values) {
   info[5] = P.max_len;
   info[6] = (uint64_t)P.n_rows;
   info[7] = P.literal.size();
-  for (size_t i = 0; i < P.windows.size(); i++) window_values[i] = P.windows[i].value;
+  for (size_t i = 0; i < P.windows.size(); i++) {
+    window_values[4 * i] = P.windows[i].value0;
+    window_values[4 * i + 1] = P.windows[i].mask0;
+    window_values[4 * i + 2] = P.windows[i].value1;
+    window_values[4 * i + 3] = P.windows[i].mask1;
+  }
   return 0;
 }
 

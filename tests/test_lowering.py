@@ -54,12 +54,12 @@ def match_all(lib, rx, tx):
 
 def plan(lib, rx):
     info = (ctypes.c_uint64 * 8)()
-    vals = (ctypes.c_uint32 * 8)()
+    vals = (ctypes.c_uint32 * 32)()
     st = lib.pe_plan(rx, info, vals)
     assert st == 0
     return dict(windows=bool(info[0]), n_windows=int(info[1]), offset=int(info[2]), n_pos=int(info[3]),
                 min_len=int(info[4]), max_len=int(info[5]), n_rows=int(info[6]), literal_len=int(info[7]),
-                values=[int(v) for v in vals[:info[1]]])
+                values=[tuple(int(v) for v in vals[4 * i:4 * i + 4]) for i in range(int(info[1]))])
 
 
 def test_all_vectors_match_reference(pe):
@@ -84,13 +84,30 @@ def test_parse_errors(pe):
         assert pe.pe_match_all(V.b(e["regex"]), b"abc", 3, buf, 2) == -1, e
 
 
+def _w(s: bytes, wild=()):
+    """(value0, mask0, value1, mask1) of an up-to-8-byte window; `wild` = wildcard positions."""
+    v = [0, 0]
+    m = [0, 0]
+    for k, c in enumerate(s):
+        if k in wild:
+            continue
+        v[k // 4] |= c << (8 * (k % 4))
+        m[k // 4] |= 0xFF << (8 * (k % 4))
+    return (v[0], m[0], v[1], m[1])
+
+
 def test_scan_plans(pe):
     p = plan(pe, b"regexp")
-    assert p["windows"] and p["n_windows"] == 1 and p["values"] == [int.from_bytes(b"rege", "little")]
+    assert p["windows"] and p["values"] == [_w(b"regexp")] and p["offset"] == 0
     assert p["literal_len"] == 6 and p["min_len"] == 6 and p["max_len"] == 6
-    for rx in V.bench()["regexdna"]["1000"]["patterns"]:
-        p = plan(pe, V.b(rx["regex"]))
-        assert p["windows"] and 2 <= p["n_windows"] <= 4, (rx["regex"], p)
+    dna = [V.b(x["regex"]) for x in V.bench()["regexdna"]["1000"]["patterns"]]
+    p = plan(pe, dna[0])
+    assert sorted(p["values"]) == sorted([_w(b"agggtaaa"), _w(b"tttaccct")])
+    p = plan(pe, dna[1])   # [cgt]gggtaaa|tttaccc[acg]: the class bytes become wildcards
+    assert sorted(p["values"]) == sorted([_w(b"?gggtaaa", (0,)), _w(b"tttaccc?", (7,))])
+    for rx in dna:
+        p = plan(pe, rx)
+        assert p["windows"] and p["n_windows"] == 2, (rx, p)
         assert p["min_len"] == 8 and p["max_len"] == 8 and p["n_pos"] == 16
     p = plan(pe, b"x*")
     assert not p["windows"] and p["min_len"] == 0 and p["max_len"] == 2 ** 64 - 1
@@ -98,3 +115,7 @@ def test_scan_plans(pe):
     assert p["min_len"] == 12 and p["max_len"] == 58
     p = plan(pe, b">.*\n|\n")
     assert p["windows"] and p["n_windows"] == 2 and p["min_len"] == 1
+    p = plan(pe, b"abc.efgh")      # a wide class inside the window is a wildcard, not a split
+    assert p["windows"] and p["values"] == [_w(b"abc?efgh", (3,))]
+    p = plan(pe, b"(alternation|more|than|two|different|strings)")
+    assert p["windows"] and p["n_windows"] == 6 and p["min_len"] == 3

@@ -1,0 +1,90 @@
+"""CPU tests of the multi-rank path: world_size-2 (and 3) gloo process groups run the
+sharding protocol of rejit_amd/sharding.py with the oracle as the local matcher, and the
+gathered result must equal the single-rank result -- including patterns whose matches
+overlap the cut, so that the carry exchange is exercised."""
+import os
+import random
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from checkers import Oracle
+from rejit_amd import sharding
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _local_scan_factory(ends):
+    def scan(lo, hi, cur, prev_end, have):
+        out = []
+        for s in range(lo, min(hi, len(ends))):
+            e = ends[s]
+            if e < 0 or s < cur:
+                continue
+            cur = e if e > s else s + 1
+            if not (e == s and have and prev_end == s):
+                out.append((s, e))
+            have, prev_end = True, e
+        return out
+    return scan
+
+
+CASES = [(b"abc", 1), (b"aa", 1), (b"(ab|ba)+", 1), (b"x*", 1), (b"a[bc]*a", 1), (b"^|b$", 1)]
+
+
+def _worker(rank, world, port, text, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    oracle = Oracle()
+    results = {}
+    for rx, align in CASES:
+        ends = oracle.longest_all(rx, text)
+        ranges = sharding.partition(len(text), world, align=align)
+        total, gathered, local = sharding.sharded_match_all(_local_scan_factory(ends), ranges, rank, world, dist)
+        results[rx] = (total, gathered)
+    if rank == 0:
+        q.put(results)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_equals_single(world):
+    rng = random.Random(world)
+    text = bytes(rng.choice(b"aabbc\nx") for _ in range(997))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, text, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    oracle = Oracle()
+    for rx, _ in CASES:
+        want = oracle.match_all_spec(rx, text)
+        total, gathered = results[rx]
+        assert total == len(want) and gathered == want, rx
+
+
+def test_partition_and_visible_range():
+    r = sharding.partition(10_000_000, 8)
+    assert r[0][0] == 0 and r[-1][1] == 10_000_001
+    assert all(a[1] == b[0] for a, b in zip(r[:-1], r[1:]))
+    assert all(lo % 1024 == 0 for lo, _ in r)
+    assert sharding.visible_range(1000, (100, 200), 8) == (36, 208)
+    assert sharding.visible_range(1000, (100, 200), None) == (36, 1000)
+    assert sharding.needs_rerun((5, 9), (6, 6, True)) and not sharding.needs_rerun((6, 9), (6, 6, True))
+    assert sharding.needs_rerun((6, 6), (6, 6, True)) and not sharding.needs_rerun(None, (6, 6, True))
