@@ -35,6 +35,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def pmc_traffic(key, **match):
+    """HBM bytes per launch of the dominant kernel, measured with rocprofv3 --pmc FETCH_SIZE in a
+    separate pass and corrected as the guide prescribes (x2 on gfx950); committed under
+    profiles/.  Reported only when the profiled configuration is the one being run, else null."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[key]
+        if all(rec.get(k) == v for k, v in match.items()):
+            return int(rec["hbm_read_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,7 +178,8 @@ def main():
         "matches_per_s": round(total_matches * args.steps / elapsed, 1),
         "matches_per_pass": counts,
         "roofline": {"bound": "hbm", "kernel": "scan_windows<K>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": pmc_traffic("regexdna", fasta_n=args.fasta_n) if world == 1 else None,
                      "avg_launch_ms": round(avg_scan_ms, 5), "bytes_per_launch": int(own_bytes),
                      "launches_timed": len(scan_ms)},
     }
@@ -218,7 +232,7 @@ def main():
             "workload": "literal 'regexp' MatchAll over %d bytes random ASCII ['0','z'), %d planted (BASELINE configs[1])" % (n, len(offs)),
             "value": round(n * steps / dt / 1e9, 1), "unit": "GB/s", "matches": int(c), "latency_ms": round(dt / steps * 1e3, 4),
             "roofline": {"bound": "hbm", "kernel": "scan_windows<1>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("literal", bytes=n),
                          "avg_launch_ms": round(a_ms, 5), "bytes_per_launch": n},
         }
 
