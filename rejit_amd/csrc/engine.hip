@@ -16,6 +16,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <cerrno>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -51,6 +52,20 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess)                                                                     \
       return fail(RJ_DEVICE_ERROR, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
+
+// The reference's generated code never touches errno, and its callers rely on that
+// (sample/jrep.cc:281-285 tests `if (errno)` right after mmap).  The HIP runtime does set it
+// (probing files, ioctls), so every entry point restores the caller's value.
+struct ErrnoGuard {
+  int saved;
+  ErrnoGuard() : saved(errno) {}
+  ~ErrnoGuard() { errno = saved; }
+};
+
+// The HIP runtime's own load-time initialisers (they run before ours: dependency order) can
+// leave errno set before main() starts -- e.g. ENOENT from probing amdgpu.ids.  A process that
+// links the reference's librejit.a starts with errno == 0, so restore that.
+__attribute__((constructor)) void rj_library_loaded() { errno = 0; }
 
 struct DeviceBuffer {
   void* p = nullptr;
@@ -415,12 +430,14 @@ extern "C" {
 const char* rj_last_error(void) { return g_error.c_str(); }
 
 int rj_device_count(void) {
+  ErrnoGuard errno_guard;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
 
 int rj_compile(const char* regexp, rj_program** out) {
+  ErrnoGuard errno_guard;
   if (!regexp || !out) return fail(RJ_BAD_ARGUMENT, "null argument");
   *out = nullptr;
   g_error.clear();
@@ -439,6 +456,7 @@ int rj_compile(const char* regexp, rj_program** out) {
 }
 
 void rj_program_free(rj_program* prog) {
+  ErrnoGuard errno_guard;
   if (!prog) return;
   // drop cached host scans of this thread that refer to the program
   auto& v = g_host_scans.v;
@@ -469,6 +487,7 @@ int rj_program_info(const rj_program* prog, rj_info* info) {
 }
 
 int rj_scan_create(const rj_program* prog, rj_scan** out) {
+  ErrnoGuard errno_guard;
   if (!prog || !out) return fail(RJ_BAD_ARGUMENT, "null argument");
   auto s = std::make_unique<rj_scan>();
   s->prog = prog;
@@ -479,6 +498,7 @@ int rj_scan_create(const rj_program* prog, rj_scan** out) {
 }
 
 void rj_scan_destroy(rj_scan* s) {
+  ErrnoGuard errno_guard;
   if (!s) return;
   if (s->host_counters) (void)hipHostFree(s->host_counters);
   if (s->host_flag) (void)hipHostFree(s->host_flag);
@@ -490,6 +510,7 @@ void rj_scan_destroy(rj_scan* s) {
 
 int64_t rj_scan_run(rj_scan* s, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end,
                     uint64_t carry_cur, uint64_t carry_prev_end, int have_prev, void* hip_stream) {
+  ErrnoGuard errno_guard;
   if (!s) return fail(RJ_BAD_ARGUMENT, "null scan");
   int rc = run_pipeline(s, static_cast<const uint8_t*>(d_text), n, own_begin, own_end, carry_cur, carry_prev_end,
                         have_prev, static_cast<hipStream_t>(hip_stream));
@@ -500,6 +521,7 @@ int64_t rj_scan_run(rj_scan* s, const void* d_text, uint64_t n, uint64_t own_beg
 const uint64_t* rj_scan_device_spans(const rj_scan* s) { return s ? s->result : nullptr; }
 
 int64_t rj_scan_copy_spans(const rj_scan* s, uint64_t* host_spans, uint64_t cap) {
+  ErrnoGuard errno_guard;
   if (!s) return fail(RJ_BAD_ARGUMENT, "null scan");
   const uint64_t k = std::min<uint64_t>(cap, s->result_count);
   if (k) {
@@ -516,6 +538,7 @@ int rj_scan_stats(const rj_scan* s, rj_stats* stats) {
 }
 
 int rj_scan_match_full(rj_scan* s, const void* d_text, uint64_t n, void* hip_stream) {
+  ErrnoGuard errno_guard;
   if (!s) return fail(RJ_BAD_ARGUMENT, "null scan");
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   launch_match_full(static_cast<const uint8_t*>(d_text), n, s->prog->dev, s->flag.as<int>(), st);
@@ -526,6 +549,7 @@ int rj_scan_match_full(rj_scan* s, const void* d_text, uint64_t n, void* hip_str
 }
 
 int64_t rj_match_all(const rj_program* prog, const char* text, size_t n, uint64_t** spans) {
+  ErrnoGuard errno_guard;
   if (spans) *spans = nullptr;
   if (!prog || (!text && n)) return fail(RJ_BAD_ARGUMENT, "null argument");
   rj_scan* s = nullptr;
@@ -552,6 +576,7 @@ int64_t rj_match_all(const rj_program* prog, const char* text, size_t n, uint64_
 void rj_free_spans(uint64_t* spans) { free(spans); }
 
 int rj_match_first(const rj_program* prog, const char* text, size_t n, uint64_t* begin, uint64_t* end) {
+  ErrnoGuard errno_guard;
   // kMatchFirst == first element of kMatchAll (left-most longest); see DESIGN.md
   uint64_t* spans = nullptr;
   int64_t c = rj_match_all(prog, text, n, &spans);
@@ -565,12 +590,14 @@ int rj_match_first(const rj_program* prog, const char* text, size_t n, uint64_t*
 }
 
 int rj_match_anywhere(const rj_program* prog, const char* text, size_t n) {
+  ErrnoGuard errno_guard;
   int64_t c = rj_match_all(prog, text, n, nullptr);
   if (c < 0) return static_cast<int>(c);
   return c > 0 ? 1 : 0;
 }
 
 int rj_match_full(const rj_program* prog, const char* text, size_t n) {
+  ErrnoGuard errno_guard;
   if (!prog || (!text && n)) return fail(RJ_BAD_ARGUMENT, "null argument");
   rj_scan* s = nullptr;
   int rc = host_scan_for(prog, &s);

@@ -1,0 +1,53 @@
+"""Drop-in proof on the GPU: the reference's OWN callers -- sample/regexdna.cc and
+sample/jrep.cc, compiled UNCHANGED against our include/rejit.h and linked against our
+librejit_hip.so (oracle/Makefile target `callers`, built in the build container) -- produce
+the canonical regex-dna output and grep-identical results."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import vectors as V
+from rejit_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REGEXDNA = os.path.join(ROOT, "oracle", "_ref", "regexdna_hip")
+JREP = os.path.join(ROOT, "oracle", "_ref", "jrep_hip")
+
+
+@pytest.mark.skipif(not os.path.exists(REGEXDNA), reason="oracle/_ref/regexdna_hip not built")
+@pytest.mark.parametrize("nf", [1000, 50000])
+def test_reference_regexdna_sample_runs_on_our_library(tmp_path, nf):
+    g = V.bench()["regexdna"][str(nf)]
+    fasta = tmp_path / "in.fasta"
+    fasta.write_bytes(W.fasta_raw_numpy(nf).tobytes())
+    with open(fasta, "rb") as f:
+        out = subprocess.run([REGEXDNA], stdin=f, capture_output=True, timeout=300, check=True).stdout.decode()
+    lines = out.strip().split("\n")
+    counts = [int(l.rsplit(" ", 1)[1]) for l in lines[:9]]
+    assert [l.rsplit(" ", 1)[0] for l in lines[:9]] == W.REGEXDNA_PATTERNS
+    assert counts == [p["count"] for p in g["patterns"]]
+    sizes = [int(x) for x in lines[-3:]]
+    assert sizes == [g["raw_size"], g["stripped_size"], g["replaced_size"]]
+    if nf == 50000:   # the canonical Benchmarks-Game output
+        assert counts == [3, 12, 43, 27, 58, 16, 15, 18, 20] and sizes == [508411, 500000, 668262]
+
+
+@pytest.mark.skipif(not os.path.exists(JREP) or shutil.which("grep") is None, reason="jrep_hip or grep missing")
+def test_reference_jrep_sample_equals_grep(tmp_path):
+    import random
+    rng = random.Random(3)
+    words = ["regexp", "alpha", "beta", "gamma", "int", "return", "for", "while", "x", "y", "regex", "exp"]
+    for d in ("a", "a/b", "c"):
+        os.makedirs(tmp_path / d, exist_ok=True)
+    for i in range(40):
+        sub = rng.choice(["a", "a/b", "c", "."])
+        lines = [" ".join(rng.choice(words) for _ in range(rng.randint(1, 9))) for _ in range(rng.randint(1, 60))]
+        (tmp_path / sub / f"f{i}.txt").write_text("\n".join(lines) + "\n")
+    for pattern in ("regexp", "gamma beta", "whil"):
+        ours = subprocess.run([JREP, "-R", "-H", "-n", pattern, "."], cwd=tmp_path, capture_output=True, timeout=300).stdout
+        ref = subprocess.run(["grep", "-R", "-H", "-n", pattern, "."], cwd=tmp_path, capture_output=True).stdout
+        assert sorted(ours.splitlines()) == sorted(ref.splitlines()), pattern
+        assert len(ref.splitlines()) > 0
