@@ -94,6 +94,7 @@ struct rj_program {
   DevProgram dev{};
   DeviceBuffer tables;
   int device = 0;
+  int window_alphabet = 0;  // distinct byte values among the fixed window bytes
   std::string pattern;
 };
 
@@ -164,6 +165,16 @@ int upload_program(rj_program* rp) {
     D.win_mask0[k] = w.mask0;
     D.win_value1[k] = w.value1;
     D.win_mask1[k] = w.mask1;
+  }
+  {
+    ByteSet seen;
+    for (const FFWindow& w : P.windows)
+      for (uint32_t k = 0; k < w.len; k++) {
+        const uint32_t m = k < 4 ? (w.mask0 >> (8 * k)) : (w.mask1 >> (8 * (k - 4)));
+        const uint32_t v = k < 4 ? (w.value0 >> (8 * k)) : (w.value1 >> (8 * (k - 4)));
+        if (m & 0xFFu) seen.add(static_cast<uint8_t>(v & 0xFFu));
+      }
+    rp->window_alphabet = seen.count();
   }
   for (int k = 0; k < 8; k++) D.first_bytes[k] = P.first_bytes.w[k];
   D.min_len = P.min_len;
@@ -278,7 +289,11 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
   // segments so the hit list stays bounded.  Windows mode: one segment.
   const bool windows = D.mode == 1;
   const uint64_t seg = windows ? (se - sb) : std::min<uint64_t>(se - sb, 1ull << 27);
-  uint64_t want_hits = windows ? std::max<uint64_t>(1u << 16, (se - sb) / 512) : seg + 64;
+  // a workgroup appends to segment (blockIdx % kHitSegs): with few workgroups one segment may
+  // receive everything, so small runs give every segment room for the whole range
+  const uint64_t hits_limit = static_cast<uint64_t>(kHitSegs) * (seg + 64);
+  uint64_t want_hits = windows ? std::max<uint64_t>(1u << 16, (se - sb) / 512)
+                               : (seg <= (1u << 20) ? hits_limit : seg + seg / 8 + 64 * kHitSegs);
   uint64_t want_cands = std::max<uint64_t>(1u << 16, (se - sb) / 512);
 
   for (int attempt = 0; attempt < 8; attempt++) {
@@ -290,7 +305,8 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     (void)scan_ms_total;
     for (uint64_t lo = sb; lo < se; lo += seg) {
       const uint64_t hi = std::min(se, lo + seg);
-      if (lo != sb) RJ_HIP(hipMemsetAsync(s->counters.as<unsigned long long>() + kCntHits, 0, sizeof(unsigned long long), st));
+      if (lo != sb)
+        RJ_HIP(hipMemsetAsync(s->counters.as<unsigned long long>() + kCntHits, 0, kHitSegs * sizeof(unsigned long long), st));
       ScanParams sp{};
       sp.text = d_text;
       sp.n = n;
@@ -311,6 +327,7 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
           masked |= D.win_mask0[k] != 0xFFFFFFFFu || (D.win_len > 4 && D.win_mask1[k] != 0xFFFFFFFFu);
         }
         ws.masked = masked;
+        ws.two_level = rp->window_alphabet > 4;
         ws.len = D.win_len;
         ws.offset = D.win_offset;
         sp.wlo = lo + D.win_offset;
@@ -349,16 +366,22 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     RJ_HIP(hipStreamSynchronize(st));
     RJ_HIP(hipGetLastError());
-    const unsigned long long n_hits = s->host_counters[kCntHits];
+    unsigned long long n_hits = 0, max_seg = 0;
+    for (int k = 0; k < kHitSegs; k++) {
+      n_hits += s->host_counters[kCntHits + k];
+      max_seg = std::max(max_seg, s->host_counters[kCntHits + k]);
+    }
     const unsigned long long n_cands = s->host_counters[kCntCands];
     s->stats.n_hits = n_hits;
     s->stats.n_candidates = n_cands;
     (void)hipEventElapsedTime(&s->stats.scan_ms, s->ev[1], s->ev[2]);
     (void)hipEventElapsedTime(&s->stats.total_ms, s->ev[0], s->ev[3]);
-    if (s->host_counters[kCntOverflow] != 0 || n_cands > s->cands_cap || n_hits > s->hits_cap) {
+    if (s->host_counters[kCntOverflow] != 0 || n_cands > s->cands_cap || max_seg > s->hits_cap / kHitSegs) {
       // grow whichever list overflowed and run again
       s->stats.retries++;
-      want_hits = std::max<uint64_t>(s->hits_cap, std::min<uint64_t>(std::max<uint64_t>(n_hits, s->hits_cap * 4), seg + 64));
+      // segments fill unevenly: size for the fullest one
+      want_hits = std::max<uint64_t>(s->hits_cap, std::min<uint64_t>(std::max<uint64_t>(max_seg * kHitSegs * 2, s->hits_cap * 4),
+                                                                     hits_limit));
       want_cands = std::max<uint64_t>(s->cands_cap, std::min<uint64_t>(std::max<uint64_t>(n_cands * 2, s->cands_cap * 4), (se - sb) + 64));
       if (want_hits == s->hits_cap && want_cands == s->cands_cap) return fail(RJ_DEVICE_ERROR, "device lists cannot grow further");
       continue;

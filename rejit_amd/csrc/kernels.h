@@ -10,7 +10,11 @@
 namespace rejit_amd {
 
 // device counters (unsigned long long[kCntSize])
-enum { kCntHits = 0, kCntCands = 1, kCntFinal = 2, kCntOverflow = 3, kCntSize = 8 };
+// The hit list is split into kHitSegs segments with one counter each: a single device-wide
+// counter sustains only ~90 atomics/us (MI355X_MICROARCH.md "dequeue": shard the head), and
+// with 64 Ki waves each flushing at least once that was the whole kernel time.
+constexpr int kHitSegs = 16;
+enum { kCntCands = 0, kCntFinal = 1, kCntOverflow = 2, kCntHits = 8, kCntSize = 8 + kHitSegs };
 
 constexpr int kFinalizeCap = 2048;  // candidates the single-workgroup finalize sorts in LDS
 
@@ -19,7 +23,7 @@ struct ScanParams {
   uint64_t n;
   uint64_t sb, se;       // candidate starts lie in [sb, se), se <= n + 1
   uint64_t wlo, whi;     // window positions scanned (windows mode): [wlo, whi)
-  uint64_t* hits;
+  uint64_t* hits;        // kHitSegs segments of hits_cap / kHitSegs entries
   uint64_t hits_cap;
   unsigned long long* counters;
 };
@@ -30,6 +34,7 @@ struct WindowSet {
   uint32_t offset;
   uint32_t len;      // 1..8 bytes
   uint32_t masked;   // some mask byte inside [0,len) is a wildcard / len is not 4 or 8
+  uint32_t two_level;  // test the first dword of all positions before the second (large alphabets)
 };
 
 struct VerifyParams {

@@ -29,6 +29,7 @@
 //
 // No MFMA: there is no contraction anywhere on this path (integer compares on a byte stream);
 // the roofline is HBM read bandwidth.
+#include <cstdlib>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -162,6 +163,14 @@ struct WaveHits {
   }
 };
 
+// this wave's staging slots and the hit-list segment (and its counter) of this workgroup
+__device__ __forceinline__ WaveHits make_wave_hits(uint64_t* lds_slots, const ScanParams& a) {
+  const unsigned seg = blockIdx.x % kHitSegs;
+  const uint64_t seg_cap = a.hits_cap / kHitSegs;
+  return WaveHits{lds_slots + (threadIdx.x >> 6) * kHitBuf, 0u, a.hits + seg * seg_cap, seg_cap,
+                  a.counters + kCntHits + seg};
+}
+
 // 16 B of the lane + the 8 B that follow, guarded against the end of the text (tail chunk).
 __device__ __forceinline__ void load_guarded(const uint8_t* text, uint64_t n, uint64_t at, uint32_t d[6]) {
 #pragma unroll
@@ -186,7 +195,7 @@ __device__ __forceinline__ void load_guarded(const uint8_t* text, uint64_t n, ui
 //     (load32(text + w + 4) & mask1[k]) == value1[k];
 // the candidate start is s = w - offset.  Scanned w range: [wlo, whi).
 // One chunk: d[0..3] = the lane's 16 bytes, d[4..5] = the 8 bytes that follow.
-template <int K, bool TWO, bool MASKED>
+template <int K, bool TWO, bool MASKED, bool TWOLEVEL>
 __device__ __forceinline__ void windows_chunk(const uint32_t (&d)[6], uint64_t at, const ScanParams& a,
                                               const WindowSet& ws, WaveHits& hits) {
   constexpr int NX = TWO ? 20 : 16;  // windows needed: 16 positions (+4 for the second dword)
@@ -204,6 +213,24 @@ __device__ __forceinline__ void windows_chunk(const uint32_t (&d)[6], uint64_t a
   // is zero iff the window matches; the minimum over all (j,k) is zero iff the lane has a
   // hit.  (The obvious form -- v_cmp per dword and s_and/s_or of the lane masks -- put ~130
   // scalar instructions per chunk on the CU's single scalar unit and ran at 2.9 TB/s.)
+  if (TWO && TWOLEVEL) {
+    // Two-level test for 5..8-byte windows over a large alphabet: the first dword alone is
+    // already a strong filter (e.g. 74^-4 on random ASCII), so test it for all 16 positions
+    // first and leave, wave-uniformly, when no lane has a first-dword hit.  Over a small
+    // alphabet (DNA) some lane always has one and this level would be pure overhead, which is
+    // why the host enables it only when the window bytes span more than 4 distinct values.
+    uint32_t acc1 = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        uint32_t t = x[j] ^ ws.value0[k];
+        if (MASKED) t &= ws.mask0[k];
+        acc1 = acc1 < t ? acc1 : t;
+      }
+    }
+    if (__ballot(acc1 == 0) == 0) return;
+  }
   uint32_t acc = 0xFFFFFFFFu;
 #pragma unroll
   for (int j = 0; j < 16; j++) {
@@ -252,10 +279,10 @@ __device__ __forceinline__ void load_chunk(const uint8_t* text, uint64_t at, uin
   }
 }
 
-template <int K, bool TWO, bool MASKED>
+template <int K, bool TWO, bool MASKED, bool TWOLEVEL>
 __global__ __launch_bounds__(256) void scan_windows(ScanParams a, WindowSet ws) {
   __shared__ uint64_t hit_slots[4 * kHitBuf];
-  WaveHits hits{hit_slots + (threadIdx.x >> 6) * kHitBuf, 0u, a.hits, a.hits_cap, a.counters + kCntHits};
+  WaveHits hits = make_wave_hits(hit_slots, a);
   const int lane = lane_id();
   // wave index as a scalar, so that chunk addresses and loop branches are wave-uniform
   const uint64_t wave = __builtin_amdgcn_readfirstlane(
@@ -269,30 +296,36 @@ __global__ __launch_bounds__(256) void scan_windows(ScanParams a, WindowSet ws) 
   if (fast_end < first_chunk) fast_end = first_chunk;
 
   // Software-pipelined streaming loop, three register buffers deep: while chunk c is compared
-  // the loads of chunks c + stride and c + 2*stride are in flight (3 KiB per wave, ~96 KiB
-  // per CU at 8 waves/SIMD).  Prefetches are unconditional -- past the end they re-read the
-  // wave's last chunk -- so the number of loads in flight is static and the compiler can
-  // wait for exactly the buffer it needs (vmcnt(4)).
-  if (first_chunk + wave < fast_end) {
+  // the loads of chunks c + stride and c + 2*stride are in flight (3 KiB per wave).  The steady
+  // loop runs only while all three prefetch targets exist, so its loads are unconditional and
+  // the compiler waits for exactly the buffer it needs (vmcnt(4)); the last <= 5 chunks of a
+  // wave are drained without prefetch, so no byte is loaded twice.
+  {
     const uint64_t lane_off = static_cast<uint64_t>(lane) * 16;
-    uint64_t last = first_chunk + wave;  // last in-range chunk of this wave (clamp target)
-    last += (fast_end - 1 - last) / n_waves * n_waves;
     uint32_t b0[6], b1[6], b2[6];
     uint64_t c = first_chunk + wave;
-    auto clamp = [&](uint64_t x) { return x < fast_end ? x : last; };
-    load_chunk<TWO>(a.text, clamp(c) * kChunk + lane_off, b0);
-    load_chunk<TWO>(a.text, clamp(c + n_waves) * kChunk + lane_off, b1);
-    load_chunk<TWO>(a.text, clamp(c + 2 * n_waves) * kChunk + lane_off, b2);
-    for (; c < fast_end; c += 3 * n_waves) {
-      windows_chunk<K, TWO, MASKED>(b0, c * kChunk + lane_off, a, ws, hits);
-      load_chunk<TWO>(a.text, clamp(c + 3 * n_waves) * kChunk + lane_off, b0);
+    if (c < fast_end) load_chunk<TWO>(a.text, c * kChunk + lane_off, b0);
+    if (c + n_waves < fast_end) load_chunk<TWO>(a.text, (c + n_waves) * kChunk + lane_off, b1);
+    if (c + 2 * n_waves < fast_end) load_chunk<TWO>(a.text, (c + 2 * n_waves) * kChunk + lane_off, b2);
+    while (c + 5 * n_waves < fast_end) {
+      windows_chunk<K, TWO, MASKED, TWOLEVEL>(b0, c * kChunk + lane_off, a, ws, hits);
+      load_chunk<TWO>(a.text, (c + 3 * n_waves) * kChunk + lane_off, b0);
       __builtin_amdgcn_sched_barrier(0);
-      if (c + n_waves < fast_end) windows_chunk<K, TWO, MASKED>(b1, (c + n_waves) * kChunk + lane_off, a, ws, hits);
-      load_chunk<TWO>(a.text, clamp(c + 4 * n_waves) * kChunk + lane_off, b1);
+      windows_chunk<K, TWO, MASKED, TWOLEVEL>(b1, (c + n_waves) * kChunk + lane_off, a, ws, hits);
+      load_chunk<TWO>(a.text, (c + 4 * n_waves) * kChunk + lane_off, b1);
       __builtin_amdgcn_sched_barrier(0);
-      if (c + 2 * n_waves < fast_end) windows_chunk<K, TWO, MASKED>(b2, (c + 2 * n_waves) * kChunk + lane_off, a, ws, hits);
-      load_chunk<TWO>(a.text, clamp(c + 5 * n_waves) * kChunk + lane_off, b2);
+      windows_chunk<K, TWO, MASKED, TWOLEVEL>(b2, (c + 2 * n_waves) * kChunk + lane_off, a, ws, hits);
+      load_chunk<TWO>(a.text, (c + 5 * n_waves) * kChunk + lane_off, b2);
       __builtin_amdgcn_sched_barrier(0);
+      c += 3 * n_waves;
+    }
+    // drain: b0..b2 hold chunks c, c+stride, c+2*stride (where they exist), then <= 2 more
+    if (c < fast_end) windows_chunk<K, TWO, MASKED, TWOLEVEL>(b0, c * kChunk + lane_off, a, ws, hits);
+    if (c + n_waves < fast_end) windows_chunk<K, TWO, MASKED, TWOLEVEL>(b1, (c + n_waves) * kChunk + lane_off, a, ws, hits);
+    if (c + 2 * n_waves < fast_end) windows_chunk<K, TWO, MASKED, TWOLEVEL>(b2, (c + 2 * n_waves) * kChunk + lane_off, a, ws, hits);
+    for (c += 3 * n_waves; c < fast_end; c += n_waves) {
+      load_chunk<TWO>(a.text, c * kChunk + lane_off, b0);
+      windows_chunk<K, TWO, MASKED, TWOLEVEL>(b0, c * kChunk + lane_off, a, ws, hits);
     }
   }
   // tail: the last chunk(s) touch the end of the text and use guarded byte loads
@@ -300,7 +333,37 @@ __global__ __launch_bounds__(256) void scan_windows(ScanParams a, WindowSet ws) 
     const uint64_t at = t * kChunk + static_cast<uint64_t>(lane) * 16;
     uint32_t d[6];
     load_guarded(a.text, a.n, at, d);
-    windows_chunk<K, TWO, MASKED>(d, at, a, ws, hits);
+    windows_chunk<K, TWO, MASKED, TWOLEVEL>(d, at, a, ws, hits);
+  }
+  hits.flush();
+}
+
+// A/B variant kept for measurements (RJ_SCAN_SIMPLE=1): no software pipeline, one chunk in
+// flight per wave.
+template <int K, bool TWO, bool MASKED, bool TWOLEVEL>
+__global__ __launch_bounds__(256) void scan_windows_simple(ScanParams a, WindowSet ws) {
+  __shared__ uint64_t hit_slots[4 * kHitBuf];
+  WaveHits hits = make_wave_hits(hit_slots, a);
+  const int lane = lane_id();
+  const uint64_t wave = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6));
+  const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+  const uint64_t first_chunk = a.wlo / kChunk;
+  const uint64_t end_chunk = (a.whi + kChunk - 1) / kChunk;
+  uint64_t fast_end = a.n >= kChunk + 8 ? (a.n - 8) / kChunk : 0;
+  if (fast_end > end_chunk) fast_end = end_chunk;
+  if (fast_end < first_chunk) fast_end = first_chunk;
+  for (uint64_t c = first_chunk + wave; c < fast_end; c += n_waves) {
+    const uint64_t at = c * kChunk + static_cast<uint64_t>(lane) * 16;
+    uint32_t d[6];
+    load_chunk<TWO>(a.text, at, d);
+    windows_chunk<K, TWO, MASKED, TWOLEVEL>(d, at, a, ws, hits);
+  }
+  for (uint64_t t = fast_end + wave; t < end_chunk; t += n_waves) {
+    const uint64_t at = t * kChunk + static_cast<uint64_t>(lane) * 16;
+    uint32_t d[6];
+    load_guarded(a.text, a.n, at, d);
+    windows_chunk<K, TWO, MASKED, TWOLEVEL>(d, at, a, ws, hits);
   }
   hits.flush();
 }
@@ -309,7 +372,7 @@ __global__ __launch_bounds__(256) void scan_windows(ScanParams a, WindowSet ws) 
 // Dense scan: every position s in [sb, se) that can start a match goes to the hit list.
 __global__ __launch_bounds__(256) void scan_dense(ScanParams a, DevProgram P) {
   __shared__ uint64_t hit_slots[4 * kHitBuf];
-  WaveHits hits{hit_slots + (threadIdx.x >> 6) * kHitBuf, 0u, a.hits, a.hits_cap, a.counters + kCntHits};
+  WaveHits hits = make_wave_hits(hit_slots, a);
   __shared__ uint32_t fb[8];
   if (threadIdx.x < 8) fb[threadIdx.x] = P.first_bytes[threadIdx.x];
   __syncthreads();
@@ -361,20 +424,26 @@ __global__ __launch_bounds__(256) void scan_dense(ScanParams a, DevProgram P) {
 // Verify: longest match from every hit; survivors become (begin,end) candidates.
 template <int NQ>
 __global__ __launch_bounds__(256) void verify_lane(VerifyParams a, DevProgram P) {
-  unsigned long long n_hits = a.counters[kCntHits];
-  if (n_hits > a.hits_cap) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[kCntOverflow] = 1;
-    n_hits = a.hits_cap;
+  const uint64_t seg_cap = a.hits_cap / kHitSegs;
+  // wave w works on segment w % kHitSegs only (a wave that walked all segments in turn
+  // serialised ~16 dependent automaton runs: +60 us per call)
+  const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;  // multiple of kHitSegs
+  const int seg = static_cast<int>(wave % kHitSegs);
+  const uint64_t local = wave / kHitSegs, n_local = n_waves / kHitSegs;
+  unsigned long long n_hits = a.counters[kCntHits + seg];
+  if (n_hits > seg_cap) {
+    if (lane_id() == 0) a.counters[kCntOverflow] = 1;
+    n_hits = seg_cap;
   }
-  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  const uint64_t* hits = a.hits + seg * seg_cap;
   // all lanes of a wave iterate together (wave-aggregated append needs the full wave)
-  const uint64_t first = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  for (uint64_t base = first - lane_id(); base < n_hits; base += stride) {
+  for (uint64_t base = local * kWave; base < n_hits; base += n_local * kWave) {
     const uint64_t i = base + lane_id();
     bool found = false;
     uint64_t s = 0, e = 0;
     if (i < n_hits) {
-      s = a.hits[i];
+      s = hits[i];
       found = rj_lane_longest<NQ>(P, a.text, a.n, s, &e);
     }
     wave_append_pair(found, s, e, a.cand_begin, a.cand_end, a.cands_cap, a.counters + kCntCands);
@@ -476,15 +545,19 @@ __device__ bool wave_longest(const DevProgram& P, const uint8_t* t, uint64_t n, 
 
 template <int NR>
 __global__ __launch_bounds__(256) void verify_wave(VerifyParams a, DevProgram P) {
-  unsigned long long n_hits = a.counters[kCntHits];
-  if (n_hits > a.hits_cap) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[kCntOverflow] = 1;
-    n_hits = a.hits_cap;
-  }
+  const uint64_t seg_cap = a.hits_cap / kHitSegs;
   const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
   const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
-  for (uint64_t i = wave; i < n_hits; i += n_waves) {
-    const uint64_t s = a.hits[i];
+  const int seg = static_cast<int>(wave % kHitSegs);
+  const uint64_t local = wave / kHitSegs, n_local = n_waves / kHitSegs;
+  unsigned long long n_hits = a.counters[kCntHits + seg];
+  if (n_hits > seg_cap) {
+    if (lane_id() == 0) a.counters[kCntOverflow] = 1;
+    n_hits = seg_cap;
+  }
+  const uint64_t* hits = a.hits + seg * seg_cap;
+  for (uint64_t i = local; i < n_hits; i += n_local) {
+    const uint64_t s = hits[i];
     uint64_t e = 0;
     const bool found = wave_longest<NR>(P, a.text, a.n, s, &e, false);
     if (found && lane_id() == 0) {
@@ -675,37 +748,53 @@ __global__ void check_and_interleave(const uint64_t* keys, const uint64_t* vals,
 // Launchers (host side of the <<< >>> syntax lives here so engine.cc stays plain C++).
 namespace {
 int grid_for_scan(uint64_t chunks) {
-  // memory-bound streaming: ~8 workgroups of 256 threads per CU, grid-stride the rest
-  const uint64_t waves = chunks;
-  uint64_t blocks = (waves + 3) / 4;
-  if (blocks > 256u * 8u) blocks = 256u * 8u;
+  // Measured on MI355X (tools/ab_probe.py): a grid of exactly the resident workgroups
+  // (2048) loses ~12% to the partially filled last round; large texts stream best with
+  // >= 16 Ki workgroups (6.2-6.4 TB/s), while every wave should still own >= ~32 chunks so
+  // that its hit staging amortises (500 MB: 4 Ki workgroups).
+  uint64_t blocks = chunks / 128;
+  if (blocks > 16384) blocks = 16384;
+  if (blocks < 256) blocks = (chunks + 3) / 4 < 256 ? (chunks + 3) / 4 : 256;
   if (blocks == 0) blocks = 1;
   return static_cast<int>(blocks);
 }
 }  // namespace
 
-template <bool TWO, bool MASKED>
+template <bool TWO, bool MASKED, bool TWOLEVEL>
 static void launch_windows_k(int k, const ScanParams& a, const WindowSet& ws, int grid, hipStream_t st) {
   // K is rounded up to an instantiated size; the host pads the window set with copies
-  if (k <= 1) hipLaunchKernelGGL((scan_windows<1, TWO, MASKED>), dim3(grid), dim3(256), 0, st, a, ws);
-  else if (k == 2) hipLaunchKernelGGL((scan_windows<2, TWO, MASKED>), dim3(grid), dim3(256), 0, st, a, ws);
-  else if (k == 3) hipLaunchKernelGGL((scan_windows<3, TWO, MASKED>), dim3(grid), dim3(256), 0, st, a, ws);
-  else if (k == 4) hipLaunchKernelGGL((scan_windows<4, TWO, MASKED>), dim3(grid), dim3(256), 0, st, a, ws);
-  else if (k <= 6) hipLaunchKernelGGL((scan_windows<6, TWO, MASKED>), dim3(grid), dim3(256), 0, st, a, ws);
-  else hipLaunchKernelGGL((scan_windows<8, TWO, MASKED>), dim3(grid), dim3(256), 0, st, a, ws);
+  if (k <= 1) hipLaunchKernelGGL((scan_windows<1, TWO, MASKED, TWOLEVEL>), dim3(grid), dim3(256), 0, st, a, ws);
+  else if (k == 2) hipLaunchKernelGGL((scan_windows<2, TWO, MASKED, TWOLEVEL>), dim3(grid), dim3(256), 0, st, a, ws);
+  else if (k == 3) hipLaunchKernelGGL((scan_windows<3, TWO, MASKED, TWOLEVEL>), dim3(grid), dim3(256), 0, st, a, ws);
+  else if (k == 4) hipLaunchKernelGGL((scan_windows<4, TWO, MASKED, TWOLEVEL>), dim3(grid), dim3(256), 0, st, a, ws);
+  else if (k <= 6) hipLaunchKernelGGL((scan_windows<6, TWO, MASKED, TWOLEVEL>), dim3(grid), dim3(256), 0, st, a, ws);
+  else hipLaunchKernelGGL((scan_windows<8, TWO, MASKED, TWOLEVEL>), dim3(grid), dim3(256), 0, st, a, ws);
 }
 
 void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows, hipStream_t st) {
   if (a.whi <= a.wlo) return;
   const uint64_t chunks = (a.whi + kChunk - 1) / kChunk - a.wlo / kChunk;
-  const int grid = grid_for_scan(chunks);
+  int grid = grid_for_scan(chunks);
+  static const char* env_grid = getenv("RJ_SCAN_GRID");
+  if (env_grid) grid = atoi(env_grid);
+  static const char* env_simple = getenv("RJ_SCAN_SIMPLE");
+  if (env_simple && n_windows == 1) {  // measurement variant, K = 1 only
+    if (ws.len > 4) hipLaunchKernelGGL((scan_windows_simple<1, true, true, true>), dim3(grid), dim3(256), 0, st, a, ws);
+    else hipLaunchKernelGGL((scan_windows_simple<1, false, false, false>), dim3(grid), dim3(256), 0, st, a, ws);
+    return;
+  }
   const bool two = ws.len > 4;
   if (two) {
-    if (ws.masked) launch_windows_k<true, true>(n_windows, a, ws, grid, st);
-    else launch_windows_k<true, false>(n_windows, a, ws, grid, st);
+    if (ws.two_level) {
+      if (ws.masked) launch_windows_k<true, true, true>(n_windows, a, ws, grid, st);
+      else launch_windows_k<true, false, true>(n_windows, a, ws, grid, st);
+    } else {
+      if (ws.masked) launch_windows_k<true, true, false>(n_windows, a, ws, grid, st);
+      else launch_windows_k<true, false, false>(n_windows, a, ws, grid, st);
+    }
   } else {
-    if (ws.masked) launch_windows_k<false, true>(n_windows, a, ws, grid, st);
-    else launch_windows_k<false, false>(n_windows, a, ws, grid, st);
+    if (ws.masked) launch_windows_k<false, true, false>(n_windows, a, ws, grid, st);
+    else launch_windows_k<false, false, false>(n_windows, a, ws, grid, st);
   }
 }
 
@@ -719,15 +808,17 @@ void launch_verify(const VerifyParams& a, const DevProgram& P, uint64_t expected
   const int W = P.n_words;
   if (W <= 4) {
     uint64_t blocks = (expected_hits + 255) / 256;
-    if (blocks < 1) blocks = 1;
+    if (blocks < 4) blocks = 4;
     if (blocks > 2048) blocks = 2048;
+    blocks = (blocks + 3) / 4 * 4;  // waves must be a multiple of kHitSegs
     if (W <= 2) hipLaunchKernelGGL((verify_lane<1>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, a, P);
     else hipLaunchKernelGGL((verify_lane<2>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, a, P);
     return;
   }
   uint64_t blocks = (expected_hits + 3) / 4;
-  if (blocks < 1) blocks = 1;
+  if (blocks < 4) blocks = 4;
   if (blocks > 2048) blocks = 2048;
+  blocks = (blocks + 3) / 4 * 4;
   const unsigned g = static_cast<unsigned>(blocks);
   if (W <= 64) hipLaunchKernelGGL((verify_wave<1>), dim3(g), dim3(256), 0, st, a, P);
   else if (W <= 128) hipLaunchKernelGGL((verify_wave<2>), dim3(g), dim3(256), 0, st, a, P);
