@@ -58,6 +58,9 @@ def parse_args():
     ap.add_argument("--no-extra", action="store_true", help="skip the literal_scan extra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=64)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for "
+                    "functional tests of the multi-rank path on a 1-GPU box together with --same-device")
+    ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -102,11 +105,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where collective buffers live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     rejit_amd.build()
     patterns = W.REGEXDNA_PATTERNS
@@ -127,7 +136,7 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     torch.cuda.synchronize(dev)
 
-    counts_dev = torch.zeros(len(patterns), dtype=torch.int64, device=dev)
+    counts_dev = torch.zeros(len(patterns), dtype=torch.int64, device=cdev)
     scan_ms = []
 
     def step(record: bool):
@@ -157,7 +166,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -60,6 +60,8 @@ typedef struct {
   float total_ms;          /* HIP-event time of the whole device pipeline            */
   int32_t retries;         /* runs repeated because a device list had to grow        */
   int32_t large_path;      /* 1 when the rocPRIM sort path was taken                 */
+  int32_t exact_path;      /* 1 when the one-lane exact kernel replaced the result   */
+  int32_t reserved;
 } rj_stats;
 
 /* ---- compile (replaces Regej::Regej + Regej::Compile, src/rejit.cc:127-137,229-267) */

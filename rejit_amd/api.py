@@ -61,7 +61,7 @@ class _Info(ctypes.Structure):
 class _Stats(ctypes.Structure):
     _fields_ = [("n_hits", ctypes.c_uint64), ("n_candidates", ctypes.c_uint64), ("n_matches", ctypes.c_uint64),
                 ("scan_ms", ctypes.c_float), ("total_ms", ctypes.c_float), ("retries", ctypes.c_int32),
-                ("large_path", ctypes.c_int32)]
+                ("large_path", ctypes.c_int32), ("exact_path", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 _lib = None

@@ -45,6 +45,25 @@ struct DevProgram {
   const uint32_t* cls;
 };
 
+// The NFA graph for the exact sequential kernel (reference ring semantics).
+//   byte edge e: src/dst state, len > 0: literal bytes lit[off .. off+len); len == 0: one byte
+//   out of the 256-bit class cls[off*8 .. off*8+8)
+//   control edge: kind 0 epsilon, 1 start-of-line, 2 end-of-line
+struct DevGraph {
+  int32_t n_states, entry, exit;
+  int32_t n_byte_edges, n_control_edges;
+  int32_t times;  // 1 + min(longest literal edge, 64)
+  const int32_t* be_src;
+  const int32_t* be_dst;
+  const int32_t* be_len;
+  const int32_t* be_off;
+  const uint8_t* lit;
+  const uint32_t* cls;
+  const int32_t* ce_src;
+  const int32_t* ce_dst;
+  const int32_t* ce_kind;
+};
+
 RJ_HD bool rj_line_break(uint32_t c) { return c == '\n' || c == '\r'; }
 
 // Context at text position p: bit0 start-of-line, bit1 end-of-line

@@ -93,6 +93,8 @@ struct rj_program {
   std::unique_ptr<Program> host;
   DevProgram dev{};
   DeviceBuffer tables;
+  DevGraph graph{};        // uploaded only for patterns with q8_risk
+  DeviceBuffer graph_blob;
   int device = 0;
   int window_alphabet = 0;  // distinct byte values among the fixed window bytes
   std::string pattern;
@@ -102,6 +104,7 @@ struct rj_scan {
   const rj_program* prog = nullptr;
   DeviceBuffer counters, hits, cand_begin, cand_end, out, keys_out, vals_out, sort_tmp, flag;
   DeviceBuffer scan_a, scan_b, taken;  // large-path selection scratch
+  DeviceBuffer ring;                   // exact sequential kernel
   uint64_t hits_cap = 0, cands_cap = 0, out_cap = 0;
   unsigned long long* host_counters = nullptr;  // pinned
   int* host_flag = nullptr;                     // pinned
@@ -184,6 +187,71 @@ int upload_program(rj_program* rp) {
   D.row_of = reinterpret_cast<const int32_t*>(base + off_rowof);
   D.rows = base + off_rows;
   D.cls = base + off_cls;
+  if (P.q8_risk) {
+    // graph for the exact sequential kernel: int32 arrays, then class bitmaps, then literal bytes
+    const Graph& g = P.graph;
+    const size_t nb = g.byte_edges.size(), nc = g.control_edges.size();
+    std::vector<int32_t> ints;
+    std::vector<uint32_t> classes;
+    std::string lits;
+    std::vector<int32_t> be_src, be_dst, be_len, be_off, ce_src, ce_dst, ce_kind;
+    size_t longest = 1;
+    for (const ByteEdge& e : g.byte_edges) {
+      be_src.push_back(e.src);
+      be_dst.push_back(e.dst);
+      if (!e.bytes.empty()) {
+        be_len.push_back(static_cast<int32_t>(e.bytes.size()));
+        be_off.push_back(static_cast<int32_t>(lits.size()));
+        lits += e.bytes;
+        longest = std::max(longest, e.bytes.size());
+      } else {
+        be_len.push_back(0);
+        be_off.push_back(static_cast<int32_t>(classes.size() / 8));
+        for (int k = 0; k < 8; k++) classes.push_back(e.cls.w[k]);
+      }
+    }
+    for (const ControlEdge& c : g.control_edges) {
+      ce_src.push_back(c.src);
+      ce_dst.push_back(c.dst);
+      ce_kind.push_back(c.kind == ControlKind::Epsilon ? 0 : c.kind == ControlKind::StartOfLine ? 1 : 2);
+    }
+    const size_t words = 4 * nb + 3 * nc + classes.size();
+    const size_t bytes = words * 4 + lits.size() + 16;
+    std::vector<uint8_t> gb(bytes, 0);
+    uint32_t* w = reinterpret_cast<uint32_t*>(gb.data());
+    size_t o = 0;
+    auto put = [&](const std::vector<int32_t>& v) {
+      size_t at = o;
+      if (!v.empty()) memcpy(w + o, v.data(), v.size() * 4);
+      o += v.size();
+      return at;
+    };
+    const size_t o_src = put(be_src), o_dst = put(be_dst), o_len = put(be_len), o_off = put(be_off);
+    const size_t o_cs = put(ce_src), o_cd = put(ce_dst), o_ck = put(ce_kind);
+    const size_t o_cls = o;
+    if (!classes.empty()) memcpy(w + o, classes.data(), classes.size() * 4);
+    o += classes.size();
+    if (!lits.empty()) memcpy(gb.data() + o * 4, lits.data(), lits.size());
+    RJ_HIP(rp->graph_blob.reserve(bytes));
+    RJ_HIP(hipMemcpy(rp->graph_blob.p, gb.data(), bytes, hipMemcpyHostToDevice));
+    const uint32_t* gbase = rp->graph_blob.as<uint32_t>();
+    DevGraph& G = rp->graph;
+    G.n_states = g.n_states;
+    G.entry = g.entry;
+    G.exit = g.exit;
+    G.n_byte_edges = static_cast<int32_t>(nb);
+    G.n_control_edges = static_cast<int32_t>(nc);
+    G.times = 1 + static_cast<int32_t>(std::min<size_t>(longest, 64));
+    G.be_src = reinterpret_cast<const int32_t*>(gbase + o_src);
+    G.be_dst = reinterpret_cast<const int32_t*>(gbase + o_dst);
+    G.be_len = reinterpret_cast<const int32_t*>(gbase + o_len);
+    G.be_off = reinterpret_cast<const int32_t*>(gbase + o_off);
+    G.ce_src = reinterpret_cast<const int32_t*>(gbase + o_cs);
+    G.ce_dst = reinterpret_cast<const int32_t*>(gbase + o_cd);
+    G.ce_kind = reinterpret_cast<const int32_t*>(gbase + o_ck);
+    G.cls = gbase + o_cls;
+    G.lit = reinterpret_cast<const uint8_t*>(gbase + o);
+  }
   return RJ_OK;
 }
 
@@ -218,6 +286,9 @@ int finalize_large(rj_scan* s, uint64_t n_cands, uint64_t text_len, const Finali
   RJ_HIP(s->sort_tmp.reserve(std::max<size_t>(tmp_bytes, 16)));
   RJ_HIP(rocprim::radix_sort_pairs(s->sort_tmp.p, tmp_bytes, kin, s->keys_out.as<uint64_t>(), vin,
                                    s->vals_out.as<uint64_t>(), n_cands, 0, bits, st));
+  if (fp.detect_adjacent)
+    launch_detect_adjacent(s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), n_cands,
+                           s->counters.as<unsigned long long>(), st);
   // common case: the sorted candidates already are the result
   *s->host_flag = 1;
   RJ_HIP(hipMemcpyAsync(s->flag.p, s->host_flag, sizeof(int), hipMemcpyHostToDevice, st));
@@ -226,6 +297,9 @@ int finalize_large(rj_scan* s, uint64_t n_cands, uint64_t text_len, const Finali
   RJ_HIP(hipMemcpyAsync(s->host_flag, s->flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
   RJ_HIP(hipStreamSynchronize(st));
   RJ_HIP(hipGetLastError());
+  if (fp.detect_adjacent)
+    RJ_HIP(hipMemcpy(s->host_counters + kCntAdjacent, s->counters.as<unsigned long long>() + kCntAdjacent,
+                     sizeof(unsigned long long), hipMemcpyDeviceToHost));
   if (*s->host_flag == 1) {
     s->result_count = n_cands;
     return RJ_OK;
@@ -273,6 +347,8 @@ int finalize_large(rj_scan* s, uint64_t n_cands, uint64_t text_len, const Finali
   s->result_count = s->host_counters[kCntFinal];
   return RJ_OK;
 }
+
+constexpr uint64_t kExactLimit = 1u << 20;  // bytes the one-lane exact kernel is allowed to walk
 
 int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, uint64_t carry_cur,
                  uint64_t carry_prev_end, int have_prev, hipStream_t st) {
@@ -361,6 +437,10 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     fp.carry_cur = carry_cur;
     fp.carry_prev_end = carry_prev_end;
     fp.have_prev = have_prev;
+    // bit-exactness with the reference's ring artefact (Q8) can only be at stake when the
+    // pattern is at risk AND a candidate begins exactly where another one ends
+    const bool whole_text = sb == 0 && se == n + 1 && carry_cur == 0 && !have_prev;
+    fp.detect_adjacent = rp->host->q8_risk && whole_text;
     launch_finalize_small(fp, st);
     RJ_HIP(hipEventRecord(s->ev[3], st));
     RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -391,6 +471,19 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       if (rc != RJ_OK) return rc;
     } else {
       s->result_count = s->host_counters[kCntFinal];
+    }
+    if (fp.detect_adjacent && s->host_counters[kCntAdjacent] != 0 && n <= kExactLimit) {
+      // run the reference's own sequential algorithm on one lane and take ITS answer
+      RJ_HIP(s->ring.reserve(static_cast<size_t>(rp->graph.times) * rp->graph.n_states * sizeof(int64_t)));
+      rc = ensure_lists(s, s->hits_cap, std::max<uint64_t>(s->cands_cap, n + 2));
+      if (rc != RJ_OK) return rc;
+      launch_exact_sequential(d_text, n, rp->graph, s->ring.as<int64_t>(), s->out.as<uint64_t>(), s->out_cap,
+                              s->counters.as<unsigned long long>(), st);
+      RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+      RJ_HIP(hipStreamSynchronize(st));
+      RJ_HIP(hipGetLastError());
+      s->result_count = s->host_counters[kCntFinal];
+      s->stats.exact_path = 1;
     }
     s->stats.n_matches = s->result_count;
     s->result = s->out.as<uint64_t>();

@@ -14,7 +14,7 @@ namespace rejit_amd {
 // counter sustains only ~90 atomics/us (MI355X_MICROARCH.md "dequeue": shard the head), and
 // with 64 Ki waves each flushing at least once that was the whole kernel time.
 constexpr int kHitSegs = 16;
-enum { kCntCands = 0, kCntFinal = 1, kCntOverflow = 2, kCntHits = 8, kCntSize = 8 + kHitSegs };
+enum { kCntCands = 0, kCntFinal = 1, kCntOverflow = 2, kCntAdjacent = 3, kCntHits = 8, kCntSize = 8 + kHitSegs };
 
 constexpr int kFinalizeCap = 2048;  // candidates the single-workgroup finalize sorts in LDS
 
@@ -60,6 +60,7 @@ struct FinalizeParams {
   uint64_t carry_cur;       // smallest begin the first match may have
   uint64_t carry_prev_end;  // end of the previous match (zero-length rule)
   int have_prev;
+  int detect_adjacent;      // set counters[kCntAdjacent] when a candidate begins where another ends
 };
 
 void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows, hipStream_t st);
@@ -71,6 +72,12 @@ void launch_finalize_small(const FinalizeParams& a, hipStream_t st);
 // valid result (pairwise disjoint, no empty match, first begin >= carry_cur)
 void launch_check_and_interleave(const uint64_t* keys, const uint64_t* vals, uint64_t n, uint64_t carry_cur,
                                  uint64_t* out, uint64_t cap, int* flag, hipStream_t st);
+// counters[kCntAdjacent] = 1 when some non-empty candidate ends exactly where another begins
+void launch_detect_adjacent(const uint64_t* keys, const uint64_t* vals, uint64_t n, unsigned long long* counters,
+                            hipStream_t st);
+// the reference's no-fast-forward algorithm on one lane (exact incl. its ring-slot artefact)
+void launch_exact_sequential(const uint8_t* text, uint64_t n, const DevGraph& G, int64_t* ring, uint64_t* out,
+                             uint64_t out_cap, unsigned long long* counters, hipStream_t st);
 void launch_select_walk(const uint64_t* keys, const uint64_t* vals, const uint64_t* pmax, uint64_t n,
                         uint64_t carry_cur, uint8_t* taken, hipStream_t st);
 void launch_taken_index(const uint8_t* taken, uint64_t n, uint64_t* idx, hipStream_t st);

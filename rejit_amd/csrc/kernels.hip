@@ -624,6 +624,18 @@ __global__ __launch_bounds__(1024) void finalize_small(FinalizeParams a) {
       __syncthreads();
     }
   }
+  if (a.detect_adjacent) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const uint64_t e = val[i];
+      if (e <= key[i]) continue;
+      int lo = 0, hi = n;  // first index with key >= e
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (key[mid] < e) lo = mid + 1; else hi = mid;
+      }
+      if (lo < n && key[lo] == e) a.counters[kCntAdjacent] = 1;
+    }
+  }
   // fast exit: pairwise disjoint, no duplicates, no empty matches -> selection is the identity
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const bool ok = val[i] > key[i] && (i == 0 || key[i] >= val[i - 1]);
@@ -726,6 +738,115 @@ __global__ void compact_kept(const uint64_t* keys, const uint64_t* vals, const u
     }
   }
   if (i == n - 1) counters[kCntFinal] = pos[i] + keep[i];
+}
+
+__global__ void detect_adjacent(const uint64_t* keys, const uint64_t* vals, uint64_t n, unsigned long long* counters) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t e = vals[i];
+  if (e <= keys[i]) return;
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < e) lo = mid + 1; else hi = mid;
+  }
+  if (lo < n && keys[lo] == e) counters[kCntAdjacent] = 1;
+}
+
+// The reference's no-fast-forward kMatchAll loop, restated for ONE lane: a ring of
+// times x states start offsets (GenerateMatchDirection, codegen-x64.cc:535-640; SetState
+// :951-987 "left-most start wins"; CheckMatch + ClearStates :401-466,1075-1097; the sink
+// MatchAllAppendFilter, src/codegen.cc:36-86).  It exists for bit-exactness only: it reproduces
+// the ring-slot artefact "Q8"  that the parallel pipeline -- which
+// implements the documented semantics -- does not, and runs only when a pattern can hit that
+// artefact AND two candidates are adjacent.  Sequential by nature: ~1 us per text byte.
+__global__ void exact_sequential(const uint8_t* t, uint64_t n, DevGraph G, int64_t* ring, uint64_t* out,
+                                 uint64_t out_cap, unsigned long long* counters) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int S = G.n_states, T = G.times;
+  const int slots = S * T;
+  for (int i = 0; i < slots; i++) ring[i] = -1;
+  int base = 0;
+  unsigned long long out_n = 0;
+  bool pending = false;
+  int64_t pb = 0, pe = 0;
+  auto at = [&](int time, int st) -> int64_t& {
+    int tt = base + time;
+    if (tt >= T) tt -= T;
+    return ring[tt * S + st];
+  };
+  auto emit = [&](int64_t b, int64_t e) {
+    while (out_n > 0 && static_cast<int64_t>(out[2 * (out_n - 1)]) >= b) out_n--;
+    if (b == e && out_n > 0 && static_cast<int64_t>(out[2 * (out_n - 1) + 1]) == b) return;
+    if (out_n < out_cap) {
+      out[2 * out_n] = static_cast<uint64_t>(b);
+      out[2 * out_n + 1] = static_cast<uint64_t>(e);
+    }
+    out_n++;
+  };
+  for (uint64_t p = 0;; p++) {
+    if (pending) {
+      emit(pb, pe);
+      pending = false;
+      if (static_cast<uint64_t>(pe) == n) break;
+    }
+    at(0, G.entry) = static_cast<int64_t>(p);
+    bool changed = true;
+    while (changed) {
+      changed = false;
+      for (int i = 0; i < G.n_control_edges; i++) {
+        const int64_t v = at(0, G.ce_src[i]);
+        if (v < 0) continue;
+        const int kind = G.ce_kind[i];
+        bool ok = true;
+        if (kind == 1) ok = p == 0 || rj_line_break(t[p - 1]);
+        else if (kind == 2) ok = p == n || rj_line_break(t[p]);
+        if (!ok) continue;
+        int64_t& tgt = at(0, G.ce_dst[i]);
+        if (tgt < 0 || v < tgt) {
+          tgt = v;
+          changed = true;
+        }
+      }
+    }
+    const int64_t xs = at(0, G.exit);
+    if (xs >= 0) {
+      pending = true;
+      pb = xs;
+      pe = static_cast<int64_t>(p);
+      for (int i = 0; i < slots; i++)
+        if (ring[i] > xs && ring[i] < pe) ring[i] = -1;
+    }
+    if (p == n) {
+      if (pending) emit(pb, pe);
+      break;
+    }
+    for (int i = 0; i < G.n_byte_edges; i++) {
+      const int64_t v = at(0, G.be_src[i]);
+      if (v < 0) continue;
+      const int len = G.be_len[i];
+      int land = 0;
+      if (len > 0) {
+        if (p + static_cast<uint64_t>(len) <= n) {
+          const uint8_t* lit = G.lit + G.be_off[i];
+          bool eq = true;
+          for (int k = 0; k < len && eq; k++) eq = t[p + k] == lit[k];
+          if (eq) land = len;
+        }
+      } else {
+        const uint32_t c = t[p];
+        if ((G.cls[G.be_off[i] * 8 + (c >> 5)] >> (c & 31)) & 1u) land = 1;
+      }
+      if (land) {
+        int64_t& tgt = at(land, G.be_dst[i]);
+        if (tgt < 0 || v < tgt) tgt = v;
+      }
+    }
+    for (int s = 0; s < S; s++) at(0, s) = -1;
+    base++;
+    if (base >= T) base -= T;
+  }
+  counters[kCntFinal] = out_n;
 }
 
 // Large path, common case in one kernel: emit the sorted candidates as pairs and find out
@@ -841,6 +962,17 @@ void launch_check_and_interleave(const uint64_t* keys, const uint64_t* vals, uin
   if (n == 0) return;
   hipLaunchKernelGGL(check_and_interleave, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, keys, vals, n,
                      carry_cur, out, cap, flag);
+}
+
+void launch_detect_adjacent(const uint64_t* keys, const uint64_t* vals, uint64_t n, unsigned long long* counters,
+                            hipStream_t st) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(detect_adjacent, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, keys, vals, n, counters);
+}
+
+void launch_exact_sequential(const uint8_t* text, uint64_t n, const DevGraph& G, int64_t* ring, uint64_t* out,
+                             uint64_t out_cap, unsigned long long* counters, hipStream_t st) {
+  hipLaunchKernelGGL(exact_sequential, dim3(1), dim3(64), 0, st, text, n, G, ring, out, out_cap, counters);
 }
 
 static unsigned blocks_for(uint64_t n) { return static_cast<unsigned>((n + 255) / 256); }

@@ -584,6 +584,33 @@ LowerResult lower(const char* regexp) {
     r.status = -2;
     return r;
   }
+  // Q8 risk: closure(entry) \ {entry} intersects the closure of some byte-edge destination
+  {
+    std::vector<std::vector<int>> adj(static_cast<size_t>(g.n_states));
+    for (const ControlEdge& c : g.control_edges) adj[static_cast<size_t>(c.src)].push_back(c.dst);
+    auto reach = [&](const std::vector<int>& seeds) {
+      std::vector<char> seen(static_cast<size_t>(g.n_states), 0);
+      std::vector<int> stack = seeds;
+      for (int s0 : seeds) seen[static_cast<size_t>(s0)] = 1;
+      while (!stack.empty()) {
+        int s0 = stack.back();
+        stack.pop_back();
+        for (int d : adj[static_cast<size_t>(s0)])
+          if (!seen[static_cast<size_t>(d)]) {
+            seen[static_cast<size_t>(d)] = 1;
+            stack.push_back(d);
+          }
+      }
+      return seen;
+    };
+    std::vector<char> from_entry = reach({g.entry});
+    std::vector<int> landings;
+    for (const ByteEdge& e : g.byte_edges) landings.push_back(e.dst);
+    std::vector<char> from_landing = reach(landings);
+    for (int q = 0; q < g.n_states; q++)
+      if (from_entry[static_cast<size_t>(q)] && from_landing[static_cast<size_t>(q)]) prog->q8_risk = true;  // q may be the entry itself
+  }
+  prog->graph = g;
   bool lit = true;
   std::string bytes;
   find_literal(*pr.root, &bytes, &lit);

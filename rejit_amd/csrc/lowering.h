@@ -148,6 +148,11 @@ struct Program {
   ScanMode mode = ScanMode::Dense;
   std::vector<FFWindow> windows;
   std::string literal;                   // non-empty: the whole pattern is this literal
+  // The NFA graph itself (reference state numbering semantics) and whether the pattern can
+  // hit the reference's "Q8" ring-slot artefact: some state reachable
+  // from the entry state through control edges can also be occupied by an older thread.
+  Graph graph;
+  bool q8_risk = false;
 };
 
 struct LowerResult {

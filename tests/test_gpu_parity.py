@@ -48,18 +48,41 @@ def prog(rj, rx: bytes):
 
 
 def test_golden_vectors(rj, oracle):
-    n = q8 = 0
+    """Bit-exact with the real reference (use_fast_forward=0) on every golden vector --
+    including the 19 random vectors that exercise the reference's ring artefact Q8, which
+    the engine reproduces through its one-lane exact kernel."""
+    n = 0
     for rx, tx, exp_all, exp_full in V.all_matchall_cases():
         p = prog(rj, rx)
         got = p.match_all(tx)
-        if got != exp_all:
-            spec = oracle.match_all_spec(rx, tx)   # documented divergence Q8
-            assert spec != exp_all and got == spec, (rx, tx, got, exp_all)
-            q8 += 1
+        assert got == exp_all, (rx, tx, got, exp_all)
         assert p.count(tx) == len(got)
         assert p.match_full(tx) == bool(exp_full), (rx, tx)
         n += 1
-    assert n > 2500 and q8 <= 19
+    assert n > 2500
+
+
+def test_fresh_random_vs_oracle(rj, oracle):
+    """Seeds that are NOT in the committed fixtures, longer texts (more adjacent matches):
+    the GPU result must equal the strict restatement of the reference bit for bit."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import RegexGen, ALPHABETS
+    rng = random.Random(4242)
+    checked = exact = 0
+    for _ in range(1500):
+        alphabet = rng.choice(ALPHABETS)
+        rx = RegexGen(rng, alphabet).alt(2).encode("latin1")
+        text = "".join(rng.choice(alphabet) for _ in range(rng.choice([5, 40, 150, 400]))).encode("latin1")
+        want = oracle.match_all(rx, text)
+        if isinstance(want, int):
+            continue
+        got = prog(rj, rx).match_all(text)
+        assert got == want, (rx, text)
+        exact += want != oracle.match_all_spec(rx, text)
+        checked += 1
+    assert checked > 1400
+    assert exact > 0   # the artefact does occur in this sample, and is reproduced
 
 
 def test_testcc_expectations(rj):
@@ -155,8 +178,7 @@ def test_dense_and_unbounded_vs_oracle(rj, oracle):
             text = bytes(rng.choice(b"ab\nc>1x") for _ in range(n))
             want = oracle.match_all(rx, text)
             got = prog(rj, rx).match_all(text)
-            if got != want:
-                assert got == oracle.match_all_spec(rx, text), (rx, n)
+            assert got == want, (rx, n)
 
 
 def test_many_matches_large_path(rj, oracle):
@@ -186,7 +208,7 @@ def test_device_scan_shards_and_carry(rj, oracle):
     t = W.random_ascii_numpy(n, seed=3, lo=ord("a"), hi=ord("e"))
     d = torch.from_numpy(t).cuda()
     for rx in (b"abc", b"aa", b"(ab|ba)+", b"a[bc]d?a", b"x*"):
-        want = oracle.match_all_spec(rx, t.tobytes()) if rx == b"x*" else oracle.match_all(rx, t.tobytes())
+        want = oracle.match_all_spec(rx, t.tobytes())   # sharded runs implement the documented semantics
         scan = rj.Scan(prog(rj, rx))
         assert scan.run_tensor(d) == len(want)
         assert scan.spans() == want
