@@ -83,6 +83,19 @@ struct DeviceBuffer {
     if (e == hipSuccess) bytes = want;
     return e;
   }
+  // grow, preserving the first `keep` bytes
+  hipError_t grow_keep(size_t want, size_t keep) {
+    if (want <= bytes) return hipSuccess;
+    void* q = nullptr;
+    size_t cap = std::max(want, bytes * 2);
+    hipError_t e = hipMalloc(&q, cap);
+    if (e != hipSuccess) return e;
+    if (p && keep) e = hipMemcpy(q, p, keep, hipMemcpyDeviceToDevice);
+    if (p) (void)hipFree(p);
+    p = q;
+    bytes = cap;
+    return e;
+  }
   template <class T>
   T* as() const { return static_cast<T*>(p); }
 };
@@ -102,10 +115,12 @@ struct rj_program {
 
 struct rj_scan {
   const rj_program* prog = nullptr;
-  DeviceBuffer counters, hits, cand_begin, cand_end, out, keys_out, vals_out, sort_tmp, flag;
+  DeviceBuffer counters, hits, hit_counts, hit_offsets, cand_begin, cand_end, out, acc_out, keys_out, vals_out, sort_tmp, flag;
   DeviceBuffer scan_a, scan_b, taken;  // large-path selection scratch
   DeviceBuffer ring;                   // exact sequential kernel
-  uint64_t hits_cap = 0, cands_cap = 0, out_cap = 0;
+  uint64_t cands_cap = 0, out_cap = 0;
+  uint32_t region_cap_hint = 64;   // hit-region size that sufficed last time (windows mode)
+  uint64_t hits_hint = 0;          // hits of the previous run (sizes the verify grid)
   unsigned long long* host_counters = nullptr;  // pinned
   int* host_flag = nullptr;                     // pinned
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -255,11 +270,12 @@ int upload_program(rj_program* rp) {
   return RJ_OK;
 }
 
-int ensure_lists(rj_scan* s, uint64_t hits_cap, uint64_t cands_cap) {
-  if (hits_cap > s->hits_cap) {
-    RJ_HIP(s->hits.reserve(hits_cap * sizeof(uint64_t)));
-    s->hits_cap = hits_cap;
-  }
+// Grow-only device lists.  hits: n_regions x region_cap;  candidates: one slot per hit.
+int ensure_lists(rj_scan* s, uint32_t n_regions, uint32_t region_cap, uint64_t cands_cap) {
+  const uint64_t hit_slots = static_cast<uint64_t>(n_regions) * region_cap;
+  RJ_HIP(s->hits.reserve(hit_slots * sizeof(uint64_t)));
+  RJ_HIP(s->hit_counts.reserve(static_cast<size_t>(n_regions) * sizeof(uint32_t)));
+  RJ_HIP(s->hit_offsets.reserve((static_cast<size_t>(n_regions) + 1) * sizeof(uint64_t)));
   if (cands_cap > s->cands_cap) {
     RJ_HIP(s->cand_begin.reserve(cands_cap * sizeof(uint64_t)));
     RJ_HIP(s->cand_end.reserve(cands_cap * sizeof(uint64_t)));
@@ -270,76 +286,70 @@ int ensure_lists(rj_scan* s, uint64_t hits_cap, uint64_t cands_cap) {
   return RJ_OK;
 }
 
-// Large path: more candidates than finalize_small sorts in LDS.
-int finalize_large(rj_scan* s, uint64_t n_cands, uint64_t text_len, const FinalizeParams& fp, hipStream_t st) {
+// Large path: more hit slots than finalize_small handles in LDS.  The slots are already in
+// text order, so no sort: drop the kNoMatch slots, then check / select.
+int finalize_large(rj_scan* s, uint64_t n_slots, const FinalizeParams& fp, hipStream_t st) {
   s->stats.large_path = 1;
-  RJ_HIP(s->keys_out.reserve(n_cands * sizeof(uint64_t)));
-  RJ_HIP(s->vals_out.reserve(n_cands * sizeof(uint64_t)));
-  uint64_t* kin = s->cand_begin.as<uint64_t>();
-  uint64_t* vin = s->cand_end.as<uint64_t>();
-  // begins are < 2^bits: sort only the bits that can differ
-  unsigned bits = 1;
-  while (bits < 64 && (text_len >> bits) != 0) bits++;
-  size_t tmp_bytes = 0;
-  RJ_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, s->keys_out.as<uint64_t>(), vin, s->vals_out.as<uint64_t>(),
-                                   n_cands, 0, bits, st));
-  RJ_HIP(s->sort_tmp.reserve(std::max<size_t>(tmp_bytes, 16)));
-  RJ_HIP(rocprim::radix_sort_pairs(s->sort_tmp.p, tmp_bytes, kin, s->keys_out.as<uint64_t>(), vin,
-                                   s->vals_out.as<uint64_t>(), n_cands, 0, bits, st));
-  if (fp.detect_adjacent)
-    launch_detect_adjacent(s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), n_cands,
-                           s->counters.as<unsigned long long>(), st);
-  // common case: the sorted candidates already are the result
-  *s->host_flag = 1;
-  RJ_HIP(hipMemcpyAsync(s->flag.p, s->host_flag, sizeof(int), hipMemcpyHostToDevice, st));
-  launch_check_and_interleave(s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), n_cands, fp.carry_cur,
-                              s->out.as<uint64_t>(), s->out_cap, s->flag.as<int>(), st);
-  RJ_HIP(hipMemcpyAsync(s->host_flag, s->flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
-  RJ_HIP(hipStreamSynchronize(st));
-  RJ_HIP(hipGetLastError());
-  if (fp.detect_adjacent)
-    RJ_HIP(hipMemcpy(s->host_counters + kCntAdjacent, s->counters.as<unsigned long long>() + kCntAdjacent,
-                     sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  if (*s->host_flag == 1) {
-    s->result_count = n_cands;
-    return RJ_OK;
-  }
-  // general case: cluster-parallel selection
-  //   pmax  = exclusive prefix max of the ends           (scan_a)
-  //   taken = per-cluster sequential walk                 (taken)
-  //   last  = exclusive prefix max of (taken ? i+1 : 0)   (scan_b; cand_begin reused as scratch)
-  //   keep  = taken minus the zero-length rule            (scan_a)
-  //   pos   = exclusive prefix sum of keep                (scan_b)
-  RJ_HIP(s->scan_a.reserve(n_cands * sizeof(uint64_t)));
-  RJ_HIP(s->scan_b.reserve(n_cands * sizeof(uint64_t)));
-  RJ_HIP(s->taken.reserve(n_cands));
+  RJ_HIP(s->keys_out.reserve(n_slots * sizeof(uint64_t)));
+  RJ_HIP(s->vals_out.reserve(n_slots * sizeof(uint64_t)));
+  RJ_HIP(s->scan_a.reserve(n_slots * sizeof(uint64_t)));
+  RJ_HIP(s->scan_b.reserve(n_slots * sizeof(uint64_t)));
   uint64_t* keys = s->keys_out.as<uint64_t>();
   uint64_t* vals = s->vals_out.as<uint64_t>();
   uint64_t* sa = s->scan_a.as<uint64_t>();
   uint64_t* sb = s->scan_b.as<uint64_t>();
-  uint64_t* scratch = s->cand_begin.as<uint64_t>();  // free again after the sort
-  auto scan_max = [&](uint64_t* in, uint64_t* out) -> hipError_t {
+  auto scan = [&](uint64_t* in, uint64_t* out, uint64_t count, bool is_max) -> hipError_t {
     size_t bytes = 0;
-    hipError_t e = rocprim::exclusive_scan(nullptr, bytes, in, out, uint64_t{0}, n_cands, rocprim::maximum<uint64_t>(), st);
+    hipError_t e = is_max ? rocprim::exclusive_scan(nullptr, bytes, in, out, uint64_t{0}, count, rocprim::maximum<uint64_t>(), st)
+                          : rocprim::exclusive_scan(nullptr, bytes, in, out, uint64_t{0}, count, rocprim::plus<uint64_t>(), st);
     if (e != hipSuccess) return e;
     e = s->sort_tmp.reserve(std::max<size_t>(bytes, 16));
     if (e != hipSuccess) return e;
-    return rocprim::exclusive_scan(s->sort_tmp.p, bytes, in, out, uint64_t{0}, n_cands, rocprim::maximum<uint64_t>(), st);
+    return is_max ? rocprim::exclusive_scan(s->sort_tmp.p, bytes, in, out, uint64_t{0}, count, rocprim::maximum<uint64_t>(), st)
+                  : rocprim::exclusive_scan(s->sort_tmp.p, bytes, in, out, uint64_t{0}, count, rocprim::plus<uint64_t>(), st);
   };
-  auto scan_sum = [&](uint64_t* in, uint64_t* out) -> hipError_t {
-    size_t bytes = 0;
-    hipError_t e = rocprim::exclusive_scan(nullptr, bytes, in, out, uint64_t{0}, n_cands, rocprim::plus<uint64_t>(), st);
-    if (e != hipSuccess) return e;
-    e = s->sort_tmp.reserve(std::max<size_t>(bytes, 16));
-    if (e != hipSuccess) return e;
-    return rocprim::exclusive_scan(s->sort_tmp.p, bytes, in, out, uint64_t{0}, n_cands, rocprim::plus<uint64_t>(), st);
-  };
-  RJ_HIP(scan_max(vals, sa));
+  // 1. ordered compaction of the verified candidates
+  launch_mark_valid(s->cand_end.as<uint64_t>(), n_slots, sa, st);
+  RJ_HIP(scan(sa, sb, n_slots, false));
+  launch_compact_valid(s->cand_begin.as<uint64_t>(), s->cand_end.as<uint64_t>(), sa, sb, n_slots, keys, vals,
+                       s->counters.as<unsigned long long>(), st);
+  RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  RJ_HIP(hipStreamSynchronize(st));
+  const uint64_t n_cands = s->host_counters[kCntCands];
+  s->stats.n_candidates = n_cands;
+  if (n_cands == 0) {
+    s->result_count = 0;
+    return RJ_OK;
+  }
+  // 2. common case: the candidates already are the result
+  if (fp.detect_adjacent) launch_detect_adjacent(keys, vals, n_cands, s->counters.as<unsigned long long>(), st);
+  *s->host_flag = 1;
+  RJ_HIP(hipMemcpyAsync(s->flag.p, s->host_flag, sizeof(int), hipMemcpyHostToDevice, st));
+  launch_check_and_interleave(keys, vals, n_cands, fp.carry_cur, s->out.as<uint64_t>(), s->out_cap, s->flag.as<int>(), st);
+  RJ_HIP(hipMemcpyAsync(s->host_flag, s->flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (fp.detect_adjacent)
+    RJ_HIP(hipMemcpyAsync(s->host_counters + kCntAdjacent, s->counters.as<unsigned long long>() + kCntAdjacent,
+                          sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  RJ_HIP(hipStreamSynchronize(st));
+  RJ_HIP(hipGetLastError());
+  if (*s->host_flag == 1) {
+    s->result_count = n_cands;
+    return RJ_OK;
+  }
+  // 3. general case: cluster-parallel selection
+  //   pmax  = exclusive prefix max of the ends            (sa)
+  //   taken = per-cluster sequential walk                  (taken)
+  //   last  = exclusive prefix max of (taken ? i+1 : 0)    (sb; cand_begin reused as scratch)
+  //   keep  = taken minus the zero-length rule             (sa)
+  //   pos   = exclusive prefix sum of keep                 (sb)
+  RJ_HIP(s->taken.reserve(n_cands));
+  uint64_t* scratch = s->cand_begin.as<uint64_t>();
+  RJ_HIP(scan(vals, sa, n_cands, true));
   launch_select_walk(keys, vals, sa, n_cands, fp.carry_cur, s->taken.as<uint8_t>(), st);
   launch_taken_index(s->taken.as<uint8_t>(), n_cands, scratch, st);
-  RJ_HIP(scan_max(scratch, sb));
+  RJ_HIP(scan(scratch, sb, n_cands, true));
   launch_zero_length_rule(keys, vals, s->taken.as<uint8_t>(), sb, n_cands, fp.carry_prev_end, fp.have_prev, sa, st);
-  RJ_HIP(scan_sum(sa, sb));
+  RJ_HIP(scan(sa, sb, n_cands, false));
   launch_compact_kept(keys, vals, sa, sb, n_cands, s->out.as<uint64_t>(), s->out_cap, s->counters.as<unsigned long long>(), st);
   RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   RJ_HIP(hipStreamSynchronize(st));
@@ -349,88 +359,86 @@ int finalize_large(rj_scan* s, uint64_t n_cands, uint64_t text_len, const Finali
 }
 
 constexpr uint64_t kExactLimit = 1u << 20;  // bytes the one-lane exact kernel is allowed to walk
+constexpr uint64_t kDenseSegment = 1ull << 27;  // dense mode: starts per pipeline run (bounds the lists)
 
-int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, uint64_t carry_cur,
-                 uint64_t carry_prev_end, int have_prev, hipStream_t st) {
+// One full pipeline over the starts [sb, se): scan -> region offsets -> verify -> finalize.
+// Results: s->out (device, ordered pairs), s->result_count.
+int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, uint64_t carry_cur,
+              uint64_t carry_prev_end, int have_prev, hipStream_t st) {
   const rj_program* rp = s->prog;
   const DevProgram& D = rp->dev;
-  if (se > n + 1) se = n + 1;
-  s->stats = rj_stats{};
-  s->result = nullptr;
-  s->result_count = 0;
-  if (sb >= se) return RJ_OK;
-  if ((reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) return fail(RJ_BAD_ARGUMENT, "device text must be 16-byte aligned");
-
-  // Dense mode produces a hit for a sizeable fraction of the bytes: walk the starts in
-  // segments so the hit list stays bounded.  Windows mode: one segment.
   const bool windows = D.mode == 1;
-  const uint64_t seg = windows ? (se - sb) : std::min<uint64_t>(se - sb, 1ull << 27);
-  // a workgroup appends to segment (blockIdx % kHitSegs): with few workgroups one segment may
-  // receive everything, so small runs give every segment room for the whole range
-  const uint64_t hits_limit = static_cast<uint64_t>(kHitSegs) * (seg + 64);
-  uint64_t want_hits = windows ? std::max<uint64_t>(1u << 16, (se - sb) / 512)
-                               : (seg <= (1u << 20) ? hits_limit : seg + seg / 8 + 64 * kHitSegs);
-  uint64_t want_cands = std::max<uint64_t>(1u << 16, (se - sb) / 512);
+  s->result_count = 0;
 
-  for (int attempt = 0; attempt < 8; attempt++) {
-    int rc = ensure_lists(s, std::max(want_hits, s->hits_cap), std::max(want_cands, s->cands_cap));
+  // what the scan kernel walks, in 1-KiB chunks
+  ScanParams sp{};
+  sp.text = d_text;
+  sp.n = n;
+  sp.sb = sb;
+  sp.se = se;
+  uint64_t first_chunk, end_chunk;
+  if (windows) {
+    sp.wlo = sb + D.win_offset;
+    const uint64_t last_w = n >= D.win_len ? n - D.win_len + 1 : 0;  // a window must fit: w + len <= n
+    sp.whi = std::min(se + D.win_offset, last_w);
+    if (sp.whi < sp.wlo) sp.whi = sp.wlo;
+    first_chunk = sp.wlo / 1024;
+    end_chunk = (sp.whi + 1023) / 1024;
+  } else {
+    first_chunk = sb / 1024;
+    end_chunk = (se + 1023) / 1024;
+  }
+  const uint64_t chunks = end_chunk > first_chunk ? end_chunk - first_chunk : 0;
+  const ScanGeometry geo = scan_geometry(std::max<uint64_t>(chunks, 1));
+  sp.span_chunks = geo.span_chunks;
+  // dense: any position may be a hit; windows: start small, grow on overflow
+  const uint64_t region_full = geo.span_chunks * 1024;
+  uint64_t region_cap = windows ? std::min<uint64_t>(std::max<uint64_t>(s->region_cap_hint, 64), region_full) : region_full;
+
+  for (int attempt = 0; attempt < 6; attempt++) {
+    const uint64_t slots = static_cast<uint64_t>(geo.n_regions) * region_cap;
+    int rc = ensure_lists(s, geo.n_regions, static_cast<uint32_t>(region_cap), std::max<uint64_t>(slots, 1u << 12));
     if (rc != RJ_OK) return rc;
+    sp.hits = s->hits.as<uint64_t>();
+    sp.region_cap = static_cast<uint32_t>(region_cap);
+    sp.hit_counts = s->hit_counts.as<uint32_t>();
     RJ_HIP(hipMemsetAsync(s->counters.p, 0, kCntSize * sizeof(unsigned long long), st));
-    RJ_HIP(hipEventRecord(s->ev[0], st));
-    float scan_ms_total = 0.f;
-    (void)scan_ms_total;
-    for (uint64_t lo = sb; lo < se; lo += seg) {
-      const uint64_t hi = std::min(se, lo + seg);
-      if (lo != sb)
-        RJ_HIP(hipMemsetAsync(s->counters.as<unsigned long long>() + kCntHits, 0, kHitSegs * sizeof(unsigned long long), st));
-      ScanParams sp{};
-      sp.text = d_text;
-      sp.n = n;
-      sp.sb = lo;
-      sp.se = hi;
-      sp.hits = s->hits.as<uint64_t>();
-      sp.hits_cap = s->hits_cap;
-      sp.counters = s->counters.as<unsigned long long>();
-      if (lo == sb) RJ_HIP(hipEventRecord(s->ev[1], st));
-      if (windows) {
-        WindowSet ws{};
-        bool masked = false;
-        for (int k = 0; k < kDevMaxWindows; k++) {
-          ws.value0[k] = D.win_value0[k];
-          ws.mask0[k] = D.win_mask0[k];
-          ws.value1[k] = D.win_value1[k];
-          ws.mask1[k] = D.win_mask1[k];
-          masked |= D.win_mask0[k] != 0xFFFFFFFFu || (D.win_len > 4 && D.win_mask1[k] != 0xFFFFFFFFu);
-        }
-        ws.masked = masked;
-        ws.two_level = rp->window_alphabet > 4;
-        ws.len = D.win_len;
-        ws.offset = D.win_offset;
-        sp.wlo = lo + D.win_offset;
-        // a window must fit into the text: w + win_len <= n
-        const uint64_t last_w = n >= D.win_len ? n - D.win_len + 1 : 0;
-        sp.whi = std::min(hi + D.win_offset, last_w);
-        launch_scan_windows(sp, ws, D.n_windows, st);
-      } else {
-        launch_scan_dense(sp, D, st);
+    RJ_HIP(hipEventRecord(s->ev[1], st));
+    if (windows) {
+      WindowSet ws{};
+      bool masked = false;
+      for (int k = 0; k < kDevMaxWindows; k++) {
+        ws.value0[k] = D.win_value0[k];
+        ws.mask0[k] = D.win_mask0[k];
+        ws.value1[k] = D.win_value1[k];
+        ws.mask1[k] = D.win_mask1[k];
+        masked |= D.win_mask0[k] != 0xFFFFFFFFu || (D.win_len > 4 && D.win_mask1[k] != 0xFFFFFFFFu);
       }
-      if (hi == se) RJ_HIP(hipEventRecord(s->ev[2], st));
-      VerifyParams vp{};
-      vp.text = d_text;
-      vp.n = n;
-      vp.hits = s->hits.as<uint64_t>();
-      vp.hits_cap = s->hits_cap;
-      vp.cand_begin = s->cand_begin.as<uint64_t>();
-      vp.cand_end = s->cand_end.as<uint64_t>();
-      vp.cands_cap = s->cands_cap;
-      vp.counters = s->counters.as<unsigned long long>();
-      launch_verify(vp, D, windows ? 65536 : (hi - lo) / 8 + 1, st);
+      ws.masked = masked;
+      ws.two_level = rp->window_alphabet > 4;
+      ws.len = D.win_len;
+      ws.offset = D.win_offset;
+      launch_scan_windows(sp, ws, D.n_windows, geo.grid, st);
+    } else {
+      launch_scan_dense(sp, D, geo.grid, st);
     }
+    RJ_HIP(hipEventRecord(s->ev[2], st));
+    launch_region_offsets(s->hit_counts.as<uint32_t>(), geo.n_regions, static_cast<uint32_t>(region_cap),
+                          s->hit_offsets.as<uint64_t>(), s->counters.as<unsigned long long>(), st);
+    VerifyParams vp{};
+    vp.text = d_text;
+    vp.n = n;
+    vp.hits = s->hits.as<uint64_t>();
+    vp.offsets = s->hit_offsets.as<uint64_t>();
+    vp.n_regions = geo.n_regions;
+    vp.region_cap = static_cast<uint32_t>(region_cap);
+    vp.cand_begin = s->cand_begin.as<uint64_t>();
+    vp.cand_end = s->cand_end.as<uint64_t>();
+    launch_verify(vp, D, windows ? std::max<uint64_t>(s->hits_hint, 1u << 14) : (se - sb) / 8 + 1, st);
     FinalizeParams fp{};
     fp.cand_begin = s->cand_begin.as<uint64_t>();
     fp.cand_end = s->cand_end.as<uint64_t>();
     fp.cands_cap = s->cands_cap;
-    fp.hits_cap = s->hits_cap;
     fp.out = s->out.as<uint64_t>();
     fp.out_cap = s->out_cap;
     fp.counters = s->counters.as<unsigned long long>();
@@ -446,36 +454,33 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     RJ_HIP(hipStreamSynchronize(st));
     RJ_HIP(hipGetLastError());
-    unsigned long long n_hits = 0, max_seg = 0;
-    for (int k = 0; k < kHitSegs; k++) {
-      n_hits += s->host_counters[kCntHits + k];
-      max_seg = std::max(max_seg, s->host_counters[kCntHits + k]);
-    }
-    const unsigned long long n_cands = s->host_counters[kCntCands];
-    s->stats.n_hits = n_hits;
-    s->stats.n_candidates = n_cands;
-    (void)hipEventElapsedTime(&s->stats.scan_ms, s->ev[1], s->ev[2]);
-    (void)hipEventElapsedTime(&s->stats.total_ms, s->ev[0], s->ev[3]);
-    if (s->host_counters[kCntOverflow] != 0 || n_cands > s->cands_cap || max_seg > s->hits_cap / kHitSegs) {
-      // grow whichever list overflowed and run again
+    const unsigned long long n_hits = s->host_counters[kCntHits];
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, s->ev[1], s->ev[2]);
+    s->stats.scan_ms += ms;
+    s->stats.n_hits += n_hits;
+    if (s->host_counters[kCntOverflow] != 0) {
+      // a region overflowed: size every region for the fullest one seen (x2) and run again
       s->stats.retries++;
-      // segments fill unevenly: size for the fullest one
-      want_hits = std::max<uint64_t>(s->hits_cap, std::min<uint64_t>(std::max<uint64_t>(max_seg * kHitSegs * 2, s->hits_cap * 4),
-                                                                     hits_limit));
-      want_cands = std::max<uint64_t>(s->cands_cap, std::min<uint64_t>(std::max<uint64_t>(n_cands * 2, s->cands_cap * 4), (se - sb) + 64));
-      if (want_hits == s->hits_cap && want_cands == s->cands_cap) return fail(RJ_DEVICE_ERROR, "device lists cannot grow further");
+      const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(s->host_counters[kCntMaxRegion] * 2, region_cap * 4), region_full);
+      if (want <= region_cap) return fail(RJ_DEVICE_ERROR, "hit regions cannot grow further");
+      region_cap = want;
+      s->region_cap_hint = static_cast<uint32_t>(std::min<uint64_t>(want, 1u << 20));
+      s->stats.n_hits -= n_hits;
       continue;
     }
+    s->hits_hint = n_hits;
     if (s->host_counters[kCntFinal] == ~0ull) {
-      rc = finalize_large(s, n_cands, n + 1, fp, st);
+      rc = finalize_large(s, n_hits, fp, st);
       if (rc != RJ_OK) return rc;
     } else {
       s->result_count = s->host_counters[kCntFinal];
+      s->stats.n_candidates += s->host_counters[kCntCands];
     }
     if (fp.detect_adjacent && s->host_counters[kCntAdjacent] != 0 && n <= kExactLimit) {
       // run the reference's own sequential algorithm on one lane and take ITS answer
       RJ_HIP(s->ring.reserve(static_cast<size_t>(rp->graph.times) * rp->graph.n_states * sizeof(int64_t)));
-      rc = ensure_lists(s, s->hits_cap, std::max<uint64_t>(s->cands_cap, n + 2));
+      rc = ensure_lists(s, geo.n_regions, static_cast<uint32_t>(region_cap), std::max<uint64_t>(s->cands_cap, n + 2));
       if (rc != RJ_OK) return rc;
       launch_exact_sequential(d_text, n, rp->graph, s->ring.as<int64_t>(), s->out.as<uint64_t>(), s->out_cap,
                               s->counters.as<unsigned long long>(), st);
@@ -485,11 +490,56 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       s->result_count = s->host_counters[kCntFinal];
       s->stats.exact_path = 1;
     }
-    s->stats.n_matches = s->result_count;
-    s->result = s->out.as<uint64_t>();
     return RJ_OK;
   }
-  return fail(RJ_DEVICE_ERROR, "device lists kept overflowing");
+  return fail(RJ_DEVICE_ERROR, "hit regions kept overflowing");
+}
+
+int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, uint64_t carry_cur,
+                 uint64_t carry_prev_end, int have_prev, hipStream_t st) {
+  const rj_program* rp = s->prog;
+  if (se > n + 1) se = n + 1;
+  s->stats = rj_stats{};
+  s->result = nullptr;
+  s->result_count = 0;
+  if (sb >= se) return RJ_OK;
+  if ((reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) return fail(RJ_BAD_ARGUMENT, "device text must be 16-byte aligned");
+  RJ_HIP(hipEventRecord(s->ev[0], st));
+  const bool windows = rp->dev.mode == 1;
+  if (windows || se - sb <= kDenseSegment) {
+    int rc = run_range(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
+    if (rc != RJ_OK) return rc;
+    s->result = s->out.as<uint64_t>();
+  } else {
+    // Dense mode over a long range: a hit slot for a sizeable fraction of the bytes would not
+    // fit, so the starts are walked in segments; the selection state is carried from one
+    // segment to the next exactly as between the shards of a multi-GPU run.
+    uint64_t total = 0;
+    for (uint64_t lo = sb; lo < se; lo += kDenseSegment) {
+      const uint64_t hi = std::min(se, lo + kDenseSegment);
+      int rc = run_range(s, d_text, n, lo, hi, carry_cur, carry_prev_end, have_prev, st);
+      if (rc != RJ_OK) return rc;
+      if (s->result_count) {
+        RJ_HIP(s->acc_out.grow_keep((total + s->result_count) * 2 * sizeof(uint64_t), total * 2 * sizeof(uint64_t)));
+        RJ_HIP(hipMemcpyAsync(s->acc_out.as<uint64_t>() + 2 * total, s->out.p, s->result_count * 2 * sizeof(uint64_t),
+                              hipMemcpyDeviceToDevice, st));
+        uint64_t last[2];
+        RJ_HIP(hipMemcpyAsync(last, s->out.as<uint64_t>() + 2 * (s->result_count - 1), sizeof(last), hipMemcpyDeviceToHost, st));
+        RJ_HIP(hipStreamSynchronize(st));
+        carry_cur = last[1] > last[0] ? last[1] : last[0] + 1;
+        carry_prev_end = last[1];
+        have_prev = 1;
+        total += s->result_count;
+      }
+    }
+    s->result_count = total;
+    s->result = s->acc_out.as<uint64_t>();
+  }
+  RJ_HIP(hipEventRecord(s->ev[3], st));
+  RJ_HIP(hipStreamSynchronize(st));
+  (void)hipEventElapsedTime(&s->stats.total_ms, s->ev[0], s->ev[3]);
+  s->stats.n_matches = s->result_count;
+  return RJ_OK;
 }
 
 int scan_init(rj_scan* s) {

@@ -10,11 +10,9 @@
 namespace rejit_amd {
 
 // device counters (unsigned long long[kCntSize])
-// The hit list is split into kHitSegs segments with one counter each: a single device-wide
-// counter sustains only ~90 atomics/us (MI355X_MICROARCH.md "dequeue": shard the head), and
-// with 64 Ki waves each flushing at least once that was the whole kernel time.
-constexpr int kHitSegs = 16;
-enum { kCntCands = 0, kCntFinal = 1, kCntOverflow = 2, kCntAdjacent = 3, kCntHits = 8, kCntSize = 8 + kHitSegs };
+enum { kCntCands = 0, kCntFinal = 1, kCntOverflow = 2, kCntAdjacent = 3, kCntHits = 4, kCntMaxRegion = 5, kCntSize = 8 };
+
+constexpr uint64_t kNoMatch = ~0ull;  // cand_end of a hit at which nothing matches
 
 constexpr int kFinalizeCap = 2048;  // candidates the single-workgroup finalize sorts in LDS
 
@@ -23,9 +21,10 @@ struct ScanParams {
   uint64_t n;
   uint64_t sb, se;       // candidate starts lie in [sb, se), se <= n + 1
   uint64_t wlo, whi;     // window positions scanned (windows mode): [wlo, whi)
-  uint64_t* hits;        // kHitSegs segments of hits_cap / kHitSegs entries
-  uint64_t hits_cap;
-  unsigned long long* counters;
+  uint64_t span_chunks;  // wave w owns chunks [first + w*span, first + (w+1)*span)
+  uint64_t* hits;        // n_regions regions of region_cap entries, region w = wave w
+  uint32_t region_cap;
+  uint32_t* hit_counts;  // [n_regions] hits each wave found (may exceed region_cap)
 };
 
 struct WindowSet {
@@ -41,18 +40,17 @@ struct VerifyParams {
   const uint8_t* text;
   uint64_t n;
   const uint64_t* hits;
-  uint64_t hits_cap;
-  uint64_t* cand_begin;  // candidates, structure of arrays
-  uint64_t* cand_end;
-  uint64_t cands_cap;
-  unsigned long long* counters;
+  const uint64_t* offsets;  // [n_regions + 1], offsets[n_regions] = number of hits
+  uint32_t n_regions;
+  uint32_t region_cap;
+  uint64_t* cand_begin;     // one slot per hit, in hit (= text) order
+  uint64_t* cand_end;       // kNoMatch when nothing matches at that start
 };
 
 struct FinalizeParams {
   const uint64_t* cand_begin;
   const uint64_t* cand_end;
   uint64_t cands_cap;
-  uint64_t hits_cap;
   uint64_t* out;         // (begin,end) pairs, ordered
   uint64_t out_cap;
   unsigned long long* counters;
@@ -63,9 +61,25 @@ struct FinalizeParams {
   int detect_adjacent;      // set counters[kCntAdjacent] when a candidate begins where another ends
 };
 
-void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows, hipStream_t st);
-void launch_scan_dense(const ScanParams& a, const DevProgram& P, hipStream_t st);
+// grid of the scan kernels for a run over `chunks` 1-KiB chunks: workgroups (4 waves each),
+// regions (= waves) and chunks per wave
+struct ScanGeometry {
+  int grid;
+  uint32_t n_regions;
+  uint64_t span_chunks;
+};
+ScanGeometry scan_geometry(uint64_t chunks);
+
+void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows, int grid, hipStream_t st);
+void launch_scan_dense(const ScanParams& a, const DevProgram& P, int grid, hipStream_t st);
+void launch_region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap, uint64_t* offsets,
+                           unsigned long long* counters, hipStream_t st);
 void launch_verify(const VerifyParams& a, const DevProgram& P, uint64_t expected_hits, hipStream_t st);
+// large path: drop the kNoMatch slots, keeping the order
+void launch_mark_valid(const uint64_t* cand_end, uint64_t n, uint64_t* flags, hipStream_t st);
+void launch_compact_valid(const uint64_t* cand_begin, const uint64_t* cand_end, const uint64_t* flags,
+                          const uint64_t* pos, uint64_t n, uint64_t* keys, uint64_t* vals,
+                          unsigned long long* counters, hipStream_t st);
 void launch_match_full(const uint8_t* text, uint64_t n, const DevProgram& P, int* result, hipStream_t st);
 void launch_finalize_small(const FinalizeParams& a, hipStream_t st);
 // writes the sorted candidates as (begin,end) pairs and clears *flag unless they already are a

@@ -46,94 +46,20 @@ constexpr int kChunk = 1024;  // bytes per wave iteration: 64 lanes x 16 B
 
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & (kWave - 1); }
 
-// Append `mine` (valid when pred) to list[] with one atomic per wave; returns nothing.
-__device__ __forceinline__ void wave_append(bool pred, uint64_t mine, uint64_t* list, uint64_t cap,
-                                            unsigned long long* counter) {
-  const unsigned long long m = __ballot(pred);
-  if (m == 0) return;
-  const int lane = lane_id();
-  const int leader = __ffsll(static_cast<long long>(m)) - 1;
-  unsigned long long base = 0;
-  if (lane == leader) base = atomicAdd(counter, static_cast<unsigned long long>(__popcll(m)));
-  base = __shfl(base, leader);
-  if (pred) {
-    const unsigned long long idx = base + __popcll(m & ((1ull << lane) - 1ull));
-    if (idx < cap) list[idx] = mine;
-  }
-}
-
-__device__ __forceinline__ void wave_append_pair(bool pred, uint64_t b, uint64_t e, uint64_t* begins,
-                                                 uint64_t* ends, uint64_t cap, unsigned long long* counter) {
-  const unsigned long long m = __ballot(pred);
-  if (m == 0) return;
-  const int lane = lane_id();
-  const int leader = __ffsll(static_cast<long long>(m)) - 1;
-  unsigned long long base = 0;
-  if (lane == leader) base = atomicAdd(counter, static_cast<unsigned long long>(__popcll(m)));
-  base = __shfl(base, leader);
-  if (pred) {
-    const unsigned long long idx = base + __popcll(m & ((1ull << lane) - 1ull));
-    if (idx < cap) {
-      begins[idx] = b;
-      ends[idx] = e;
-    }
-  }
-}
-
-// Append the positions of the set bits of `mask16` (bit j <-> position at + j - bias) of every
-// lane, in position order, with ONE atomic for the whole wave: wave prefix sum of the
-// per-lane popcounts, then each lane writes its own run.
-__device__ __forceinline__ void wave_append_bits(uint32_t mask16, uint64_t at, uint64_t bias, uint64_t* list,
-                                                 uint64_t cap, unsigned long long* counter) {
-  const int lane = lane_id();
-  const uint32_t cnt = __popc(mask16);
-  uint32_t inc = cnt;
-#pragma unroll
-  for (int o = 1; o < kWave; o <<= 1) {
-    const uint32_t v = __shfl_up(inc, o);
-    if (lane >= o) inc += v;
-  }
-  const uint32_t total = __shfl(inc, kWave - 1);
-  unsigned long long base = 0;
-  if (lane == 0) base = atomicAdd(counter, static_cast<unsigned long long>(total));
-  base = __shfl(base, 0);
-  unsigned long long idx = base + inc - cnt;
-  while (mask16) {
-    const int j = __ffs(static_cast<int>(mask16)) - 1;
-    mask16 &= mask16 - 1;
-    if (idx < cap) list[idx] = at + j - bias;
-    idx++;
-  }
-}
-
-// Per-wave staging buffer in LDS for hit offsets.  A single device-wide counter sustains
-// only ~90 atomics/us (MI355X_MICROARCH.md "dequeue"), so appending chunk by chunk costs
-// ~11 ns per chunk-with-hits -- measured: the regexdna patterns with 20-60k hits per pass ran
-// at 0.7-2.3 TB/s instead of 4.8.  Hits are therefore collected per wave in LDS (position
-// order is kept inside a batch) and flushed with ONE atomic per kHitBuf/2.. hits.
-constexpr int kHitBuf = 256;  // entries per wave (2 KiB)
-
-struct WaveHits {
-  uint64_t* slots;      // LDS, kHitBuf entries of this wave
-  uint32_t count;       // wave-uniform
-  uint64_t* list;       // global hit list
-  uint64_t cap;
-  unsigned long long* counter;
-
-  __device__ __forceinline__ void flush() {
-    if (count == 0) return;
-    const int lane = lane_id();
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(counter, static_cast<unsigned long long>(count));
-    base = __shfl(base, 0);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (uint32_t i = lane; i < count; i += kWave) {
-      const unsigned long long idx = base + i;
-      if (idx < cap) list[idx] = slots[i];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    count = 0;
-  }
+// Hit offsets of one wave go to the wave's own REGION of the hit list: region w = wave w,
+// `cap` entries, filled in position order, no atomics.  Every wave owns a contiguous span of
+// the text, so the regions concatenated in wave order are globally sorted by offset -- which
+// is what lets the rest of the pipeline run without a sort.
+//
+// History (all measured, tools/ab_probe.py): appending chunk by chunk to one global counter ran
+// into the ~90 atomics/us limit of a single address (11 ns per chunk-with-hits); staging 256
+// hits per wave in LDS fixed that but cost one returning atomic per wave, whose latency under
+// a saturated memory pipeline (~20 us) made the kernel slower the more waves it had; 16 sharded
+// counters helped little.  Regions need no atomic at all.
+struct RegionHits {
+  uint64_t* slots;   // this wave's region
+  uint32_t cap;
+  uint32_t count;    // wave-uniform; keeps counting past cap so the host can size a retry
 
   // bit j of mask16 <-> offset at + j - bias; appended in position order
   __device__ __forceinline__ void push_bits(uint32_t mask16, uint64_t at, uint64_t bias) {
@@ -146,29 +72,36 @@ struct WaveHits {
       if (lane >= o) inc += v;
     }
     const uint32_t total = __shfl(inc, kWave - 1);
-    if (total == 0) return;
-    if (count + total > kHitBuf) flush();
-    if (total > kHitBuf) {  // a very dense chunk: straight to the global list
-      wave_append_bits(mask16, at, bias, list, cap, counter);
-      return;
-    }
     uint32_t idx = count + inc - cnt;
     while (mask16) {
       const int j = __ffs(static_cast<int>(mask16)) - 1;
       mask16 &= mask16 - 1;
-      slots[idx++] = at + j - bias;
+      if (idx < cap) slots[idx] = at + j - bias;
+      idx++;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     count += total;
   }
 };
 
-// this wave's staging slots and the hit-list segment (and its counter) of this workgroup
-__device__ __forceinline__ WaveHits make_wave_hits(uint64_t* lds_slots, const ScanParams& a) {
-  const unsigned seg = blockIdx.x % kHitSegs;
-  const uint64_t seg_cap = a.hits_cap / kHitSegs;
-  return WaveHits{lds_slots + (threadIdx.x >> 6) * kHitBuf, 0u, a.hits + seg * seg_cap, seg_cap,
-                  a.counters + kCntHits + seg};
+// geometry shared by the scan kernels: wave w owns chunks [c0, c1)
+struct WaveSpan {
+  uint64_t c0, c1;
+};
+
+__device__ __forceinline__ uint64_t scalar_wave_index() {
+  // as a scalar, so that chunk addresses and loop branches are wave-uniform
+  return __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6));
+}
+
+__device__ __forceinline__ WaveSpan wave_span(const ScanParams& a, uint64_t wave, uint64_t first_chunk,
+                                              uint64_t end_chunk) {
+  WaveSpan w;
+  w.c0 = first_chunk + wave * a.span_chunks;
+  w.c1 = w.c0 + a.span_chunks;
+  if (w.c0 > end_chunk) w.c0 = end_chunk;
+  if (w.c1 > end_chunk) w.c1 = end_chunk;
+  return w;
 }
 
 // 16 B of the lane + the 8 B that follow, guarded against the end of the text (tail chunk).
@@ -197,7 +130,7 @@ __device__ __forceinline__ void load_guarded(const uint8_t* text, uint64_t n, ui
 // One chunk: d[0..3] = the lane's 16 bytes, d[4..5] = the 8 bytes that follow.
 template <int K, bool TWO, bool MASKED, bool TWOLEVEL>
 __device__ __forceinline__ void windows_chunk(const uint32_t (&d)[6], uint64_t at, const ScanParams& a,
-                                              const WindowSet& ws, WaveHits& hits) {
+                                              const WindowSet& ws, RegionHits& hits) {
   constexpr int NX = TWO ? 20 : 16;  // windows needed: 16 positions (+4 for the second dword)
   // the unaligned 4-byte windows of this lane: x[j] = bytes [at+j, at+j+4)
   uint32_t x[NX];
@@ -281,109 +214,74 @@ __device__ __forceinline__ void load_chunk(const uint8_t* text, uint64_t at, uin
 
 template <int K, bool TWO, bool MASKED, bool TWOLEVEL>
 __global__ __launch_bounds__(256) void scan_windows(ScanParams a, WindowSet ws) {
-  __shared__ uint64_t hit_slots[4 * kHitBuf];
-  WaveHits hits = make_wave_hits(hit_slots, a);
   const int lane = lane_id();
-  // wave index as a scalar, so that chunk addresses and loop branches are wave-uniform
-  const uint64_t wave = __builtin_amdgcn_readfirstlane(
-      static_cast<uint32_t>((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6));
-  const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+  const uint64_t wave = scalar_wave_index();
+  RegionHits hits{a.hits + wave * a.region_cap, a.region_cap, 0u};
   const uint64_t first_chunk = a.wlo / kChunk;
   const uint64_t end_chunk = (a.whi + kChunk - 1) / kChunk;
-  // chunks [first_chunk, fast_end) can be loaded without guards (16 B + 8 B halo stay < n)
+  const WaveSpan span = wave_span(a, wave, first_chunk, end_chunk);
+  // chunks below fast_end can be loaded without guards (16 B + 8 B halo stay < n)
   uint64_t fast_end = a.n >= kChunk + 8 ? (a.n - 8) / kChunk : 0;
-  if (fast_end > end_chunk) fast_end = end_chunk;
-  if (fast_end < first_chunk) fast_end = first_chunk;
+  if (fast_end > span.c1) fast_end = span.c1;
+  if (fast_end < span.c0) fast_end = span.c0;
+  const uint64_t lane_off = static_cast<uint64_t>(lane) * 16;
 
   // Software-pipelined streaming loop, three register buffers deep: while chunk c is compared
-  // the loads of chunks c + stride and c + 2*stride are in flight (3 KiB per wave).  The steady
-  // loop runs only while all three prefetch targets exist, so its loads are unconditional and
-  // the compiler waits for exactly the buffer it needs (vmcnt(4)); the last <= 5 chunks of a
-  // wave are drained without prefetch, so no byte is loaded twice.
+  // the loads of chunks c+1 and c+2 are in flight (3 KiB per wave).  The steady loop runs only
+  // while all three prefetch targets exist, so its loads are unconditional and the compiler
+  // waits for exactly the buffer it needs (vmcnt(4)); the last <= 5 chunks of the span are
+  // drained without prefetch, so no byte is loaded twice.
   {
-    const uint64_t lane_off = static_cast<uint64_t>(lane) * 16;
     uint32_t b0[6], b1[6], b2[6];
-    uint64_t c = first_chunk + wave;
+    uint64_t c = span.c0;
     if (c < fast_end) load_chunk<TWO>(a.text, c * kChunk + lane_off, b0);
-    if (c + n_waves < fast_end) load_chunk<TWO>(a.text, (c + n_waves) * kChunk + lane_off, b1);
-    if (c + 2 * n_waves < fast_end) load_chunk<TWO>(a.text, (c + 2 * n_waves) * kChunk + lane_off, b2);
-    while (c + 5 * n_waves < fast_end) {
+    if (c + 1 < fast_end) load_chunk<TWO>(a.text, (c + 1) * kChunk + lane_off, b1);
+    if (c + 2 < fast_end) load_chunk<TWO>(a.text, (c + 2) * kChunk + lane_off, b2);
+    while (c + 5 < fast_end) {
       windows_chunk<K, TWO, MASKED, TWOLEVEL>(b0, c * kChunk + lane_off, a, ws, hits);
-      load_chunk<TWO>(a.text, (c + 3 * n_waves) * kChunk + lane_off, b0);
+      load_chunk<TWO>(a.text, (c + 3) * kChunk + lane_off, b0);
       __builtin_amdgcn_sched_barrier(0);
-      windows_chunk<K, TWO, MASKED, TWOLEVEL>(b1, (c + n_waves) * kChunk + lane_off, a, ws, hits);
-      load_chunk<TWO>(a.text, (c + 4 * n_waves) * kChunk + lane_off, b1);
+      windows_chunk<K, TWO, MASKED, TWOLEVEL>(b1, (c + 1) * kChunk + lane_off, a, ws, hits);
+      load_chunk<TWO>(a.text, (c + 4) * kChunk + lane_off, b1);
       __builtin_amdgcn_sched_barrier(0);
-      windows_chunk<K, TWO, MASKED, TWOLEVEL>(b2, (c + 2 * n_waves) * kChunk + lane_off, a, ws, hits);
-      load_chunk<TWO>(a.text, (c + 5 * n_waves) * kChunk + lane_off, b2);
+      windows_chunk<K, TWO, MASKED, TWOLEVEL>(b2, (c + 2) * kChunk + lane_off, a, ws, hits);
+      load_chunk<TWO>(a.text, (c + 5) * kChunk + lane_off, b2);
       __builtin_amdgcn_sched_barrier(0);
-      c += 3 * n_waves;
+      c += 3;
     }
-    // drain: b0..b2 hold chunks c, c+stride, c+2*stride (where they exist), then <= 2 more
+    // drain: b0..b2 hold chunks c, c+1, c+2 (where they exist), then <= 2 more
     if (c < fast_end) windows_chunk<K, TWO, MASKED, TWOLEVEL>(b0, c * kChunk + lane_off, a, ws, hits);
-    if (c + n_waves < fast_end) windows_chunk<K, TWO, MASKED, TWOLEVEL>(b1, (c + n_waves) * kChunk + lane_off, a, ws, hits);
-    if (c + 2 * n_waves < fast_end) windows_chunk<K, TWO, MASKED, TWOLEVEL>(b2, (c + 2 * n_waves) * kChunk + lane_off, a, ws, hits);
-    for (c += 3 * n_waves; c < fast_end; c += n_waves) {
+    if (c + 1 < fast_end) windows_chunk<K, TWO, MASKED, TWOLEVEL>(b1, (c + 1) * kChunk + lane_off, a, ws, hits);
+    if (c + 2 < fast_end) windows_chunk<K, TWO, MASKED, TWOLEVEL>(b2, (c + 2) * kChunk + lane_off, a, ws, hits);
+    for (c += 3; c < fast_end; c++) {
       load_chunk<TWO>(a.text, c * kChunk + lane_off, b0);
       windows_chunk<K, TWO, MASKED, TWOLEVEL>(b0, c * kChunk + lane_off, a, ws, hits);
     }
   }
-  // tail: the last chunk(s) touch the end of the text and use guarded byte loads
-  for (uint64_t t = fast_end + wave; t < end_chunk; t += n_waves) {
-    const uint64_t at = t * kChunk + static_cast<uint64_t>(lane) * 16;
+  // tail: the chunk(s) that touch the end of the text use guarded byte loads
+  for (uint64_t t = fast_end; t < span.c1; t++) {
     uint32_t d[6];
-    load_guarded(a.text, a.n, at, d);
-    windows_chunk<K, TWO, MASKED, TWOLEVEL>(d, at, a, ws, hits);
+    load_guarded(a.text, a.n, t * kChunk + lane_off, d);
+    windows_chunk<K, TWO, MASKED, TWOLEVEL>(d, t * kChunk + lane_off, a, ws, hits);
   }
-  hits.flush();
-}
-
-// A/B variant kept for measurements (RJ_SCAN_SIMPLE=1): no software pipeline, one chunk in
-// flight per wave.
-template <int K, bool TWO, bool MASKED, bool TWOLEVEL>
-__global__ __launch_bounds__(256) void scan_windows_simple(ScanParams a, WindowSet ws) {
-  __shared__ uint64_t hit_slots[4 * kHitBuf];
-  WaveHits hits = make_wave_hits(hit_slots, a);
-  const int lane = lane_id();
-  const uint64_t wave = __builtin_amdgcn_readfirstlane(
-      static_cast<uint32_t>((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6));
-  const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
-  const uint64_t first_chunk = a.wlo / kChunk;
-  const uint64_t end_chunk = (a.whi + kChunk - 1) / kChunk;
-  uint64_t fast_end = a.n >= kChunk + 8 ? (a.n - 8) / kChunk : 0;
-  if (fast_end > end_chunk) fast_end = end_chunk;
-  if (fast_end < first_chunk) fast_end = first_chunk;
-  for (uint64_t c = first_chunk + wave; c < fast_end; c += n_waves) {
-    const uint64_t at = c * kChunk + static_cast<uint64_t>(lane) * 16;
-    uint32_t d[6];
-    load_chunk<TWO>(a.text, at, d);
-    windows_chunk<K, TWO, MASKED, TWOLEVEL>(d, at, a, ws, hits);
-  }
-  for (uint64_t t = fast_end + wave; t < end_chunk; t += n_waves) {
-    const uint64_t at = t * kChunk + static_cast<uint64_t>(lane) * 16;
-    uint32_t d[6];
-    load_guarded(a.text, a.n, at, d);
-    windows_chunk<K, TWO, MASKED, TWOLEVEL>(d, at, a, ws, hits);
-  }
-  hits.flush();
+  if (lane == 0) a.hit_counts[wave] = hits.count;
 }
 
 // ---------------------------------------------------------------------------------------
 // Dense scan: every position s in [sb, se) that can start a match goes to the hit list.
 __global__ __launch_bounds__(256) void scan_dense(ScanParams a, DevProgram P) {
-  __shared__ uint64_t hit_slots[4 * kHitBuf];
-  WaveHits hits = make_wave_hits(hit_slots, a);
   __shared__ uint32_t fb[8];
   if (threadIdx.x < 8) fb[threadIdx.x] = P.first_bytes[threadIdx.x];
   __syncthreads();
   const int lane = lane_id();
-  const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+  const uint64_t wave = scalar_wave_index();
+  RegionHits hits{a.hits + wave * a.region_cap, a.region_cap, 0u};
   const uint64_t first_chunk = a.sb / kChunk;
   const uint64_t end_chunk = (a.se + kChunk - 1) / kChunk;  // se <= n + 1
+  const WaveSpan span = wave_span(a, wave, first_chunk, end_chunk);
   const bool ctxed = P.n_ctx > 1;
 
-  for (uint64_t c = first_chunk + wave; c < end_chunk; c += n_waves) {
+  for (uint64_t c = span.c0; c < span.c1; c++) {
     const uint64_t base = c * kChunk;
     const uint64_t at = base + static_cast<uint64_t>(lane) * 16;
     uint32_t d[6];
@@ -417,36 +315,82 @@ __global__ __launch_bounds__(256) void scan_dense(ScanParams a, DevProgram P) {
     if (__ballot(cand != 0) == 0) continue;
     hits.push_bits(cand, at, 0);
   }
-  hits.flush();
+  if (lane == 0) a.hit_counts[wave] = hits.count;
 }
 
 // ---------------------------------------------------------------------------------------
+// Region bookkeeping: offsets[r] = sum of min(count, cap) of the regions before r (so hit i of
+// the run lives in region upper_bound(offsets, i) - 1), the total, and the fullest region.
+// One workgroup; n_regions <= 64 Ki.
+__global__ __launch_bounds__(1024) void region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap,
+                                                       uint64_t* offsets, unsigned long long* counters) {
+  __shared__ uint64_t part[1024];
+  __shared__ uint32_t maxc;
+  const uint32_t per = (n_regions + 1023) / 1024;
+  const uint32_t lo = threadIdx.x * per;
+  const uint32_t hi = lo + per < n_regions ? lo + per : n_regions;
+  if (threadIdx.x == 0) maxc = 0;
+  __syncthreads();
+  uint64_t sum = 0;
+  uint32_t mx = 0;
+  for (uint32_t r = lo; r < hi; r++) {
+    const uint32_t c = counts[r];
+    mx = c > mx ? c : mx;
+    sum += c < cap ? c : cap;
+  }
+  if (mx) atomicMax(&maxc, mx);
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {  // inclusive Hillis-Steele scan
+    uint64_t v = 0;
+    if (static_cast<int>(threadIdx.x) >= o) v = part[threadIdx.x - o];
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint64_t run = part[threadIdx.x] - sum;  // exclusive prefix of this thread's slice
+  for (uint32_t r = lo; r < hi; r++) {
+    offsets[r] = run;
+    const uint32_t c = counts[r];
+    run += c < cap ? c : cap;
+  }
+  if (threadIdx.x == 1023) {
+    offsets[n_regions] = part[1023];
+    counters[kCntHits] = part[1023];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    counters[kCntMaxRegion] = maxc;
+    if (maxc > cap) counters[kCntOverflow] = 1;
+  }
+}
+
+namespace {
+// hit i of the run: region = upper_bound(offsets, i) - 1
+__device__ __forceinline__ uint64_t hit_at(const VerifyParams& a, uint64_t i) {
+  uint32_t lo = 0, hi = a.n_regions;  // invariant: offsets[lo] <= i < offsets[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a.offsets[mid] <= i) lo = mid; else hi = mid;
+  }
+  return a.hits[static_cast<uint64_t>(lo) * a.region_cap + (i - a.offsets[lo])];
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
 // Verify: longest match from every hit; survivors become (begin,end) candidates.
+// The result goes to slot i of the candidate arrays (end = kNoMatch when nothing matches at
+// that start), so the candidates stay sorted by begin and need no atomic either.
 template <int NQ>
 __global__ __launch_bounds__(256) void verify_lane(VerifyParams a, DevProgram P) {
-  const uint64_t seg_cap = a.hits_cap / kHitSegs;
-  // wave w works on segment w % kHitSegs only (a wave that walked all segments in turn
-  // serialised ~16 dependent automaton runs: +60 us per call)
-  const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;  // multiple of kHitSegs
-  const int seg = static_cast<int>(wave % kHitSegs);
-  const uint64_t local = wave / kHitSegs, n_local = n_waves / kHitSegs;
-  unsigned long long n_hits = a.counters[kCntHits + seg];
-  if (n_hits > seg_cap) {
-    if (lane_id() == 0) a.counters[kCntOverflow] = 1;
-    n_hits = seg_cap;
-  }
-  const uint64_t* hits = a.hits + seg * seg_cap;
-  // all lanes of a wave iterate together (wave-aggregated append needs the full wave)
-  for (uint64_t base = local * kWave; base < n_hits; base += n_local * kWave) {
-    const uint64_t i = base + lane_id();
-    bool found = false;
-    uint64_t s = 0, e = 0;
-    if (i < n_hits) {
-      s = hits[i];
-      found = rj_lane_longest<NQ>(P, a.text, a.n, s, &e);
-    }
-    wave_append_pair(found, s, e, a.cand_begin, a.cand_end, a.cands_cap, a.counters + kCntCands);
+  const uint64_t n_hits = a.offsets[a.n_regions];
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_hits; i += stride) {
+    const uint64_t s = hit_at(a, i);
+    uint64_t e = 0;
+    const bool found = rj_lane_longest<NQ>(P, a.text, a.n, s, &e);
+    a.cand_begin[i] = s;
+    a.cand_end[i] = found ? e : kNoMatch;
   }
 }
 
@@ -545,27 +489,16 @@ __device__ bool wave_longest(const DevProgram& P, const uint8_t* t, uint64_t n, 
 
 template <int NR>
 __global__ __launch_bounds__(256) void verify_wave(VerifyParams a, DevProgram P) {
-  const uint64_t seg_cap = a.hits_cap / kHitSegs;
+  const uint64_t n_hits = a.offsets[a.n_regions];
   const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
   const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
-  const int seg = static_cast<int>(wave % kHitSegs);
-  const uint64_t local = wave / kHitSegs, n_local = n_waves / kHitSegs;
-  unsigned long long n_hits = a.counters[kCntHits + seg];
-  if (n_hits > seg_cap) {
-    if (lane_id() == 0) a.counters[kCntOverflow] = 1;
-    n_hits = seg_cap;
-  }
-  const uint64_t* hits = a.hits + seg * seg_cap;
-  for (uint64_t i = local; i < n_hits; i += n_local) {
-    const uint64_t s = hits[i];
+  for (uint64_t i = wave; i < n_hits; i += n_waves) {
+    const uint64_t s = hit_at(a, i);
     uint64_t e = 0;
     const bool found = wave_longest<NR>(P, a.text, a.n, s, &e, false);
-    if (found && lane_id() == 0) {
-      const unsigned long long idx = atomicAdd(a.counters + kCntCands, 1ull);
-      if (idx < a.cands_cap) {
-        a.cand_begin[idx] = s;
-        a.cand_end[idx] = e;
-      }
+    if (lane_id() == 0) {
+      a.cand_begin[i] = s;
+      a.cand_end[i] = found ? e : kNoMatch;
     }
   }
 }
@@ -585,7 +518,8 @@ __global__ __launch_bounds__(1024) void finalize_small(FinalizeParams a) {
   __shared__ uint64_t key[kFinalizeCap];
   __shared__ uint64_t val[kFinalizeCap];
   __shared__ int all_disjoint;
-  const unsigned long long n_raw = a.counters[kCntCands];
+  __shared__ int n_valid;
+  const unsigned long long n_raw = a.counters[kCntHits];  // one candidate slot per hit
   if (n_raw > a.cands_cap || a.counters[kCntOverflow] != 0) {
     if (threadIdx.x == 0) {  // a list overflowed: the host grows it and retries
       a.counters[kCntOverflow] = 1;
@@ -597,15 +531,27 @@ __global__ __launch_bounds__(1024) void finalize_small(FinalizeParams a) {
     if (threadIdx.x == 0) a.counters[kCntFinal] = ~0ull;
     return;
   }
-  const int n = static_cast<int>(n_raw);
+  const int n_slots = static_cast<int>(n_raw);
   int m = 1;
-  while (m < n) m <<= 1;
-  for (int i = threadIdx.x; i < m; i += blockDim.x) {
-    key[i] = i < n ? a.cand_begin[i] : ~0ull;
-    val[i] = i < n ? a.cand_end[i] : ~0ull;
+  while (m < n_slots) m <<= 1;
+  if (threadIdx.x == 0) {
+    all_disjoint = 1;
+    n_valid = 0;
   }
-  if (threadIdx.x == 0) all_disjoint = 1;
   __syncthreads();
+  int mine = 0;
+  for (int i = threadIdx.x; i < m; i += blockDim.x) {
+    // starts without a match sort to the end (the input is already ordered by begin; the sort is
+    // kept because it also serves callers that pass unordered candidates, and costs ~3 us)
+    const bool ok = i < n_slots && a.cand_end[i] != kNoMatch;
+    key[i] = ok ? a.cand_begin[i] : ~0ull;
+    val[i] = ok ? a.cand_end[i] : ~0ull;
+    mine += ok;
+  }
+  if (mine) atomicAdd(&n_valid, mine);
+  __syncthreads();
+  const int n = n_valid;
+  if (threadIdx.x == 0) a.counters[kCntCands] = static_cast<unsigned long long>(n);
   // bitonic sort on (key, val)
   for (int k = 2; k <= m; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -849,6 +795,23 @@ __global__ void exact_sequential(const uint8_t* t, uint64_t n, DevGraph G, int64
   counters[kCntFinal] = out_n;
 }
 
+__global__ void mark_valid(const uint64_t* cand_end, uint64_t n, uint64_t* flags) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = cand_end[i] != kNoMatch ? 1 : 0;
+}
+
+__global__ void compact_valid(const uint64_t* cand_begin, const uint64_t* cand_end, const uint64_t* flags,
+                              const uint64_t* pos, uint64_t n, uint64_t* keys, uint64_t* vals,
+                              unsigned long long* counters) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (flags[i]) {
+    keys[pos[i]] = cand_begin[i];
+    vals[pos[i]] = cand_end[i];
+  }
+  if (i == n - 1) counters[kCntCands] = pos[i] + flags[i];
+}
+
 // Large path, common case in one kernel: emit the sorted candidates as pairs and find out
 // whether they already are the result (pairwise disjoint, no empty match, nothing hidden by
 // the carry); *flag is cleared otherwise and the cluster-parallel selection runs.
@@ -867,19 +830,24 @@ __global__ void check_and_interleave(const uint64_t* keys, const uint64_t* vals,
 
 // ---------------------------------------------------------------------------------------
 // Launchers (host side of the <<< >>> syntax lives here so engine.cc stays plain C++).
-namespace {
-int grid_for_scan(uint64_t chunks) {
-  // Measured on MI355X (tools/ab_probe.py): a grid of exactly the resident workgroups
-  // (2048) loses ~12% to the partially filled last round; large texts stream best with
-  // >= 16 Ki workgroups (6.2-6.4 TB/s), while every wave should still own >= ~32 chunks so
-  // that its hit staging amortises (500 MB: 4 Ki workgroups).
+ScanGeometry scan_geometry(uint64_t chunks) {
+  // Measured on MI355X (tools/ab_probe.py): a grid of exactly the resident workgroups loses
+  // ~12% to the partially filled last round; large texts stream best with >= 16 Ki workgroups
+  // (6.2-6.4 TB/s) while tiny spans waste the pipeline prologue, so aim at >= 32 chunks per
+  // wave and cap at 16 Ki workgroups.
   uint64_t blocks = chunks / 128;
   if (blocks > 16384) blocks = 16384;
   if (blocks < 256) blocks = (chunks + 3) / 4 < 256 ? (chunks + 3) / 4 : 256;
   if (blocks == 0) blocks = 1;
-  return static_cast<int>(blocks);
+  static const char* env_grid = getenv("RJ_SCAN_GRID");  // measurement override
+  if (env_grid && atoi(env_grid) > 0) blocks = static_cast<uint64_t>(atoi(env_grid));
+  ScanGeometry g;
+  g.grid = static_cast<int>(blocks);
+  g.n_regions = static_cast<uint32_t>(blocks * 4);
+  g.span_chunks = (chunks + g.n_regions - 1) / g.n_regions;
+  if (g.span_chunks == 0) g.span_chunks = 1;
+  return g;
 }
-}  // namespace
 
 template <bool TWO, bool MASKED, bool TWOLEVEL>
 static void launch_windows_k(int k, const ScanParams& a, const WindowSet& ws, int grid, hipStream_t st) {
@@ -892,18 +860,7 @@ static void launch_windows_k(int k, const ScanParams& a, const WindowSet& ws, in
   else hipLaunchKernelGGL((scan_windows<8, TWO, MASKED, TWOLEVEL>), dim3(grid), dim3(256), 0, st, a, ws);
 }
 
-void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows, hipStream_t st) {
-  if (a.whi <= a.wlo) return;
-  const uint64_t chunks = (a.whi + kChunk - 1) / kChunk - a.wlo / kChunk;
-  int grid = grid_for_scan(chunks);
-  static const char* env_grid = getenv("RJ_SCAN_GRID");
-  if (env_grid) grid = atoi(env_grid);
-  static const char* env_simple = getenv("RJ_SCAN_SIMPLE");
-  if (env_simple && n_windows == 1) {  // measurement variant, K = 1 only
-    if (ws.len > 4) hipLaunchKernelGGL((scan_windows_simple<1, true, true, true>), dim3(grid), dim3(256), 0, st, a, ws);
-    else hipLaunchKernelGGL((scan_windows_simple<1, false, false, false>), dim3(grid), dim3(256), 0, st, a, ws);
-    return;
-  }
+void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows, int grid, hipStream_t st) {
   const bool two = ws.len > 4;
   if (two) {
     if (ws.two_level) {
@@ -919,10 +876,13 @@ void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows
   }
 }
 
-void launch_scan_dense(const ScanParams& a, const DevProgram& P, hipStream_t st) {
-  if (a.se <= a.sb) return;
-  const uint64_t chunks = (a.se + kChunk - 1) / kChunk - a.sb / kChunk;
-  hipLaunchKernelGGL(scan_dense, dim3(grid_for_scan(chunks)), dim3(256), 0, st, a, P);
+void launch_scan_dense(const ScanParams& a, const DevProgram& P, int grid, hipStream_t st) {
+  hipLaunchKernelGGL(scan_dense, dim3(grid), dim3(256), 0, st, a, P);
+}
+
+void launch_region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap, uint64_t* offsets,
+                           unsigned long long* counters, hipStream_t st) {
+  hipLaunchKernelGGL(region_offsets, dim3(1), dim3(1024), 0, st, counts, n_regions, cap, offsets, counters);
 }
 
 void launch_verify(const VerifyParams& a, const DevProgram& P, uint64_t expected_hits, hipStream_t st) {
@@ -931,7 +891,6 @@ void launch_verify(const VerifyParams& a, const DevProgram& P, uint64_t expected
     uint64_t blocks = (expected_hits + 255) / 256;
     if (blocks < 4) blocks = 4;
     if (blocks > 2048) blocks = 2048;
-    blocks = (blocks + 3) / 4 * 4;  // waves must be a multiple of kHitSegs
     if (W <= 2) hipLaunchKernelGGL((verify_lane<1>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, a, P);
     else hipLaunchKernelGGL((verify_lane<2>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, a, P);
     return;
@@ -939,11 +898,23 @@ void launch_verify(const VerifyParams& a, const DevProgram& P, uint64_t expected
   uint64_t blocks = (expected_hits + 3) / 4;
   if (blocks < 4) blocks = 4;
   if (blocks > 2048) blocks = 2048;
-  blocks = (blocks + 3) / 4 * 4;
   const unsigned g = static_cast<unsigned>(blocks);
   if (W <= 64) hipLaunchKernelGGL((verify_wave<1>), dim3(g), dim3(256), 0, st, a, P);
   else if (W <= 128) hipLaunchKernelGGL((verify_wave<2>), dim3(g), dim3(256), 0, st, a, P);
   else hipLaunchKernelGGL((verify_wave<4>), dim3(g), dim3(256), 0, st, a, P);
+}
+
+void launch_mark_valid(const uint64_t* cand_end, uint64_t n, uint64_t* flags, hipStream_t st) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(mark_valid, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, cand_end, n, flags);
+}
+
+void launch_compact_valid(const uint64_t* cand_begin, const uint64_t* cand_end, const uint64_t* flags,
+                          const uint64_t* pos, uint64_t n, uint64_t* keys, uint64_t* vals,
+                          unsigned long long* counters, hipStream_t st) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(compact_valid, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, cand_begin, cand_end,
+                     flags, pos, n, keys, vals, counters);
 }
 
 void launch_match_full(const uint8_t* text, uint64_t n, const DevProgram& P, int* result, hipStream_t st) {
