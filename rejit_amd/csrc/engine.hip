@@ -313,25 +313,23 @@ int finalize_large(rj_scan* s, uint64_t n_slots, const FinalizeParams& fp, hipSt
   RJ_HIP(scan(sa, sb, n_slots, false));
   launch_compact_valid(s->cand_begin.as<uint64_t>(), s->cand_end.as<uint64_t>(), sa, sb, n_slots, keys, vals,
                        s->counters.as<unsigned long long>(), st);
+  // 2. common case, still without a host round trip: the candidates already are the result
+  //    (the kernels read the candidate count from device memory; grids sized for n_slots)
+  if (fp.detect_adjacent) launch_detect_adjacent(keys, vals, n_slots, s->counters.as<unsigned long long>(), st);
+  *s->host_flag = 1;
+  RJ_HIP(hipMemcpyAsync(s->flag.p, s->host_flag, sizeof(int), hipMemcpyHostToDevice, st));
+  launch_check_and_interleave(keys, vals, s->counters.as<unsigned long long>() + kCntCands, n_slots, fp.carry_cur,
+                              s->out.as<uint64_t>(), s->out_cap, s->flag.as<int>(), st);
+  RJ_HIP(hipMemcpyAsync(s->host_flag, s->flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
   RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   RJ_HIP(hipStreamSynchronize(st));
+  RJ_HIP(hipGetLastError());
   const uint64_t n_cands = s->host_counters[kCntCands];
   s->stats.n_candidates = n_cands;
   if (n_cands == 0) {
     s->result_count = 0;
     return RJ_OK;
   }
-  // 2. common case: the candidates already are the result
-  if (fp.detect_adjacent) launch_detect_adjacent(keys, vals, n_cands, s->counters.as<unsigned long long>(), st);
-  *s->host_flag = 1;
-  RJ_HIP(hipMemcpyAsync(s->flag.p, s->host_flag, sizeof(int), hipMemcpyHostToDevice, st));
-  launch_check_and_interleave(keys, vals, n_cands, fp.carry_cur, s->out.as<uint64_t>(), s->out_cap, s->flag.as<int>(), st);
-  RJ_HIP(hipMemcpyAsync(s->host_flag, s->flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
-  if (fp.detect_adjacent)
-    RJ_HIP(hipMemcpyAsync(s->host_counters + kCntAdjacent, s->counters.as<unsigned long long>() + kCntAdjacent,
-                          sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-  RJ_HIP(hipStreamSynchronize(st));
-  RJ_HIP(hipGetLastError());
   if (*s->host_flag == 1) {
     s->result_count = n_cands;
     return RJ_OK;
@@ -535,9 +533,8 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     s->result_count = total;
     s->result = s->acc_out.as<uint64_t>();
   }
-  RJ_HIP(hipEventRecord(s->ev[3], st));
-  RJ_HIP(hipStreamSynchronize(st));
-  (void)hipEventElapsedTime(&s->stats.total_ms, s->ev[0], s->ev[3]);
+  RJ_HIP(hipEventRecord(s->ev[3], st));  // total_ms is resolved lazily in rj_scan_stats
+  s->stats.total_ms = -1.f;
   s->stats.n_matches = s->result_count;
   return RJ_OK;
 }
@@ -699,6 +696,11 @@ int64_t rj_scan_copy_spans(const rj_scan* s, uint64_t* host_spans, uint64_t cap)
 
 int rj_scan_stats(const rj_scan* s, rj_stats* stats) {
   if (!s || !stats) return fail(RJ_BAD_ARGUMENT, "null argument");
+  if (s->stats.total_ms < 0.f) {
+    rj_scan* m = const_cast<rj_scan*>(s);
+    (void)hipEventSynchronize(m->ev[3]);
+    if (hipEventElapsedTime(&m->stats.total_ms, m->ev[0], m->ev[3]) != hipSuccess) m->stats.total_ms = 0.f;
+  }
   *stats = s->stats;
   return RJ_OK;
 }

@@ -84,10 +84,11 @@ void launch_match_full(const uint8_t* text, uint64_t n, const DevProgram& P, int
 void launch_finalize_small(const FinalizeParams& a, hipStream_t st);
 // writes the sorted candidates as (begin,end) pairs and clears *flag unless they already are a
 // valid result (pairwise disjoint, no empty match, first begin >= carry_cur)
-void launch_check_and_interleave(const uint64_t* keys, const uint64_t* vals, uint64_t n, uint64_t carry_cur,
-                                 uint64_t* out, uint64_t cap, int* flag, hipStream_t st);
+void launch_check_and_interleave(const uint64_t* keys, const uint64_t* vals, const unsigned long long* n_ptr,
+                                 uint64_t n_upper, uint64_t carry_cur, uint64_t* out, uint64_t cap, int* flag,
+                                 hipStream_t st);
 // counters[kCntAdjacent] = 1 when some non-empty candidate ends exactly where another begins
-void launch_detect_adjacent(const uint64_t* keys, const uint64_t* vals, uint64_t n, unsigned long long* counters,
+void launch_detect_adjacent(const uint64_t* keys, const uint64_t* vals, uint64_t n_upper, unsigned long long* counters,
                             hipStream_t st);
 // the reference's no-fast-forward algorithm on one lane (exact incl. its ring-slot artefact)
 void launch_exact_sequential(const uint8_t* text, uint64_t n, const DevGraph& G, int64_t* ring, uint64_t* out,

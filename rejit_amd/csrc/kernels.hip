@@ -164,9 +164,13 @@ __device__ __forceinline__ void windows_chunk(const uint32_t (&d)[6], uint64_t a
     }
     if (__ballot(acc1 == 0) == 0) return;
   }
+  // tj[j] == 0 iff some window matches at position j; kept in registers so that the (rare)
+  // hit path does not have to redo the compares
+  uint32_t tj[16];
   uint32_t acc = 0xFFFFFFFFu;
 #pragma unroll
   for (int j = 0; j < 16; j++) {
+    uint32_t best = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = 0; k < K; k++) {
       uint32_t t = x[j] ^ ws.value0[k];
@@ -175,26 +179,25 @@ __device__ __forceinline__ void windows_chunk(const uint32_t (&d)[6], uint64_t a
         uint32_t u = x[j + 4] ^ ws.value1[k];
         t = MASKED ? ((u & ws.mask1[k]) | t) : (u | t);  // v_and_or_b32
       }
-      acc = acc < t ? acc : t;
+      best = best < t ? best : t;
     }
+    tj[j] = best;
+    acc = acc < best ? acc : best;
   }
-  const bool any = acc == 0;
-  if (__ballot(any) == 0) return;  // wave-uniform: the common case leaves here
+  if (__ballot(acc == 0) == 0) return;  // wave-uniform: the common case leaves here
 
-  // rare path: per-lane 16-bit hit mask, staged in the wave's LDS buffer
+  // rare path: per-lane 16-bit hit mask -> the wave's region of the hit list
   uint32_t hm = 0;
 #pragma unroll
-  for (int j = 0; j < 16; j++) {
-    bool hit = false;
+  for (int j = 0; j < 16; j++) hm |= static_cast<uint32_t>(tj[j] == 0) << j;
+  // positions outside [wlo, whi) only exist in the first / last chunk of the range
+  const uint64_t chunk_base = at - static_cast<uint64_t>(lane_id()) * 16;
+  if (chunk_base < a.wlo || chunk_base + kChunk > a.whi) {
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-      bool h = ((MASKED ? (x[j] & ws.mask0[k]) : x[j]) == ws.value0[k]);
-      if (TWO) h = h && ((MASKED ? (x[j + 4] & ws.mask1[k]) : x[j + 4]) == ws.value1[k]);
-      hit |= h;
+    for (int j = 0; j < 16; j++) {
+      const uint64_t w = at + j;
+      if (w < a.wlo || w >= a.whi) hm &= ~(1u << j);
     }
-    const uint64_t w = at + j;
-    hit = hit && w >= a.wlo && w < a.whi;
-    hm |= static_cast<uint32_t>(hit) << j;
   }
   hits.push_bits(hm, at, ws.offset);
 }
@@ -322,44 +325,55 @@ __global__ __launch_bounds__(256) void scan_dense(ScanParams a, DevProgram P) {
 // Region bookkeeping: offsets[r] = sum of min(count, cap) of the regions before r (so hit i of
 // the run lives in region upper_bound(offsets, i) - 1), the total, and the fullest region.
 // One workgroup; n_regions <= 64 Ki.
+template <int PER>
 __global__ __launch_bounds__(1024) void region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap,
                                                        uint64_t* offsets, unsigned long long* counters) {
-  __shared__ uint64_t part[1024];
-  __shared__ uint32_t maxc;
-  const uint32_t per = (n_regions + 1023) / 1024;
-  const uint32_t lo = threadIdx.x * per;
-  const uint32_t hi = lo + per < n_regions ? lo + per : n_regions;
-  if (threadIdx.x == 0) maxc = 0;
-  __syncthreads();
+  __shared__ uint64_t wave_sum[16];
+  __shared__ uint32_t wave_max[16];
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  const uint32_t lo = threadIdx.x * PER;
+  // the thread's slice lives in registers: PER independent loads in flight instead of a
+  // dependent chain (the slice loop was the whole 20-50 us of this kernel)
+  uint32_t pre[PER];
+#pragma unroll
+  for (int k = 0; k < PER; k++) pre[k] = (lo + k < n_regions) ? counts[lo + k] : 0u;
   uint64_t sum = 0;
   uint32_t mx = 0;
-  for (uint32_t r = lo; r < hi; r++) {
-    const uint32_t c = counts[r];
-    mx = c > mx ? c : mx;
-    sum += c < cap ? c : cap;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    mx = pre[k] > mx ? pre[k] : mx;
+    sum += pre[k] < cap ? pre[k] : cap;
   }
-  if (mx) atomicMax(&maxc, mx);
-  part[threadIdx.x] = sum;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {  // inclusive Hillis-Steele scan
-    uint64_t v = 0;
-    if (static_cast<int>(threadIdx.x) >= o) v = part[threadIdx.x - o];
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
+  // inclusive scan inside the wave, then across the 16 waves
+  uint64_t inc = sum;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const uint64_t v = __shfl_up(inc, o);
+    if (lane >= o) inc += v;
+    const uint32_t m2 = __shfl_xor(mx, o);
+    mx = m2 > mx ? m2 : mx;
   }
-  uint64_t run = part[threadIdx.x] - sum;  // exclusive prefix of this thread's slice
-  for (uint32_t r = lo; r < hi; r++) {
-    offsets[r] = run;
-    const uint32_t c = counts[r];
-    run += c < cap ? c : cap;
-  }
-  if (threadIdx.x == 1023) {
-    offsets[n_regions] = part[1023];
-    counters[kCntHits] = part[1023];
+  if (lane == kWave - 1) {
+    wave_sum[wv] = inc;
+    wave_max[wv] = mx;
   }
   __syncthreads();
+  uint64_t before = 0, total = 0;
+  uint32_t maxc = 0;
+  for (int w = 0; w < 16; w++) {
+    if (w < wv) before += wave_sum[w];
+    total += wave_sum[w];
+    maxc = wave_max[w] > maxc ? wave_max[w] : maxc;
+  }
+  uint64_t run = before + inc - sum;  // exclusive prefix of this thread's slice
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    if (lo + k < n_regions) offsets[lo + k] = run;
+    run += pre[k] < cap ? pre[k] : cap;
+  }
   if (threadIdx.x == 0) {
+    offsets[n_regions] = total;
+    counters[kCntHits] = total;
     counters[kCntMaxRegion] = maxc;
     if (maxc > cap) counters[kCntOverflow] = 1;
   }
@@ -486,6 +500,26 @@ __device__ bool wave_longest(const DevProgram& P, const uint8_t* t, uint64_t n, 
 }
 
 }  // namespace
+
+// Dense mode: regions are long (thousands of hits each), so a wave walks whole regions and
+// needs no per-hit search for the region (135M hits/GB made that search the whole run time).
+template <int NQ>
+__global__ __launch_bounds__(256) void verify_lane_regions(VerifyParams a, DevProgram P) {
+  const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+  const int lane = lane_id();
+  for (uint64_t r = wave; r < a.n_regions; r += n_waves) {
+    const uint64_t lo = a.offsets[r], hi = a.offsets[r + 1];
+    const uint64_t* region = a.hits + r * a.region_cap;
+    for (uint64_t k = lane; k < hi - lo; k += kWave) {
+      const uint64_t s = region[k];
+      uint64_t e = 0;
+      const bool found = rj_lane_longest<NQ>(P, a.text, a.n, s, &e);
+      a.cand_begin[lo + k] = s;
+      a.cand_end[lo + k] = found ? e : kNoMatch;
+    }
+  }
+}
 
 template <int NR>
 __global__ __launch_bounds__(256) void verify_wave(VerifyParams a, DevProgram P) {
@@ -686,7 +720,8 @@ __global__ void compact_kept(const uint64_t* keys, const uint64_t* vals, const u
   if (i == n - 1) counters[kCntFinal] = pos[i] + keep[i];
 }
 
-__global__ void detect_adjacent(const uint64_t* keys, const uint64_t* vals, uint64_t n, unsigned long long* counters) {
+__global__ void detect_adjacent(const uint64_t* keys, const uint64_t* vals, unsigned long long* counters) {
+  const uint64_t n = counters[kCntCands];
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t e = vals[i];
@@ -815,8 +850,9 @@ __global__ void compact_valid(const uint64_t* cand_begin, const uint64_t* cand_e
 // Large path, common case in one kernel: emit the sorted candidates as pairs and find out
 // whether they already are the result (pairwise disjoint, no empty match, nothing hidden by
 // the carry); *flag is cleared otherwise and the cluster-parallel selection runs.
-__global__ void check_and_interleave(const uint64_t* keys, const uint64_t* vals, uint64_t n, uint64_t carry_cur,
-                                     uint64_t* out, uint64_t cap, int* flag) {
+__global__ void check_and_interleave(const uint64_t* keys, const uint64_t* vals, const unsigned long long* n_ptr,
+                                     uint64_t carry_cur, uint64_t* out, uint64_t cap, int* flag) {
+  const uint64_t n = *n_ptr;  // number of compacted candidates, produced earlier on this stream
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t b = keys[i], e = vals[i];
@@ -882,11 +918,22 @@ void launch_scan_dense(const ScanParams& a, const DevProgram& P, int grid, hipSt
 
 void launch_region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap, uint64_t* offsets,
                            unsigned long long* counters, hipStream_t st) {
-  hipLaunchKernelGGL(region_offsets, dim3(1), dim3(1024), 0, st, counts, n_regions, cap, offsets, counters);
+  // n_regions <= 64 Ki (scan_geometry caps the grid at 16 Ki workgroups of 4 waves)
+  if (n_regions <= 16 * 1024) hipLaunchKernelGGL((region_offsets<16>), dim3(1), dim3(1024), 0, st, counts, n_regions, cap, offsets, counters);
+  else if (n_regions <= 32 * 1024) hipLaunchKernelGGL((region_offsets<32>), dim3(1), dim3(1024), 0, st, counts, n_regions, cap, offsets, counters);
+  else hipLaunchKernelGGL((region_offsets<64>), dim3(1), dim3(1024), 0, st, counts, n_regions, cap, offsets, counters);
 }
 
 void launch_verify(const VerifyParams& a, const DevProgram& P, uint64_t expected_hits, hipStream_t st) {
   const int W = P.n_words;
+  if (W <= 4 && P.mode == 0) {  // dense: long regions, one wave per region
+    uint64_t blocks = (static_cast<uint64_t>(a.n_regions) + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    if (W <= 2) hipLaunchKernelGGL((verify_lane_regions<1>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, a, P);
+    else hipLaunchKernelGGL((verify_lane_regions<2>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, a, P);
+    return;
+  }
   if (W <= 4) {
     uint64_t blocks = (expected_hits + 255) / 256;
     if (blocks < 4) blocks = 4;
@@ -928,17 +975,18 @@ void launch_finalize_small(const FinalizeParams& a, hipStream_t st) {
   hipLaunchKernelGGL(finalize_small, dim3(1), dim3(1024), 0, st, a);
 }
 
-void launch_check_and_interleave(const uint64_t* keys, const uint64_t* vals, uint64_t n, uint64_t carry_cur,
-                                 uint64_t* out, uint64_t cap, int* flag, hipStream_t st) {
-  if (n == 0) return;
-  hipLaunchKernelGGL(check_and_interleave, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, keys, vals, n,
-                     carry_cur, out, cap, flag);
+void launch_check_and_interleave(const uint64_t* keys, const uint64_t* vals, const unsigned long long* n_ptr,
+                                 uint64_t n_upper, uint64_t carry_cur, uint64_t* out, uint64_t cap, int* flag,
+                                 hipStream_t st) {
+  if (n_upper == 0) return;
+  hipLaunchKernelGGL(check_and_interleave, dim3(static_cast<unsigned>((n_upper + 255) / 256)), dim3(256), 0, st, keys, vals,
+                     n_ptr, carry_cur, out, cap, flag);
 }
 
-void launch_detect_adjacent(const uint64_t* keys, const uint64_t* vals, uint64_t n, unsigned long long* counters,
+void launch_detect_adjacent(const uint64_t* keys, const uint64_t* vals, uint64_t n_upper, unsigned long long* counters,
                             hipStream_t st) {
-  if (n == 0) return;
-  hipLaunchKernelGGL(detect_adjacent, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, keys, vals, n, counters);
+  if (n_upper == 0) return;
+  hipLaunchKernelGGL(detect_adjacent, dim3(static_cast<unsigned>((n_upper + 255) / 256)), dim3(256), 0, st, keys, vals, counters);
 }
 
 void launch_exact_sequential(const uint8_t* text, uint64_t n, const DevGraph& G, int64_t* ring, uint64_t* out,

@@ -23,8 +23,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     run(W.REGEXDNA_PATTERNS[0], f, f.numel(), "dna1"); run(W.REGEXDNA_PATTERNS[4], f, f.numel(), "dna5")
     print(json.dumps(res))
 else:
-    variants = [{"RJ_SCAN_SIMPLE": "1", "RJ_SCAN_GRID": str(g)} for g in (4096, 16384)] + \
-               [{"RJ_SCAN_SIMPLE": "1", "RJ_SCAN_CONTIG": "1", "RJ_SCAN_GRID": str(g)} for g in (2048, 4096, 16384, 65536)]
+    variants = [{}] + [{"RJ_SCAN_GRID": str(g)} for g in (2048, 4096, 8192, 16384, 32768)]
     for env in variants:
         e = dict(os.environ); e.update(env)
         out = subprocess.run([sys.executable, __file__, "child"], env=e, capture_output=True, text=True)
