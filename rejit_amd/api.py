@@ -40,6 +40,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     the built library travels with the repo snapshot).  hipcc cross-compiles without a GPU."""
     if not force and not _stale():
         return LIB
+    # several ranks of one job may arrive here together: serialise, and re-check under the lock
+    import fcntl
+    lock = open(os.path.join(PKG, ".build.lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and not _stale():
+            return LIB
+        return _build_locked(verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(verbose: bool) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"

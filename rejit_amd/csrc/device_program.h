@@ -79,8 +79,14 @@ RJ_HD int rj_context(const uint8_t* t, uint64_t n, uint64_t p) {
 // lane (P <= 64 * NQ).  Returns false when no match starts at s.
 // One step is S' = follow_ctx(S) & cls[byte]: the linear part is a shift, positions with
 // a non-trivial follow set OR in their row.
+// `max_steps` bounds the walk: a start that is still alive after that many bytes sets *overrun
+// (the engine then falls back to the sequential kernel or reports RJ_TOO_LARGE instead of
+// letting dense candidates x unbounded repetitions run for hours).
+constexpr uint64_t kMaxSimSteps = 1ull << 20;
+
 template <int NQ>
-RJ_HD bool rj_lane_longest(const DevProgram& P, const uint8_t* t, uint64_t n, uint64_t s, uint64_t* end) {
+RJ_HD bool rj_lane_longest(const DevProgram& P, const uint8_t* t, uint64_t n, uint64_t s, uint64_t* end,
+                           bool* overrun) {
   const int W = P.n_words;  // 32-bit words; NQ*2 >= W
   const bool ctxed = P.n_ctx > 1;
   int ctx = ctxed ? rj_context(t, n, s) : 0;
@@ -128,6 +134,10 @@ RJ_HD bool rj_lane_longest(const DevProgram& P, const uint8_t* t, uint64_t n, ui
       }
     }
     if (p == n) break;
+    if (p - s >= kMaxSimSteps) {
+      *overrun = true;
+      break;
+    }
     uint64_t T[NQ];
     uint64_t carry = 0;
     for (int q = 0; q < NQ; q++) {

@@ -432,6 +432,7 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
     vp.region_cap = static_cast<uint32_t>(region_cap);
     vp.cand_begin = s->cand_begin.as<uint64_t>();
     vp.cand_end = s->cand_end.as<uint64_t>();
+    vp.counters = s->counters.as<unsigned long long>();
     launch_verify(vp, D, windows ? std::max<uint64_t>(s->hits_hint, 1u << 14) : (se - sb) / 8 + 1, st);
     FinalizeParams fp{};
     fp.cand_begin = s->cand_begin.as<uint64_t>();
@@ -468,6 +469,14 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
       continue;
     }
     s->hits_hint = n_hits;
+    if (s->host_counters[kCntOverrun] != 0) {
+      // some start was still alive after kMaxSimSteps bytes (an unbounded repetition over a very
+      // long run): the per-start walks would be quadratic, so refuse loudly rather than run for
+      // hours.  (A chunked state-carry scan for this case is future work)
+      return fail(RJ_TOO_LARGE, "a match candidate runs longer than %llu bytes; unbounded repetitions over such runs "
+                                "are not supported by the parallel verifier",
+                  static_cast<unsigned long long>(kMaxSimSteps));
+    }
     if (s->host_counters[kCntFinal] == ~0ull) {
       rc = finalize_large(s, n_hits, fp, st);
       if (rc != RJ_OK) return rc;

@@ -10,7 +10,7 @@
 namespace rejit_amd {
 
 // device counters (unsigned long long[kCntSize])
-enum { kCntCands = 0, kCntFinal = 1, kCntOverflow = 2, kCntAdjacent = 3, kCntHits = 4, kCntMaxRegion = 5, kCntSize = 8 };
+enum { kCntCands = 0, kCntFinal = 1, kCntOverflow = 2, kCntAdjacent = 3, kCntHits = 4, kCntMaxRegion = 5, kCntOverrun = 6, kCntSize = 8 };
 
 constexpr uint64_t kNoMatch = ~0ull;  // cand_end of a hit at which nothing matches
 
@@ -45,6 +45,7 @@ struct VerifyParams {
   uint32_t region_cap;
   uint64_t* cand_begin;     // one slot per hit, in hit (= text) order
   uint64_t* cand_end;       // kNoMatch when nothing matches at that start
+  unsigned long long* counters;  // kCntOverrun is set when a walk hits kMaxSimSteps
 };
 
 struct FinalizeParams {

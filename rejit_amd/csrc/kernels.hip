@@ -402,7 +402,9 @@ __global__ __launch_bounds__(256) void verify_lane(VerifyParams a, DevProgram P)
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_hits; i += stride) {
     const uint64_t s = hit_at(a, i);
     uint64_t e = 0;
-    const bool found = rj_lane_longest<NQ>(P, a.text, a.n, s, &e);
+    bool overrun = false;
+    const bool found = rj_lane_longest<NQ>(P, a.text, a.n, s, &e, &overrun);
+    if (overrun) a.counters[kCntOverrun] = 1;
     a.cand_begin[i] = s;
     a.cand_end[i] = found ? e : kNoMatch;
   }
@@ -413,7 +415,7 @@ namespace {
 // Automaton state spread over the wave: lane l holds 32-bit words l, l+64, ... (NR of them).
 template <int NR>
 __device__ bool wave_longest(const DevProgram& P, const uint8_t* t, uint64_t n, uint64_t s, uint64_t* end,
-                             bool anchored_full) {
+                             bool anchored_full, bool* overrun) {
   const int lane = lane_id();
   const int W = P.n_words;
   const bool ctxed = P.n_ctx > 1;
@@ -458,6 +460,10 @@ __device__ bool wave_longest(const DevProgram& P, const uint8_t* t, uint64_t n, 
       }
     }
     if (p == n) break;
+    if (!anchored_full && p - s >= kMaxSimSteps) {
+      *overrun = true;
+      break;
+    }
     uint32_t T[NR];
     uint32_t carry_in = 0;  // bit shifted out of the previous register's lane 63
 #pragma unroll
@@ -514,7 +520,9 @@ __global__ __launch_bounds__(256) void verify_lane_regions(VerifyParams a, DevPr
     for (uint64_t k = lane; k < hi - lo; k += kWave) {
       const uint64_t s = region[k];
       uint64_t e = 0;
-      const bool found = rj_lane_longest<NQ>(P, a.text, a.n, s, &e);
+      bool overrun = false;
+      const bool found = rj_lane_longest<NQ>(P, a.text, a.n, s, &e, &overrun);
+      if (overrun) a.counters[kCntOverrun] = 1;
       a.cand_begin[lo + k] = s;
       a.cand_end[lo + k] = found ? e : kNoMatch;
     }
@@ -529,7 +537,9 @@ __global__ __launch_bounds__(256) void verify_wave(VerifyParams a, DevProgram P)
   for (uint64_t i = wave; i < n_hits; i += n_waves) {
     const uint64_t s = hit_at(a, i);
     uint64_t e = 0;
-    const bool found = wave_longest<NR>(P, a.text, a.n, s, &e, false);
+    bool overrun = false;
+    const bool found = wave_longest<NR>(P, a.text, a.n, s, &e, false, &overrun);
+    if (overrun && lane_id() == 0) a.counters[kCntOverrun] = 1;
     if (lane_id() == 0) {
       a.cand_begin[i] = s;
       a.cand_end[i] = found ? e : kNoMatch;
@@ -541,7 +551,8 @@ __global__ __launch_bounds__(256) void verify_wave(VerifyParams a, DevProgram P)
 template <int NR>
 __global__ __launch_bounds__(64) void match_full(const uint8_t* text, uint64_t n, DevProgram P, int* result) {
   uint64_t e = 0;
-  const bool found = wave_longest<NR>(P, text, n, 0, &e, true);
+  bool overrun = false;
+  const bool found = wave_longest<NR>(P, text, n, 0, &e, true, &overrun);
   if (lane_id() == 0) result[0] = (found && e == n) ? 1 : 0;
 }
 
