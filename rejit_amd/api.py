@@ -26,13 +26,30 @@ def library_path() -> str:
     return LIB
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
+HASH = os.path.join(PKG, "librejit_hip.srchash")
+
+
+def _source_hash() -> str:
+    import hashlib
+    h = hashlib.sha256()
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
     deps += [os.path.join(PKG, "..", "include", f) for f in ("rejit.h", "rejit_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale() -> bool:
+    """The library is rebuilt when the CONTENT of a source differs from what it was built
+    from (mtimes do not survive the copy to the GPU box)."""
+    if not os.path.exists(LIB) or not os.path.exists(HASH):
+        return True
+    try:
+        return open(HASH).read().strip() != _source_hash()
+    except OSError:
+        return True
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -63,6 +80,8 @@ def _build_locked(verbose: bool) -> str:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
+    with open(HASH, "w") as f:
+        f.write(_source_hash() + "\n")
     return LIB
 
 
