@@ -84,6 +84,14 @@ int rj_match_first(const rj_program* prog, const char* text, size_t n, uint64_t*
 int64_t rj_match_all(const rj_program* prog, const char* text, size_t n, uint64_t** spans);
 void rj_free_spans(uint64_t* spans);
 
+/* ReplaceAll (replaces MatchAll + rejit::Replace, src/rejit.cc:97-112,220-226): every match is
+ * replaced by with[0..with_len).  Returns the number of matches (>= 0) or rj_status; *out receives
+ * a malloc'ed copy of the new text (NUL-terminated for convenience, *out_len excludes the NUL),
+ * to be released with rj_free_text.  Only the new text crosses PCIe, not the match list. */
+int64_t rj_replace_all(const rj_program* prog, const char* text, size_t n, const char* with, size_t with_len, char** out,
+                       size_t* out_len);
+void rj_free_text(char* text);
+
 /* ---- device-resident text (what bench.py and the multi-GPU driver use; no copies).
  * d_text must be 16-byte aligned device memory with bytes [0, n) readable.  Matches whose
  * BEGIN lies in [own_begin, own_end) are reported (own_end may be n + 1 to include the
@@ -97,6 +105,11 @@ int64_t rj_scan_run(rj_scan* scan, const void* d_text, uint64_t n, uint64_t own_
 /* results of the last run: device pointer to 2*count uint64 offsets, or a host copy */
 const uint64_t* rj_scan_device_spans(const rj_scan* scan);
 int64_t rj_scan_copy_spans(const rj_scan* scan, uint64_t* host_spans, uint64_t cap);
+/* Replace over device text: the matches of the LAST rj_scan_run on this scan (which must have
+ * covered d_text[0..n) ) are replaced by `with` (host bytes); the result is written to d_out
+ * (device, out_cap bytes).  Returns the new length or rj_status. */
+int64_t rj_scan_replace(rj_scan* scan, const void* d_text, uint64_t n, const char* with, uint64_t with_len, void* d_out,
+                        uint64_t out_cap, void* hip_stream);
 int rj_scan_stats(const rj_scan* scan, rj_stats* stats);
 /* 1 / 0 / <0: kMatchFull over device text */
 int rj_scan_match_full(rj_scan* scan, const void* d_text, uint64_t n, void* hip_stream);

@@ -103,7 +103,7 @@ _lib = None
 C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_error", "rj_match_full",
                  "rj_match_anywhere", "rj_match_first", "rj_match_all", "rj_free_spans", "rj_scan_create",
                  "rj_scan_destroy", "rj_scan_run", "rj_scan_device_spans", "rj_scan_copy_spans", "rj_scan_stats",
-                 "rj_scan_match_full", "rj_device_count"]
+                 "rj_scan_match_full", "rj_device_count", "rj_replace_all", "rj_free_text", "rj_scan_replace"]
 
 
 def load_library():
@@ -136,6 +136,11 @@ def load_library():
     L.rj_scan_copy_spans.argtypes = [vp, _u64p, u64]
     L.rj_scan_stats.argtypes = [vp, ctypes.POINTER(_Stats)]
     L.rj_scan_match_full.argtypes = [vp, vp, u64, vp]
+    L.rj_replace_all.restype = i64
+    L.rj_replace_all.argtypes = [vp, cp, sz, cp, sz, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz)]
+    L.rj_free_text.argtypes = [ctypes.c_void_p]
+    L.rj_scan_replace.restype = i64
+    L.rj_scan_replace.argtypes = [vp, vp, u64, cp, u64, vp, u64, vp]
     L.rj_device_count.restype = ctypes.c_int
     _lib = L
     return L
@@ -186,6 +191,15 @@ class Program:
     def count(self, text: bytes) -> int:
         return int(_check(self._lib.rj_match_all(self._h, text, len(text), None)))
 
+    def replace_all(self, text: bytes, repl: bytes) -> Tuple[int, bytes]:
+        """(number of matches, new text): MatchAll + Replace, spliced on the GPU."""
+        out = ctypes.c_void_p()
+        out_len = ctypes.c_size_t()
+        m = _check(self._lib.rj_replace_all(self._h, text, len(text), repl, len(repl), ctypes.byref(out), ctypes.byref(out_len)))
+        data = ctypes.string_at(out, out_len.value)
+        self._lib.rj_free_text(out)
+        return int(m), data
+
     def match_first(self, text: bytes) -> Optional[Tuple[int, int]]:
         b, e = ctypes.c_uint64(), ctypes.c_uint64()
         r = _check(self._lib.rj_match_first(self._h, text, len(text), ctypes.byref(b), ctypes.byref(e)))
@@ -228,6 +242,11 @@ class Scan:
         assert t.dtype == torch.uint8 and t.is_contiguous() and t.is_cuda
         st = torch.cuda.current_stream(t.device).cuda_stream if stream is None else stream
         return self.run(t.data_ptr(), int(t.numel() if n is None else n), stream=st, **kw)
+
+    def replace(self, d_text_ptr: int, n: int, repl: bytes, d_out_ptr: int, out_cap: int, stream: int = 0) -> int:
+        """Replace the matches of the last run(); returns the new length (text stays in HBM)."""
+        return int(_check(self._lib.rj_scan_replace(self._h, ctypes.c_void_p(d_text_ptr), n, repl, len(repl),
+                                                    ctypes.c_void_p(d_out_ptr), out_cap, ctypes.c_void_p(stream))))
 
     def spans(self) -> List[Tuple[int, int]]:
         n = int(_check(self._lib.rj_scan_copy_spans(self._h, None, 0)))

@@ -118,6 +118,7 @@ struct rj_scan {
   DeviceBuffer counters, hits, hit_counts, hit_offsets, cand_begin, cand_end, out, acc_out, keys_out, vals_out, sort_tmp, flag;
   DeviceBuffer scan_a, scan_b, taken;  // large-path selection scratch
   DeviceBuffer ring;                   // exact sequential kernel
+  DeviceBuffer with_buf, long_gaps, repl_out;  // replace_gather
   uint64_t cands_cap = 0, out_cap = 0;
   uint32_t region_cap_hint = 64;   // hit-region size that sufficed last time (windows mode)
   uint64_t hits_hint = 0;          // hits of the previous run (sizes the verify grid)
@@ -702,6 +703,76 @@ int64_t rj_scan_copy_spans(const rj_scan* s, uint64_t* host_spans, uint64_t cap)
   }
   return static_cast<int64_t>(s->result_count);
 }
+
+int64_t rj_scan_replace(rj_scan* s, const void* d_text, uint64_t n, const char* with, uint64_t with_len, void* d_out,
+                        uint64_t out_cap, void* hip_stream) {
+  ErrnoGuard errno_guard;
+  if (!s || (!with && with_len)) return fail(RJ_BAD_ARGUMENT, "null argument");
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const uint64_t m = s->result_count;
+  const uint64_t* spans = s->result;
+  RJ_HIP(s->with_buf.reserve(std::max<uint64_t>(with_len, 16)));
+  if (with_len) RJ_HIP(hipMemcpyAsync(s->with_buf.p, with, with_len, hipMemcpyHostToDevice, st));
+  RJ_HIP(s->scan_a.reserve(std::max<uint64_t>(m, 1) * sizeof(uint64_t)));
+  RJ_HIP(s->scan_b.reserve(std::max<uint64_t>(m, 1) * sizeof(uint64_t)));
+  RJ_HIP(s->long_gaps.reserve((m + 1) * 3 * sizeof(uint64_t)));
+  RJ_HIP(hipMemsetAsync(s->counters.p, 0, kCntSize * sizeof(unsigned long long), st));
+  if (m) {
+    launch_match_lengths(spans, m, s->scan_a.as<uint64_t>(), st);
+    size_t bytes = 0;
+    RJ_HIP(rocprim::exclusive_scan(nullptr, bytes, s->scan_a.as<uint64_t>(), s->scan_b.as<uint64_t>(), uint64_t{0}, m,
+                                   rocprim::plus<uint64_t>(), st));
+    RJ_HIP(s->sort_tmp.reserve(std::max<size_t>(bytes, 16)));
+    RJ_HIP(rocprim::exclusive_scan(s->sort_tmp.p, bytes, s->scan_a.as<uint64_t>(), s->scan_b.as<uint64_t>(), uint64_t{0}, m,
+                                   rocprim::plus<uint64_t>(), st));
+  }
+  launch_replace_gather(static_cast<const uint8_t*>(d_text), n, spans, s->scan_b.as<uint64_t>(), m, s->with_buf.as<uint8_t>(),
+                        with_len, static_cast<uint8_t*>(d_out), out_cap, s->long_gaps.as<uint64_t>(),
+                        s->counters.as<unsigned long long>(), st);
+  RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  RJ_HIP(hipStreamSynchronize(st));
+  RJ_HIP(hipGetLastError());
+  const uint64_t new_len = s->host_counters[kCntFinal];
+  if (new_len > out_cap) return fail(RJ_BAD_ARGUMENT, "replace output needs %llu bytes", static_cast<unsigned long long>(new_len));
+  return static_cast<int64_t>(new_len);
+}
+
+int64_t rj_replace_all(const rj_program* prog, const char* text, size_t n, const char* with, size_t with_len, char** out,
+                       size_t* out_len) {
+  ErrnoGuard errno_guard;
+  if (!prog || (!text && n) || !out || !out_len) return fail(RJ_BAD_ARGUMENT, "null argument");
+  *out = nullptr;
+  *out_len = 0;
+  rj_scan* s = nullptr;
+  int rc = host_scan_for(prog, &s);
+  if (rc != RJ_OK) return rc;
+  const uint8_t* d_text = nullptr;
+  rc = stage_text(s, text, n, &d_text);
+  if (rc != RJ_OK) return rc;
+  rc = run_pipeline(s, d_text, n, 0, n + 1, 0, 0, 0, s->own_stream);
+  if (rc != RJ_OK) return rc;
+  const uint64_t m = s->result_count;
+  // worst case: every match is empty and nothing is removed
+  uint64_t cap = n + m * with_len + 64;
+  RJ_HIP(s->repl_out.reserve(cap));
+  int64_t new_len = rj_scan_replace(s, d_text, n, with, with_len, s->repl_out.p, cap, s->own_stream);
+  if (new_len < 0) return new_len;
+  char* h = static_cast<char*>(malloc(static_cast<size_t>(new_len) + 1));
+  if (!h) return fail(RJ_DEVICE_ERROR, "out of host memory");
+  if (new_len) {
+    hipError_t e = hipMemcpy(h, s->repl_out.p, static_cast<size_t>(new_len), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+      free(h);
+      return fail(RJ_DEVICE_ERROR, "hipMemcpy failed: %s", hipGetErrorString(e));
+    }
+  }
+  h[new_len] = 0;
+  *out = h;
+  *out_len = static_cast<size_t>(new_len);
+  return static_cast<int64_t>(m);
+}
+
+void rj_free_text(char* text) { free(text); }
 
 int rj_scan_stats(const rj_scan* s, rj_stats* stats) {
   if (!s || !stats) return fail(RJ_BAD_ARGUMENT, "null argument");

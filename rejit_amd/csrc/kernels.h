@@ -94,6 +94,12 @@ void launch_detect_adjacent(const uint64_t* keys, const uint64_t* vals, uint64_t
 // the reference's no-fast-forward algorithm on one lane (exact incl. its ring-slot artefact)
 void launch_exact_sequential(const uint8_t* text, uint64_t n, const DevGraph& G, int64_t* ring, uint64_t* out,
                              uint64_t out_cap, unsigned long long* counters, hipStream_t st);
+// Replace: match lengths (input of the prefix sum) and the gather itself; the result length is
+// left in counters[kCntFinal]; long_gaps needs 3 * (m + 1) uint64
+void launch_match_lengths(const uint64_t* spans, uint64_t m, uint64_t* len, hipStream_t st);
+void launch_replace_gather(const uint8_t* text, uint64_t n, const uint64_t* spans, const uint64_t* removed, uint64_t m,
+                           const uint8_t* with, uint64_t with_len, uint8_t* out, uint64_t out_cap, uint64_t* long_gaps,
+                           unsigned long long* counters, hipStream_t st);
 void launch_select_walk(const uint64_t* keys, const uint64_t* vals, const uint64_t* pmax, uint64_t n,
                         uint64_t carry_cur, uint8_t* taken, hipStream_t st);
 void launch_taken_index(const uint8_t* taken, uint64_t n, uint64_t* idx, hipStream_t st);

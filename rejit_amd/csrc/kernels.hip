@@ -876,6 +876,63 @@ __global__ void check_and_interleave(const uint64_t* keys, const uint64_t* vals,
 }
 
 // ---------------------------------------------------------------------------------------
+// replace_gather: rejit::Replace (reference src/rejit.cc:97-112: append the text between the
+// matches and the replacement, sequentially) as a parallel gather.  With M ordered,
+// non-overlapping matches the text has M+1 gaps; gap i = [end[i-1], begin[i]) lands at
+//     dst_i = gap_begin_i - (bytes removed before it) + i * with_len
+// followed (for i < M) by the replacement.  `removed` = exclusive prefix sum of the match
+// lengths, computed by the caller.
+__global__ __launch_bounds__(256) void match_lengths(const uint64_t* spans, uint64_t m, uint64_t* len) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < m) len[i] = spans[2 * i + 1] - spans[2 * i];
+}
+
+constexpr uint64_t kLongGap = 4096;  // gaps longer than this are copied by the whole grid
+
+__global__ __launch_bounds__(256) void replace_gather(const uint8_t* text, uint64_t n, const uint64_t* spans,
+                                                      const uint64_t* removed, uint64_t m, const uint8_t* with,
+                                                      uint64_t with_len, uint8_t* out, uint64_t out_cap,
+                                                      uint64_t* long_gaps, unsigned long long* counters) {
+  const int lane = lane_id();
+  const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+  for (uint64_t i = wave; i <= m; i += n_waves) {  // one wave per gap (typically a line: ~60 bytes)
+    const uint64_t gb = i == 0 ? 0 : spans[2 * (i - 1) + 1];
+    const uint64_t ge = i == m ? n : spans[2 * i];
+    const uint64_t rem = i == m ? (m ? removed[m - 1] + (spans[2 * (m - 1) + 1] - spans[2 * (m - 1)]) : 0) : removed[i];
+    const uint64_t dst = gb - rem + i * with_len;
+    const uint64_t len = ge - gb;
+    if (len > kLongGap) {
+      if (lane == 0) {  // rare: hand the gap to the grid-wide copy
+        const unsigned long long k = atomicAdd(counters + kCntHits, 1ull);
+        long_gaps[3 * k] = gb;
+        long_gaps[3 * k + 1] = len;
+        long_gaps[3 * k + 2] = dst;
+      }
+    } else {
+      for (uint64_t k = lane; k < len; k += kWave)
+        if (dst + k < out_cap) out[dst + k] = text[gb + k];
+    }
+    if (i < m)
+      for (uint64_t k = lane; k < with_len; k += kWave)
+        if (dst + len + k < out_cap) out[dst + len + k] = with[k];
+    if (i == m && lane == 0) counters[kCntFinal] = dst + len;  // length of the result
+  }
+}
+
+__global__ __launch_bounds__(256) void copy_long_gaps(const uint8_t* text, const uint64_t* long_gaps,
+                                                      const unsigned long long* counters, uint8_t* out, uint64_t out_cap) {
+  const uint64_t n_gaps = counters[kCntHits];
+  const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t g = 0; g < n_gaps; g++) {
+    const uint64_t src = long_gaps[3 * g], len = long_gaps[3 * g + 1], dst = long_gaps[3 * g + 2];
+    for (uint64_t k = tid; k < len; k += stride)
+      if (dst + k < out_cap) out[dst + k] = text[src + k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Launchers (host side of the <<< >>> syntax lives here so engine.cc stays plain C++).
 ScanGeometry scan_geometry(uint64_t chunks) {
   // Measured on MI355X (tools/ab_probe.py): a grid of exactly the resident workgroups loses
@@ -1003,6 +1060,21 @@ void launch_detect_adjacent(const uint64_t* keys, const uint64_t* vals, uint64_t
 void launch_exact_sequential(const uint8_t* text, uint64_t n, const DevGraph& G, int64_t* ring, uint64_t* out,
                              uint64_t out_cap, unsigned long long* counters, hipStream_t st) {
   hipLaunchKernelGGL(exact_sequential, dim3(1), dim3(64), 0, st, text, n, G, ring, out, out_cap, counters);
+}
+
+void launch_match_lengths(const uint64_t* spans, uint64_t m, uint64_t* len, hipStream_t st) {
+  if (m == 0) return;
+  hipLaunchKernelGGL(match_lengths, dim3(static_cast<unsigned>((m + 255) / 256)), dim3(256), 0, st, spans, m, len);
+}
+
+void launch_replace_gather(const uint8_t* text, uint64_t n, const uint64_t* spans, const uint64_t* removed, uint64_t m,
+                           const uint8_t* with, uint64_t with_len, uint8_t* out, uint64_t out_cap, uint64_t* long_gaps,
+                           unsigned long long* counters, hipStream_t st) {
+  uint64_t blocks = (m + 1 + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(replace_gather, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, text, n, spans, removed, m, with,
+                     with_len, out, out_cap, long_gaps, counters);
+  hipLaunchKernelGGL(copy_long_gaps, dim3(2048), dim3(256), 0, st, text, long_gaps, counters, out, out_cap);
 }
 
 static unsigned blocks_for(uint64_t n) { return static_cast<unsigned>((n + 255) / 256); }

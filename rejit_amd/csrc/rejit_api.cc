@@ -124,10 +124,18 @@ bool Regej::ReplaceFirst(string& text, const string& with) {
 }
 
 size_t Regej::ReplaceAll(string& text, const string& with) {
-  std::vector<Match> ms;
-  MatchAll(text, &ms);
-  Replace(&ms, text, with);
-  return ms.size();
+  if (status_ != RejitSuccess) return 0;
+  // MatchAll + Replace fused on the device: only the new text comes back over PCIe
+  char* out = nullptr;
+  size_t out_len = 0;
+  int64_t n = rj_replace_all(program_, text.data(), text.size(), with.data(), with.size(), &out, &out_len);
+  if (n < 0) {
+    set_status_string(rj_last_error());
+    return 0;
+  }
+  text.assign(out, out_len);
+  rj_free_text(out);
+  return static_cast<size_t>(n);
 }
 
 // ----------------------------------------------------------------------------- free functions

@@ -51,3 +51,15 @@ def test_reference_jrep_sample_equals_grep(tmp_path):
         ref = subprocess.run(["grep", "-R", "-H", "-n", pattern, "."], cwd=tmp_path, capture_output=True).stdout
         assert sorted(ours.splitlines()) == sorted(ref.splitlines()), pattern
         assert len(ref.splitlines()) > 0
+
+
+def test_own_regexdna_counterpart(tmp_path):
+    """samples/regexdna_gpu.py (text resident in HBM for the whole program) prints the same
+    output as the reference's sample on the same input."""
+    import sys
+    g = V.bench()["regexdna"]["50000"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "samples", "regexdna_gpu.py"), "--n", "50000"],
+                         capture_output=True, timeout=600, check=True).stdout.decode()
+    lines = out.strip().split("\n")
+    assert [int(l.rsplit(" ", 1)[1]) for l in lines[:9]] == [3, 12, 43, 27, 58, 16, 15, 18, 20]
+    assert [int(x) for x in lines[-3:]] == [508411, 500000, 668262]

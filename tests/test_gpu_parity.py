@@ -248,3 +248,56 @@ def test_planted_literal_large(rj):
     assert set(offs) <= set(truth)
     st = scan.stats()
     assert st["n_matches"] == count and st["scan_ms"] > 0
+
+
+def _splice(text: bytes, spans, repl: bytes) -> bytes:
+    out, p = bytearray(), 0
+    for b_, e_ in spans:
+        out += text[p:b_] + repl
+        p = e_
+    out += text[p:]
+    return bytes(out)
+
+
+def test_replace_all_vs_oracle(rj, oracle):
+    """rj_replace_all (MatchAll + the device replace_gather) == the reference's Replace
+    (src/rejit.cc:97-112) applied to the oracle's matches."""
+    from rejit_amd import workloads as W
+    rng = random.Random(17)
+    cases = [(b"regexp", b"X"), (b"a", b""), (b"ab|ba", b"<->"), (b"x*", b"-"), (b"\n", b""), (b">.*\n|\n", b""),
+             (b"[0-9]+", b"#"), (b"^", b"> "), (b"zzzz", b"never")]
+    for rx, repl in cases:
+        for n in (0, 1, 50, 3000, 200000):
+            text = bytes(rng.choice(b"ab\nx>1regexp z") for _ in range(n))
+            want_spans = oracle.match_all(rx, text)
+            m, got = prog(rj, rx).replace_all(text, repl)
+            assert m == len(want_spans) and got == _splice(text, want_spans, repl), (rx, n)
+    # long gaps (copied by the whole grid) and the regexdna pipeline sizes
+    big = W.random_ascii_numpy(3_000_000, 3)
+    offs = W.plant_offsets(len(big), 6, 5, seed=5)
+    W.plant(big, offs, b"regexp")
+    tb = big.tobytes()
+    m, got = prog(rj, b"regexp").replace_all(tb, b"<<literal>>")
+    assert got == tb.replace(b"regexp", b"<<literal>>") and m == tb.count(b"regexp")
+    g = V.bench()["regexdna"]["50000"]
+    raw = W.fasta_raw_numpy(50000).tobytes()
+    m, stripped = prog(rj, V.b(g["strip"]["regex"])).replace_all(raw, b"")
+    assert m == g["strip"]["count"] and hashlib.sha256(stripped).hexdigest() == g["stripped_sha256"]
+    text = stripped
+    for code, repl in W.REGEXDNA_IUB:
+        _, text = prog(rj, code.encode()).replace_all(text, repl.encode())
+    assert len(text) == g["replaced_size"] and hashlib.sha256(text).hexdigest() == g["replaced_sha256"]
+
+
+def test_device_replace_keeps_text_in_hbm(rj):
+    import torch
+    from rejit_amd import workloads as W
+    dev = torch.device("cuda:0")
+    raw = torch.from_numpy(W.fasta_raw_numpy(20000)).to(dev)
+    scan = rj.Scan(rj.Program(W.REGEXDNA_STRIP))
+    n = raw.numel()
+    m = scan.run_tensor(raw)
+    out = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    new_len = scan.replace(raw.data_ptr(), n, b"", out.data_ptr(), out.numel())
+    assert new_len == 200000 and m == n - new_len - (len(b"".join(W.HEADERS)) - 3)
+    assert (out[:new_len].cpu().numpy() == W.fasta_stripped_numpy(20000)).all()
