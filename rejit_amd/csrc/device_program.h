@@ -35,6 +35,8 @@ struct DevProgram {
   uint32_t win_len;     // pattern bytes covered by a window (1..8)
   uint32_t win_value0[kDevMaxWindows], win_mask0[kDevMaxWindows];  // first dword of the window
   uint32_t win_value1[kDevMaxWindows], win_mask1[kDevMaxWindows];  // second dword (win_len > 4)
+  uint32_t float_range;  // candidate starts per window hit: 1 = fixed offset, else float_max-float_min+1
+  uint32_t float_max;    // floating windows: start s = w - float_max + delta, delta < float_range
   uint32_t first_bytes[8];
   uint64_t min_len;
   const uint32_t* first;

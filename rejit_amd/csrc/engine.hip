@@ -195,6 +195,8 @@ int upload_program(rj_program* rp) {
       }
     rp->window_alphabet = seen.count();
   }
+  D.float_range = P.floating ? P.float_max - P.float_min + 1 : 1;
+  D.float_max = P.floating ? P.float_max : 0;
   for (int k = 0; k < 8; k++) D.first_bytes[k] = P.first_bytes.w[k];
   D.min_len = P.min_len;
   D.first = base + off_first;
@@ -289,7 +291,7 @@ int ensure_lists(rj_scan* s, uint32_t n_regions, uint32_t region_cap, uint64_t c
 
 // Large path: more hit slots than finalize_small handles in LDS.  The slots are already in
 // text order, so no sort: drop the kNoMatch slots, then check / select.
-int finalize_large(rj_scan* s, uint64_t n_slots, const FinalizeParams& fp, hipStream_t st) {
+int finalize_large(rj_scan* s, uint64_t n_slots, bool unsorted, uint64_t text_len, const FinalizeParams& fp, hipStream_t st) {
   s->stats.large_path = 1;
   RJ_HIP(s->keys_out.reserve(n_slots * sizeof(uint64_t)));
   RJ_HIP(s->vals_out.reserve(n_slots * sizeof(uint64_t)));
@@ -314,6 +316,25 @@ int finalize_large(rj_scan* s, uint64_t n_slots, const FinalizeParams& fp, hipSt
   RJ_HIP(scan(sa, sb, n_slots, false));
   launch_compact_valid(s->cand_begin.as<uint64_t>(), s->cand_end.as<uint64_t>(), sa, sb, n_slots, keys, vals,
                        s->counters.as<unsigned long long>(), st);
+  if (unsorted) {
+    // floating windows: the starts derived from neighbouring hits interleave (and may repeat), so
+    // this mode -- rare hits by construction -- pays for a sort of the compacted candidates
+    RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    RJ_HIP(hipStreamSynchronize(st));
+    const uint64_t nc = s->host_counters[kCntCands];
+    if (nc > 1) {
+      unsigned bits = 1;
+      while (bits < 64 && (text_len >> bits) != 0) bits++;
+      uint64_t* k2 = s->cand_begin.as<uint64_t>();  // free again: reuse as sort output
+      uint64_t* v2 = s->cand_end.as<uint64_t>();
+      size_t tmp_bytes = 0;
+      RJ_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, k2, vals, v2, nc, 0, bits, st));
+      RJ_HIP(s->sort_tmp.reserve(std::max<size_t>(tmp_bytes, 16)));
+      RJ_HIP(rocprim::radix_sort_pairs(s->sort_tmp.p, tmp_bytes, keys, k2, vals, v2, nc, 0, bits, st));
+      RJ_HIP(hipMemcpyAsync(keys, k2, nc * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+      RJ_HIP(hipMemcpyAsync(vals, v2, nc * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    }
+  }
   // 2. common case, still without a host round trip: the candidates already are the result
   //    (the kernels read the candidate count from device memory; grids sized for n_slots)
   if (fp.detect_adjacent) launch_detect_adjacent(keys, vals, n_slots, s->counters.as<unsigned long long>(), st);
@@ -376,10 +397,13 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
   sp.sb = sb;
   sp.se = se;
   uint64_t first_chunk, end_chunk;
+  const uint32_t expand = windows ? D.float_range : 1;
   if (windows) {
-    sp.wlo = sb + D.win_offset;
+    // fixed windows: w = s + offset.  floating: w in [s + float_min, s + float_max]
+    const uint64_t float_min = D.float_max + 1 - D.float_range;
+    sp.wlo = sb + (expand > 1 ? float_min : D.win_offset);
     const uint64_t last_w = n >= D.win_len ? n - D.win_len + 1 : 0;  // a window must fit: w + len <= n
-    sp.whi = std::min(se + D.win_offset, last_w);
+    sp.whi = std::min(se + (expand > 1 ? D.float_max : D.win_offset), last_w);
     if (sp.whi < sp.wlo) sp.whi = sp.wlo;
     first_chunk = sp.wlo / 1024;
     end_chunk = (sp.whi + 1023) / 1024;
@@ -396,7 +420,10 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
 
   for (int attempt = 0; attempt < 6; attempt++) {
     const uint64_t slots = static_cast<uint64_t>(geo.n_regions) * region_cap;
-    int rc = ensure_lists(s, geo.n_regions, static_cast<uint32_t>(region_cap), std::max<uint64_t>(slots, 1u << 12));
+    // candidate slots: one per (hit, possible start); floating windows start with room for a few
+    // thousand hits and grow when a run needs more
+    uint64_t cand_slots = expand == 1 ? slots : std::max<uint64_t>(s->hits_hint * expand * 2, 1u << 16);
+    int rc = ensure_lists(s, geo.n_regions, static_cast<uint32_t>(region_cap), std::max<uint64_t>(cand_slots, 1u << 12));
     if (rc != RJ_OK) return rc;
     sp.hits = s->hits.as<uint64_t>();
     sp.region_cap = static_cast<uint32_t>(region_cap);
@@ -434,6 +461,23 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
     vp.cand_begin = s->cand_begin.as<uint64_t>();
     vp.cand_end = s->cand_end.as<uint64_t>();
     vp.counters = s->counters.as<unsigned long long>();
+    vp.sb = sb;
+    vp.se = se;
+    vp.expand = expand;
+    vp.float_max = D.float_max;
+    if (expand > 1) {
+      // the slot count depends on the hit count, which only the device knows yet: verify must not
+      // write past the candidate arrays, so floating runs read the count first (hits are rare)
+      RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+      RJ_HIP(hipStreamSynchronize(st));
+      if (s->host_counters[kCntOverflow] == 0) {
+        const uint64_t need = s->host_counters[kCntHits] * expand;
+        rc = ensure_lists(s, geo.n_regions, static_cast<uint32_t>(region_cap), std::max<uint64_t>(need, s->cands_cap));
+        if (rc != RJ_OK) return rc;
+        vp.cand_begin = s->cand_begin.as<uint64_t>();
+        vp.cand_end = s->cand_end.as<uint64_t>();
+      }
+    }
     launch_verify(vp, D, windows ? std::max<uint64_t>(s->hits_hint, 1u << 14) : (se - sb) / 8 + 1, st);
     FinalizeParams fp{};
     fp.cand_begin = s->cand_begin.as<uint64_t>();
@@ -449,6 +493,7 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
     // pattern is at risk AND a candidate begins exactly where another one ends
     const bool whole_text = sb == 0 && se == n + 1 && carry_cur == 0 && !have_prev;
     fp.detect_adjacent = rp->host->q8_risk && whole_text;
+    fp.expand = expand;
     launch_finalize_small(fp, st);
     RJ_HIP(hipEventRecord(s->ev[3], st));
     RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -479,7 +524,7 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
                   static_cast<unsigned long long>(kMaxSimSteps));
     }
     if (s->host_counters[kCntFinal] == ~0ull) {
-      rc = finalize_large(s, n_hits, fp, st);
+      rc = finalize_large(s, n_hits * expand, expand > 1, n + 1, fp, st);
       if (rc != RJ_OK) return rc;
     } else {
       s->result_count = s->host_counters[kCntFinal];

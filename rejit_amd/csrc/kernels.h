@@ -43,7 +43,10 @@ struct VerifyParams {
   const uint64_t* offsets;  // [n_regions + 1], offsets[n_regions] = number of hits
   uint32_t n_regions;
   uint32_t region_cap;
-  uint64_t* cand_begin;     // one slot per hit, in hit (= text) order
+  uint64_t sb, se;          // candidate starts must lie in [sb, se)
+  uint32_t expand;          // slots per hit (floating windows: one per possible start), >= 1
+  uint32_t float_max;       // slot (hit h, delta d): start = hit - float_max + d
+  uint64_t* cand_begin;     // one slot per (hit, delta), in hit (= text) order
   uint64_t* cand_end;       // kNoMatch when nothing matches at that start
   unsigned long long* counters;  // kCntOverrun is set when a walk hits kMaxSimSteps
 };
@@ -60,6 +63,7 @@ struct FinalizeParams {
   uint64_t carry_prev_end;  // end of the previous match (zero-length rule)
   int have_prev;
   int detect_adjacent;      // set counters[kCntAdjacent] when a candidate begins where another ends
+  uint32_t expand;          // candidate slots per hit (see VerifyParams)
 };
 
 // grid of the scan kernels for a run over `chunks` 1-KiB chunks: workgroups (4 waves each),

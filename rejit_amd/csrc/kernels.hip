@@ -397,13 +397,16 @@ __device__ __forceinline__ uint64_t hit_at(const VerifyParams& a, uint64_t i) {
 // that start), so the candidates stay sorted by begin and need no atomic either.
 template <int NQ>
 __global__ __launch_bounds__(256) void verify_lane(VerifyParams a, DevProgram P) {
-  const uint64_t n_hits = a.offsets[a.n_regions];
+  const uint64_t n_slots = a.offsets[a.n_regions] * a.expand;
   const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_hits; i += stride) {
-    const uint64_t s = hit_at(a, i);
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_slots; i += stride) {
+    // slot i = (hit i / expand, delta i % expand); fixed-offset windows have expand == 1
+    const uint64_t w = hit_at(a, i / a.expand);
+    const uint64_t back = static_cast<uint64_t>(a.float_max) - (i % a.expand);
     uint64_t e = 0;
-    bool overrun = false;
-    const bool found = rj_lane_longest<NQ>(P, a.text, a.n, s, &e, &overrun);
+    bool overrun = false, found = false;
+    const uint64_t s = w - back;
+    if (w >= back && s >= a.sb && s < a.se) found = rj_lane_longest<NQ>(P, a.text, a.n, s, &e, &overrun);
     if (overrun) a.counters[kCntOverrun] = 1;
     a.cand_begin[i] = s;
     a.cand_end[i] = found ? e : kNoMatch;
@@ -531,14 +534,16 @@ __global__ __launch_bounds__(256) void verify_lane_regions(VerifyParams a, DevPr
 
 template <int NR>
 __global__ __launch_bounds__(256) void verify_wave(VerifyParams a, DevProgram P) {
-  const uint64_t n_hits = a.offsets[a.n_regions];
+  const uint64_t n_slots = a.offsets[a.n_regions] * a.expand;
   const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
   const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
-  for (uint64_t i = wave; i < n_hits; i += n_waves) {
-    const uint64_t s = hit_at(a, i);
+  for (uint64_t i = wave; i < n_slots; i += n_waves) {
+    const uint64_t w = hit_at(a, i / a.expand);
+    const uint64_t back = static_cast<uint64_t>(a.float_max) - (i % a.expand);
+    const uint64_t s = w - back;
     uint64_t e = 0;
     bool overrun = false;
-    const bool found = wave_longest<NR>(P, a.text, a.n, s, &e, false, &overrun);
+    const bool found = w >= back && s >= a.sb && s < a.se && wave_longest<NR>(P, a.text, a.n, s, &e, false, &overrun);
     if (overrun && lane_id() == 0) a.counters[kCntOverrun] = 1;
     if (lane_id() == 0) {
       a.cand_begin[i] = s;
@@ -564,7 +569,7 @@ __global__ __launch_bounds__(1024) void finalize_small(FinalizeParams a) {
   __shared__ uint64_t val[kFinalizeCap];
   __shared__ int all_disjoint;
   __shared__ int n_valid;
-  const unsigned long long n_raw = a.counters[kCntHits];  // one candidate slot per hit
+  const unsigned long long n_raw = a.counters[kCntHits] * a.expand;  // candidate slots
   if (n_raw > a.cands_cap || a.counters[kCntOverflow] != 0) {
     if (threadIdx.x == 0) {  // a list overflowed: the host grows it and retries
       a.counters[kCntOverflow] = 1;

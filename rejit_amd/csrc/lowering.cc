@@ -482,7 +482,10 @@ class Automaton {
       level = step_any(level);
       if (!level.any()) break;
     }
-    if (best.empty()) return;
+    if (best.empty()) {
+      plan_floating(first_any);
+      return;
+    }
     p_->mode = ScanMode::Windows;
     for (const Pattern& pt : best) {
       FFWindow w{};
@@ -499,6 +502,135 @@ class Automaton {
         }
       }
       p_->windows.push_back(w);
+    }
+  }
+
+  // ---- floating windows: a set of literal edges that every match has to cross ----
+  bool is_cut(const std::vector<char>& chosen) const {
+    // can the exit be reached from the entry without using a chosen byte edge?
+    std::vector<char> seen(static_cast<size_t>(g_.n_states), 0);
+    std::vector<int> stack{g_.entry};
+    seen[static_cast<size_t>(g_.entry)] = 1;
+    while (!stack.empty()) {
+      int q = stack.back();
+      stack.pop_back();
+      if (q == g_.exit) return false;
+      for (const ControlEdge* c : ctrl_[static_cast<size_t>(q)])
+        if (!seen[static_cast<size_t>(c->dst)]) {
+          seen[static_cast<size_t>(c->dst)] = 1;
+          stack.push_back(c->dst);
+        }
+      for (int e : out_edges_[static_cast<size_t>(q)]) {
+        if (chosen[static_cast<size_t>(e)]) continue;
+        int d = g_.byte_edges[static_cast<size_t>(e)].dst;
+        if (!seen[static_cast<size_t>(d)]) {
+          seen[static_cast<size_t>(d)] = 1;
+          stack.push_back(d);
+        }
+      }
+    }
+    return true;
+  }
+
+  void plan_floating(const Bits& first_any) {
+    const size_t ne = g_.byte_edges.size();
+    // candidate cuts, strongest first: one literal edge alone (longest first), then all literal
+    // edges of at least L bytes for L = 8..2
+    std::vector<std::vector<char>> tries;
+    std::vector<size_t> by_len;
+    for (size_t e = 0; e < ne; e++)
+      if (g_.byte_edges[e].bytes.size() >= 2) by_len.push_back(e);
+    std::sort(by_len.begin(), by_len.end(), [&](size_t a, size_t b) {
+      return g_.byte_edges[a].bytes.size() > g_.byte_edges[b].bytes.size();
+    });
+    for (size_t e : by_len) {
+      std::vector<char> c(ne, 0);
+      c[e] = 1;
+      tries.push_back(std::move(c));
+      if (tries.size() >= 64) break;
+    }
+    for (size_t L = 8; L >= 2; L--) {
+      std::vector<char> c(ne, 0);
+      int n = 0;
+      for (size_t e = 0; e < ne; e++)
+        if (g_.byte_edges[e].bytes.size() >= L) { c[e] = 1; n++; }
+      if (n) tries.push_back(std::move(c));
+    }
+    // depth range of every position: dmin by BFS levels, dmax by longest path (inf on a cycle)
+    std::vector<uint32_t> dmin(static_cast<size_t>(P_), 0xFFFFFFFFu);
+    {
+      Bits level = first_any, seen(W_);
+      uint32_t depth = 0;
+      while (level.any()) {
+        level.for_each([&](int i) { dmin[static_cast<size_t>(i)] = depth; });
+        seen |= level;
+        Bits next = step_any(level);
+        for (int k = 0; k < W_; k++) next.w[static_cast<size_t>(k)] &= ~seen.w[static_cast<size_t>(k)];
+        level = next;
+        depth++;
+      }
+    }
+    std::vector<std::vector<int>> preds(static_cast<size_t>(P_));
+    for (int i = 0; i < P_; i++) follow_any(i).for_each([&](int j) { preds[static_cast<size_t>(j)].push_back(i); });
+    constexpr uint32_t kInf = 0xFFFFFFFFu;
+    std::vector<int> colour(static_cast<size_t>(P_), 0);
+    std::vector<uint32_t> dmax(static_cast<size_t>(P_), 0);
+    std::function<uint32_t(int)> longest = [&](int i) -> uint32_t {
+      if (colour[static_cast<size_t>(i)] == 2) return dmax[static_cast<size_t>(i)];
+      if (colour[static_cast<size_t>(i)] == 1) return kInf;  // cycle among the ancestors
+      colour[static_cast<size_t>(i)] = 1;
+      uint32_t best = 0;  // a first position can be entered with nothing consumed
+      bool is_first = first_any.get(i);
+      bool any_pred = false;
+      for (int q : preds[static_cast<size_t>(i)]) {
+        uint32_t v = longest(q);
+        if (v == kInf) { best = kInf; break; }
+        best = std::max(best, v + 1);
+        any_pred = true;
+      }
+      if (!is_first && !any_pred) best = kInf;  // unreachable: treat as unusable
+      colour[static_cast<size_t>(i)] = 2;
+      dmax[static_cast<size_t>(i)] = best;
+      return best;
+    };
+    for (const std::vector<char>& chosen : tries) {
+      if (!is_cut(chosen)) continue;
+      // windows = the first min(8, len) bytes of the distinct literals; common length
+      size_t wl = 8;
+      std::set<std::string> lits;
+      uint32_t lo = kInf, hi = 0;
+      bool ok = true;
+      for (size_t e = 0; e < ne && ok; e++) {
+        if (!chosen[e]) continue;
+        const std::string& b = g_.byte_edges[e].bytes;
+        wl = std::min(wl, b.size());
+        int pos = edge_first_[e];
+        if (dmin[static_cast<size_t>(pos)] == 0xFFFFFFFFu) continue;  // unreachable copy
+        uint32_t mx = longest(pos);
+        if (mx == kInf) ok = false;
+        lo = std::min(lo, dmin[static_cast<size_t>(pos)]);
+        hi = std::max(hi, mx);
+      }
+      if (!ok || lo == kInf || hi - lo > 255) continue;
+      for (size_t e = 0; e < ne; e++)
+        if (chosen[e]) lits.insert(g_.byte_edges[e].bytes.substr(0, wl));
+      if (lits.empty() || lits.size() > static_cast<size_t>(kMaxWindows)) continue;
+      p_->mode = ScanMode::Windows;
+      p_->floating = true;
+      p_->float_min = lo;
+      p_->float_max = hi;
+      for (const std::string& lit : lits) {
+        FFWindow w{};
+        w.offset = 0;
+        w.len = static_cast<uint32_t>(wl);
+        for (size_t k = 0; k < wl; k++) {
+          const uint32_t c = static_cast<uint8_t>(lit[k]);
+          if (k < 4) { w.value0 |= c << (8 * k); w.mask0 |= 0xFFu << (8 * k); }
+          else { w.value1 |= c << (8 * (k - 4)); w.mask1 |= 0xFFu << (8 * (k - 4)); }
+        }
+        p_->windows.push_back(w);
+      }
+      return;
     }
   }
 

@@ -147,6 +147,13 @@ struct Program {
   // fast-forward plan
   ScanMode mode = ScanMode::Dense;
   std::vector<FFWindow> windows;
+  // Floating windows (the reference's fast-forward element that is NOT at the start of the
+  // match, e.g. `abcdefgh` in ([complex]|(regexp)){2,7}abcdefgh(...), src/codegen.cc:352-383):
+  // every match contains one of the windows somewhere between float_min and float_max bytes
+  // after its start.  A hit at w makes every s in [w - float_max, w - float_min] a candidate
+  // start (the reference runs its NFA backwards from the hit instead, codegen-x64.cc:643-650).
+  bool floating = false;
+  uint32_t float_min = 0, float_max = 0;
   std::string literal;                   // non-empty: the whole pattern is this literal
   // The NFA graph itself (reference state numbering semantics) and whether the pattern can
   // hit the reference's "Q8" ring-slot artefact: some state reachable

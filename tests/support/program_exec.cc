@@ -82,6 +82,21 @@ bool longest_at(const Program& P, const uint8_t* t, uint64_t n, uint64_t s, uint
 }
 
 bool candidate(const Program& P, const uint8_t* t, uint64_t n, uint64_t s) {
+  if (P.mode == ScanMode::Windows && P.floating) {
+    // some window must occur at w in [s + float_min, s + float_max]
+    for (uint64_t w0 = s + P.float_min; w0 <= s + P.float_max; w0++)
+      for (const FFWindow& w : P.windows) {
+        if (w0 + w.len > n) continue;
+        uint32_t v0 = 0, v1 = 0;
+        for (uint32_t k = 0; k < w.len; k++) {
+          uint32_t c = t[w0 + k];
+          if (k < 4) v0 |= c << (8 * k);
+          else v1 |= c << (8 * (k - 4));
+        }
+        if ((v0 & w.mask0) == w.value0 && (v1 & w.mask1) == w.value1) return true;
+      }
+    return false;
+  }
   if (P.mode == ScanMode::Windows) {
     for (const FFWindow& w : P.windows) {
       if (s + w.offset + w.len > n) continue;
@@ -196,6 +211,9 @@ int pe_plan(const char* re, uint64_t* info, uint32_t* window_values) {
   info[5] = P.max_len;
   info[6] = (uint64_t)P.n_rows;
   info[7] = P.literal.size();
+  info[8] = P.floating;
+  info[9] = P.float_min;
+  info[10] = P.float_max;
   for (size_t i = 0; i < P.windows.size(); i++) {
     window_values[4 * i] = P.windows[i].value0;
     window_values[4 * i + 1] = P.windows[i].mask0;

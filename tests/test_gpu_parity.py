@@ -301,3 +301,40 @@ def test_device_replace_keeps_text_in_hbm(rj):
     new_len = scan.replace(raw.data_ptr(), n, b"", out.data_ptr(), out.numel())
     assert new_len == 200000 and m == n - new_len - (len(b"".join(W.HEADERS)) - 3)
     assert (out[:new_len].cpu().numpy() == W.fasta_stripped_numpy(20000)).all()
+
+
+def test_complex_regex_floating_windows_large(rj, oracle):
+    """BASELINE configs[3] shape: the complex benchmark regex over device-resident random text
+    with planted strings of its language and `abcdefgh` decoys.  The scan plan is the floating
+    window `abcdefgh` (2..42 bytes after the match start); every reported match must be a true
+    left-most-longest match (checked with the oracle on a window around it) and every planted
+    string must be covered by one."""
+    import torch
+    from rejit_amd import workloads as W
+    rx = W.BENCH_REGEXES[3][0].encode()
+    p = rj.Program(rx)
+    info = p.info()
+    assert info["scan_mode"] == 1
+    dev = torch.device("cuda:0")
+    n = 1 << 27
+    d = W.random_ascii_torch(n, 23, dev)
+    rng = random.Random(23)
+    planted = []
+    offs = W.plant_offsets(n, 80, 400, seed=23, boundaries=[1024, 1 << 20, 1 << 26])
+    for k, o in enumerate(offs):
+        sample = W.complex_regex_sample(rng) if k % 4 else b"abcdefgh"      # every 4th is a decoy
+        W.plant(d, [o + 4], sample)
+        if k % 4:
+            planted.append((o + 4, o + 4 + len(sample)))
+    scan = rj.Scan(p)
+    count = scan.run_tensor(d)
+    spans = scan.spans()
+    assert count == len(spans) and count >= len(planted)
+    host = d.cpu().numpy()
+    for b_, e_ in spans:      # each reported match, re-derived by the oracle on its neighbourhood
+        lo, hi = max(0, b_ - 64), min(n, e_ + 64)
+        local = oracle.match_all(rx, host[lo:hi].tobytes())
+        assert (b_ - lo, e_ - lo) in local, (b_, e_)
+    got = set(spans)
+    for b_, e_ in planted:    # a planted string is matched (possibly extended to the left by the repetition)
+        assert any(gb <= b_ and ge == e_ for gb, ge in got if gb >= b_ - 48 and ge == e_), (b_, e_)

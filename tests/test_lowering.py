@@ -53,12 +53,13 @@ def match_all(lib, rx, tx):
 
 
 def plan(lib, rx):
-    info = (ctypes.c_uint64 * 8)()
+    info = (ctypes.c_uint64 * 16)()
     vals = (ctypes.c_uint32 * 32)()
     st = lib.pe_plan(rx, info, vals)
     assert st == 0
     return dict(windows=bool(info[0]), n_windows=int(info[1]), offset=int(info[2]), n_pos=int(info[3]),
                 min_len=int(info[4]), max_len=int(info[5]), n_rows=int(info[6]), literal_len=int(info[7]),
+                floating=bool(info[8]), float_min=int(info[9]), float_max=int(info[10]),
                 values=[tuple(int(v) for v in vals[4 * i:4 * i + 4]) for i in range(int(info[1]))])
 
 
@@ -113,6 +114,13 @@ def test_scan_plans(pe):
     assert not p["windows"] and p["min_len"] == 0 and p["max_len"] == 2 ** 64 - 1
     p = plan(pe, b"([complex]|(regexp)){2,7}abcdefgh(at|the|[e-nd]as well)")
     assert p["min_len"] == 12 and p["max_len"] == 58
+    # the reference's FF element `abcdefgh` floats 2..42 bytes after the start of the match
+    assert p["windows"] and p["floating"] and p["values"] == [_w(b"abcdefgh")]
+    assert (p["float_min"], p["float_max"]) == (2, 42)
+    p = plan(pe, b"[a-z]+@example")
+    assert not p["windows"]            # unbounded prefix: no usable window, dense scan
+    p = plan(pe, b"[0-9]{2,3}foo(bar|baz)")
+    assert p["windows"] and p["floating"] and (p["float_min"], p["float_max"]) == (2, 3) and p["values"] == [_w(b"foo")]
     p = plan(pe, b">.*\n|\n")
     assert p["windows"] and p["n_windows"] == 2 and p["min_len"] == 1
     p = plan(pe, b"abc.efgh")      # a wide class inside the window is a wildcard, not a split
