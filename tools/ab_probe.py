@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of scan-kernel launch variants (env RJ_SCAN_SIMPLE / RJ_SCAN_GRID)."""
+"""A/B of scan-kernel launch geometry (env RJ_SCAN_GRID = workgroups)."""
 import os, sys, subprocess, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
