@@ -164,10 +164,29 @@ __device__ __forceinline__ void windows_chunk(const uint32_t (&d)[6], uint64_t a
     }
     if (__ballot(acc1 == 0) == 0) return;
   }
-  // tj[j] == 0 iff some window matches at position j; kept in registers so that the (rare)
-  // hit path does not have to redo the compares
-  uint32_t tj[16];
-  uint32_t acc = 0xFFFFFFFFu;
+  // four independent min chains (the single chain of 16*K dependent v_min was latency-bound:
+  // 2 chains 0.144 -> 0.139 ms although they cost 16 more VGPRs and one wave of occupancy)
+  uint32_t accs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      uint32_t t = x[j] ^ ws.value0[k];
+      if (MASKED) t &= ws.mask0[k];
+      if (TWO) {
+        uint32_t u = x[j + 4] ^ ws.value1[k];
+        t = MASKED ? ((u & ws.mask1[k]) | t) : (u | t);  // v_and_or_b32
+      }
+      accs[j & 3] = accs[j & 3] < t ? accs[j & 3] : t;
+    }
+  }
+  const uint32_t m01 = accs[0] < accs[1] ? accs[0] : accs[1];
+  const uint32_t m23 = accs[2] < accs[3] ? accs[2] : accs[3];
+  const uint32_t acc = m01 < m23 ? m01 : m23;
+  if (__ballot(acc == 0) == 0) return;  // wave-uniform: the common case leaves here
+
+  // rare path: per-lane 16-bit hit mask -> the wave's region of the hit list
+  uint32_t hm = 0;
 #pragma unroll
   for (int j = 0; j < 16; j++) {
     uint32_t best = 0xFFFFFFFFu;
@@ -177,19 +196,12 @@ __device__ __forceinline__ void windows_chunk(const uint32_t (&d)[6], uint64_t a
       if (MASKED) t &= ws.mask0[k];
       if (TWO) {
         uint32_t u = x[j + 4] ^ ws.value1[k];
-        t = MASKED ? ((u & ws.mask1[k]) | t) : (u | t);  // v_and_or_b32
+        t = MASKED ? ((u & ws.mask1[k]) | t) : (u | t);
       }
       best = best < t ? best : t;
     }
-    tj[j] = best;
-    acc = acc < best ? acc : best;
+    hm |= static_cast<uint32_t>(best == 0) << j;
   }
-  if (__ballot(acc == 0) == 0) return;  // wave-uniform: the common case leaves here
-
-  // rare path: per-lane 16-bit hit mask -> the wave's region of the hit list
-  uint32_t hm = 0;
-#pragma unroll
-  for (int j = 0; j < 16; j++) hm |= static_cast<uint32_t>(tj[j] == 0) << j;
   // positions outside [wlo, whi) only exist in the first / last chunk of the range
   const uint64_t chunk_base = at - static_cast<uint64_t>(lane_id()) * 16;
   if (chunk_base < a.wlo || chunk_base + kChunk > a.whi) {
