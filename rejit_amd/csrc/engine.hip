@@ -464,6 +464,9 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
     vp.sb = sb;
     vp.se = se;
     vp.expand = expand;
+    if (!windows && D.n_words > 4 && se - sb > (1ull << 24))
+      return fail(RJ_TOO_LARGE, "patterns of more than 128 positions without a fast-forward window are limited to 16 MiB "
+                                "of text per call (one wave per candidate start)");
     vp.float_max = D.float_max;
     if (expand > 1) {
       // the slot count depends on the hit count, which only the device knows yet: verify must not
