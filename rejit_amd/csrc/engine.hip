@@ -115,7 +115,7 @@ struct rj_program {
 
 struct rj_scan {
   const rj_program* prog = nullptr;
-  DeviceBuffer counters, hits, hit_counts, hit_offsets, cand_begin, cand_end, out, acc_out, keys_out, vals_out, sort_tmp, flag;
+  DeviceBuffer counters, hits, hit_counts, valid_counts, hit_offsets, cand_begin, cand_end, out, acc_out, keys_out, vals_out, sort_tmp, flag;
   DeviceBuffer scan_a, scan_b, taken;  // large-path selection scratch
   DeviceBuffer ring;                   // exact sequential kernel
   DeviceBuffer with_buf, long_gaps, repl_out;  // replace_gather
@@ -291,6 +291,19 @@ int ensure_lists(rj_scan* s, uint32_t n_regions, uint32_t region_cap, uint64_t c
 
 // Large path: more hit slots than finalize_small handles in LDS.  The slots are already in
 // text order, so no sort: drop the kNoMatch slots, then check / select.
+hipError_t prefix_scan(rj_scan* s, uint64_t* in, uint64_t* out, uint64_t count, bool is_max, hipStream_t st) {
+  size_t bytes = 0;
+  hipError_t e = is_max ? rocprim::exclusive_scan(nullptr, bytes, in, out, uint64_t{0}, count, rocprim::maximum<uint64_t>(), st)
+                        : rocprim::exclusive_scan(nullptr, bytes, in, out, uint64_t{0}, count, rocprim::plus<uint64_t>(), st);
+  if (e != hipSuccess) return e;
+  e = s->sort_tmp.reserve(std::max<size_t>(bytes, 16));
+  if (e != hipSuccess) return e;
+  return is_max ? rocprim::exclusive_scan(s->sort_tmp.p, bytes, in, out, uint64_t{0}, count, rocprim::maximum<uint64_t>(), st)
+                : rocprim::exclusive_scan(s->sort_tmp.p, bytes, in, out, uint64_t{0}, count, rocprim::plus<uint64_t>(), st);
+}
+
+int check_and_select(rj_scan* s, uint64_t n_upper, const FinalizeParams& fp, hipStream_t st);
+
 int finalize_large(rj_scan* s, uint64_t n_slots, bool unsorted, uint64_t text_len, const FinalizeParams& fp, hipStream_t st) {
   s->stats.large_path = 1;
   RJ_HIP(s->keys_out.reserve(n_slots * sizeof(uint64_t)));
@@ -302,14 +315,7 @@ int finalize_large(rj_scan* s, uint64_t n_slots, bool unsorted, uint64_t text_le
   uint64_t* sa = s->scan_a.as<uint64_t>();
   uint64_t* sb = s->scan_b.as<uint64_t>();
   auto scan = [&](uint64_t* in, uint64_t* out, uint64_t count, bool is_max) -> hipError_t {
-    size_t bytes = 0;
-    hipError_t e = is_max ? rocprim::exclusive_scan(nullptr, bytes, in, out, uint64_t{0}, count, rocprim::maximum<uint64_t>(), st)
-                          : rocprim::exclusive_scan(nullptr, bytes, in, out, uint64_t{0}, count, rocprim::plus<uint64_t>(), st);
-    if (e != hipSuccess) return e;
-    e = s->sort_tmp.reserve(std::max<size_t>(bytes, 16));
-    if (e != hipSuccess) return e;
-    return is_max ? rocprim::exclusive_scan(s->sort_tmp.p, bytes, in, out, uint64_t{0}, count, rocprim::maximum<uint64_t>(), st)
-                  : rocprim::exclusive_scan(s->sort_tmp.p, bytes, in, out, uint64_t{0}, count, rocprim::plus<uint64_t>(), st);
+    return prefix_scan(s, in, out, count, is_max, st);
   };
   // 1. ordered compaction of the verified candidates
   launch_mark_valid(s->cand_end.as<uint64_t>(), n_slots, sa, st);
@@ -335,28 +341,40 @@ int finalize_large(rj_scan* s, uint64_t n_slots, bool unsorted, uint64_t text_le
       RJ_HIP(hipMemcpyAsync(vals, v2, nc * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
     }
   }
-  // 2. common case, still without a host round trip: the candidates already are the result
-  //    (the kernels read the candidate count from device memory; grids sized for n_slots)
+  return check_and_select(s, n_slots, fp, st);
+}
+
+// The ordered candidates are in keys_out / vals_out, their count in counters[kCntCands] (device).
+// Common case, without a host round trip before it: the candidates already are the result.
+int check_and_select(rj_scan* s, uint64_t n_slots, const FinalizeParams& fp, hipStream_t st) {
+  uint64_t* keys = s->keys_out.as<uint64_t>();
+  uint64_t* vals = s->vals_out.as<uint64_t>();
   if (fp.detect_adjacent) launch_detect_adjacent(keys, vals, n_slots, s->counters.as<unsigned long long>(), st);
-  *s->host_flag = 1;
-  RJ_HIP(hipMemcpyAsync(s->flag.p, s->host_flag, sizeof(int), hipMemcpyHostToDevice, st));
   launch_check_and_interleave(keys, vals, s->counters.as<unsigned long long>() + kCntCands, n_slots, fp.carry_cur,
-                              s->out.as<uint64_t>(), s->out_cap, s->flag.as<int>(), st);
-  RJ_HIP(hipMemcpyAsync(s->host_flag, s->flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+                              s->out.as<uint64_t>(), s->out_cap, s->counters.as<unsigned long long>() + kCntUnordered, st);
   RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   RJ_HIP(hipStreamSynchronize(st));
   RJ_HIP(hipGetLastError());
+  if (s->host_counters[kCntOverflow] != 0) return RJ_OK;  // the caller grows the regions and runs again
   const uint64_t n_cands = s->host_counters[kCntCands];
   s->stats.n_candidates = n_cands;
   if (n_cands == 0) {
     s->result_count = 0;
     return RJ_OK;
   }
-  if (*s->host_flag == 1) {
+  if (s->host_counters[kCntUnordered] == 0) {
     s->result_count = n_cands;
     return RJ_OK;
   }
-  // 3. general case: cluster-parallel selection
+  // general case: cluster-parallel selection
+  RJ_HIP(s->scan_a.reserve(n_cands * sizeof(uint64_t)));
+  RJ_HIP(s->scan_b.reserve(n_cands * sizeof(uint64_t)));
+  RJ_HIP(s->cand_begin.reserve(n_cands * sizeof(uint64_t)));
+  uint64_t* sa = s->scan_a.as<uint64_t>();
+  uint64_t* sb = s->scan_b.as<uint64_t>();
+  auto scan = [&](uint64_t* in, uint64_t* out, uint64_t count, bool is_max) -> hipError_t {
+    return prefix_scan(s, in, out, count, is_max, st);
+  };
   //   pmax  = exclusive prefix max of the ends            (sa)
   //   taken = per-cluster sequential walk                  (taken)
   //   last  = exclusive prefix max of (taken ? i+1 : 0)    (sb; cand_begin reused as scratch)
@@ -418,6 +436,10 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
   const uint64_t region_full = geo.span_chunks * 1024;
   uint64_t region_cap = windows ? std::min<uint64_t>(std::max<uint64_t>(s->region_cap_hint, 64), region_full) : region_full;
 
+  // fixed windows + an automaton that fits a lane: candidates are verified and compacted inside
+  // their hit regions (no global compaction, no sort)
+  const bool in_regions = windows && expand == 1 && D.n_words <= 4;
+
   for (int attempt = 0; attempt < 6; attempt++) {
     const uint64_t slots = static_cast<uint64_t>(geo.n_regions) * region_cap;
     // candidate slots: one per (hit, possible start); floating windows start with room for a few
@@ -425,6 +447,11 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
     uint64_t cand_slots = expand == 1 ? slots : std::max<uint64_t>(s->hits_hint * expand * 2, 1u << 16);
     int rc = ensure_lists(s, geo.n_regions, static_cast<uint32_t>(region_cap), std::max<uint64_t>(cand_slots, 1u << 12));
     if (rc != RJ_OK) return rc;
+    if (in_regions) {
+      RJ_HIP(s->valid_counts.reserve(static_cast<size_t>(geo.n_regions) * sizeof(uint32_t)));
+      RJ_HIP(s->keys_out.reserve(slots * sizeof(uint64_t)));
+      RJ_HIP(s->vals_out.reserve(slots * sizeof(uint64_t)));
+    }
     sp.hits = s->hits.as<uint64_t>();
     sp.region_cap = static_cast<uint32_t>(region_cap);
     sp.hit_counts = s->hit_counts.as<uint32_t>();
@@ -449,9 +476,25 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
       launch_scan_dense(sp, D, geo.grid, st);
     }
     RJ_HIP(hipEventRecord(s->ev[2], st));
-    launch_region_offsets(s->hit_counts.as<uint32_t>(), geo.n_regions, static_cast<uint32_t>(region_cap),
-                          s->hit_offsets.as<uint64_t>(), s->counters.as<unsigned long long>(), st);
+    FinalizeParams fp{};
+    fp.cand_begin = s->cand_begin.as<uint64_t>();
+    fp.cand_end = s->cand_end.as<uint64_t>();
+    fp.cands_cap = s->cands_cap;
+    fp.out = s->out.as<uint64_t>();
+    fp.out_cap = s->out_cap;
+    fp.counters = s->counters.as<unsigned long long>();
+    fp.carry_cur = carry_cur;
+    fp.carry_prev_end = carry_prev_end;
+    fp.have_prev = have_prev;
+    // bit-exactness with the reference's ring artefact (Q8) can only be at stake when the
+    // pattern is at risk AND a candidate begins exactly where another one ends
+    const bool whole_text = sb == 0 && se == n + 1 && carry_cur == 0 && !have_prev;
+    fp.detect_adjacent = rp->host->q8_risk && whole_text;
+    fp.expand = expand;
     VerifyParams vp{};
+    if (!in_regions)
+      launch_region_offsets(s->hit_counts.as<uint32_t>(), geo.n_regions, static_cast<uint32_t>(region_cap), false,
+                            s->hit_offsets.as<uint64_t>(), s->counters.as<unsigned long long>(), st);
     vp.text = d_text;
     vp.n = n;
     vp.hits = s->hits.as<uint64_t>();
@@ -481,27 +524,22 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
         vp.cand_end = s->cand_end.as<uint64_t>();
       }
     }
-    launch_verify(vp, D, windows ? std::max<uint64_t>(s->hits_hint, 1u << 14) : (se - sb) / 8 + 1, st);
-    FinalizeParams fp{};
-    fp.cand_begin = s->cand_begin.as<uint64_t>();
-    fp.cand_end = s->cand_end.as<uint64_t>();
-    fp.cands_cap = s->cands_cap;
-    fp.out = s->out.as<uint64_t>();
-    fp.out_cap = s->out_cap;
-    fp.counters = s->counters.as<unsigned long long>();
-    fp.carry_cur = carry_cur;
-    fp.carry_prev_end = carry_prev_end;
-    fp.have_prev = have_prev;
-    // bit-exactness with the reference's ring artefact (Q8) can only be at stake when the
-    // pattern is at risk AND a candidate begins exactly where another one ends
-    const bool whole_text = sb == 0 && se == n + 1 && carry_cur == 0 && !have_prev;
-    fp.detect_adjacent = rp->host->q8_risk && whole_text;
-    fp.expand = expand;
-    launch_finalize_small(fp, st);
-    RJ_HIP(hipEventRecord(s->ev[3], st));
-    RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    RJ_HIP(hipStreamSynchronize(st));
-    RJ_HIP(hipGetLastError());
+    if (in_regions) {
+      // verify + compact inside the regions, lay the survivors out, check / select: one sync
+      launch_verify_in_regions(vp, D, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(), s->cand_end.as<uint64_t>(), st);
+      launch_region_offsets(s->valid_counts.as<uint32_t>(), geo.n_regions, static_cast<uint32_t>(region_cap), true,
+                            s->hit_offsets.as<uint64_t>(), s->counters.as<unsigned long long>(), st);
+      launch_gather_pairs(s->hits.as<uint64_t>(), s->cand_end.as<uint64_t>(), s->hit_offsets.as<uint64_t>(), geo.n_regions,
+                          static_cast<uint32_t>(region_cap), s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), st);
+      rc = check_and_select(s, std::max<uint64_t>(s->hits_hint, 1u << 12), fp, st);
+      if (rc != RJ_OK) return rc;
+    } else {
+      launch_verify(vp, D, windows ? std::max<uint64_t>(s->hits_hint, 1u << 14) : (se - sb) / 8 + 1, st);
+      launch_finalize_small(fp, st);
+      RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+      RJ_HIP(hipStreamSynchronize(st));
+      RJ_HIP(hipGetLastError());
+    }
     const unsigned long long n_hits = s->host_counters[kCntHits];
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, s->ev[1], s->ev[2]);
@@ -526,7 +564,9 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
                                 "are not supported by the parallel verifier",
                   static_cast<unsigned long long>(kMaxSimSteps));
     }
-    if (s->host_counters[kCntFinal] == ~0ull) {
+    if (in_regions) {
+      // check_and_select produced the result
+    } else if (s->host_counters[kCntFinal] == ~0ull) {
       rc = finalize_large(s, n_hits * expand, expand > 1, n + 1, fp, st);
       if (rc != RJ_OK) return rc;
     } else {

@@ -10,7 +10,9 @@
 namespace rejit_amd {
 
 // device counters (unsigned long long[kCntSize])
-enum { kCntCands = 0, kCntFinal = 1, kCntOverflow = 2, kCntAdjacent = 3, kCntHits = 4, kCntMaxRegion = 5, kCntOverrun = 6, kCntSize = 8 };
+enum { kCntCands = 0, kCntFinal = 1, kCntOverflow = 2, kCntAdjacent = 3, kCntHits = 4, kCntMaxRegion = 5, kCntOverrun = 6,
+  kCntUnordered = 7,  // check_and_interleave: the candidates are not already the result
+  kCntSize = 8 };
 
 constexpr uint64_t kNoMatch = ~0ull;  // cand_end of a hit at which nothing matches
 
@@ -39,7 +41,7 @@ struct WindowSet {
 struct VerifyParams {
   const uint8_t* text;
   uint64_t n;
-  const uint64_t* hits;
+  uint64_t* hits;
   const uint64_t* offsets;  // [n_regions + 1], offsets[n_regions] = number of hits
   uint32_t n_regions;
   uint32_t region_cap;
@@ -77,8 +79,14 @@ ScanGeometry scan_geometry(uint64_t chunks);
 
 void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows, int grid, hipStream_t st);
 void launch_scan_dense(const ScanParams& a, const DevProgram& P, int grid, hipStream_t st);
-void launch_region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap, uint64_t* offsets,
+void launch_region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap, bool verified, uint64_t* offsets,
                            unsigned long long* counters, hipStream_t st);
+// windows mode, lane-sized automaton: verify + compact inside every region (16 lanes each), then
+// gather the survivors into the ordered candidate list that region_offsets(verified) laid out
+void launch_verify_in_regions(const VerifyParams& a, const DevProgram& P, const uint32_t* hit_counts, uint32_t* valid_counts,
+                              uint64_t* region_ends, hipStream_t st);
+void launch_gather_pairs(const uint64_t* region_begins, const uint64_t* region_ends, const uint64_t* offsets,
+                         uint32_t n_regions, uint32_t region_cap, uint64_t* keys, uint64_t* vals, hipStream_t st);
 void launch_verify(const VerifyParams& a, const DevProgram& P, uint64_t expected_hits, hipStream_t st);
 // large path: drop the kNoMatch slots, keeping the order
 void launch_mark_valid(const uint64_t* cand_end, uint64_t n, uint64_t* flags, hipStream_t st);
@@ -87,10 +95,10 @@ void launch_compact_valid(const uint64_t* cand_begin, const uint64_t* cand_end, 
                           unsigned long long* counters, hipStream_t st);
 void launch_match_full(const uint8_t* text, uint64_t n, const DevProgram& P, int* result, hipStream_t st);
 void launch_finalize_small(const FinalizeParams& a, hipStream_t st);
-// writes the sorted candidates as (begin,end) pairs and clears *flag unless they already are a
+// writes the sorted candidates as (begin,end) pairs and sets *unordered unless they already are a
 // valid result (pairwise disjoint, no empty match, first begin >= carry_cur)
 void launch_check_and_interleave(const uint64_t* keys, const uint64_t* vals, const unsigned long long* n_ptr,
-                                 uint64_t n_upper, uint64_t carry_cur, uint64_t* out, uint64_t cap, int* flag,
+                                 uint64_t n_upper, uint64_t carry_cur, uint64_t* out, uint64_t cap, unsigned long long* unordered,
                                  hipStream_t st);
 // counters[kCntAdjacent] = 1 when some non-empty candidate ends exactly where another begins
 void launch_detect_adjacent(const uint64_t* keys, const uint64_t* vals, uint64_t n_upper, unsigned long long* counters,

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void scan_dense(ScanParams a, DevProgram P) {
 // One workgroup; n_regions <= 64 Ki.
 template <int PER>
 __global__ __launch_bounds__(1024) void region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap,
-                                                       uint64_t* offsets, unsigned long long* counters) {
+                                                       uint64_t* offsets, unsigned long long* counters, bool verified) {
   __shared__ uint64_t wave_sum[16];
   __shared__ uint32_t wave_max[16];
   const int lane = lane_id(), wv = threadIdx.x >> 6;
@@ -386,8 +386,12 @@ __global__ __launch_bounds__(1024) void region_offsets(const uint32_t* counts, u
   if (threadIdx.x == 0) {
     offsets[n_regions] = total;
     counters[kCntHits] = total;
-    counters[kCntMaxRegion] = maxc;
-    if (maxc > cap) counters[kCntOverflow] = 1;
+    if (verified) {  // counts of verified candidates (verify_in_regions saw the raw counts)
+      counters[kCntCands] = total;
+    } else {
+      counters[kCntMaxRegion] = maxc;
+      if (maxc > cap) counters[kCntOverflow] = 1;
+    }
   }
 }
 
@@ -540,6 +544,63 @@ __global__ __launch_bounds__(256) void verify_lane_regions(VerifyParams a, DevPr
       if (overrun) a.counters[kCntOverrun] = 1;
       a.cand_begin[lo + k] = s;
       a.cand_end[lo + k] = found ? e : kNoMatch;
+    }
+  }
+}
+
+// Fast-forward windows with a lane-sized automaton: 16 lanes take one hit region, verify its
+// hits and compact the survivors IN PLACE (begins stay in the region, ends go to the same slot
+// of region_ends).  The count per region then drives region_offsets, so the candidates need no
+// global compaction pass at all.
+template <int NQ>
+__global__ __launch_bounds__(256) void verify_in_regions(VerifyParams a, DevProgram P, const uint32_t* hit_counts,
+                                                         uint32_t* valid_counts, uint64_t* region_ends) {
+  const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t n_groups = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 4;
+  const int lane = lane_id(), sub = lane & 15, shift = lane & 48;
+  for (uint64_t r = tid >> 4; r < a.n_regions; r += n_groups) {
+    const uint32_t raw = hit_counts[r];
+    const uint32_t cnt = raw < a.region_cap ? raw : a.region_cap;
+    if (raw > a.region_cap && sub == 0) {  // the host grows the regions and runs again
+      a.counters[kCntOverflow] = 1;
+      atomicMax(&a.counters[kCntMaxRegion], static_cast<unsigned long long>(raw));
+    }
+    uint64_t* region = a.hits + r * a.region_cap;
+    uint64_t* ends = region_ends + r * a.region_cap;
+    uint32_t kept = 0;
+    for (uint32_t base = 0; base < cnt; base += 16) {
+      const uint32_t k = base + sub;
+      const uint64_t w = k < cnt ? region[k] : 0;
+      const uint64_t s = w - a.float_max;
+      uint64_t e = 0;
+      bool overrun = false;
+      const bool found = k < cnt && w >= a.float_max && s >= a.sb && s < a.se &&
+                         rj_lane_longest<NQ>(P, a.text, a.n, s, &e, &overrun);
+      if (overrun) a.counters[kCntOverrun] = 1;
+      const uint32_t mine = static_cast<uint32_t>(__ballot(found) >> shift) & 0xFFFFu;
+      const uint32_t pos = kept + __popc(mine & ((1u << sub) - 1u));
+      if (found) {  // pos <= k, and every lane of the group has read its hit already
+        region[pos] = s;
+        ends[pos] = e;
+      }
+      kept += __popc(mine);
+    }
+    if (sub == 0) valid_counts[r] = kept;
+  }
+}
+
+// ... and the regions' survivors are copied to their place in the ordered candidate list.
+__global__ __launch_bounds__(256) void gather_pairs(const uint64_t* region_begins, const uint64_t* region_ends,
+                                                    const uint64_t* offsets, uint32_t n_regions, uint32_t region_cap,
+                                                    uint64_t* keys, uint64_t* vals) {
+  const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t n_groups = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 4;
+  const int sub = lane_id() & 15;
+  for (uint64_t r = tid >> 4; r < n_regions; r += n_groups) {
+    const uint64_t lo = offsets[r], cnt = offsets[r + 1] - lo;
+    for (uint64_t k = sub; k < cnt; k += 16) {
+      keys[lo + k] = region_begins[r * region_cap + k];
+      vals[lo + k] = region_ends[r * region_cap + k];
     }
   }
 }
@@ -750,16 +811,17 @@ __global__ void compact_kept(const uint64_t* keys, const uint64_t* vals, const u
 
 __global__ void detect_adjacent(const uint64_t* keys, const uint64_t* vals, unsigned long long* counters) {
   const uint64_t n = counters[kCntCands];
-  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t e = vals[i];
-  if (e <= keys[i]) return;
-  uint64_t lo = 0, hi = n;
-  while (lo < hi) {
-    const uint64_t mid = (lo + hi) >> 1;
-    if (keys[mid] < e) lo = mid + 1; else hi = mid;
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint64_t e = vals[i];
+    if (e <= keys[i]) continue;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+      const uint64_t mid = (lo + hi) >> 1;
+      if (keys[mid] < e) lo = mid + 1; else hi = mid;
+    }
+    if (lo < n && keys[lo] == e) counters[kCntAdjacent] = 1;
   }
-  if (lo < n && keys[lo] == e) counters[kCntAdjacent] = 1;
 }
 
 // The reference's no-fast-forward kMatchAll loop, restated for ONE lane: a ring of
@@ -877,18 +939,20 @@ __global__ void compact_valid(const uint64_t* cand_begin, const uint64_t* cand_e
 
 // Large path, common case in one kernel: emit the sorted candidates as pairs and find out
 // whether they already are the result (pairwise disjoint, no empty match, nothing hidden by
-// the carry); *flag is cleared otherwise and the cluster-parallel selection runs.
+// the carry); *unordered is set otherwise and the cluster-parallel selection runs.
 __global__ void check_and_interleave(const uint64_t* keys, const uint64_t* vals, const unsigned long long* n_ptr,
-                                     uint64_t carry_cur, uint64_t* out, uint64_t cap, int* flag) {
-  const uint64_t n = *n_ptr;  // number of compacted candidates, produced earlier on this stream
-  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t b = keys[i], e = vals[i];
-  const bool ok = e > b && (i == 0 ? b >= carry_cur : b >= vals[i - 1]);
-  if (!ok) *flag = 0;
-  if (i < cap) {
-    out[2 * i] = b;
-    out[2 * i + 1] = e;
+                                     uint64_t carry_cur, uint64_t* out, uint64_t cap, unsigned long long* unordered) {
+  const uint64_t n = *n_ptr;  // number of candidates, produced earlier on this stream
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint64_t b = keys[i], e = vals[i];
+    // (a slot that did not verify holds kNoMatch: it fails here or as the next slot's predecessor)
+    const bool ok = e != kNoMatch && e > b && (i == 0 ? b >= carry_cur : b >= vals[i - 1]);
+    if (!ok) *unordered = 1;
+    if (i < cap) {
+      out[2 * i] = b;
+      out[2 * i + 1] = e;
+    }
   }
 }
 
@@ -1001,12 +1065,12 @@ void launch_scan_dense(const ScanParams& a, const DevProgram& P, int grid, hipSt
   hipLaunchKernelGGL(scan_dense, dim3(grid), dim3(256), 0, st, a, P);
 }
 
-void launch_region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap, uint64_t* offsets,
+void launch_region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap, bool verified, uint64_t* offsets,
                            unsigned long long* counters, hipStream_t st) {
   // n_regions <= 64 Ki (scan_geometry caps the grid at 16 Ki workgroups of 4 waves)
-  if (n_regions <= 16 * 1024) hipLaunchKernelGGL((region_offsets<16>), dim3(1), dim3(1024), 0, st, counts, n_regions, cap, offsets, counters);
-  else if (n_regions <= 32 * 1024) hipLaunchKernelGGL((region_offsets<32>), dim3(1), dim3(1024), 0, st, counts, n_regions, cap, offsets, counters);
-  else hipLaunchKernelGGL((region_offsets<64>), dim3(1), dim3(1024), 0, st, counts, n_regions, cap, offsets, counters);
+  if (n_regions <= 16 * 1024) hipLaunchKernelGGL((region_offsets<16>), dim3(1), dim3(1024), 0, st, counts, n_regions, cap, offsets, counters, verified);
+  else if (n_regions <= 32 * 1024) hipLaunchKernelGGL((region_offsets<32>), dim3(1), dim3(1024), 0, st, counts, n_regions, cap, offsets, counters, verified);
+  else hipLaunchKernelGGL((region_offsets<64>), dim3(1), dim3(1024), 0, st, counts, n_regions, cap, offsets, counters, verified);
 }
 
 void launch_verify(const VerifyParams& a, const DevProgram& P, uint64_t expected_hits, hipStream_t st) {
@@ -1036,6 +1100,24 @@ void launch_verify(const VerifyParams& a, const DevProgram& P, uint64_t expected
   else hipLaunchKernelGGL((verify_wave<4>), dim3(g), dim3(256), 0, st, a, P);
 }
 
+void launch_verify_in_regions(const VerifyParams& a, const DevProgram& P, const uint32_t* hit_counts, uint32_t* valid_counts,
+                              uint64_t* region_ends, hipStream_t st) {
+  uint64_t blocks = (static_cast<uint64_t>(a.n_regions) + 15) / 16;  // 16 lanes per region
+  blocks = blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks;
+  if (P.n_words <= 2) hipLaunchKernelGGL((verify_in_regions<1>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, a, P,
+                                         hit_counts, valid_counts, region_ends);
+  else hipLaunchKernelGGL((verify_in_regions<2>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, a, P, hit_counts,
+                          valid_counts, region_ends);
+}
+
+void launch_gather_pairs(const uint64_t* region_begins, const uint64_t* region_ends, const uint64_t* offsets,
+                         uint32_t n_regions, uint32_t region_cap, uint64_t* keys, uint64_t* vals, hipStream_t st) {
+  uint64_t blocks = (static_cast<uint64_t>(n_regions) + 15) / 16;
+  blocks = blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks;
+  hipLaunchKernelGGL(gather_pairs, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, region_begins, region_ends, offsets,
+                     n_regions, region_cap, keys, vals);
+}
+
 void launch_mark_valid(const uint64_t* cand_end, uint64_t n, uint64_t* flags, hipStream_t st) {
   if (n == 0) return;
   hipLaunchKernelGGL(mark_valid, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, cand_end, n, flags);
@@ -1061,17 +1143,19 @@ void launch_finalize_small(const FinalizeParams& a, hipStream_t st) {
 }
 
 void launch_check_and_interleave(const uint64_t* keys, const uint64_t* vals, const unsigned long long* n_ptr,
-                                 uint64_t n_upper, uint64_t carry_cur, uint64_t* out, uint64_t cap, int* flag,
+                                 uint64_t n_upper, uint64_t carry_cur, uint64_t* out, uint64_t cap, unsigned long long* unordered,
                                  hipStream_t st) {
-  if (n_upper == 0) return;
-  hipLaunchKernelGGL(check_and_interleave, dim3(static_cast<unsigned>((n_upper + 255) / 256)), dim3(256), 0, st, keys, vals,
-                     n_ptr, carry_cur, out, cap, flag);
+  uint64_t blocks = (n_upper + 255) / 256;  // grid-stride: an estimate of n is enough
+  blocks = blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks;
+  hipLaunchKernelGGL(check_and_interleave, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, keys, vals,
+                     n_ptr, carry_cur, out, cap, unordered);
 }
 
 void launch_detect_adjacent(const uint64_t* keys, const uint64_t* vals, uint64_t n_upper, unsigned long long* counters,
                             hipStream_t st) {
-  if (n_upper == 0) return;
-  hipLaunchKernelGGL(detect_adjacent, dim3(static_cast<unsigned>((n_upper + 255) / 256)), dim3(256), 0, st, keys, vals, counters);
+  uint64_t blocks = (n_upper + 255) / 256;
+  blocks = blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks;
+  hipLaunchKernelGGL(detect_adjacent, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, keys, vals, counters);
 }
 
 void launch_exact_sequential(const uint8_t* text, uint64_t n, const DevGraph& G, int64_t* ring, uint64_t* out,
