@@ -110,6 +110,7 @@ struct rj_program {
   DeviceBuffer graph_blob;
   int device = 0;
   int window_alphabet = 0;  // distinct byte values among the fixed window bytes
+  bool window_nibbles = false;  // those values differ in their low nibble (nibble filter usable)
   std::string pattern;
 };
 
@@ -194,6 +195,21 @@ int upload_program(rj_program* rp) {
         if (m & 0xFFu) seen.add(static_cast<uint8_t>(v & 0xFFu));
       }
     rp->window_alphabet = seen.count();
+    // nibble filter: the alphabet's low nibbles must be distinct (else the pattern's own letters
+    // alias each other) and every mask byte must be all-or-nothing
+    bool ok = true;
+    uint32_t nib_seen = 0;
+    for (int b = 0; b < 256; b++)
+      if (seen.has(static_cast<uint8_t>(b))) {
+        ok = ok && !((nib_seen >> (b & 15)) & 1u);
+        nib_seen |= 1u << (b & 15);
+      }
+    for (const FFWindow& w : P.windows)
+      for (uint32_t k = 0; k < 8; k++) {
+        const uint32_t m = (k < 4 ? (w.mask0 >> (8 * k)) : (w.mask1 >> (8 * (k - 4)))) & 0xFFu;
+        ok = ok && (m == 0 || m == 0xFFu);
+      }
+    rp->window_nibbles = ok && getenv("RJ_NO_NIBBLE") == nullptr;
   }
   D.float_range = P.floating ? P.float_max - P.float_min + 1 : 1;
   D.float_max = P.floating ? P.float_max : 0;
@@ -469,6 +485,26 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
       }
       ws.masked = masked;
       ws.two_level = rp->window_alphabet > 4;
+      ws.nibble = D.win_len > 4 && !ws.two_level && rp->window_nibbles;
+      if (ws.nibble) {
+        bool nib_masked = false;
+        for (int k = 0; k < kDevMaxWindows; k++) {
+          uint32_t v = 0, m = 0;
+          for (int i = 0; i < 8; i++) {
+            const uint32_t vb = (i < 4 ? (D.win_value0[k] >> (8 * i)) : (D.win_value1[k] >> (8 * (i - 4)))) & 0xFFu;
+            const uint32_t mb = (i < 4 ? (D.win_mask0[k] >> (8 * i)) : (D.win_mask1[k] >> (8 * (i - 4)))) & 0xFFu;
+            const int at = 8 * (i & 3) + 4 * (i >> 2);
+            if (mb) {
+              v |= (vb & 15u) << at;
+              m |= 15u << at;
+            }
+          }
+          ws.value0[k] = v;
+          ws.mask0[k] = m;
+          nib_masked |= m != 0xFFFFFFFFu;
+        }
+        ws.masked = nib_masked;
+      }
       ws.len = D.win_len;
       ws.offset = D.win_offset;
       launch_scan_windows(sp, ws, D.n_windows, geo.grid, st);

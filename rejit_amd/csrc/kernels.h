@@ -36,6 +36,10 @@ struct WindowSet {
   uint32_t len;      // 1..8 bytes
   uint32_t masked;   // some mask byte inside [0,len) is a wildcard / len is not 4 or 8
   uint32_t two_level;  // test the first dword of all positions before the second (large alphabets)
+  // nibble filter (len > 4, small alphabets): value0/mask0 hold the LOW NIBBLES of the 8 window
+  // bytes packed into one dword (byte i < 4 -> bits 8i..8i+3, byte i >= 4 -> bits 8(i-4)+4..+7);
+  // a superset test with one compare per window instead of two -- verify removes the aliases
+  uint32_t nibble;
 };
 
 struct VerifyParams {

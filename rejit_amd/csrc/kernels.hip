@@ -128,7 +128,7 @@ __device__ __forceinline__ void load_guarded(const uint8_t* text, uint64_t n, ui
 //     (load32(text + w + 4) & mask1[k]) == value1[k];
 // the candidate start is s = w - offset.  Scanned w range: [wlo, whi).
 // One chunk: d[0..3] = the lane's 16 bytes, d[4..5] = the 8 bytes that follow.
-template <int K, bool TWO, bool MASKED, bool TWOLEVEL>
+template <int K, bool TWO, bool MASKED, bool TWOLEVEL, bool NIB>
 __device__ __forceinline__ void windows_chunk(const uint32_t (&d)[6], uint64_t at, const ScanParams& a,
                                               const WindowSet& ws, RegionHits& hits) {
   constexpr int NX = TWO ? 20 : 16;  // windows needed: 16 positions (+4 for the second dword)
@@ -136,10 +136,56 @@ __device__ __forceinline__ void windows_chunk(const uint32_t (&d)[6], uint64_t a
   uint32_t x[NX];
 #pragma unroll
   for (int q = 0; q < NX / 4; q++) {
-    x[4 * q] = d[q];
-    x[4 * q + 1] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1);
-    x[4 * q + 2] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2);
-    x[4 * q + 3] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 3);
+    // nibble filter: keep only the low nibble of every byte ...
+    const uint32_t lo = NIB ? (d[q] & 0x0F0F0F0Fu) : d[q], hi = NIB ? (d[q + 1] & 0x0F0F0F0Fu) : d[q + 1];
+    x[4 * q] = lo;
+    x[4 * q + 1] = __builtin_amdgcn_alignbyte(hi, lo, 1);
+    x[4 * q + 2] = __builtin_amdgcn_alignbyte(hi, lo, 2);
+    x[4 * q + 3] = __builtin_amdgcn_alignbyte(hi, lo, 3);
+  }
+  if (NIB) {
+    // ... so that the 8 bytes of a window pack into ONE dword, pk = x[j] | x[j+4] << 4, and a
+    // window costs one v_bitop3 ((pk ^ value) & mask) instead of three VALU ops.  With two
+    // masked 8-byte windows (regexdna) the exact form needs ~8.5 VALU ops per text byte, which
+    // bounds the kernel at ~4.6 TB/s on 256 CUs; this form needs ~5.3.
+    uint32_t accs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint32_t pk[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      pk[j] = x[j] | (x[j + 4] << 4);  // v_lshl_or_b32
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        uint32_t t = pk[j] ^ ws.value0[k];
+        if (MASKED) t &= ws.mask0[k];
+        accs[j & 3] = accs[j & 3] < t ? accs[j & 3] : t;
+      }
+    }
+    const uint32_t m01 = accs[0] < accs[1] ? accs[0] : accs[1];
+    const uint32_t m23 = accs[2] < accs[3] ? accs[2] : accs[3];
+    const uint32_t acc = m01 < m23 ? m01 : m23;
+    if (__ballot(acc == 0) == 0) return;
+    uint32_t hm = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        uint32_t t = pk[j] ^ ws.value0[k];
+        if (MASKED) t &= ws.mask0[k];
+        best = best < t ? best : t;
+      }
+      hm |= static_cast<uint32_t>(best == 0) << j;
+    }
+    const uint64_t chunk_base = at - static_cast<uint64_t>(lane_id()) * 16;
+    if (chunk_base < a.wlo || chunk_base + kChunk > a.whi) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint64_t w = at + j;
+        if (w < a.wlo || w >= a.whi) hm &= ~(1u << j);
+      }
+    }
+    hits.push_bits(hm, at, ws.offset);
+    return;
   }
   // Streaming test, VALU only.  For window k at position j
   //     t = ((x[j] ^ value0[k]) & mask0[k]) | ((x[j+4] ^ value1[k]) & mask1[k])
@@ -227,7 +273,7 @@ __device__ __forceinline__ void load_chunk(const uint8_t* text, uint64_t at, uin
   }
 }
 
-template <int K, bool TWO, bool MASKED, bool TWOLEVEL>
+template <int K, bool TWO, bool MASKED, bool TWOLEVEL, bool NIB>
 __global__ __launch_bounds__(256) void scan_windows(ScanParams a, WindowSet ws) {
   const int lane = lane_id();
   const uint64_t wave = scalar_wave_index();
@@ -253,31 +299,31 @@ __global__ __launch_bounds__(256) void scan_windows(ScanParams a, WindowSet ws) 
     if (c + 1 < fast_end) load_chunk<TWO>(a.text, (c + 1) * kChunk + lane_off, b1);
     if (c + 2 < fast_end) load_chunk<TWO>(a.text, (c + 2) * kChunk + lane_off, b2);
     while (c + 5 < fast_end) {
-      windows_chunk<K, TWO, MASKED, TWOLEVEL>(b0, c * kChunk + lane_off, a, ws, hits);
+      windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b0, c * kChunk + lane_off, a, ws, hits);
       load_chunk<TWO>(a.text, (c + 3) * kChunk + lane_off, b0);
       __builtin_amdgcn_sched_barrier(0);
-      windows_chunk<K, TWO, MASKED, TWOLEVEL>(b1, (c + 1) * kChunk + lane_off, a, ws, hits);
+      windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b1, (c + 1) * kChunk + lane_off, a, ws, hits);
       load_chunk<TWO>(a.text, (c + 4) * kChunk + lane_off, b1);
       __builtin_amdgcn_sched_barrier(0);
-      windows_chunk<K, TWO, MASKED, TWOLEVEL>(b2, (c + 2) * kChunk + lane_off, a, ws, hits);
+      windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b2, (c + 2) * kChunk + lane_off, a, ws, hits);
       load_chunk<TWO>(a.text, (c + 5) * kChunk + lane_off, b2);
       __builtin_amdgcn_sched_barrier(0);
       c += 3;
     }
     // drain: b0..b2 hold chunks c, c+1, c+2 (where they exist), then <= 2 more
-    if (c < fast_end) windows_chunk<K, TWO, MASKED, TWOLEVEL>(b0, c * kChunk + lane_off, a, ws, hits);
-    if (c + 1 < fast_end) windows_chunk<K, TWO, MASKED, TWOLEVEL>(b1, (c + 1) * kChunk + lane_off, a, ws, hits);
-    if (c + 2 < fast_end) windows_chunk<K, TWO, MASKED, TWOLEVEL>(b2, (c + 2) * kChunk + lane_off, a, ws, hits);
+    if (c < fast_end) windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b0, c * kChunk + lane_off, a, ws, hits);
+    if (c + 1 < fast_end) windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b1, (c + 1) * kChunk + lane_off, a, ws, hits);
+    if (c + 2 < fast_end) windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b2, (c + 2) * kChunk + lane_off, a, ws, hits);
     for (c += 3; c < fast_end; c++) {
       load_chunk<TWO>(a.text, c * kChunk + lane_off, b0);
-      windows_chunk<K, TWO, MASKED, TWOLEVEL>(b0, c * kChunk + lane_off, a, ws, hits);
+      windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b0, c * kChunk + lane_off, a, ws, hits);
     }
   }
   // tail: the chunk(s) that touch the end of the text use guarded byte loads
   for (uint64_t t = fast_end; t < span.c1; t++) {
     uint32_t d[6];
     load_guarded(a.text, a.n, t * kChunk + lane_off, d);
-    windows_chunk<K, TWO, MASKED, TWOLEVEL>(d, t * kChunk + lane_off, a, ws, hits);
+    windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(d, t * kChunk + lane_off, a, ws, hits);
   }
   if (lane == 0) a.hit_counts[wave] = hits.count;
 }
@@ -1034,30 +1080,33 @@ ScanGeometry scan_geometry(uint64_t chunks) {
   return g;
 }
 
-template <bool TWO, bool MASKED, bool TWOLEVEL>
+template <bool TWO, bool MASKED, bool TWOLEVEL, bool NIB>
 static void launch_windows_k(int k, const ScanParams& a, const WindowSet& ws, int grid, hipStream_t st) {
   // K is rounded up to an instantiated size; the host pads the window set with copies
-  if (k <= 1) hipLaunchKernelGGL((scan_windows<1, TWO, MASKED, TWOLEVEL>), dim3(grid), dim3(256), 0, st, a, ws);
-  else if (k == 2) hipLaunchKernelGGL((scan_windows<2, TWO, MASKED, TWOLEVEL>), dim3(grid), dim3(256), 0, st, a, ws);
-  else if (k == 3) hipLaunchKernelGGL((scan_windows<3, TWO, MASKED, TWOLEVEL>), dim3(grid), dim3(256), 0, st, a, ws);
-  else if (k == 4) hipLaunchKernelGGL((scan_windows<4, TWO, MASKED, TWOLEVEL>), dim3(grid), dim3(256), 0, st, a, ws);
-  else if (k <= 6) hipLaunchKernelGGL((scan_windows<6, TWO, MASKED, TWOLEVEL>), dim3(grid), dim3(256), 0, st, a, ws);
-  else hipLaunchKernelGGL((scan_windows<8, TWO, MASKED, TWOLEVEL>), dim3(grid), dim3(256), 0, st, a, ws);
+  if (k <= 1) hipLaunchKernelGGL((scan_windows<1, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, a, ws);
+  else if (k == 2) hipLaunchKernelGGL((scan_windows<2, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, a, ws);
+  else if (k == 3) hipLaunchKernelGGL((scan_windows<3, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, a, ws);
+  else if (k == 4) hipLaunchKernelGGL((scan_windows<4, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, a, ws);
+  else if (k <= 6) hipLaunchKernelGGL((scan_windows<6, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, a, ws);
+  else hipLaunchKernelGGL((scan_windows<8, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, a, ws);
 }
 
 void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows, int grid, hipStream_t st) {
   const bool two = ws.len > 4;
   if (two) {
     if (ws.two_level) {
-      if (ws.masked) launch_windows_k<true, true, true>(n_windows, a, ws, grid, st);
-      else launch_windows_k<true, false, true>(n_windows, a, ws, grid, st);
+      if (ws.masked) launch_windows_k<true, true, true, false>(n_windows, a, ws, grid, st);
+      else launch_windows_k<true, false, true, false>(n_windows, a, ws, grid, st);
+    } else if (ws.nibble) {
+      if (ws.masked) launch_windows_k<true, true, false, true>(n_windows, a, ws, grid, st);
+      else launch_windows_k<true, false, false, true>(n_windows, a, ws, grid, st);
     } else {
-      if (ws.masked) launch_windows_k<true, true, false>(n_windows, a, ws, grid, st);
-      else launch_windows_k<true, false, false>(n_windows, a, ws, grid, st);
+      if (ws.masked) launch_windows_k<true, true, false, false>(n_windows, a, ws, grid, st);
+      else launch_windows_k<true, false, false, false>(n_windows, a, ws, grid, st);
     }
   } else {
-    if (ws.masked) launch_windows_k<false, true, false>(n_windows, a, ws, grid, st);
-    else launch_windows_k<false, false, false>(n_windows, a, ws, grid, st);
+    if (ws.masked) launch_windows_k<false, true, false, false>(n_windows, a, ws, grid, st);
+    else launch_windows_k<false, false, false, false>(n_windows, a, ws, grid, st);
   }
 }
 
