@@ -56,8 +56,8 @@ typedef struct {
   uint64_t n_hits;         /* candidate starts produced by the scan kernel           */
   uint64_t n_candidates;   /* verified (begin,end) candidates before selection       */
   uint64_t n_matches;      /* final left-most-longest, non-overlapping matches       */
-  float scan_ms;           /* HIP-event time of the scan kernel(s) on the run's stream */
-  float total_ms;          /* HIP-event time of the whole device pipeline            */
+  float scan_ms;           /* start-to-end time of the scan kernel(s), from their dispatch timestamps */
+  float total_ms;          /* host clock: first launch to final synchronise of the run */
   int32_t retries;         /* runs repeated because a device list had to grow        */
   int32_t large_path;      /* 1 when the rocPRIM sort path was taken                 */
   int32_t exact_path;      /* 1 when the one-lane exact kernel replaced the result   */

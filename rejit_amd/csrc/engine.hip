@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -319,6 +320,7 @@ hipError_t prefix_scan(rj_scan* s, uint64_t* in, uint64_t* out, uint64_t count, 
 }
 
 int check_and_select(rj_scan* s, uint64_t n_upper, const FinalizeParams& fp, hipStream_t st);
+int resolve_selection(rj_scan* s, const FinalizeParams& fp, hipStream_t st);
 
 int finalize_large(rj_scan* s, uint64_t n_slots, bool unsorted, uint64_t text_len, const FinalizeParams& fp, hipStream_t st) {
   s->stats.large_path = 1;
@@ -371,6 +373,14 @@ int check_and_select(rj_scan* s, uint64_t n_slots, const FinalizeParams& fp, hip
   RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   RJ_HIP(hipStreamSynchronize(st));
   RJ_HIP(hipGetLastError());
+  return resolve_selection(s, fp, st);
+}
+
+// host_counters hold the counters of a finished check: take the candidates as they are, or run
+// the cluster-parallel selection over keys_out / vals_out.
+int resolve_selection(rj_scan* s, const FinalizeParams& fp, hipStream_t st) {
+  uint64_t* keys = s->keys_out.as<uint64_t>();
+  uint64_t* vals = s->vals_out.as<uint64_t>();
   if (s->host_counters[kCntOverflow] != 0) return RJ_OK;  // the caller grows the regions and runs again
   const uint64_t n_cands = s->host_counters[kCntCands];
   s->stats.n_candidates = n_cands;
@@ -471,8 +481,8 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
     sp.hits = s->hits.as<uint64_t>();
     sp.region_cap = static_cast<uint32_t>(region_cap);
     sp.hit_counts = s->hit_counts.as<uint32_t>();
-    RJ_HIP(hipMemsetAsync(s->counters.p, 0, kCntSize * sizeof(unsigned long long), st));
-    RJ_HIP(hipEventRecord(s->ev[1], st));
+    if (in_regions) sp.zero_counters = s->counters.as<unsigned long long>();  // the scan kernel clears them
+    else RJ_HIP(hipMemsetAsync(s->counters.p, 0, kCntSize * sizeof(unsigned long long), st));
     if (windows) {
       WindowSet ws{};
       bool masked = false;
@@ -507,11 +517,10 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
       }
       ws.len = D.win_len;
       ws.offset = D.win_offset;
-      launch_scan_windows(sp, ws, D.n_windows, geo.grid, st);
+      launch_scan_windows(sp, ws, D.n_windows, geo.grid, s->ev[1], s->ev[2], st);
     } else {
-      launch_scan_dense(sp, D, geo.grid, st);
+      launch_scan_dense(sp, D, geo.grid, s->ev[1], s->ev[2], st);
     }
-    RJ_HIP(hipEventRecord(s->ev[2], st));
     FinalizeParams fp{};
     fp.cand_begin = s->cand_begin.as<uint64_t>();
     fp.cand_end = s->cand_end.as<uint64_t>();
@@ -529,7 +538,7 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
     fp.expand = expand;
     VerifyParams vp{};
     if (!in_regions)
-      launch_region_offsets(s->hit_counts.as<uint32_t>(), geo.n_regions, static_cast<uint32_t>(region_cap), false,
+      launch_region_offsets(s->hit_counts.as<uint32_t>(), geo.n_regions, static_cast<uint32_t>(region_cap),
                             s->hit_offsets.as<uint64_t>(), s->counters.as<unsigned long long>(), st);
     vp.text = d_text;
     vp.n = n;
@@ -562,12 +571,26 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
     }
     if (in_regions) {
       // verify + compact inside the regions, lay the survivors out, check / select: one sync
+      // (verifying at the tail of the scan kernel instead was measured: 5 us slower per pass)
       launch_verify_in_regions(vp, D, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(), s->cand_end.as<uint64_t>(), st);
-      launch_region_offsets(s->valid_counts.as<uint32_t>(), geo.n_regions, static_cast<uint32_t>(region_cap), true,
-                            s->hit_offsets.as<uint64_t>(), s->counters.as<unsigned long long>(), st);
-      launch_gather_pairs(s->hits.as<uint64_t>(), s->cand_end.as<uint64_t>(), s->hit_offsets.as<uint64_t>(), geo.n_regions,
-                          static_cast<uint32_t>(region_cap), s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), st);
-      rc = check_and_select(s, std::max<uint64_t>(s->hits_hint, 1u << 12), fp, st);
+      // (letting the last workgroup publish the counters to pinned host memory instead of the copy
+      // below was measured: slower, its agent-scope fence writes L2 back)
+      launch_offsets_gather_check(s->valid_counts.as<uint32_t>(), s->hits.as<uint64_t>(), s->cand_end.as<uint64_t>(), geo.n_regions,
+                                  static_cast<uint32_t>(region_cap), fp.carry_cur, s->out.as<uint64_t>(), s->out_cap,
+                                  s->counters.as<unsigned long long>(), st);
+      const uint64_t n_guess = std::max<uint64_t>(s->hits_hint, 1u << 12);
+      if (fp.detect_adjacent) {
+        launch_split_pairs(s->out.as<uint64_t>(), s->counters.as<unsigned long long>() + kCntCands, n_guess,
+                           s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), st);
+        launch_detect_adjacent(s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), n_guess, s->counters.as<unsigned long long>(), st);
+      }
+      RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+      RJ_HIP(hipStreamSynchronize(st));
+      RJ_HIP(hipGetLastError());
+      if (!fp.detect_adjacent && s->host_counters[kCntUnordered] != 0 && s->host_counters[kCntOverflow] == 0)
+        launch_split_pairs(s->out.as<uint64_t>(), s->counters.as<unsigned long long>() + kCntCands, s->host_counters[kCntCands],
+                           s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), st);
+      rc = resolve_selection(s, fp, st);
       if (rc != RJ_OK) return rc;
     } else {
       launch_verify(vp, D, windows ? std::max<uint64_t>(s->hits_hint, 1u << 14) : (se - sb) / 8 + 1, st);
@@ -636,7 +659,7 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
   s->result_count = 0;
   if (sb >= se) return RJ_OK;
   if ((reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) return fail(RJ_BAD_ARGUMENT, "device text must be 16-byte aligned");
-  RJ_HIP(hipEventRecord(s->ev[0], st));
+  const auto wall0 = std::chrono::steady_clock::now();
   const bool windows = rp->dev.mode == 1;
   if (windows || se - sb <= kDenseSegment) {
     int rc = run_range(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
@@ -667,8 +690,9 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     s->result_count = total;
     s->result = s->acc_out.as<uint64_t>();
   }
-  RJ_HIP(hipEventRecord(s->ev[3], st));  // total_ms is resolved lazily in rj_scan_stats
-  s->stats.total_ms = -1.f;
+  // (every run_range ends with a stream synchronise, so the host clock covers the whole pipeline
+  // and no event commands are needed on the stream)
+  s->stats.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
   s->stats.n_matches = s->result_count;
   return RJ_OK;
 }
@@ -900,11 +924,6 @@ void rj_free_text(char* text) { free(text); }
 
 int rj_scan_stats(const rj_scan* s, rj_stats* stats) {
   if (!s || !stats) return fail(RJ_BAD_ARGUMENT, "null argument");
-  if (s->stats.total_ms < 0.f) {
-    rj_scan* m = const_cast<rj_scan*>(s);
-    (void)hipEventSynchronize(m->ev[3]);
-    if (hipEventElapsedTime(&m->stats.total_ms, m->ev[0], m->ev[3]) != hipSuccess) m->stats.total_ms = 0.f;
-  }
   *stats = s->stats;
   return RJ_OK;
 }

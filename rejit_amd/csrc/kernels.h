@@ -27,6 +27,9 @@ struct ScanParams {
   uint64_t* hits;        // n_regions regions of region_cap entries, region w = wave w
   uint32_t region_cap;
   uint32_t* hit_counts;  // [n_regions] hits each wave found (may exceed region_cap)
+  // scan_windows: when set, the kernel zeroes the counter block (its first use is in the kernels
+  // that follow on the stream), which saves the host a memset command per run
+  unsigned long long* zero_counters;
 };
 
 struct WindowSet {
@@ -81,16 +84,24 @@ struct ScanGeometry {
 };
 ScanGeometry scan_geometry(uint64_t chunks);
 
-void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows, int grid, hipStream_t st);
-void launch_scan_dense(const ScanParams& a, const DevProgram& P, int grid, hipStream_t st);
-void launch_region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap, bool verified, uint64_t* offsets,
+// t0 / t1: events stamped with the kernel's own start / end (hipExtLaunchKernelGGL), no extra
+// stream commands
+void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows, int grid, hipEvent_t t0, hipEvent_t t1,
+                         hipStream_t st);
+void launch_scan_dense(const ScanParams& a, const DevProgram& P, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
+void launch_region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap, uint64_t* offsets,
                            unsigned long long* counters, hipStream_t st);
 // windows mode, lane-sized automaton: verify + compact inside every region (16 lanes each), then
-// gather the survivors into the ordered candidate list that region_offsets(verified) laid out
+// offsets_gather_check lays the survivors out
 void launch_verify_in_regions(const VerifyParams& a, const DevProgram& P, const uint32_t* hit_counts, uint32_t* valid_counts,
                               uint64_t* region_ends, hipStream_t st);
-void launch_gather_pairs(const uint64_t* region_begins, const uint64_t* region_ends, const uint64_t* offsets,
-                         uint32_t n_regions, uint32_t region_cap, uint64_t* keys, uint64_t* vals, hipStream_t st);
+// region offsets + gather + check_and_interleave in one launch (see the kernel)
+void launch_offsets_gather_check(const uint32_t* counts, const uint64_t* region_begins, const uint64_t* region_ends,
+                                 uint32_t n_regions, uint32_t region_cap, uint64_t carry_cur, uint64_t* out, uint64_t out_cap,
+                                 unsigned long long* counters, hipStream_t st);
+// (begin,end) pairs -> begin[] / end[]; n read from device memory
+void launch_split_pairs(const uint64_t* pairs, const unsigned long long* n_ptr, uint64_t n_upper, uint64_t* keys, uint64_t* vals,
+                        hipStream_t st);
 void launch_verify(const VerifyParams& a, const DevProgram& P, uint64_t expected_hits, hipStream_t st);
 // large path: drop the kNoMatch slots, keeping the order
 void launch_mark_valid(const uint64_t* cand_end, uint64_t n, uint64_t* flags, hipStream_t st);

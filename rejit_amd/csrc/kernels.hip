@@ -33,6 +33,7 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "device_program.h"
 #include "kernels.h"
@@ -277,6 +278,7 @@ template <int K, bool TWO, bool MASKED, bool TWOLEVEL, bool NIB>
 __global__ __launch_bounds__(256) void scan_windows(ScanParams a, WindowSet ws) {
   const int lane = lane_id();
   const uint64_t wave = scalar_wave_index();
+  if (a.zero_counters != nullptr && wave == 0 && lane < kCntSize) a.zero_counters[lane] = 0;
   RegionHits hits{a.hits + wave * a.region_cap, a.region_cap, 0u};
   const uint64_t first_chunk = a.wlo / kChunk;
   const uint64_t end_chunk = (a.whi + kChunk - 1) / kChunk;
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256) void scan_dense(ScanParams a, DevProgram P) {
 // One workgroup; n_regions <= 64 Ki.
 template <int PER>
 __global__ __launch_bounds__(1024) void region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap,
-                                                       uint64_t* offsets, unsigned long long* counters, bool verified) {
+                                                       uint64_t* offsets, unsigned long long* counters) {
   __shared__ uint64_t wave_sum[16];
   __shared__ uint32_t wave_max[16];
   const int lane = lane_id(), wv = threadIdx.x >> 6;
@@ -432,12 +434,8 @@ __global__ __launch_bounds__(1024) void region_offsets(const uint32_t* counts, u
   if (threadIdx.x == 0) {
     offsets[n_regions] = total;
     counters[kCntHits] = total;
-    if (verified) {  // counts of verified candidates (verify_in_regions saw the raw counts)
-      counters[kCntCands] = total;
-    } else {
-      counters[kCntMaxRegion] = maxc;
-      if (maxc > cap) counters[kCntOverflow] = 1;
-    }
+    counters[kCntMaxRegion] = maxc;
+    if (maxc > cap) counters[kCntOverflow] = 1;
   }
 }
 
@@ -596,8 +594,8 @@ __global__ __launch_bounds__(256) void verify_lane_regions(VerifyParams a, DevPr
 
 // Fast-forward windows with a lane-sized automaton: 16 lanes take one hit region, verify its
 // hits and compact the survivors IN PLACE (begins stay in the region, ends go to the same slot
-// of region_ends).  The count per region then drives region_offsets, so the candidates need no
-// global compaction pass at all.
+// of region_ends).  The count per region then drives offsets_gather_check, so the candidates need
+// no global compaction pass at all.
 template <int NQ>
 __global__ __launch_bounds__(256) void verify_in_regions(VerifyParams a, DevProgram P, const uint32_t* hit_counts,
                                                          uint32_t* valid_counts, uint64_t* region_ends) {
@@ -635,19 +633,131 @@ __global__ __launch_bounds__(256) void verify_in_regions(VerifyParams a, DevProg
   }
 }
 
-// ... and the regions' survivors are copied to their place in the ordered candidate list.
-__global__ __launch_bounds__(256) void gather_pairs(const uint64_t* region_begins, const uint64_t* region_ends,
-                                                    const uint64_t* offsets, uint32_t n_regions, uint32_t region_cap,
-                                                    uint64_t* keys, uint64_t* vals) {
-  const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const uint64_t n_groups = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 4;
-  const int sub = lane_id() & 15;
-  for (uint64_t r = tid >> 4; r < n_regions; r += n_groups) {
-    const uint64_t lo = offsets[r], cnt = offsets[r + 1] - lo;
-    for (uint64_t k = sub; k < cnt; k += 16) {
-      keys[lo + k] = region_begins[r * region_cap + k];
-      vals[lo + k] = region_ends[r * region_cap + k];
+// region offsets + gather + disjointness check in one multi-workgroup launch: workgroup b owns
+// regions [256 b, 256 b + 256), one per thread.  It sums the counts of ALL regions before its
+// own (<= 64 Ki counts, read as uint4 by 256 threads: cheaper than another launch, and no
+// workgroup waits for another), scans its own counts, and copies its regions' survivors to their
+// final place in `out` (pairs).  The candidates already are the result iff every one is non-empty
+// and begins at or after the end of all earlier ones (begins are sorted, so "all earlier" =
+// running maximum); the maximum before a workgroup's first candidate is the last end of the
+// nearest non-empty region before it.  Otherwise counters[kCntUnordered] is set and the host
+// splits the pairs and runs the cluster-parallel selection.
+constexpr int kOgcThreads = 256;
+__global__ __launch_bounds__(kOgcThreads) void offsets_gather_check(const uint32_t* counts, const uint64_t* region_begins,
+                                                                    const uint64_t* region_ends, uint32_t n_regions,
+                                                                    uint32_t region_cap, uint64_t carry_cur, uint64_t* out,
+                                                                    uint64_t out_cap, unsigned long long* counters) {
+  constexpr int kWaves = kOgcThreads / kWave;
+  __shared__ uint64_t wave_sum[kWaves], wave_before[kWaves], wave_end[kWaves];
+  __shared__ int64_t wave_last[kWaves];
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  const uint32_t first = blockIdx.x * kOgcThreads;  // a multiple of 4
+  // 1. everything before this workgroup: candidate count, nearest non-empty region (its index and
+  //    count packed in one word so that the maximum carries both)
+  uint64_t before = 0;
+  int64_t last = -1;
+  const uint4* counts4 = reinterpret_cast<const uint4*>(counts);
+  for (uint32_t q = threadIdx.x; q < first / 4; q += kOgcThreads) {
+    const uint4 c = counts4[q];
+    before += static_cast<uint64_t>(c.x) + c.y + c.z + c.w;
+    const uint32_t i = 4 * q;
+    if (c.x) last = (static_cast<int64_t>(i) << 32) | c.x;  // q grows along the loop
+    if (c.y) last = (static_cast<int64_t>(i + 1) << 32) | c.y;
+    if (c.z) last = (static_cast<int64_t>(i + 2) << 32) | c.z;
+    if (c.w) last = (static_cast<int64_t>(i + 3) << 32) | c.w;
+  }
+  // 2. own region: the first kHeld entries are loaded at once and kept in registers (regions hold
+  //    a few candidates; one round trip instead of one per entry), the largest end
+  constexpr int kHeld = 4;
+  const uint32_t r = first + threadIdx.x;
+  const uint32_t cnt = r < n_regions ? counts[r] : 0u;
+  const uint64_t src = static_cast<uint64_t>(r) * region_cap;
+  uint64_t hb[kHeld], he[kHeld];
+#pragma unroll
+  for (int k = 0; k < kHeld; k++) {
+    hb[k] = static_cast<uint32_t>(k) < cnt ? region_begins[src + k] : 0;
+    he[k] = static_cast<uint32_t>(k) < cnt ? region_ends[src + k] : 0;
+  }
+  uint64_t my_end = 0;
+#pragma unroll
+  for (int k = 0; k < kHeld; k++) my_end = he[k] > my_end ? he[k] : my_end;
+  for (uint32_t k = kHeld; k < cnt; k++) {
+    const uint64_t e = region_ends[src + k];
+    my_end = e > my_end ? e : my_end;
+  }
+  uint64_t inc = cnt, inc_end = my_end;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const uint64_t v = __shfl_up(inc, o);
+    const uint64_t ve = __shfl_up(inc_end, o);
+    if (lane >= o) {
+      inc += v;
+      inc_end = ve > inc_end ? ve : inc_end;
     }
+    before += __shfl_xor(before, o);
+    const int64_t l2 = __shfl_xor(last, o);
+    last = l2 > last ? l2 : last;
+  }
+  if (lane == kWave - 1) {
+    wave_sum[wv] = inc;
+    wave_end[wv] = inc_end;
+  }
+  if (lane == 0) {
+    wave_before[wv] = before;
+    wave_last[wv] = last;
+  }
+  __syncthreads();
+  uint64_t base = 0, own_before = 0, own_total = 0, end_before = 0;
+  int64_t nearest = -1;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) {
+    base += wave_before[w];
+    nearest = wave_last[w] > nearest ? wave_last[w] : nearest;
+    if (w < wv) {
+      own_before += wave_sum[w];
+      end_before = wave_end[w] > end_before ? wave_end[w] : end_before;
+    }
+    own_total += wave_sum[w];
+  }
+  // running maximum of the ends before this thread's first candidate
+  uint64_t prev = carry_cur;
+  if (nearest >= 0) {
+    const uint64_t e = region_ends[static_cast<uint64_t>(nearest >> 32) * region_cap + (nearest & 0xFFFFFFFF) - 1];
+    prev = e > prev ? e : prev;
+  }
+  prev = end_before > prev ? end_before : prev;
+  const uint64_t up = __shfl_up(inc_end, 1);  // inclusive maximum of the lanes below
+  if (lane > 0) prev = up > prev ? up : prev;
+  // 3. copy + check (a few entries per region)
+  const uint64_t off = base + own_before + inc - cnt;
+  bool ok = true;
+  for (uint32_t k = 0; k < cnt; k++) {
+    uint64_t b, e;
+    if (k < kHeld) {
+      b = k == 0 ? hb[0] : k == 1 ? hb[1] : k == 2 ? hb[2] : hb[3];
+      e = k == 0 ? he[0] : k == 1 ? he[1] : k == 2 ? he[2] : he[3];
+    } else {
+      b = region_begins[src + k];
+      e = region_ends[src + k];
+    }
+    ok = ok && e > b && b >= prev;
+    prev = e > prev ? e : prev;
+    if (off + k < out_cap) *reinterpret_cast<ulonglong2*>(out + 2 * (off + k)) = make_ulonglong2(b, e);
+  }
+  if (!ok) counters[kCntUnordered] = 1;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    counters[kCntHits] = base + own_total;
+    counters[kCntCands] = base + own_total;
+  }
+}
+
+// pairs -> begin[] / end[] for the selection kernels (only when the pairs are not the result yet)
+__global__ void split_pairs(const uint64_t* pairs, const unsigned long long* n_ptr, uint64_t* keys, uint64_t* vals) {
+  const uint64_t n = *n_ptr;
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    keys[i] = pairs[2 * i];
+    vals[i] = pairs[2 * i + 1];
   }
 }
 
@@ -1081,45 +1191,47 @@ ScanGeometry scan_geometry(uint64_t chunks) {
 }
 
 template <bool TWO, bool MASKED, bool TWOLEVEL, bool NIB>
-static void launch_windows_k(int k, const ScanParams& a, const WindowSet& ws, int grid, hipStream_t st) {
+static void launch_windows_k(int k, const ScanParams& a, const WindowSet& ws, int grid, hipEvent_t t0, hipEvent_t t1,
+                             hipStream_t st) {
   // K is rounded up to an instantiated size; the host pads the window set with copies
-  if (k <= 1) hipLaunchKernelGGL((scan_windows<1, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, a, ws);
-  else if (k == 2) hipLaunchKernelGGL((scan_windows<2, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, a, ws);
-  else if (k == 3) hipLaunchKernelGGL((scan_windows<3, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, a, ws);
-  else if (k == 4) hipLaunchKernelGGL((scan_windows<4, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, a, ws);
-  else if (k <= 6) hipLaunchKernelGGL((scan_windows<6, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, a, ws);
-  else hipLaunchKernelGGL((scan_windows<8, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, a, ws);
+  if (k <= 1) hipExtLaunchKernelGGL((scan_windows<1, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a, ws);
+  else if (k == 2) hipExtLaunchKernelGGL((scan_windows<2, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a, ws);
+  else if (k == 3) hipExtLaunchKernelGGL((scan_windows<3, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a, ws);
+  else if (k == 4) hipExtLaunchKernelGGL((scan_windows<4, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a, ws);
+  else if (k <= 6) hipExtLaunchKernelGGL((scan_windows<6, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a, ws);
+  else hipExtLaunchKernelGGL((scan_windows<8, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a, ws);
 }
 
-void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows, int grid, hipStream_t st) {
+void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows, int grid, hipEvent_t t0, hipEvent_t t1,
+                         hipStream_t st) {
   const bool two = ws.len > 4;
   if (two) {
     if (ws.two_level) {
-      if (ws.masked) launch_windows_k<true, true, true, false>(n_windows, a, ws, grid, st);
-      else launch_windows_k<true, false, true, false>(n_windows, a, ws, grid, st);
+      if (ws.masked) launch_windows_k<true, true, true, false>(n_windows, a, ws, grid, t0, t1, st);
+      else launch_windows_k<true, false, true, false>(n_windows, a, ws, grid, t0, t1, st);
     } else if (ws.nibble) {
-      if (ws.masked) launch_windows_k<true, true, false, true>(n_windows, a, ws, grid, st);
-      else launch_windows_k<true, false, false, true>(n_windows, a, ws, grid, st);
+      if (ws.masked) launch_windows_k<true, true, false, true>(n_windows, a, ws, grid, t0, t1, st);
+      else launch_windows_k<true, false, false, true>(n_windows, a, ws, grid, t0, t1, st);
     } else {
-      if (ws.masked) launch_windows_k<true, true, false, false>(n_windows, a, ws, grid, st);
-      else launch_windows_k<true, false, false, false>(n_windows, a, ws, grid, st);
+      if (ws.masked) launch_windows_k<true, true, false, false>(n_windows, a, ws, grid, t0, t1, st);
+      else launch_windows_k<true, false, false, false>(n_windows, a, ws, grid, t0, t1, st);
     }
   } else {
-    if (ws.masked) launch_windows_k<false, true, false, false>(n_windows, a, ws, grid, st);
-    else launch_windows_k<false, false, false, false>(n_windows, a, ws, grid, st);
+    if (ws.masked) launch_windows_k<false, true, false, false>(n_windows, a, ws, grid, t0, t1, st);
+    else launch_windows_k<false, false, false, false>(n_windows, a, ws, grid, t0, t1, st);
   }
 }
 
-void launch_scan_dense(const ScanParams& a, const DevProgram& P, int grid, hipStream_t st) {
-  hipLaunchKernelGGL(scan_dense, dim3(grid), dim3(256), 0, st, a, P);
+void launch_scan_dense(const ScanParams& a, const DevProgram& P, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+  hipExtLaunchKernelGGL(scan_dense, dim3(grid), dim3(256), 0, st, t0, t1, 0, a, P);
 }
 
-void launch_region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap, bool verified, uint64_t* offsets,
+void launch_region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap, uint64_t* offsets,
                            unsigned long long* counters, hipStream_t st) {
   // n_regions <= 64 Ki (scan_geometry caps the grid at 16 Ki workgroups of 4 waves)
-  if (n_regions <= 16 * 1024) hipLaunchKernelGGL((region_offsets<16>), dim3(1), dim3(1024), 0, st, counts, n_regions, cap, offsets, counters, verified);
-  else if (n_regions <= 32 * 1024) hipLaunchKernelGGL((region_offsets<32>), dim3(1), dim3(1024), 0, st, counts, n_regions, cap, offsets, counters, verified);
-  else hipLaunchKernelGGL((region_offsets<64>), dim3(1), dim3(1024), 0, st, counts, n_regions, cap, offsets, counters, verified);
+  if (n_regions <= 16 * 1024) hipLaunchKernelGGL((region_offsets<16>), dim3(1), dim3(1024), 0, st, counts, n_regions, cap, offsets, counters);
+  else if (n_regions <= 32 * 1024) hipLaunchKernelGGL((region_offsets<32>), dim3(1), dim3(1024), 0, st, counts, n_regions, cap, offsets, counters);
+  else hipLaunchKernelGGL((region_offsets<64>), dim3(1), dim3(1024), 0, st, counts, n_regions, cap, offsets, counters);
 }
 
 void launch_verify(const VerifyParams& a, const DevProgram& P, uint64_t expected_hits, hipStream_t st) {
@@ -1159,12 +1271,19 @@ void launch_verify_in_regions(const VerifyParams& a, const DevProgram& P, const 
                           valid_counts, region_ends);
 }
 
-void launch_gather_pairs(const uint64_t* region_begins, const uint64_t* region_ends, const uint64_t* offsets,
-                         uint32_t n_regions, uint32_t region_cap, uint64_t* keys, uint64_t* vals, hipStream_t st) {
-  uint64_t blocks = (static_cast<uint64_t>(n_regions) + 15) / 16;
+void launch_offsets_gather_check(const uint32_t* counts, const uint64_t* region_begins, const uint64_t* region_ends,
+                                 uint32_t n_regions, uint32_t region_cap, uint64_t carry_cur, uint64_t* out, uint64_t out_cap,
+                                 unsigned long long* counters, hipStream_t st) {
+  const unsigned blocks = n_regions ? (n_regions + kOgcThreads - 1) / kOgcThreads : 1u;
+  hipLaunchKernelGGL(offsets_gather_check, dim3(blocks), dim3(kOgcThreads), 0, st, counts, region_begins, region_ends, n_regions,
+                     region_cap, carry_cur, out, out_cap, counters);
+}
+
+void launch_split_pairs(const uint64_t* pairs, const unsigned long long* n_ptr, uint64_t n_upper, uint64_t* keys, uint64_t* vals,
+                        hipStream_t st) {
+  uint64_t blocks = (n_upper + 255) / 256;
   blocks = blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks;
-  hipLaunchKernelGGL(gather_pairs, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, region_begins, region_ends, offsets,
-                     n_regions, region_cap, keys, vals);
+  hipLaunchKernelGGL(split_pairs, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, pairs, n_ptr, keys, vals);
 }
 
 void launch_mark_valid(const uint64_t* cand_end, uint64_t n, uint64_t* flags, hipStream_t st) {
