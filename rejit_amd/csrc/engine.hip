@@ -575,16 +575,17 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
       launch_verify_in_regions(vp, D, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(), s->cand_end.as<uint64_t>(), st);
       // (letting the last workgroup publish the counters to pinned host memory instead of the copy
       // below was measured: slower, its agent-scope fence writes L2 back)
+      s->host_counters[kCntUnordered] = 0;  // the kernel below writes the pinned block itself
       launch_offsets_gather_check(s->valid_counts.as<uint32_t>(), s->hits.as<uint64_t>(), s->cand_end.as<uint64_t>(), geo.n_regions,
                                   static_cast<uint32_t>(region_cap), fp.carry_cur, s->out.as<uint64_t>(), s->out_cap,
-                                  s->counters.as<unsigned long long>(), st);
+                                  s->counters.as<unsigned long long>(), fp.detect_adjacent ? nullptr : s->host_counters, st);
       const uint64_t n_guess = std::max<uint64_t>(s->hits_hint, 1u << 12);
       if (fp.detect_adjacent) {
         launch_split_pairs(s->out.as<uint64_t>(), s->counters.as<unsigned long long>() + kCntCands, n_guess,
                            s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), st);
         launch_detect_adjacent(s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), n_guess, s->counters.as<unsigned long long>(), st);
+        RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
       }
-      RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
       RJ_HIP(hipStreamSynchronize(st));
       RJ_HIP(hipGetLastError());
       if (!fp.detect_adjacent && s->host_counters[kCntUnordered] != 0 && s->host_counters[kCntOverflow] == 0)

@@ -646,7 +646,8 @@ constexpr int kOgcThreads = 256;
 __global__ __launch_bounds__(kOgcThreads) void offsets_gather_check(const uint32_t* counts, const uint64_t* region_begins,
                                                                     const uint64_t* region_ends, uint32_t n_regions,
                                                                     uint32_t region_cap, uint64_t carry_cur, uint64_t* out,
-                                                                    uint64_t out_cap, unsigned long long* counters) {
+                                                                    uint64_t out_cap, unsigned long long* counters,
+                                                                    unsigned long long* host_counters) {
   constexpr int kWaves = kOgcThreads / kWave;
   __shared__ uint64_t wave_sum[kWaves], wave_before[kWaves], wave_end[kWaves];
   __shared__ int64_t wave_last[kWaves];
@@ -744,10 +745,25 @@ __global__ __launch_bounds__(kOgcThreads) void offsets_gather_check(const uint32
     prev = e > prev ? e : prev;
     if (off + k < out_cap) *reinterpret_cast<ulonglong2*>(out + 2 * (off + k)) = make_ulonglong2(b, e);
   }
-  if (!ok) counters[kCntUnordered] = 1;
+  if (!ok) {
+    counters[kCntUnordered] = 1;
+    if (host_counters) host_counters[kCntUnordered] = 1;
+  }
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
     counters[kCntHits] = base + own_total;
     counters[kCntCands] = base + own_total;
+    if (host_counters) {
+      // straight into pinned host memory (visible when the kernel has completed): the host needs
+      // no copy command, only the synchronise.  The flags below were set by EARLIER kernels; the
+      // host cleared its kCntUnordered word before the launch.
+      host_counters[kCntHits] = base + own_total;
+      host_counters[kCntCands] = base + own_total;
+      host_counters[kCntOverflow] = counters[kCntOverflow];
+      host_counters[kCntMaxRegion] = counters[kCntMaxRegion];
+      host_counters[kCntOverrun] = counters[kCntOverrun];
+      host_counters[kCntAdjacent] = 0;
+      host_counters[kCntFinal] = 0;
+    }
   }
 }
 
@@ -1273,10 +1289,10 @@ void launch_verify_in_regions(const VerifyParams& a, const DevProgram& P, const 
 
 void launch_offsets_gather_check(const uint32_t* counts, const uint64_t* region_begins, const uint64_t* region_ends,
                                  uint32_t n_regions, uint32_t region_cap, uint64_t carry_cur, uint64_t* out, uint64_t out_cap,
-                                 unsigned long long* counters, hipStream_t st) {
+                                 unsigned long long* counters, unsigned long long* host_counters, hipStream_t st) {
   const unsigned blocks = n_regions ? (n_regions + kOgcThreads - 1) / kOgcThreads : 1u;
   hipLaunchKernelGGL(offsets_gather_check, dim3(blocks), dim3(kOgcThreads), 0, st, counts, region_begins, region_ends, n_regions,
-                     region_cap, carry_cur, out, out_cap, counters);
+                     region_cap, carry_cur, out, out_cap, counters, host_counters);
 }
 
 void launch_split_pairs(const uint64_t* pairs, const unsigned long long* n_ptr, uint64_t n_upper, uint64_t* keys, uint64_t* vals,
