@@ -45,6 +45,7 @@ struct DevProgram {
   const int32_t* row_of;
   const uint32_t* rows;
   const uint32_t* cls;
+  uint32_t table_words;  // the tables are one contiguous blob of this many words starting at `first`
 };
 
 // The NFA graph for the exact sequential kernel (reference ring semantics).

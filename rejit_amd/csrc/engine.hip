@@ -169,6 +169,7 @@ int upload_program(rj_program* rp) {
   const uint32_t* base = rp->tables.as<uint32_t>();
   DevProgram& D = rp->dev;
   D.n_pos = P.n_pos;
+  D.table_words = static_cast<uint32_t>(total);
   D.n_words = W;
   D.n_ctx = C;
   D.n_rows = R;
@@ -460,11 +461,17 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
   sp.span_chunks = geo.span_chunks;
   // dense: any position may be a hit; windows: start small, grow on overflow
   const uint64_t region_full = geo.span_chunks * 1024;
-  uint64_t region_cap = windows ? std::min<uint64_t>(std::max<uint64_t>(s->region_cap_hint, 64), region_full) : region_full;
+  // dense mode with a lane-sized automaton: one kernel finds, walks and compacts the candidates,
+  // so its regions hold verified matches only (few) and are sized like the windows regions
+  static const bool no_dense_walk = getenv("RJ_NO_DENSE_WALK") != nullptr;  // measurement override
+  const bool dense_walk = !windows && dense_walk_fits(D) && !no_dense_walk;
+  uint64_t region_cap = windows      ? std::min<uint64_t>(std::max<uint64_t>(s->region_cap_hint, 64), region_full)
+                        : dense_walk ? std::min<uint64_t>(std::max<uint64_t>(s->region_cap_hint, 256), region_full)
+                                     : region_full;
 
   // fixed windows + an automaton that fits a lane: candidates are verified and compacted inside
   // their hit regions (no global compaction, no sort)
-  const bool in_regions = windows && expand == 1 && D.n_words <= 4;
+  const bool in_regions = (windows && expand == 1 && D.n_words <= 4) || dense_walk;
 
   for (int attempt = 0; attempt < 6; attempt++) {
     const uint64_t slots = static_cast<uint64_t>(geo.n_regions) * region_cap;
@@ -473,15 +480,11 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
     uint64_t cand_slots = expand == 1 ? slots : std::max<uint64_t>(s->hits_hint * expand * 2, 1u << 16);
     int rc = ensure_lists(s, geo.n_regions, static_cast<uint32_t>(region_cap), std::max<uint64_t>(cand_slots, 1u << 12));
     if (rc != RJ_OK) return rc;
-    if (in_regions) {
-      RJ_HIP(s->valid_counts.reserve(static_cast<size_t>(geo.n_regions) * sizeof(uint32_t)));
-      RJ_HIP(s->keys_out.reserve(slots * sizeof(uint64_t)));
-      RJ_HIP(s->vals_out.reserve(slots * sizeof(uint64_t)));
-    }
+    if (in_regions) RJ_HIP(s->valid_counts.reserve(static_cast<size_t>(geo.n_regions) * sizeof(uint32_t)));
     sp.hits = s->hits.as<uint64_t>();
     sp.region_cap = static_cast<uint32_t>(region_cap);
     sp.hit_counts = s->hit_counts.as<uint32_t>();
-    if (in_regions) sp.zero_counters = s->counters.as<unsigned long long>();  // the scan kernel clears them
+    if (in_regions && windows) sp.zero_counters = s->counters.as<unsigned long long>();  // the scan kernel clears them
     else RJ_HIP(hipMemsetAsync(s->counters.p, 0, kCntSize * sizeof(unsigned long long), st));
     if (windows) {
       WindowSet ws{};
@@ -518,6 +521,9 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
       ws.len = D.win_len;
       ws.offset = D.win_offset;
       launch_scan_windows(sp, ws, D.n_windows, geo.grid, s->ev[1], s->ev[2], st);
+    } else if (dense_walk) {
+      launch_scan_dense_walk(sp, D, geo.grid, s->cand_end.as<uint64_t>(), s->counters.as<unsigned long long>(), s->ev[1],
+                             s->ev[2], st);
     } else {
       launch_scan_dense(sp, D, geo.grid, s->ev[1], s->ev[2], st);
     }
@@ -572,15 +578,20 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
     if (in_regions) {
       // verify + compact inside the regions, lay the survivors out, check / select: one sync
       // (verifying at the tail of the scan kernel instead was measured: 5 us slower per pass)
-      launch_verify_in_regions(vp, D, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(), s->cand_end.as<uint64_t>(), st);
+      if (!dense_walk)
+        launch_verify_in_regions(vp, D, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(), s->cand_end.as<uint64_t>(), st);
+      const uint32_t* survivors = dense_walk ? s->hit_counts.as<uint32_t>() : s->valid_counts.as<uint32_t>();
       // (letting the last workgroup publish the counters to pinned host memory instead of the copy
       // below was measured: slower, its agent-scope fence writes L2 back)
       s->host_counters[kCntUnordered] = 0;  // the kernel below writes the pinned block itself
-      launch_offsets_gather_check(s->valid_counts.as<uint32_t>(), s->hits.as<uint64_t>(), s->cand_end.as<uint64_t>(), geo.n_regions,
+      launch_offsets_gather_check(survivors, s->hits.as<uint64_t>(), s->cand_end.as<uint64_t>(), geo.n_regions,
                                   static_cast<uint32_t>(region_cap), fp.carry_cur, s->out.as<uint64_t>(), s->out_cap,
                                   s->counters.as<unsigned long long>(), fp.detect_adjacent ? nullptr : s->host_counters, st);
       const uint64_t n_guess = std::max<uint64_t>(s->hits_hint, 1u << 12);
       if (fp.detect_adjacent) {
+        // (the selection kernels work on begin[] / end[]; sized for every slot as the count is not known yet)
+        RJ_HIP(s->keys_out.reserve(slots * sizeof(uint64_t)));
+        RJ_HIP(s->vals_out.reserve(slots * sizeof(uint64_t)));
         launch_split_pairs(s->out.as<uint64_t>(), s->counters.as<unsigned long long>() + kCntCands, n_guess,
                            s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), st);
         launch_detect_adjacent(s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), n_guess, s->counters.as<unsigned long long>(), st);
@@ -588,9 +599,12 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
       }
       RJ_HIP(hipStreamSynchronize(st));
       RJ_HIP(hipGetLastError());
-      if (!fp.detect_adjacent && s->host_counters[kCntUnordered] != 0 && s->host_counters[kCntOverflow] == 0)
+      if (!fp.detect_adjacent && s->host_counters[kCntUnordered] != 0 && s->host_counters[kCntOverflow] == 0) {
+        RJ_HIP(s->keys_out.reserve(s->host_counters[kCntCands] * sizeof(uint64_t)));
+        RJ_HIP(s->vals_out.reserve(s->host_counters[kCntCands] * sizeof(uint64_t)));
         launch_split_pairs(s->out.as<uint64_t>(), s->counters.as<unsigned long long>() + kCntCands, s->host_counters[kCntCands],
                            s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), st);
+      }
       rc = resolve_selection(s, fp, st);
       if (rc != RJ_OK) return rc;
     } else {
@@ -662,7 +676,7 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
   if ((reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) return fail(RJ_BAD_ARGUMENT, "device text must be 16-byte aligned");
   const auto wall0 = std::chrono::steady_clock::now();
   const bool windows = rp->dev.mode == 1;
-  if (windows || se - sb <= kDenseSegment) {
+  if (windows || dense_walk_fits(rp->dev) || se - sb <= kDenseSegment) {
     int rc = run_range(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
     if (rc != RJ_OK) return rc;
     s->result = s->out.as<uint64_t>();

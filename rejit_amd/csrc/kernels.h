@@ -88,6 +88,12 @@ ScanGeometry scan_geometry(uint64_t chunks);
 // stream commands
 void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows, int grid, hipEvent_t t0, hipEvent_t t1,
                          hipStream_t st);
+// dense mode with a lane-sized automaton whose tables fit LDS: candidates are found, walked and
+// compacted in one kernel; the regions then hold verified (begin | end) like after
+// verify_in_regions.  hit_counts = survivors per region (clamped to region_cap; overflow flagged).
+bool dense_walk_fits(const DevProgram& P);
+void launch_scan_dense_walk(const ScanParams& a, const DevProgram& P, int grid, uint64_t* region_ends,
+                            unsigned long long* counters, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 void launch_scan_dense(const ScanParams& a, const DevProgram& P, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 void launch_region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap, uint64_t* offsets,
                            unsigned long long* counters, hipStream_t st);

@@ -777,6 +777,147 @@ __global__ void split_pairs(const uint64_t* pairs, const unsigned long long* n_p
   }
 }
 
+// Dense mode, lane-sized automaton: the NFA inner loop proper.  Two things made the plain
+// one-walk-per-lane kernel (verify_lane_regions) slow -- 1700 lane-cycles per walk on
+// `[A-Z][a-z]+ ...` although the average walk is under two steps:
+//   * a wave ran as long as its LONGEST walk (walk lengths are geometric), and
+//   * every step was a chain of dependent global loads (text byte -> class row -> follow rows).
+// Here the lanes are persistent walkers: each loop iteration advances every live walk by one
+// byte, and a lane whose walk has ended takes the next hit of the region at once (wave-shared
+// cursor, ballot + mbcnt), so the lanes stay busy regardless of the length distribution.  The
+// automaton tables (a few KiB) are staged in LDS once per workgroup, and the next text byte is
+// loaded one step ahead.
+template <int NQ>
+__global__ __launch_bounds__(256) void verify_walkers(VerifyParams a, DevProgram P) {
+  extern __shared__ uint32_t tab[];
+  const int W = P.n_words, C = P.n_ctx, NP = P.n_pos > 0 ? P.n_pos : 1;
+  const int o_last = C * W, o_lin = 2 * C * W, o_rowof = o_lin + W, o_rows = o_rowof + NP, o_cls = o_rows + C * P.n_rows * W;
+  for (uint32_t i = threadIdx.x; i < P.table_words; i += blockDim.x) tab[i] = P.first[i];
+  __syncthreads();
+  const bool ctxed = C > 1;
+  const int lane = lane_id();
+  const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+  uint64_t lin[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    lin[q] = 2 * q < W ? tab[o_lin + 2 * q] : 0u;
+    if (2 * q + 1 < W) lin[q] |= static_cast<uint64_t>(tab[o_lin + 2 * q + 1]) << 32;
+  }
+  auto word2 = [&](int base, int q) -> uint64_t {  // 64-bit word q of a W-word LDS row
+    uint64_t v = 2 * q < W ? tab[base + 2 * q] : 0u;
+    if (2 * q + 1 < W) v |= static_cast<uint64_t>(tab[base + 2 * q + 1]) << 32;
+    return v;
+  };
+  for (uint64_t r = wave; r < a.n_regions; r += n_waves) {
+    const uint64_t lo = a.offsets[r];
+    const uint32_t cnt = static_cast<uint32_t>(a.offsets[r + 1] - lo);
+    const uint64_t* region = a.hits + r * a.region_cap;
+    uint32_t cursor = 0;  // wave-uniform: next hit of the region to hand out
+    // lane state
+    bool active = false, found = false;
+    uint32_t my_k = 0, prevb = 0, curb = 0;  // bytes at p-1 and p
+    uint64_t s = 0, p = 0, e = 0, S[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) S[q] = 0;
+    for (;;) {
+      // ---- refill: idle lanes take the next hits
+      const uint64_t idle = __ballot(!active);
+      if (idle != 0 && cursor < cnt) {
+        const uint32_t k = cursor + __popcll(idle & ((1ull << lane) - 1ull));
+        if (!active && k < cnt) {
+          my_k = k;
+          s = region[k];
+          active = true;
+          found = false;
+          e = 0;
+          p = s;
+          prevb = s > 0 && s <= a.n ? a.text[s - 1] : '\n';
+          curb = s < a.n ? a.text[s] : '\n';
+          int ctx = 0;
+          if (ctxed) {
+            if (s == 0 || rj_line_break(prevb)) ctx |= 1;
+            if (s == a.n || rj_line_break(curb)) ctx |= 2;
+          }
+          if ((P.nullable >> ctx) & 1u) {
+            found = true;
+            e = s;
+          }
+          const bool can_start = s < a.n && P.n_pos != 0;
+#pragma unroll
+          for (int q = 0; q < NQ; q++)
+            S[q] = can_start ? (word2(ctx * W, q) & word2(o_cls + static_cast<int>(curb) * W, q)) : 0;
+          // p -> s + 1, its byte one step ahead
+          p = s + 1;
+          prevb = curb;
+          curb = p < a.n ? a.text[p] : '\n';
+        }
+        cursor += __popcll(idle);
+        if (cursor > cnt) cursor = cnt;
+      }
+      if (__ballot(active) == 0) break;  // nothing live and (cursor >= cnt): region done
+      // ---- one step of every live walk
+      if (active) {
+        uint64_t alive = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) alive |= S[q];
+        bool done = alive == 0;
+        if (!done) {
+          int ctx = 0;
+          if (ctxed) {
+            if (rj_line_break(prevb)) ctx |= 1;  // p >= 1 here
+            if (p == a.n || rj_line_break(curb)) ctx |= 2;
+          }
+          uint64_t acc = 0;
+#pragma unroll
+          for (int q = 0; q < NQ; q++) acc |= S[q] & word2(o_last + ctx * W, q);
+          if (acc) {
+            found = true;
+            e = p;
+          }
+          if (p == a.n) {
+            done = true;
+          } else if (p - s >= kMaxSimSteps) {
+            a.counters[kCntOverrun] = 1;
+            done = true;
+          } else {
+            const uint32_t nextb = p + 1 < a.n ? a.text[p + 1] : '\n';  // issued before the table work
+            uint64_t T[NQ];
+            uint64_t carry = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+              const uint64_t x = S[q] & lin[q];
+              T[q] = (x << 1) | carry;
+              carry = x >> 63;
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+              uint64_t sp = S[q] & ~lin[q];
+              while (sp) {
+                const int b = __builtin_ctzll(sp);
+                sp &= sp - 1;
+                const int row = o_rows + (ctx * P.n_rows + static_cast<int>(tab[o_rowof + q * 64 + b])) * W;
+#pragma unroll
+                for (int j = 0; j < NQ; j++) T[j] |= word2(row, j);
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; q++) S[q] = T[q] & word2(o_cls + static_cast<int>(curb) * W, q);
+            p++;
+            prevb = curb;
+            curb = nextb;
+          }
+        }
+        if (done) {
+          a.cand_begin[lo + my_k] = s;
+          a.cand_end[lo + my_k] = found ? e : kNoMatch;
+          active = false;
+        }
+      }
+    }
+  }
+}
+
 template <int NR>
 __global__ __launch_bounds__(256) void verify_wave(VerifyParams a, DevProgram P) {
   const uint64_t n_slots = a.offsets[a.n_regions] * a.expand;
@@ -1186,6 +1327,230 @@ __global__ __launch_bounds__(256) void copy_long_gaps(const uint8_t* text, const
 }
 
 // ---------------------------------------------------------------------------------------
+// Dense mode, lane-sized automaton, everything in one kernel: find the candidate starts of a
+// 1-KiB chunk, walk them, keep only the starts at which something matched.
+//
+// The list-based dense pipeline (scan_dense -> region_offsets -> verify -> mark/scan/compact)
+// moves ~100 bytes of list traffic per candidate START; `[A-Z][a-z]+ [A-Z][a-z]+` over random
+// ASCII has a start at 35% of the bytes, so 1 GB of text cost 35 GB of traffic (13.6 ms) for
+// zero matches.  Here a start that does not match leaves no trace in HBM:
+//   1. each lane tests its 16 bytes (first-byte bitmap / nullable contexts) -> 16-bit mask;
+//      a wave scan ranks the chunk's candidates and their in-chunk offsets go to an LDS list;
+//   2. persistent walkers (see verify_walkers) run the automaton from every listed start and
+//      put the match length back into the candidate's LDS slot;
+//   3. the slots are compacted in order and the survivors appended to the wave's region as
+//      (begin -> region, end -> region_ends).
+// Downstream is the windows pipeline's offsets_gather_check.  Tables and the next text byte as
+// in verify_walkers.
+template <int NQ>
+__global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram P, uint64_t* region_ends,
+                                                       unsigned long long* counters) {
+  extern __shared__ uint32_t tab[];
+  const int W = P.n_words, C = P.n_ctx, NP = P.n_pos > 0 ? P.n_pos : 1;
+  const int o_last = C * W, o_lin = 2 * C * W, o_rowof = o_lin + W, o_rows = o_rowof + NP, o_cls = o_rows + C * P.n_rows * W;
+  for (uint32_t i = threadIdx.x; i < P.table_words; i += blockDim.x) tab[i] = P.first[i];
+  __syncthreads();
+  const bool ctxed = C > 1;
+  const int lane = lane_id();
+  // candidate slots of this wave: bits 0..9 offset inside the chunk, bits 10.. match length + 1
+  uint32_t* slot = tab + ((P.table_words + 3u) & ~3u) + (threadIdx.x >> 6) * kChunk;
+  const uint64_t wave = scalar_wave_index();
+  uint64_t* region = a.hits + wave * a.region_cap;
+  uint64_t* ends = region_ends + wave * a.region_cap;
+  uint32_t count = 0;  // survivors of this wave so far (wave-uniform)
+  const uint64_t first_chunk = a.sb / kChunk;
+  const uint64_t end_chunk = (a.se + kChunk - 1) / kChunk;  // se <= n + 1
+  const WaveSpan span = wave_span(a, wave, first_chunk, end_chunk);
+  uint64_t lin[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    lin[q] = 2 * q < W ? tab[o_lin + 2 * q] : 0u;
+    if (2 * q + 1 < W) lin[q] |= static_cast<uint64_t>(tab[o_lin + 2 * q + 1]) << 32;
+  }
+  auto word2 = [&](int base, int q) -> uint64_t {  // 64-bit word q of a W-word LDS row
+    uint64_t v = 2 * q < W ? tab[base + 2 * q] : 0u;
+    if (2 * q + 1 < W) v |= static_cast<uint64_t>(tab[base + 2 * q + 1]) << 32;
+    return v;
+  };
+  uint32_t fb[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) fb[k] = P.first_bytes[k];
+
+  for (uint64_t c = span.c0; c < span.c1; c++) {
+    const uint64_t base = c * kChunk;
+    const uint64_t at = base + static_cast<uint64_t>(lane) * 16;
+    // ---- 1. candidate mask of the lane's 16 positions
+    uint32_t d[6];
+    if (base + kChunk <= a.n) {
+      const uint4 v = *reinterpret_cast<const uint4*>(a.text + at);
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    } else {
+      load_guarded(a.text, a.n, at, d);
+    }
+    uint32_t prev = '\n';  // byte before the lane's first byte ('\n' stands for "start of text")
+    if (ctxed && P.nullable && at > 0 && at <= a.n) prev = a.text[at - 1];
+    uint32_t cand = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint32_t cur = (d[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+      const uint64_t s = at + j;
+      bool ok = false;
+      if (s < a.n) ok = (fb[cur >> 5] >> (cur & 31)) & 1u;
+      if (P.nullable && s <= a.n) {
+        int ctx = 0;
+        if (ctxed) {
+          if (s == 0 || rj_line_break(prev)) ctx |= 1;
+          if (s == a.n || rj_line_break(cur)) ctx |= 2;
+        }
+        ok = ok || ((P.nullable >> ctx) & 1u);
+      }
+      ok = ok && s >= a.sb && s < a.se;
+      cand |= static_cast<uint32_t>(ok) << j;
+      prev = cur;
+    }
+    if (__ballot(cand != 0) == 0) continue;
+    const uint32_t mine = __popc(cand);
+    uint32_t inc = mine;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const uint32_t v = __shfl_up(inc, o);
+      if (lane >= o) inc += v;
+    }
+    const uint32_t total = __shfl(inc, kWave - 1);
+    {
+      uint32_t idx = inc - mine, m = cand;
+      while (m) {
+        const int j = __ffs(static_cast<int>(m)) - 1;
+        m &= m - 1;
+        slot[idx++] = static_cast<uint32_t>(lane * 16 + j);
+      }
+    }
+    // ---- 2. persistent walkers over slot[0 .. total)
+    {
+      uint32_t cursor = 0;
+      bool active = false, found = false;
+      uint32_t my_k = 0, prevb = 0, curb = 0;
+      uint64_t s = 0, p = 0, e = 0, S[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; q++) S[q] = 0;
+      for (;;) {
+        const uint64_t idle = __ballot(!active);
+        if (idle != 0 && cursor < total) {
+          const uint32_t k = cursor + __popcll(idle & ((1ull << lane) - 1ull));
+          if (!active && k < total) {
+            my_k = k;
+            s = base + slot[k];
+            active = true;
+            found = false;
+            e = 0;
+            prevb = s > 0 && s <= a.n ? a.text[s - 1] : '\n';
+            curb = s < a.n ? a.text[s] : '\n';
+            int ctx = 0;
+            if (ctxed) {
+              if (s == 0 || rj_line_break(prevb)) ctx |= 1;
+              if (s == a.n || rj_line_break(curb)) ctx |= 2;
+            }
+            if ((P.nullable >> ctx) & 1u) {
+              found = true;
+              e = s;
+            }
+            const bool can_start = s < a.n && P.n_pos != 0;
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+              S[q] = can_start ? (word2(ctx * W, q) & word2(o_cls + static_cast<int>(curb) * W, q)) : 0;
+            p = s + 1;
+            prevb = curb;
+            curb = p < a.n ? a.text[p] : '\n';
+          }
+          cursor += __popcll(idle);
+          if (cursor > total) cursor = total;
+        }
+        if (__ballot(active) == 0) break;
+        if (active) {
+          uint64_t alive = 0;
+#pragma unroll
+          for (int q = 0; q < NQ; q++) alive |= S[q];
+          bool done = alive == 0;
+          if (!done) {
+            int ctx = 0;
+            if (ctxed) {
+              if (rj_line_break(prevb)) ctx |= 1;
+              if (p == a.n || rj_line_break(curb)) ctx |= 2;
+            }
+            uint64_t acc = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) acc |= S[q] & word2(o_last + ctx * W, q);
+            if (acc) {
+              found = true;
+              e = p;
+            }
+            if (p == a.n) {
+              done = true;
+            } else if (p - s >= kMaxSimSteps) {
+              counters[kCntOverrun] = 1;
+              done = true;
+            } else {
+              const uint32_t nextb = p + 1 < a.n ? a.text[p + 1] : '\n';
+              uint64_t T[NQ];
+              uint64_t carry = 0;
+#pragma unroll
+              for (int q = 0; q < NQ; q++) {
+                const uint64_t x = S[q] & lin[q];
+                T[q] = (x << 1) | carry;
+                carry = x >> 63;
+              }
+#pragma unroll
+              for (int q = 0; q < NQ; q++) {
+                uint64_t sp = S[q] & ~lin[q];
+                while (sp) {
+                  const int b = __builtin_ctzll(sp);
+                  sp &= sp - 1;
+                  const int row = o_rows + (ctx * P.n_rows + static_cast<int>(tab[o_rowof + q * 64 + b])) * W;
+#pragma unroll
+                  for (int j = 0; j < NQ; j++) T[j] |= word2(row, j);
+                }
+              }
+#pragma unroll
+              for (int q = 0; q < NQ; q++) S[q] = T[q] & word2(o_cls + static_cast<int>(curb) * W, q);
+              p++;
+              prevb = curb;
+              curb = nextb;
+            }
+          }
+          if (done) {
+            // length + 1 in bits 10..31 (a walk is cut at kMaxSimSteps = 2^20 bytes), 0 = no match
+            const uint32_t off = static_cast<uint32_t>(s - base);
+            slot[my_k] = off | (found ? static_cast<uint32_t>(e - s + 1) << 10 : 0u);
+            active = false;
+          }
+        }
+      }
+    }
+    // ---- 3. ordered compaction into the region
+    for (uint32_t kb = 0; kb < total; kb += kWave) {
+      const uint32_t k = kb + lane;
+      const uint32_t v = k < total ? slot[k] : 0u;
+      const bool keep = (v >> 10) != 0;
+      const uint64_t kept = __ballot(keep);
+      const uint32_t pos = count + __popcll(kept & ((1ull << lane) - 1ull));
+      if (keep && pos < a.region_cap) {
+        const uint64_t s = base + (v & 1023u);
+        region[pos] = s;
+        ends[pos] = s + (v >> 10) - 1;
+      }
+      count += __popcll(kept);
+    }
+  }
+  if (lane == 0) {
+    if (count > a.region_cap) {  // the host grows the regions and runs again
+      counters[kCntOverflow] = 1;
+      atomicMax(&counters[kCntMaxRegion], static_cast<unsigned long long>(count));
+    }
+    a.hit_counts[wave] = count < a.region_cap ? count : a.region_cap;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Launchers (host side of the <<< >>> syntax lives here so engine.cc stays plain C++).
 ScanGeometry scan_geometry(uint64_t chunks) {
   // Measured on MI355X (tools/ab_probe.py): a grid of exactly the resident workgroups loses
@@ -1242,6 +1607,17 @@ void launch_scan_dense(const ScanParams& a, const DevProgram& P, int grid, hipEv
   hipExtLaunchKernelGGL(scan_dense, dim3(grid), dim3(256), 0, st, t0, t1, 0, a, P);
 }
 
+bool dense_walk_fits(const DevProgram& P) { return P.n_words <= 4 && P.table_words <= 8192; }
+
+void launch_scan_dense_walk(const ScanParams& a, const DevProgram& P, int grid, uint64_t* region_ends,
+                            unsigned long long* counters, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+  const size_t lds = (((static_cast<size_t>(P.table_words) + 3) & ~size_t{3}) + 4 * kChunk) * sizeof(uint32_t);
+  if (P.n_words <= 2)
+    hipExtLaunchKernelGGL((scan_dense_walk<1>), dim3(grid), dim3(256), lds, st, t0, t1, 0, a, P, region_ends, counters);
+  else
+    hipExtLaunchKernelGGL((scan_dense_walk<2>), dim3(grid), dim3(256), lds, st, t0, t1, 0, a, P, region_ends, counters);
+}
+
 void launch_region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap, uint64_t* offsets,
                            unsigned long long* counters, hipStream_t st) {
   // n_regions <= 64 Ki (scan_geometry caps the grid at 16 Ki workgroups of 4 waves)
@@ -1256,6 +1632,13 @@ void launch_verify(const VerifyParams& a, const DevProgram& P, uint64_t expected
     uint64_t blocks = (static_cast<uint64_t>(a.n_regions) + 3) / 4;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
+    static const bool no_walkers = getenv("RJ_NO_WALKERS") != nullptr;  // measurement override
+    if (P.table_words <= 12288 && !no_walkers) {  // tables fit 48 KiB of LDS: persistent walkers
+      const size_t lds = static_cast<size_t>(P.table_words) * sizeof(uint32_t);
+      if (W <= 2) hipLaunchKernelGGL((verify_walkers<1>), dim3(static_cast<unsigned>(blocks)), dim3(256), lds, st, a, P);
+      else hipLaunchKernelGGL((verify_walkers<2>), dim3(static_cast<unsigned>(blocks)), dim3(256), lds, st, a, P);
+      return;
+    }
     if (W <= 2) hipLaunchKernelGGL((verify_lane_regions<1>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, a, P);
     else hipLaunchKernelGGL((verify_lane_regions<2>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, a, P);
     return;
