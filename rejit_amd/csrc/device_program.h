@@ -46,6 +46,11 @@ struct DevProgram {
   const uint32_t* rows;
   const uint32_t* cls;
   uint32_t table_words;  // the tables are one contiguous blob of this many words starting at `first`
+  // lane-sized automata (n_words <= 4) only: non-linear positions whose follow set is, in every
+  // context, exactly {i, i+1} (x+ / x*) or {i+1, i+2} (the position before an optional one);
+  // the dense walker steps them with shifts instead of fetching their rows
+  uint32_t loop_mask[4];
+  uint32_t skip_mask[4];
 };
 
 // The NFA graph for the exact sequential kernel (reference ring semantics).

@@ -1342,15 +1342,18 @@ __global__ __launch_bounds__(256) void copy_long_gaps(const uint8_t* text, const
 //      (begin -> region, end -> region_ends).
 // Downstream is the windows pipeline's offsets_gather_check.  Tables and the next text byte as
 // in verify_walkers.
-template <int NQ>
+// NW = 32-bit words of automaton state per lane (1, 2 or 4); CTX = the pattern has ^ / $.
+// Positions inside the kernel are 32-bit offsets from the chunk base.
+template <int NW, bool CTX>
 __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram P, uint64_t* region_ends,
                                                        unsigned long long* counters) {
   extern __shared__ uint32_t tab[];
+  __shared__ uint32_t fb[8];  // first-byte bitmap (indexed by data: LDS, not registers)
+  if (threadIdx.x < 8) fb[threadIdx.x] = P.first_bytes[threadIdx.x];
   const int W = P.n_words, C = P.n_ctx, NP = P.n_pos > 0 ? P.n_pos : 1;
   const int o_last = C * W, o_lin = 2 * C * W, o_rowof = o_lin + W, o_rows = o_rowof + NP, o_cls = o_rows + C * P.n_rows * W;
   for (uint32_t i = threadIdx.x; i < P.table_words; i += blockDim.x) tab[i] = P.first[i];
   __syncthreads();
-  const bool ctxed = C > 1;
   const int lane = lane_id();
   // candidate slots of this wave: bits 0..9 offset inside the chunk, bits 10.. match length + 1
   uint32_t* slot = tab + ((P.table_words + 3u) & ~3u) + (threadIdx.x >> 6) * kChunk;
@@ -1361,24 +1364,25 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
   const uint64_t first_chunk = a.sb / kChunk;
   const uint64_t end_chunk = (a.se + kChunk - 1) / kChunk;  // se <= n + 1
   const WaveSpan span = wave_span(a, wave, first_chunk, end_chunk);
-  uint64_t lin[NQ];
+  // per-word constants: linear / loop / skip masks; first and last rows of context 0 (all there is
+  // without assertions)
+  uint32_t step1[NW], loopm[NW], skipm[NW], first0[NW], last0[NW];
 #pragma unroll
-  for (int q = 0; q < NQ; q++) {
-    lin[q] = 2 * q < W ? tab[o_lin + 2 * q] : 0u;
-    if (2 * q + 1 < W) lin[q] |= static_cast<uint64_t>(tab[o_lin + 2 * q + 1]) << 32;
+  for (int q = 0; q < NW; q++) {
+    const bool in = q < W;
+    loopm[q] = in ? P.loop_mask[q] : 0u;
+    skipm[q] = in ? P.skip_mask[q] : 0u;
+    step1[q] = (in ? tab[o_lin + q] : 0u) | loopm[q] | skipm[q];  // positions that pass to i + 1
+    first0[q] = in ? tab[q] : 0u;
+    last0[q] = in ? tab[o_last + q] : 0u;
   }
-  auto word2 = [&](int base, int q) -> uint64_t {  // 64-bit word q of a W-word LDS row
-    uint64_t v = 2 * q < W ? tab[base + 2 * q] : 0u;
-    if (2 * q + 1 < W) v |= static_cast<uint64_t>(tab[base + 2 * q + 1]) << 32;
-    return v;
-  };
-  uint32_t fb[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) fb[k] = P.first_bytes[k];
 
   for (uint64_t c = span.c0; c < span.c1; c++) {
     const uint64_t base = c * kChunk;
     const uint64_t at = base + static_cast<uint64_t>(lane) * 16;
+    const uint8_t* tbase = a.text + base;
+    // text length as seen from the chunk (a walk is cut at 2^20 bytes, so clamping is exact)
+    const uint32_t n_rel = a.n - base < 0x7FFFFFFFull ? static_cast<uint32_t>(a.n - base) : 0x7FFFFFFFu;
     // ---- 1. candidate mask of the lane's 16 positions
     uint32_t d[6];
     if (base + kChunk <= a.n) {
@@ -1387,26 +1391,39 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
     } else {
       load_guarded(a.text, a.n, at, d);
     }
-    uint32_t prev = '\n';  // byte before the lane's first byte ('\n' stands for "start of text")
-    if (ctxed && P.nullable && at > 0 && at <= a.n) prev = a.text[at - 1];
     uint32_t cand = 0;
+    if (P.nullable == 0) {
+      // (the common case) a start needs a first byte: 16 bitmap lookups, then the range as a mask
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const uint32_t cur = (d[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-      const uint64_t s = at + j;
-      bool ok = false;
-      if (s < a.n) ok = (fb[cur >> 5] >> (cur & 31)) & 1u;
-      if (P.nullable && s <= a.n) {
-        int ctx = 0;
-        if (ctxed) {
-          if (s == 0 || rj_line_break(prev)) ctx |= 1;
-          if (s == a.n || rj_line_break(cur)) ctx |= 2;
-        }
-        ok = ok || ((P.nullable >> ctx) & 1u);
+      for (int j = 0; j < 16; j++) {
+        const uint32_t cur = (d[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        cand |= ((fb[cur >> 5] >> (cur & 31)) & 1u) << j;
       }
-      ok = ok && s >= a.sb && s < a.se;
-      cand |= static_cast<uint32_t>(ok) << j;
-      prev = cur;
+      const uint64_t lim = a.se < a.n ? a.se : a.n;  // starts s with sb <= s < min(se, n)
+      const uint32_t hi = lim > at ? (lim - at < 16 ? static_cast<uint32_t>(lim - at) : 16u) : 0u;
+      const uint32_t lo = a.sb > at ? (a.sb - at < 16 ? static_cast<uint32_t>(a.sb - at) : 16u) : 0u;
+      cand &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+    } else {
+      uint32_t prev = '\n';  // byte before the lane's first byte ('\n' stands for "start of text")
+      if (CTX && at > 0 && at <= a.n) prev = a.text[at - 1];
+#pragma unroll 1
+      for (int j = 0; j < 16; j++) {
+        const uint32_t cur = (d[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        const uint64_t s = at + j;
+        bool ok = false;
+        if (s < a.n) ok = (fb[cur >> 5] >> (cur & 31)) & 1u;
+        if (s <= a.n) {
+          int ctx = 0;
+          if (CTX) {
+            if (s == 0 || rj_line_break(prev)) ctx |= 1;
+            if (s == a.n || rj_line_break(cur)) ctx |= 2;
+          }
+          ok = ok || ((P.nullable >> ctx) & 1u);
+        }
+        ok = ok && s >= a.sb && s < a.se;
+        cand |= static_cast<uint32_t>(ok) << j;
+        prev = cur;
+      }
     }
     if (__ballot(cand != 0) == 0) continue;
     const uint32_t mine = __popc(cand);
@@ -1430,88 +1447,94 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
       uint32_t cursor = 0;
       bool active = false, found = false;
       uint32_t my_k = 0, prevb = 0, curb = 0;
-      uint64_t s = 0, p = 0, e = 0, S[NQ];
+      uint32_t s = 0, p = 0, e = 0, S[NW];  // offsets from the chunk base
 #pragma unroll
-      for (int q = 0; q < NQ; q++) S[q] = 0;
+      for (int q = 0; q < NW; q++) S[q] = 0;
       for (;;) {
         const uint64_t idle = __ballot(!active);
         if (idle != 0 && cursor < total) {
           const uint32_t k = cursor + __popcll(idle & ((1ull << lane) - 1ull));
           if (!active && k < total) {
             my_k = k;
-            s = base + slot[k];
+            s = slot[k];
             active = true;
             found = false;
             e = 0;
-            prevb = s > 0 && s <= a.n ? a.text[s - 1] : '\n';
-            curb = s < a.n ? a.text[s] : '\n';
+            curb = s < n_rel ? tbase[s] : '\n';
             int ctx = 0;
-            if (ctxed) {
-              if (s == 0 || rj_line_break(prevb)) ctx |= 1;
-              if (s == a.n || rj_line_break(curb)) ctx |= 2;
+            if (CTX) {
+              prevb = (base + s) > 0 ? *(tbase + s - 1) : '\n';  // s <= n here
+              if (base + s == 0 || rj_line_break(prevb)) ctx |= 1;
+              if (s == n_rel || rj_line_break(curb)) ctx |= 2;
             }
             if ((P.nullable >> ctx) & 1u) {
               found = true;
               e = s;
             }
-            const bool can_start = s < a.n && P.n_pos != 0;
+            const bool can_start = s < n_rel && P.n_pos != 0;
+            const int crow = o_cls + static_cast<int>(curb) * W;
 #pragma unroll
-            for (int q = 0; q < NQ; q++)
-              S[q] = can_start ? (word2(ctx * W, q) & word2(o_cls + static_cast<int>(curb) * W, q)) : 0;
+            for (int q = 0; q < NW; q++) {
+              const uint32_t f = CTX ? (q < W ? tab[ctx * W + q] : 0u) : first0[q];
+              S[q] = can_start && q < W ? (f & tab[crow + q]) : 0u;
+            }
             p = s + 1;
             prevb = curb;
-            curb = p < a.n ? a.text[p] : '\n';
+            curb = p < n_rel ? tbase[p] : '\n';
           }
           cursor += __popcll(idle);
           if (cursor > total) cursor = total;
         }
         if (__ballot(active) == 0) break;
         if (active) {
-          uint64_t alive = 0;
+          uint32_t alive = 0;
 #pragma unroll
-          for (int q = 0; q < NQ; q++) alive |= S[q];
+          for (int q = 0; q < NW; q++) alive |= S[q];
           bool done = alive == 0;
           if (!done) {
             int ctx = 0;
-            if (ctxed) {
-              if (rj_line_break(prevb)) ctx |= 1;
-              if (p == a.n || rj_line_break(curb)) ctx |= 2;
+            if (CTX) {
+              if (rj_line_break(prevb)) ctx |= 1;  // p >= 1 here
+              if (p == n_rel || rj_line_break(curb)) ctx |= 2;
             }
-            uint64_t acc = 0;
+            uint32_t acc = 0;
 #pragma unroll
-            for (int q = 0; q < NQ; q++) acc |= S[q] & word2(o_last + ctx * W, q);
+            for (int q = 0; q < NW; q++) acc |= S[q] & (CTX ? (q < W ? tab[o_last + ctx * W + q] : 0u) : last0[q]);
             if (acc) {
               found = true;
               e = p;
             }
-            if (p == a.n) {
+            if (p == n_rel) {
               done = true;
             } else if (p - s >= kMaxSimSteps) {
               counters[kCntOverrun] = 1;
               done = true;
             } else {
-              const uint32_t nextb = p + 1 < a.n ? a.text[p + 1] : '\n';
-              uint64_t T[NQ];
-              uint64_t carry = 0;
+              const uint32_t nextb = p + 1 < n_rel ? tbase[p + 1] : '\n';  // issued before the table work
+              uint32_t T[NW];
+              uint32_t c1 = 0, c2 = 0;
 #pragma unroll
-              for (int q = 0; q < NQ; q++) {
-                const uint64_t x = S[q] & lin[q];
-                T[q] = (x << 1) | carry;
-                carry = x >> 63;
+              for (int q = 0; q < NW; q++) {
+                const uint32_t x = S[q] & step1[q], y = S[q] & skipm[q];
+                T[q] = (x << 1) | c1 | (y << 2) | c2 | (S[q] & loopm[q]);
+                c1 = x >> 31;
+                c2 = y >> 30;
               }
 #pragma unroll
-              for (int q = 0; q < NQ; q++) {
-                uint64_t sp = S[q] & ~lin[q];
+              for (int q = 0; q < NW; q++) {
+                uint32_t sp = S[q] & ~step1[q];  // positions with a general follow set: OR their rows in
                 while (sp) {
-                  const int b = __builtin_ctzll(sp);
+                  const int b = __ffs(static_cast<int>(sp)) - 1;
                   sp &= sp - 1;
-                  const int row = o_rows + (ctx * P.n_rows + static_cast<int>(tab[o_rowof + q * 64 + b])) * W;
+                  const int row = o_rows + (ctx * P.n_rows + static_cast<int>(tab[o_rowof + q * 32 + b])) * W;
 #pragma unroll
-                  for (int j = 0; j < NQ; j++) T[j] |= word2(row, j);
+                  for (int j = 0; j < NW; j++)
+                    if (j < W) T[j] |= tab[row + j];
                 }
               }
+              const int crow = o_cls + static_cast<int>(curb) * W;
 #pragma unroll
-              for (int q = 0; q < NQ; q++) S[q] = T[q] & word2(o_cls + static_cast<int>(curb) * W, q);
+              for (int q = 0; q < NW; q++) S[q] = q < W ? (T[q] & tab[crow + q]) : 0u;
               p++;
               prevb = curb;
               curb = nextb;
@@ -1519,8 +1542,7 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
           }
           if (done) {
             // length + 1 in bits 10..31 (a walk is cut at kMaxSimSteps = 2^20 bytes), 0 = no match
-            const uint32_t off = static_cast<uint32_t>(s - base);
-            slot[my_k] = off | (found ? static_cast<uint32_t>(e - s + 1) << 10 : 0u);
+            slot[my_k] = s | (found ? (e - s + 1) << 10 : 0u);
             active = false;
           }
         }
@@ -1612,10 +1634,18 @@ bool dense_walk_fits(const DevProgram& P) { return P.n_words <= 4 && P.table_wor
 void launch_scan_dense_walk(const ScanParams& a, const DevProgram& P, int grid, uint64_t* region_ends,
                             unsigned long long* counters, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
   const size_t lds = (((static_cast<size_t>(P.table_words) + 3) & ~size_t{3}) + 4 * kChunk) * sizeof(uint32_t);
-  if (P.n_words <= 2)
-    hipExtLaunchKernelGGL((scan_dense_walk<1>), dim3(grid), dim3(256), lds, st, t0, t1, 0, a, P, region_ends, counters);
-  else
-    hipExtLaunchKernelGGL((scan_dense_walk<2>), dim3(grid), dim3(256), lds, st, t0, t1, 0, a, P, region_ends, counters);
+  const dim3 g(grid), b(256);
+  const bool ctx = P.n_ctx > 1;
+  if (P.n_words <= 1) {
+    if (ctx) hipExtLaunchKernelGGL((scan_dense_walk<1, true>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
+    else hipExtLaunchKernelGGL((scan_dense_walk<1, false>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
+  } else if (P.n_words == 2) {
+    if (ctx) hipExtLaunchKernelGGL((scan_dense_walk<2, true>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
+    else hipExtLaunchKernelGGL((scan_dense_walk<2, false>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
+  } else {
+    if (ctx) hipExtLaunchKernelGGL((scan_dense_walk<4, true>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
+    else hipExtLaunchKernelGGL((scan_dense_walk<4, false>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
+  }
 }
 
 void launch_region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap, uint64_t* offsets,
