@@ -1344,6 +1344,9 @@ __global__ __launch_bounds__(256) void copy_long_gaps(const uint8_t* text, const
 // in verify_walkers.
 // NW = 32-bit words of automaton state per lane (1, 2 or 4); CTX = the pattern has ^ / $.
 // Positions inside the kernel are 32-bit offsets from the chunk base.
+constexpr int kHalo = 64;                    // bytes after the chunk kept in LDS for the walkers
+constexpr int kTextWindow = kChunk + kHalo;  // per wave
+
 template <int NW, bool CTX>
 __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram P, uint64_t* region_ends,
                                                        unsigned long long* counters) {
@@ -1357,6 +1360,10 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
   const int lane = lane_id();
   // candidate slots of this wave: bits 0..9 offset inside the chunk, bits 10.. match length + 1
   uint32_t* slot = tab + ((P.table_words + 3u) & ~3u) + (threadIdx.x >> 6) * kChunk;
+  // the chunk's text for the walkers (+ kHalo bytes after it): a global byte load per step made
+  // every step wait a full memory latency -- the one-ahead prefetch cannot be waited for
+  // separately (vmcnt counts in order) -- and the kernel was bound by exactly that
+  uint8_t* txt = reinterpret_cast<uint8_t*>(tab + ((P.table_words + 3u) & ~3u) + 4 * kChunk) + (threadIdx.x >> 6) * kTextWindow;
   const uint64_t wave = scalar_wave_index();
   uint64_t* region = a.hits + wave * a.region_cap;
   uint64_t* ends = region_ends + wave * a.region_cap;
@@ -1426,6 +1433,21 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
       }
     }
     if (__ballot(cand != 0) == 0) continue;
+    *reinterpret_cast<uint4*>(txt + lane * 16) = make_uint4(d[0], d[1], d[2], d[3]);
+    if (lane < kHalo / 4) {
+      const uint64_t hp = base + kChunk + 4 * lane;
+      uint32_t hv = 0;
+      if (hp + 4 <= a.n) {
+        hv = *reinterpret_cast<const uint32_t*>(a.text + hp);
+      } else {
+        for (int q = 0; q < 4; q++)
+          if (hp + q < a.n) hv |= static_cast<uint32_t>(a.text[hp + q]) << (8 * q);
+      }
+      *reinterpret_cast<uint32_t*>(txt + kChunk + 4 * lane) = hv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // byte at chunk offset x < n_rel
+    auto tb = [&](uint32_t x) -> uint32_t { return x < kChunk + kHalo ? txt[x] : tbase[x]; };
     const uint32_t mine = __popc(cand);
     uint32_t inc = mine;
 #pragma unroll
@@ -1460,7 +1482,7 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
             active = true;
             found = false;
             e = 0;
-            curb = s < n_rel ? tbase[s] : '\n';
+            curb = s < n_rel ? tb(s) : '\n';
             int ctx = 0;
             if (CTX) {
               prevb = (base + s) > 0 ? *(tbase + s - 1) : '\n';  // s <= n here
@@ -1480,7 +1502,7 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
             }
             p = s + 1;
             prevb = curb;
-            curb = p < n_rel ? tbase[p] : '\n';
+            curb = p < n_rel ? tb(p) : '\n';
           }
           cursor += __popcll(idle);
           if (cursor > total) cursor = total;
@@ -1510,7 +1532,7 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
               counters[kCntOverrun] = 1;
               done = true;
             } else {
-              const uint32_t nextb = p + 1 < n_rel ? tbase[p + 1] : '\n';  // issued before the table work
+              const uint32_t nextb = p + 1 < n_rel ? tb(p + 1) : '\n';
               uint32_t T[NW];
               uint32_t c1 = 0, c2 = 0;
 #pragma unroll
@@ -1633,7 +1655,7 @@ bool dense_walk_fits(const DevProgram& P) { return P.n_words <= 4 && P.table_wor
 
 void launch_scan_dense_walk(const ScanParams& a, const DevProgram& P, int grid, uint64_t* region_ends,
                             unsigned long long* counters, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
-  const size_t lds = (((static_cast<size_t>(P.table_words) + 3) & ~size_t{3}) + 4 * kChunk) * sizeof(uint32_t);
+  const size_t lds = (((static_cast<size_t>(P.table_words) + 3) & ~size_t{3}) + 4 * kChunk) * sizeof(uint32_t) + 4 * kTextWindow;
   const dim3 g(grid), b(256);
   const bool ctx = P.n_ctx > 1;
   if (P.n_words <= 1) {
