@@ -1399,8 +1399,56 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
       load_guarded(a.text, a.n, at, d);
     }
     uint32_t cand = 0;
-    if (P.nullable == 0) {
-      // (the common case) a start needs a first byte: 16 bitmap lookups, then the range as a mask
+    uint32_t fin = 0, flen = 0;  // starts already decided by the pre-steps, 2 bits of length each
+    if (NW == 1 && !CTX && P.nullable == 0 && base + kChunk + 4 <= a.n) {
+      // Pre-steps: the first kPre automaton steps of ALL 16 starts of the lane, in registers, with
+      // no divergence.  Most starts die within a few bytes (a walk on random text is ~1.5 steps
+      // long), and those never reach the walkers: a start that is dead after kPre + 1 bytes is
+      // decided here (its longest match, if any, has length <= kPre).  Positions with a general
+      // follow row are not stepped here: a state that holds one keeps the start for the walkers.
+      constexpr int kPre = 2;
+      uint32_t r[16 + kPre];  // class rows of the lane's bytes and of the kPre bytes after them
+      const uint32_t nx = __shfl_down(d[0], 1);
+#pragma unroll
+      for (int k = 0; k < 16 + kPre; k++) {
+        const uint32_t byte = ((k < 16 ? d[k >> 2] : nx) >> (8 * (k & 3))) & 0xFFu;
+        r[k] = tab[o_cls + byte];
+      }
+      // (all flags as 0/1 integers: comparisons would go through the scalar unit)
+      auto nz = [](uint32_t x) -> uint32_t { return x < 1u ? x : 1u; };
+      uint32_t walk = 0;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        uint32_t S = first0[0] & r[j];
+        uint32_t f = 0, gen = 0;
+#pragma unroll
+        for (int t = 1; t <= kPre; t++) {
+          const uint32_t hit = nz(S & last0[0]);
+          f = hit * t > f ? hit * t : f;
+          gen |= S & ~step1[0];
+          S = ((((S & step1[0]) << 1) | ((S & skipm[0]) << 2) | (S & loopm[0]))) & r[j + t];
+        }
+        const uint32_t alive = nz(S | gen);  // alive or decided, a start has a first byte
+        walk |= alive << j;
+        fin |= (nz(f) & (alive ^ 1u)) << j;
+        flen |= f << (2 * j);
+      }
+      if (lane == kWave - 1) {  // no neighbour: the rows past the lane's bytes are not valid
+        constexpr uint32_t tail = ((1u << kPre) - 1u) << (16 - kPre);
+        uint32_t starts = 0;
+#pragma unroll
+        for (int j = 16 - kPre; j < 16; j++) starts |= static_cast<uint32_t>((first0[0] & r[j]) != 0) << j;
+        walk = (walk & ~tail) | starts;
+        fin &= ~tail;
+      }
+      const uint64_t lim = a.se < a.n ? a.se : a.n;
+      const uint32_t hi = lim > at ? (lim - at < 16 ? static_cast<uint32_t>(lim - at) : 16u) : 0u;
+      const uint32_t lo = a.sb > at ? (a.sb - at < 16 ? static_cast<uint32_t>(a.sb - at) : 16u) : 0u;
+      const uint32_t range = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+      fin &= range;
+      cand = (walk & range) | fin;
+    } else if (P.nullable == 0) {
+      // a start needs a first byte: 16 bitmap lookups, then the range as a mask
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const uint32_t cur = (d[j >> 2] >> (8 * (j & 3))) & 0xFFu;
@@ -1461,7 +1509,9 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
       while (m) {
         const int j = __ffs(static_cast<int>(m)) - 1;
         m &= m - 1;
-        slot[idx++] = static_cast<uint32_t>(lane * 16 + j);
+        // decided starts carry their length already (bits 10..: length + 1), the others go to the walkers
+        const uint32_t len1 = (fin >> j) & 1u ? ((flen >> (2 * j)) & 3u) + 1u : 0u;
+        slot[idx++] = static_cast<uint32_t>(lane * 16 + j) | (len1 << 10);
       }
     }
     // ---- 2. persistent walkers over slot[0 .. total)
@@ -1476,9 +1526,10 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
         const uint64_t idle = __ballot(!active);
         if (idle != 0 && cursor < total) {
           const uint32_t k = cursor + __popcll(idle & ((1ull << lane) - 1ull));
-          if (!active && k < total) {
+          const uint32_t entry = !active && k < total ? slot[k] : 1u << 10;
+          if ((entry >> 10) == 0) {  // (an entry decided by the pre-steps is left as it is)
             my_k = k;
-            s = slot[k];
+            s = entry;
             active = true;
             found = false;
             e = 0;
