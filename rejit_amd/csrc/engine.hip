@@ -236,6 +236,13 @@ int upload_program(rj_program* rp) {
       }
     rp->window_nibbles = ok && getenv("RJ_NO_NIBBLE") == nullptr;
   }
+  // One-byte windows with three or more alternatives hit several percent of the positions of
+  // ordinary text: that is dense work, and the fused dense kernel (candidates walked in place, no
+  // hit lists) serves it better than window hits + verify.  ([a-f]+[0-9] over random ASCII:
+  // 12M hits/GB, 4.4 ms as windows.)
+  if (D.mode == 1 && !P.floating && D.win_len == 1 && D.n_windows >= 3 && dense_walk_fits(D) &&
+      getenv("RJ_NO_DENSE_WALK") == nullptr)
+    D.mode = 0;
   D.float_range = P.floating ? P.float_max - P.float_min + 1 : 1;
   D.float_max = P.floating ? P.float_max : 0;
   for (int k = 0; k < 8; k++) D.first_bytes[k] = P.first_bytes.w[k];
@@ -607,26 +614,26 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
       // (letting the last workgroup publish the counters to pinned host memory instead of the copy
       // below was measured: slower, its agent-scope fence writes L2 back)
       s->host_counters[kCntUnordered] = 0;  // the kernel below writes the pinned block itself
+      s->host_counters[kCntAdjacent] = 0;
       launch_offsets_gather_check(survivors, s->hits.as<uint64_t>(), s->cand_end.as<uint64_t>(), geo.n_regions,
                                   static_cast<uint32_t>(region_cap), fp.carry_cur, s->out.as<uint64_t>(), s->out_cap,
-                                  s->counters.as<unsigned long long>(), fp.detect_adjacent ? nullptr : s->host_counters, st);
-      const uint64_t n_guess = std::max<uint64_t>(s->hits_hint, 1u << 12);
-      if (fp.detect_adjacent) {
-        // (the selection kernels work on begin[] / end[]; sized for every slot as the count is not known yet)
-        RJ_HIP(s->keys_out.reserve(slots * sizeof(uint64_t)));
-        RJ_HIP(s->vals_out.reserve(slots * sizeof(uint64_t)));
-        launch_split_pairs(s->out.as<uint64_t>(), s->counters.as<unsigned long long>() + kCntCands, n_guess,
-                           s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), st);
-        launch_detect_adjacent(s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), n_guess, s->counters.as<unsigned long long>(), st);
-        RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-      }
+                                  s->counters.as<unsigned long long>(), s->host_counters, st);
       RJ_HIP(hipStreamSynchronize(st));
       RJ_HIP(hipGetLastError());
-      if (!fp.detect_adjacent && s->host_counters[kCntUnordered] != 0 && s->host_counters[kCntOverflow] == 0) {
-        RJ_HIP(s->keys_out.reserve(s->host_counters[kCntCands] * sizeof(uint64_t)));
-        RJ_HIP(s->vals_out.reserve(s->host_counters[kCntCands] * sizeof(uint64_t)));
-        launch_split_pairs(s->out.as<uint64_t>(), s->counters.as<unsigned long long>() + kCntCands, s->host_counters[kCntCands],
+      if (s->host_counters[kCntUnordered] != 0 && s->host_counters[kCntOverflow] == 0) {
+        // not the result yet: the selection kernels work on begin[] / end[]
+        const uint64_t nc = s->host_counters[kCntCands];
+        RJ_HIP(s->keys_out.reserve(nc * sizeof(uint64_t)));
+        RJ_HIP(s->vals_out.reserve(nc * sizeof(uint64_t)));
+        launch_split_pairs(s->out.as<uint64_t>(), s->counters.as<unsigned long long>() + kCntCands, nc,
                            s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), st);
+        if (fp.detect_adjacent) {
+          // (overlapping candidates: adjacency is no longer a neighbour property)
+          launch_detect_adjacent(s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), nc, s->counters.as<unsigned long long>(), st);
+          RJ_HIP(hipMemcpyAsync(&s->host_counters[kCntAdjacent], s->counters.as<unsigned long long>() + kCntAdjacent,
+                                sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+          RJ_HIP(hipStreamSynchronize(st));
+        }
       }
       rc = resolve_selection(s, fp, st);
       if (rc != RJ_OK) return rc;

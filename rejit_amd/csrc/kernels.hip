@@ -648,6 +648,10 @@ __global__ __launch_bounds__(kOgcThreads) void offsets_gather_check(const uint32
                                                                     uint32_t region_cap, uint64_t carry_cur, uint64_t* out,
                                                                     uint64_t out_cap, unsigned long long* counters,
                                                                     unsigned long long* host_counters) {
+  // Adjacency (a candidate begins exactly where an earlier one ends) is wanted for the Q8 check.
+  // When the list is ordered and disjoint -- the only case in which this kernel's verdict is
+  // used -- only neighbours can be adjacent, so comparing with the running maximum is exact.
+  bool adjacent = false;
   constexpr int kWaves = kOgcThreads / kWave;
   __shared__ uint64_t wave_sum[kWaves], wave_before[kWaves], wave_end[kWaves];
   __shared__ int64_t wave_last[kWaves];
@@ -742,12 +746,17 @@ __global__ __launch_bounds__(kOgcThreads) void offsets_gather_check(const uint32
       e = region_ends[src + k];
     }
     ok = ok && e > b && b >= prev;
+    adjacent = adjacent || (b == prev && prev != 0);
     prev = e > prev ? e : prev;
     if (off + k < out_cap) *reinterpret_cast<ulonglong2*>(out + 2 * (off + k)) = make_ulonglong2(b, e);
   }
   if (!ok) {
     counters[kCntUnordered] = 1;
     if (host_counters) host_counters[kCntUnordered] = 1;
+  }
+  if (adjacent) {
+    counters[kCntAdjacent] = 1;
+    if (host_counters) host_counters[kCntAdjacent] = 1;
   }
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
     counters[kCntHits] = base + own_total;
@@ -761,7 +770,6 @@ __global__ __launch_bounds__(kOgcThreads) void offsets_gather_check(const uint32
       host_counters[kCntOverflow] = counters[kCntOverflow];
       host_counters[kCntMaxRegion] = counters[kCntMaxRegion];
       host_counters[kCntOverrun] = counters[kCntOverrun];
-      host_counters[kCntAdjacent] = 0;
       host_counters[kCntFinal] = 0;
     }
   }
