@@ -236,13 +236,21 @@ int upload_program(rj_program* rp) {
       }
     rp->window_nibbles = ok && getenv("RJ_NO_NIBBLE") == nullptr;
   }
-  // One-byte windows with three or more alternatives hit several percent of the positions of
-  // ordinary text: that is dense work, and the fused dense kernel (candidates walked in place, no
-  // hit lists) serves it better than window hits + verify.  ([a-f]+[0-9] over random ASCII:
-  // 12M hits/GB, 4.4 ms as windows.)
-  if (D.mode == 1 && !P.floating && D.win_len == 1 && D.n_windows >= 3 && dense_walk_fits(D) &&
-      getenv("RJ_NO_DENSE_WALK") == nullptr)
-    D.mode = 0;
+  // Windows with few fixed bytes hit several percent of the positions of ordinary text (estimate:
+  // every fixed byte passes 1/64 of the positions): that is dense work, and the fused dense
+  // kernel (candidates walked in place, no hit lists) serves it better than hits + verify.
+  if (D.mode == 1 && !P.floating && dense_walk_fits(D) && getenv("RJ_NO_DENSE_WALK") == nullptr) {
+    double density = 0.0;
+    for (const FFWindow& w : P.windows) {
+      int fixed = 0;
+      for (uint32_t k = 0; k < w.len; k++)
+        fixed += ((k < 4 ? (w.mask0 >> (8 * k)) : (w.mask1 >> (8 * (k - 4)))) & 0xFFu) != 0;
+      double p = 1.0;
+      for (int k = 0; k < fixed; k++) p /= 64.0;
+      density += p;
+    }
+    if (density > 0.03) D.mode = 0;
+  }
   D.float_range = P.floating ? P.float_max - P.float_min + 1 : 1;
   D.float_max = P.floating ? P.float_max : 0;
   for (int k = 0; k < 8; k++) D.first_bytes[k] = P.first_bytes.w[k];
@@ -843,7 +851,7 @@ int rj_program_info(const rj_program* prog, rj_info* info) {
   info->n_positions = P.n_pos;
   info->n_words = P.n_words;
   info->has_assertions = P.has_assertions;
-  info->scan_mode = P.mode == ScanMode::Windows;
+  info->scan_mode = prog->dev.mode;  // the mode the kernels run (the engine may prefer dense over weak windows)
   info->n_windows = static_cast<int32_t>(P.windows.size());
   info->window_offset = prog->dev.win_offset;
   info->window_len = prog->dev.win_len;

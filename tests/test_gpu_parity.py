@@ -181,6 +181,35 @@ def test_dense_and_unbounded_vs_oracle(rj, oracle):
             assert got == want, (rx, n)
 
 
+def test_dense_walk_kernel_shapes(rj, oracle):
+    """The fused dense kernel: 1, 2 and 4 state words, with and without assertions, region overflow
+    (every position matches), starts decided by the register pre-steps vs walked, chunk and wave
+    edges (texts of a few chunks so that the last lane's positions and the tail chunk are hit)."""
+    rng = random.Random(11)
+    A, B = b"abcdefgh", b"ijklmnop"
+    cases = [
+        (b"[a-h][i-p]", A + B),                      # 1 word, everything decided by the pre-steps
+        (b"[a-h]+[i-p]", A + B),                     # loops: long walks
+        (b"[a-h][i-p]?[a-h]", A + B),                # skip positions
+        (b"([a-h][i-p]){17}", A + B),                # 34 positions: 2 words
+        (b"[a-h]{70}", A + b"i"),                    # 70 positions: 4 words (3 used)
+        (b"^[a-h]+$", A + b"\n"),                    # assertions: context tables
+        (b"[a-h]+$", A + b"q\n"),
+        (b"[a-p]", A + B),                           # every position matches: regions overflow and grow
+        (b"[a-p]+", A + B + b"z"),
+        (b"([a-h]|[i-p][i-p])+[a-h]", A + B),        # general follow rows
+    ]
+    n_dense = 0
+    for rx, alphabet in cases:
+        n_dense += prog(rj, rx).info()["scan_mode"] == 0
+        for n in (1, 15, 16, 17, 1023, 1024, 1025, 1027, 1028, 2049, 5000, 70001, 300000):
+            text = bytes(rng.choice(alphabet) for _ in range(n))
+            want = oracle.match_all(rx, text)
+            got = prog(rj, rx).match_all(text)
+            assert got == want, (rx, n)
+    assert n_dense >= 8, "these patterns are meant to run in dense mode"
+
+
 def test_many_matches_large_path(rj, oracle):
     """More candidates than the LDS finalize holds: the rocPRIM sort path."""
     rng = random.Random(9)
