@@ -1019,25 +1019,64 @@ int64_t rj_match_all(const rj_program* prog, const char* text, size_t n, uint64_
 
 void rj_free_spans(uint64_t* spans) { free(spans); }
 
+// kMatchFirst / kMatchAnywhere with early exit (the reference's generated code returns at the
+// first match, codegen-x64.cc:401-446).  kMatchFirst is the first element of kMatchAll (left-most
+// longest; reference behaviour Q6), and the greedy selection takes the left-most candidate whatever
+// follows it, so it is enough to look at growing prefixes of the START positions: [0, 256 KiB),
+// then 8x more each time.  When the longest match is bounded only the bytes a block's candidates
+// can reach are uploaded first (a walk from s < hi ends before hi + max_len), so a hit near the
+// start of a large host buffer costs microseconds instead of the whole PCIe copy.
+static int first_match(const rj_program* prog, const char* text, size_t n, uint64_t* begin, uint64_t* end) {
+  if (!prog || (!text && n)) return fail(RJ_BAD_ARGUMENT, "null argument");
+  rj_scan* s = nullptr;
+  int rc = host_scan_for(prog, &s);
+  if (rc != RJ_OK) return rc;
+  RJ_HIP(s->text.reserve(((n + 64 + 4095) / 4096) * 4096));
+  const uint8_t* d_text = s->text.as<uint8_t>();
+  const uint64_t max_len = prog->host->max_len;
+  const bool bounded = max_len < (1ull << 20);
+  uint64_t uploaded = 0;
+  auto upload_to = [&](uint64_t upto) -> hipError_t {
+    if (upto > n) upto = n;
+    if (upto <= uploaded) return hipSuccess;
+    hipError_t e = hipMemcpyAsync(static_cast<char*>(s->text.p) + uploaded, text + uploaded, upto - uploaded,
+                                  hipMemcpyHostToDevice, s->own_stream);
+    uploaded = upto;
+    return e;
+  };
+  uint64_t lo = 0, block = 256u << 10;
+  for (;;) {
+    uint64_t hi = lo + block;
+    const bool last = hi >= n;
+    if (last) hi = n;
+    // text the automaton may see in this round: everything for the last block or an unbounded
+    // pattern, else up to the furthest byte a candidate of the block can reach (+1 for the
+    // end-of-line context)
+    const uint64_t visible = (last || !bounded) ? n : std::min<uint64_t>(n, hi + max_len + 1);
+    RJ_HIP(upload_to(visible));
+    rc = run_pipeline(s, d_text, visible, lo, (last && visible == n) ? n + 1 : hi, 0, 0, 0, s->own_stream);
+    if (rc != RJ_OK) return rc;
+    if (s->result_count > 0) {
+      uint64_t pair[2];
+      RJ_HIP(hipMemcpy(pair, s->result, sizeof(pair), hipMemcpyDeviceToHost));
+      if (begin) *begin = pair[0];
+      if (end) *end = pair[1];
+      return 1;
+    }
+    if (last) return 0;
+    lo = hi;
+    block *= 8;
+  }
+}
+
 int rj_match_first(const rj_program* prog, const char* text, size_t n, uint64_t* begin, uint64_t* end) {
   ErrnoGuard errno_guard;
-  // kMatchFirst == first element of kMatchAll (left-most longest); see DESIGN.md
-  uint64_t* spans = nullptr;
-  int64_t c = rj_match_all(prog, text, n, &spans);
-  if (c < 0) return static_cast<int>(c);
-  if (c > 0) {
-    if (begin) *begin = spans[0];
-    if (end) *end = spans[1];
-  }
-  rj_free_spans(spans);
-  return c > 0 ? 1 : 0;
+  return first_match(prog, text, n, begin, end);
 }
 
 int rj_match_anywhere(const rj_program* prog, const char* text, size_t n) {
   ErrnoGuard errno_guard;
-  int64_t c = rj_match_all(prog, text, n, nullptr);
-  if (c < 0) return static_cast<int>(c);
-  return c > 0 ? 1 : 0;
+  return first_match(prog, text, n, nullptr, nullptr);
 }
 
 int rj_match_full(const rj_program* prog, const char* text, size_t n) {

@@ -210,6 +210,44 @@ def test_dense_walk_kernel_shapes(rj, oracle):
     assert n_dense >= 8, "these patterns are meant to run in dense mode"
 
 
+def test_match_first_and_anywhere_early_exit(rj, oracle):
+    """kMatchFirst / kMatchAnywhere look at growing prefixes of the start positions and upload only
+    what those can reach: same answers as MatchAll[0] wherever the first match lies (block edges at
+    256 KiB and 2 MiB + 256 KiB, bounded and unbounded patterns, `$` at a false text end)."""
+    import time
+    from rejit_amd import workloads as W
+    n = 6 << 20
+    base = W.random_ascii_numpy(n, seed=77)
+    for rx, needle in ((b"regexp", b"regexp"), (b"reg+exp$", b"reggggexp\n"), (b"re[a-g]+xp|abc$", b"regexp"),
+                       (b"q[0-9]*regexp", b"q123regexp")):
+        p = prog(rj, rx)
+        for where in (None, 0, 100, (256 << 10) - 3, (256 << 10), (256 << 10) + 1, (2 << 20) + (256 << 10) - 2, n - len(needle)):
+            t = base.copy()
+            if where is not None:
+                W.plant(t, [where], needle)
+            tb = t.tobytes()
+            all_ = p.match_all(tb)
+            first = p.match_first(tb)
+            assert first == (all_[0] if all_ else None), (rx, where)
+            assert p.match_anywhere(tb) == bool(all_), (rx, where)
+    # an early hit must not pay for the whole buffer
+    t = base.copy()
+    W.plant(t, [1000], b"regexp")
+    tb = t.tobytes()
+    p = prog(rj, b"regexp")
+    p.match_first(tb)
+    t0 = time.perf_counter(); p.match_first(tb); early = time.perf_counter() - t0
+    t0 = time.perf_counter(); p.match_all(tb); full = time.perf_counter() - t0
+    assert early < full / 2, (early, full)
+    # small texts vs the oracle (all block logic collapses to one run)
+    rng = random.Random(3)
+    for rx in (b"a+b", b"^b", b"b$", b"x*", b"(ab|ba)+"):
+        for _ in range(20):
+            text = bytes(rng.choice(b"ab\n") for _ in range(rng.randrange(0, 40)))
+            want = oracle.match_all(rx, text)
+            assert prog(rj, rx).match_first(text) == (want[0] if want else None), (rx, text)
+
+
 def test_many_matches_large_path(rj, oracle):
     """More candidates than the LDS finalize holds: the rocPRIM sort path."""
     rng = random.Random(9)
