@@ -84,6 +84,16 @@ int rj_match_first(const rj_program* prog, const char* text, size_t n, uint64_t*
 int64_t rj_match_all(const rj_program* prog, const char* text, size_t n, uint64_t** spans);
 void rj_free_spans(uint64_t* spans);
 
+/* A batch of independent texts in ONE device pass -- replaces the per-file loop of a grep-like
+ * caller (`for each file: re->MatchAll(file, size, &matches)`, sample/jrep.cc:261-313), whose
+ * per-call latency (~50 us + a PCIe copy each) a GPU cannot afford for many small files.  Every
+ * text is matched on its own: no match crosses a text boundary, `^` / `$` see each text's own
+ * begin and end.  counts[i] receives the number of matches of text i; *spans (may be NULL to only
+ * count) a malloc'ed array of 2 * total offsets, text after text, RELATIVE to their own text;
+ * release with rj_free_spans.  Returns the total number of matches or rj_status. */
+int64_t rj_match_all_batch(const rj_program* prog, const char* const* texts, const size_t* sizes, size_t n_texts,
+                           uint64_t* counts, uint64_t** spans);
+
 /* ReplaceAll (replaces MatchAll + rejit::Replace, src/rejit.cc:97-112,220-226): every match is
  * replaced by with[0..with_len).  Returns the number of matches (>= 0) or rj_status; *out receives
  * a malloc'ed copy of the new text (NUL-terminated for convenience, *out_len excludes the NUL),

@@ -103,7 +103,8 @@ _lib = None
 C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_error", "rj_match_full",
                  "rj_match_anywhere", "rj_match_first", "rj_match_all", "rj_free_spans", "rj_scan_create",
                  "rj_scan_destroy", "rj_scan_run", "rj_scan_device_spans", "rj_scan_copy_spans", "rj_scan_stats",
-                 "rj_scan_match_full", "rj_device_count", "rj_replace_all", "rj_free_text", "rj_scan_replace"]
+                 "rj_scan_match_full", "rj_device_count", "rj_replace_all", "rj_free_text", "rj_scan_replace",
+                 "rj_match_all_batch"]
 
 
 def load_library():
@@ -126,6 +127,8 @@ def load_library():
     L.rj_match_all.restype = i64
     L.rj_match_all.argtypes = [vp, cp, sz, ctypes.POINTER(_u64p)]
     L.rj_free_spans.argtypes = [_u64p]
+    L.rj_match_all_batch.restype = i64
+    L.rj_match_all_batch.argtypes = [vp, ctypes.POINTER(cp), ctypes.POINTER(sz), sz, _u64p, ctypes.POINTER(_u64p)]
     L.rj_scan_create.argtypes = [vp, ctypes.POINTER(vp)]
     L.rj_scan_destroy.argtypes = [vp]
     L.rj_scan_run.restype = i64
@@ -185,6 +188,25 @@ class Program:
         n = _check(self._lib.rj_match_all(self._h, text, len(text), ctypes.byref(spans)))
         out = [(int(spans[2 * i]), int(spans[2 * i + 1])) for i in range(n)]
         if n:
+            self._lib.rj_free_spans(spans)
+        return out
+
+    def match_all_batch(self, texts: List[bytes]) -> List[List[Tuple[int, int]]]:
+        """MatchAll over many independent texts (files) in one device pass; offsets are relative to
+        each text."""
+        k = len(texts)
+        arr = (ctypes.c_char_p * k)(*texts)
+        sizes = (ctypes.c_size_t * k)(*[len(t) for t in texts])
+        counts = (ctypes.c_uint64 * k)()
+        spans = _u64p()
+        total = _check(self._lib.rj_match_all_batch(self._h, arr, sizes, k, counts, ctypes.byref(spans)))
+        out, at = [], 0
+        for i in range(k):
+            c = int(counts[i])
+            out.append([(int(spans[2 * (at + j)]), int(spans[2 * (at + j) + 1])) for j in range(c)])
+            at += c
+        assert at == total
+        if total:
             self._lib.rj_free_spans(spans)
         return out
 

@@ -111,7 +111,8 @@ struct rj_program {
   DeviceBuffer graph_blob;
   int device = 0;
   int window_alphabet = 0;  // distinct byte values among the fixed window bytes
-  bool window_nibbles = false;  // those values differ in their low nibble (nibble filter usable)
+  bool window_nibbles = false;
+  int batch_separator = -1;  // byte that ends a text inside a concatenated batch, -1: none exists  // those values differ in their low nibble (nibble filter usable)
   std::string pattern;
 };
 
@@ -132,6 +133,8 @@ struct rj_scan {
   uint64_t result_count = 0;
   // host-text path
   DeviceBuffer text;
+  char* pinned = nullptr;  // staging for rj_match_all_batch
+  size_t pinned_cap = 0;
   hipStream_t own_stream = nullptr;
 };
 
@@ -235,6 +238,26 @@ int upload_program(rj_program* rp) {
         ok = ok && (m == 0 || m == 0xFFu);
       }
     rp->window_nibbles = ok && getenv("RJ_NO_NIBBLE") == nullptr;
+  }
+  {
+    // Batches of texts are concatenated with a separator that no pattern position can consume, so
+    // that every walk dies at a text's end exactly as it would at the end of the text.  A line
+    // break gives the `^` / `$` contexts of a text begin / end for free; without assertions any
+    // dead byte will do.  Patterns at risk of Q8 are matched text by text (the exact kernel has
+    // whole-text state).
+    auto dead = [&](int b) {
+      for (int k = 0; k < W; k++)
+        if (P.cls[static_cast<size_t>(b) * W + k] != 0) return false;
+      return true;
+    };
+    rp->batch_separator = -1;
+    if (!P.q8_risk) {
+      if (dead('\n')) rp->batch_separator = '\n';
+      else if (dead('\r')) rp->batch_separator = '\r';
+      else if (!P.has_assertions)
+        for (int b = 0; b < 256 && rp->batch_separator < 0; b++)
+          if (dead(b)) rp->batch_separator = b;
+    }
   }
   // Windows with few fixed bytes hit several percent of the positions of ordinary text (estimate:
   // every fixed byte passes 1/64 of the positions): that is dense work, and the fused dense
@@ -876,6 +899,7 @@ void rj_scan_destroy(rj_scan* s) {
   if (!s) return;
   if (s->host_counters) (void)hipHostFree(s->host_counters);
   if (s->host_flag) (void)hipHostFree(s->host_flag);
+  if (s->pinned) (void)hipHostFree(s->pinned);
   for (auto& e : s->ev)
     if (e) (void)hipEventDestroy(e);
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
@@ -1015,6 +1039,88 @@ int64_t rj_match_all(const rj_program* prog, const char* text, size_t n, uint64_
     *spans = h;
   }
   return static_cast<int64_t>(s->result_count);
+}
+
+int64_t rj_match_all_batch(const rj_program* prog, const char* const* texts, const size_t* sizes, size_t n_texts,
+                           uint64_t* counts, uint64_t** spans) {
+  ErrnoGuard errno_guard;
+  if (spans) *spans = nullptr;
+  if (!prog || (n_texts && (!texts || !sizes || !counts))) return fail(RJ_BAD_ARGUMENT, "null argument");
+  for (size_t i = 0; i < n_texts; i++)
+    if (!texts[i] && sizes[i]) return fail(RJ_BAD_ARGUMENT, "null text in batch");
+  if (n_texts == 0) return 0;
+  if (prog->batch_separator < 0 || n_texts == 1) {
+    // no byte can safely end a text inside a concatenation (or nothing to batch): text by text
+    std::vector<uint64_t> all;
+    uint64_t total = 0;
+    for (size_t i = 0; i < n_texts; i++) {
+      uint64_t* one = nullptr;
+      int64_t c = rj_match_all(prog, texts[i], sizes[i], spans ? &one : nullptr);
+      if (c < 0) return c;
+      counts[i] = static_cast<uint64_t>(c);
+      if (spans && c) all.insert(all.end(), one, one + 2 * c);
+      rj_free_spans(one);
+      total += static_cast<uint64_t>(c);
+    }
+    if (spans && total) {
+      uint64_t* h = static_cast<uint64_t*>(malloc(all.size() * sizeof(uint64_t)));
+      if (!h) return fail(RJ_DEVICE_ERROR, "out of host memory");
+      memcpy(h, all.data(), all.size() * sizeof(uint64_t));
+      *spans = h;
+    }
+    return static_cast<int64_t>(total);
+  }
+  rj_scan* s = nullptr;
+  int rc = host_scan_for(prog, &s);
+  if (rc != RJ_OK) return rc;
+  // text i occupies [off[i], off[i] + sizes[i]); position off[i] + sizes[i] holds the separator and
+  // is text i's end position (an empty match there belongs to text i)
+  std::vector<uint64_t> off(n_texts + 1);
+  uint64_t total_bytes = 0;
+  for (size_t i = 0; i < n_texts; i++) {
+    off[i] = total_bytes;
+    total_bytes += sizes[i] + 1;
+  }
+  off[n_texts] = total_bytes;
+  const uint64_t n = total_bytes - 1;  // the last separator is the end of the buffer
+  if (total_bytes > s->pinned_cap) {
+    if (s->pinned) (void)hipHostFree(s->pinned);
+    s->pinned = nullptr;
+    s->pinned_cap = 0;
+    const size_t want = ((total_bytes + (1u << 20)) / 4096 + 1) * 4096;
+    RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->pinned), want));
+    s->pinned_cap = want;
+  }
+  const char sep = static_cast<char>(prog->batch_separator);
+  for (size_t i = 0; i < n_texts; i++) {
+    if (sizes[i]) memcpy(s->pinned + off[i], texts[i], sizes[i]);
+    s->pinned[off[i] + sizes[i]] = sep;
+  }
+  RJ_HIP(s->text.reserve(((total_bytes + 64 + 4095) / 4096) * 4096));
+  RJ_HIP(hipMemcpyAsync(s->text.p, s->pinned, total_bytes, hipMemcpyHostToDevice, s->own_stream));
+  rc = run_pipeline(s, s->text.as<uint8_t>(), n, 0, n + 1, 0, 0, 0, s->own_stream);
+  if (rc != RJ_OK) return rc;
+  const uint64_t m = s->result_count;
+  std::vector<uint64_t> pairs(2 * m);
+  if (m) RJ_HIP(hipMemcpy(pairs.data(), s->result, m * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  // the matches are ordered by begin: one merge pass assigns them to their texts
+  for (size_t i = 0; i < n_texts; i++) counts[i] = 0;
+  size_t t = 0;
+  for (uint64_t k = 0; k < m; k++) {
+    const uint64_t b = pairs[2 * k], e = pairs[2 * k + 1];
+    while (b > off[t] + sizes[t]) t++;
+    if (e > off[t] + sizes[t]) return fail(RJ_DEVICE_ERROR, "internal: a match crosses a text boundary in a batch");
+    counts[t]++;
+    pairs[2 * k] = b - off[t];
+    pairs[2 * k + 1] = e - off[t];
+  }
+  if (spans && m) {
+    uint64_t* h = static_cast<uint64_t*>(malloc(pairs.size() * sizeof(uint64_t)));
+    if (!h) return fail(RJ_DEVICE_ERROR, "out of host memory");
+    memcpy(h, pairs.data(), pairs.size() * sizeof(uint64_t));
+    *spans = h;
+  }
+  return static_cast<int64_t>(m);
 }
 
 void rj_free_spans(uint64_t* spans) { free(spans); }

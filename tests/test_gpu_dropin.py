@@ -53,6 +53,48 @@ def test_reference_jrep_sample_equals_grep(tmp_path):
         assert len(ref.splitlines()) > 0
 
 
+@pytest.mark.skipif(shutil.which("grep") is None, reason="grep missing")
+def test_own_jrep_counterpart_equals_grep_and_reference_jrep(tmp_path):
+    """samples/jrep_gpu.py (whole batches of files in one device pass, rj_match_all_batch) prints
+    what GNU grep prints for literal patterns, and what the reference's own jrep prints on our
+    library for an alternation."""
+    import random
+    import sys
+    rng = random.Random(5)
+    words = ["regexp", "alpha", "beta", "gamma", "int", "return", "for", "while", "x", "y", "regex", "exp"]
+    for d in ("a", "a/b", "c"):
+        os.makedirs(tmp_path / d, exist_ok=True)
+    for i in range(120):
+        sub = rng.choice(["a", "a/b", "c", "."])
+        lines = [" ".join(rng.choice(words) for _ in range(rng.randint(0, 9))) for _ in range(rng.randint(0, 60))]
+        (tmp_path / sub / f"f{i}.txt").write_text("\n".join(lines) + ("\n" if i % 7 or sub == "c" else ""))
+    sample = os.path.join(ROOT, "samples", "jrep_gpu.py")
+    for pattern, extra in (("regexp", []), ("gamma beta", []), ("whil", ["-C", "1"]), ("x y", ["-A", "2"])):
+        ours = subprocess.run([sys.executable, sample, "-R", "-H", "-n", *extra, "--batch-mib", "1", pattern, "."], cwd=tmp_path,
+                              capture_output=True, timeout=600, check=True).stdout
+        ref = subprocess.run(["grep", "-R", "-H", "-n", *extra, pattern, "."], cwd=tmp_path, capture_output=True).stdout
+        if extra:   # with context the file order matters (group separators): compare per file
+            def per_file(blob):
+                d = {}
+                for line in blob.splitlines():
+                    if line == b"--":
+                        continue
+                    d.setdefault(line.split(b"-")[0].split(b":")[0], []).append(line)
+                return d
+            assert per_file(ours) == per_file(ref), pattern
+        else:
+            assert sorted(ours.splitlines()) == sorted(ref.splitlines()), pattern
+        assert len(ref.splitlines()) > 0
+    if os.path.exists(JREP):
+        # (the reference's jrep prints a last line without a line break as it is, so its output glues
+        # it to the next file's first line; grep and jrep_gpu.py end it -- compare where files end in \n)
+        pattern = "(regexp|gamma) (x|y)"
+        ours = subprocess.run([sys.executable, sample, "-R", "-H", "-n", pattern, "c"], cwd=tmp_path, capture_output=True,
+                              timeout=600, check=True).stdout
+        theirs = subprocess.run([JREP, "-R", "-H", "-n", pattern, "c"], cwd=tmp_path, capture_output=True, timeout=300).stdout
+        assert sorted(ours.splitlines()) == sorted(theirs.splitlines()) and len(ours.splitlines()) > 0
+
+
 def test_own_regexdna_counterpart(tmp_path):
     """samples/regexdna_gpu.py (text resident in HBM for the whole program) prints the same
     output as the reference's sample on the same input."""

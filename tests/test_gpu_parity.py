@@ -248,6 +248,34 @@ def test_match_first_and_anywhere_early_exit(rj, oracle):
             assert prog(rj, rx).match_first(text) == (want[0] if want else None), (rx, text)
 
 
+def test_match_all_batch_vs_per_text_oracle(rj, oracle):
+    """rj_match_all_batch (many files, one device pass) == the oracle run on every text alone:
+    empty texts, texts ending in a match, empty matches at text ends, ^ / $ at text boundaries,
+    patterns that can consume a newline (other separator or the text-by-text fallback)."""
+    rng = random.Random(21)
+    patterns = [b"ab+", b"^a", b"a$", b"^$", b"x*", b"(ab|ba)+", b"[^a]+", b"a\nb|b", b"\s+", b"[ab]{2,3}",
+                b".*b", b"^[ab]+$", b"regexp"]
+    for rx in patterns:
+        for alphabet in (b"ab\n", b"abx \r\n"):
+            texts = [bytes(rng.choice(alphabet) for _ in range(rng.choice((0, 0, 1, 2, 5, 17, 64, 300)))) for _ in range(40)]
+            texts += [b"", b"ab", b"b" * 20, b"regexp", b"xregexp\n", b"\n"]
+            want = [oracle.match_all(rx, t) for t in texts]
+            got = prog(rj, rx).match_all_batch(texts)
+            assert got == want, rx
+    # larger batch: 2000 "files" of a few KiB with planted needles, counts per file
+    from rejit_amd import workloads as W
+    files = []
+    for i in range(2000):
+        n = rng.randrange(0, 6000)
+        t = W.random_ascii_numpy(n, seed=1000 + i) if n else np.zeros(0, dtype=np.uint8)
+        if n > 40 and i % 3 == 0:
+            W.plant(t, [rng.randrange(0, n - 6) for _ in range(i % 4 + 1)], b"regexp")
+        files.append(t.tobytes())
+    got = prog(rj, b"regexp").match_all_batch(files)
+    for t, g in zip(files, got):
+        assert g == oracle.match_all(b"regexp", t)
+
+
 def test_many_matches_large_path(rj, oracle):
     """More candidates than the LDS finalize holds: the rocPRIM sort path."""
     rng = random.Random(9)
