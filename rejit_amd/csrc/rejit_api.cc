@@ -6,6 +6,10 @@
 
 #include <cstdio>
 #include <cstring>
+#include <list>
+#include <memory>
+#include <mutex>
+#include <string>
 
 #include "../../include/rejit_hip.h"
 
@@ -139,22 +143,46 @@ size_t Regej::ReplaceAll(string& text, const string& with) {
 }
 
 // ----------------------------------------------------------------------------- free functions
+// The reference's free functions build a temporary Regej -- parse + JIT -- on every call
+// (src/rejit.cc:37-87; "there is no cache", include/rejit.h:48-50).  Here a compile also allocates
+// and fills device tables, so the most recent patterns are kept.  A Regej is safe
+// for concurrent use; entries are shared_ptrs so an evicted one lives until its callers return.
+namespace {
+std::shared_ptr<Regej> cached(const char* regexp) {
+  static std::mutex mu;
+  // (never destroyed: at process exit the HIP runtime may be gone before static destructors run)
+  static auto& lru = *new std::list<std::pair<std::string, std::shared_ptr<Regej>>>;  // front = most recent
+  const std::string key = regexp ? regexp : "";
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto it = lru.begin(); it != lru.end(); ++it)
+    if (it->first == key) {
+      lru.splice(lru.begin(), lru, it);
+      return lru.front().second;
+    }
+  std::shared_ptr<Regej> fresh = std::make_shared<Regej>(key);
+  if (fresh->status() != RejitSuccess) return fresh;  // not kept: the next call reports the error again
+  lru.emplace_front(key, fresh);
+  if (lru.size() > 32) lru.pop_back();
+  return fresh;
+}
+}  // namespace
+
 bool MatchFull(const char* regexp, const string& text) { return MatchFull(regexp, text.c_str(), text.size()); }
-bool MatchFull(const char* regexp, const char* text, size_t n) { return Regej(regexp).MatchFull(text, n); }
+bool MatchFull(const char* regexp, const char* text, size_t n) { return cached(regexp)->MatchFull(text, n); }
 bool MatchAnywhere(const char* regexp, const string& text) { return MatchAnywhere(regexp, text.c_str(), text.size()); }
-bool MatchAnywhere(const char* regexp, const char* text, size_t n) { return Regej(regexp).MatchAnywhere(text, n); }
+bool MatchAnywhere(const char* regexp, const char* text, size_t n) { return cached(regexp)->MatchAnywhere(text, n); }
 bool MatchFirst(const char* regexp, const string& text, Match* m) {
   return MatchFirst(regexp, text.c_str(), text.size(), m);
 }
-bool MatchFirst(const char* regexp, const char* text, size_t n, Match* m) { return Regej(regexp).MatchFirst(text, n, m); }
+bool MatchFirst(const char* regexp, const char* text, size_t n, Match* m) { return cached(regexp)->MatchFirst(text, n, m); }
 size_t MatchAll(const char* regexp, const string& text, std::vector<Match>* ms) {
   return MatchAll(regexp, text.c_str(), text.size(), ms);
 }
 size_t MatchAll(const char* regexp, const char* text, size_t n, std::vector<Match>* ms) {
-  return Regej(regexp).MatchAll(text, n, ms);
+  return cached(regexp)->MatchAll(text, n, ms);
 }
 size_t MatchAllCount(const char* regexp, const string& text) { return MatchAllCount(regexp, text.c_str(), text.size()); }
-size_t MatchAllCount(const char* regexp, const char* text, size_t n) { return Regej(regexp).MatchAllCount(text, n); }
+size_t MatchAllCount(const char* regexp, const char* text, size_t n) { return cached(regexp)->MatchAllCount(text, n); }
 
 void Replace(Match to_replace, string& text, const string& with) {
   std::vector<Match> one(1, to_replace);
@@ -175,7 +203,7 @@ void Replace(vector<Match>* to_replace, string& text, const string& with) {
   text.swap(out);
 }
 
-bool ReplaceFirst(const char* regexp, string& text, const string& with) { return Regej(regexp).ReplaceFirst(text, with); }
-size_t ReplaceAll(const char* regexp, string& text, const string& with) { return Regej(regexp).ReplaceAll(text, with); }
+bool ReplaceFirst(const char* regexp, string& text, const string& with) { return cached(regexp)->ReplaceFirst(text, with); }
+size_t ReplaceAll(const char* regexp, string& text, const string& with) { return cached(regexp)->ReplaceAll(text, with); }
 
 }  // namespace rejit
