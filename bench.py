@@ -155,6 +155,8 @@ def main():
         st_i = streams[i].cuda_stream if (pool or own_stream) else stream
         return scans[i].run(text_ptr, n_local, own_begin=own_lo, own_end=own_hi, stream=st_i)
 
+    pending = []   # (all_reduce work, device tensor) of steps whose exchange is still in flight
+
     def step(record: bool):
         if pool:
             local = list(pool.map(run_one, range(len(scans))))
@@ -163,10 +165,25 @@ def main():
         if record:
             scan_ms.extend(sc.stats()["scan_ms"] for sc in scans)
         if world > 1:
-            counts_dev.copy_(torch.tensor(local, dtype=torch.int64), non_blocking=False)
-            dist.all_reduce(counts_dev)       # RCCL over xGMI: 9 x 8 bytes
-            return counts_dev.tolist()
+            # exchange step of the path: sum of the 9 match counts (72 bytes) over the ranks, RCCL over
+            # xGMI.  It is issued asynchronously and collected one step later, so the next step's scans
+            # run while the (latency-only) all_reduce is in flight.
+            t = torch.tensor(local, dtype=torch.int64).to(cdev)
+            pending.append((dist.all_reduce(t, async_op=True), t))
+            while len(pending) > 1:
+                w, done = pending.pop(0)
+                w.wait()
+            return None
         return local
+
+    def drain():
+        """Complete the outstanding exchanges; returns the job-wide counts of the last step."""
+        last = None
+        while pending:
+            w, t = pending.pop(0)
+            w.wait()
+            last = t
+        return last.tolist() if last is not None else None
 
     def barrier():
         if world > 1:
@@ -175,10 +192,13 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    drain()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         counts = step(True)
+    if world > 1:
+        counts = drain()          # inside the timed region: every step's exchange has completed
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
