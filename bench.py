@@ -247,6 +247,28 @@ def main():
         out["overlapped"] = {"pattern_threads": 3, "value": round(scanned / e3 / 1e9, 3), "unit": "GB/s",
                              "ms_per_step": round(e3 / args.steps * 1e3, 4)}
 
+    if rank == 0 and world == 1 and not args.no_extra:
+        # the nine patterns in ONE pass over the text (rj_multi).  Same results; the
+        # text is read once instead of nine times, and the kernel becomes VALU-bound.
+        multi = rejit_amd.MultiScan(progs)
+        for _ in range(2):
+            cf = multi.run(text_ptr, n_local, stream=stream)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        fms = []
+        for _ in range(args.steps):
+            cf = multi.run(text_ptr, n_local, stream=stream)
+            fms.append(multi.scan_ms())
+        torch.cuda.synchronize(dev)
+        ef = time.perf_counter() - t1
+        assert cf == counts, "fused run disagrees with the nine single runs"
+        a_ms = sum(fms) / len(fms)
+        out["fused"] = {"api": "rj_multi_run (9 patterns, one pass over the text)", "fused": bool(multi.fused),
+                        "value": round(scanned / ef / 1e9, 3), "unit": "GB/s", "ms_per_step": round(ef / args.steps * 1e3, 4),
+                        "scan_kernel_ms": round(a_ms, 5),
+                        "hbm_read_GBps": round(own_bytes / (a_ms * 1e-3) / 1e9, 1) if a_ms > 0 else None,
+                        "bound": "VALU issue (~29 ops per text byte for 18 windows), not HBM"}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample taken from the lower-case (matching) part of the text: the first 20 %
         # is the upper-case ALU repeat, which no pattern can match

@@ -124,6 +124,21 @@ int rj_scan_stats(const rj_scan* scan, rj_stats* stats);
 /* 1 / 0 / <0: kMatchFull over device text */
 int rj_scan_match_full(rj_scan* scan, const void* d_text, uint64_t n, void* hip_stream);
 
+/* ---- several patterns over the same device-resident text (regexdna: nine MatchAllCount calls on
+ * one text, sample/regexdna.cc:56-70).  When every pattern has a nibble-form window set (DESIGN.md
+ * section 4) the text is read ONCE for all of them; otherwise the patterns run one after another.
+ * Results are those of rj_scan_run per pattern: rj_multi_scan(m, i) is an ordinary rj_scan holding
+ * pattern i's spans / stats after rj_multi_run. */
+typedef struct rj_multi rj_multi;
+int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out);
+void rj_multi_destroy(rj_multi* multi);
+/* counts[i] = matches of pattern i over d_text[0..n); returns 1 when the fused kernel ran, 0 when
+ * the patterns ran one by one, <0 = rj_status */
+int rj_multi_run(rj_multi* multi, const void* d_text, uint64_t n, uint64_t* counts, void* hip_stream);
+rj_scan* rj_multi_scan(rj_multi* multi, int i);
+/* duration of the last fused scan kernel in ms (0 when not fused) */
+float rj_multi_scan_ms(const rj_multi* multi);
+
 /* number of visible HIP devices (0 when there is none), for callers that want to probe */
 int rj_device_count(void);
 

@@ -5,4 +5,4 @@ include/rejit.h); this package only builds it (hipcc, gfx950) and binds it with 
 tests and bench.py.  There is no Python or CPU implementation of the matching path: if the
 library is missing, or no HIP device is present, every call fails loudly.
 """
-from .api import (RejitError, Program, Scan, build, library_path, load_library, device_count)  # noqa: F401
+from .api import (RejitError, Program, Scan, MultiScan, build, library_path, load_library, device_count)  # noqa: F401

@@ -104,7 +104,8 @@ C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_er
                  "rj_match_anywhere", "rj_match_first", "rj_match_all", "rj_free_spans", "rj_scan_create",
                  "rj_scan_destroy", "rj_scan_run", "rj_scan_device_spans", "rj_scan_copy_spans", "rj_scan_stats",
                  "rj_scan_match_full", "rj_device_count", "rj_replace_all", "rj_free_text", "rj_scan_replace",
-                 "rj_match_all_batch"]
+                 "rj_match_all_batch", "rj_multi_create", "rj_multi_destroy", "rj_multi_run", "rj_multi_scan",
+                 "rj_multi_scan_ms"]
 
 
 def load_library():
@@ -130,6 +131,13 @@ def load_library():
     L.rj_match_all_batch.restype = i64
     L.rj_match_all_batch.argtypes = [vp, ctypes.POINTER(cp), ctypes.POINTER(sz), sz, _u64p, ctypes.POINTER(_u64p)]
     L.rj_scan_create.argtypes = [vp, ctypes.POINTER(vp)]
+    L.rj_multi_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(vp)]
+    L.rj_multi_destroy.argtypes = [vp]
+    L.rj_multi_run.argtypes = [vp, vp, u64, _u64p, vp]
+    L.rj_multi_scan.restype = vp
+    L.rj_multi_scan.argtypes = [vp, ctypes.c_int]
+    L.rj_multi_scan_ms.restype = ctypes.c_float
+    L.rj_multi_scan_ms.argtypes = [vp]
     L.rj_scan_destroy.argtypes = [vp]
     L.rj_scan_run.restype = i64
     L.rj_scan_run.argtypes = [vp, vp, u64, u64, u64, u64, u64, ctypes.c_int, vp]
@@ -286,3 +294,48 @@ class Scan:
 
     def match_full(self, d_text_ptr: int, n: int, stream: int = 0) -> bool:
         return bool(_check(self._lib.rj_scan_match_full(self._h, ctypes.c_void_p(d_text_ptr), n, ctypes.c_void_p(stream))))
+
+
+class _BorrowedScan(Scan):
+    """A rj_scan owned by a rj_multi (not destroyed from Python)."""
+
+    def __init__(self, handle, program, owner):
+        self._lib = load_library()
+        self.program = program
+        self._h = handle
+        self._owner = owner
+
+    def __del__(self):
+        self._h = None
+
+
+class MultiScan:
+    """Several patterns over the same device-resident text (rj_multi): one pass over the text when
+    every pattern has a nibble-form window set, else one pattern after the other."""
+
+    def __init__(self, programs: List[Program]):
+        self._lib = load_library()
+        self.programs = list(programs)
+        arr = (ctypes.c_void_p * len(programs))(*[p._h for p in programs])
+        h = ctypes.c_void_p()
+        _check(self._lib.rj_multi_create(arr, len(programs), ctypes.byref(h)))
+        self._h = h
+        self.fused = False
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.rj_multi_destroy(h)
+            self._h = None
+
+    def run(self, d_text_ptr: int, n: int, stream: int = 0) -> List[int]:
+        counts = (ctypes.c_uint64 * len(self.programs))()
+        r = _check(self._lib.rj_multi_run(self._h, ctypes.c_void_p(d_text_ptr), n, counts, ctypes.c_void_p(stream)))
+        self.fused = bool(r)
+        return [int(c) for c in counts]
+
+    def scan(self, i: int) -> Scan:
+        return _BorrowedScan(ctypes.c_void_p(self._lib.rj_multi_scan(self._h, i)), self.programs[i], self)
+
+    def scan_ms(self) -> float:
+        return float(self._lib.rj_multi_scan_ms(self._h))

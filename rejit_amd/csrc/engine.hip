@@ -821,6 +821,157 @@ int stage_text(rj_scan* s, const char* text, size_t n, const uint8_t** d_text) {
   return RJ_OK;
 }
 
+// ----------------------------------------------------------------------------- fused multi-pattern run
+bool fusable(const rj_program* rp) {
+  const DevProgram& D = rp->dev;
+  return D.mode == 1 && D.float_range == 1 && D.n_words <= 4 && D.win_len > 4 && D.n_windows <= 2 &&
+         rp->window_alphabet <= 4 && rp->window_nibbles && !rp->host->q8_risk;
+}
+
+// nibble form of window k (see WindowSet::nibble)
+void nibble_window(const DevProgram& D, int k, uint32_t* value, uint32_t* mask) {
+  uint32_t v = 0, m = 0;
+  for (int i = 0; i < 8; i++) {
+    const uint32_t vb = (i < 4 ? (D.win_value0[k] >> (8 * i)) : (D.win_value1[k] >> (8 * (i - 4)))) & 0xFFu;
+    const uint32_t mb = (i < 4 ? (D.win_mask0[k] >> (8 * i)) : (D.win_mask1[k] >> (8 * (i - 4)))) & 0xFFu;
+    const int at = 8 * (i & 3) + 4 * (i >> 2);
+    if (mb) {
+      v |= (vb & 15u) << at;
+      m |= 15u << at;
+    }
+  }
+  *value = v;
+  *mask = m;
+}
+
+}  // namespace
+
+struct rj_multi {
+  std::vector<rj_scan*> scans;
+  std::vector<hipStream_t> streams;
+  hipEvent_t scan_done = nullptr;
+  DeviceBuffer dummy_counts;  // hit_counts of the padding patterns
+  bool fused = false;
+  float scan_ms = 0.f;
+};
+
+namespace {
+
+// One fused scan + the per-pattern tails on their own streams.  Whole text, starts [0, n].
+int run_fused(rj_multi* m, const uint8_t* d_text, uint64_t n, hipStream_t st) {
+  const int P = static_cast<int>(m->scans.size());
+  const uint64_t chunks = std::max<uint64_t>((n + 1023) / 1024, 1);
+  const ScanGeometry geo = scan_geometry(chunks);
+  for (int attempt = 0; attempt < 6; attempt++) {
+    FusedParams fp{};
+    fp.text = d_text;
+    fp.n = n;
+    fp.sb = 0;
+    fp.se = n + 1;
+    fp.span_chunks = geo.span_chunks;
+    fp.n_patterns = static_cast<uint32_t>((P + kFuseGroup - 1) / kFuseGroup * kFuseGroup);
+    RJ_HIP(m->dummy_counts.reserve(static_cast<size_t>(geo.n_regions) * sizeof(uint32_t)));
+    std::vector<uint64_t> caps(static_cast<size_t>(P));
+    for (int p = 0; p < static_cast<int>(fp.n_patterns); p++) {
+      const int q = p < P ? p : 0;  // padding repeats pattern 0 with no room for hits
+      rj_scan* s = m->scans[static_cast<size_t>(q)];
+      const DevProgram& D = s->prog->dev;
+      nibble_window(D, 0, &fp.value[p][0], &fp.mask[p][0]);
+      nibble_window(D, D.n_windows > 1 ? 1 : 0, &fp.value[p][1], &fp.mask[p][1]);
+      fp.offset[p] = D.win_offset;
+      fp.len[p] = D.win_len;
+      if (p < P) {
+        const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(s->region_cap_hint, 64), geo.span_chunks * 1024);
+        caps[static_cast<size_t>(p)] = cap;
+        int rc = ensure_lists(s, geo.n_regions, static_cast<uint32_t>(cap), static_cast<uint64_t>(geo.n_regions) * cap);
+        if (rc != RJ_OK) return rc;
+        RJ_HIP(s->valid_counts.reserve(static_cast<size_t>(geo.n_regions) * sizeof(uint32_t)));
+        fp.hits[p] = s->hits.as<uint64_t>();
+        fp.region_cap[p] = static_cast<uint32_t>(cap);
+        fp.hit_counts[p] = s->hit_counts.as<uint32_t>();
+        fp.zero_counters[p] = s->counters.as<unsigned long long>();
+        s->stats = rj_stats{};
+        s->result = nullptr;
+        s->result_count = 0;
+      } else {
+        fp.hits[p] = m->scans[0]->hits.as<uint64_t>();
+        fp.region_cap[p] = 0;
+        fp.hit_counts[p] = m->dummy_counts.as<uint32_t>();
+        fp.zero_counters[p] = nullptr;
+      }
+    }
+    rj_scan* s0 = m->scans[0];
+    launch_scan_windows_fused(fp, geo.grid, s0->ev[1], s0->ev[2], st);
+    RJ_HIP(hipEventRecord(m->scan_done, st));
+    // the single-pattern tail, pattern p on stream p (enqueued while the scan runs)
+    for (int p = 0; p < P; p++) {
+      rj_scan* s = m->scans[static_cast<size_t>(p)];
+      hipStream_t sp = m->streams[static_cast<size_t>(p)];
+      RJ_HIP(hipStreamWaitEvent(sp, m->scan_done, 0));
+      VerifyParams vp{};
+      vp.text = d_text;
+      vp.n = n;
+      vp.hits = s->hits.as<uint64_t>();
+      vp.n_regions = geo.n_regions;
+      vp.region_cap = static_cast<uint32_t>(caps[static_cast<size_t>(p)]);
+      vp.counters = s->counters.as<unsigned long long>();
+      vp.sb = 0;
+      vp.se = n + 1;
+      vp.expand = 1;
+      vp.float_max = s->prog->dev.float_max;
+      launch_verify_in_regions(vp, s->prog->dev, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(),
+                               s->cand_end.as<uint64_t>(), sp);
+      s->host_counters[kCntUnordered] = 0;
+      s->host_counters[kCntAdjacent] = 0;
+      launch_offsets_gather_check(s->valid_counts.as<uint32_t>(), s->hits.as<uint64_t>(), s->cand_end.as<uint64_t>(), geo.n_regions,
+                                  vp.region_cap, 0, s->out.as<uint64_t>(), s->out_cap, s->counters.as<unsigned long long>(),
+                                  s->host_counters, sp);
+    }
+    bool again = false;
+    for (int p = 0; p < P; p++) {
+      rj_scan* s = m->scans[static_cast<size_t>(p)];
+      hipStream_t sp = m->streams[static_cast<size_t>(p)];
+      RJ_HIP(hipStreamSynchronize(sp));
+      RJ_HIP(hipGetLastError());
+      if (s->host_counters[kCntOverflow] != 0) {
+        const uint64_t cap = caps[static_cast<size_t>(p)];
+        const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(s->host_counters[kCntMaxRegion] * 2, cap * 4), geo.span_chunks * 1024);
+        if (want <= cap) return fail(RJ_DEVICE_ERROR, "hit regions cannot grow further");
+        s->region_cap_hint = static_cast<uint32_t>(std::min<uint64_t>(want, 1u << 20));
+        again = true;
+      }
+    }
+    (void)hipEventElapsedTime(&m->scan_ms, s0->ev[1], s0->ev[2]);
+    if (again) continue;
+    for (int p = 0; p < P; p++) {
+      rj_scan* s = m->scans[static_cast<size_t>(p)];
+      hipStream_t sp = m->streams[static_cast<size_t>(p)];
+      if (s->host_counters[kCntOverrun] != 0)
+        return fail(RJ_TOO_LARGE, "a match candidate runs longer than %llu bytes", static_cast<unsigned long long>(kMaxSimSteps));
+      s->hits_hint = s->host_counters[kCntHits];
+      s->stats.n_hits = s->host_counters[kCntHits];
+      FinalizeParams sel{};
+      sel.carry_cur = 0;
+      sel.carry_prev_end = 0;
+      sel.have_prev = 0;
+      if (s->host_counters[kCntUnordered] != 0) {
+        const uint64_t nc = s->host_counters[kCntCands];
+        RJ_HIP(s->keys_out.reserve(nc * sizeof(uint64_t)));
+        RJ_HIP(s->vals_out.reserve(nc * sizeof(uint64_t)));
+        launch_split_pairs(s->out.as<uint64_t>(), s->counters.as<unsigned long long>() + kCntCands, nc,
+                           s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), sp);
+      }
+      int rc = resolve_selection(s, sel, sp);
+      if (rc != RJ_OK) return rc;
+      s->result = s->out.as<uint64_t>();
+      s->stats.n_matches = s->result_count;
+      s->stats.scan_ms = m->scan_ms;
+    }
+    return RJ_OK;
+  }
+  return fail(RJ_DEVICE_ERROR, "hit regions kept overflowing");
+}
+
 }  // namespace
 
 extern "C" {
@@ -997,6 +1148,76 @@ int64_t rj_replace_all(const rj_program* prog, const char* text, size_t n, const
   *out_len = static_cast<size_t>(new_len);
   return static_cast<int64_t>(m);
 }
+
+int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out) {
+  ErrnoGuard errno_guard;
+  if (!progs || !out || n_progs < 1) return fail(RJ_BAD_ARGUMENT, "null argument");
+  if (n_progs > kMaxFused - kFuseGroup + 1) return fail(RJ_BAD_ARGUMENT, "at most %d patterns per rj_multi", kMaxFused - kFuseGroup + 1);
+  auto m = std::make_unique<rj_multi>();
+  bool all = true;
+  for (int i = 0; i < n_progs; i++) {
+    if (!progs[i]) return fail(RJ_BAD_ARGUMENT, "null program");
+    rj_scan* s = nullptr;
+    int rc = rj_scan_create(progs[i], &s);
+    if (rc != RJ_OK) {
+      rj_multi_destroy(m.release());
+      return rc;
+    }
+    m->scans.push_back(s);
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+      rj_multi_destroy(m.release());
+      return fail(RJ_DEVICE_ERROR, "hipStreamCreate failed");
+    }
+    m->streams.push_back(st);
+    all = all && fusable(progs[i]);
+  }
+  if (hipEventCreateWithFlags(&m->scan_done, hipEventDisableTiming) != hipSuccess) {
+    rj_multi_destroy(m.release());
+    return fail(RJ_DEVICE_ERROR, "hipEventCreate failed");
+  }
+  m->fused = all && n_progs > 1 && getenv("RJ_NO_FUSION") == nullptr;
+  *out = m.release();
+  return RJ_OK;
+}
+
+void rj_multi_destroy(rj_multi* m) {
+  ErrnoGuard errno_guard;
+  if (!m) return;
+  for (rj_scan* s : m->scans) rj_scan_destroy(s);
+  for (hipStream_t st : m->streams)
+    if (st) (void)hipStreamDestroy(st);
+  if (m->scan_done) (void)hipEventDestroy(m->scan_done);
+  delete m;
+}
+
+int rj_multi_run(rj_multi* m, const void* d_text, uint64_t n, uint64_t* counts, void* hip_stream) {
+  ErrnoGuard errno_guard;
+  if (!m || (!d_text && n) || !counts) return fail(RJ_BAD_ARGUMENT, "null argument");
+  if ((reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) return fail(RJ_BAD_ARGUMENT, "device text must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  m->scan_ms = 0.f;
+  int fused = 0;
+  if (m->fused && n >= 16) {
+    int rc = run_fused(m, static_cast<const uint8_t*>(d_text), n, st);
+    if (rc != RJ_OK) return rc;
+    fused = 1;
+  } else {
+    for (rj_scan* s : m->scans) {
+      int rc = run_pipeline(s, static_cast<const uint8_t*>(d_text), n, 0, n + 1, 0, 0, 0, st);
+      if (rc != RJ_OK) return rc;
+    }
+  }
+  for (size_t i = 0; i < m->scans.size(); i++) counts[i] = m->scans[i]->result_count;
+  return fused;
+}
+
+rj_scan* rj_multi_scan(rj_multi* m, int i) {
+  if (!m || i < 0 || static_cast<size_t>(i) >= m->scans.size()) return nullptr;
+  return m->scans[static_cast<size_t>(i)];
+}
+
+float rj_multi_scan_ms(const rj_multi* m) { return m ? m->scan_ms : 0.f; }
 
 void rj_free_text(char* text) { free(text); }
 

@@ -77,6 +77,26 @@ struct FinalizeParams {
 
 // grid of the scan kernels for a run over `chunks` 1-KiB chunks: workgroups (4 waves each),
 // regions (= waves) and chunks per wave
+// Several patterns in one pass over the text: every pattern has up to two 5..8-byte
+// windows in nibble form (see WindowSet::nibble) and its own hit regions; patterns are processed in
+// groups of kFuseGroup with their constants in scalar registers.
+constexpr int kMaxFused = 18;
+constexpr int kFuseGroup = 3;
+struct FusedParams {
+  const uint8_t* text;
+  uint64_t n;
+  uint64_t sb, se;        // candidate starts [sb, se)
+  uint64_t span_chunks;
+  uint32_t n_patterns;    // a multiple of kFuseGroup (padding entries have region_cap 0)
+  uint32_t value[kMaxFused][2], mask[kMaxFused][2];
+  uint32_t offset[kMaxFused], len[kMaxFused];
+  uint64_t* hits[kMaxFused];
+  uint32_t region_cap[kMaxFused];
+  uint32_t* hit_counts[kMaxFused];
+  unsigned long long* zero_counters[kMaxFused];  // may be null
+};
+void launch_scan_windows_fused(const FusedParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
+
 struct ScanGeometry {
   int grid;
   uint32_t n_regions;

@@ -331,6 +331,128 @@ __global__ __launch_bounds__(256) void scan_windows(ScanParams a, WindowSet ws) 
 }
 
 // ---------------------------------------------------------------------------------------
+// Fused fast-forward scan: P patterns in ONE pass over the text (regexdna's nine patterns read the
+// same 500 MB nine times otherwise).  The nibble-packed dwords pk[j] of a chunk are built once;
+// each pattern then costs two v_bitop3 + one v_min3 per position.  29 VALU per text byte for 9
+// patterns makes this kernel VALU-bound (~1.3 TB/s of text, i.e. ~12 TB/s of "pattern-bytes"),
+// but it moves 1/9 of the HBM bytes of nine separate scans.  Hits go to per-pattern regions, so
+// everything downstream is the single-pattern pipeline, run per pattern on its own stream.
+__device__ __forceinline__ void fused_chunk(const uint32_t (&d)[6], uint64_t at, const FusedParams& a, uint32_t* counts,
+                                            uint64_t wave) {
+  uint32_t x[20];
+#pragma unroll
+  for (int q = 0; q < 5; q++) {
+    const uint32_t lo = d[q] & 0x0F0F0F0Fu, hi = d[q + 1] & 0x0F0F0F0Fu;
+    x[4 * q] = lo;
+    x[4 * q + 1] = __builtin_amdgcn_alignbyte(hi, lo, 1);
+    x[4 * q + 2] = __builtin_amdgcn_alignbyte(hi, lo, 2);
+    x[4 * q + 3] = __builtin_amdgcn_alignbyte(hi, lo, 3);
+  }
+  uint32_t pk[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) pk[j] = x[j] | (x[j + 4] << 4);
+  for (uint32_t g = 0; g < a.n_patterns; g += kFuseGroup) {
+    uint32_t acc[kFuseGroup];
+#pragma unroll
+    for (int u = 0; u < kFuseGroup; u++) {
+      const uint32_t v0 = a.value[g + u][0], m0 = a.mask[g + u][0], v1 = a.value[g + u][1], m1 = a.mask[g + u][1];
+      uint32_t c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint32_t t0 = (pk[j] ^ v0) & m0, t1 = (pk[j] ^ v1) & m1;
+        const uint32_t t = t0 < t1 ? t0 : t1;
+        if (j & 1) c1 = c1 < t ? c1 : t; else c0 = c0 < t ? c0 : t;
+      }
+      acc[u] = c0 < c1 ? c0 : c1;
+    }
+    uint32_t any = acc[0];
+#pragma unroll
+    for (int u = 1; u < kFuseGroup; u++) any = any < acc[u] ? any : acc[u];
+    if (__ballot(any == 0) == 0) continue;  // wave-uniform: no pattern of the group hits in this chunk
+    // rare path, pattern by pattern
+    for (int u = 0; u < kFuseGroup; u++) {
+      const uint32_t p = g + u;
+      const uint32_t v0 = a.value[p][0], m0 = a.mask[p][0], v1 = a.value[p][1], m1 = a.mask[p][1];
+      uint32_t hm = 0;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint32_t t0 = (pk[j] ^ v0) & m0, t1 = (pk[j] ^ v1) & m1;
+        hm |= static_cast<uint32_t>((t0 < t1 ? t0 : t1) == 0) << j;
+      }
+      if (__ballot(hm != 0) == 0) continue;
+      // window positions of pattern p: w = s + offset, sb <= s < se, and the window must fit
+      const uint64_t wlo = a.sb + a.offset[p];
+      const uint64_t last_w = a.n >= a.len[p] ? a.n - a.len[p] + 1 : 0;
+      uint64_t whi = a.se + a.offset[p];
+      if (whi > last_w) whi = last_w;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint64_t w = at + j;
+        if (w < wlo || w >= whi) hm &= ~(1u << j);
+      }
+      RegionHits hits{a.hits[p] + wave * a.region_cap[p], a.region_cap[p], counts[p]};
+      hits.push_bits(hm, at, a.offset[p]);
+      counts[p] = hits.count;  // wave-uniform, every lane stores the same value
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void scan_windows_fused(FusedParams a) {
+  __shared__ uint32_t region_count[4][kMaxFused];
+  const int lane = lane_id();
+  const uint64_t wave = scalar_wave_index();
+  uint32_t* counts = region_count[threadIdx.x >> 6];
+  if (lane < kMaxFused) counts[lane] = 0;
+  if (wave == 0 && lane < kCntSize)
+    for (uint32_t p = 0; p < a.n_patterns; p++)
+      if (a.zero_counters[p] != nullptr) a.zero_counters[p][lane] = 0;
+  const uint64_t first_chunk = a.sb / kChunk;
+  const uint64_t end_chunk = (a.n + kChunk - 1) / kChunk;  // a window may begin up to 7 bytes after its start
+  WaveSpan span;
+  span.c0 = first_chunk + wave * a.span_chunks;
+  span.c1 = span.c0 + a.span_chunks;
+  if (span.c0 > end_chunk) span.c0 = end_chunk;
+  if (span.c1 > end_chunk) span.c1 = end_chunk;
+  uint64_t fast_end = a.n >= kChunk + 8 ? (a.n - 8) / kChunk : 0;
+  if (fast_end > span.c1) fast_end = span.c1;
+  if (fast_end < span.c0) fast_end = span.c0;
+  const uint64_t lane_off = static_cast<uint64_t>(lane) * 16;
+  {
+    // the same 3-deep register pipeline as scan_windows
+    uint32_t b0[6], b1[6], b2[6];
+    uint64_t c = span.c0;
+    if (c < fast_end) load_chunk<true>(a.text, c * kChunk + lane_off, b0);
+    if (c + 1 < fast_end) load_chunk<true>(a.text, (c + 1) * kChunk + lane_off, b1);
+    if (c + 2 < fast_end) load_chunk<true>(a.text, (c + 2) * kChunk + lane_off, b2);
+    while (c + 5 < fast_end) {
+      fused_chunk(b0, c * kChunk + lane_off, a, counts, wave);
+      load_chunk<true>(a.text, (c + 3) * kChunk + lane_off, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      fused_chunk(b1, (c + 1) * kChunk + lane_off, a, counts, wave);
+      load_chunk<true>(a.text, (c + 4) * kChunk + lane_off, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      fused_chunk(b2, (c + 2) * kChunk + lane_off, a, counts, wave);
+      load_chunk<true>(a.text, (c + 5) * kChunk + lane_off, b2);
+      __builtin_amdgcn_sched_barrier(0);
+      c += 3;
+    }
+    if (c < fast_end) fused_chunk(b0, c * kChunk + lane_off, a, counts, wave);
+    if (c + 1 < fast_end) fused_chunk(b1, (c + 1) * kChunk + lane_off, a, counts, wave);
+    if (c + 2 < fast_end) fused_chunk(b2, (c + 2) * kChunk + lane_off, a, counts, wave);
+    for (c += 3; c < fast_end; c++) {
+      load_chunk<true>(a.text, c * kChunk + lane_off, b0);
+      fused_chunk(b0, c * kChunk + lane_off, a, counts, wave);
+    }
+  }
+  for (uint64_t t = fast_end; t < span.c1; t++) {
+    uint32_t d[6];
+    load_guarded(a.text, a.n, t * kChunk + lane_off, d);
+    fused_chunk(d, t * kChunk + lane_off, a, counts, wave);
+  }
+  if (lane < static_cast<int>(a.n_patterns) && a.region_cap[lane] != 0) a.hit_counts[lane][wave] = counts[lane];
+}
+
+// ---------------------------------------------------------------------------------------
 // Dense scan: every position s in [sb, se) that can start a match goes to the hit list.
 __global__ __launch_bounds__(256) void scan_dense(ScanParams a, DevProgram P) {
   __shared__ uint32_t fb[8];
@@ -1704,6 +1826,10 @@ void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows
     if (ws.masked) launch_windows_k<false, true, false, false>(n_windows, a, ws, grid, t0, t1, st);
     else launch_windows_k<false, false, false, false>(n_windows, a, ws, grid, t0, t1, st);
   }
+}
+
+void launch_scan_windows_fused(const FusedParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+  hipExtLaunchKernelGGL(scan_windows_fused, dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
 }
 
 void launch_scan_dense(const ScanParams& a, const DevProgram& P, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {

@@ -276,6 +276,43 @@ def test_match_all_batch_vs_per_text_oracle(rj, oracle):
         assert g == oracle.match_all(b"regexp", t)
 
 
+def test_fused_multi_pattern_equals_single_runs(rj):
+    """rj_multi: the nine regexdna patterns in one pass over the text give the spans of nine single
+    runs (SURVEY 8f-4 "fused vs unfused results identical"); a set with a pattern that cannot be
+    fused runs pattern by pattern; region overflow inside the fused kernel grows and reruns."""
+    import torch
+    from rejit_amd import workloads as W
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    progs = [rj.Program(rx) for rx in W.REGEXDNA_PATTERNS]
+    multi = rj.MultiScan(progs)
+    singles = [rj.Scan(p) for p in progs]
+    texts = [W.fasta_stripped_torch(50000, dev), W.fasta_stripped_torch(3000000, dev)]
+    # a text made of hits only: every region overflows its first capacity
+    dense = torch.from_numpy(np.frombuffer(b"agggtaaatttaccct" * 40000, dtype=np.uint8).copy()).to(dev)
+    texts.append(dense)
+    for t in texts:
+        n = int(t.numel())
+        counts = multi.run(t.data_ptr(), n, stream=st)
+        assert multi.fused
+        for i, sc in enumerate(singles):
+            c = sc.run(t.data_ptr(), n, stream=st)
+            assert counts[i] == c, (i, counts[i], c)
+            assert multi.scan(i).spans() == sc.spans(), i
+    assert multi.run(texts[0].data_ptr(), int(texts[0].numel()), stream=st) == [3, 12, 43, 27, 58, 16, 15, 18, 20]
+    # tiny and ragged sizes
+    for n in (0, 1, 15, 16, 17, 1023, 1025, 4099):
+        t = texts[1][1000:1000 + max(n, 1)].clone()
+        counts = multi.run(t.data_ptr(), n, stream=st)
+        assert counts == [sc.run(t.data_ptr(), n, stream=st) for sc in singles], n
+    mixed = [rj.Program(b"agggtaaa|tttaccct"), rj.Program(b"[cgt]+a"), rj.Program(b"regexp")]
+    m2 = rj.MultiScan(mixed)
+    t = texts[0]
+    counts = m2.run(t.data_ptr(), int(t.numel()), stream=st)
+    assert not m2.fused
+    assert counts == [rj.Scan(p).run(t.data_ptr(), int(t.numel()), stream=st) for p in mixed]
+
+
 def test_many_matches_large_path(rj, oracle):
     """More candidates than the LDS finalize holds: the rocPRIM sort path."""
     rng = random.Random(9)
