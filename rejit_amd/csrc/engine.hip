@@ -848,16 +848,16 @@ void nibble_window(const DevProgram& D, int k, uint32_t* value, uint32_t* mask) 
 
 struct rj_multi {
   std::vector<rj_scan*> scans;
-  std::vector<hipStream_t> streams;
-  hipEvent_t scan_done = nullptr;
   DeviceBuffer dummy_counts;  // hit_counts of the padding patterns
+  DeviceBuffer tails;         // MultiTail[P]
+  MultiTail* host_tails = nullptr;  // pinned
   bool fused = false;
   float scan_ms = 0.f;
 };
 
 namespace {
 
-// One fused scan + the per-pattern tails on their own streams.  Whole text, starts [0, n].
+// One fused scan + the tails of all patterns in two launches.  Whole text, starts [0, n].
 int run_fused(rj_multi* m, const uint8_t* d_text, uint64_t n, hipStream_t st) {
   const int P = static_cast<int>(m->scans.size());
   const uint64_t chunks = std::max<uint64_t>((n + 1023) / 1024, 1);
@@ -902,37 +902,39 @@ int run_fused(rj_multi* m, const uint8_t* d_text, uint64_t n, hipStream_t st) {
     }
     rj_scan* s0 = m->scans[0];
     launch_scan_windows_fused(fp, geo.grid, s0->ev[1], s0->ev[2], st);
-    RJ_HIP(hipEventRecord(m->scan_done, st));
-    // the single-pattern tail, pattern p on stream p (enqueued while the scan runs)
+    // the single-pattern tails (verify inside the regions, offsets + gather + check) of all patterns
+    // in two launches; their parameters travel as one small array
     for (int p = 0; p < P; p++) {
       rj_scan* s = m->scans[static_cast<size_t>(p)];
-      hipStream_t sp = m->streams[static_cast<size_t>(p)];
-      RJ_HIP(hipStreamWaitEvent(sp, m->scan_done, 0));
-      VerifyParams vp{};
-      vp.text = d_text;
-      vp.n = n;
-      vp.hits = s->hits.as<uint64_t>();
-      vp.n_regions = geo.n_regions;
-      vp.region_cap = static_cast<uint32_t>(caps[static_cast<size_t>(p)]);
-      vp.counters = s->counters.as<unsigned long long>();
-      vp.sb = 0;
-      vp.se = n + 1;
-      vp.expand = 1;
-      vp.float_max = s->prog->dev.float_max;
-      launch_verify_in_regions(vp, s->prog->dev, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(),
-                               s->cand_end.as<uint64_t>(), sp);
+      MultiTail& t = m->host_tails[p];
+      t = MultiTail{};
+      t.verify.text = d_text;
+      t.verify.n = n;
+      t.verify.hits = s->hits.as<uint64_t>();
+      t.verify.n_regions = geo.n_regions;
+      t.verify.region_cap = static_cast<uint32_t>(caps[static_cast<size_t>(p)]);
+      t.verify.counters = s->counters.as<unsigned long long>();
+      t.verify.sb = 0;
+      t.verify.se = n + 1;
+      t.verify.expand = 1;
+      t.verify.float_max = s->prog->dev.float_max;
+      t.program = s->prog->dev;
+      t.hit_counts = s->hit_counts.as<uint32_t>();
+      t.valid_counts = s->valid_counts.as<uint32_t>();
+      t.region_ends = s->cand_end.as<uint64_t>();
+      t.out = s->out.as<uint64_t>();
+      t.out_cap = s->out_cap;
+      t.host_counters = s->host_counters;
       s->host_counters[kCntUnordered] = 0;
       s->host_counters[kCntAdjacent] = 0;
-      launch_offsets_gather_check(s->valid_counts.as<uint32_t>(), s->hits.as<uint64_t>(), s->cand_end.as<uint64_t>(), geo.n_regions,
-                                  vp.region_cap, 0, s->out.as<uint64_t>(), s->out_cap, s->counters.as<unsigned long long>(),
-                                  s->host_counters, sp);
     }
+    RJ_HIP(hipMemcpyAsync(m->tails.p, m->host_tails, sizeof(MultiTail) * P, hipMemcpyHostToDevice, st));
+    launch_tails_multi(m->tails.as<MultiTail>(), P, geo.n_regions, st);
+    RJ_HIP(hipStreamSynchronize(st));
+    RJ_HIP(hipGetLastError());
     bool again = false;
     for (int p = 0; p < P; p++) {
       rj_scan* s = m->scans[static_cast<size_t>(p)];
-      hipStream_t sp = m->streams[static_cast<size_t>(p)];
-      RJ_HIP(hipStreamSynchronize(sp));
-      RJ_HIP(hipGetLastError());
       if (s->host_counters[kCntOverflow] != 0) {
         const uint64_t cap = caps[static_cast<size_t>(p)];
         const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(s->host_counters[kCntMaxRegion] * 2, cap * 4), geo.span_chunks * 1024);
@@ -945,7 +947,7 @@ int run_fused(rj_multi* m, const uint8_t* d_text, uint64_t n, hipStream_t st) {
     if (again) continue;
     for (int p = 0; p < P; p++) {
       rj_scan* s = m->scans[static_cast<size_t>(p)];
-      hipStream_t sp = m->streams[static_cast<size_t>(p)];
+      hipStream_t sp = st;  // (rare) selection kernels of one pattern after the other
       if (s->host_counters[kCntOverrun] != 0)
         return fail(RJ_TOO_LARGE, "a match candidate runs longer than %llu bytes", static_cast<unsigned long long>(kMaxSimSteps));
       s->hits_hint = s->host_counters[kCntHits];
@@ -1164,17 +1166,12 @@ int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out)
       return rc;
     }
     m->scans.push_back(s);
-    hipStream_t st = nullptr;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
-      rj_multi_destroy(m.release());
-      return fail(RJ_DEVICE_ERROR, "hipStreamCreate failed");
-    }
-    m->streams.push_back(st);
     all = all && fusable(progs[i]);
   }
-  if (hipEventCreateWithFlags(&m->scan_done, hipEventDisableTiming) != hipSuccess) {
+  if (m->tails.reserve(sizeof(MultiTail) * static_cast<size_t>(n_progs)) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&m->host_tails), sizeof(MultiTail) * static_cast<size_t>(n_progs)) != hipSuccess) {
     rj_multi_destroy(m.release());
-    return fail(RJ_DEVICE_ERROR, "hipEventCreate failed");
+    return fail(RJ_DEVICE_ERROR, "out of memory");
   }
   m->fused = all && n_progs > 1 && getenv("RJ_NO_FUSION") == nullptr;
   *out = m.release();
@@ -1185,9 +1182,7 @@ void rj_multi_destroy(rj_multi* m) {
   ErrnoGuard errno_guard;
   if (!m) return;
   for (rj_scan* s : m->scans) rj_scan_destroy(s);
-  for (hipStream_t st : m->streams)
-    if (st) (void)hipStreamDestroy(st);
-  if (m->scan_done) (void)hipEventDestroy(m->scan_done);
+  if (m->host_tails) (void)hipHostFree(m->host_tails);
   delete m;
 }
 

@@ -117,6 +117,20 @@ void launch_scan_dense_walk(const ScanParams& a, const DevProgram& P, int grid, 
 void launch_scan_dense(const ScanParams& a, const DevProgram& P, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 void launch_region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap, uint64_t* offsets,
                            unsigned long long* counters, hipStream_t st);
+// what verify_in_regions + offsets_gather_check need for one pattern; rj_multi runs the tails of all
+// its patterns in two launches (grid.y = pattern) from a device array of these
+struct MultiTail {
+  VerifyParams verify;
+  DevProgram program;
+  const uint32_t* hit_counts;
+  uint32_t* valid_counts;
+  uint64_t* region_ends;
+  uint64_t* out;
+  uint64_t out_cap;
+  unsigned long long* host_counters;
+};
+void launch_tails_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_regions, hipStream_t st);
+
 // windows mode, lane-sized automaton: verify + compact inside every region (16 lanes each), then
 // offsets_gather_check lays the survivors out
 void launch_verify_in_regions(const VerifyParams& a, const DevProgram& P, const uint32_t* hit_counts, uint32_t* valid_counts,

@@ -66,13 +66,30 @@ struct RegionHits {
   __device__ __forceinline__ void push_bits(uint32_t mask16, uint64_t at, uint64_t bias) {
     const int lane = lane_id();
     const uint32_t cnt = __popc(mask16);
-    uint32_t inc = cnt;
+    uint32_t inc, total;
+    uint64_t hitters = __ballot(cnt != 0);
+    if (__popcll(hitters) <= 4) {
+      // the usual case in window scans: a handful of lanes hold hits -- walk them (scalar loop,
+      // v_readlane) instead of a 6-step wave scan
+      uint32_t before = 0;
+      total = 0;
+      while (hitters) {
+        const int l = __builtin_ctzll(hitters);
+        hitters &= hitters - 1;
+        const uint32_t c = __builtin_amdgcn_readlane(cnt, l);
+        before += lane > l ? c : 0u;
+        total += c;
+      }
+      inc = before + cnt;
+    } else {
+      inc = cnt;
 #pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const uint32_t v = __shfl_up(inc, o);
-      if (lane >= o) inc += v;
+      for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+      }
+      total = __shfl(inc, kWave - 1);
     }
-    const uint32_t total = __shfl(inc, kWave - 1);
     uint32_t idx = count + inc - cnt;
     while (mask16) {
       const int j = __ffs(static_cast<int>(mask16)) - 1;
@@ -155,9 +172,18 @@ __device__ __forceinline__ void windows_chunk(const uint32_t (&d)[6], uint64_t a
     for (int j = 0; j < 16; j++) {
       pk[j] = x[j] | (x[j + 4] << 4);  // v_lshl_or_b32
 #pragma unroll
-      for (int k = 0; k < K; k++) {
-        uint32_t t = pk[j] ^ ws.value0[k];
-        if (MASKED) t &= ws.mask0[k];
+      for (int k = 0; k + 1 < K; k += 2) {  // two windows per v_min3_u32
+        uint32_t t0 = pk[j] ^ ws.value0[k], t1 = pk[j] ^ ws.value0[k + 1];
+        if (MASKED) {
+          t0 &= ws.mask0[k];
+          t1 &= ws.mask0[k + 1];
+        }
+        const uint32_t ab = accs[j & 3] < t0 ? accs[j & 3] : t0;
+        accs[j & 3] = ab < t1 ? ab : t1;
+      }
+      if (K & 1) {
+        uint32_t t = pk[j] ^ ws.value0[K - 1];
+        if (MASKED) t &= ws.mask0[K - 1];
         accs[j & 3] = accs[j & 3] < t ? accs[j & 3] : t;
       }
     }
@@ -336,7 +362,12 @@ __global__ __launch_bounds__(256) void scan_windows(ScanParams a, WindowSet ws) 
 // each pattern then costs two v_bitop3 + one v_min3 per position.  29 VALU per text byte for 9
 // patterns makes this kernel VALU-bound (~1.3 TB/s of text, i.e. ~12 TB/s of "pattern-bytes"),
 // but it moves 1/9 of the HBM bytes of nine separate scans.  Hits go to per-pattern regions, so
-// everything downstream is the single-pattern pipeline, run per pattern on its own stream.
+// everything downstream is the single-pattern pipeline (its kernels take grid.y = pattern).
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
+  const uint32_t ab = a < b ? a : b;
+  return ab < c ? ab : c;
+}
+
 __device__ __forceinline__ void fused_chunk(const uint32_t (&d)[6], uint64_t at, const FusedParams& a, uint32_t* counts,
                                             uint64_t wave) {
   uint32_t x[20];
@@ -356,21 +387,22 @@ __device__ __forceinline__ void fused_chunk(const uint32_t (&d)[6], uint64_t at,
 #pragma unroll
     for (int u = 0; u < kFuseGroup; u++) {
       const uint32_t v0 = a.value[g + u][0], m0 = a.mask[g + u][0], v1 = a.value[g + u][1], m1 = a.mask[g + u][1];
-      uint32_t c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu;
+      uint32_t c[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // independent chains
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const uint32_t t0 = (pk[j] ^ v0) & m0, t1 = (pk[j] ^ v1) & m1;
-        const uint32_t t = t0 < t1 ? t0 : t1;
-        if (j & 1) c1 = c1 < t ? c1 : t; else c0 = c0 < t ? c0 : t;
+        c[j & 3] = umin3(c[j & 3], t0, t1);  // one v_min3_u32 per position
       }
-      acc[u] = c0 < c1 ? c0 : c1;
+      acc[u] = umin3(c[0], c[1], c[2] < c[3] ? c[2] : c[3]);
     }
     uint32_t any = acc[0];
 #pragma unroll
     for (int u = 1; u < kFuseGroup; u++) any = any < acc[u] ? any : acc[u];
     if (__ballot(any == 0) == 0) continue;  // wave-uniform: no pattern of the group hits in this chunk
     // rare path, pattern by pattern
+#pragma unroll
     for (int u = 0; u < kFuseGroup; u++) {
+      if (__ballot(acc[u] == 0) == 0) continue;  // this pattern has no hit in the chunk
       const uint32_t p = g + u;
       const uint32_t v0 = a.value[p][0], m0 = a.mask[p][0], v1 = a.value[p][1], m1 = a.mask[p][1];
       uint32_t hm = 0;
@@ -379,16 +411,18 @@ __device__ __forceinline__ void fused_chunk(const uint32_t (&d)[6], uint64_t at,
         const uint32_t t0 = (pk[j] ^ v0) & m0, t1 = (pk[j] ^ v1) & m1;
         hm |= static_cast<uint32_t>((t0 < t1 ? t0 : t1) == 0) << j;
       }
-      if (__ballot(hm != 0) == 0) continue;
       // window positions of pattern p: w = s + offset, sb <= s < se, and the window must fit
       const uint64_t wlo = a.sb + a.offset[p];
       const uint64_t last_w = a.n >= a.len[p] ? a.n - a.len[p] + 1 : 0;
       uint64_t whi = a.se + a.offset[p];
       if (whi > last_w) whi = last_w;
+      const uint64_t chunk_base = at - static_cast<uint64_t>(lane_id()) * 16;
+      if (chunk_base < wlo || chunk_base + kChunk > whi) {  // only the first / last chunks of the range
 #pragma unroll
-      for (int j = 0; j < 16; j++) {
-        const uint64_t w = at + j;
-        if (w < wlo || w >= whi) hm &= ~(1u << j);
+        for (int j = 0; j < 16; j++) {
+          const uint64_t w = at + j;
+          if (w < wlo || w >= whi) hm &= ~(1u << j);
+        }
       }
       RegionHits hits{a.hits[p] + wave * a.region_cap[p], a.region_cap[p], counts[p]};
       hits.push_bits(hm, at, a.offset[p]);
@@ -719,8 +753,8 @@ __global__ __launch_bounds__(256) void verify_lane_regions(VerifyParams a, DevPr
 // of region_ends).  The count per region then drives offsets_gather_check, so the candidates need
 // no global compaction pass at all.
 template <int NQ>
-__global__ __launch_bounds__(256) void verify_in_regions(VerifyParams a, DevProgram P, const uint32_t* hit_counts,
-                                                         uint32_t* valid_counts, uint64_t* region_ends) {
+__device__ __forceinline__ void verify_in_regions_body(const VerifyParams& a, const DevProgram& P, const uint32_t* hit_counts,
+                                                       uint32_t* valid_counts, uint64_t* region_ends) {
   const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   const uint64_t n_groups = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 4;
   const int lane = lane_id(), sub = lane & 15, shift = lane & 48;
@@ -755,6 +789,20 @@ __global__ __launch_bounds__(256) void verify_in_regions(VerifyParams a, DevProg
   }
 }
 
+template <int NQ>
+__global__ __launch_bounds__(256) void verify_in_regions(VerifyParams a, DevProgram P, const uint32_t* hit_counts,
+                                                         uint32_t* valid_counts, uint64_t* region_ends) {
+  verify_in_regions_body<NQ>(a, P, hit_counts, valid_counts, region_ends);
+}
+
+// The tails of several patterns in one launch (rj_multi): blockIdx.y selects the pattern, whose
+// parameters are read from a device array.
+__global__ __launch_bounds__(256) void verify_in_regions_multi(const MultiTail* tails) {
+  const MultiTail& t = tails[blockIdx.y];
+  if (t.program.n_words <= 2) verify_in_regions_body<1>(t.verify, t.program, t.hit_counts, t.valid_counts, t.region_ends);
+  else verify_in_regions_body<2>(t.verify, t.program, t.hit_counts, t.valid_counts, t.region_ends);
+}
+
 // region offsets + gather + disjointness check in one multi-workgroup launch: workgroup b owns
 // regions [256 b, 256 b + 256), one per thread.  It sums the counts of ALL regions before its
 // own (<= 64 Ki counts, read as uint4 by 256 threads: cheaper than another launch, and no
@@ -765,11 +813,11 @@ __global__ __launch_bounds__(256) void verify_in_regions(VerifyParams a, DevProg
 // nearest non-empty region before it.  Otherwise counters[kCntUnordered] is set and the host
 // splits the pairs and runs the cluster-parallel selection.
 constexpr int kOgcThreads = 256;
-__global__ __launch_bounds__(kOgcThreads) void offsets_gather_check(const uint32_t* counts, const uint64_t* region_begins,
-                                                                    const uint64_t* region_ends, uint32_t n_regions,
-                                                                    uint32_t region_cap, uint64_t carry_cur, uint64_t* out,
-                                                                    uint64_t out_cap, unsigned long long* counters,
-                                                                    unsigned long long* host_counters) {
+__device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts, const uint64_t* region_begins,
+                                                          const uint64_t* region_ends, uint32_t n_regions,
+                                                          uint32_t region_cap, uint64_t carry_cur, uint64_t* out,
+                                                          uint64_t out_cap, unsigned long long* counters,
+                                                          unsigned long long* host_counters) {
   // Adjacency (a candidate begins exactly where an earlier one ends) is wanted for the Q8 check.
   // When the list is ordered and disjoint -- the only case in which this kernel's verdict is
   // used -- only neighbours can be adjacent, so comparing with the running maximum is exact.
@@ -895,6 +943,21 @@ __global__ __launch_bounds__(kOgcThreads) void offsets_gather_check(const uint32
       host_counters[kCntFinal] = 0;
     }
   }
+}
+
+__global__ __launch_bounds__(kOgcThreads) void offsets_gather_check(const uint32_t* counts, const uint64_t* region_begins,
+                                                                    const uint64_t* region_ends, uint32_t n_regions,
+                                                                    uint32_t region_cap, uint64_t carry_cur, uint64_t* out,
+                                                                    uint64_t out_cap, unsigned long long* counters,
+                                                                    unsigned long long* host_counters) {
+  offsets_gather_check_body(counts, region_begins, region_ends, n_regions, region_cap, carry_cur, out, out_cap, counters,
+                            host_counters);
+}
+
+__global__ __launch_bounds__(kOgcThreads) void offsets_gather_check_multi(const MultiTail* tails) {
+  const MultiTail& t = tails[blockIdx.y];
+  offsets_gather_check_body(t.valid_counts, t.verify.hits, t.region_ends, t.verify.n_regions, t.verify.region_cap, 0, t.out,
+                            t.out_cap, t.verify.counters, t.host_counters);
 }
 
 // pairs -> begin[] / end[] for the selection kernels (only when the pairs are not the result yet)
@@ -1913,6 +1976,14 @@ void launch_offsets_gather_check(const uint32_t* counts, const uint64_t* region_
   const unsigned blocks = n_regions ? (n_regions + kOgcThreads - 1) / kOgcThreads : 1u;
   hipLaunchKernelGGL(offsets_gather_check, dim3(blocks), dim3(kOgcThreads), 0, st, counts, region_begins, region_ends, n_regions,
                      region_cap, carry_cur, out, out_cap, counters, host_counters);
+}
+
+void launch_tails_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_regions, hipStream_t st) {
+  uint64_t vblocks = (static_cast<uint64_t>(n_regions) + 15) / 16;
+  vblocks = vblocks < 1 ? 1 : vblocks > 4096 ? 4096 : vblocks;
+  hipLaunchKernelGGL(verify_in_regions_multi, dim3(static_cast<unsigned>(vblocks), n_patterns), dim3(256), 0, st, d_tails);
+  const unsigned gblocks = n_regions ? (n_regions + kOgcThreads - 1) / kOgcThreads : 1u;
+  hipLaunchKernelGGL(offsets_gather_check_multi, dim3(gblocks, n_patterns), dim3(kOgcThreads), 0, st, d_tails);
 }
 
 void launch_split_pairs(const uint64_t* pairs, const unsigned long long* n_ptr, uint64_t n_upper, uint64_t* keys, uint64_t* vals,
