@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """regex-dna on the GPU: counterpart of the reference's sample/regexdna.cc:25-94 with the text
 kept in HBM for the whole program -- one upload, strip (`>.*\\n|\\n` -> ""), nine
-MatchAllCount, eleven ReplaceAll (IUB codes), three sizes printed -- through the C ABI
-(rj_scan_run / rj_scan_replace).  The reference's own sample also runs unchanged on
+MatchAllCount (one fused pass, rj_multi_run), eleven ReplaceAll (IUB codes), three sizes printed --
+through the C ABI (rj_scan_run / rj_scan_replace / rj_multi_run).  The reference's own sample also runs unchanged on
 librejit_hip.so (oracle/_ref/regexdna_hip), but pays a PCIe round trip per call.
 
     python samples/regexdna_gpu.py < input.fasta
@@ -45,10 +45,10 @@ def main():
     t0 = time.perf_counter()
     text, n = replace_all(text, raw_size, W.REGEXDNA_STRIP, b"")
     text_size = n
-    lines = []
-    for rx in W.REGEXDNA_PATTERNS:
-        sc = rejit_amd.Scan(rejit_amd.Program(rx))
-        lines.append("%s %d" % (rx, sc.run(text.data_ptr(), n, stream=stream)))
+    # the nine counts share one pass over the text (rj_multi, fused window scan)
+    multi = rejit_amd.MultiScan([rejit_amd.Program(rx) for rx in W.REGEXDNA_PATTERNS])
+    counts = multi.run(text.data_ptr(), n, stream=stream)
+    lines = ["%s %d" % (rx, c) for rx, c in zip(W.REGEXDNA_PATTERNS, counts)]
     for code, repl in W.REGEXDNA_IUB:
         text, n = replace_all(text, n, code, repl.encode())
     torch.cuda.synchronize()
