@@ -455,6 +455,28 @@ int resolve_selection(rj_scan* s, const FinalizeParams& fp, hipStream_t st) {
     s->result_count = n_cands;
     return RJ_OK;
   }
+  if (n_cands <= kFinalizeCap) {
+    // few candidates: one workgroup sorts (a no-op here), deduplicates and selects in LDS
+    FinalizeParams f = fp;
+    f.cand_begin = keys;
+    f.cand_end = vals;
+    f.cands_cap = n_cands;
+    f.out = s->out.as<uint64_t>();
+    f.out_cap = s->out_cap;
+    f.counters = s->counters.as<unsigned long long>();
+    f.detect_adjacent = 0;
+    f.expand = 1;
+    unsigned long long* scratch = reinterpret_cast<unsigned long long*>(s->host_flag);  // pinned, 16 bytes
+    *scratch = n_cands;  // finalize_small takes its slot count from counters[kCntHits]
+    RJ_HIP(hipMemcpyAsync(s->counters.as<unsigned long long>() + kCntHits, scratch, sizeof(unsigned long long),
+                          hipMemcpyHostToDevice, st));
+    launch_finalize_small(f, st);
+    RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    RJ_HIP(hipStreamSynchronize(st));
+    RJ_HIP(hipGetLastError());
+    s->result_count = s->host_counters[kCntFinal];
+    return RJ_OK;
+  }
   // general case: cluster-parallel selection
   RJ_HIP(s->scan_a.reserve(n_cands * sizeof(uint64_t)));
   RJ_HIP(s->scan_b.reserve(n_cands * sizeof(uint64_t)));
@@ -533,13 +555,14 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
 
   // fixed windows + an automaton that fits a lane: candidates are verified and compacted inside
   // their hit regions (no global compaction, no sort)
-  const bool in_regions = (windows && expand == 1 && D.n_words <= 4) || dense_walk;
+  const bool floating_regions = windows && expand > 1 && D.n_words <= 4 && getenv("RJ_NO_FLOAT_REGIONS") == nullptr;
+  const bool in_regions = (windows && D.n_words <= 4 && (expand == 1 || floating_regions)) || dense_walk;
 
   for (int attempt = 0; attempt < 6; attempt++) {
     const uint64_t slots = static_cast<uint64_t>(geo.n_regions) * region_cap;
     // candidate slots: one per (hit, possible start); floating windows start with room for a few
     // thousand hits and grow when a run needs more
-    uint64_t cand_slots = expand == 1 ? slots : std::max<uint64_t>(s->hits_hint * expand * 2, 1u << 16);
+    uint64_t cand_slots = (expand == 1 || floating_regions) ? slots : std::max<uint64_t>(s->hits_hint * expand * 2, 1u << 16);
     int rc = ensure_lists(s, geo.n_regions, static_cast<uint32_t>(region_cap), std::max<uint64_t>(cand_slots, 1u << 12));
     if (rc != RJ_OK) return rc;
     if (in_regions) RJ_HIP(s->valid_counts.reserve(static_cast<size_t>(geo.n_regions) * sizeof(uint32_t)));
@@ -624,7 +647,7 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
       return fail(RJ_TOO_LARGE, "patterns of more than 128 positions without a fast-forward window are limited to 16 MiB "
                                 "of text per call (one wave per candidate start)");
     vp.float_max = D.float_max;
-    if (expand > 1) {
+    if (expand > 1 && !floating_regions) {
       // the slot count depends on the hit count, which only the device knows yet: verify must not
       // write past the candidate arrays, so floating runs read the count first (hits are rare)
       RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -640,14 +663,20 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
     if (in_regions) {
       // verify + compact inside the regions, lay the survivors out, check / select: one sync
       // (verifying at the tail of the scan kernel instead was measured: 5 us slower per pass)
-      if (!dense_walk)
+      const uint64_t* begins = s->hits.as<uint64_t>();
+      if (floating_regions) {
+        launch_verify_floating_in_regions(vp, D, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(),
+                                          s->cand_begin.as<uint64_t>(), s->cand_end.as<uint64_t>(), st);
+        begins = s->cand_begin.as<uint64_t>();
+      } else if (!dense_walk) {
         launch_verify_in_regions(vp, D, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(), s->cand_end.as<uint64_t>(), st);
+      }
       const uint32_t* survivors = dense_walk ? s->hit_counts.as<uint32_t>() : s->valid_counts.as<uint32_t>();
       // (letting the last workgroup publish the counters to pinned host memory instead of the copy
       // below was measured: slower, its agent-scope fence writes L2 back)
       s->host_counters[kCntUnordered] = 0;  // the kernel below writes the pinned block itself
       s->host_counters[kCntAdjacent] = 0;
-      launch_offsets_gather_check(survivors, s->hits.as<uint64_t>(), s->cand_end.as<uint64_t>(), geo.n_regions,
+      launch_offsets_gather_check(survivors, begins, s->cand_end.as<uint64_t>(), geo.n_regions,
                                   static_cast<uint32_t>(region_cap), fp.carry_cur, s->out.as<uint64_t>(), s->out_cap,
                                   s->counters.as<unsigned long long>(), s->host_counters, st);
       RJ_HIP(hipStreamSynchronize(st));

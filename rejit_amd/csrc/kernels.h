@@ -135,6 +135,10 @@ void launch_tails_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_reg
 // offsets_gather_check lays the survivors out
 void launch_verify_in_regions(const VerifyParams& a, const DevProgram& P, const uint32_t* hit_counts, uint32_t* valid_counts,
                               uint64_t* region_ends, hipStream_t st);
+// floating windows: the candidate starts of every hit (ranges clipped so that each start is verified
+// once, in order); survivors go to region_begins / region_ends
+void launch_verify_floating_in_regions(const VerifyParams& a, const DevProgram& P, const uint32_t* hit_counts,
+                                       uint32_t* valid_counts, uint64_t* region_begins, uint64_t* region_ends, hipStream_t st);
 // region offsets + gather + check_and_interleave in one launch (see the kernel); host_counters
 // (pinned, may be null) receives the counter block directly
 void launch_offsets_gather_check(const uint32_t* counts, const uint64_t* region_begins, const uint64_t* region_ends,

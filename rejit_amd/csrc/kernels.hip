@@ -752,6 +752,25 @@ __global__ __launch_bounds__(256) void verify_lane_regions(VerifyParams a, DevPr
 // hits and compact the survivors IN PLACE (begins stay in the region, ends go to the same slot
 // of region_ends).  The count per region then drives offsets_gather_check, so the candidates need
 // no global compaction pass at all.
+// Copy the automaton tables into LDS (dynamic shared memory, `lds_words` = 0 when they do not fit)
+// and return a descriptor whose table pointers point there: the per-lane walk then reads LDS
+// instead of chasing global loads (every step is a chain of dependent table reads).
+__device__ __forceinline__ DevProgram stage_tables(const DevProgram& P, uint32_t* tab, uint32_t lds_words) {
+  DevProgram Q = P;
+  if (lds_words >= P.table_words) {
+    for (uint32_t i = threadIdx.x; i < P.table_words; i += blockDim.x) tab[i] = P.first[i];
+    const int W = P.n_words, C = P.n_ctx, NP = P.n_pos > 0 ? P.n_pos : 1;
+    Q.first = tab;
+    Q.last = tab + C * W;
+    Q.linear = tab + 2 * C * W;
+    Q.row_of = reinterpret_cast<const int32_t*>(tab + 2 * C * W + W);
+    Q.rows = tab + 2 * C * W + W + NP;
+    Q.cls = tab + 2 * C * W + W + NP + C * P.n_rows * W;
+  }
+  __syncthreads();
+  return Q;
+}
+
 template <int NQ>
 __device__ __forceinline__ void verify_in_regions_body(const VerifyParams& a, const DevProgram& P, const uint32_t* hit_counts,
                                                        uint32_t* valid_counts, uint64_t* region_ends) {
@@ -793,6 +812,79 @@ template <int NQ>
 __global__ __launch_bounds__(256) void verify_in_regions(VerifyParams a, DevProgram P, const uint32_t* hit_counts,
                                                          uint32_t* valid_counts, uint64_t* region_ends) {
   verify_in_regions_body<NQ>(a, P, hit_counts, valid_counts, region_ends);
+}
+
+// Floating windows (a hit at w makes every s in [w - float_max, w - float_min] a candidate start):
+// the same in-region scheme.  The start ranges of consecutive hits are clipped against each other
+// -- also across regions, against the last hit of the nearest non-empty region before -- so every
+// start is verified once and the survivors come out sorted by begin; they go to separate arrays
+// (one hit can yield several candidates, so compacting in place could overtake unread hits).
+template <int NQ>
+__global__ __launch_bounds__(256) void verify_floating_in_regions(VerifyParams a, DevProgram P, const uint32_t* hit_counts,
+                                                                  uint32_t* valid_counts, uint64_t* region_begins,
+                                                                  uint64_t* region_ends, uint32_t float_min,
+                                                                  uint32_t lds_words) {
+  extern __shared__ uint32_t tab[];
+  const DevProgram Q = stage_tables(P, tab, lds_words);
+  const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  // a whole wave per region: one hit has up to 256 starts and every walk is a chain of dependent
+  // steps, so the width of a round is what bounds the kernel's latency (16 lanes: 126 us at 1000 hits)
+  const uint64_t n_groups = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+  const int sub = lane_id();
+  for (uint64_t r = tid >> 6; r < a.n_regions; r += n_groups) {
+    const uint32_t raw = hit_counts[r];
+    const uint32_t cnt = raw < a.region_cap ? raw : a.region_cap;
+    if (raw > a.region_cap && sub == 0) {
+      a.counters[kCntOverflow] = 1;
+      atomicMax(&a.counters[kCntMaxRegion], static_cast<unsigned long long>(raw));
+    }
+    if (cnt == 0) {
+      if (sub == 0) valid_counts[r] = 0;
+      continue;
+    }
+    // first start not yet covered by an earlier hit.  Start ranges are at most 256 wide
+    // (lowering.cc: plan_floating) and a region spans >= 1 KiB, so of all earlier hits only the
+    // last one of the region right before can reach into this region's ranges.
+    uint64_t next_lo = a.sb;
+    if (r > 0) {
+      const uint32_t c = hit_counts[r - 1];
+      if (c != 0) {
+        const uint64_t w = a.hits[(r - 1) * a.region_cap + (c < a.region_cap ? c : a.region_cap) - 1];
+        if (w >= float_min && w - float_min + 1 > next_lo) next_lo = w - float_min + 1;
+      }
+    }
+    const uint64_t* region = a.hits + r * a.region_cap;
+    uint64_t* begins = region_begins + r * a.region_cap;
+    uint64_t* ends = region_ends + r * a.region_cap;
+    uint32_t kept = 0;
+    for (uint32_t i = 0; i < cnt; i++) {
+      const uint64_t w = region[i];
+      if (w < float_min) continue;
+      const uint64_t hi = w - float_min;                       // last start of this hit
+      uint64_t lo = w >= a.float_max ? w - a.float_max : 0;    // first
+      if (lo < next_lo) lo = next_lo;
+      for (uint64_t base = lo; base <= hi; base += kWave) {
+        const uint64_t s = base + sub;
+        uint64_t e = 0;
+        bool overrun = false;
+        const bool found = s <= hi && s >= a.sb && s < a.se && rj_lane_longest<NQ>(Q, a.text, a.n, s, &e, &overrun);
+        if (overrun) a.counters[kCntOverrun] = 1;
+        const uint64_t mine = __ballot(found);
+        const uint32_t pos = kept + __popcll(mine & ((1ull << sub) - 1ull));
+        if (found && pos < a.region_cap) {
+          begins[pos] = s;
+          ends[pos] = e;
+        }
+        kept += __popcll(mine);
+      }
+      if (hi + 1 > next_lo) next_lo = hi + 1;
+    }
+    if (kept > a.region_cap && sub == 0) {  // more candidates than the region holds: grow and run again
+      a.counters[kCntOverflow] = 1;
+      atomicMax(&a.counters[kCntMaxRegion], static_cast<unsigned long long>(kept));
+    }
+    if (sub == 0) valid_counts[r] = kept < a.region_cap ? kept : a.region_cap;
+  }
 }
 
 // The tails of several patterns in one launch (rj_multi): blockIdx.y selects the pattern, whose
@@ -1976,6 +2068,21 @@ void launch_offsets_gather_check(const uint32_t* counts, const uint64_t* region_
   const unsigned blocks = n_regions ? (n_regions + kOgcThreads - 1) / kOgcThreads : 1u;
   hipLaunchKernelGGL(offsets_gather_check, dim3(blocks), dim3(kOgcThreads), 0, st, counts, region_begins, region_ends, n_regions,
                      region_cap, carry_cur, out, out_cap, counters, host_counters);
+}
+
+void launch_verify_floating_in_regions(const VerifyParams& a, const DevProgram& P, const uint32_t* hit_counts,
+                                       uint32_t* valid_counts, uint64_t* region_begins, uint64_t* region_ends, hipStream_t st) {
+  uint64_t blocks = (static_cast<uint64_t>(a.n_regions) + 3) / 4;  // a wave per region
+  blocks = blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks;
+  const uint32_t float_min = P.float_max + 1 - P.float_range;
+  const uint32_t lds_words = P.table_words <= 12288 ? P.table_words : 0;
+  const size_t lds = static_cast<size_t>(lds_words) * sizeof(uint32_t);
+  if (P.n_words <= 2)
+    hipLaunchKernelGGL((verify_floating_in_regions<1>), dim3(static_cast<unsigned>(blocks)), dim3(256), lds, st, a, P,
+                       hit_counts, valid_counts, region_begins, region_ends, float_min, lds_words);
+  else
+    hipLaunchKernelGGL((verify_floating_in_regions<2>), dim3(static_cast<unsigned>(blocks)), dim3(256), lds, st, a, P,
+                       hit_counts, valid_counts, region_begins, region_ends, float_min, lds_words);
 }
 
 void launch_tails_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_regions, hipStream_t st) {
