@@ -1843,7 +1843,10 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
           cursor += __popcll(idle);
           if (cursor > total) cursor = total;
         }
-        if (__ballot(active) == 0) break;
+        if (__ballot(active) == 0) {
+          if (cursor >= total) break;
+          continue;  // a whole round of entries was already decided by the pre-steps: hand out the next
+        }
         if (active) {
           uint32_t alive = 0;
 #pragma unroll

@@ -85,6 +85,29 @@ def test_fresh_random_vs_oracle(rj, oracle):
     assert exact > 0   # the artefact does occur in this sample, and is reproduced
 
 
+def test_fresh_random_multi_chunk_vs_oracle(rj, oracle):
+    """The same generator over texts of several 1-KiB chunks, so that the full-chunk fast paths
+    (register pre-steps, pipelined scan loop, halos, wave edges, walker refill) are compared with
+    the oracle on arbitrary patterns, not only the guarded tail chunk.  (tools/fuzz_large.py runs
+    thousands of these; a lost pair of matches at every chunk edge was found that way.)"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import RegexGen, ALPHABETS
+    rng = random.Random(90125)
+    checked = 0
+    for _ in range(500):
+        alphabet = rng.choice(ALPHABETS)
+        rx = RegexGen(rng, alphabet).alt(2).encode("latin1")
+        n = rng.choice([1500, 2047, 2048, 2053, 3100, 4096, 5000])
+        text = "".join(rng.choice(alphabet) for _ in range(n)).encode("latin1")
+        want = oracle.match_all(rx, text)
+        if isinstance(want, int):
+            continue
+        assert prog(rj, rx).match_all(text) == want, (rx, n)
+        checked += 1
+    assert checked > 450
+
+
 def test_testcc_expectations(rj):
     """The expectations written in the reference's test.cc, for every match type."""
     for v in V.testcc():
@@ -198,6 +221,8 @@ def test_dense_walk_kernel_shapes(rj, oracle):
         (b"[a-p]", A + B),                           # every position matches: regions overflow and grow
         (b"[a-p]+", A + B + b"z"),
         (b"([a-h]|[i-p][i-p])+[a-h]", A + B),        # general follow rows
+        (b"[a-h][ ]?", A),                           # every start decided by the pre-steps except the wave's last two
+        (b"[^ ]{1,2}", A),
     ]
     n_dense = 0
     for rx, alphabet in cases:
