@@ -115,6 +115,13 @@ def load_library():
         return _lib
     if not os.path.exists(LIB):
         raise FileNotFoundError(f"{LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    try:
+        # PyTorch ships its own copy of the HIP runtime.  If librejit_hip.so (linked against
+        # /opt/rocm's) is loaded first, the process ends up with two runtimes and the later one sees
+        # no device; loading torch first makes both use the one runtime.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB)
     vp, cp, sz, i64, u64 = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_uint64
     L.rj_compile.restype = ctypes.c_int
