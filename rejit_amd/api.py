@@ -47,7 +47,8 @@ def _stale() -> bool:
     if not os.path.exists(LIB) or not os.path.exists(HASH):
         return True
     try:
-        return open(HASH).read().strip() != _source_hash()
+        with open(HASH) as fh:
+            return fh.read().strip() != _source_hash()
     except OSError:
         return True
 

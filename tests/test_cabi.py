@@ -20,7 +20,8 @@ def lib():
 
 
 def test_exports_match_header(lib):
-    header = open(os.path.join(ROOT, "include", "rejit_hip.h")).read()
+    with open(os.path.join(ROOT, "include", "rejit_hip.h")) as fh:
+        header = fh.read()
     declared = set(re.findall(r"\b(rj_[a-z_]+)\s*\(", header))
     assert declared == set(C_ABI_SYMBOLS), declared ^ set(C_ABI_SYMBOLS)
     for sym in declared:
@@ -63,5 +64,6 @@ def test_product_does_not_reference_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "rejit_amd")):
         for f in files:
             if f.endswith((".py", ".cc", ".h", ".hip")):
-                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                with open(os.path.join(dirpath, f), errors="ignore") as fh:
+                    src = fh.read()
                 assert "rejit_oracle" not in src and "librejit_ref" not in src and "oracle/" not in src, f
