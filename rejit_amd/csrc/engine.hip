@@ -1338,9 +1338,11 @@ int64_t rj_match_all_batch(const rj_program* prog, const char* const* texts, con
     s->pinned_cap = want;
   }
   const char sep = static_cast<char>(prog->batch_separator);
+  RJ_HIP(s->text.reserve(((total_bytes + 64 + 4095) / 4096) * 4096));
   {
-    // packing is a host memcpy of the whole batch: spread it over a few threads (one core moves
-    // ~10 GB/s, PCIe takes 50+), split by bytes
+    // Packing is a host memcpy of the whole batch (one core moves ~10 GB/s, PCIe takes 50+): it is
+    // spread over a few threads and done slice by slice, each slice's DMA starting as soon as it is
+    // packed, so packing slice k+1 overlaps the upload of slice k.
     const unsigned n_thr = total_bytes > (8u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
     auto pack = [&](size_t first, size_t last) {
       for (size_t i = first; i < last; i++) {
@@ -1348,24 +1350,32 @@ int64_t rj_match_all_batch(const rj_program* prog, const char* const* texts, con
         s->pinned[off[i] + sizes[i]] = sep;
       }
     };
-    if (n_thr == 1) {
-      pack(0, n_texts);
-    } else {
-      std::vector<std::thread> pool;
-      size_t first = 0;
-      for (unsigned t = 0; t < n_thr; t++) {
-        const uint64_t upto = total_bytes * (t + 1) / n_thr;
-        size_t last = first;
-        while (last < n_texts && off[last] < upto) last++;
-        if (t + 1 == n_thr) last = n_texts;
-        pool.emplace_back(pack, first, last);
-        first = last;
+    constexpr uint64_t kSlice = 64ull << 20;
+    size_t first = 0;
+    while (first < n_texts) {
+      // texts [first, last) make up about one slice
+      size_t last = first;
+      while (last < n_texts && off[last] - off[first] < kSlice) last++;
+      const uint64_t lo = off[first], hi = off[last];
+      if (n_thr == 1 || hi - lo < (8u << 20)) {
+        pack(first, last);
+      } else {
+        std::vector<std::thread> pool;
+        size_t f = first;
+        for (unsigned t = 0; t < n_thr; t++) {
+          const uint64_t upto = lo + (hi - lo) * (t + 1) / n_thr;
+          size_t l = f;
+          while (l < last && off[l] < upto) l++;
+          if (t + 1 == n_thr) l = last;
+          pool.emplace_back(pack, f, l);
+          f = l;
+        }
+        for (auto& th : pool) th.join();
       }
-      for (auto& th : pool) th.join();
+      RJ_HIP(hipMemcpyAsync(static_cast<char*>(s->text.p) + lo, s->pinned + lo, hi - lo, hipMemcpyHostToDevice, s->own_stream));
+      first = last;
     }
   }
-  RJ_HIP(s->text.reserve(((total_bytes + 64 + 4095) / 4096) * 4096));
-  RJ_HIP(hipMemcpyAsync(s->text.p, s->pinned, total_bytes, hipMemcpyHostToDevice, s->own_stream));
   rc = run_pipeline(s, s->text.as<uint8_t>(), n, 0, n + 1, 0, 0, 0, s->own_stream);
   if (rc != RJ_OK) return rc;
   const uint64_t m = s->result_count;
