@@ -316,33 +316,39 @@ __global__ __launch_bounds__(256) void scan_windows(ScanParams a, WindowSet ws) 
   const uint64_t lane_off = static_cast<uint64_t>(lane) * 16;
 
   // Software-pipelined streaming loop, three register buffers deep: while chunk c is compared
-  // the loads of chunks c+1 and c+2 are in flight (3 KiB per wave).  The steady loop runs only
-  // while all three prefetch targets exist, so its loads are unconditional and the compiler
-  // waits for exactly the buffer it needs (vmcnt(4)); the last <= 5 chunks of the span are
-  // drained without prefetch, so no byte is loaded twice.
+  // the loads of chunks c+1 and c+2 are in flight (3 KiB per wave).  The prologue and the steady
+  // loop run only when all their loads exist, so every load is unconditional and the compiler can
+  // count them: it waits for exactly the buffer it needs (vmcnt(4)).  A conditional prologue
+  // ("load b1 if it exists") made the count at the loop head ambiguous and the compiler waited for
+  // ALL loads there -- including the one issued just before the back edge, i.e. a full memory
+  // latency exposed every third chunk.  Spans shorter than 6 chunks and the last <= 2 chunks of a
+  // span take the plain loop below; no byte is loaded twice.
   {
     uint32_t b0[6], b1[6], b2[6];
     uint64_t c = span.c0;
-    if (c < fast_end) load_chunk<TWO>(a.text, c * kChunk + lane_off, b0);
-    if (c + 1 < fast_end) load_chunk<TWO>(a.text, (c + 1) * kChunk + lane_off, b1);
-    if (c + 2 < fast_end) load_chunk<TWO>(a.text, (c + 2) * kChunk + lane_off, b2);
-    while (c + 5 < fast_end) {
+    if (c + 5 < fast_end) {
+      load_chunk<TWO>(a.text, c * kChunk + lane_off, b0);
+      load_chunk<TWO>(a.text, (c + 1) * kChunk + lane_off, b1);
+      load_chunk<TWO>(a.text, (c + 2) * kChunk + lane_off, b2);
+      while (c + 5 < fast_end) {
+        windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b0, c * kChunk + lane_off, a, ws, hits);
+        load_chunk<TWO>(a.text, (c + 3) * kChunk + lane_off, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b1, (c + 1) * kChunk + lane_off, a, ws, hits);
+        load_chunk<TWO>(a.text, (c + 4) * kChunk + lane_off, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b2, (c + 2) * kChunk + lane_off, a, ws, hits);
+        load_chunk<TWO>(a.text, (c + 5) * kChunk + lane_off, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        c += 3;
+      }
+      // b0..b2 hold chunks c, c+1, c+2 (the loads of the last iteration, all inside the span)
       windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b0, c * kChunk + lane_off, a, ws, hits);
-      load_chunk<TWO>(a.text, (c + 3) * kChunk + lane_off, b0);
-      __builtin_amdgcn_sched_barrier(0);
       windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b1, (c + 1) * kChunk + lane_off, a, ws, hits);
-      load_chunk<TWO>(a.text, (c + 4) * kChunk + lane_off, b1);
-      __builtin_amdgcn_sched_barrier(0);
       windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b2, (c + 2) * kChunk + lane_off, a, ws, hits);
-      load_chunk<TWO>(a.text, (c + 5) * kChunk + lane_off, b2);
-      __builtin_amdgcn_sched_barrier(0);
       c += 3;
     }
-    // drain: b0..b2 hold chunks c, c+1, c+2 (where they exist), then <= 2 more
-    if (c < fast_end) windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b0, c * kChunk + lane_off, a, ws, hits);
-    if (c + 1 < fast_end) windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b1, (c + 1) * kChunk + lane_off, a, ws, hits);
-    if (c + 2 < fast_end) windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b2, (c + 2) * kChunk + lane_off, a, ws, hits);
-    for (c += 3; c < fast_end; c++) {
+    for (; c < fast_end; c++) {
       load_chunk<TWO>(a.text, c * kChunk + lane_off, b0);
       windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b0, c * kChunk + lane_off, a, ws, hits);
     }
@@ -452,28 +458,31 @@ __global__ __launch_bounds__(256) void scan_windows_fused(FusedParams a) {
   if (fast_end < span.c0) fast_end = span.c0;
   const uint64_t lane_off = static_cast<uint64_t>(lane) * 16;
   {
-    // the same 3-deep register pipeline as scan_windows
+    // the same 3-deep register pipeline as scan_windows (unconditional prologue, see there)
     uint32_t b0[6], b1[6], b2[6];
     uint64_t c = span.c0;
-    if (c < fast_end) load_chunk<true>(a.text, c * kChunk + lane_off, b0);
-    if (c + 1 < fast_end) load_chunk<true>(a.text, (c + 1) * kChunk + lane_off, b1);
-    if (c + 2 < fast_end) load_chunk<true>(a.text, (c + 2) * kChunk + lane_off, b2);
-    while (c + 5 < fast_end) {
+    if (c + 5 < fast_end) {
+      load_chunk<true>(a.text, c * kChunk + lane_off, b0);
+      load_chunk<true>(a.text, (c + 1) * kChunk + lane_off, b1);
+      load_chunk<true>(a.text, (c + 2) * kChunk + lane_off, b2);
+      while (c + 5 < fast_end) {
+        fused_chunk(b0, c * kChunk + lane_off, a, counts, wave);
+        load_chunk<true>(a.text, (c + 3) * kChunk + lane_off, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        fused_chunk(b1, (c + 1) * kChunk + lane_off, a, counts, wave);
+        load_chunk<true>(a.text, (c + 4) * kChunk + lane_off, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        fused_chunk(b2, (c + 2) * kChunk + lane_off, a, counts, wave);
+        load_chunk<true>(a.text, (c + 5) * kChunk + lane_off, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        c += 3;
+      }
       fused_chunk(b0, c * kChunk + lane_off, a, counts, wave);
-      load_chunk<true>(a.text, (c + 3) * kChunk + lane_off, b0);
-      __builtin_amdgcn_sched_barrier(0);
       fused_chunk(b1, (c + 1) * kChunk + lane_off, a, counts, wave);
-      load_chunk<true>(a.text, (c + 4) * kChunk + lane_off, b1);
-      __builtin_amdgcn_sched_barrier(0);
       fused_chunk(b2, (c + 2) * kChunk + lane_off, a, counts, wave);
-      load_chunk<true>(a.text, (c + 5) * kChunk + lane_off, b2);
-      __builtin_amdgcn_sched_barrier(0);
       c += 3;
     }
-    if (c < fast_end) fused_chunk(b0, c * kChunk + lane_off, a, counts, wave);
-    if (c + 1 < fast_end) fused_chunk(b1, (c + 1) * kChunk + lane_off, a, counts, wave);
-    if (c + 2 < fast_end) fused_chunk(b2, (c + 2) * kChunk + lane_off, a, counts, wave);
-    for (c += 3; c < fast_end; c++) {
+    for (; c < fast_end; c++) {
       load_chunk<true>(a.text, c * kChunk + lane_off, b0);
       fused_chunk(b0, c * kChunk + lane_off, a, counts, wave);
     }
