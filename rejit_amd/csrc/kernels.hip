@@ -149,28 +149,30 @@ __device__ __forceinline__ void load_guarded(const uint8_t* text, uint64_t n, ui
 template <int K, bool TWO, bool MASKED, bool TWOLEVEL, bool NIB>
 __device__ __forceinline__ void windows_chunk(const uint32_t (&d)[6], uint64_t at, const ScanParams& a,
                                               const WindowSet& ws, RegionHits& hits) {
-  constexpr int NX = TWO ? 20 : 16;  // windows needed: 16 positions (+4 for the second dword)
-  // the unaligned 4-byte windows of this lane: x[j] = bytes [at+j, at+j+4)
-  uint32_t x[NX];
-#pragma unroll
-  for (int q = 0; q < NX / 4; q++) {
-    // nibble filter: keep only the low nibble of every byte ...
-    const uint32_t lo = NIB ? (d[q] & 0x0F0F0F0Fu) : d[q], hi = NIB ? (d[q + 1] & 0x0F0F0F0Fu) : d[q + 1];
-    x[4 * q] = lo;
-    x[4 * q + 1] = __builtin_amdgcn_alignbyte(hi, lo, 1);
-    x[4 * q + 2] = __builtin_amdgcn_alignbyte(hi, lo, 2);
-    x[4 * q + 3] = __builtin_amdgcn_alignbyte(hi, lo, 3);
-  }
   if (NIB) {
-    // ... so that the 8 bytes of a window pack into ONE dword, pk = x[j] | x[j+4] << 4, and a
-    // window costs one v_bitop3 ((pk ^ value) & mask) instead of three VALU ops.  With two
-    // masked 8-byte windows (regexdna) the exact form needs ~8.5 VALU ops per text byte, which
-    // bounds the kernel at ~4.6 TB/s on 256 CUs; this form needs ~5.3.
+    // Nibble filter: keep only the low nibble of every byte, so that the 8 bytes of a window pack
+    // into ONE dword -- byte i of pk[j] = nibble of text byte j+i | nibble of text byte j+4+i << 4 --
+    // and a window costs one v_bitop3 ((pk ^ value) & mask) instead of three VALU ops.  The packing
+    // is done on the ALIGNED dwords first (z[q] = nib(d[q]) | nib(d[q+1]) << 4: 6 v_and + 5
+    // v_lshl_or) and the unaligned positions are v_alignbyte of neighbouring z: 26 VALU per chunk
+    // for all 16 pk[j] (packing after the alignment took 37).  With two masked 8-byte windows
+    // (regexdna) the exact form needs ~8.5 VALU per text byte, which bounds the kernel at ~4.6 TB/s
+    // on 256 CUs; this form needs ~4.6.
+    uint32_t nib[6], z[5], pk[16];
+#pragma unroll
+    for (int q = 0; q < 6; q++) nib[q] = d[q] & 0x0F0F0F0Fu;
+#pragma unroll
+    for (int q = 0; q < 5; q++) z[q] = nib[q] | (nib[q + 1] << 4);  // v_lshl_or_b32
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      pk[4 * q] = z[q];
+      pk[4 * q + 1] = __builtin_amdgcn_alignbyte(z[q + 1], z[q], 1);
+      pk[4 * q + 2] = __builtin_amdgcn_alignbyte(z[q + 1], z[q], 2);
+      pk[4 * q + 3] = __builtin_amdgcn_alignbyte(z[q + 1], z[q], 3);
+    }
     uint32_t accs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    uint32_t pk[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-      pk[j] = x[j] | (x[j + 4] << 4);  // v_lshl_or_b32
 #pragma unroll
       for (int k = 0; k + 1 < K; k += 2) {  // two windows per v_min3_u32
         uint32_t t0 = pk[j] ^ ws.value0[k], t1 = pk[j] ^ ws.value0[k + 1];
@@ -213,6 +215,16 @@ __device__ __forceinline__ void windows_chunk(const uint32_t (&d)[6], uint64_t a
     }
     hits.push_bits(hm, at, ws.offset);
     return;
+  }
+  constexpr int NX = TWO ? 20 : 16;  // windows needed: 16 positions (+4 for the second dword)
+  // the unaligned 4-byte windows of this lane: x[j] = bytes [at+j, at+j+4)
+  uint32_t x[NX];
+#pragma unroll
+  for (int q = 0; q < NX / 4; q++) {
+    x[4 * q] = d[q];
+    x[4 * q + 1] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1);
+    x[4 * q + 2] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2);
+    x[4 * q + 3] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 3);
   }
   // Streaming test, VALU only.  For window k at position j
   //     t = ((x[j] ^ value0[k]) & mask0[k]) | ((x[j+4] ^ value1[k]) & mask1[k])
@@ -376,18 +388,18 @@ __device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
 
 __device__ __forceinline__ void fused_chunk(const uint32_t (&d)[6], uint64_t at, const FusedParams& a, uint32_t* counts,
                                             uint64_t wave) {
-  uint32_t x[20];
+  uint32_t nib[6], z[5], pk[16];  // packed on the aligned dwords first, see windows_chunk
 #pragma unroll
-  for (int q = 0; q < 5; q++) {
-    const uint32_t lo = d[q] & 0x0F0F0F0Fu, hi = d[q + 1] & 0x0F0F0F0Fu;
-    x[4 * q] = lo;
-    x[4 * q + 1] = __builtin_amdgcn_alignbyte(hi, lo, 1);
-    x[4 * q + 2] = __builtin_amdgcn_alignbyte(hi, lo, 2);
-    x[4 * q + 3] = __builtin_amdgcn_alignbyte(hi, lo, 3);
+  for (int q = 0; q < 6; q++) nib[q] = d[q] & 0x0F0F0F0Fu;
+#pragma unroll
+  for (int q = 0; q < 5; q++) z[q] = nib[q] | (nib[q + 1] << 4);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    pk[4 * q] = z[q];
+    pk[4 * q + 1] = __builtin_amdgcn_alignbyte(z[q + 1], z[q], 1);
+    pk[4 * q + 2] = __builtin_amdgcn_alignbyte(z[q + 1], z[q], 2);
+    pk[4 * q + 3] = __builtin_amdgcn_alignbyte(z[q + 1], z[q], 3);
   }
-  uint32_t pk[16];
-#pragma unroll
-  for (int j = 0; j < 16; j++) pk[j] = x[j] | (x[j + 4] << 4);
   for (uint32_t g = 0; g < a.n_patterns; g += kFuseGroup) {
     uint32_t acc[kFuseGroup];
 #pragma unroll
