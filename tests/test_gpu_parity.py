@@ -278,7 +278,7 @@ def test_match_all_batch_vs_per_text_oracle(rj, oracle):
     empty texts, texts ending in a match, empty matches at text ends, ^ / $ at text boundaries,
     patterns that can consume a newline (other separator or the text-by-text fallback)."""
     rng = random.Random(21)
-    patterns = [b"ab+", b"^a", b"a$", b"^$", b"x*", b"(ab|ba)+", b"[^a]+", b"a\nb|b", b"\s+", b"[ab]{2,3}",
+    patterns = [b"ab+", b"^a", b"a$", b"^$", b"x*", b"(ab|ba)+", b"[^a]+", b"a\nb|b", b"\\s+", b"[ab]{2,3}",
                 b".*b", b"^[ab]+$", b"regexp"]
     for rx in patterns:
         for alphabet in (b"ab\n", b"abx \r\n"):
@@ -336,6 +336,23 @@ def test_fused_multi_pattern_equals_single_runs(rj):
     counts = m2.run(t.data_ptr(), int(t.numel()), stream=st)
     assert not m2.fused
     assert counts == [rj.Scan(p).run(t.data_ptr(), int(t.numel()), stream=st) for p in mixed]
+
+
+def test_concurrent_match_all_on_one_program(rj, oracle):
+    """A compiled pattern is shared by worker threads that call MatchAll concurrently (jrep -j,
+    sample/jrep.cc:461-493): scratch is per thread, results are those of serial calls."""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = random.Random(17)
+    texts = [bytes(rng.choice(b"abc \n") for _ in range(rng.choice([0, 10, 3000, 70000]))) for _ in range(48)]
+    for rx in (b"ab+c", b"^a.*c$", b"[ab]{3}", b"abc"):
+        p = prog(rj, rx)
+        want = [oracle.match_all(rx, t) for t in texts]
+        with ThreadPoolExecutor(max_workers=6) as pool:
+            got = list(pool.map(p.match_all, texts))
+        assert got == want, rx
+        with ThreadPoolExecutor(max_workers=6) as pool:
+            firsts = list(pool.map(p.match_first, texts))
+        assert firsts == [w[0] if w else None for w in want], rx
 
 
 def test_many_matches_large_path(rj, oracle):
