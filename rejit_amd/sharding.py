@@ -135,3 +135,41 @@ def _device_for(dist):
     if dist.get_backend() == "nccl":
         return torch.device("cuda", torch.cuda.current_device())
     return torch.device("cpu")
+
+
+# ----------------------------------------------------------------------------- many files (jrep, C5)
+def partition_files(sizes, world):
+    """Greedy bin packing of files onto ranks by size (largest first, least-loaded rank), the file
+    sharding of a grep over a tree: every rank walks the same tree, so the assignment is computed
+    identically everywhere and nothing is exchanged.  Returns, per rank, the indices of its files in
+    their original order."""
+    load = [0] * world
+    owner = [0] * len(sizes)
+    for i in sorted(range(len(sizes)), key=lambda k: (-sizes[k], k)):
+        r = min(range(world), key=lambda q: (load[q], q))
+        owner[i] = r
+        load[r] += sizes[i] + 1
+    return [[i for i in range(len(sizes)) if owner[i] == r] for r in range(world)]
+
+
+def gather_bytes(blob: bytes, rank, world, dist, device=None):
+    """Exchange step of the file-sharded path: every rank's output (bytes) on rank 0, in rank order
+    (other ranks get None).  Two collectives over RCCL/gloo: all_gather of the lengths, all_gather of
+    the padded byte tensors."""
+    import torch
+    if world == 1:
+        return blob
+    dev = device if device is not None else torch.device("cpu")
+    n = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
+    lens = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(lens, n)
+    lens = [int(x.item()) for x in lens]
+    width = max(max(lens), 1)
+    mine = torch.zeros(width, dtype=torch.uint8, device=dev)
+    if blob:
+        mine[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    parts = [torch.zeros(width, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    if rank != 0:
+        return None
+    return b"".join(bytes(p[:k].cpu().numpy().tobytes()) for p, k in zip(parts, lens))

@@ -5,6 +5,10 @@ rj_match_all_batch -- the files of a whole batch (default 256 MiB) are matched i
 instead of one call (and one PCIe copy, and ~50 us of latency) per file.
 
     python samples/jrep_gpu.py [-H] [-n] [-r|-R] [-c] [-A n] [-B n] [-C n] [--count] PATTERN PATH...
+    python -m torch.distributed.run --nproc-per-node 8 samples/jrep_gpu.py -R -H -n PATTERN PATH   # one rank per GPU
+
+Under torch.distributed every rank walks the tree, takes its share of the files (greedy packing by
+size, rejit_amd.sharding.partition_files) and rank 0 prints the gathered output (RCCL all_gather).
 
 The reference's own jrep also runs unchanged on librejit_hip.so (oracle/_ref/jrep_hip); this one
 is what a many-small-files workload (BASELINE config C5) should use.
@@ -127,13 +131,31 @@ def main():
     ap.add_argument("-C", "--context", type=int, default=0)
     ap.add_argument("--count", action="store_true", help="print only `file:matches` per file with matches")
     ap.add_argument("--batch-mib", type=int, default=256)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend when launched with several ranks")
+    ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("pattern")
     ap.add_argument("paths", nargs="+")
     args = ap.parse_args()
     if args.context:
         args.after = args.before = args.context
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dist = None
+    cdev = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        if args.backend == "nccl":
+            cdev = torch.device("cuda", local)
+            dist.init_process_group("nccl", device_id=cdev)
+        else:
+            dist.init_process_group(args.backend)
     import rejit_amd
+    from rejit_amd import sharding
     rejit_amd.build()
     try:
         prog = rejit_amd.Program(args.pattern.encode())
@@ -141,9 +163,20 @@ def main():
         sys.stderr.write(f"jrep_gpu: {e}\n")
         return 2
     sol = rejit_amd.Program(b"^")      # jrep.cc:239: the line table is a MatchAll of "^"
-    out = sys.stdout.buffer
+    import io
+    out = io.BytesIO() if world > 1 else sys.stdout.buffer
     found = False
     names = walk(args.paths, args.recursive or args.dereference_recursive, args.dereference_recursive)
+    if world > 1:
+        # every rank sees the same tree: the assignment needs no exchange
+        names = list(names)
+        sizes = []
+        for nm in names:
+            try:
+                sizes.append(os.path.getsize(nm))
+            except OSError:
+                sizes.append(0)
+        names = [names[i] for i in sharding.partition_files(sizes, world)[rank]]
     for batch in batches(names, args.batch_mib << 20):
         texts = [d for _, d in batch]
         results = prog.match_all_batch(texts)
@@ -159,7 +192,18 @@ def main():
         lines = sol.match_all_batch([texts[i] for i in hit])
         for i, ls in zip(hit, lines):
             print_file(out, batch[i][0], texts[i], results[i], [b for b, _ in ls], args)
-    out.flush()
+    if world > 1:
+        import torch
+        whole = sharding.gather_bytes(out.getvalue(), rank, world, dist, device=cdev)
+        flag = torch.tensor([int(found)], dtype=torch.int64, device=cdev if cdev is not None else "cpu")
+        dist.all_reduce(flag)
+        found = bool(flag.item())
+        if rank == 0:
+            sys.stdout.buffer.write(whole)
+            sys.stdout.buffer.flush()
+        dist.destroy_process_group()
+    else:
+        out.flush()
     return 0 if found else 1
 
 

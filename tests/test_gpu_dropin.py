@@ -95,6 +95,31 @@ def test_own_jrep_counterpart_equals_grep_and_reference_jrep(tmp_path):
         assert sorted(ours.splitlines()) == sorted(theirs.splitlines()) and len(ours.splitlines()) > 0
 
 
+@pytest.mark.skipif(shutil.which("grep") is None, reason="grep missing")
+def test_own_jrep_counterpart_two_ranks(tmp_path):
+    """The file-sharded path of samples/jrep_gpu.py (BASELINE C5 shape): two ranks (gloo, both on
+    cuda:0 -- the GPU box has one GPU) split the files, rank 0 prints the gathered output; as a set of
+    lines it equals GNU grep."""
+    import random
+    import socket
+    import sys
+    rng = random.Random(8)
+    words = ["regexp", "alpha", "beta", "gamma", "int", "return", "x", "y"]
+    os.makedirs(tmp_path / "d", exist_ok=True)
+    for i in range(60):
+        lines = [" ".join(rng.choice(words) for _ in range(rng.randint(0, 8))) for _ in range(rng.randint(0, 80))]
+        (tmp_path / ("d" if i % 2 else ".") / f"g{i}.txt").write_text("\n".join(lines) + "\n")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    sample = os.path.join(ROOT, "samples", "jrep_gpu.py")
+    ours = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), sample, "--backend", "gloo",
+                           "--same-device", "-R", "-H", "-n", "regexp", "."], cwd=tmp_path, capture_output=True, timeout=900)
+    assert ours.returncode == 0, ours.stderr.decode()[-2000:]
+    ref = subprocess.run(["grep", "-R", "-H", "-n", "regexp", "."], cwd=tmp_path, capture_output=True).stdout
+    got = [l for l in ours.stdout.splitlines() if not l.startswith(b"[Gloo]")]   # (gloo logs its rendezvous on stdout)
+    assert sorted(got) == sorted(ref.splitlines()) and len(ref.splitlines()) > 0
+
+
 def test_own_regexdna_counterpart(tmp_path):
     """samples/regexdna_gpu.py (text resident in HBM for the whole program) prints the same
     output as the reference's sample on the same input."""

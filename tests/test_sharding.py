@@ -88,3 +88,47 @@ def test_partition_and_visible_range():
     assert sharding.visible_range(1000, (100, 200), None) == (36, 1000)
     assert sharding.needs_rerun((5, 9), (6, 6, True)) and not sharding.needs_rerun((6, 9), (6, 6, True))
     assert sharding.needs_rerun((6, 6), (6, 6, True)) and not sharding.needs_rerun(None, (6, 6, True))
+
+
+# ----------------------------------------------------------------------------- file sharding (jrep, C5)
+def test_partition_files_balances_and_is_deterministic():
+    rng = random.Random(2)
+    sizes = [rng.choice([0, 10, 500, 4000, 100000, 2000000]) for _ in range(500)]
+    for world in (1, 2, 3, 8):
+        parts = sharding.partition_files(sizes, world)
+        assert sorted(i for p in parts for i in p) == list(range(len(sizes)))       # every file exactly once
+        assert all(p == sorted(p) for p in parts)                                      # original order kept
+        loads = [sum(sizes[i] + 1 for i in p) for p in parts]
+        assert max(loads) - min(loads) <= max(sizes) + 1                               # greedy bound
+        assert parts == sharding.partition_files(list(sizes), world)
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    blob = (b"rank%d:" % rank) + bytes(range(rank * 7 % 256, 256)) * rank    # different lengths, rank 0 short
+    whole = sharding.gather_bytes(blob, rank, world, dist)
+    empty = sharding.gather_bytes(b"", rank, world, dist)
+    if rank == 0:
+        q.put((whole, empty))
+    else:
+        assert whole is None and empty is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_bytes_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    whole, empty = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = b"".join((b"rank%d:" % r) + bytes(range(r * 7 % 256, 256)) * r for r in range(world))
+    assert whole == want and empty == b""
