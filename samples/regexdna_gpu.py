@@ -42,21 +42,34 @@ def main():
         new_len = sc.replace(buf.data_ptr(), n, repl, out.data_ptr(), int(out.numel()), stream=stream)
         return out, new_len
 
+    phases = []
+
+    def lap(name, since):
+        if args.timing:
+            torch.cuda.synchronize()
+            phases.append("%s %.1f ms" % (name, (time.perf_counter() - since) * 1e3))
+
     t0 = time.perf_counter()
     text, n = replace_all(text, raw_size, W.REGEXDNA_STRIP, b"")
     text_size = n
+    lap("strip", t0)
+    t1 = time.perf_counter()
     # the nine counts share one pass over the text (rj_multi, fused window scan)
     multi = rejit_amd.MultiScan([rejit_amd.Program(rx) for rx in W.REGEXDNA_PATTERNS])
     counts = multi.run(text.data_ptr(), n, stream=stream)
     lines = ["%s %d" % (rx, c) for rx, c in zip(W.REGEXDNA_PATTERNS, counts)]
+    lap("9 counts", t1)
     for code, repl in W.REGEXDNA_IUB:
+        t2 = time.perf_counter()
         text, n = replace_all(text, n, code, repl.encode())
+        lap("replace " + code, t2)
     torch.cuda.synchronize()
     t_dev = time.perf_counter() - t0
     print("\n".join(lines))
     print("\n%d\n%d\n%d" % (raw_size, text_size, n))
     if args.timing:
         print("upload %.3f s, device pipeline (strip + 9 counts + 11 replaces) %.3f s" % (t_up, t_dev), file=sys.stderr)
+        print("; ".join(phases), file=sys.stderr)
 
 
 if __name__ == "__main__":
