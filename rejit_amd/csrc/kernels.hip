@@ -1765,25 +1765,43 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
       const uint32_t lo = a.sb > at ? (a.sb - at < 16 ? static_cast<uint32_t>(a.sb - at) : 16u) : 0u;
       cand &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
     } else {
-      uint32_t prev = '\n';  // byte before the lane's first byte ('\n' stands for "start of text")
-      if (CTX && at > 0 && at <= a.n) prev = a.text[at - 1];
-#pragma unroll 1
+      // Nullable patterns (x*, ^, $, ...): a position also starts a match when the empty string
+      // matches in its context (bit0: start of line, bit1: end of line).  The contexts of all 16
+      // positions come from one line-break bitmask of the lane's bytes: sol = that mask shifted by
+      // one with the neighbour's last byte shifted in, eol = the mask itself plus the end of text.
+      uint32_t lb = 0, first16 = 0;
+#pragma unroll
       for (int j = 0; j < 16; j++) {
         const uint32_t cur = (d[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-        const uint64_t s = at + j;
-        bool ok = false;
-        if (s < a.n) ok = (fb[cur >> 5] >> (cur & 31)) & 1u;
-        if (s <= a.n) {
-          int ctx = 0;
-          if (CTX) {
-            if (s == 0 || rj_line_break(prev)) ctx |= 1;
-            if (s == a.n || rj_line_break(cur)) ctx |= 2;
-          }
-          ok = ok || ((P.nullable >> ctx) & 1u);
-        }
-        ok = ok && s >= a.sb && s < a.se;
-        cand |= static_cast<uint32_t>(ok) << j;
-        prev = cur;
+        lb |= static_cast<uint32_t>(cur == '\n' || cur == '\r') << j;
+        first16 |= ((fb[cur >> 5] >> (cur & 31)) & 1u) << j;
+      }
+      // positions with a byte (s < n) / positions at all (s <= n)
+      const uint32_t lt_n = a.n > at ? (a.n - at < 16 ? (1u << (a.n - at)) - 1u : 0xFFFFu) : 0u;
+      const uint32_t le_n = a.n >= at ? (a.n - at < 15 ? (2u << (a.n - at)) - 1u : 0xFFFFu) : 0u;
+      lb &= lt_n;  // (bytes past the end read as zero already; kept explicit)
+      uint32_t null16 = 0xFFFFu;
+      if (CTX) {
+        uint32_t prev_lb = __shfl_up(lb >> 15, 1);  // the neighbour's last byte
+        if (lane == 0) prev_lb = base > 0 ? static_cast<uint32_t>(rj_line_break(a.text[base - 1])) : 1u;  // text start
+        const uint32_t sol = ((lb << 1) | prev_lb) & 0xFFFFu;
+        uint32_t eol = lb;
+        if (a.n >= at && a.n - at < 16) eol |= 1u << (a.n - at);  // the end of the text
+        null16 = 0;
+        if (P.nullable & 1u) null16 |= ~sol & ~eol;
+        if (P.nullable & 2u) null16 |= sol & ~eol;
+        if (P.nullable & 4u) null16 |= ~sol & eol;
+        if (P.nullable & 8u) null16 |= sol & eol;
+      }
+      const uint32_t hi = a.se > at ? (a.se - at < 16 ? static_cast<uint32_t>(a.se - at) : 16u) : 0u;
+      const uint32_t lo = a.sb > at ? (a.sb - at < 16 ? static_cast<uint32_t>(a.sb - at) : 16u) : 0u;
+      const uint32_t range = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+      cand = ((first16 & lt_n) | (null16 & le_n & 0xFFFFu)) & range;
+      if (P.n_pos == 0) {
+        // only assertions (^, $, ^$): every candidate IS a match, the empty one -- no walk at all
+        // (the line table of a grep-like caller is a MatchAll of "^", sample/jrep.cc:294)
+        fin = cand;
+        flen = 0;
       }
     }
     if (__ballot(cand != 0) == 0) continue;
