@@ -676,9 +676,18 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
       // below was measured: slower, its agent-scope fence writes L2 back)
       s->host_counters[kCntUnordered] = 0;  // the kernel below writes the pinned block itself
       s->host_counters[kCntAdjacent] = 0;
+      // many candidates per region expected (the previous run had them): lay out first, then copy
+      // with a wave per region
+      uint64_t *off_scratch = nullptr, *prev_scratch = nullptr;
+      if (s->hits_hint > static_cast<uint64_t>(geo.n_regions) * 16) {
+        RJ_HIP(s->hit_offsets.reserve((static_cast<size_t>(geo.n_regions) + 1) * sizeof(uint64_t)));
+        RJ_HIP(s->scan_a.reserve(static_cast<size_t>(geo.n_regions) * sizeof(uint64_t)));
+        off_scratch = s->hit_offsets.as<uint64_t>();
+        prev_scratch = s->scan_a.as<uint64_t>();
+      }
       launch_offsets_gather_check(survivors, begins, s->cand_end.as<uint64_t>(), geo.n_regions,
                                   static_cast<uint32_t>(region_cap), fp.carry_cur, s->out.as<uint64_t>(), s->out_cap,
-                                  s->counters.as<unsigned long long>(), s->host_counters, st);
+                                  s->counters.as<unsigned long long>(), s->host_counters, off_scratch, prev_scratch, st);
       RJ_HIP(hipStreamSynchronize(st));
       RJ_HIP(hipGetLastError());
       if (s->host_counters[kCntUnordered] != 0 && s->host_counters[kCntOverflow] == 0) {

@@ -140,10 +140,13 @@ void launch_verify_in_regions(const VerifyParams& a, const DevProgram& P, const 
 void launch_verify_floating_in_regions(const VerifyParams& a, const DevProgram& P, const uint32_t* hit_counts,
                                        uint32_t* valid_counts, uint64_t* region_begins, uint64_t* region_ends, hipStream_t st);
 // region offsets + gather + check_and_interleave in one launch (see the kernel); host_counters
-// (pinned, may be null) receives the counter block directly
+// (pinned, may be null) receives the counter block directly.  With offsets_scratch / prev_scratch
+// ([n_regions] each) the first launch only lays the regions out and a second one copies and checks
+// with a wave per region -- for runs whose regions hold many candidates
 void launch_offsets_gather_check(const uint32_t* counts, const uint64_t* region_begins, const uint64_t* region_ends,
                                  uint32_t n_regions, uint32_t region_cap, uint64_t carry_cur, uint64_t* out, uint64_t out_cap,
-                                 unsigned long long* counters, unsigned long long* host_counters, hipStream_t st);
+                                 unsigned long long* counters, unsigned long long* host_counters, uint64_t* offsets_scratch,
+                                 uint64_t* prev_scratch, hipStream_t st);
 // (begin,end) pairs -> begin[] / end[]; n read from device memory
 void launch_split_pairs(const uint64_t* pairs, const unsigned long long* n_ptr, uint64_t n_upper, uint64_t* keys, uint64_t* vals,
                         hipStream_t st);

@@ -930,7 +930,8 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
                                                           const uint64_t* region_ends, uint32_t n_regions,
                                                           uint32_t region_cap, uint64_t carry_cur, uint64_t* out,
                                                           uint64_t out_cap, unsigned long long* counters,
-                                                          unsigned long long* host_counters) {
+                                                          unsigned long long* host_counters, uint64_t* offsets_out = nullptr,
+                                                          uint64_t* prev_out = nullptr) {
   // Adjacency (a candidate begins exactly where an earlier one ends) is wanted for the Q8 check.
   // When the list is ordered and disjoint -- the only case in which this kernel's verdict is
   // used -- only neighbours can be adjacent, so comparing with the running maximum is exact.
@@ -966,11 +967,13 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
     hb[k] = static_cast<uint32_t>(k) < cnt ? region_begins[src + k] : 0;
     he[k] = static_cast<uint32_t>(k) < cnt ? region_ends[src + k] : 0;
   }
+  // the region's largest end: the held ones and the LAST one.  (Exact whenever the region is
+  // ordered inside, and when it is not the copy below flags the list anyway.)
   uint64_t my_end = 0;
 #pragma unroll
   for (int k = 0; k < kHeld; k++) my_end = he[k] > my_end ? he[k] : my_end;
-  for (uint32_t k = kHeld; k < cnt; k++) {
-    const uint64_t e = region_ends[src + k];
+  if (cnt > kHeld) {
+    const uint64_t e = region_ends[src + cnt - 1];
     my_end = e > my_end ? e : my_end;
   }
   uint64_t inc = cnt, inc_end = my_end;
@@ -1016,9 +1019,40 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
   prev = end_before > prev ? end_before : prev;
   const uint64_t up = __shfl_up(inc_end, 1);  // inclusive maximum of the lanes below
   if (lane > 0) prev = up > prev ? up : prev;
-  // 3. copy + check (a few entries per region)
+  // 3. copy + check
   const uint64_t off = base + own_before + inc - cnt;
   bool ok = true;
+  if (offsets_out != nullptr) {
+    // offsets only: a second launch (gather_regions_by_wave) copies and checks, one wave per region
+    if (r < n_regions) {
+      offsets_out[r] = off;
+      prev_out[r] = prev;
+    }
+  } else if (own_total > 4 * kOgcThreads) {
+    // many candidates per region (dense patterns, `^` over a file, one-letter replaces): the
+    // workgroup copies them together, entry e of the workgroup by thread e mod 256 -- coalesced
+    // 16-byte stores instead of one thread walking hundreds of entries.  The region of an entry
+    // comes from a binary search in the workgroup's prefix (LDS); an entry is checked against the
+    // entry before it (the running maximum before the region for its first one).
+    __shared__ uint32_t s_pre[kOgcThreads];
+    __shared__ uint64_t s_prev[kOgcThreads];
+    s_pre[threadIdx.x] = static_cast<uint32_t>(own_before + inc - cnt);
+    s_prev[threadIdx.x] = prev;
+    __syncthreads();
+    for (uint64_t e = threadIdx.x; e < own_total; e += kOgcThreads) {
+      uint32_t lo = 0, hi = kOgcThreads;  // last t with s_pre[t] <= e  (an empty region shares its prefix with the next one)
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_pre[mid] <= e) lo = mid; else hi = mid;
+      }
+      const uint64_t at = static_cast<uint64_t>(first + lo) * region_cap + (e - s_pre[lo]);
+      const uint64_t b = region_begins[at], en = region_ends[at];
+      const uint64_t before_it = e > s_pre[lo] ? region_ends[at - 1] : s_prev[lo];
+      ok = ok && en > b && b >= before_it;
+      adjacent = adjacent || (b == before_it && before_it != 0);
+      if (base + e < out_cap) *reinterpret_cast<ulonglong2*>(out + 2 * (base + e)) = make_ulonglong2(b, en);
+    }
+  } else
   for (uint32_t k = 0; k < cnt; k++) {
     uint64_t b, e;
     if (k < kHeld) {
@@ -1062,9 +1096,44 @@ __global__ __launch_bounds__(kOgcThreads) void offsets_gather_check(const uint32
                                                                     const uint64_t* region_ends, uint32_t n_regions,
                                                                     uint32_t region_cap, uint64_t carry_cur, uint64_t* out,
                                                                     uint64_t out_cap, unsigned long long* counters,
-                                                                    unsigned long long* host_counters) {
+                                                                    unsigned long long* host_counters, uint64_t* offsets_out,
+                                                                    uint64_t* prev_out) {
   offsets_gather_check_body(counts, region_begins, region_ends, n_regions, region_cap, carry_cur, out, out_cap, counters,
-                            host_counters);
+                            host_counters, offsets_out, prev_out);
+}
+
+// Second half of the two-launch form used when regions hold many candidates (tens and more each:
+// dense patterns, `^` over a text, one-letter replaces): one wave per region copies its survivors
+// with coalesced 16-byte stores and checks each against the one before it.
+__global__ __launch_bounds__(256) void gather_regions_by_wave(const uint32_t* counts, const uint64_t* region_begins,
+                                                              const uint64_t* region_ends, const uint64_t* offsets,
+                                                              const uint64_t* prev_end, uint32_t n_regions, uint32_t region_cap,
+                                                              uint64_t* out, uint64_t out_cap, unsigned long long* counters,
+                                                              unsigned long long* host_counters) {
+  const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+  const int lane = lane_id();
+  bool ok = true, adjacent = false;
+  for (uint64_t r = wave; r < n_regions; r += n_waves) {
+    const uint32_t cnt = counts[r];
+    if (cnt == 0) continue;
+    const uint64_t src = r * region_cap, off = offsets[r], before_region = prev_end[r];
+    for (uint32_t k = lane; k < cnt; k += kWave) {
+      const uint64_t b = region_begins[src + k], e = region_ends[src + k];
+      const uint64_t before_it = k ? region_ends[src + k - 1] : before_region;
+      ok = ok && e > b && b >= before_it;
+      adjacent = adjacent || (b == before_it && before_it != 0);
+      if (off + k < out_cap) *reinterpret_cast<ulonglong2*>(out + 2 * (off + k)) = make_ulonglong2(b, e);
+    }
+  }
+  if (!ok) {
+    counters[kCntUnordered] = 1;
+    if (host_counters) host_counters[kCntUnordered] = 1;
+  }
+  if (adjacent) {
+    counters[kCntAdjacent] = 1;
+    if (host_counters) host_counters[kCntAdjacent] = 1;
+  }
 }
 
 __global__ __launch_bounds__(kOgcThreads) void offsets_gather_check_multi(const MultiTail* tails) {
@@ -2106,10 +2175,17 @@ void launch_verify_in_regions(const VerifyParams& a, const DevProgram& P, const 
 
 void launch_offsets_gather_check(const uint32_t* counts, const uint64_t* region_begins, const uint64_t* region_ends,
                                  uint32_t n_regions, uint32_t region_cap, uint64_t carry_cur, uint64_t* out, uint64_t out_cap,
-                                 unsigned long long* counters, unsigned long long* host_counters, hipStream_t st) {
+                                 unsigned long long* counters, unsigned long long* host_counters, uint64_t* offsets_scratch,
+                                 uint64_t* prev_scratch, hipStream_t st) {
   const unsigned blocks = n_regions ? (n_regions + kOgcThreads - 1) / kOgcThreads : 1u;
   hipLaunchKernelGGL(offsets_gather_check, dim3(blocks), dim3(kOgcThreads), 0, st, counts, region_begins, region_ends, n_regions,
-                     region_cap, carry_cur, out, out_cap, counters, host_counters);
+                     region_cap, carry_cur, out, out_cap, counters, host_counters, offsets_scratch, prev_scratch);
+  if (offsets_scratch != nullptr) {
+    uint64_t wblocks = (static_cast<uint64_t>(n_regions) + 3) / 4;
+    wblocks = wblocks < 1 ? 1 : wblocks > 16384 ? 16384 : wblocks;
+    hipLaunchKernelGGL(gather_regions_by_wave, dim3(static_cast<unsigned>(wblocks)), dim3(256), 0, st, counts, region_begins,
+                       region_ends, offsets_scratch, prev_scratch, n_regions, region_cap, out, out_cap, counters, host_counters);
+  }
 }
 
 void launch_verify_floating_in_regions(const VerifyParams& a, const DevProgram& P, const uint32_t* hit_counts,
