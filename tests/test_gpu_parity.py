@@ -355,6 +355,22 @@ def test_concurrent_match_all_on_one_program(rj, oracle):
         assert firsts == [w[0] if w else None for w in want], rx
 
 
+def test_dense_output_gather_paths(rj, oracle):
+    """Many matches per hit region: the first call sizes the regions (overflow + retry) and copies
+    inside the offsets kernel, the second call -- the scan remembers the density -- takes the
+    two-launch gather with a wave per region.  Both must equal the oracle, also when the candidates
+    overlap (selection path) and across several sizes."""
+    rng = random.Random(23)
+    for rx, alphabet in ((b"^", b"ab\n"), (b"x", b"xy"), (b"[ab]+", b"abc"), (b"(ab|ba)+", b"ab"), (b"[ab][ab]", b"ab"),
+                         (b"a*", b"ab")):
+        for n in (5000, 70000, 400000):
+            text = bytes(rng.choice(alphabet) for _ in range(n))
+            want = oracle.match_all(rx, text)
+            p = rj.Program(rx)          # a fresh program: its scan starts without any hint
+            for call in range(3):
+                assert p.match_all(text) == want, (rx, n, call)
+
+
 def test_many_matches_large_path(rj, oracle):
     """More candidates than the LDS finalize holds: the rocPRIM sort path."""
     rng = random.Random(9)
