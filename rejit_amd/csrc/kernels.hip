@@ -1758,6 +1758,12 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
     first0[q] = in ? tab[q] : 0u;
     last0[q] = in ? tab[o_last + q] : 0u;
   }
+  // contexts in which a non-empty match can start at all (bit c: first[c] is not empty)
+  uint32_t first_ctx = 0;
+  for (int c = 0; c < C; c++)
+    for (int q = 0; q < W; q++)
+      if (tab[c * W + q] != 0) first_ctx |= 1u << c;
+  if (C == 1) first_ctx = 0xFu;
 
   for (uint64_t c = span.c0; c < span.c1; c++) {
     const uint64_t base = c * kChunk;
@@ -1822,50 +1828,45 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
       const uint32_t range = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
       fin &= range;
       cand = (walk & range) | fin;
-    } else if (P.nullable == 0) {
-      // a start needs a first byte: 16 bitmap lookups, then the range as a mask
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
-        const uint32_t cur = (d[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-        cand |= ((fb[cur >> 5] >> (cur & 31)) & 1u) << j;
-      }
-      const uint64_t lim = a.se < a.n ? a.se : a.n;  // starts s with sb <= s < min(se, n)
-      const uint32_t hi = lim > at ? (lim - at < 16 ? static_cast<uint32_t>(lim - at) : 16u) : 0u;
-      const uint32_t lo = a.sb > at ? (a.sb - at < 16 ? static_cast<uint32_t>(a.sb - at) : 16u) : 0u;
-      cand &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
     } else {
-      // Nullable patterns (x*, ^, $, ...): a position also starts a match when the empty string
-      // matches in its context (bit0: start of line, bit1: end of line).  The contexts of all 16
-      // positions come from one line-break bitmask of the lane's bytes: sol = that mask shifted by
-      // one with the neighbour's last byte shifted in, eol = the mask itself plus the end of text.
+      // General form.  A position starts a candidate when its byte can begin a match in the
+      // position's context, or (nullable patterns: x*, ^, $, ...) when the empty string matches
+      // there.  Contexts (bit0: start of line, bit1: end of line) of all 16 positions come from one
+      // line-break bitmask of the lane's bytes: sol = that mask shifted by one with the neighbour's
+      // last byte shifted in, eol = the mask itself plus the end of the text.  Patterns that begin
+      // with an assertion (`^[a-z]+:`) have an EMPTY first set outside their context: without the
+      // context filter every [a-z] byte of the text was a candidate for the walkers.
       uint32_t lb = 0, first16 = 0;
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const uint32_t cur = (d[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-        lb |= static_cast<uint32_t>(cur == '\n' || cur == '\r') << j;
+        if (CTX) lb |= static_cast<uint32_t>(cur == '\n' || cur == '\r') << j;
         first16 |= ((fb[cur >> 5] >> (cur & 31)) & 1u) << j;
       }
       // positions with a byte (s < n) / positions at all (s <= n)
       const uint32_t lt_n = a.n > at ? (a.n - at < 16 ? (1u << (a.n - at)) - 1u : 0xFFFFu) : 0u;
       const uint32_t le_n = a.n >= at ? (a.n - at < 15 ? (2u << (a.n - at)) - 1u : 0xFFFFu) : 0u;
-      lb &= lt_n;  // (bytes past the end read as zero already; kept explicit)
-      uint32_t null16 = 0xFFFFu;
+      uint32_t null16 = P.nullable ? 0xFFFFu : 0u, allowed16 = 0xFFFFu;
       if (CTX) {
+        lb &= lt_n;
         uint32_t prev_lb = __shfl_up(lb >> 15, 1);  // the neighbour's last byte
         if (lane == 0) prev_lb = base > 0 ? static_cast<uint32_t>(rj_line_break(a.text[base - 1])) : 1u;  // text start
         const uint32_t sol = ((lb << 1) | prev_lb) & 0xFFFFu;
         uint32_t eol = lb;
         if (a.n >= at && a.n - at < 16) eol |= 1u << (a.n - at);  // the end of the text
+        const uint32_t in_ctx[4] = {~sol & ~eol, sol & ~eol, ~sol & eol, sol & eol};
         null16 = 0;
-        if (P.nullable & 1u) null16 |= ~sol & ~eol;
-        if (P.nullable & 2u) null16 |= sol & ~eol;
-        if (P.nullable & 4u) null16 |= ~sol & eol;
-        if (P.nullable & 8u) null16 |= sol & eol;
+        allowed16 = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          if ((P.nullable >> c) & 1u) null16 |= in_ctx[c];
+          if ((first_ctx >> c) & 1u) allowed16 |= in_ctx[c];
+        }
       }
       const uint32_t hi = a.se > at ? (a.se - at < 16 ? static_cast<uint32_t>(a.se - at) : 16u) : 0u;
       const uint32_t lo = a.sb > at ? (a.sb - at < 16 ? static_cast<uint32_t>(a.sb - at) : 16u) : 0u;
       const uint32_t range = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-      cand = ((first16 & lt_n) | (null16 & le_n & 0xFFFFu)) & range;
+      cand = ((first16 & allowed16 & lt_n) | (null16 & le_n)) & 0xFFFFu & range;
       if (P.n_pos == 0) {
         // only assertions (^, $, ^$): every candidate IS a match, the empty one -- no walk at all
         // (the line table of a grep-like caller is a MatchAll of "^", sample/jrep.cc:294)
