@@ -131,6 +131,8 @@ def main():
     ap.add_argument("-C", "--context", type=int, default=0)
     ap.add_argument("--count", action="store_true", help="print only `file:matches` per file with matches")
     ap.add_argument("--batch-mib", type=int, default=256)
+    ap.add_argument("-o", "--output", default=None, help="write the result to this file instead of stdout (with several "
+                    "ranks the launcher shares one stdout between all of them and their logs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend when launched with several ranks")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("pattern")
@@ -164,7 +166,7 @@ def main():
         return 2
     sol = rejit_amd.Program(b"^")      # jrep.cc:239: the line table is a MatchAll of "^"
     import io
-    out = io.BytesIO() if world > 1 else sys.stdout.buffer
+    out = io.BytesIO() if world > 1 else (open(args.output, "wb") if args.output else sys.stdout.buffer)
     found = False
     names = walk(args.paths, args.recursive or args.dereference_recursive, args.dereference_recursive)
     if world > 1:
@@ -199,8 +201,12 @@ def main():
         dist.all_reduce(flag)
         found = bool(flag.item())
         if rank == 0:
-            sys.stdout.buffer.write(whole)
-            sys.stdout.buffer.flush()
+            if args.output:
+                with open(args.output, "wb") as fh:
+                    fh.write(whole)
+            else:
+                sys.stdout.buffer.write(whole)
+                sys.stdout.buffer.flush()
         dist.destroy_process_group()
     else:
         out.flush()
