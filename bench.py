@@ -138,7 +138,6 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     torch.cuda.synchronize(dev)
 
-    counts_dev = torch.zeros(len(patterns), dtype=torch.int64, device=cdev)
     scan_ms = []
     # The nine patterns of a step are independent calls: like the reference's own
     # sample/regexdna-multithread.cc:65-78 they are issued from a few host threads, each on its
@@ -171,7 +170,7 @@ def main():
             t = torch.tensor(local, dtype=torch.int64).to(cdev)
             pending.append((dist.all_reduce(t, async_op=True), t))
             while len(pending) > 1:
-                w, done = pending.pop(0)
+                w, _ = pending.pop(0)
                 w.wait()
             return None
         return local
