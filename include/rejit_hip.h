@@ -112,6 +112,14 @@ int rj_scan_create(const rj_program* prog, rj_scan** out);
 void rj_scan_destroy(rj_scan* scan);
 int64_t rj_scan_run(rj_scan* scan, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end,
                     uint64_t carry_cur, uint64_t carry_prev_end, int have_prev, void* hip_stream);
+/* The same whole-text run in two halves, so that a caller with several patterns (or texts) in
+ * flight does not serialise on every call's latency-bound tail: rj_scan_start enqueues the scan on
+ * hip_stream and the verify / gather kernels behind it on the scan's own stream, rj_scan_finish
+ * waits and returns the count (results as after rj_scan_run).  One start per scan at a time; scans
+ * started back to back on one stream run their scan kernels one after the other while the tails of
+ * earlier ones overlap them. */
+int rj_scan_start(rj_scan* scan, const void* d_text, uint64_t n, void* hip_stream);
+int64_t rj_scan_finish(rj_scan* scan);
 /* results of the last run: device pointer to 2*count uint64 offsets, or a host copy */
 const uint64_t* rj_scan_device_spans(const rj_scan* scan);
 int64_t rj_scan_copy_spans(const rj_scan* scan, uint64_t* host_spans, uint64_t cap);

@@ -106,7 +106,7 @@ C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_er
                  "rj_scan_destroy", "rj_scan_run", "rj_scan_device_spans", "rj_scan_copy_spans", "rj_scan_stats",
                  "rj_scan_match_full", "rj_device_count", "rj_replace_all", "rj_free_text", "rj_scan_replace",
                  "rj_match_all_batch", "rj_multi_create", "rj_multi_destroy", "rj_multi_run", "rj_multi_scan",
-                 "rj_multi_scan_ms"]
+                 "rj_multi_scan_ms", "rj_scan_start", "rj_scan_finish"]
 
 
 def load_library():
@@ -149,6 +149,9 @@ def load_library():
     L.rj_scan_destroy.argtypes = [vp]
     L.rj_scan_run.restype = i64
     L.rj_scan_run.argtypes = [vp, vp, u64, u64, u64, u64, u64, ctypes.c_int, vp]
+    L.rj_scan_start.argtypes = [vp, vp, u64, vp]
+    L.rj_scan_finish.restype = i64
+    L.rj_scan_finish.argtypes = [vp]
     L.rj_scan_device_spans.restype = vp
     L.rj_scan_device_spans.argtypes = [vp]
     L.rj_scan_copy_spans.restype = i64
@@ -272,6 +275,13 @@ class Scan:
             own_end = n + 1
         return int(_check(self._lib.rj_scan_run(self._h, ctypes.c_void_p(d_text_ptr), n, own_begin, own_end, carry_cur,
                                                 carry_prev_end, int(have_prev), ctypes.c_void_p(stream))))
+
+    def start(self, d_text_ptr: int, n: int, stream: int = 0) -> None:
+        """Enqueue a whole-text run; finish() returns its count (several scans can be in flight)."""
+        _check(self._lib.rj_scan_start(self._h, ctypes.c_void_p(d_text_ptr), n, ctypes.c_void_p(stream)))
+
+    def finish(self) -> int:
+        return int(_check(self._lib.rj_scan_finish(self._h)))
 
     def run_tensor(self, t, n: Optional[int] = None, stream=None, **kw) -> int:
         """t: a contiguous uint8 torch tensor on the GPU."""

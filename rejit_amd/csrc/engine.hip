@@ -132,6 +132,12 @@ struct rj_scan {
   rj_stats stats{};
   const uint64_t* result = nullptr;  // device pointer to the final pairs
   uint64_t result_count = 0;
+  // rj_scan_start / rj_scan_finish
+  hipStream_t tail_stream = nullptr;
+  bool pending = false, pending_launched = false;
+  const uint8_t* pending_text = nullptr;
+  uint64_t pending_n = 0;
+  hipStream_t pending_stream = nullptr;
   // host-text path
   DeviceBuffer text;
   char* pinned = nullptr;  // staging for rj_match_all_batch
@@ -507,6 +513,45 @@ int resolve_selection(rj_scan* s, const FinalizeParams& fp, hipStream_t st) {
   return RJ_OK;
 }
 
+// The window constants a scan kernel takes (exact or nibble form, see WindowSet).
+WindowSet make_window_set(const rj_program* rp) {
+  const DevProgram& D = rp->dev;
+  WindowSet ws{};
+  bool masked = false;
+  for (int k = 0; k < kDevMaxWindows; k++) {
+    ws.value0[k] = D.win_value0[k];
+    ws.mask0[k] = D.win_mask0[k];
+    ws.value1[k] = D.win_value1[k];
+    ws.mask1[k] = D.win_mask1[k];
+    masked |= D.win_mask0[k] != 0xFFFFFFFFu || (D.win_len > 4 && D.win_mask1[k] != 0xFFFFFFFFu);
+  }
+  ws.masked = masked;
+  ws.two_level = rp->window_alphabet > 4;
+  ws.nibble = D.win_len > 4 && !ws.two_level && rp->window_nibbles;
+  if (ws.nibble) {
+    bool nib_masked = false;
+    for (int k = 0; k < kDevMaxWindows; k++) {
+      uint32_t v = 0, m = 0;
+      for (int i = 0; i < 8; i++) {
+        const uint32_t vb = (i < 4 ? (D.win_value0[k] >> (8 * i)) : (D.win_value1[k] >> (8 * (i - 4)))) & 0xFFu;
+        const uint32_t mb = (i < 4 ? (D.win_mask0[k] >> (8 * i)) : (D.win_mask1[k] >> (8 * (i - 4)))) & 0xFFu;
+        const int at = 8 * (i & 3) + 4 * (i >> 2);
+        if (mb) {
+          v |= (vb & 15u) << at;
+          m |= 15u << at;
+        }
+      }
+      ws.value0[k] = v;
+      ws.mask0[k] = m;
+      nib_masked |= m != 0xFFFFFFFFu;
+    }
+    ws.masked = nib_masked;
+  }
+  ws.len = D.win_len;
+  ws.offset = D.win_offset;
+  return ws;
+}
+
 constexpr uint64_t kExactLimit = 1u << 20;  // bytes the one-lane exact kernel is allowed to walk
 constexpr uint64_t kDenseSegment = 1ull << 27;  // dense mode: starts per pipeline run (bounds the lists)
 
@@ -572,39 +617,7 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
     if (in_regions && windows) sp.zero_counters = s->counters.as<unsigned long long>();  // the scan kernel clears them
     else RJ_HIP(hipMemsetAsync(s->counters.p, 0, kCntSize * sizeof(unsigned long long), st));
     if (windows) {
-      WindowSet ws{};
-      bool masked = false;
-      for (int k = 0; k < kDevMaxWindows; k++) {
-        ws.value0[k] = D.win_value0[k];
-        ws.mask0[k] = D.win_mask0[k];
-        ws.value1[k] = D.win_value1[k];
-        ws.mask1[k] = D.win_mask1[k];
-        masked |= D.win_mask0[k] != 0xFFFFFFFFu || (D.win_len > 4 && D.win_mask1[k] != 0xFFFFFFFFu);
-      }
-      ws.masked = masked;
-      ws.two_level = rp->window_alphabet > 4;
-      ws.nibble = D.win_len > 4 && !ws.two_level && rp->window_nibbles;
-      if (ws.nibble) {
-        bool nib_masked = false;
-        for (int k = 0; k < kDevMaxWindows; k++) {
-          uint32_t v = 0, m = 0;
-          for (int i = 0; i < 8; i++) {
-            const uint32_t vb = (i < 4 ? (D.win_value0[k] >> (8 * i)) : (D.win_value1[k] >> (8 * (i - 4)))) & 0xFFu;
-            const uint32_t mb = (i < 4 ? (D.win_mask0[k] >> (8 * i)) : (D.win_mask1[k] >> (8 * (i - 4)))) & 0xFFu;
-            const int at = 8 * (i & 3) + 4 * (i >> 2);
-            if (mb) {
-              v |= (vb & 15u) << at;
-              m |= 15u << at;
-            }
-          }
-          ws.value0[k] = v;
-          ws.mask0[k] = m;
-          nib_masked |= m != 0xFFFFFFFFu;
-        }
-        ws.masked = nib_masked;
-      }
-      ws.len = D.win_len;
-      ws.offset = D.win_offset;
+      const WindowSet ws = make_window_set(rp);
       launch_scan_windows(sp, ws, D.n_windows, geo.grid, s->ev[1], s->ev[2], st);
     } else if (dense_walk) {
       launch_scan_dense_walk(sp, D, geo.grid, s->cand_end.as<uint64_t>(), s->counters.as<unsigned long long>(), s->ev[1],
@@ -1095,6 +1108,7 @@ void rj_scan_destroy(rj_scan* s) {
   for (auto& e : s->ev)
     if (e) (void)hipEventDestroy(e);
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
+  if (s->tail_stream) (void)hipStreamDestroy(s->tail_stream);
   delete s;
 }
 
@@ -1109,6 +1123,107 @@ int64_t rj_scan_run(rj_scan* s, const void* d_text, uint64_t n, uint64_t own_beg
 }
 
 const uint64_t* rj_scan_device_spans(const rj_scan* s) { return s ? s->result : nullptr; }
+
+// Start / finish: the scan of the next pattern does not have to wait for the (latency-bound)
+// verify + gather kernels of this one.  rj_scan_start enqueues the scan on the caller's stream and
+// the tail on the scan object's own stream (ordered after the scan by an event) and returns;
+// rj_scan_finish waits for the tail.  Whole text, no carry.  Anything but the common outcome (a
+// region overflowed, candidates overlap, a pattern the in-region pipeline does not take) is handled
+// by running the ordinary synchronous pipeline in rj_scan_finish.
+int rj_scan_start(rj_scan* s, const void* d_text, uint64_t n, void* hip_stream) {
+  ErrnoGuard errno_guard;
+  if (!s || (!d_text && n)) return fail(RJ_BAD_ARGUMENT, "null argument");
+  if (s->pending) return fail(RJ_BAD_ARGUMENT, "rj_scan_start: the previous start has not been finished");
+  if ((reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) return fail(RJ_BAD_ARGUMENT, "device text must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  s->pending = true;
+  s->pending_launched = false;
+  s->pending_text = static_cast<const uint8_t*>(d_text);
+  s->pending_n = n;
+  s->pending_stream = st;
+  const rj_program* rp = s->prog;
+  const DevProgram& D = rp->dev;
+  if (!(D.mode == 1 && D.float_range == 1 && D.n_words <= 4 && !rp->host->q8_risk && n >= 16)) return RJ_OK;
+  // (default priority: with a high-priority tail stream the runtime preempts the running scan's
+  // waves for every tail kernel -- measured 1.13 -> 1.68 ms per step.  At equal priority the tails
+  // mostly run when the queued scans have drained; what is saved is the host round trip per call.)
+  if (!s->tail_stream) RJ_HIP(hipStreamCreateWithFlags(&s->tail_stream, hipStreamNonBlocking));
+  ScanParams sp{};
+  sp.text = s->pending_text;
+  sp.n = n;
+  sp.sb = 0;
+  sp.se = n + 1;
+  sp.wlo = D.win_offset;
+  const uint64_t last_w = n >= D.win_len ? n - D.win_len + 1 : 0;
+  sp.whi = std::min<uint64_t>(n + 1 + D.win_offset, last_w);
+  if (sp.whi < sp.wlo) sp.whi = sp.wlo;
+  const uint64_t first_chunk = sp.wlo / 1024, end_chunk = (sp.whi + 1023) / 1024;
+  const ScanGeometry geo = scan_geometry(std::max<uint64_t>(end_chunk > first_chunk ? end_chunk - first_chunk : 0, 1));
+  sp.span_chunks = geo.span_chunks;
+  const uint64_t region_cap = std::min<uint64_t>(std::max<uint64_t>(s->region_cap_hint, 64), geo.span_chunks * 1024);
+  int rc = ensure_lists(s, geo.n_regions, static_cast<uint32_t>(region_cap), static_cast<uint64_t>(geo.n_regions) * region_cap);
+  if (rc != RJ_OK) return rc;
+  RJ_HIP(s->valid_counts.reserve(static_cast<size_t>(geo.n_regions) * sizeof(uint32_t)));
+  sp.hits = s->hits.as<uint64_t>();
+  sp.region_cap = static_cast<uint32_t>(region_cap);
+  sp.hit_counts = s->hit_counts.as<uint32_t>();
+  sp.zero_counters = s->counters.as<unsigned long long>();
+  s->stats = rj_stats{};
+  s->result = nullptr;
+  s->result_count = 0;
+  launch_scan_windows(sp, make_window_set(rp), D.n_windows, geo.grid, s->ev[1], s->ev[2], st);
+  RJ_HIP(hipEventRecord(s->ev[0], st));
+  RJ_HIP(hipStreamWaitEvent(s->tail_stream, s->ev[0], 0));
+  VerifyParams vp{};
+  vp.text = s->pending_text;
+  vp.n = n;
+  vp.hits = s->hits.as<uint64_t>();
+  vp.n_regions = geo.n_regions;
+  vp.region_cap = static_cast<uint32_t>(region_cap);
+  vp.counters = s->counters.as<unsigned long long>();
+  vp.sb = 0;
+  vp.se = n + 1;
+  vp.expand = 1;
+  vp.float_max = D.float_max;
+  launch_verify_in_regions(vp, D, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(), s->cand_end.as<uint64_t>(),
+                           s->tail_stream);
+  s->host_counters[kCntUnordered] = 0;
+  s->host_counters[kCntAdjacent] = 0;
+  launch_offsets_gather_check(s->valid_counts.as<uint32_t>(), s->hits.as<uint64_t>(), s->cand_end.as<uint64_t>(), geo.n_regions,
+                              static_cast<uint32_t>(region_cap), 0, s->out.as<uint64_t>(), s->out_cap,
+                              s->counters.as<unsigned long long>(), s->host_counters, nullptr, nullptr, s->tail_stream);
+  s->pending_launched = true;
+  return RJ_OK;
+}
+
+int64_t rj_scan_finish(rj_scan* s) {
+  ErrnoGuard errno_guard;
+  if (!s) return fail(RJ_BAD_ARGUMENT, "null scan");
+  if (!s->pending) return fail(RJ_BAD_ARGUMENT, "rj_scan_finish without rj_scan_start");
+  s->pending = false;
+  if (s->pending_launched) {
+    RJ_HIP(hipStreamSynchronize(s->tail_stream));
+    RJ_HIP(hipGetLastError());
+    const unsigned long long* hc = s->host_counters;
+    if (hc[kCntOverflow] == 0 && hc[kCntOverrun] == 0 && hc[kCntUnordered] == 0) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, s->ev[1], s->ev[2]);
+      s->stats.scan_ms = ms;
+      s->stats.n_hits = hc[kCntHits];
+      s->stats.n_candidates = hc[kCntCands];
+      s->hits_hint = hc[kCntHits];
+      s->result_count = hc[kCntCands];
+      s->result = s->out.as<uint64_t>();
+      s->stats.n_matches = s->result_count;
+      return static_cast<int64_t>(s->result_count);
+    }
+    if (hc[kCntOverflow] != 0)  // size the regions for the fullest one before running again
+      s->region_cap_hint = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(hc[kCntMaxRegion] * 2, 256), 1u << 20));
+  }
+  int rc = run_pipeline(s, s->pending_text, s->pending_n, 0, s->pending_n + 1, 0, 0, 0, s->pending_stream);
+  if (rc != RJ_OK) return rc;
+  return static_cast<int64_t>(s->result_count);
+}
 
 int64_t rj_scan_copy_spans(const rj_scan* s, uint64_t* host_spans, uint64_t cap) {
   ErrnoGuard errno_guard;

@@ -371,6 +371,38 @@ def test_dense_output_gather_paths(rj, oracle):
                 assert p.match_all(text) == want, (rx, n, call)
 
 
+def test_scan_start_finish_equals_run(rj):
+    """rj_scan_start / rj_scan_finish with several scans in flight (all started, then all finished)
+    give the results of rj_scan_run -- for patterns the overlapped tail takes (fixed windows) and for
+    those that fall back to the synchronous pipeline (dense, floating, Q8-risk, overlapping
+    candidates, a region overflow on the first call)."""
+    import torch
+    from rejit_amd import workloads as W
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    pats = W.REGEXDNA_PATTERNS + ["[cgt]+a", "(ag|ga)+", "a.{0,2}g", "agggtaaa", "ttt", "[acgt]{2,9}tttaccct"]
+    progs = [rj.Program(p) for p in pats]
+    for t in (W.fasta_stripped_torch(50000, dev), W.fasta_stripped_torch(2000000, dev),
+              torch.from_numpy(np.frombuffer(b"agggtaaatttaccct" * 30000, dtype=np.uint8).copy()).to(dev)):
+        n = int(t.numel())
+        a = [rj.Scan(p) for p in progs]
+        b = [rj.Scan(p) for p in progs]
+        for rounds in range(2):            # second round: hints are warm
+            for sc in a:
+                sc.start(t.data_ptr(), n, stream=st)
+            got = [sc.finish() for sc in a]
+            want = [sc.run(t.data_ptr(), n, stream=st) for sc in b]
+            assert got == want
+            for x, y, p in zip(a, b, pats):
+                assert x.spans() == y.spans(), p
+    with pytest.raises(rj.RejitError):
+        a[0].finish()                      # nothing started
+    a[0].start(t.data_ptr(), n, stream=st)
+    with pytest.raises(rj.RejitError):
+        a[0].start(t.data_ptr(), n, stream=st)
+    a[0].finish()
+
+
 def test_many_matches_large_path(rj, oracle):
     """More candidates than the LDS finalize holds: the rocPRIM sort path."""
     rng = random.Random(9)
