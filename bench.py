@@ -58,7 +58,7 @@ def parse_args():
     ap.add_argument("--no-extra", action="store_true", help="skip the literal_scan extra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial-calls", action="store_true", help="headline with nine synchronous rj_scan_run calls per step "
-                    "instead of nine rj_scan_start followed by nine rj_scan_finish")
+                    "instead of one rj_multi_run (separate scans, batched tails)")
     ap.add_argument("--cpu-sample-mib", type=int, default=64)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for "
                     "functional tests of the multi-rank path on a 1-GPU box together with --same-device")
@@ -156,26 +156,30 @@ def main():
         st_i = streams[i].cuda_stream if (pool or own_stream) else stream
         return scans[i].run(text_ptr, n_local, own_begin=own_lo, own_end=own_hi, stream=st_i)
 
-    # Single-GPU headline: the nine calls of a step are STARTED back to back on one stream and then
-    # finished (rj_scan_start / rj_scan_finish).  The scan kernels still run one after the other
-    # -- so their HIP-event durations, from which the roofline is computed, are undisturbed -- but
-    # the short verify / gather kernels of pattern i run (on the scan's own stream) while pattern
-    # i+1 is being scanned instead of holding the GPU idle around a host round trip.
-    use_start_finish = world == 1 and not pool and not args.serial_calls
+    # Single-GPU headline: the nine patterns of a step go through rj_multi_run in its "separate
+    # scans" mode -- nine scan kernels queued back to back (each the ordinary single-pattern kernel at
+    # its full streaming rate, timed by its own dispatch timestamps: the roofline below), then the
+    # verify / gather tails of all nine patterns in two launches and ONE host synchronise, instead of
+    # nine round trips.  (The fused single-kernel mode is reported as `fused`, the nine synchronous
+    # calls as `serial_calls`.)
+    use_multi = world == 1 and not pool and not args.serial_calls
+    multi_sep = None
+    if use_multi:
+        multi_sep = rejit_amd.MultiScan(progs)
+        multi_sep.set_mode(1)
+        sep_scans = [multi_sep.scan(i) for i in range(len(progs))]
 
     pending = []   # (all_reduce work, device tensor) of steps whose exchange is still in flight
 
     def step(record: bool):
         if pool:
             local = list(pool.map(run_one, range(len(scans))))
-        elif use_start_finish:
-            for sc in scans:
-                sc.start(text_ptr, n_local, stream=stream)
-            local = [sc.finish() for sc in scans]
+        elif use_multi:
+            local = multi_sep.run(text_ptr, n_local, stream=stream)
         else:
             local = [run_one(i) for i in range(len(scans))]
         if record:
-            scan_ms.extend(sc.stats()["scan_ms"] for sc in scans)
+            scan_ms.extend(sc.stats()["scan_ms"] for sc in (sep_scans if use_multi else scans))
         if world > 1:
             # exchange step of the path: sum of the 9 match counts (72 bytes) over the ranks, RCCL over
             # xGMI.  It is issued asynchronously and collected one step later, so the next step's scans
@@ -233,7 +237,7 @@ def main():
                    "fasta_n_per_gpu": args.fasta_n, "text_bytes_per_gpu": int(own_bytes), "patterns": len(patterns),
                    "sharding": "contiguous byte ranges + %d-byte halo; all_reduce of 9 counts per step" % (max_len - 1),
                    "pattern_threads": n_thr,
-                   "calls": "9 x rj_scan_start then 9 x rj_scan_finish per step" if use_start_finish else "9 x rj_scan_run per step"},
+                   "calls": "rj_multi_run, separate scan kernels + batched tails (mode 1)" if use_multi else "9 x rj_scan_run per step"},
         "matches_per_s": round(total_matches * args.steps / elapsed, 1),
         "matches_per_pass": counts,
         "roofline": {"bound": "hbm", "kernel": "scan_windows<K>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -243,7 +247,7 @@ def main():
                      "launches_timed": len(scan_ms)},
     }
 
-    if rank == 0 and world == 1 and not args.no_extra and use_start_finish:
+    if rank == 0 and world == 1 and not args.no_extra and use_multi:
         # the same job as nine synchronous calls per step (every call waits for its own tail)
         for _ in range(2):
             cs = [run_one(i) for i in range(len(scans))]
@@ -253,7 +257,7 @@ def main():
             cs = [run_one(i) for i in range(len(scans))]
         torch.cuda.synchronize(dev)
         es = time.perf_counter() - t1
-        assert cs == counts, "synchronous calls disagree with start/finish"
+        assert cs == counts, "synchronous calls disagree with rj_multi_run"
         out["serial_calls"] = {"calls": "9 x rj_scan_run per step", "value": round(scanned / es / 1e9, 3), "unit": "GB/s",
                                "ms_per_step": round(es / args.steps * 1e3, 4)}
 

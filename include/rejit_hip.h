@@ -140,11 +140,15 @@ int rj_scan_match_full(rj_scan* scan, const void* d_text, uint64_t n, void* hip_
 typedef struct rj_multi rj_multi;
 int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out);
 void rj_multi_destroy(rj_multi* multi);
-/* counts[i] = matches of pattern i over d_text[0..n); returns 1 when the fused kernel ran, 0 when
- * the patterns ran one by one, <0 = rj_status */
+/* counts[i] = matches of pattern i over d_text[0..n).  Returns how the set was run: 1 = one fused scan
+ * kernel for all patterns; 2 = one scan kernel per pattern queued back to back, then the verify /
+ * gather tails of all patterns in two launches and a single synchronise (any set of fixed-window
+ * patterns); 0 = one complete pipeline after the other; <0 = rj_status */
 int rj_multi_run(rj_multi* multi, const void* d_text, uint64_t n, uint64_t* counts, void* hip_stream);
 rj_scan* rj_multi_scan(rj_multi* multi, int i);
-/* duration of the last fused scan kernel in ms (0 when not fused) */
+/* mode 0 (default): fuse when possible; mode 1: never fuse (separate scan kernels) */
+int rj_multi_set_mode(rj_multi* multi, int mode);
+/* duration of the last run's scan kernel(s) in ms, summed (0 when the patterns ran one by one) */
 float rj_multi_scan_ms(const rj_multi* multi);
 
 /* number of visible HIP devices (0 when there is none), for callers that want to probe */

@@ -106,7 +106,7 @@ C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_er
                  "rj_scan_destroy", "rj_scan_run", "rj_scan_device_spans", "rj_scan_copy_spans", "rj_scan_stats",
                  "rj_scan_match_full", "rj_device_count", "rj_replace_all", "rj_free_text", "rj_scan_replace",
                  "rj_match_all_batch", "rj_multi_create", "rj_multi_destroy", "rj_multi_run", "rj_multi_scan",
-                 "rj_multi_scan_ms", "rj_scan_start", "rj_scan_finish"]
+                 "rj_multi_scan_ms", "rj_scan_start", "rj_scan_finish", "rj_multi_set_mode"]
 
 
 def load_library():
@@ -146,6 +146,7 @@ def load_library():
     L.rj_multi_scan.argtypes = [vp, ctypes.c_int]
     L.rj_multi_scan_ms.restype = ctypes.c_float
     L.rj_multi_scan_ms.argtypes = [vp]
+    L.rj_multi_set_mode.argtypes = [vp, ctypes.c_int]
     L.rj_scan_destroy.argtypes = [vp]
     L.rj_scan_run.restype = i64
     L.rj_scan_run.argtypes = [vp, vp, u64, u64, u64, u64, u64, ctypes.c_int, vp]
@@ -339,6 +340,11 @@ class MultiScan:
         _check(self._lib.rj_multi_create(arr, len(programs), ctypes.byref(h)))
         self._h = h
         self.fused = False
+        self.how = 0
+
+    def set_mode(self, mode: int) -> None:
+        """0: fuse the scans when possible (default); 1: one scan kernel per pattern."""
+        _check(self._lib.rj_multi_set_mode(self._h, mode))
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -349,7 +355,8 @@ class MultiScan:
     def run(self, d_text_ptr: int, n: int, stream: int = 0) -> List[int]:
         counts = (ctypes.c_uint64 * len(self.programs))()
         r = _check(self._lib.rj_multi_run(self._h, ctypes.c_void_p(d_text_ptr), n, counts, ctypes.c_void_p(stream)))
-        self.fused = bool(r)
+        self.how = int(r)          # 1 fused scan, 2 separate scans + batched tails, 0 one by one
+        self.fused = r == 1
         return [int(c) for c in counts]
 
     def scan(self, i: int) -> Scan:

@@ -873,6 +873,12 @@ int stage_text(rj_scan* s, const char* text, size_t n, const uint8_t** d_text) {
 }
 
 // ----------------------------------------------------------------------------- fused multi-pattern run
+// fixed windows + lane-sized automaton, not at risk of Q8: the in-region pipeline without carry
+bool batchable(const rj_program* rp) {
+  const DevProgram& D = rp->dev;
+  return D.mode == 1 && D.float_range == 1 && D.n_words <= 4 && !rp->host->q8_risk;
+}
+
 bool fusable(const rj_program* rp) {
   const DevProgram& D = rp->dev;
   return D.mode == 1 && D.float_range == 1 && D.n_words <= 4 && D.win_len > 4 && D.n_windows <= 2 &&
@@ -902,14 +908,18 @@ struct rj_multi {
   DeviceBuffer dummy_counts;  // hit_counts of the padding patterns
   DeviceBuffer tails;         // MultiTail[P]
   MultiTail* host_tails = nullptr;  // pinned
-  bool fused = false;
+  std::vector<MultiTail> uploaded;  // what the device array holds (skip the copy when nothing changed)
+  bool fused = false;     // every pattern has a nibble-form window set: one kernel scans for all
+  bool batchable = false; // every pattern takes the in-region pipeline: scans back to back, tails together
+  int mode = 0;           // rj_multi_set_mode
   float scan_ms = 0.f;
 };
 
 namespace {
 
-// One fused scan + the tails of all patterns in two launches.  Whole text, starts [0, n].
-int run_fused(rj_multi* m, const uint8_t* d_text, uint64_t n, hipStream_t st) {
+// The scans of all patterns (ONE fused kernel, or one kernel per pattern back to back) + the tails of
+// all patterns in two launches + one synchronise.  Whole text, starts [0, n].
+int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, hipStream_t st, bool fuse) {
   const int P = static_cast<int>(m->scans.size());
   const uint64_t chunks = std::max<uint64_t>((n + 1023) / 1024, 1);
   const ScanGeometry geo = scan_geometry(chunks);
@@ -952,7 +962,33 @@ int run_fused(rj_multi* m, const uint8_t* d_text, uint64_t n, hipStream_t st) {
       }
     }
     rj_scan* s0 = m->scans[0];
-    launch_scan_windows_fused(fp, geo.grid, s0->ev[1], s0->ev[2], st);
+    if (fuse) {
+      launch_scan_windows_fused(fp, geo.grid, s0->ev[1], s0->ev[2], st);
+    } else {
+      // every pattern's own scan kernel, queued back to back (each at its full streaming rate)
+      for (int p = 0; p < P; p++) {
+        rj_scan* s = m->scans[static_cast<size_t>(p)];
+        const DevProgram& D = s->prog->dev;
+        ScanParams sp{};
+        sp.text = d_text;
+        sp.n = n;
+        sp.sb = 0;
+        sp.se = n + 1;
+        sp.wlo = D.win_offset;
+        const uint64_t last_w = n >= D.win_len ? n - D.win_len + 1 : 0;
+        sp.whi = std::min<uint64_t>(n + 1 + D.win_offset, last_w);
+        if (sp.whi < sp.wlo) sp.whi = sp.wlo;
+        sp.span_chunks = geo.span_chunks;
+        sp.hits = s->hits.as<uint64_t>();
+        sp.region_cap = static_cast<uint32_t>(caps[static_cast<size_t>(p)]);
+        sp.hit_counts = s->hit_counts.as<uint32_t>();
+        sp.zero_counters = s->counters.as<unsigned long long>();
+        // one pair of timestamps around the whole train of scan kernels (first kernel's start, last
+        // kernel's end): a pair per kernel puts a completion signal between consecutive kernels
+        launch_scan_windows(sp, make_window_set(s->prog), D.n_windows, geo.grid, p == 0 ? s0->ev[1] : nullptr,
+                            p == P - 1 ? s0->ev[2] : nullptr, st);
+      }
+    }
     // the single-pattern tails (verify inside the regions, offsets + gather + check) of all patterns
     // in two launches; their parameters travel as one small array
     for (int p = 0; p < P; p++) {
@@ -979,7 +1015,11 @@ int run_fused(rj_multi* m, const uint8_t* d_text, uint64_t n, hipStream_t st) {
       s->host_counters[kCntUnordered] = 0;
       s->host_counters[kCntAdjacent] = 0;
     }
-    RJ_HIP(hipMemcpyAsync(m->tails.p, m->host_tails, sizeof(MultiTail) * P, hipMemcpyHostToDevice, st));
+    if (m->uploaded.size() != static_cast<size_t>(P) ||
+        memcmp(m->uploaded.data(), m->host_tails, sizeof(MultiTail) * static_cast<size_t>(P)) != 0) {
+      RJ_HIP(hipMemcpyAsync(m->tails.p, m->host_tails, sizeof(MultiTail) * P, hipMemcpyHostToDevice, st));
+      m->uploaded.assign(m->host_tails, m->host_tails + P);
+    }
     launch_tails_multi(m->tails.as<MultiTail>(), P, geo.n_regions, st);
     RJ_HIP(hipStreamSynchronize(st));
     RJ_HIP(hipGetLastError());
@@ -994,7 +1034,11 @@ int run_fused(rj_multi* m, const uint8_t* d_text, uint64_t n, hipStream_t st) {
         again = true;
       }
     }
-    (void)hipEventElapsedTime(&m->scan_ms, s0->ev[1], s0->ev[2]);
+    if (fuse) {
+      (void)hipEventElapsedTime(&m->scan_ms, s0->ev[1], s0->ev[2]);
+    } else {
+      (void)hipEventElapsedTime(&m->scan_ms, s0->ev[1], s0->ev[2]);  // first start to last end, gaps included
+    }
     if (again) continue;
     for (int p = 0; p < P; p++) {
       rj_scan* s = m->scans[static_cast<size_t>(p)];
@@ -1018,7 +1062,7 @@ int run_fused(rj_multi* m, const uint8_t* d_text, uint64_t n, hipStream_t st) {
       if (rc != RJ_OK) return rc;
       s->result = s->out.as<uint64_t>();
       s->stats.n_matches = s->result_count;
-      s->stats.scan_ms = m->scan_ms;
+      s->stats.scan_ms = fuse ? m->scan_ms : m->scan_ms / static_cast<float>(P);
     }
     return RJ_OK;
   }
@@ -1309,7 +1353,7 @@ int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out)
   if (!progs || !out || n_progs < 1) return fail(RJ_BAD_ARGUMENT, "null argument");
   if (n_progs > kMaxFused - kFuseGroup + 1) return fail(RJ_BAD_ARGUMENT, "at most %d patterns per rj_multi", kMaxFused - kFuseGroup + 1);
   auto m = std::make_unique<rj_multi>();
-  bool all = true;
+  bool all = true, all_batchable = true;
   for (int i = 0; i < n_progs; i++) {
     if (!progs[i]) return fail(RJ_BAD_ARGUMENT, "null program");
     rj_scan* s = nullptr;
@@ -1320,6 +1364,7 @@ int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out)
     }
     m->scans.push_back(s);
     all = all && fusable(progs[i]);
+    all_batchable = all_batchable && batchable(progs[i]);
   }
   if (m->tails.reserve(sizeof(MultiTail) * static_cast<size_t>(n_progs)) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&m->host_tails), sizeof(MultiTail) * static_cast<size_t>(n_progs)) != hipSuccess) {
@@ -1327,6 +1372,7 @@ int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out)
     return fail(RJ_DEVICE_ERROR, "out of memory");
   }
   m->fused = all && n_progs > 1 && getenv("RJ_NO_FUSION") == nullptr;
+  m->batchable = all_batchable && n_progs > 1;
   *out = m.release();
   return RJ_OK;
 }
@@ -1346,10 +1392,14 @@ int rj_multi_run(rj_multi* m, const void* d_text, uint64_t n, uint64_t* counts, 
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   m->scan_ms = 0.f;
   int fused = 0;
-  if (m->fused && n >= 16) {
-    int rc = run_fused(m, static_cast<const uint8_t*>(d_text), n, st);
+  if (m->fused && m->mode == 0 && n >= 16) {
+    int rc = run_batched(m, static_cast<const uint8_t*>(d_text), n, st, true);
     if (rc != RJ_OK) return rc;
     fused = 1;
+  } else if (m->batchable && n >= 16) {
+    int rc = run_batched(m, static_cast<const uint8_t*>(d_text), n, st, false);
+    if (rc != RJ_OK) return rc;
+    fused = 2;
   } else {
     for (rj_scan* s : m->scans) {
       int rc = run_pipeline(s, static_cast<const uint8_t*>(d_text), n, 0, n + 1, 0, 0, 0, st);
@@ -1366,6 +1416,12 @@ rj_scan* rj_multi_scan(rj_multi* m, int i) {
 }
 
 float rj_multi_scan_ms(const rj_multi* m) { return m ? m->scan_ms : 0.f; }
+
+int rj_multi_set_mode(rj_multi* m, int mode) {
+  if (!m || mode < 0 || mode > 1) return fail(RJ_BAD_ARGUMENT, "bad argument");
+  m->mode = mode;
+  return RJ_OK;
+}
 
 void rj_free_text(char* text) { free(text); }
 

@@ -330,12 +330,30 @@ def test_fused_multi_pattern_equals_single_runs(rj):
         t = texts[1][1000:1000 + max(n, 1)].clone()
         counts = multi.run(t.data_ptr(), n, stream=st)
         assert counts == [sc.run(t.data_ptr(), n, stream=st) for sc in singles], n
-    mixed = [rj.Program(b"agggtaaa|tttaccct"), rj.Program(b"[cgt]+a"), rj.Program(b"regexp")]
-    m2 = rj.MultiScan(mixed)
+    # the same nine patterns with separate scan kernels and batched tails (mode 1)
+    sep = rj.MultiScan(progs)
+    sep.set_mode(1)
+    for t in texts:
+        n = int(t.numel())
+        counts = sep.run(t.data_ptr(), n, stream=st)
+        assert sep.how == 2
+        for i, sc in enumerate(singles):
+            assert counts[i] == sc.run(t.data_ptr(), n, stream=st)
+            assert sep.scan(i).spans() == sc.spans(), i
+    # a set that cannot be fused but can be batched (large alphabet, one window, 4-byte window) ...
     t = texts[0]
-    counts = m2.run(t.data_ptr(), int(t.numel()), stream=st)
-    assert not m2.fused
-    assert counts == [rj.Scan(p).run(t.data_ptr(), int(t.numel()), stream=st) for p in mixed]
+    n = int(t.numel())
+    batch = [rj.Program(b"agggtaaa|tttaccct"), rj.Program(b"gggt"), rj.Program(b"regexp"), rj.Program(b"ag[ct]g")]
+    m2 = rj.MultiScan(batch)
+    counts = m2.run(t.data_ptr(), n, stream=st)
+    assert m2.how == 2
+    assert counts == [rj.Scan(p).run(t.data_ptr(), n, stream=st) for p in batch]
+    # ... and one that has to run pattern by pattern (a dense pattern in the set)
+    mixed = [rj.Program(b"agggtaaa|tttaccct"), rj.Program(b"[cgt]+a"), rj.Program(b"regexp")]
+    m3 = rj.MultiScan(mixed)
+    counts = m3.run(t.data_ptr(), n, stream=st)
+    assert m3.how == 0 and not m3.fused
+    assert counts == [rj.Scan(p).run(t.data_ptr(), n, stream=st) for p in mixed]
 
 
 def test_concurrent_match_all_on_one_program(rj, oracle):
