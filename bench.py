@@ -156,13 +156,13 @@ def main():
         st_i = streams[i].cuda_stream if (pool or own_stream) else stream
         return scans[i].run(text_ptr, n_local, own_begin=own_lo, own_end=own_hi, stream=st_i)
 
-    # Single-GPU headline: the nine patterns of a step go through rj_multi_run in its "separate
+    # Headline: the nine patterns of a step go through rj_multi_run in its "separate
     # scans" mode -- nine scan kernels queued back to back (each the ordinary single-pattern kernel at
     # its full streaming rate, timed by its own dispatch timestamps: the roofline below), then the
     # verify / gather tails of all nine patterns in two launches and ONE host synchronise, instead of
     # nine round trips.  (The fused single-kernel mode is reported as `fused`, the nine synchronous
     # calls as `serial_calls`.)
-    use_multi = world == 1 and not pool and not args.serial_calls
+    use_multi = not pool and not args.serial_calls
     multi_sep = None
     if use_multi:
         multi_sep = rejit_amd.MultiScan(progs)
@@ -175,7 +175,7 @@ def main():
         if pool:
             local = list(pool.map(run_one, range(len(scans))))
         elif use_multi:
-            local = multi_sep.run(text_ptr, n_local, stream=stream)
+            local = multi_sep.run(text_ptr, n_local, stream=stream, own_begin=own_lo, own_end=own_hi)
         else:
             local = [run_one(i) for i in range(len(scans))]
         if record:

@@ -145,6 +145,10 @@ void rj_multi_destroy(rj_multi* multi);
  * gather tails of all patterns in two launches and a single synchronise (any set of fixed-window
  * patterns); 0 = one complete pipeline after the other; <0 = rj_status */
 int rj_multi_run(rj_multi* multi, const void* d_text, uint64_t n, uint64_t* counts, void* hip_stream);
+/* the same for the matches whose begin lies in [own_begin, own_end) -- a shard with its halo inside
+ * [0, n), as for rj_scan_run; no selection state is carried in (first shard / independent ranges) */
+int rj_multi_run_range(rj_multi* multi, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end,
+                       uint64_t* counts, void* hip_stream);
 rj_scan* rj_multi_scan(rj_multi* multi, int i);
 /* mode 0 (default): fuse when possible; mode 1: never fuse (separate scan kernels) */
 int rj_multi_set_mode(rj_multi* multi, int mode);

@@ -106,7 +106,7 @@ C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_er
                  "rj_scan_destroy", "rj_scan_run", "rj_scan_device_spans", "rj_scan_copy_spans", "rj_scan_stats",
                  "rj_scan_match_full", "rj_device_count", "rj_replace_all", "rj_free_text", "rj_scan_replace",
                  "rj_match_all_batch", "rj_multi_create", "rj_multi_destroy", "rj_multi_run", "rj_multi_scan",
-                 "rj_multi_scan_ms", "rj_scan_start", "rj_scan_finish", "rj_multi_set_mode"]
+                 "rj_multi_scan_ms", "rj_scan_start", "rj_scan_finish", "rj_multi_set_mode", "rj_multi_run_range"]
 
 
 def load_library():
@@ -142,6 +142,7 @@ def load_library():
     L.rj_multi_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(vp)]
     L.rj_multi_destroy.argtypes = [vp]
     L.rj_multi_run.argtypes = [vp, vp, u64, _u64p, vp]
+    L.rj_multi_run_range.argtypes = [vp, vp, u64, u64, u64, _u64p, vp]
     L.rj_multi_scan.restype = vp
     L.rj_multi_scan.argtypes = [vp, ctypes.c_int]
     L.rj_multi_scan_ms.restype = ctypes.c_float
@@ -352,9 +353,10 @@ class MultiScan:
             self._lib.rj_multi_destroy(h)
             self._h = None
 
-    def run(self, d_text_ptr: int, n: int, stream: int = 0) -> List[int]:
+    def run(self, d_text_ptr: int, n: int, stream: int = 0, own_begin: int = 0, own_end: Optional[int] = None) -> List[int]:
         counts = (ctypes.c_uint64 * len(self.programs))()
-        r = _check(self._lib.rj_multi_run(self._h, ctypes.c_void_p(d_text_ptr), n, counts, ctypes.c_void_p(stream)))
+        r = _check(self._lib.rj_multi_run_range(self._h, ctypes.c_void_p(d_text_ptr), n, own_begin,
+                                                n + 1 if own_end is None else own_end, counts, ctypes.c_void_p(stream)))
         self.how = int(r)          # 1 fused scan, 2 separate scans + batched tails, 0 one by one
         self.fused = r == 1
         return [int(c) for c in counts]

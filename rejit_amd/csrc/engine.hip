@@ -919,16 +919,18 @@ namespace {
 
 // The scans of all patterns (ONE fused kernel, or one kernel per pattern back to back) + the tails of
 // all patterns in two launches + one synchronise.  Whole text, starts [0, n].
-int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, hipStream_t st, bool fuse) {
+int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, hipStream_t st, bool fuse) {
   const int P = static_cast<int>(m->scans.size());
-  const uint64_t chunks = std::max<uint64_t>((n + 1023) / 1024, 1);
+  // chunks that can hold a window of a start in [sb, se): a window begins at most 7 bytes after its start
+  const uint64_t end_byte = std::min<uint64_t>(n, se + 8);
+  const uint64_t chunks = std::max<uint64_t>((end_byte + 1023) / 1024 - sb / 1024, 1);
   const ScanGeometry geo = scan_geometry(chunks);
   for (int attempt = 0; attempt < 6; attempt++) {
     FusedParams fp{};
     fp.text = d_text;
     fp.n = n;
-    fp.sb = 0;
-    fp.se = n + 1;
+    fp.sb = sb;
+    fp.se = se;
     fp.span_chunks = geo.span_chunks;
     fp.n_patterns = static_cast<uint32_t>((P + kFuseGroup - 1) / kFuseGroup * kFuseGroup);
     RJ_HIP(m->dummy_counts.reserve(static_cast<size_t>(geo.n_regions) * sizeof(uint32_t)));
@@ -972,11 +974,11 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, hipStream_t st, 
         ScanParams sp{};
         sp.text = d_text;
         sp.n = n;
-        sp.sb = 0;
-        sp.se = n + 1;
-        sp.wlo = D.win_offset;
+        sp.sb = sb;
+        sp.se = se;
+        sp.wlo = sb + D.win_offset;
         const uint64_t last_w = n >= D.win_len ? n - D.win_len + 1 : 0;
-        sp.whi = std::min<uint64_t>(n + 1 + D.win_offset, last_w);
+        sp.whi = std::min<uint64_t>(se + D.win_offset, last_w);
         if (sp.whi < sp.wlo) sp.whi = sp.wlo;
         sp.span_chunks = geo.span_chunks;
         sp.hits = s->hits.as<uint64_t>();
@@ -1001,8 +1003,8 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, hipStream_t st, 
       t.verify.n_regions = geo.n_regions;
       t.verify.region_cap = static_cast<uint32_t>(caps[static_cast<size_t>(p)]);
       t.verify.counters = s->counters.as<unsigned long long>();
-      t.verify.sb = 0;
-      t.verify.se = n + 1;
+      t.verify.sb = sb;
+      t.verify.se = se;
       t.verify.expand = 1;
       t.verify.float_max = s->prog->dev.float_max;
       t.program = s->prog->dev;
@@ -1386,23 +1388,33 @@ void rj_multi_destroy(rj_multi* m) {
 }
 
 int rj_multi_run(rj_multi* m, const void* d_text, uint64_t n, uint64_t* counts, void* hip_stream) {
+  return rj_multi_run_range(m, d_text, n, 0, n + 1, counts, hip_stream);
+}
+
+int rj_multi_run_range(rj_multi* m, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end, uint64_t* counts,
+                       void* hip_stream) {
   ErrnoGuard errno_guard;
   if (!m || (!d_text && n) || !counts) return fail(RJ_BAD_ARGUMENT, "null argument");
+  if (own_end > n + 1) own_end = n + 1;
+  if (own_begin >= own_end) {
+    for (size_t i = 0; i < m->scans.size(); i++) counts[i] = 0;
+    return 0;
+  }
   if ((reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) return fail(RJ_BAD_ARGUMENT, "device text must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   m->scan_ms = 0.f;
   int fused = 0;
   if (m->fused && m->mode == 0 && n >= 16) {
-    int rc = run_batched(m, static_cast<const uint8_t*>(d_text), n, st, true);
+    int rc = run_batched(m, static_cast<const uint8_t*>(d_text), n, own_begin, own_end, st, true);
     if (rc != RJ_OK) return rc;
     fused = 1;
   } else if (m->batchable && n >= 16) {
-    int rc = run_batched(m, static_cast<const uint8_t*>(d_text), n, st, false);
+    int rc = run_batched(m, static_cast<const uint8_t*>(d_text), n, own_begin, own_end, st, false);
     if (rc != RJ_OK) return rc;
     fused = 2;
   } else {
     for (rj_scan* s : m->scans) {
-      int rc = run_pipeline(s, static_cast<const uint8_t*>(d_text), n, 0, n + 1, 0, 0, 0, st);
+      int rc = run_pipeline(s, static_cast<const uint8_t*>(d_text), n, own_begin, own_end, 0, 0, 0, st);
       if (rc != RJ_OK) return rc;
     }
   }

@@ -459,7 +459,9 @@ __global__ __launch_bounds__(256) void scan_windows_fused(FusedParams a) {
     for (uint32_t p = 0; p < a.n_patterns; p++)
       if (a.zero_counters[p] != nullptr) a.zero_counters[p][lane] = 0;
   const uint64_t first_chunk = a.sb / kChunk;
-  const uint64_t end_chunk = (a.n + kChunk - 1) / kChunk;  // a window may begin up to 7 bytes after its start
+  // a window may begin up to 7 bytes after its start
+  const uint64_t end_byte = a.se + 8 < a.n ? a.se + 8 : a.n;
+  const uint64_t end_chunk = (end_byte + kChunk - 1) / kChunk;
   WaveSpan span;
   span.c0 = first_chunk + wave * a.span_chunks;
   span.c1 = span.c0 + a.span_chunks;

@@ -340,6 +340,15 @@ def test_fused_multi_pattern_equals_single_runs(rj):
         for i, sc in enumerate(singles):
             assert counts[i] == sc.run(t.data_ptr(), n, stream=st)
             assert sep.scan(i).spans() == sc.spans(), i
+    # shards: matches that begin in [own_begin, own_end) of a text with its halo (multi-GPU ranks)
+    t = texts[1]
+    n = int(t.numel())
+    for lo, hi in ((0, 1000000), (999999, 2000001), (1234567, n + 1), (5, 6)):
+        for ms in (multi, sep):
+            counts = ms.run(t.data_ptr(), n, stream=st, own_begin=lo, own_end=hi)
+            for i, sc in enumerate(singles):
+                assert counts[i] == sc.run(t.data_ptr(), n, own_begin=lo, own_end=hi, stream=st), (lo, hi, i)
+                assert ms.scan(i).spans() == sc.spans()
     # a set that cannot be fused but can be batched (large alphabet, one window, 4-byte window) ...
     t = texts[0]
     n = int(t.numel())
