@@ -913,9 +913,15 @@ __global__ __launch_bounds__(256) void verify_floating_in_regions(VerifyParams a
 // The tails of several patterns in one launch (rj_multi): blockIdx.y selects the pattern, whose
 // parameters are read from a device array.
 __global__ __launch_bounds__(256) void verify_in_regions_multi(const MultiTail* tails) {
-  const MultiTail& t = tails[blockIdx.y];
-  if (t.program.n_words <= 2) verify_in_regions_body<1>(t.verify, t.program, t.hit_counts, t.valid_counts, t.region_ends);
-  else verify_in_regions_body<2>(t.verify, t.program, t.hit_counts, t.valid_counts, t.region_ends);
+  // by value: the parameters are read once (uniform address: scalar loads) instead of through a
+  // reference that has to be re-read after the stores of the body
+  const VerifyParams a = tails[blockIdx.y].verify;
+  const DevProgram P = tails[blockIdx.y].program;
+  const uint32_t* hit_counts = tails[blockIdx.y].hit_counts;
+  uint32_t* valid_counts = tails[blockIdx.y].valid_counts;
+  uint64_t* region_ends = tails[blockIdx.y].region_ends;
+  if (P.n_words <= 2) verify_in_regions_body<1>(a, P, hit_counts, valid_counts, region_ends);
+  else verify_in_regions_body<2>(a, P, hit_counts, valid_counts, region_ends);
 }
 
 // region offsets + gather + disjointness check in one multi-workgroup launch: workgroup b owns
@@ -1139,7 +1145,7 @@ __global__ __launch_bounds__(256) void gather_regions_by_wave(const uint32_t* co
 }
 
 __global__ __launch_bounds__(kOgcThreads) void offsets_gather_check_multi(const MultiTail* tails) {
-  const MultiTail& t = tails[blockIdx.y];
+  const MultiTail t = tails[blockIdx.y];  // by value, see verify_in_regions_multi
   offsets_gather_check_body(t.valid_counts, t.verify.hits, t.region_ends, t.verify.n_regions, t.verify.region_cap, 0, t.out,
                             t.out_cap, t.verify.counters, t.host_counters);
 }
