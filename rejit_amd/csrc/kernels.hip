@@ -794,13 +794,16 @@ __device__ __forceinline__ DevProgram stage_tables(const DevProgram& P, uint32_t
   return Q;
 }
 
-template <int NQ>
+// G = lanes per region (a power of two <= 16)
+template <int NQ, int G = 16>
 __device__ __forceinline__ void verify_in_regions_body(const VerifyParams& a, const DevProgram& P, const uint32_t* hit_counts,
                                                        uint32_t* valid_counts, uint64_t* region_ends) {
+  constexpr int kShift = G == 16 ? 4 : G == 8 ? 3 : 2;
+  static_assert(G == 16 || G == 8 || G == 4, "lanes per region");
   const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const uint64_t n_groups = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 4;
-  const int lane = lane_id(), sub = lane & 15, shift = lane & 48;
-  for (uint64_t r = tid >> 4; r < a.n_regions; r += n_groups) {
+  const uint64_t n_groups = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> kShift;
+  const int lane = lane_id(), sub = lane & (G - 1), shift = lane & (64 - G);
+  for (uint64_t r = tid >> kShift; r < a.n_regions; r += n_groups) {
     const uint32_t raw = hit_counts[r];
     const uint32_t cnt = raw < a.region_cap ? raw : a.region_cap;
     if (raw > a.region_cap && sub == 0) {  // the host grows the regions and runs again
@@ -810,7 +813,7 @@ __device__ __forceinline__ void verify_in_regions_body(const VerifyParams& a, co
     uint64_t* region = a.hits + r * a.region_cap;
     uint64_t* ends = region_ends + r * a.region_cap;
     uint32_t kept = 0;
-    for (uint32_t base = 0; base < cnt; base += 16) {
+    for (uint32_t base = 0; base < cnt; base += G) {
       const uint32_t k = base + sub;
       const uint64_t w = k < cnt ? region[k] : 0;
       const uint64_t s = w - a.float_max;
@@ -819,7 +822,7 @@ __device__ __forceinline__ void verify_in_regions_body(const VerifyParams& a, co
       const bool found = k < cnt && w >= a.float_max && s >= a.sb && s < a.se &&
                          rj_lane_longest<NQ>(P, a.text, a.n, s, &e, &overrun);
       if (overrun) a.counters[kCntOverrun] = 1;
-      const uint32_t mine = static_cast<uint32_t>(__ballot(found) >> shift) & 0xFFFFu;
+      const uint32_t mine = static_cast<uint32_t>(__ballot(found) >> shift) & ((1u << G) - 1u);
       const uint32_t pos = kept + __popc(mine & ((1u << sub) - 1u));
       if (found) {  // pos <= k, and every lane of the group has read its hit already
         region[pos] = s;
@@ -920,8 +923,10 @@ __global__ __launch_bounds__(256) void verify_in_regions_multi(const MultiTail* 
   const uint32_t* hit_counts = tails[blockIdx.y].hit_counts;
   uint32_t* valid_counts = tails[blockIdx.y].valid_counts;
   uint64_t* region_ends = tails[blockIdx.y].region_ends;
-  if (P.n_words <= 2) verify_in_regions_body<1>(a, P, hit_counts, valid_counts, region_ends);
-  else verify_in_regions_body<2>(a, P, hit_counts, valid_counts, region_ends);
+  // 8 lanes per region here: with nine patterns the launch is several rounds of workgroups, each a
+  // latency chain, and regions hold a handful of hits -- half the threads, half the rounds
+  if (P.n_words <= 2) verify_in_regions_body<1, 8>(a, P, hit_counts, valid_counts, region_ends);
+  else verify_in_regions_body<2, 8>(a, P, hit_counts, valid_counts, region_ends);
 }
 
 // region offsets + gather + disjointness check in one multi-workgroup launch: workgroup b owns
@@ -2213,7 +2218,7 @@ void launch_verify_floating_in_regions(const VerifyParams& a, const DevProgram& 
 }
 
 void launch_tails_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_regions, hipStream_t st) {
-  uint64_t vblocks = (static_cast<uint64_t>(n_regions) + 15) / 16;
+  uint64_t vblocks = (static_cast<uint64_t>(n_regions) + 31) / 32;  // 8 lanes per region
   vblocks = vblocks < 1 ? 1 : vblocks > 4096 ? 4096 : vblocks;
   hipLaunchKernelGGL(verify_in_regions_multi, dim3(static_cast<unsigned>(vblocks), n_patterns), dim3(256), 0, st, d_tails);
   const unsigned gblocks = n_regions ? (n_regions + kOgcThreads - 1) / kOgcThreads : 1u;
