@@ -137,7 +137,7 @@ int rj_scan_match_full(rj_scan* scan, const void* d_text, uint64_t n, void* hip_
  * section 4) the text is read ONCE for all of them; otherwise the patterns run one after another.
  * Results are those of rj_scan_run per pattern: rj_multi_scan(m, i) is an ordinary rj_scan holding
  * pattern i's spans / stats after rj_multi_run. */
-typedef struct rj_multi rj_multi;
+typedef struct rj_multi rj_multi;   /* like rj_scan: per caller, NOT thread-safe */
 int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out);
 void rj_multi_destroy(rj_multi* multi);
 /* counts[i] = matches of pattern i over d_text[0..n).  Returns how the set was run: 1 = one fused scan

@@ -1176,8 +1176,7 @@ const uint64_t* rj_scan_device_spans(const rj_scan* s) { return s ? s->result : 
 // rj_scan_finish waits for the tail.  Whole text, no carry.  Anything but the common outcome (a
 // region overflowed, candidates overlap, a pattern the in-region pipeline does not take) is handled
 // by running the ordinary synchronous pipeline in rj_scan_finish.
-int rj_scan_start(rj_scan* s, const void* d_text, uint64_t n, void* hip_stream) {
-  ErrnoGuard errno_guard;
+static int scan_start(rj_scan* s, const void* d_text, uint64_t n, void* hip_stream) {
   if (!s || (!d_text && n)) return fail(RJ_BAD_ARGUMENT, "null argument");
   if (s->pending) return fail(RJ_BAD_ARGUMENT, "rj_scan_start: the previous start has not been finished");
   if ((reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) return fail(RJ_BAD_ARGUMENT, "device text must be 16-byte aligned");
@@ -1240,6 +1239,14 @@ int rj_scan_start(rj_scan* s, const void* d_text, uint64_t n, void* hip_stream) 
                               s->counters.as<unsigned long long>(), s->host_counters, nullptr, nullptr, s->tail_stream);
   s->pending_launched = true;
   return RJ_OK;
+}
+
+int rj_scan_start(rj_scan* s, const void* d_text, uint64_t n, void* hip_stream) {
+  ErrnoGuard errno_guard;
+  const bool was_pending = s && s->pending;
+  const int rc = scan_start(s, d_text, n, hip_stream);
+  if (rc != RJ_OK && s && !was_pending) s->pending = false;  // a failed start leaves nothing to finish
+  return rc;
 }
 
 int64_t rj_scan_finish(rj_scan* s) {

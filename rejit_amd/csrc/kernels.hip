@@ -923,10 +923,11 @@ __global__ __launch_bounds__(256) void verify_in_regions_multi(const MultiTail* 
   const uint32_t* hit_counts = tails[blockIdx.y].hit_counts;
   uint32_t* valid_counts = tails[blockIdx.y].valid_counts;
   uint64_t* region_ends = tails[blockIdx.y].region_ends;
-  // 8 lanes per region here: with nine patterns the launch is several rounds of workgroups, each a
-  // latency chain, and regions hold a handful of hits -- half the threads, half the rounds
-  if (P.n_words <= 2) verify_in_regions_body<1, 8>(a, P, hit_counts, valid_counts, region_ends);
-  else verify_in_regions_body<2, 8>(a, P, hit_counts, valid_counts, region_ends);
+  // 4 lanes per region here: with nine patterns 16 lanes per region made several rounds of
+  // workgroups, each a latency chain, and regions hold a handful of hits -- a quarter of the
+  // threads fits the GPU in one round
+  if (P.n_words <= 2) verify_in_regions_body<1, 4>(a, P, hit_counts, valid_counts, region_ends);
+  else verify_in_regions_body<2, 4>(a, P, hit_counts, valid_counts, region_ends);
 }
 
 // region offsets + gather + disjointness check in one multi-workgroup launch: workgroup b owns
@@ -2218,7 +2219,7 @@ void launch_verify_floating_in_regions(const VerifyParams& a, const DevProgram& 
 }
 
 void launch_tails_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_regions, hipStream_t st) {
-  uint64_t vblocks = (static_cast<uint64_t>(n_regions) + 31) / 32;  // 8 lanes per region
+  uint64_t vblocks = (static_cast<uint64_t>(n_regions) + 63) / 64;  // 4 lanes per region
   vblocks = vblocks < 1 ? 1 : vblocks > 4096 ? 4096 : vblocks;
   hipLaunchKernelGGL(verify_in_regions_multi, dim3(static_cast<unsigned>(vblocks), n_patterns), dim3(256), 0, st, d_tails);
   const unsigned gblocks = n_regions ? (n_regions + kOgcThreads - 1) / kOgcThreads : 1u;
