@@ -261,6 +261,25 @@ def main():
         out["serial_calls"] = {"calls": "9 x rj_scan_run per step", "value": round(scanned / es / 1e9, 3), "unit": "GB/s",
                                "ms_per_step": round(es / args.steps * 1e3, 4)}
 
+    if rank == 0 and world == 1 and not args.no_extra and use_multi:
+        # the same with the scan kernels alternating between two streams (rj_multi mode 2): consecutive
+        # kernels overlap at their boundaries instead of draining and ramping up one by one.  Faster,
+        # but two scan kernels then share the GPU part of the time, so a per-kernel duration (rocprof
+        # shows ~160 us each) is no roofline input any more -- which is why it is not the headline.
+        multi_il = rejit_amd.MultiScan(progs)
+        multi_il.set_mode(2)
+        for _ in range(2):
+            ci = multi_il.run(text_ptr, n_local, stream=stream)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ci = multi_il.run(text_ptr, n_local, stream=stream)
+        torch.cuda.synchronize(dev)
+        ei = time.perf_counter() - t1
+        assert ci == counts, "interleaved run disagrees"
+        out["interleaved"] = {"calls": "rj_multi_run mode 2 (scan kernels on two alternating streams)",
+                              "value": round(scanned / ei / 1e9, 3), "unit": "GB/s", "ms_per_step": round(ei / args.steps * 1e3, 4)}
+
     if rank == 0 and world == 1 and not args.no_extra and n_thr == 1:
         # the same job with the 9 calls issued from 3 host threads (one stream each): the calls'
         # host-side latency overlaps, the kernels share the GPU (so per-kernel times stretch, which

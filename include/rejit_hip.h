@@ -150,7 +150,9 @@ int rj_multi_run(rj_multi* multi, const void* d_text, uint64_t n, uint64_t* coun
 int rj_multi_run_range(rj_multi* multi, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end,
                        uint64_t* counts, void* hip_stream);
 rj_scan* rj_multi_scan(rj_multi* multi, int i);
-/* mode 0 (default): fuse when possible; mode 1: never fuse (separate scan kernels) */
+/* mode 0 (default): fuse when possible; mode 1: never fuse (one scan kernel per pattern, back to back on
+ * the caller's stream); mode 2: as 1, the scan kernels alternating between the caller's stream and a second
+ * one so that consecutive kernels overlap at their boundaries */
 int rj_multi_set_mode(rj_multi* multi, int mode);
 /* duration of the last run's scan kernel(s) in ms, summed (0 when the patterns ran one by one) */
 float rj_multi_scan_ms(const rj_multi* multi);

@@ -344,7 +344,8 @@ class MultiScan:
         self.how = 0
 
     def set_mode(self, mode: int) -> None:
-        """0: fuse the scans when possible (default); 1: one scan kernel per pattern."""
+        """0: fuse the scans when possible (default); 1: one scan kernel per pattern; 2: as 1, on two
+        alternating streams."""
         _check(self._lib.rj_multi_set_mode(self._h, mode))
 
     def __del__(self):

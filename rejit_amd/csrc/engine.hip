@@ -908,6 +908,8 @@ struct rj_multi {
   DeviceBuffer dummy_counts;  // hit_counts of the padding patterns
   DeviceBuffer tails;         // MultiTail[P]
   MultiTail* host_tails = nullptr;  // pinned
+  hipStream_t second = nullptr;     // separate-scans mode: odd patterns' scan kernels
+  hipEvent_t fork = nullptr, join = nullptr;
   std::vector<MultiTail> uploaded;  // what the device array holds (skip the copy when nothing changed)
   bool fused = false;     // every pattern has a nibble-form window set: one kernel scans for all
   bool batchable = false; // every pattern takes the in-region pipeline: scans back to back, tails together
@@ -967,7 +969,18 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     if (fuse) {
       launch_scan_windows_fused(fp, geo.grid, s0->ev[1], s0->ev[2], st);
     } else {
-      // every pattern's own scan kernel, queued back to back (each at its full streaming rate)
+      // every pattern's own scan kernel (each at its full streaming rate), queued back to back on
+      // the caller's stream -- or, mode 2, alternating between it and a second stream: kernels of ONE
+      // stream run strictly one after the other, so every kernel boundary costs the drain of the
+      // last workgroups plus the ramp-up of the next grid; with two streams the next kernel's
+      // workgroups fill the slots as they become free (regexdna step 0.95 -> 0.89 ms)
+      // (mode 2 only: the kernels of the two streams overlap in time, so a per-kernel duration no
+      // longer means what a roofline needs; the default keeps them on the caller's stream)
+      const bool two_streams = m->mode == 2;
+      if (two_streams) {
+        RJ_HIP(hipEventRecord(m->fork, st));
+        RJ_HIP(hipStreamWaitEvent(m->second, m->fork, 0));
+      }
       for (int p = 0; p < P; p++) {
         rj_scan* s = m->scans[static_cast<size_t>(p)];
         const DevProgram& D = s->prog->dev;
@@ -987,8 +1000,14 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
         sp.zero_counters = s->counters.as<unsigned long long>();
         // one pair of timestamps around the whole train of scan kernels (first kernel's start, last
         // kernel's end): a pair per kernel puts a completion signal between consecutive kernels
+        hipStream_t sp_stream = (two_streams && (p & 1)) ? m->second : st;
         launch_scan_windows(sp, make_window_set(s->prog), D.n_windows, geo.grid, p == 0 ? s0->ev[1] : nullptr,
-                            p == P - 1 ? s0->ev[2] : nullptr, st);
+                            (!two_streams && p == P - 1) ? s0->ev[2] : nullptr, sp_stream);
+      }
+      if (two_streams) {
+        RJ_HIP(hipEventRecord(m->join, m->second));
+        RJ_HIP(hipStreamWaitEvent(st, m->join, 0));
+        RJ_HIP(hipEventRecord(s0->ev[2], st));  // end of the train: both streams have drained
       }
     }
     // the single-pattern tails (verify inside the regions, offsets + gather + check) of all patterns
@@ -1380,6 +1399,12 @@ int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out)
     rj_multi_destroy(m.release());
     return fail(RJ_DEVICE_ERROR, "out of memory");
   }
+  if (hipStreamCreateWithFlags(&m->second, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&m->fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&m->join, hipEventDisableTiming) != hipSuccess) {
+    rj_multi_destroy(m.release());
+    return fail(RJ_DEVICE_ERROR, "hipStreamCreate / hipEventCreate failed");
+  }
   m->fused = all && n_progs > 1 && getenv("RJ_NO_FUSION") == nullptr;
   m->batchable = all_batchable && n_progs > 1;
   *out = m.release();
@@ -1391,6 +1416,9 @@ void rj_multi_destroy(rj_multi* m) {
   if (!m) return;
   for (rj_scan* s : m->scans) rj_scan_destroy(s);
   if (m->host_tails) (void)hipHostFree(m->host_tails);
+  if (m->second) (void)hipStreamDestroy(m->second);
+  if (m->fork) (void)hipEventDestroy(m->fork);
+  if (m->join) (void)hipEventDestroy(m->join);
   delete m;
 }
 
@@ -1437,7 +1465,7 @@ rj_scan* rj_multi_scan(rj_multi* m, int i) {
 float rj_multi_scan_ms(const rj_multi* m) { return m ? m->scan_ms : 0.f; }
 
 int rj_multi_set_mode(rj_multi* m, int mode) {
-  if (!m || mode < 0 || mode > 1) return fail(RJ_BAD_ARGUMENT, "bad argument");
+  if (!m || mode < 0 || mode > 2) return fail(RJ_BAD_ARGUMENT, "bad argument");
   m->mode = mode;
   return RJ_OK;
 }

@@ -333,13 +333,16 @@ def test_fused_multi_pattern_equals_single_runs(rj):
     # the same nine patterns with separate scan kernels and batched tails (mode 1)
     sep = rj.MultiScan(progs)
     sep.set_mode(1)
+    il = rj.MultiScan(progs)
+    il.set_mode(2)                  # ... and with the scan kernels on two alternating streams
     for t in texts:
         n = int(t.numel())
-        counts = sep.run(t.data_ptr(), n, stream=st)
-        assert sep.how == 2
-        for i, sc in enumerate(singles):
-            assert counts[i] == sc.run(t.data_ptr(), n, stream=st)
-            assert sep.scan(i).spans() == sc.spans(), i
+        for ms in (sep, il):
+            counts = ms.run(t.data_ptr(), n, stream=st)
+            assert ms.how == 2
+            for i, sc in enumerate(singles):
+                assert counts[i] == sc.run(t.data_ptr(), n, stream=st)
+                assert ms.scan(i).spans() == sc.spans(), i
     # shards: matches that begin in [own_begin, own_end) of a text with its halo (multi-GPU ranks)
     t = texts[1]
     n = int(t.numel())
