@@ -1,31 +1,32 @@
 // rejit_amd/csrc/kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the hot path.
 //
 // What the reference JITs per pattern (src/x64/codegen-x64.cc) is here a fixed family of
-// kernels that interpret the lowered program (device_program.h):
+// kernels that interpret the lowered program (device_program.h).  The common pipeline:
 //
-//   scan_windows<K>   the "fast-forward" scan (FastForwardGen::VisitSingleMultipleChar /
-//                     ::Generate multi-literal branch, codegen-x64.cc:1102-1403):
-//                     streams the text from HBM with one coalesced 16-byte load per lane
-//                     (1 KiB per wave instruction), builds the 16 unaligned 4-byte windows of
-//                     the lane with v_alignbyte_b32 and compares them with the <=8 window
-//                     constants held in SGPRs; the per-lane results live as 64-bit lane masks
-//                     in SGPRs (v_cmp + s_or), so the streaming loop has no divergent code.
-//                     Only when the wave-wide mask is non-zero are the hit offsets appended to
-//                     the hit list (one wave-aggregated atomic per 64 hits).
-//   scan_dense        the no-fast-forward case (GenerateMatchDirection seeding every
-//                     position, codegen-x64.cc:544-554): every byte is tested against the
-//                     256-bit first-byte set / the nullable contexts; survivors go to the
-//                     hit list.
-//   verify_lane<NQ>   the NFA inner loop (GenerateMatchDirection + GenerateTransitions,
-//                     codegen-x64.cc:535-677): one candidate start per lane, automaton state
-//                     in NQ 64-bit registers, longest match from that start.
-//   verify_wave       same for automata of more than 128 positions: one candidate per wave,
-//                     the state vector spread over the 64 lanes.
-//   match_full        kMatchFull: one wave walks the whole text (codegen-x64.cc:162-164).
-//   finalize_small    MatchAllAppendFilter + the non-overlap rule (src/codegen.cc:36-86,
-//                     codegen-x64.cc:448-460) for <= kFinalizeCap candidates: LDS bitonic
-//                     sort by begin, duplicate removal, left-most-longest selection.
-//   select_sorted     the same selection over an already sorted candidate list of any size.
+//   scan_windows<K,...>    the "fast-forward" scan (FastForwardGen::VisitSingleMultipleChar /
+//                          ::Generate multi-literal branch, codegen-x64.cc:1102-1403): every wave
+//                          streams a contiguous span of the text (one coalesced 16-byte load per
+//                          lane, three chunks in flight), builds the lane's 16 unaligned windows
+//                          with v_alignbyte_b32 and compares them with <= 8 window constants held
+//                          in SGPRs, VALU only (xor/and/min, one v_cmp + ballot per chunk); exact,
+//                          two-level or nibble-packed form.  Hit offsets go to the wave's own
+//                          region of the hit list: no atomics, sorted by construction.
+//   scan_windows_fused     the same for several patterns in one pass over the text (rj_multi).
+//   verify_in_regions<NQ>  the NFA inner loop (GenerateMatchDirection + GenerateTransitions,
+//                          codegen-x64.cc:535-677): longest match from every hit, automaton state
+//                          in NQ 64-bit registers per lane, survivors compacted inside their region;
+//                          verify_floating_in_regions for floating windows.
+//   offsets_gather_check   region offsets + gather + "the candidates already are the result" check
+//                          (MatchAllAppendFilter + the non-overlap rule, src/codegen.cc:36-86,
+//                          codegen-x64.cc:448-460) in one multi-workgroup launch.
+//   scan_dense_walk<NW,CTX> dense mode (no fast-forward window; GenerateMatchDirection seeding
+//                          every position, codegen-x64.cc:544-554) in ONE kernel: candidate masks,
+//                          register pre-steps, persistent walker lanes, in-region compaction.
+//
+// and around it: finalize_small / select_walk & co (the selection when candidates overlap),
+// verify_wave + region_offsets + mark/compact (automata of more than 128 positions), match_full
+// (kMatchFull, codegen-x64.cc:162-164), exact_sequential (the reference's whole loop on one lane,
+// for the Q8 artefact), replace_gather (rejit::Replace, src/rejit.cc:97-112).
 //
 // No MFMA: there is no contraction anywhere on this path (integer compares on a byte stream);
 // the roofline is HBM read bandwidth.
