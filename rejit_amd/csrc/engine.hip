@@ -3,10 +3,14 @@
 // Compile + indirect call into JIT code) and its result sink src/codegen.cc:36-86.
 //
 //   rj_compile : parse -> lower -> upload the automaton tables to HBM once
-//   rj_scan_run: memset counters -> scan kernel(s) -> verify kernel -> finalize kernel
-//                -> ONE host synchronisation to read {hits, candidates, final count};
-//                lists that overflowed are grown and the run repeated; more than
-//                kFinalizeCap candidates take the rocPRIM radix-sort path.
+//   rj_scan_run: scan kernel -> verify inside the hit regions -> offsets + gather + check
+//                -> ONE host synchronisation (the last kernel writes the counters into pinned
+//                host memory); regions that overflowed are grown and the run repeated; candidates
+//                that overlap go through the selection kernels.  Dense patterns: one kernel
+//                (scan_dense_walk) + the gather.  Automata of more than 128 positions: the list
+//                pipeline (region_offsets, verify_wave, finalize_small / mark + compact).
+//   rj_multi_* : several patterns over one text (fused scan, or scans back to back + batched tails)
+//   rj_match_all_batch: many texts in one pass; rj_match_first/anywhere: early exit
 //
 // There is no CPU matching code in this library: without a working HIP device every
 // entry point fails with RJ_DEVICE_ERROR.
