@@ -285,6 +285,7 @@ class Automaton {
     }
     lengths(first_any);
     plan(first_any);
+    build_reverse();
     return true;
   }
 
@@ -673,6 +674,70 @@ class Automaton {
       // continuation can only come from the context over-approximation -- drop it
       if (depth + 1 < len && !next.any()) continue;
       enumerate(next, depth + 1, len, cur, found, overflow);
+    }
+  }
+
+  // follow set of position i in context ctx
+  Bits follow_ctx(int i, int ctx) const {
+    Bits f(W_);
+    if ((p_->linear[static_cast<size_t>(i) >> 5] >> (i & 31)) & 1u) {
+      f.set(i + 1);
+      return f;
+    }
+    const int r = p_->row_of[static_cast<size_t>(i)];
+    for (int k = 0; k < W_; k++) f.w[static_cast<size_t>(k)] = p_->rows[ctx][static_cast<size_t>(r) * W_ + k];
+    return f;
+  }
+
+  // Program::rev: positions back to front, follow transposed per context
+  void build_reverse() {
+    Program::Reverse& R = p_->rev;
+    const auto rv = [&](int i) { return P_ - 1 - i; };
+    const auto flip = [&](const std::vector<uint32_t>& in) {
+      std::vector<uint32_t> out(static_cast<size_t>(W_), 0u);
+      for (int i = 0; i < P_; i++)
+        if ((in[static_cast<size_t>(i) >> 5] >> (i & 31)) & 1u) set_bit(out.data(), rv(i));
+      return out;
+    };
+    for (int ctx = 0; ctx < kNumCtx; ctx++) {
+      R.first[ctx] = flip(p_->last[ctx]);
+      R.last[ctx] = flip(p_->first[ctx]);
+    }
+    R.cls.assign(static_cast<size_t>(256) * W_, 0u);
+    for (int b = 0; b < 256; b++) {
+      std::vector<uint32_t> row(p_->cls.begin() + static_cast<long>(b) * W_, p_->cls.begin() + static_cast<long>(b + 1) * W_);
+      std::vector<uint32_t> f = flip(row);
+      std::copy(f.begin(), f.end(), R.cls.begin() + static_cast<long>(b) * W_);
+    }
+    // rfollow_ctx[r(k)] = { r(i) : k in follow_ctx(i) }
+    std::vector<Bits> rf[kNumCtx];
+    for (int ctx = 0; ctx < kNumCtx; ctx++) {
+      rf[ctx].assign(static_cast<size_t>(std::max(P_, 1)), Bits(W_));
+      for (int i = 0; i < P_; i++) follow_ctx(i, ctx).for_each([&](int k) { rf[ctx][static_cast<size_t>(rv(k))].set(rv(i)); });
+    }
+    R.linear.assign(static_cast<size_t>(W_), 0u);
+    R.row_of.assign(static_cast<size_t>(std::max(P_, 1)), -1);
+    R.n_rows = 0;
+    std::vector<std::vector<uint32_t>> rows[kNumCtx];
+    for (int j = 0; j < P_; j++) {
+      bool lin = j + 1 < P_;
+      for (int ctx = 0; ctx < kNumCtx && lin; ctx++) {
+        Bits want(W_);
+        want.set(j + 1);
+        lin = rf[ctx][static_cast<size_t>(j)] == want;
+      }
+      if (lin) {
+        set_bit(R.linear.data(), j);
+      } else {
+        R.row_of[static_cast<size_t>(j)] = R.n_rows++;
+        for (int ctx = 0; ctx < kNumCtx; ctx++) rows[ctx].push_back(rf[ctx][static_cast<size_t>(j)].w);
+      }
+    }
+    for (int ctx = 0; ctx < kNumCtx; ctx++) {
+      R.rows[ctx].assign(static_cast<size_t>(std::max(R.n_rows, 1)) * W_, 0u);
+      for (int r = 0; r < R.n_rows; r++)
+        std::copy(rows[ctx][static_cast<size_t>(r)].begin(), rows[ctx][static_cast<size_t>(r)].end(),
+                  R.rows[ctx].begin() + static_cast<long>(r) * W_);
     }
   }
 

@@ -160,6 +160,18 @@ struct Program {
   // from the entry state through control edges can also be occupied by an older thread.
   Graph graph;
   bool q8_risk = false;
+  // The REVERSE position automaton: the same positions renumbered back to front (j' = P-1-j),
+  // first' = last, last' = first, follow transposed per context, so that the kernels' ordinary
+  // step  S' = follow_ctx(S) & cls[byte]  applied while reading the text BACKWARDS walks a match
+  // from its end to its start.  The context of a step is still the one of the boundary crossed.
+  // Used by the linear-time carry scan (longest end of every start in one backward pass; the
+  // reference gets linear time from its merged state ring, codegen-x64.cc:951-987) and by the
+  // backward pass from a fast-forward hit to the match start (codegen-x64.cc:643-650).
+  struct Reverse {
+    std::vector<uint32_t> first[kNumCtx], last[kNumCtx], linear, rows[kNumCtx], cls;
+    std::vector<int32_t> row_of;
+    int n_rows = 0;
+  } rev;
 };
 
 struct LowerResult {

@@ -1,0 +1,108 @@
+// tests/support/carry_exec.cc -- TEST-ONLY driver of the linear-time carry scan on the CPU.
+//
+// Compiles rejit_amd/csrc/carry_scan.h -- the very bodies the HIP kernels call per sub-chunk -- with
+// g++ and runs the phases one sub-chunk after the other, so the algorithm (reverse automaton,
+// class stepping, symbolic summaries, chain selection) is checked against the oracle without a GPU.
+// Never linked into the product library.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../rejit_amd/csrc/carry_scan.h"
+#include "../../rejit_amd/csrc/lowering.h"
+#include "../../rejit_amd/csrc/table_layout.h"
+
+using namespace rejit_amd;
+
+namespace {
+
+template <int NW>
+long run(const Program& P, const DevProgram& R, const uint8_t* t, uint64_t n, uint64_t sub, uint64_t sb, uint64_t se,
+         uint64_t carry_cur, uint64_t carry_prev_end, int have_prev, uint64_t* out, uint64_t cap) {
+  if (se > n + 1) se = n + 1;
+  if (sb >= se) return 0;
+  const int np = std::max(P.n_pos, 1), W = P.n_words;
+  const uint64_t c_first = sb / sub, n_sub = n / sub + 1;  // sub-chunk c: bytes [c*sub, min((c+1)*sub, n))
+  const uint64_t e_base = c_first * sub;
+  std::vector<uint64_t> cval(static_cast<size_t>(np));
+  std::vector<uint32_t> cset(static_cast<size_t>(np) * NW), src(static_cast<size_t>(np) * NW);
+  CsClasses<NW> C{CsArr<uint64_t>{cval.data(), 1}, CsArr<uint32_t>{cset.data(), 1}, 0};
+  const CsArr<uint32_t> srcarr{src.data(), 1};
+  const uint64_t m = n_sub - c_first;
+  std::vector<uint64_t> D(static_cast<size_t>(m + 1) * np, 0);  // [m] = beyond the text: zeros
+  std::vector<uint32_t> Rm(static_cast<size_t>(m) * np * W, 0);
+  for (uint64_t i = 0; i < m; i++) {
+    const uint64_t a = (c_first + i) * sub, b = std::min(a + sub, n);
+    cs_summarize<NW>(R, t, n, a, b, C, srcarr, &D[i * np], &Rm[i * np * W]);
+  }
+  for (uint64_t i = m; i-- > 0;) cs_resolve(P.n_pos, W, &D[i * np], &Rm[i * np * W], &D[(i + 1) * np]);
+  const uint64_t n_own = (se - 1) / sub - c_first + 1;  // sub-chunks that hold own starts
+  std::vector<uint64_t> E(static_cast<size_t>(n_own * sub), kCsNone), G(static_cast<size_t>(n_own * sub), 0);
+  for (uint64_t i = 0; i < n_own; i++) {
+    const uint64_t a = (c_first + i) * sub, b = std::min(a + sub, n);
+    cs_emit<NW>(R, t, n, a, b, sb, se, i + 1 < m ? &D[(i + 1) * np] : nullptr, C, E.data(), e_base);
+  }
+  auto bounds = [&](uint64_t i, uint64_t* lo, uint64_t* hi) {
+    *lo = std::max((c_first + i) * sub, sb);
+    *hi = std::min((c_first + i + 1) * sub, se);
+  };
+  for (uint64_t i = 0; i < n_own; i++) {
+    uint64_t lo, hi;
+    bounds(i, &lo, &hi);
+    cs_local_chain(E.data(), G.data(), e_base, lo, hi);
+  }
+  std::vector<uint64_t> entry(static_cast<size_t>(n_own), kCsNone);
+  for (uint64_t cur = std::max(carry_cur, sb); cur < se;) {
+    entry[cur / sub - c_first] = cur;
+    cur = G[cur - e_base];
+  }
+  RjSelectState st{carry_cur, carry_prev_end, have_prev != 0};
+  uint64_t out_n = 0;
+  for (uint64_t i = 0; i < n_own; i++) {
+    if (entry[i] == kCsNone) continue;
+    uint64_t lo, hi;
+    bounds(i, &lo, &hi);
+    const uint32_t cnt = cs_take(E.data(), G.data(), e_base, lo, hi, entry[i]);
+    for (uint32_t k = 0; k < cnt; k++) {
+      const uint64_t bb = G[lo - e_base + k], ee = E[lo - e_base + k];
+      bool taken;
+      if (rj_select_step(&st, bb, ee, &taken)) {  // the zero-length rule (the device tail applies it)
+        if (out_n < cap) {
+          out[2 * out_n] = bb;
+          out[2 * out_n + 1] = ee;
+        }
+        out_n++;
+      }
+      if (!taken) return -8;  // the chain must only hold takeable matches
+    }
+  }
+  return static_cast<long>(out_n);
+}
+
+}  // namespace
+
+extern "C" {
+
+// MatchAll of the starts in [sb, se) through the carry scan with sub-chunks of `sub` bytes;
+// returns the count, a negative lowering status, or -9 (automaton too wide for this driver)
+long ce_match_range(const char* re, const uint8_t* text, uint64_t n, uint64_t sub, uint64_t sb, uint64_t se,
+                    uint64_t carry_cur, uint64_t carry_prev_end, int have_prev, uint64_t* out, uint64_t cap) {
+  LowerResult lr = lower(re);
+  if (lr.status != 0) return lr.status;
+  const Program& P = *lr.program;
+  const TableBlob blob = make_table_blob(P.rev, P.n_pos, P.n_words, P.has_assertions);
+  DevProgram R{};
+  point_tables(&R, blob.words.data(), blob, P.n_pos);
+  R.nullable = nullable_bits(P);
+  if (P.n_words <= 1) return run<1>(P, R, text, n, sub, sb, se, carry_cur, carry_prev_end, have_prev, out, cap);
+  if (P.n_words <= 2) return run<2>(P, R, text, n, sub, sb, se, carry_cur, carry_prev_end, have_prev, out, cap);
+  if (P.n_words <= 4) return run<4>(P, R, text, n, sub, sb, se, carry_cur, carry_prev_end, have_prev, out, cap);
+  if (P.n_words <= 8) return run<8>(P, R, text, n, sub, sb, se, carry_cur, carry_prev_end, have_prev, out, cap);
+  return -9;
+}
+
+long ce_match_all(const char* re, const uint8_t* text, uint64_t n, uint64_t sub, uint64_t* out, uint64_t cap) {
+  return ce_match_range(re, text, n, sub, 0, n + 1, 0, 0, 0, out, cap);
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+"""CPU tests of the linear-time carry scan (rejit_amd/csrc/carry_scan.h).
+
+The header is compiled with g++ into a TEST-ONLY driver (tests/support/carry_exec.cc) that runs the
+same per-sub-chunk bodies the HIP kernels call -- summaries with a symbolic entering state, the
+resolve pass, the emit pass, the chain selection -- one sub-chunk after the other, and the result
+is compared with the oracle on every golden vector for several sub-chunk sizes (1 byte per
+sub-chunk makes every byte a boundary).  Where the reference's ring artefact (Q8)
+applies, the documented semantics (Oracle.match_all_spec) are the expectation, as for the parallel
+verifier.
+"""
+import ctypes
+import os
+import random
+import subprocess
+
+import pytest
+
+import vectors as V
+from checkers import Oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(ROOT, "rejit_amd", "csrc")
+SO = os.path.join(HERE, "support", "libcarry_exec.so")
+SRCS = [os.path.join(HERE, "support", "carry_exec.cc"), os.path.join(CSRC, "parser.cc"), os.path.join(CSRC, "lowering.cc")]
+DEPS = SRCS + [os.path.join(CSRC, h) for h in ("carry_scan.h", "device_program.h", "lowering.h", "table_layout.h")]
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+@pytest.fixture(scope="module")
+def ce():
+    if not os.path.exists(SO) or any(os.path.getmtime(SO) < os.path.getmtime(s) for s in DEPS):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", SO] + SRCS)
+    lib = ctypes.CDLL(SO)
+    lib.ce_match_range.restype = ctypes.c_long
+    lib.ce_match_range.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                   ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, _u64p, ctypes.c_uint64]
+    return lib
+
+
+def carry(lib, rx, tx, sub, sb=0, se=None, cur=0, prev_end=0, have_prev=False):
+    se = len(tx) + 1 if se is None else se
+    cap = len(tx) + 2
+    buf = (ctypes.c_uint64 * (2 * cap))()
+    n = lib.ce_match_range(rx, tx, len(tx), sub, sb, se, cur, prev_end, int(have_prev), buf, cap)
+    if n < 0:
+        return int(n)
+    return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n)]
+
+
+def test_all_vectors(ce):
+    oracle = Oracle()
+    n = q8 = 0
+    for rx, tx, exp_all, _ in V.all_matchall_cases():
+        want = exp_all
+        for sub in (1, 3, 16, 4096):
+            got = carry(ce, rx, tx, sub)
+            if got == -9:       # wider than 256 positions (the 1000-byte literals): not this driver's business
+                assert len(rx) > 256
+                break
+            if got != want:
+                spec = oracle.match_all_spec(rx, tx)
+                assert spec != exp_all and got == spec, (rx, tx, sub, got, exp_all)
+                want = spec
+                q8 += 1
+        n += 1
+    assert n > 2500
+    assert q8 <= 19
+
+
+HARD = [b"[acgt]+", b"[^>]+", b"(ab|ba)+", b"a.*b", b"x*", b"a+b*", b"(a|b)*abb", b"[ab]+c|[bc]+d", b"^.*$", b".*x", b"\\d+x",
+        b"[a-z]+@[a-z]+", b"a{2,}", b"(a|ab)(c|bcd)*", b"x*y?z+", b"(aa|aaa)+", b".{0,2}.", b"[ab]{1,30}c", b"a.{3,}b"]
+
+
+def test_long_runs_vs_oracle(ce):
+    """Unbounded repetitions over long runs (what the per-start verifier cannot do in linear time)."""
+    oracle = Oracle()
+    rng = random.Random(5)
+    for rx in HARD:
+        for alphabet, n in ((b"ab", 700), (b"acgt", 900), (b"abcx\n", 800), (b"aabb>xyz09@.cd", 1200)):
+            tx = bytes(rng.choice(alphabet) for _ in range(n))
+            spec = oracle.match_all_spec(rx, tx)
+            for sub in (1, 7, 64, 256):
+                assert carry(ce, rx, tx, sub) == spec, (rx, alphabet, sub)
+
+
+def test_ranges_compose(ce):
+    """Own ranges with the selection state carried over a cut reproduce the whole-text result."""
+    oracle = Oracle()
+    rng = random.Random(11)
+    for rx in HARD + [b"^", b"$", b"^$", b"x?"]:
+        tx = bytes(rng.choice(b"abx\nacgt") for _ in range(500))
+        want = oracle.match_all_spec(rx, tx)
+        for cut in (1, 64, 250, 333, 499, 500):
+            first = carry(ce, rx, tx, 32, 0, cut)
+            if first:
+                b, e = first[-1]
+                state = (e if e > b else b + 1, e, True)
+            else:
+                state = (0, 0, False)
+            second = carry(ce, rx, tx, 32, cut, len(tx) + 1, *state)
+            assert first + second == want, (rx, cut)
+
+
+def test_wide_automata(ce):
+    """More than 32 / 64 / 128 positions (2, 4, 8 state words)."""
+    oracle = Oracle()
+    rng = random.Random(3)
+    for rx in (b"[ab]{40}c*", b"(abcdefghijklmnopqrstuvwxyz0123456789)+x*", b"[ab]{70,90}", b"([ab]{3}c){30,}", b"a{150}b*"):
+        tx = bytes(rng.choice(b"ab") for _ in range(600)) + b"c" + b"a" * 200 + b"bbb"
+        want = oracle.match_all_spec(rx, tx)
+        assert not isinstance(want, int)
+        for sub in (5, 128):
+            assert carry(ce, rx, tx, sub) == want, (rx, sub)
