@@ -61,7 +61,7 @@ typedef struct {
   int32_t retries;         /* runs repeated because a device list had to grow        */
   int32_t large_path;      /* 1 when the rocPRIM sort path was taken                 */
   int32_t exact_path;      /* 1 when the one-lane exact kernel replaced the result   */
-  int32_t reserved;
+  int32_t linear_path;    /* 1 when a candidate outlived the parallel verifier's walk and the linear-time carry scan ran */
 } rj_stats;
 
 /* ---- compile (replaces Regej::Regej + Regej::Compile, src/rejit.cc:127-137,229-267) */

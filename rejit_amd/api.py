@@ -8,8 +8,8 @@ from typing import List, Optional, Tuple
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-SOURCES = ["kernels.hip", "engine.hip", "parser.cc", "lowering.cc", "rejit_api.cc"]
-HEADERS = ["kernels.h", "device_program.h", "lowering.h"]
+SOURCES = ["kernels.hip", "carry_kernels.hip", "engine.hip", "linear.hip", "parser.cc", "lowering.cc", "rejit_api.cc"]
+HEADERS = ["kernels.h", "device_program.h", "lowering.h", "carry_scan.h", "engine_internal.h", "table_layout.h"]
 LIB = os.path.join(PKG, "librejit_hip.so")
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -95,7 +95,7 @@ class _Info(ctypes.Structure):
 class _Stats(ctypes.Structure):
     _fields_ = [("n_hits", ctypes.c_uint64), ("n_candidates", ctypes.c_uint64), ("n_matches", ctypes.c_uint64),
                 ("scan_ms", ctypes.c_float), ("total_ms", ctypes.c_float), ("retries", ctypes.c_int32),
-                ("large_path", ctypes.c_int32), ("exact_path", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("large_path", ctypes.c_int32), ("exact_path", ctypes.c_int32), ("linear_path", ctypes.c_int32)]
 
 
 _lib = None

@@ -322,17 +322,17 @@ RJ_HD void cs_local_chain(const uint64_t* E, uint64_t* G, uint64_t e_base, uint6
 }
 
 // ---- phase 6 (one lane; the kernel has a wave-cooperative form): follow the chain that enters the
-// sub-chunk's starts [lo, hi) at `cur`; the taken matches are compacted to the front of the slab,
-// begins into G, ends into E (never ahead of the read position).  Returns their number.
-RJ_HD uint32_t cs_take(uint64_t* E, uint64_t* G, uint64_t e_base, uint64_t lo, uint64_t hi, uint64_t cur) {
+// sub-chunk's starts (they end at hi) at `cur`; the taken matches are compacted to the front of the
+// sub-chunk's slab (index `slab` of E / G), begins into G, ends into E.  Returns their number.
+RJ_HD uint32_t cs_take(uint64_t* E, uint64_t* G, uint64_t e_base, uint64_t slab, uint64_t hi, uint64_t cur) {
   uint32_t cnt = 0;
   while (cur < hi) {
     uint64_t s = cur;
     while (s < hi && E[s - e_base] == kCsNone) s++;
     if (s >= hi) break;
     const uint64_t e = E[s - e_base];
-    G[lo - e_base + cnt] = s;
-    E[lo - e_base + cnt] = e;
+    G[slab + cnt] = s;  // slab + cnt <= s - e_base: behind the read position
+    E[slab + cnt] = e;
     cnt++;
     cur = e > s ? e : s + 1;
   }

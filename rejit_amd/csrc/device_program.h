@@ -51,6 +51,9 @@ struct DevProgram {
   // the dense walker steps them with shifts instead of fetching their rows
   uint32_t loop_mask[4];
   uint32_t skip_mask[4];
+  // A walk from one start is cut after this many bytes and the run flagged (kCntOverrun); the engine
+  // then repeats the run on the linear-time carry scan (carry_scan.h).  <= kMaxSimSteps.
+  uint32_t max_walk;
 };
 
 // The NFA graph for the exact sequential kernel (reference ring semantics).
@@ -87,14 +90,15 @@ RJ_HD int rj_context(const uint8_t* t, uint64_t n, uint64_t p) {
 // lane (P <= 64 * NQ).  Returns false when no match starts at s.
 // One step is S' = follow_ctx(S) & cls[byte]: the linear part is a shift, positions with
 // a non-trivial follow set OR in their row.
-// `max_steps` bounds the walk: a start that is still alive after that many bytes sets *overrun
-// (the engine then falls back to the sequential kernel or reports RJ_TOO_LARGE instead of
-// letting dense candidates x unbounded repetitions run for hours).
+// P.max_walk bounds the walk: a start that is still alive after that many bytes sets *overrun (per-start
+// walks are quadratic when many starts live long; the engine then repeats the run on the linear-time
+// carry scan).  `abort` (may be null) is polled now and then: once any walk of the run has overrun
+// the run is void, and the others need not finish.
 constexpr uint64_t kMaxSimSteps = 1ull << 20;
 
 template <int NQ>
 RJ_HD bool rj_lane_longest(const DevProgram& P, const uint8_t* t, uint64_t n, uint64_t s, uint64_t* end,
-                           bool* overrun) {
+                           bool* overrun, const volatile unsigned long long* abort = nullptr) {
   const int W = P.n_words;  // 32-bit words; NQ*2 >= W
   const bool ctxed = P.n_ctx > 1;
   int ctx = ctxed ? rj_context(t, n, s) : 0;
@@ -142,10 +146,11 @@ RJ_HD bool rj_lane_longest(const DevProgram& P, const uint8_t* t, uint64_t n, ui
       }
     }
     if (p == n) break;
-    if (p - s >= kMaxSimSteps) {
+    if (p - s >= P.max_walk) {
       *overrun = true;
       break;
     }
+    if (abort != nullptr && ((p - s) & 1023u) == 0 && *abort != 0) break;  // the run is void already
     uint64_t T[NQ];
     uint64_t carry = 0;
     for (int q = 0; q < NQ; q++) {

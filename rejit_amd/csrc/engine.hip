@@ -31,18 +31,16 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/rejit_hip.h"
-#include "device_program.h"
-#include "kernels.h"
-#include "lowering.h"
+#include "engine_internal.h"
+#include "table_layout.h"
 
 using namespace rejit_amd;
 
-namespace {
+namespace rejit_amd {
 
 thread_local std::string g_error;
 
-int fail(int code, const char* fmt, ...) {
+int rj_fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -52,102 +50,18 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
-#define RJ_HIP(call)                                                                          \
-  do {                                                                                        \
-    hipError_t e_ = (call);                                                                   \
-    if (e_ != hipSuccess)                                                                     \
-      return fail(RJ_DEVICE_ERROR, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-  } while (0)
+}  // namespace rejit_amd
 
-// The reference's generated code never touches errno, and its callers rely on that
-// (sample/jrep.cc:281-285 tests `if (errno)` right after mmap).  The HIP runtime does set it
-// (probing files, ioctls), so every entry point restores the caller's value.
-struct ErrnoGuard {
-  int saved;
-  ErrnoGuard() : saved(errno) {}
-  ~ErrnoGuard() { errno = saved; }
-};
+#define fail ::rejit_amd::rj_fail
+
+namespace {
 
 // The HIP runtime's own load-time initialisers (they run before ours: dependency order) can
 // leave errno set before main() starts -- e.g. ENOENT from probing amdgpu.ids.  A process that
 // links the reference's librejit.a starts with errno == 0, so restore that.
 __attribute__((constructor)) void rj_library_loaded() { errno = 0; }
 
-struct DeviceBuffer {
-  void* p = nullptr;
-  size_t bytes = 0;
-  ~DeviceBuffer() {
-    if (p) (void)hipFree(p);
-  }
-  // grow-only; contents are NOT preserved
-  hipError_t reserve(size_t want) {
-    if (want <= bytes) return hipSuccess;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    bytes = 0;
-    hipError_t e = hipMalloc(&p, want);
-    if (e == hipSuccess) bytes = want;
-    return e;
-  }
-  // grow, preserving the first `keep` bytes
-  hipError_t grow_keep(size_t want, size_t keep) {
-    if (want <= bytes) return hipSuccess;
-    void* q = nullptr;
-    size_t cap = std::max(want, bytes * 2);
-    hipError_t e = hipMalloc(&q, cap);
-    if (e != hipSuccess) return e;
-    if (p && keep) e = hipMemcpy(q, p, keep, hipMemcpyDeviceToDevice);
-    if (p) (void)hipFree(p);
-    p = q;
-    bytes = cap;
-    return e;
-  }
-  template <class T>
-  T* as() const { return static_cast<T*>(p); }
-};
-
 }  // namespace
-
-struct rj_program {
-  std::unique_ptr<Program> host;
-  DevProgram dev{};
-  DeviceBuffer tables;
-  DevGraph graph{};        // uploaded only for patterns with q8_risk
-  DeviceBuffer graph_blob;
-  int device = 0;
-  int window_alphabet = 0;  // distinct byte values among the fixed window bytes
-  bool window_nibbles = false;
-  int batch_separator = -1;  // byte that ends a text inside a concatenated batch, -1: none exists  // those values differ in their low nibble (nibble filter usable)
-  std::string pattern;
-};
-
-struct rj_scan {
-  const rj_program* prog = nullptr;
-  DeviceBuffer counters, hits, hit_counts, valid_counts, hit_offsets, cand_begin, cand_end, out, acc_out, keys_out, vals_out, sort_tmp, flag;
-  DeviceBuffer scan_a, scan_b, taken;  // large-path selection scratch
-  DeviceBuffer ring;                   // exact sequential kernel
-  DeviceBuffer with_buf, long_gaps, repl_out;  // replace_gather
-  uint64_t cands_cap = 0, out_cap = 0;
-  uint32_t region_cap_hint = 64;   // hit-region size that sufficed last time (windows mode)
-  uint64_t hits_hint = 0;          // hits of the previous run (sizes the verify grid)
-  unsigned long long* host_counters = nullptr;  // pinned
-  int* host_flag = nullptr;                     // pinned
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  rj_stats stats{};
-  const uint64_t* result = nullptr;  // device pointer to the final pairs
-  uint64_t result_count = 0;
-  // rj_scan_start / rj_scan_finish
-  hipStream_t tail_stream = nullptr;
-  bool pending = false, pending_launched = false;
-  const uint8_t* pending_text = nullptr;
-  uint64_t pending_n = 0;
-  hipStream_t pending_stream = nullptr;
-  // host-text path
-  DeviceBuffer text;
-  char* pinned = nullptr;  // staging for rj_match_all_batch
-  size_t pinned_cap = 0;
-  hipStream_t own_stream = nullptr;
-};
 
 namespace {
 
@@ -155,31 +69,24 @@ int upload_program(rj_program* rp) {
   const Program& P = *rp->host;
   const int W = P.n_words;
   const int C = P.has_assertions ? kNumCtx : 1;
-  const int R = std::max(P.n_rows, 1);
-  const int Pn = std::max(P.n_pos, 1);
-  // layout in 32-bit words
-  size_t off_first = 0;
-  size_t off_last = off_first + static_cast<size_t>(C) * W;
-  size_t off_linear = off_last + static_cast<size_t>(C) * W;
-  size_t off_rowof = off_linear + W;
-  size_t off_rows = off_rowof + Pn;
-  size_t off_cls = off_rows + static_cast<size_t>(C) * R * W;
-  size_t total = off_cls + static_cast<size_t>(256) * W;
-  std::vector<uint32_t> blob(total, 0u);
-  for (int c = 0; c < C; c++) {
-    std::copy(P.first[c].begin(), P.first[c].end(), blob.begin() + off_first + static_cast<size_t>(c) * W);
-    std::copy(P.last[c].begin(), P.last[c].end(), blob.begin() + off_last + static_cast<size_t>(c) * W);
-    for (int r = 0; r < P.n_rows; r++)
-      std::copy(P.rows[c].begin() + static_cast<long>(r) * W, P.rows[c].begin() + static_cast<long>(r + 1) * W,
-                blob.begin() + off_rows + (static_cast<size_t>(c) * R + r) * W);
-  }
-  std::copy(P.linear.begin(), P.linear.end(), blob.begin() + off_linear);
-  for (int i = 0; i < P.n_pos; i++) blob[off_rowof + i] = static_cast<uint32_t>(P.row_of[static_cast<size_t>(i)]);
-  std::copy(P.cls.begin(), P.cls.end(), blob.begin() + off_cls);
+  const TableBlob blob = make_table_blob(P, P.n_pos, P.n_words, P.has_assertions);
+  const size_t total = blob.words.size();
+  const size_t off_first = blob.off_first, off_last = blob.off_last, off_linear = blob.off_linear, off_rowof = blob.off_rowof,
+               off_rows = blob.off_rows, off_cls = blob.off_cls;
+  const int R = blob.R;
 
   RJ_HIP(hipGetDevice(&rp->device));
   RJ_HIP(rp->tables.reserve(total * sizeof(uint32_t)));
-  RJ_HIP(hipMemcpy(rp->tables.p, blob.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice));
+  RJ_HIP(hipMemcpy(rp->tables.p, blob.words.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice));
+  {
+    // the reverse automaton for the linear-time carry scan (linear.hip) and backward passes
+    const TableBlob rb = make_table_blob(P.rev, P.n_pos, P.n_words, P.has_assertions);
+    RJ_HIP(rp->rev_tables.reserve(rb.words.size() * sizeof(uint32_t)));
+    RJ_HIP(hipMemcpy(rp->rev_tables.p, rb.words.data(), rb.words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    rp->rev = DevProgram{};
+    point_tables(&rp->rev, rp->rev_tables.as<uint32_t>(), rb, P.n_pos);
+    rp->rev.nullable = nullable_bits(P);
+  }
   const uint32_t* base = rp->tables.as<uint32_t>();
   DevProgram& D = rp->dev;
   D.n_pos = P.n_pos;
@@ -285,6 +192,13 @@ int upload_program(rj_program* rp) {
     }
     if (density > 0.03) D.mode = 0;
   }
+  // How far one start may be walked before the run is handed to the linear-time carry scan
+  // (linear.hip).  Dense mode walks a start at a sizeable share of the bytes, so a long-lived
+  // candidate means many of them: cut early.  Window hits are rare: a long line is cheaper to walk.
+  D.max_walk = static_cast<uint32_t>(kMaxSimSteps);
+  if (linear_path_fits(rp)) D.max_walk = D.mode == 0 ? 4096u : 65536u;
+  if (const char* mw = getenv("RJ_MAX_WALK"))  // test / measurement override
+    if (atoi(mw) > 0) D.max_walk = static_cast<uint32_t>(std::min<long>(atol(mw), static_cast<long>(kMaxSimSteps)));
   D.float_range = P.floating ? P.float_max - P.float_min + 1 : 1;
   D.float_max = P.floating ? P.float_max : 0;
   for (int k = 0; k < 8; k++) D.first_bytes[k] = P.first_bytes.w[k];
@@ -363,6 +277,9 @@ int upload_program(rj_program* rp) {
   return RJ_OK;
 }
 
+}  // namespace
+
+namespace rejit_amd {
 // Grow-only device lists.  hits: n_regions x region_cap;  candidates: one slot per hit.
 int ensure_lists(rj_scan* s, uint32_t n_regions, uint32_t region_cap, uint64_t cands_cap) {
   const uint64_t hit_slots = static_cast<uint64_t>(n_regions) * region_cap;
@@ -378,6 +295,9 @@ int ensure_lists(rj_scan* s, uint32_t n_regions, uint32_t region_cap, uint64_t c
   }
   return RJ_OK;
 }
+}  // namespace rejit_amd
+
+namespace {
 
 // Large path: more hit slots than finalize_small handles in LDS.  The slots are already in
 // text order, so no sort: drop the kNoMatch slots, then check / select.
@@ -393,7 +313,6 @@ hipError_t prefix_scan(rj_scan* s, uint64_t* in, uint64_t* out, uint64_t count, 
 }
 
 int check_and_select(rj_scan* s, uint64_t n_upper, const FinalizeParams& fp, hipStream_t st);
-int resolve_selection(rj_scan* s, const FinalizeParams& fp, hipStream_t st);
 
 int finalize_large(rj_scan* s, uint64_t n_slots, bool unsorted, uint64_t text_len, const FinalizeParams& fp, hipStream_t st) {
   s->stats.large_path = 1;
@@ -449,6 +368,9 @@ int check_and_select(rj_scan* s, uint64_t n_slots, const FinalizeParams& fp, hip
   return resolve_selection(s, fp, st);
 }
 
+}  // namespace
+
+namespace rejit_amd {
 // host_counters hold the counters of a finished check: take the candidates as they are, or run
 // the cluster-parallel selection over keys_out / vals_out.
 int resolve_selection(rj_scan* s, const FinalizeParams& fp, hipStream_t st) {
@@ -516,6 +438,9 @@ int resolve_selection(rj_scan* s, const FinalizeParams& fp, hipStream_t st) {
   s->result_count = s->host_counters[kCntFinal];
   return RJ_OK;
 }
+}  // namespace rejit_amd
+
+namespace {
 
 // The window constants a scan kernel takes (exact or nibble form, see WindowSet).
 WindowSet make_window_set(const rj_program* rp) {
@@ -567,6 +492,10 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
   const DevProgram& D = rp->dev;
   const bool windows = D.mode == 1;
   s->result_count = 0;
+  s->result = nullptr;
+  // the previous text needed the linear-time path: go there directly (run_linear clears the hint
+  // when the text turns out not to need it)
+  if (s->linear_hint && linear_path_fits(rp)) return run_linear(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
 
   // what the scan kernel walks, in 1-KiB chunks
   ScanParams sp{};
@@ -660,9 +589,6 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
     vp.sb = sb;
     vp.se = se;
     vp.expand = expand;
-    if (!windows && D.n_words > 4 && se - sb > (1ull << 24))
-      return fail(RJ_TOO_LARGE, "patterns of more than 128 positions without a fast-forward window are limited to 16 MiB "
-                                "of text per call (one wave per candidate start)");
     vp.float_max = D.float_max;
     if (expand > 1 && !floating_regions) {
       // the slot count depends on the hit count, which only the device knows yet: verify must not
@@ -736,7 +662,7 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
     (void)hipEventElapsedTime(&ms, s->ev[1], s->ev[2]);
     s->stats.scan_ms += ms;
     s->stats.n_hits += n_hits;
-    if (s->host_counters[kCntOverflow] != 0) {
+    if (s->host_counters[kCntOverflow] != 0 && s->host_counters[kCntOverrun] == 0) {
       // a region overflowed: size every region for the fullest one seen (x2) and run again
       s->stats.retries++;
       const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(s->host_counters[kCntMaxRegion] * 2, region_cap * 4), region_full);
@@ -748,12 +674,12 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
     }
     s->hits_hint = n_hits;
     if (s->host_counters[kCntOverrun] != 0) {
-      // some start was still alive after kMaxSimSteps bytes (an unbounded repetition over a very
-      // long run): the per-start walks would be quadratic, so refuse loudly rather than run for
-      // hours.  (A chunked state-carry scan for this case is future work)
-      return fail(RJ_TOO_LARGE, "a match candidate runs longer than %llu bytes; unbounded repetitions over such runs "
-                                "are not supported by the parallel verifier",
-                  static_cast<unsigned long long>(kMaxSimSteps));
+      // some start was still alive after max_walk bytes (an unbounded repetition over a long run):
+      // walking every start on its own is quadratic there.  The carry scan is linear in the text
+      // whatever the pattern, like the reference's loop (codegen-x64.cc:535-640).
+      s->linear_hint = true;
+      s->stats.retries++;
+      return run_linear(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
     }
     if (in_regions) {
       // check_and_select produced the result
@@ -793,25 +719,28 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
   if ((reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) return fail(RJ_BAD_ARGUMENT, "device text must be 16-byte aligned");
   const auto wall0 = std::chrono::steady_clock::now();
   const bool windows = rp->dev.mode == 1;
-  if (windows || dense_walk_fits(rp->dev) || se - sb <= kDenseSegment) {
+  if (windows || dense_walk_fits(rp->dev) || se - sb <= kDenseSegment || (s->linear_hint && linear_path_fits(rp))) {
     int rc = run_range(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
     if (rc != RJ_OK) return rc;
-    s->result = s->out.as<uint64_t>();
+    if (s->result == nullptr) s->result = s->out.as<uint64_t>();  // (the carry scan may have accumulated segments elsewhere)
   } else {
     // Dense mode over a long range: a hit slot for a sizeable fraction of the bytes would not
     // fit, so the starts are walked in segments; the selection state is carried from one
     // segment to the next exactly as between the shards of a multi-GPU run.
     uint64_t total = 0;
-    for (uint64_t lo = sb; lo < se; lo += kDenseSegment) {
-      const uint64_t hi = std::min(se, lo + kDenseSegment);
+    for (uint64_t lo = sb, hi; lo < se; lo = hi) {
+      // (once a segment needed the carry scan the rest of the range goes there in one piece: its
+      // summaries cover the text to its end, so many small runs would repeat that work)
+      hi = (s->linear_hint && linear_path_fits(rp)) ? se : std::min(se, lo + kDenseSegment);
       int rc = run_range(s, d_text, n, lo, hi, carry_cur, carry_prev_end, have_prev, st);
       if (rc != RJ_OK) return rc;
       if (s->result_count) {
+        const uint64_t* from = s->result ? s->result : s->out.as<uint64_t>();
         RJ_HIP(s->acc_out.grow_keep((total + s->result_count) * 2 * sizeof(uint64_t), total * 2 * sizeof(uint64_t)));
-        RJ_HIP(hipMemcpyAsync(s->acc_out.as<uint64_t>() + 2 * total, s->out.p, s->result_count * 2 * sizeof(uint64_t),
+        RJ_HIP(hipMemcpyAsync(s->acc_out.as<uint64_t>() + 2 * total, from, s->result_count * 2 * sizeof(uint64_t),
                               hipMemcpyDeviceToDevice, st));
         uint64_t last[2];
-        RJ_HIP(hipMemcpyAsync(last, s->out.as<uint64_t>() + 2 * (s->result_count - 1), sizeof(last), hipMemcpyDeviceToHost, st));
+        RJ_HIP(hipMemcpyAsync(last, from + 2 * (s->result_count - 1), sizeof(last), hipMemcpyDeviceToHost, st));
         RJ_HIP(hipStreamSynchronize(st));
         carry_cur = last[1] > last[0] ? last[1] : last[0] + 1;
         carry_prev_end = last[1];
@@ -1068,8 +997,13 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     for (int p = 0; p < P; p++) {
       rj_scan* s = m->scans[static_cast<size_t>(p)];
       hipStream_t sp = st;  // (rare) selection kernels of one pattern after the other
-      if (s->host_counters[kCntOverrun] != 0)
-        return fail(RJ_TOO_LARGE, "a match candidate runs longer than %llu bytes", static_cast<unsigned long long>(kMaxSimSteps));
+      if (s->host_counters[kCntOverrun] != 0) {
+        // a long-lived candidate: this pattern's run is void; its own pipeline takes the carry scan
+        s->linear_hint = true;
+        int rc = run_pipeline(s, d_text, n, sb, se, 0, 0, 0, st);
+        if (rc != RJ_OK) return rc;
+        continue;
+      }
       s->hits_hint = s->host_counters[kCntHits];
       s->stats.n_hits = s->host_counters[kCntHits];
       FinalizeParams sel{};

@@ -1,0 +1,136 @@
+// rejit_amd/csrc/engine_internal.h -- what the host-side translation units of the engine share:
+// error plumbing, grow-only device buffers, and the objects behind the opaque C-ABI handles
+// (include/rejit_hip.h).  engine.hip holds the common pipeline and the C ABI, linear.hip the
+// linear-time carry scan, multi_device.hip the split of one call over all visible GPUs.
+#ifndef REJIT_AMD_ENGINE_INTERNAL_H_
+#define REJIT_AMD_ENGINE_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <memory>
+#include <string>
+
+#include "../../include/rejit_hip.h"
+#include "device_program.h"
+#include "kernels.h"
+#include "lowering.h"
+
+namespace rejit_amd {
+
+// sets the calling thread's rj_last_error() text and returns `code`
+int rj_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define RJ_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return ::rejit_amd::rj_fail(RJ_DEVICE_ERROR, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// The reference's generated code never touches errno, and its callers rely on that
+// (sample/jrep.cc:281-285 tests `if (errno)` right after mmap).  The HIP runtime does set it
+// (probing files, ioctls), so every entry point restores the caller's value.
+struct ErrnoGuard {
+  int saved;
+  ErrnoGuard() : saved(errno) {}
+  ~ErrnoGuard() { errno = saved; }
+};
+
+struct DeviceBuffer {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DeviceBuffer() {
+    if (p) (void)hipFree(p);
+  }
+  // grow-only; contents are NOT preserved
+  hipError_t reserve(size_t want) {
+    if (want <= bytes) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) bytes = want;
+    return e;
+  }
+  // grow, preserving the first `keep` bytes
+  hipError_t grow_keep(size_t want, size_t keep) {
+    if (want <= bytes) return hipSuccess;
+    void* q = nullptr;
+    size_t cap = std::max(want, bytes * 2);
+    hipError_t e = hipMalloc(&q, cap);
+    if (e != hipSuccess) return e;
+    if (p && keep) e = hipMemcpy(q, p, keep, hipMemcpyDeviceToDevice);
+    if (p) (void)hipFree(p);
+    p = q;
+    bytes = cap;
+    return e;
+  }
+  template <class T>
+  T* as() const { return static_cast<T*>(p); }
+};
+
+}  // namespace rejit_amd
+
+struct rj_program {
+  std::unique_ptr<rejit_amd::Program> host;
+  rejit_amd::DevProgram dev{};
+  rejit_amd::DeviceBuffer tables;
+  rejit_amd::DevProgram rev{};   // the reverse automaton (table fields only), see lowering.h Program::rev
+  rejit_amd::DeviceBuffer rev_tables;
+  rejit_amd::DevGraph graph{};        // uploaded only for patterns with q8_risk
+  rejit_amd::DeviceBuffer graph_blob;
+  int device = 0;
+  int window_alphabet = 0;  // distinct byte values among the fixed window bytes
+  bool window_nibbles = false;  // those values differ in their low nibble (nibble filter usable)
+  int batch_separator = -1;  // byte that ends a text inside a concatenated batch, -1: none exists
+  std::string pattern;
+};
+
+struct rj_scan {
+  const rj_program* prog = nullptr;
+  rejit_amd::DeviceBuffer counters, hits, hit_counts, valid_counts, hit_offsets, cand_begin, cand_end, out, acc_out, keys_out, vals_out, sort_tmp, flag;
+  rejit_amd::DeviceBuffer scan_a, scan_b, taken;  // large-path selection scratch
+  rejit_amd::DeviceBuffer ring;                   // exact sequential kernel
+  rejit_amd::DeviceBuffer with_buf, long_gaps, repl_out;  // replace_gather
+  // carry scan (linear.hip): summaries (resolved in place), reachability matrices, E / G slabs,
+  // entry points, per-sub-chunk counts, wide-automaton scratch
+  rejit_amd::DeviceBuffer cs_vals, cs_mats, cs_e, cs_g, cs_entry, cs_counts, cs_scratch, cs_acc;
+  bool linear_hint = false;        // the previous run needed the carry scan: go there directly
+  uint64_t cands_cap = 0, out_cap = 0;
+  uint32_t region_cap_hint = 64;   // hit-region size that sufficed last time (windows mode)
+  uint64_t hits_hint = 0;          // hits of the previous run (sizes the verify grid)
+  unsigned long long* host_counters = nullptr;  // pinned
+  int* host_flag = nullptr;                     // pinned
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  rj_stats stats{};
+  const uint64_t* result = nullptr;  // device pointer to the final pairs
+  uint64_t result_count = 0;
+  // rj_scan_start / rj_scan_finish
+  hipStream_t tail_stream = nullptr;
+  bool pending = false, pending_launched = false;
+  const uint8_t* pending_text = nullptr;
+  uint64_t pending_n = 0;
+  hipStream_t pending_stream = nullptr;
+  // host-text path
+  rejit_amd::DeviceBuffer text;
+  char* pinned = nullptr;  // staging for rj_match_all_batch
+  size_t pinned_cap = 0;
+  hipStream_t own_stream = nullptr;
+};
+
+namespace rejit_amd {
+
+// engine.hip
+int ensure_lists(rj_scan* s, uint32_t n_regions, uint32_t region_cap, uint64_t cands_cap);
+int resolve_selection(rj_scan* s, const FinalizeParams& fp, hipStream_t st);
+// linear.hip: MatchAll of the starts [sb, se) in time linear in the text (carry_scan.h); results as
+// after run_range (s->out, s->result_count).  RJ_TOO_LARGE when the automaton is wider than the
+// carry kernels take.
+bool linear_path_fits(const rj_program* rp);
+int run_linear(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, uint64_t carry_cur,
+               uint64_t carry_prev_end, int have_prev, hipStream_t st);
+
+}  // namespace rejit_amd
+#endif

@@ -184,5 +184,22 @@ void launch_zero_length_rule(const uint64_t* keys, const uint64_t* vals, const u
 void launch_compact_kept(const uint64_t* keys, const uint64_t* vals, const uint64_t* keep, const uint64_t* pos,
                          uint64_t n, uint64_t* out, uint64_t out_cap, unsigned long long* counters, hipStream_t st);
 
+
+// ---- the linear-time carry scan (carry_kernels.hip, carry_scan.h).  R = the REVERSE automaton.
+// A run covers the sub-chunks [a0 + i*sub, ..), i < m, up to the end of the text; the first m_own of
+// them hold the starts [sb, se).  vals [m][P] uint64 (summaries, resolved in place), mats [m][P*W].
+int cs_state_words(const DevProgram& R);                       // 1, 2, 4, 8; 0 = automaton too wide
+size_t cs_scratch_bytes(const DevProgram& R, uint64_t lanes);  // global slab for the lanes' private state
+void launch_cs_summarize(const DevProgram& R, const uint8_t* text, uint64_t n, uint64_t a0, uint64_t sub, uint64_t m, uint64_t* vals,
+                         uint32_t* mats, uint8_t* scratch, hipStream_t st);
+void launch_cs_resolve(const DevProgram& R, uint64_t m, uint64_t* vals, const uint32_t* mats, hipStream_t st);
+void launch_cs_emit(const DevProgram& R, const uint8_t* text, uint64_t n, uint64_t a0, uint64_t sub, uint64_t m, uint64_t m_own,
+                    uint64_t sb, uint64_t se, const uint64_t* vals, uint64_t* E, uint8_t* scratch, unsigned long long* longest,
+                    hipStream_t st);   // *longest = max E(s) - s (atomicMax; the caller zeroes it)
+// local chains, the hop over the sub-chunks from `cur`, and the taken matches compacted to the front
+// of every sub-chunk's slab (begins in G, ends in E, counts[i] of them; *total = their sum)
+void launch_cs_chain(uint64_t* E, uint64_t* G, uint64_t a0, uint64_t sub, uint64_t m_own, uint64_t sb, uint64_t se, uint64_t cur,
+                     uint64_t* entry, uint32_t* counts, unsigned long long* total, hipStream_t st);
+
 }  // namespace rejit_amd
 #endif

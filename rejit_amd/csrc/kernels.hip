@@ -646,7 +646,7 @@ __global__ __launch_bounds__(256) void verify_lane(VerifyParams a, DevProgram P)
     uint64_t e = 0;
     bool overrun = false, found = false;
     const uint64_t s = w - back;
-    if (w >= back && s >= a.sb && s < a.se) found = rj_lane_longest<NQ>(P, a.text, a.n, s, &e, &overrun);
+    if (w >= back && s >= a.sb && s < a.se) found = rj_lane_longest<NQ>(P, a.text, a.n, s, &e, &overrun, a.counters + kCntOverrun);
     if (overrun) a.counters[kCntOverrun] = 1;
     a.cand_begin[i] = s;
     a.cand_end[i] = found ? e : kNoMatch;
@@ -703,7 +703,7 @@ __device__ bool wave_longest(const DevProgram& P, const uint8_t* t, uint64_t n, 
       }
     }
     if (p == n) break;
-    if (!anchored_full && p - s >= kMaxSimSteps) {
+    if (!anchored_full && p - s >= P.max_walk) {
       *overrun = true;
       break;
     }
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(256) void verify_lane_regions(VerifyParams a, DevPr
       const uint64_t s = region[k];
       uint64_t e = 0;
       bool overrun = false;
-      const bool found = rj_lane_longest<NQ>(P, a.text, a.n, s, &e, &overrun);
+      const bool found = rj_lane_longest<NQ>(P, a.text, a.n, s, &e, &overrun, a.counters + kCntOverrun);
       if (overrun) a.counters[kCntOverrun] = 1;
       a.cand_begin[lo + k] = s;
       a.cand_end[lo + k] = found ? e : kNoMatch;
@@ -821,7 +821,7 @@ __device__ __forceinline__ void verify_in_regions_body(const VerifyParams& a, co
       uint64_t e = 0;
       bool overrun = false;
       const bool found = k < cnt && w >= a.float_max && s >= a.sb && s < a.se &&
-                         rj_lane_longest<NQ>(P, a.text, a.n, s, &e, &overrun);
+                         rj_lane_longest<NQ>(P, a.text, a.n, s, &e, &overrun, a.counters + kCntOverrun);
       if (overrun) a.counters[kCntOverrun] = 1;
       const uint32_t mine = static_cast<uint32_t>(__ballot(found) >> shift) & ((1u << G) - 1u);
       const uint32_t pos = kept + __popc(mine & ((1u << sub) - 1u));
@@ -894,7 +894,7 @@ __global__ __launch_bounds__(256) void verify_floating_in_regions(VerifyParams a
         const uint64_t s = base + sub;
         uint64_t e = 0;
         bool overrun = false;
-        const bool found = s <= hi && s >= a.sb && s < a.se && rj_lane_longest<NQ>(Q, a.text, a.n, s, &e, &overrun);
+        const bool found = s <= hi && s >= a.sb && s < a.se && rj_lane_longest<NQ>(Q, a.text, a.n, s, &e, &overrun, a.counters + kCntOverrun);
         if (overrun) a.counters[kCntOverrun] = 1;
         const uint64_t mine = __ballot(found);
         const uint32_t pos = kept + __popcll(mine & ((1ull << sub) - 1ull));
@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(256) void verify_walkers(VerifyParams a, DevProgram
           }
           if (p == a.n) {
             done = true;
-          } else if (p - s >= kMaxSimSteps) {
+          } else if (p - s >= P.max_walk) {
             a.counters[kCntOverrun] = 1;
             done = true;
           } else {
@@ -1781,6 +1781,9 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
   if (C == 1) first_ctx = 0xFu;
 
   for (uint64_t c = span.c0; c < span.c1; c++) {
+    // some walk of this run has hit P.max_walk: the run is void (the engine repeats it on the carry
+    // scan), no point in finishing it
+    if (*static_cast<const volatile unsigned long long*>(counters + kCntOverrun) != 0) break;
     const uint64_t base = c * kChunk;
     const uint64_t at = base + static_cast<uint64_t>(lane) * 16;
     const uint8_t* tbase = a.text + base;
@@ -1991,7 +1994,7 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
             }
             if (p == n_rel) {
               done = true;
-            } else if (p - s >= kMaxSimSteps) {
+            } else if (p - s >= P.max_walk) {
               counters[kCntOverrun] = 1;
               done = true;
             } else {

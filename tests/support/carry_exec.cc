@@ -62,9 +62,9 @@ long run(const Program& P, const DevProgram& R, const uint8_t* t, uint64_t n, ui
     if (entry[i] == kCsNone) continue;
     uint64_t lo, hi;
     bounds(i, &lo, &hi);
-    const uint32_t cnt = cs_take(E.data(), G.data(), e_base, lo, hi, entry[i]);
+    const uint32_t cnt = cs_take(E.data(), G.data(), e_base, i * sub, hi, entry[i]);
     for (uint32_t k = 0; k < cnt; k++) {
-      const uint64_t bb = G[lo - e_base + k], ee = E[lo - e_base + k];
+      const uint64_t bb = G[i * sub + k], ee = E[i * sub + k];
       bool taken;
       if (rj_select_step(&st, bb, ee, &taken)) {  // the zero-length rule (the device tail applies it)
         if (out_n < cap) {
