@@ -75,8 +75,23 @@ def _build_locked(verbose: bool) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB + ".tmp"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    # one object per source, compiled side by side (kernels.hip alone takes about a minute), then linked
+    objdir = os.path.join(PKG, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread"]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

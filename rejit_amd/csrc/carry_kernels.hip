@@ -79,9 +79,45 @@ __global__ __launch_bounds__(64) void cs_summarize_kernel(DevProgram R, const ui
   }
 }
 
-// phase 2: right to left over the summaries, one wave, lane = position (more than 64 positions: each
-// lane takes several).  Sub-chunks nothing passes through (their matrix is zero) need no work:
-// their summary already is the resolved state.
+// phase 2, two levels (a strictly sequential pass over 32 Ki sub-chunk summaries was 15 of the 17 ms of
+// `[acgt]+` over 64 MiB): (a) every group of kCsGroup consecutive sub-chunks composes its transfers
+// into one, a lane per group; (b) one wave resolves the groups right to left; (c) every group resolves
+// its own sub-chunks from the state entering at its right edge, a lane per group again.
+constexpr uint64_t kCsGroup = 64;
+
+__global__ __launch_bounds__(64) void cs_group_compose_kernel(int P, int W, uint64_t m, const uint64_t* vals, const uint32_t* mats,
+                                                              uint64_t* gvals, uint32_t* gmats, uint8_t* scratch) {
+  const int np = P > 0 ? P : 1;
+  const uint64_t ng = (m + kCsGroup - 1) / kCsGroup;
+  const uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  // ping-pong buffers of this lane: 2 x (np values + np*W words)
+  const size_t one = static_cast<size_t>(np) * 8 + static_cast<size_t>(np) * W * 4;
+  uint8_t* mine = scratch + g * 2 * one;
+  uint64_t* la = reinterpret_cast<uint64_t*>(mine);
+  uint32_t* ra = reinterpret_cast<uint32_t*>(mine + static_cast<size_t>(np) * 8);
+  uint64_t* lb = reinterpret_cast<uint64_t*>(mine + one);
+  uint32_t* rb = reinterpret_cast<uint32_t*>(mine + one + static_cast<size_t>(np) * 8);
+  for (int k = 0; k < P; k++) {
+    la[k] = 0;
+    for (int j = 0; j < W; j++) ra[static_cast<size_t>(k) * W + j] = 0;
+    ra[static_cast<size_t>(k) * W + (k >> 5)] = 1u << (k & 31);  // identity
+  }
+  uint64_t hi = (g + 1) * kCsGroup;
+  if (hi > m) hi = m;
+  for (uint64_t i = hi; i-- > g * kCsGroup;) {
+    cs_compose(P, W, vals + i * np, mats + i * static_cast<uint64_t>(np) * W, la, ra, lb, rb);
+    uint64_t* tl = la; la = lb; lb = tl;
+    uint32_t* tr = ra; ra = rb; rb = tr;
+  }
+  for (int k = 0; k < P; k++) {
+    gvals[g * np + k] = la[k];
+    for (int j = 0; j < W; j++) gmats[(g * np + k) * W + j] = ra[static_cast<size_t>(k) * W + j];
+  }
+}
+
+// (b): right to left over the groups, one wave, lane = position (more than 64 positions: each lane
+// takes several)
 __global__ __launch_bounds__(64) void cs_resolve_kernel(int P, int W, uint64_t m, uint64_t* vals, const uint32_t* mats) {
   const int np = P > 0 ? P : 1;
   const int lane = threadIdx.x;
@@ -91,7 +127,6 @@ __global__ __launch_bounds__(64) void cs_resolve_kernel(int P, int W, uint64_t m
   for (uint64_t i = m; i-- > 0;) {
     uint64_t* D = vals + i * np;
     const uint32_t* Rm = mats + i * static_cast<uint64_t>(np) * W;
-    // which entering positions are live at all
     for (int k = lane; k < P; k += kCsWave) {
       uint64_t d = D[k];
       for (int mm = 0; mm < P; mm++) {
@@ -104,6 +139,19 @@ __global__ __launch_bounds__(64) void cs_resolve_kernel(int P, int W, uint64_t m
     for (int k = lane; k < P; k += kCsWave) dn[k] = D[k];
     __syncthreads();
   }
+}
+
+// (c): gvals[g + 1] = resolved state entering group g at its right edge (zeros beyond the last group)
+__global__ __launch_bounds__(64) void cs_group_apply_kernel(int P, int W, uint64_t m, uint64_t* vals, const uint32_t* mats,
+                                                            const uint64_t* gvals) {
+  const int np = P > 0 ? P : 1;
+  const uint64_t ng = (m + kCsGroup - 1) / kCsGroup;
+  const uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  uint64_t hi = (g + 1) * kCsGroup;
+  if (hi > m) hi = m;
+  for (uint64_t i = hi; i-- > g * kCsGroup;)
+    cs_resolve(P, W, vals + i * np, mats + i * static_cast<uint64_t>(np) * W, i + 1 == hi ? gvals + (g + 1) * np : vals + (i + 1) * np);
 }
 
 // phase 3: E(s) for the own sub-chunks (the first m_own of the run)
@@ -246,8 +294,25 @@ void launch_cs_summarize(const DevProgram& R, const uint8_t* text, uint64_t n, u
 #undef RJ_CS_SUM
 }
 
-void launch_cs_resolve(const DevProgram& R, uint64_t m, uint64_t* vals, const uint32_t* mats, hipStream_t st) {
-  hipLaunchKernelGGL(cs_resolve_kernel, dim3(1), dim3(64), 0, st, R.n_pos, R.n_words, m, vals, mats);
+size_t cs_resolve_scratch_bytes(const DevProgram& R, uint64_t m) {
+  const size_t np = R.n_pos > 0 ? static_cast<size_t>(R.n_pos) : 1, W = static_cast<size_t>(R.n_words);
+  const size_t ng = (m + kCsGroup - 1) / kCsGroup;
+  const size_t one = np * 8 + np * W * 4;
+  // group values [ng + 1][np], group matrices [ng][np * W], ping-pong buffers
+  return (ng + 1) * np * 8 + ng * np * W * 4 + ng * 2 * one + 64;
+}
+
+void launch_cs_resolve(const DevProgram& R, uint64_t m, uint64_t* vals, const uint32_t* mats, uint8_t* scratch, hipStream_t st) {
+  const size_t np = R.n_pos > 0 ? static_cast<size_t>(R.n_pos) : 1, W = static_cast<size_t>(R.n_words);
+  const uint64_t ng = (m + kCsGroup - 1) / kCsGroup;
+  uint64_t* gvals = reinterpret_cast<uint64_t*>(scratch);
+  uint32_t* gmats = reinterpret_cast<uint32_t*>(scratch + (ng + 1) * np * 8);
+  uint8_t* ping = scratch + (((ng + 1) * np * 8 + ng * np * W * 4 + 15) & ~static_cast<size_t>(15));
+  (void)hipMemsetAsync(gvals + ng * np, 0, np * 8, st);  // nothing enters the last group
+  const unsigned blocks = static_cast<unsigned>((ng + 63) / 64);
+  hipLaunchKernelGGL(cs_group_compose_kernel, dim3(blocks), dim3(64), 0, st, R.n_pos, R.n_words, m, vals, mats, gvals, gmats, ping);
+  hipLaunchKernelGGL(cs_resolve_kernel, dim3(1), dim3(64), 0, st, R.n_pos, R.n_words, ng, gvals, gmats);
+  hipLaunchKernelGGL(cs_group_apply_kernel, dim3(blocks), dim3(64), 0, st, R.n_pos, R.n_words, m, vals, mats, gvals);
 }
 
 void launch_cs_emit(const DevProgram& R, const uint8_t* text, uint64_t n, uint64_t a0, uint64_t sub, uint64_t m, uint64_t m_own,

@@ -241,6 +241,28 @@ RJ_HD void cs_resolve(int P, int W, uint64_t* D, const uint32_t* Rmat, const uin
   }
 }
 
+// Two-level resolve: the transfer of a GROUP of consecutive sub-chunks composed into one, so that the
+// sequential pass runs over groups (cs_resolve per group), not over sub-chunks.  (Lc_in, Rc_in) =
+// the transfer of the sub-chunks to the right inside the group (identity / zeros to begin with);
+// (L, R) = the next sub-chunk to the left:   Lc_out = L (+) R x Lc_in,   Rc_out[m] = R x Rc_in[m].
+RJ_HD void cs_compose(int P, int W, const uint64_t* L, const uint32_t* R, const uint64_t* Lc_in, const uint32_t* Rc_in,
+                      uint64_t* Lc_out, uint32_t* Rc_out) {
+  for (int k = 0; k < P; k++) Lc_out[k] = L[k];
+  cs_resolve(P, W, Lc_out, R, Lc_in);
+  for (int m = 0; m < P; m++) {
+    for (int j = 0; j < W; j++) Rc_out[static_cast<size_t>(m) * W + j] = 0;
+    for (int k0 = 0; k0 < W; k0++) {
+      uint32_t s = Rc_in[static_cast<size_t>(m) * W + k0];
+      while (s) {
+        const int bit = __builtin_ctz(s);
+        s &= s - 1;
+        const uint32_t* row = R + static_cast<size_t>(k0 * 32 + bit) * W;
+        for (int j = 0; j < W; j++) Rc_out[static_cast<size_t>(m) * W + j] |= row[j];
+      }
+    }
+  }
+}
+
 // E(s) at boundary s from the state D(s): the largest value among the classes that hold a position
 // able to START a match here (rev.last = forward first), else the empty match if allowed.
 template <int NW>

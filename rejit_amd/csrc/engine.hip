@@ -426,7 +426,8 @@ int resolve_selection(rj_scan* s, const FinalizeParams& fp, hipStream_t st) {
   RJ_HIP(s->taken.reserve(n_cands));
   uint64_t* scratch = s->cand_begin.as<uint64_t>();
   RJ_HIP(scan(vals, sa, n_cands, true));
-  launch_select_walk(keys, vals, sa, n_cands, fp.carry_cur, s->taken.as<uint8_t>(), st);
+  RJ_HIP(s->chain_blocks.reserve(chain_select_scratch_bytes(n_cands)));
+  launch_chain_select(keys, vals, sa, n_cands, fp.carry_cur, s->taken.as<uint8_t>(), sb, scratch, s->chain_blocks.as<uint64_t>(), st);
   launch_taken_index(s->taken.as<uint8_t>(), n_cands, scratch, st);
   RJ_HIP(scan(scratch, sb, n_cands, true));
   launch_zero_length_rule(keys, vals, s->taken.as<uint8_t>(), sb, n_cands, fp.carry_prev_end, fp.have_prev, sa, st);

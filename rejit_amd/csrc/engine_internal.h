@@ -91,12 +91,12 @@ struct rj_program {
 struct rj_scan {
   const rj_program* prog = nullptr;
   rejit_amd::DeviceBuffer counters, hits, hit_counts, valid_counts, hit_offsets, cand_begin, cand_end, out, acc_out, keys_out, vals_out, sort_tmp, flag;
-  rejit_amd::DeviceBuffer scan_a, scan_b, taken;  // large-path selection scratch
+  rejit_amd::DeviceBuffer scan_a, scan_b, taken, chain_blocks;  // large-path selection scratch
   rejit_amd::DeviceBuffer ring;                   // exact sequential kernel
   rejit_amd::DeviceBuffer with_buf, long_gaps, repl_out;  // replace_gather
   // carry scan (linear.hip): summaries (resolved in place), reachability matrices, E / G slabs,
   // entry points, per-sub-chunk counts, wide-automaton scratch
-  rejit_amd::DeviceBuffer cs_vals, cs_mats, cs_e, cs_g, cs_entry, cs_counts, cs_scratch, cs_acc;
+  rejit_amd::DeviceBuffer cs_vals, cs_mats, cs_e, cs_g, cs_entry, cs_counts, cs_scratch, cs_acc, cs_groups;
   bool linear_hint = false;        // the previous run needed the carry scan: go there directly
   uint64_t cands_cap = 0, out_cap = 0;
   uint32_t region_cap_hint = 64;   // hit-region size that sufficed last time (windows mode)

@@ -175,8 +175,12 @@ void launch_match_lengths(const uint64_t* spans, uint64_t m, uint64_t* len, hipS
 void launch_replace_gather(const uint8_t* text, uint64_t n, const uint64_t* spans, const uint64_t* removed, uint64_t m,
                            const uint8_t* with, uint64_t with_len, uint8_t* out, uint64_t out_cap, uint64_t* long_gaps,
                            unsigned long long* counters, hipStream_t st);
-void launch_select_walk(const uint64_t* keys, const uint64_t* vals, const uint64_t* pmax, uint64_t n,
-                        uint64_t carry_cur, uint8_t* taken, hipStream_t st);
+// taken[i] = 1 for the candidates the greedy left-most-longest rule takes (keys / vals sorted by begin,
+// pmax = exclusive prefix max of vals); nxt, G: n uint64 of scratch each, blocks_scratch:
+// chain_select_scratch_bytes(n)
+size_t chain_select_scratch_bytes(uint64_t n);
+void launch_chain_select(const uint64_t* keys, const uint64_t* vals, const uint64_t* pmax, uint64_t n, uint64_t carry_cur,
+                         uint8_t* taken, uint64_t* nxt, uint64_t* G, uint64_t* blocks_scratch, hipStream_t st);
 void launch_taken_index(const uint8_t* taken, uint64_t n, uint64_t* idx, hipStream_t st);
 void launch_zero_length_rule(const uint64_t* keys, const uint64_t* vals, const uint8_t* taken,
                              const uint64_t* last_taken, uint64_t n, uint64_t carry_prev_end, int have_prev,
@@ -192,7 +196,8 @@ int cs_state_words(const DevProgram& R);                       // 1, 2, 4, 8; 0 
 size_t cs_scratch_bytes(const DevProgram& R, uint64_t lanes);  // global slab for the lanes' private state
 void launch_cs_summarize(const DevProgram& R, const uint8_t* text, uint64_t n, uint64_t a0, uint64_t sub, uint64_t m, uint64_t* vals,
                          uint32_t* mats, uint8_t* scratch, hipStream_t st);
-void launch_cs_resolve(const DevProgram& R, uint64_t m, uint64_t* vals, const uint32_t* mats, hipStream_t st);
+size_t cs_resolve_scratch_bytes(const DevProgram& R, uint64_t m);
+void launch_cs_resolve(const DevProgram& R, uint64_t m, uint64_t* vals, const uint32_t* mats, uint8_t* scratch, hipStream_t st);
 void launch_cs_emit(const DevProgram& R, const uint8_t* text, uint64_t n, uint64_t a0, uint64_t sub, uint64_t m, uint64_t m_own,
                     uint64_t sb, uint64_t se, const uint64_t* vals, uint64_t* E, uint8_t* scratch, unsigned long long* longest,
                     hipStream_t st);   // *longest = max E(s) - s (atomicMax; the caller zeroes it)

@@ -1446,30 +1446,104 @@ __global__ __launch_bounds__(1024) void finalize_small(FinalizeParams a) {
   }
 }
 
-// Selection over a sorted candidate list of any size (large path), cluster-parallel.
+// Selection over a sorted candidate list of any size (large path).
 //
-// With M[i] = max end of the candidates before i (exclusive prefix max, computed by the
-// caller) candidate i starts a CLUSTER iff begin[i] >= max(M[i], carry_cur): nothing before it
-// can overlap it, so whatever was selected earlier, i is selected.  Clusters are independent;
-// the thread of a cluster head walks its cluster with the sequential rule.  Clusters are a
-// handful of candidates in practice (overlapping or adjacent-empty matches).
-__global__ void select_walk(const uint64_t* keys, const uint64_t* vals, const uint64_t* pmax, uint64_t n,
-                            uint64_t carry_cur, uint8_t* taken) {
+// The greedy rule (reference: MatchAllAppendFilter + CheckMatch, src/codegen.cc:36-86,
+// codegen-x64.cc:401-466) is a CHAIN over the candidates: after taking i the next one taken is
+//     nxt[i] = the first j > i with begin[j] >= max(end[i], begin[i] + 1).
+// With M[i] = max end of the candidates before i (exclusive prefix max, computed by the caller)
+// candidate i is a HEAD iff begin[i] >= max(M[i], carry_cur) and begin[i] > begin[i-1]: nothing
+// before it can overlap it, so every chain passes through it.  Round 1 let the thread of a head walk
+// its whole cluster, which is sequential in the cluster's size -- `[ab]{40}c*` over 4 MiB of a/b is
+// ONE cluster of 4 M overlapping candidates: 1.05 s in that kernel.  Now the list is cut into blocks:
+//   chain_next    nxt[] by binary search, one thread per candidate
+//   chain_local   per block, right to left: G[i] = where a chain that stands at i leaves the block
+//   chain_hop     from every block that holds a head (and from the chain's first candidate) hop block
+//                 to block through G until a block with a head of its own: the entry points
+//   chain_mark    per block: follow nxt[] from the entry point (or the first head) to the block's end
+// Sequential depth: block + (largest cluster / block) + block instead of the largest cluster.
+constexpr uint64_t kChainBlock = 1024;
+constexpr uint64_t kChainNone = ~0ull;
+
+__global__ void chain_next(const uint64_t* keys, const uint64_t* vals, uint64_t n, uint64_t* nxt) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint64_t floor_i = pmax[i] > carry_cur ? pmax[i] : carry_cur;
-  const bool head = keys[i] >= floor_i;
-  if (!head && i != 0) return;  // index 0 also walks the candidates hidden by the carry
-  uint64_t cur = i == 0 ? carry_cur : 0;
-  for (uint64_t j = i; j < n; j++) {
-    if (j > i) {
-      const uint64_t fl = pmax[j] > carry_cur ? pmax[j] : carry_cur;
-      if (keys[j] >= fl) break;  // next cluster: its own thread takes over
-    }
-    const uint64_t b = keys[j], e = vals[j];
-    bool t = b >= cur && !(j > 0 && keys[j - 1] == b);  // duplicates of a begin: keep the first
-    if (t) cur = e > b ? e : b + 1;
-    taken[j] = t ? 1 : 0;
+  const uint64_t b = keys[i], e = vals[i];
+  const uint64_t cur = e > b ? e : b + 1;
+  uint64_t lo = i + 1, hi = n;  // first index in (i, n] with key >= cur
+  // the next candidate usually is close: gallop before bisecting
+  uint64_t step = 1;
+  while (lo + step < n && keys[lo + step] < cur) {
+    lo += step + 1;
+    step <<= 1;
+  }
+  if (lo + step < hi) hi = lo + step;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < cur) lo = mid + 1; else hi = mid;
+  }
+  nxt[i] = lo;
+}
+
+// one thread: the chain's first candidate i0 = first index with begin >= carry_cur; entry[] preset
+__global__ void chain_start(const uint64_t* keys, uint64_t n, uint64_t carry_cur, uint64_t* entry, uint64_t* i0_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < carry_cur) lo = mid + 1; else hi = mid;
+  }
+  *i0_out = lo;
+  if (lo < n) entry[lo / kChainBlock] = lo;
+}
+
+__global__ __launch_bounds__(64) void chain_local(const uint64_t* keys, const uint64_t* pmax, const uint64_t* nxt, uint64_t n,
+                                                  uint64_t carry_cur, uint64_t* G, uint64_t* first_head) {
+  const uint64_t blk = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t lo = blk * kChainBlock;
+  if (lo >= n) return;
+  const uint64_t hi = lo + kChainBlock < n ? lo + kChainBlock : n;
+  uint64_t head = kChainNone;
+  for (uint64_t i = hi; i-- > lo;) {
+    const uint64_t t = nxt[i];
+    G[i] = t >= hi ? t : G[t];
+    const uint64_t floor_i = pmax[i] > carry_cur ? pmax[i] : carry_cur;
+    if (keys[i] >= floor_i && (i == 0 || keys[i] > keys[i - 1])) head = i;
+  }
+  first_head[blk] = head;
+}
+
+__global__ __launch_bounds__(64) void chain_hop(const uint64_t* G, const uint64_t* first_head, const uint64_t* i0_ptr, uint64_t n,
+                                                uint64_t* entry) {
+  const uint64_t blk = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (blk * kChainBlock >= n) return;
+  const uint64_t i0 = *i0_ptr;
+  uint64_t start = first_head[blk];
+  if (i0 < n && i0 / kChainBlock == blk) start = i0;  // (a head of this block, if any, lies at or after i0)
+  else if (start == kChainNone || start < i0) return;
+  uint64_t idx = G[start];
+  while (idx < n) {
+    const uint64_t b2 = idx / kChainBlock;
+    entry[b2] = idx;
+    if (first_head[b2] != kChainNone) break;  // that block's own thread goes on from its head
+    idx = G[idx];
+  }
+}
+
+__global__ __launch_bounds__(64) void chain_mark(const uint64_t* nxt, const uint64_t* first_head, const uint64_t* entry,
+                                                 const uint64_t* i0_ptr, uint64_t n, uint8_t* taken) {
+  const uint64_t blk = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t lo = blk * kChainBlock;
+  if (lo >= n) return;
+  const uint64_t hi = lo + kChainBlock < n ? lo + kChainBlock : n;
+  uint64_t i = entry[blk];
+  if (i == kChainNone) {
+    i = first_head[blk];
+    if (i == kChainNone || i < *i0_ptr) return;  // no chain comes through this block
+  }
+  while (i < hi) {
+    taken[i] = 1;
+    i = nxt[i];
   }
 }
 
@@ -2299,9 +2373,22 @@ void launch_replace_gather(const uint8_t* text, uint64_t n, const uint64_t* span
 
 static unsigned blocks_for(uint64_t n) { return static_cast<unsigned>((n + 255) / 256); }
 
-void launch_select_walk(const uint64_t* keys, const uint64_t* vals, const uint64_t* pmax, uint64_t n,
-                        uint64_t carry_cur, uint8_t* taken, hipStream_t st) {
-  hipLaunchKernelGGL(select_walk, dim3(blocks_for(n)), dim3(256), 0, st, keys, vals, pmax, n, carry_cur, taken);
+size_t chain_select_scratch_bytes(uint64_t n) { return ((n + kChainBlock - 1) / kChainBlock * 2 + 2) * sizeof(uint64_t); }
+
+void launch_chain_select(const uint64_t* keys, const uint64_t* vals, const uint64_t* pmax, uint64_t n, uint64_t carry_cur,
+                         uint8_t* taken, uint64_t* nxt, uint64_t* G, uint64_t* blocks_scratch, hipStream_t st) {
+  const uint64_t nb = (n + kChainBlock - 1) / kChainBlock;
+  uint64_t* first_head = blocks_scratch;
+  uint64_t* entry = blocks_scratch + nb;
+  uint64_t* i0 = blocks_scratch + 2 * nb;
+  (void)hipMemsetAsync(entry, 0xFF, nb * sizeof(uint64_t), st);
+  (void)hipMemsetAsync(taken, 0, n, st);
+  hipLaunchKernelGGL(chain_next, dim3(blocks_for(n)), dim3(256), 0, st, keys, vals, n, nxt);
+  hipLaunchKernelGGL(chain_start, dim3(1), dim3(64), 0, st, keys, n, carry_cur, entry, i0);
+  const unsigned lb = static_cast<unsigned>((nb + 63) / 64);
+  hipLaunchKernelGGL(chain_local, dim3(lb), dim3(64), 0, st, keys, pmax, nxt, n, carry_cur, G, first_head);
+  hipLaunchKernelGGL(chain_hop, dim3(lb), dim3(64), 0, st, G, first_head, i0, n, entry);
+  hipLaunchKernelGGL(chain_mark, dim3(lb), dim3(64), 0, st, nxt, first_head, entry, i0, n, taken);
 }
 
 void launch_taken_index(const uint8_t* taken, uint64_t n, uint64_t* idx, hipStream_t st) {

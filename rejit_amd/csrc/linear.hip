@@ -50,7 +50,8 @@ int run_linear(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint6
   RJ_HIP(s->cs_scratch.reserve(std::max<size_t>(cs_scratch_bytes(R, m), 16)));
   RJ_HIP(hipEventRecord(s->ev[1], st));
   launch_cs_summarize(R, d_text, n, a0, sub, m, s->cs_vals.as<uint64_t>(), s->cs_mats.as<uint32_t>(), s->cs_scratch.as<uint8_t>(), st);
-  launch_cs_resolve(R, m, s->cs_vals.as<uint64_t>(), s->cs_mats.as<uint32_t>(), st);
+  RJ_HIP(s->cs_groups.reserve(cs_resolve_scratch_bytes(R, m)));
+  launch_cs_resolve(R, m, s->cs_vals.as<uint64_t>(), s->cs_mats.as<uint32_t>(), s->cs_groups.as<uint8_t>(), st);
 
   const uint64_t seg_starts = std::max<uint64_t>(kCsSegment / sub, 1) * sub;
   uint64_t total = 0, longest = 0;

@@ -35,7 +35,31 @@ long run(const Program& P, const DevProgram& R, const uint8_t* t, uint64_t n, ui
     const uint64_t a = (c_first + i) * sub, b = std::min(a + sub, n);
     cs_summarize<NW>(R, t, n, a, b, C, srcarr, &D[i * np], &Rm[i * np * W]);
   }
-  for (uint64_t i = m; i-- > 0;) cs_resolve(P.n_pos, W, &D[i * np], &Rm[i * np * W], &D[(i + 1) * np]);
+  {
+    // two-level resolve as on the device: groups of `grp` sub-chunks composed into one transfer each,
+    // a sequential pass over the groups, then every group's own sub-chunks
+    const uint64_t grp = 3, ng = (m + grp - 1) / grp;
+    std::vector<uint64_t> gD(static_cast<size_t>(ng + 1) * np, 0), la(np), lb(np);
+    std::vector<uint32_t> gR(static_cast<size_t>(ng) * np * W, 0), ra(static_cast<size_t>(np) * W), rb(static_cast<size_t>(np) * W);
+    for (uint64_t g = 0; g < ng; g++) {
+      std::fill(la.begin(), la.end(), 0);
+      std::fill(ra.begin(), ra.end(), 0u);
+      for (int k = 0; k < P.n_pos; k++) ra[static_cast<size_t>(k) * W + (k >> 5)] = 1u << (k & 31);  // identity
+      for (uint64_t i = std::min(m, (g + 1) * grp); i-- > g * grp;) {
+        cs_compose(P.n_pos, W, &D[i * np], &Rm[i * np * W], la.data(), ra.data(), lb.data(), rb.data());
+        la.swap(lb);
+        ra.swap(rb);
+      }
+      std::copy(la.begin(), la.end(), gD.begin() + static_cast<long>(g * np));
+      std::copy(ra.begin(), ra.end(), gR.begin() + static_cast<long>(g * np * W));
+    }
+    for (uint64_t g = ng; g-- > 0;) cs_resolve(P.n_pos, W, &gD[g * np], &gR[g * np * W], &gD[(g + 1) * np]);
+    for (uint64_t g = 0; g < ng; g++) {
+      const uint64_t last = std::min(m, (g + 1) * grp) - 1;
+      for (uint64_t i = last + 1; i-- > g * grp;)
+        cs_resolve(P.n_pos, W, &D[i * np], &Rm[i * np * W], i == last ? &gD[(g + 1) * np] : &D[(i + 1) * np]);
+    }
+  }
   const uint64_t n_own = (se - 1) / sub - c_first + 1;  // sub-chunks that hold own starts
   std::vector<uint64_t> E(static_cast<size_t>(n_own * sub), kCsNone), G(static_cast<size_t>(n_own * sub), 0);
   for (uint64_t i = 0; i < n_own; i++) {
