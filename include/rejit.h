@@ -54,6 +54,12 @@ class Regej {
   ~Regej();
 
   Status status() const { return status_; }
+  // Outcome of the most recent Match* / Replace* call on this object: RejitSuccess, or the reason it
+  // returned "no match" without having matched (a HIP failure, an input the device automaton cannot
+  // take).  The reference aborts in the equivalent situations (rejit_fatal, src/checks.cc:19-26);
+  // here the call returns 0 / false, rejit_status_string holds the message, a line goes to stderr
+  // and this accessor tells a caller the result is not an answer.
+  Status last_status() const { return last_status_; }
 
   bool MatchFull(const string& text);
   bool MatchFull(const char* text, size_t text_size);
@@ -78,9 +84,12 @@ class Regej {
   Regej& operator=(const Regej&);
   void init(const char* regexp);
 
+  bool failed(long rc);
+
   string regexp_;
   rj_program* program_;
   Status status_;
+  Status last_status_;
 };
 
 // One-shot helpers: each builds a temporary Regej (there is no compiled-pattern cache).

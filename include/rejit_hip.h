@@ -120,7 +120,8 @@ int64_t rj_scan_run(rj_scan* scan, const void* d_text, uint64_t n, uint64_t own_
  * earlier ones overlap them. */
 int rj_scan_start(rj_scan* scan, const void* d_text, uint64_t n, void* hip_stream);
 int64_t rj_scan_finish(rj_scan* scan);
-/* results of the last run: device pointer to 2*count uint64 offsets, or a host copy */
+/* results of the last run: device pointer to 2*count uint64 offsets, or a copy (host_spans may be host or
+ * device memory; returns the number of matches, copies at most cap of them) */
 const uint64_t* rj_scan_device_spans(const rj_scan* scan);
 int64_t rj_scan_copy_spans(const rj_scan* scan, uint64_t* host_spans, uint64_t cap);
 /* Replace over device text: the matches of the LAST rj_scan_run on this scan (which must have
@@ -150,6 +151,12 @@ int rj_multi_run(rj_multi* multi, const void* d_text, uint64_t n, uint64_t* coun
 int rj_multi_run_range(rj_multi* multi, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end,
                        uint64_t* counts, void* hip_stream);
 rj_scan* rj_multi_scan(rj_multi* multi, int i);
+/* First and last match of every pattern's result after rj_multi_run / _run_range: bounds[4*i .. 4*i+3] =
+ * first begin, first end, last begin, last end (all UINT64_MAX when pattern i has no match).  This is what
+ * neighbouring shards exchange to carry the left-most-longest selection over a cut: a shard whose first
+ * match begins before its left neighbour's last end re-runs that pattern with rj_scan_run(rj_multi_scan(m, i),
+ * ..., carry) -- 32 bytes per pattern instead of the match list. */
+int rj_multi_bounds(rj_multi* multi, uint64_t* bounds, void* hip_stream);
 /* mode 0 (default): fuse when possible; mode 1: never fuse (one scan kernel per pattern, back to back on
  * the caller's stream); mode 2: as 1, the scan kernels alternating between the caller's stream and a second
  * one so that consecutive kernels overlap at their boundaries */

@@ -6,3 +6,7 @@ tests and bench.py.  There is no Python or CPU implementation of the matching pa
 library is missing, or no HIP device is present, every call fails loudly.
 """
 from .api import (RejitError, Program, Scan, MultiScan, build, library_path, load_library, device_count)  # noqa: F401
+
+# VALU operations the fused nine-pattern scan kernel (scan_windows_fused) spends per text byte, counted
+# from its ISA (DESIGN.md section 4); bench.py prices the kernel's VALU roofline with it
+FUSED_VALU_OPS_PER_BYTE = 29.0

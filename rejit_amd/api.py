@@ -121,7 +121,8 @@ C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_er
                  "rj_scan_destroy", "rj_scan_run", "rj_scan_device_spans", "rj_scan_copy_spans", "rj_scan_stats",
                  "rj_scan_match_full", "rj_device_count", "rj_replace_all", "rj_free_text", "rj_scan_replace",
                  "rj_match_all_batch", "rj_multi_create", "rj_multi_destroy", "rj_multi_run", "rj_multi_scan",
-                 "rj_multi_scan_ms", "rj_scan_start", "rj_scan_finish", "rj_multi_set_mode", "rj_multi_run_range"]
+                 "rj_multi_scan_ms", "rj_scan_start", "rj_scan_finish", "rj_multi_set_mode", "rj_multi_run_range",
+                 "rj_multi_bounds"]
 
 
 def load_library():
@@ -163,6 +164,7 @@ def load_library():
     L.rj_multi_scan_ms.restype = ctypes.c_float
     L.rj_multi_scan_ms.argtypes = [vp]
     L.rj_multi_set_mode.argtypes = [vp, ctypes.c_int]
+    L.rj_multi_bounds.argtypes = [vp, _u64p, vp]
     L.rj_scan_destroy.argtypes = [vp]
     L.rj_scan_run.restype = i64
     L.rj_scan_run.argtypes = [vp, vp, u64, u64, u64, u64, u64, ctypes.c_int, vp]
@@ -319,6 +321,17 @@ class Scan:
         _check(self._lib.rj_scan_copy_spans(self._h, buf, n))
         return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n)]
 
+    def spans_tensor(self, device):
+        """The matches of the last run as an (k, 2) int64 torch tensor on `device` (no trip through Python
+        lists: what the multi-GPU gather of many matches works on)."""
+        import torch
+
+        n = int(_check(self._lib.rj_scan_copy_spans(self._h, None, 0)))
+        out = torch.empty((max(n, 1), 2), dtype=torch.int64, device=device)
+        if n:
+            _check(self._lib.rj_scan_copy_spans(self._h, ctypes.cast(ctypes.c_void_p(out.data_ptr()), _u64p), n))
+        return out[:n]
+
     def device_spans_ptr(self) -> int:
         return int(self._lib.rj_scan_device_spans(self._h) or 0)
 
@@ -382,3 +395,12 @@ class MultiScan:
 
     def scan_ms(self) -> float:
         return float(self._lib.rj_multi_scan_ms(self._h))
+
+    def bounds(self, stream: int = 0) -> List[Optional[Tuple[int, int, int, int]]]:
+        """Per pattern (first begin, first end, last begin, last end) of the last run, None without a
+        match: what neighbouring shards exchange to carry the selection over a cut (rj_multi_bounds)."""
+        k = len(self.programs)
+        buf = (ctypes.c_uint64 * (4 * k))()
+        _check(self._lib.rj_multi_bounds(self._h, buf, ctypes.c_void_p(stream)))
+        none = (1 << 64) - 1
+        return [None if buf[4 * i] == none else tuple(int(buf[4 * i + j]) for j in range(4)) for i in range(k)]

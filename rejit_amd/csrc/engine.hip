@@ -20,6 +20,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <chrono>
 #include <cstdarg>
@@ -770,7 +771,7 @@ int scan_init(rj_scan* s) {
 
 // one scratch per (thread, program) for the host-text entry points
 struct HostScans {
-  std::vector<std::pair<const rj_program*, rj_scan*>> v;
+  std::vector<std::pair<uint64_t, rj_scan*>> v;  // keyed by rj_program::id, not by address
   ~HostScans() {
     for (auto& p : v) rj_scan_destroy(p.second);
   }
@@ -779,7 +780,7 @@ thread_local HostScans g_host_scans;
 
 int host_scan_for(const rj_program* prog, rj_scan** out) {
   for (auto& p : g_host_scans.v)
-    if (p.first == prog) {
+    if (p.first == prog->id) {
       *out = p.second;
       return RJ_OK;
     }
@@ -794,7 +795,7 @@ int host_scan_for(const rj_program* prog, rj_scan** out) {
     rj_scan_destroy(g_host_scans.v.front().second);
     g_host_scans.v.erase(g_host_scans.v.begin());
   }
-  g_host_scans.v.emplace_back(prog, s);
+  g_host_scans.v.emplace_back(prog->id, s);
   *out = s;
   return RJ_OK;
 }
@@ -842,6 +843,7 @@ struct rj_multi {
   DeviceBuffer dummy_counts;  // hit_counts of the padding patterns
   DeviceBuffer tails;         // MultiTail[P]
   MultiTail* host_tails = nullptr;  // pinned
+  uint64_t* host_bounds = nullptr;  // pinned, rj_multi_bounds
   hipStream_t second = nullptr;     // separate-scans mode: odd patterns' scan kernels
   hipEvent_t fork = nullptr, join = nullptr;
   std::vector<MultiTail> uploaded;  // what the device array holds (skip the copy when nothing changed)
@@ -1055,6 +1057,8 @@ int rj_compile(const char* regexp, rj_program** out) {
   auto rp = std::make_unique<rj_program>();
   rp->host = std::move(lr.program);
   rp->pattern = regexp;
+  static std::atomic<uint64_t> next_id{1};
+  rp->id = next_id.fetch_add(1);
   int rc = upload_program(rp.get());
   if (rc != RJ_OK) return rc;
   *out = rp.release();
@@ -1067,7 +1071,7 @@ void rj_program_free(rj_program* prog) {
   // drop cached host scans of this thread that refer to the program
   auto& v = g_host_scans.v;
   for (size_t i = 0; i < v.size();) {
-    if (v[i].first == prog) {
+    if (v[i].first == prog->id) {
       rj_scan_destroy(v[i].second);
       v.erase(v.begin() + static_cast<long>(i));
     } else {
@@ -1241,7 +1245,8 @@ int64_t rj_scan_copy_spans(const rj_scan* s, uint64_t* host_spans, uint64_t cap)
   if (!s) return fail(RJ_BAD_ARGUMENT, "null scan");
   const uint64_t k = std::min<uint64_t>(cap, s->result_count);
   if (k) {
-    hipError_t e = hipMemcpy(host_spans, s->result, k * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    // (hipMemcpyDefault: the destination may be host or device memory)
+    hipError_t e = hipMemcpy(host_spans, s->result, k * 2 * sizeof(uint64_t), hipMemcpyDefault);
     if (e != hipSuccess) return fail(RJ_DEVICE_ERROR, "hipMemcpy failed: %s", hipGetErrorString(e));
   }
   return static_cast<int64_t>(s->result_count);
@@ -1355,6 +1360,7 @@ void rj_multi_destroy(rj_multi* m) {
   if (!m) return;
   for (rj_scan* s : m->scans) rj_scan_destroy(s);
   if (m->host_tails) (void)hipHostFree(m->host_tails);
+  if (m->host_bounds) (void)hipHostFree(m->host_bounds);
   if (m->second) (void)hipStreamDestroy(m->second);
   if (m->fork) (void)hipEventDestroy(m->fork);
   if (m->join) (void)hipEventDestroy(m->join);
@@ -1402,6 +1408,25 @@ rj_scan* rj_multi_scan(rj_multi* m, int i) {
 }
 
 float rj_multi_scan_ms(const rj_multi* m) { return m ? m->scan_ms : 0.f; }
+
+int rj_multi_bounds(rj_multi* m, uint64_t* bounds, void* hip_stream) {
+  ErrnoGuard errno_guard;
+  if (!m || !bounds) return fail(RJ_BAD_ARGUMENT, "null argument");
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const int P = static_cast<int>(m->scans.size());
+  if (!m->host_bounds) RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&m->host_bounds), sizeof(uint64_t) * 4 * kMaxFused));
+  BoundsParams bp{};
+  bp.n_lists = P;
+  for (int p = 0; p < P; p++) {
+    bp.spans[p] = m->scans[static_cast<size_t>(p)]->result;
+    bp.count[p] = bp.spans[p] ? m->scans[static_cast<size_t>(p)]->result_count : 0;
+  }
+  launch_first_last(bp, m->host_bounds, st);
+  RJ_HIP(hipStreamSynchronize(st));
+  RJ_HIP(hipGetLastError());
+  memcpy(bounds, m->host_bounds, sizeof(uint64_t) * 4 * static_cast<size_t>(P));
+  return RJ_OK;
+}
 
 int rj_multi_set_mode(rj_multi* m, int mode) {
   if (!m || mode < 0 || mode > 2) return fail(RJ_BAD_ARGUMENT, "bad argument");

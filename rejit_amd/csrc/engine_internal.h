@@ -82,6 +82,7 @@ struct rj_program {
   rejit_amd::DevGraph graph{};        // uploaded only for patterns with q8_risk
   rejit_amd::DeviceBuffer graph_blob;
   int device = 0;
+  uint64_t id = 0;          // unique per compile: keys per-thread caches (a freed program's address may be reused)
   int window_alphabet = 0;  // distinct byte values among the fixed window bytes
   bool window_nibbles = false;  // those values differ in their low nibble (nibble filter usable)
   int batch_separator = -1;  // byte that ends a text inside a concatenated batch, -1: none exists

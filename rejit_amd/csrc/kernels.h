@@ -95,6 +95,12 @@ struct FusedParams {
   uint32_t* hit_counts[kMaxFused];
   unsigned long long* zero_counters[kMaxFused];  // may be null
 };
+struct BoundsParams {
+  int n_lists;
+  const uint64_t* spans[kMaxFused];
+  uint64_t count[kMaxFused];
+};
+void launch_first_last(const BoundsParams& a, uint64_t* pinned_bounds, hipStream_t st);
 void launch_scan_windows_fused(const FusedParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 
 struct ScanGeometry {

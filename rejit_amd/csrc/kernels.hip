@@ -1157,6 +1157,24 @@ __global__ __launch_bounds__(kOgcThreads) void offsets_gather_check_multi(const 
                             t.out_cap, t.verify.counters, t.host_counters);
 }
 
+// First and last match of up to kMaxFused result lists (rj_multi_bounds: what a shard exchanges with
+// its neighbours to carry the selection over a cut): bounds[p] = {first begin, first end, last begin,
+// last end}, all ~0 when the list is empty.  One thread per list; written straight to pinned memory.
+__global__ void first_last_kernel(BoundsParams a, uint64_t* bounds) {
+  const int p = threadIdx.x;
+  if (p >= a.n_lists) return;
+  const uint64_t n = a.count[p];
+  const uint64_t* r = a.spans[p];
+  bounds[4 * p + 0] = n ? r[0] : ~0ull;
+  bounds[4 * p + 1] = n ? r[1] : ~0ull;
+  bounds[4 * p + 2] = n ? r[2 * (n - 1)] : ~0ull;
+  bounds[4 * p + 3] = n ? r[2 * (n - 1) + 1] : ~0ull;
+}
+
+void launch_first_last(const BoundsParams& a, uint64_t* pinned_bounds, hipStream_t st) {
+  hipLaunchKernelGGL(first_last_kernel, dim3(1), dim3(64), 0, st, a, pinned_bounds);
+}
+
 // pairs -> begin[] / end[] for the selection kernels (only when the pairs are not the result yet)
 __global__ void split_pairs(const uint64_t* pairs, const unsigned long long* n_ptr, uint64_t* keys, uint64_t* vals) {
   const uint64_t n = *n_ptr;

@@ -39,7 +39,21 @@ void Regej::init(const char* regexp) {
   program_ = nullptr;
   int rc = rj_compile(regexp_.c_str(), &program_);
   status_ = to_status(rc);
+  last_status_ = status_;
   if (rc != RJ_OK) set_status_string(rj_last_error());
+}
+
+// A run-time failure must not look like "no match" (the reference aborts where this library returns
+// an error code): record it, keep the message, and say so on stderr.
+bool Regej::failed(long rc) {
+  if (rc >= 0) {
+    last_status_ = RejitSuccess;
+    return false;
+  }
+  last_status_ = to_status(static_cast<int>(rc));
+  set_status_string(rj_last_error());
+  fprintf(stderr, "rejit: matching /%s/ failed: %s\n", regexp_.c_str(), rejit_status_string);
+  return true;
 }
 
 Regej::Regej(const char* regexp) { init(regexp); }
@@ -53,7 +67,7 @@ bool Regej::MatchFull(const string& text) { return MatchFull(text.c_str(), text.
 bool Regej::MatchFull(const char* text, size_t text_size) {
   if (status_ != RejitSuccess) return false;
   int r = rj_match_full(program_, text, text_size);
-  if (r < 0) set_status_string(rj_last_error());
+  if (failed(r)) return false;
   return r > 0;
 }
 
@@ -62,7 +76,7 @@ bool Regej::MatchAnywhere(const string& text) { return MatchAnywhere(text.c_str(
 bool Regej::MatchAnywhere(const char* text, size_t text_size) {
   if (status_ != RejitSuccess) return false;
   int r = rj_match_anywhere(program_, text, text_size);
-  if (r < 0) set_status_string(rj_last_error());
+  if (failed(r)) return false;
   return r > 0;
 }
 
@@ -72,7 +86,7 @@ bool Regej::MatchFirst(const char* text, size_t text_size, Match* match) {
   if (status_ != RejitSuccess) return false;
   uint64_t b = 0, e = 0;
   int r = rj_match_first(program_, text, text_size, &b, &e);
-  if (r < 0) set_status_string(rj_last_error());
+  if (failed(r)) return false;
   if (r > 0 && match) {
     match->begin = text + b;
     match->end = text + e;
@@ -88,10 +102,7 @@ size_t Regej::MatchAll(const char* text, size_t text_size, std::vector<Match>* m
   if (status_ != RejitSuccess) return 0;
   uint64_t* spans = nullptr;
   int64_t n = rj_match_all(program_, text, text_size, matches ? &spans : nullptr);
-  if (n < 0) {
-    set_status_string(rj_last_error());
-    return matches ? matches->size() : 0;
-  }
+  if (failed(n)) return matches ? matches->size() : 0;
   if (!matches) return static_cast<size_t>(n);
   for (int64_t i = 0; i < n; i++) {
     Match m;
@@ -113,10 +124,7 @@ size_t Regej::MatchAllCount(const string& text) { return MatchAllCount(text.c_st
 size_t Regej::MatchAllCount(const char* text, size_t text_size) {
   if (status_ != RejitSuccess) return 0;
   int64_t n = rj_match_all(program_, text, text_size, nullptr);  // count only: 8 bytes come back
-  if (n < 0) {
-    set_status_string(rj_last_error());
-    return 0;
-  }
+  if (failed(n)) return 0;
   return static_cast<size_t>(n);
 }
 
@@ -133,10 +141,7 @@ size_t Regej::ReplaceAll(string& text, const string& with) {
   char* out = nullptr;
   size_t out_len = 0;
   int64_t n = rj_replace_all(program_, text.data(), text.size(), with.data(), with.size(), &out, &out_len);
-  if (n < 0) {
-    set_status_string(rj_last_error());
-    return 0;
-  }
+  if (failed(n)) return 0;
   text.assign(out, out_len);
   rj_free_text(out);
   return static_cast<size_t>(n);

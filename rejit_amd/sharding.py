@@ -129,6 +129,116 @@ def sharded_match_all(local_scan: LocalScan, ranges: Sequence[Tuple[int, int]], 
     return total, gathered, spans
 
 
+def sharded_match_all_tensor(local_scan, ranges, rank: int, world: int, dist=None, device=None):
+    """sharded_match_all on tensors: local_scan(lo, hi, carry_cur, carry_prev_end, have_prev) returns an
+    (k, 2) int64 tensor of GLOBAL spans (any device); the carry exchange moves 5 integers per rank, the
+    spans go to rank 0 through gather_spans_tensor.  Returns (total, spans on rank 0 or None, local)."""
+    import torch
+
+    own = ranges[rank]
+    empty = (0, 0, False)
+    spans = local_scan(own[0], own[1], *empty)
+    if world == 1 or dist is None:
+        return int(spans.shape[0]), spans, spans
+    used = empty
+
+    def head_tail(sp):
+        if sp.shape[0] == 0:
+            return None, None
+        ht = torch.stack([sp[0], sp[-1]]).cpu().tolist()
+        return tuple(ht[0]), tuple(ht[1])
+
+    for _ in range(world):
+        first, last = head_tail(spans)
+        co = carry_out([last] if last else [], used)
+        mine = torch.tensor([co[0], co[1], int(co[2]), first[0] if first else -1, first[1] if first else -1],
+                            dtype=torch.int64, device=device)
+        allc = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine)
+        cin = empty
+        for r in range(rank):
+            cc = allc[r].tolist()
+            if cc[2]:
+                cin = (cc[0], cc[1], True)
+        rerun = cin != used and needs_rerun(first, cin)
+        flag = torch.tensor([int(rerun)], dtype=torch.int64, device=device)
+        dist.all_reduce(flag)
+        if rerun:
+            spans = local_scan(own[0], own[1], *cin)
+            used = cin
+        if int(flag.item()) == 0:
+            break
+    gathered = gather_spans_tensor(spans.to(device), rank, world, dist)
+    cnt = torch.tensor([int(spans.shape[0])], dtype=torch.int64, device=device)
+    dist.all_reduce(cnt)
+    return int(cnt.item()), gathered, spans
+
+
+def gather_spans_tensor(spans, rank: int, world: int, dist, dst: int = 0):
+    """Exchange step for MANY matches: `spans` is an (k, 2) int64 tensor on the collective device (HBM
+    for RCCL); counts travel by all_gather, the pairs by one padded gather to `dst` -- no Python lists
+    of tuples (C5's line tables are ~10^8 entries).  Returns the concatenated (K, 2) tensor on `dst`,
+    None elsewhere."""
+    import torch
+
+    dev = spans.device
+    cnt = torch.tensor([int(spans.shape[0])], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt)
+    counts = [int(c.item()) for c in counts]
+    width = max(max(counts), 1)
+    buf = torch.zeros((width, 2), dtype=torch.int64, device=dev)
+    if spans.shape[0]:
+        buf[:spans.shape[0]] = spans
+    parts = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, parts, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([parts[r][:counts[r]] for r in range(world)], dim=0)
+
+
+def multi_pattern_counts(run_local, rerun_one, n_patterns: int, rank: int, world: int, dist, device):
+    """Sharded COUNTS of several patterns over one text (regexdna's nine, BASELINE configs[2]) with the
+    selection carried over the cuts.  run_local() -> (counts, bounds): this rank's counts with an empty
+    carry and per pattern None or (first begin, first end, last begin, last end); rerun_one(i, carry_cur,
+    carry_prev_end) -> (count, bounds_i) re-runs pattern i with the true carry.  One all_gather of
+    5 integers per pattern per round; a second round only when some rank's first match begins before its
+    left neighbour's last end (self-overlapping occurrences across a cut: rare).  Returns the job-wide
+    counts, identical on every rank."""
+    import torch
+
+    counts, bounds = run_local()
+    for _ in range(world):
+        mine = torch.full((n_patterns, 5), -1, dtype=torch.int64)
+        for i in range(n_patterns):
+            mine[i, 0] = counts[i]
+            if bounds[i] is not None:
+                mine[i, 1:] = torch.tensor(bounds[i], dtype=torch.int64)
+        mine = mine.to(device)
+        allb = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allb, mine)
+        allb = torch.stack(allb).cpu()          # [world][pattern][count, fb, fe, lb, le]
+        again = False
+        for i in range(n_patterns):
+            # carry into rank r = the last match of the nearest rank before it that has one
+            for r in range(1, world):
+                if allb[r, i, 1] < 0:
+                    continue
+                prev = [q for q in range(r) if allb[q, i, 1] >= 0]
+                if not prev:
+                    continue
+                lb, le = int(allb[prev[-1], i, 3]), int(allb[prev[-1], i, 4])
+                cur = le if le > lb else lb + 1
+                fb, fe = int(allb[r, i, 1]), int(allb[r, i, 2])
+                if fb < cur or (fb == fe and le == fb):
+                    again = True
+                    if r == rank:
+                        counts[i], bounds[i] = rerun_one(i, cur, le)
+        if not again:
+            return [int(allb[:, i, 0].sum()) for i in range(n_patterns)]
+    raise RuntimeError("carry exchange did not converge")
+
+
 def _device_for(dist):
     import torch
 

@@ -135,3 +135,56 @@ def test_own_regexdna_counterpart(tmp_path):
     lines = out.strip().split("\n")
     assert [int(l.rsplit(" ", 1)[1]) for l in lines[:9]] == [3, 12, 43, 27, 58, 16, 15, 18, 20]
     assert [int(x) for x in lines[-3:]] == [508411, 500000, 668262]
+
+
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DIR, "regexdna_mt_hip")), reason="oracle/_ref/regexdna_mt_hip not built")
+def test_reference_regexdna_multithread_sample(tmp_path):
+    """sample/regexdna-multithread.cc unchanged: a Regej per thread per call, hardware_concurrency()
+    threads hammering one library (reference sample/regexdna-multithread.cc:65-78, 117-167)."""
+    g = V.bench()["regexdna"]["50000"]
+    fasta = tmp_path / "in.fasta"
+    fasta.write_bytes(W.fasta_raw_numpy(50000).tobytes())
+    with open(fasta, "rb") as f:
+        out = subprocess.run([os.path.join(REF_DIR, "regexdna_mt_hip")], stdin=f, capture_output=True, timeout=600, check=True).stdout.decode()
+    lines = out.strip().split("\n")
+    assert [l.rsplit(" ", 1)[0] for l in lines[:9]] == W.REGEXDNA_PATTERNS
+    assert [int(l.rsplit(" ", 1)[1]) for l in lines[:9]] == [3, 12, 43, 27, 58, 16, 15, 18, 20]
+    assert [int(x) for x in lines[-3:]] == [g["raw_size"], g["stripped_size"], g["replaced_size"]] == [508411, 500000, 668262]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DIR, "basic_hip")), reason="oracle/_ref/basic_hip not built")
+def test_reference_basic_sample(tmp_path):
+    """sample/basic.cc unchanged (MatchAll over a file named LICENCE through the string overload)."""
+    from checkers import Oracle
+    text = ("Copyright holders reserve every right.  Redistribution, conversion and extension of this\n"
+            "section are subject to the conditions of the licence; no permission is implied.\n") * 7
+    (tmp_path / "LICENCE").write_text(text)
+    out = subprocess.run([os.path.join(REF_DIR, "basic_hip")], cwd=tmp_path, capture_output=True, timeout=120, check=True).stdout.decode()
+    want = Oracle().match_all(b"(right|[ts]ion)", text.encode())
+    assert "Found %d matches." % len(want) in out, out
+    shown = out.split("Printing the first 10:\n")[1].split("\n")[:10]
+    assert shown == [text[b:e] for b, e in want[:10]]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DIR, "test_rejit_hip")), reason="oracle/_ref/test_rejit_hip not built")
+def test_reference_test_program_passes():
+    """tools/tests/test.cc unchanged -- the reference's ONLY test suite (282 macros, ~4.7 k checks of
+    all four match types, 33 alignments each for the fast-forward cases) -- prints `success` on this
+    library.  (The reference itself fails one of them with its default flags)"""
+    r = subprocess.run([os.path.join(REF_DIR, "test_rejit_hip")], capture_output=True, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and out.strip().endswith("success"), out[-2000:]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DIR, "bench_rejit_hip")), reason="oracle/_ref/bench_rejit_hip not built")
+def test_reference_bench_harness_runs():
+    """tools/benchmarks/engines/{bench_engine.cc, rejit/engine.cc} unchanged: the harness the
+    reference's published curves come from (bytes/s worst / amortised / best per text size)."""
+    r = subprocess.run([os.path.join(REF_DIR, "bench_rejit_hip"), "regexp", "--size=1024,65536,4194304", "--iterations=5"],
+                       capture_output=True, timeout=300, check=True)
+    rows = [l.split() for l in r.stdout.decode().strip().split("\n")]
+    assert rows[0][0] == "text_size" and [int(x[0]) for x in rows[1:]] == [1024, 65536, 4194304]
+    assert all(float(v) > 0 for x in rows[1:] for v in x[1:])

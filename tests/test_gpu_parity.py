@@ -590,3 +590,38 @@ def test_complex_regex_floating_windows_large(rj, oracle):
     got = set(spans)
     for b_, e_ in planted:    # a planted string is matched (possibly extended to the left by the repetition)
         assert any(gb <= b_ and ge == e_ for gb, ge in got if gb >= b_ - 48 and ge == e_), (b_, e_)
+
+
+def test_planted_literal_beyond_4gib(rj):
+    """64-bit offsets in a pytest (round 1 only checked them inside bench.py): 4.5 GiB of device text,
+    occurrences planted on both sides of 2^32, the result compared with an independent torch compare
+    of the six bytes around every planted position and of a window across the 4 GiB line."""
+    import torch
+    from rejit_amd import workloads as W
+    dev = torch.device("cuda:0")
+    n = (9 << 29) + 12345          # 4.5 GiB and a ragged tail
+    t = W.random_ascii_torch(n, 0xBEEF, dev)
+    offs = sorted(set(W.plant_offsets(n, 6, 300, seed=5, boundaries=[1 << 32, (1 << 32) + 1024, 1 << 31, n // 2])
+                      + [(1 << 32) - 3, (1 << 32) - 6, (1 << 32), (1 << 32) + 7, n - 6]))
+    keep, last = [], -10
+    for o in offs:                 # planted occurrences must not overlap
+        if o >= last + 6 and o + 6 <= n:
+            keep.append(o)
+            last = o
+    W.plant(t, keep, b"regexp")
+    sc = rj.Scan(rj.Program(b"regexp"))
+    cnt = sc.run_tensor(t)
+    spans = sc.spans()
+    found = [b for b, _ in spans]
+    assert all(e - b == 6 for b, e in spans) and found == sorted(found) and cnt == len(spans)
+    assert set(keep) <= set(found)
+    assert sum(1 for b in found if b >= (1 << 32)) >= 5 and max(found) == n - 6
+    # independent check of the natural occurrences: a sliding compare over a 256 MiB window across 2^32
+    lo, hi = (1 << 32) - (128 << 20), (1 << 32) + (128 << 20)
+    w = t[lo:hi]
+    pat = torch.tensor(list(b"regexp"), dtype=torch.uint8, device=dev)
+    m = torch.ones(w.numel() - 5, dtype=torch.bool, device=dev)
+    for k in range(6):
+        m &= w[k:w.numel() - 5 + k] == pat[k]
+    want = (torch.nonzero(m).flatten() + lo).tolist()
+    assert [b for b in found if lo <= b < hi - 5] == want

@@ -52,6 +52,33 @@ def _worker(rank, world, port, text, q):
         ranges = sharding.partition(len(text), world, align=align)
         total, gathered, local = sharding.sharded_match_all(_local_scan_factory(ends), ranges, rank, world, dist)
         results[rx] = (total, gathered)
+        # the tensor form (what bench.py's multi-GPU workloads use): same protocol, no tuple lists
+        import torch
+        scan_l = _local_scan_factory(ends)
+        tscan = lambda lo, hi, cur, pe, have: torch.tensor(scan_l(lo, hi, cur, pe, have), dtype=torch.int64).reshape(-1, 2)
+        t_total, t_gathered, _ = sharding.sharded_match_all_tensor(tscan, ranges, rank, world, dist, torch.device("cpu"))
+        assert t_total == total
+        if rank == 0:
+            assert [tuple(x) for x in t_gathered.tolist()] == gathered
+    # several patterns' COUNTS with the selection carried over the cuts (bench.py's regexdna step)
+    pats = [rx for rx, _ in CASES]
+    all_ends = [oracle.longest_all(rx, text) for rx in pats]
+    ranges = sharding.partition(len(text), world, align=1)
+    own = ranges[rank]
+
+    def bounds_of(sp):
+        return (sp[0][0], sp[0][1], sp[-1][0], sp[-1][1]) if sp else None
+
+    def run_local():
+        sps = [_local_scan_factory(e)(own[0], own[1], 0, 0, False) for e in all_ends]
+        return [len(sp) for sp in sps], [bounds_of(sp) for sp in sps]
+
+    def rerun_one(i, cur, prev_end):
+        sp = _local_scan_factory(all_ends[i])(own[0], own[1], cur, prev_end, True)
+        return len(sp), bounds_of(sp)
+
+    import torch
+    results["multi_counts"] = sharding.multi_pattern_counts(run_local, rerun_one, len(pats), rank, world, dist, torch.device("cpu"))
     if rank == 0:
         q.put(results)
     dist.barrier()
@@ -77,6 +104,7 @@ def test_sharded_equals_single(world):
         want = oracle.match_all_spec(rx, text)
         total, gathered = results[rx]
         assert total == len(want) and gathered == want, rx
+    assert results["multi_counts"] == [len(oracle.match_all_spec(rx, text)) for rx, _ in CASES]
 
 
 def test_partition_and_visible_range():
