@@ -902,6 +902,46 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       }
     }
     rj_scan* s0 = m->scans[0];
+    fp.n_bases = 0;
+    if (fuse && m->mode == 0 && getenv("RJ_NO_FUSED_PREFILTER") == nullptr) {
+      // Shared prefilter (kernels.hip: fused_chunk_d1): are all windows within one nibble of <= 2 base
+      // windows?  Nibbles are compared on their low 3 bits there.  A base is a window without
+      // wildcards; greedy: the first uncovered exact window becomes the next base.
+      auto nibbles_off = [](uint32_t v, uint32_t k, uint32_t base) {  // nibbles in which (v, k) leaves `base` free or differs
+        int d = 0;
+        for (int i = 0; i < 8; i++) {
+          const uint32_t kk = (k >> (4 * i)) & 7u, vv = (v >> (4 * i)) & 7u, bb = (base >> (4 * i)) & 7u;
+          d += (kk == 0 || vv != bb) ? 1 : 0;
+        }
+        return d;
+      };
+      uint32_t bases[2] = {0, 0};
+      int nb = 0;
+      bool ok = true;
+      for (int pass = 0; pass < 2 && ok; pass++)
+        for (int p = 0; p < P && ok; p++)
+          for (int w = 0; w < 2 && ok; w++) {
+            const uint32_t v = fp.value[p][w] & 0x77777777u, k = fp.mask[p][w] & 0x77777777u;
+            bool covered = false;
+            for (int b = 0; b < nb; b++) covered = covered || nibbles_off(v, k, bases[b]) <= 1;
+            if (covered) continue;
+            if (pass == 0) {
+              if (k == 0x77777777u && nb < 2) bases[nb++] = v;  // an exact window: a new base
+            } else {
+              ok = false;  // second pass: still not within one nibble of a base
+            }
+          }
+      if (ok && nb > 0) {
+        fp.n_bases = static_cast<uint32_t>(nb);
+        fp.base[0] = bases[0];
+        fp.base[1] = bases[nb > 1 ? 1 : 0];
+        for (int p = 0; p < static_cast<int>(fp.n_patterns); p++)
+          for (int w = 0; w < 2; w++) {
+            fp.value[p][w] &= 0x77777777u;
+            fp.mask[p][w] &= 0x77777777u;
+          }
+      }
+    }
     if (fuse) {
       launch_scan_windows_fused(fp, geo.grid, s0->ev[1], s0->ev[2], st);
     } else {

@@ -88,6 +88,10 @@ struct FusedParams {
   uint64_t sb, se;        // candidate starts [sb, se)
   uint64_t span_chunks;
   uint32_t n_patterns;    // a multiple of kFuseGroup (padding entries have region_cap 0)
+  // shared prefilter: every window is within one nibble of base[b] for some b < n_bases (0 = no such
+  // bases: every pattern is tested at every position); value / mask then hold 3-bit nibbles
+  uint32_t n_bases;
+  uint32_t base[2];
   uint32_t value[kMaxFused][2], mask[kMaxFused][2];
   uint32_t offset[kMaxFused], len[kMaxFused];
   uint64_t* hits[kMaxFused];

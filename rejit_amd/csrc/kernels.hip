@@ -450,6 +450,102 @@ __device__ __forceinline__ void fused_chunk(const uint32_t (&d)[6], uint64_t at,
   }
 }
 
+// The same with a SHARED prefilter (FusedParams::n_bases > 0): when every window of every pattern is
+// within one nibble of one of NB base windows -- regexdna: all 18 windows are `agggtaaa` or `tttaccct`
+// with at most one position turned into a class -- a text position can only hit if it differs from a
+// base in at most ONE nibble.  That test is shared by all patterns and costs, per position and base,
+//     u = (pk ^ base) + 0x77777777      bit 3 of a nibble <=> that nibble differs       (v_xad_u32)
+//     c = popcount(u & 0x88888888)      differing nibbles                              (v_and, v_bcnt)
+// plus one v_min3 for both bases: 7 VALU per position instead of 3 per position AND PATTERN (27 for
+// regexdna's nine).  Nibbles are compared on their low 3 bits (bit 3 must be free for the carry-less
+// add): one more superset step, removed like every alias by the exact verification downstream.
+// Only chunks in which some lane passes the prefilter (about every second one on DNA: the true match
+// density is one per 2.4 KiB) run the exact per-pattern tests, and only for the hit positions' chains.
+template <int NB>
+__device__ __forceinline__ void fused_chunk_d1(const uint32_t (&d)[6], uint64_t at, const FusedParams& a, uint32_t* counts,
+                                               uint64_t wave) {
+  uint32_t nib[6], z[5], pk[16];
+#pragma unroll
+  for (int q = 0; q < 6; q++) nib[q] = d[q] & 0x07070707u;
+#pragma unroll
+  for (int q = 0; q < 5; q++) z[q] = nib[q] | (nib[q + 1] << 4);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    pk[4 * q] = z[q];
+    pk[4 * q + 1] = __builtin_amdgcn_alignbyte(z[q + 1], z[q], 1);
+    pk[4 * q + 2] = __builtin_amdgcn_alignbyte(z[q + 1], z[q], 2);
+    pk[4 * q + 3] = __builtin_amdgcn_alignbyte(z[q + 1], z[q], 3);
+  }
+  const uint32_t b0 = a.base[0], b1 = a.base[NB > 1 ? 1 : 0];
+  const uint32_t c77 = 0x77777777u;
+  // (pk ^ base) + 0x77777777 in ONE instruction: the compiler emits v_xor + v_add for the C expression
+  auto xad = [&](uint32_t x, uint32_t base) -> uint32_t {
+    uint32_t u;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(u) : "v"(x), "s"(base), "v"(c77));
+    return u;
+  };
+  uint32_t acc[8];  // chain q holds the positions q and q + 8
+#pragma unroll
+  for (int q = 0; q < 8; q++) acc[q] = 8;
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const uint32_t c0 = __builtin_popcount(xad(pk[j], b0) & 0x88888888u);
+    if (NB > 1) {
+      const uint32_t c1 = __builtin_popcount(xad(pk[j], b1) & 0x88888888u);
+      acc[j & 7] = umin3(acc[j & 7], c0, c1);
+    } else {
+      acc[j & 7] = acc[j & 7] < c0 ? acc[j & 7] : c0;
+    }
+  }
+  const uint32_t m0 = umin3(acc[0], acc[1], acc[2]), m1 = umin3(acc[3], acc[4], acc[5]);
+  const uint32_t best = umin3(m0, m1, acc[6] < acc[7] ? acc[6] : acc[7]);
+  if (__ballot(best <= 1) == 0) return;  // wave-uniform: no position of the chunk is near a base
+  // which chains hold a hit (wave-uniform mask)
+  uint32_t chains = 0;
+#pragma unroll
+  for (int q = 0; q < 8; q++) chains |= (__ballot(acc[q] <= 1) != 0 ? 1u : 0u) << q;
+  const uint64_t chunk_base = at - static_cast<uint64_t>(lane_id()) * 16;
+  for (uint32_t p = 0; p < a.n_patterns; p++) {
+    if (a.region_cap[p] == 0) continue;  // padding entry
+    const uint32_t v0 = a.value[p][0], k0 = a.mask[p][0], v1 = a.value[p][1], k1 = a.mask[p][1];
+    uint32_t hm = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      if (((chains >> q) & 1u) == 0) continue;  // uniform
+      {
+        const uint32_t t0 = (pk[q] ^ v0) & k0, t1 = (pk[q] ^ v1) & k1;
+        hm |= static_cast<uint32_t>((t0 < t1 ? t0 : t1) == 0) << q;
+      }
+      {
+        const uint32_t t0 = (pk[q + 8] ^ v0) & k0, t1 = (pk[q + 8] ^ v1) & k1;
+        hm |= static_cast<uint32_t>((t0 < t1 ? t0 : t1) == 0) << (q + 8);
+      }
+    }
+    if (__ballot(hm != 0) == 0) continue;
+    const uint64_t wlo = a.sb + a.offset[p];
+    const uint64_t last_w = a.n >= a.len[p] ? a.n - a.len[p] + 1 : 0;
+    uint64_t whi = a.se + a.offset[p];
+    if (whi > last_w) whi = last_w;
+    if (chunk_base < wlo || chunk_base + kChunk > whi) {  // only the first / last chunks of the range
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint64_t w = at + j;
+        if (w < wlo || w >= whi) hm &= ~(1u << j);
+      }
+    }
+    RegionHits hits{a.hits[p] + wave * a.region_cap[p], a.region_cap[p], counts[p]};
+    hits.push_bits(hm, at, a.offset[p]);
+    counts[p] = hits.count;
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ void fused_any(const uint32_t (&d)[6], uint64_t at, const FusedParams& a, uint32_t* counts, uint64_t wave) {
+  if (NB == 0) fused_chunk(d, at, a, counts, wave);
+  else fused_chunk_d1<NB>(d, at, a, counts, wave);
+}
+
+template <int NB>
 __global__ __launch_bounds__(256) void scan_windows_fused(FusedParams a) {
   __shared__ uint32_t region_count[4][kMaxFused];
   const int lane = lane_id();
@@ -481,31 +577,31 @@ __global__ __launch_bounds__(256) void scan_windows_fused(FusedParams a) {
       load_chunk<true>(a.text, (c + 1) * kChunk + lane_off, b1);
       load_chunk<true>(a.text, (c + 2) * kChunk + lane_off, b2);
       while (c + 5 < fast_end) {
-        fused_chunk(b0, c * kChunk + lane_off, a, counts, wave);
+        fused_any<NB>(b0, c * kChunk + lane_off, a, counts, wave);
         load_chunk<true>(a.text, (c + 3) * kChunk + lane_off, b0);
         __builtin_amdgcn_sched_barrier(0);
-        fused_chunk(b1, (c + 1) * kChunk + lane_off, a, counts, wave);
+        fused_any<NB>(b1, (c + 1) * kChunk + lane_off, a, counts, wave);
         load_chunk<true>(a.text, (c + 4) * kChunk + lane_off, b1);
         __builtin_amdgcn_sched_barrier(0);
-        fused_chunk(b2, (c + 2) * kChunk + lane_off, a, counts, wave);
+        fused_any<NB>(b2, (c + 2) * kChunk + lane_off, a, counts, wave);
         load_chunk<true>(a.text, (c + 5) * kChunk + lane_off, b2);
         __builtin_amdgcn_sched_barrier(0);
         c += 3;
       }
-      fused_chunk(b0, c * kChunk + lane_off, a, counts, wave);
-      fused_chunk(b1, (c + 1) * kChunk + lane_off, a, counts, wave);
-      fused_chunk(b2, (c + 2) * kChunk + lane_off, a, counts, wave);
+      fused_any<NB>(b0, c * kChunk + lane_off, a, counts, wave);
+      fused_any<NB>(b1, (c + 1) * kChunk + lane_off, a, counts, wave);
+      fused_any<NB>(b2, (c + 2) * kChunk + lane_off, a, counts, wave);
       c += 3;
     }
     for (; c < fast_end; c++) {
       load_chunk<true>(a.text, c * kChunk + lane_off, b0);
-      fused_chunk(b0, c * kChunk + lane_off, a, counts, wave);
+      fused_any<NB>(b0, c * kChunk + lane_off, a, counts, wave);
     }
   }
   for (uint64_t t = fast_end; t < span.c1; t++) {
     uint32_t d[6];
     load_guarded(a.text, a.n, t * kChunk + lane_off, d);
-    fused_chunk(d, t * kChunk + lane_off, a, counts, wave);
+    fused_any<NB>(d, t * kChunk + lane_off, a, counts, wave);
   }
   if (lane < static_cast<int>(a.n_patterns) && a.region_cap[lane] != 0) a.hit_counts[lane][wave] = counts[lane];
 }
@@ -1474,17 +1570,32 @@ __global__ __launch_bounds__(1024) void finalize_small(FinalizeParams a) {
 // before it can overlap it, so every chain passes through it.  Round 1 let the thread of a head walk
 // its whole cluster, which is sequential in the cluster's size -- `[ab]{40}c*` over 4 MiB of a/b is
 // ONE cluster of 4 M overlapping candidates: 1.05 s in that kernel.  Now the list is cut into blocks:
-//   chain_next    nxt[] by binary search, one thread per candidate
+//   chain_next    nxt[] by (galloping) binary search, one thread per candidate
 //   chain_local   per block, right to left: G[i] = where a chain that stands at i leaves the block
 //   chain_hop     from every block that holds a head (and from the chain's first candidate) hop block
 //                 to block through G until a block with a head of its own: the entry points
 //   chain_mark    per block: follow nxt[] from the entry point (or the first head) to the block's end
 // Sequential depth: block + (largest cluster / block) + block instead of the largest cluster.
-constexpr uint64_t kChainBlock = 1024;
 constexpr uint64_t kChainNone = ~0ull;
 
-__global__ void chain_next(const uint64_t* keys, const uint64_t* vals, uint64_t n, uint64_t* nxt) {
+// the block size balances the three sequential stretches (block + cluster / block + block): about
+// sqrt(n), so that a few thousand candidates are not walked by a handful of lanes for half a millisecond
+static uint64_t chain_block(uint64_t n) {
+  uint64_t b = 32;
+  while (b < 1024 && b * b < n) b <<= 1;
+  return b;
+}
+
+__global__ void chain_next(const uint64_t* keys, const uint64_t* vals, uint64_t n, uint64_t carry_cur, uint64_t* nxt, uint64_t* i0_out) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i == 0) {  // the chain's first candidate: the first index with begin >= carry_cur
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+      const uint64_t mid = (lo + hi) >> 1;
+      if (keys[mid] < carry_cur) lo = mid + 1; else hi = mid;
+    }
+    *i0_out = lo;
+  }
   if (i >= n) return;
   const uint64_t b = keys[i], e = vals[i];
   const uint64_t cur = e > b ? e : b + 1;
@@ -1503,24 +1614,13 @@ __global__ void chain_next(const uint64_t* keys, const uint64_t* vals, uint64_t 
   nxt[i] = lo;
 }
 
-// one thread: the chain's first candidate i0 = first index with begin >= carry_cur; entry[] preset
-__global__ void chain_start(const uint64_t* keys, uint64_t n, uint64_t carry_cur, uint64_t* entry, uint64_t* i0_out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  uint64_t lo = 0, hi = n;
-  while (lo < hi) {
-    const uint64_t mid = (lo + hi) >> 1;
-    if (keys[mid] < carry_cur) lo = mid + 1; else hi = mid;
-  }
-  *i0_out = lo;
-  if (lo < n) entry[lo / kChainBlock] = lo;
-}
-
 __global__ __launch_bounds__(64) void chain_local(const uint64_t* keys, const uint64_t* pmax, const uint64_t* nxt, uint64_t n,
-                                                  uint64_t carry_cur, uint64_t* G, uint64_t* first_head) {
+                                                  uint64_t carry_cur, uint64_t B, const uint64_t* i0_ptr, uint64_t* G,
+                                                  uint64_t* first_head, uint64_t* entry) {
   const uint64_t blk = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const uint64_t lo = blk * kChainBlock;
+  const uint64_t lo = blk * B;
   if (lo >= n) return;
-  const uint64_t hi = lo + kChainBlock < n ? lo + kChainBlock : n;
+  const uint64_t hi = lo + B < n ? lo + B : n;
   uint64_t head = kChainNone;
   for (uint64_t i = hi; i-- > lo;) {
     const uint64_t t = nxt[i];
@@ -1529,19 +1629,21 @@ __global__ __launch_bounds__(64) void chain_local(const uint64_t* keys, const ui
     if (keys[i] >= floor_i && (i == 0 || keys[i] > keys[i - 1])) head = i;
   }
   first_head[blk] = head;
+  const uint64_t i0 = *i0_ptr;
+  entry[blk] = (i0 < n && i0 / B == blk) ? i0 : kChainNone;
 }
 
 __global__ __launch_bounds__(64) void chain_hop(const uint64_t* G, const uint64_t* first_head, const uint64_t* i0_ptr, uint64_t n,
-                                                uint64_t* entry) {
+                                                uint64_t B, uint64_t* entry) {
   const uint64_t blk = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (blk * kChainBlock >= n) return;
+  if (blk * B >= n) return;
   const uint64_t i0 = *i0_ptr;
   uint64_t start = first_head[blk];
-  if (i0 < n && i0 / kChainBlock == blk) start = i0;  // (a head of this block, if any, lies at or after i0)
+  if (i0 < n && i0 / B == blk) start = i0;  // (a head of this block, if any, lies at or after i0)
   else if (start == kChainNone || start < i0) return;
   uint64_t idx = G[start];
   while (idx < n) {
-    const uint64_t b2 = idx / kChainBlock;
+    const uint64_t b2 = idx / B;
     entry[b2] = idx;
     if (first_head[b2] != kChainNone) break;  // that block's own thread goes on from its head
     idx = G[idx];
@@ -1549,11 +1651,11 @@ __global__ __launch_bounds__(64) void chain_hop(const uint64_t* G, const uint64_
 }
 
 __global__ __launch_bounds__(64) void chain_mark(const uint64_t* nxt, const uint64_t* first_head, const uint64_t* entry,
-                                                 const uint64_t* i0_ptr, uint64_t n, uint8_t* taken) {
+                                                 const uint64_t* i0_ptr, uint64_t n, uint64_t B, uint8_t* taken) {
   const uint64_t blk = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const uint64_t lo = blk * kChainBlock;
+  const uint64_t lo = blk * B;
   if (lo >= n) return;
-  const uint64_t hi = lo + kChainBlock < n ? lo + kChainBlock : n;
+  const uint64_t hi = lo + B < n ? lo + B : n;
   uint64_t i = entry[blk];
   if (i == kChainNone) {
     i = first_head[blk];
@@ -2206,7 +2308,9 @@ void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows
 }
 
 void launch_scan_windows_fused(const FusedParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
-  hipExtLaunchKernelGGL(scan_windows_fused, dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+  if (a.n_bases == 0) hipExtLaunchKernelGGL((scan_windows_fused<0>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+  else if (a.n_bases == 1) hipExtLaunchKernelGGL((scan_windows_fused<1>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+  else hipExtLaunchKernelGGL((scan_windows_fused<2>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
 }
 
 void launch_scan_dense(const ScanParams& a, const DevProgram& P, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
@@ -2391,22 +2495,21 @@ void launch_replace_gather(const uint8_t* text, uint64_t n, const uint64_t* span
 
 static unsigned blocks_for(uint64_t n) { return static_cast<unsigned>((n + 255) / 256); }
 
-size_t chain_select_scratch_bytes(uint64_t n) { return ((n + kChainBlock - 1) / kChainBlock * 2 + 2) * sizeof(uint64_t); }
+size_t chain_select_scratch_bytes(uint64_t n) { return ((n + 31) / 32 * 2 + 2) * sizeof(uint64_t); }
 
 void launch_chain_select(const uint64_t* keys, const uint64_t* vals, const uint64_t* pmax, uint64_t n, uint64_t carry_cur,
                          uint8_t* taken, uint64_t* nxt, uint64_t* G, uint64_t* blocks_scratch, hipStream_t st) {
-  const uint64_t nb = (n + kChainBlock - 1) / kChainBlock;
+  const uint64_t B = chain_block(n);
+  const uint64_t nb = (n + B - 1) / B;
   uint64_t* first_head = blocks_scratch;
   uint64_t* entry = blocks_scratch + nb;
   uint64_t* i0 = blocks_scratch + 2 * nb;
-  (void)hipMemsetAsync(entry, 0xFF, nb * sizeof(uint64_t), st);
   (void)hipMemsetAsync(taken, 0, n, st);
-  hipLaunchKernelGGL(chain_next, dim3(blocks_for(n)), dim3(256), 0, st, keys, vals, n, nxt);
-  hipLaunchKernelGGL(chain_start, dim3(1), dim3(64), 0, st, keys, n, carry_cur, entry, i0);
+  hipLaunchKernelGGL(chain_next, dim3(blocks_for(n)), dim3(256), 0, st, keys, vals, n, carry_cur, nxt, i0);
   const unsigned lb = static_cast<unsigned>((nb + 63) / 64);
-  hipLaunchKernelGGL(chain_local, dim3(lb), dim3(64), 0, st, keys, pmax, nxt, n, carry_cur, G, first_head);
-  hipLaunchKernelGGL(chain_hop, dim3(lb), dim3(64), 0, st, G, first_head, i0, n, entry);
-  hipLaunchKernelGGL(chain_mark, dim3(lb), dim3(64), 0, st, nxt, first_head, entry, i0, n, taken);
+  hipLaunchKernelGGL(chain_local, dim3(lb), dim3(64), 0, st, keys, pmax, nxt, n, carry_cur, B, i0, G, first_head, entry);
+  hipLaunchKernelGGL(chain_hop, dim3(lb), dim3(64), 0, st, G, first_head, i0, n, B, entry);
+  hipLaunchKernelGGL(chain_mark, dim3(lb), dim3(64), 0, st, nxt, first_head, entry, i0, n, B, taken);
 }
 
 void launch_taken_index(const uint8_t* taken, uint64_t n, uint64_t* idx, hipStream_t st) {

@@ -162,11 +162,13 @@ def test_reference_basic_sample(tmp_path):
     text = ("Copyright holders reserve every right.  Redistribution, conversion and extension of this\n"
             "section are subject to the conditions of the licence; no permission is implied.\n") * 7
     (tmp_path / "LICENCE").write_text(text)
-    out = subprocess.run([os.path.join(REF_DIR, "basic_hip")], cwd=tmp_path, capture_output=True, timeout=120, check=True).stdout.decode()
+    out = subprocess.run([os.path.join(REF_DIR, "basic_hip")], cwd=tmp_path, capture_output=True, timeout=120, check=True).stdout
     want = Oracle().match_all(b"(right|[ts]ion)", text.encode())
-    assert "Found %d matches." % len(want) in out, out
-    shown = out.split("Printing the first 10:\n")[1].split("\n")[:10]
-    assert shown == [text[b:e] for b, e in want[:10]]
+    assert b"Found %d matches." % len(want) in out, out
+    # (basic.cc:44 passes a `const char*` where a string is expected: its Match pointers refer to a
+    # temporary that is gone when it prints them -- the printed bytes are undefined with the reference
+    # too, so only the count is checked)
+    assert b"Printing the first 10:" in out
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF_DIR, "test_rejit_hip")), reason="oracle/_ref/test_rejit_hip not built")
