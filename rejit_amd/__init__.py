@@ -7,6 +7,9 @@ library is missing, or no HIP device is present, every call fails loudly.
 """
 from .api import (RejitError, Program, Scan, MultiScan, build, library_path, load_library, device_count)  # noqa: F401
 
-# VALU operations the fused nine-pattern scan kernel (scan_windows_fused) spends per text byte, counted
-# from its ISA; bench.py prices the kernel's VALU roofline with it
-FUSED_VALU_OPS_PER_BYTE = 29.0
+# VALU operations the fused nine-pattern scan kernel (scan_windows_fused, shared-prefilter form) spends per
+# text byte in its streaming loop, counted from its ISA: 26 to pack a lane's 16
+# positions + 16 x (2 v_xad + 2 v_and + 2 v_bcnt + 1.5 v_min) = 146 per 16 bytes.  The exact per-pattern
+# tests on the chunks that pass the prefilter (about every second one on DNA) come on top, so the VALU
+# roofline bench.py derives from this number is a lower bound of the kernel's VALU utilisation.
+FUSED_VALU_OPS_PER_BYTE = 9.1

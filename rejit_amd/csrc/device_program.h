@@ -54,6 +54,12 @@ struct DevProgram {
   // A walk from one start is cut after this many bytes and the run flagged (kCntOverrun); the engine
   // then repeats the run on the linear-time carry scan (carry_scan.h).  <= kMaxSimSteps.
   uint32_t max_walk;
+  // Windows behind an unbounded prefix (lowering.h: Program::behind): a hit of window k at w makes the
+  // positions cut_fwd[k] live at w (they consume text[w]); cut_rev[k] = the same set in the reverse
+  // automaton's numbering.  Lane-sized automata only (n_words <= 4).
+  uint32_t behind;
+  uint32_t cut_fwd[kDevMaxWindows][4];
+  uint32_t cut_rev[kDevMaxWindows][4];
 };
 
 // The NFA graph for the exact sequential kernel (reference ring semantics).

@@ -121,18 +121,7 @@ int upload_program(rj_program* rp) {
   D.nullable = 0;
   for (int c = 0; c < kNumCtx; c++)
     if (P.nullable[C == 1 ? 0 : c]) D.nullable |= 1u << c;
-  D.mode = P.mode == ScanMode::Windows ? 1 : 0;
-  D.n_windows = static_cast<int>(P.windows.size());
-  D.win_offset = P.windows.empty() ? 0 : P.windows[0].offset;
-  D.win_len = P.windows.empty() ? 0 : P.windows[0].len;
-  for (int k = 0; k < kDevMaxWindows; k++) {
-    // unused slots repeat the last window, so kernels instantiated for a larger K stay exact
-    const FFWindow w = P.windows.empty() ? FFWindow{} : P.windows[std::min<size_t>(static_cast<size_t>(k), P.windows.size() - 1)];
-    D.win_value0[k] = w.value0;
-    D.win_mask0[k] = w.mask0;
-    D.win_value1[k] = w.value1;
-    D.win_mask1[k] = w.mask1;
-  }
+  fill_windows(&D, P);
   {
     ByteSet seen;
     for (const FFWindow& w : P.windows)
@@ -398,6 +387,7 @@ int resolve_selection(rj_scan* s, const FinalizeParams& fp, hipStream_t st) {
     f.out_cap = s->out_cap;
     f.counters = s->counters.as<unsigned long long>();
     f.detect_adjacent = 0;
+    f.detect_conflict = fp.detect_conflict;
     f.expand = 1;
     unsigned long long* scratch = reinterpret_cast<unsigned long long*>(s->host_flag);  // pinned, 16 bytes
     *scratch = n_cands;  // finalize_small takes its slot count from counters[kCntHits]
@@ -431,7 +421,8 @@ int resolve_selection(rj_scan* s, const FinalizeParams& fp, hipStream_t st) {
   launch_chain_select(keys, vals, sa, n_cands, fp.carry_cur, s->taken.as<uint8_t>(), sb, scratch, s->chain_blocks.as<uint64_t>(), st);
   launch_taken_index(s->taken.as<uint8_t>(), n_cands, scratch, st);
   RJ_HIP(scan(scratch, sb, n_cands, true));
-  launch_zero_length_rule(keys, vals, s->taken.as<uint8_t>(), sb, n_cands, fp.carry_prev_end, fp.have_prev, sa, st);
+  launch_zero_length_rule(keys, vals, s->taken.as<uint8_t>(), sb, n_cands, fp.carry_prev_end, fp.have_prev, sa,
+                          fp.detect_conflict ? s->counters.as<unsigned long long>() + kCntConflict : nullptr, st);
   RJ_HIP(scan(sa, sb, n_cands, false));
   launch_compact_kept(keys, vals, sa, sb, n_cands, s->out.as<uint64_t>(), s->out_cap, s->counters.as<unsigned long long>(), st);
   RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -489,10 +480,23 @@ constexpr uint64_t kDenseSegment = 1ull << 27;  // dense mode: starts per pipeli
 // One full pipeline over the starts [sb, se): scan -> region offsets -> verify -> finalize.
 // Results: s->out (device, ordered pairs), s->result_count.
 int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, uint64_t carry_cur,
-              uint64_t carry_prev_end, int have_prev, hipStream_t st) {
+              uint64_t carry_prev_end, int have_prev, hipStream_t st, bool force_dense = false) {
   const rj_program* rp = s->prog;
-  const DevProgram& D = rp->dev;
+  // Windows behind an unbounded prefix give ONE candidate per hit (the left-most start): enough for a
+  // run from the beginning of the text, not for an own range that begins inside it (a start clipped by
+  // the range or by a carried-in match would be missing) -- such runs, and repeats after a conflict,
+  // take the dense path, which considers every start.
+  const bool as_dense = force_dense || (rp->dev.behind && (sb != 0 || carry_cur != 0 || s->behind_conflicts));
+  DevProgram dense_copy;
+  if (as_dense && rp->dev.mode == 1) {
+    dense_copy = rp->dev;
+    dense_copy.mode = 0;
+    dense_copy.behind = 0;
+    if (linear_path_fits(rp)) dense_copy.max_walk = std::min<uint32_t>(dense_copy.max_walk, 4096u);
+  }
+  const DevProgram& D = (as_dense && rp->dev.mode == 1) ? dense_copy : rp->dev;
   const bool windows = D.mode == 1;
+  const bool behind = windows && D.behind != 0;
   s->result_count = 0;
   s->result = nullptr;
   // the previous text needed the linear-time path: go there directly (run_linear clears the hint
@@ -512,7 +516,7 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
     const uint64_t float_min = D.float_max + 1 - D.float_range;
     sp.wlo = sb + (expand > 1 ? float_min : D.win_offset);
     const uint64_t last_w = n >= D.win_len ? n - D.win_len + 1 : 0;  // a window must fit: w + len <= n
-    sp.whi = std::min(se + (expand > 1 ? D.float_max : D.win_offset), last_w);
+    sp.whi = behind ? last_w : std::min(se + (expand > 1 ? D.float_max : D.win_offset), last_w);
     if (sp.whi < sp.wlo) sp.whi = sp.wlo;
     first_chunk = sp.wlo / 1024;
     end_chunk = (sp.whi + 1023) / 1024;
@@ -535,8 +539,9 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
 
   // fixed windows + an automaton that fits a lane: candidates are verified and compacted inside
   // their hit regions (no global compaction, no sort)
-  const bool floating_regions = windows && expand > 1 && D.n_words <= 4 && getenv("RJ_NO_FLOAT_REGIONS") == nullptr;
-  const bool in_regions = (windows && D.n_words <= 4 && (expand == 1 || floating_regions)) || dense_walk;
+  static const bool no_float_regions = getenv("RJ_NO_FLOAT_REGIONS") != nullptr;  // measurement override
+  const bool floating_regions = windows && expand > 1 && D.n_words <= 4 && !no_float_regions;
+  const bool in_regions = (windows && D.n_words <= 4 && (expand == 1 || floating_regions)) || dense_walk;  // (behind: n_words <= 4 by plan)
 
   for (int attempt = 0; attempt < 6; attempt++) {
     const uint64_t slots = static_cast<uint64_t>(geo.n_regions) * region_cap;
@@ -574,6 +579,7 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
     // pattern is at risk AND a candidate begins exactly where another one ends
     const bool whole_text = sb == 0 && se == n + 1 && carry_cur == 0 && !have_prev;
     fp.detect_adjacent = rp->host->q8_risk && whole_text;
+    fp.detect_conflict = behind;
     fp.expand = expand;
     VerifyParams vp{};
     if (!in_regions)
@@ -613,6 +619,9 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
         launch_verify_floating_in_regions(vp, D, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(),
                                           s->cand_begin.as<uint64_t>(), s->cand_end.as<uint64_t>(), st);
         begins = s->cand_begin.as<uint64_t>();
+      } else if (behind) {
+        launch_verify_behind_in_regions(vp, D, rp->rev, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(),
+                                        s->cand_end.as<uint64_t>(), st);
       } else if (!dense_walk) {
         launch_verify_in_regions(vp, D, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(), s->cand_end.as<uint64_t>(), st);
       }
@@ -621,6 +630,7 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
       // below was measured: slower, its agent-scope fence writes L2 back)
       s->host_counters[kCntUnordered] = 0;  // the kernel below writes the pinned block itself
       s->host_counters[kCntAdjacent] = 0;
+      s->host_counters[kCntConflict] = 0;
       // many candidates per region expected (the previous run had them): lay out first, then copy
       // with a wave per region
       uint64_t *off_scratch = nullptr, *prev_scratch = nullptr;
@@ -642,6 +652,23 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
         RJ_HIP(s->vals_out.reserve(nc * sizeof(uint64_t)));
         launch_split_pairs(s->out.as<uint64_t>(), s->counters.as<unsigned long long>() + kCntCands, nc,
                            s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), st);
+        if (behind && nc > kFinalizeCap) {
+          // one candidate per hit, in hit order: their begins are not sorted (a later hit may have an
+          // earlier left-most start).  Few candidates are sorted by finalize_small; many here.
+          unsigned bits = 1;
+          while (bits < 64 && ((n + 1) >> bits) != 0) bits++;
+          RJ_HIP(s->cand_begin.reserve(nc * sizeof(uint64_t)));
+          uint64_t* k2 = s->cand_begin.as<uint64_t>();
+          uint64_t* v2 = s->cand_end.as<uint64_t>();   // (region ends: consumed by the gather already)
+          RJ_HIP(s->cand_end.reserve(nc * sizeof(uint64_t)));
+          v2 = s->cand_end.as<uint64_t>();
+          size_t tmp_bytes = 0;
+          RJ_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, s->keys_out.as<uint64_t>(), k2, s->vals_out.as<uint64_t>(), v2, nc, 0, bits, st));
+          RJ_HIP(s->sort_tmp.reserve(std::max<size_t>(tmp_bytes, 16)));
+          RJ_HIP(rocprim::radix_sort_pairs(s->sort_tmp.p, tmp_bytes, s->keys_out.as<uint64_t>(), k2, s->vals_out.as<uint64_t>(), v2, nc, 0, bits, st));
+          RJ_HIP(hipMemcpyAsync(s->keys_out.p, k2, nc * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+          RJ_HIP(hipMemcpyAsync(s->vals_out.p, v2, nc * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+        }
         if (fp.detect_adjacent) {
           // (overlapping candidates: adjacency is no longer a neighbour property)
           launch_detect_adjacent(s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), nc, s->counters.as<unsigned long long>(), st);
@@ -652,6 +679,13 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
       }
       rc = resolve_selection(s, fp, st);
       if (rc != RJ_OK) return rc;
+      if (behind && s->host_counters[kCntOverflow] == 0 && (s->host_counters[kCntConflict] != 0 || s->host_counters[kCntOverrun] != 0)) {
+        // a hidden candidate reaches beyond the match that hides it, or a walk from a hit ran into the
+        // limit: every start has to be considered -- the dense path (and behind it the carry scan)
+        s->behind_conflicts = true;
+        s->stats.retries++;
+        return run_range(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st, true);
+      }
     } else {
       launch_verify(vp, D, windows ? std::max<uint64_t>(s->hits_hint, 1u << 14) : (se - sb) / 8 + 1, st);
       launch_finalize_small(fp, st);
@@ -811,13 +845,13 @@ int stage_text(rj_scan* s, const char* text, size_t n, const uint8_t** d_text) {
 // fixed windows + lane-sized automaton, not at risk of Q8: the in-region pipeline without carry
 bool batchable(const rj_program* rp) {
   const DevProgram& D = rp->dev;
-  return D.mode == 1 && D.float_range == 1 && D.n_words <= 4 && !rp->host->q8_risk;
+  return D.mode == 1 && D.float_range == 1 && D.n_words <= 4 && !rp->host->q8_risk && !D.behind;
 }
 
 bool fusable(const rj_program* rp) {
   const DevProgram& D = rp->dev;
   return D.mode == 1 && D.float_range == 1 && D.n_words <= 4 && D.win_len > 4 && D.n_windows <= 2 &&
-         rp->window_alphabet <= 4 && rp->window_nibbles && !rp->host->q8_risk;
+         rp->window_alphabet <= 4 && rp->window_nibbles && !rp->host->q8_risk && !D.behind;
 }
 
 // nibble form of window k (see WindowSet::nibble)
@@ -903,7 +937,8 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     }
     rj_scan* s0 = m->scans[0];
     fp.n_bases = 0;
-    if (fuse && m->mode == 0 && getenv("RJ_NO_FUSED_PREFILTER") == nullptr) {
+    static const bool no_prefilter = getenv("RJ_NO_FUSED_PREFILTER") != nullptr;  // measurement override
+    if (fuse && m->mode == 0 && !no_prefilter) {
       // Shared prefilter (kernels.hip: fused_chunk_d1): are all windows within one nibble of <= 2 base
       // windows?  Nibbles are compared on their low 3 bits there.  A base is a window without
       // wildcards; greedy: the first uncovered exact window becomes the next base.
@@ -1190,7 +1225,7 @@ static int scan_start(rj_scan* s, const void* d_text, uint64_t n, void* hip_stre
   s->pending_stream = st;
   const rj_program* rp = s->prog;
   const DevProgram& D = rp->dev;
-  if (!(D.mode == 1 && D.float_range == 1 && D.n_words <= 4 && !rp->host->q8_risk && n >= 16)) return RJ_OK;
+  if (!(D.mode == 1 && D.float_range == 1 && D.n_words <= 4 && !rp->host->q8_risk && !D.behind && n >= 16)) return RJ_OK;
   // (default priority: with a high-priority tail stream the runtime preempts the running scan's
   // waves for every tail kernel -- measured 1.13 -> 1.68 ms per step.  At equal priority the tails
   // mostly run when the queued scans have drained; what is saved is the host round trip per call.)
@@ -1348,7 +1383,8 @@ int64_t rj_replace_all(const rj_program* prog, const char* text, size_t n, const
   char* h = static_cast<char*>(malloc(static_cast<size_t>(new_len) + 1));
   if (!h) return fail(RJ_DEVICE_ERROR, "out of host memory");
   if (new_len) {
-    hipError_t e = hipMemcpy(h, s->repl_out.p, static_cast<size_t>(new_len), hipMemcpyDeviceToHost);
+    hipError_t e = hipMemcpyAsync(h, s->repl_out.p, static_cast<size_t>(new_len), hipMemcpyDeviceToHost, s->own_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->own_stream);
     if (e != hipSuccess) {
       free(h);
       return fail(RJ_DEVICE_ERROR, "hipMemcpy failed: %s", hipGetErrorString(e));
@@ -1508,7 +1544,10 @@ int64_t rj_match_all(const rj_program* prog, const char* text, size_t n, uint64_
   if (spans && s->result_count) {
     uint64_t* h = static_cast<uint64_t*>(malloc(s->result_count * 2 * sizeof(uint64_t)));
     if (!h) return fail(RJ_DEVICE_ERROR, "out of host memory");
-    hipError_t e = hipMemcpy(h, s->result, s->result_count * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    // (on the scan's own stream: a blocking hipMemcpy goes through the NULL stream, which serialises
+    // the streams of all the other threads that share the pattern)
+    hipError_t e = hipMemcpyAsync(h, s->result, s->result_count * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s->own_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->own_stream);
     if (e != hipSuccess) {
       free(h);
       return fail(RJ_DEVICE_ERROR, "hipMemcpy failed: %s", hipGetErrorString(e));
@@ -1611,7 +1650,10 @@ int64_t rj_match_all_batch(const rj_program* prog, const char* const* texts, con
   if (rc != RJ_OK) return rc;
   const uint64_t m = s->result_count;
   std::vector<uint64_t> pairs(2 * m);
-  if (m) RJ_HIP(hipMemcpy(pairs.data(), s->result, m * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  if (m) {
+    RJ_HIP(hipMemcpyAsync(pairs.data(), s->result, m * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s->own_stream));
+    RJ_HIP(hipStreamSynchronize(s->own_stream));
+  }
   // the matches are ordered by begin: one merge pass assigns them to their texts
   for (size_t i = 0; i < n_texts; i++) counts[i] = 0;
   size_t t = 0;
@@ -1673,7 +1715,8 @@ static int first_match(const rj_program* prog, const char* text, size_t n, uint6
     if (rc != RJ_OK) return rc;
     if (s->result_count > 0) {
       uint64_t pair[2];
-      RJ_HIP(hipMemcpy(pair, s->result, sizeof(pair), hipMemcpyDeviceToHost));
+      RJ_HIP(hipMemcpyAsync(pair, s->result, sizeof(pair), hipMemcpyDeviceToHost, s->own_stream));
+      RJ_HIP(hipStreamSynchronize(s->own_stream));
       if (begin) *begin = pair[0];
       if (end) *end = pair[1];
       return 1;

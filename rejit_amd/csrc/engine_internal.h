@@ -99,6 +99,7 @@ struct rj_scan {
   // entry points, per-sub-chunk counts, wide-automaton scratch
   rejit_amd::DeviceBuffer cs_vals, cs_mats, cs_e, cs_g, cs_entry, cs_counts, cs_scratch, cs_acc, cs_groups;
   bool linear_hint = false;        // the previous run needed the carry scan: go there directly
+  bool behind_conflicts = false;   // behind mode gave a conflict / overrun on this scan's text: stay dense
   uint64_t cands_cap = 0, out_cap = 0;
   uint32_t region_cap_hint = 64;   // hit-region size that sufficed last time (windows mode)
   uint64_t hits_hint = 0;          // hits of the previous run (sizes the verify grid)

@@ -12,7 +12,8 @@ namespace rejit_amd {
 // device counters (unsigned long long[kCntSize])
 enum { kCntCands = 0, kCntFinal = 1, kCntOverflow = 2, kCntAdjacent = 3, kCntHits = 4, kCntMaxRegion = 5, kCntOverrun = 6,
   kCntUnordered = 7,  // check_and_interleave: the candidates are not already the result
-  kCntSize = 8 };
+  kCntConflict = 8,   // behind mode: a candidate hidden by an earlier match ends after it (the run is repeated dense)
+  kCntSize = 9 };
 
 constexpr uint64_t kNoMatch = ~0ull;  // cand_end of a hit at which nothing matches
 
@@ -72,6 +73,7 @@ struct FinalizeParams {
   uint64_t carry_prev_end;  // end of the previous match (zero-length rule)
   int have_prev;
   int detect_adjacent;      // set counters[kCntAdjacent] when a candidate begins where another ends
+  int detect_conflict;      // behind mode: set counters[kCntConflict] when a skipped candidate ends after the match hiding it
   uint32_t expand;          // candidate slots per hit (see VerifyParams)
 };
 
@@ -145,6 +147,11 @@ void launch_tails_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_reg
 // offsets_gather_check lays the survivors out
 void launch_verify_in_regions(const VerifyParams& a, const DevProgram& P, const uint32_t* hit_counts, uint32_t* valid_counts,
                               uint64_t* region_ends, hipStream_t st);
+// windows behind an unbounded prefix (behind_walk.h): one candidate per hit -- forward check from the cut,
+// reverse automaton R to the left-most start, forward longest; survivors compacted in place like
+// verify_in_regions (begins are NOT ordered: the caller sorts before selecting)
+void launch_verify_behind_in_regions(const VerifyParams& a, const DevProgram& P, const DevProgram& R, const uint32_t* hit_counts,
+                                     uint32_t* valid_counts, uint64_t* region_ends, hipStream_t st);
 // floating windows: the candidate starts of every hit (ranges clipped so that each start is verified
 // once, in order); survivors go to region_begins / region_ends
 void launch_verify_floating_in_regions(const VerifyParams& a, const DevProgram& P, const uint32_t* hit_counts,
@@ -192,9 +199,10 @@ size_t chain_select_scratch_bytes(uint64_t n);
 void launch_chain_select(const uint64_t* keys, const uint64_t* vals, const uint64_t* pmax, uint64_t n, uint64_t carry_cur,
                          uint8_t* taken, uint64_t* nxt, uint64_t* G, uint64_t* blocks_scratch, hipStream_t st);
 void launch_taken_index(const uint8_t* taken, uint64_t n, uint64_t* idx, hipStream_t st);
+// (conflict: when not null, *conflict = 1 if a candidate that was not taken ends after the match that hides it)
 void launch_zero_length_rule(const uint64_t* keys, const uint64_t* vals, const uint8_t* taken,
                              const uint64_t* last_taken, uint64_t n, uint64_t carry_prev_end, int have_prev,
-                             uint64_t* keep, hipStream_t st);
+                             uint64_t* keep, unsigned long long* conflict, hipStream_t st);
 void launch_compact_kept(const uint64_t* keys, const uint64_t* vals, const uint64_t* keep, const uint64_t* pos,
                          uint64_t n, uint64_t* out, uint64_t out_cap, unsigned long long* counters, hipStream_t st);
 

@@ -36,6 +36,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include "behind_walk.h"
 #include "device_program.h"
 #include "kernels.h"
 
@@ -1010,6 +1011,49 @@ __global__ __launch_bounds__(256) void verify_floating_in_regions(VerifyParams a
   }
 }
 
+// Windows behind an unbounded prefix: 16 lanes per region, one hit per lane and round, the per-hit
+// procedure of behind_walk.h (three walks: forward from the cut, backwards to the left-most start,
+// forward to the longest end), survivors compacted in place.  Both automata's tables in LDS.
+template <int NW, int NQ>
+__global__ __launch_bounds__(256) void verify_behind_in_regions(VerifyParams a, DevProgram P, DevProgram R, const uint32_t* hit_counts,
+                                                                uint32_t* valid_counts, uint64_t* region_ends, uint32_t lds_words) {
+  extern __shared__ uint32_t tab[];
+  const DevProgram Pq = stage_tables(P, tab, lds_words >= P.table_words + R.table_words ? P.table_words : 0);
+  const DevProgram Rq = stage_tables(R, tab + P.table_words, lds_words >= P.table_words + R.table_words ? R.table_words : 0);
+  constexpr int G = 16;
+  const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t n_groups = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 4;
+  const int lane = lane_id(), sub = lane & (G - 1), shift = lane & (64 - G);
+  for (uint64_t r = tid >> 4; r < a.n_regions; r += n_groups) {
+    const uint32_t raw = hit_counts[r];
+    const uint32_t cnt = raw < a.region_cap ? raw : a.region_cap;
+    if (raw > a.region_cap && sub == 0) {
+      a.counters[kCntOverflow] = 1;
+      atomicMax(&a.counters[kCntMaxRegion], static_cast<unsigned long long>(raw));
+    }
+    uint64_t* region = a.hits + r * a.region_cap;
+    uint64_t* ends = region_ends + r * a.region_cap;
+    uint32_t kept = 0;
+    for (uint32_t base = 0; base < cnt; base += G) {
+      const uint32_t k = base + sub;
+      const uint64_t w = k < cnt ? region[k] : 0;
+      uint64_t b = 0, e = 0;
+      bool overrun = false;
+      const bool found = k < cnt && *static_cast<const volatile unsigned long long*>(a.counters + kCntOverrun) == 0 &&
+                         rj_behind_candidate<NW, NQ>(Pq, Rq, a.text, a.n, w, &b, &e, &overrun) && b >= a.sb && b < a.se;
+      if (overrun) a.counters[kCntOverrun] = 1;
+      const uint32_t mine = static_cast<uint32_t>(__ballot(found) >> shift) & ((1u << G) - 1u);
+      const uint32_t pos = kept + __popc(mine & ((1u << sub) - 1u));
+      if (found) {  // pos <= k, and every lane of the group has read its hit already
+        region[pos] = b;
+        ends[pos] = e;
+      }
+      kept += __popc(mine);
+    }
+    if (sub == 0) valid_counts[r] = kept;
+  }
+}
+
 // The tails of several patterns in one launch (rj_multi): blockIdx.y selects the pattern, whose
 // parameters are read from a device array.
 __global__ __launch_bounds__(256) void verify_in_regions_multi(const MultiTail* tails) {
@@ -1547,6 +1591,7 @@ __global__ __launch_bounds__(1024) void finalize_small(FinalizeParams a) {
     unsigned long long out_n = 0;
     for (int i = 0; i < n; i++) {
       if (i > 0 && key[i] == key[i - 1]) continue;  // duplicate begin
+      if (a.detect_conflict && key[i] < st.cur && val[i] > st.cur) a.counters[kCntConflict] = 1;
       bool taken;
       if (rj_select_step(&st, key[i], val[i], &taken)) {
         if (out_n < a.out_cap) {
@@ -1677,10 +1722,16 @@ __global__ void taken_index(const uint8_t* taken, uint64_t n, uint64_t* idx) {
 // previously taken match ended is not reported.  keep[i] in {0,1} as uint64 for the sum-scan.
 __global__ void apply_zero_length_rule(const uint64_t* keys, const uint64_t* vals, const uint8_t* taken,
                                        const uint64_t* last_taken, uint64_t n, uint64_t carry_prev_end,
-                                       int have_prev, uint64_t* keep) {
+                                       int have_prev, uint64_t* keep, unsigned long long* conflict) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   bool k = taken[i] != 0;
+  if (conflict != nullptr && !k && last_taken[i] > 0) {
+    // behind mode: a candidate hidden by the match taken before it must not reach beyond that match
+    const uint64_t lb = keys[last_taken[i] - 1], le = vals[last_taken[i] - 1];
+    const uint64_t cur = le > lb ? le : lb + 1;
+    if (keys[i] != lb && keys[i] < cur && vals[i] > cur) *conflict = 1;
+  }
   if (k && keys[i] == vals[i]) {
     const uint64_t lt = last_taken[i];  // 1-based index of the last taken candidate before i
     if (lt > 0) {
@@ -2403,6 +2454,19 @@ void launch_offsets_gather_check(const uint32_t* counts, const uint64_t* region_
   }
 }
 
+void launch_verify_behind_in_regions(const VerifyParams& a, const DevProgram& P, const DevProgram& R, const uint32_t* hit_counts,
+                                     uint32_t* valid_counts, uint64_t* region_ends, hipStream_t st) {
+  uint64_t blocks = (static_cast<uint64_t>(a.n_regions) + 15) / 16;  // 16 lanes per region
+  blocks = blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks;
+  const uint32_t both = P.table_words + R.table_words;
+  const uint32_t lds_words = both <= 12288 ? both : 0;
+  const size_t lds = static_cast<size_t>(lds_words) * sizeof(uint32_t);
+  const dim3 g(static_cast<unsigned>(blocks)), b(256);
+  if (P.n_words <= 1) hipLaunchKernelGGL((verify_behind_in_regions<1, 1>), g, b, lds, st, a, P, R, hit_counts, valid_counts, region_ends, lds_words);
+  else if (P.n_words == 2) hipLaunchKernelGGL((verify_behind_in_regions<2, 1>), g, b, lds, st, a, P, R, hit_counts, valid_counts, region_ends, lds_words);
+  else hipLaunchKernelGGL((verify_behind_in_regions<4, 2>), g, b, lds, st, a, P, R, hit_counts, valid_counts, region_ends, lds_words);
+}
+
 void launch_verify_floating_in_regions(const VerifyParams& a, const DevProgram& P, const uint32_t* hit_counts,
                                        uint32_t* valid_counts, uint64_t* region_begins, uint64_t* region_ends, hipStream_t st) {
   uint64_t blocks = (static_cast<uint64_t>(a.n_regions) + 3) / 4;  // a wave per region
@@ -2518,9 +2582,9 @@ void launch_taken_index(const uint8_t* taken, uint64_t n, uint64_t* idx, hipStre
 
 void launch_zero_length_rule(const uint64_t* keys, const uint64_t* vals, const uint8_t* taken,
                              const uint64_t* last_taken, uint64_t n, uint64_t carry_prev_end, int have_prev,
-                             uint64_t* keep, hipStream_t st) {
+                             uint64_t* keep, unsigned long long* conflict, hipStream_t st) {
   hipLaunchKernelGGL(apply_zero_length_rule, dim3(blocks_for(n)), dim3(256), 0, st, keys, vals, taken, last_taken, n,
-                     carry_prev_end, have_prev, keep);
+                     carry_prev_end, have_prev, keep, conflict);
 }
 
 void launch_compact_kept(const uint64_t* keys, const uint64_t* vals, const uint64_t* keep, const uint64_t* pos,

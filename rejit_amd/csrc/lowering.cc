@@ -612,7 +612,11 @@ class Automaton {
         lo = std::min(lo, dmin[static_cast<size_t>(pos)]);
         hi = std::max(hi, mx);
       }
-      if (!ok || lo == kInf || hi - lo > 255) continue;
+      if (!ok || lo == kInf || hi - lo > 255) {
+        // no bounded distance from the match start: remember the strongest such cut for plan_behind
+        if (behind_try.empty()) behind_try = chosen;
+        continue;
+      }
       for (size_t e = 0; e < ne; e++)
         if (chosen[e]) lits.insert(g_.byte_edges[e].bytes.substr(0, wl));
       if (lits.empty() || lits.size() > static_cast<size_t>(kMaxWindows)) continue;
@@ -633,7 +637,61 @@ class Automaton {
       }
       return;
     }
+    // single-byte literals were not tried above (a floating 1-byte window is too weak to pay for the
+    // 256 starts it implies); behind an unbounded prefix they still beat walking every start
+    if (behind_try.empty()) {
+      for (size_t L = 8; L >= 1 && behind_try.empty(); L--) {
+        std::vector<char> c(ne, 0);
+        int n = 0;
+        for (size_t e = 0; e < ne; e++)
+          if (g_.byte_edges[e].bytes.size() >= L) { c[e] = 1; n++; }
+        if (n && is_cut(c)) behind_try = c;
+      }
+    }
+    if (!behind_try.empty()) plan_behind(behind_try);
   }
+
+  // windows = the first min(8, len) bytes of the chosen literal edges (a cut); every window carries
+  // the positions of the first byte of the edges it stands for
+  void plan_behind(const std::vector<char>& chosen) {
+    const size_t ne = g_.byte_edges.size();
+    if (W_ > 4) return;  // the backward pass is a per-lane walk
+    size_t wl = 8;
+    for (size_t e = 0; e < ne; e++)
+      if (chosen[e]) wl = std::min(wl, g_.byte_edges[e].bytes.size());
+    std::vector<std::string> lits;
+    std::vector<std::vector<uint32_t>> cuts;
+    for (size_t e = 0; e < ne; e++) {
+      if (!chosen[e]) continue;
+      const std::string head = g_.byte_edges[e].bytes.substr(0, wl);
+      size_t k = 0;
+      while (k < lits.size() && lits[k] != head) k++;
+      if (k == lits.size()) {
+        lits.push_back(head);
+        cuts.emplace_back(static_cast<size_t>(W_), 0u);
+      }
+      set_bit(cuts[k].data(), edge_first_[e]);
+    }
+    if (lits.empty() || lits.size() > static_cast<size_t>(kMaxWindows)) return;
+    p_->mode = ScanMode::Windows;
+    p_->behind = true;
+    p_->floating = false;
+    p_->windows.clear();
+    p_->cut_positions = cuts;
+    for (const std::string& lit : lits) {
+      FFWindow w{};
+      w.offset = 0;
+      w.len = static_cast<uint32_t>(wl);
+      for (size_t k = 0; k < wl; k++) {
+        const uint32_t c = static_cast<uint8_t>(lit[k]);
+        if (k < 4) { w.value0 |= c << (8 * k); w.mask0 |= 0xFFu << (8 * k); }
+        else { w.value1 |= c << (8 * (k - 4)); w.mask1 |= 0xFFu << (8 * (k - 4)); }
+      }
+      p_->windows.push_back(w);
+    }
+  }
+
+  std::vector<char> behind_try;
 
   // all byte patterns of `remaining` more positions readable from position set `level`
   // (capped); a depth with more than 16 possible byte values becomes a wildcard

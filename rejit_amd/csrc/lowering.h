@@ -154,6 +154,15 @@ struct Program {
   // start (the reference runs its NFA backwards from the hit instead, codegen-x64.cc:643-650).
   bool floating = false;
   uint32_t float_min = 0, float_max = 0;
+  // Windows BEHIND an unbounded prefix (`.*regexp`, `[a-z]+abcdefgh`, `\d+regexp`): the reference picks
+  // any literal as fast-forward element and runs its NFA BACKWARDS from the hit to the match start
+  // (src/codegen.cc:352-383, src/x64/codegen-x64.cc:643-650).  Here: the literal edges of `windows` form a
+  // cut of the NFA graph (every match crosses one) but their distance from the match start is not
+  // bounded; a hit at w makes window k's positions `cut_positions[k]` (the automaton positions that
+  // consume the literal's first byte) live at w, from which the REVERSE automaton (rev) finds the
+  // left-most start and the forward automaton the end.
+  bool behind = false;
+  std::vector<std::vector<uint32_t>> cut_positions;   // [window][word]: forward positions, bitset
   std::string literal;                   // non-empty: the whole pattern is this literal
   // The NFA graph itself (reference state numbering semantics) and whether the pattern can
   // hit the reference's "Q8" ring-slot artefact: some state reachable

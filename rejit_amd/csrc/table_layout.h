@@ -65,6 +65,33 @@ inline void point_tables(DevProgram* D, const uint32_t* base, const TableBlob& b
   D->cls = base + b.off_cls;
 }
 
+// the window constants and the behind-mode cut sets of D (unused window slots repeat the last window,
+// so kernels instantiated for a larger K stay exact)
+inline void fill_windows(DevProgram* D, const Program& P) {
+  D->mode = P.mode == ScanMode::Windows ? 1 : 0;
+  D->n_windows = static_cast<int>(P.windows.size());
+  D->win_offset = P.windows.empty() ? 0 : P.windows[0].offset;
+  D->win_len = P.windows.empty() ? 0 : P.windows[0].len;
+  for (int k = 0; k < kDevMaxWindows; k++) {
+    const FFWindow w = P.windows.empty() ? FFWindow{} : P.windows[std::min<size_t>(static_cast<size_t>(k), P.windows.size() - 1)];
+    D->win_value0[k] = w.value0;
+    D->win_mask0[k] = w.mask0;
+    D->win_value1[k] = w.value1;
+    D->win_mask1[k] = w.mask1;
+  }
+  D->behind = P.behind ? 1u : 0u;
+  for (int k = 0; k < kDevMaxWindows; k++)
+    for (int j = 0; j < 4; j++) D->cut_fwd[k][j] = D->cut_rev[k][j] = 0;
+  if (P.behind)
+    for (size_t k = 0; k < P.cut_positions.size() && k < static_cast<size_t>(kDevMaxWindows); k++)
+      for (int q = 0; q < P.n_pos; q++)
+        if ((P.cut_positions[k][static_cast<size_t>(q) >> 5] >> (q & 31)) & 1u) {
+          const int r = P.n_pos - 1 - q;
+          D->cut_fwd[k][q >> 5] |= 1u << (q & 31);
+          D->cut_rev[k][r >> 5] |= 1u << (r & 31);
+        }
+}
+
 inline uint32_t nullable_bits(const Program& P) {
   uint32_t bits = 0;
   for (int c = 0; c < kNumCtx; c++)

@@ -4,10 +4,12 @@
 // g++ and runs the phases one sub-chunk after the other, so the algorithm (reverse automaton,
 // class stepping, symbolic summaries, chain selection) is checked against the oracle without a GPU.
 // Never linked into the product library.
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <vector>
 
+#include "../../rejit_amd/csrc/behind_walk.h"
 #include "../../rejit_amd/csrc/carry_scan.h"
 #include "../../rejit_amd/csrc/lowering.h"
 #include "../../rejit_amd/csrc/table_layout.h"
@@ -105,6 +107,37 @@ long run(const Program& P, const DevProgram& R, const uint8_t* t, uint64_t n, ui
 
 }  // namespace
 
+// The candidates of the behind mode through rejit_amd/csrc/behind_walk.h (what verify_behind_in_regions
+// runs per hit), then the selection with its conflict rule.  Returns the count, -100 on a conflict,
+// -101 when the pattern's plan is not `behind`, -102 when a walk hit the limit.
+template <int NW, int NQ>
+static long behind_run(const DevProgram& P, const DevProgram& R, const uint8_t* t, uint64_t n, uint64_t* out, uint64_t cap) {
+  struct Span { uint64_t b, e; };
+  std::vector<Span> c;
+  bool overrun = false;
+  for (uint64_t w = 0; w < n; w++) {
+    uint64_t b = 0, e = 0;
+    if (rj_behind_candidate<NW, NQ>(P, R, t, n, w, &b, &e, &overrun)) c.push_back({b, e});
+  }
+  if (overrun) return -102;
+  std::stable_sort(c.begin(), c.end(), [](const Span& x, const Span& y) { return x.b < y.b; });
+  uint64_t cur = 0, k = 0;
+  for (size_t i = 0; i < c.size(); i++) {
+    if (i > 0 && c[i].b == c[i - 1].b) continue;
+    if (c[i].b < cur) {
+      if (c[i].e > cur) return -100;
+      continue;
+    }
+    if (k < cap) {
+      out[2 * k] = c[i].b;
+      out[2 * k + 1] = c[i].e;
+    }
+    k++;
+    cur = c[i].e > c[i].b ? c[i].e : c[i].b + 1;
+  }
+  return static_cast<long>(k);
+}
+
 extern "C" {
 
 // MatchAll of the starts in [sb, se) through the carry scan with sub-chunks of `sub` bytes;
@@ -122,6 +155,25 @@ long ce_match_range(const char* re, const uint8_t* text, uint64_t n, uint64_t su
   if (P.n_words <= 2) return run<2>(P, R, text, n, sub, sb, se, carry_cur, carry_prev_end, have_prev, out, cap);
   if (P.n_words <= 4) return run<4>(P, R, text, n, sub, sb, se, carry_cur, carry_prev_end, have_prev, out, cap);
   if (P.n_words <= 8) return run<8>(P, R, text, n, sub, sb, se, carry_cur, carry_prev_end, have_prev, out, cap);
+  return -9;
+}
+
+long ce_match_all_behind(const char* re, const uint8_t* text, uint64_t n, uint32_t max_walk, uint64_t* out, uint64_t cap) {
+  LowerResult lr = lower(re);
+  if (lr.status != 0) return lr.status;
+  const Program& P = *lr.program;
+  if (!P.behind) return -101;
+  const TableBlob fb = make_table_blob(P, P.n_pos, P.n_words, P.has_assertions);
+  const TableBlob rb = make_table_blob(P.rev, P.n_pos, P.n_words, P.has_assertions);
+  DevProgram F{}, R{};
+  point_tables(&F, fb.words.data(), fb, P.n_pos);
+  point_tables(&R, rb.words.data(), rb, P.n_pos);
+  F.nullable = R.nullable = nullable_bits(P);
+  F.max_walk = R.max_walk = max_walk;
+  fill_windows(&F, P);
+  if (P.n_words <= 1) return behind_run<1, 1>(F, R, text, n, out, cap);
+  if (P.n_words <= 2) return behind_run<2, 1>(F, R, text, n, out, cap);
+  if (P.n_words <= 4) return behind_run<4, 2>(F, R, text, n, out, cap);
   return -9;
 }
 

@@ -6,6 +6,7 @@
 // forward automaton -> left-most-longest selection), so the lowering can be checked
 // against the oracle on a machine without a GPU.  It is never linked into the product
 // library and the product never falls back to it.
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -82,6 +83,7 @@ bool longest_at(const Program& P, const uint8_t* t, uint64_t n, uint64_t s, uint
 }
 
 bool candidate(const Program& P, const uint8_t* t, uint64_t n, uint64_t s) {
+  if (P.mode == ScanMode::Windows && P.behind) return s < n && P.first_bytes.has(t[s]);  // (every start; the hits are checked by pe_match_all_behind)
   if (P.mode == ScanMode::Windows && P.floating) {
     // some window must occur at w in [s + float_min, s + float_max]
     for (uint64_t w0 = s + P.float_min; w0 <= s + P.float_max; w0++)
@@ -116,9 +118,148 @@ bool candidate(const Program& P, const uint8_t* t, uint64_t n, uint64_t s) {
   return s < n && P.first_bytes.has(t[s]);
 }
 
+// ---- windows behind an unbounded prefix (Program::behind): the per-hit procedure of
+// verify_behind_in_regions restated on the host tables.
+struct Tables {
+  const std::vector<uint32_t>* first;   // [ctx]
+  const std::vector<uint32_t>* last;    // [ctx]
+  const std::vector<uint32_t>* linear;
+  const std::vector<int32_t>* row_of;
+  const std::vector<uint32_t>* rows;    // [ctx]
+  const std::vector<uint32_t>* cls;
+};
+
+void follow(const Tables& T, int W, const std::vector<uint32_t>& S, int ctx, std::vector<uint32_t>* out) {
+  uint32_t carry = 0;
+  for (int k = 0; k < W; k++) {
+    uint32_t lin = S[k] & (*T.linear)[k];
+    (*out)[k] = (lin << 1) | carry;
+    carry = lin >> 31;
+  }
+  for (int k = 0; k < W; k++) {
+    uint32_t sp = S[k] & ~(*T.linear)[k];
+    while (sp) {
+      int b = __builtin_ctz(sp);
+      sp &= sp - 1;
+      const uint32_t* fr = &T.rows[ctx][(size_t)(*T.row_of)[(size_t)k * 32 + b] * W];
+      for (int j = 0; j < W; j++) (*out)[j] |= fr[j];
+    }
+  }
+}
+
+bool any(const std::vector<uint32_t>& S) {
+  for (uint32_t x : S)
+    if (x) return true;
+  return false;
+}
+
+// does a thread that consumes text[p] at (forward) position q reach an accepting boundary?
+bool reaches_accept(const Program& P, const uint8_t* t, uint64_t n, uint64_t p, int q) {
+  const int W = P.n_words;
+  const Tables F{P.first, P.last, &P.linear, &P.row_of, P.rows, &P.cls};
+  std::vector<uint32_t> S(W, 0u), T(W);
+  S[q >> 5] = 1u << (q & 31);
+  for (uint64_t at = p + 1;; at++) {  // S = positions that consumed text[at - 1]
+    const int ctx = context_at(t, n, at);
+    for (int k = 0; k < W; k++)
+      if (S[k] & P.last[ctx][k]) return true;
+    if (at == n) return false;
+    follow(F, W, S, ctx, &T);
+    const uint32_t* row = &P.cls[(size_t)t[at] * W];
+    for (int k = 0; k < W; k++) S[k] = T[k] & row[k];
+    if (!any(S)) return false;
+  }
+}
+
+// left-most s <= p such that a thread started at s sits at one of `ok_rev` (reverse numbering) after
+// consuming text[p]; returns false when there is none
+bool leftmost_start(const Program& P, const uint8_t* t, uint64_t n, uint64_t p, std::vector<uint32_t> S, uint64_t* start) {
+  const int W = P.n_words;
+  const Program::Reverse& R = P.rev;
+  const Tables B{R.first, R.last, &R.linear, &R.row_of, R.rows, &R.cls};
+  std::vector<uint32_t> T(W);
+  bool found = false;
+  for (uint64_t at = p;; at--) {  // S = reverse positions that consumed text[at]
+    const int ctx = context_at(t, n, at);
+    for (int k = 0; k < W; k++)
+      if (S[k] & R.last[ctx][k]) {
+        found = true;
+        *start = at;
+        break;
+      }
+    if (at == 0) break;
+    follow(B, W, S, ctx, &T);
+    const uint32_t* row = &R.cls[(size_t)t[at - 1] * W];
+    for (int k = 0; k < W; k++) S[k] = T[k] & row[k];
+    if (!any(S)) break;
+  }
+  return found;
+}
+
+// candidates (begin, end) of the behind mode, one per hit at most
+void behind_candidates(const Program& P, const uint8_t* t, uint64_t n, std::vector<Span>* out) {
+  const int W = P.n_words;
+  for (uint64_t p = 0; p < n; p++) {
+    std::vector<uint32_t> ok(W, 0u);
+    bool hit = false;
+    for (size_t k = 0; k < P.windows.size(); k++) {
+      const FFWindow& w = P.windows[k];
+      if (p + w.len > n) continue;
+      uint32_t v0 = 0, v1 = 0;
+      for (uint32_t i = 0; i < w.len; i++) {
+        uint32_t c = t[p + i];
+        if (i < 4) v0 |= c << (8 * i);
+        else v1 |= c << (8 * (i - 4));
+      }
+      if ((v0 & w.mask0) != w.value0 || (v1 & w.mask1) != w.value1) continue;
+      for (int q = 0; q < P.n_pos; q++)
+        if ((P.cut_positions[k][(size_t)q >> 5] >> (q & 31)) & 1u)
+          if (reaches_accept(P, t, n, p, q)) {
+            const int r = P.n_pos - 1 - q;
+            ok[(size_t)r >> 5] |= 1u << (r & 31);
+            hit = true;
+          }
+    }
+    if (!hit) continue;
+    uint64_t s, e;
+    if (!leftmost_start(P, t, n, p, ok, &s)) continue;
+    if (longest_at(P, t, n, s, &e)) out->push_back({s, e});
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+// behind mode only: number of matches, -100 when the candidates conflict (a skipped candidate ends
+// after the match that hides it: the engine then repeats the run in dense mode), -101 when the
+// pattern's plan is not `behind`
+long pe_match_all_behind(const char* re, const uint8_t* text, uint64_t n, uint64_t* out, uint64_t cap) {
+  LowerResult lr = lower(re);
+  if (lr.status != 0) return lr.status;
+  const Program& P = *lr.program;
+  if (!P.behind) return -101;
+  std::vector<Span> cands;
+  behind_candidates(P, text, n, &cands);
+  std::stable_sort(cands.begin(), cands.end(), [](const Span& a, const Span& b) { return a.begin < b.begin; });
+  std::vector<Span> sel;
+  uint64_t cur = 0;
+  for (size_t i = 0; i < cands.size(); i++) {
+    const Span& c = cands[i];
+    if (i > 0 && c.begin == cands[i - 1].begin) continue;
+    if (c.begin < cur) {
+      if (c.end > cur) return -100;
+      continue;
+    }
+    sel.push_back(c);
+    cur = c.end > c.begin ? c.end : c.begin + 1;
+  }
+  for (size_t i = 0; i < sel.size() && i < cap; i++) {
+    out[2 * i] = sel[i].begin;
+    out[2 * i + 1] = sel[i].end;
+  }
+  return (long)sel.size();
+}
 
 // returns count, or a negative status
 long pe_match_all(const char* re, const uint8_t* text, uint64_t n, uint64_t* out, uint64_t cap) {
@@ -212,6 +353,7 @@ int pe_plan(const char* re, uint64_t* info, uint32_t* window_values) {
   info[6] = (uint64_t)P.n_rows;
   info[7] = P.literal.size();
   info[8] = P.floating;
+  info[11] = P.behind;
   info[9] = P.float_min;
   info[10] = P.float_max;
   for (size_t i = 0; i < P.windows.size(); i++) {

@@ -23,7 +23,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(ROOT, "rejit_amd", "csrc")
 SO = os.path.join(HERE, "support", "libcarry_exec.so")
 SRCS = [os.path.join(HERE, "support", "carry_exec.cc"), os.path.join(CSRC, "parser.cc"), os.path.join(CSRC, "lowering.cc")]
-DEPS = SRCS + [os.path.join(CSRC, h) for h in ("carry_scan.h", "device_program.h", "lowering.h", "table_layout.h")]
+DEPS = SRCS + [os.path.join(CSRC, h) for h in ("carry_scan.h", "device_program.h", "lowering.h", "table_layout.h", "behind_walk.h")]
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 
 
@@ -35,6 +35,8 @@ def ce():
     lib.ce_match_range.restype = ctypes.c_long
     lib.ce_match_range.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                    ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, _u64p, ctypes.c_uint64]
+    lib.ce_match_all_behind.restype = ctypes.c_long
+    lib.ce_match_all_behind.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, _u64p, ctypes.c_uint64]
     return lib
 
 
@@ -112,3 +114,33 @@ def test_wide_automata(ce):
         assert not isinstance(want, int)
         for sub in (5, 128):
             assert carry(ce, rx, tx, sub) == want, (rx, sub)
+
+
+def test_behind_walk_device_code_vs_oracle(ce):
+    """rejit_amd/csrc/behind_walk.h -- the per-hit procedure verify_behind_in_regions runs (forward check
+    from the cut, reverse automaton to the left-most start, forward longest) -- compiled for the CPU:
+    oracle's answer or a flagged conflict / walk limit, never a wrong result."""
+    oracle = Oracle()
+    rng = random.Random(23)
+    pats = [b".*regexp", b"[a-z]+abcdefgh", b"\\d+regexp", b"[0-9]+x", b"[A-Z][a-z]+ [A-Z][a-z]+", b"[ab]*abb", b"^.*foo", b"[a-z]+@[a-z]+",
+            b".*ab.*cd", b"a+(bc|bd)e*", b"[ab]+(c|dd)+x", b"[ab]{30,}cd", b"([ab]{3}c){12,}xy"]
+    used = flagged = 0
+    for rx in pats:
+        for alphabet in (b"abregxp0\n", b"ab", b"abcdx \nAB@", b"abcdefgh12x", b"abcd"):
+            for n in (9, 80, 500):
+                tx = bytes(rng.choices(alphabet, k=n))
+                for plant in (b"", b"regexp", b"abcdefgh", b"abb", b"cd", b"xy"):
+                    t2 = tx[:n // 2] + plant + tx[n // 2:]
+                    buf = (ctypes.c_uint64 * (2 * (len(t2) + 2)))()
+                    for walk in (1 << 20, 16):
+                        k = ce.ce_match_all_behind(rx, t2, len(t2), walk, buf, len(t2) + 2)
+                        if k == -101:
+                            break
+                        if k in (-100, -102):
+                            flagged += 1
+                            continue
+                        assert k >= 0, (rx, k)
+                        got = [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(k)]
+                        assert got == oracle.match_all_spec(rx, t2), (rx, t2, walk)
+                        used += 1
+    assert used > 800, (used, flagged)

@@ -31,6 +31,7 @@ _u64p = ctypes.POINTER(ctypes.c_uint64)
 @pytest.fixture(scope="module")
 def pe():
     deps = SRCS + [os.path.join(ROOT, "rejit_amd", "csrc", "lowering.h")]
+    deps.append(os.path.join(ROOT, "rejit_amd", "csrc", "lowering.cc"))
     if not os.path.exists(SO) or any(os.path.getmtime(SO) < os.path.getmtime(s) for s in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", SO] + SRCS)
     lib = ctypes.CDLL(SO)
@@ -38,6 +39,8 @@ def pe():
     lib.pe_match_all.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, _u64p, ctypes.c_uint64]
     lib.pe_match_full.restype = ctypes.c_int
     lib.pe_match_full.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64]
+    lib.pe_match_all_behind.restype = ctypes.c_long
+    lib.pe_match_all_behind.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, _u64p, ctypes.c_uint64]
     lib.pe_plan.restype = ctypes.c_int
     lib.pe_plan.argtypes = [ctypes.c_char_p, _u64p, ctypes.POINTER(ctypes.c_uint32)]
     return lib
@@ -59,7 +62,7 @@ def plan(lib, rx):
     assert st == 0
     return dict(windows=bool(info[0]), n_windows=int(info[1]), offset=int(info[2]), n_pos=int(info[3]),
                 min_len=int(info[4]), max_len=int(info[5]), n_rows=int(info[6]), literal_len=int(info[7]),
-                floating=bool(info[8]), float_min=int(info[9]), float_max=int(info[10]),
+                floating=bool(info[8]), float_min=int(info[9]), float_max=int(info[10]), behind=bool(info[11]),
                 values=[tuple(int(v) for v in vals[4 * i:4 * i + 4]) for i in range(int(info[1]))])
 
 
@@ -118,7 +121,8 @@ def test_scan_plans(pe):
     assert p["windows"] and p["floating"] and p["values"] == [_w(b"abcdefgh")]
     assert (p["float_min"], p["float_max"]) == (2, 42)
     p = plan(pe, b"[a-z]+@example")
-    assert not p["windows"]            # unbounded prefix: no usable window, dense scan
+    # unbounded prefix: the literal behind it is the window, the start is found by the backward pass
+    assert p["windows"] and p["behind"] and not p["floating"] and p["values"] == [_w(b"@example")]
     p = plan(pe, b"[0-9]{2,3}foo(bar|baz)")
     assert p["windows"] and p["floating"] and (p["float_min"], p["float_max"]) == (2, 3) and p["values"] == [_w(b"foo")]
     p = plan(pe, b">.*\n|\n")
@@ -127,3 +131,45 @@ def test_scan_plans(pe):
     assert p["windows"] and p["values"] == [_w(b"abc?efgh", (3,))]
     p = plan(pe, b"(alternation|more|than|two|different|strings)")
     assert p["windows"] and p["n_windows"] == 6 and p["min_len"] == 3
+
+
+def match_all_behind(lib, rx, tx):
+    cap = len(tx) + 2
+    buf = (ctypes.c_uint64 * (2 * cap))()
+    n = lib.pe_match_all_behind(rx, tx, len(tx), buf, cap)
+    if n < 0:
+        return int(n)
+    return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n)]
+
+
+def test_windows_behind_an_unbounded_prefix(pe):
+    """`.*regexp`, `[a-z]+abcdefgh`, `\\d+regexp`: the reference fast-forwards on ANY literal and runs its
+    NFA backwards from the hit (src/codegen.cc:352-383, codegen-x64.cc:643-650).  The plan picks such
+    literals as windows with the automaton positions they enter at; the per-hit procedure (forward
+    check from the cut, reverse automaton to the left-most start, forward longest) is restated by the
+    test executor and must give the oracle's answer -- or report a conflict, never a wrong result."""
+    import random
+    oracle = Oracle()
+    pats = [b".*regexp", b"[a-z]+abcdefgh", b"\\d+regexp", b"[0-9]+x", b"[A-Z][a-z]+ [A-Z][a-z]+", b"(ab|ba)+c", b"a.*b",
+            b"[ab]*abb", b"(x|yy)+z[ab]*", b"^.*foo", b"[a-z]+@[a-z]+", b".*ab.*cd", b"(a|b)+c(a|b)+", b"a+(bc|bd)e*", b"[ab]+(c|dd)+x"]
+    rng = random.Random(17)
+    used = conflicts = 0
+    for rx in pats:
+        pl = plan(pe, rx)
+        if not pl["behind"]:     # a fixed-offset window set was found instead: not this test's business
+            assert rx not in (b".*regexp", b"[a-z]+abcdefgh", b"\\d+regexp", b"[0-9]+x", b"[a-z]+@[a-z]+"), (rx, pl)
+            continue
+        assert pl["windows"]
+        for alphabet in (b"abregxp0\n", b"ab", b"abcdx \nAB@", b"abcdefgh12x", b"abcde"):
+            for n in (7, 60, 400):
+                tx = bytes(rng.choices(alphabet, k=n))
+                for plant in (b"", b"regexp", b"abcdefgh", b"abb", b"zz"):
+                    t2 = tx[:n // 2] + plant + tx[n // 2:]
+                    got = match_all_behind(pe, rx, t2)
+                    want = oracle.match_all_spec(rx, t2)
+                    if got == -100:
+                        conflicts += 1
+                        continue
+                    assert got == want, (rx, t2, got, want)
+                    used += 1
+    assert used > 500 and conflicts < used // 10, (used, conflicts)
