@@ -44,7 +44,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-VALU_PEAK_TOPS = 39.3        # 256 CUs x 64 lanes x 2.4 GHz simple 32-bit VALU lane-ops per second (same guide)
+VALU_PEAK_TOPS = 78.6        # 256 CUs x 4 SIMD-32 x 32 lanes/clk x 2.4 GHz simple 32-bit VALU lane-ops per second (same guide:
+                             # a wave64 instruction issues over 2 cycles; = the 157.3 TFLOP/s FP32 vector peak / 2 flops per FMA)
 
 
 def pmc_traffic(key, **match):
@@ -502,6 +503,18 @@ def literal_and_complex_extras(args, c, out):
     out["complex_scan"] = single_pattern_extra(
         c, rejit_amd, t, n, rx, "%s MatchAll over %d bytes random ASCII, %d planted (BASELINE configs[3] shape, 1 GPU)" % (rx, n, len(offs2)),
         "scan_windows<1> (floating window)", 5, check_complex, "complex", True, args)
+    # a required literal BEHIND an unbounded prefix (the reference's backward pass from the fast-forward hit,
+    # src/x64/codegen-x64.cc:643-650): the window scan finds `abcdefgh`, verify_behind_in_regions walks the
+    # reverse automaton to the start.  Round 1 ran these patterns in dense mode (0.6 TB/s).
+    rxb = "[a-z]+abcdefgh"
+
+    def check_behind(sc):
+        sp = sc.spans()
+        assert len(sp) >= 300 and all(e - b >= 9 for b, e in sp), "behind-mode matches missing"
+
+    out["behind_scan"] = single_pattern_extra(
+        c, rejit_amd, t, n, rxb, "%s MatchAll over the same %d bytes (window behind an unbounded prefix)" % (rxb, n),
+        "scan_windows<1> + verify_behind_in_regions", 5, check_behind, None, True, args)
     del t
     torch.cuda.empty_cache()
 

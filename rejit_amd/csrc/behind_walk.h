@@ -39,8 +39,11 @@ RJ_HD bool rj_window_at(const DevProgram& P, int k, const uint8_t* t, uint64_t n
 }
 
 // step 1: a thread that has consumed text[p] at forward position q -- does it reach an accepting boundary?
+// (`abort`, may be null: polled every 256 steps -- once any walk of the run has hit the limit the run is
+// void and the others need not finish; a step is a chain of dependent loads, ~1 us)
 template <int NW>
-RJ_HD bool rj_reaches_accept(const DevProgram& P, const uint8_t* t, uint64_t n, uint64_t p, int q, bool* overrun) {
+RJ_HD bool rj_reaches_accept(const DevProgram& P, const uint8_t* t, uint64_t n, uint64_t p, int q, bool* overrun,
+                             const volatile unsigned long long* abort = nullptr) {
   const int W = P.n_words;
   uint32_t S[NW], T[NW];
 #pragma unroll
@@ -59,6 +62,7 @@ RJ_HD bool rj_reaches_accept(const DevProgram& P, const uint8_t* t, uint64_t n, 
       *overrun = true;
       return false;
     }
+    if (abort != nullptr && ((at - p) & 255u) == 0 && *abort != 0) return false;
     cs_follow<NW>(P, S, ctx, T);
     const uint32_t* cr = P.cls + static_cast<size_t>(t[at]) * W;
 #pragma unroll
@@ -74,7 +78,7 @@ RJ_HD bool rj_reaches_accept(const DevProgram& P, const uint8_t* t, uint64_t n, 
 // of their threads can begin a match.  false: there is none.
 template <int NW>
 RJ_HD bool rj_leftmost_start(const DevProgram& R, const uint8_t* t, uint64_t n, uint64_t p, uint32_t (&S)[NW], uint32_t max_walk,
-                             uint64_t* start, bool* overrun) {
+                             uint64_t* start, bool* overrun, const volatile unsigned long long* abort = nullptr) {
   const int W = R.n_words;
   uint32_t T[NW];
   bool found = false;
@@ -94,6 +98,7 @@ RJ_HD bool rj_leftmost_start(const DevProgram& R, const uint8_t* t, uint64_t n, 
       *overrun = true;
       break;
     }
+    if (abort != nullptr && ((p - at) & 255u) == 0 && *abort != 0) break;
     cs_follow<NW>(R, S, ctx, T);
     const uint32_t* cr = R.cls + static_cast<size_t>(t[at - 1]) * W;
 #pragma unroll
@@ -110,7 +115,7 @@ RJ_HD bool rj_leftmost_start(const DevProgram& R, const uint8_t* t, uint64_t n, 
 // the forward walk (rj_lane_longest), NW = 32-bit words: NQ = (NW + 1) / 2.
 template <int NW, int NQ>
 RJ_HD bool rj_behind_candidate(const DevProgram& P, const DevProgram& R, const uint8_t* t, uint64_t n, uint64_t w, uint64_t* begin,
-                               uint64_t* end, bool* overrun) {
+                               uint64_t* end, bool* overrun, const volatile unsigned long long* abort = nullptr) {
   const int W = P.n_words;
   uint32_t ok[NW];
 #pragma unroll
@@ -124,7 +129,7 @@ RJ_HD bool rj_behind_candidate(const DevProgram& P, const DevProgram& R, const u
         const int b = __builtin_ctz(bits);
         bits &= bits - 1;
         const int q = j * 32 + b;
-        if (rj_reaches_accept<NW>(P, t, n, w, q, overrun)) {
+        if (rj_reaches_accept<NW>(P, t, n, w, q, overrun, abort)) {
           const int r = P.n_pos - 1 - q;
           ok[r >> 5] |= 1u << (r & 31);
           any = true;
@@ -134,9 +139,9 @@ RJ_HD bool rj_behind_candidate(const DevProgram& P, const DevProgram& R, const u
   }
   if (!any) return false;
   uint64_t s = 0;
-  if (!rj_leftmost_start<NW>(R, t, n, w, ok, P.max_walk, &s, overrun)) return false;
+  if (*overrun || !rj_leftmost_start<NW>(R, t, n, w, ok, P.max_walk, &s, overrun, abort) || *overrun) return false;
   *begin = s;
-  return rj_lane_longest<NQ>(P, t, n, s, end, overrun);
+  return rj_lane_longest<NQ>(P, t, n, s, end, overrun, abort);
 }
 
 }  // namespace rejit_amd

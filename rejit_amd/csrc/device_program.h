@@ -156,7 +156,7 @@ RJ_HD bool rj_lane_longest(const DevProgram& P, const uint8_t* t, uint64_t n, ui
       *overrun = true;
       break;
     }
-    if (abort != nullptr && ((p - s) & 1023u) == 0 && *abort != 0) break;  // the run is void already
+    if (abort != nullptr && ((p - s) & 255u) == 0 && *abort != 0) break;  // the run is void already
     uint64_t T[NQ];
     uint64_t carry = 0;
     for (int q = 0; q < NQ; q++) {

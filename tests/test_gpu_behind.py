@@ -39,8 +39,8 @@ def test_small_texts_vs_oracle(rj):
     n_cases = 0
     for rx in PATS:
         p = rj.Program(rx)
-        for alphabet in (b"abregxp0\n", b"ab", b"abcdx \nAB@", b"abcdefgh12x", b"abcd"):
-            for n in (9, 300, 5000, 70000):
+        for alphabet in (b"abregxp0\n", b"ab", b"abcdx \nAB@", b"abcdefgh12x"):
+            for n in (9, 300, 6000):
                 tx = bytes(rng.choices(alphabet, k=n))
                 for plant in (b"", b"regexp", b"abcdefgh"):
                     t2 = tx[:n // 2] + plant + tx[n // 2:] + plant
@@ -49,11 +49,11 @@ def test_small_texts_vs_oracle(rj):
                     got = p.match_all(t2)
                     assert got == spec, (rx, alphabet, n, plant, got[:3], spec[:3])
                     n_cases += want == spec
-    assert n_cases > 500
+    assert n_cases > 300
 
 
-@pytest.mark.parametrize("rx,lo,hi,plant", [(b".*regexp", "0", "z", b"regexp"), (b"[a-z]+abcdefgh", "0", "z", b"abcdefgh"),
-                                              (b"\\d+regexp", "0", "z", b"regexp"), (b"[0-9]+x", "0", "z", b"x"),
+@pytest.mark.parametrize("rx,lo,hi,plant", [(b".*regexp", "0", "z", b"regexp"), (b"[a-z]+abcdefgh", "0", "z", b"qabcdefgh"),
+                                              (b"\\d+regexp", "0", "z", b"7regexp"), (b"[0-9]+x", "0", "z", b"7x"),
                                               (b"([complex]|(regexp)){2,}abcdefgh(at|the)", "0", "z", b"complexabcdefghthe")])
 def test_large_random_ascii_vs_oracle(rj, rx, lo, hi, plant):
     """256 MiB of the benchmark harness's random text (line-free for `.*`: ONE candidate start per hit at
