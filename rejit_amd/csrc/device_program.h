@@ -58,6 +58,14 @@ struct DevProgram {
   // positions cut_fwd[k] live at w (they consume text[w]); cut_rev[k] = the same set in the reverse
   // automaton's numbering.  Lane-sized automata only (n_words <= 4).
   uint32_t behind;
+  // `X+ rest`: in every context a match can only begin at ONE position, and that position follows itself
+  // (no assertions, not nullable).  A start s whose previous byte is in X as well is then never selected:
+  // the thread of s - 1 passes through the same position at s, so it reaches every end s reaches (s - 1
+  // is a candidate whenever s is, with an end at least as far), and no selected match can END at s -- its
+  // own thread would still be alive in X at s and run on to whatever s reaches.  The dense kernel
+  // therefore takes only the FIRST byte of every run of X as a candidate: `[a-z]+` over 1 GB has 338 M
+  // starts with a match but 35 M runs.
+  uint32_t loop_first;
   uint32_t cut_fwd[kDevMaxWindows][4];
   uint32_t cut_rev[kDevMaxWindows][4];
 };

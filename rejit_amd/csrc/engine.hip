@@ -189,6 +189,23 @@ int upload_program(rj_program* rp) {
   if (linear_path_fits(rp)) D.max_walk = (D.mode == 0 || D.behind) ? 4096u : 65536u;  // (behind: three walks per hit, a step ~1 us)
   if (const char* mw = getenv("RJ_MAX_WALK"))  // test / measurement override
     if (atoi(mw) > 0) D.max_walk = static_cast<uint32_t>(std::min<long>(atol(mw), static_cast<long>(kMaxSimSteps)));
+  {
+    // X+ rest (DevProgram::loop_first): one first position, the same in the only context, following itself
+    D.loop_first = 0;
+    int n_first = 0, p0 = -1;
+    for (int i = 0; i < P.n_pos; i++)
+      if ((P.first[0][static_cast<size_t>(i) >> 5] >> (i & 31)) & 1u) {
+        n_first++;
+        p0 = i;
+      }
+    if (!P.has_assertions && !P.any_nullable && n_first == 1 && W <= 4) {
+      bool self = false;
+      const int r = P.row_of[static_cast<size_t>(p0)];
+      if (r >= 0) self = (P.rows[0][static_cast<size_t>(r) * W + (p0 >> 5)] >> (p0 & 31)) & 1u;
+      D.loop_first = self ? 1u : 0u;
+    }
+    if (getenv("RJ_NO_LOOP_FIRST") != nullptr) D.loop_first = 0;  // measurement override
+  }
   D.float_range = P.floating ? P.float_max - P.float_min + 1 : 1;
   D.float_max = P.floating ? P.float_max : 0;
   for (int k = 0; k < 8; k++) D.first_bytes[k] = P.first_bytes.w[k];
@@ -642,7 +659,8 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
       }
       launch_offsets_gather_check(survivors, begins, s->cand_end.as<uint64_t>(), geo.n_regions,
                                   static_cast<uint32_t>(region_cap), fp.carry_cur, s->out.as<uint64_t>(), s->out_cap,
-                                  s->counters.as<unsigned long long>(), s->host_counters, off_scratch, prev_scratch, st);
+                                  s->counters.as<unsigned long long>(), s->host_counters, off_scratch, prev_scratch, st,
+                                  fp.carry_prev_end, fp.have_prev);
       RJ_HIP(hipStreamSynchronize(st));
       RJ_HIP(hipGetLastError());
       if (s->host_counters[kCntUnordered] != 0 && s->host_counters[kCntOverflow] == 0) {

@@ -163,7 +163,7 @@ void launch_verify_floating_in_regions(const VerifyParams& a, const DevProgram& 
 void launch_offsets_gather_check(const uint32_t* counts, const uint64_t* region_begins, const uint64_t* region_ends,
                                  uint32_t n_regions, uint32_t region_cap, uint64_t carry_cur, uint64_t* out, uint64_t out_cap,
                                  unsigned long long* counters, unsigned long long* host_counters, uint64_t* offsets_scratch,
-                                 uint64_t* prev_scratch, hipStream_t st);
+                                 uint64_t* prev_scratch, hipStream_t st, uint64_t carry_prev_end = 0, int have_prev = 0);
 // (begin,end) pairs -> begin[] / end[]; n read from device memory
 void launch_split_pairs(const uint64_t* pairs, const unsigned long long* n_ptr, uint64_t n_upper, uint64_t* keys, uint64_t* vals,
                         hipStream_t st);

@@ -1082,12 +1082,21 @@ __global__ __launch_bounds__(256) void verify_in_regions_multi(const MultiTail* 
 // nearest non-empty region before it.  Otherwise counters[kCntUnordered] is set and the host
 // splits the pairs and runs the cluster-parallel selection.
 constexpr int kOgcThreads = 256;
+// Is candidate (b, e) in place as it stands?  Ordered and disjoint: it begins at or after every earlier
+// end (`before_it`: their running maximum, or the carried-in cur).  An EMPTY match additionally must begin
+// strictly behind that end -- one that begins where the previous match ended is dropped by the zero-length
+// rule (src/codegen.cc:65-73), which the selection kernels apply -- except the very first candidate of a
+// run into which no match ending there was carried (`^` at offset 0).  With this the line table of a
+// grep-like caller (16 M empty matches per GB) and class hits take the no-selection path.
+__device__ __forceinline__ bool candidate_in_place(uint64_t b, uint64_t e, uint64_t before_it, bool first_overall, uint64_t carry_pe) {
+  return b >= before_it && (e > b || b > before_it || (first_overall && carry_pe != b));
+}
 __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts, const uint64_t* region_begins,
                                                           const uint64_t* region_ends, uint32_t n_regions,
                                                           uint32_t region_cap, uint64_t carry_cur, uint64_t* out,
                                                           uint64_t out_cap, unsigned long long* counters,
-                                                          unsigned long long* host_counters, uint64_t* offsets_out = nullptr,
-                                                          uint64_t* prev_out = nullptr) {
+                                                          unsigned long long* host_counters, uint64_t carry_pe,
+                                                          uint64_t* offsets_out = nullptr, uint64_t* prev_out = nullptr) {
   // Adjacency (a candidate begins exactly where an earlier one ends) is wanted for the Q8 check.
   // When the list is ordered and disjoint -- the only case in which this kernel's verdict is
   // used -- only neighbours can be adjacent, so comparing with the running maximum is exact.
@@ -1204,7 +1213,7 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
       const uint64_t at = static_cast<uint64_t>(first + lo) * region_cap + (e - s_pre[lo]);
       const uint64_t b = region_begins[at], en = region_ends[at];
       const uint64_t before_it = e > s_pre[lo] ? region_ends[at - 1] : s_prev[lo];
-      ok = ok && en > b && b >= before_it;
+      ok = ok && candidate_in_place(b, en, before_it, base + e == 0, carry_pe);
       adjacent = adjacent || (b == before_it && before_it != 0);
       if (base + e < out_cap) *reinterpret_cast<ulonglong2*>(out + 2 * (base + e)) = make_ulonglong2(b, en);
     }
@@ -1218,7 +1227,7 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
       b = region_begins[src + k];
       e = region_ends[src + k];
     }
-    ok = ok && e > b && b >= prev;
+    ok = ok && candidate_in_place(b, e, prev, off + k == 0, carry_pe);
     adjacent = adjacent || (b == prev && prev != 0);
     prev = e > prev ? e : prev;
     if (off + k < out_cap) *reinterpret_cast<ulonglong2*>(out + 2 * (off + k)) = make_ulonglong2(b, e);
@@ -1252,10 +1261,10 @@ __global__ __launch_bounds__(kOgcThreads) void offsets_gather_check(const uint32
                                                                     const uint64_t* region_ends, uint32_t n_regions,
                                                                     uint32_t region_cap, uint64_t carry_cur, uint64_t* out,
                                                                     uint64_t out_cap, unsigned long long* counters,
-                                                                    unsigned long long* host_counters, uint64_t* offsets_out,
-                                                                    uint64_t* prev_out) {
+                                                                    unsigned long long* host_counters, uint64_t carry_pe,
+                                                                    uint64_t* offsets_out, uint64_t* prev_out) {
   offsets_gather_check_body(counts, region_begins, region_ends, n_regions, region_cap, carry_cur, out, out_cap, counters,
-                            host_counters, offsets_out, prev_out);
+                            host_counters, carry_pe, offsets_out, prev_out);
 }
 
 // Second half of the two-launch form used when regions hold many candidates (tens and more each:
@@ -1265,7 +1274,7 @@ __global__ __launch_bounds__(256) void gather_regions_by_wave(const uint32_t* co
                                                               const uint64_t* region_ends, const uint64_t* offsets,
                                                               const uint64_t* prev_end, uint32_t n_regions, uint32_t region_cap,
                                                               uint64_t* out, uint64_t out_cap, unsigned long long* counters,
-                                                              unsigned long long* host_counters) {
+                                                              unsigned long long* host_counters, uint64_t carry_pe) {
   const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
   const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
   const int lane = lane_id();
@@ -1277,7 +1286,7 @@ __global__ __launch_bounds__(256) void gather_regions_by_wave(const uint32_t* co
     for (uint32_t k = lane; k < cnt; k += kWave) {
       const uint64_t b = region_begins[src + k], e = region_ends[src + k];
       const uint64_t before_it = k ? region_ends[src + k - 1] : before_region;
-      ok = ok && e > b && b >= before_it;
+      ok = ok && candidate_in_place(b, e, before_it, off + k == 0, carry_pe);
       adjacent = adjacent || (b == before_it && before_it != 0);
       if (off + k < out_cap) *reinterpret_cast<ulonglong2*>(out + 2 * (off + k)) = make_ulonglong2(b, e);
     }
@@ -1295,7 +1304,7 @@ __global__ __launch_bounds__(256) void gather_regions_by_wave(const uint32_t* co
 __global__ __launch_bounds__(kOgcThreads) void offsets_gather_check_multi(const MultiTail* tails) {
   const MultiTail t = tails[blockIdx.y];  // by value, see verify_in_regions_multi
   offsets_gather_check_body(t.valid_counts, t.verify.hits, t.region_ends, t.verify.n_regions, t.verify.region_cap, 0, t.out,
-                            t.out_cap, t.verify.counters, t.host_counters);
+                            t.out_cap, t.verify.counters, t.host_counters, ~0ull);
 }
 
 // First and last match of up to kMaxFused result lists (rj_multi_bounds: what a shard exchanges with
@@ -2092,6 +2101,15 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
       const uint32_t range = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
       fin &= range;
       cand = (walk & range) | fin;
+      if (P.loop_first) {
+        // `X+...`: a start whose previous byte is in X too is never selected (see DevProgram::loop_first)
+        uint32_t in_x = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) in_x |= static_cast<uint32_t>((first0[0] & r[j]) != 0) << j;
+        uint32_t prev_in = __shfl_up(in_x >> 15, 1);
+        if (lane == 0) prev_in = base > 0 ? ((fb[a.text[base - 1] >> 5] >> (a.text[base - 1] & 31)) & 1u) : 0u;
+        cand &= ~((in_x << 1) | prev_in);
+      }
     } else {
       // General form.  A position starts a candidate when its byte can begin a match in the
       // position's context, or (nullable patterns: x*, ^, $, ...) when the empty string matches
@@ -2131,6 +2149,12 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
       const uint32_t lo = a.sb > at ? (a.sb - at < 16 ? static_cast<uint32_t>(a.sb - at) : 16u) : 0u;
       const uint32_t range = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
       cand = ((first16 & allowed16 & lt_n) | (null16 & le_n)) & 0xFFFFu & range;
+      if (P.loop_first) {  // (no assertions, not nullable: first16 is membership in X)
+        const uint32_t in_x = first16 & lt_n;
+        uint32_t prev_in = __shfl_up(in_x >> 15, 1);
+        if (lane == 0) prev_in = base > 0 ? ((fb[a.text[base - 1] >> 5] >> (a.text[base - 1] & 31)) & 1u) : 0u;
+        cand &= ~((in_x << 1) | prev_in);
+      }
       if (P.n_pos == 0) {
         // only assertions (^, $, ^$): every candidate IS a match, the empty one -- no walk at all
         // (the line table of a grep-like caller is a MatchAll of "^", sample/jrep.cc:294)
@@ -2443,15 +2467,16 @@ void launch_verify_in_regions(const VerifyParams& a, const DevProgram& P, const 
 void launch_offsets_gather_check(const uint32_t* counts, const uint64_t* region_begins, const uint64_t* region_ends,
                                  uint32_t n_regions, uint32_t region_cap, uint64_t carry_cur, uint64_t* out, uint64_t out_cap,
                                  unsigned long long* counters, unsigned long long* host_counters, uint64_t* offsets_scratch,
-                                 uint64_t* prev_scratch, hipStream_t st) {
+                                 uint64_t* prev_scratch, hipStream_t st, uint64_t carry_prev_end, int have_prev) {
+  const uint64_t carry_pe = have_prev ? carry_prev_end : ~0ull;
   const unsigned blocks = n_regions ? (n_regions + kOgcThreads - 1) / kOgcThreads : 1u;
   hipLaunchKernelGGL(offsets_gather_check, dim3(blocks), dim3(kOgcThreads), 0, st, counts, region_begins, region_ends, n_regions,
-                     region_cap, carry_cur, out, out_cap, counters, host_counters, offsets_scratch, prev_scratch);
+                     region_cap, carry_cur, out, out_cap, counters, host_counters, carry_pe, offsets_scratch, prev_scratch);
   if (offsets_scratch != nullptr) {
     uint64_t wblocks = (static_cast<uint64_t>(n_regions) + 3) / 4;
     wblocks = wblocks < 1 ? 1 : wblocks > 16384 ? 16384 : wblocks;
     hipLaunchKernelGGL(gather_regions_by_wave, dim3(static_cast<unsigned>(wblocks)), dim3(256), 0, st, counts, region_begins,
-                       region_ends, offsets_scratch, prev_scratch, n_regions, region_cap, out, out_cap, counters, host_counters);
+                       region_ends, offsets_scratch, prev_scratch, n_regions, region_cap, out, out_cap, counters, host_counters, carry_pe);
   }
 }
 

@@ -104,7 +104,8 @@ int run_linear(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint6
     }
     launch_offsets_gather_check(s->cs_counts.as<uint32_t>(), s->cs_g.as<uint64_t>(), s->cs_e.as<uint64_t>(), static_cast<uint32_t>(m_own),
                                 static_cast<uint32_t>(sub), carry_cur, s->out.as<uint64_t>(), s->out_cap,
-                                s->counters.as<unsigned long long>(), s->host_counters, off_scratch, prev_scratch, st);
+                                s->counters.as<unsigned long long>(), s->host_counters, off_scratch, prev_scratch, st, carry_prev_end,
+                                have_prev);
     RJ_HIP(hipStreamSynchronize(st));
     RJ_HIP(hipGetLastError());
     if (s->host_counters[kCntUnordered] != 0) {
