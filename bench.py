@@ -515,6 +515,36 @@ def literal_and_complex_extras(args, c, out):
     out["behind_scan"] = single_pattern_extra(
         c, rejit_amd, t, n, rxb, "%s MatchAll over the same %d bytes (window behind an unbounded prefix)" % (rxb, n),
         "scan_windows<1> + verify_behind_in_regions", 5, check_behind, None, True, args)
+    # Patterns WITHOUT a fast-forward window (the NFA half of the north star): scan_dense_walk finds, walks and
+    # compacts the candidates in one kernel.  `[a-f]+[0-9]`: a start at 8 % of the bytes of this text (only the
+    # first byte of every run of [a-f] is walked, DevProgram::loop_first).
+    def check_dense(sc):
+        assert sc.stats()["n_matches"] > 1000
+
+    out["dense_scan"] = single_pattern_extra(
+        c, rejit_amd, t, n, "[a-f]+[0-9]", "[a-f]+[0-9] MatchAll over the same %d bytes (no fast-forward window: dense mode)" % n,
+        "scan_dense_walk<1,false>", 5, check_dense, None, True, args)
+    # The line table of a grep-like caller (sample/jrep.cc:294: MatchAll of "^"): a class scan whose OUTPUT is
+    # the traffic -- 16 bytes per line start next to 1 byte read per text byte.
+    nl = torch.arange(60, n, 61, device=dev)
+    t[nl] = 10
+    del nl
+    sc_l = rejit_amd.Scan(rejit_amd.Program("^"))
+    for _ in range(2):
+        sc_l.run(t.data_ptr(), n, stream=c.stream)
+    lms, ltot = [], []
+    for _ in range(5):
+        k = sc_l.run(t.data_ptr(), n, stream=c.stream)
+        st = sc_l.stats()
+        lms.append(st["scan_ms"])
+        ltot.append(st["total_ms"])
+    assert k == n // 61 + 1 + (1 if n % 61 > 60 else 0) or k >= n // 61, "line table count"
+    a_l = sum(lms) / len(lms)
+    bytes_l = n + 16 * k
+    out["line_table"] = {"workload": "`^` MatchAll over %d bytes with a line break every 61 bytes (jrep's line table)" % n, "matches": int(k),
+                         "value": round(n / (sum(ltot) / len(ltot) * 1e-3) / 1e9, 1), "unit": "GB/s of text", "latency_ms": round(sum(ltot) / len(ltot), 4),
+                         "write_bytes_per_launch": 16 * int(k),
+                         "roofline": hbm_roofline("scan_dense_walk<1,true> (n text bytes read + 16 B written per match)", bytes_l, a_l)}
     del t
     torch.cuda.empty_cache()
 

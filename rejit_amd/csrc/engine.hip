@@ -1171,6 +1171,8 @@ void rj_program_free(rj_program* prog) {
       i++;
     }
   }
+  for (rj_program* r : prog->replicas)
+    if (r != nullptr) rj_program_free(r);
   delete prog;
 }
 
@@ -1547,17 +1549,22 @@ int rj_scan_match_full(rj_scan* s, const void* d_text, uint64_t n, void* hip_str
   return *s->host_flag ? 1 : 0;
 }
 
-int64_t rj_match_all(const rj_program* prog, const char* text, size_t n, uint64_t** spans) {
-  ErrnoGuard errno_guard;
+}  // extern "C"
+
+// MatchAll of the starts [own_begin, own_end) of a host text, on the program's device: H2D copy, device
+// pipeline, D2H of the spans (relative to `text`).  rj_match_all is the whole-text case; multi_device.hip
+// runs one of these per device.
+int64_t rejit_amd::rj_match_range_host(const rj_program* prog, const char* text, size_t n, uint64_t own_begin, uint64_t own_end,
+                                       uint64_t carry_cur, uint64_t carry_prev_end, int have_prev, uint64_t** spans) {
   if (spans) *spans = nullptr;
-  if (!prog || (!text && n)) return fail(RJ_BAD_ARGUMENT, "null argument");
+  DeviceGuard on_device(prog->device);
   rj_scan* s = nullptr;
   int rc = host_scan_for(prog, &s);
   if (rc != RJ_OK) return rc;
   const uint8_t* d_text = nullptr;
   rc = stage_text(s, text, n, &d_text);
   if (rc != RJ_OK) return rc;
-  rc = run_pipeline(s, d_text, n, 0, n + 1, 0, 0, 0, s->own_stream);
+  rc = run_pipeline(s, d_text, n, own_begin, own_end, carry_cur, carry_prev_end, have_prev, s->own_stream);
   if (rc != RJ_OK) return rc;
   if (spans && s->result_count) {
     uint64_t* h = static_cast<uint64_t*>(malloc(s->result_count * 2 * sizeof(uint64_t)));
@@ -1575,6 +1582,17 @@ int64_t rj_match_all(const rj_program* prog, const char* text, size_t n, uint64_
   return static_cast<int64_t>(s->result_count);
 }
 
+extern "C" {
+
+int64_t rj_match_all(const rj_program* prog, const char* text, size_t n, uint64_t** spans) {
+  ErrnoGuard errno_guard;
+  if (spans) *spans = nullptr;
+  if (!prog || (!text && n)) return fail(RJ_BAD_ARGUMENT, "null argument");
+  int64_t result = 0;
+  if (multi_device_match_all(prog, text, n, spans, &result)) return result;  // large text, several GPUs: one range per device
+  return rj_match_range_host(prog, text, n, 0, n + 1, 0, 0, 0, spans);
+}
+
 int64_t rj_match_all_batch(const rj_program* prog, const char* const* texts, const size_t* sizes, size_t n_texts,
                            uint64_t* counts, uint64_t** spans) {
   ErrnoGuard errno_guard;
@@ -1583,6 +1601,17 @@ int64_t rj_match_all_batch(const rj_program* prog, const char* const* texts, con
   for (size_t i = 0; i < n_texts; i++)
     if (!texts[i] && sizes[i]) return fail(RJ_BAD_ARGUMENT, "null text in batch");
   if (n_texts == 0) return 0;
+  int64_t result = 0;
+  if (multi_device_match_all_batch(prog, texts, sizes, n_texts, counts, spans, &result)) return result;  // files spread over the GPUs
+  return rj_match_all_batch_one_device(prog, texts, sizes, n_texts, counts, spans);
+}
+
+}  // extern "C"
+
+int64_t rejit_amd::rj_match_all_batch_one_device(const rj_program* prog, const char* const* texts, const size_t* sizes, size_t n_texts,
+                                                 uint64_t* counts, uint64_t** spans) {
+  if (spans) *spans = nullptr;
+  DeviceGuard on_device(prog->device);
   if (prog->batch_separator < 0 || n_texts == 1) {
     // no byte can safely end a text inside a concatenation (or nothing to batch): text by text
     std::vector<uint64_t> all;
@@ -1691,6 +1720,8 @@ int64_t rj_match_all_batch(const rj_program* prog, const char* const* texts, con
   }
   return static_cast<int64_t>(m);
 }
+
+extern "C" {
 
 void rj_free_spans(uint64_t* spans) { free(spans); }
 

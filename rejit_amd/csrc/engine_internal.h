@@ -11,6 +11,7 @@
 #include <cerrno>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "../../include/rejit_hip.h"
 #include "device_program.h"
@@ -82,6 +83,7 @@ struct rj_program {
   rejit_amd::DevGraph graph{};        // uploaded only for patterns with q8_risk
   rejit_amd::DeviceBuffer graph_blob;
   int device = 0;
+  std::vector<rj_program*> replicas;  // multi_device.hip: the same pattern compiled on the other devices (index = device), lazily
   uint64_t id = 0;          // unique per compile: keys per-thread caches (a freed program's address may be reused)
   int window_alphabet = 0;  // distinct byte values among the fixed window bytes
   bool window_nibbles = false;  // those values differ in their low nibble (nibble filter usable)
@@ -133,6 +135,30 @@ int resolve_selection(rj_scan* s, const FinalizeParams& fp, hipStream_t st);
 bool linear_path_fits(const rj_program* rp);
 int run_linear(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, uint64_t carry_cur,
                uint64_t carry_prev_end, int have_prev, hipStream_t st);
+
+// multi_device.hip: one call over every visible device (false = not applicable, take the one-device path)
+bool multi_device_match_all(const rj_program* prog, const char* text, size_t n, uint64_t** spans, int64_t* result);
+bool multi_device_match_all_batch(const rj_program* prog, const char* const* texts, const size_t* sizes, size_t n_texts, uint64_t* counts,
+                                  uint64_t** spans, int64_t* result);
+// engine.hip: MatchAll of the starts [own_begin, own_end) of a host text on the program's device (spans relative
+// to `text`), and the one-device batch
+int64_t rj_match_range_host(const rj_program* prog, const char* text, size_t n, uint64_t own_begin, uint64_t own_end, uint64_t carry_cur,
+                            uint64_t carry_prev_end, int have_prev, uint64_t** spans);
+int64_t rj_match_all_batch_one_device(const rj_program* prog, const char* const* texts, const size_t* sizes, size_t n_texts,
+                                      uint64_t* counts, uint64_t** spans);
+
+// the calling thread runs on `device` until the guard goes (a program's tables live in ONE device's HBM)
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) (void)hipSetDevice(device);
+    else prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
 
 }  // namespace rejit_amd
 #endif

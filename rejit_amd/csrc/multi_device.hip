@@ -1,0 +1,342 @@
+// rejit_amd/csrc/multi_device.hip -- one C-ABI call spread over every visible GPU, from ONE process.
+//
+// The reference's callers get their parallelism from host threads sharing a compiled Regej
+// (sample/jrep.cc:408-493 fans files over threads, sample/regexdna-multithread.cc:117-167 patterns); a
+// rejit.h caller of this library would otherwise only ever use GPU 0 -- the byte-range / file sharding
+// of rejit_amd/sharding.py lives above the C boundary (one process per GPU, torch.distributed).  Here
+// the same partitioning runs BELOW it:
+//
+//   rj_match_all        a host text of >= 256 MiB whose longest match is bounded is cut into one
+//                       contiguous range of starts per device (+ halo of max_len - 1 bytes, + 64 bytes
+//                       to the left for the line-start context); a thread per device uploads its part
+//                       over its own PCIe link, runs the ordinary pipeline on its replica of the
+//                       program, and the selection is carried over the cuts on the host exactly as
+//                       sharding.sharded_match_all does over RCCL (a shard is re-run only when the true
+//                       carry-in reaches into its first match)
+//   rj_match_all_batch  the texts are packed onto the devices by size (largest first, least loaded),
+//                       every device runs its share as one batch, results return in the caller's order
+//
+// Nothing is exchanged between devices: matches travel to the host anyway (that is the API).  A
+// replica = the same pattern compiled with the other device current (tables in that device's HBM).
+// RJ_VIRTUAL_DEVICES=k (tests, measurement): k shards on however many real devices there are.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+#include "engine_internal.h"
+
+namespace rejit_amd {
+
+namespace {
+
+constexpr size_t kMultiDeviceMinBytes = 256ull << 20;
+
+std::mutex g_replica_mutex;
+
+int real_devices() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+}  // namespace
+
+int shard_count() {
+  static const int virt = [] {
+    const char* v = getenv("RJ_VIRTUAL_DEVICES");
+    return v ? atoi(v) : 0;
+  }();
+  if (virt > 0) return std::min(virt, 64);
+  return real_devices();
+}
+
+size_t multi_device_min_bytes() {
+  static const size_t v = [] {
+    const char* e = getenv("RJ_MULTI_DEVICE_MIN_BYTES");  // tests lower it
+    return e ? static_cast<size_t>(atoll(e)) : kMultiDeviceMinBytes;
+  }();
+  return v;
+}
+
+// the program of shard `shard` (device shard % real devices); replica 0 on the program's own device is
+// the program itself
+const rj_program* replica_for(const rj_program* prog, int shard, int* device) {
+  const int real = std::max(real_devices(), 1);
+  const int dev = (prog->device + shard) % real;
+  *device = dev;
+  if (dev == prog->device) return prog;
+  std::lock_guard<std::mutex> lock(g_replica_mutex);
+  rj_program* root = const_cast<rj_program*>(prog);
+  if (root->replicas.size() < static_cast<size_t>(real)) root->replicas.resize(static_cast<size_t>(real), nullptr);
+  if (root->replicas[static_cast<size_t>(dev)] == nullptr) {
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(dev) != hipSuccess) return nullptr;
+    rj_program* r = nullptr;
+    const int rc = rj_compile(prog->pattern.c_str(), &r);
+    (void)hipSetDevice(prev);
+    if (rc != RJ_OK) return nullptr;
+    root->replicas[static_cast<size_t>(dev)] = r;
+  }
+  return root->replicas[static_cast<size_t>(dev)];
+}
+
+namespace {
+
+// One worker thread per shard, kept for the life of the process: a worker's per-thread scan objects
+// (device text buffer, pinned staging, stream) then survive from call to call like those of any caller
+// thread.  run() hands every worker one task and waits for all of them.
+class ShardWorkers {
+ public:
+  void run(std::vector<std::function<void()>>& tasks) {
+    std::unique_lock<std::mutex> lock(mu_);
+    while (threads_.size() < tasks.size()) {
+      const size_t id = threads_.size();
+      slots_.emplace_back();
+      threads_.emplace_back([this, id] { loop(id); });
+      threads_.back().detach();
+    }
+    pending_ = tasks.size();
+    for (size_t i = 0; i < tasks.size(); i++) slots_[i] = &tasks[i];
+    wake_.notify_all();
+    done_.wait(lock, [this] { return pending_ == 0; });
+  }
+
+ private:
+  void loop(size_t id) {
+    std::unique_lock<std::mutex> lock(mu_);
+    for (;;) {
+      wake_.wait(lock, [&] { return slots_[id] != nullptr; });
+      std::function<void()>* task = slots_[id];
+      lock.unlock();
+      (*task)();
+      lock.lock();
+      slots_[id] = nullptr;
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable wake_, done_;
+  std::deque<std::function<void()>*> slots_;
+  std::vector<std::thread> threads_;
+  size_t pending_ = 0;
+};
+
+std::mutex g_workers_mutex;  // one multi-device call at a time uses the workers
+
+ShardWorkers& workers() {
+  static ShardWorkers* w = new ShardWorkers;  // (never destroyed: the HIP runtime may be gone at exit)
+  return *w;
+}
+
+struct ShardResult {
+  int64_t count = 0;
+  std::vector<uint64_t> spans;  // global offsets
+  std::string error;
+  int rc = RJ_OK;
+};
+
+// the starts [lo, hi) of `text` on shard `shard`: spans in GLOBAL offsets
+void run_shard(const rj_program* prog, int shard, const char* text, size_t n, uint64_t lo, uint64_t hi, uint64_t max_len,
+               uint64_t carry_cur, uint64_t carry_prev_end, int have_prev, ShardResult* out) {
+  int dev = 0;
+  const rj_program* rp = replica_for(prog, shard, &dev);
+  if (rp == nullptr) {
+    out->rc = RJ_DEVICE_ERROR;
+    out->error = "no replica of the program on device " + std::to_string(dev);
+    return;
+  }
+  const uint64_t vis_lo = lo > 64 ? (lo - 64) & ~static_cast<uint64_t>(15) : 0;
+  const uint64_t vis_hi = std::min<uint64_t>(n, hi + max_len);
+  const uint64_t local_n = vis_hi - vis_lo;
+  uint64_t* spans = nullptr;
+  const int64_t c = rj_match_range_host(rp, text + vis_lo, local_n, lo - vis_lo, std::min<uint64_t>(hi, n + 1) - vis_lo,
+                                        carry_cur > vis_lo ? carry_cur - vis_lo : 0, carry_prev_end > vis_lo ? carry_prev_end - vis_lo : 0,
+                                        have_prev, &spans);
+  if (c < 0) {
+    out->rc = static_cast<int>(c);
+    out->error = rj_last_error();
+    return;
+  }
+  out->count = c;
+  out->spans.resize(static_cast<size_t>(2 * c));
+  for (int64_t i = 0; i < 2 * c; i++) out->spans[static_cast<size_t>(i)] = spans[i] + vis_lo;
+  rj_free_spans(spans);
+}
+
+}  // namespace
+
+// rj_match_all over all devices; returns false when the call should take the single-device path
+bool multi_device_match_all(const rj_program* prog, const char* text, size_t n, uint64_t** spans, int64_t* result) {
+  const int shards = shard_count();
+  const uint64_t max_len = prog->host->max_len;
+  if (shards < 2 || n < multi_device_min_bytes() || max_len == Program::kUnboundedLen || max_len > (1u << 20)) return false;
+  // contiguous ranges of starts, cut at multiples of 4096; the last one owns the start n (the empty match at the end)
+  std::vector<uint64_t> cuts(static_cast<size_t>(shards) + 1, 0);
+  for (int r = 1; r < shards; r++) cuts[static_cast<size_t>(r)] = std::max(cuts[static_cast<size_t>(r) - 1], (n * r / shards) & ~static_cast<uint64_t>(4095));
+  cuts[static_cast<size_t>(shards)] = n + 1;
+  std::vector<ShardResult> res(static_cast<size_t>(shards));
+  std::lock_guard<std::mutex> one_call(g_workers_mutex);
+  {
+    std::vector<std::function<void()>> tasks;
+    for (int r = 0; r < shards; r++)
+      tasks.emplace_back([=, &res, &cuts] {
+        run_shard(prog, r, text, n, cuts[static_cast<size_t>(r)], cuts[static_cast<size_t>(r) + 1], max_len, 0, 0, 0, &res[static_cast<size_t>(r)]);
+      });
+    workers().run(tasks);
+  }
+  // carry the selection over the cuts, left to right (sharding.py: carry_out / needs_rerun)
+  uint64_t cur = 0, prev_end = 0;
+  int have_prev = 0;
+  for (int r = 0; r < shards; r++) {
+    ShardResult& s = res[static_cast<size_t>(r)];
+    if (s.rc != RJ_OK) {
+      rj_fail(s.rc, "%s", s.error.c_str());
+      *result = s.rc;
+      return true;
+    }
+    if (r > 0 && have_prev && s.count > 0) {
+      const uint64_t b = s.spans[0], e = s.spans[1];
+      if (b < cur || (b == e && prev_end == b)) {  // the first match would change under the true carry-in
+        ShardResult again;
+        run_shard(prog, r, text, n, cuts[static_cast<size_t>(r)], cuts[static_cast<size_t>(r) + 1], max_len, cur, prev_end, 1, &again);
+        if (again.rc != RJ_OK) {
+          rj_fail(again.rc, "%s", again.error.c_str());
+          *result = again.rc;
+          return true;
+        }
+        s = std::move(again);
+      }
+    }
+    if (s.count > 0) {
+      const uint64_t b = s.spans[static_cast<size_t>(2 * s.count - 2)], e = s.spans[static_cast<size_t>(2 * s.count - 1)];
+      cur = e > b ? e : b + 1;
+      prev_end = e;
+      have_prev = 1;
+    }
+  }
+  int64_t total = 0;
+  for (const ShardResult& s : res) total += s.count;
+  if (spans != nullptr && total > 0) {
+    uint64_t* h = static_cast<uint64_t*>(malloc(static_cast<size_t>(total) * 2 * sizeof(uint64_t)));
+    if (h == nullptr) {
+      *result = rj_fail(RJ_DEVICE_ERROR, "out of host memory");
+      return true;
+    }
+    size_t at = 0;
+    for (const ShardResult& s : res) {
+      if (!s.spans.empty()) memcpy(h + at, s.spans.data(), s.spans.size() * sizeof(uint64_t));
+      at += s.spans.size();
+    }
+    *spans = h;
+  }
+  *result = total;
+  return true;
+}
+
+// rj_match_all_batch over all devices; false = take the single-device path
+bool multi_device_match_all_batch(const rj_program* prog, const char* const* texts, const size_t* sizes, size_t n_texts, uint64_t* counts,
+                                  uint64_t** spans, int64_t* result) {
+  const int shards = shard_count();
+  size_t total_bytes = 0;
+  for (size_t i = 0; i < n_texts; i++) total_bytes += sizes[i];
+  if (shards < 2 || n_texts < 2 * static_cast<size_t>(shards) || total_bytes < multi_device_min_bytes()) return false;
+  // greedy packing by size, as sharding.partition_files
+  std::vector<size_t> order(n_texts);
+  std::iota(order.begin(), order.end(), size_t{0});
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return sizes[a] > sizes[b]; });
+  std::vector<uint64_t> load(static_cast<size_t>(shards), 0);
+  std::vector<std::vector<size_t>> mine(static_cast<size_t>(shards));
+  for (size_t i : order) {
+    const size_t r = static_cast<size_t>(std::min_element(load.begin(), load.end()) - load.begin());
+    mine[r].push_back(i);
+    load[r] += sizes[i] + 1;
+  }
+  for (auto& v : mine) std::sort(v.begin(), v.end());
+  struct Part {
+    std::vector<const char*> t;
+    std::vector<size_t> s;
+    std::vector<uint64_t> c;
+    uint64_t* spans = nullptr;
+    int64_t rc = 0;
+    std::string error;
+  };
+  std::vector<Part> parts(static_cast<size_t>(shards));
+  std::lock_guard<std::mutex> one_call(g_workers_mutex);
+  std::vector<std::function<void()>> tasks;
+  for (int r = 0; r < shards; r++) {
+    Part& p = parts[static_cast<size_t>(r)];
+    for (size_t i : mine[static_cast<size_t>(r)]) {
+      p.t.push_back(texts[i]);
+      p.s.push_back(sizes[i]);
+    }
+    p.c.assign(p.t.size(), 0);
+    tasks.emplace_back([prog, r, &p, spans]() {
+      int dev = 0;
+      const rj_program* rp = replica_for(prog, r, &dev);
+      if (rp == nullptr || hipSetDevice(dev) != hipSuccess) {
+        p.rc = RJ_DEVICE_ERROR;
+        p.error = "no replica of the program on device " + std::to_string(dev);
+        return;
+      }
+      if (p.t.empty()) return;
+      p.rc = rj_match_all_batch_one_device(rp, p.t.data(), p.s.data(), p.t.size(), p.c.data(), spans ? &p.spans : nullptr);
+      if (p.rc < 0) p.error = rj_last_error();
+    });
+  }
+  workers().run(tasks);
+  int64_t total = 0;
+  for (Part& p : parts) {
+    if (p.rc < 0) {
+      for (Part& q : parts) rj_free_spans(q.spans);
+      *result = rj_fail(static_cast<int>(p.rc), "%s", p.error.c_str());
+      return true;
+    }
+    total += p.rc;
+  }
+  // back into the caller's order
+  std::vector<size_t> shard_of(n_texts), index_in(n_texts);
+  for (int r = 0; r < shards; r++)
+    for (size_t k = 0; k < mine[static_cast<size_t>(r)].size(); k++) {
+      shard_of[mine[static_cast<size_t>(r)][k]] = static_cast<size_t>(r);
+      index_in[mine[static_cast<size_t>(r)][k]] = k;
+    }
+  std::vector<std::vector<uint64_t>> first_span(static_cast<size_t>(shards));  // prefix of the span counts per shard
+  for (int r = 0; r < shards; r++) {
+    const Part& p = parts[static_cast<size_t>(r)];
+    first_span[static_cast<size_t>(r)].assign(p.c.size() + 1, 0);
+    for (size_t k = 0; k < p.c.size(); k++) first_span[static_cast<size_t>(r)][k + 1] = first_span[static_cast<size_t>(r)][k] + p.c[k];
+  }
+  uint64_t* h = nullptr;
+  if (spans != nullptr && total > 0) {
+    h = static_cast<uint64_t*>(malloc(static_cast<size_t>(total) * 2 * sizeof(uint64_t)));
+    if (h == nullptr) {
+      for (Part& q : parts) rj_free_spans(q.spans);
+      *result = rj_fail(RJ_DEVICE_ERROR, "out of host memory");
+      return true;
+    }
+  }
+  size_t at = 0;
+  for (size_t i = 0; i < n_texts; i++) {
+    const Part& p = parts[shard_of[i]];
+    const uint64_t c = p.c[index_in[i]];
+    counts[i] = c;
+    if (h != nullptr && c > 0) memcpy(h + 2 * at, p.spans + 2 * first_span[shard_of[i]][index_in[i]], static_cast<size_t>(c) * 2 * sizeof(uint64_t));
+    at += c;
+  }
+  for (Part& q : parts) rj_free_spans(q.spans);
+  if (spans != nullptr) *spans = h;
+  *result = total;
+  return true;
+}
+
+}  // namespace rejit_amd
