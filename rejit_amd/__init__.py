@@ -8,8 +8,8 @@ library is missing, or no HIP device is present, every call fails loudly.
 from .api import (RejitError, Program, Scan, MultiScan, build, library_path, load_library, device_count)  # noqa: F401
 
 # VALU operations the fused nine-pattern scan kernel (scan_windows_fused, shared-prefilter form) spends per
-# text byte in its streaming loop, counted from its ISA: 26 to pack a lane's 16
-# positions + 16 x (2 v_xad + 2 v_and + 2 v_bcnt + 1.5 v_min) = 146 per 16 bytes.  The exact per-pattern
-# tests on the chunks that pass the prefilter (about every second one on DNA) come on top, so the VALU
-# roofline bench.py derives from this number is a lower bound of the kernel's VALU utilisation.
-FUSED_VALU_OPS_PER_BYTE = 9.1
+# text byte on the regexdna text: MEASURED (rocprofv3 --pmc SQ_INSTS_VALU, profiles/r02_pmc_sq.txt:
+# 120.86 M wave-instructions per 500 MB launch = 247.5 per 1-KiB chunk and wave = 15.5 per byte and lane).
+# Of these 9.1 are the streaming loop (26 to pack a lane's 16 positions + 16 x (2 v_xad + 2 v_and + 2 v_bcnt
+# + 1.5 v_min), from the ISA); the rest are the exact per-pattern tests on the chunks that pass the prefilter.
+FUSED_VALU_OPS_PER_BYTE = 15.5

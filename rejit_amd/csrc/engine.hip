@@ -1006,11 +1006,45 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       // (mode 2 only: the kernels of the two streams overlap in time, so a per-kernel duration no
       // longer means what a roofline needs; the default keeps them on the caller's stream)
       const bool two_streams = m->mode == 2;
+      // mode 1, every pattern with the regexdna shape (two nibble-form windows): the scans as one launch
+      static const bool no_train = getenv("RJ_NO_TRAIN") != nullptr;  // measurement override
+      bool train = m->mode == 1 && !no_train;
+      for (int p = 0; p < P && train; p++) train = fusable(m->scans[static_cast<size_t>(p)]->prog);
+      if (train) {
+        TrainParams tp{};
+        tp.text = d_text;
+        tp.n = n;
+        tp.sb = sb;
+        tp.se = se;
+        tp.span_chunks = geo.span_chunks;
+        tp.n_patterns = static_cast<uint32_t>(P);
+        bool masked = false;
+        for (int p = 0; p < P; p++) {
+          rj_scan* s = m->scans[static_cast<size_t>(p)];
+          const DevProgram& D = s->prog->dev;
+          tp.value[p][0] = fp.value[p][0];
+          tp.mask[p][0] = fp.mask[p][0];
+          tp.value[p][1] = fp.value[p][1];
+          tp.mask[p][1] = fp.mask[p][1];
+          masked = masked || fp.mask[p][0] != 0xFFFFFFFFu || fp.mask[p][1] != 0xFFFFFFFFu;
+          tp.offset[p] = D.win_offset;
+          tp.len[p] = D.win_len;
+          tp.wlo[p] = sb + D.win_offset;
+          const uint64_t last_w = n >= D.win_len ? n - D.win_len + 1 : 0;
+          tp.whi[p] = std::min<uint64_t>(se + D.win_offset, last_w);
+          if (tp.whi[p] < tp.wlo[p]) tp.whi[p] = tp.wlo[p];
+          tp.hits[p] = s->hits.as<uint64_t>();
+          tp.region_cap[p] = static_cast<uint32_t>(caps[static_cast<size_t>(p)]);
+          tp.hit_counts[p] = s->hit_counts.as<uint32_t>();
+          tp.zero_counters[p] = s->counters.as<unsigned long long>();
+        }
+        launch_scan_windows_train(tp, masked, geo.grid, s0->ev[1], s0->ev[2], st);
+      }
       if (two_streams) {
         RJ_HIP(hipEventRecord(m->fork, st));
         RJ_HIP(hipStreamWaitEvent(m->second, m->fork, 0));
       }
-      for (int p = 0; p < P; p++) {
+      for (int p = 0; p < P && !train; p++) {
         rj_scan* s = m->scans[static_cast<size_t>(p)];
         const DevProgram& D = s->prog->dev;
         ScanParams sp{};

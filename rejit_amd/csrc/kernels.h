@@ -101,6 +101,23 @@ struct FusedParams {
   uint32_t* hit_counts[kMaxFused];
   unsigned long long* zero_counters[kMaxFused];  // may be null
 };
+// several patterns' scans as ONE launch (scan_windows_train): per pattern what ScanParams + WindowSet hold
+struct TrainParams {
+  const uint8_t* text;
+  uint64_t n;
+  uint64_t sb, se;
+  uint64_t span_chunks;
+  uint32_t n_patterns;
+  uint32_t value[kMaxFused][2], mask[kMaxFused][2];   // nibble form, see WindowSet::nibble
+  uint32_t offset[kMaxFused], len[kMaxFused];
+  uint64_t wlo[kMaxFused], whi[kMaxFused];
+  uint64_t* hits[kMaxFused];
+  uint32_t region_cap[kMaxFused];
+  uint32_t* hit_counts[kMaxFused];
+  unsigned long long* zero_counters[kMaxFused];
+};
+void launch_scan_windows_train(const TrainParams& t, bool masked, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
+
 struct BoundsParams {
   int n_lists;
   const uint64_t* spans[kMaxFused];

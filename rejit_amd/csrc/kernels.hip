@@ -315,7 +315,7 @@ __device__ __forceinline__ void load_chunk(const uint8_t* text, uint64_t at, uin
 }
 
 template <int K, bool TWO, bool MASKED, bool TWOLEVEL, bool NIB>
-__global__ __launch_bounds__(256) void scan_windows(ScanParams a, WindowSet ws) {
+__device__ __forceinline__ void scan_windows_body(const ScanParams& a, const WindowSet& ws) {
   const int lane = lane_id();
   const uint64_t wave = scalar_wave_index();
   if (a.zero_counters != nullptr && wave == 0 && lane < kCntSize) a.zero_counters[lane] = 0;
@@ -374,6 +374,44 @@ __global__ __launch_bounds__(256) void scan_windows(ScanParams a, WindowSet ws) 
     windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(d, t * kChunk + lane_off, a, ws, hits);
   }
   if (lane == 0) a.hit_counts[wave] = hits.count;
+}
+
+template <int K, bool TWO, bool MASKED, bool TWOLEVEL, bool NIB>
+__global__ __launch_bounds__(256) void scan_windows(ScanParams a, WindowSet ws) {
+  scan_windows_body<K, TWO, MASKED, TWOLEVEL, NIB>(a, ws);
+}
+
+// A TRAIN of scans in one launch: the same streaming scan for several patterns, one after the other, every
+// wave over its own span -- pattern p + 1 starts in a wave as soon as that wave is done with pattern p.
+// Launched one by one (rj_multi mode 1 of round 1) every kernel boundary cost the drain of the last
+// workgroups and the ramp-up of the next grid: 94-96 us per 500 MB pattern against 88 us in the
+// kernel's steady state.  Every pattern still streams the whole text from HBM on its own (a wave's span is
+// 30 KB, the text 500 MB: nothing survives in L2 from one pattern to the next), so the launch's algorithmic
+// bytes are patterns x text bytes.  Two 5..8-byte nibble-form windows per pattern (regexdna's shape).
+template <bool MASKED>
+__global__ __launch_bounds__(256) void scan_windows_train(TrainParams t) {
+  for (uint32_t p = 0; p < t.n_patterns; p++) {
+    ScanParams a;
+    a.text = t.text;
+    a.n = t.n;
+    a.sb = t.sb;
+    a.se = t.se;
+    a.wlo = t.wlo[p];
+    a.whi = t.whi[p];
+    a.span_chunks = t.span_chunks;
+    a.hits = t.hits[p];
+    a.region_cap = t.region_cap[p];
+    a.hit_counts = t.hit_counts[p];
+    a.zero_counters = t.zero_counters[p];
+    WindowSet ws;
+    ws.value0[0] = t.value[p][0];
+    ws.value0[1] = t.value[p][1];
+    ws.mask0[0] = t.mask[p][0];
+    ws.mask0[1] = t.mask[p][1];
+    ws.offset = t.offset[p];
+    ws.len = t.len[p];
+    scan_windows_body<2, true, MASKED, false, true>(a, ws);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2381,6 +2419,11 @@ void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows
     if (ws.masked) launch_windows_k<false, true, false, false>(n_windows, a, ws, grid, t0, t1, st);
     else launch_windows_k<false, false, false, false>(n_windows, a, ws, grid, t0, t1, st);
   }
+}
+
+void launch_scan_windows_train(const TrainParams& t, bool masked, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+  if (masked) hipExtLaunchKernelGGL((scan_windows_train<true>), dim3(grid), dim3(256), 0, st, t0, t1, 0, t);
+  else hipExtLaunchKernelGGL((scan_windows_train<false>), dim3(grid), dim3(256), 0, st, t0, t1, 0, t);
 }
 
 void launch_scan_windows_fused(const FusedParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
