@@ -320,6 +320,10 @@ def run_regexdna(args, c):
         # whole text: algorithmic bytes per launch = 9 x text bytes (1 byte read per text byte per MatchAll call)
         out["roofline"] = hbm_roofline("scan_windows_train<NIB> (9 pattern scans per launch)", len(patterns) * own_bytes, avg_scan_ms,
                                        pmc_traffic("regexdna", fasta_n=args.fasta_n) if world == 1 else None, len(scan_ms))
+        out["roofline"]["note"] = ("a wave scans its own 32 KB span for pattern after pattern, so passes 2..9 are served by the 256 MiB "
+                                   "Infinity Cache (rocprofv3's FETCH_SIZE counts those hits too): `achieved` is the rate of ALGORITHMIC "
+                                   "bytes, above what HBM alone delivers (6.29 TB/s measured copy ceiling).  The streaming scan's HBM-bound "
+                                   "figures: `separate_launches` (one pattern per kernel) and `hbm_not_cache` (2.5 GB text)")
     else:
         out["roofline"] = hbm_roofline("scan_windows<2,NIB>", own_bytes, avg_scan_ms, None, len(scan_ms))
     extras = rank == 0 and world == 1 and not args.no_extra
@@ -336,6 +340,27 @@ def run_regexdna(args, c):
         return time.perf_counter() - t1, r
 
     if extras and use_multi:
+        # One launch PER PATTERN (rj_multi mode 3, the headline of round 1): every kernel streams the whole text
+        # from HBM with nothing of it left in a cache from the pattern before, so this is the per-kernel HBM
+        # roofline of the streaming scan; the train above is faster because a wave's passes 2..9 over its own
+        # 32 KB span hit the Infinity Cache.
+        multi_k = rejit_amd.MultiScan(progs)
+        multi_k.set_mode(3)
+        kms = []
+
+        def per_kernel_step():
+            r = multi_k.run(text_ptr, n_local, stream=stream)
+            kms.extend(multi_k.scan(i).stats()["scan_ms"] for i in range(len(progs)))
+            return r
+
+        ek, ck = time_steps(per_kernel_step)
+        assert ck == counts, "per-kernel launches disagree with the train"
+        kms = kms[2 * len(progs):]
+        out["separate_launches"] = {"calls": "rj_multi_run mode 3: one scan kernel per pattern, back to back, batched tails",
+                                    "value": round(scanned / ek / 1e9, 3), "unit": "GB/s", "ms_per_step": round(ek / args.steps * 1e3, 4),
+                                    "roofline": hbm_roofline("scan_windows<2,NIB>", own_bytes, sum(kms) / len(kms),
+                                                             pmc_traffic("regexdna_single", fasta_n=args.fasta_n), len(kms))}
+        del multi_k
         es, cs = time_steps(lambda: [run_one(i) for i in range(len(scans))])
         assert cs == counts, "synchronous calls disagree with rj_multi_run"
         out["serial_calls"] = {"calls": "9 x rj_scan_run per step", "value": round(scanned / es / 1e9, 3), "unit": "GB/s",

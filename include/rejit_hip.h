@@ -157,9 +157,11 @@ rj_scan* rj_multi_scan(rj_multi* multi, int i);
  * match begins before its left neighbour's last end re-runs that pattern with rj_scan_run(rj_multi_scan(m, i),
  * ..., carry) -- 32 bytes per pattern instead of the match list. */
 int rj_multi_bounds(rj_multi* multi, uint64_t* bounds, void* hip_stream);
-/* mode 0 (default): fuse when possible; mode 1: never fuse (one scan kernel per pattern, back to back on
- * the caller's stream); mode 2: as 1, the scan kernels alternating between the caller's stream and a second
- * one so that consecutive kernels overlap at their boundaries */
+/* mode 0 (default): fuse when possible; mode 1: never fuse -- every pattern scans the whole text on its own,
+ * all of them in ONE launch when the patterns have the regexdna shape (scan_windows_train), else one kernel
+ * per pattern back to back on the caller's stream; mode 2: one kernel per pattern, alternating between the
+ * caller's stream and a second one so that consecutive kernels overlap at their boundaries; mode 3: one
+ * kernel per pattern back to back (measurement: the per-kernel HBM roofline) */
 int rj_multi_set_mode(rj_multi* multi, int mode);
 /* duration of the last run's scan kernel(s) in ms, summed (0 when the patterns ran one by one) */
 float rj_multi_scan_ms(const rj_multi* multi);

@@ -372,8 +372,8 @@ class MultiScan:
         self.how = 0
 
     def set_mode(self, mode: int) -> None:
-        """0: fuse the scans when possible (default); 1: one scan kernel per pattern; 2: as 1, on two
-        alternating streams."""
+        """0: fuse the scans when possible (default); 1: every pattern scans the text on its own, as one launch
+        when possible; 2: one kernel per pattern on two alternating streams; 3: one kernel per pattern."""
         _check(self._lib.rj_multi_set_mode(self._h, mode))
 
     def __del__(self):

@@ -1008,7 +1008,7 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       const bool two_streams = m->mode == 2;
       // mode 1, every pattern with the regexdna shape (two nibble-form windows): the scans as one launch
       static const bool no_train = getenv("RJ_NO_TRAIN") != nullptr;  // measurement override
-      bool train = m->mode == 1 && !no_train;
+      bool train = m->mode == 1 && !no_train;  // (mode 3: one launch per pattern, as round 1 did)
       for (int p = 0; p < P && train; p++) train = fusable(m->scans[static_cast<size_t>(p)]->prog);
       if (train) {
         TrainParams tp{};
@@ -1559,7 +1559,7 @@ int rj_multi_bounds(rj_multi* m, uint64_t* bounds, void* hip_stream) {
 }
 
 int rj_multi_set_mode(rj_multi* m, int mode) {
-  if (!m || mode < 0 || mode > 2) return fail(RJ_BAD_ARGUMENT, "bad argument");
+  if (!m || mode < 0 || mode > 3) return fail(RJ_BAD_ARGUMENT, "bad argument");
   m->mode = mode;
   return RJ_OK;
 }

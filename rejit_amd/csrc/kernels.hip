@@ -385,9 +385,12 @@ __global__ __launch_bounds__(256) void scan_windows(ScanParams a, WindowSet ws) 
 // wave over its own span -- pattern p + 1 starts in a wave as soon as that wave is done with pattern p.
 // Launched one by one (rj_multi mode 1 of round 1) every kernel boundary cost the drain of the last
 // workgroups and the ramp-up of the next grid: 94-96 us per 500 MB pattern against 88 us in the
-// kernel's steady state.  Every pattern still streams the whole text from HBM on its own (a wave's span is
-// 30 KB, the text 500 MB: nothing survives in L2 from one pattern to the next), so the launch's algorithmic
-// bytes are patterns x text bytes.  Two 5..8-byte nibble-form windows per pattern (regexdna's shape).
+// kernel's steady state.  More than the boundaries is saved: a wave's passes 2..P run over the 32 KB span it
+// has just read, and the spans of all resident waves (~150 MB) fit the 256 MiB Infinity Cache, so only the
+// first pass of a span comes from HBM -- 77 us per 500 MB pattern.  (On a text several times the cache --
+// bench.py `hbm_not_cache`, 2.5 GB -- the spans are 5 x larger and the passes stream from HBM again.)  The
+// launch's algorithmic bytes are patterns x text bytes.  Two 5..8-byte nibble-form windows per pattern
+// (regexdna's shape); every other set of patterns gets one launch per pattern.
 template <bool MASKED>
 __global__ __launch_bounds__(256) void scan_windows_train(TrainParams t) {
   for (uint32_t p = 0; p < t.n_patterns; p++) {
