@@ -772,6 +772,39 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
   if (sb >= se) return RJ_OK;
   if ((reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) return fail(RJ_BAD_ARGUMENT, "device text must be 16-byte aligned");
   const auto wall0 = std::chrono::steady_clock::now();
+  static const bool no_small = getenv("RJ_NO_SMALL") != nullptr;  // measurement override
+  if (n <= kSmallMaxText && rp->dev.n_words <= 4 && rp->dev.table_words <= kSmallMaxTableWords && !no_small) {
+    // one launch, one synchronise: the whole MatchAll in one workgroup (kernels.hip: match_small)
+    if (s->small_out == nullptr) {
+      RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->small_out), static_cast<size_t>(kSmallMaxCands) * 2 * sizeof(uint64_t)));
+      RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->small_hdr), 2 * sizeof(unsigned long long)));
+    }
+    SmallParams sp{};
+    sp.text = d_text;
+    sp.n = static_cast<uint32_t>(n);
+    sp.sb = static_cast<uint32_t>(sb);
+    sp.se = static_cast<uint32_t>(se);
+    sp.carry_cur = carry_cur;
+    sp.carry_prev_end = carry_prev_end;
+    sp.have_prev = have_prev;
+    sp.q8_risk = rp->host->q8_risk ? 1 : 0;
+    sp.out = s->small_out;
+    sp.out_cap = kSmallMaxCands;
+    sp.hdr = s->small_hdr;
+    s->small_hdr[1] = 1;
+    launch_match_small(sp, rp->dev, st);
+    RJ_HIP(hipStreamSynchronize(st));
+    RJ_HIP(hipGetLastError());
+    if (s->small_hdr[1] == 0) {
+      s->result_count = s->small_hdr[0];
+      s->result = s->small_out;   // pinned host memory: readable from the device and from the host
+      s->stats.n_candidates = s->result_count;
+      s->stats.n_matches = s->result_count;
+      s->stats.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+      return RJ_OK;
+    }
+    // too many candidates, a long walk, or a Q8-sensitive adjacency: the general pipeline
+  }
   const bool windows = rp->dev.mode == 1;
   if (windows || dense_walk_fits(rp->dev) || se - sb <= kDenseSegment || (s->linear_hint && linear_path_fits(rp))) {
     int rc = run_range(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
@@ -852,7 +885,31 @@ int host_scan_for(const rj_program* prog, rj_scan** out) {
   return RJ_OK;
 }
 
+// the first `pairs` result pairs of the last run into host memory (the results of the small-text kernel
+// already ARE in host memory)
+hipError_t copy_result_pairs(rj_scan* s, uint64_t* dst, uint64_t first, uint64_t pairs, hipStream_t st) {
+  if (pairs == 0) return hipSuccess;
+  if (s->result == s->small_out && s->small_out != nullptr) {
+    memcpy(dst, s->small_out + 2 * first, pairs * 2 * sizeof(uint64_t));
+    return hipSuccess;
+  }
+  hipError_t e = hipMemcpyAsync(dst, s->result + 2 * first, pairs * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  return e;
+}
+
 int stage_text(rj_scan* s, const char* text, size_t n, const uint8_t** d_text) {
+  static const bool no_small = getenv("RJ_NO_SMALL") != nullptr;
+  const DevProgram& D = s->prog->dev;
+  if (n <= kSmallMaxText && D.n_words <= 4 && D.table_words <= kSmallMaxTableWords && !no_small) {
+    // a small text stays in (pinned) host memory: match_small reads it over PCIe in one round trip, which
+    // beats a copy command plus its completion wait; should the general pipeline have to take the run
+    // after all, its kernels read the same memory (slower, rare)
+    if (s->small_text == nullptr) RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->small_text), kSmallMaxText + 64));
+    if (n) memcpy(s->small_text, text, n);
+    *d_text = reinterpret_cast<const uint8_t*>(s->small_text);
+    return RJ_OK;
+  }
   RJ_HIP(s->text.reserve(((n + 64 + 4095) / 4096) * 4096));
   if (n) RJ_HIP(hipMemcpyAsync(s->text.p, text, n, hipMemcpyHostToDevice, s->own_stream));
   *d_text = s->text.as<uint8_t>();
@@ -1242,6 +1299,9 @@ void rj_scan_destroy(rj_scan* s) {
   if (s->host_counters) (void)hipHostFree(s->host_counters);
   if (s->host_flag) (void)hipHostFree(s->host_flag);
   if (s->pinned) (void)hipHostFree(s->pinned);
+  if (s->small_out) (void)hipHostFree(s->small_out);
+  if (s->small_hdr) (void)hipHostFree(s->small_hdr);
+  if (s->small_text) (void)hipHostFree(s->small_text);
   for (auto& e : s->ev)
     if (e) (void)hipEventDestroy(e);
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
@@ -1605,8 +1665,7 @@ int64_t rejit_amd::rj_match_range_host(const rj_program* prog, const char* text,
     if (!h) return fail(RJ_DEVICE_ERROR, "out of host memory");
     // (on the scan's own stream: a blocking hipMemcpy goes through the NULL stream, which serialises
     // the streams of all the other threads that share the pattern)
-    hipError_t e = hipMemcpyAsync(h, s->result, s->result_count * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s->own_stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(s->own_stream);
+    hipError_t e = copy_result_pairs(s, h, 0, s->result_count, s->own_stream);
     if (e != hipSuccess) {
       free(h);
       return fail(RJ_DEVICE_ERROR, "hipMemcpy failed: %s", hipGetErrorString(e));
@@ -1731,10 +1790,7 @@ int64_t rejit_amd::rj_match_all_batch_one_device(const rj_program* prog, const c
   if (rc != RJ_OK) return rc;
   const uint64_t m = s->result_count;
   std::vector<uint64_t> pairs(2 * m);
-  if (m) {
-    RJ_HIP(hipMemcpyAsync(pairs.data(), s->result, m * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s->own_stream));
-    RJ_HIP(hipStreamSynchronize(s->own_stream));
-  }
+  if (m) RJ_HIP(copy_result_pairs(s, pairs.data(), 0, m, s->own_stream));
   // the matches are ordered by begin: one merge pass assigns them to their texts
   for (size_t i = 0; i < n_texts; i++) counts[i] = 0;
   size_t t = 0;
@@ -1798,8 +1854,7 @@ static int first_match(const rj_program* prog, const char* text, size_t n, uint6
     if (rc != RJ_OK) return rc;
     if (s->result_count > 0) {
       uint64_t pair[2];
-      RJ_HIP(hipMemcpyAsync(pair, s->result, sizeof(pair), hipMemcpyDeviceToHost, s->own_stream));
-      RJ_HIP(hipStreamSynchronize(s->own_stream));
+      RJ_HIP(copy_result_pairs(s, pair, 0, 1, s->own_stream));
       if (begin) *begin = pair[0];
       if (end) *end = pair[1];
       return 1;

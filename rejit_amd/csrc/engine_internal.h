@@ -117,6 +117,11 @@ struct rj_scan {
   const uint8_t* pending_text = nullptr;
   uint64_t pending_n = 0;
   hipStream_t pending_stream = nullptr;
+  // small texts (match_small): pinned, device-visible buffers -- the result pairs + header the kernel writes,
+  // and the staging copy of a small HOST text (the kernel reads it over PCIe: no copy command, no device buffer)
+  uint64_t* small_out = nullptr;
+  unsigned long long* small_hdr = nullptr;
+  char* small_text = nullptr;
   // host-text path
   rejit_amd::DeviceBuffer text;
   char* pinned = nullptr;  // staging for rj_match_all_batch

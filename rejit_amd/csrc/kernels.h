@@ -118,6 +118,26 @@ struct TrainParams {
 };
 void launch_scan_windows_train(const TrainParams& t, bool masked, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 
+// ---- small texts: ONE kernel, one workgroup, one host synchronise (match_small): scan + verify + selection
+// for a text of <= kSmallMaxText bytes and a lane-sized automaton.  hdr[0] = matches, hdr[1] = 1 when the
+// general pipeline has to take the run (too many candidates, a walk limit, a Q8-sensitive adjacency).
+constexpr uint32_t kSmallMaxText = 32768;
+constexpr uint32_t kSmallMaxCands = 8192;
+constexpr uint32_t kSmallMaxTableWords = 4096;
+struct SmallParams {
+  const uint8_t* text;        // device-accessible (HBM or pinned host memory)
+  uint32_t n;
+  uint32_t sb, se;            // starts [sb, se), se <= n + 1
+  uint64_t carry_cur, carry_prev_end;
+  int have_prev;
+  int q8_risk;
+  uint64_t* out;              // (begin, end) pairs, device-accessible
+  uint32_t out_cap;
+  unsigned long long* hdr;    // [2]
+};
+size_t small_lds_bytes(const DevProgram& P, uint32_t n);
+void launch_match_small(const SmallParams& a, const DevProgram& P, hipStream_t st);
+
 struct BoundsParams {
   int n_lists;
   const uint64_t* spans[kMaxFused];

@@ -1656,6 +1656,157 @@ __global__ __launch_bounds__(1024) void finalize_small(FinalizeParams a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Small texts in ONE launch.  The general pipeline is three kernels and one synchronise -- ~35 us per call
+// however small the text, ~60 us with the copies of a host text -- which a caller that matches file by
+// file (the reference's sample/jrep.cc:261-313 does one MatchAll per file, and a second one for the line
+// table) pays per file.  Here one workgroup of 1024 lanes does the whole MatchAll of a text of up to 32 KiB:
+//   text (read straight from pinned host memory when the caller's buffer is on the host) and tables -> LDS;
+//   every lane takes a contiguous slice of start positions: candidate test + longest match from LDS
+//   (the same rj_lane_longest), length + 1 into a 16-bit array;
+//   a workgroup scan lays the candidates out in position order;
+//   "already the result" check in parallel, else the sequential rule on one lane (few candidates);
+//   pairs and count go straight to the output (pinned host memory for host callers).
+template <int NQ>
+__global__ __launch_bounds__(1024) void match_small(SmallParams a, DevProgram P) {
+  extern __shared__ uint32_t tab[];
+  __shared__ uint32_t wave_sums[16];
+  __shared__ int s_flags[4];  // 0: fallback, 1: not in place, 2: adjacent
+  const DevProgram Q = stage_tables(P, tab, P.table_words);
+  const uint32_t n = a.n;
+  uint8_t* txt = reinterpret_cast<uint8_t*>(tab + ((P.table_words + 3u) & ~3u));
+  const uint32_t txt_bytes = (n + 31u) & ~15u;
+  uint16_t* len1 = reinterpret_cast<uint16_t*>(txt + txt_bytes);
+  uint32_t* cands = reinterpret_cast<uint32_t*>(txt + txt_bytes + ((2u * (n + 2u) + 15u) & ~15u));
+  const uint32_t tid = threadIdx.x;
+  if (tid < 4) s_flags[tid] = 0;
+  for (uint32_t i = tid * 16; i < txt_bytes; i += 1024 * 16) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (i + 16 <= n) {
+      v = *reinterpret_cast<const uint4*>(a.text + i);  // (a.text is 16-byte aligned)
+    } else {
+      uint32_t w[4] = {0, 0, 0, 0};
+      for (uint32_t k = 0; k < 16 && i + k < n; k++) w[k >> 2] |= static_cast<uint32_t>(a.text[i + k]) << (8 * (k & 3));
+      v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    *reinterpret_cast<uint4*>(txt + i) = v;
+  }
+  __syncthreads();
+  // ---- longest match from every start of this lane's slice
+  const uint32_t per = (n + 1 + 1023) / 1024;
+  const uint32_t s0 = tid * per, s1 = s0 + per < n + 1 ? s0 + per : n + 1;
+  uint32_t mine = 0;
+  for (uint32_t s = s0; s < s1; s++) {
+    uint32_t l = 0;
+    if (s >= a.sb && s < a.se && rj_dense_candidate(Q, txt, n, s) &&
+        !(Q.loop_first && s > 0 && ((Q.first_bytes[txt[s - 1] >> 5] >> (txt[s - 1] & 31)) & 1u))) {
+      uint64_t e = 0;
+      bool overrun = false;
+      if (rj_lane_longest<NQ>(Q, txt, n, s, &e, &overrun)) l = static_cast<uint32_t>(e - s) + 1;
+      if (overrun) s_flags[0] = 1;
+    }
+    len1[s] = static_cast<uint16_t>(l);
+    mine += l != 0;
+  }
+  // ---- exclusive scan of the lanes' counts
+  const int lane = lane_id(), wv = tid >> 6;
+  uint32_t inc = mine;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const uint32_t v = __shfl_up(inc, o);
+    if (lane >= o) inc += v;
+  }
+  if (lane == kWave - 1) wave_sums[wv] = inc;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+  for (int w = 0; w < 16; w++) {
+    if (w < wv) before += wave_sums[w];
+    total += wave_sums[w];
+  }
+  if (total > kSmallMaxCands || total > a.out_cap) {
+    if (tid == 0) s_flags[0] = 1;
+    total = 0;
+  }
+  __syncthreads();
+  if (s_flags[0]) {
+    if (tid == 0) {
+      a.hdr[0] = 0;
+      a.hdr[1] = 1;
+    }
+    return;
+  }
+  uint32_t at = before + inc - mine;
+  for (uint32_t s = s0; s < s1; s++)
+    if (len1[s]) cands[at++] = (s << 16) | len1[s];
+  __syncthreads();
+  // ---- are the candidates the result as they stand?
+  for (uint32_t i = tid; i < total; i += 1024) {
+    const uint64_t b = cands[i] >> 16, e = b + (cands[i] & 0xFFFFu) - 1;
+    const uint64_t before_it = i ? (cands[i - 1] >> 16) + (cands[i - 1] & 0xFFFFu) - 1 : a.carry_cur;
+    if (!candidate_in_place(b, e, before_it, i == 0, a.have_prev ? a.carry_prev_end : ~0ull)) s_flags[1] = 1;
+    if (i && b == before_it && before_it != 0) s_flags[2] = 1;
+  }
+  __syncthreads();
+  // (Q8, DESIGN.md: where a candidate begins exactly at the end of another the reference's ring artefact can
+  // change the answer; the general pipeline knows what to do)
+  if (a.q8_risk && (s_flags[1] || s_flags[2])) {
+    if (tid == 0) {
+      a.hdr[0] = 0;
+      a.hdr[1] = 1;
+    }
+    return;
+  }
+  if (!s_flags[1]) {
+    for (uint32_t i = tid; i < total; i += 1024) {
+      const uint64_t b = cands[i] >> 16, e = b + (cands[i] & 0xFFFFu) - 1;
+      *reinterpret_cast<ulonglong2*>(a.out + 2 * i) = make_ulonglong2(b, e);
+    }
+    if (tid == 0) {
+      a.hdr[0] = total;
+      a.hdr[1] = 0;
+    }
+    return;
+  }
+  if (tid == 0) {  // overlapping or empty candidates: the sequential rule
+    RjSelectState st;
+    st.cur = a.carry_cur;
+    st.prev_end = a.carry_prev_end;
+    st.have_prev = a.have_prev != 0;
+    unsigned long long k = 0;
+    for (uint32_t i = 0; i < total; i++) {
+      const uint64_t b = cands[i] >> 16, e = b + (cands[i] & 0xFFFFu) - 1;
+      bool taken;
+      if (rj_select_step(&st, b, e, &taken)) {
+        a.out[2 * k] = b;
+        a.out[2 * k + 1] = e;
+        k++;
+      }
+    }
+    a.hdr[0] = k;
+    a.hdr[1] = 0;
+  }
+}
+
+size_t small_lds_bytes(const DevProgram& P, uint32_t n) {
+  const size_t tables = ((static_cast<size_t>(P.table_words) + 3) & ~size_t{3}) * 4;
+  const size_t txt = (n + 31u) & ~15u;
+  const size_t lens = (2u * (n + 2u) + 15u) & ~15u;
+  return tables + txt + lens + static_cast<size_t>(kSmallMaxCands) * 4;
+}
+
+void launch_match_small(const SmallParams& a, const DevProgram& P, hipStream_t st) {
+  const size_t lds = small_lds_bytes(P, a.n);
+  static bool raised[2] = {false, false};
+  const int which = P.n_words <= 2 ? 0 : 1;
+  if (!raised[which]) {  // more than the default 64 KiB of dynamic LDS
+    if (which == 0) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(match_small<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(match_small<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    raised[which] = true;
+  }
+  if (which == 0) hipLaunchKernelGGL((match_small<1>), dim3(1), dim3(1024), lds, st, a, P);
+  else hipLaunchKernelGGL((match_small<2>), dim3(1), dim3(1024), lds, st, a, P);
+}
+
 // Selection over a sorted candidate list of any size (large path).
 //
 // The greedy rule (reference: MatchAllAppendFilter + CheckMatch, src/codegen.cc:36-86,

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""grep over a synthetic source tree, four ways, timed in one script (run on the GPU box):
+  1. the reference's jrep on the reference's own library (oracle/_ref/jrep_ref), 1 thread and -j <cores>
+  2. the reference's jrep UNCHANGED on librejit_hip.so (oracle/_ref/jrep_hip): one MatchAll per file
+  3. samples/jrep_gpu.py: whole batches of files per device pass (rj_match_all_batch)
+usage: jrep_compare.py [n_files] [dir]"""
+import os, shutil, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # synthetic_tree
+
+n_files = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+base = sys.argv[2] if len(sys.argv) > 2 else tempfile.mkdtemp(prefix="jrep_tree_")
+files = bench.synthetic_tree(n_files, 4242)
+total = 0
+for i, data in enumerate(files):
+    d = os.path.join(base, "d%03d" % (i // 200))
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "f%05d.c" % i), "wb") as fh:
+        fh.write(data)
+    total += len(data)
+print("tree: %d files, %.1f MB under %s" % (n_files, total / 1e6, base), flush=True)
+ref = os.path.join(ROOT, "oracle", "_ref")
+cores = os.cpu_count() or 1
+
+
+def run(label, cmd, repeat=3):
+    best, out = None, b""
+    for _ in range(repeat):
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, cwd=base, capture_output=True)
+        dt = time.perf_counter() - t0
+        if r.returncode not in (0, 1):
+            print("%-64s FAILED rc=%d %s" % (label, r.returncode, r.stderr.decode()[-300:]))
+            return None
+        out = r.stdout
+        best = dt if best is None else min(best, dt)
+    print("%-64s %8.1f ms  %7.2f GB/s  (%d output lines)" % (label, best * 1e3, total / best / 1e9, out.count(b"\n")), flush=True)
+    return sorted(out.splitlines())
+
+
+outs = {}
+outs["ref1"] = run("reference jrep, reference library, 1 thread", [os.path.join(ref, "jrep_ref"), "-R", "-H", "-n", "regexp", "."])
+outs["refj"] = run("reference jrep, reference library, -j %d" % min(cores, 64), [os.path.join(ref, "jrep_ref"), "-R", "-H", "-n", "-j", str(min(cores, 64)), "regexp", "."])
+outs["hip1"] = run("reference jrep UNCHANGED on librejit_hip.so, 1 thread", [os.path.join(ref, "jrep_hip"), "-R", "-H", "-n", "regexp", "."])
+outs["hipj"] = run("reference jrep UNCHANGED on librejit_hip.so, -j 16", [os.path.join(ref, "jrep_hip"), "-R", "-H", "-n", "-j", "16", "regexp", "."])
+outs["batch"] = run("samples/jrep_gpu.py (rj_match_all_batch, whole batches per pass)", [sys.executable, os.path.join(ROOT, "samples", "jrep_gpu.py"), "-R", "-H", "-n", "regexp", "."], repeat=2)
+if shutil.which("grep"):
+    outs["grep"] = run("GNU grep -R -H -n", ["grep", "-R", "-H", "-n", "regexp", "."])
+want = outs.get("ref1")
+for k, v in outs.items():
+    if v is not None and want is not None:
+        print("  output of %-6s == reference jrep: %s" % (k, v == want))
+if len(sys.argv) <= 2:
+    shutil.rmtree(base, ignore_errors=True)
