@@ -773,7 +773,8 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
   if ((reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) return fail(RJ_BAD_ARGUMENT, "device text must be 16-byte aligned");
   const auto wall0 = std::chrono::steady_clock::now();
   static const bool no_small = getenv("RJ_NO_SMALL") != nullptr;  // measurement override
-  if (n <= kSmallMaxText && rp->dev.n_words <= 4 && rp->dev.table_words <= kSmallMaxTableWords && !no_small) {
+  if (n <= kSmallMaxText && rp->dev.n_words <= 4 && rp->dev.table_words <= kSmallMaxTableWords && !no_small &&
+      small_lds_bytes(rp->dev, static_cast<uint32_t>(n)) <= small_lds_limit()) {
     // one launch, one synchronise: the whole MatchAll in one workgroup (kernels.hip: match_small)
     if (s->small_out == nullptr) {
       RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->small_out), static_cast<size_t>(kSmallMaxCands) * 2 * sizeof(uint64_t)));
@@ -901,7 +902,8 @@ hipError_t copy_result_pairs(rj_scan* s, uint64_t* dst, uint64_t first, uint64_t
 int stage_text(rj_scan* s, const char* text, size_t n, const uint8_t** d_text) {
   static const bool no_small = getenv("RJ_NO_SMALL") != nullptr;
   const DevProgram& D = s->prog->dev;
-  if (n <= kSmallMaxText && D.n_words <= 4 && D.table_words <= kSmallMaxTableWords && !no_small) {
+  if (n <= kSmallMaxText && D.n_words <= 4 && D.table_words <= kSmallMaxTableWords && !no_small &&
+      small_lds_bytes(D, static_cast<uint32_t>(n)) <= small_lds_limit()) {
     // a small text stays in (pinned) host memory: match_small reads it over PCIe in one round trip, which
     // beats a copy command plus its completion wait; should the general pipeline have to take the run
     // after all, its kernels read the same memory (slower, rare)

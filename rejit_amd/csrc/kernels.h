@@ -122,7 +122,7 @@ void launch_scan_windows_train(const TrainParams& t, bool masked, int grid, hipE
 // for a text of <= kSmallMaxText bytes and a lane-sized automaton.  hdr[0] = matches, hdr[1] = 1 when the
 // general pipeline has to take the run (too many candidates, a walk limit, a Q8-sensitive adjacency).
 constexpr uint32_t kSmallMaxText = 32768;
-constexpr uint32_t kSmallMaxCands = 8192;
+constexpr uint32_t kSmallMaxCands = 4096;
 constexpr uint32_t kSmallMaxTableWords = 4096;
 struct SmallParams {
   const uint8_t* text;        // device-accessible (HBM or pinned host memory)
@@ -136,6 +136,7 @@ struct SmallParams {
   unsigned long long* hdr;    // [2]
 };
 size_t small_lds_bytes(const DevProgram& P, uint32_t n);
+size_t small_lds_limit();   // dynamic LDS a workgroup of match_small may use on this device
 void launch_match_small(const SmallParams& a, const DevProgram& P, hipStream_t st);
 
 struct BoundsParams {

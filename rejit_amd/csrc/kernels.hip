@@ -30,6 +30,7 @@
 //
 // No MFMA: there is no contraction anywhere on this path (integer compares on a byte stream);
 // the roofline is HBM read bandwidth.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -1794,16 +1795,26 @@ size_t small_lds_bytes(const DevProgram& P, uint32_t n) {
   return tables + txt + lens + static_cast<size_t>(kSmallMaxCands) * 4;
 }
 
+// dynamic LDS one workgroup of match_small may use on this device (the runtime's per-block limit, raised to
+// the hardware's where the runtime allows it); queried once
+size_t small_lds_limit() {
+  static const size_t limit = [] {
+    int dev = 0, per_block = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || per_block <= 0) per_block = 64 * 1024;
+    size_t lim = static_cast<size_t>(per_block);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(match_small<1>), hipFuncAttributeMaxDynamicSharedMemorySize, per_block) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(match_small<2>), hipFuncAttributeMaxDynamicSharedMemorySize, per_block) != hipSuccess)
+      lim = std::min<size_t>(lim, 64 * 1024);
+    (void)hipGetLastError();  // (a refused attribute must not surface as a later call's error)
+    return lim - 256;         // room for the kernel's static LDS
+  }();
+  return limit;
+}
+
 void launch_match_small(const SmallParams& a, const DevProgram& P, hipStream_t st) {
   const size_t lds = small_lds_bytes(P, a.n);
-  static bool raised[2] = {false, false};
-  const int which = P.n_words <= 2 ? 0 : 1;
-  if (!raised[which]) {  // more than the default 64 KiB of dynamic LDS
-    if (which == 0) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(match_small<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(match_small<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    raised[which] = true;
-  }
-  if (which == 0) hipLaunchKernelGGL((match_small<1>), dim3(1), dim3(1024), lds, st, a, P);
+  if (P.n_words <= 2) hipLaunchKernelGGL((match_small<1>), dim3(1), dim3(1024), lds, st, a, P);
   else hipLaunchKernelGGL((match_small<2>), dim3(1), dim3(1024), lds, st, a, P);
 }
 
