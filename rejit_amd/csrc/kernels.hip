@@ -1673,6 +1673,17 @@ __global__ __launch_bounds__(1024) void match_small(SmallParams a, DevProgram P)
   extern __shared__ uint32_t tab[];
   __shared__ uint32_t wave_sums[16];
   __shared__ int s_flags[4];  // 0: fallback, 1: not in place, 2: adjacent
+  __shared__ unsigned long long s_count;
+  // every exit goes through `finish`: results first, then (system-scope release) the header the host polls
+  auto finish = [&](unsigned long long count, unsigned long long status) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      a.hdr[0] = count;
+      __threadfence_system();
+      a.hdr[1] = status;
+    }
+  };
   const DevProgram Q = stage_tables(P, tab, P.table_words);
   const uint32_t n = a.n;
   uint8_t* txt = reinterpret_cast<uint8_t*>(tab + ((P.table_words + 3u) & ~3u));
@@ -1730,10 +1741,7 @@ __global__ __launch_bounds__(1024) void match_small(SmallParams a, DevProgram P)
   }
   __syncthreads();
   if (s_flags[0]) {
-    if (tid == 0) {
-      a.hdr[0] = 0;
-      a.hdr[1] = 1;
-    }
+    finish(0, 1);
     return;
   }
   uint32_t at = before + inc - mine;
@@ -1751,10 +1759,7 @@ __global__ __launch_bounds__(1024) void match_small(SmallParams a, DevProgram P)
   // (Q8, DESIGN.md: where a candidate begins exactly at the end of another the reference's ring artefact can
   // change the answer; the general pipeline knows what to do)
   if (a.q8_risk && (s_flags[1] || s_flags[2])) {
-    if (tid == 0) {
-      a.hdr[0] = 0;
-      a.hdr[1] = 1;
-    }
+    finish(0, 1);
     return;
   }
   if (!s_flags[1]) {
@@ -1762,10 +1767,7 @@ __global__ __launch_bounds__(1024) void match_small(SmallParams a, DevProgram P)
       const uint64_t b = cands[i] >> 16, e = b + (cands[i] & 0xFFFFu) - 1;
       *reinterpret_cast<ulonglong2*>(a.out + 2 * i) = make_ulonglong2(b, e);
     }
-    if (tid == 0) {
-      a.hdr[0] = total;
-      a.hdr[1] = 0;
-    }
+    finish(total, 0);
     return;
   }
   if (tid == 0) {  // overlapping or empty candidates: the sequential rule
@@ -1783,9 +1785,10 @@ __global__ __launch_bounds__(1024) void match_small(SmallParams a, DevProgram P)
         k++;
       }
     }
-    a.hdr[0] = k;
-    a.hdr[1] = 0;
+    s_count = k;
   }
+  __syncthreads();
+  finish(s_count, 0);
 }
 
 size_t small_lds_bytes(const DevProgram& P, uint32_t n) {
