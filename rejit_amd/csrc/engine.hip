@@ -777,8 +777,12 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       small_lds_bytes(rp->dev, static_cast<uint32_t>(n)) <= small_lds_limit()) {
     // one launch, one synchronise: the whole MatchAll in one workgroup (kernels.hip: match_small)
     if (s->small_out == nullptr) {
-      RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->small_out), static_cast<size_t>(kSmallMaxCands) * 2 * sizeof(uint64_t)));
-      RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->small_hdr), 2 * sizeof(unsigned long long)));
+      // (fine-grained, coherent: the host polls these while the kernel is still running, so the kernel's
+      // system-scope release has to make its stores visible in order -- coarse-grained pinned memory only
+      // promises visibility at the end of the kernel)
+      RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->small_out), static_cast<size_t>(kSmallMaxCands) * 2 * sizeof(uint64_t),
+                           hipHostMallocCoherent | hipHostMallocMapped));
+      RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->small_hdr), 2 * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped));
     }
     SmallParams sp{};
     sp.text = d_text;
