@@ -777,9 +777,7 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       small_lds_bytes(rp->dev, static_cast<uint32_t>(n)) <= small_lds_limit()) {
     // one launch, one synchronise: the whole MatchAll in one workgroup (kernels.hip: match_small)
     if (s->small_out == nullptr) {
-      // (fine-grained, coherent: the host polls these while the kernel is still running, so the kernel's
-      // system-scope release has to make its stores visible in order -- coarse-grained pinned memory only
-      // promises visibility at the end of the kernel)
+      // (pinned, mapped, coherent host memory: the kernel writes the result where the host reads it)
       RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->small_out), static_cast<size_t>(kSmallMaxCands) * 2 * sizeof(uint64_t),
                            hipHostMallocCoherent | hipHostMallocMapped));
       RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->small_hdr), 2 * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped));
@@ -796,32 +794,12 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     sp.out = s->small_out;
     sp.out_cap = kSmallMaxCands;
     sp.hdr = s->small_hdr;
-    // The kernel's last act is a system-scope release of the header word, so the host polls pinned memory
-    // instead of waiting for the stream's completion signal (~15 us of wake-up on top of a ~10 us kernel);
-    // the stream orders the next launch behind this kernel anyway.  (Bounded: a kernel that does not answer
-    // within ~1 ms is waited for the ordinary way.)
-    volatile unsigned long long* hdr = s->small_hdr;
-    hdr[1] = 2;
+    // (Polling the pinned header instead of waiting for the stream was tried: the call's latency did not
+    // move -- it is launch + kernel, not the wake-up -- and results occasionally arrived stale.)
+    s->small_hdr[1] = 1;
     launch_match_small(sp, rp->dev, st);
+    RJ_HIP(hipStreamSynchronize(st));
     RJ_HIP(hipGetLastError());
-    bool answered = false;
-    const auto spin0 = std::chrono::steady_clock::now();
-    for (uint32_t spins = 0;; spins++) {
-      if (hdr[1] != 2) {
-        answered = true;
-        break;
-      }
-      if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - spin0 > std::chrono::milliseconds(1)) break;
-#if defined(__x86_64__)
-      __builtin_ia32_pause();
-#endif
-    }
-    if (!answered) {
-      RJ_HIP(hipStreamSynchronize(st));
-      RJ_HIP(hipGetLastError());
-      if (hdr[1] == 2) return fail(RJ_DEVICE_ERROR, "match_small did not report a result");
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
     if (s->small_hdr[1] == 0) {
       s->result_count = s->small_hdr[0];
       s->result = s->small_out;   // pinned host memory: readable from the device and from the host
