@@ -1674,6 +1674,11 @@ __global__ __launch_bounds__(1024) void match_small(SmallParams a, DevProgram P)
   __shared__ uint32_t wave_sums[16];
   __shared__ int s_flags[4];  // 0: fallback, 1: not in place, 2: adjacent
   __shared__ unsigned long long s_count;
+  __shared__ uint32_t fb[8];  // first-byte bitmap (indexed by data: LDS -- indexing the by-value struct put it in scratch)
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) fb[k] = P.first_bytes[k];
+  }
   // every exit goes through `finish`: results first, then (system-scope release) the header the host polls
   auto finish = [&](unsigned long long count, unsigned long long status) {
     __threadfence_system();
@@ -1710,8 +1715,14 @@ __global__ __launch_bounds__(1024) void match_small(SmallParams a, DevProgram P)
   uint32_t mine = 0;
   for (uint32_t s = s0; s < s1; s++) {
     uint32_t l = 0;
-    if (s >= a.sb && s < a.se && rj_dense_candidate(Q, txt, n, s) &&
-        !(Q.loop_first && s > 0 && ((Q.first_bytes[txt[s - 1] >> 5] >> (txt[s - 1] & 31)) & 1u))) {
+    bool cand = s >= a.sb && s < a.se;
+    if (cand) {
+      bool ok = false;
+      if (Q.nullable) ok = (Q.nullable >> (Q.n_ctx > 1 ? rj_context(txt, n, s) : 0)) & 1u;
+      if (!ok && s < n) ok = (fb[txt[s] >> 5] >> (txt[s] & 31)) & 1u;
+      cand = ok && !(Q.loop_first && s > 0 && ((fb[txt[s - 1] >> 5] >> (txt[s - 1] & 31)) & 1u));
+    }
+    if (cand) {
       uint64_t e = 0;
       bool overrun = false;
       if (rj_lane_longest<NQ>(Q, txt, n, s, &e, &overrun)) l = static_cast<uint32_t>(e - s) + 1;
