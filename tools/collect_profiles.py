@@ -1,21 +1,23 @@
 #!/usr/bin/env python3
-"""Turn the gpurun_out/prof_<tag>_* files written by tools/profile_round.sh into the committed
-profiles/ files.  usage: collect_profiles.py <tag>"""
-import json, os, sys
+"""Turn the gpurun_out/prof_<tag>_* files written by tools/profile_round.sh (and the probes run with it) into
+the committed profiles/<tag>_* files and profiles/pmc_traffic.json.   usage: collect_profiles.py <tag>"""
+import json, os, shutil, sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 g = lambda name: os.path.join(root, "gpurun_out", f"prof_{tag}_{name}")
-hdr = """# rocprofv3 PMC passes, one counter per pass (MI355X, gfx950, ROCm 7.2), run by tools/profile_round.sh; command per pass:
-#   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
-#   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+P = lambda name: os.path.join(root, "profiles", f"{tag}_{name}")
+hdr = f"""# rocprofv3 PMC passes, one counter group per pass (MI355X, gfx950, ROCm 7.2), run by tools/profile_round.sh; command per pass:
+#   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-big
+#   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-big
 # Unit: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM):
 # FETCH_SIZE counts a wide coalesced 16-B/lane stream at exactly 1/2 -> HBM read bytes = FETCH_SIZE*1024*2.
-# WRITE_SIZE is uncalibrated on gfx950 (guide); it is listed raw and is <0.2% of the read side here.
+# FETCH_SIZE also counts requests the 256 MiB Infinity Cache serves (same guide): for scan_windows_train
+# (nine passes of every wave over its own 32 KB span) it shows the bytes REQUESTED from beyond L2, 0.98 x the
+# 9 x 500 MB algorithmic bytes, not what HBM delivered.  WRITE_SIZE is uncalibrated on gfx950; listed raw.
 
 """
 f, w = open(g("pmc_fetch.txt")).read(), open(g("pmc_write.txt")).read()
-open(os.path.join(root, "profiles", "r01_pmc_hbm_traffic.txt"), "w").write(
-    hdr + "## FETCH_SIZE (KiB per launch)\n" + f + "\n## WRITE_SIZE (KiB per launch, raw)\n" + w)
+open(P("pmc_hbm_traffic.txt"), "w").write(hdr + "## FETCH_SIZE (KiB per launch)\n" + f + "\n## WRITE_SIZE (KiB per launch, raw)\n" + w)
 
 
 def avg(txt, prefix):
@@ -25,25 +27,40 @@ def avg(txt, prefix):
     raise KeyError(prefix)
 
 
-j = {"source": "profiles/r01_pmc_hbm_traffic.txt",
-     "regexdna": {"kernel": "scan_windows<2,true,true,false,true>", "fasta_n": 50000000,
-                  "hbm_read_bytes_per_launch": avg(f, "scan_windows<2, true, true, false, true>") * 1024 * 2},
+j = {"source": f"profiles/{tag}_pmc_hbm_traffic.txt",
+     "regexdna": {"kernel": "scan_windows_train<true> (9 pattern scans per launch; Infinity-Cache hits are counted)", "fasta_n": 50000000,
+                  "hbm_read_bytes_per_launch": avg(f, "scan_windows_train<true>") * 1024 * 2},
+     "regexdna_single": {"kernel": "scan_windows<2,true,true,false,true>", "fasta_n": 50000000,
+                         "hbm_read_bytes_per_launch": avg(f, "scan_windows<2, true, true, false, true>") * 1024 * 2},
+     "fused": {"kernel": "scan_windows_fused<2>", "fasta_n": 50000000, "hbm_read_bytes_per_launch": avg(f, "scan_windows_fused<2>") * 1024 * 2},
      "literal": {"kernel": "scan_windows<1,true,false,true,false>", "bytes": 5000000000,
-                 "hbm_read_bytes_per_launch": avg(f, "scan_windows<1, true, false, true, false>") * 1024 * 2}}
+                 "hbm_read_bytes_per_launch": avg(f, "scan_windows<1, true, false, true, false>") * 1024 * 2},
+     "complex": {"kernel": "scan_windows<1,true,true,true,false> (floating window abcdefgh)", "bytes": 5000000000,
+                 "hbm_read_bytes_per_launch": avg(f, "scan_windows<1, true, true, true, false>") * 1024 * 2}}
 json.dump(j, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
-ks = open(g("kernel_stats.txt")).read()
 prof_line = open(g("bench_profiled.json")).read().strip().splitlines()[-1]
-open(os.path.join(root, "profiles", "r01_bench_kernel_stats.txt"), "w").write(
+open(P("bench_kernel_stats.txt"), "w").write(
     "# rocprofv3 --kernel-trace --stats -- python bench.py --no-extra --no-cpu-baseline   (MI355X)\n"
-    "# = the headline run alone (default K/W, the extras and the CPU sample left out so that the per-kernel\n"
-    "# averages are those of the timed region); summarised from the rocpd database by tools/prof_summary.py.\n"
-    "# The un-profiled bench line (profiles/r01_bench_line.json) reports roofline.avg_launch_ms, which agrees\n"
-    "# with scan_windows avg_us below; under the profiler the event-based time reads ~7% higher:\n# " + prof_line + "\n" + ks)
-open(os.path.join(root, "profiles", "r01_bench_line.json"), "w").write(open(g("bench.json")).read().strip().splitlines()[-1] + "\n")
-d = json.load(open(os.path.join(root, "profiles", "r01_bench_line.json")))
-print("value", d["value"], "ms/step", d["ms_per_step"], "roofline", d["roofline"])
-for k in ("overlapped", "fused"):
-    print(k, d.get(k))
-for k in ("literal_scan", "complex_scan"):
-    print(k, d[k]["value"], d[k]["latency_ms"], d[k]["roofline"]["frac"], d[k]["roofline"]["traffic"])
-print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["kind"])
+    "# = the headline run alone (default K/W; the extras and the CPU sample left out so that the per-kernel averages are\n"
+    "# those of the timed region); summarised from the rocpd database by tools/rocpd_stats.py.  The un-profiled bench line\n"
+    f"# (profiles/{tag}_bench_line.json) reports roofline.avg_launch_ms, which agrees with scan_windows_train avg_us below\n"
+    "# (under the profiler the dispatch-timestamp time reads a few % higher):\n# " + prof_line + "\n" + open(g("kernel_stats.txt")).read())
+open(P("bench_full_kernel_stats.txt"), "w").write(
+    "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-big --steps 5   (MI355X): every kernel of the\n"
+    "# bench line's extras -- train / per-pattern / fused scans, literal, complex (floating), behind, dense, line table, tails\n"
+    + open(g("kernel_stats_full.txt")).read())
+open(P("linear_path_kernel_stats.txt"), "w").write(
+    "# rocprofv3 --kernel-trace --stats -- python tools/linear_probe.py   (MI355X): the linear-time carry scan (cs_*), the blocked\n"
+    "# chain selection (chain_*) and the dense kernel on `[acgt]+` / `a.*b` 64 MiB single-line, `x*` 16 MiB, `[ab]{40}c*` 4 MiB\n"
+    + "\n".join(l for l in open(g("linear_probe.txt")).read().splitlines() if " run " in l) + "\n" + open(g("kernel_stats_linear.txt")).read())
+open(P("pmc_sq_counters.txt"), "w").write(
+    "# rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY\n"
+    "#           --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-big   (MI355X)\n"
+    "# per kernel: calls, avg / min / max of the counter per launch.  SQ_INSTS_VALU are WAVE instructions: / (text bytes / 1024) = per\n"
+    "# 1-KiB chunk and wave = per 16 bytes and lane.\n" + open(g("pmc_sq.txt")).read())
+for src, dst in (("dense_probe.txt", "dense_probe.txt"), ("jrep_compare.txt", "jrep_compare.txt"), ("bench_sizes.txt", "bench_sizes.txt")):
+    if os.path.exists(g(src)):
+        shutil.copy(g(src), P(dst))
+open(P("bench_line.json"), "w").write(open(g("bench.json")).read().strip().splitlines()[-1] + "\n")
+d = json.load(open(P("bench_line.json")))
+print("value", d["value"], "ms/step", d["ms_per_step"], "roofline", d["roofline"]["frac"])
