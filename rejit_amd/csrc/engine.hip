@@ -217,69 +217,11 @@ int upload_program(rj_program* rp) {
   D.rows = base + off_rows;
   D.cls = base + off_cls;
   if (P.q8_risk) {
-    // graph for the exact sequential kernel: int32 arrays, then class bitmaps, then literal bytes
-    const Graph& g = P.graph;
-    const size_t nb = g.byte_edges.size(), nc = g.control_edges.size();
-    std::vector<int32_t> ints;
-    std::vector<uint32_t> classes;
-    std::string lits;
-    std::vector<int32_t> be_src, be_dst, be_len, be_off, ce_src, ce_dst, ce_kind;
-    size_t longest = 1;
-    for (const ByteEdge& e : g.byte_edges) {
-      be_src.push_back(e.src);
-      be_dst.push_back(e.dst);
-      if (!e.bytes.empty()) {
-        be_len.push_back(static_cast<int32_t>(e.bytes.size()));
-        be_off.push_back(static_cast<int32_t>(lits.size()));
-        lits += e.bytes;
-        longest = std::max(longest, e.bytes.size());
-      } else {
-        be_len.push_back(0);
-        be_off.push_back(static_cast<int32_t>(classes.size() / 8));
-        for (int k = 0; k < 8; k++) classes.push_back(e.cls.w[k]);
-      }
-    }
-    for (const ControlEdge& c : g.control_edges) {
-      ce_src.push_back(c.src);
-      ce_dst.push_back(c.dst);
-      ce_kind.push_back(c.kind == ControlKind::Epsilon ? 0 : c.kind == ControlKind::StartOfLine ? 1 : 2);
-    }
-    const size_t words = 4 * nb + 3 * nc + classes.size();
-    const size_t bytes = words * 4 + lits.size() + 16;
-    std::vector<uint8_t> gb(bytes, 0);
-    uint32_t* w = reinterpret_cast<uint32_t*>(gb.data());
-    size_t o = 0;
-    auto put = [&](const std::vector<int32_t>& v) {
-      size_t at = o;
-      if (!v.empty()) memcpy(w + o, v.data(), v.size() * 4);
-      o += v.size();
-      return at;
-    };
-    const size_t o_src = put(be_src), o_dst = put(be_dst), o_len = put(be_len), o_off = put(be_off);
-    const size_t o_cs = put(ce_src), o_cd = put(ce_dst), o_ck = put(ce_kind);
-    const size_t o_cls = o;
-    if (!classes.empty()) memcpy(w + o, classes.data(), classes.size() * 4);
-    o += classes.size();
-    if (!lits.empty()) memcpy(gb.data() + o * 4, lits.data(), lits.size());
-    RJ_HIP(rp->graph_blob.reserve(bytes));
-    RJ_HIP(hipMemcpy(rp->graph_blob.p, gb.data(), bytes, hipMemcpyHostToDevice));
-    const uint32_t* gbase = rp->graph_blob.as<uint32_t>();
-    DevGraph& G = rp->graph;
-    G.n_states = g.n_states;
-    G.entry = g.entry;
-    G.exit = g.exit;
-    G.n_byte_edges = static_cast<int32_t>(nb);
-    G.n_control_edges = static_cast<int32_t>(nc);
-    G.times = 1 + static_cast<int32_t>(std::min<size_t>(longest, 64));
-    G.be_src = reinterpret_cast<const int32_t*>(gbase + o_src);
-    G.be_dst = reinterpret_cast<const int32_t*>(gbase + o_dst);
-    G.be_len = reinterpret_cast<const int32_t*>(gbase + o_len);
-    G.be_off = reinterpret_cast<const int32_t*>(gbase + o_off);
-    G.ce_src = reinterpret_cast<const int32_t*>(gbase + o_cs);
-    G.ce_dst = reinterpret_cast<const int32_t*>(gbase + o_cd);
-    G.ce_kind = reinterpret_cast<const int32_t*>(gbase + o_ck);
-    G.cls = gbase + o_cls;
-    G.lit = reinterpret_cast<const uint8_t*>(gbase + o);
+    // graph for the exact replay kernels (table_layout.h: int32 arrays, class bitmaps, literal bytes)
+    const GraphBlob gb = make_graph_blob(P.graph);
+    RJ_HIP(rp->graph_blob.reserve(gb.bytes.size()));
+    RJ_HIP(hipMemcpy(rp->graph_blob.p, gb.bytes.data(), gb.bytes.size(), hipMemcpyHostToDevice));
+    point_graph(&rp->graph, rp->graph_blob.as<uint8_t>(), gb);
   }
   return RJ_OK;
 }
@@ -744,22 +686,28 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
       s->result_count = s->host_counters[kCntFinal];
       s->stats.n_candidates += s->host_counters[kCntCands];
     }
-    if (fp.detect_adjacent && s->host_counters[kCntAdjacent] != 0 && n <= kExactLimit) {
-      // run the reference's own sequential algorithm on one lane and take ITS answer
-      RJ_HIP(s->ring.reserve(static_cast<size_t>(rp->graph.times) * rp->graph.n_states * sizeof(int64_t)));
-      rc = ensure_lists(s, geo.n_regions, static_cast<uint32_t>(region_cap), std::max<uint64_t>(s->cands_cap, n + 2));
-      if (rc != RJ_OK) return rc;
-      launch_exact_sequential(d_text, n, rp->graph, s->ring.as<int64_t>(), s->out.as<uint64_t>(), s->out_cap,
-                              s->counters.as<unsigned long long>(), st);
-      RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-      RJ_HIP(hipStreamSynchronize(st));
-      RJ_HIP(hipGetLastError());
-      s->result_count = s->host_counters[kCntFinal];
-      s->stats.exact_path = 1;
-    }
+    // (run_pipeline then takes the reference's own answer from the exact replay)
+    if (fp.detect_adjacent && s->host_counters[kCntAdjacent] != 0) s->want_exact = true;
     return RJ_OK;
   }
   return fail(RJ_DEVICE_ERROR, "hit regions kept overflowing");
+}
+
+// automata too wide for the exact replay's synchronisation scan: the reference's loop on ONE lane over the
+// whole text, up to kExactLimit bytes
+int run_exact_one_lane(rj_scan* s, const uint8_t* d_text, uint64_t n, hipStream_t st) {
+  const rj_program* rp = s->prog;
+  RJ_HIP(s->ring.reserve(static_cast<size_t>(rp->graph.times) * rp->graph.n_states * sizeof(int64_t)));
+  int rc = ensure_lists(s, 1, 1, std::max<uint64_t>(s->cands_cap, n + 2));
+  if (rc != RJ_OK) return rc;
+  launch_exact_sequential(d_text, n, rp->graph, s->ring.as<int64_t>(), s->out.as<uint64_t>(), s->out_cap,
+                          s->counters.as<unsigned long long>(), st);
+  RJ_HIP(hipMemcpyAsync(s->host_counters, s->counters.p, kCntSize * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  RJ_HIP(hipStreamSynchronize(st));
+  RJ_HIP(hipGetLastError());
+  s->result_count = s->host_counters[kCntFinal];
+  s->result = s->out.as<uint64_t>();
+  return RJ_OK;
 }
 
 int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, uint64_t carry_cur,
@@ -769,9 +717,27 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
   s->stats = rj_stats{};
   s->result = nullptr;
   s->result_count = 0;
+  s->want_exact = false;
   if (sb >= se) return RJ_OK;
   if ((reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) return fail(RJ_BAD_ARGUMENT, "device text must be 16-byte aligned");
   const auto wall0 = std::chrono::steady_clock::now();
+  const bool whole_text = sb == 0 && se == n + 1 && carry_cur == 0 && !have_prev;
+  if (rp->host->q8_risk && !whole_text && exact_replay_fits(rp)) {
+    // A pattern at risk of the reference's ring artefact (Q8) over a RANGE of the text: the artefact's
+    // state crosses any cut that is not a synchronisation point of the reference's loop, so the range owns
+    // whole segments between such points -- [first point >= sb, first point >= se) -- and replays the
+    // reference's loop over them (exact_replay.hip).  Neighbouring ranges agree on the points, their
+    // results concatenate to the reference's answer, and no carry is needed (nothing crosses a point).
+    int rc = run_exact(s, d_text, n, sb, se, st);
+    if (rc < 0) return rc;
+    if (rc == 1) {
+      s->stats.exact_path = 1;
+      s->stats.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+      s->stats.n_matches = s->result_count;
+      return RJ_OK;
+    }
+    // (a stretch too long to replay: the documented semantics, as for any other pattern)
+  }
   static const bool no_small = getenv("RJ_NO_SMALL") != nullptr;  // measurement override
   if (n <= kSmallMaxText && rp->dev.n_words <= 4 && rp->dev.table_words <= kSmallMaxTableWords && !no_small &&
       small_lds_bytes(rp->dev, static_cast<uint32_t>(n)) <= small_lds_limit()) {
@@ -811,7 +777,8 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     // too many candidates, a long walk, or a Q8-sensitive adjacency: the general pipeline
   }
   const bool windows = rp->dev.mode == 1;
-  if (windows || dense_walk_fits(rp->dev) || se - sb <= kDenseSegment || (s->linear_hint && linear_path_fits(rp))) {
+  const bool single_run = windows || dense_walk_fits(rp->dev) || se - sb <= kDenseSegment || (s->linear_hint && linear_path_fits(rp));
+  if (single_run) {
     int rc = run_range(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
     if (rc != RJ_OK) return rc;
     if (s->result == nullptr) s->result = s->out.as<uint64_t>();  // (the carry scan may have accumulated segments elsewhere)
@@ -842,6 +809,16 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     }
     s->result_count = total;
     s->result = s->acc_out.as<uint64_t>();
+  }
+  if (rp->host->q8_risk && whole_text && (s->want_exact || s->stats.linear_path || !single_run)) {
+    // the result may differ from the reference's by the ring artefact (a candidate begins exactly where
+    // another ends; the carry scan and the segmented dense runs do not look for that): take the
+    // reference's own answer
+    int rc = 0;
+    if (exact_replay_fits(rp)) rc = run_exact(s, d_text, n, 0, n + 1, st);
+    else if (n <= kExactLimit && rp->graph.n_states > 0) rc = run_exact_one_lane(s, d_text, n, st) == RJ_OK ? 1 : RJ_DEVICE_ERROR;
+    if (rc < 0) return rc;
+    if (rc == 1) s->stats.exact_path = 1;
   }
   // (every run_range ends with a stream synchronise, so the host clock covers the whole pipeline
   // and no event commands are needed on the stream)

@@ -95,7 +95,9 @@ struct rj_scan {
   const rj_program* prog = nullptr;
   rejit_amd::DeviceBuffer counters, hits, hit_counts, valid_counts, hit_offsets, cand_begin, cand_end, out, acc_out, keys_out, vals_out, sort_tmp, flag;
   rejit_amd::DeviceBuffer scan_a, scan_b, taken, chain_blocks;  // large-path selection scratch
-  rejit_amd::DeviceBuffer ring;                   // exact sequential kernel
+  rejit_amd::DeviceBuffer ring;                   // exact sequential kernel / exact replay with a ring too big for LDS
+  rejit_amd::DeviceBuffer xr_state, xr_sync, xr_seg_end, xr_offs, xr_counts, xr_scratch;  // exact replay (exact_replay.hip)
+  bool want_exact = false;         // the run just made may differ from the reference by the ring artefact (Q8)
   rejit_amd::DeviceBuffer with_buf, long_gaps, repl_out;  // replace_gather
   // carry scan (linear.hip): summaries (resolved in place), reachability matrices, E / G slabs,
   // entry points, per-sub-chunk counts, wide-automaton scratch
@@ -140,6 +142,13 @@ int resolve_selection(rj_scan* s, const FinalizeParams& fp, hipStream_t st);
 bool linear_path_fits(const rj_program* rp);
 int run_linear(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, uint64_t carry_cur,
                uint64_t carry_prev_end, int have_prev, hipStream_t st);
+
+// exact_replay.hip: the reference's answer, ring artefact included, for the starts the range [sb, se) owns
+// (whole segments between synchronisation points: [first point >= sb, first point >= se)); the text buffer
+// is taken to be the whole text.  1 = done (s->out, s->result_count), 0 = not done (pattern not at risk /
+// too wide, or a stretch without synchronisation point too long to replay), < 0 = error.
+bool exact_replay_fits(const rj_program* rp);
+int run_exact(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, hipStream_t st);
 
 // multi_device.hip: one call over every visible device (false = not applicable, take the one-device path)
 bool multi_device_match_all(const rj_program* prog, const char* text, size_t n, uint64_t** spans, int64_t* result);

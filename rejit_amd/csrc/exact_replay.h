@@ -1,0 +1,252 @@
+// rejit_amd/csrc/exact_replay.h -- bit-exactness with the reference's ring artefact ("Q8", DESIGN.md
+// section 6) on texts of any size: the reference's own no-fast-forward loop (GenerateMatchDirection,
+// reference src/x64/codegen-x64.cc:535-640; SetState :951-987; CheckMatch + ClearStates :401-466,
+// :1075-1097; the sink MatchAllAppendFilter, src/codegen.cc:36-86) replayed segment by segment, one
+// lane per segment, all segments in parallel.
+//
+// What makes that possible: a SYNCHRONISATION POINT is a text position p at which no thread of the
+// reference's ring is alive before the thread of p is seeded.  There the loop's state is the initial one
+// (every pending match has been emitted, no match reaches p, no later match can begin before p), so the
+// text between two synchronisation points is an independent run of the loop and the concatenation of the
+// segments' outputs is the reference's output.  Synchronisation points are found with the position
+// automaton the rest of the engine uses: A(p) = the positions some start s < p has alive after consuming
+// text[p-1], i.e. A(p+1) = (follow(A(p)) | first(ctx(p))) & cls[text[p]].  Every thread of the ring was
+// seeded at some start and advanced over NFA edges -- the ring only ever LOSES threads to ClearStates --
+// so A(p) == 0 implies an empty ring: every such p is a synchronisation point (the converse need not
+// hold; missing one only makes a segment longer).
+//
+// RJ_HD only, no HIP runtime calls: tests/support/exact_exec.cc compiles these bodies with g++.
+#ifndef REJIT_AMD_EXACT_REPLAY_H_
+#define REJIT_AMD_EXACT_REPLAY_H_
+
+#include <stdint.h>
+
+#include "device_program.h"
+
+namespace rejit_amd {
+
+constexpr uint64_t kNoSync = ~0ull;
+
+template <int NQ>
+struct RjAlive {
+  uint64_t S[NQ];
+  uint64_t lin[NQ];
+};
+
+template <int NQ>
+RJ_HD void rj_alive_init(const DevProgram& P, RjAlive<NQ>* A, bool full) {
+  const int W = P.n_words;
+  for (int q = 0; q < NQ; q++) {
+    uint64_t l = 0;
+    if (2 * q < W) l = P.linear[2 * q];
+    if (2 * q + 1 < W) l |= (uint64_t)P.linear[2 * q + 1] << 32;
+    A->lin[q] = l;
+    // `full`: every position alive -- a superset of whatever really is alive at an arbitrary position
+    const int lo = q * 64, hi = lo + 64;
+    uint64_t m = 0;
+    if (full && P.n_pos > lo) m = P.n_pos >= hi ? ~0ull : ((1ull << (P.n_pos - lo)) - 1);
+    A->S[q] = m;
+  }
+}
+
+template <int NQ>
+RJ_HD bool rj_alive_empty(const RjAlive<NQ>& A) {
+  uint64_t any = 0;
+  for (int q = 0; q < NQ; q++) any |= A.S[q];
+  return any == 0;
+}
+
+// A(p) -> A(p+1); p < n
+template <int NQ>
+RJ_HD void rj_alive_step(const DevProgram& P, const uint8_t* t, uint64_t n, uint64_t p, RjAlive<NQ>* A) {
+  const int W = P.n_words;
+  const int ctx = P.n_ctx > 1 ? rj_context(t, n, p) : 0;
+  uint64_t T[NQ];
+  uint64_t carry = 0;
+  for (int q = 0; q < NQ; q++) {
+    const uint64_t x = A->S[q] & A->lin[q];
+    T[q] = (x << 1) | carry;
+    carry = x >> 63;
+  }
+  for (int q = 0; q < NQ; q++) {
+    uint64_t sp = A->S[q] & ~A->lin[q];
+    while (sp) {
+      const int b = __builtin_ctzll(sp);
+      sp &= sp - 1;
+      const uint32_t* row = P.rows + ((size_t)ctx * P.n_rows + P.row_of[q * 64 + b]) * W;
+      for (int j = 0; j < NQ; j++) {
+        uint64_t r = 0;
+        if (2 * j < W) r = row[2 * j];
+        if (2 * j + 1 < W) r |= (uint64_t)row[2 * j + 1] << 32;
+        T[j] |= r;
+      }
+    }
+  }
+  const uint32_t* fr = P.first + ctx * W;
+  const uint32_t* cr = P.cls + (uint32_t)t[p] * W;
+  for (int q = 0; q < NQ; q++) {
+    uint64_t f = 0, c = 0;
+    if (2 * q < W) { f = fr[2 * q]; c = cr[2 * q]; }
+    if (2 * q + 1 < W) {
+      f |= (uint64_t)fr[2 * q + 1] << 32;
+      c |= (uint64_t)cr[2 * q + 1] << 32;
+    }
+    A->S[q] = (T[q] | f) & c;
+  }
+}
+
+// The first synchronisation point at or after x that A() PROVES (A(p) == 0), or n + 1 when there is none
+// up to and including n.  A(x) depends on the text before x: the walk starts `back` bytes earlier with
+// every position alive (a superset), and is exact from the first position at which that superset dies
+// out; `back` grows until that happens before x (position 0 is exact by definition: nothing is alive at
+// the start of the text).  The answer does not depend on `back` -- two callers with different ranges
+// agree on it, which is what lets neighbouring shards split the text at these points.
+template <int NQ>
+RJ_HD uint64_t rj_first_sync(const DevProgram& P, const uint8_t* t, uint64_t n, uint64_t x) {
+  if (x == 0) return 0;
+  if (x > n) return n + 1;
+  for (uint64_t back = 256;; back *= 4) {
+    const uint64_t start = x > back ? x - back : 0;
+    RjAlive<NQ> A;
+    rj_alive_init<NQ>(P, &A, start != 0);
+    bool exact = start == 0;
+    bool widen = false;
+    for (uint64_t p = start;; p++) {
+      if (rj_alive_empty<NQ>(A)) {
+        exact = true;
+        if (p >= x) return p;
+      }
+      if (p >= x && !exact) {
+        widen = true;
+        break;
+      }
+      if (p == n) break;
+      rj_alive_step<NQ>(P, t, n, p, &A);
+    }
+    if (!widen) return n + 1;
+  }
+}
+
+// First proven synchronisation point in [c0, c1) (c1 <= n + 1), or kNoSync.  `exact_start`: c0 is known to
+// be a synchronisation point itself; otherwise the walk starts with every position alive, which can only
+// hide synchronisation points near the beginning of the chunk.
+template <int NQ>
+RJ_HD uint64_t rj_chunk_first_sync(const DevProgram& P, const uint8_t* t, uint64_t n, uint64_t c0, uint64_t c1,
+                                   bool exact_start) {
+  RjAlive<NQ> A;
+  rj_alive_init<NQ>(P, &A, !exact_start);
+  for (uint64_t p = c0; p < c1; p++) {
+    if (rj_alive_empty<NQ>(A)) return p;
+    if (p >= n) break;
+    rj_alive_step<NQ>(P, t, n, p, &A);
+  }
+  return kNoSync;
+}
+
+// The reference's loop over one segment [a, b): a is a synchronisation point (the ring starts empty),
+// b the next one (b <= n), or n + 1 for the segment that runs to the end of the text.  `ring(i)` is slot
+// i of times x states start offsets (int64_t&).  Matches go to out[2*k], out[2*k+1]; begins are strictly
+// increasing and lie in [a, b), so b - a pairs of room suffice.  Returns the number of matches.
+//
+// No state crosses b: nothing is alive there, a match found at b - 1 is emitted before the loop stops,
+// the sink can neither pop (begins before b are smaller than any later begin) nor filter (a match that
+// ENDS at b would mean a thread alive at b) anything of this segment on behalf of a later one.
+template <class Ring>
+RJ_HD uint64_t rj_replay_segment(const DevGraph& G, const uint8_t* t, uint64_t n, uint64_t a, uint64_t b, Ring ring,
+                                 uint64_t* out) {
+  const int S = G.n_states, T = G.times;
+  const int slots = S * T;
+  for (int i = 0; i < slots; i++) ring(i) = -1;
+  int base = 0;
+  uint64_t out_n = 0;
+  bool pending = false;
+  int64_t pb = 0, pe = 0;
+  for (uint64_t p = a;; p++) {
+    if (pending) {
+      // MatchAllAppendFilter: a match replaces those that begin at or after its begin; an empty match
+      // right at the end of the previous one is dropped
+      while (out_n > 0 && static_cast<int64_t>(out[2 * (out_n - 1)]) >= pb) out_n--;
+      if (!(pb == pe && out_n > 0 && static_cast<int64_t>(out[2 * (out_n - 1) + 1]) == pb)) {
+        out[2 * out_n] = static_cast<uint64_t>(pb);
+        out[2 * out_n + 1] = static_cast<uint64_t>(pe);
+        out_n++;
+      }
+      pending = false;
+      if (static_cast<uint64_t>(pe) == n) break;
+    }
+    if (p == b) break;
+    const int t0 = base * S;
+    ring(t0 + G.entry) = static_cast<int64_t>(p);
+    bool changed = true;
+    while (changed) {
+      changed = false;
+      for (int i = 0; i < G.n_control_edges; i++) {
+        const int64_t v = ring(t0 + G.ce_src[i]);
+        if (v < 0) continue;
+        const int kind = G.ce_kind[i];
+        bool ok = true;
+        if (kind == 1) ok = p == 0 || rj_line_break(t[p - 1]);
+        else if (kind == 2) ok = p == n || rj_line_break(t[p]);
+        if (!ok) continue;
+        const int d = t0 + G.ce_dst[i];
+        const int64_t cur = ring(d);
+        if (cur < 0 || v < cur) {
+          ring(d) = v;
+          changed = true;
+        }
+      }
+    }
+    const int64_t xs = ring(t0 + G.exit);
+    if (xs >= 0) {
+      pending = true;
+      pb = xs;
+      pe = static_cast<int64_t>(p);
+      for (int i = 0; i < slots; i++) {
+        const int64_t v = ring(i);
+        if (v > xs && v < pe) ring(i) = -1;
+      }
+    }
+    if (p == n) {
+      if (pending) {
+        while (out_n > 0 && static_cast<int64_t>(out[2 * (out_n - 1)]) >= pb) out_n--;
+        if (!(pb == pe && out_n > 0 && static_cast<int64_t>(out[2 * (out_n - 1) + 1]) == pb)) {
+          out[2 * out_n] = static_cast<uint64_t>(pb);
+          out[2 * out_n + 1] = static_cast<uint64_t>(pe);
+          out_n++;
+        }
+      }
+      break;
+    }
+    for (int i = 0; i < G.n_byte_edges; i++) {
+      const int64_t v = ring(t0 + G.be_src[i]);
+      if (v < 0) continue;
+      const int len = G.be_len[i];
+      int land = 0;
+      if (len > 0) {
+        if (p + static_cast<uint64_t>(len) <= n) {
+          const uint8_t* lit = G.lit + G.be_off[i];
+          bool eq = true;
+          for (int k = 0; k < len && eq; k++) eq = t[p + k] == lit[k];
+          if (eq) land = len;
+        }
+      } else {
+        const uint32_t c = t[p];
+        if ((G.cls[G.be_off[i] * 8 + (c >> 5)] >> (c & 31)) & 1u) land = 1;
+      }
+      if (land) {
+        int tt = base + land;
+        if (tt >= T) tt -= T;
+        const int d = tt * S + G.be_dst[i];
+        const int64_t cur = ring(d);
+        if (cur < 0 || v < cur) ring(d) = v;
+      }
+    }
+    for (int s = 0; s < S; s++) ring(t0 + s) = -1;
+    base++;
+    if (base >= T) base -= T;
+  }
+  return out_n;
+}
+
+}  // namespace rejit_amd
+#endif

@@ -180,6 +180,9 @@ bool multi_device_match_all(const rj_program* prog, const char* text, size_t n, 
   const int shards = shard_count();
   const uint64_t max_len = prog->host->max_len;
   if (shards < 2 || n < multi_device_min_bytes() || max_len == Program::kUnboundedLen || max_len > (1u << 20)) return false;
+  // (a pattern at risk of the ring artefact needs the text up to the next synchronisation point of the
+  // reference's loop, not a fixed halo -- exact_replay.h: one device)
+  if (prog->host->q8_risk) return false;
   // contiguous ranges of starts, cut at multiples of 4096; the last one owns the start n (the empty match at the end)
   std::vector<uint64_t> cuts(static_cast<size_t>(shards) + 1, 0);
   for (int r = 1; r < shards; r++) cuts[static_cast<size_t>(r)] = std::max(cuts[static_cast<size_t>(r) - 1], (n * r / shards) & ~static_cast<uint64_t>(4095));

@@ -8,6 +8,8 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstring>
+#include <string>
 #include <vector>
 
 #include "device_program.h"
@@ -97,6 +99,92 @@ inline uint32_t nullable_bits(const Program& P) {
   for (int c = 0; c < kNumCtx; c++)
     if (P.nullable[P.has_assertions ? c : 0]) bits |= 1u << c;
   return bits;
+}
+
+
+// The NFA graph for the exact replay (DevGraph): seven int32 arrays (byte edges: src dst len off; control
+// edges: src dst kind), the 256-bit classes of the class edges, then the bytes of the literal edges.
+struct GraphBlob {
+  std::vector<uint8_t> bytes;
+  size_t o_src = 0, o_dst = 0, o_len = 0, o_off = 0, o_cs = 0, o_cd = 0, o_ck = 0, o_cls = 0, o_lit = 0;  // in words
+  int32_t n_states = 0, entry = 0, exit = 0, n_byte_edges = 0, n_control_edges = 0, times = 1;
+};
+
+inline GraphBlob make_graph_blob(const Graph& g) {
+  GraphBlob b;
+  std::vector<uint32_t> classes;
+  std::string lits;
+  std::vector<int32_t> be_src, be_dst, be_len, be_off, ce_src, ce_dst, ce_kind;
+  size_t longest = 1;
+  for (const ByteEdge& e : g.byte_edges) {
+    be_src.push_back(e.src);
+    be_dst.push_back(e.dst);
+    if (!e.bytes.empty()) {
+      be_len.push_back(static_cast<int32_t>(e.bytes.size()));
+      be_off.push_back(static_cast<int32_t>(lits.size()));
+      lits += e.bytes;
+      longest = std::max(longest, e.bytes.size());
+    } else {
+      be_len.push_back(0);
+      be_off.push_back(static_cast<int32_t>(classes.size() / 8));
+      for (int k = 0; k < 8; k++) classes.push_back(e.cls.w[k]);
+    }
+  }
+  for (const ControlEdge& c : g.control_edges) {
+    ce_src.push_back(c.src);
+    ce_dst.push_back(c.dst);
+    ce_kind.push_back(c.kind == ControlKind::Epsilon ? 0 : c.kind == ControlKind::StartOfLine ? 1 : 2);
+  }
+  const size_t nb = be_src.size(), nc = ce_src.size();
+  const size_t words = 4 * nb + 3 * nc + classes.size();
+  b.bytes.assign(words * 4 + lits.size() + 16, 0);
+  uint32_t* w = reinterpret_cast<uint32_t*>(b.bytes.data());
+  size_t o = 0;
+  auto put = [&](const std::vector<int32_t>& v) {
+    const size_t at = o;
+    if (!v.empty()) memcpy(w + o, v.data(), v.size() * 4);
+    o += v.size();
+    return at;
+  };
+  b.o_src = put(be_src);
+  b.o_dst = put(be_dst);
+  b.o_len = put(be_len);
+  b.o_off = put(be_off);
+  b.o_cs = put(ce_src);
+  b.o_cd = put(ce_dst);
+  b.o_ck = put(ce_kind);
+  b.o_cls = o;
+  if (!classes.empty()) memcpy(w + o, classes.data(), classes.size() * 4);
+  o += classes.size();
+  b.o_lit = o;
+  if (!lits.empty()) memcpy(b.bytes.data() + o * 4, lits.data(), lits.size());
+  b.n_states = g.n_states;
+  b.entry = g.entry;
+  b.exit = g.exit;
+  b.n_byte_edges = static_cast<int32_t>(nb);
+  b.n_control_edges = static_cast<int32_t>(nc);
+  b.times = 1 + static_cast<int32_t>(std::min<size_t>(longest, 64));
+  return b;
+}
+
+// pointers of G for a blob that lives at `base` (host or device memory)
+inline void point_graph(DevGraph* G, const uint8_t* base, const GraphBlob& b) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(base);
+  G->n_states = b.n_states;
+  G->entry = b.entry;
+  G->exit = b.exit;
+  G->n_byte_edges = b.n_byte_edges;
+  G->n_control_edges = b.n_control_edges;
+  G->times = b.times;
+  G->be_src = reinterpret_cast<const int32_t*>(w + b.o_src);
+  G->be_dst = reinterpret_cast<const int32_t*>(w + b.o_dst);
+  G->be_len = reinterpret_cast<const int32_t*>(w + b.o_len);
+  G->be_off = reinterpret_cast<const int32_t*>(w + b.o_off);
+  G->ce_src = reinterpret_cast<const int32_t*>(w + b.o_cs);
+  G->ce_dst = reinterpret_cast<const int32_t*>(w + b.o_cd);
+  G->ce_kind = reinterpret_cast<const int32_t*>(w + b.o_ck);
+  G->cls = w + b.o_cls;
+  G->lit = reinterpret_cast<const uint8_t*>(w + b.o_lit);
 }
 
 }  // namespace rejit_amd

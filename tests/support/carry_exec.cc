@@ -11,6 +11,7 @@
 
 #include "../../rejit_amd/csrc/behind_walk.h"
 #include "../../rejit_amd/csrc/carry_scan.h"
+#include "../../rejit_amd/csrc/exact_replay.h"
 #include "../../rejit_amd/csrc/lowering.h"
 #include "../../rejit_amd/csrc/table_layout.h"
 
@@ -138,6 +139,42 @@ static long behind_run(const DevProgram& P, const DevProgram& R, const uint8_t* 
   return static_cast<long>(k);
 }
 
+
+// The exact replay (rejit_amd/csrc/exact_replay.h) as exact_replay.hip drives it: ownership
+// [first sync >= sb, first sync >= se), chunks of `chunk` bytes each reporting its first proven
+// synchronisation point, one replay of the reference's loop per segment.  Returns the count; -9 when the
+// automaton is too wide; *n_segments = segments replayed, *longest = the longest of them.
+template <int NQ>
+static long exact_run(const Program& P, const DevProgram& F, const DevGraph& G, const uint8_t* t, uint64_t n, uint64_t chunk,
+                      uint64_t sb, uint64_t se, uint64_t* out, uint64_t cap, uint64_t* n_segments, uint64_t* longest) {
+  (void)P;
+  if (se > n + 1) se = n + 1;
+  const uint64_t y0 = rj_first_sync<NQ>(F, t, n, sb);
+  const uint64_t y1 = se > n ? n + 1 : rj_first_sync<NQ>(F, t, n, se);
+  std::vector<uint64_t> syncs;
+  for (uint64_t c0 = y0; c0 < y1; c0 += chunk) {
+    const uint64_t s = rj_chunk_first_sync<NQ>(F, t, n, c0, std::min(c0 + chunk, y1), c0 == y0);
+    if (s != kNoSync) syncs.push_back(s);
+  }
+  std::vector<int64_t> ring(static_cast<size_t>(G.n_states) * G.times);
+  uint64_t k = 0;
+  *n_segments = syncs.size();
+  *longest = 0;
+  for (size_t i = 0; i < syncs.size(); i++) {
+    const uint64_t a = syncs[i], b = i + 1 < syncs.size() ? syncs[i + 1] : y1;
+    *longest = std::max(*longest, b - a);
+    std::vector<uint64_t> seg(2 * (b - a) + 2);
+    int64_t* r = ring.data();
+    const uint64_t m = rj_replay_segment(G, t, n, a, b, [r](int i2) -> int64_t& { return r[i2]; }, seg.data());
+    for (uint64_t j = 0; j < m; j++, k++)
+      if (k < cap) {
+        out[2 * k] = seg[2 * j];
+        out[2 * k + 1] = seg[2 * j + 1];
+      }
+  }
+  return static_cast<long>(k);
+}
+
 extern "C" {
 
 // MatchAll of the starts in [sb, se) through the carry scan with sub-chunks of `sub` bytes;
@@ -179,6 +216,25 @@ long ce_match_all_behind(const char* re, const uint8_t* text, uint64_t n, uint32
 
 long ce_match_all(const char* re, const uint8_t* text, uint64_t n, uint64_t sub, uint64_t* out, uint64_t cap) {
   return ce_match_range(re, text, n, sub, 0, n + 1, 0, 0, 0, out, cap);
+}
+
+long ce_exact_range(const char* re, const uint8_t* text, uint64_t n, uint64_t chunk, uint64_t sb, uint64_t se, uint64_t* out,
+                    uint64_t cap, uint64_t* n_segments, uint64_t* longest, int* q8_risk) {
+  LowerResult lr = lower(re);
+  if (lr.status != 0) return lr.status;
+  const Program& P = *lr.program;
+  *q8_risk = P.q8_risk ? 1 : 0;
+  const TableBlob fb = make_table_blob(P, P.n_pos, P.n_words, P.has_assertions);
+  DevProgram F{};
+  point_tables(&F, fb.words.data(), fb, P.n_pos);
+  F.nullable = nullable_bits(P);
+  const GraphBlob gb = make_graph_blob(P.graph);
+  DevGraph G{};
+  point_graph(&G, gb.bytes.data(), gb);
+  if (P.n_words <= 2) return exact_run<1>(P, F, G, text, n, chunk, sb, se, out, cap, n_segments, longest);
+  if (P.n_words <= 4) return exact_run<2>(P, F, G, text, n, chunk, sb, se, out, cap, n_segments, longest);
+  if (P.n_words <= 8) return exact_run<4>(P, F, G, text, n, chunk, sb, se, out, cap, n_segments, longest);
+  return -9;
 }
 
 }  // extern "C"

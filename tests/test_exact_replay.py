@@ -1,0 +1,102 @@
+"""CPU tests of the exact replay (rejit_amd/csrc/exact_replay.h): synchronisation points from the
+all-starts position automaton, then the reference's own loop per segment.
+
+Unlike the parallel verifier and the carry scan, this path must give the REFERENCE's answer on every
+input, the ring artefact (Q8) included: the expectation is always the golden vector /
+Oracle.match_all, never match_all_spec.  The header is compiled with g++ into the test-only driver
+tests/support/carry_exec.cc, which drives it the way exact_replay.hip does (ownership by synchronisation
+points, one proven point per chunk, one replay per segment).
+"""
+import ctypes
+import os
+import random
+import subprocess
+
+import pytest
+
+import vectors as V
+from checkers import Oracle
+from test_carry_scan import SO, SRCS, DEPS, CSRC
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+DEPS = DEPS + [os.path.join(CSRC, "exact_replay.h")]
+
+
+@pytest.fixture(scope="module")
+def ce():
+    if not os.path.exists(SO) or any(os.path.getmtime(SO) < os.path.getmtime(s) for s in DEPS):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", SO] + SRCS)
+    lib = ctypes.CDLL(SO)
+    lib.ce_exact_range.restype = ctypes.c_long
+    lib.ce_exact_range.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                   ctypes.c_uint64, _u64p, ctypes.c_uint64, _u64p, _u64p, ctypes.POINTER(ctypes.c_int)]
+    return lib
+
+
+def exact(lib, rx, tx, chunk, sb=0, se=None):
+    se = len(tx) + 1 if se is None else se
+    cap = len(tx) + 2
+    buf = (ctypes.c_uint64 * (2 * cap))()
+    nseg, longest, risk = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_int()
+    n = lib.ce_exact_range(rx, tx, len(tx), chunk, sb, se, buf, cap, ctypes.byref(nseg), ctypes.byref(longest), ctypes.byref(risk))
+    if n < 0:
+        return int(n), None
+    return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n)], (nseg.value, longest.value, risk.value)
+
+
+def test_all_vectors_equal_the_reference(ce):
+    n = risky = 0
+    for rx, tx, exp_all, _ in V.all_matchall_cases():
+        for chunk in (1, 3, 16, 4096):
+            got, info = exact(ce, rx, tx, chunk)
+            if got == -9:
+                assert len(rx) > 256
+                break
+            assert got == exp_all, (rx, tx, chunk, got, exp_all)
+            risky += info[2]
+        n += 1
+    assert n > 2500 and risky > 0
+
+
+AT_RISK = [b".{0,2}.", b"x*", b"(a|ab)(c|bcd)*", b"a*b*", b"(ab|a)*", b".{0,3}x?", b"[ab]*c?", b"(a|b|ab)+", b"^.{0,2}.", b"a?b?c?",
+           b"(x|xy)*z?", b".?.?"]
+
+
+def test_segments_are_independent_and_exact(ce):
+    """Random texts with many adjacent candidates: whole text and every split into two / three ranges give the
+    reference's answer; the segments really are many (the replay is parallel work, not one long run)."""
+    oracle = Oracle()
+    rng = random.Random(11)
+    differs = total_segments = 0
+    for rx in AT_RISK:
+        for trial in range(6):
+            alphabet = [b"abcxyz\n", b"ab", b"abc\n\r", b"xyz \n"][trial % 4]
+            n = rng.choice([0, 1, 7, 64, 300, 1500])
+            tx = bytes(rng.choice(alphabet) for _ in range(n))
+            want = oracle.match_all(rx, tx)
+            differs += want != oracle.match_all_spec(rx, tx)
+            for chunk in (1, 5, 64, 1024):
+                got, info = exact(ce, rx, tx, chunk)
+                assert got == want, (rx, tx, chunk)
+                total_segments += info[0]
+            for cuts in ([n // 2], [n // 3, 2 * n // 3], [1], [n]):
+                bounds = [0] + sorted(cuts) + [n + 1]
+                parts = []
+                for lo, hi in zip(bounds, bounds[1:]):
+                    got, _ = exact(ce, rx, tx, 16, lo, hi)
+                    parts += got
+                assert parts == want, (rx, tx, cuts, parts, want)
+    assert differs >= 3           # the artefact really is exercised
+    assert total_segments > 1000
+
+
+def test_long_stretch_without_synchronisation_point(ce):
+    oracle = Oracle()
+    tx = b"x" * 5000 + b"\n" + b"ab" * 700 + b"q"
+    for rx in (b"x*", b".{0,2}.", b"(ab|a)*"):
+        want = oracle.match_all(rx, tx)
+        for chunk in (64, 1024):
+            got, info = exact(ce, rx, tx, chunk)
+            assert got == want, rx
+    got, info = exact(ce, b"x*", tx, 64)
+    assert info[1] >= 5000        # one segment holds the whole run of x

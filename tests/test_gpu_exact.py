@@ -1,0 +1,123 @@
+"""GPU parity tests (-m gpu) of the exact replay (rejit_amd/csrc/exact_replay.{h,hip}): patterns at risk
+of the reference's ring artefact (Q8) on texts far beyond the 1 MiB the one-lane kernel
+of round 1 could take -- whole text, ranges of a sharded run, the carry-scan path, several 64-MiB batches,
+a ring too big for LDS.  The expectation is always Oracle.match_all, the strict restatement of the
+reference's loop, never the documented semantics."""
+import random
+
+import numpy as np
+import pytest
+
+from test_gpu_linear import gpu_spans_np, oracle_spans_np, rj, oracle  # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+
+
+def text_of(n, alphabet, seed):
+    rng = np.random.default_rng(seed)
+    return np.frombuffer(alphabet, dtype=np.uint8)[rng.integers(0, len(alphabet), size=n)].copy()
+
+
+def run_ranges(rj, scan, d, n, cuts):
+    parts = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        scan.run_tensor(d, own_begin=lo, own_end=hi)
+        parts.append(gpu_spans_np(rj, scan).copy())
+    return np.concatenate(parts) if parts else np.empty((0, 2), dtype=np.uint64)
+
+
+@pytest.mark.parametrize("rx,alphabet", [(b".{0,2}.", b"abcdefghijklmnopqrstuvwxyz0123456789  \n"), (b"(x|xy)*z?", b"xyz"),
+                                         (b"(ab|a)*", b"abc"), (b"a?b?c?", b"abcd")])
+def test_whole_text_and_shards_8mib(rj, oracle, rx, alphabet):
+    import torch
+    n = 8 << 20
+    t = text_of(n, alphabet, 5)
+    want = oracle_spans_np(oracle, rx, t)
+    spec = oracle_spans_np(oracle, rx, t, spec=True)
+    d = torch.from_numpy(t).cuda()
+    scan = rj.Scan(rj.Program(rx))
+    cnt = scan.run_tensor(d)
+    got = gpu_spans_np(rj, scan)
+    st = scan.stats()
+    assert cnt == len(want) and np.array_equal(got, want), (rx, cnt, len(want), len(spec))
+    if len(want) != len(spec) or not np.array_equal(want, spec):
+        assert st["exact_path"] == 1     # the artefact applies on this text: only the replay gets it right
+    # ranges of a sharded run: every range owns whole segments between synchronisation points
+    for cuts in ([0, n // 2 + 7, n + 1], [0, 1, n // 3, n // 3 + 1, 2 * n // 3 + 5, n, n + 1]):
+        got = run_ranges(rj, scan, d, n, cuts)
+        assert np.array_equal(got, want), (rx, cuts)
+
+
+def test_artefact_is_exercised(rj, oracle):
+    """`.{0,2}.` over lines: the reference and the documented semantics differ on a sizeable share of the
+    matches, so the tests above do tell the two apart."""
+    t = text_of(1 << 20, b"abcdefghijklmnopqrstuvwxyz0123456789  \n", 5)
+    want = oracle_spans_np(oracle, b".{0,2}.", t)
+    spec = oracle_spans_np(oracle, b".{0,2}.", t, spec=True)
+    assert len(want) != len(spec)
+
+
+def test_carry_scan_then_replay(rj, oracle, monkeypatch):
+    """At-risk patterns whose candidates outlive the walk limit: the carry scan answers with the documented
+    semantics, the replay then takes the reference's answer."""
+    import torch
+    monkeypatch.setenv("RJ_MAX_WALK", "64")
+    rng = random.Random(3)
+    for rx, alphabet in ((b"x*", b"xxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxy"),
+                         (b"(ab|a)*c?", b"aaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaabc"),
+                         (b"[a-y]+z?", b"abcdefghijklmnopqrstuvwxy" * 8 + b"z ")):
+        n = (4 << 20) + rng.randrange(1000)
+        t = text_of(n, alphabet, rng.randrange(1 << 30))
+        want = oracle_spans_np(oracle, rx, t)
+        d = torch.from_numpy(t).cuda()
+        scan = rj.Scan(rj.Program(rx))
+        cnt = scan.run_tensor(d)
+        st = scan.stats()
+        assert cnt == len(want) and np.array_equal(gpu_spans_np(rj, scan), want), (rx, st)
+        assert st["linear_path"] == 1 and st["exact_path"] == 1, (rx, st)
+
+
+def test_stretch_too_long_to_replay_keeps_documented_semantics(rj, oracle):
+    import torch
+    n = 20 << 20
+    t = np.full(n, ord("x"), dtype=np.uint8)
+    t[n - 5:] = np.frombuffer(b"yxxyx", dtype=np.uint8)
+    want = oracle_spans_np(oracle, b"x*", t)     # (reference == documented semantics on this text)
+    d = torch.from_numpy(t).cuda()
+    scan = rj.Scan(rj.Program(b"x*"))
+    cnt = scan.run_tensor(d)
+    assert cnt == len(want) and np.array_equal(gpu_spans_np(rj, scan), want)
+    assert scan.stats()["exact_path"] == 0
+
+
+def test_several_batches_72mib(rj, oracle):
+    import torch
+    n = 72 << 20
+    t = text_of(n, b"abcdefghijklmnopqrstuvwxyz0123456789  \n", 77)
+    t[(10 << 20):(10 << 20) + (3 << 20)] = ord("q")      # a 3 MiB stretch without a line break inside the first batch
+    want = oracle_spans_np(oracle, b".{0,2}.", t)
+    d = torch.from_numpy(t).cuda()
+    scan = rj.Scan(rj.Program(b".{0,2}."))
+    cnt = scan.run_tensor(d)
+    assert scan.stats()["exact_path"] == 1
+    assert cnt == len(want) and np.array_equal(gpu_spans_np(rj, scan), want)
+    got = run_ranges(rj, scan, d, n, [0, (64 << 20) + 3, n + 1])
+    assert np.array_equal(got, want)
+
+
+def test_ring_in_global_memory(rj, oracle):
+    """A long literal edge makes the ring times x states too big for LDS."""
+    import torch
+    rx = b"(abcdefghijklmnopqrstuvwxyzabcdefghijkl|x|xy)*z?"
+    n = 2 << 20
+    t = text_of(n, b"xyz", 9)
+    lit = np.frombuffer(b"abcdefghijklmnopqrstuvwxyzabcdefghijkl", dtype=np.uint8)
+    for o in range(1000, n - 100, 50021):
+        t[o:o + len(lit)] = lit
+    want = oracle_spans_np(oracle, rx, t)
+    d = torch.from_numpy(t).cuda()
+    scan = rj.Scan(rj.Program(rx))
+    cnt = scan.run_tensor(d)
+    assert cnt == len(want) and np.array_equal(gpu_spans_np(rj, scan), want), scan.stats()
+    host = rj.Program(rx).match_all(t.tobytes()[:300000])
+    assert np.array_equal(np.array(host, dtype=np.uint64).reshape(-1, 2), oracle_spans_np(oracle, rx, t[:300000]))

@@ -74,11 +74,12 @@ def test_forced_carry_scan_vs_oracle(rj, oracle, monkeypatch):
         for alphabet, n in ((b"ab", 300), (b"acgt", 5000), (b"abcx\n", 70000), (b"aabb>xyz09@.cd", 20000)):
             tx = bytes(rng.choices(alphabet, k=n))
             want = oracle.match_all(rx, tx)
-            spec = oracle.match_all_spec(rx, tx)
             got = p.match_all(tx)
-            assert got == spec, (rx, alphabet, n, got[:4], spec[:4])
-            if want != spec or n == 300:
-                continue   # (want != spec: the reference's ring artefact Q8 -- documented semantics)
+            # (the reference's answer also where its ring artefact Q8 applies: the carry scan's result is
+            # then replaced by the exact replay, exact_replay.hip)
+            assert got == want, (rx, alphabet, n, got[:4], want[:4])
+            if n == 300:
+                continue
             d = torch.frombuffer(bytearray(tx), dtype=torch.uint8).cuda()
             cnt = sc.run_tensor(d)
             took += sc.stats()["linear_path"]

@@ -460,7 +460,7 @@ def test_device_scan_shards_and_carry(rj, oracle):
     t = W.random_ascii_numpy(n, seed=3, lo=ord("a"), hi=ord("e"))
     d = torch.from_numpy(t).cuda()
     for rx in (b"abc", b"aa", b"(ab|ba)+", b"a[bc]d?a", b"x*"):
-        want = oracle.match_all_spec(rx, t.tobytes())   # sharded runs implement the documented semantics
+        want = oracle.match_all(rx, t.tobytes())   # (patterns at risk of the ring artefact: ranges own whole segments, exact_replay.hip)
         scan = rj.Scan(prog(rj, rx))
         assert scan.run_tensor(d) == len(want)
         assert scan.spans() == want
