@@ -96,7 +96,8 @@ struct rj_scan {
   rejit_amd::DeviceBuffer counters, hits, hit_counts, valid_counts, hit_offsets, cand_begin, cand_end, out, acc_out, keys_out, vals_out, sort_tmp, flag;
   rejit_amd::DeviceBuffer scan_a, scan_b, taken, chain_blocks;  // large-path selection scratch
   rejit_amd::DeviceBuffer ring;                   // exact sequential kernel / exact replay with a ring too big for LDS
-  rejit_amd::DeviceBuffer xr_state, xr_sync, xr_seg_end, xr_offs, xr_counts, xr_scratch;  // exact replay (exact_replay.hip)
+  rejit_amd::DeviceBuffer xr_state, xr_sync, xr_seg_end, xr_offs, xr_counts, xr_scratch, xr_out;  // exact replay (exact_replay.hip)
+  uint64_t xr_out_cap = 0;
   bool want_exact = false;         // the run just made may differ from the reference by the ring artefact (Q8)
   rejit_amd::DeviceBuffer with_buf, long_gaps, repl_out;  // replace_gather
   // carry scan (linear.hip): summaries (resolved in place), reachability matrices, E / G slabs,

@@ -162,13 +162,18 @@ int run_exact_nq(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
   }
   const int slots = G.n_states * G.times;
   const bool lds = slots <= kLdsRingSlots;
+  // (the pairs go to a buffer of their own: when a later batch turns out not to be replayable the caller
+  // keeps the result it has)
   for (int attempt = 0; attempt < 2; attempt++) {
-    s->result_count = 0;
-    if (y0 >= y1) return 1;  // nothing begins in this range
+    if (y0 >= y1) {  // nothing begins in this range
+      s->result_count = 0;
+      s->result = s->out.as<uint64_t>();
+      return 1;
+    }
     RJ_HIP(hipMemsetAsync(state + kXrTotal, 0, sizeof(unsigned long long), st));
-    if (s->out_cap < (y1 - y0) / 8 + 1024) {  // (a first guess; the count decides below)
-      int rc = ensure_lists(s, 1, 1, (y1 - y0) / 8 + 1024);
-      if (rc != RJ_OK) return rc;
+    if (s->xr_out_cap < (y1 - y0) / 8 + 1024) {  // (a first guess; the count decides below)
+      s->xr_out_cap = (y1 - y0) / 8 + 1024;
+      RJ_HIP(s->xr_out.reserve(s->xr_out_cap * 2 * sizeof(uint64_t)));
     }
     const uint64_t all_chunks = (y1 - y0 + kChunk - 1) / kChunk;
     const uint64_t cap_chunks = std::min(all_chunks, kBatchChunks);
@@ -205,21 +210,21 @@ int run_exact_nq(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       hipLaunchKernelGGL(xr_offsets, dim3(1), dim3(1024), 0, st, s->xr_counts.as<uint32_t>(), nb, s->xr_offs.as<uint64_t>(), state);
       hipLaunchKernelGGL(xr_compact, dim3(static_cast<int>((nb * 64 + 255) / 256)), dim3(256), 0, st, s->xr_sync.as<uint64_t>(),
                          s->xr_counts.as<uint32_t>(), s->xr_offs.as<uint64_t>(), nb, ys, s->xr_scratch.as<uint64_t>(),
-                         s->out.as<uint64_t>(), s->out_cap);
+                         s->xr_out.as<uint64_t>(), s->xr_out_cap);
       ys = final ? y1 : last;
     }
     RJ_HIP(hipMemcpyAsync(h, state, sizeof(h), hipMemcpyDeviceToHost, st));
     RJ_HIP(hipStreamSynchronize(st));
     RJ_HIP(hipGetLastError());
     const uint64_t total = h[kXrTotal];
-    if (total <= s->out_cap) {
+    if (total <= s->xr_out_cap) {
       s->result_count = total;
-      s->result = s->out.as<uint64_t>();
+      s->result = s->xr_out.as<uint64_t>();
       return 1;
     }
     // the result did not fit: make room and replay once more
-    int rc = ensure_lists(s, 1, 1, std::max<uint64_t>(s->cands_cap, total + 1));
-    if (rc != RJ_OK) return rc;
+    s->xr_out_cap = total + 1;
+    RJ_HIP(s->xr_out.reserve(s->xr_out_cap * 2 * sizeof(uint64_t)));
   }
   return rj_fail(RJ_DEVICE_ERROR, "exact replay: result kept overflowing");
 }

@@ -94,7 +94,7 @@ def test_several_batches_72mib(rj, oracle):
     import torch
     n = 72 << 20
     t = text_of(n, b"abcdefghijklmnopqrstuvwxyz0123456789  \n", 77)
-    t[(10 << 20):(10 << 20) + (3 << 20)] = ord("q")      # a 3 MiB stretch without a line break inside the first batch
+    t[(10 << 20):(10 << 20) + (1 << 19)] = ord("q")      # a 512 KiB stretch without a line break (one lane replays it: ~2 us per byte)
     want = oracle_spans_np(oracle, b".{0,2}.", t)
     d = torch.from_numpy(t).cuda()
     scan = rj.Scan(rj.Program(b".{0,2}."))
