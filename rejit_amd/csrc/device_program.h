@@ -20,6 +20,25 @@ namespace rejit_amd {
 
 constexpr int kDevMaxWindows = 8;
 
+// Lane-packed pre-steps of the dense kernel (dense_swar.h): automata of at most 8 positions without
+// assertions whose classes are a few byte ranges.  Four starts share a register, one state BYTE each; the
+// class rows of four text bytes are computed with byte-parallel range tests instead of table lookups.
+constexpr int kSwarMaxRanges = 12;
+struct SwarPlan {
+  uint32_t n_ranges;  // 0: not usable
+  uint32_t n_low;     // ranges [0, n_low) lie in 0x00..0x7f, the rest in 0x80..0xff
+  uint32_t depth;     // pre-steps: 1, 2 or 4
+  // range r = [lo, hi] within one half of the byte values: a byte b (low 7 bits b7) is inside when
+  // b7 + add_lo carries into bit 7 (b7 >= lo) and b7 + add_hi does not (b7 <= hi); replicated x4
+  uint32_t add_lo[kSwarMaxRanges], add_hi[kSwarMaxRanges];
+  uint32_t shift[kSwarMaxRanges];  // 7 - position: bit 7 of the test goes to the position's bit
+  // position masks replicated into all four bytes: the first set, positions that pass to i + 1, loops
+  // (stay), positions whose follow set is neither (their starts go to the walkers)
+  uint32_t first, step1, loopm, gen;
+  uint32_t last_shift[2];  // the (one or two) accepting positions
+  uint32_t first_shift;    // the first position when there is exactly one (DevProgram::loop_first)
+};
+
 // Table layout (all uint32 words, W = n_words, C = n_ctx in {1,4}):
 //   first [C][W]   last [C][W]   linear [W]   row_of [P] (int32)   rows [C][n_rows][W]
 //   cls [256][W]
@@ -68,6 +87,7 @@ struct DevProgram {
   uint32_t loop_first;
   uint32_t cut_fwd[kDevMaxWindows][4];
   uint32_t cut_rev[kDevMaxWindows][4];
+  SwarPlan swar;
 };
 
 // The NFA graph for the exact sequential kernel (reference ring semantics).

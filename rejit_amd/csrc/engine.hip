@@ -92,29 +92,8 @@ int upload_program(rj_program* rp) {
   DevProgram& D = rp->dev;
   D.n_pos = P.n_pos;
   D.table_words = static_cast<uint32_t>(total);
-  for (int k = 0; k < 4; k++) D.loop_mask[k] = D.skip_mask[k] = 0;
-  if (W <= 4) {
-    for (int i = 0; i < P.n_pos; i++) {
-      const int r = P.row_of[static_cast<size_t>(i)];
-      if (r < 0) continue;  // linear
-      bool is_loop = i + 1 < P.n_pos, is_skip = i + 2 < P.n_pos;
-      for (int c = 0; c < C; c++)
-        for (int k = 0; k < W; k++) {
-          const uint32_t row = P.rows[c][static_cast<size_t>(r) * W + k];
-          uint32_t want_loop = 0, want_skip = 0;
-          for (int d = 0; d < 3; d++) {
-            const int j = i + d;
-            if ((j >> 5) != k) continue;
-            if (d <= 1) want_loop |= 1u << (j & 31);
-            if (d >= 1) want_skip |= 1u << (j & 31);
-          }
-          is_loop = is_loop && row == want_loop;
-          is_skip = is_skip && row == want_skip;
-        }
-      if (is_loop) D.loop_mask[i >> 5] |= 1u << (i & 31);
-      else if (is_skip) D.skip_mask[i >> 5] |= 1u << (i & 31);
-    }
-  }
+  loop_skip_masks(P, D.loop_mask, D.skip_mask);
+  D.swar = getenv("RJ_NO_SWAR") == nullptr ? make_swar_plan(P) : SwarPlan{};  // (env: measurement override)
   D.n_words = W;
   D.n_ctx = C;
   D.n_rows = R;

@@ -38,6 +38,7 @@
 #include <hip/hip_ext.h>
 
 #include "behind_walk.h"
+#include "dense_swar.h"
 #include "device_program.h"
 #include "kernels.h"
 
@@ -2209,7 +2210,8 @@ __global__ __launch_bounds__(256) void copy_long_gaps(const uint8_t* text, const
 constexpr int kHalo = 64;                    // bytes after the chunk kept in LDS for the walkers
 constexpr int kTextWindow = kChunk + kHalo;  // per wave
 
-template <int NW, bool CTX>
+// PD = depth of the lane-packed pre-steps (dense_swar.h), 0: the pattern does not qualify.
+template <int NW, bool CTX, int PD>
 __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram P, uint64_t* region_ends,
                                                        unsigned long long* counters) {
   extern __shared__ uint32_t tab[];
@@ -2271,7 +2273,36 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
     }
     uint32_t cand = 0;
     uint32_t fin = 0, flen = 0;  // starts already decided by the pre-steps, 2 bits of length each
-    if (NW == 1 && !CTX && P.nullable == 0 && base + kChunk + 4 <= a.n) {
+    uint32_t Hs[4] = {0, 0, 0, 0};  // packed pre-steps: per start the lengths that matched (dense_swar.h)
+    const bool packed = PD > 0 && base + kChunk + 4 <= a.n;  // (wave-uniform)
+    if (packed) {
+      // Pre-steps, four starts per register (dense_swar.h): class rows by byte-parallel range tests, the
+      // first `depth` automaton steps of all 16 starts, no lookups and no divergence.  A start that is
+      // dead after depth + 1 bytes is decided here; the others go to the walkers.
+      uint32_t x[5] = {d[0], d[1], d[2], d[3], __shfl_down(d[0], 1)};
+      if (lane == kWave - 1) x[4] = *reinterpret_cast<const uint32_t*>(a.text + base + kChunk);  // (in the text: see `packed`)
+      uint32_t rows[5], walk, matched, in_x;
+      rj_swar_rows5(P.swar, x, rows);
+      // (masks in F layout from here on: bit 8k + g = the lane's start 4g + k, dense_swar.h)
+      if (P.loop_first) rj_swar_presteps<(PD > 0 ? PD : 1), true>(P.swar, rows, &walk, &matched, Hs, &in_x);
+      else rj_swar_presteps<(PD > 0 ? PD : 1), false>(P.swar, rows, &walk, &matched, Hs, &in_x);
+      fin = matched & ~walk;
+      cand = walk | fin;
+      const uint64_t lim = a.se < a.n ? a.se : a.n;
+      if (at < a.sb || at + 16 > lim) {  // the ends of the own range
+        const uint32_t hi = lim > at ? (lim - at < 16 ? static_cast<uint32_t>(lim - at) : 16u) : 0u;
+        const uint32_t lo = a.sb > at ? (a.sb - at < 16 ? static_cast<uint32_t>(a.sb - at) : 16u) : 0u;
+        const uint32_t range = rj_swar_f_from_starts(((1u << hi) - 1u) & ~((1u << lo) - 1u));
+        fin &= range;
+        cand &= range;
+      }
+      if (P.loop_first) {
+        // `X+...`: a start whose previous byte is in X too is never selected (see DevProgram::loop_first)
+        uint32_t prev_in = __shfl_up(rj_swar_f_last(in_x), 1);
+        if (lane == 0) prev_in = base > 0 ? ((fb[a.text[base - 1] >> 5] >> (a.text[base - 1] & 31)) & 1u) : 0u;
+        cand &= ~rj_swar_f_next(in_x, prev_in);
+      }
+    } else if (PD == 0 && NW == 1 && !CTX && P.nullable == 0 && base + kChunk + 4 <= a.n) {
       // Pre-steps: the first kPre automaton steps of ALL 16 starts of the lane, in registers, with
       // no divergence.  Most starts die within a few bytes (a walk on random text is ~1.5 steps
       // long), and those never reach the walkers: a start that is dead after kPre + 1 bytes is
@@ -2336,11 +2367,21 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
       // with an assertion (`^[a-z]+:`) have an EMPTY first set outside their context: without the
       // context filter every [a-z] byte of the text was a candidate for the walkers.
       uint32_t lb = 0, first16 = 0;
+      if (CTX) {
+        // line breaks of the 16 bytes, four bytes per operation (a byte is \n or \r when one of the two
+        // differences is zero)
 #pragma unroll
-      for (int j = 0; j < 16; j++) {
-        const uint32_t cur = (d[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-        if (CTX) lb |= static_cast<uint32_t>(cur == '\n' || cur == '\r') << j;
-        first16 |= ((fb[cur >> 5] >> (cur & 31)) & 1u) << j;
+        for (int q = 0; q < 4; q++) {
+          const uint32_t both = rj_swar_nz(d[q] ^ 0x0a0a0a0au) & rj_swar_nz(d[q] ^ 0x0d0d0d0du);
+          lb |= rj_swar_movemask(both ^ 0x80808080u) << (4 * q);
+        }
+      }
+      if (P.n_pos != 0) {  // (only assertions: no byte begins a match)
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          const uint32_t cur = (d[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+          first16 |= ((fb[cur >> 5] >> (cur & 31)) & 1u) << j;
+        }
       }
       // positions with a byte (s < n) / positions at all (s <= n)
       const uint32_t lt_n = a.n > at ? (a.n - at < 16 ? (1u << (a.n - at)) - 1u : 0xFFFFu) : 0u;
@@ -2403,7 +2444,22 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
       if (lane >= o) inc += v;
     }
     const uint32_t total = __shfl(inc, kWave - 1);
-    {
+    if (packed) {
+      uint32_t idx = inc - mine;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {  // (text order: group by group, byte by byte; Hs[] stays in registers)
+        uint32_t m = (cand >> g) & 0x01010101u;
+        while (m) {
+          const int b = __ffs(static_cast<int>(m)) - 1;  // 8k
+          m &= m - 1;
+          const int j = 4 * g + (b >> 3);
+          // decided starts carry their length already (bits 10..: length + 1): the longest prefix that matched
+          const uint32_t hb = (Hs[g] >> b) & 0xFu;
+          const uint32_t len1 = (fin >> (b + g)) & 1u ? (32u - static_cast<uint32_t>(__clz(static_cast<int>(hb)))) + 1u : 0u;
+          slot[idx++] = static_cast<uint32_t>(lane * 16 + j) | (len1 << 10);
+        }
+      }
+    } else {
       uint32_t idx = inc - mine, m = cand;
       while (m) {
         const int j = __ffs(static_cast<int>(m)) - 1;
@@ -2622,15 +2678,22 @@ void launch_scan_dense_walk(const ScanParams& a, const DevProgram& P, int grid, 
   const size_t lds = (((static_cast<size_t>(P.table_words) + 3) & ~size_t{3}) + 4 * kChunk) * sizeof(uint32_t) + 4 * kTextWindow;
   const dim3 g(grid), b(256);
   const bool ctx = P.n_ctx > 1;
-  if (P.n_words <= 1) {
-    if (ctx) hipExtLaunchKernelGGL((scan_dense_walk<1, true>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
-    else hipExtLaunchKernelGGL((scan_dense_walk<1, false>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
+  const int pd = (P.n_words <= 1 && !ctx && P.swar.n_ranges != 0) ? static_cast<int>(P.swar.depth) : 0;
+  if (pd == 1) {
+    hipExtLaunchKernelGGL((scan_dense_walk<1, false, 1>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
+  } else if (pd == 2) {
+    hipExtLaunchKernelGGL((scan_dense_walk<1, false, 2>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
+  } else if (pd == 4) {
+    hipExtLaunchKernelGGL((scan_dense_walk<1, false, 4>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
+  } else if (P.n_words <= 1) {
+    if (ctx) hipExtLaunchKernelGGL((scan_dense_walk<1, true, 0>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
+    else hipExtLaunchKernelGGL((scan_dense_walk<1, false, 0>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
   } else if (P.n_words == 2) {
-    if (ctx) hipExtLaunchKernelGGL((scan_dense_walk<2, true>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
-    else hipExtLaunchKernelGGL((scan_dense_walk<2, false>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
+    if (ctx) hipExtLaunchKernelGGL((scan_dense_walk<2, true, 0>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
+    else hipExtLaunchKernelGGL((scan_dense_walk<2, false, 0>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
   } else {
-    if (ctx) hipExtLaunchKernelGGL((scan_dense_walk<4, true>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
-    else hipExtLaunchKernelGGL((scan_dense_walk<4, false>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
+    if (ctx) hipExtLaunchKernelGGL((scan_dense_walk<4, true, 0>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
+    else hipExtLaunchKernelGGL((scan_dense_walk<4, false, 0>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
   }
 }
 

@@ -102,6 +102,84 @@ inline uint32_t nullable_bits(const Program& P) {
 }
 
 
+// Positions of a lane-sized automaton whose follow set is, in every context, exactly {i, i+1} (a loop) or
+// {i+1, i+2} (a skip): the dense kernel steps them with shifts (DevProgram::loop_mask / skip_mask).
+inline void loop_skip_masks(const Program& P, uint32_t (&loop)[4], uint32_t (&skip)[4]) {
+  const int W = P.n_words, C = P.has_assertions ? kNumCtx : 1;
+  for (int k = 0; k < 4; k++) loop[k] = skip[k] = 0;
+  if (W > 4) return;
+  for (int i = 0; i < P.n_pos; i++) {
+    const int r = P.row_of[static_cast<size_t>(i)];
+    if (r < 0) continue;  // linear
+    bool is_loop = i + 1 < P.n_pos, is_skip = i + 2 < P.n_pos;
+    for (int c = 0; c < C; c++)
+      for (int k = 0; k < W; k++) {
+        const uint32_t row = P.rows[c][static_cast<size_t>(r) * W + k];
+        uint32_t want_loop = 0, want_skip = 0;
+        for (int d = 0; d < 3; d++) {
+          const int j = i + d;
+          if ((j >> 5) != k) continue;
+          if (d <= 1) want_loop |= 1u << (j & 31);
+          if (d >= 1) want_skip |= 1u << (j & 31);
+        }
+        is_loop = is_loop && row == want_loop;
+        is_skip = is_skip && row == want_skip;
+      }
+    if (is_loop) loop[i >> 5] |= 1u << (i & 31);
+    else if (is_skip) skip[i >> 5] |= 1u << (i & 31);
+  }
+}
+
+// The plan of the lane-packed pre-steps (device_program.h: SwarPlan), or n_ranges = 0 when the pattern
+// does not qualify: <= 8 positions, no assertions, not nullable, at most two accepting positions, every
+// class a few ranges.
+inline SwarPlan make_swar_plan(const Program& P) {
+  SwarPlan pl{};
+  if (P.n_pos < 1 || P.n_pos > 8 || P.has_assertions || P.any_nullable || P.n_words != 1) return pl;
+  uint32_t loop[4], skip[4];
+  loop_skip_masks(P, loop, skip);
+  uint32_t n = 0;
+  for (int half = 0; half < 2; half++) {
+    for (int p = 0; p < P.n_pos; p++) {
+      int b = 0;
+      while (b < 128) {
+        while (b < 128 && !((P.cls[static_cast<size_t>(half * 128 + b)] >> p) & 1u)) b++;
+        if (b >= 128) break;
+        int e = b;
+        while (e + 1 < 128 && ((P.cls[static_cast<size_t>(half * 128 + e + 1)] >> p) & 1u)) e++;
+        if (n >= static_cast<uint32_t>(kSwarMaxRanges)) return SwarPlan{};
+        pl.add_lo[n] = static_cast<uint32_t>(0x80 - b) * 0x01010101u;
+        pl.add_hi[n] = static_cast<uint32_t>(0x7f - e) * 0x01010101u;
+        pl.shift[n] = static_cast<uint32_t>(7 - p);
+        n++;
+        b = e + 1;
+      }
+    }
+    if (half == 0) pl.n_low = n;
+  }
+  if (n == 0) return pl;
+  const uint32_t all = (1u << P.n_pos) - 1u;
+  uint32_t gen = 0;
+  for (int p = 0; p < P.n_pos; p++) {
+    const int r = P.row_of[static_cast<size_t>(p)];
+    if (r < 0 || (loop[0] >> p) & 1u) continue;
+    if (P.rows[0][static_cast<size_t>(r)] != 0) gen |= 1u << p;  // (an empty row: the position is a dead end)
+  }
+  const uint32_t last = P.last[0][0] & all, first = P.first[0][0] & all;
+  if (last == 0 || __builtin_popcount(last) > 2) return SwarPlan{};
+  pl.last_shift[0] = static_cast<uint32_t>(__builtin_ctz(last));
+  pl.last_shift[1] = static_cast<uint32_t>(31 - __builtin_clz(last));
+  pl.first_shift = __builtin_popcount(first) == 1 ? static_cast<uint32_t>(__builtin_ctz(first)) : 0u;
+  const uint32_t rep = 0x01010101u;
+  pl.first = first * rep;
+  pl.loopm = (loop[0] & all) * rep;
+  pl.step1 = ((P.linear[0] | loop[0]) & all) * rep;
+  pl.gen = gen * rep;
+  pl.depth = P.max_len <= 1 ? 1 : P.max_len <= 2 ? 2 : 4;
+  pl.n_ranges = n;
+  return pl;
+}
+
 // The NFA graph for the exact replay (DevGraph): seven int32 arrays (byte edges: src dst len off; control
 // edges: src dst kind), the 256-bit classes of the class edges, then the bytes of the literal edges.
 struct GraphBlob {

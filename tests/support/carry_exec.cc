@@ -11,6 +11,7 @@
 
 #include "../../rejit_amd/csrc/behind_walk.h"
 #include "../../rejit_amd/csrc/carry_scan.h"
+#include "../../rejit_amd/csrc/dense_swar.h"
 #include "../../rejit_amd/csrc/exact_replay.h"
 #include "../../rejit_amd/csrc/lowering.h"
 #include "../../rejit_amd/csrc/table_layout.h"
@@ -175,6 +176,70 @@ static long exact_run(const Program& P, const DevProgram& F, const DevGraph& G, 
   return static_cast<long>(k);
 }
 
+
+// dense_swar.h against the scalar automaton: every 16-byte block of the text (with the 4 bytes after it),
+// every start of the block.  Returns the number of disagreements (0 expected), -101 when the pattern does
+// not qualify for the packed pre-steps; stats: [0] starts checked, [1] sent to the walkers, [2] decided with
+// a match, [3] depth.
+template <int D>
+static long swar_check(const Program& P, const SwarPlan& pl, const uint8_t* t, uint64_t n, uint64_t* stats) {
+  long bad = 0;
+  uint32_t loop[4], skip[4];
+  loop_skip_masks(P, loop, skip);
+  for (uint64_t o = 0; o + 20 <= n; o += 16) {
+    uint32_t x[5], rows[5], H[4], walk, matched, in_first;
+    memcpy(x, t + o, 20);
+    rj_swar_rows5(pl, x, rows);
+    const bool one_first = __builtin_popcount(P.first[0][0]) == 1;
+    if (one_first) rj_swar_presteps<D, true>(pl, rows, &walk, &matched, H, &in_first);
+    else rj_swar_presteps<D, false>(pl, rows, &walk, &matched, H, &in_first);
+    {  // F layout -> one bit per start, and the layout helpers themselves
+      const uint32_t w16 = rj_swar_f_to_starts(walk);
+      if (rj_swar_f_from_starts(w16) != walk) bad++;
+      if (rj_swar_f_to_starts(rj_swar_f_next(walk, 1)) != (((w16 << 1) | 1u) & 0xFFFFu)) bad++;
+      if (rj_swar_f_last(walk) != ((w16 >> 15) & 1u)) bad++;
+      walk = w16;
+      matched = rj_swar_f_to_starts(matched);
+      in_first = rj_swar_f_to_starts(in_first);
+    }
+    for (int j = 0; j < 16; j++) {
+      // the scalar truth: D + 1 steps of the position automaton from start o + j
+      uint32_t S = P.first[0][0] & P.cls[t[o + j]];
+      const bool first_ok = S != 0;
+      uint32_t hits = 0;
+      bool gen = false;
+      for (int k = 1; k <= D; k++) {
+        if (S & P.last[0][0]) hits |= 1u << (k - 1);
+        uint32_t T = 0;
+        for (int p = 0; p < P.n_pos; p++) {
+          if (!((S >> p) & 1u)) continue;
+          const int r = P.row_of[static_cast<size_t>(p)];
+          if (r < 0) T |= 1u << (p + 1);
+          else {
+            T |= P.rows[0][static_cast<size_t>(r)];
+            if (!((loop[0] >> p) & 1u) && P.rows[0][static_cast<size_t>(r)] != 0) gen = true;
+          }
+        }
+        S = T & P.cls[t[o + j + k]];
+      }
+      const uint32_t hb = (H[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+      stats[0]++;
+      if (one_first && ((in_first >> j) & 1u) != (first_ok ? 1u : 0u)) bad++;
+      if (gen) {
+        if (!((walk >> j) & 1u)) bad++;
+        stats[1]++;
+        continue;
+      }
+      if (((walk >> j) & 1u) != (S != 0 ? 1u : 0u)) bad++;
+      if (hb != hits || ((matched >> j) & 1u) != (hits != 0 ? 1u : 0u)) bad++;
+      if ((walk >> j) & 1u) stats[1]++;
+      else if (hits) stats[2]++;
+    }
+  }
+  stats[3] = D;
+  return bad;
+}
+
 extern "C" {
 
 // MatchAll of the starts in [sb, se) through the carry scan with sub-chunks of `sub` bytes;
@@ -235,6 +300,17 @@ long ce_exact_range(const char* re, const uint8_t* text, uint64_t n, uint64_t ch
   if (P.n_words <= 4) return exact_run<2>(P, F, G, text, n, chunk, sb, se, out, cap, n_segments, longest);
   if (P.n_words <= 8) return exact_run<4>(P, F, G, text, n, chunk, sb, se, out, cap, n_segments, longest);
   return -9;
+}
+
+long ce_swar_check(const char* re, const uint8_t* text, uint64_t n, uint64_t* stats) {
+  LowerResult lr = lower(re);
+  if (lr.status != 0) return lr.status;
+  const Program& P = *lr.program;
+  const SwarPlan pl = make_swar_plan(P);
+  if (pl.n_ranges == 0) return -101;
+  if (pl.depth == 1) return swar_check<1>(P, pl, text, n, stats);
+  if (pl.depth == 2) return swar_check<2>(P, pl, text, n, stats);
+  return swar_check<4>(P, pl, text, n, stats);
 }
 
 }  // extern "C"
