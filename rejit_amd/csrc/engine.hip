@@ -168,23 +168,9 @@ int upload_program(rj_program* rp) {
   if (linear_path_fits(rp)) D.max_walk = (D.mode == 0 || D.behind) ? 4096u : 65536u;  // (behind: three walks per hit, a step ~1 us)
   if (const char* mw = getenv("RJ_MAX_WALK"))  // test / measurement override
     if (atoi(mw) > 0) D.max_walk = static_cast<uint32_t>(std::min<long>(atol(mw), static_cast<long>(kMaxSimSteps)));
-  {
-    // X+ rest (DevProgram::loop_first): one first position, the same in the only context, following itself
-    D.loop_first = 0;
-    int n_first = 0, p0 = -1;
-    for (int i = 0; i < P.n_pos; i++)
-      if ((P.first[0][static_cast<size_t>(i) >> 5] >> (i & 31)) & 1u) {
-        n_first++;
-        p0 = i;
-      }
-    if (!P.has_assertions && !P.any_nullable && n_first == 1 && W <= 4) {
-      bool self = false;
-      const int r = P.row_of[static_cast<size_t>(p0)];
-      if (r >= 0) self = (P.rows[0][static_cast<size_t>(r) * W + (p0 >> 5)] >> (p0 & 31)) & 1u;
-      D.loop_first = self ? 1u : 0u;
-    }
-    if (getenv("RJ_NO_LOOP_FIRST") != nullptr) D.loop_first = 0;  // measurement override
-  }
+  // (patterns at risk of the ring artefact keep every start as a candidate: the test "a candidate begins where
+  // another one ends" that sends a text to the exact replay is made on the candidates)
+  D.loop_first = run_start_rule(P) && !P.q8_risk && getenv("RJ_NO_LOOP_FIRST") == nullptr ? 1u : 0u;  // (env: measurement override)
   D.float_range = P.floating ? P.float_max - P.float_min + 1 : 1;
   D.float_max = P.floating ? P.float_max : 0;
   for (int k = 0; k < 8; k++) D.first_bytes[k] = P.first_bytes.w[k];

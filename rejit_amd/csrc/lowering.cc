@@ -820,6 +820,70 @@ void find_literal(const Node& n, std::string* out, bool* ok) {
 
 }  // namespace
 
+// Two threads of the reference's ring, started at b < s and both alive at time t: when the positions the
+// younger one holds are always a subset of the older one's, "left-most start wins" (SetState,
+// reference src/x64/codegen-x64.cc:951-987) gives every slot the younger would occupy to the older, i.e.
+// the younger thread does not exist.  Checked on the position automaton by exploring the pairs
+// (older set, younger set) over the pattern's byte classes: the younger starts with first & cls[c] while the
+// older, already alive, steps on the same byte; then both step together.  Conservative: assertions, more
+// than 64 positions or too many pairs answer "no".
+bool threads_always_nested(const Program& P) {
+  if (P.has_assertions || P.n_pos == 0 || P.n_pos > 64) return false;
+  const int W = P.n_words;
+  auto word64 = [&](const std::vector<uint32_t>& v, size_t off) {
+    uint64_t x = v[off];
+    if (W > 1) x |= static_cast<uint64_t>(v[off + 1]) << 32;
+    return x;
+  };
+  std::vector<uint64_t> fol(static_cast<size_t>(P.n_pos), 0);
+  for (int p = 0; p < P.n_pos; p++) {
+    const int r = P.row_of[static_cast<size_t>(p)];
+    if (r < 0) {
+      if (p + 1 < P.n_pos) fol[static_cast<size_t>(p)] = 1ull << (p + 1);
+    } else {
+      fol[static_cast<size_t>(p)] = word64(P.rows[0], static_cast<size_t>(r) * W);
+    }
+  }
+  std::vector<uint64_t> classes;  // distinct, non-empty class rows
+  for (int b = 0; b < 256; b++) {
+    const uint64_t row = word64(P.cls, static_cast<size_t>(b) * W);
+    if (row != 0 && std::find(classes.begin(), classes.end(), row) == classes.end()) classes.push_back(row);
+  }
+  const uint64_t F = word64(P.first[0], 0);
+  auto step = [&](uint64_t S, uint64_t row) {
+    uint64_t T = 0;
+    for (uint64_t m = S; m; m &= m - 1) T |= fol[static_cast<size_t>(__builtin_ctzll(m))];
+    return T & row;
+  };
+  // every set an alive thread can hold
+  std::vector<uint64_t> singles;
+  auto add_single = [&](uint64_t S) {
+    if (S != 0 && std::find(singles.begin(), singles.end(), S) == singles.end()) singles.push_back(S);
+  };
+  for (uint64_t row : classes) add_single(F & row);
+  for (size_t i = 0; i < singles.size(); i++) {
+    if (singles.size() > 4096) return false;
+    for (uint64_t row : classes) add_single(step(singles[i], row));
+  }
+  std::vector<std::pair<uint64_t, uint64_t>> pairs;
+  auto add_pair = [&](uint64_t B, uint64_t S) {
+    if (B == 0 || S == 0) return true;   // one of them is dead: nothing to absorb
+    if (S & ~B) return false;            // the younger thread holds a position of its own
+    const std::pair<uint64_t, uint64_t> q(B, S);
+    if (std::find(pairs.begin(), pairs.end(), q) == pairs.end()) pairs.push_back(q);
+    return true;
+  };
+  for (uint64_t B : singles)
+    for (uint64_t row : classes)
+      if (!add_pair(step(B, row), F & row)) return false;
+  for (size_t i = 0; i < pairs.size(); i++) {
+    if (pairs.size() > 8192) return false;
+    for (uint64_t row : classes)
+      if (!add_pair(step(pairs[i].first, row), step(pairs[i].second, row))) return false;
+  }
+  return true;
+}
+
 LowerResult lower(const char* regexp) {
   LowerResult r;
   ParseResult pr = parse(regexp);
@@ -864,6 +928,10 @@ LowerResult lower(const char* regexp) {
     std::vector<char> from_landing = reach(landings);
     for (int q = 0; q < g.n_states; q++)
       if (from_entry[static_cast<size_t>(q)] && from_landing[static_cast<size_t>(q)]) prog->q8_risk = true;  // q may be the entry itself
+    // ... and the artefact needs a thread that started INSIDE a match and still owns a ring slot when the
+    // match is found; where every younger thread is absorbed by the older one that is alive (`X+ rest`,
+    // `x*`, `[acgt]+`: "left-most start wins" leaves one thread) there is no such thread
+    if (prog->q8_risk && threads_always_nested(*prog)) prog->q8_risk = false;
   }
   prog->graph = g;
   bool lit = true;

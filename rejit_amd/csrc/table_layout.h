@@ -130,6 +130,52 @@ inline void loop_skip_masks(const Program& P, uint32_t (&loop)[4], uint32_t (&sk
   }
 }
 
+// DevProgram::loop_first -- `X+ rest`: only the FIRST byte of a run of X can begin a selected match.
+// Holds when (1) in the only context a match can begin at ONE position p0, which follows itself, the
+// pattern has no assertions and is not nullable: the thread of start s - 1 then passes through p0 at s, so
+// s - 1 reaches every end s reaches, and by induction so does the run's first byte; a start inside the run
+// could then only be selected as the END of an earlier match; and (2) no longest match ends inside a run:
+// an accepting position q that can consume a byte of X is followed by accepting positions that consume
+// every byte of X, so a match whose last byte is in X goes on while the text stays in X
+// (`[a-z]+@[a-z]+` qualifies, `[a-f]+[0-9][a-f]` does not: "ab1c|d2e").
+inline bool run_start_rule(const Program& P) {
+  if (P.has_assertions || P.any_nullable || P.n_words > 4 || P.n_pos == 0) return false;
+  const int W = P.n_words;
+  int n_first = 0, p0 = -1;
+  for (int i = 0; i < P.n_pos; i++)
+    if ((P.first[0][static_cast<size_t>(i) >> 5] >> (i & 31)) & 1u) {
+      n_first++;
+      p0 = i;
+    }
+  if (n_first != 1) return false;
+  const int r0 = P.row_of[static_cast<size_t>(p0)];
+  if (r0 < 0 || !((P.rows[0][static_cast<size_t>(r0) * W + (p0 >> 5)] >> (p0 & 31)) & 1u)) return false;
+  auto in_cls = [&](int b, int q) { return (P.cls[static_cast<size_t>(b) * W + (q >> 5)] >> (q & 31)) & 1u; };
+  auto is_last = [&](int q) { return (P.last[0][static_cast<size_t>(q) >> 5] >> (q & 31)) & 1u; };
+  for (int q = 0; q < P.n_pos; q++) {
+    if (!is_last(q)) continue;
+    bool eats_x = false;
+    for (int b = 0; b < 256 && !eats_x; b++) eats_x = in_cls(b, p0) && in_cls(b, q);
+    if (!eats_x) continue;
+    // follow(q) & last must cover X
+    std::vector<uint32_t> fol(static_cast<size_t>(W), 0);
+    const int rq = P.row_of[static_cast<size_t>(q)];
+    if (rq < 0) {
+      if (q + 1 < P.n_pos) fol[static_cast<size_t>(q + 1) >> 5] |= 1u << ((q + 1) & 31);
+    } else {
+      for (int k = 0; k < W; k++) fol[static_cast<size_t>(k)] = P.rows[0][static_cast<size_t>(rq) * W + k];
+    }
+    for (int b = 0; b < 256; b++) {
+      if (!in_cls(b, p0)) continue;
+      bool goes_on = false;
+      for (int k = 0; k < W && !goes_on; k++)
+        goes_on = (fol[static_cast<size_t>(k)] & P.last[0][static_cast<size_t>(k)] & P.cls[static_cast<size_t>(b) * W + k]) != 0;
+      if (!goes_on) return false;
+    }
+  }
+  return true;
+}
+
 // The plan of the lane-packed pre-steps (device_program.h: SwarPlan), or n_ranges = 0 when the pattern
 // does not qualify: <= 8 positions, no assertions, not nullable, at most two accepting positions, every
 // class a few ranges.

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../rejit_amd/csrc/lowering.h"
+#include "../../rejit_amd/csrc/table_layout.h"
 
 using namespace rejit_amd;
 
@@ -118,18 +119,7 @@ bool candidate(const Program& P, const uint8_t* t, uint64_t n, uint64_t s) {
   if (!(s < n && P.first_bytes.has(t[s]))) return false;
   // `X+ rest` (DevProgram::loop_first, as the engine derives it): a start whose previous byte is in X
   // too is never selected, so the dense kernel does not take it as a candidate
-  if (!P.has_assertions && !P.any_nullable && s > 0 && P.first_bytes.has(t[s - 1])) {
-    int n_first = 0, p0 = -1;
-    for (int i = 0; i < P.n_pos; i++)
-      if ((P.first[0][(size_t)i >> 5] >> (i & 31)) & 1u) {
-        n_first++;
-        p0 = i;
-      }
-    if (n_first == 1 && P.n_words <= 4) {
-      const int r = P.row_of[(size_t)p0];
-      if (r >= 0 && ((P.rows[0][(size_t)r * P.n_words + (p0 >> 5)] >> (p0 & 31)) & 1u)) return false;
-    }
-  }
+  if (s > 0 && P.first_bytes.has(t[s - 1]) && run_start_rule(P)) return false;
   return true;
 }
 

@@ -100,3 +100,47 @@ def test_long_stretch_without_synchronisation_point(ce):
             assert got == want, rx
     got, info = exact(ce, b"x*", tx, 64)
     assert info[1] >= 5000        # one segment holds the whole run of x
+
+
+def _risk(lib, rx):
+    buf = (ctypes.c_uint64 * 8)()
+    a, b, r = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_int(-1)
+    rc = lib.ce_exact_range(rx, b"", 0, 16, 0, 1, buf, 4, ctypes.byref(a), ctypes.byref(b), ctypes.byref(r))
+    return None if (rc < 0 and r.value == -1) else bool(r.value)
+
+
+def test_refined_risk_flag_is_sound(ce):
+    """Program::q8_risk = the closure criterion AND NOT "every younger thread is absorbed by the older one"
+    (lowering.cc: threads_always_nested).  A pattern that is not flagged never goes to the exact replay, so
+    on it the reference must agree with the documented semantics on every text."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import RegexGen, ALPHABETS
+    oracle = Oracle()
+    for rx, want in ((b"[a-f]+[0-9]", False), (b"[a-z]+", False), (b"[acgt]+", False), (b"[^>]+", False), (b"x*", False), (b"[0-9]+x", False),
+                     (b".*regexp", False), (b"[a-f]+[0-9][a-f]", True), (b".{0,2}.", True), (b"(ab|ba)+", True), (b"agggtaaa|tttaccct", False)):
+        assert _risk(ce, rx) == want, rx
+    assert oracle.match_all(b"[a-f]+[0-9][a-f]", b"ab1cd2e") == [(0, 4)]          # the artefact ...
+    assert oracle.match_all_spec(b"[a-f]+[0-9][a-f]", b"ab1cd2e") == [(0, 4), (4, 7)]  # ... on an `X+ rest` pattern
+    rng = random.Random(77)
+    checked = flagged = artefact = 0
+    for _ in range(3000):
+        alphabet = rng.choice(ALPHABETS)
+        rx = RegexGen(rng, alphabet).alt(2).encode("latin1")
+        if oracle.status(rx) != 0:
+            continue
+        risk = _risk(ce, rx)
+        if risk is None:
+            continue
+        checked += 1
+        flagged += risk
+        for k in range(4):
+            al = alphabet if k % 2 == 0 else rng.choice(ALPHABETS)
+            tx = "".join(rng.choice(al) for _ in range(rng.choice([8, 40, 150]))).encode("latin1")
+            want = oracle.match_all(rx, tx)
+            if isinstance(want, int):
+                break
+            if want != oracle.match_all_spec(rx, tx):
+                artefact += 1
+                assert risk, (rx, tx)
+    assert checked > 2500 and 0 < flagged < checked * 0.6 and artefact > 20

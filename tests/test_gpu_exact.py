@@ -26,8 +26,8 @@ def run_ranges(rj, scan, d, n, cuts):
     return np.concatenate(parts) if parts else np.empty((0, 2), dtype=np.uint64)
 
 
-@pytest.mark.parametrize("rx,alphabet", [(b".{0,2}.", b"abcdefghijklmnopqrstuvwxyz0123456789  \n"), (b"(x|xy)*z?", b"xyz"),
-                                         (b"(ab|a)*", b"abc"), (b"a?b?c?", b"abcd")])
+@pytest.mark.parametrize("rx,alphabet", [(b".{0,2}.", b"abcdefghijklmnopqrstuvwxyz0123456789  \n"), (b"[a-f]+[0-9][a-f]", b"abcdef0123 "),
+                                         (b"(ab|ba)+", b"abc"), (b"[xy]+z[xy]", b"xyz ")])
 def test_whole_text_and_shards_8mib(rj, oracle, rx, alphabet):
     import torch
     n = 8 << 20
@@ -63,9 +63,9 @@ def test_carry_scan_then_replay(rj, oracle, monkeypatch):
     import torch
     monkeypatch.setenv("RJ_MAX_WALK", "64")
     rng = random.Random(3)
-    for rx, alphabet in ((b"x*", b"xxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxy"),
-                         (b"(ab|a)*c?", b"aaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaabc"),
-                         (b"[a-y]+z?", b"abcdefghijklmnopqrstuvwxy" * 8 + b"z ")):
+    for rx, alphabet in ((b"[xy]+z[xy]", b"x" * 60 + b"y" * 38 + b"z "),
+                         (b"(aa|aaa)+", b"a" * 72 + b"bc"),
+                         (b"[a-y]+z[a-y]", b"abcdefghijklmnopqrstuvwxy" * 8 + b"z ")):
         n = (4 << 20) + rng.randrange(1000)
         t = text_of(n, alphabet, rng.randrange(1 << 30))
         want = oracle_spans_np(oracle, rx, t)
@@ -81,10 +81,11 @@ def test_stretch_too_long_to_replay_keeps_documented_semantics(rj, oracle):
     import torch
     n = 20 << 20
     t = np.full(n, ord("x"), dtype=np.uint8)
-    t[n - 5:] = np.frombuffer(b"yxxyx", dtype=np.uint8)
-    want = oracle_spans_np(oracle, b"x*", t)     # (reference == documented semantics on this text)
+    t[n - 6:] = np.frombuffer(b"zx xzy", dtype=np.uint8)
+    want = oracle_spans_np(oracle, b"[xy]+z[xy]", t)     # (reference == documented semantics on this text)
+    assert len(want) == 2
     d = torch.from_numpy(t).cuda()
-    scan = rj.Scan(rj.Program(b"x*"))
+    scan = rj.Scan(rj.Program(b"[xy]+z[xy]"))
     cnt = scan.run_tensor(d)
     assert cnt == len(want) and np.array_equal(gpu_spans_np(rj, scan), want)
     assert scan.stats()["exact_path"] == 0

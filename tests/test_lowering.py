@@ -12,6 +12,7 @@ overlapping answer.
 """
 import ctypes
 import os
+import random
 import subprocess
 
 import pytest
@@ -173,3 +174,22 @@ def test_windows_behind_an_unbounded_prefix(pe):
                     assert got == want, (rx, t2, got, want)
                     used += 1
     assert used > 500 and conflicts < used // 10, (used, conflicts)
+
+
+def test_run_start_rule_is_sound(pe):
+    """`X+ rest` patterns: the dense kernel takes only the first byte of a run of X as a candidate
+    (DevProgram::loop_first, table_layout.h: run_start_rule).  That is only right when no longest match can
+    end inside a run -- `[a-f]+[0-9][a-f]` over "ab1cd2e" has the matches (0,4) and (4,7), the second one
+    beginning in the middle of the run "cd".  The executor must give the documented semantics on all of
+    these (the reference's own answer differs on some by its ring artefact, which the engine's exact replay
+    handles separately)."""
+    oracle = Oracle()
+    rng = random.Random(21)
+    pats = [b"[a-f]+[0-9][a-f]", b"[a-z]+@[a-z]+", b"[a-f]+[0-9]", b"a+ba", b"[ab]+a", b"[ab]+b[ab]", b"x+yx?", b"[0-9]+x", b"[a-c]+[b-d]",
+            b"[a-c]+d[a-c]*", b"a+(b|ca)", b"[ab]+c?[ab]"]
+    assert match_all(pe, b"[a-f]+[0-9][a-f]", b"ab1cd2e") == [(0, 4), (4, 7)]
+    for rx in pats:
+        for alphabet in (b"ab1cd2e", b"ab", b"abcd", b"xy", b"abc@.", b"a1b2"):
+            for _ in range(40):
+                tx = bytes(rng.choice(alphabet) for _ in range(rng.choice([7, 30, 120])))
+                assert match_all(pe, rx, tx) == oracle.match_all_spec(rx, tx), (rx, tx)
