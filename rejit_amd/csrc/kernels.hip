@@ -2421,6 +2421,48 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
       }
     }
     if (__ballot(cand != 0) == 0) continue;
+    if ((packed || P.n_pos == 0) && __ballot((cand & ~fin) != 0) == 0) {
+      // Every candidate of the chunk is decided already (the common chunk of `[a-f]+[0-9]`, every chunk of
+      // `^`): no walkers, so no text window, no slots -- the lanes put their matches straight into the region
+      const uint32_t mine = __popc(cand);
+      uint32_t inc = mine;
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+      }
+      uint32_t pos = count + inc - mine;
+      if (packed) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {  // (text order: group by group, byte by byte)
+          uint32_t m = (cand >> g) & 0x01010101u;
+          while (m) {
+            const int b = __ffs(static_cast<int>(m)) - 1;  // 8k
+            m &= m - 1;
+            const uint32_t hb = (Hs[g] >> b) & 0xFu;
+            if (pos < a.region_cap) {
+              const uint64_t s = at + static_cast<uint64_t>(4 * g + (b >> 3));
+              region[pos] = s;
+              ends[pos] = s + (32u - static_cast<uint32_t>(__clz(static_cast<int>(hb))));
+            }
+            pos++;
+          }
+        }
+      } else {
+        uint32_t m = cand;
+        while (m) {  // (only assertions: the empty match)
+          const int j = __ffs(static_cast<int>(m)) - 1;
+          m &= m - 1;
+          if (pos < a.region_cap) {
+            region[pos] = at + static_cast<uint64_t>(j);
+            ends[pos] = at + static_cast<uint64_t>(j);
+          }
+          pos++;
+        }
+      }
+      count += __shfl(inc, kWave - 1);
+      continue;
+    }
     *reinterpret_cast<uint4*>(txt + lane * 16) = make_uint4(d[0], d[1], d[2], d[3]);
     if (lane < kHalo / 4) {
       const uint64_t hp = base + kChunk + 4 * lane;
