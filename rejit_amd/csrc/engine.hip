@@ -1382,9 +1382,19 @@ int64_t rj_scan_copy_spans(const rj_scan* s, uint64_t* host_spans, uint64_t cap)
   if (!s) return fail(RJ_BAD_ARGUMENT, "null scan");
   const uint64_t k = std::min<uint64_t>(cap, s->result_count);
   if (k) {
-    // (hipMemcpyDefault: the destination may be host or device memory)
-    hipError_t e = hipMemcpy(host_spans, s->result, k * 2 * sizeof(uint64_t), hipMemcpyDefault);
-    if (e != hipSuccess) return fail(RJ_DEVICE_ERROR, "hipMemcpy failed: %s", hipGetErrorString(e));
+    // (hipMemcpyDefault: the destination may be host or device memory.  The run has been synchronised
+    // before it returned; the copy goes over a non-blocking stream of the calling thread -- hipMemcpy on the
+    // null stream would wait for every other thread's blocking streams)
+    static thread_local hipStream_t copy_stream = nullptr;
+    static thread_local int copy_device = -1;
+    int dev = 0;
+    RJ_HIP(hipGetDevice(&dev));
+    if (copy_stream == nullptr || copy_device != dev) {
+      RJ_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));  // (one per thread and device change; never destroyed)
+      copy_device = dev;
+    }
+    RJ_HIP(hipMemcpyAsync(host_spans, s->result, k * 2 * sizeof(uint64_t), hipMemcpyDefault, copy_stream));
+    RJ_HIP(hipStreamSynchronize(copy_stream));
   }
   return static_cast<int64_t>(s->result_count);
 }
@@ -1683,9 +1693,16 @@ int64_t rejit_amd::rj_match_all_batch_one_device(const rj_program* prog, const c
   uint64_t total_bytes = 0;
   for (size_t i = 0; i < n_texts; i++) {
     off[i] = total_bytes;
+    if (sizes[i] >= (1ull << 62) || total_bytes + sizes[i] + 1 < total_bytes) return fail(RJ_BAD_ARGUMENT, "batch: sizes overflow");
     total_bytes += sizes[i] + 1;
   }
   off[n_texts] = total_bytes;
+  // uploads are queued slice by slice from s->pinned: whatever way this function is left, no copy may still
+  // be in flight (the next call may free or refill the staging buffer)
+  struct DrainStream {
+    hipStream_t st;
+    ~DrainStream() { (void)hipStreamSynchronize(st); }
+  } drain{s->own_stream};
   const uint64_t n = total_bytes - 1;  // the last separator is the end of the buffer
   if (total_bytes > s->pinned_cap) {
     if (s->pinned) (void)hipHostFree(s->pinned);

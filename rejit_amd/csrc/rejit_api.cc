@@ -18,7 +18,11 @@ namespace rejit {
 namespace {
 char g_status_buffer[512] = "";
 
+// (the reference's global buffer, shared by every Regej of the process: writers take turns, so a message is
+// never a mix of two; a reader racing with a writer is inherent to the reference's interface)
+std::mutex g_status_mutex;
 void set_status_string(const char* msg) {
+  std::lock_guard<std::mutex> lock(g_status_mutex);
   snprintf(g_status_buffer, sizeof(g_status_buffer), "%s", msg ? msg : "");
 }
 

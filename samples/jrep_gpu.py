@@ -178,7 +178,10 @@ def main():
                 sizes.append(os.path.getsize(nm))
             except OSError:
                 sizes.append(0)
-        names = [names[i] for i in sharding.partition_files(sizes, world)[rank]]
+        mine = sharding.partition_files(sizes, world)[rank]
+        order = {names[i]: i for i in mine}     # a file's place in the single-rank (and the reference's) output order
+        names = [names[i] for i in mine]
+    records = []    # (global file index, that file's output) -- several ranks: merged in file order on rank 0
     for batch in batches(names, args.batch_mib << 20):
         texts = [d for _, d in batch]
         results = prog.match_all_batch(texts)
@@ -188,15 +191,35 @@ def main():
         found = True
         if args.count:
             for i in hit:
-                out.write(batch[i][0].encode() + b":" + str(len(results[i])).encode() + b"\n")
+                line = batch[i][0].encode() + b":" + str(len(results[i])).encode() + b"\n"
+                if world > 1:
+                    records.append((order[batch[i][0]], line))
+                else:
+                    out.write(line)
             continue
         # second pass, only over the files with matches (jrep.cc:292-295)
         lines = sol.match_all_batch([texts[i] for i in hit])
         for i, ls in zip(hit, lines):
-            print_file(out, batch[i][0], texts[i], results[i], [b for b, _ in ls], args)
+            if world > 1:
+                one = io.BytesIO()
+                print_file(one, batch[i][0], texts[i], results[i], [b for b, _ in ls], args)
+                records.append((order[batch[i][0]], one.getvalue()))
+            else:
+                print_file(out, batch[i][0], texts[i], results[i], [b for b, _ in ls], args)
     if world > 1:
+        import struct
         import torch
-        whole = sharding.gather_bytes(out.getvalue(), rank, world, dist, device=cdev)
+        # every record travels with its file index; rank 0 puts the files back into the walk's order, so the
+        # output does not depend on the number of ranks
+        blob = b"".join(struct.pack("<QQ", gi, len(o)) + o for gi, o in records)
+        whole = sharding.gather_bytes(blob, rank, world, dist, device=cdev)
+        if rank == 0:
+            recs, at = [], 0
+            while at < len(whole):
+                gi, ln = struct.unpack_from("<QQ", whole, at)
+                recs.append((gi, whole[at + 16:at + 16 + ln]))
+                at += 16 + ln
+            whole = b"".join(o for _, o in sorted(recs, key=lambda r: r[0]))
         flag = torch.tensor([int(found)], dtype=torch.int64, device=cdev if cdev is not None else "cpu")
         dist.all_reduce(flag)
         found = bool(flag.item())

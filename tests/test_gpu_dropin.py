@@ -123,6 +123,12 @@ def test_own_jrep_counterpart_two_ranks(tmp_path):
     # (the launcher shares one stdout between the ranks and gloo's rendezvous log: the result goes to a file)
     got = (tmp_path / "out.txt").read_bytes().splitlines()
     assert sorted(got) == sorted(ref.splitlines()) and len(ref.splitlines()) > 0
+    # ... and in the order of a single rank (every file's output travels with its place in the walk)
+    one = subprocess.run([sys.executable, sample, "-o", str(tmp_path / "one.txt"), "-R", "-H", "-n", "regexp", "."], cwd=tmp_path,
+                         capture_output=True, timeout=600)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    single = [l for l in (tmp_path / "one.txt").read_bytes().splitlines() if not l.startswith((b"./out.txt", b"./one.txt"))]
+    assert [l for l in got if not l.startswith((b"./out.txt", b"./one.txt"))] == single
 
 
 def test_own_regexdna_counterpart(tmp_path):
