@@ -551,13 +551,14 @@ def literal_and_complex_extras(args, c, out):
         "scan_windows<1> + verify_behind_in_regions", 5, check_behind, None, True, args)
     # Patterns WITHOUT a fast-forward window (the NFA half of the north star): scan_dense_walk finds, walks and
     # compacts the candidates in one kernel.  `[a-f]+[0-9]`: a start at 8 % of the bytes of this text (only the
-    # first byte of every run of [a-f] is walked, DevProgram::loop_first).
+    # first byte of every run of [a-f] is taken, DevProgram::loop_first); the first four automaton steps of all
+    # starts run lane-packed, four starts per register (dense_swar.h).
     def check_dense(sc):
         assert sc.stats()["n_matches"] > 1000
 
     out["dense_scan"] = single_pattern_extra(
         c, rejit_amd, t, n, "[a-f]+[0-9]", "[a-f]+[0-9] MatchAll over the same %d bytes (no fast-forward window: dense mode)" % n,
-        "scan_dense_walk<1,false>", 5, check_dense, None, True, args)
+        "scan_dense_walk<1,false,4> (lane-packed pre-steps)", 5, check_dense, None, True, args)
     # The line table of a grep-like caller (sample/jrep.cc:294: MatchAll of "^"): a class scan whose OUTPUT is
     # the traffic -- 16 bytes per line start next to 1 byte read per text byte.
     nl = torch.arange(60, n, 61, device=dev)
@@ -578,7 +579,7 @@ def literal_and_complex_extras(args, c, out):
     out["line_table"] = {"workload": "`^` MatchAll over %d bytes with a line break every 61 bytes (jrep's line table)" % n, "matches": int(k),
                          "value": round(n / (sum(ltot) / len(ltot) * 1e-3) / 1e9, 1), "unit": "GB/s of text", "latency_ms": round(sum(ltot) / len(ltot), 4),
                          "write_bytes_per_launch": 16 * int(k),
-                         "roofline": hbm_roofline("scan_dense_walk<1,true> (n text bytes read + 16 B written per match)", bytes_l, a_l)}
+                         "roofline": hbm_roofline("scan_dense_walk<1,true,0> (n text bytes read + 16 B written per match)", bytes_l, a_l)}
     del t
     torch.cuda.empty_cache()
 
