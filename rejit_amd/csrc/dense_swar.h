@@ -33,6 +33,24 @@ RJ_HD void rj_swar_rows5(const SwarPlan& pl, const uint32_t (&x)[5], uint32_t (&
     lowh[i] = highh[i] ^ 0x80808080u;
     rows[i] = 0;
   }
+  if (pl.n_ranges <= 4) {
+    // the usual few ranges: unrolled, so that the constants are loop-invariant scalars of the caller's chunk
+    // loop instead of three scalar loads (and a wait) per range and chunk
+#pragma unroll
+    for (uint32_t r = 0; r < 4; r++) {
+      if (r < pl.n_ranges) {
+        const uint32_t lo = pl.add_lo[r], hi = pl.add_hi[r], sh = pl.shift[r];
+        if (r < pl.n_low) {
+#pragma unroll
+          for (int i = 0; i < 5; i++) rows[i] |= ((x7[i] + lo) & ~(x7[i] + hi) & lowh[i]) >> sh;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 5; i++) rows[i] |= ((x7[i] + lo) & ~(x7[i] + hi) & highh[i]) >> sh;
+        }
+      }
+    }
+    return;
+  }
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
   for (uint32_t r = 0; r < pl.n_low; r++) {
     const uint32_t lo = pl.add_lo[r], hi = pl.add_hi[r], sh = pl.shift[r];
