@@ -51,6 +51,28 @@ constexpr int kChunk = 1024;  // bytes per wave iteration: 64 lanes x 16 B
 
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & (kWave - 1); }
 
+// Cross-lane moves of the dense kernel through DPP (data-parallel primitives: the operand of a VALU
+// instruction comes from another lane of the wave, no LDS crossbar round trip as with ds_bpermute, which
+// is what __shfl_up / __shfl_down compile to).  gfx9 family: row_shr within rows of 16 lanes, row_bcast:15 /
+// row_bcast:31 to carry a row's total into the next rows, wave_shl / wave_shr by one lane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t x) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, ROW_MASK, 0xF, true));
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+  x += dpp_or_zero<0x111, 0xF>(x);  // row_shr:1
+  x += dpp_or_zero<0x112, 0xF>(x);  // row_shr:2
+  x += dpp_or_zero<0x114, 0xF>(x);  // row_shr:4
+  x += dpp_or_zero<0x118, 0xF>(x);  // row_shr:8
+  x += dpp_or_zero<0x142, 0xA>(x);  // row_bcast:15 into rows 1 and 3
+  x += dpp_or_zero<0x143, 0xC>(x);  // row_bcast:31 into rows 2 and 3
+  return x;
+}
+__device__ __forceinline__ uint32_t wave_from_lane_below(uint32_t x) { return dpp_or_zero<0x138, 0xF>(x); }  // wave_shr:1, lane 0 gets 0
+__device__ __forceinline__ uint32_t wave_from_lane_above(uint32_t x) { return dpp_or_zero<0x130, 0xF>(x); }  // wave_shl:1, lane 63 gets 0
+__device__ __forceinline__ uint32_t wave_last_lane(uint32_t x) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(x), kWave - 1)); }
+
 // Hit offsets of one wave go to the wave's own REGION of the hit list: region w = wave w,
 // `cap` entries, filled in position order, no atomics.  Every wave owns a contiguous span of
 // the text, so the regions concatenated in wave order are globally sorted by offset -- which
@@ -2279,7 +2301,7 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
       // Pre-steps, four starts per register (dense_swar.h): class rows by byte-parallel range tests, the
       // first `depth` automaton steps of all 16 starts, no lookups and no divergence.  A start that is
       // dead after depth + 1 bytes is decided here; the others go to the walkers.
-      uint32_t x[5] = {d[0], d[1], d[2], d[3], __shfl_down(d[0], 1)};
+      uint32_t x[5] = {d[0], d[1], d[2], d[3], wave_from_lane_above(d[0])};
       if (lane == kWave - 1) x[4] = *reinterpret_cast<const uint32_t*>(a.text + base + kChunk);  // (in the text: see `packed`)
       uint32_t rows[5], walk, matched, in_x;
       rj_swar_rows5(P.swar, x, rows);
@@ -2298,7 +2320,7 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
       }
       if (P.loop_first) {
         // `X+...`: a start whose previous byte is in X too is never selected (see DevProgram::loop_first)
-        uint32_t prev_in = __shfl_up(rj_swar_f_last(in_x), 1);
+        uint32_t prev_in = wave_from_lane_below(rj_swar_f_last(in_x));
         if (lane == 0) prev_in = base > 0 ? ((fb[a.text[base - 1] >> 5] >> (a.text[base - 1] & 31)) & 1u) : 0u;
         cand &= ~rj_swar_f_next(in_x, prev_in);
       }
@@ -2310,7 +2332,7 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
       // follow row are not stepped here: a state that holds one keeps the start for the walkers.
       constexpr int kPre = 2;
       uint32_t r[16 + kPre];  // class rows of the lane's bytes and of the kPre bytes after them
-      const uint32_t nx = __shfl_down(d[0], 1);
+      const uint32_t nx = wave_from_lane_above(d[0]);
 #pragma unroll
       for (int k = 0; k < 16 + kPre; k++) {
         const uint32_t byte = ((k < 16 ? d[k >> 2] : nx) >> (8 * (k & 3))) & 0xFFu;
@@ -2354,7 +2376,7 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
         uint32_t in_x = 0;
 #pragma unroll
         for (int j = 0; j < 16; j++) in_x |= static_cast<uint32_t>((first0[0] & r[j]) != 0) << j;
-        uint32_t prev_in = __shfl_up(in_x >> 15, 1);
+        uint32_t prev_in = wave_from_lane_below(in_x >> 15);
         if (lane == 0) prev_in = base > 0 ? ((fb[a.text[base - 1] >> 5] >> (a.text[base - 1] & 31)) & 1u) : 0u;
         cand &= ~((in_x << 1) | prev_in);
       }
@@ -2389,7 +2411,7 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
       uint32_t null16 = P.nullable ? 0xFFFFu : 0u, allowed16 = 0xFFFFu;
       if (CTX) {
         lb &= lt_n;
-        uint32_t prev_lb = __shfl_up(lb >> 15, 1);  // the neighbour's last byte
+        uint32_t prev_lb = wave_from_lane_below(lb >> 15);  // the neighbour's last byte
         if (lane == 0) prev_lb = base > 0 ? static_cast<uint32_t>(rj_line_break(a.text[base - 1])) : 1u;  // text start
         const uint32_t sol = ((lb << 1) | prev_lb) & 0xFFFFu;
         uint32_t eol = lb;
@@ -2409,7 +2431,7 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
       cand = ((first16 & allowed16 & lt_n) | (null16 & le_n)) & 0xFFFFu & range;
       if (P.loop_first) {  // (no assertions, not nullable: first16 is membership in X)
         const uint32_t in_x = first16 & lt_n;
-        uint32_t prev_in = __shfl_up(in_x >> 15, 1);
+        uint32_t prev_in = wave_from_lane_below(in_x >> 15);
         if (lane == 0) prev_in = base > 0 ? ((fb[a.text[base - 1] >> 5] >> (a.text[base - 1] & 31)) & 1u) : 0u;
         cand &= ~((in_x << 1) | prev_in);
       }
@@ -2425,12 +2447,7 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
       // Every candidate of the chunk is decided already (the common chunk of `[a-f]+[0-9]`, every chunk of
       // `^`): no walkers, so no text window, no slots -- the lanes put their matches straight into the region
       const uint32_t mine = __popc(cand);
-      uint32_t inc = mine;
-#pragma unroll
-      for (int o = 1; o < kWave; o <<= 1) {
-        const uint32_t v = __shfl_up(inc, o);
-        if (lane >= o) inc += v;
-      }
+      const uint32_t inc = wave_inclusive_sum(mine);
       uint32_t pos = count + inc - mine;
       if (packed) {
 #pragma unroll
@@ -2460,7 +2477,7 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
           pos++;
         }
       }
-      count += __shfl(inc, kWave - 1);
+      count += wave_last_lane(inc);
       continue;
     }
     *reinterpret_cast<uint4*>(txt + lane * 16) = make_uint4(d[0], d[1], d[2], d[3]);
@@ -2479,13 +2496,8 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
     // byte at chunk offset x < n_rel
     auto tb = [&](uint32_t x) -> uint32_t { return x < kChunk + kHalo ? txt[x] : tbase[x]; };
     const uint32_t mine = __popc(cand);
-    uint32_t inc = mine;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const uint32_t v = __shfl_up(inc, o);
-      if (lane >= o) inc += v;
-    }
-    const uint32_t total = __shfl(inc, kWave - 1);
+    const uint32_t inc = wave_inclusive_sum(mine);
+    const uint32_t total = wave_last_lane(inc);
     if (packed) {
       uint32_t idx = inc - mine;
 #pragma unroll
