@@ -8,12 +8,15 @@
 """
 import ctypes
 import hashlib
+import os
 import random
 
 import numpy as np
 import pytest
 
 import vectors as V
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from checkers import Oracle
 
 pytestmark = pytest.mark.gpu
@@ -625,3 +628,20 @@ def test_planted_literal_beyond_4gib(rj):
         m &= w[k:w.numel() - 5 + k] == pat[k]
     want = (torch.nonzero(m).flatten() + lo).tolist()
     assert [b for b in found if lo <= b < hi - 5] == want
+
+
+def test_random_patterns_through_the_general_pipeline():
+    """Texts of a few KiB take the one-workgroup kernel (match_small), so the random-pattern tests above no
+    longer reach the kernels large texts run on.  tools/fuzz_large.py with RJ_NO_SMALL=1 (read once per
+    process, hence the subprocess) sends the same kind of random patterns over texts of 1.5..9 KiB through
+    the general pipeline -- window scans, the dense kernel with its lane-packed pre-steps, verification,
+    gather, selection, the exact replay -- and compares every result with the oracle."""
+    import subprocess
+    import sys
+    env = dict(os.environ, RJ_NO_SMALL="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_large.py"), "700", "4711"], env=env, capture_output=True,
+                       timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    last = out.strip().splitlines()[-1]
+    assert last.startswith("checked 700") and last.endswith("mismatches 0"), out[-2000:]
