@@ -2276,19 +2276,39 @@ __global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram 
       if (tab[c * W + q] != 0) first_ctx |= 1u << c;
   if (C == 1) first_ctx = 0xFu;
 
+  // The lane's 16 bytes of the NEXT chunk and the run's "void" flag are loaded one iteration ahead: a load
+  // at the top of the iteration that needs it put a full memory latency (two, with the flag) on every
+  // wave's critical path.
+  uint4 pre_v = make_uint4(0, 0, 0, 0);
+  unsigned long long pre_flag = 0;
+  bool pre_valid = false;  // (wave-uniform)
+  // (a relaxed atomic load at device scope: fresh data, but -- unlike a volatile access -- nothing to wait for
+  // until the value is used, an iteration later)
+  auto load_flag = [&]() { return __hip_atomic_load(counters + kCntOverrun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   for (uint64_t c = span.c0; c < span.c1; c++) {
-    // some walk of this run has hit P.max_walk: the run is void (the engine repeats it on the carry
-    // scan), no point in finishing it
-    if (*static_cast<const volatile unsigned long long*>(counters + kCntOverrun) != 0) break;
     const uint64_t base = c * kChunk;
     const uint64_t at = base + static_cast<uint64_t>(lane) * 16;
     const uint8_t* tbase = a.text + base;
+    const bool full = base + kChunk <= a.n;
+    uint4 v = pre_v;
+    unsigned long long stop = pre_flag;
+    if (!pre_valid) {
+      stop = load_flag();
+      if (full) v = *reinterpret_cast<const uint4*>(a.text + at);
+    }
+    pre_valid = c + 1 < span.c1 && base + 2 * kChunk <= a.n;
+    if (pre_valid) {
+      pre_v = *reinterpret_cast<const uint4*>(a.text + at + kChunk);
+      pre_flag = load_flag();
+    }
+    // some walk of this run has hit P.max_walk: the run is void (the engine repeats it on the carry
+    // scan), no point in finishing it
+    if (stop != 0) break;
     // text length as seen from the chunk (a walk is cut at 2^20 bytes, so clamping is exact)
     const uint32_t n_rel = a.n - base < 0x7FFFFFFFull ? static_cast<uint32_t>(a.n - base) : 0x7FFFFFFFu;
     // ---- 1. candidate mask of the lane's 16 positions
     uint32_t d[6];
-    if (base + kChunk <= a.n) {
-      const uint4 v = *reinterpret_cast<const uint4*>(a.text + at);
+    if (full) {
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     } else {
       load_guarded(a.text, a.n, at, d);
