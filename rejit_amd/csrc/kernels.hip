@@ -2233,8 +2233,10 @@ constexpr int kHalo = 64;                    // bytes after the chunk kept in LD
 constexpr int kTextWindow = kChunk + kHalo;  // per wave
 
 // PD = depth of the lane-packed pre-steps (dense_swar.h), 0: the pattern does not qualify.
+// (amdgpu_waves_per_eu(6, 8): 80 instead of 90 VGPRs, six waves per SIMD instead of five -- measured 6 % on
+// `[a-f]+[0-9]`, 10 % on `[@#]`; seven waves need scratch and are slower again.)
 template <int NW, bool CTX, int PD>
-__global__ __launch_bounds__(256) void scan_dense_walk(ScanParams a, DevProgram P, uint64_t* region_ends,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void scan_dense_walk(ScanParams a, DevProgram P, uint64_t* region_ends,
                                                        unsigned long long* counters) {
   extern __shared__ uint32_t tab[];
   __shared__ uint32_t fb[8];  // first-byte bitmap (indexed by data: LDS, not registers)
