@@ -88,6 +88,11 @@ struct DevProgram {
   uint32_t cut_fwd[kDevMaxWindows][4];
   uint32_t cut_rev[kDevMaxWindows][4];
   SwarPlan swar;
+  // Bounded patterns of at most 16 bytes without assertions and <= 64 positions (the nine regexdna
+  // patterns: 8): the longest possible match in bytes, else 0.  rj_lane_longest_short then reads a
+  // candidate's text with two loads and fetches the class rows of its bytes together, instead of a
+  // byte load and a row load per step, each waiting for the one before.
+  uint32_t short_max;
 };
 
 // The NFA graph for the exact sequential kernel (reference ring semantics).
@@ -214,6 +219,69 @@ RJ_HD bool rj_lane_longest(const DevProgram& P, const uint8_t* t, uint64_t n, ui
       S[q] = T[q] & c;
     }
     p++;
+  }
+  return found;
+}
+
+// rj_lane_longest for DevProgram::short_max != 0 (n_ctx == 1, n_words <= 2, every match at most short_max
+// <= 16 bytes): same result, but the dependent chain is  text (two 8-byte loads) -> the class rows of all
+// bytes (independent loads) -> register arithmetic,  where the general walk has a byte load and a row load
+// per step, each waiting for the previous step.  The tails of the headline run are made of such chains.
+RJ_HD bool rj_lane_longest_short(const DevProgram& P, const uint8_t* t, uint64_t n, uint64_t s, uint64_t* end) {
+  const int W = P.n_words;
+  bool found = false;
+  if (P.nullable & 1u) {
+    found = true;
+    *end = s;
+  }
+  if (s >= n || P.n_pos == 0) return found;
+  const uint32_t L = P.short_max;
+  uint64_t lo = 0, hi = 0;
+  if (s + 16 <= n) {
+    __builtin_memcpy(&lo, t + s, 8);
+    __builtin_memcpy(&hi, t + s + 8, 8);
+  } else {
+    for (uint32_t k = 0; k < 16 && s + k < n; k++) {
+      const uint64_t c = t[s + k];
+      if (k < 8) lo |= c << (8 * k);
+      else hi |= c << (8 * (k - 8));
+    }
+  }
+  const uint32_t avail = n - s < 16 ? static_cast<uint32_t>(n - s) : 16u;
+  const uint32_t steps = L < avail ? L : avail;  // bytes a match can consume here
+  uint64_t row[16];
+#pragma unroll
+  for (uint32_t k = 0; k < 16; k++) {
+    row[k] = 0;
+    if (k < steps) {
+      const uint32_t c = static_cast<uint32_t>(((k < 8 ? lo : hi) >> (8 * (k & 7))) & 0xFFu);
+      const uint32_t* cr = P.cls + c * W;
+      row[k] = cr[0];
+      if (W > 1) row[k] |= static_cast<uint64_t>(cr[1]) << 32;
+    }
+  }
+  uint64_t first = P.first[0], last = P.last[0], lin = P.linear[0];
+  if (W > 1) {
+    first |= static_cast<uint64_t>(P.first[1]) << 32;
+    last |= static_cast<uint64_t>(P.last[1]) << 32;
+    lin |= static_cast<uint64_t>(P.linear[1]) << 32;
+  }
+  uint64_t S = first & row[0];
+#pragma unroll
+  for (uint32_t k = 1; k <= 16; k++) {
+    if (S == 0 || k > steps) break;
+    if (S & last) {
+      found = true;
+      *end = s + k;
+    }
+    if (k == steps) break;
+    uint64_t T = (S & lin) << 1;
+    for (uint64_t sp = S & ~lin; sp; sp &= sp - 1) {
+      const uint32_t* r = P.rows + static_cast<size_t>(P.row_of[__builtin_ctzll(sp)]) * W;
+      T |= r[0];
+      if (W > 1) T |= static_cast<uint64_t>(r[1]) << 32;
+    }
+    S = T & row[k];
   }
   return found;
 }

@@ -94,6 +94,7 @@ int upload_program(rj_program* rp) {
   D.table_words = static_cast<uint32_t>(total);
   loop_skip_masks(P, D.loop_mask, D.skip_mask);
   D.swar = getenv("RJ_NO_SWAR") == nullptr ? make_swar_plan(P) : SwarPlan{};  // (env: measurement override)
+  D.short_max = getenv("RJ_NO_SHORT") == nullptr ? short_match_bound(P) : 0u;   // (env: measurement override)
   D.n_words = W;
   D.n_ctx = C;
   D.n_rows = R;

@@ -982,8 +982,10 @@ __device__ __forceinline__ void verify_in_regions_body(const VerifyParams& a, co
       const uint64_t s = w - a.float_max;
       uint64_t e = 0;
       bool overrun = false;
-      const bool found = k < cnt && w >= a.float_max && s >= a.sb && s < a.se &&
-                         rj_lane_longest<NQ>(P, a.text, a.n, s, &e, &overrun, a.counters + kCntOverrun);
+      const bool in_range = k < cnt && w >= a.float_max && s >= a.sb && s < a.se;
+      // (short bounded patterns: the candidate's text in two loads, DevProgram::short_max)
+      const bool found = in_range && (NQ == 1 && P.short_max != 0 ? rj_lane_longest_short(P, a.text, a.n, s, &e)
+                                                                   : rj_lane_longest<NQ>(P, a.text, a.n, s, &e, &overrun, a.counters + kCntOverrun));
       if (overrun) a.counters[kCntOverrun] = 1;
       const uint32_t mine = static_cast<uint32_t>(__ballot(found) >> shift) & ((1u << G) - 1u);
       const uint32_t pos = kept + __popc(mine & ((1u << sub) - 1u));

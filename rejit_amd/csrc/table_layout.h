@@ -176,6 +176,12 @@ inline bool run_start_rule(const Program& P) {
   return true;
 }
 
+// DevProgram::short_max: the longest match of a bounded pattern that rj_lane_longest_short can take, else 0
+inline uint32_t short_match_bound(const Program& P) {
+  if (P.has_assertions || P.n_words > 2 || P.n_pos == 0 || P.max_len == Program::kUnboundedLen || P.max_len > 16 || P.max_len == 0) return 0;
+  return static_cast<uint32_t>(P.max_len);
+}
+
 // The plan of the lane-packed pre-steps (device_program.h: SwarPlan), or n_ranges = 0 when the pattern
 // does not qualify: <= 8 positions, no assertions, not nullable, at most two accepting positions, every
 // class a few ranges.

@@ -313,4 +313,29 @@ long ce_swar_check(const char* re, const uint8_t* text, uint64_t n, uint64_t* st
   return swar_check<4>(P, pl, text, n, stats);
 }
 
+// rj_lane_longest_short against rj_lane_longest, every start of the text.  Returns disagreements, -101 when
+// the pattern has no short bound; *checked = starts compared.
+long ce_short_check(const char* re, const uint8_t* text, uint64_t n, uint64_t* checked) {
+  LowerResult lr = lower(re);
+  if (lr.status != 0) return lr.status;
+  const Program& P = *lr.program;
+  const TableBlob fb = make_table_blob(P, P.n_pos, P.n_words, P.has_assertions);
+  DevProgram F{};
+  point_tables(&F, fb.words.data(), fb, P.n_pos);
+  F.nullable = nullable_bits(P);
+  F.max_walk = 1u << 20;
+  F.short_max = short_match_bound(P);
+  if (F.short_max == 0) return -101;
+  long bad = 0;
+  for (uint64_t s0 = 0; s0 <= n; s0++) {
+    uint64_t e1 = 0, e2 = 0;
+    bool overrun = false;
+    const bool f1 = rj_lane_longest<1>(F, text, n, s0, &e1, &overrun);
+    const bool f2 = rj_lane_longest_short(F, text, n, s0, &e2);
+    if (f1 != f2 || (f1 && e1 != e2)) bad++;
+    (*checked)++;
+  }
+  return bad;
+}
+
 }  // extern "C"

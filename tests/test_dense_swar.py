@@ -56,3 +56,31 @@ def test_plans(ce):
         assert ce.ce_swar_check(rx, tx, len(tx), st) == -101, rx
     for rx, depth in ((b"[@#]", 1), (b"[a-f][0-9]", 2), (b"[a-f]+[0-9]", 4)):
         assert ce.ce_swar_check(rx, tx, len(tx), st) == 0 and st[3] == depth, rx
+
+
+def test_short_bounded_verifier_equals_the_general_walk(ce):
+    """rj_lane_longest_short (device_program.h: a candidate's text in two loads, the class rows of its bytes
+    fetched together) against rj_lane_longest on every start -- the nine regexdna patterns and other bounded
+    patterns of up to 16 bytes, text ends included."""
+    import vectors as V
+    ce.ce_short_check.restype = ctypes.c_long
+    ce.ce_short_check.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, _u64p]
+    rng = random.Random(5)
+    pats = [V.b(x["regex"]) for x in V.bench()["regexdna"]["1000"]["patterns"]]
+    pats += [b"regexp", b"a", b"ab?c", b"[a-c]{2,5}x", b"(ab|cd|abcd)e?", b"a{16}", b"(a|b)(c|d)?(e|f)?", b"[acgt]{3}t|ca", b"x?y?z?", b"a{0,16}"]
+    total = 0
+    for rx in pats:
+        for alphabet in (b"acgt", b"abcdefxyz", b"ab", b"aaab"):
+            for n in (0, 1, 5, 15, 16, 17, 200):
+                tx = bytes(rng.choice(alphabet) for _ in range(n))
+                checked = ctypes.c_uint64(0)
+                bad = ce.ce_short_check(rx, tx, n, ctypes.byref(checked))
+                if bad == -101:     # (e.g. `x?`: the reference parses it as `x*`, SURVEY quirks -- no bound)
+                    assert rx not in pats[:10], rx
+                    continue
+                assert bad == 0, (rx, tx)
+                total += checked.value
+    assert total > 10000
+    c = ctypes.c_uint64(0)
+    for rx in (b"a+", b"^ab", b"a{17}", b"[a-z]+@x"):
+        assert ce.ce_short_check(rx, b"aaaa", 4, ctypes.byref(c)) == -101, rx
