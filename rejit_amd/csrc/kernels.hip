@@ -1911,23 +1911,45 @@ __global__ void chain_next(const uint64_t* keys, const uint64_t* vals, uint64_t 
   nxt[i] = lo;
 }
 
+// One WAVE per block of B <= 1024 candidates: the block's `nxt` is staged in LDS (coalesced), lane 0 resolves
+// G back to front there (a dependent step per candidate costs an LDS access, not a round trip to L2 as when one
+// lane walked a block in global memory -- that was 125 us of the complex-regex tail), the heads are found by
+// all lanes, G goes back coalesced.
 __global__ __launch_bounds__(64) void chain_local(const uint64_t* keys, const uint64_t* pmax, const uint64_t* nxt, uint64_t n,
                                                   uint64_t carry_cur, uint64_t B, const uint64_t* i0_ptr, uint64_t* G,
                                                   uint64_t* first_head, uint64_t* entry) {
-  const uint64_t blk = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  __shared__ uint64_t s_nxt[1024];
+  __shared__ uint64_t s_g[1024];
+  const uint64_t blk = blockIdx.x;
   const uint64_t lo = blk * B;
   if (lo >= n) return;
   const uint64_t hi = lo + B < n ? lo + B : n;
+  const uint32_t len = static_cast<uint32_t>(hi - lo), lane = threadIdx.x;
   uint64_t head = kChainNone;
-  for (uint64_t i = hi; i-- > lo;) {
-    const uint64_t t = nxt[i];
-    G[i] = t >= hi ? t : G[t];
+  for (uint32_t k = lane; k < len; k += 64) {
+    const uint64_t i = lo + k;
+    s_nxt[k] = nxt[i];
     const uint64_t floor_i = pmax[i] > carry_cur ? pmax[i] : carry_cur;
-    if (keys[i] >= floor_i && (i == 0 || keys[i] > keys[i - 1])) head = i;
+    if (head == kChainNone && keys[i] >= floor_i && (i == 0 || keys[i] > keys[i - 1])) head = i;  // (the lane's first: k ascends)
   }
-  first_head[blk] = head;
-  const uint64_t i0 = *i0_ptr;
-  entry[blk] = (i0 < n && i0 / B == blk) ? i0 : kChainNone;
+  __syncthreads();
+  if (lane == 0)
+    for (uint32_t k = len; k-- > 0;) {
+      const uint64_t t = s_nxt[k];
+      s_g[k] = t >= hi ? t : s_g[t - lo];
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {  // the block's first head = the minimum over the lanes
+    const uint64_t other = __shfl_xor(head, o);
+    head = other < head ? other : head;
+  }
+  __syncthreads();
+  for (uint32_t k = lane; k < len; k += 64) G[lo + k] = s_g[k];
+  if (lane == 0) {
+    first_head[blk] = head;
+    const uint64_t i0 = *i0_ptr;
+    entry[blk] = (i0 < n && i0 / B == blk) ? i0 : kChainNone;
+  }
 }
 
 __global__ __launch_bounds__(64) void chain_hop(const uint64_t* G, const uint64_t* first_head, const uint64_t* i0_ptr, uint64_t n,
@@ -1947,21 +1969,34 @@ __global__ __launch_bounds__(64) void chain_hop(const uint64_t* G, const uint64_
   }
 }
 
+// (a wave per block as well: the chain through the block is followed in LDS)
 __global__ __launch_bounds__(64) void chain_mark(const uint64_t* nxt, const uint64_t* first_head, const uint64_t* entry,
                                                  const uint64_t* i0_ptr, uint64_t n, uint64_t B, uint8_t* taken) {
-  const uint64_t blk = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  __shared__ uint64_t s_nxt[1024];
+  __shared__ uint8_t s_taken[1024];
+  const uint64_t blk = blockIdx.x;
   const uint64_t lo = blk * B;
   if (lo >= n) return;
   const uint64_t hi = lo + B < n ? lo + B : n;
   uint64_t i = entry[blk];
   if (i == kChainNone) {
     i = first_head[blk];
-    if (i == kChainNone || i < *i0_ptr) return;  // no chain comes through this block
+    if (i == kChainNone || i < *i0_ptr) return;  // no chain comes through this block (wave-uniform)
   }
-  while (i < hi) {
-    taken[i] = 1;
-    i = nxt[i];
+  const uint32_t len = static_cast<uint32_t>(hi - lo), lane = threadIdx.x;
+  for (uint32_t k = lane; k < len; k += 64) {
+    s_nxt[k] = nxt[lo + k];
+    s_taken[k] = 0;
   }
+  __syncthreads();
+  if (lane == 0)
+    while (i < hi) {
+      s_taken[i - lo] = 1;
+      i = s_nxt[i - lo];
+    }
+  __syncthreads();
+  for (uint32_t k = lane; k < len; k += 64)
+    if (s_taken[k]) taken[lo + k] = 1;
 }
 
 // idx[i] = i + 1 if candidate i was taken else 0 (input of the "last taken before i" max-scan)
@@ -2960,9 +2995,10 @@ void launch_chain_select(const uint64_t* keys, const uint64_t* vals, const uint6
   (void)hipMemsetAsync(taken, 0, n, st);
   hipLaunchKernelGGL(chain_next, dim3(blocks_for(n)), dim3(256), 0, st, keys, vals, n, carry_cur, nxt, i0);
   const unsigned lb = static_cast<unsigned>((nb + 63) / 64);
-  hipLaunchKernelGGL(chain_local, dim3(lb), dim3(64), 0, st, keys, pmax, nxt, n, carry_cur, B, i0, G, first_head, entry);
+  const unsigned wb = static_cast<unsigned>(nb);  // a wave per block of candidates
+  hipLaunchKernelGGL(chain_local, dim3(wb), dim3(64), 0, st, keys, pmax, nxt, n, carry_cur, B, i0, G, first_head, entry);
   hipLaunchKernelGGL(chain_hop, dim3(lb), dim3(64), 0, st, G, first_head, i0, n, B, entry);
-  hipLaunchKernelGGL(chain_mark, dim3(lb), dim3(64), 0, st, nxt, first_head, entry, i0, n, B, taken);
+  hipLaunchKernelGGL(chain_mark, dim3(wb), dim3(64), 0, st, nxt, first_head, entry, i0, n, B, taken);
 }
 
 void launch_taken_index(const uint8_t* taken, uint64_t n, uint64_t* idx, hipStream_t st) {
