@@ -27,7 +27,8 @@
 namespace rejit_amd {
 
 // does window k of P (<= 8 bytes, per-byte masks) occur at text position w?
-RJ_HD bool rj_window_at(const DevProgram& P, int k, const uint8_t* t, uint64_t n, uint64_t w) {
+template <class Text>
+RJ_HD bool rj_window_at(const DevProgram& P, int k, const Text& t, uint64_t n, uint64_t w) {
   if (w + P.win_len > n) return false;
   uint32_t v0 = 0, v1 = 0;
   for (uint32_t i = 0; i < P.win_len; i++) {
@@ -41,8 +42,8 @@ RJ_HD bool rj_window_at(const DevProgram& P, int k, const uint8_t* t, uint64_t n
 // step 1: a thread that has consumed text[p] at forward position q -- does it reach an accepting boundary?
 // (`abort`, may be null: polled every 256 steps -- once any walk of the run has hit the limit the run is
 // void and the others need not finish; a step is a chain of dependent loads, ~1 us)
-template <int NW>
-RJ_HD bool rj_reaches_accept(const DevProgram& P, const uint8_t* t, uint64_t n, uint64_t p, int q, bool* overrun,
+template <int NW, class Text>
+RJ_HD bool rj_reaches_accept(const DevProgram& P, const Text& t, uint64_t n, uint64_t p, int q, bool* overrun,
                              const volatile unsigned long long* abort = nullptr) {
   const int W = P.n_words;
   uint32_t S[NW], T[NW];
@@ -76,8 +77,8 @@ RJ_HD bool rj_reaches_accept(const DevProgram& P, const uint8_t* t, uint64_t n, 
 
 // step 2: S = reverse-automaton positions that have consumed text[p]; the left-most boundary at which one
 // of their threads can begin a match.  false: there is none.
-template <int NW>
-RJ_HD bool rj_leftmost_start(const DevProgram& R, const uint8_t* t, uint64_t n, uint64_t p, uint32_t (&S)[NW], uint32_t max_walk,
+template <int NW, class Text>
+RJ_HD bool rj_leftmost_start(const DevProgram& R, const Text& t, uint64_t n, uint64_t p, uint32_t (&S)[NW], uint32_t max_walk,
                              uint64_t* start, bool* overrun, const volatile unsigned long long* abort = nullptr) {
   const int W = R.n_words;
   uint32_t T[NW];
@@ -114,26 +115,40 @@ RJ_HD bool rj_leftmost_start(const DevProgram& R, const uint8_t* t, uint64_t n, 
 // the candidate of the hit at w: true and (*begin, *end) when there is one.  NQ = 64-bit state words of
 // the forward walk (rj_lane_longest), NW = 32-bit words: NQ = (NW + 1) / 2.
 template <int NW, int NQ>
-RJ_HD bool rj_behind_candidate(const DevProgram& P, const DevProgram& R, const uint8_t* t, uint64_t n, uint64_t w, uint64_t* begin,
+RJ_HD bool rj_behind_candidate(const DevProgram& P, const DevProgram& R, const uint8_t* text, uint64_t n, uint64_t w, uint64_t* begin,
                                uint64_t* end, bool* overrun, const volatile unsigned long long* abort = nullptr) {
+  // (the three walks read the text around the hit through 16 bytes in registers, device_program.h)
+  const RjCachedText t(text, n);
   const int W = P.n_words;
   uint32_t ok[NW];
 #pragma unroll
   for (int k = 0; k < NW; k++) ok[k] = 0;
   bool any = false;
-  for (int k = 0; k < P.n_windows; k++) {
-    if (!rj_window_at(P, k, t, n, w)) continue;
-    for (int j = 0; j < W; j++) {
-      uint32_t bits = P.cut_fwd[k][j];
-      while (bits) {
-        const int b = __builtin_ctz(bits);
-        bits &= bits - 1;
-        const int q = j * 32 + b;
-        if (rj_reaches_accept<NW>(P, t, n, w, q, overrun, abort)) {
-          const int r = P.n_pos - 1 - q;
-          ok[r >> 5] |= 1u << (r & 31);
-          any = true;
-        }
+  // The positions that may have consumed text[w]: those of every window that occurs at w.  (Constant
+  // indices into P -- the loop is unrolled over the maximum count: an index that is only known at run time
+  // makes the compiler keep the whole descriptor, two of them here, in scratch memory, which every lane of
+  // every workgroup then fills: 800 MB of stores per launch, the kernel's whole 180 us.)
+  uint32_t cut[NW];
+#pragma unroll
+  for (int j = 0; j < NW; j++) cut[j] = 0;
+#pragma unroll
+  for (int k = 0; k < kDevMaxWindows; k++) {
+    if (k >= P.n_windows || !rj_window_at(P, k, t, n, w)) continue;
+#pragma unroll
+    for (int j = 0; j < NW; j++)
+      if (j < W) cut[j] |= P.cut_fwd[k][j];
+  }
+#pragma unroll
+  for (int j = 0; j < NW; j++) {
+    uint32_t bits = cut[j];
+    while (bits) {
+      const int b = __builtin_ctz(bits);
+      bits &= bits - 1;
+      const int q = j * 32 + b;
+      if (rj_reaches_accept<NW>(P, t, n, w, q, overrun, abort)) {
+        const int r = P.n_pos - 1 - q;
+        ok[r >> 5] |= 1u << (r & 31);
+        any = true;
       }
     }
   }

@@ -57,7 +57,8 @@ struct CsArr {
 };
 
 // boundary context as in rj_context, 0 when the pattern has no assertions
-RJ_HD int cs_context(const DevProgram& R, const uint8_t* t, uint64_t n, uint64_t q) {
+template <class Text>
+RJ_HD int cs_context(const DevProgram& R, const Text& t, uint64_t n, uint64_t q) {
   return R.n_ctx > 1 ? rj_context(t, n, q) : 0;
 }
 

@@ -116,9 +116,46 @@ struct DevGraph {
 
 RJ_HD bool rj_line_break(uint32_t c) { return c == '\n' || c == '\r'; }
 
+// The text as the walkers read it: `t[p]` for a plain pointer, or through RjCachedText -- 16 aligned bytes
+// of the text held in registers, reloaded when a walk leaves them.  A walk's step is then a chain of
+// register operations and table lookups; with a plain pointer every step waits for a byte load, which for
+// the text around a fast-forward hit (streamed past minutes of kernel time ago, long out of the caches) is
+// a trip to HBM.  The text must be 16-byte aligned (the engine's device texts are) unless built for the host.
+struct RjCachedText {
+  const uint8_t* t;
+  uint64_t n;
+  mutable uint64_t base, lo, hi;
+  RJ_HD RjCachedText(const uint8_t* text, uint64_t len) : t(text), n(len), base(~0ull), lo(0), hi(0) {}
+  RJ_HD uint8_t operator[](uint64_t p) const {
+    const uint64_t b = p & ~15ull;
+    if (b != base) {
+      base = b;
+      if (b + 16 <= n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(t + b);
+        lo = v.x;
+        hi = v.y;
+#else
+        __builtin_memcpy(&lo, t + b, 8);
+        __builtin_memcpy(&hi, t + b + 8, 8);
+#endif
+      } else {
+        lo = hi = 0;
+        for (uint64_t k = 0; k < 16 && b + k < n; k++) {
+          const uint64_t c = t[b + k];
+          if (k < 8) lo |= c << (8 * k);
+          else hi |= c << (8 * (k - 8));
+        }
+      }
+    }
+    return static_cast<uint8_t>(((p & 8) ? hi : lo) >> (8 * (p & 7)));
+  }
+};
+
 // Context at text position p: bit0 start-of-line, bit1 end-of-line
-// (MatchStartOrEndOfLine, reference src/x64/codegen-x64.cc:686-708).
-RJ_HD int rj_context(const uint8_t* t, uint64_t n, uint64_t p) {
+// (MatchStartOrEndOfLine, reference src/x64/codegen-x64.cc:686-708).  Text: const uint8_t* or RjCachedText.
+template <class Text>
+RJ_HD int rj_context(const Text& t, uint64_t n, uint64_t p) {
   int ctx = 0;
   if (p == 0 || rj_line_break(t[p - 1])) ctx |= 1;
   if (p == n || rj_line_break(t[p])) ctx |= 2;
@@ -135,8 +172,8 @@ RJ_HD int rj_context(const uint8_t* t, uint64_t n, uint64_t p) {
 // the run is void, and the others need not finish.
 constexpr uint64_t kMaxSimSteps = 1ull << 20;
 
-template <int NQ>
-RJ_HD bool rj_lane_longest(const DevProgram& P, const uint8_t* t, uint64_t n, uint64_t s, uint64_t* end,
+template <int NQ, class Text>
+RJ_HD bool rj_lane_longest(const DevProgram& P, const Text& t, uint64_t n, uint64_t s, uint64_t* end,
                            bool* overrun, const volatile unsigned long long* abort = nullptr) {
   const int W = P.n_words;  // 32-bit words; NQ*2 >= W
   const bool ctxed = P.n_ctx > 1;

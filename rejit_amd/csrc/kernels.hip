@@ -1058,7 +1058,8 @@ __global__ __launch_bounds__(256) void verify_floating_in_regions(VerifyParams a
         const uint64_t s = base + sub;
         uint64_t e = 0;
         bool overrun = false;
-        const bool found = s <= hi && s >= a.sb && s < a.se && rj_lane_longest<NQ>(Q, a.text, a.n, s, &e, &overrun, a.counters + kCntOverrun);
+        const RjCachedText ct(a.text, a.n);  // (the walk reads the text 16 bytes at a time, device_program.h)
+        const bool found = s <= hi && s >= a.sb && s < a.se && rj_lane_longest<NQ>(Q, ct, a.n, s, &e, &overrun, a.counters + kCntOverrun);
         if (overrun) a.counters[kCntOverrun] = 1;
         const uint64_t mine = __ballot(found);
         const uint32_t pos = kept + __popcll(mine & ((1ull << sub) - 1ull));
