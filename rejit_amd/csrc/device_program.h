@@ -148,7 +148,10 @@ struct RjCachedText {
         }
       }
     }
-    return static_cast<uint8_t>(((p & 8) ? hi : lo) >> (8 * (p & 7)));
+    // (an arithmetic select: `(p & 8) ? hi : lo` becomes an indexed load from the object, which then lives
+    // in scratch memory instead of registers)
+    const uint64_t m = 0ull - ((p >> 3) & 1ull);
+    return static_cast<uint8_t>(((lo & ~m) | (hi & m)) >> (8 * (p & 7)));
   }
 };
 
