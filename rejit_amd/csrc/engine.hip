@@ -9,8 +9,13 @@
 //                that overlap go through the selection kernels.  Dense patterns: one kernel
 //                (scan_dense_walk) + the gather.  Automata of more than 128 positions: the list
 //                pipeline (region_offsets, verify_wave, finalize_small / mark + compact).
-//   rj_multi_* : several patterns over one text (fused scan, or scans back to back + batched tails)
-//   rj_match_all_batch: many texts in one pass; rj_match_first/anywhere: early exit
+//                Texts of a few KiB: one workgroup, one launch (match_small).  A walk that outlives
+//                max_walk: the run is repeated on the linear-time carry scan (linear.hip).  Patterns at risk
+//                of the reference's ring artefact whose candidates touch, and ranges of such patterns: the
+//                reference's own loop replayed between synchronisation points (exact_replay.hip).
+//   rj_multi_* : several patterns over one text (fused scan / scan train / scans back to back + batched tails)
+//   rj_match_all_batch: many texts in one pass; rj_match_first/anywhere: early exit;
+//   rj_match_all / _batch over host buffers >= 256 MiB: one part per visible device (multi_device.hip)
 //
 // There is no CPU matching code in this library: without a working HIP device every
 // entry point fails with RJ_DEVICE_ERROR.

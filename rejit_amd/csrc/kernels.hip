@@ -11,22 +11,33 @@
 //                          in SGPRs, VALU only (xor/and/min, one v_cmp + ballot per chunk); exact,
 //                          two-level or nibble-packed form.  Hit offsets go to the wave's own
 //                          region of the hit list: no atomics, sorted by construction.
-//   scan_windows_fused     the same for several patterns in one pass over the text (rj_multi).
+//   scan_windows_fused     the same for several patterns in one pass over the text (rj_multi mode 0: a shared
+//                          nibble-distance prefilter, per-pattern classification on hit lanes only);
+//   scan_windows_train     every pattern's own scan in ONE launch, a wave going through its span pattern
+//                          after pattern (rj_multi mode 1, the bench headline).
 //   verify_in_regions<NQ>  the NFA inner loop (GenerateMatchDirection + GenerateTransitions,
 //                          codegen-x64.cc:535-677): longest match from every hit, automaton state
-//                          in NQ 64-bit registers per lane, survivors compacted inside their region;
-//                          verify_floating_in_regions for floating windows.
+//                          in NQ 64-bit registers per lane, survivors compacted inside their region
+//                          (bounded patterns of <= 16 bytes: rj_lane_longest_short, the candidate's text in
+//                          two loads); verify_floating_in_regions for floating windows;
+//                          verify_behind_in_regions for windows behind an unbounded prefix (behind_walk.h:
+//                          forward check, REVERSE automaton back to the left-most start, forward longest).
 //   offsets_gather_check   region offsets + gather + "the candidates already are the result" check
 //                          (MatchAllAppendFilter + the non-overlap rule, src/codegen.cc:36-86,
 //                          codegen-x64.cc:448-460) in one multi-workgroup launch.
-//   scan_dense_walk<NW,CTX> dense mode (no fast-forward window; GenerateMatchDirection seeding
+//   scan_dense_walk<NW,CTX,PD> dense mode (no fast-forward window; GenerateMatchDirection seeding
 //                          every position, codegen-x64.cc:544-554) in ONE kernel: candidate masks,
-//                          register pre-steps, persistent walker lanes, in-region compaction.
+//                          pre-steps in registers (PD > 0: lane-packed, four starts per register, class rows
+//                          by byte-parallel range tests -- dense_swar.h), chunks whose candidates are all
+//                          decided emit directly, the others go through persistent walker lanes and an
+//                          in-region compaction.
+//   match_small<NQ>        texts of a few KiB: the whole MatchAll in one workgroup, one launch.
 //
-// and around it: finalize_small / select_walk & co (the selection when candidates overlap),
-// verify_wave + region_offsets + mark/compact (automata of more than 128 positions), match_full
-// (kMatchFull, codegen-x64.cc:162-164), exact_sequential (the reference's whole loop on one lane,
-// for the Q8 artefact), replace_gather (rejit::Replace, src/rejit.cc:97-112).
+// and around it: finalize_small / chain_* & co (the selection when candidates overlap: blocked chains, a wave
+// per block, staged in LDS), verify_wave + region_offsets + mark/compact (automata of more than 128
+// positions), match_full (kMatchFull, codegen-x64.cc:162-164), exact_sequential (the reference's whole loop
+// on one lane: automata too wide for exact_replay.hip), replace_gather (rejit::Replace, src/rejit.cc:97-112).
+// The linear-time carry scan lives in carry_kernels.hip, the reference-exact replay in exact_replay.hip.
 //
 // No MFMA: there is no contraction anywhere on this path (integer compares on a byte stream);
 // the roofline is HBM read bandwidth.
