@@ -18,6 +18,11 @@ text is stored):
                          Q1-Q3 inputs) with reference(ff=0) outputs and, where they differ,
                          the known-bad default-flag outputs.
   fuzz_vectors.json      seeded random (regexp, text) pairs with reference(ff=0) outputs.
+  artefact_vectors.json  inputs on which the reference's ring artefact ("Q8") applies or nearly
+                         applies: hand-written at-risk patterns and random patterns on which the reference and
+                         the documented semantics were seen to differ, over texts of up to 600 bytes with many
+                         adjacent candidates; reference(ff=0) outputs.  (The oracle's `match_all_spec` is used
+                         only to SELECT inputs; every expectation stored is the real reference's.)
   bench_vectors.json     the 12 benchmark regexps (tools/benchmarks/run.py:347-360) on
                          seeded random text with planted matches; regexdna patterns on the
                          FASTA n=50000 input; reference(ff=0) outputs (offsets or digest).
@@ -359,6 +364,44 @@ def gen_fuzz(ref: RefProc, count=2500, seed=20260926):
     return out
 
 
+
+# --------------------------------------------------------------------------- the ring artefact
+ARTEFACT_PATTERNS = [".{0,2}.", "[a-f]+[0-9][a-f]", "(ab|ba)+", "[xy]+z[xy]", "x+yx", "(aa|aaa)+", "[a-z]+@[a-z]+", "^.{0,2}.",
+                     "[ab]+b[ab]", "a+(b|ca)", ".{1,3}b", "(a|bc){1,3}d?", "[a-c]+d[a-c]*"]
+
+
+def gen_artefact(ref: RefProc, seed=20260927):
+    from checkers import Oracle
+    oracle = Oracle()
+    rng = random.Random(seed)
+    out, differ = [], 0
+    pats = [(p, "abcdef0123xyz@ \n") for p in ARTEFACT_PATTERNS]
+    tries = 0
+    while len(pats) < 60 and tries < 20000:     # random patterns on which the artefact shows
+        tries += 1
+        alphabet = rng.choice(ALPHABETS)
+        rx = RegexGen(rng, alphabet).alt(2)
+        text = "".join(rng.choice(alphabet) for _ in range(120)).encode("latin1")
+        w = oracle.match_all(rx.encode("latin1"), text)
+        if isinstance(w, list) and w != oracle.match_all_spec(rx.encode("latin1"), text):
+            pats.append((rx, alphabet))
+    for rx, alphabet in pats:
+        rxb = rx.encode("latin1")
+        for n in (5, 12, 40, 90, 200, 350, 600):
+            for alpha in (alphabet, alphabet[:max(2, len(alphabet) // 3)]):
+                text = "".join(rng.choice(alpha) for _ in range(n))
+                txb = text.encode("latin1")
+                allm = ref.call("all", rxb, txb, timeout=5.0)
+                if not isinstance(allm, list):
+                    continue
+                full = ref.call("full", rxb, txb, timeout=5.0)
+                if full not in (0, 1):
+                    continue
+                differ += pairs(allm) != [list(x) for x in oracle.match_all_spec(rxb, txb)]
+                out.append(dict(regex=rx, text=text, ref_all=pairs(allm), ref_full=full))
+    print(f"artefact: {len(out)} vectors over {len(pats)} patterns; the reference differs from the documented semantics on {differ}")
+    return out
+
 # --------------------------------------------------------------------------- bench-shaped
 def digest(ms):
     h = hashlib.sha256()
@@ -441,13 +484,15 @@ def dump(name, obj):
 
 def main():
     ref = RefProc()
-    which = sys.argv[1:] or ["testcc", "semantics", "fuzz", "bench"]
+    which = sys.argv[1:] or ["testcc", "semantics", "fuzz", "artefact", "bench"]
     if "testcc" in which:
         dump("testcc_vectors.json", gen_testcc(ref))
     if "semantics" in which:
         dump("semantics_vectors.json", gen_semantics(ref))
     if "fuzz" in which:
         dump("fuzz_vectors.json", gen_fuzz(ref))
+    if "artefact" in which:
+        dump("artefact_vectors.json", gen_artefact(ref))
     if "bench" in which:
         dump("bench_vectors.json", gen_bench(ref))
 

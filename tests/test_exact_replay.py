@@ -58,6 +58,22 @@ def test_all_vectors_equal_the_reference(ce):
     assert n > 2500 and risky > 0
 
 
+def test_ring_artefact_vectors_equal_the_reference(ce):
+    """The 840 artefact vectors (expectations from the real reference): the replay gives the reference's answer
+    whole-text and split into ranges."""
+    n = 0
+    for rx, tx, exp_all, _ in V.artefact_cases():
+        for chunk in (7, 1024):
+            got, _info = exact(ce, rx, tx, chunk)
+            assert got == exp_all, (rx, tx, chunk)
+        cut = len(tx) // 2
+        a, _ = exact(ce, rx, tx, 16, 0, cut)
+        b, _ = exact(ce, rx, tx, 16, cut, len(tx) + 1)
+        assert a + b == exp_all, (rx, tx, cut)
+        n += 1
+    assert n >= 800
+
+
 AT_RISK = [b".{0,2}.", b"x*", b"(a|ab)(c|bcd)*", b"a*b*", b"(ab|a)*", b".{0,3}x?", b"[ab]*c?", b"(a|b|ab)+", b"^.{0,2}.", b"a?b?c?",
            b"(x|xy)*z?", b".?.?"]
 

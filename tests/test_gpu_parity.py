@@ -65,6 +65,19 @@ def test_golden_vectors(rj, oracle):
     assert n > 2500
 
 
+def test_ring_artefact_vectors(rj):
+    """The engine against the REAL reference's outputs where its ring artefact applies (263 of these 840 vectors
+    differ from the documented semantics): host-text calls, i.e. the small-text kernel handing over to the
+    general pipeline and the exact replay."""
+    n = 0
+    for rx, tx, exp_all, exp_full in V.artefact_cases():
+        p = prog(rj, rx)
+        assert p.match_all(tx) == exp_all, (rx, tx)
+        assert p.match_full(tx) == bool(exp_full), (rx, tx)
+        n += 1
+    assert n >= 800
+
+
 def test_fresh_random_vs_oracle(rj, oracle):
     """Seeds that are NOT in the committed fixtures, longer texts (more adjacent matches):
     the GPU result must equal the strict restatement of the reference bit for bit."""

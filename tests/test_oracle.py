@@ -57,6 +57,19 @@ def test_against_reference_outputs(oracle):
     assert n > 2500
 
 
+def test_ring_artefact_vectors(oracle):
+    """The oracle is the REFERENCE's loop, artefact included: 840 vectors on which the reference's ring artefact
+     applies or nearly applies -- on 263 of them the reference differs from the documented
+    left-most-longest semantics -- with the real reference's outputs (tests/golden/make_golden.py artefact)."""
+    n = differ = 0
+    for rx, tx, exp_all, exp_full in V.artefact_cases():
+        assert oracle.match_all(rx, tx) == exp_all, (rx, tx)
+        assert oracle.match_full(rx, tx) == exp_full, (rx, tx)
+        differ += oracle.match_all_spec(rx, tx) != exp_all
+        n += 1
+    assert n >= 800 and differ >= 200
+
+
 def test_parse_errors(oracle):
     for e in V.semantics()["errors"]:
         st = oracle.status(V.b(e["regex"]))

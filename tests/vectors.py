@@ -34,6 +34,17 @@ def bench():
     return _load("bench_vectors.json")
 
 
+def artefact():
+    return _load("artefact_vectors.json")
+
+
+def artefact_cases():
+    """(regex, text, the reference's MatchAll offsets, MatchFull) where the reference's ring artefact applies or
+    nearly applies (make_golden.py: gen_artefact) -- expectations from the real reference, never from the oracle."""
+    for v in artefact():
+        yield b(v["regex"]), b(v["text"]), tup(v["ref_all"]), v["ref_full"]
+
+
 def all_matchall_cases():
     """Every (regex, text, expected MatchAll offsets, expected MatchFull) in the fixtures."""
     seen = set()
