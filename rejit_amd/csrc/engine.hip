@@ -13,9 +13,9 @@
 //                max_walk: the run is repeated on the linear-time carry scan (linear.hip).  Patterns at risk
 //                of the reference's ring artefact whose candidates touch, and ranges of such patterns: the
 //                reference's own loop replayed between synchronisation points (exact_replay.hip).
-//   rj_multi_* : several patterns over one text (fused scan / scan train / scans back to back + batched tails)
-//   rj_match_all_batch: many texts in one pass; rj_match_first/anywhere: early exit;
-//   rj_match_all / _batch over host buffers >= 256 MiB: one part per visible device (multi_device.hip)
+// rj_multi_* (several patterns over one text) live in multi_pattern.hip, the host-text entry points
+// (rj_match_all, rj_match_all_batch, rj_match_first / anywhere / full, rj_replace_all) in host_api.hip, the
+// split of one call over all visible devices in multi_device.hip.
 //
 // There is no CPU matching code in this library: without a working HIP device every
 // entry point fails with RJ_DEVICE_ERROR.
@@ -363,7 +363,7 @@ int resolve_selection(rj_scan* s, const FinalizeParams& fp, hipStream_t st) {
 }
 }  // namespace rejit_amd
 
-namespace {
+namespace rejit_amd {
 
 // The window constants a scan kernel takes (exact or nibble form, see WindowSet).
 WindowSet make_window_set(const rj_program* rp) {
@@ -409,8 +409,8 @@ constexpr uint64_t kDenseSegment = 1ull << 27;  // dense mode: starts per pipeli
 
 // One full pipeline over the starts [sb, se): scan -> region offsets -> verify -> finalize.
 // Results: s->out (device, ordered pairs), s->result_count.
-int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, uint64_t carry_cur,
-              uint64_t carry_prev_end, int have_prev, hipStream_t st, bool force_dense = false) {
+static int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, uint64_t carry_cur,
+                     uint64_t carry_prev_end, int have_prev, hipStream_t st, bool force_dense = false) {
   const rj_program* rp = s->prog;
   // Windows behind an unbounded prefix give ONE candidate per hit (the left-most start): enough for a
   // run from the beginning of the text, not for an own range that begins inside it (a start clipped by
@@ -666,7 +666,7 @@ int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
 
 // automata too wide for the exact replay's synchronisation scan: the reference's loop on ONE lane over the
 // whole text, up to kExactLimit bytes
-int run_exact_one_lane(rj_scan* s, const uint8_t* d_text, uint64_t n, hipStream_t st) {
+static int run_exact_one_lane(rj_scan* s, const uint8_t* d_text, uint64_t n, hipStream_t st) {
   const rj_program* rp = s->prog;
   RJ_HIP(s->ring.reserve(static_cast<size_t>(rp->graph.times) * rp->graph.n_states * sizeof(int64_t)));
   int rc = ensure_lists(s, 1, 1, std::max<uint64_t>(s->cands_cap, n + 2));
@@ -798,7 +798,7 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
   return RJ_OK;
 }
 
-int scan_init(rj_scan* s) {
+static int scan_init(rj_scan* s) {
   RJ_HIP(s->counters.reserve(kCntSize * sizeof(unsigned long long)));
   RJ_HIP(s->flag.reserve(16));
   RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->host_counters), kCntSize * sizeof(unsigned long long)));
@@ -807,369 +807,7 @@ int scan_init(rj_scan* s) {
   return RJ_OK;
 }
 
-// one scratch per (thread, program) for the host-text entry points
-struct HostScans {
-  std::vector<std::pair<uint64_t, rj_scan*>> v;  // keyed by rj_program::id, not by address
-  ~HostScans() {
-    for (auto& p : v) rj_scan_destroy(p.second);
-  }
-};
-thread_local HostScans g_host_scans;
-
-int host_scan_for(const rj_program* prog, rj_scan** out) {
-  for (auto& p : g_host_scans.v)
-    if (p.first == prog->id) {
-      *out = p.second;
-      return RJ_OK;
-    }
-  rj_scan* s = nullptr;
-  int rc = rj_scan_create(prog, &s);
-  if (rc != RJ_OK) return rc;
-  if (hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking) != hipSuccess) {
-    rj_scan_destroy(s);
-    return fail(RJ_DEVICE_ERROR, "hipStreamCreate failed");
-  }
-  if (g_host_scans.v.size() >= 16) {  // bound the cache
-    rj_scan_destroy(g_host_scans.v.front().second);
-    g_host_scans.v.erase(g_host_scans.v.begin());
-  }
-  g_host_scans.v.emplace_back(prog->id, s);
-  *out = s;
-  return RJ_OK;
-}
-
-// the first `pairs` result pairs of the last run into host memory (the results of the small-text kernel
-// already ARE in host memory)
-hipError_t copy_result_pairs(rj_scan* s, uint64_t* dst, uint64_t first, uint64_t pairs, hipStream_t st) {
-  if (pairs == 0) return hipSuccess;
-  if (s->result == s->small_out && s->small_out != nullptr) {
-    memcpy(dst, s->small_out + 2 * first, pairs * 2 * sizeof(uint64_t));
-    return hipSuccess;
-  }
-  hipError_t e = hipMemcpyAsync(dst, s->result + 2 * first, pairs * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
-  return e;
-}
-
-int stage_text(rj_scan* s, const char* text, size_t n, const uint8_t** d_text) {
-  static const bool no_small = getenv("RJ_NO_SMALL") != nullptr;
-  const DevProgram& D = s->prog->dev;
-  if (n <= kSmallMaxText && D.n_words <= 4 && D.table_words <= kSmallMaxTableWords && !no_small &&
-      small_lds_bytes(D, static_cast<uint32_t>(n)) <= small_lds_limit()) {
-    // a small text stays in (pinned) host memory: match_small reads it over PCIe in one round trip, which
-    // beats a copy command plus its completion wait; should the general pipeline have to take the run
-    // after all, its kernels read the same memory (slower, rare)
-    if (s->small_text == nullptr) RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->small_text), kSmallMaxText + 64));
-    if (n) memcpy(s->small_text, text, n);
-    *d_text = reinterpret_cast<const uint8_t*>(s->small_text);
-    return RJ_OK;
-  }
-  RJ_HIP(s->text.reserve(((n + 64 + 4095) / 4096) * 4096));
-  if (n) RJ_HIP(hipMemcpyAsync(s->text.p, text, n, hipMemcpyHostToDevice, s->own_stream));
-  *d_text = s->text.as<uint8_t>();
-  return RJ_OK;
-}
-
-// ----------------------------------------------------------------------------- fused multi-pattern run
-// fixed windows + lane-sized automaton, not at risk of Q8: the in-region pipeline without carry
-bool batchable(const rj_program* rp) {
-  const DevProgram& D = rp->dev;
-  return D.mode == 1 && D.float_range == 1 && D.n_words <= 4 && !rp->host->q8_risk && !D.behind;
-}
-
-bool fusable(const rj_program* rp) {
-  const DevProgram& D = rp->dev;
-  return D.mode == 1 && D.float_range == 1 && D.n_words <= 4 && D.win_len > 4 && D.n_windows <= 2 &&
-         rp->window_alphabet <= 4 && rp->window_nibbles && !rp->host->q8_risk && !D.behind;
-}
-
-// nibble form of window k (see WindowSet::nibble)
-void nibble_window(const DevProgram& D, int k, uint32_t* value, uint32_t* mask) {
-  uint32_t v = 0, m = 0;
-  for (int i = 0; i < 8; i++) {
-    const uint32_t vb = (i < 4 ? (D.win_value0[k] >> (8 * i)) : (D.win_value1[k] >> (8 * (i - 4)))) & 0xFFu;
-    const uint32_t mb = (i < 4 ? (D.win_mask0[k] >> (8 * i)) : (D.win_mask1[k] >> (8 * (i - 4)))) & 0xFFu;
-    const int at = 8 * (i & 3) + 4 * (i >> 2);
-    if (mb) {
-      v |= (vb & 15u) << at;
-      m |= 15u << at;
-    }
-  }
-  *value = v;
-  *mask = m;
-}
-
-}  // namespace
-
-struct rj_multi {
-  std::vector<rj_scan*> scans;
-  DeviceBuffer dummy_counts;  // hit_counts of the padding patterns
-  DeviceBuffer tails;         // MultiTail[P]
-  MultiTail* host_tails = nullptr;  // pinned
-  uint64_t* host_bounds = nullptr;  // pinned, rj_multi_bounds
-  hipStream_t second = nullptr;     // separate-scans mode: odd patterns' scan kernels
-  hipEvent_t fork = nullptr, join = nullptr;
-  std::vector<MultiTail> uploaded;  // what the device array holds (skip the copy when nothing changed)
-  bool fused = false;     // every pattern has a nibble-form window set: one kernel scans for all
-  bool batchable = false; // every pattern takes the in-region pipeline: scans back to back, tails together
-  int mode = 0;           // rj_multi_set_mode
-  float scan_ms = 0.f;
-};
-
-namespace {
-
-// The scans of all patterns (ONE fused kernel, or one kernel per pattern back to back) + the tails of
-// all patterns in two launches + one synchronise.  Whole text, starts [0, n].
-int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, hipStream_t st, bool fuse) {
-  const int P = static_cast<int>(m->scans.size());
-  // chunks that can hold a window of a start in [sb, se): a window begins at most 7 bytes after its start
-  const uint64_t end_byte = std::min<uint64_t>(n, se + 8);
-  const uint64_t chunks = std::max<uint64_t>((end_byte + 1023) / 1024 - sb / 1024, 1);
-  const ScanGeometry geo = scan_geometry(chunks);
-  for (int attempt = 0; attempt < 6; attempt++) {
-    FusedParams fp{};
-    fp.text = d_text;
-    fp.n = n;
-    fp.sb = sb;
-    fp.se = se;
-    fp.span_chunks = geo.span_chunks;
-    fp.n_patterns = static_cast<uint32_t>((P + kFuseGroup - 1) / kFuseGroup * kFuseGroup);
-    RJ_HIP(m->dummy_counts.reserve(static_cast<size_t>(geo.n_regions) * sizeof(uint32_t)));
-    std::vector<uint64_t> caps(static_cast<size_t>(P));
-    for (int p = 0; p < static_cast<int>(fp.n_patterns); p++) {
-      const int q = p < P ? p : 0;  // padding repeats pattern 0 with no room for hits
-      rj_scan* s = m->scans[static_cast<size_t>(q)];
-      const DevProgram& D = s->prog->dev;
-      nibble_window(D, 0, &fp.value[p][0], &fp.mask[p][0]);
-      nibble_window(D, D.n_windows > 1 ? 1 : 0, &fp.value[p][1], &fp.mask[p][1]);
-      fp.offset[p] = D.win_offset;
-      fp.len[p] = D.win_len;
-      if (p < P) {
-        const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(s->region_cap_hint, 64), geo.span_chunks * 1024);
-        caps[static_cast<size_t>(p)] = cap;
-        int rc = ensure_lists(s, geo.n_regions, static_cast<uint32_t>(cap), static_cast<uint64_t>(geo.n_regions) * cap);
-        if (rc != RJ_OK) return rc;
-        RJ_HIP(s->valid_counts.reserve(static_cast<size_t>(geo.n_regions) * sizeof(uint32_t)));
-        fp.hits[p] = s->hits.as<uint64_t>();
-        fp.region_cap[p] = static_cast<uint32_t>(cap);
-        fp.hit_counts[p] = s->hit_counts.as<uint32_t>();
-        fp.zero_counters[p] = s->counters.as<unsigned long long>();
-        s->stats = rj_stats{};
-        s->result = nullptr;
-        s->result_count = 0;
-      } else {
-        fp.hits[p] = m->scans[0]->hits.as<uint64_t>();
-        fp.region_cap[p] = 0;
-        fp.hit_counts[p] = m->dummy_counts.as<uint32_t>();
-        fp.zero_counters[p] = nullptr;
-      }
-    }
-    rj_scan* s0 = m->scans[0];
-    fp.n_bases = 0;
-    static const bool no_prefilter = getenv("RJ_NO_FUSED_PREFILTER") != nullptr;  // measurement override
-    if (fuse && m->mode == 0 && !no_prefilter) {
-      // Shared prefilter (kernels.hip: fused_chunk_d1): are all windows within one nibble of <= 2 base
-      // windows?  Nibbles are compared on their low 3 bits there.  A base is a window without
-      // wildcards; greedy: the first uncovered exact window becomes the next base.
-      auto nibbles_off = [](uint32_t v, uint32_t k, uint32_t base) {  // nibbles in which (v, k) leaves `base` free or differs
-        int d = 0;
-        for (int i = 0; i < 8; i++) {
-          const uint32_t kk = (k >> (4 * i)) & 7u, vv = (v >> (4 * i)) & 7u, bb = (base >> (4 * i)) & 7u;
-          d += (kk == 0 || vv != bb) ? 1 : 0;
-        }
-        return d;
-      };
-      uint32_t bases[2] = {0, 0};
-      int nb = 0;
-      bool ok = true;
-      for (int pass = 0; pass < 2 && ok; pass++)
-        for (int p = 0; p < P && ok; p++)
-          for (int w = 0; w < 2 && ok; w++) {
-            const uint32_t v = fp.value[p][w] & 0x77777777u, k = fp.mask[p][w] & 0x77777777u;
-            bool covered = false;
-            for (int b = 0; b < nb; b++) covered = covered || nibbles_off(v, k, bases[b]) <= 1;
-            if (covered) continue;
-            if (pass == 0) {
-              if (k == 0x77777777u && nb < 2) bases[nb++] = v;  // an exact window: a new base
-            } else {
-              ok = false;  // second pass: still not within one nibble of a base
-            }
-          }
-      if (ok && nb > 0) {
-        fp.n_bases = static_cast<uint32_t>(nb);
-        fp.base[0] = bases[0];
-        fp.base[1] = bases[nb > 1 ? 1 : 0];
-        for (int p = 0; p < static_cast<int>(fp.n_patterns); p++)
-          for (int w = 0; w < 2; w++) {
-            fp.value[p][w] &= 0x77777777u;
-            fp.mask[p][w] &= 0x77777777u;
-          }
-      }
-    }
-    if (fuse) {
-      launch_scan_windows_fused(fp, geo.grid, s0->ev[1], s0->ev[2], st);
-    } else {
-      // every pattern's own scan kernel (each at its full streaming rate), queued back to back on
-      // the caller's stream -- or, mode 2, alternating between it and a second stream: kernels of ONE
-      // stream run strictly one after the other, so every kernel boundary costs the drain of the
-      // last workgroups plus the ramp-up of the next grid; with two streams the next kernel's
-      // workgroups fill the slots as they become free (regexdna step 0.95 -> 0.89 ms)
-      // (mode 2 only: the kernels of the two streams overlap in time, so a per-kernel duration no
-      // longer means what a roofline needs; the default keeps them on the caller's stream)
-      const bool two_streams = m->mode == 2;
-      // mode 1, every pattern with the regexdna shape (two nibble-form windows): the scans as one launch
-      static const bool no_train = getenv("RJ_NO_TRAIN") != nullptr;  // measurement override
-      bool train = m->mode == 1 && !no_train;  // (mode 3: one launch per pattern, as round 1 did)
-      for (int p = 0; p < P && train; p++) train = fusable(m->scans[static_cast<size_t>(p)]->prog);
-      if (train) {
-        TrainParams tp{};
-        tp.text = d_text;
-        tp.n = n;
-        tp.sb = sb;
-        tp.se = se;
-        tp.span_chunks = geo.span_chunks;
-        tp.n_patterns = static_cast<uint32_t>(P);
-        bool masked = false;
-        for (int p = 0; p < P; p++) {
-          rj_scan* s = m->scans[static_cast<size_t>(p)];
-          const DevProgram& D = s->prog->dev;
-          tp.value[p][0] = fp.value[p][0];
-          tp.mask[p][0] = fp.mask[p][0];
-          tp.value[p][1] = fp.value[p][1];
-          tp.mask[p][1] = fp.mask[p][1];
-          masked = masked || fp.mask[p][0] != 0xFFFFFFFFu || fp.mask[p][1] != 0xFFFFFFFFu;
-          tp.offset[p] = D.win_offset;
-          tp.len[p] = D.win_len;
-          tp.wlo[p] = sb + D.win_offset;
-          const uint64_t last_w = n >= D.win_len ? n - D.win_len + 1 : 0;
-          tp.whi[p] = std::min<uint64_t>(se + D.win_offset, last_w);
-          if (tp.whi[p] < tp.wlo[p]) tp.whi[p] = tp.wlo[p];
-          tp.hits[p] = s->hits.as<uint64_t>();
-          tp.region_cap[p] = static_cast<uint32_t>(caps[static_cast<size_t>(p)]);
-          tp.hit_counts[p] = s->hit_counts.as<uint32_t>();
-          tp.zero_counters[p] = s->counters.as<unsigned long long>();
-        }
-        launch_scan_windows_train(tp, masked, geo.grid, s0->ev[1], s0->ev[2], st);
-      }
-      if (two_streams) {
-        RJ_HIP(hipEventRecord(m->fork, st));
-        RJ_HIP(hipStreamWaitEvent(m->second, m->fork, 0));
-      }
-      for (int p = 0; p < P && !train; p++) {
-        rj_scan* s = m->scans[static_cast<size_t>(p)];
-        const DevProgram& D = s->prog->dev;
-        ScanParams sp{};
-        sp.text = d_text;
-        sp.n = n;
-        sp.sb = sb;
-        sp.se = se;
-        sp.wlo = sb + D.win_offset;
-        const uint64_t last_w = n >= D.win_len ? n - D.win_len + 1 : 0;
-        sp.whi = std::min<uint64_t>(se + D.win_offset, last_w);
-        if (sp.whi < sp.wlo) sp.whi = sp.wlo;
-        sp.span_chunks = geo.span_chunks;
-        sp.hits = s->hits.as<uint64_t>();
-        sp.region_cap = static_cast<uint32_t>(caps[static_cast<size_t>(p)]);
-        sp.hit_counts = s->hit_counts.as<uint32_t>();
-        sp.zero_counters = s->counters.as<unsigned long long>();
-        // one pair of timestamps around the whole train of scan kernels (first kernel's start, last
-        // kernel's end): a pair per kernel puts a completion signal between consecutive kernels
-        hipStream_t sp_stream = (two_streams && (p & 1)) ? m->second : st;
-        launch_scan_windows(sp, make_window_set(s->prog), D.n_windows, geo.grid, p == 0 ? s0->ev[1] : nullptr,
-                            (!two_streams && p == P - 1) ? s0->ev[2] : nullptr, sp_stream);
-      }
-      if (two_streams) {
-        RJ_HIP(hipEventRecord(m->join, m->second));
-        RJ_HIP(hipStreamWaitEvent(st, m->join, 0));
-        RJ_HIP(hipEventRecord(s0->ev[2], st));  // end of the train: both streams have drained
-      }
-    }
-    // the single-pattern tails (verify inside the regions, offsets + gather + check) of all patterns
-    // in two launches; their parameters travel as one small array
-    for (int p = 0; p < P; p++) {
-      rj_scan* s = m->scans[static_cast<size_t>(p)];
-      MultiTail& t = m->host_tails[p];
-      t = MultiTail{};
-      t.verify.text = d_text;
-      t.verify.n = n;
-      t.verify.hits = s->hits.as<uint64_t>();
-      t.verify.n_regions = geo.n_regions;
-      t.verify.region_cap = static_cast<uint32_t>(caps[static_cast<size_t>(p)]);
-      t.verify.counters = s->counters.as<unsigned long long>();
-      t.verify.sb = sb;
-      t.verify.se = se;
-      t.verify.expand = 1;
-      t.verify.float_max = s->prog->dev.float_max;
-      t.program = s->prog->dev;
-      t.hit_counts = s->hit_counts.as<uint32_t>();
-      t.valid_counts = s->valid_counts.as<uint32_t>();
-      t.region_ends = s->cand_end.as<uint64_t>();
-      t.out = s->out.as<uint64_t>();
-      t.out_cap = s->out_cap;
-      t.host_counters = s->host_counters;
-      s->host_counters[kCntUnordered] = 0;
-      s->host_counters[kCntAdjacent] = 0;
-    }
-    if (m->uploaded.size() != static_cast<size_t>(P) ||
-        memcmp(m->uploaded.data(), m->host_tails, sizeof(MultiTail) * static_cast<size_t>(P)) != 0) {
-      RJ_HIP(hipMemcpyAsync(m->tails.p, m->host_tails, sizeof(MultiTail) * P, hipMemcpyHostToDevice, st));
-      m->uploaded.assign(m->host_tails, m->host_tails + P);
-    }
-    launch_tails_multi(m->tails.as<MultiTail>(), P, geo.n_regions, st);
-    RJ_HIP(hipStreamSynchronize(st));
-    RJ_HIP(hipGetLastError());
-    bool again = false;
-    for (int p = 0; p < P; p++) {
-      rj_scan* s = m->scans[static_cast<size_t>(p)];
-      if (s->host_counters[kCntOverflow] != 0) {
-        const uint64_t cap = caps[static_cast<size_t>(p)];
-        const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(s->host_counters[kCntMaxRegion] * 2, cap * 4), geo.span_chunks * 1024);
-        if (want <= cap) return fail(RJ_DEVICE_ERROR, "hit regions cannot grow further");
-        s->region_cap_hint = static_cast<uint32_t>(std::min<uint64_t>(want, 1u << 20));
-        again = true;
-      }
-    }
-    if (fuse) {
-      (void)hipEventElapsedTime(&m->scan_ms, s0->ev[1], s0->ev[2]);
-    } else {
-      (void)hipEventElapsedTime(&m->scan_ms, s0->ev[1], s0->ev[2]);  // first start to last end, gaps included
-    }
-    if (again) continue;
-    for (int p = 0; p < P; p++) {
-      rj_scan* s = m->scans[static_cast<size_t>(p)];
-      hipStream_t sp = st;  // (rare) selection kernels of one pattern after the other
-      if (s->host_counters[kCntOverrun] != 0) {
-        // a long-lived candidate: this pattern's run is void; its own pipeline takes the carry scan
-        s->linear_hint = true;
-        int rc = run_pipeline(s, d_text, n, sb, se, 0, 0, 0, st);
-        if (rc != RJ_OK) return rc;
-        continue;
-      }
-      s->hits_hint = s->host_counters[kCntHits];
-      s->stats.n_hits = s->host_counters[kCntHits];
-      FinalizeParams sel{};
-      sel.carry_cur = 0;
-      sel.carry_prev_end = 0;
-      sel.have_prev = 0;
-      if (s->host_counters[kCntUnordered] != 0) {
-        const uint64_t nc = s->host_counters[kCntCands];
-        RJ_HIP(s->keys_out.reserve(nc * sizeof(uint64_t)));
-        RJ_HIP(s->vals_out.reserve(nc * sizeof(uint64_t)));
-        launch_split_pairs(s->out.as<uint64_t>(), s->counters.as<unsigned long long>() + kCntCands, nc,
-                           s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), sp);
-      }
-      int rc = resolve_selection(s, sel, sp);
-      if (rc != RJ_OK) return rc;
-      s->result = s->out.as<uint64_t>();
-      s->stats.n_matches = s->result_count;
-      s->stats.scan_ms = fuse ? m->scan_ms : m->scan_ms / static_cast<float>(P);
-    }
-    return RJ_OK;
-  }
-  return fail(RJ_DEVICE_ERROR, "hit regions kept overflowing");
-}
-
-}  // namespace
+}  // namespace rejit_amd
 
 extern "C" {
 
@@ -1206,16 +844,7 @@ int rj_compile(const char* regexp, rj_program** out) {
 void rj_program_free(rj_program* prog) {
   ErrnoGuard errno_guard;
   if (!prog) return;
-  // drop cached host scans of this thread that refer to the program
-  auto& v = g_host_scans.v;
-  for (size_t i = 0; i < v.size();) {
-    if (v[i].first == prog->id) {
-      rj_scan_destroy(v[i].second);
-      v.erase(v.begin() + static_cast<long>(i));
-    } else {
-      i++;
-    }
-  }
+  forget_host_scans(prog->id);  // (host_api.hip: this thread's cached scans of the program)
   for (rj_program* r : prog->replicas)
     if (r != nullptr) rj_program_free(r);
   delete prog;
@@ -1438,156 +1067,6 @@ int64_t rj_scan_replace(rj_scan* s, const void* d_text, uint64_t n, const char* 
   return static_cast<int64_t>(new_len);
 }
 
-int64_t rj_replace_all(const rj_program* prog, const char* text, size_t n, const char* with, size_t with_len, char** out,
-                       size_t* out_len) {
-  ErrnoGuard errno_guard;
-  if (!prog || (!text && n) || !out || !out_len) return fail(RJ_BAD_ARGUMENT, "null argument");
-  *out = nullptr;
-  *out_len = 0;
-  rj_scan* s = nullptr;
-  int rc = host_scan_for(prog, &s);
-  if (rc != RJ_OK) return rc;
-  const uint8_t* d_text = nullptr;
-  rc = stage_text(s, text, n, &d_text);
-  if (rc != RJ_OK) return rc;
-  rc = run_pipeline(s, d_text, n, 0, n + 1, 0, 0, 0, s->own_stream);
-  if (rc != RJ_OK) return rc;
-  const uint64_t m = s->result_count;
-  // worst case: every match is empty and nothing is removed
-  uint64_t cap = n + m * with_len + 64;
-  RJ_HIP(s->repl_out.reserve(cap));
-  int64_t new_len = rj_scan_replace(s, d_text, n, with, with_len, s->repl_out.p, cap, s->own_stream);
-  if (new_len < 0) return new_len;
-  char* h = static_cast<char*>(malloc(static_cast<size_t>(new_len) + 1));
-  if (!h) return fail(RJ_DEVICE_ERROR, "out of host memory");
-  if (new_len) {
-    hipError_t e = hipMemcpyAsync(h, s->repl_out.p, static_cast<size_t>(new_len), hipMemcpyDeviceToHost, s->own_stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(s->own_stream);
-    if (e != hipSuccess) {
-      free(h);
-      return fail(RJ_DEVICE_ERROR, "hipMemcpy failed: %s", hipGetErrorString(e));
-    }
-  }
-  h[new_len] = 0;
-  *out = h;
-  *out_len = static_cast<size_t>(new_len);
-  return static_cast<int64_t>(m);
-}
-
-int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out) {
-  ErrnoGuard errno_guard;
-  if (!progs || !out || n_progs < 1) return fail(RJ_BAD_ARGUMENT, "null argument");
-  if (n_progs > kMaxFused - kFuseGroup + 1) return fail(RJ_BAD_ARGUMENT, "at most %d patterns per rj_multi", kMaxFused - kFuseGroup + 1);
-  auto m = std::make_unique<rj_multi>();
-  bool all = true, all_batchable = true;
-  for (int i = 0; i < n_progs; i++) {
-    if (!progs[i]) return fail(RJ_BAD_ARGUMENT, "null program");
-    rj_scan* s = nullptr;
-    int rc = rj_scan_create(progs[i], &s);
-    if (rc != RJ_OK) {
-      rj_multi_destroy(m.release());
-      return rc;
-    }
-    m->scans.push_back(s);
-    all = all && fusable(progs[i]);
-    all_batchable = all_batchable && batchable(progs[i]);
-  }
-  if (m->tails.reserve(sizeof(MultiTail) * static_cast<size_t>(n_progs)) != hipSuccess ||
-      hipHostMalloc(reinterpret_cast<void**>(&m->host_tails), sizeof(MultiTail) * static_cast<size_t>(n_progs)) != hipSuccess) {
-    rj_multi_destroy(m.release());
-    return fail(RJ_DEVICE_ERROR, "out of memory");
-  }
-  if (hipStreamCreateWithFlags(&m->second, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&m->fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&m->join, hipEventDisableTiming) != hipSuccess) {
-    rj_multi_destroy(m.release());
-    return fail(RJ_DEVICE_ERROR, "hipStreamCreate / hipEventCreate failed");
-  }
-  m->fused = all && n_progs > 1 && getenv("RJ_NO_FUSION") == nullptr;
-  m->batchable = all_batchable && n_progs > 1;
-  *out = m.release();
-  return RJ_OK;
-}
-
-void rj_multi_destroy(rj_multi* m) {
-  ErrnoGuard errno_guard;
-  if (!m) return;
-  for (rj_scan* s : m->scans) rj_scan_destroy(s);
-  if (m->host_tails) (void)hipHostFree(m->host_tails);
-  if (m->host_bounds) (void)hipHostFree(m->host_bounds);
-  if (m->second) (void)hipStreamDestroy(m->second);
-  if (m->fork) (void)hipEventDestroy(m->fork);
-  if (m->join) (void)hipEventDestroy(m->join);
-  delete m;
-}
-
-int rj_multi_run(rj_multi* m, const void* d_text, uint64_t n, uint64_t* counts, void* hip_stream) {
-  return rj_multi_run_range(m, d_text, n, 0, n + 1, counts, hip_stream);
-}
-
-int rj_multi_run_range(rj_multi* m, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end, uint64_t* counts,
-                       void* hip_stream) {
-  ErrnoGuard errno_guard;
-  if (!m || (!d_text && n) || !counts) return fail(RJ_BAD_ARGUMENT, "null argument");
-  if (own_end > n + 1) own_end = n + 1;
-  if (own_begin >= own_end) {
-    for (size_t i = 0; i < m->scans.size(); i++) counts[i] = 0;
-    return 0;
-  }
-  if ((reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) return fail(RJ_BAD_ARGUMENT, "device text must be 16-byte aligned");
-  hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  m->scan_ms = 0.f;
-  int fused = 0;
-  if (m->fused && m->mode == 0 && n >= 16) {
-    int rc = run_batched(m, static_cast<const uint8_t*>(d_text), n, own_begin, own_end, st, true);
-    if (rc != RJ_OK) return rc;
-    fused = 1;
-  } else if (m->batchable && n >= 16) {
-    int rc = run_batched(m, static_cast<const uint8_t*>(d_text), n, own_begin, own_end, st, false);
-    if (rc != RJ_OK) return rc;
-    fused = 2;
-  } else {
-    for (rj_scan* s : m->scans) {
-      int rc = run_pipeline(s, static_cast<const uint8_t*>(d_text), n, own_begin, own_end, 0, 0, 0, st);
-      if (rc != RJ_OK) return rc;
-    }
-  }
-  for (size_t i = 0; i < m->scans.size(); i++) counts[i] = m->scans[i]->result_count;
-  return fused;
-}
-
-rj_scan* rj_multi_scan(rj_multi* m, int i) {
-  if (!m || i < 0 || static_cast<size_t>(i) >= m->scans.size()) return nullptr;
-  return m->scans[static_cast<size_t>(i)];
-}
-
-float rj_multi_scan_ms(const rj_multi* m) { return m ? m->scan_ms : 0.f; }
-
-int rj_multi_bounds(rj_multi* m, uint64_t* bounds, void* hip_stream) {
-  ErrnoGuard errno_guard;
-  if (!m || !bounds) return fail(RJ_BAD_ARGUMENT, "null argument");
-  hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  const int P = static_cast<int>(m->scans.size());
-  if (!m->host_bounds) RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&m->host_bounds), sizeof(uint64_t) * 4 * kMaxFused));
-  BoundsParams bp{};
-  bp.n_lists = P;
-  for (int p = 0; p < P; p++) {
-    bp.spans[p] = m->scans[static_cast<size_t>(p)]->result;
-    bp.count[p] = bp.spans[p] ? m->scans[static_cast<size_t>(p)]->result_count : 0;
-  }
-  launch_first_last(bp, m->host_bounds, st);
-  RJ_HIP(hipStreamSynchronize(st));
-  RJ_HIP(hipGetLastError());
-  memcpy(bounds, m->host_bounds, sizeof(uint64_t) * 4 * static_cast<size_t>(P));
-  return RJ_OK;
-}
-
-int rj_multi_set_mode(rj_multi* m, int mode) {
-  if (!m || mode < 0 || mode > 3) return fail(RJ_BAD_ARGUMENT, "bad argument");
-  m->mode = mode;
-  return RJ_OK;
-}
-
 void rj_free_text(char* text) { free(text); }
 
 int rj_scan_stats(const rj_scan* s, rj_stats* stats) {
@@ -1609,253 +1088,3 @@ int rj_scan_match_full(rj_scan* s, const void* d_text, uint64_t n, void* hip_str
 
 }  // extern "C"
 
-// MatchAll of the starts [own_begin, own_end) of a host text, on the program's device: H2D copy, device
-// pipeline, D2H of the spans (relative to `text`).  rj_match_all is the whole-text case; multi_device.hip
-// runs one of these per device.
-int64_t rejit_amd::rj_match_range_host(const rj_program* prog, const char* text, size_t n, uint64_t own_begin, uint64_t own_end,
-                                       uint64_t carry_cur, uint64_t carry_prev_end, int have_prev, uint64_t** spans) {
-  if (spans) *spans = nullptr;
-  DeviceGuard on_device(prog->device);
-  rj_scan* s = nullptr;
-  int rc = host_scan_for(prog, &s);
-  if (rc != RJ_OK) return rc;
-  const uint8_t* d_text = nullptr;
-  rc = stage_text(s, text, n, &d_text);
-  if (rc != RJ_OK) return rc;
-  rc = run_pipeline(s, d_text, n, own_begin, own_end, carry_cur, carry_prev_end, have_prev, s->own_stream);
-  if (rc != RJ_OK) return rc;
-  if (spans && s->result_count) {
-    uint64_t* h = static_cast<uint64_t*>(malloc(s->result_count * 2 * sizeof(uint64_t)));
-    if (!h) return fail(RJ_DEVICE_ERROR, "out of host memory");
-    // (on the scan's own stream: a blocking hipMemcpy goes through the NULL stream, which serialises
-    // the streams of all the other threads that share the pattern)
-    hipError_t e = copy_result_pairs(s, h, 0, s->result_count, s->own_stream);
-    if (e != hipSuccess) {
-      free(h);
-      return fail(RJ_DEVICE_ERROR, "hipMemcpy failed: %s", hipGetErrorString(e));
-    }
-    *spans = h;
-  }
-  return static_cast<int64_t>(s->result_count);
-}
-
-extern "C" {
-
-int64_t rj_match_all(const rj_program* prog, const char* text, size_t n, uint64_t** spans) {
-  ErrnoGuard errno_guard;
-  if (spans) *spans = nullptr;
-  if (!prog || (!text && n)) return fail(RJ_BAD_ARGUMENT, "null argument");
-  int64_t result = 0;
-  if (multi_device_match_all(prog, text, n, spans, &result)) return result;  // large text, several GPUs: one range per device
-  return rj_match_range_host(prog, text, n, 0, n + 1, 0, 0, 0, spans);
-}
-
-int64_t rj_match_all_batch(const rj_program* prog, const char* const* texts, const size_t* sizes, size_t n_texts,
-                           uint64_t* counts, uint64_t** spans) {
-  ErrnoGuard errno_guard;
-  if (spans) *spans = nullptr;
-  if (!prog || (n_texts && (!texts || !sizes || !counts))) return fail(RJ_BAD_ARGUMENT, "null argument");
-  for (size_t i = 0; i < n_texts; i++)
-    if (!texts[i] && sizes[i]) return fail(RJ_BAD_ARGUMENT, "null text in batch");
-  if (n_texts == 0) return 0;
-  int64_t result = 0;
-  if (multi_device_match_all_batch(prog, texts, sizes, n_texts, counts, spans, &result)) return result;  // files spread over the GPUs
-  return rj_match_all_batch_one_device(prog, texts, sizes, n_texts, counts, spans);
-}
-
-}  // extern "C"
-
-int64_t rejit_amd::rj_match_all_batch_one_device(const rj_program* prog, const char* const* texts, const size_t* sizes, size_t n_texts,
-                                                 uint64_t* counts, uint64_t** spans) {
-  if (spans) *spans = nullptr;
-  DeviceGuard on_device(prog->device);
-  if (prog->batch_separator < 0 || n_texts == 1) {
-    // no byte can safely end a text inside a concatenation (or nothing to batch): text by text
-    std::vector<uint64_t> all;
-    uint64_t total = 0;
-    for (size_t i = 0; i < n_texts; i++) {
-      uint64_t* one = nullptr;
-      int64_t c = rj_match_all(prog, texts[i], sizes[i], spans ? &one : nullptr);
-      if (c < 0) return c;
-      counts[i] = static_cast<uint64_t>(c);
-      if (spans && c) all.insert(all.end(), one, one + 2 * c);
-      rj_free_spans(one);
-      total += static_cast<uint64_t>(c);
-    }
-    if (spans && total) {
-      uint64_t* h = static_cast<uint64_t*>(malloc(all.size() * sizeof(uint64_t)));
-      if (!h) return fail(RJ_DEVICE_ERROR, "out of host memory");
-      memcpy(h, all.data(), all.size() * sizeof(uint64_t));
-      *spans = h;
-    }
-    return static_cast<int64_t>(total);
-  }
-  rj_scan* s = nullptr;
-  int rc = host_scan_for(prog, &s);
-  if (rc != RJ_OK) return rc;
-  // text i occupies [off[i], off[i] + sizes[i]); position off[i] + sizes[i] holds the separator and
-  // is text i's end position (an empty match there belongs to text i)
-  std::vector<uint64_t> off(n_texts + 1);
-  uint64_t total_bytes = 0;
-  for (size_t i = 0; i < n_texts; i++) {
-    off[i] = total_bytes;
-    if (sizes[i] >= (1ull << 62) || total_bytes + sizes[i] + 1 < total_bytes) return fail(RJ_BAD_ARGUMENT, "batch: sizes overflow");
-    total_bytes += sizes[i] + 1;
-  }
-  off[n_texts] = total_bytes;
-  // uploads are queued slice by slice from s->pinned: whatever way this function is left, no copy may still
-  // be in flight (the next call may free or refill the staging buffer)
-  struct DrainStream {
-    hipStream_t st;
-    ~DrainStream() { (void)hipStreamSynchronize(st); }
-  } drain{s->own_stream};
-  const uint64_t n = total_bytes - 1;  // the last separator is the end of the buffer
-  if (total_bytes > s->pinned_cap) {
-    if (s->pinned) (void)hipHostFree(s->pinned);
-    s->pinned = nullptr;
-    s->pinned_cap = 0;
-    const size_t want = ((total_bytes + (1u << 20)) / 4096 + 1) * 4096;
-    RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->pinned), want));
-    s->pinned_cap = want;
-  }
-  const char sep = static_cast<char>(prog->batch_separator);
-  RJ_HIP(s->text.reserve(((total_bytes + 64 + 4095) / 4096) * 4096));
-  {
-    // Packing is a host memcpy of the whole batch (one core moves ~10 GB/s, PCIe takes 50+): it is
-    // spread over a few threads and done slice by slice, each slice's DMA starting as soon as it is
-    // packed, so packing slice k+1 overlaps the upload of slice k.
-    const unsigned n_thr = total_bytes > (8u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-    auto pack = [&](size_t first, size_t last) {
-      for (size_t i = first; i < last; i++) {
-        if (sizes[i]) memcpy(s->pinned + off[i], texts[i], sizes[i]);
-        s->pinned[off[i] + sizes[i]] = sep;
-      }
-    };
-    constexpr uint64_t kSlice = 64ull << 20;
-    size_t first = 0;
-    while (first < n_texts) {
-      // texts [first, last) make up about one slice
-      size_t last = first;
-      while (last < n_texts && off[last] - off[first] < kSlice) last++;
-      const uint64_t lo = off[first], hi = off[last];
-      if (n_thr == 1 || hi - lo < (8u << 20)) {
-        pack(first, last);
-      } else {
-        std::vector<std::thread> pool;
-        size_t f = first;
-        for (unsigned t = 0; t < n_thr; t++) {
-          const uint64_t upto = lo + (hi - lo) * (t + 1) / n_thr;
-          size_t l = f;
-          while (l < last && off[l] < upto) l++;
-          if (t + 1 == n_thr) l = last;
-          pool.emplace_back(pack, f, l);
-          f = l;
-        }
-        for (auto& th : pool) th.join();
-      }
-      RJ_HIP(hipMemcpyAsync(static_cast<char*>(s->text.p) + lo, s->pinned + lo, hi - lo, hipMemcpyHostToDevice, s->own_stream));
-      first = last;
-    }
-  }
-  rc = run_pipeline(s, s->text.as<uint8_t>(), n, 0, n + 1, 0, 0, 0, s->own_stream);
-  if (rc != RJ_OK) return rc;
-  const uint64_t m = s->result_count;
-  std::vector<uint64_t> pairs(2 * m);
-  if (m) RJ_HIP(copy_result_pairs(s, pairs.data(), 0, m, s->own_stream));
-  // the matches are ordered by begin: one merge pass assigns them to their texts
-  for (size_t i = 0; i < n_texts; i++) counts[i] = 0;
-  size_t t = 0;
-  for (uint64_t k = 0; k < m; k++) {
-    const uint64_t b = pairs[2 * k], e = pairs[2 * k + 1];
-    while (b > off[t] + sizes[t]) t++;
-    if (e > off[t] + sizes[t]) return fail(RJ_DEVICE_ERROR, "internal: a match crosses a text boundary in a batch");
-    counts[t]++;
-    pairs[2 * k] = b - off[t];
-    pairs[2 * k + 1] = e - off[t];
-  }
-  if (spans && m) {
-    uint64_t* h = static_cast<uint64_t*>(malloc(pairs.size() * sizeof(uint64_t)));
-    if (!h) return fail(RJ_DEVICE_ERROR, "out of host memory");
-    memcpy(h, pairs.data(), pairs.size() * sizeof(uint64_t));
-    *spans = h;
-  }
-  return static_cast<int64_t>(m);
-}
-
-extern "C" {
-
-void rj_free_spans(uint64_t* spans) { free(spans); }
-
-// kMatchFirst / kMatchAnywhere with early exit (the reference's generated code returns at the
-// first match, codegen-x64.cc:401-446).  kMatchFirst is the first element of kMatchAll (left-most
-// longest; reference behaviour Q6), and the greedy selection takes the left-most candidate whatever
-// follows it, so it is enough to look at growing prefixes of the START positions: [0, 256 KiB),
-// then 8x more each time.  When the longest match is bounded only the bytes a block's candidates
-// can reach are uploaded first (a walk from s < hi ends before hi + max_len), so a hit near the
-// start of a large host buffer costs microseconds instead of the whole PCIe copy.
-static int first_match(const rj_program* prog, const char* text, size_t n, uint64_t* begin, uint64_t* end) {
-  if (!prog || (!text && n)) return fail(RJ_BAD_ARGUMENT, "null argument");
-  rj_scan* s = nullptr;
-  int rc = host_scan_for(prog, &s);
-  if (rc != RJ_OK) return rc;
-  RJ_HIP(s->text.reserve(((n + 64 + 4095) / 4096) * 4096));
-  const uint8_t* d_text = s->text.as<uint8_t>();
-  const uint64_t max_len = prog->host->max_len;
-  const bool bounded = max_len < (1ull << 20);
-  uint64_t uploaded = 0;
-  auto upload_to = [&](uint64_t upto) -> hipError_t {
-    if (upto > n) upto = n;
-    if (upto <= uploaded) return hipSuccess;
-    hipError_t e = hipMemcpyAsync(static_cast<char*>(s->text.p) + uploaded, text + uploaded, upto - uploaded,
-                                  hipMemcpyHostToDevice, s->own_stream);
-    uploaded = upto;
-    return e;
-  };
-  uint64_t lo = 0, block = 256u << 10;
-  for (;;) {
-    uint64_t hi = lo + block;
-    const bool last = hi >= n;
-    if (last) hi = n;
-    // text the automaton may see in this round: everything for the last block or an unbounded
-    // pattern, else up to the furthest byte a candidate of the block can reach (+1 for the
-    // end-of-line context)
-    const uint64_t visible = (last || !bounded) ? n : std::min<uint64_t>(n, hi + max_len + 1);
-    RJ_HIP(upload_to(visible));
-    rc = run_pipeline(s, d_text, visible, lo, (last && visible == n) ? n + 1 : hi, 0, 0, 0, s->own_stream);
-    if (rc != RJ_OK) return rc;
-    if (s->result_count > 0) {
-      uint64_t pair[2];
-      RJ_HIP(copy_result_pairs(s, pair, 0, 1, s->own_stream));
-      if (begin) *begin = pair[0];
-      if (end) *end = pair[1];
-      return 1;
-    }
-    if (last) return 0;
-    lo = hi;
-    block *= 8;
-  }
-}
-
-int rj_match_first(const rj_program* prog, const char* text, size_t n, uint64_t* begin, uint64_t* end) {
-  ErrnoGuard errno_guard;
-  return first_match(prog, text, n, begin, end);
-}
-
-int rj_match_anywhere(const rj_program* prog, const char* text, size_t n) {
-  ErrnoGuard errno_guard;
-  return first_match(prog, text, n, nullptr, nullptr);
-}
-
-int rj_match_full(const rj_program* prog, const char* text, size_t n) {
-  ErrnoGuard errno_guard;
-  if (!prog || (!text && n)) return fail(RJ_BAD_ARGUMENT, "null argument");
-  rj_scan* s = nullptr;
-  int rc = host_scan_for(prog, &s);
-  if (rc != RJ_OK) return rc;
-  const uint8_t* d_text = nullptr;
-  rc = stage_text(s, text, n, &d_text);
-  if (rc != RJ_OK) return rc;
-  return rj_scan_match_full(s, d_text, n, s->own_stream);
-}
-
-}  // extern "C"

@@ -1,7 +1,9 @@
 // rejit_amd/csrc/engine_internal.h -- what the host-side translation units of the engine share:
 // error plumbing, grow-only device buffers, and the objects behind the opaque C-ABI handles
-// (include/rejit_hip.h).  engine.hip holds the common pipeline and the C ABI, linear.hip the
-// linear-time carry scan, multi_device.hip the split of one call over all visible GPUs.
+// (include/rejit_hip.h).  engine.hip holds the device pipeline and the device-text C ABI (rj_compile,
+// rj_scan_*), multi_pattern.hip rj_multi_*, host_api.hip the host-text entry points, linear.hip the linear-time
+// carry scan, exact_replay.hip the reference-exact replay, multi_device.hip the split of one call over all
+// visible GPUs.
 #ifndef REJIT_AMD_ENGINE_INTERNAL_H_
 #define REJIT_AMD_ENGINE_INTERNAL_H_
 
@@ -134,9 +136,15 @@ struct rj_scan {
 
 namespace rejit_amd {
 
-// engine.hip
+// engine.hip: the device pipeline.  run_pipeline = MatchAll of the starts [sb, se) of a device-resident text
+// (every path: small texts, windows / dense, carry scan, exact replay); results in s->result, s->result_count.
 int ensure_lists(rj_scan* s, uint32_t n_regions, uint32_t region_cap, uint64_t cands_cap);
 int resolve_selection(rj_scan* s, const FinalizeParams& fp, hipStream_t st);
+WindowSet make_window_set(const rj_program* rp);
+int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, uint64_t carry_cur, uint64_t carry_prev_end,
+                 int have_prev, hipStream_t st);
+// host_api.hip
+void forget_host_scans(uint64_t program_id);
 // linear.hip: MatchAll of the starts [sb, se) in time linear in the text (carry_scan.h); results as
 // after run_range (s->out, s->result_count).  RJ_TOO_LARGE when the automaton is wider than the
 // carry kernels take.

@@ -1,0 +1,395 @@
+// rejit_amd/csrc/host_api.hip -- the entry points that take HOST text, i.e. what a rejit.h caller reaches
+// (rejit_api.cc): rj_match_all / rj_match_all_batch / rj_match_first / rj_match_anywhere / rj_match_full /
+// rj_replace_all.  They replace the four JIT function pointers of the reference (src/regexp.h:533-536) called
+// from src/rejit.cc:150-227.  A scratch rj_scan per (thread, program), a non-blocking stream of its own, small
+// texts read in place from pinned memory, large ones copied; then run_pipeline (engine.hip).
+
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "engine_internal.h"
+
+using namespace rejit_amd;
+
+#define fail ::rejit_amd::rj_fail
+
+namespace {
+
+// one scratch per (thread, program) for the host-text entry points
+struct HostScans {
+  std::vector<std::pair<uint64_t, rj_scan*>> v;  // keyed by rj_program::id, not by address
+  ~HostScans() {
+    for (auto& p : v) rj_scan_destroy(p.second);
+  }
+};
+thread_local HostScans g_host_scans;
+
+int host_scan_for(const rj_program* prog, rj_scan** out) {
+  for (auto& p : g_host_scans.v)
+    if (p.first == prog->id) {
+      *out = p.second;
+      return RJ_OK;
+    }
+  rj_scan* s = nullptr;
+  int rc = rj_scan_create(prog, &s);
+  if (rc != RJ_OK) return rc;
+  if (hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    rj_scan_destroy(s);
+    return fail(RJ_DEVICE_ERROR, "hipStreamCreate failed");
+  }
+  if (g_host_scans.v.size() >= 16) {  // bound the cache
+    rj_scan_destroy(g_host_scans.v.front().second);
+    g_host_scans.v.erase(g_host_scans.v.begin());
+  }
+  g_host_scans.v.emplace_back(prog->id, s);
+  *out = s;
+  return RJ_OK;
+}
+
+// the first `pairs` result pairs of the last run into host memory (the results of the small-text kernel
+// already ARE in host memory)
+hipError_t copy_result_pairs(rj_scan* s, uint64_t* dst, uint64_t first, uint64_t pairs, hipStream_t st) {
+  if (pairs == 0) return hipSuccess;
+  if (s->result == s->small_out && s->small_out != nullptr) {
+    memcpy(dst, s->small_out + 2 * first, pairs * 2 * sizeof(uint64_t));
+    return hipSuccess;
+  }
+  hipError_t e = hipMemcpyAsync(dst, s->result + 2 * first, pairs * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  return e;
+}
+
+int stage_text(rj_scan* s, const char* text, size_t n, const uint8_t** d_text) {
+  static const bool no_small = getenv("RJ_NO_SMALL") != nullptr;
+  const DevProgram& D = s->prog->dev;
+  if (n <= kSmallMaxText && D.n_words <= 4 && D.table_words <= kSmallMaxTableWords && !no_small &&
+      small_lds_bytes(D, static_cast<uint32_t>(n)) <= small_lds_limit()) {
+    // a small text stays in (pinned) host memory: match_small reads it over PCIe in one round trip, which
+    // beats a copy command plus its completion wait; should the general pipeline have to take the run
+    // after all, its kernels read the same memory (slower, rare)
+    if (s->small_text == nullptr) RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->small_text), kSmallMaxText + 64));
+    if (n) memcpy(s->small_text, text, n);
+    *d_text = reinterpret_cast<const uint8_t*>(s->small_text);
+    return RJ_OK;
+  }
+  RJ_HIP(s->text.reserve(((n + 64 + 4095) / 4096) * 4096));
+  if (n) RJ_HIP(hipMemcpyAsync(s->text.p, text, n, hipMemcpyHostToDevice, s->own_stream));
+  *d_text = s->text.as<uint8_t>();
+  return RJ_OK;
+}
+
+}  // namespace
+
+// rj_program_free (engine.hip): the calling thread's cached scans of a program go with it
+void rejit_amd::forget_host_scans(uint64_t program_id) {
+  auto& v = g_host_scans.v;
+  for (size_t i = 0; i < v.size();) {
+    if (v[i].first == program_id) {
+      rj_scan_destroy(v[i].second);
+      v.erase(v.begin() + static_cast<long>(i));
+    } else {
+      i++;
+    }
+  }
+}
+
+extern "C" {
+
+int64_t rj_replace_all(const rj_program* prog, const char* text, size_t n, const char* with, size_t with_len, char** out,
+                       size_t* out_len) {
+  ErrnoGuard errno_guard;
+  if (!prog || (!text && n) || !out || !out_len) return fail(RJ_BAD_ARGUMENT, "null argument");
+  *out = nullptr;
+  *out_len = 0;
+  rj_scan* s = nullptr;
+  int rc = host_scan_for(prog, &s);
+  if (rc != RJ_OK) return rc;
+  const uint8_t* d_text = nullptr;
+  rc = stage_text(s, text, n, &d_text);
+  if (rc != RJ_OK) return rc;
+  rc = run_pipeline(s, d_text, n, 0, n + 1, 0, 0, 0, s->own_stream);
+  if (rc != RJ_OK) return rc;
+  const uint64_t m = s->result_count;
+  // worst case: every match is empty and nothing is removed
+  uint64_t cap = n + m * with_len + 64;
+  RJ_HIP(s->repl_out.reserve(cap));
+  int64_t new_len = rj_scan_replace(s, d_text, n, with, with_len, s->repl_out.p, cap, s->own_stream);
+  if (new_len < 0) return new_len;
+  char* h = static_cast<char*>(malloc(static_cast<size_t>(new_len) + 1));
+  if (!h) return fail(RJ_DEVICE_ERROR, "out of host memory");
+  if (new_len) {
+    hipError_t e = hipMemcpyAsync(h, s->repl_out.p, static_cast<size_t>(new_len), hipMemcpyDeviceToHost, s->own_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->own_stream);
+    if (e != hipSuccess) {
+      free(h);
+      return fail(RJ_DEVICE_ERROR, "hipMemcpy failed: %s", hipGetErrorString(e));
+    }
+  }
+  h[new_len] = 0;
+  *out = h;
+  *out_len = static_cast<size_t>(new_len);
+  return static_cast<int64_t>(m);
+}
+
+}  // extern "C"
+
+// MatchAll of the starts [own_begin, own_end) of a host text, on the program's device: H2D copy, device
+// pipeline, D2H of the spans (relative to `text`).  rj_match_all is the whole-text case; multi_device.hip
+// runs one of these per device.
+int64_t rejit_amd::rj_match_range_host(const rj_program* prog, const char* text, size_t n, uint64_t own_begin, uint64_t own_end,
+                                       uint64_t carry_cur, uint64_t carry_prev_end, int have_prev, uint64_t** spans) {
+  if (spans) *spans = nullptr;
+  DeviceGuard on_device(prog->device);
+  rj_scan* s = nullptr;
+  int rc = host_scan_for(prog, &s);
+  if (rc != RJ_OK) return rc;
+  const uint8_t* d_text = nullptr;
+  rc = stage_text(s, text, n, &d_text);
+  if (rc != RJ_OK) return rc;
+  rc = run_pipeline(s, d_text, n, own_begin, own_end, carry_cur, carry_prev_end, have_prev, s->own_stream);
+  if (rc != RJ_OK) return rc;
+  if (spans && s->result_count) {
+    uint64_t* h = static_cast<uint64_t*>(malloc(s->result_count * 2 * sizeof(uint64_t)));
+    if (!h) return fail(RJ_DEVICE_ERROR, "out of host memory");
+    // (on the scan's own stream: a blocking hipMemcpy goes through the NULL stream, which serialises
+    // the streams of all the other threads that share the pattern)
+    hipError_t e = copy_result_pairs(s, h, 0, s->result_count, s->own_stream);
+    if (e != hipSuccess) {
+      free(h);
+      return fail(RJ_DEVICE_ERROR, "hipMemcpy failed: %s", hipGetErrorString(e));
+    }
+    *spans = h;
+  }
+  return static_cast<int64_t>(s->result_count);
+}
+
+extern "C" {
+
+int64_t rj_match_all(const rj_program* prog, const char* text, size_t n, uint64_t** spans) {
+  ErrnoGuard errno_guard;
+  if (spans) *spans = nullptr;
+  if (!prog || (!text && n)) return fail(RJ_BAD_ARGUMENT, "null argument");
+  int64_t result = 0;
+  if (multi_device_match_all(prog, text, n, spans, &result)) return result;  // large text, several GPUs: one range per device
+  return rj_match_range_host(prog, text, n, 0, n + 1, 0, 0, 0, spans);
+}
+
+int64_t rj_match_all_batch(const rj_program* prog, const char* const* texts, const size_t* sizes, size_t n_texts,
+                           uint64_t* counts, uint64_t** spans) {
+  ErrnoGuard errno_guard;
+  if (spans) *spans = nullptr;
+  if (!prog || (n_texts && (!texts || !sizes || !counts))) return fail(RJ_BAD_ARGUMENT, "null argument");
+  for (size_t i = 0; i < n_texts; i++)
+    if (!texts[i] && sizes[i]) return fail(RJ_BAD_ARGUMENT, "null text in batch");
+  if (n_texts == 0) return 0;
+  int64_t result = 0;
+  if (multi_device_match_all_batch(prog, texts, sizes, n_texts, counts, spans, &result)) return result;  // files spread over the GPUs
+  return rj_match_all_batch_one_device(prog, texts, sizes, n_texts, counts, spans);
+}
+
+}  // extern "C"
+
+int64_t rejit_amd::rj_match_all_batch_one_device(const rj_program* prog, const char* const* texts, const size_t* sizes, size_t n_texts,
+                                                 uint64_t* counts, uint64_t** spans) {
+  if (spans) *spans = nullptr;
+  DeviceGuard on_device(prog->device);
+  if (prog->batch_separator < 0 || n_texts == 1) {
+    // no byte can safely end a text inside a concatenation (or nothing to batch): text by text
+    std::vector<uint64_t> all;
+    uint64_t total = 0;
+    for (size_t i = 0; i < n_texts; i++) {
+      uint64_t* one = nullptr;
+      int64_t c = rj_match_all(prog, texts[i], sizes[i], spans ? &one : nullptr);
+      if (c < 0) return c;
+      counts[i] = static_cast<uint64_t>(c);
+      if (spans && c) all.insert(all.end(), one, one + 2 * c);
+      rj_free_spans(one);
+      total += static_cast<uint64_t>(c);
+    }
+    if (spans && total) {
+      uint64_t* h = static_cast<uint64_t*>(malloc(all.size() * sizeof(uint64_t)));
+      if (!h) return fail(RJ_DEVICE_ERROR, "out of host memory");
+      memcpy(h, all.data(), all.size() * sizeof(uint64_t));
+      *spans = h;
+    }
+    return static_cast<int64_t>(total);
+  }
+  rj_scan* s = nullptr;
+  int rc = host_scan_for(prog, &s);
+  if (rc != RJ_OK) return rc;
+  // text i occupies [off[i], off[i] + sizes[i]); position off[i] + sizes[i] holds the separator and
+  // is text i's end position (an empty match there belongs to text i)
+  std::vector<uint64_t> off(n_texts + 1);
+  uint64_t total_bytes = 0;
+  for (size_t i = 0; i < n_texts; i++) {
+    off[i] = total_bytes;
+    if (sizes[i] >= (1ull << 62) || total_bytes + sizes[i] + 1 < total_bytes) return fail(RJ_BAD_ARGUMENT, "batch: sizes overflow");
+    total_bytes += sizes[i] + 1;
+  }
+  off[n_texts] = total_bytes;
+  // uploads are queued slice by slice from s->pinned: whatever way this function is left, no copy may still
+  // be in flight (the next call may free or refill the staging buffer)
+  struct DrainStream {
+    hipStream_t st;
+    ~DrainStream() { (void)hipStreamSynchronize(st); }
+  } drain{s->own_stream};
+  const uint64_t n = total_bytes - 1;  // the last separator is the end of the buffer
+  if (total_bytes > s->pinned_cap) {
+    if (s->pinned) (void)hipHostFree(s->pinned);
+    s->pinned = nullptr;
+    s->pinned_cap = 0;
+    const size_t want = ((total_bytes + (1u << 20)) / 4096 + 1) * 4096;
+    RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->pinned), want));
+    s->pinned_cap = want;
+  }
+  const char sep = static_cast<char>(prog->batch_separator);
+  RJ_HIP(s->text.reserve(((total_bytes + 64 + 4095) / 4096) * 4096));
+  {
+    // Packing is a host memcpy of the whole batch (one core moves ~10 GB/s, PCIe takes 50+): it is
+    // spread over a few threads and done slice by slice, each slice's DMA starting as soon as it is
+    // packed, so packing slice k+1 overlaps the upload of slice k.
+    const unsigned n_thr = total_bytes > (8u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    auto pack = [&](size_t first, size_t last) {
+      for (size_t i = first; i < last; i++) {
+        if (sizes[i]) memcpy(s->pinned + off[i], texts[i], sizes[i]);
+        s->pinned[off[i] + sizes[i]] = sep;
+      }
+    };
+    constexpr uint64_t kSlice = 64ull << 20;
+    size_t first = 0;
+    while (first < n_texts) {
+      // texts [first, last) make up about one slice
+      size_t last = first;
+      while (last < n_texts && off[last] - off[first] < kSlice) last++;
+      const uint64_t lo = off[first], hi = off[last];
+      if (n_thr == 1 || hi - lo < (8u << 20)) {
+        pack(first, last);
+      } else {
+        std::vector<std::thread> pool;
+        size_t f = first;
+        for (unsigned t = 0; t < n_thr; t++) {
+          const uint64_t upto = lo + (hi - lo) * (t + 1) / n_thr;
+          size_t l = f;
+          while (l < last && off[l] < upto) l++;
+          if (t + 1 == n_thr) l = last;
+          pool.emplace_back(pack, f, l);
+          f = l;
+        }
+        for (auto& th : pool) th.join();
+      }
+      RJ_HIP(hipMemcpyAsync(static_cast<char*>(s->text.p) + lo, s->pinned + lo, hi - lo, hipMemcpyHostToDevice, s->own_stream));
+      first = last;
+    }
+  }
+  rc = run_pipeline(s, s->text.as<uint8_t>(), n, 0, n + 1, 0, 0, 0, s->own_stream);
+  if (rc != RJ_OK) return rc;
+  const uint64_t m = s->result_count;
+  std::vector<uint64_t> pairs(2 * m);
+  if (m) RJ_HIP(copy_result_pairs(s, pairs.data(), 0, m, s->own_stream));
+  // the matches are ordered by begin: one merge pass assigns them to their texts
+  for (size_t i = 0; i < n_texts; i++) counts[i] = 0;
+  size_t t = 0;
+  for (uint64_t k = 0; k < m; k++) {
+    const uint64_t b = pairs[2 * k], e = pairs[2 * k + 1];
+    while (b > off[t] + sizes[t]) t++;
+    if (e > off[t] + sizes[t]) return fail(RJ_DEVICE_ERROR, "internal: a match crosses a text boundary in a batch");
+    counts[t]++;
+    pairs[2 * k] = b - off[t];
+    pairs[2 * k + 1] = e - off[t];
+  }
+  if (spans && m) {
+    uint64_t* h = static_cast<uint64_t*>(malloc(pairs.size() * sizeof(uint64_t)));
+    if (!h) return fail(RJ_DEVICE_ERROR, "out of host memory");
+    memcpy(h, pairs.data(), pairs.size() * sizeof(uint64_t));
+    *spans = h;
+  }
+  return static_cast<int64_t>(m);
+}
+
+extern "C" {
+
+void rj_free_spans(uint64_t* spans) { free(spans); }
+
+// kMatchFirst / kMatchAnywhere with early exit (the reference's generated code returns at the
+// first match, codegen-x64.cc:401-446).  kMatchFirst is the first element of kMatchAll (left-most
+// longest; reference behaviour Q6), and the greedy selection takes the left-most candidate whatever
+// follows it, so it is enough to look at growing prefixes of the START positions: [0, 256 KiB),
+// then 8x more each time.  When the longest match is bounded only the bytes a block's candidates
+// can reach are uploaded first (a walk from s < hi ends before hi + max_len), so a hit near the
+// start of a large host buffer costs microseconds instead of the whole PCIe copy.
+static int first_match(const rj_program* prog, const char* text, size_t n, uint64_t* begin, uint64_t* end) {
+  if (!prog || (!text && n)) return fail(RJ_BAD_ARGUMENT, "null argument");
+  rj_scan* s = nullptr;
+  int rc = host_scan_for(prog, &s);
+  if (rc != RJ_OK) return rc;
+  RJ_HIP(s->text.reserve(((n + 64 + 4095) / 4096) * 4096));
+  const uint8_t* d_text = s->text.as<uint8_t>();
+  const uint64_t max_len = prog->host->max_len;
+  const bool bounded = max_len < (1ull << 20);
+  uint64_t uploaded = 0;
+  auto upload_to = [&](uint64_t upto) -> hipError_t {
+    if (upto > n) upto = n;
+    if (upto <= uploaded) return hipSuccess;
+    hipError_t e = hipMemcpyAsync(static_cast<char*>(s->text.p) + uploaded, text + uploaded, upto - uploaded,
+                                  hipMemcpyHostToDevice, s->own_stream);
+    uploaded = upto;
+    return e;
+  };
+  uint64_t lo = 0, block = 256u << 10;
+  for (;;) {
+    uint64_t hi = lo + block;
+    const bool last = hi >= n;
+    if (last) hi = n;
+    // text the automaton may see in this round: everything for the last block or an unbounded
+    // pattern, else up to the furthest byte a candidate of the block can reach (+1 for the
+    // end-of-line context)
+    const uint64_t visible = (last || !bounded) ? n : std::min<uint64_t>(n, hi + max_len + 1);
+    RJ_HIP(upload_to(visible));
+    rc = run_pipeline(s, d_text, visible, lo, (last && visible == n) ? n + 1 : hi, 0, 0, 0, s->own_stream);
+    if (rc != RJ_OK) return rc;
+    if (s->result_count > 0) {
+      uint64_t pair[2];
+      RJ_HIP(copy_result_pairs(s, pair, 0, 1, s->own_stream));
+      if (begin) *begin = pair[0];
+      if (end) *end = pair[1];
+      return 1;
+    }
+    if (last) return 0;
+    lo = hi;
+    block *= 8;
+  }
+}
+
+int rj_match_first(const rj_program* prog, const char* text, size_t n, uint64_t* begin, uint64_t* end) {
+  ErrnoGuard errno_guard;
+  return first_match(prog, text, n, begin, end);
+}
+
+int rj_match_anywhere(const rj_program* prog, const char* text, size_t n) {
+  ErrnoGuard errno_guard;
+  return first_match(prog, text, n, nullptr, nullptr);
+}
+
+int rj_match_full(const rj_program* prog, const char* text, size_t n) {
+  ErrnoGuard errno_guard;
+  if (!prog || (!text && n)) return fail(RJ_BAD_ARGUMENT, "null argument");
+  rj_scan* s = nullptr;
+  int rc = host_scan_for(prog, &s);
+  if (rc != RJ_OK) return rc;
+  const uint8_t* d_text = nullptr;
+  rc = stage_text(s, text, n, &d_text);
+  if (rc != RJ_OK) return rc;
+  return rj_scan_match_full(s, d_text, n, s->own_stream);
+}
+
+}  // extern "C"

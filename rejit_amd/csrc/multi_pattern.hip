@@ -1,0 +1,446 @@
+// rejit_amd/csrc/multi_pattern.hip -- several patterns over ONE device-resident text (rj_multi_*): the nine
+// counts of regexdna (reference sample/regexdna.cc:51-67 runs one MatchAllCount per pattern).  One pass over
+// the text for all patterns where their window sets allow it (scan_windows_fused), every pattern's own scan
+// in one launch (scan_windows_train) or back to back, and in every mode the tails of all patterns together:
+// two launches and ONE synchronise.  Patterns that do not take the in-region pipeline run one after the other
+// through run_pipeline (engine.hip).
+
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "engine_internal.h"
+
+using namespace rejit_amd;
+
+#define fail ::rejit_amd::rj_fail
+
+namespace {
+
+// ----------------------------------------------------------------------------- fused multi-pattern run
+// fixed windows + lane-sized automaton, not at risk of Q8: the in-region pipeline without carry
+bool batchable(const rj_program* rp) {
+  const DevProgram& D = rp->dev;
+  return D.mode == 1 && D.float_range == 1 && D.n_words <= 4 && !rp->host->q8_risk && !D.behind;
+}
+
+bool fusable(const rj_program* rp) {
+  const DevProgram& D = rp->dev;
+  return D.mode == 1 && D.float_range == 1 && D.n_words <= 4 && D.win_len > 4 && D.n_windows <= 2 &&
+         rp->window_alphabet <= 4 && rp->window_nibbles && !rp->host->q8_risk && !D.behind;
+}
+
+// nibble form of window k (see WindowSet::nibble)
+void nibble_window(const DevProgram& D, int k, uint32_t* value, uint32_t* mask) {
+  uint32_t v = 0, m = 0;
+  for (int i = 0; i < 8; i++) {
+    const uint32_t vb = (i < 4 ? (D.win_value0[k] >> (8 * i)) : (D.win_value1[k] >> (8 * (i - 4)))) & 0xFFu;
+    const uint32_t mb = (i < 4 ? (D.win_mask0[k] >> (8 * i)) : (D.win_mask1[k] >> (8 * (i - 4)))) & 0xFFu;
+    const int at = 8 * (i & 3) + 4 * (i >> 2);
+    if (mb) {
+      v |= (vb & 15u) << at;
+      m |= 15u << at;
+    }
+  }
+  *value = v;
+  *mask = m;
+}
+
+}  // namespace
+
+struct rj_multi {
+  std::vector<rj_scan*> scans;
+  DeviceBuffer dummy_counts;  // hit_counts of the padding patterns
+  DeviceBuffer tails;         // MultiTail[P]
+  MultiTail* host_tails = nullptr;  // pinned
+  uint64_t* host_bounds = nullptr;  // pinned, rj_multi_bounds
+  hipStream_t second = nullptr;     // separate-scans mode: odd patterns' scan kernels
+  hipEvent_t fork = nullptr, join = nullptr;
+  std::vector<MultiTail> uploaded;  // what the device array holds (skip the copy when nothing changed)
+  bool fused = false;     // every pattern has a nibble-form window set: one kernel scans for all
+  bool batchable = false; // every pattern takes the in-region pipeline: scans back to back, tails together
+  int mode = 0;           // rj_multi_set_mode
+  float scan_ms = 0.f;
+};
+
+namespace {
+
+// The scans of all patterns (ONE fused kernel, or one kernel per pattern back to back) + the tails of
+// all patterns in two launches + one synchronise.  Whole text, starts [0, n].
+int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, hipStream_t st, bool fuse) {
+  const int P = static_cast<int>(m->scans.size());
+  // chunks that can hold a window of a start in [sb, se): a window begins at most 7 bytes after its start
+  const uint64_t end_byte = std::min<uint64_t>(n, se + 8);
+  const uint64_t chunks = std::max<uint64_t>((end_byte + 1023) / 1024 - sb / 1024, 1);
+  const ScanGeometry geo = scan_geometry(chunks);
+  for (int attempt = 0; attempt < 6; attempt++) {
+    FusedParams fp{};
+    fp.text = d_text;
+    fp.n = n;
+    fp.sb = sb;
+    fp.se = se;
+    fp.span_chunks = geo.span_chunks;
+    fp.n_patterns = static_cast<uint32_t>((P + kFuseGroup - 1) / kFuseGroup * kFuseGroup);
+    RJ_HIP(m->dummy_counts.reserve(static_cast<size_t>(geo.n_regions) * sizeof(uint32_t)));
+    std::vector<uint64_t> caps(static_cast<size_t>(P));
+    for (int p = 0; p < static_cast<int>(fp.n_patterns); p++) {
+      const int q = p < P ? p : 0;  // padding repeats pattern 0 with no room for hits
+      rj_scan* s = m->scans[static_cast<size_t>(q)];
+      const DevProgram& D = s->prog->dev;
+      nibble_window(D, 0, &fp.value[p][0], &fp.mask[p][0]);
+      nibble_window(D, D.n_windows > 1 ? 1 : 0, &fp.value[p][1], &fp.mask[p][1]);
+      fp.offset[p] = D.win_offset;
+      fp.len[p] = D.win_len;
+      if (p < P) {
+        const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(s->region_cap_hint, 64), geo.span_chunks * 1024);
+        caps[static_cast<size_t>(p)] = cap;
+        int rc = ensure_lists(s, geo.n_regions, static_cast<uint32_t>(cap), static_cast<uint64_t>(geo.n_regions) * cap);
+        if (rc != RJ_OK) return rc;
+        RJ_HIP(s->valid_counts.reserve(static_cast<size_t>(geo.n_regions) * sizeof(uint32_t)));
+        fp.hits[p] = s->hits.as<uint64_t>();
+        fp.region_cap[p] = static_cast<uint32_t>(cap);
+        fp.hit_counts[p] = s->hit_counts.as<uint32_t>();
+        fp.zero_counters[p] = s->counters.as<unsigned long long>();
+        s->stats = rj_stats{};
+        s->result = nullptr;
+        s->result_count = 0;
+      } else {
+        fp.hits[p] = m->scans[0]->hits.as<uint64_t>();
+        fp.region_cap[p] = 0;
+        fp.hit_counts[p] = m->dummy_counts.as<uint32_t>();
+        fp.zero_counters[p] = nullptr;
+      }
+    }
+    rj_scan* s0 = m->scans[0];
+    fp.n_bases = 0;
+    static const bool no_prefilter = getenv("RJ_NO_FUSED_PREFILTER") != nullptr;  // measurement override
+    if (fuse && m->mode == 0 && !no_prefilter) {
+      // Shared prefilter (kernels.hip: fused_chunk_d1): are all windows within one nibble of <= 2 base
+      // windows?  Nibbles are compared on their low 3 bits there.  A base is a window without
+      // wildcards; greedy: the first uncovered exact window becomes the next base.
+      auto nibbles_off = [](uint32_t v, uint32_t k, uint32_t base) {  // nibbles in which (v, k) leaves `base` free or differs
+        int d = 0;
+        for (int i = 0; i < 8; i++) {
+          const uint32_t kk = (k >> (4 * i)) & 7u, vv = (v >> (4 * i)) & 7u, bb = (base >> (4 * i)) & 7u;
+          d += (kk == 0 || vv != bb) ? 1 : 0;
+        }
+        return d;
+      };
+      uint32_t bases[2] = {0, 0};
+      int nb = 0;
+      bool ok = true;
+      for (int pass = 0; pass < 2 && ok; pass++)
+        for (int p = 0; p < P && ok; p++)
+          for (int w = 0; w < 2 && ok; w++) {
+            const uint32_t v = fp.value[p][w] & 0x77777777u, k = fp.mask[p][w] & 0x77777777u;
+            bool covered = false;
+            for (int b = 0; b < nb; b++) covered = covered || nibbles_off(v, k, bases[b]) <= 1;
+            if (covered) continue;
+            if (pass == 0) {
+              if (k == 0x77777777u && nb < 2) bases[nb++] = v;  // an exact window: a new base
+            } else {
+              ok = false;  // second pass: still not within one nibble of a base
+            }
+          }
+      if (ok && nb > 0) {
+        fp.n_bases = static_cast<uint32_t>(nb);
+        fp.base[0] = bases[0];
+        fp.base[1] = bases[nb > 1 ? 1 : 0];
+        for (int p = 0; p < static_cast<int>(fp.n_patterns); p++)
+          for (int w = 0; w < 2; w++) {
+            fp.value[p][w] &= 0x77777777u;
+            fp.mask[p][w] &= 0x77777777u;
+          }
+      }
+    }
+    if (fuse) {
+      launch_scan_windows_fused(fp, geo.grid, s0->ev[1], s0->ev[2], st);
+    } else {
+      // every pattern's own scan kernel (each at its full streaming rate), queued back to back on
+      // the caller's stream -- or, mode 2, alternating between it and a second stream: kernels of ONE
+      // stream run strictly one after the other, so every kernel boundary costs the drain of the
+      // last workgroups plus the ramp-up of the next grid; with two streams the next kernel's
+      // workgroups fill the slots as they become free (regexdna step 0.95 -> 0.89 ms)
+      // (mode 2 only: the kernels of the two streams overlap in time, so a per-kernel duration no
+      // longer means what a roofline needs; the default keeps them on the caller's stream)
+      const bool two_streams = m->mode == 2;
+      // mode 1, every pattern with the regexdna shape (two nibble-form windows): the scans as one launch
+      static const bool no_train = getenv("RJ_NO_TRAIN") != nullptr;  // measurement override
+      bool train = m->mode == 1 && !no_train;  // (mode 3: one launch per pattern, as round 1 did)
+      for (int p = 0; p < P && train; p++) train = fusable(m->scans[static_cast<size_t>(p)]->prog);
+      if (train) {
+        TrainParams tp{};
+        tp.text = d_text;
+        tp.n = n;
+        tp.sb = sb;
+        tp.se = se;
+        tp.span_chunks = geo.span_chunks;
+        tp.n_patterns = static_cast<uint32_t>(P);
+        bool masked = false;
+        for (int p = 0; p < P; p++) {
+          rj_scan* s = m->scans[static_cast<size_t>(p)];
+          const DevProgram& D = s->prog->dev;
+          tp.value[p][0] = fp.value[p][0];
+          tp.mask[p][0] = fp.mask[p][0];
+          tp.value[p][1] = fp.value[p][1];
+          tp.mask[p][1] = fp.mask[p][1];
+          masked = masked || fp.mask[p][0] != 0xFFFFFFFFu || fp.mask[p][1] != 0xFFFFFFFFu;
+          tp.offset[p] = D.win_offset;
+          tp.len[p] = D.win_len;
+          tp.wlo[p] = sb + D.win_offset;
+          const uint64_t last_w = n >= D.win_len ? n - D.win_len + 1 : 0;
+          tp.whi[p] = std::min<uint64_t>(se + D.win_offset, last_w);
+          if (tp.whi[p] < tp.wlo[p]) tp.whi[p] = tp.wlo[p];
+          tp.hits[p] = s->hits.as<uint64_t>();
+          tp.region_cap[p] = static_cast<uint32_t>(caps[static_cast<size_t>(p)]);
+          tp.hit_counts[p] = s->hit_counts.as<uint32_t>();
+          tp.zero_counters[p] = s->counters.as<unsigned long long>();
+        }
+        launch_scan_windows_train(tp, masked, geo.grid, s0->ev[1], s0->ev[2], st);
+      }
+      if (two_streams) {
+        RJ_HIP(hipEventRecord(m->fork, st));
+        RJ_HIP(hipStreamWaitEvent(m->second, m->fork, 0));
+      }
+      for (int p = 0; p < P && !train; p++) {
+        rj_scan* s = m->scans[static_cast<size_t>(p)];
+        const DevProgram& D = s->prog->dev;
+        ScanParams sp{};
+        sp.text = d_text;
+        sp.n = n;
+        sp.sb = sb;
+        sp.se = se;
+        sp.wlo = sb + D.win_offset;
+        const uint64_t last_w = n >= D.win_len ? n - D.win_len + 1 : 0;
+        sp.whi = std::min<uint64_t>(se + D.win_offset, last_w);
+        if (sp.whi < sp.wlo) sp.whi = sp.wlo;
+        sp.span_chunks = geo.span_chunks;
+        sp.hits = s->hits.as<uint64_t>();
+        sp.region_cap = static_cast<uint32_t>(caps[static_cast<size_t>(p)]);
+        sp.hit_counts = s->hit_counts.as<uint32_t>();
+        sp.zero_counters = s->counters.as<unsigned long long>();
+        // one pair of timestamps around the whole train of scan kernels (first kernel's start, last
+        // kernel's end): a pair per kernel puts a completion signal between consecutive kernels
+        hipStream_t sp_stream = (two_streams && (p & 1)) ? m->second : st;
+        launch_scan_windows(sp, make_window_set(s->prog), D.n_windows, geo.grid, p == 0 ? s0->ev[1] : nullptr,
+                            (!two_streams && p == P - 1) ? s0->ev[2] : nullptr, sp_stream);
+      }
+      if (two_streams) {
+        RJ_HIP(hipEventRecord(m->join, m->second));
+        RJ_HIP(hipStreamWaitEvent(st, m->join, 0));
+        RJ_HIP(hipEventRecord(s0->ev[2], st));  // end of the train: both streams have drained
+      }
+    }
+    // the single-pattern tails (verify inside the regions, offsets + gather + check) of all patterns
+    // in two launches; their parameters travel as one small array
+    for (int p = 0; p < P; p++) {
+      rj_scan* s = m->scans[static_cast<size_t>(p)];
+      MultiTail& t = m->host_tails[p];
+      t = MultiTail{};
+      t.verify.text = d_text;
+      t.verify.n = n;
+      t.verify.hits = s->hits.as<uint64_t>();
+      t.verify.n_regions = geo.n_regions;
+      t.verify.region_cap = static_cast<uint32_t>(caps[static_cast<size_t>(p)]);
+      t.verify.counters = s->counters.as<unsigned long long>();
+      t.verify.sb = sb;
+      t.verify.se = se;
+      t.verify.expand = 1;
+      t.verify.float_max = s->prog->dev.float_max;
+      t.program = s->prog->dev;
+      t.hit_counts = s->hit_counts.as<uint32_t>();
+      t.valid_counts = s->valid_counts.as<uint32_t>();
+      t.region_ends = s->cand_end.as<uint64_t>();
+      t.out = s->out.as<uint64_t>();
+      t.out_cap = s->out_cap;
+      t.host_counters = s->host_counters;
+      s->host_counters[kCntUnordered] = 0;
+      s->host_counters[kCntAdjacent] = 0;
+    }
+    if (m->uploaded.size() != static_cast<size_t>(P) ||
+        memcmp(m->uploaded.data(), m->host_tails, sizeof(MultiTail) * static_cast<size_t>(P)) != 0) {
+      RJ_HIP(hipMemcpyAsync(m->tails.p, m->host_tails, sizeof(MultiTail) * P, hipMemcpyHostToDevice, st));
+      m->uploaded.assign(m->host_tails, m->host_tails + P);
+    }
+    launch_tails_multi(m->tails.as<MultiTail>(), P, geo.n_regions, st);
+    RJ_HIP(hipStreamSynchronize(st));
+    RJ_HIP(hipGetLastError());
+    bool again = false;
+    for (int p = 0; p < P; p++) {
+      rj_scan* s = m->scans[static_cast<size_t>(p)];
+      if (s->host_counters[kCntOverflow] != 0) {
+        const uint64_t cap = caps[static_cast<size_t>(p)];
+        const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(s->host_counters[kCntMaxRegion] * 2, cap * 4), geo.span_chunks * 1024);
+        if (want <= cap) return fail(RJ_DEVICE_ERROR, "hit regions cannot grow further");
+        s->region_cap_hint = static_cast<uint32_t>(std::min<uint64_t>(want, 1u << 20));
+        again = true;
+      }
+    }
+    if (fuse) {
+      (void)hipEventElapsedTime(&m->scan_ms, s0->ev[1], s0->ev[2]);
+    } else {
+      (void)hipEventElapsedTime(&m->scan_ms, s0->ev[1], s0->ev[2]);  // first start to last end, gaps included
+    }
+    if (again) continue;
+    for (int p = 0; p < P; p++) {
+      rj_scan* s = m->scans[static_cast<size_t>(p)];
+      hipStream_t sp = st;  // (rare) selection kernels of one pattern after the other
+      if (s->host_counters[kCntOverrun] != 0) {
+        // a long-lived candidate: this pattern's run is void; its own pipeline takes the carry scan
+        s->linear_hint = true;
+        int rc = run_pipeline(s, d_text, n, sb, se, 0, 0, 0, st);
+        if (rc != RJ_OK) return rc;
+        continue;
+      }
+      s->hits_hint = s->host_counters[kCntHits];
+      s->stats.n_hits = s->host_counters[kCntHits];
+      FinalizeParams sel{};
+      sel.carry_cur = 0;
+      sel.carry_prev_end = 0;
+      sel.have_prev = 0;
+      if (s->host_counters[kCntUnordered] != 0) {
+        const uint64_t nc = s->host_counters[kCntCands];
+        RJ_HIP(s->keys_out.reserve(nc * sizeof(uint64_t)));
+        RJ_HIP(s->vals_out.reserve(nc * sizeof(uint64_t)));
+        launch_split_pairs(s->out.as<uint64_t>(), s->counters.as<unsigned long long>() + kCntCands, nc,
+                           s->keys_out.as<uint64_t>(), s->vals_out.as<uint64_t>(), sp);
+      }
+      int rc = resolve_selection(s, sel, sp);
+      if (rc != RJ_OK) return rc;
+      s->result = s->out.as<uint64_t>();
+      s->stats.n_matches = s->result_count;
+      s->stats.scan_ms = fuse ? m->scan_ms : m->scan_ms / static_cast<float>(P);
+    }
+    return RJ_OK;
+  }
+  return fail(RJ_DEVICE_ERROR, "hit regions kept overflowing");
+}
+
+}  // namespace
+
+extern "C" {
+
+int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out) {
+  ErrnoGuard errno_guard;
+  if (!progs || !out || n_progs < 1) return fail(RJ_BAD_ARGUMENT, "null argument");
+  if (n_progs > kMaxFused - kFuseGroup + 1) return fail(RJ_BAD_ARGUMENT, "at most %d patterns per rj_multi", kMaxFused - kFuseGroup + 1);
+  auto m = std::make_unique<rj_multi>();
+  bool all = true, all_batchable = true;
+  for (int i = 0; i < n_progs; i++) {
+    if (!progs[i]) return fail(RJ_BAD_ARGUMENT, "null program");
+    rj_scan* s = nullptr;
+    int rc = rj_scan_create(progs[i], &s);
+    if (rc != RJ_OK) {
+      rj_multi_destroy(m.release());
+      return rc;
+    }
+    m->scans.push_back(s);
+    all = all && fusable(progs[i]);
+    all_batchable = all_batchable && batchable(progs[i]);
+  }
+  if (m->tails.reserve(sizeof(MultiTail) * static_cast<size_t>(n_progs)) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&m->host_tails), sizeof(MultiTail) * static_cast<size_t>(n_progs)) != hipSuccess) {
+    rj_multi_destroy(m.release());
+    return fail(RJ_DEVICE_ERROR, "out of memory");
+  }
+  if (hipStreamCreateWithFlags(&m->second, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&m->fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&m->join, hipEventDisableTiming) != hipSuccess) {
+    rj_multi_destroy(m.release());
+    return fail(RJ_DEVICE_ERROR, "hipStreamCreate / hipEventCreate failed");
+  }
+  m->fused = all && n_progs > 1 && getenv("RJ_NO_FUSION") == nullptr;
+  m->batchable = all_batchable && n_progs > 1;
+  *out = m.release();
+  return RJ_OK;
+}
+
+void rj_multi_destroy(rj_multi* m) {
+  ErrnoGuard errno_guard;
+  if (!m) return;
+  for (rj_scan* s : m->scans) rj_scan_destroy(s);
+  if (m->host_tails) (void)hipHostFree(m->host_tails);
+  if (m->host_bounds) (void)hipHostFree(m->host_bounds);
+  if (m->second) (void)hipStreamDestroy(m->second);
+  if (m->fork) (void)hipEventDestroy(m->fork);
+  if (m->join) (void)hipEventDestroy(m->join);
+  delete m;
+}
+
+int rj_multi_run(rj_multi* m, const void* d_text, uint64_t n, uint64_t* counts, void* hip_stream) {
+  return rj_multi_run_range(m, d_text, n, 0, n + 1, counts, hip_stream);
+}
+
+int rj_multi_run_range(rj_multi* m, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end, uint64_t* counts,
+                       void* hip_stream) {
+  ErrnoGuard errno_guard;
+  if (!m || (!d_text && n) || !counts) return fail(RJ_BAD_ARGUMENT, "null argument");
+  if (own_end > n + 1) own_end = n + 1;
+  if (own_begin >= own_end) {
+    for (size_t i = 0; i < m->scans.size(); i++) counts[i] = 0;
+    return 0;
+  }
+  if ((reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) return fail(RJ_BAD_ARGUMENT, "device text must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  m->scan_ms = 0.f;
+  int fused = 0;
+  if (m->fused && m->mode == 0 && n >= 16) {
+    int rc = run_batched(m, static_cast<const uint8_t*>(d_text), n, own_begin, own_end, st, true);
+    if (rc != RJ_OK) return rc;
+    fused = 1;
+  } else if (m->batchable && n >= 16) {
+    int rc = run_batched(m, static_cast<const uint8_t*>(d_text), n, own_begin, own_end, st, false);
+    if (rc != RJ_OK) return rc;
+    fused = 2;
+  } else {
+    for (rj_scan* s : m->scans) {
+      int rc = run_pipeline(s, static_cast<const uint8_t*>(d_text), n, own_begin, own_end, 0, 0, 0, st);
+      if (rc != RJ_OK) return rc;
+    }
+  }
+  for (size_t i = 0; i < m->scans.size(); i++) counts[i] = m->scans[i]->result_count;
+  return fused;
+}
+
+rj_scan* rj_multi_scan(rj_multi* m, int i) {
+  if (!m || i < 0 || static_cast<size_t>(i) >= m->scans.size()) return nullptr;
+  return m->scans[static_cast<size_t>(i)];
+}
+
+float rj_multi_scan_ms(const rj_multi* m) { return m ? m->scan_ms : 0.f; }
+
+int rj_multi_bounds(rj_multi* m, uint64_t* bounds, void* hip_stream) {
+  ErrnoGuard errno_guard;
+  if (!m || !bounds) return fail(RJ_BAD_ARGUMENT, "null argument");
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const int P = static_cast<int>(m->scans.size());
+  if (!m->host_bounds) RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&m->host_bounds), sizeof(uint64_t) * 4 * kMaxFused));
+  BoundsParams bp{};
+  bp.n_lists = P;
+  for (int p = 0; p < P; p++) {
+    bp.spans[p] = m->scans[static_cast<size_t>(p)]->result;
+    bp.count[p] = bp.spans[p] ? m->scans[static_cast<size_t>(p)]->result_count : 0;
+  }
+  launch_first_last(bp, m->host_bounds, st);
+  RJ_HIP(hipStreamSynchronize(st));
+  RJ_HIP(hipGetLastError());
+  memcpy(bounds, m->host_bounds, sizeof(uint64_t) * 4 * static_cast<size_t>(P));
+  return RJ_OK;
+}
+
+int rj_multi_set_mode(rj_multi* m, int mode) {
+  if (!m || mode < 0 || mode > 3) return fail(RJ_BAD_ARGUMENT, "bad argument");
+  m->mode = mode;
+  return RJ_OK;
+}
+
+}  // extern "C"
