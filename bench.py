@@ -237,7 +237,7 @@ def run_regexdna(args, c):
     n_total = W.fasta_stripped_size(n_fa)
     ranges = sharding.partition(n_total, world)
     own = ranges[rank]
-    vis_lo, vis_hi = sharding.visible_range(n_total, own, max_len)
+    vis_lo, vis_hi = sharding.visible_range(n_total, own, max_len, whole_text=any(p.info()["ring_artefact_risk"] for p in progs))
     text = W.fasta_stripped_torch(n_fa, dev, lo=vis_lo, hi=vis_hi)
     n_local = int(text.numel())
     own_lo, own_hi = own[0] - vis_lo, min(own[1], n_total + 1) - vis_lo
@@ -624,7 +624,7 @@ def run_single_pattern(args, c, which):
     n_total = args.literal_bytes * world
     ranges = sharding.partition(n_total, world)
     own = ranges[rank]
-    vis_lo, vis_hi = sharding.visible_range(n_total, own, max_len)
+    vis_lo, vis_hi = sharding.visible_range(n_total, own, max_len, whole_text=bool(prog.info()["ring_artefact_risk"]))
     t = W.random_ascii_torch(vis_hi - vis_lo, 0xC0FFEE, dev, start=vis_lo)
     n_local = vis_hi - vis_lo
     # planted occurrences, also across the cuts (global offsets; every rank writes the part it sees)

@@ -50,6 +50,12 @@ typedef struct {
   uint32_t window_len;     /* bytes compared per window                             */
   uint64_t min_len;        /* shortest match                                         */
   uint64_t max_len;        /* longest match, UINT64_MAX when unbounded               */
+  int32_t ring_artefact_risk; /* 1: the reference's answer on this pattern can depend on its ring artefact (DESIGN.md
+                              * section 6).  A RANGE of such a pattern (rj_scan_run with own_begin / own_end) owns the whole
+                              * segments between synchronisation points, [first point >= own_begin, first point >= own_end),
+                              * and takes the text buffer to be the WHOLE text: give every rank the text up to its end
+                              * (rejit_amd/sharding.py: visible_range(..., whole_text=True)), not a fixed halo. */
+  int32_t reserved;
 } rj_info;
 
 typedef struct {

@@ -104,7 +104,8 @@ def _build_locked(verbose: bool) -> str:
 class _Info(ctypes.Structure):
     _fields_ = [("n_positions", ctypes.c_int32), ("n_words", ctypes.c_int32), ("has_assertions", ctypes.c_int32),
                 ("scan_mode", ctypes.c_int32), ("n_windows", ctypes.c_int32), ("window_offset", ctypes.c_uint32),
-                ("window_len", ctypes.c_uint32), ("min_len", ctypes.c_uint64), ("max_len", ctypes.c_uint64)]
+                ("window_len", ctypes.c_uint32), ("min_len", ctypes.c_uint64), ("max_len", ctypes.c_uint64),
+                ("ring_artefact_risk", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class _Stats(ctypes.Structure):

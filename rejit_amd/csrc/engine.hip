@@ -862,6 +862,8 @@ int rj_program_info(const rj_program* prog, rj_info* info) {
   info->window_len = prog->dev.win_len;
   info->min_len = P.min_len;
   info->max_len = P.max_len;
+  info->ring_artefact_risk = P.q8_risk ? 1 : 0;
+  info->reserved = 0;
   return RJ_OK;
 }
 

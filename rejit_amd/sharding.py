@@ -42,10 +42,15 @@ def partition(n: int, world: int, align: int = 1024) -> List[Tuple[int, int]]:
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def visible_range(n: int, own: Tuple[int, int], max_len: Optional[int], left: int = 64) -> Tuple[int, int]:
+def visible_range(n: int, own: Tuple[int, int], max_len: Optional[int], left: int = 64, whole_text: bool = False) -> Tuple[int, int]:
     """Bytes a rank must hold to decide every match that begins in `own`.  max_len None =
-    unbounded pattern: the rank needs the text up to its end."""
+    unbounded pattern: the rank needs the text up to its end.  whole_text (pass
+    `Program.info()["ring_artefact_risk"]`): a pattern whose answer can depend on the reference's ring
+    artefact -- the engine then gives a range the whole segments between synchronisation points of the
+    reference's loop, which it looks for in the buffer it is given, so the buffer must be the whole text."""
     lo, hi = own
+    if whole_text:
+        return 0, n
     vis_lo = max(0, lo - left)
     vis_hi = n if max_len is None else min(n, hi + max_len)
     return vis_lo, vis_hi

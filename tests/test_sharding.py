@@ -114,6 +114,7 @@ def test_partition_and_visible_range():
     assert all(lo % 1024 == 0 for lo, _ in r)
     assert sharding.visible_range(1000, (100, 200), 8) == (36, 208)
     assert sharding.visible_range(1000, (100, 200), None) == (36, 1000)
+    assert sharding.visible_range(1000, (100, 200), 8, whole_text=True) == (0, 1000)
     assert sharding.needs_rerun((5, 9), (6, 6, True)) and not sharding.needs_rerun((6, 9), (6, 6, True))
     assert sharding.needs_rerun((6, 6), (6, 6, True)) and not sharding.needs_rerun(None, (6, 6, True))
 
