@@ -562,6 +562,13 @@ def literal_and_complex_extras(args, c, out):
     out["dense_scan"] = single_pattern_extra(
         c, rejit_amd, t, n, "[a-f]+[0-9]", "[a-f]+[0-9] MatchAll over the same %d bytes (no fast-forward window: dense mode)" % n,
         "scan_dense_walk<1,false,4> (lane-packed pre-steps)", 5, check_dense, None, True, args)
+    # (the dense kernel is issue-bound, not HBM-bound: its VALU roofline says how close to the other ceiling it runs)
+    _dl = out["dense_scan"]["roofline"]["avg_launch_ms"]
+    if _dl:
+        _valu = n * rejit_amd.DENSE_VALU_OPS_PER_BYTE / (_dl * 1e-3) / 1e12
+        out["dense_scan"]["roofline_valu"] = {"bound": "valu", "kernel": "scan_dense_walk<1,false,4>",
+                                              "ops_per_text_byte": rejit_amd.DENSE_VALU_OPS_PER_BYTE, "achieved": round(_valu, 2),
+                                              "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s", "frac": round(_valu / VALU_PEAK_TOPS, 4)}
     # The line table of a grep-like caller (sample/jrep.cc:294: MatchAll of "^"): a class scan whose OUTPUT is
     # the traffic -- 16 bytes per line start next to 1 byte read per text byte.
     nl = torch.arange(60, n, 61, device=dev)
