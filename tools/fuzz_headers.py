@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""CPU fuzz of the host/device algorithm headers through the test driver tests/support/libcarry_exec.so
+(built by the CPU tests; run `python -m pytest tests/test_carry_scan.py -q -k behind` once if it is missing):
+
+  exact  exact_replay.h against the oracle: whole text and random 3-way splits into ranges, random chunk sizes
+         (round 2: 96 000 cases, 0 mismatches)
+  swar   dense_swar.h against the scalar automaton, rj_lane_longest_short against rj_lane_longest, random patterns
+         (round 2: 6600 + 6500 plans, 0 mismatches)
+
+usage: fuzz_headers.py exact|swar [seed] [cases]"""
+import ctypes, os, random, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+SO = os.path.join(ROOT, "tests", "support", "libcarry_exec.so")
+mode = sys.argv[1] if len(sys.argv) > 1 else "exact"
+sys.argv = [sys.argv[0]] + (sys.argv[2:] + ["1", "5000"])[:2]
+
+
+def fuzz_exact():
+    from checkers import Oracle
+    from make_golden import RegexGen, ALPHABETS
+    o=Oracle()
+    lib=ctypes.CDLL(SO)
+    _u64p=ctypes.POINTER(ctypes.c_uint64)
+    lib.ce_exact_range.restype=ctypes.c_long
+    lib.ce_exact_range.argtypes=[ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, _u64p, ctypes.c_uint64, _u64p, _u64p, ctypes.POINTER(ctypes.c_int)]
+    def exact(rx,tx,chunk,sb=0,se=None):
+        se=len(tx)+1 if se is None else se
+        cap=len(tx)+2; buf=(ctypes.c_uint64*(2*cap))(); a=ctypes.c_uint64(); b=ctypes.c_uint64(); r=ctypes.c_int()
+        n=lib.ce_exact_range(rx,tx,len(tx),chunk,sb,se,buf,cap,ctypes.byref(a),ctypes.byref(b),ctypes.byref(r))
+        if n<0: return int(n)
+        return [(int(buf[2*i]),int(buf[2*i+1])) for i in range(n)]
+    seed=int(sys.argv[1]); N=int(sys.argv[2]); rng=random.Random(seed)
+    ALPH=ALPHABETS+["ab\n\r","xyz ^$","aA0-"]
+    n=bad=0; t0=time.time()
+    for it in range(N):
+        alphabet=rng.choice(ALPH)
+        rx=RegexGen(rng, alphabet).alt(3).encode('latin1')
+        if o.status(rx)!=0: continue
+        tx="".join(rng.choice(alphabet) for _ in range(rng.choice([0,1,9,33,120,500]))).encode('latin1')
+        want=o.match_all(rx,tx)
+        if isinstance(want,int): continue
+        chunk=rng.choice([1,2,5,16,64,1024])
+        got=exact(rx,tx,chunk)
+        if got==-9: continue
+        n+=1
+        if got!=want:
+            print("MISMATCH whole", rx, tx, chunk, got[:4], want[:4]); bad+=1
+        k=rng.randrange(0,len(tx)+2); k2=rng.randrange(k,len(tx)+2)
+        parts=[]
+        for lo,hi in ((0,k),(k,k2),(k2,len(tx)+1)):
+            if lo<hi:
+                g=exact(rx,tx,rng.choice([3,16,256]),lo,hi); parts+=g
+        if parts!=want:
+            print("MISMATCH split", rx, tx, (k,k2), parts[:4], want[:4]); bad+=1
+        if bad>5: break
+    print(f"seed {seed}: checked {n}, mismatches {bad}, {time.time()-t0:.0f}s")
+
+
+
+def fuzz_swar():
+    from make_golden import RegexGen, ALPHABETS
+    lib=ctypes.CDLL(SO)
+    _u64p=ctypes.POINTER(ctypes.c_uint64)
+    lib.ce_swar_check.restype=ctypes.c_long
+    lib.ce_swar_check.argtypes=[ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, _u64p]
+    lib.ce_short_check.restype=ctypes.c_long
+    lib.ce_short_check.argtypes=[ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, _u64p]
+    seed=int(sys.argv[1]); N=int(sys.argv[2]); rng=random.Random(seed)
+    ALPH=ALPHABETS+["abcdef0123456789","xyz@#AZ az","\x80\x90\xffab"]
+    used=short=bad=0; t0=time.time()
+    for it in range(N):
+        alphabet=rng.choice(ALPH)
+        rx=RegexGen(rng, alphabet).alt(2).encode('latin1')
+        tx=bytes(rng.choice(alphabet.encode('latin1')) for _ in range(16*40+4))
+        st=(ctypes.c_uint64*4)()
+        r=lib.ce_swar_check(rx,tx,len(tx),st)
+        if r>=0:
+            used+=1
+            if r!=0: print("SWAR MISMATCH", rx, r); bad+=1
+        c=ctypes.c_uint64(0)
+        r=lib.ce_short_check(rx,tx[:200],200,ctypes.byref(c))
+        if r>=0:
+            short+=1
+            if r!=0: print("SHORT MISMATCH", rx, r); bad+=1
+        if bad>5: break
+    print(f"seed {seed}: swar plans {used}, short plans {short}, mismatches {bad}, {time.time()-t0:.0f}s")
+
+
+
+(fuzz_exact if mode == "exact" else fuzz_swar)()
