@@ -267,15 +267,9 @@ RJ_HD bool rj_lane_longest(const DevProgram& P, const Text& t, uint64_t n, uint6
 // <= 16 bytes): same result, but the dependent chain is  text (two 8-byte loads) -> the class rows of all
 // bytes (independent loads) -> register arithmetic,  where the general walk has a byte load and a row load
 // per step, each waiting for the previous step.  The tails of the headline run are made of such chains.
-RJ_HD bool rj_lane_longest_short(const DevProgram& P, const uint8_t* t, uint64_t n, uint64_t s, uint64_t* end) {
-  const int W = P.n_words;
-  bool found = false;
-  if (P.nullable & 1u) {
-    found = true;
-    *end = s;
-  }
-  if (s >= n || P.n_pos == 0) return found;
-  const uint32_t L = P.short_max;
+//
+// rj_load16: the 16 text bytes from s on (zeros beyond the end of the text)
+RJ_HD void rj_load16(const uint8_t* t, uint64_t n, uint64_t s, uint64_t* lo_out, uint64_t* hi_out) {
   uint64_t lo = 0, hi = 0;
   if (s + 16 <= n) {
     __builtin_memcpy(&lo, t + s, 8);
@@ -287,6 +281,20 @@ RJ_HD bool rj_lane_longest_short(const DevProgram& P, const uint8_t* t, uint64_t
       else hi |= c << (8 * (k - 8));
     }
   }
+  *lo_out = lo;
+  *hi_out = hi;
+}
+
+// (lo, hi) = rj_load16(t, n, s): callers that test several patterns at one start load the text once
+RJ_HD bool rj_lane_longest_short_at(const DevProgram& P, uint64_t lo, uint64_t hi, uint64_t n, uint64_t s, uint64_t* end) {
+  const int W = P.n_words;
+  bool found = false;
+  if (P.nullable & 1u) {
+    found = true;
+    *end = s;
+  }
+  if (s >= n || P.n_pos == 0) return found;
+  const uint32_t L = P.short_max;
   const uint32_t avail = n - s < 16 ? static_cast<uint32_t>(n - s) : 16u;
   const uint32_t steps = L < avail ? L : avail;  // bytes a match can consume here
   uint64_t row[16];
@@ -324,6 +332,12 @@ RJ_HD bool rj_lane_longest_short(const DevProgram& P, const uint8_t* t, uint64_t
     S = T & row[k];
   }
   return found;
+}
+
+RJ_HD bool rj_lane_longest_short(const DevProgram& P, const uint8_t* t, uint64_t n, uint64_t s, uint64_t* end) {
+  uint64_t lo, hi;
+  rj_load16(t, n, s, &lo, &hi);
+  return rj_lane_longest_short_at(P, lo, hi, n, s, end);
 }
 
 // Candidate test used by the dense scan: can a match start at s at all?

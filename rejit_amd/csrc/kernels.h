@@ -13,7 +13,8 @@ namespace rejit_amd {
 enum { kCntCands = 0, kCntFinal = 1, kCntOverflow = 2, kCntAdjacent = 3, kCntHits = 4, kCntMaxRegion = 5, kCntOverrun = 6,
   kCntUnordered = 7,  // check_and_interleave: the candidates are not already the result
   kCntConflict = 8,   // behind mode: a candidate hidden by an earlier match ends after it (the run is repeated dense)
-  kCntSize = 9 };
+  kCntSharedMax = 9,  // plane scan (plane_scan.hip): fullest SHARED candidate region when one overflowed, else 0
+  kCntSize = 10 };
 
 constexpr uint64_t kNoMatch = ~0ull;  // cand_end of a hit at which nothing matches
 
@@ -147,6 +148,31 @@ struct BoundsParams {
 void launch_first_last(const BoundsParams& a, uint64_t* pinned_bounds, hipStream_t st);
 void launch_scan_windows_fused(const FusedParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 
+// ---- plane scan (plane_scan.hip): the one-pass scan for SEVERAL patterns whose 8-byte windows all lie within
+// one byte of <= 2 base windows over an alphabet of <= 4 symbols (regexdna: every window is `agggtaaa` or
+// `tttaccct` with at most one position turned into a class).  The text is reduced to 2-bit symbol codes
+// ((byte >> code_shift) & 3), held as bit planes, and "at most one symbol differs from base b" is evaluated
+// for 32 positions per VALU instruction.  Positions that pass go to ONE candidate list shared by all
+// patterns (regions as everywhere: region w = wave w, sorted by construction); classify_shared_multi then
+// tests every candidate against every pattern's own windows and automaton.
+struct PlaneParams {
+  const uint8_t* text;   // 16-byte aligned
+  uint64_t n;
+  uint64_t sb, se;       // candidate starts [sb, se)
+  uint64_t span_pairs;   // wave w owns the 2-KiB pairs [first + w*span, first + (w+1)*span)
+  uint32_t offset;       // window offset inside a match (the same for all patterns); windows are 8 bytes
+  uint32_t code_shift;
+  uint32_t n_bases;      // 1 or 2
+  // base b, window byte i: lo[b][i] / hi[b][i] = 0 when the low / high bit of its symbol code is 1, else ~0
+  uint32_t lo[2][8], hi[2][8];
+  uint64_t* hits;        // shared candidate regions (starts s = w - offset)
+  uint32_t region_cap;
+  uint32_t* hit_counts;  // [n_regions]
+  uint32_t n_zero;
+  unsigned long long* zero_counters[kMaxFused];  // counter blocks the kernel clears (one per pattern)
+};
+void launch_plane_scan(const PlaneParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
+
 struct ScanGeometry {
   int grid;
   uint32_t n_regions;
@@ -180,6 +206,20 @@ struct MultiTail {
   unsigned long long* host_counters;
 };
 void launch_tails_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_regions, hipStream_t st);
+// the same tails fed from ONE shared candidate list (plane scan): classify_shared_multi verifies every candidate
+// against every pattern (window test first, automaton for the patterns whose window matches) and compacts the
+// survivors into the patterns' own regions; then offsets_gather_check_multi as above.  A shared region that
+// overflowed is reported in pattern 0's counters[kCntSharedMax].
+struct SharedHits {
+  const uint64_t* hits;
+  const uint32_t* counts;
+  uint32_t cap;
+  uint32_t n_regions;
+  uint32_t n_patterns;
+  uint32_t win_offset;
+};
+void launch_tails_shared(const MultiTail* d_tails, const SharedHits& sh, hipStream_t st);
+void launch_offsets_gather_check_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_regions, hipStream_t st);
 
 // windows mode, lane-sized automaton: verify + compact inside every region (16 lanes each), then
 // offsets_gather_check lays the survivors out

@@ -1331,6 +1331,7 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
       host_counters[kCntOverflow] = counters[kCntOverflow];
       host_counters[kCntMaxRegion] = counters[kCntMaxRegion];
       host_counters[kCntOverrun] = counters[kCntOverrun];
+      host_counters[kCntSharedMax] = counters[kCntSharedMax];
       host_counters[kCntFinal] = 0;
     }
   }
@@ -2922,6 +2923,10 @@ void launch_tails_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_reg
   uint64_t vblocks = (static_cast<uint64_t>(n_regions) + 63) / 64;  // 4 lanes per region
   vblocks = vblocks < 1 ? 1 : vblocks > 4096 ? 4096 : vblocks;
   hipLaunchKernelGGL(verify_in_regions_multi, dim3(static_cast<unsigned>(vblocks), n_patterns), dim3(256), 0, st, d_tails);
+  launch_offsets_gather_check_multi(d_tails, n_patterns, n_regions, st);
+}
+
+void launch_offsets_gather_check_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_regions, hipStream_t st) {
   const unsigned gblocks = n_regions ? (n_regions + kOgcThreads - 1) / kOgcThreads : 1u;
   hipLaunchKernelGGL(offsets_gather_check_multi, dim3(gblocks, n_patterns), dim3(kOgcThreads), 0, st, d_tails);
 }

@@ -55,10 +55,91 @@ void nibble_window(const DevProgram& D, int k, uint32_t* value, uint32_t* mask) 
   *mask = m;
 }
 
+// Plane scan (plane_scan.hip): do all windows of all patterns lie within ONE byte of <= 2 base windows over an
+// alphabet that 2-bit symbol codes (byte >> shift) & 3 separate?  A base is a window without wildcards; greedy:
+// the first uncovered exact window becomes the next base.
+struct PlanePlan {
+  bool ok = false;
+  uint32_t code_shift = 0, n_bases = 0, offset = 0;
+  uint8_t base[2][8] = {};
+};
+
+PlanePlan plan_plane(const std::vector<rj_scan*>& scans) {
+  PlanePlan pl;
+  struct Win {
+    uint8_t v[8];
+    bool fixed[8];
+  };
+  std::vector<Win> wins;
+  for (size_t p = 0; p < scans.size(); p++) {
+    const DevProgram& D = scans[p]->prog->dev;
+    if (D.win_len != 8 || D.n_windows < 1 || D.n_windows > 2) return pl;
+    if (p == 0) pl.offset = D.win_offset;
+    else if (D.win_offset != pl.offset) return pl;
+    for (int k = 0; k < D.n_windows; k++) {
+      Win w;
+      for (int i = 0; i < 8; i++) {
+        const uint32_t vb = (i < 4 ? (D.win_value0[k] >> (8 * i)) : (D.win_value1[k] >> (8 * (i - 4)))) & 0xFFu;
+        const uint32_t mb = (i < 4 ? (D.win_mask0[k] >> (8 * i)) : (D.win_mask1[k] >> (8 * (i - 4)))) & 0xFFu;
+        if (mb != 0 && mb != 0xFFu) return pl;
+        w.v[i] = static_cast<uint8_t>(vb);
+        w.fixed[i] = mb != 0;
+      }
+      wins.push_back(w);
+    }
+  }
+  auto off = [&](const Win& w, const uint8_t* base) {  // bytes in which w is free or differs from base
+    int d = 0;
+    for (int i = 0; i < 8; i++) d += (!w.fixed[i] || w.v[i] != base[i]) ? 1 : 0;
+    return d;
+  };
+  int nb = 0;
+  for (int pass = 0; pass < 2; pass++)
+    for (const Win& w : wins) {
+      bool covered = false;
+      for (int b = 0; b < nb; b++) covered = covered || off(w, pl.base[b]) <= 1;
+      if (covered) continue;
+      bool exact = true;
+      for (int i = 0; i < 8; i++) exact = exact && w.fixed[i];
+      if (pass == 0 && exact && nb < 2) memcpy(pl.base[nb++], w.v, 8);
+      else if (pass == 1) return pl;  // not within one byte of a base
+    }
+  if (nb == 0) return pl;
+  // symbol codes: the distinct bytes of the bases must get distinct codes (else the test loses its selectivity)
+  bool seen[256] = {};
+  std::vector<int> alphabet;
+  for (int b = 0; b < nb; b++)
+    for (int i = 0; i < 8; i++)
+      if (!seen[pl.base[b][i]]) {
+        seen[pl.base[b][i]] = true;
+        alphabet.push_back(pl.base[b][i]);
+      }
+  if (alphabet.size() > 4) return pl;
+  for (uint32_t sh = 0; sh <= 6; sh++) {
+    uint32_t codes = 0;
+    bool distinct = true;
+    for (int c : alphabet) {
+      const uint32_t code = (static_cast<uint32_t>(c) >> sh) & 3u;
+      distinct = distinct && !((codes >> code) & 1u);
+      codes |= 1u << code;
+    }
+    if (distinct) {
+      pl.code_shift = sh;
+      pl.n_bases = static_cast<uint32_t>(nb);
+      pl.ok = true;
+      return pl;
+    }
+  }
+  return pl;
+}
+
 }  // namespace
 
 struct rj_multi {
   std::vector<rj_scan*> scans;
+  PlanePlan plane;             // mode 0: the one-pass bit-plane scan with a shared candidate list
+  DeviceBuffer shared_hits, shared_counts;
+  uint32_t shared_cap_hint = 128;
   DeviceBuffer dummy_counts;  // hit_counts of the padding patterns
   DeviceBuffer tails;         // MultiTail[P]
   MultiTail* host_tails = nullptr;  // pinned
@@ -80,7 +161,19 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
   const int P = static_cast<int>(m->scans.size());
   // chunks that can hold a window of a start in [sb, se): a window begins at most 7 bytes after its start
   const uint64_t end_byte = std::min<uint64_t>(n, se + 8);
-  const uint64_t chunks = std::max<uint64_t>((end_byte + 1023) / 1024 - sb / 1024, 1);
+  uint64_t chunks = std::max<uint64_t>((end_byte + 1023) / 1024 - sb / 1024, 1);
+  // mode 0, every window within one byte of <= 2 bases: the bit-plane scan (plane_scan.hip), which walks the
+  // window positions [wlo, whi) in pairs of chunks
+  static const bool no_plane = getenv("RJ_NO_PLANE") != nullptr;  // measurement override
+  const bool plane = fuse && m->mode == 0 && m->plane.ok && !no_plane;
+  uint64_t plane_pairs = 0;
+  if (plane) {
+    const uint64_t wlo = sb + m->plane.offset;
+    const uint64_t last_w = n >= 8 ? n - 8 + 1 : 0;
+    const uint64_t whi = std::min<uint64_t>(se + m->plane.offset, last_w);
+    plane_pairs = whi > wlo ? (whi + 2047) / 2048 - wlo / 2048 : 0;
+    chunks = std::max<uint64_t>(plane_pairs * 2, 1);
+  }
   const ScanGeometry geo = scan_geometry(chunks);
   for (int attempt = 0; attempt < 6; attempt++) {
     FusedParams fp{};
@@ -162,7 +255,33 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
           }
       }
     }
-    if (fuse) {
+    uint32_t shared_cap = 0;
+    if (plane) {
+      PlaneParams pp{};
+      pp.text = d_text;
+      pp.n = n;
+      pp.sb = sb;
+      pp.se = se;
+      pp.span_pairs = std::max<uint64_t>((plane_pairs + geo.n_regions - 1) / geo.n_regions, 1);
+      pp.offset = m->plane.offset;
+      pp.code_shift = m->plane.code_shift;
+      pp.n_bases = m->plane.n_bases;
+      for (uint32_t b = 0; b < 2; b++)
+        for (int i = 0; i < 8; i++) {
+          const uint32_t code = (static_cast<uint32_t>(m->plane.base[b < m->plane.n_bases ? b : 0][i]) >> m->plane.code_shift) & 3u;
+          pp.lo[b][i] = (code & 1u) ? 0u : ~0u;
+          pp.hi[b][i] = (code & 2u) ? 0u : ~0u;
+        }
+      shared_cap = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint32_t>(m->shared_cap_hint, 64), pp.span_pairs * 2048));
+      RJ_HIP(m->shared_hits.reserve(static_cast<size_t>(geo.n_regions) * shared_cap * sizeof(uint64_t)));
+      RJ_HIP(m->shared_counts.reserve(static_cast<size_t>(geo.n_regions) * sizeof(uint32_t)));
+      pp.hits = m->shared_hits.as<uint64_t>();
+      pp.region_cap = shared_cap;
+      pp.hit_counts = m->shared_counts.as<uint32_t>();
+      pp.n_zero = static_cast<uint32_t>(P);
+      for (int p = 0; p < P; p++) pp.zero_counters[p] = m->scans[static_cast<size_t>(p)]->counters.as<unsigned long long>();
+      launch_plane_scan(pp, geo.grid, s0->ev[1], s0->ev[2], st);
+    } else if (fuse) {
       launch_scan_windows_fused(fp, geo.grid, s0->ev[1], s0->ev[2], st);
     } else {
       // every pattern's own scan kernel (each at its full streaming rate), queued back to back on
@@ -271,10 +390,29 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       RJ_HIP(hipMemcpyAsync(m->tails.p, m->host_tails, sizeof(MultiTail) * P, hipMemcpyHostToDevice, st));
       m->uploaded.assign(m->host_tails, m->host_tails + P);
     }
-    launch_tails_multi(m->tails.as<MultiTail>(), P, geo.n_regions, st);
+    if (plane) {
+      SharedHits sh{};
+      sh.hits = m->shared_hits.as<uint64_t>();
+      sh.counts = m->shared_counts.as<uint32_t>();
+      sh.cap = shared_cap;
+      sh.n_regions = geo.n_regions;
+      sh.n_patterns = static_cast<uint32_t>(P);
+      sh.win_offset = m->plane.offset;
+      launch_tails_shared(m->tails.as<MultiTail>(), sh, st);
+    } else {
+      launch_tails_multi(m->tails.as<MultiTail>(), P, geo.n_regions, st);
+    }
     RJ_HIP(hipStreamSynchronize(st));
     RJ_HIP(hipGetLastError());
     bool again = false;
+    if (plane && s0->host_counters[kCntSharedMax] != 0) {
+      // a shared candidate region overflowed: size them all for the fullest one seen (x2) and run again
+      const uint64_t want = std::max<uint64_t>(s0->host_counters[kCntSharedMax] * 2, static_cast<uint64_t>(shared_cap) * 2);
+      if (shared_cap >= 2048 * std::max<uint64_t>((plane_pairs + geo.n_regions - 1) / geo.n_regions, 1))
+        return fail(RJ_DEVICE_ERROR, "candidate regions cannot grow further");
+      m->shared_cap_hint = static_cast<uint32_t>(std::min<uint64_t>(want, 1u << 20));
+      again = true;
+    }
     for (int p = 0; p < P; p++) {
       rj_scan* s = m->scans[static_cast<size_t>(p)];
       if (s->host_counters[kCntOverflow] != 0) {
@@ -359,6 +497,7 @@ int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out)
     return fail(RJ_DEVICE_ERROR, "hipStreamCreate / hipEventCreate failed");
   }
   m->fused = all && n_progs > 1 && getenv("RJ_NO_FUSION") == nullptr;
+  if (m->fused) m->plane = plan_plane(m->scans);
   m->batchable = all_batchable && n_progs > 1;
   *out = m.release();
   return RJ_OK;

@@ -1,0 +1,356 @@
+// rejit_amd/csrc/plane_scan.hip -- the one-pass fast-forward scan for SEVERAL patterns (regexdna's nine
+// counts, reference sample/regexdna.cc:51-67, which runs FastForwardGen's multi-literal scan,
+// src/x64/codegen-x64.cc:1102-1252, once per pattern) as a BIT-PLANE kernel, and the classification of its
+// candidates.
+//
+// Shape it serves (host check: multi_pattern.hip): every pattern has <= 2 windows of 8 bytes at the same
+// offset, and every window lies within ONE byte of one of <= 2 base windows without wildcards -- all 18
+// regexdna windows are `agggtaaa` or `tttaccct` with at most one position turned into a class.  A text
+// position can then only begin a window of ANY pattern if it differs from a base in at most one byte: one
+// test for all patterns, and the reference's idea of scanning for what the alternatives have in common
+// (FF_finder::ff_alternation_reduce, src/codegen.cc:395-531) carried one step further.
+//
+// How the test is evaluated.  The kernel of round 2 (scan_windows_fused, kernels.hip) built the window of
+// every position in a register and counted differing nibbles: 7 VALU instructions per position, 8.6 per text
+// byte with the packing -- VALU-bound at 0.23 of HBM.  Here the text is turned "vertical":
+//   * every byte becomes a 2-bit symbol code (byte >> code_shift) & 3 -- a, c, g, t -> 0, 1, 3, 2 -- and four
+//     codes pack into a byte with ONE v_dot4_u32_u8 ((d & 0x06060606) . (1, 4, 16, 64));  any byte aliases to
+//     some symbol, which makes the test a superset test like every fast-forward filter (the automaton removes
+//     the aliases);
+//   * the low and the high code bits of two 1-KiB chunks A and B are interleaved into two plane registers per
+//     lane: bit 2k = position k of the lane's 16 bytes of A, bit 2k + 1 = position k of its 16 bytes of B;
+//   * window byte i of a base is the symbol (l_i, h_i): positions where the text shifted by i matches it are
+//     E_i = ~(L_i ^ l_i) & ~(H_i ^ h_i) with L_i = v_alignbit(L_halo, L, 2 i) -- both chunks in one shift;
+//   * "no mismatch so far" Z and "at most one" O are carried over the eight window bytes: Z' = Z & E,
+//     O' = Z | (O & E) -- one v_bitop3 each.
+// 32 positions per instruction: 118 VALU instructions per 2 KiB and wave = 3.7 lane-operations per text byte
+// for ALL patterns (the single-pattern nibble scan needs 5.4), so the kernel streams at the HBM rate.
+// Candidates (one per ~1.3 KiB on DNA) go to ONE list shared by all patterns, in the wave's own region like
+// every hit list of this engine (no atomics, sorted by construction).
+//
+// classify_shared_multi then takes the place of verify_in_regions_multi: a wave per region; every candidate's
+// window bytes are loaded once and tested against the windows of pattern after pattern (exact, with wildcards);
+// the automaton (device_program.h) runs only for the patterns whose window matches -- one of nine for a
+// candidate one byte off a base -- and the survivors are compacted into that pattern's own region, from where
+// offsets_gather_check_multi lays them out as before.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "device_program.h"
+#include "kernels.h"
+
+namespace rejit_amd {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr uint64_t kChunk = 1024;   // bytes of one chunk: 64 lanes x 16 B
+constexpr uint64_t kPair = 2048;    // two chunks per wave iteration (the planes interleave them)
+
+__device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & (kWave - 1); }
+
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
+// 16 B of the lane + the 8 B that follow (the neighbour lane's first bytes: same cache lines, L1 hits)
+__device__ __forceinline__ void load_chunk24(const uint8_t* text, uint64_t at, uint32_t (&d)[6]) {
+  const uint4 v = *reinterpret_cast<const uint4*>(text + at);
+  const uint2 h = *reinterpret_cast<const uint2*>(text + at + 16);
+  d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  d[4] = h.x; d[5] = h.y;
+}
+
+__device__ __forceinline__ void load_guarded24(const uint8_t* text, uint64_t n, uint64_t at, uint32_t (&d)[6]) {
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint64_t p = at + 4 * q + k;
+      if (p < n) v |= static_cast<uint32_t>(text[p]) << (8 * k);
+    }
+    d[q] = v;
+  }
+}
+
+struct PlaneConsts {
+  uint32_t cmask;   // 0x03030303 << code_shift
+  uint32_t shift;   // code_shift
+};
+
+// the 2-bit codes of a dword's four bytes as one byte (times 2^shift)
+__device__ __forceinline__ uint32_t codes4(uint32_t d, const PlaneConsts& k) {
+  return __builtin_amdgcn_udot4(d & k.cmask, 0x40100401u, 0u, false);
+}
+
+// Candidate positions of one pair of chunks: bit 2k = position k of the lane's 16 bytes of chunk A, bit
+// 2k + 1 = position k of its 16 bytes of chunk B.
+template <int NB>
+__device__ __forceinline__ uint32_t plane_candidates(const uint32_t (&dA)[6], const uint32_t (&dB)[6], const PlaneConsts& k,
+                                                     const PlaneParams& a) {
+  const uint32_t s = k.shift;
+  const uint32_t ta = (codes4(dA[0], k) >> s) | (codes4(dA[1], k) << (8 - s)) | (codes4(dA[2], k) << (16 - s)) | (codes4(dA[3], k) << (24 - s));
+  const uint32_t tb = (codes4(dB[0], k) >> s) | (codes4(dB[1], k) << (8 - s)) | (codes4(dB[2], k) << (16 - s)) | (codes4(dB[3], k) << (24 - s));
+  const uint32_t ha = (codes4(dA[4], k) >> s) | (codes4(dA[5], k) << (8 - s));   // the 8 positions that follow
+  const uint32_t hb = (codes4(dB[4], k) >> s) | (codes4(dB[5], k) << (8 - s));
+  constexpr uint32_t kEven = 0x55555555u;
+  // planes: low / high code bit, A in the even bits, B in the odd ones (v_bfi_b32)
+  const uint32_t L = (ta & kEven) | ((tb << 1) & ~kEven);
+  const uint32_t H = ((ta >> 1) & kEven) | (tb & ~kEven);
+  const uint32_t Ln = (ha & kEven) | ((hb << 1) & ~kEven);
+  const uint32_t Hn = ((ha >> 1) & kEven) | (hb & ~kEven);
+  uint32_t Z[NB], O[NB];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint32_t Li = i ? __builtin_amdgcn_alignbit(Ln, L, 2 * i) : L;
+    const uint32_t Hi = i ? __builtin_amdgcn_alignbit(Hn, H, 2 * i) : H;
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      const uint32_t E = (Li ^ a.lo[b][i]) & (Hi ^ a.hi[b][i]);
+      if (i == 0) {
+        Z[b] = E;
+      } else if (i == 1) {
+        O[b] = Z[b] | E;
+        Z[b] &= E;
+      } else {
+        O[b] = Z[b] | (O[b] & E);
+        if (i < 7) Z[b] &= E;
+      }
+    }
+  }
+  return NB > 1 ? (O[0] | O[NB - 1]) : O[0];
+}
+
+struct SharedRegion {
+  uint64_t* slots;
+  uint32_t cap;
+  uint32_t count;  // wave-uniform; keeps counting past cap so that the host can size a retry
+};
+
+// inclusive prefix sum over the wave (DPP row shifts + row broadcasts, see kernels.hip)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t x) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+  x += dpp_or_zero<0x111, 0xF>(x);
+  x += dpp_or_zero<0x112, 0xF>(x);
+  x += dpp_or_zero<0x114, 0xF>(x);
+  x += dpp_or_zero<0x118, 0xF>(x);
+  x += dpp_or_zero<0x142, 0xA>(x);
+  x += dpp_or_zero<0x143, 0xC>(x);
+  return x;
+}
+
+// Append the candidates of a pair in position order: all of chunk A (even bits), then all of chunk B.
+// `at` = byte offset of the lane's 16 bytes of chunk A; the slot holds the candidate START (w - bias).
+__device__ __forceinline__ void push_pair(SharedRegion& r, uint32_t hm, uint64_t at, uint64_t bias) {
+  const uint32_t hA = hm & 0x55555555u, hB = hm & 0xAAAAAAAAu;
+  const uint64_t mA = __ballot(hA != 0), mB = __ballot(hB != 0);
+  const uint64_t several = __ballot(((hA & (hA - 1)) | (hB & (hB - 1))) != 0);
+  if (several == 0) {
+    // the usual case: no lane holds two candidates of one chunk -- ranks straight from the lane masks
+    const uint32_t nA = __popcll(mA), nB = __popcll(mB);
+    if (hA != 0) {
+      const uint32_t idx = r.count + lanes_below(mA);
+      if (idx < r.cap) r.slots[idx] = at + (static_cast<uint32_t>(__builtin_ctz(hA)) >> 1) - bias;
+    }
+    if (hB != 0) {
+      const uint32_t idx = r.count + nA + lanes_below(mB);
+      if (idx < r.cap) r.slots[idx] = at + kChunk + (static_cast<uint32_t>(__builtin_ctz(hB)) >> 1) - bias;
+    }
+    r.count += nA + nB;
+    return;
+  }
+  const uint32_t cA = __popc(hA), cB = __popc(hB);
+  const uint32_t incA = wave_inclusive_sum(cA), incB = wave_inclusive_sum(cB);
+  const uint32_t totA = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incA), kWave - 1));
+  const uint32_t totB = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incB), kWave - 1));
+  uint32_t idx = r.count + incA - cA;
+  for (uint32_t m = hA; m; m &= m - 1, idx++)
+    if (idx < r.cap) r.slots[idx] = at + (static_cast<uint32_t>(__builtin_ctz(m)) >> 1) - bias;
+  idx = r.count + totA + incB - cB;
+  for (uint32_t m = hB; m; m &= m - 1, idx++)
+    if (idx < r.cap) r.slots[idx] = at + kChunk + (static_cast<uint32_t>(__builtin_ctz(m)) >> 1) - bias;
+  r.count += totA + totB;
+}
+
+// (No clipping here: window positions of a boundary pair that lie outside [wlo, whi) -- before the range, or
+// with window bytes beyond the end of the text, where the guarded loads read zeros -- may be reported;
+// classify_shared_multi drops them.  The test for it took more registers than the scan itself.)
+template <int NB>
+__device__ __forceinline__ void plane_pair(const uint32_t (&dA)[6], const uint32_t (&dB)[6], uint64_t at, const PlaneConsts& k,
+                                           const PlaneParams& a, SharedRegion& region) {
+  const uint32_t hm = plane_candidates<NB>(dA, dB, k, a);
+  if (__ballot(hm != 0) == 0) return;  // wave-uniform
+  push_pair(region, hm, at, a.offset);
+}
+
+}  // namespace
+
+template <int NB>
+__global__ __launch_bounds__(256) void plane_scan(PlaneParams a) {
+  const int lane = lane_id();
+  const uint64_t wave = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6));
+  if (wave == 0 && lane < kCntSize)
+    for (uint32_t p = 0; p < a.n_zero; p++) a.zero_counters[p][lane] = 0;
+  PlaneConsts k;
+  k.shift = a.code_shift;
+  k.cmask = 0x03030303u << a.code_shift;
+  SharedRegion region{a.hits + wave * a.region_cap, a.region_cap, 0u};
+  // window positions: w = s + offset, sb <= s < se, and the 8 window bytes must lie inside the text
+  const uint64_t wlo = a.sb + a.offset;
+  const uint64_t last_w = a.n >= 8 ? a.n - 8 + 1 : 0;
+  uint64_t whi = a.se + a.offset;
+  if (whi > last_w) whi = last_w;
+  const uint64_t first_pair = wlo / kPair;
+  const uint64_t end_pair = whi > wlo ? (whi + kPair - 1) / kPair : first_pair;
+  uint64_t c0 = first_pair + wave * a.span_pairs, c1 = c0 + a.span_pairs;
+  if (c0 > end_pair) c0 = end_pair;
+  if (c1 > end_pair) c1 = end_pair;
+  // pairs below fast_end can be loaded without guards (2 KiB + 8 B of halo stay < n)
+  uint64_t fast_end = a.n >= kPair + 8 ? (a.n - 8) / kPair : 0;
+  if (fast_end > c1) fast_end = c1;
+  if (fast_end < c0) fast_end = c0;
+  const uint64_t lane_off = static_cast<uint64_t>(lane) * 16;
+  {
+    // two pairs deep: while a pair is evaluated the loads of the next two are in flight (unconditional
+    // prologue, so that the compiler can count the loads -- see scan_windows_body in kernels.hip)
+    uint32_t a0[6], b0[6], a1[6], b1[6];
+    uint64_t c = c0;
+    if (c + 3 < fast_end) {
+      load_chunk24(a.text, c * kPair + lane_off, a0);
+      load_chunk24(a.text, c * kPair + kChunk + lane_off, b0);
+      load_chunk24(a.text, (c + 1) * kPair + lane_off, a1);
+      load_chunk24(a.text, (c + 1) * kPair + kChunk + lane_off, b1);
+      while (c + 3 < fast_end) {
+        plane_pair<NB>(a0, b0, c * kPair + lane_off, k, a, region);
+        load_chunk24(a.text, (c + 2) * kPair + lane_off, a0);
+        load_chunk24(a.text, (c + 2) * kPair + kChunk + lane_off, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        plane_pair<NB>(a1, b1, (c + 1) * kPair + lane_off, k, a, region);
+        load_chunk24(a.text, (c + 3) * kPair + lane_off, a1);
+        load_chunk24(a.text, (c + 3) * kPair + kChunk + lane_off, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        c += 2;
+      }
+      plane_pair<NB>(a0, b0, c * kPair + lane_off, k, a, region);
+      plane_pair<NB>(a1, b1, (c + 1) * kPair + lane_off, k, a, region);
+      c += 2;
+    }
+    for (; c < fast_end; c++) {
+      load_chunk24(a.text, c * kPair + lane_off, a0);
+      load_chunk24(a.text, c * kPair + kChunk + lane_off, b0);
+      plane_pair<NB>(a0, b0, c * kPair + lane_off, k, a, region);
+    }
+  }
+  // tail: the pair(s) that touch the end of the text use guarded byte loads
+  for (uint64_t t = fast_end; t < c1; t++) {
+    uint32_t dA[6], dB[6];
+    load_guarded24(a.text, a.n, t * kPair + lane_off, dA);
+    load_guarded24(a.text, a.n, t * kPair + kChunk + lane_off, dB);
+    plane_pair<NB>(dA, dB, t * kPair + lane_off, k, a, region);
+  }
+  if (lane == 0) a.hit_counts[wave] = region.count;
+}
+
+void launch_plane_scan(const PlaneParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+  if (a.n_bases <= 1) hipExtLaunchKernelGGL((plane_scan<1>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+  else hipExtLaunchKernelGGL((plane_scan<2>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+}
+
+// ---------------------------------------------------------------------------------------
+// Classification of the shared candidates: a wave per region, 64 candidates per round.  The patterns are
+// taken one after the other (wave-uniform loop: their descriptors are read with scalar loads); the lanes
+// whose candidate passes the pattern's exact window test run its automaton, and the survivors go, in
+// position order, to the pattern's own region (begins in verify.hits, ends in region_ends) -- what
+// verify_in_regions_multi leaves behind for offsets_gather_check_multi.
+namespace {
+
+// longest match of pattern P from s; (lo, hi) = the 16 text bytes from s on
+template <int NQ>
+__device__ __forceinline__ bool longest_from(const DevProgram& P, const uint8_t* text, uint64_t n, uint64_t s, uint64_t lo, uint64_t hi,
+                                             uint64_t* e, unsigned long long* counters) {
+  if (NQ == 1 && P.short_max != 0) return rj_lane_longest_short_at(P, lo, hi, n, s, e);
+  bool overrun = false;
+  const bool found = rj_lane_longest<NQ>(P, text, n, s, e, &overrun, counters + kCntOverrun);
+  if (overrun) counters[kCntOverrun] = 1;
+  return found;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void classify_shared_multi(const MultiTail* __restrict__ tails, SharedHits sh) {
+  const int lane = lane_id();
+  const uint64_t wave = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6));
+  const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+  const VerifyParams& a0 = tails[0].verify;
+  const uint8_t* text = a0.text;
+  const uint64_t n = a0.n, sb = a0.sb, se = a0.se;
+  for (uint64_t r = wave; r < sh.n_regions; r += n_waves) {
+    const uint32_t raw = sh.counts[r];
+    const uint32_t cnt = raw < sh.cap ? raw : sh.cap;
+    if (raw > sh.cap && lane == 0) atomicMax(&a0.counters[kCntSharedMax], static_cast<unsigned long long>(raw));
+    uint32_t kept = 0;  // lane p: survivors of pattern p in this region
+    const uint64_t* region = sh.hits + r * sh.cap;
+    for (uint32_t base = 0; base < cnt; base += kWave) {
+      const uint32_t k = base + lane;
+      const bool have = k < cnt;
+      const uint64_t s = have ? region[k] : 0;
+      const uint64_t w = s + sh.win_offset;
+      // the candidate's 8 window bytes; the scan does not clip (starts outside [sb, se), windows that reach
+      // past the end of the text): dropped here
+      const bool in_range = have && s >= sb && s < se && w + 8 <= n;
+      uint32_t lo = 0, hi = 0;
+      uint64_t t_lo = 0, t_hi = 0;  // the text from s on, loaded once for all patterns
+      if (in_range) {
+        __builtin_memcpy(&lo, text + w, 4);
+        __builtin_memcpy(&hi, text + w + 4, 4);
+        rj_load16(text, n, s, &t_lo, &t_hi);
+      }
+      for (uint32_t p = 0; p < sh.n_patterns; p++) {
+        const MultiTail& t = tails[p];
+        const DevProgram& P = t.program;
+        bool win = false;
+        for (int q = 0; q < P.n_windows; q++)
+          win = win || ((((lo ^ P.win_value0[q]) & P.win_mask0[q]) | ((hi ^ P.win_value1[q]) & P.win_mask1[q])) == 0);
+        const bool active = in_range && win;
+        if (__ballot(active) == 0) continue;
+        uint64_t e = 0;
+        bool found = false;
+        if (active) found = P.n_words <= 2 ? longest_from<1>(P, text, n, s, t_lo, t_hi, &e, t.verify.counters)
+                                           : longest_from<2>(P, text, n, s, t_lo, t_hi, &e, t.verify.counters);
+        const uint64_t mine = __ballot(found);
+        const uint32_t before = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(kept), static_cast<int>(p)));
+        const uint32_t pos = before + lanes_below(mine);
+        const uint32_t cap_p = t.verify.region_cap;
+        if (found && pos < cap_p) {
+          t.verify.hits[r * cap_p + pos] = s;
+          t.region_ends[r * cap_p + pos] = e;
+        }
+        if (lane == static_cast<int>(p)) kept += static_cast<uint32_t>(__popcll(mine));
+      }
+    }
+    if (lane < static_cast<int>(sh.n_patterns)) {
+      const MultiTail& t = tails[lane];
+      const uint32_t c = kept, cap_p = t.verify.region_cap;
+      if (c > cap_p) {  // the host grows this pattern's regions and runs again
+        t.verify.counters[kCntOverflow] = 1;
+        atomicMax(&t.verify.counters[kCntMaxRegion], static_cast<unsigned long long>(c));
+      }
+      t.valid_counts[r] = c < cap_p ? c : cap_p;
+    }
+  }
+}
+
+void launch_tails_shared(const MultiTail* d_tails, const SharedHits& sh, hipStream_t st) {
+  uint64_t blocks = (static_cast<uint64_t>(sh.n_regions) + 3) / 4;  // a wave per region
+  blocks = blocks < 1 ? 1 : blocks > 8192 ? 8192 : blocks;
+  hipLaunchKernelGGL(classify_shared_multi, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, d_tails, sh);
+  launch_offsets_gather_check_multi(d_tails, static_cast<int>(sh.n_patterns), sh.n_regions, st);
+}
+
+}  // namespace rejit_amd
