@@ -207,9 +207,26 @@ struct MultiTail {
 };
 void launch_tails_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_regions, hipStream_t st);
 // the same tails fed from ONE shared candidate list (plane scan): classify_shared_multi verifies every candidate
-// against every pattern (window test first, automaton for the patterns whose window matches) and compacts the
-// survivors into the patterns' own regions; then offsets_gather_check_multi as above.  A shared region that
+// against every pattern (exact window test first, automaton for the patterns whose window matches) and compacts
+// the survivors into the patterns' own regions; then offsets_gather_check_multi as above.  A shared region that
 // overflowed is reported in pattern 0's counters[kCntSharedMax].
+// Every pattern must be short (DevProgram::short_max != 0, n_words <= 2).  What the kernel needs of the patterns
+// travels as ONE blob that every workgroup copies into LDS: ClassifyDesc[n_patterns] (padded to 16 bytes), then
+// the patterns' automaton tables one after the other (each padded to 4 words), <= kClassifyMaxTableWords in all.
+constexpr uint32_t kClassifyMaxTableWords = 12288;
+struct ClassifyDesc {
+  uint32_t n_windows;
+  uint32_t v0[2], m0[2], v1[2], m1[2];
+  uint32_t tab;         // the pattern's tables, word offset behind the descriptors
+  uint32_t n_words, n_pos, n_rows, short_max, nullable;
+  uint32_t rowbits[2];  // non-linear positions whose follow set is not empty
+  uint32_t region_cap;
+  uint32_t pad[2];      // (the pointers below start on an 8-byte boundary without implicit padding)
+  uint64_t* begins;     // the pattern's own regions
+  uint64_t* ends;
+  uint32_t* valid_counts;
+  unsigned long long* counters;
+};
 struct SharedHits {
   const uint64_t* hits;
   const uint32_t* counts;
@@ -217,8 +234,13 @@ struct SharedHits {
   uint32_t n_regions;
   uint32_t n_patterns;
   uint32_t win_offset;
+  const uint8_t* text;
+  uint64_t n, sb, se;
+  const uint32_t* blob;   // descriptors + tables (device memory)
+  uint32_t desc_words;    // words the descriptors take (a multiple of 4)
+  uint32_t blob_words;    // descriptors + tables (a multiple of 4)
 };
-void launch_tails_shared(const MultiTail* d_tails, const SharedHits& sh, hipStream_t st);
+void launch_tails_shared(const MultiTail* d_tails, const SharedHits& sh, unsigned long long* counters0, hipStream_t st);
 void launch_offsets_gather_check_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_regions, hipStream_t st);
 
 // windows mode, lane-sized automaton: verify + compact inside every region (16 lanes each), then

@@ -71,9 +71,14 @@ PlanePlan plan_plane(const std::vector<rj_scan*>& scans) {
     bool fixed[8];
   };
   std::vector<Win> wins;
+  uint32_t table_words = 0;
   for (size_t p = 0; p < scans.size(); p++) {
     const DevProgram& D = scans[p]->prog->dev;
     if (D.win_len != 8 || D.n_windows < 1 || D.n_windows > 2) return pl;
+    // classify_shared_multi keeps every pattern's tables in LDS: short bounded patterns only
+    if (D.short_max == 0 || D.n_words > 2) return pl;
+    table_words += (D.table_words + 3u) & ~3u;
+    if (table_words > kClassifyMaxTableWords) return pl;
     if (p == 0) pl.offset = D.win_offset;
     else if (D.win_offset != pl.offset) return pl;
     for (int k = 0; k < D.n_windows; k++) {
@@ -140,6 +145,12 @@ struct rj_multi {
   PlanePlan plane;             // mode 0: the one-pass bit-plane scan with a shared candidate list
   DeviceBuffer shared_hits, shared_counts;
   uint32_t shared_cap_hint = 128;
+  // what classify_shared_multi copies into LDS: ClassifyDesc[P] + the patterns' tables (kernels.h)
+  DeviceBuffer classify_blob;
+  ClassifyDesc* host_desc = nullptr;   // pinned
+  std::vector<ClassifyDesc> desc_uploaded;
+  uint32_t desc_words = 0, blob_words = 0;
+  bool classify_tables_ready = false;
   DeviceBuffer dummy_counts;  // hit_counts of the padding patterns
   DeviceBuffer tails;         // MultiTail[P]
   MultiTail* host_tails = nullptr;  // pinned
@@ -154,6 +165,68 @@ struct rj_multi {
 };
 
 namespace {
+
+// The blob classify_shared_multi stages in LDS (kernels.h): the tables are copied once, device to device; the
+// descriptors hold this run's output pointers and are uploaded when they changed (host_tails is filled already).
+int classify_blob(rj_multi* m, hipStream_t st) {
+  const int P = static_cast<int>(m->scans.size());
+  if (!m->host_desc) RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&m->host_desc), sizeof(ClassifyDesc) * kMaxFused));
+  m->desc_words = static_cast<uint32_t>((sizeof(ClassifyDesc) * static_cast<size_t>(P) + 15) / 16 * 4);
+  uint32_t off = 0;
+  for (int p = 0; p < P; p++) {
+    const MultiTail& t = m->host_tails[p];
+    const DevProgram& D = t.program;
+    ClassifyDesc& d = m->host_desc[p];
+    d = ClassifyDesc{};
+    d.n_windows = static_cast<uint32_t>(std::min(D.n_windows, 2));
+    for (int q = 0; q < 2; q++) {
+      d.v0[q] = D.win_value0[q];
+      d.m0[q] = D.win_mask0[q];
+      d.v1[q] = D.win_value1[q];
+      d.m1[q] = D.win_mask1[q];
+    }
+    d.tab = off;
+    d.n_words = static_cast<uint32_t>(D.n_words);
+    d.n_pos = static_cast<uint32_t>(D.n_pos);
+    d.n_rows = static_cast<uint32_t>(D.n_rows);
+    d.short_max = D.short_max;
+    d.nullable = D.nullable;
+    {
+      const Program& H = *m->scans[static_cast<size_t>(p)]->prog->host;
+      for (int pos = 0; pos < H.n_pos && pos < 64; pos++) {
+        const int row = H.row_of[static_cast<size_t>(pos)];
+        if (row < 0) continue;
+        bool any = false;
+        for (int k = 0; k < H.n_words; k++) any = any || H.rows[0][static_cast<size_t>(row) * H.n_words + k] != 0;
+        if (any) d.rowbits[pos >> 5] |= 1u << (pos & 31);
+      }
+    }
+    d.region_cap = t.verify.region_cap;
+    d.begins = t.verify.hits;
+    d.ends = t.region_ends;
+    d.valid_counts = t.valid_counts;
+    d.counters = t.verify.counters;
+    off += (D.table_words + 3u) & ~3u;
+  }
+  m->blob_words = m->desc_words + off;
+  if (!m->classify_tables_ready) {
+    RJ_HIP(m->classify_blob.reserve(static_cast<size_t>(m->blob_words) * sizeof(uint32_t)));
+    RJ_HIP(hipMemsetAsync(m->classify_blob.p, 0, static_cast<size_t>(m->blob_words) * sizeof(uint32_t), st));
+    for (int p = 0; p < P; p++) {
+      const DevProgram& D = m->host_tails[p].program;
+      RJ_HIP(hipMemcpyAsync(m->classify_blob.as<uint32_t>() + m->desc_words + m->host_desc[p].tab, D.first,
+                            static_cast<size_t>(D.table_words) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    }
+    m->classify_tables_ready = true;
+    m->desc_uploaded.clear();
+  }
+  if (m->desc_uploaded.size() != static_cast<size_t>(P) ||
+      memcmp(m->desc_uploaded.data(), m->host_desc, sizeof(ClassifyDesc) * static_cast<size_t>(P)) != 0) {
+    RJ_HIP(hipMemcpyAsync(m->classify_blob.p, m->host_desc, sizeof(ClassifyDesc) * static_cast<size_t>(P), hipMemcpyHostToDevice, st));
+    m->desc_uploaded.assign(m->host_desc, m->host_desc + P);
+  }
+  return RJ_OK;
+}
 
 // The scans of all patterns (ONE fused kernel, or one kernel per pattern back to back) + the tails of
 // all patterns in two launches + one synchronise.  Whole text, starts [0, n].
@@ -398,7 +471,16 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       sh.n_regions = geo.n_regions;
       sh.n_patterns = static_cast<uint32_t>(P);
       sh.win_offset = m->plane.offset;
-      launch_tails_shared(m->tails.as<MultiTail>(), sh, st);
+      sh.text = d_text;
+      sh.n = n;
+      sh.sb = sb;
+      sh.se = se;
+      int rc = classify_blob(m, st);
+      if (rc != RJ_OK) return rc;
+      sh.blob = m->classify_blob.as<uint32_t>();
+      sh.desc_words = m->desc_words;
+      sh.blob_words = m->blob_words;
+      launch_tails_shared(m->tails.as<MultiTail>(), sh, s0->counters.as<unsigned long long>(), st);
     } else {
       launch_tails_multi(m->tails.as<MultiTail>(), P, geo.n_regions, st);
     }
@@ -509,6 +591,7 @@ void rj_multi_destroy(rj_multi* m) {
   for (rj_scan* s : m->scans) rj_scan_destroy(s);
   if (m->host_tails) (void)hipHostFree(m->host_tails);
   if (m->host_bounds) (void)hipHostFree(m->host_bounds);
+  if (m->host_desc) (void)hipHostFree(m->host_desc);
   if (m->second) (void)hipStreamDestroy(m->second);
   if (m->fork) (void)hipEventDestroy(m->fork);
   if (m->join) (void)hipEventDestroy(m->join);

@@ -36,6 +36,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <type_traits>
+
 #include "device_program.h"
 #include "kernels.h"
 
@@ -262,42 +264,106 @@ void launch_plane_scan(const PlaneParams& a, int grid, hipEvent_t t0, hipEvent_t
 }
 
 // ---------------------------------------------------------------------------------------
-// Classification of the shared candidates: a wave per region, 64 candidates per round.  The patterns are
-// taken one after the other (wave-uniform loop: their descriptors are read with scalar loads); the lanes
-// whose candidate passes the pattern's exact window test run its automaton, and the survivors go, in
-// position order, to the pattern's own region (begins in verify.hits, ends in region_ends) -- what
-// verify_in_regions_multi leaves behind for offsets_gather_check_multi.
+// Classification of the shared candidates: HALF a wave per region (a region holds ~25 candidates on DNA), 32
+// candidates per round and region.  The patterns are taken one after the other (wave-uniform loop); the lanes
+// whose candidate passes the pattern's exact window test run its automaton, and the survivors go, in position
+// order, to the pattern's own region (begins / ends) -- what verify_in_regions_multi leaves behind for
+// offsets_gather_check_multi.
+//
+// Everything a candidate needs except its own text lives in LDS: every workgroup copies, once, ONE contiguous
+// blob (kernels.h: ClassifyDesc per pattern -- window constants, output pointers -- and the automaton tables of
+// all patterns: short bounded patterns only, DevProgram::short_max, 1.4 KB each for regexdna) and then takes
+// regions grid-stride.  A pattern's test is register arithmetic and LDS lookups; a region costs three dependent
+// trips to device memory (count, candidates, their text) whatever the number of patterns.  History: reading
+// descriptors and tables from device memory pattern after pattern: 82 us; tables staged table by table through
+// their pointers (nine dependent copies per workgroup, a workgroup per four regions): 87 us -- the scan itself
+// takes 97.
 namespace {
 
-// longest match of pattern P from s; (lo, hi) = the 16 text bytes from s on
-template <int NQ>
-__device__ __forceinline__ bool longest_from(const DevProgram& P, const uint8_t* text, uint64_t n, uint64_t s, uint64_t lo, uint64_t hi,
-                                             uint64_t* e, unsigned long long* counters) {
-  if (NQ == 1 && P.short_max != 0) return rj_lane_longest_short_at(P, lo, hi, n, s, e);
-  bool overrun = false;
-  const bool found = rj_lane_longest<NQ>(P, text, n, s, e, &overrun, counters + kCntOverrun);
-  if (overrun) counters[kCntOverrun] = 1;
+// Longest match from a start whose 16 text bytes are (lo, hi), `avail` of them inside the text; tables in LDS at
+// t0:  first [W] last [W] linear [W] row_of [n_pos] rows [n_rows][W] cls [256][W]  (table_layout.h, one context).
+// Same result as rj_lane_longest_short_at (device_program.h), written without divergent exits: the class rows of
+// all bytes are fetched together (a row beyond the bytes a match may consume is zero, which kills the state),
+// every step is straight-line code, and the walk through the rows of non-linear positions -- only those with a
+// non-empty follow set count, ClassifyDesc::rowbits: none in an alternation of literals and classes -- sits
+// behind a wave-uniform test.
+template <int W, int MAXK>
+__device__ __forceinline__ bool short_longest_lds(const uint32_t* t0, const ClassifyDesc& d, uint64_t lo, uint64_t hi, uint32_t avail,
+                                                  uint32_t* length) {
+  using State = typename std::conditional<W == 1, uint32_t, uint64_t>::type;
+  const uint32_t NP = d.n_pos;
+  const uint32_t steps = d.short_max < avail ? d.short_max : avail;  // bytes a match can consume here
+  const uint32_t* cls = t0 + 3 * W + NP + d.n_rows * W;
+  auto word = [&](const uint32_t* q) -> State {
+    State v = q[0];
+    if (W > 1) v |= static_cast<State>(static_cast<uint64_t>(q[W - 1]) << 32);
+    return v;
+  };
+  State row[MAXK];
+#pragma unroll
+  for (int k = 0; k < MAXK; k++) {
+    const uint32_t c = static_cast<uint32_t>(((k < 8 ? lo : hi) >> (8 * (k & 7))) & 0xFFu);
+    const State v = word(cls + c * W);
+    row[k] = static_cast<uint32_t>(k) < steps ? v : State{0};
+  }
+  const State first = word(t0), last = word(t0 + W), lin = word(t0 + 2 * W);
+  State rowbits = d.rowbits[0];
+  if (W > 1) rowbits |= static_cast<State>(static_cast<uint64_t>(d.rowbits[W - 1]) << 32);
+  const int32_t* row_of = reinterpret_cast<const int32_t*>(t0 + 3 * W);
+  const uint32_t* rows = t0 + 3 * W + NP;
+  bool found = (d.nullable & 1u) != 0;
+  uint32_t len = 0;
+  State S = first & row[0];
+#pragma unroll
+  for (int k = 1; k <= MAXK; k++) {
+    const bool acc = (S & last) != 0;  // S = the positions that consumed byte k - 1
+    len = acc ? static_cast<uint32_t>(k) : len;
+    found = found || acc;
+    if (k < MAXK) {
+      State T = (S & lin) << 1;
+      State sp = S & rowbits;
+      if (__ballot(sp != 0) != 0) {
+        for (; sp; sp &= sp - 1) {
+          const int bit = W == 1 ? __builtin_ctz(static_cast<uint32_t>(sp)) : __builtin_ctzll(static_cast<uint64_t>(sp));
+          T |= word(rows + static_cast<uint32_t>(row_of[bit]) * W);
+        }
+      }
+      S = T & row[k < MAXK ? k : 0];
+    }
+  }
+  *length = len;
   return found;
 }
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void classify_shared_multi(const MultiTail* __restrict__ tails, SharedHits sh) {
+__global__ __launch_bounds__(256, 4) void classify_shared_multi(SharedHits sh, unsigned long long* counters0) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(sh.blob);
+    uint4* dst = reinterpret_cast<uint4*>(lds);
+    for (uint32_t i = threadIdx.x; i < sh.blob_words / 4; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const ClassifyDesc* desc = reinterpret_cast<const ClassifyDesc*>(lds);
+  const uint32_t* tab = lds + sh.desc_words;
   const int lane = lane_id();
+  const int half = lane >> 5, sub = lane & 31;
   const uint64_t wave = __builtin_amdgcn_readfirstlane(
       static_cast<uint32_t>((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6));
   const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
-  const VerifyParams& a0 = tails[0].verify;
-  const uint8_t* text = a0.text;
-  const uint64_t n = a0.n, sb = a0.sb, se = a0.se;
-  for (uint64_t r = wave; r < sh.n_regions; r += n_waves) {
-    const uint32_t raw = sh.counts[r];
+  const uint8_t* text = sh.text;
+  const uint64_t n = sh.n, sb = sh.sb, se = sh.se;
+  for (uint64_t r0 = wave * 2; r0 < sh.n_regions; r0 += n_waves * 2) {
+    const uint64_t r = r0 + half;
+    const bool live = r < sh.n_regions;
+    const uint32_t raw = live ? sh.counts[r] : 0u;
     const uint32_t cnt = raw < sh.cap ? raw : sh.cap;
-    if (raw > sh.cap && lane == 0) atomicMax(&a0.counters[kCntSharedMax], static_cast<unsigned long long>(raw));
-    uint32_t kept = 0;  // lane p: survivors of pattern p in this region
+    if (raw > sh.cap && sub == 0) atomicMax(&counters0[kCntSharedMax], static_cast<unsigned long long>(raw));
+    uint32_t kept = 0;  // lane 32 * half + p: survivors of pattern p in the half's region
     const uint64_t* region = sh.hits + r * sh.cap;
-    for (uint32_t base = 0; base < cnt; base += kWave) {
-      const uint32_t k = base + lane;
+    for (uint32_t base = 0; __ballot(base < cnt) != 0; base += 32) {
+      const uint32_t k = base + sub;
       const bool have = k < cnt;
       const uint64_t s = have ? region[k] : 0;
       const uint64_t w = s + sh.win_offset;
@@ -311,45 +377,53 @@ __global__ __launch_bounds__(256) void classify_shared_multi(const MultiTail* __
         __builtin_memcpy(&hi, text + w + 4, 4);
         rj_load16(text, n, s, &t_lo, &t_hi);
       }
+      const uint32_t avail = n - s < 16 ? static_cast<uint32_t>(n - s) : 16u;
       for (uint32_t p = 0; p < sh.n_patterns; p++) {
-        const MultiTail& t = tails[p];
-        const DevProgram& P = t.program;
-        bool win = false;
-        for (int q = 0; q < P.n_windows; q++)
-          win = win || ((((lo ^ P.win_value0[q]) & P.win_mask0[q]) | ((hi ^ P.win_value1[q]) & P.win_mask1[q])) == 0);
+        const ClassifyDesc& d = desc[p];
+        bool win = (((lo ^ d.v0[0]) & d.m0[0]) | ((hi ^ d.v1[0]) & d.m1[0])) == 0;
+        if (d.n_windows > 1) win = win || ((((lo ^ d.v0[1]) & d.m0[1]) | ((hi ^ d.v1[1]) & d.m1[1])) == 0);
         const bool active = in_range && win;
         if (__ballot(active) == 0) continue;
-        uint64_t e = 0;
+        uint32_t len = 0;
         bool found = false;
-        if (active) found = P.n_words <= 2 ? longest_from<1>(P, text, n, s, t_lo, t_hi, &e, t.verify.counters)
-                                           : longest_from<2>(P, text, n, s, t_lo, t_hi, &e, t.verify.counters);
-        const uint64_t mine = __ballot(found);
-        const uint32_t before = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(kept), static_cast<int>(p)));
-        const uint32_t pos = before + lanes_below(mine);
-        const uint32_t cap_p = t.verify.region_cap;
-        if (found && pos < cap_p) {
-          t.verify.hits[r * cap_p + pos] = s;
-          t.region_ends[r * cap_p + pos] = e;
+        {
+          const uint32_t* t0 = tab + d.tab;
+          if (d.n_words <= 1) found = d.short_max <= 8 ? short_longest_lds<1, 8>(t0, d, t_lo, t_hi, avail, &len) : short_longest_lds<1, 16>(t0, d, t_lo, t_hi, avail, &len);
+          else found = short_longest_lds<2, 16>(t0, d, t_lo, t_hi, avail, &len);
         }
-        if (lane == static_cast<int>(p)) kept += static_cast<uint32_t>(__popcll(mine));
+        found = found && active;
+        const uint64_t e = s + len;
+        const uint64_t mine = __ballot(found);
+        const uint32_t mine_half = static_cast<uint32_t>(mine >> (32 * half));
+        const uint32_t b0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(kept), static_cast<int>(p)));
+        const uint32_t b1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(kept), static_cast<int>(32 + p)));
+        const uint32_t pos = (half ? b1 : b0) + __popc(mine_half & ((1u << sub) - 1u));
+        const uint32_t cap_p = d.region_cap;
+        if (found && pos < cap_p) {
+          d.begins[r * cap_p + pos] = s;
+          d.ends[r * cap_p + pos] = e;
+        }
+        if (sub == static_cast<int>(p)) kept += __popc(mine_half);
       }
     }
-    if (lane < static_cast<int>(sh.n_patterns)) {
-      const MultiTail& t = tails[lane];
-      const uint32_t c = kept, cap_p = t.verify.region_cap;
+    if (live && sub < static_cast<int>(sh.n_patterns)) {
+      const ClassifyDesc& d = desc[sub];
+      const uint32_t c = kept, cap_p = d.region_cap;
       if (c > cap_p) {  // the host grows this pattern's regions and runs again
-        t.verify.counters[kCntOverflow] = 1;
-        atomicMax(&t.verify.counters[kCntMaxRegion], static_cast<unsigned long long>(c));
+        d.counters[kCntOverflow] = 1;
+        atomicMax(&d.counters[kCntMaxRegion], static_cast<unsigned long long>(c));
       }
-      t.valid_counts[r] = c < cap_p ? c : cap_p;
+      d.valid_counts[r] = c < cap_p ? c : cap_p;
     }
   }
 }
 
-void launch_tails_shared(const MultiTail* d_tails, const SharedHits& sh, hipStream_t st) {
-  uint64_t blocks = (static_cast<uint64_t>(sh.n_regions) + 3) / 4;  // a wave per region
-  blocks = blocks < 1 ? 1 : blocks > 8192 ? 8192 : blocks;
-  hipLaunchKernelGGL(classify_shared_multi, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, d_tails, sh);
+void launch_tails_shared(const MultiTail* d_tails, const SharedHits& sh, unsigned long long* counters0, hipStream_t st) {
+  // half a wave per region; at most one resident round of workgroups (each copies the blob into LDS first)
+  uint64_t blocks = (static_cast<uint64_t>(sh.n_regions) + 7) / 8;
+  blocks = blocks < 1 ? 1 : blocks > 1024 ? 1024 : blocks;
+  hipLaunchKernelGGL(classify_shared_multi, dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(sh.blob_words) * sizeof(uint32_t), st,
+                     sh, counters0);
   launch_offsets_gather_check_multi(d_tails, static_cast<int>(sh.n_patterns), sh.n_regions, st);
 }
 
