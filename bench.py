@@ -250,15 +250,16 @@ def run_regexdna(args, c):
     def run_one(i, st=None):
         return scans[i].run(text_ptr, n_local, own_begin=own_lo, own_end=own_hi, stream=stream if st is None else st)
 
-    # Headline: the nine patterns of a step go through rj_multi_run in its "separate scans" mode -- nine
-    # scan kernels queued back to back (each the ordinary single-pattern kernel at its full streaming
-    # rate, timed by its own dispatch timestamps: the roofline below), then the verify / gather tails of
-    # all nine patterns in two launches and ONE host synchronise, instead of nine round trips.
+    # Headline: the nine patterns of a step go through ONE rj_multi_run in its one-pass mode (mode 0): the
+    # bit-plane scan (plane_scan.hip) reads the text ONCE for all nine patterns and leaves one shared candidate
+    # list; classify_shared_multi + offsets_gather_check_multi are the tails of all nine patterns; ONE host
+    # synchronise.  It is the fastest way to get the nine counts; its roofline is n / t of the scan kernel
+    # (never 9 n / t) against the HBM peak, with the VALU roofline beside it.
     use_multi = not args.serial_calls
     multi_sep = sep_scans = None
     if use_multi:
         multi_sep = rejit_amd.MultiScan(progs)
-        multi_sep.set_mode(1)
+        multi_sep.set_mode(0)
         sep_scans = [multi_sep.scan(i) for i in range(len(progs))]
 
     def local_counts():
@@ -312,35 +313,71 @@ def run_regexdna(args, c):
                      "fasta_n_per_gpu": args.fasta_n, "text_bytes_per_gpu": int(own_bytes), "patterns": len(patterns),
                      "sharding": "contiguous byte ranges + %d-byte halo; all_gather of (count, first, last match) per pattern per step"
                                  % (max_len - 1),
-                     "calls": "rj_multi_run mode 1: the nine scans as one launch (scan_windows_train) + batched tails" if use_multi else "9 x rj_scan_run per step"})
+                     "calls": "rj_multi_run mode 0: one pass over the text for the nine patterns (plane_scan) + classify + gather, one synchronise" if use_multi else "9 x rj_scan_run per step"})
     out["matches_per_s"] = round(total_matches * args.steps / elapsed, 1)
     out["matches_per_pass"] = counts
     if use_multi:
-        # the dominant kernel: scan_windows_train = the nine patterns' streaming scans in one launch, each over the
-        # whole text: algorithmic bytes per launch = 9 x text bytes (1 byte read per text byte per MatchAll call)
-        out["roofline"] = hbm_roofline("scan_windows_train<NIB> (9 pattern scans per launch)", len(patterns) * own_bytes, avg_scan_ms,
-                                       pmc_traffic("regexdna", fasta_n=args.fasta_n) if world == 1 else None, len(scan_ms))
-        out["roofline"]["note"] = ("a wave scans its own 32 KB span for pattern after pattern, so passes 2..9 are served by the 256 MiB "
-                                   "Infinity Cache (rocprofv3's FETCH_SIZE counts those hits too): `achieved` is the rate of ALGORITHMIC "
-                                   "bytes, above what HBM alone delivers (6.29 TB/s measured copy ceiling).  The streaming scan's HBM-bound "
-                                   "figures: `separate_launches` (one pattern per kernel), `hbm_not_cache` (the same on a 2.5 GB text) and the "
-                                   "literal scans over 5 and 50 GB")
+        # the dominant kernel: plane_scan reads every text byte ONCE for all nine patterns: algorithmic bytes per
+        # launch = text bytes (for a fused pass quote n / t_fused, never 9 n / t_fused, against HBM)
+        one_pass = multi_sep.how == 1
+        out["roofline"] = hbm_roofline("plane_scan<2> (one pass, nine patterns)" if one_pass else "scan kernels of rj_multi_run", own_bytes, avg_scan_ms,
+                                       pmc_traffic("plane", fasta_n=args.fasta_n) if world == 1 else None, len(scan_ms))
+        out["roofline"]["note"] = ("n / t of the one launch that scans the text for all nine patterns; `value` counts the text once per pattern "
+                                   "(9 x n per step, the reference's convention: nine MatchAllCount calls)")
+        ops_per_byte = rejit_amd.PLANE_VALU_OPS_PER_BYTE
+        valu = own_bytes * ops_per_byte / (avg_scan_ms * 1e-3) / 1e12 if avg_scan_ms > 0 else 0.0
+        out["roofline_valu"] = {"bound": "valu", "kernel": "plane_scan<2>", "ops_per_text_byte": ops_per_byte,
+                                "achieved": round(valu, 2), "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",
+                                "frac": round(valu / VALU_PEAK_TOPS, 4),
+                                "note": "SQ_INSTS_VALU x 64 / text bytes from profiles/r03_pmc_sq_counters.txt"}
     else:
         out["roofline"] = hbm_roofline("scan_windows<2,NIB>", own_bytes, avg_scan_ms, None, len(scan_ms))
     extras = rank == 0 and world == 1 and not args.no_extra
 
-    def time_steps(fn, warm=2, steps=None):
-        steps = steps or args.steps
+    call_times = {}
+
+    def time_steps(fn, warm=2, steps=None, key=None):
+        steps = steps or max(args.steps, 10)
         for _ in range(warm):
             r = fn()
         torch.cuda.synchronize(dev)
+        per = []
         t1 = time.perf_counter()
         for _ in range(steps):
+            t2 = time.perf_counter()
             r = fn()
+            per.append(time.perf_counter() - t2)
         torch.cuda.synchronize(dev)
-        return time.perf_counter() - t1, r
+        if key:
+            call_times[key] = {"calls_timed": steps, "median_ms": round(sorted(per)[len(per) // 2] * 1e3, 4), "min_ms": round(min(per) * 1e3, 4)}
+        return (time.perf_counter() - t1) * args.steps / steps, r
 
     if extras and use_multi:
+        ek0, ck0 = time_steps(lambda: multi_sep.run(text_ptr, n_local, stream=stream, own_begin=own_lo, own_end=own_hi), key="headline")
+        out["call_latency"] = call_times["headline"]
+        # The nine per-pattern scans as ONE launch (rj_multi mode 1, round 2's headline): a wave runs its own 32 KB
+        # span through pattern after pattern, so passes 2..9 are served by the 256 MiB Infinity Cache -- 9 n / t of
+        # that launch is a rate of algorithmic bytes, not an HBM rate, and is reported as such.
+        multi_t = rejit_amd.MultiScan(progs)
+        multi_t.set_mode(1)
+        tms = []
+
+        def train_step():
+            r = multi_t.run(text_ptr, n_local, stream=stream)
+            tms.append(multi_t.scan_ms())
+            return r
+
+        et, ct = time_steps(train_step, key="train")
+        assert ct == counts, "the train of scans disagrees with the one-pass run"
+        tms = tms[2:]
+        out["train"] = {"calls": "rj_multi_run mode 1: the nine per-pattern scans as one launch (scan_windows_train) + batched tails",
+                        "value": round(scanned / et / 1e9, 3), "unit": "GB/s", "ms_per_step": round(et / args.steps * 1e3, 4),
+                        "call": call_times["train"],
+                        "algorithmic_rate": {"kernel": "scan_windows_train<NIB>", "bytes_per_launch": int(len(patterns) * own_bytes),
+                                             "avg_launch_ms": round(sum(tms) / len(tms), 5),
+                                             "GB_per_s": round(len(patterns) * own_bytes / (sum(tms) / len(tms) * 1e-3) / 1e9, 1),
+                                             "note": "NOT an HBM roofline: passes 2..9 of a wave's span hit the Infinity Cache (one HBM pass + eight cached ones)"}}
+        del multi_t
         # One launch PER PATTERN (rj_multi mode 3, the headline of round 1): every kernel streams the whole text
         # from HBM with nothing of it left in a cache from the pattern before, so this is the per-kernel HBM
         # roofline of the streaming scan; the train above is faster because a wave's passes 2..9 over its own
@@ -391,35 +428,6 @@ def run_regexdna(args, c):
         out["overlapped"] = {"pattern_threads": 3, "value": round(scanned / e3 / 1e9, 3), "unit": "GB/s",
                              "ms_per_step": round(e3 / args.steps * 1e3, 4)}
 
-    if extras:
-        # the nine patterns in ONE pass over the text (rj_multi, fused scan kernel): the
-        # FASTEST way to get the nine counts.  Same results; the text is read once instead of nine
-        # times and the kernel is VALU-bound, so it carries two rooflines: its HBM one (n / t against
-        # the 8 TB/s peak -- never 9n / t) and its VALU one (ops per text byte x bytes / t against the
-        # chip's simple-VALU rate).
-        multi = rejit_amd.MultiScan(progs)
-        fms = []
-
-        def fused_step():
-            r = multi.run(text_ptr, n_local, stream=stream)
-            fms.append(multi.scan_ms())
-            return r
-
-        ef, cf = time_steps(fused_step)
-        assert cf == counts, "fused run disagrees with the nine single runs"
-        fms = fms[2:]
-        a_ms = sum(fms) / len(fms)
-        ops_per_byte = rejit_amd.FUSED_VALU_OPS_PER_BYTE
-        valu = own_bytes * ops_per_byte / (a_ms * 1e-3) / 1e12 if a_ms > 0 else 0.0
-        out["fused"] = {"api": "rj_multi_run (9 patterns, one pass over the text)", "fused": bool(multi.fused),
-                        "value": round(scanned / ef / 1e9, 3), "unit": "GB/s", "ms_per_step": round(ef / args.steps * 1e3, 4),
-                        "note": "fastest way to run the job; `value` counts 9 x 500 MB of text scanned per step",
-                        "roofline": hbm_roofline("scan_windows_fused", own_bytes, a_ms, pmc_traffic("fused", fasta_n=args.fasta_n), len(fms)),
-                        "roofline_valu": {"bound": "valu", "kernel": "scan_windows_fused", "ops_per_text_byte": ops_per_byte,
-                                          "achieved": round(valu, 2), "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",
-                                          "frac": round(valu / VALU_PEAK_TOPS, 4)}}
-        del multi
-
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample taken from the lower-case (matching) part of the text: the first 20 %
         # is the upper-case ALU repeat, which no pattern can match
@@ -457,10 +465,25 @@ def run_regexdna(args, c):
         eb, cb = time_steps(big_step, warm=1, steps=5)
         ms2 = ms2[len(progs):]
         out["hbm_not_cache"] = {"workload": "the same nine patterns, one kernel per pattern (mode 3), over a 2.5 GB stripped FASTA (fasta_n 250M)",
-                                "value": round(9 * nb * 5 / eb / 1e9, 3), "unit": "GB/s", "ms_per_step": round(eb / 5 * 1e3, 4),
+                                "value": round(9 * nb / (eb / args.steps) / 1e9, 3), "unit": "GB/s", "ms_per_step": round(eb / args.steps * 1e3, 4),
                                 "matches_per_pass": cb,
                                 "roofline": hbm_roofline("scan_windows<2,NIB>", nb, sum(ms2) / len(ms2), None, len(ms2))}
-        del big, m2
+        m0 = rejit_amd.MultiScan(progs)
+        ms0 = []
+
+        def big_plane_step():
+            r = m0.run(big.data_ptr(), nb, stream=stream)
+            ms0.append(m0.scan_ms())
+            return r
+
+        e0, c0 = time_steps(big_plane_step, warm=1, steps=5)
+        assert c0 == cb, "one-pass and per-pattern runs disagree on the 2.5 GB text"
+        ms0 = ms0[1:]
+        out["one_pass_2p5gb"] = {"workload": "the headline's one-pass run over the same 2.5 GB text",
+                                 "value": round(9 * nb / (e0 / args.steps) / 1e9, 3), "unit": "GB/s",
+                                 "ms_per_step": round(e0 / args.steps * 1e3, 4),
+                                 "roofline": hbm_roofline("plane_scan<2>", nb, sum(ms0) / len(ms0), None, len(ms0))}
+        del big, m2, m0
         torch.cuda.empty_cache()
     return out, extras
 

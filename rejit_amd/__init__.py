@@ -13,6 +13,10 @@ from .api import (RejitError, Program, Scan, MultiScan, build, library_path, loa
 # Of these 9.1 are the streaming loop (26 to pack a lane's 16 positions + 16 x (2 v_xad + 2 v_and + 2 v_bcnt
 # + 1.5 v_min), from the ISA); the rest are the exact per-pattern tests on the chunks that pass the prefilter.
 FUSED_VALU_OPS_PER_BYTE = 15.5
+# plane_scan<2> (the one-pass bit-plane scan, round 3) on the same text: SQ_INSTS_VALU 43.44 M wave-instructions per
+# 500 MB launch x 64 lanes / 5e8 bytes (profiles/r03_pmc_sq_counters.txt) -- 4.2 in the streaming loop (135 per
+# 2-KiB pair and wave), the rest appends the candidates (about four pairs in five hold one on DNA)
+PLANE_VALU_OPS_PER_BYTE = 5.56
 # scan_dense_walk<1,false,4> on `[a-f]+[0-9]` over random ASCII: SQ_INSTS_VALU 2.233e9 wave instructions per 5 GB launch
 # x 64 lanes / 5e9 bytes (profiles/r02_pmc_sq_counters.txt); 59 before the lane-packed pre-steps
 DENSE_VALU_OPS_PER_BYTE = 28.6

@@ -178,7 +178,7 @@ struct ScanGeometry {
   uint32_t n_regions;
   uint64_t span_chunks;
 };
-ScanGeometry scan_geometry(uint64_t chunks);
+ScanGeometry scan_geometry(uint64_t chunks, uint64_t chunks_per_block = 128);
 
 // t0 / t1: events stamped with the kernel's own start / end (hipExtLaunchKernelGGL), no extra
 // stream commands
@@ -240,7 +240,9 @@ struct SharedHits {
   uint32_t desc_words;    // words the descriptors take (a multiple of 4)
   uint32_t blob_words;    // descriptors + tables (a multiple of 4)
 };
-void launch_tails_shared(const MultiTail* d_tails, const SharedHits& sh, unsigned long long* counters0, hipStream_t st);
+// max_words / max_short: the largest n_words / short_max among the patterns (selects the kernel instantiation)
+void launch_tails_shared(const MultiTail* d_tails, const SharedHits& sh, int max_words, uint32_t max_short, unsigned long long* counters0,
+                         hipStream_t st);
 void launch_offsets_gather_check_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_regions, hipStream_t st);
 
 // windows mode, lane-sized automaton: verify + compact inside every region (16 lanes each), then

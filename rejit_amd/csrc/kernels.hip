@@ -2731,12 +2731,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 
 // ---------------------------------------------------------------------------------------
 // Launchers (host side of the <<< >>> syntax lives here so engine.cc stays plain C++).
-ScanGeometry scan_geometry(uint64_t chunks) {
+ScanGeometry scan_geometry(uint64_t chunks, uint64_t chunks_per_block) {
   // Measured on MI355X (tools/ab_probe.py): a grid of exactly the resident workgroups loses
   // ~12% to the partially filled last round; large texts stream best with >= 16 Ki workgroups
   // (6.2-6.4 TB/s) while tiny spans waste the pipeline prologue, so aim at >= 32 chunks per
   // wave and cap at 16 Ki workgroups.
-  uint64_t blocks = chunks / 128;
+  uint64_t blocks = chunks / chunks_per_block;
   if (blocks > 16384) blocks = 16384;
   if (blocks < 256) blocks = (chunks + 3) / 4 < 256 ? (chunks + 3) / 4 : 256;
   if (blocks == 0) blocks = 1;

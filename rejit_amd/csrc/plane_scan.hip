@@ -337,8 +337,23 @@ __device__ __forceinline__ bool short_longest_lds(const uint32_t* t0, const Clas
 
 }  // namespace
 
-__global__ __launch_bounds__(256, 4) void classify_shared_multi(SharedHits sh, unsigned long long* counters0) {
+// W / MAXK: state words and step bound of the widest / longest pattern of the set (one instantiation per shape,
+// so that the nine 8-byte patterns of regexdna do not carry the registers of a 64-position automaton)
+template <int W, int MAXK>
+__global__ __launch_bounds__(256) void classify_shared_multi(SharedHits sh, unsigned long long* counters0) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int lane = lane_id();
+  const int half = lane >> 5, sub = lane & 31;
+  const uint64_t wave = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6));
+  const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+  const uint8_t* text = sh.text;
+  const uint64_t n = sh.n, sb = sh.sb, se = sh.se;
+  // the first region's count and candidates are on their way while the blob is copied (a region has at least
+  // 64 slots: the first 32 are read whatever the count says)
+  uint64_t r = wave * 2 + half;
+  uint32_t raw = r < sh.n_regions ? sh.counts[r] : 0u;
+  uint64_t s_first = r < sh.n_regions ? sh.hits[r * sh.cap + sub] : 0;
   {
     const uint4* src = reinterpret_cast<const uint4*>(sh.blob);
     uint4* dst = reinterpret_cast<uint4*>(lds);
@@ -347,17 +362,13 @@ __global__ __launch_bounds__(256, 4) void classify_shared_multi(SharedHits sh, u
   __syncthreads();
   const ClassifyDesc* desc = reinterpret_cast<const ClassifyDesc*>(lds);
   const uint32_t* tab = lds + sh.desc_words;
-  const int lane = lane_id();
-  const int half = lane >> 5, sub = lane & 31;
-  const uint64_t wave = __builtin_amdgcn_readfirstlane(
-      static_cast<uint32_t>((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6));
-  const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
-  const uint8_t* text = sh.text;
-  const uint64_t n = sh.n, sb = sh.sb, se = sh.se;
   for (uint64_t r0 = wave * 2; r0 < sh.n_regions; r0 += n_waves * 2) {
-    const uint64_t r = r0 + half;
+    r = r0 + half;
     const bool live = r < sh.n_regions;
-    const uint32_t raw = live ? sh.counts[r] : 0u;
+    if (r0 != wave * 2) {
+      raw = live ? sh.counts[r] : 0u;
+      s_first = live ? sh.hits[r * sh.cap + sub] : 0;
+    }
     const uint32_t cnt = raw < sh.cap ? raw : sh.cap;
     if (raw > sh.cap && sub == 0) atomicMax(&counters0[kCntSharedMax], static_cast<unsigned long long>(raw));
     uint32_t kept = 0;  // lane 32 * half + p: survivors of pattern p in the half's region
@@ -365,7 +376,7 @@ __global__ __launch_bounds__(256, 4) void classify_shared_multi(SharedHits sh, u
     for (uint32_t base = 0; __ballot(base < cnt) != 0; base += 32) {
       const uint32_t k = base + sub;
       const bool have = k < cnt;
-      const uint64_t s = have ? region[k] : 0;
+      const uint64_t s = !have ? 0 : base == 0 ? s_first : region[k];
       const uint64_t w = s + sh.win_offset;
       // the candidate's 8 window bytes; the scan does not clip (starts outside [sb, se), windows that reach
       // past the end of the text): dropped here
@@ -388,8 +399,8 @@ __global__ __launch_bounds__(256, 4) void classify_shared_multi(SharedHits sh, u
         bool found = false;
         {
           const uint32_t* t0 = tab + d.tab;
-          if (d.n_words <= 1) found = d.short_max <= 8 ? short_longest_lds<1, 8>(t0, d, t_lo, t_hi, avail, &len) : short_longest_lds<1, 16>(t0, d, t_lo, t_hi, avail, &len);
-          else found = short_longest_lds<2, 16>(t0, d, t_lo, t_hi, avail, &len);
+          if (W == 1 || d.n_words <= 1) found = short_longest_lds<1, MAXK>(t0, d, t_lo, t_hi, avail, &len);
+          else found = short_longest_lds<W, MAXK>(t0, d, t_lo, t_hi, avail, &len);
         }
         found = found && active;
         const uint64_t e = s + len;
@@ -418,12 +429,16 @@ __global__ __launch_bounds__(256, 4) void classify_shared_multi(SharedHits sh, u
   }
 }
 
-void launch_tails_shared(const MultiTail* d_tails, const SharedHits& sh, unsigned long long* counters0, hipStream_t st) {
-  // half a wave per region; at most one resident round of workgroups (each copies the blob into LDS first)
+void launch_tails_shared(const MultiTail* d_tails, const SharedHits& sh, int max_words, uint32_t max_short, unsigned long long* counters0,
+                         hipStream_t st) {
+  // half a wave per region; every workgroup copies the blob into LDS first
   uint64_t blocks = (static_cast<uint64_t>(sh.n_regions) + 7) / 8;
-  blocks = blocks < 1 ? 1 : blocks > 1024 ? 1024 : blocks;
-  hipLaunchKernelGGL(classify_shared_multi, dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(sh.blob_words) * sizeof(uint32_t), st,
-                     sh, counters0);
+  blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
+  const dim3 g(static_cast<unsigned>(blocks)), b(256);
+  const size_t lds = static_cast<size_t>(sh.blob_words) * sizeof(uint32_t);
+  if (max_words <= 1 && max_short <= 8) hipLaunchKernelGGL((classify_shared_multi<1, 8>), g, b, lds, st, sh, counters0);
+  else if (max_words <= 1) hipLaunchKernelGGL((classify_shared_multi<1, 16>), g, b, lds, st, sh, counters0);
+  else hipLaunchKernelGGL((classify_shared_multi<2, 16>), g, b, lds, st, sh, counters0);
   launch_offsets_gather_check_multi(d_tails, static_cast<int>(sh.n_patterns), sh.n_regions, st);
 }
 
