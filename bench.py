@@ -158,8 +158,7 @@ def setup(args):
     c.world = int(os.environ.get("WORLD_SIZE", "1"))
     c.rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if c.world != args.gpus and c.world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    assert c.world == args.gpus, "WORLD_SIZE %d != --gpus %d" % (c.world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     if args.same_device:
         local_rank = 0
@@ -777,8 +776,27 @@ def run_jrep(args, c):
     return out
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU under
+    torch.distributed.run on this node (the way sample/regexdna-multithread.cc:65-78 fans out threads), and pass
+    rank 0's JSON line through."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(args)
     c = setup(args)
     import rejit_amd
     rejit_amd.build()

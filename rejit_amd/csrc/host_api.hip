@@ -346,6 +346,12 @@ static int first_match(const rj_program* prog, const char* text, size_t n, uint6
     return e;
   };
   uint64_t lo = 0, block = 256u << 10;
+  // Patterns at risk of the reference's ring artefact: a RANGE of starts owns whole segments between
+  // synchronisation points of the reference's loop and needs the whole text to find them (rj_scan_run's
+  // contract); on a truncated buffer the starts of a sync-free stretch that crosses a block boundary would be
+  // owned by no round (`x{0,2}yz` over 300 000 x + "yz" reported no match).  One round over the whole text:
+  // MatchFirst is the first element of the exact MatchAll.
+  if (prog->host->q8_risk) block = n + 1;
   for (;;) {
     uint64_t hi = lo + block;
     const bool last = hi >= n;

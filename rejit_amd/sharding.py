@@ -76,6 +76,21 @@ def needs_rerun(first: Optional[Span], carry_in: Tuple[int, int, bool]) -> bool:
     return bool(have and b == e and prev_end == b)  # zero-length rule, src/codegen.cc:65-73
 
 
+def must_rerun(first_empty: Optional[Span], used: Tuple[int, int, bool], carry_in: Tuple[int, int, bool]) -> bool:
+    """Does a shard whose current result was selected under the carry `used` have to select again under
+    `carry_in`?  `first_empty` is its first match under the EMPTY carry.  A shard that has not re-run yet
+    (used == empty) re-runs iff the true carry reaches into that first match.  One that HAS re-run holds a result
+    that depends on the carry it used; its current first match says nothing about what a different -- e.g.
+    smaller, because the left neighbour re-ran in the same round and its last match moved -- carry would select
+    (pattern `aaa` over a run of a: the matches skipped under the stale carry were missing), so it re-runs whenever
+    the carry changed."""
+    if carry_in == used:
+        return False
+    if used != (0, 0, False):
+        return True
+    return needs_rerun(first_empty, carry_in)
+
+
 def sharded_match_all(local_scan: LocalScan, ranges: Sequence[Tuple[int, int]], rank: int, world: int,
                       dist=None, gather_to_root: bool = True):
     """Runs the protocol above.  Returns (total_count, spans_on_root_or_None, local_spans).
@@ -84,11 +99,12 @@ def sharded_match_all(local_scan: LocalScan, ranges: Sequence[Tuple[int, int]], 
     empty = (0, 0, False)
     spans = local_scan(own[0], own[1], *empty)
     used = empty
+    first_empty = spans[0] if spans else None   # the first match under the EMPTY carry (see must_rerun)
     if world > 1:
         import torch
 
         dev = _device_for(dist)
-        for _ in range(world):
+        for _ in range(world + 1):
             co = carry_out(spans, used)
             mine = torch.tensor([co[0], co[1], int(co[2]), spans[0][0] if spans else -1,
                                  spans[0][1] if spans else -1], dtype=torch.int64, device=dev)
@@ -100,7 +116,7 @@ def sharded_match_all(local_scan: LocalScan, ranges: Sequence[Tuple[int, int]], 
                 c = allc[r].tolist()
                 if c[2]:
                     cin = (c[0], c[1], True)
-            rerun = cin != used and needs_rerun(spans[0] if spans else None, cin)
+            rerun = must_rerun(first_empty, used, cin)
             flag = torch.tensor([int(rerun)], dtype=torch.int64, device=dev)
             dist.all_reduce(flag)
             if rerun:
@@ -146,6 +162,7 @@ def sharded_match_all_tensor(local_scan, ranges, rank: int, world: int, dist=Non
     if world == 1 or dist is None:
         return int(spans.shape[0]), spans, spans
     used = empty
+    first_empty = tuple(spans[0].cpu().tolist()) if spans.shape[0] else None
 
     def head_tail(sp):
         if sp.shape[0] == 0:
@@ -153,7 +170,7 @@ def sharded_match_all_tensor(local_scan, ranges, rank: int, world: int, dist=Non
         ht = torch.stack([sp[0], sp[-1]]).cpu().tolist()
         return tuple(ht[0]), tuple(ht[1])
 
-    for _ in range(world):
+    for _ in range(world + 1):
         first, last = head_tail(spans)
         co = carry_out([last] if last else [], used)
         mine = torch.tensor([co[0], co[1], int(co[2]), first[0] if first else -1, first[1] if first else -1],
@@ -165,7 +182,7 @@ def sharded_match_all_tensor(local_scan, ranges, rank: int, world: int, dist=Non
             cc = allc[r].tolist()
             if cc[2]:
                 cin = (cc[0], cc[1], True)
-        rerun = cin != used and needs_rerun(first, cin)
+        rerun = must_rerun(first_empty, used, cin)
         flag = torch.tensor([int(rerun)], dtype=torch.int64, device=device)
         dist.all_reduce(flag)
         if rerun:
@@ -207,41 +224,50 @@ def multi_pattern_counts(run_local, rerun_one, n_patterns: int, rank: int, world
     selection carried over the cuts.  run_local() -> (counts, bounds): this rank's counts with an empty
     carry and per pattern None or (first begin, first end, last begin, last end); rerun_one(i, carry_cur,
     carry_prev_end) -> (count, bounds_i) re-runs pattern i with the true carry.  One all_gather of
-    5 integers per pattern per round; a second round only when some rank's first match begins before its
-    left neighbour's last end (self-overlapping occurrences across a cut: rare).  Returns the job-wide
-    counts, identical on every rank."""
+    8 integers per pattern per round -- count, the first match under the EMPTY carry, the current last match,
+    and the carry the current result was selected under, so that every rank can tell which ranks re-run
+    (must_rerun) --; a second round only when some rank's first match begins before its left neighbour's last
+    end (self-overlapping occurrences across a cut: rare).  Returns the job-wide counts, identical on every
+    rank."""
     import torch
 
     counts, bounds = run_local()
-    for _ in range(world):
-        mine = torch.full((n_patterns, 5), -1, dtype=torch.int64)
+    first_empty = [None if b is None else (b[0], b[1]) for b in bounds]
+    used = [(0, 0, False)] * n_patterns
+    for _ in range(world + 1):
+        mine = torch.full((n_patterns, 8), -1, dtype=torch.int64)
         for i in range(n_patterns):
-            mine[i, 0] = counts[i]
-            if bounds[i] is not None:
-                mine[i, 1:] = torch.tensor(bounds[i], dtype=torch.int64)
+            fe = first_empty[i] or (-1, -1)
+            last = (bounds[i][2], bounds[i][3]) if bounds[i] is not None else (-1, -1)
+            mine[i] = torch.tensor([counts[i], fe[0], fe[1], last[0], last[1], used[i][0], used[i][1], int(used[i][2])], dtype=torch.int64)
         mine = mine.to(device)
         allb = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allb, mine)
-        allb = torch.stack(allb).cpu()          # [world][pattern][count, fb, fe, lb, le]
+        allb = torch.stack(allb).cpu().tolist()   # [world][pattern][count, fb0, fe0, lb, le, used_cur, used_pe, used_have]
         again = False
         for i in range(n_patterns):
             # carry into rank r = the last match of the nearest rank before it that has one
             for r in range(1, world):
-                if allb[r, i, 1] < 0:
-                    continue
-                prev = [q for q in range(r) if allb[q, i, 1] >= 0]
-                if not prev:
-                    continue
-                lb, le = int(allb[prev[-1], i, 3]), int(allb[prev[-1], i, 4])
-                cur = le if le > lb else lb + 1
-                fb, fe = int(allb[r, i, 1]), int(allb[r, i, 2])
-                if fb < cur or (fb == fe and le == fb):
+                prev = [q for q in range(r) if allb[q][i][3] >= 0]
+                cin = (0, 0, False)
+                if prev:
+                    lb, le = allb[prev[-1]][i][3], allb[prev[-1]][i][4]
+                    cin = (le if le > lb else lb + 1, le, True)
+                row = allb[r][i]
+                fe = (row[1], row[2]) if row[1] >= 0 else None
+                if must_rerun(fe, (row[5], row[6], bool(row[7])), cin):
                     again = True
                     if r == rank:
-                        counts[i], bounds[i] = rerun_one(i, cur, le)
+                        counts[i], bounds[i] = rerun_one(i, cin[0], cin[1]) if cin[2] else _rerun_empty(rerun_one, i)
+                        used[i] = cin
         if not again:
-            return [int(allb[:, i, 0].sum()) for i in range(n_patterns)]
+            return [sum(allb[r][i][0] for r in range(world)) for i in range(n_patterns)]
     raise RuntimeError("carry exchange did not converge")
+
+
+def _rerun_empty(rerun_one, i):
+    # (a carry that went back to "no earlier match": select again from an empty carry)
+    return rerun_one(i, 0, 0)
 
 
 def _device_for(dist):

@@ -4,7 +4,6 @@ carry exchange (regexdna, literal, complex), file sharding + output gather (jrep
 the one-rank run.  RCCL itself is exercised only on a multi-GPU node (the driver's SCALE run)."""
 import json
 import os
-import socket
 import subprocess
 import sys
 
@@ -17,12 +16,8 @@ SMALL = ["--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline", "--
 
 
 def bench(workload, ranks):
-    cmd = [sys.executable]
-    if ranks > 1:
-        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
-                "--master-port", str(port)]
-    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--workload", workload] + SMALL
+    # `python bench.py --gpus N` as the driver calls it: bench.py starts its own ranks (spawn_ranks)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--workload", workload] + SMALL
     if ranks > 1:
         cmd += ["--backend", "gloo", "--same-device"]
     for attempt in range(2):   # (a rendezvous on a just-freed port can fail once in a while)
