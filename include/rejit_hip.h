@@ -100,6 +100,21 @@ void rj_free_spans(uint64_t* spans);
 int64_t rj_match_all_batch(const rj_program* prog, const char* const* texts, const size_t* sizes, size_t n_texts,
                            uint64_t* counts, uint64_t** spans);
 
+/* The same for a batch its owner lays out ITSELF, so that no text is copied twice: text i is
+ * packed[offsets[i] .. offsets[i] + sizes[i]), offsets ascending, and EVERY byte of packed[0 .. total_bytes) that
+ * belongs to no text -- at least one behind every text, the last one included -- holds rj_batch_separator(prog).
+ * `packed` is uploaded as it is: from memory of rj_host_alloc (pinned) at the PCIe rate, from ordinary memory
+ * through the runtime's staging copy.  A native grep reads its files straight into such a buffer
+ * (samples/jrep_gpu.cc); the reference's loop has no counterpart (one mmap + MatchAll per file,
+ * sample/jrep.cc:261-313).  counts / spans / return value as for rj_match_all_batch.  A pattern for which
+ * rj_batch_separator is -1 (every byte value can be consumed by some position of an automaton with assertions, or
+ * the pattern is at risk of the ring artefact) is matched text by text. */
+int rj_batch_separator(const rj_program* prog);
+int64_t rj_match_all_packed(const rj_program* prog, const char* packed, const uint64_t* offsets, const size_t* sizes, size_t n_texts,
+                            uint64_t total_bytes, uint64_t* counts, uint64_t** spans);
+void* rj_host_alloc(size_t bytes);   /* pinned host memory (NULL when there is none to be had) */
+void rj_host_free(void* p);
+
 /* ReplaceAll (replaces MatchAll + rejit::Replace, src/rejit.cc:97-112,220-226): every match is
  * replaced by with[0..with_len).  Returns the number of matches (>= 0) or rj_status; *out receives
  * a malloc'ed copy of the new text (NUL-terminated for convenience, *out_len excludes the NUL),

@@ -845,6 +845,7 @@ void rj_program_free(rj_program* prog) {
   ErrnoGuard errno_guard;
   if (!prog) return;
   forget_host_scans(prog->id);  // (host_api.hip: this thread's cached scans of the program)
+  forget_combiner(prog->id);
   for (rj_program* r : prog->replicas)
     if (r != nullptr) rj_program_free(r);
   delete prog;

@@ -145,6 +145,8 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
                  int have_prev, hipStream_t st);
 // host_api.hip
 void forget_host_scans(uint64_t program_id);
+void forget_combiner(uint64_t program_id);
+extern thread_local std::string g_error;   // engine.hip: the calling thread's rj_last_error() text
 // linear.hip: MatchAll of the starts [sb, se) in time linear in the text (carry_scan.h); results as
 // after run_range (s->out, s->result_count).  RJ_TOO_LARGE when the automaton is wider than the
 // carry kernels take.

@@ -9,12 +9,16 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "engine_internal.h"
@@ -173,6 +177,247 @@ int64_t rejit_amd::rj_match_range_host(const rj_program* prog, const char* text,
   return static_cast<int64_t>(s->result_count);
 }
 
+namespace {
+
+// The texts of a batch lie in the scan's device text buffer as laid out by `off` / `sizes` (text i at
+// [off[i], off[i] + sizes[i]), separator bytes behind it up to off[i + 1]); the uploads are queued on the scan's
+// stream.  One device pass, then one merge pass that hands every match to its text.
+int64_t finish_packed(rj_scan* s, const uint64_t* off, const size_t* sizes, size_t n_texts, uint64_t total_bytes, uint64_t* counts,
+                      uint64_t** spans) {
+  const uint64_t n = total_bytes - 1;  // the last separator is the end of the buffer
+  int rc = run_pipeline(s, s->text.as<uint8_t>(), n, 0, n + 1, 0, 0, 0, s->own_stream);
+  if (rc != RJ_OK) return rc;
+  const uint64_t m = s->result_count;
+  std::vector<uint64_t> pairs(2 * m);
+  if (m) RJ_HIP(copy_result_pairs(s, pairs.data(), 0, m, s->own_stream));
+  // the matches are ordered by begin: one merge pass assigns them to their texts
+  for (size_t i = 0; i < n_texts; i++) counts[i] = 0;
+  size_t t = 0;
+  uint64_t kept = 0;
+  for (uint64_t k = 0; k < m; k++) {
+    const uint64_t b = pairs[2 * k], e = pairs[2 * k + 1];
+    while (t + 1 < n_texts && b >= off[t + 1]) t++;
+    if (b > off[t] + sizes[t]) continue;  // (an empty match between the separators of a gap: belongs to no text)
+    if (e > off[t] + sizes[t]) return fail(RJ_DEVICE_ERROR, "internal: a match crosses a text boundary in a batch");
+    counts[t]++;
+    pairs[2 * kept] = b - off[t];
+    pairs[2 * kept + 1] = e - off[t];
+    kept++;
+  }
+  if (spans && kept) {
+    uint64_t* h = static_cast<uint64_t*>(malloc(kept * 2 * sizeof(uint64_t)));
+    if (!h) return fail(RJ_DEVICE_ERROR, "out of host memory");
+    memcpy(h, pairs.data(), kept * 2 * sizeof(uint64_t));
+    *spans = h;
+  }
+  return static_cast<int64_t>(kept);
+}
+
+// A batch that its owner laid out already (rj_match_all_packed, the call combiner): uploaded as it is.
+// `s`: the scratch to use (null: the calling thread's own for this pattern).
+int64_t run_packed(const rj_program* prog, const char* packed, const uint64_t* off, const size_t* sizes, size_t n_texts, uint64_t total_bytes,
+                   uint64_t* counts, uint64_t** spans, rj_scan* s = nullptr) {
+  if (spans) *spans = nullptr;
+  DeviceGuard on_device(prog->device);
+  if (!s) {
+    int rc = host_scan_for(prog, &s);
+    if (rc != RJ_OK) return rc;
+  }
+  struct DrainStream {
+    hipStream_t st;
+    ~DrainStream() { (void)hipStreamSynchronize(st); }
+  } drain{s->own_stream};  // (the caller may refill `packed` as soon as this returns)
+  RJ_HIP(s->text.reserve(((total_bytes + 64 + 4095) / 4096) * 4096));
+  constexpr uint64_t kSlice = 64ull << 20;
+  for (uint64_t lo = 0; lo < total_bytes; lo += kSlice) {
+    const uint64_t len = std::min(kSlice, total_bytes - lo);
+    RJ_HIP(hipMemcpyAsync(static_cast<char*>(s->text.p) + lo, packed + lo, len, hipMemcpyHostToDevice, s->own_stream));
+  }
+  return finish_packed(s, off, sizes, n_texts, total_bytes, counts, spans);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// Concurrent callers of one pattern are COMBINED.  The reference's jrep shares one compiled Regej between its
+// worker threads and calls MatchAll once per file (sample/jrep.cc:288, workers :461-493); on the CPU that is N
+// independent passes, here every call is a device round trip of >= 20 us whatever the size of the file, and
+// concurrent round trips serialise in the runtime (jrep -j 8 was SLOWER than -j 0 in round 2).  So a caller with
+// a small text reserves room in the pattern's open batch buffer (pinned host memory) and copies its text there
+// itself -- the copies, and the page faults of an mmap'ed file, run in parallel on the callers' threads --;
+// whoever finds no batch on the device becomes the leader, closes the buffer (new arrivals fill the second one),
+// runs it as ONE packed batch -- one upload, one device pass -- and hands the results out; the others sleep on
+// their own condition variable until their result is there or it is their turn to lead ("group commit").  A
+// single caller leads a batch of one: the ordinary path plus an uncontended mutex.
+namespace {
+
+constexpr size_t kCombineBuffer = 8u << 20;    // bytes per batch buffer
+constexpr size_t kCombineMaxText = 1u << 20;   // (a text this large gains nothing from sharing a pass)
+
+struct PendingCall {
+  const char* text;
+  size_t n;
+  bool want_spans;
+  uint64_t off = 0;
+  uint64_t* spans = nullptr;
+  int64_t result = 0;
+  std::string error;
+  bool done = false;
+  std::condition_variable cv;
+};
+
+struct Combiner {
+  std::mutex mu;
+  char* buf[2] = {nullptr, nullptr};   // pinned
+  int open = 0;                        // the buffer arrivals fill
+  uint64_t used = 0;                   // bytes reserved in it
+  int copying[2] = {0, 0};             // callers still copying into a buffer
+  std::vector<PendingCall*> calls;     // the open batch, in buffer order
+  bool leader_active = false;
+  rj_scan* scan = nullptr;             // the device scratch of the batches: ONE for all leaders (they lead one at a time;
+                                       // a scratch per leading thread cost ~10 ms of allocations per thread: jrep -j 128)
+  std::atomic<int> inside{0};          // calls of this pattern in flight (combined or not)
+  std::condition_variable copied;      // a buffer's last copy has finished
+  std::condition_variable room;        // the open buffer was swapped: there is room again
+  ~Combiner() {
+    if (buf[0]) (void)hipHostFree(buf[0]);   // (buf[1] is its second half)
+    if (scan) rj_scan_destroy(scan);
+  }
+};
+
+std::mutex g_combiners_mu;
+std::unordered_map<uint64_t, std::shared_ptr<Combiner>> g_combiners;  // by rj_program::id
+
+std::shared_ptr<Combiner> combiner_for(const rj_program* prog) {
+  std::lock_guard<std::mutex> lk(g_combiners_mu);
+  auto& c = g_combiners[prog->id];
+  if (!c) c = std::make_shared<Combiner>();
+  return c;
+}
+
+// the closed batch `batch` lies in `packed` (text, separator, text, separator, ...)
+void run_combined(const rj_program* prog, rj_scan* scan, const char* packed, uint64_t used, std::vector<PendingCall*>& batch) {
+  std::vector<uint64_t> off(batch.size() + 1);
+  std::vector<size_t> sizes(batch.size());
+  std::vector<uint64_t> counts(batch.size(), 0);
+  for (size_t i = 0; i < batch.size(); i++) {
+    off[i] = batch[i]->off;
+    sizes[i] = batch[i]->n;
+  }
+  off[batch.size()] = used;
+  uint64_t* all = nullptr;
+  const int64_t total = run_packed(prog, packed, off.data(), sizes.data(), batch.size(), used, counts.data(), &all, scan);
+  if (total < 0) {
+    for (PendingCall* p : batch) {
+      p->result = total;
+      p->error = g_error;
+    }
+    return;
+  }
+  uint64_t at = 0;
+  for (size_t i = 0; i < batch.size(); i++) {
+    PendingCall* p = batch[i];
+    p->result = static_cast<int64_t>(counts[i]);
+    if (p->want_spans && counts[i]) {
+      p->spans = static_cast<uint64_t*>(malloc(counts[i] * 2 * sizeof(uint64_t)));
+      if (!p->spans) {
+        p->result = RJ_DEVICE_ERROR;
+        p->error = "out of host memory";
+      } else {
+        memcpy(p->spans, all + 2 * at, counts[i] * 2 * sizeof(uint64_t));
+      }
+    }
+    at += counts[i];
+  }
+  free(all);
+}
+
+// 0: take the direct path (this call is alone, or there is no pinned memory); 1: done, *result holds the answer
+int combined_match_all(const rj_program* prog, const char* text, size_t n, uint64_t** spans, int64_t* result) {
+  std::shared_ptr<Combiner> c = combiner_for(prog);
+  struct Inside {
+    std::atomic<int>& v;
+    int seen;
+    explicit Inside(std::atomic<int>& a) : v(a), seen(a.fetch_add(1) + 1) {}
+    ~Inside() { v.fetch_sub(1); }
+  } inside(c->inside);
+  // a call that finds no other call of the pattern in flight takes the direct path -- a single-threaded caller
+  // never comes further than this, and the batch buffers (pinned memory) are only ever allocated for patterns
+  // that ARE called concurrently
+  if (inside.seen < 2) {
+    *result = rj_match_range_host(prog, text, n, 0, n + 1, 0, 0, 0, spans);
+    return 1;
+  }
+  PendingCall me{text, n, spans != nullptr};
+  std::unique_lock<std::mutex> lk(c->mu);
+  if (!c->buf[0]) {
+    DeviceGuard on_device(prog->device);
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->buf[0]), 2 * kCombineBuffer) != hipSuccess) {
+      c->buf[0] = nullptr;
+      return 0;
+    }
+    c->buf[1] = c->buf[0] + kCombineBuffer;
+    if (rj_scan_create(prog, &c->scan) != RJ_OK || hipStreamCreateWithFlags(&c->scan->own_stream, hipStreamNonBlocking) != hipSuccess) {
+      if (c->scan) rj_scan_destroy(c->scan);
+      c->scan = nullptr;
+      (void)hipHostFree(c->buf[0]);
+      c->buf[0] = c->buf[1] = nullptr;
+      return 0;
+    }
+  }
+  // room in the open buffer (when it is full its batch is led by one of the callers in it: wait for the swap)
+  while (c->used + n + 1 > kCombineBuffer) c->room.wait(lk);
+  const int b = c->open;
+  me.off = c->used;
+  c->used += n + 1;
+  c->calls.push_back(&me);
+  c->copying[b]++;
+  char* dst = c->buf[b] + me.off;
+  lk.unlock();
+  if (n) memcpy(dst, text, n);
+  dst[n] = static_cast<char>(prog->batch_separator);
+  lk.lock();
+  if (--c->copying[b] == 0) c->copied.notify_all();
+  while (!me.done) {
+    if (c->leader_active || c->open != b) {  // (c->open != b: my batch is closed already, its leader will wake me)
+      me.cv.wait(lk);
+      continue;
+    }
+    // lead the open batch (this call is in it)
+    c->leader_active = true;
+    std::vector<PendingCall*> batch;
+    batch.swap(c->calls);
+    const uint64_t used = c->used;
+    c->open ^= 1;
+    c->used = 0;
+    c->room.notify_all();
+    while (c->copying[b] > 0) c->copied.wait(lk);
+    lk.unlock();
+    run_combined(prog, c->scan, c->buf[b], used, batch);
+    lk.lock();
+    c->leader_active = false;
+    for (PendingCall* p : batch) {
+      p->done = true;
+      if (p != &me) p->cv.notify_one();
+    }
+    // the batch that filled meanwhile: its first caller leads it
+    if (!c->calls.empty()) c->calls.front()->cv.notify_one();
+  }
+  lk.unlock();
+  if (me.result < 0) g_error = me.error;
+  if (spans) *spans = me.spans;
+  *result = me.result;
+  return 1;
+}
+
+}  // namespace
+
+// rj_program_free (engine.hip)
+void rejit_amd::forget_combiner(uint64_t program_id) {
+  std::lock_guard<std::mutex> lk(g_combiners_mu);
+  g_combiners.erase(program_id);
+}
+
 extern "C" {
 
 int64_t rj_match_all(const rj_program* prog, const char* text, size_t n, uint64_t** spans) {
@@ -181,6 +426,8 @@ int64_t rj_match_all(const rj_program* prog, const char* text, size_t n, uint64_
   if (!prog || (!text && n)) return fail(RJ_BAD_ARGUMENT, "null argument");
   int64_t result = 0;
   if (multi_device_match_all(prog, text, n, spans, &result)) return result;  // large text, several GPUs: one range per device
+  static const bool no_combine = getenv("RJ_NO_COMBINE") != nullptr;  // measurement override
+  if (n <= kCombineMaxText && prog->batch_separator >= 0 && !no_combine && combined_match_all(prog, text, n, spans, &result) == 1) return result;
   return rj_match_range_host(prog, text, n, 0, n + 1, 0, 0, 0, spans);
 }
 
@@ -291,32 +538,51 @@ int64_t rejit_amd::rj_match_all_batch_one_device(const rj_program* prog, const c
       first = last;
     }
   }
-  rc = run_pipeline(s, s->text.as<uint8_t>(), n, 0, n + 1, 0, 0, 0, s->own_stream);
-  if (rc != RJ_OK) return rc;
-  const uint64_t m = s->result_count;
-  std::vector<uint64_t> pairs(2 * m);
-  if (m) RJ_HIP(copy_result_pairs(s, pairs.data(), 0, m, s->own_stream));
-  // the matches are ordered by begin: one merge pass assigns them to their texts
-  for (size_t i = 0; i < n_texts; i++) counts[i] = 0;
-  size_t t = 0;
-  for (uint64_t k = 0; k < m; k++) {
-    const uint64_t b = pairs[2 * k], e = pairs[2 * k + 1];
-    while (b > off[t] + sizes[t]) t++;
-    if (e > off[t] + sizes[t]) return fail(RJ_DEVICE_ERROR, "internal: a match crosses a text boundary in a batch");
-    counts[t]++;
-    pairs[2 * k] = b - off[t];
-    pairs[2 * k + 1] = e - off[t];
-  }
-  if (spans && m) {
-    uint64_t* h = static_cast<uint64_t*>(malloc(pairs.size() * sizeof(uint64_t)));
-    if (!h) return fail(RJ_DEVICE_ERROR, "out of host memory");
-    memcpy(h, pairs.data(), pairs.size() * sizeof(uint64_t));
-    *spans = h;
-  }
-  return static_cast<int64_t>(m);
+  return finish_packed(s, off.data(), sizes, n_texts, total_bytes, counts, spans);
 }
 
 extern "C" {
+
+int rj_batch_separator(const rj_program* prog) { return prog ? prog->batch_separator : -1; }
+
+void* rj_host_alloc(size_t bytes) {
+  ErrnoGuard errno_guard;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+  return p;
+}
+
+void rj_host_free(void* p) {
+  ErrnoGuard errno_guard;
+  if (p) (void)hipHostFree(p);
+}
+
+int64_t rj_match_all_packed(const rj_program* prog, const char* packed, const uint64_t* offsets, const size_t* sizes, size_t n_texts,
+                            uint64_t total_bytes, uint64_t* counts, uint64_t** spans) {
+  ErrnoGuard errno_guard;
+  if (spans) *spans = nullptr;
+  if (!prog || (n_texts && (!packed || !offsets || !sizes || !counts))) return fail(RJ_BAD_ARGUMENT, "null argument");
+  if (n_texts == 0) return 0;
+  for (size_t i = 0; i < n_texts; i++) {
+    const uint64_t end = offsets[i] + sizes[i];
+    if (end < offsets[i] || end >= total_bytes || (i + 1 < n_texts && end >= offsets[i + 1]))
+      return fail(RJ_BAD_ARGUMENT, "packed batch: text %zu overlaps the next one or leaves no room for its separator", i);
+  }
+  if (prog->batch_separator < 0 || n_texts == 1) {
+    // (no byte can end a text inside a concatenation, or nothing to batch: text by text)
+    std::vector<const char*> texts(n_texts);
+    for (size_t i = 0; i < n_texts; i++) texts[i] = packed + offsets[i];
+    return rj_match_all_batch_one_device(prog, texts.data(), sizes, n_texts, counts, spans);
+  }
+  int64_t result = 0;
+  {
+    // several GPUs: the files are spread over them (every device packs its share itself)
+    std::vector<const char*> texts(n_texts);
+    for (size_t i = 0; i < n_texts; i++) texts[i] = packed + offsets[i];
+    if (multi_device_match_all_batch(prog, texts.data(), sizes, n_texts, counts, spans, &result)) return result;
+  }
+  return run_packed(prog, packed, offsets, sizes, n_texts, total_bytes, counts, spans);
+}
 
 void rj_free_spans(uint64_t* spans) { free(spans); }
 

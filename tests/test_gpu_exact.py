@@ -122,3 +122,20 @@ def test_ring_in_global_memory(rj, oracle):
     assert cnt == len(want) and np.array_equal(gpu_spans_np(rj, scan), want), scan.stats()
     host = rj.Program(rx).match_all(t.tobytes()[:300000])
     assert np.array_equal(np.array(host, dtype=np.uint64).reshape(-1, 2), oracle_spans_np(oracle, rx, t[:300000]))
+
+
+def test_match_first_of_an_at_risk_pattern_beyond_the_first_block(rj, oracle):
+    """MatchFirst / MatchAnywhere look at growing blocks of starts on a truncated buffer -- not for patterns at
+    risk of the ring artefact, whose ranges own whole segments between synchronisation points: a sync-free
+    stretch across the 256-KiB block boundary was owned by no round and the call reported "no match"."""
+    rx = b"x{0,2}yz"
+    prog = rj.Program(rx)
+    assert prog.info()["ring_artefact_risk"]
+    for n_x in (300000, 262143, 262144, 262146, 3 * 262144 + 5):
+        text = b"x" * n_x + b"yz" + b"q" * 100
+        want = oracle.match_all(rx, text)
+        assert want and want[0] == (n_x - 2, n_x + 2)
+        assert prog.match_first(text) == want[0], n_x
+        assert prog.match_anywhere(text)
+    assert prog.match_first(b"x" * 400000) is None
+    assert not prog.match_anywhere(b"x" * 400000)

@@ -19,6 +19,7 @@ for i, data in enumerate(files):
     with open(os.path.join(d, "f%05d.c" % i), "wb") as fh:
         fh.write(data)
     total += len(data)
+os.makedirs(os.path.join(base, "..", "jrep_empty_dir"), exist_ok=True)
 print("tree: %d files, %.1f MB under %s" % (n_files, total / 1e6, base), flush=True)
 ref = os.path.join(ROOT, "oracle", "_ref")
 cores = os.cpu_count() or 1
@@ -41,9 +42,17 @@ def run(label, cmd, repeat=3):
 
 outs = {}
 outs["ref1"] = run("reference jrep, reference library, 1 thread", [os.path.join(ref, "jrep_ref"), "-R", "-H", "-n", "regexp", "."])
-outs["refj"] = run("reference jrep, reference library, -j 8", [os.path.join(ref, "jrep_ref"), "-R", "-H", "-n", "-j", "8", "regexp", "."])
+# (argp: the optional argument of -j must be attached -- `-j 8` makes "8" the pattern)
+outs["refj"] = run("reference jrep, reference library, -j8", [os.path.join(ref, "jrep_ref"), "-R", "-H", "-n", "-j8", "regexp", "."])
 outs["hip1"] = run("reference jrep UNCHANGED on librejit_hip.so, 1 thread", [os.path.join(ref, "jrep_hip"), "-R", "-H", "-n", "regexp", "."])
-outs["hipj"] = run("reference jrep UNCHANGED on librejit_hip.so, -j 8", [os.path.join(ref, "jrep_hip"), "-R", "-H", "-n", "-j", "8", "regexp", "."])
+for j in (8, 32, 128):
+    outs["hipj%d" % j] = run("reference jrep UNCHANGED on librejit_hip.so, -j%d (calls combined in the library)" % j,
+                             [os.path.join(ref, "jrep_hip"), "-R", "-H", "-n", "-j%d" % j, "regexp", "."])
+run("  (start-up alone: the same binary over an empty directory)", [os.path.join(ref, "jrep_hip"), "-R", "-H", "-n", "regexp", os.path.join(base, "..", "jrep_empty_dir")])
+native = os.path.join(ROOT, "samples", "jrep_gpu")
+if os.path.exists(native):
+    outs["native"] = run("samples/jrep_gpu (C++ over the C ABI: batches per device pass)", [native, "-R", "-H", "-n", "regexp", "."])
+    run("  (start-up alone: the same binary over an empty directory)", [native, "-R", "-H", "-n", "regexp", os.path.join(base, "..", "jrep_empty_dir")])
 outs["batch"] = run("samples/jrep_gpu.py (rj_match_all_batch, whole batches per pass)", [sys.executable, os.path.join(ROOT, "samples", "jrep_gpu.py"), "-R", "-H", "-n", "regexp", "."], repeat=2)
 # the library alone on the same files, already in memory: the pattern's batch call + the line-table batch call
 # over the files with matches (what a C++ caller of rj_match_all_batch pays; no file I/O, no formatting)
@@ -61,6 +70,6 @@ if shutil.which("grep"):
 want = outs.get("ref1")
 for k, v in outs.items():
     if v is not None and want is not None:
-        print("  output of %-6s == reference jrep: %s" % (k, v == want))
+        print("  output of %-7s == reference jrep (sorted lines): %s" % (k, v == want))
 if len(sys.argv) <= 2:
     shutil.rmtree(base, ignore_errors=True)
