@@ -8,7 +8,7 @@ from typing import List, Optional, Tuple
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-SOURCES = ["kernels.hip", "plane_scan.hip", "carry_kernels.hip", "engine.hip", "multi_pattern.hip", "host_api.hip", "linear.hip", "exact_replay.hip", "multi_device.hip", "parser.cc", "lowering.cc", "rejit_api.cc"]
+SOURCES = ["kernels.hip", "plane_scan.hip", "emit_scan.hip", "carry_kernels.hip", "engine.hip", "multi_pattern.hip", "host_api.hip", "linear.hip", "exact_replay.hip", "multi_device.hip", "parser.cc", "lowering.cc", "rejit_api.cc"]
 HEADERS = ["kernels.h", "device_program.h", "lowering.h", "carry_scan.h", "behind_walk.h", "exact_replay.h", "engine_internal.h", "table_layout.h"]
 LIB = os.path.join(PKG, "librejit_hip.so")
 

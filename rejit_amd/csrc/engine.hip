@@ -404,6 +404,47 @@ WindowSet make_window_set(const rj_program* rp) {
   return ws;
 }
 
+// Assertion-only patterns (`^`, `$`: the line table of a grep-like caller) from the beginning of a selection: every
+// position in a matching context is a match, so the result is written once, in place (emit_scan.hip).
+// 1 = done, 0 = not applicable / look-back timed out (the caller takes the dense kernel), < 0 = error.
+static int run_assertions(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, hipStream_t st) {
+  const DevProgram& D = s->prog->dev;
+  static const bool off = getenv("RJ_NO_EMIT") != nullptr;  // measurement override
+  if (off || D.n_pos != 0 || D.nullable == 0 || se <= sb) return 0;
+  uint64_t cap = std::max<uint64_t>(s->hits_hint + s->hits_hint / 8 + 1024, (se - sb) / 48 + 1024);
+  RJ_HIP(s->scan_a.reserve(emit_scratch_bytes(sb, se)));
+  for (int attempt = 0; attempt < 3; attempt++) {
+    if (cap > s->out_cap) {
+      RJ_HIP(s->out.reserve(cap * 2 * sizeof(uint64_t)));
+      s->out_cap = cap;
+    }
+    RJ_HIP(hipMemsetAsync(s->counters.p, 0, kCntSize * sizeof(unsigned long long), st));
+    s->host_counters[kCntOverrun] = 0;
+    s->host_counters[kCntFinal] = 0;
+    launch_emit_assertions(d_text, n, sb, se, D.nullable, s->scan_a.as<unsigned long long>(), s->out.as<uint64_t>(), s->out_cap,
+                           s->counters.as<unsigned long long>(), s->host_counters, s->ev[1], s->ev[2], st);
+    RJ_HIP(hipStreamSynchronize(st));
+    RJ_HIP(hipGetLastError());
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, s->ev[1], s->ev[2]);
+    s->stats.scan_ms += ms;
+    if (s->host_counters[kCntOverrun] != 0) return 0;
+    const uint64_t cnt = s->host_counters[kCntFinal];
+    if (cnt > s->out_cap) {  // more matches than room: once more with room for all of them
+      s->stats.retries++;
+      cap = cnt + cnt / 16 + 1024;
+      continue;
+    }
+    s->result_count = cnt;
+    s->result = s->out.as<uint64_t>();
+    s->hits_hint = cnt;
+    s->stats.n_hits += cnt;
+    s->stats.n_candidates += cnt;
+    return 1;
+  }
+  return 0;
+}
+
 constexpr uint64_t kExactLimit = 1u << 20;  // bytes the one-lane exact kernel is allowed to walk
 constexpr uint64_t kDenseSegment = 1ull << 27;  // dense mode: starts per pipeline run (bounds the lists)
 
@@ -432,6 +473,10 @@ static int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb,
   // the previous text needed the linear-time path: go there directly (run_linear clears the hint
   // when the text turns out not to need it)
   if (s->linear_hint && linear_path_fits(rp)) return run_linear(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
+  if (!windows && carry_cur == 0 && !have_prev) {
+    const int rc = run_assertions(s, d_text, n, sb, se, st);
+    if (rc != 0) return rc < 0 ? rc : RJ_OK;
+  }
 
   // what the scan kernel walks, in 1-KiB chunks
   ScanParams sp{};

@@ -191,6 +191,15 @@ bool dense_walk_fits(const DevProgram& P);
 void launch_scan_dense_walk(const ScanParams& a, const DevProgram& P, int grid, uint64_t* region_ends,
                             unsigned long long* counters, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 void launch_scan_dense(const ScanParams& a, const DevProgram& P, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
+// assertion-only patterns (n_pos == 0) in one pass, the pairs written once at their final place through a decoupled
+// look-back over 32-KiB tiles (emit_scan.hip).  scratch: emit_scratch_bytes(sb, se) bytes (zeroed by the launcher).
+// counters[kCntFinal] (and host_counters, pinned, when given) = the number of matches, also when it exceeds out_cap;
+// [kCntOverrun] = 1 when a look-back timed out (the caller takes the dense kernel instead).
+uint64_t emit_tiles(uint64_t sb, uint64_t se);
+size_t emit_scratch_bytes(uint64_t sb, uint64_t se);
+void launch_emit_assertions(const uint8_t* text, uint64_t n, uint64_t sb, uint64_t se, uint32_t nullable, unsigned long long* scratch,
+                            uint64_t* out, uint64_t out_cap, unsigned long long* counters, unsigned long long* host_counters, hipEvent_t t0,
+                            hipEvent_t t1, hipStream_t st);
 void launch_region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap, uint64_t* offsets,
                            unsigned long long* counters, hipStream_t st);
 // what verify_in_regions + offsets_gather_check need for one pattern; rj_multi runs the tails of all

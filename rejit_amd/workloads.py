@@ -258,6 +258,29 @@ def plant(text, offsets: Sequence[int], needle: bytes):
     return text
 
 
+# ---- a digest of a span list that numpy (the reference's output, tests/golden/make_fullsize.py) and torch (the
+# engine's output, left on the device) compute alike: 64-bit wrapping sums.  Pins results at BASELINE sizes, where
+# the span lists themselves are too large for a fixture.
+_D1 = 0x9E3779B97F4A7C15
+_D2 = 0xC2B2AE3D27D4EB4F
+
+
+def span_digest_numpy(spans: np.ndarray) -> dict:
+    """spans: (k, 2) uint64."""
+    b, e = spans[:, 0].astype(np.uint64), spans[:, 1].astype(np.uint64)
+    with np.errstate(over="ignore"):
+        mix = ((b * np.uint64(_D1)) ^ (e * np.uint64(_D2))).sum(dtype=np.uint64)
+        return {"count": int(len(b)), "sum_begin": int(b.sum(dtype=np.uint64)), "sum_len": int((e - b).sum(dtype=np.uint64)),
+                "mix": int(mix)}
+
+
+def span_digest_torch(spans) -> dict:
+    """spans: (k, 2) int64 tensor (any device); int64 arithmetic wraps like uint64."""
+    b, e = spans[:, 0], spans[:, 1]
+    mix = ((b * _signed(_D1)) ^ (e * _signed(_D2))).sum()
+    return {"count": int(spans.shape[0]), "sum_begin": int(b.sum()) & _MASK, "sum_len": int((e - b).sum()) & _MASK, "mix": int(mix) & _MASK}
+
+
 # Strings drawn from the language of the "complex" benchmark regex
 # ([complex]|(regexp)){2,7}abcdefgh(at|the|[e-nd]as well)   (tools/benchmarks/run.py:351)
 def complex_regex_sample(rng: _random.Random) -> bytes:
