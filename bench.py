@@ -71,6 +71,8 @@ def parse_args():
     ap.add_argument("--literal-bytes", type=int, default=5_000_000_000, help="text bytes per GPU of the literal / complex workloads")
     ap.add_argument("--big-literal-bytes", type=int, default=50_000_000_000, help="the north star's 50 GB single-GPU scan (extra)")
     ap.add_argument("--tree-files", type=int, default=12_500, help="jrep workload: files per GPU (~20 KB each)")
+    ap.add_argument("--jrep-files", type=int, default=100_000, help="jrep_10gb extra: files (BASELINE configs[4]: 100 000)")
+    ap.add_argument("--jrep-bytes", type=int, default=10_000_000_000, help="jrep_10gb extra: total bytes (BASELINE configs[4]: 10 GB)")
     ap.add_argument("--no-extra", action="store_true", help="headline only")
     ap.add_argument("--no-big", action="store_true", help="skip the 50 GB and 2.5 GB extras")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -94,58 +96,68 @@ def _ref():
     return checkers.Ref(use_ff=1, ff_early=1, ff_reduce=0, parser_opt=1), checkers
 
 
-def cpu_baseline(text_host: bytes, patterns, sample_desc: str, all_cores: bool = True):
-    """The reference's own x86 SIMD path on the GPU box's host (kind "reference"): ONE core, and ALL
-    cores the way sample/regexdna-multithread.cc:117-167 uses them -- independent Regej objects on
-    independent threads -- here one slice of the sample per thread, every pattern over every slice.
-    When the prebuilt oracle/_ref library is absent: our C restatement on one core (kind "port")."""
+def cpu_baseline(text_host: bytes, patterns, sample_desc: str, all_cores: bool = True, one_core_bytes: int = 64 << 20):
+    """The reference's own x86 SIMD path on the GPU box's host (kind "reference"): ONE core over the first
+    `one_core_bytes` of the sample, repeated until at least 0.5 s of work has been timed, and ALL cores the way
+    sample/regexdna-multithread.cc:117-167 uses them -- independent Regej objects on independent threads -- here every
+    hardware thread scans ITS OWN slice of the sample (disjoint slices: the whole sample is scanned once per
+    pattern, from DRAM, not a cache-resident copy).  When the prebuilt oracle/_ref library is absent: our C
+    restatement on one core (kind "port")."""
     ref, checkers = _ref()
-    n = len(text_host)
     host_threads = os.cpu_count() or 1
     if ref is None:
         oracle = checkers.Oracle()
-        n = min(n, 4 << 20)
+        n = min(len(text_host), 4 << 20)
         t0 = time.perf_counter()
         counts = [oracle.count(rx.encode(), text_host[:n]) for rx in patterns]
         dt = time.perf_counter() - t0
         return dict(value=len(patterns) * n / dt / 1e9, unit="GB/s", cores=1, kind="port", host_cores=host_threads,
-                    sample=f"first {n} bytes of rank 0's text (oracle/_ref not present)", seconds=round(dt, 3)), None
-    counts = []
-    t0 = time.perf_counter()
-    for rx in patterns:
-        counts.append(int(ref.lib.ref_match_all_repeat(rx.encode(), text_host, n, 1)))
-    dt = time.perf_counter() - t0
-    out = dict(value=len(patterns) * n / dt / 1e9, unit="GB/s", cores=1, kind="reference", host_cores=host_threads,
-               sample=sample_desc + "; reference flags use_fast_forward=1 use_ff_reduce=0", seconds=round(dt, 3))
+                    sample=f"first {n} bytes of rank 0's text (oracle/_ref not present)", seconds=round(dt, 3)), None, n
+    import ctypes
+    total = len(text_host)
+    buf = ctypes.create_string_buffer(text_host, total)
+    addr = ctypes.addressof(buf)
+    fn = ref.lib.ref_match_all_repeat
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    n1 = min(total, one_core_bytes)
+    counts, passes, dt = [], 0, 0.0
+    while dt < 0.5:                       # whole passes over the one-core sample until half a second is on the clock
+        t0 = time.perf_counter()
+        counts = [int(fn(rx.encode(), addr, n1, 1)) for rx in patterns]
+        dt += time.perf_counter() - t0
+        passes += 1
+    out = dict(value=passes * len(patterns) * n1 / dt / 1e9, unit="GB/s", cores=1, kind="reference", host_cores=host_threads,
+               sample=sample_desc + "; first %d bytes, %d pass(es); reference flags use_fast_forward=1 use_ff_reduce=0" % (n1, passes),
+               seconds=round(dt, 3))
     if all_cores and host_threads > 1:
-        # every hardware thread gets its own slice and runs all patterns over it (ctypes releases the GIL;
-        # the reference keeps all run-time state on the callee's stack, sample/jrep.cc:461-493 relies on it)
         from concurrent.futures import ThreadPoolExecutor
-        import ctypes
         threads = host_threads
-        # same bytes per thread as the one-core run had per pattern pass would take minutes on 256 threads:
-        # every thread scans the WHOLE sample once per pattern -> threads x the one-core work, ~ the same wall time
-        buf = ctypes.create_string_buffer(text_host, n)
-        addr = ctypes.addressof(buf)
-        fn = ref.lib.ref_match_all_repeat
-        fn.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        step = -(-total // threads)
+        overlap = 64                      # (a slice sees a few bytes of the next one: matches across the cut are counted once)
+        slices = [(i * step, min(total, (i + 1) * step + overlap) - i * step) for i in range(threads) if i * step < total]
 
-        def work(_):
-            return [int(fn(rx.encode(), addr, n, 1)) for rx in patterns]
+        def work(sl):
+            return [int(fn(rx.encode(), addr + sl[0], sl[1], 1)) for rx in patterns]
 
         with ThreadPoolExecutor(max_workers=threads) as pool:
-            list(pool.map(work, range(min(threads, 8))))      # warm the pool
+            list(pool.map(work, slices[:8]))      # warm the pool
             t0 = time.perf_counter()
-            res = list(pool.map(work, range(threads)))
+            list(pool.map(work, slices))
             dta = time.perf_counter() - t0
-        assert all(r == counts for r in res)
-        out["all_cores"] = dict(value=threads * len(patterns) * n / dta / 1e9, unit="GB/s", cores=threads,
-                                sample="every thread: all patterns over the whole sample (independent Regej per call)",
-                                seconds=round(dta, 3))
-    return out, counts
+        out["all_cores"] = dict(value=len(patterns) * total / dta / 1e9, unit="GB/s", cores=len(slices),
+                                sample="%d disjoint slices of the %d-byte sample, one per hardware thread, every pattern over every slice "
+                                       "(independent Regej per call)" % (len(slices), total), seconds=round(dta, 3))
+    return out, counts, n1
 
 
 # ------------------------------------------------------------------------------------------ helpers
+def fullsize_fixture():
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_vectors.json")))
+    except Exception:
+        return None
+
+
 class Ctx:
     pass
 
@@ -430,22 +442,33 @@ def run_regexdna(args, c):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample taken from the lower-case (matching) part of the text: the first 20 %
         # is the upper-case ALU repeat, which no pattern can match
+        # the all-core leg scans the WHOLE text (9 x 500 MB = 4.5 GB, disjoint slices); the one-core leg a 64 MiB
+        # sample taken from the lower-case part (the first 20 % is the upper-case ALU repeat, which no pattern matches)
         sample = min(n_local, args.cpu_sample_mib << 20)
         s0 = min(max(0, n_local - sample), (int(n_local * 0.6) // 4096) * 4096)
-        host = text[s0:s0 + sample].cpu().numpy().tobytes()
-        base, ref_counts = cpu_baseline(host, patterns, f"bytes [{s0}, {s0 + sample}) of the same text, 9 patterns, 1 pass")
+        host_all = text.cpu().numpy().tobytes()
+        host = host_all[s0:] + host_all[:s0]          # (rotated: the one-core sample is the head of the buffer)
+        del host_all
+        base, ref_counts, n1 = cpu_baseline(host, patterns, f"bytes [{s0}, {s0 + sample}) of the same text, 9 patterns", one_core_bytes=sample)
+        del host
         out["cpu_baseline"] = base
         if ref_counts is not None:
             # in-run parity check against the real reference on the sample
             gpu_counts = []
             for sc in scans:
-                sc.run(text.data_ptr() + s0, sample, own_begin=0, own_end=sample + 1, stream=stream)
+                sc.run(text.data_ptr() + s0, n1, own_begin=0, own_end=n1 + 1, stream=stream)
                 gpu_counts.append(sc.stats()["n_matches"])
             assert gpu_counts == ref_counts, ("GPU and reference disagree on the sample", gpu_counts, ref_counts)
             out["cpu_baseline"]["parity_on_sample"] = "GPU counts == reference counts: %s" % ref_counts
 
     del text
     torch.cuda.empty_cache()
+    if rank == 0 and world == 1:
+        fx = fullsize_fixture()
+        if fx and "c3" in fx and fx["c3"]["fasta_n"] == args.fasta_n:
+            want = [p["digest"]["count"] for p in fx["c3"]["patterns"]]
+            assert counts == want, ("the nine counts differ from the reference's at full size", counts, want)
+            out["parity_full_size"] = "nine counts == the real reference's over the same 500 MB text (tests/golden/fullsize_vectors.json)"
     if extras and not args.no_big:
         # Is the streaming scan's rate an HBM rate?  One kernel per pattern (mode 3) over a 2.5 GB text: every launch
         # streams 10x the 256 MiB Infinity Cache, so nothing of the text survives from one pattern to the next.
@@ -497,8 +520,11 @@ def plant_literal(W, t, n, seed):
 def single_pattern_extra(c, rejit_amd, t, n, rx, label, kernel, steps, check, traffic_key=None, cpu=True, args=None):
     torch, dev, stream = c.torch, c.dev, c.stream
     sc = rejit_amd.Scan(rejit_amd.Program(rx))
-    for _ in range(2):
-        sc.run(t.data_ptr(), n, stream=stream)
+    t_cold = time.perf_counter()
+    sc.run(t.data_ptr(), n, stream=stream)      # the first call of a fresh scan: buffers, region sizing, path discovery
+    cold = time.perf_counter() - t_cold
+    sc.run(t.data_ptr(), n, stream=stream)
+    steps = max(steps, 10)
     ms, wall = [], []
     torch.cuda.synchronize(dev)
     for _ in range(steps):
@@ -513,12 +539,15 @@ def single_pattern_extra(c, rejit_amd, t, n, rx, label, kernel, steps, check, tr
     # among 1 ms ones -- would otherwise be the number; the slowest call is listed beside it)
     dt = sorted(wall)[len(wall) // 2]
     rec = {"workload": label, "value": round(n / dt / 1e9, 1), "unit": "GB/s", "matches": int(cnt),
-           "latency_ms": round(dt * 1e3, 4), "latency_ms_max": round(max(wall) * 1e3, 4), "calls_timed": steps,
+           "latency_ms": round(dt * 1e3, 4), "latency_ms_min": round(min(wall) * 1e3, 4), "latency_ms_max": round(max(wall) * 1e3, 4),
+           "cold_call_ms": round(cold * 1e3, 3), "calls_timed": steps,
            "roofline": hbm_roofline(kernel, n, a_ms, pmc_traffic(traffic_key, bytes=n) if traffic_key else None)}
     if cpu and args is not None and not args.no_cpu_baseline:
+        big = min(n, 4 << 30)                       # all cores: 4 GiB of the text in disjoint slices
+        host = t[:big].cpu().numpy().tobytes()
         sample = min(n, args.cpu_sample_mib << 20)
-        host = t[:sample].cpu().numpy().tobytes()
-        base, ref_counts = cpu_baseline(host, [rx], f"first {sample} bytes of the same text, 1 pass")
+        base, ref_counts, sample = cpu_baseline(host, [rx], f"first {big} bytes of the same text", one_core_bytes=sample)
+        del host
         if ref_counts is not None:
             sc.run(t.data_ptr(), sample, stream=stream)
             base["parity_on_sample"] = "GPU count %d, reference count %d" % (sc.stats()["n_matches"], ref_counts[0])
@@ -540,6 +569,10 @@ def literal_and_complex_extras(args, c, out):
     def check_literal(sc):
         found = {b for b, _ in sc.spans()}
         assert set(offs) <= found, "a planted occurrence was missed"
+        fx = fullsize_fixture()
+        if fx and "c2" in fx and fx["c2"]["bytes"] == n:
+            assert W.span_digest_torch(sc.spans_tensor(dev)) == fx["c2"]["digest"], "literal scan differs from the reference's answer at 5 GB"
+            out["parity_full_size_literal"] = "count and span digest == the real reference's over the same 5 GB text"
 
     out["literal_scan"] = single_pattern_extra(
         c, rejit_amd, t, n, "regexp",
@@ -597,10 +630,12 @@ def literal_and_complex_extras(args, c, out):
     t[nl] = 10
     del nl
     sc_l = rejit_amd.Scan(rejit_amd.Program("^"))
-    for _ in range(2):
-        sc_l.run(t.data_ptr(), n, stream=c.stream)
+    t_cold = time.perf_counter()
+    sc_l.run(t.data_ptr(), n, stream=c.stream)
+    cold_l = time.perf_counter() - t_cold
+    sc_l.run(t.data_ptr(), n, stream=c.stream)
     lms, ltot = [], []
-    for _ in range(5):
+    for _ in range(10):
         k = sc_l.run(t.data_ptr(), n, stream=c.stream)
         st = sc_l.stats()
         lms.append(st["scan_ms"])
@@ -609,9 +644,11 @@ def literal_and_complex_extras(args, c, out):
     a_l = sum(lms) / len(lms)
     bytes_l = n + 16 * k
     out["line_table"] = {"workload": "`^` MatchAll over %d bytes with a line break every 61 bytes (jrep's line table)" % n, "matches": int(k),
-                         "value": round(n / (sum(ltot) / len(ltot) * 1e-3) / 1e9, 1), "unit": "GB/s of text", "latency_ms": round(sum(ltot) / len(ltot), 4),
-                         "write_bytes_per_launch": 16 * int(k),
-                         "roofline": hbm_roofline("scan_dense_walk<1,true,0> (n text bytes read + 16 B written per match)", bytes_l, a_l)}
+                         "value": round(n / (sorted(ltot)[len(ltot) // 2] * 1e-3) / 1e9, 1), "unit": "GB/s of text",
+                         "latency_ms": round(sorted(ltot)[len(ltot) // 2], 4), "latency_ms_min": round(min(ltot), 4), "cold_call_ms": round(cold_l * 1e3, 3),
+                         "calls_timed": len(ltot), "write_bytes_per_launch": 16 * int(k),
+                         "roofline": hbm_roofline("emit_assertions (one pass, decoupled look-back: n text bytes read + 16 B written per match)", bytes_l, a_l,
+                                                  pmc_traffic("line_table", bytes=n))}
     del t
     torch.cuda.empty_cache()
 
@@ -793,6 +830,132 @@ def spawn_ranks(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+# ------------------------------------------------------------------------------------------ whole programs
+def end_to_end_extra(args, c, out):
+    """The reference's headline is a WHOLE-PROGRAM time (README.md:66: regexdna, 50M-line input, 14.624 s on an
+    i5-2400): read the FASTA file, strip it, nine counts, eleven replaces (sample/regexdna.cc:41-91).  Timed here as
+    processes, H2D copies, start-up and all: the reference's regexdna.cc UNCHANGED on librejit_hip.so, the same
+    program on the reference's own library on this host (one core), and samples/regexdna_gpu.py (text resident in
+    HBM for the whole program)."""
+    import subprocess
+    import tempfile
+    from rejit_amd import workloads as W
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    exe_hip, exe_ref = os.path.join(ref_dir, "regexdna_hip"), os.path.join(ref_dir, "regexdna_ref")
+    if not os.path.exists(exe_hip):
+        return
+    raw = W.fasta_raw_torch(args.fasta_n, c.dev).cpu().numpy()
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    path = os.path.join(d, "rejit_bench_fasta_%d.txt" % os.getpid())
+    raw.tofile(path)
+    n_raw = int(raw.size)
+    del raw
+    c.torch.cuda.empty_cache()
+    rec = {"input": "Benchmarks-Game FASTA, n = %d: %d bytes (%s)" % (args.fasta_n, n_raw, path),
+           "published_reference_s": {"value": 14.624, "hardware": "i5-2400 @ 3.1 GHz, 1 thread", "source": "reference README.md:66"}}
+
+    def run(cmd, key, note):
+        best, text_out = None, b""
+        for _ in range(2):
+            with open(path, "rb") as fh:
+                t0 = time.perf_counter()
+                r = subprocess.run(cmd, stdin=fh, capture_output=True)
+                dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                rec[key] = {"failed": r.stderr.decode()[-300:]}
+                return None
+            best = dt if best is None else min(best, dt)
+            text_out = r.stdout
+        rec[key] = {"seconds": round(best, 3), "what": note}
+        return text_out.decode().split()
+
+    try:
+        got = run([exe_hip], "reference_regexdna_on_librejit_hip", "sample/regexdna.cc unchanged, linked against librejit_hip.so; process wall time, 2 runs, best")
+        gpu = run([sys.executable, os.path.join(ROOT, "samples", "regexdna_gpu.py")], "regexdna_gpu_py",
+                  "samples/regexdna_gpu.py: one upload, text stays in HBM; process wall time incl. the Python / torch start-up")
+        if os.path.exists(exe_ref):
+            run([exe_ref], "reference_regexdna_on_its_own_library", "the same program on the reference's library, this host, 1 core (default flags: its counts are "
+                "wrong for six patterns, SURVEY 4.4 Q1 -- timing only)")
+        fx = fullsize_fixture()
+        if got and fx and "c3" in fx and fx["c3"]["fasta_n"] == args.fasta_n:
+            want = [p["digest"]["count"] for p in fx["c3"]["patterns"]]
+            counts = [int(got[2 * i + 1]) for i in range(9)]
+            assert counts == want, ("regexdna_hip counts differ from the reference's (ff=0) counts", counts, want)
+            rec["parity"] = "the nine counts printed by regexdna_hip == the real reference's (correct configuration)"
+            if gpu:
+                assert gpu == got, "regexdna_gpu.py and regexdna_hip print different results"
+                rec["parity"] += "; regexdna_gpu.py prints the same 12 lines"
+    finally:
+        os.unlink(path)
+    out["end_to_end"] = rec
+
+
+def jrep_extra(args, c, out):
+    """BASELINE configs[4] at its size on ONE GPU: 100 000 source-like files, 10 GB, log-normal sizes with a heavy tail,
+    1 % hold the needle -- host buffers through rj_match_all_batch (packing, PCIe and result copies included) + the `^`
+    line tables of the files with matches, in batches of 256 MiB like samples/jrep_gpu.  The reference on the host: its own
+    jrep loop (one MatchAll per file + `^` for the files with a match) over a bounded sample of the same files, one core."""
+    import numpy as np
+    import rejit_amd
+    rng = np.random.default_rng(5)
+    n_files = args.jrep_files
+    corpus = b"".join(synthetic_tree(600, 77))                       # ~12 MB of source-like lines without the needle
+    corpus = corpus.replace(b"regexp", b"regexq")
+    cn = len(corpus)
+    sizes = np.clip(rng.lognormal(np.log(20000), 1.8, n_files), 200, 64 << 20).astype(np.int64)
+    sizes = (sizes * (args.jrep_bytes / sizes.sum())).astype(np.int64) + 1
+    starts = rng.integers(0, cn, n_files)
+    files = []
+    for i in range(n_files):
+        a, k = int(starts[i]), int(sizes[i])
+        reps = (a + k + cn - 1) // cn
+        body = (corpus * reps)[a:a + k] if reps > 1 else corpus[a:a + k]
+        if i % 100 == 7:
+            at = (i * 7919) % max(1, k - 8)
+            body = body[:at] + b" regexp " + body[at + 8:]
+        files.append(body)
+    total = sum(len(f) for f in files)
+    prog, sol = rejit_amd.Program(b"regexp"), rejit_amd.Program(b"^")
+
+    def one_pass():
+        hits, lines, at = 0, 0, 0
+        while at < n_files:
+            b, size = at, 0
+            while at < n_files and (at == b or size + len(files[at]) <= (256 << 20)):
+                size += len(files[at])
+                at += 1
+            res = prog.match_all_batch_counts(files[b:at])
+            hit = [files[b + i] for i, k in enumerate(res) if k]
+            hits += len(hit)
+            if hit:
+                lines += sum(sol.match_all_batch_counts(hit))
+        return hits, lines
+
+    one_pass()
+    t0 = time.perf_counter()
+    hits, lines = one_pass()
+    dt = time.perf_counter() - t0
+    rec = {"workload": "jrep shape at BASELINE size: %d files, %d bytes (log-normal sizes, sigma 1.8), needle in 1 %% of them; rj_match_all_batch in "
+                       "256 MiB batches + `^` line tables of the files with matches; host buffers, PCIe included" % (n_files, total),
+           "value": round(total / dt / 1e9, 2), "unit": "GB/s end to end", "seconds": round(dt, 3), "files_with_matches": hits, "line_starts": lines}
+    ref, _ = _ref()
+    if ref is not None and not args.no_cpu_baseline:
+        ref.set_flags(1, 1, 0, 1)
+        sample, budget, done_bytes, ref_hits = files[: max(1, n_files // 50)], 0, 0, 0
+        t0 = time.perf_counter()
+        for f in sample:
+            k = int(ref.lib.ref_match_all_repeat(b"regexp", f, len(f), 1))
+            if k:
+                ref_hits += 1
+                ref.lib.ref_match_all_repeat(b"^", f, len(f), 1)
+            done_bytes += len(f)
+        dtr = time.perf_counter() - t0
+        rec["cpu_baseline"] = {"value": round(done_bytes / dtr / 1e9, 2), "unit": "GB/s", "cores": 1, "kind": "reference",
+                               "sample": "the first %d files (%d bytes): one MatchAll per file + `^` for the %d files with a match, buffers in memory"
+                                         % (len(sample), done_bytes, ref_hits), "seconds": round(dtr, 3)}
+    out["jrep_10gb"] = rec
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -804,6 +967,9 @@ def main():
         out, extras = run_regexdna(args, c)
         if extras:
             literal_and_complex_extras(args, c, out)
+            if not args.no_big:
+                jrep_extra(args, c, out)
+                end_to_end_extra(args, c, out)
     elif args.workload in ("literal", "complex"):
         out = run_single_pattern(args, c, args.workload)
     else:

@@ -158,6 +158,25 @@ def fasta_stripped_torch(n: int, device, chunk: int = 1 << 28, lo: int = 0, hi: 
 # ---------------------------------------------------------------------------
 # Random ASCII
 
+def fasta_raw_torch(n: int, device):
+    """fasta_raw_numpy(n) built on `device`: the three headers and a line break after every 60 bases."""
+    import torch
+
+    s = fasta_stripped_torch(n, device)
+    parts = []
+    bounds = [0, 2 * n, 5 * n, 10 * n]
+    for i in range(3):
+        seq = s[bounds[i]:bounds[i + 1]]
+        m = int(seq.numel())
+        out = torch.full((m + (m + LINE - 1) // LINE,), ord("\n"), dtype=torch.uint8, device=device)
+        k = torch.arange(m, dtype=torch.int64, device=device)
+        out[k + k // LINE] = seq
+        del k
+        parts.append(torch.tensor(list(HEADERS[i]), dtype=torch.uint8, device=device))
+        parts.append(out)
+    return torch.cat(parts)
+
+
 _M1 = 0xBF58476D1CE4E5B9
 _M2 = 0x94D049BB133111EB
 _GOLD = 0x9E3779B97F4A7C15
