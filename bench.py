@@ -300,10 +300,17 @@ def run_regexdna(args, c):
         sp = sc.spans()
         return k, (to_global((sp[0][0], sp[0][1], sp[-1][0], sp[-1][1])) if sp else None)
 
+    exchange = sharding.CarryExchange(len(patterns), rank, world, dist, dev, c.cdev) if (world > 1 and use_multi) else None
+
+    def rerun_local(i, cur, prev_end, have):
+        sep_scans[i].run(text_ptr, n_local, own_begin=own_lo, own_end=own_hi, carry_cur=cur, carry_prev_end=prev_end, have_prev=have, stream=stream)
+
     def step(record):
-        if world > 1:
-            # exchange step of the path: per pattern the count and the first / last match of every shard
-            # (45 integers per rank, one all_gather over RCCL/xGMI); totals are identical on every rank
+        if exchange is not None:
+            # exchange step of the path: per pattern 8 integers per rank (count, first / last match, carry used) written by a
+            # kernel, one all_gather over RCCL/xGMI, the decision taken by a kernel: no host tensors, one extra synchronise
+            counts = exchange.counts(multi_sep, local_counts, rerun_local, vis_lo, stream)
+        elif world > 1:
             counts = sharding.multi_pattern_counts(run_local, rerun_one, len(patterns), rank, world, dist, c.cdev)
         else:
             counts = local_counts()
@@ -322,7 +329,7 @@ def run_regexdna(args, c):
                     scanned / elapsed / 1e9, elapsed,
                     {"workload": "regexdna: 9 x MatchAllCount over the stripped 50M-line FASTA (BASELINE configs[2])",
                      "fasta_n_per_gpu": args.fasta_n, "text_bytes_per_gpu": int(own_bytes), "patterns": len(patterns),
-                     "sharding": "contiguous byte ranges + %d-byte halo; all_gather of (count, first, last match) per pattern per step"
+                     "sharding": "contiguous byte ranges + %d-byte halo; all_gather of 8 integers per pattern (count, first / last match, carry used) per step, rows and decision on the device"
                                  % (max_len - 1),
                      "calls": "rj_multi_run mode 0: one pass over the text for the nine patterns (plane_scan) + classify + gather, one synchronise" if use_multi else "9 x rj_scan_run per step"})
     out["matches_per_s"] = round(total_matches * args.steps / elapsed, 1)

@@ -178,6 +178,19 @@ rj_scan* rj_multi_scan(rj_multi* multi, int i);
  * match begins before its left neighbour's last end re-runs that pattern with rj_scan_run(rj_multi_scan(m, i),
  * ..., carry) -- 32 bytes per pattern instead of the match list. */
 int rj_multi_bounds(rj_multi* multi, uint64_t* bounds, void* hip_stream);
+/* The rows of an exchange that stays on the device (one process per GPU, torch.distributed / RCCL): d_rows[8 * i ..]
+ * = what a rank contributes per pattern to the carry exchange between shards: count | first begin, first end (written
+ * only when first_round != 0: the result under the empty carry) | last begin, last end (-1 without a match) | the
+ * carry the result was selected under (cur, prev_end, have: zeroed when first_round != 0, kept by the caller when
+ * it re-runs a pattern); begins and ends plus `offset` (the shard's position in the whole text).  Written by a kernel
+ * queued on hip_stream -- no synchronisation, the collective that gathers the rows is queued behind it. */
+int rj_multi_bounds_device(rj_multi* multi, int64_t offset, int first_round, int64_t* d_rows, void* hip_stream);
+/* The decision every rank takes from the gathered rows d_all[world][n_patterns][8] = count, first begin / end under
+ * the EMPTY carry, current last begin / end, carry the current result was selected under (cur, prev_end, have):
+ * out (device or pinned host memory, 4 * n_patterns + 1 integers) = job-wide counts | 1 where `rank` has to select
+ * the pattern again | the (cur, prev_end) to select it under | 1 when any rank re-runs anything.  One kernel on
+ * hip_stream; the caller synchronises once per round. */
+int rj_carry_decide(const int64_t* d_all, int world, int rank, int n_patterns, int64_t* out, void* hip_stream);
 /* mode 0 (default): fuse when possible; mode 1: never fuse -- every pattern scans the whole text on its own,
  * all of them in ONE launch when the patterns have the regexdna shape (scan_windows_train), else one kernel
  * per pattern back to back on the caller's stream; mode 2: one kernel per pattern, alternating between the

@@ -123,7 +123,8 @@ C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_er
                  "rj_scan_match_full", "rj_device_count", "rj_replace_all", "rj_free_text", "rj_scan_replace",
                  "rj_match_all_batch", "rj_multi_create", "rj_multi_destroy", "rj_multi_run", "rj_multi_scan",
                  "rj_multi_scan_ms", "rj_scan_start", "rj_scan_finish", "rj_multi_set_mode", "rj_multi_run_range",
-                 "rj_multi_bounds", "rj_batch_separator", "rj_match_all_packed", "rj_host_alloc", "rj_host_free"]
+                 "rj_multi_bounds", "rj_batch_separator", "rj_match_all_packed", "rj_host_alloc", "rj_host_free",
+                 "rj_multi_bounds_device", "rj_carry_decide"]
 
 
 def load_library():
@@ -166,6 +167,8 @@ def load_library():
     L.rj_multi_scan_ms.argtypes = [vp]
     L.rj_multi_set_mode.argtypes = [vp, ctypes.c_int]
     L.rj_multi_bounds.argtypes = [vp, _u64p, vp]
+    L.rj_multi_bounds_device.argtypes = [vp, ctypes.c_int64, ctypes.c_int, vp, vp]
+    L.rj_carry_decide.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
     L.rj_scan_destroy.argtypes = [vp]
     L.rj_scan_run.restype = i64
     L.rj_scan_run.argtypes = [vp, vp, u64, u64, u64, u64, u64, ctypes.c_int, vp]
@@ -186,6 +189,13 @@ def load_library():
     L.rj_device_count.restype = ctypes.c_int
     _lib = L
     return L
+
+
+def carry_decide(all_rows, world: int, rank: int, n_patterns: int, out, stream: int = 0) -> None:
+    """rj_carry_decide on tensors: all_rows (world, P, 8) int64 on the device, out (4 P + 1) int64 (device or pinned)."""
+    lib = load_library()
+    _check(lib.rj_carry_decide(ctypes.c_void_p(all_rows.data_ptr()), world, rank, n_patterns, ctypes.c_void_p(out.data_ptr()),
+                               ctypes.c_void_p(stream)))
 
 
 def device_count() -> int:
@@ -409,6 +419,13 @@ class MultiScan:
 
     def scan_ms(self) -> float:
         return float(self._lib.rj_multi_scan_ms(self._h))
+
+    def bounds_rows(self, rows_tensor, offset: int = 0, first_round: bool = True, stream: int = 0) -> None:
+        """rj_multi_bounds_device: this rank's rows of the carry exchange (8 integers per pattern, include/rejit_hip.h)
+        into the (P, 8) int64 device tensor `rows_tensor`; queued on `stream`, nothing waits."""
+        assert rows_tensor.dtype.itemsize == 8 and rows_tensor.numel() >= 8 * len(self.programs) and rows_tensor.is_contiguous()
+        _check(self._lib.rj_multi_bounds_device(self._h, ctypes.c_int64(offset), int(first_round), ctypes.c_void_p(rows_tensor.data_ptr()),
+                                                ctypes.c_void_p(stream)))
 
     def bounds(self, stream: int = 0) -> List[Optional[Tuple[int, int, int, int]]]:
         """Per pattern (first begin, first end, last begin, last end) of the last run, None without a

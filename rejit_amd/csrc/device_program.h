@@ -174,6 +174,15 @@ RJ_HD int rj_context(const Text& t, uint64_t n, uint64_t p) {
 // carry scan).  `abort` (may be null) is polled now and then: once any walk of the run has overrun
 // the run is void, and the others need not finish.
 constexpr uint64_t kMaxSimSteps = 1ull << 20;
+// A walk that passes kLongWalk bytes reports itself (once) in the run's long-walk counter, kLongWalksAfterOverrun
+// slots behind the overrun flag `abort` points at; the kLongWalkBudget-th such walk of a run voids the run like one
+// that reaches P.max_walk.  A FEW long candidates -- a window hit on a very long line -- are cheaper to walk than to
+// hand the text to the carry scan, which is why max_walk is 64 Ki bytes in windows mode; but `a.*b` over a text
+// without line breaks has a long candidate at every `a`, and all of them walked 64 Ki dependent steps (~0.8 us each
+// from device memory: 54 ms) before the first one reached the limit.
+constexpr uint32_t kLongWalk = 4096;
+constexpr unsigned long long kLongWalkBudget = 64;
+constexpr int kLongWalksAfterOverrun = 4;
 
 template <int NQ, class Text>
 RJ_HD bool rj_lane_longest(const DevProgram& P, const Text& t, uint64_t n, uint64_t s, uint64_t* end,
@@ -230,6 +239,15 @@ RJ_HD bool rj_lane_longest(const DevProgram& P, const Text& t, uint64_t n, uint6
       break;
     }
     if (abort != nullptr && ((p - s) & 255u) == 0 && *abort != 0) break;  // the run is void already
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (abort != nullptr && p - s == kLongWalk && P.max_walk > kLongWalk) {
+      unsigned long long* long_walks = const_cast<unsigned long long*>(abort) + kLongWalksAfterOverrun;
+      if (atomicAdd(long_walks, 1ull) + 1 >= kLongWalkBudget) {
+        *overrun = true;
+        break;
+      }
+    }
+#endif
     uint64_t T[NQ];
     uint64_t carry = 0;
     for (int q = 0; q < NQ; q++) {

@@ -606,10 +606,12 @@ static int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb,
       s->host_counters[kCntUnordered] = 0;  // the kernel below writes the pinned block itself
       s->host_counters[kCntAdjacent] = 0;
       s->host_counters[kCntConflict] = 0;
-      // many candidates per region expected (the previous run had them): lay out first, then copy
-      // with a wave per region
+      // many candidates per region expected (the previous run had them, or the pattern is dense: its FIRST run
+      // over a text has no history, and the one-launch form took 20 ms for the 8.4 M matches of `x*` over 16 MiB
+      // where the second launch costs microseconds when there is little to copy): lay out first, then copy with a
+      // wave per region
       uint64_t *off_scratch = nullptr, *prev_scratch = nullptr;
-      if (s->hits_hint > static_cast<uint64_t>(geo.n_regions) * 16) {
+      if (dense_walk || s->hits_hint > static_cast<uint64_t>(geo.n_regions) * 16) {
         RJ_HIP(s->hit_offsets.reserve((static_cast<size_t>(geo.n_regions) + 1) * sizeof(uint64_t)));
         RJ_HIP(s->scan_a.reserve(static_cast<size_t>(geo.n_regions) * sizeof(uint64_t)));
         off_scratch = s->hit_offsets.as<uint64_t>();

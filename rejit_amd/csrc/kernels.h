@@ -14,7 +14,9 @@ enum { kCntCands = 0, kCntFinal = 1, kCntOverflow = 2, kCntAdjacent = 3, kCntHit
   kCntUnordered = 7,  // check_and_interleave: the candidates are not already the result
   kCntConflict = 8,   // behind mode: a candidate hidden by an earlier match ends after it (the run is repeated dense)
   kCntSharedMax = 9,  // plane scan (plane_scan.hip): fullest SHARED candidate region when one overflowed, else 0
-  kCntSize = 10 };
+  kCntLongWalks = 10, // walks of the run that went past kLongWalk bytes (device_program.h: rj_lane_longest)
+  kCntSize = 11 };
+static_assert(kCntLongWalks - kCntOverrun == kLongWalksAfterOverrun, "rj_lane_longest finds the long-walk counter behind the overrun flag");
 
 constexpr uint64_t kNoMatch = ~0ull;  // cand_end of a hit at which nothing matches
 
@@ -146,6 +148,8 @@ struct BoundsParams {
   uint64_t count[kMaxFused];
 };
 void launch_first_last(const BoundsParams& a, uint64_t* pinned_bounds, hipStream_t st);
+void launch_bounds_rows(const BoundsParams& a, int64_t offset, int first_round, int64_t* d_rows, hipStream_t st);
+void launch_carry_decide(const int64_t* d_all, int world, int rank, int n_patterns, int64_t* out, hipStream_t st);
 void launch_scan_windows_fused(const FusedParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 
 // ---- plane scan (plane_scan.hip): the one-pass scan for SEVERAL patterns whose 8-byte windows all lie within

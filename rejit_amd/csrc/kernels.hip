@@ -1405,6 +1405,93 @@ void launch_first_last(const BoundsParams& a, uint64_t* pinned_bounds, hipStream
   hipLaunchKernelGGL(first_last_kernel, dim3(1), dim3(64), 0, st, a, pinned_bounds);
 }
 
+// The same as rows of the carry exchange between shards (rejit_amd/sharding.py: multi_pattern_counts_device), left in
+// device memory, plus an offset that turns the shard's local offsets into global ones.  rows[p] = the 8 integers a
+// rank contributes per pattern: count | first begin, first end (written in the FIRST round only: the result under the
+// empty carry) | last begin, last end (-1 without a match) | the carry the result was selected under (cur, prev_end,
+// have: zeroed in the first round, kept up to date by the caller when it re-runs a pattern).  Nothing waits for it:
+// the collective that follows is queued on the same stream.
+__global__ void bounds_rows_kernel(BoundsParams a, int64_t offset, int first_round, int64_t* rows) {
+  const int p = threadIdx.x;
+  if (p >= a.n_lists) return;
+  const uint64_t n = a.count[p];
+  const uint64_t* r = a.spans[p];
+  rows[8 * p + 0] = static_cast<int64_t>(n);
+  if (first_round) {  // (selected under the empty carry: the first match every later round is judged by)
+    rows[8 * p + 1] = n ? static_cast<int64_t>(r[0]) + offset : -1;
+    rows[8 * p + 2] = n ? static_cast<int64_t>(r[1]) + offset : -1;
+    rows[8 * p + 5] = rows[8 * p + 6] = rows[8 * p + 7] = 0;
+  }
+  rows[8 * p + 3] = n ? static_cast<int64_t>(r[2 * (n - 1)]) + offset : -1;
+  rows[8 * p + 4] = n ? static_cast<int64_t>(r[2 * (n - 1) + 1]) + offset : -1;
+}
+
+void launch_bounds_rows(const BoundsParams& a, int64_t offset, int first_round, int64_t* d_rows, hipStream_t st) {
+  hipLaunchKernelGGL(bounds_rows_kernel, dim3(1), dim3(64), 0, st, a, offset, first_round, d_rows);
+}
+
+// The decision step of the carry exchange, on the device: all[r][p] = count, first begin / end under the EMPTY carry,
+// current last begin / end, the carry the current result was selected under (cur, prev_end, have) -- 8 integers per
+// rank and pattern, as gathered.  out: [0, P) the job-wide counts; [P, 2P) 1 when `rank` has to select pattern p again
+// (must_rerun, sharding.py); [2P, 4P) the carry (cur, prev_end) to select it under; [4P] 1 when ANY rank re-runs
+// anything (another round is needed).
+__global__ void carry_decide_kernel(const int64_t* all, int world, int rank, int n_patterns, int64_t* out) {
+  const int p = threadIdx.x;
+  __shared__ int any_again;
+  if (threadIdx.x == 0) any_again = 0;
+  __syncthreads();
+  if (p < n_patterns) {
+    int64_t total = 0;
+    int64_t carry_cur = 0, carry_pe = 0;
+    bool have = false, mine_again = false, again = false;
+    int64_t my_cur = 0, my_pe = 0;
+    for (int r = 0; r < world; r++) {
+      const int64_t* row = all + (static_cast<int64_t>(r) * n_patterns + p) * 8;
+      total += row[0];
+      if (r > 0) {
+        // carry into rank r = the last match of the nearest rank before it that has one (carried along below)
+        const int64_t used_cur = row[5], used_pe = row[6];
+        const bool used_have = row[7] != 0;
+        const bool same = (have == used_have) && (!have || (carry_cur == used_cur && carry_pe == used_pe));
+        bool rerun = false;
+        if (!same) {
+          if (used_have) {
+            rerun = true;  // it re-ran already: its result depends on the carry it used
+          } else if (row[1] >= 0 && have) {
+            const int64_t fb = row[1], fe = row[2];
+            rerun = fb < carry_cur || (fb == fe && carry_pe == fb);
+          }
+        }
+        if (rerun) {
+          again = true;
+          if (r == rank) {
+            mine_again = true;
+            my_cur = have ? carry_cur : 0;
+            my_pe = have ? carry_pe : 0;
+          }
+        }
+      }
+      if (row[3] >= 0) {
+        const int64_t lb = row[3], le = row[4];
+        carry_cur = le > lb ? le : lb + 1;
+        carry_pe = le;
+        have = true;
+      }
+    }
+    out[p] = total;
+    out[n_patterns + p] = mine_again ? 1 : 0;
+    out[2 * n_patterns + 2 * p] = my_cur;
+    out[2 * n_patterns + 2 * p + 1] = my_pe;
+    if (again) atomicOr(&any_again, 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) out[4 * n_patterns] = any_again;
+}
+
+void launch_carry_decide(const int64_t* d_all, int world, int rank, int n_patterns, int64_t* out, hipStream_t st) {
+  hipLaunchKernelGGL(carry_decide_kernel, dim3(1), dim3(64), 0, st, d_all, world, rank, n_patterns, out);
+}
+
 // pairs -> begin[] / end[] for the selection kernels (only when the pairs are not the result yet)
 __global__ void split_pairs(const uint64_t* pairs, const unsigned long long* n_ptr, uint64_t* keys, uint64_t* vals) {
   const uint64_t n = *n_ptr;

@@ -667,6 +667,29 @@ int rj_multi_bounds(rj_multi* m, uint64_t* bounds, void* hip_stream) {
   return RJ_OK;
 }
 
+int rj_multi_bounds_device(rj_multi* m, int64_t offset, int first_round, int64_t* d_rows, void* hip_stream) {
+  ErrnoGuard errno_guard;
+  if (!m || !d_rows) return fail(RJ_BAD_ARGUMENT, "null argument");
+  const int P = static_cast<int>(m->scans.size());
+  BoundsParams bp{};
+  bp.n_lists = P;
+  for (int p = 0; p < P; p++) {
+    bp.spans[p] = m->scans[static_cast<size_t>(p)]->result;
+    bp.count[p] = bp.spans[p] ? m->scans[static_cast<size_t>(p)]->result_count : 0;
+  }
+  launch_bounds_rows(bp, offset, first_round, d_rows, static_cast<hipStream_t>(hip_stream));
+  RJ_HIP(hipGetLastError());
+  return RJ_OK;
+}
+
+int rj_carry_decide(const int64_t* d_all, int world, int rank, int n_patterns, int64_t* out, void* hip_stream) {
+  ErrnoGuard errno_guard;
+  if (!d_all || !out || world < 1 || rank < 0 || rank >= world || n_patterns < 1 || n_patterns > 64) return fail(RJ_BAD_ARGUMENT, "bad argument");
+  launch_carry_decide(d_all, world, rank, n_patterns, out, static_cast<hipStream_t>(hip_stream));
+  RJ_HIP(hipGetLastError());
+  return RJ_OK;
+}
+
 int rj_multi_set_mode(rj_multi* m, int mode) {
   if (!m || mode < 0 || mode > 3) return fail(RJ_BAD_ARGUMENT, "bad argument");
   m->mode = mode;

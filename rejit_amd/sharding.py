@@ -265,6 +265,58 @@ def multi_pattern_counts(run_local, rerun_one, n_patterns: int, rank: int, world
     raise RuntimeError("carry exchange did not converge")
 
 
+class CarryExchange:
+    """The same exchange with the rows left on the device (what bench.py's regexdna step uses under RCCL): per round
+    ONE kernel that writes this rank's rows (rj_multi_bounds_device), ONE all_gather of (P, 8) integers, ONE kernel
+    that takes the decision for this rank from the gathered rows (rj_carry_decide) into pinned host memory, and ONE
+    synchronise -- no tensors built on the host, no per-pattern Python loop, two host syncs per step in all (the other
+    one is rj_multi_run's own).  With a CPU process group (gloo: tests on one GPU) the rows take the detour over the
+    host for the collective only."""
+
+    def __init__(self, n_patterns: int, rank: int, world: int, dist, device, collective_device=None):
+        import torch
+
+        self.P, self.rank, self.world, self.dist = n_patterns, rank, world, dist
+        self.device = device
+        self.cdev = collective_device if collective_device is not None else device
+        self.mine = torch.zeros((n_patterns, 8), dtype=torch.int64, device=device)
+        self.all = torch.zeros((world, n_patterns, 8), dtype=torch.int64, device=device)
+        self.out = torch.zeros(4 * n_patterns + 1, dtype=torch.int64).pin_memory()
+        self.staged = self.cdev.type != device.type
+        if self.staged:
+            self.all_c = torch.zeros((world, n_patterns, 8), dtype=torch.int64, device=self.cdev)
+
+    def counts(self, multi, run_local, rerun_one, offset: int, stream: int):
+        """run_local() -> local counts (rj_multi_run over this rank's range, empty carry); rerun_one(i, cur, prev_end)
+        re-runs pattern i of `multi` under the true carry (offsets LOCAL to the shard).  Returns the job-wide counts."""
+        import torch
+        from . import api
+
+        run_local()
+        first = True
+        for _ in range(self.world + 1):
+            multi.bounds_rows(self.mine, offset, first, stream)
+            first = False
+            if self.staged:
+                self.dist.all_gather([self.all_c[r] for r in range(self.world)], self.mine.to(self.cdev))
+                self.all.copy_(self.all_c)
+            else:
+                self.dist.all_gather_into_tensor(self.all.view(-1), self.mine.view(-1))
+            api.carry_decide(self.all, self.world, self.rank, self.P, self.out, stream)
+            torch.cuda.current_stream(self.device).synchronize()
+            out = self.out.tolist()
+            P = self.P
+            if out[4 * P] == 0:
+                return out[:P]
+            for i in range(P):
+                if out[P + i]:
+                    cur, pe = out[2 * P + 2 * i], out[2 * P + 2 * i + 1]
+                    have = cur != 0 or pe != 0
+                    rerun_one(i, max(cur - offset, 0), max(pe - offset, 0), have)
+                    self.mine[i, 5:8] = torch.tensor([cur, pe, int(have)], dtype=torch.int64)
+        raise RuntimeError("carry exchange did not converge")
+
+
 def _rerun_empty(rerun_one, i):
     # (a carry that went back to "no earlier match": select again from an empty carry)
     return rerun_one(i, 0, 0)

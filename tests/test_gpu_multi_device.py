@@ -46,3 +46,54 @@ def run(virtual):
 def test_shards_equal_one_device(virtual):
     one = run(0)
     assert run(virtual) == one
+
+
+def test_carry_decide_kernel_equals_the_host_protocol():
+    """rj_carry_decide (the device half of sharding.CarryExchange) against sharding.must_rerun on random rows."""
+    import random
+    import torch
+    import rejit_amd
+    from rejit_amd import api, sharding
+    rejit_amd.build()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    rng = random.Random(5)
+    for trial in range(200):
+        world, P = rng.randint(1, 8), rng.randint(1, 9)
+        rows = torch.full((world, P, 8), -1, dtype=torch.int64)
+        pos = 0
+        for r in range(world):
+            for p in range(P):
+                k = rng.choice([0, 0, 1, 3])
+                rows[r, p, 0] = k
+                if k:
+                    fb = 1000 * r + rng.randint(0, 30)
+                    fe = fb + rng.choice([0, 1, 5])
+                    lb = max(fb, 1000 * r + rng.randint(0, 999))
+                    le = lb + rng.choice([0, 1, 5, 40])
+                    rows[r, p, 1:5] = torch.tensor([fb, fe, lb, le])
+                used = rng.choice([(0, 0, 0), (0, 0, 0), (1000 * r - rng.randint(0, 3) + 2, 1000 * r - 1, 1)])
+                rows[r, p, 5:8] = torch.tensor(used)
+        rank = rng.randrange(world)
+        out = torch.zeros(4 * P + 1, dtype=torch.int64).pin_memory()
+        api.carry_decide(rows.to(dev), world, rank, P, out, st)
+        torch.cuda.synchronize(dev)
+        out = out.tolist()
+        again = 0
+        for p in range(P):
+            assert out[p] == int(rows[:, p, 0].sum())
+            for r in range(1, world):
+                prev = [q for q in range(r) if rows[q, p, 3] >= 0]
+                cin = (0, 0, False)
+                if prev:
+                    lb, le = int(rows[prev[-1], p, 3]), int(rows[prev[-1], p, 4])
+                    cin = (le if le > lb else lb + 1, le, True)
+                row = rows[r, p].tolist()
+                fe = (row[1], row[2]) if row[1] >= 0 else None
+                need = sharding.must_rerun(fe, (row[5], row[6], bool(row[7])), cin)
+                again |= int(need)
+                if r == rank:
+                    assert out[P + p] == int(need), (trial, r, p)
+                    if need:
+                        assert (out[2 * P + 2 * p], out[2 * P + 2 * p + 1]) == (cin[0], cin[1])
+        assert out[4 * P] == again
