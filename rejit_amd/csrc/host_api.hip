@@ -38,7 +38,36 @@ struct HostScans {
 };
 thread_local HostScans g_host_scans;
 
+// Programs freed by ANY thread: a thread's cached scans of them are dropped the next time it looks for a scan (the
+// persistent shard workers of multi_device.hip keep a scan -- with a device text buffer the size of their shard -- per
+// program they served; rj_program_free only reaches the calling thread's cache directly).
+std::mutex g_freed_mu;
+std::vector<uint64_t> g_freed_ids;
+std::atomic<uint64_t> g_freed_epoch{0};
+thread_local uint64_t g_seen_epoch = 0;
+
+void purge_freed_scans() {
+  const uint64_t epoch = g_freed_epoch.load(std::memory_order_acquire);
+  if (epoch == g_seen_epoch) return;
+  std::vector<uint64_t> freed;
+  {
+    std::lock_guard<std::mutex> lk(g_freed_mu);
+    freed = g_freed_ids;
+  }
+  g_seen_epoch = epoch;
+  auto& v = g_host_scans.v;
+  for (size_t i = 0; i < v.size();) {
+    if (std::find(freed.begin(), freed.end(), v[i].first) != freed.end()) {
+      rj_scan_destroy(v[i].second);
+      v.erase(v.begin() + static_cast<long>(i));
+    } else {
+      i++;
+    }
+  }
+}
+
 int host_scan_for(const rj_program* prog, rj_scan** out) {
+  purge_freed_scans();
   for (auto& p : g_host_scans.v)
     if (p.first == prog->id) {
       *out = p.second;
@@ -96,6 +125,15 @@ int stage_text(rj_scan* s, const char* text, size_t n, const uint8_t** d_text) {
 
 // rj_program_free (engine.hip): the calling thread's cached scans of a program go with it
 void rejit_amd::forget_host_scans(uint64_t program_id) {
+  {
+    // (other threads drop theirs when they next look for a scan; the list only grows by 8 bytes per freed program
+    // and is trimmed once it is long: ids are never reused, so forgetting old ones only delays a purge that no
+    // cache of 16 entries can still need)
+    std::lock_guard<std::mutex> lk(g_freed_mu);
+    if (g_freed_ids.size() >= 4096) g_freed_ids.erase(g_freed_ids.begin(), g_freed_ids.begin() + 2048);
+    g_freed_ids.push_back(program_id);
+    g_freed_epoch.fetch_add(1, std::memory_order_release);
+  }
   auto& v = g_host_scans.v;
   for (size_t i = 0; i < v.size();) {
     if (v[i].first == program_id) {

@@ -43,6 +43,10 @@ int run_linear(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint6
   while (sub > 256 && (n - sb) / sub < 32768) sub >>= 1;
   while ((n - sb) / sub > (16u << 20)) sub <<= 1;
   const int np = std::max(R.n_pos, 1), W = R.n_words;
+  // ... and the summaries (np * (8 + 4 W) bytes per sub-chunk: 10 KiB for a 256-position automaton) stay below half
+  // the text: with 4-KiB sub-chunks a wide automaton took 2.5 x the text in HBM and a multi-GB text failed with an
+  // out-of-memory error where the path is meant to serve every input
+  while (sub < (64u << 10) && static_cast<uint64_t>(np) * (8 + 4 * static_cast<uint64_t>(W)) * 2 > sub) sub <<= 1;
   const uint64_t a0 = sb / sub * sub;
   const uint64_t m = n / sub - sb / sub + 1;  // sub-chunks from the first own start to the one that holds position n
   RJ_HIP(s->cs_vals.reserve((m + 1) * np * sizeof(uint64_t)));
