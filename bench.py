@@ -496,7 +496,7 @@ def run_regexdna(args, c):
         out["hbm_not_cache"] = {"workload": "the same nine patterns, one kernel per pattern (mode 3), over a 2.5 GB stripped FASTA (fasta_n 250M)",
                                 "value": round(9 * nb / (eb / args.steps) / 1e9, 3), "unit": "GB/s", "ms_per_step": round(eb / args.steps * 1e3, 4),
                                 "matches_per_pass": cb,
-                                "roofline": hbm_roofline("scan_windows<2,NIB>", nb, sum(ms2) / len(ms2), None, len(ms2))}
+                                "roofline": hbm_roofline("scan_windows<2,NIB>", nb, sum(ms2) / len(ms2), pmc_traffic("regexdna_single_2p5gb", bytes=nb), len(ms2))}
         m0 = rejit_amd.MultiScan(progs)
         ms0 = []
 
@@ -511,7 +511,7 @@ def run_regexdna(args, c):
         out["one_pass_2p5gb"] = {"workload": "the headline's one-pass run over the same 2.5 GB text",
                                  "value": round(9 * nb / (e0 / args.steps) / 1e9, 3), "unit": "GB/s",
                                  "ms_per_step": round(e0 / args.steps * 1e3, 4),
-                                 "roofline": hbm_roofline("plane_scan<2>", nb, sum(ms0) / len(ms0), None, len(ms0))}
+                                 "roofline": hbm_roofline("plane_scan<2>", nb, sum(ms0) / len(ms0), pmc_traffic("plane_2p5gb", bytes=nb), len(ms0))}
         del big, m2, m0
         torch.cuda.empty_cache()
     return out, extras
@@ -613,7 +613,7 @@ def literal_and_complex_extras(args, c, out):
 
     out["behind_scan"] = single_pattern_extra(
         c, rejit_amd, t, n, rxb, "%s MatchAll over the same %d bytes (window behind an unbounded prefix)" % (rxb, n),
-        "scan_windows<1> + verify_behind_in_regions", 5, check_behind, None, True, args)
+        "scan_windows<1> + verify_behind_in_regions", 5, check_behind, "behind", True, args)
     # Patterns WITHOUT a fast-forward window (the NFA half of the north star): scan_dense_walk finds, walks and
     # compacts the candidates in one kernel.  `[a-f]+[0-9]`: a start at 8 % of the bytes of this text (only the
     # first byte of every run of [a-f] is taken, DevProgram::loop_first); the first four automaton steps of all
@@ -623,7 +623,7 @@ def literal_and_complex_extras(args, c, out):
 
     out["dense_scan"] = single_pattern_extra(
         c, rejit_amd, t, n, "[a-f]+[0-9]", "[a-f]+[0-9] MatchAll over the same %d bytes (no fast-forward window: dense mode)" % n,
-        "scan_dense_walk<1,false,4> (lane-packed pre-steps)", 5, check_dense, None, True, args)
+        "scan_dense_walk<1,false,4> (lane-packed pre-steps)", 5, check_dense, "dense", True, args)
     # (the dense kernel is issue-bound, not HBM-bound: its VALU roofline says how close to the other ceiling it runs)
     _dl = out["dense_scan"]["roofline"]["avg_launch_ms"]
     if _dl:
@@ -675,7 +675,7 @@ def literal_and_complex_extras(args, c, out):
             out["literal_50gb"] = single_pattern_extra(
                 c, rejit_amd, tb, nb, "regexp",
                 "literal 'regexp' MatchAll over %d bytes random ASCII, %d planted (north star: 50 GB fast-forward scan, 1 GPU)" % (nb, len(offs_b)),
-                "scan_windows<1>", 5, check_big, None, False, args)
+                "scan_windows<1>", 5, check_big, "literal_50gb", False, args)
             del tb
             torch.cuda.empty_cache()
         else:

@@ -7,13 +7,14 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 g = lambda name: os.path.join(root, "gpurun_out", f"prof_{tag}_{name}")
 P = lambda name: os.path.join(root, "profiles", f"{tag}_{name}")
 hdr = f"""# rocprofv3 PMC passes, one counter group per pass (MI355X, gfx950, ROCm 7.2), run by tools/profile_round.sh; command per pass:
-#   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-big
-#   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-big
+#   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --jrep-files 2000 --jrep-bytes 200000000
+#   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- (the same)
 # Unit: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM):
 # FETCH_SIZE counts a wide coalesced 16-B/lane stream at exactly 1/2 -> HBM read bytes = FETCH_SIZE*1024*2.
 # FETCH_SIZE also counts requests the 256 MiB Infinity Cache serves (same guide): for scan_windows_train
 # (nine passes of every wave over its own 32 KB span) it shows the bytes REQUESTED from beyond L2, 0.98 x the
 # 9 x 500 MB algorithmic bytes, not what HBM delivered.  WRITE_SIZE is uncalibrated on gfx950; listed raw.
+# plane_scan<2> / scan_windows<..> run at two text sizes in this command (500 MB and 2.5 GB; 5 GB and 50 GB): min = the small one.
 
 """
 f, w = open(g("pmc_fetch.txt")).read(), open(g("pmc_write.txt")).read()
@@ -27,27 +28,57 @@ def avg(txt, prefix):
     raise KeyError(prefix)
 
 
+def maybe(key, prefix, **extra):
+    """a pmc_traffic.json entry when the kernel shows up in the FETCH_SIZE pass"""
+    try:
+        j[key] = dict(kernel=prefix, hbm_read_bytes_per_launch=avg(f, prefix) * 1024 * 2, **extra)
+    except KeyError:
+        pass
+
+
+def avg_of(txt, prefix, expect_bytes):
+    """kernels that run at several text sizes in one pass (plane_scan at 500 MB and 2.5 GB, small calls of the latency sweep):
+    the group of launches (pmc_summary.py's last column) whose FETCH_SIZE is nearest to the text size"""
+    for line in txt.splitlines():
+        if line.startswith(prefix):
+            groups = [float(x.split("x")[0]) for x in line[60:].split()[4:]]
+            return min(groups, key=lambda kib: abs(kib * 2048 / expect_bytes - 1))
+    raise KeyError(prefix)
+
+
 j = {"source": f"profiles/{tag}_pmc_hbm_traffic.txt",
-     "regexdna": {"kernel": "scan_windows_train<true> (9 pattern scans per launch; Infinity-Cache hits are counted)", "fasta_n": 50000000,
-                  "hbm_read_bytes_per_launch": avg(f, "scan_windows_train<true>") * 1024 * 2},
-     "regexdna_single": {"kernel": "scan_windows<2,true,true,false,true>", "fasta_n": 50000000,
-                         "hbm_read_bytes_per_launch": avg(f, "scan_windows<2, true, true, false, true>") * 1024 * 2},
-     "fused": {"kernel": "scan_windows_fused<2>", "fasta_n": 50000000, "hbm_read_bytes_per_launch": avg(f, "scan_windows_fused<2>") * 1024 * 2},
-     "literal": {"kernel": "scan_windows<1,true,false,true,false>", "bytes": 5000000000,
-                 "hbm_read_bytes_per_launch": avg(f, "scan_windows<1, true, false, true, false>") * 1024 * 2},
-     "complex": {"kernel": "scan_windows<1,true,true,true,false> (floating window abcdefgh)", "bytes": 5000000000,
-                 "hbm_read_bytes_per_launch": avg(f, "scan_windows<1, true, true, true, false>") * 1024 * 2}}
+     "note": "HBM read bytes per launch = FETCH_SIZE (KiB) x 1024 x 2 (gfx950 counts a wide coalesced stream at 1/2, MI355X guide); kernels that "
+             "run at two text sizes in the profiled command take the min / max launch"}
+FASTA = 500000000  # bytes of the stripped 50 M-base FASTA input (workloads.fasta_stripped_size)
+for key, prefix, nbytes, extra in (
+        ("plane", "plane_scan<2>", FASTA, {"fasta_n": 50000000}),
+        ("plane_2p5gb", "plane_scan<2>", 2500000000, {}),
+        ("regexdna_single", "scan_windows<2, true, true, false, true>", FASTA, {"fasta_n": 50000000}),
+        ("regexdna_single_2p5gb", "scan_windows<2, true, true, false, true>", 2500000000, {}),
+        ("literal", "scan_windows<1, true, false, true, false>", 5000000000, {}),
+        ("literal_50gb", "scan_windows<1, true, false, true, false>", 50000000000, {}),
+        ("complex", "scan_windows<1, true, true, true, false>", 5000000000, {}),
+        ("dense", "scan_dense_walk<1, false, 4>", 5000000000, {}),
+        ("line_table", "emit_assertions", 5000000000, {})):
+    try:
+        j[key] = dict(kernel=prefix, hbm_read_bytes_per_launch=avg_of(f, prefix, nbytes) * 1024 * 2, bytes=nbytes, **extra)
+    except KeyError:
+        pass
+# (behind: the same scan kernel as `literal`, over the same text)
+if "literal" in j:
+    j["behind"] = dict(j["literal"], note="same kernel and text as `literal`")
 json.dump(j, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
 prof_line = open(g("bench_profiled.json")).read().strip().splitlines()[-1]
 open(P("bench_kernel_stats.txt"), "w").write(
     "# rocprofv3 --kernel-trace --stats -- python bench.py --no-extra --no-cpu-baseline   (MI355X)\n"
     "# = the headline run alone (default K/W; the extras and the CPU sample left out so that the per-kernel averages are\n"
     "# those of the timed region); summarised from the rocpd database by tools/rocpd_stats.py.  The un-profiled bench line\n"
-    f"# (profiles/{tag}_bench_line.json) reports roofline.avg_launch_ms, which agrees with scan_windows_train avg_us below\n"
+    f"# (profiles/{tag}_bench_line.json) reports roofline.avg_launch_ms, which agrees with plane_scan<2> avg_us below\n"
     "# (under the profiler the dispatch-timestamp time reads a few % higher):\n# " + prof_line + "\n" + open(g("kernel_stats.txt")).read())
 open(P("bench_full_kernel_stats.txt"), "w").write(
-    "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-big --steps 5   (MI355X): every kernel of the\n"
-    "# bench line's extras -- train / per-pattern / fused scans, literal, complex (floating), behind, dense, line table, tails\n"
+    "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 5 --jrep-files 5000 --jrep-bytes 500000000   (MI355X):\n"
+    "# every kernel of the bench line's extras -- one-pass / train / per-pattern scans at 500 MB and 2.5 GB, literal at 5 and 50 GB, complex\n"
+    "# (floating), behind, dense, line table (emit_assertions), batches, tails\n"
     + open(g("kernel_stats_full.txt")).read())
 open(P("linear_path_kernel_stats.txt"), "w").write(
     "# rocprofv3 --kernel-trace --stats -- python tools/linear_probe.py   (MI355X): the linear-time carry scan (cs_*), the blocked\n"
