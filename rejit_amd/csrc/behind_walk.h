@@ -24,6 +24,10 @@
 #include "carry_scan.h"
 #include "device_program.h"
 
+#ifndef RJ_STAMP  // (kernels.hip, -DRJ_TRACE_VERIFY: phase time stamps of a debug build)
+#define RJ_STAMP(i) ((void)0)
+#endif
+
 namespace rejit_amd {
 
 // does window k of P (<= 8 bytes, per-byte masks) occur at text position w?
@@ -138,6 +142,7 @@ RJ_HD bool rj_behind_candidate(const DevProgram& P, const DevProgram& R, const u
     for (int j = 0; j < NW; j++)
       if (j < W) cut[j] |= P.cut_fwd[k][j];
   }
+  if (cut[0] != 0) RJ_STAMP(4);
 #pragma unroll
   for (int j = 0; j < NW; j++) {
     uint32_t bits = cut[j];
@@ -153,10 +158,14 @@ RJ_HD bool rj_behind_candidate(const DevProgram& P, const DevProgram& R, const u
     }
   }
   if (!any) return false;
+  RJ_STAMP(5);
   uint64_t s = 0;
   if (*overrun || !rj_leftmost_start<NW>(R, t, n, w, ok, P.max_walk, &s, overrun, abort) || *overrun) return false;
+  RJ_STAMP(6);
   *begin = s;
-  return rj_lane_longest<NQ>(P, t, n, s, end, overrun, abort);
+  const bool found = rj_lane_longest<NQ>(P, t, n, s, end, overrun, abort);
+  RJ_STAMP(7);
+  return found;
 }
 
 }  // namespace rejit_amd

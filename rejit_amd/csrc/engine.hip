@@ -93,6 +93,26 @@ int upload_program(rj_program* rp) {
     point_tables(&rp->rev, rp->rev_tables.as<uint32_t>(), rb, P.n_pos);
     rp->rev.nullable = nullable_bits(P);
   }
+  rp->walk = WalkDesc{};
+  if (W <= 4 && (P.floating || P.behind) && getenv("RJ_NO_LDS_WALK") == nullptr) {  // (env: measurement override)
+    const int nq = W <= 2 ? 1 : 2;
+    std::vector<uint64_t> fw = make_walk_blob(blob, P.n_pos, nq);
+    if (fw.size() & 1) fw.push_back(0);  // (copied to LDS 16 bytes at a time)
+    const size_t words = fw.size();
+    if (P.behind) {
+      std::vector<uint64_t> rv = make_walk_blob(make_table_blob(P.rev, P.n_pos, P.n_words, P.has_assertions), P.n_pos, nq);
+      rv.resize(words, 0);
+      fw.insert(fw.end(), rv.begin(), rv.end());
+    }
+    RJ_HIP(rp->walk_tables.reserve(fw.size() * sizeof(uint64_t)));
+    RJ_HIP(hipMemcpy(rp->walk_tables.p, fw.data(), fw.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    rp->walk.blob = rp->walk_tables.as<uint64_t>();
+    rp->walk.rev_blob = P.behind ? rp->walk_tables.as<uint64_t>() + words : nullptr;
+    rp->walk.words = static_cast<uint32_t>(words);
+    rp->walk.nq = nq;
+    rp->walk.n_ctx = C;
+    rp->walk.n_pos = P.n_pos;
+  }
   const uint32_t* base = rp->tables.as<uint32_t>();
   DevProgram& D = rp->dev;
   D.n_pos = P.n_pos;
@@ -187,6 +207,8 @@ int upload_program(rj_program* rp) {
   D.row_of = reinterpret_cast<const int32_t*>(base + off_rowof);
   D.rows = base + off_rows;
   D.cls = base + off_cls;
+  rp->walk.nullable = D.nullable;
+  rp->walk.max_walk = D.max_walk;
   if (P.q8_risk) {
     // graph for the exact replay kernels (table_layout.h: int32 arrays, class bitmaps, literal bytes)
     const GraphBlob gb = make_graph_blob(P.graph);
@@ -590,13 +612,23 @@ static int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb,
       // verify + compact inside the regions, lay the survivors out, check / select: one sync
       // (verifying at the tail of the scan kernel instead was measured: 5 us slower per pass)
       const uint64_t* begins = s->hits.as<uint64_t>();
+      // floating windows: the wave that verifies a region also applies the selection rule to the region's candidates,
+      // which then usually are the result already (verify_lds.hip); not for patterns at risk of the ring artefact
+      // (the adjacency test below wants every candidate)
+      bool local_select = floating_regions && !rp->host->q8_risk && !s->no_local_select && getenv("RJ_NO_LOCAL_SELECT") == nullptr;
       if (floating_regions) {
-        launch_verify_floating_in_regions(vp, D, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(),
-                                          s->cand_begin.as<uint64_t>(), s->cand_end.as<uint64_t>(), st);
+        if (!launch_verify_floating_lds(vp, D, rp->walk, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(),
+                                        s->cand_begin.as<uint64_t>(), s->cand_end.as<uint64_t>(), local_select, st)) {
+          local_select = false;
+          launch_verify_floating_in_regions(vp, D, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(),
+                                            s->cand_begin.as<uint64_t>(), s->cand_end.as<uint64_t>(), st);
+        }
         begins = s->cand_begin.as<uint64_t>();
       } else if (behind) {
-        launch_verify_behind_in_regions(vp, D, rp->rev, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(),
-                                        s->cand_end.as<uint64_t>(), st);
+        if (!launch_verify_behind_lds(vp, D, rp->walk, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(),
+                                      s->cand_end.as<uint64_t>(), st))
+          launch_verify_behind_in_regions(vp, D, rp->rev, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(),
+                                          s->cand_end.as<uint64_t>(), st);
       } else if (!dense_walk) {
         launch_verify_in_regions(vp, D, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(), s->cand_end.as<uint64_t>(), st);
       }
@@ -623,6 +655,22 @@ static int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb,
                                   fp.carry_prev_end, fp.have_prev);
       RJ_HIP(hipStreamSynchronize(st));
       RJ_HIP(hipGetLastError());
+      if (local_select && s->host_counters[kCntUnordered] != 0 && s->host_counters[kCntOverflow] == 0 && s->host_counters[kCntOverrun] == 0) {
+        // a match reaches from one region into the candidates of the next: the general selection needs every
+        // candidate -- verify once more without the in-region rule (the hit lists are untouched: floating
+        // candidates go to their own arrays), and remember it for this scan's next runs
+        s->no_local_select = true;
+        s->stats.retries++;
+        launch_verify_floating_lds(vp, D, rp->walk, s->hit_counts.as<uint32_t>(), s->valid_counts.as<uint32_t>(),
+                                   s->cand_begin.as<uint64_t>(), s->cand_end.as<uint64_t>(), false, st);
+        s->host_counters[kCntUnordered] = 0;
+        launch_offsets_gather_check(survivors, begins, s->cand_end.as<uint64_t>(), geo.n_regions,
+                                    static_cast<uint32_t>(region_cap), fp.carry_cur, s->out.as<uint64_t>(), s->out_cap,
+                                    s->counters.as<unsigned long long>(), s->host_counters, off_scratch, prev_scratch, st,
+                                    fp.carry_prev_end, fp.have_prev);
+        RJ_HIP(hipStreamSynchronize(st));
+        RJ_HIP(hipGetLastError());
+      }
       if (s->host_counters[kCntUnordered] != 0 && s->host_counters[kCntOverflow] == 0) {
         // not the result yet: the selection kernels work on begin[] / end[]
         const uint64_t nc = s->host_counters[kCntCands];

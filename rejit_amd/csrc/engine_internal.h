@@ -82,6 +82,10 @@ struct rj_program {
   rejit_amd::DeviceBuffer tables;
   rejit_amd::DevProgram rev{};   // the reverse automaton (table fields only), see lowering.h Program::rev
   rejit_amd::DeviceBuffer rev_tables;
+  // the same tables padded for the LDS walkers (lds_walk.h / verify_lds.hip): automata of <= 128 positions whose
+  // scan plan has floating windows or windows behind an unbounded prefix; walk.blob == nullptr otherwise
+  rejit_amd::WalkDesc walk{};
+  rejit_amd::DeviceBuffer walk_tables;
   rejit_amd::DevGraph graph{};        // uploaded only for patterns with q8_risk
   rejit_amd::DeviceBuffer graph_blob;
   int device = 0;
@@ -107,6 +111,7 @@ struct rj_scan {
   rejit_amd::DeviceBuffer cs_vals, cs_mats, cs_e, cs_g, cs_entry, cs_counts, cs_scratch, cs_acc, cs_groups;
   bool linear_hint = false;        // the previous run needed the carry scan: go there directly
   bool behind_conflicts = false;   // behind mode gave a conflict / overrun on this scan's text: stay dense
+  bool no_local_select = false;    // floating windows: the in-region selection left overlapping candidates on this text
   uint64_t cands_cap = 0, out_cap = 0;
   uint32_t region_cap_hint = 64;   // hit-region size that sufficed last time (windows mode)
   uint64_t hits_hint = 0;          // hits of the previous run (sizes the verify grid)

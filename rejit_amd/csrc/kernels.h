@@ -271,6 +271,24 @@ void launch_verify_behind_in_regions(const VerifyParams& a, const DevProgram& P,
 // once, in order); survivors go to region_begins / region_ends
 void launch_verify_floating_in_regions(const VerifyParams& a, const DevProgram& P, const uint32_t* hit_counts,
                                        uint32_t* valid_counts, uint64_t* region_begins, uint64_t* region_ends, hipStream_t st);
+// The same two tails over PADDED tables in LDS (verify_lds.hip, lds_walk.h): automata of <= 128 positions.  A step of
+// a walk is two LDS reads instead of a chain of 10-20 flat loads, the text around a hit is staged in LDS in one
+// trip; the floating kernel can also make the left-most-longest selection among the candidates of its own region
+// (`select`), which usually leaves the candidates "already the result" for offsets_gather_check -- when that check
+// fails the caller repeats the launch with select = false (the general selection needs every candidate).
+struct WalkDesc {
+  const uint64_t* blob;      // forward tables, lds_walk.h layout
+  const uint64_t* rev_blob;  // reverse tables (behind mode), same shape; else null
+  uint32_t words;            // uint64 words of one blob, rounded up to an even number
+  int32_t nq;                // 64-bit words per row: 1 or 2
+  int32_t n_ctx, n_pos;
+  uint32_t nullable, max_walk;
+};
+// false: the tables + text windows do not fit the workgroup's LDS (the caller takes the kernels above)
+bool launch_verify_floating_lds(const VerifyParams& a, const DevProgram& P, const WalkDesc& d, const uint32_t* hit_counts,
+                                uint32_t* valid_counts, uint64_t* region_begins, uint64_t* region_ends, bool select, hipStream_t st);
+bool launch_verify_behind_lds(const VerifyParams& a, const DevProgram& P, const WalkDesc& d, const uint32_t* hit_counts,
+                              uint32_t* valid_counts, uint64_t* region_ends, hipStream_t st);
 // region offsets + gather + check_and_interleave in one launch (see the kernel); host_counters
 // (pinned, may be null) receives the counter block directly.  With offsets_scratch / prev_scratch
 // ([n_regions] each) the first launch only lays the regions out and a second one copies and checks

@@ -48,6 +48,10 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include "trace_stamp.h"
+RJ_TRACE_EXPORT(rj_debug_trace)
+
+
 #include "behind_walk.h"
 #include "dense_swar.h"
 #include "device_program.h"
@@ -1027,7 +1031,9 @@ __global__ __launch_bounds__(256) void verify_floating_in_regions(VerifyParams a
                                                                   uint64_t* region_ends, uint32_t float_min,
                                                                   uint32_t lds_words) {
   extern __shared__ uint32_t tab[];
+  if (blockIdx.x == 0 && threadIdx.x == 0) RJ_STAMP(0);
   const DevProgram Q = stage_tables(P, tab, lds_words);
+  if (blockIdx.x == 0 && threadIdx.x == 0) RJ_STAMP(1);
   const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   // a whole wave per region: one hit has up to 256 starts and every walk is a chain of dependent
   // steps, so the width of a round is what bounds the kernel's latency (16 lanes: 126 us at 1000 hits)
@@ -1059,8 +1065,10 @@ __global__ __launch_bounds__(256) void verify_floating_in_regions(VerifyParams a
     uint64_t* begins = region_begins + r * a.region_cap;
     uint64_t* ends = region_ends + r * a.region_cap;
     uint32_t kept = 0;
+    if (sub == 0) RJ_STAMP(2);
     for (uint32_t i = 0; i < cnt; i++) {
       const uint64_t w = region[i];
+      if (sub == 0 && w != 0) RJ_STAMP(3);
       if (w < float_min) continue;
       const uint64_t hi = w - float_min;                       // last start of this hit
       uint64_t lo = w >= a.float_max ? w - a.float_max : 0;    // first
@@ -1072,11 +1080,14 @@ __global__ __launch_bounds__(256) void verify_floating_in_regions(VerifyParams a
         const RjCachedText ct(a.text, a.n);  // (the walk reads the text 16 bytes at a time, device_program.h)
         const bool found = s <= hi && s >= a.sb && s < a.se && rj_lane_longest<NQ>(Q, ct, a.n, s, &e, &overrun, a.counters + kCntOverrun);
         if (overrun) a.counters[kCntOverrun] = 1;
+        if (found) RJ_STAMP(7);
         const uint64_t mine = __ballot(found);
+        if (sub == 0) RJ_STAMP(8);
         const uint32_t pos = kept + __popcll(mine & ((1ull << sub) - 1ull));
         if (found && pos < a.region_cap) {
           begins[pos] = s;
           ends[pos] = e;
+          RJ_STAMP(9);
         }
         kept += __popcll(mine);
       }
@@ -1088,6 +1099,7 @@ __global__ __launch_bounds__(256) void verify_floating_in_regions(VerifyParams a
     }
     if (sub == 0) valid_counts[r] = kept < a.region_cap ? kept : a.region_cap;
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) RJ_STAMP(10);
 }
 
 // Windows behind an unbounded prefix: 16 lanes per region, one hit per lane and round, the per-hit
@@ -1097,8 +1109,10 @@ template <int NW, int NQ>
 __global__ __launch_bounds__(256) void verify_behind_in_regions(VerifyParams a, DevProgram P, DevProgram R, const uint32_t* hit_counts,
                                                                 uint32_t* valid_counts, uint64_t* region_ends, uint32_t lds_words) {
   extern __shared__ uint32_t tab[];
+  if (blockIdx.x == 0 && threadIdx.x == 0) RJ_STAMP(0);
   const DevProgram Pq = stage_tables(P, tab, lds_words >= P.table_words + R.table_words ? P.table_words : 0);
   const DevProgram Rq = stage_tables(R, tab + P.table_words, lds_words >= P.table_words + R.table_words ? R.table_words : 0);
+  if (blockIdx.x == 0 && threadIdx.x == 0) RJ_STAMP(1);
   constexpr int G = 16;
   const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   const uint64_t n_groups = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 4;
@@ -1115,7 +1129,9 @@ __global__ __launch_bounds__(256) void verify_behind_in_regions(VerifyParams a, 
     uint32_t kept = 0;
     for (uint32_t base = 0; base < cnt; base += G) {
       const uint32_t k = base + sub;
+      if (k < cnt) RJ_STAMP(2);
       const uint64_t w = k < cnt ? region[k] : 0;
+      if (k < cnt && w != 0) RJ_STAMP(3);
       uint64_t b = 0, e = 0;
       bool overrun = false;
       const bool found = k < cnt && *static_cast<const volatile unsigned long long*>(a.counters + kCntOverrun) == 0 &&
@@ -1127,11 +1143,13 @@ __global__ __launch_bounds__(256) void verify_behind_in_regions(VerifyParams a, 
       if (found) {  // pos <= k, and every lane of the group has read its hit already
         region[pos] = b;
         ends[pos] = e;
+        RJ_STAMP(9);
       }
       kept += __popc(mine);
     }
     if (sub == 0) valid_counts[r] = kept;
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) RJ_STAMP(10);
 }
 
 // The tails of several patterns in one launch (rj_multi): blockIdx.y selects the pattern, whose

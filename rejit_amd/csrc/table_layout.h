@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "device_program.h"
+#include "lds_walk.h"
 #include "lowering.h"
 
 namespace rejit_amd {
@@ -50,6 +51,28 @@ TableBlob make_table_blob(const Tables& T, int n_pos, int n_words, bool has_asse
   for (int i = 0; i < n_pos; i++) b.words[b.off_rowof + static_cast<size_t>(i)] = static_cast<uint32_t>(T.row_of[static_cast<size_t>(i)]);
   std::copy(T.cls.begin(), T.cls.end(), b.words.begin() + static_cast<long>(b.off_cls));
   return b;
+}
+
+// The same tables padded for the LDS walkers (lds_walk.h): NQ 64-bit words per row, rows by position (row n_pos
+// all zero), first / last / linear / rows / cls in this order.
+inline std::vector<uint64_t> make_walk_blob(const TableBlob& b, int n_pos, int nq) {
+  const size_t NQ = static_cast<size_t>(nq), C = static_cast<size_t>(b.C), W = static_cast<size_t>(b.W), P = static_cast<size_t>(std::max(n_pos, 0));
+  std::vector<uint64_t> out(static_cast<size_t>(lw_blob_words(nq, b.C, static_cast<int>(P))), 0ull);
+  auto pack = [&](size_t dst, size_t src) {  // W 32-bit words at b.words[src] -> NQ 64-bit words at out[dst]
+    for (size_t k = 0; k < W && k < 2 * NQ; k++) out[dst + k / 2] |= static_cast<uint64_t>(b.words[src + k]) << (32 * (k & 1));
+  };
+  const size_t o_first = 0, o_last = C * NQ, o_lin = 2 * C * NQ, o_rows = o_lin + NQ, o_cls = o_rows + C * (P + 1) * NQ;
+  for (size_t c = 0; c < C; c++) {
+    pack(o_first + c * NQ, b.off_first + c * W);
+    pack(o_last + c * NQ, b.off_last + c * W);
+    for (size_t i = 0; i < P; i++) {
+      const int32_t r = static_cast<int32_t>(b.words[b.off_rowof + i]);
+      if (r >= 0) pack(o_rows + (c * (P + 1) + i) * NQ, b.off_rows + (c * static_cast<size_t>(b.R) + static_cast<size_t>(r)) * W);
+    }
+  }
+  pack(o_lin, b.off_linear);
+  for (size_t v = 0; v < 256; v++) pack(o_cls + v * NQ, b.off_cls + v * W);
+  return out;
 }
 
 // table pointers / sizes of D for a blob that lives at `base` (host or device memory)

@@ -339,3 +339,80 @@ long ce_short_check(const char* re, const uint8_t* text, uint64_t n, uint64_t* c
 }
 
 }  // extern "C"
+
+// The padded-table walkers of lds_walk.h against the ones they replace (device_program.h, behind_walk.h):
+//   every start: lw_longest == rj_lane_longest (found, end, overrun);
+//   every (text position p, automaton position q): lw_reaches_accept == rj_reaches_accept, and
+//   lw_leftmost_start == rj_leftmost_start from the single reverse position of q;
+//   behind patterns, every text position: lw_behind_candidate == rj_behind_candidate.
+// Returns the number of disagreements (-9: wider than 128 positions); *checked = comparisons made.
+template <int NQ, int NW, bool CTX>
+static long lds_walk_check(const Program& P, const DevProgram& F, const DevProgram& R, const WalkTab<NQ>& WF, const WalkTab<NQ>& WR,
+                           const uint8_t* text, uint64_t n, uint64_t* checked) {
+  long bad = 0;
+  for (uint64_t s0 = 0; s0 <= n; s0++) {
+    uint64_t e1 = 0, e2 = 0;
+    bool o1 = false, o2 = false;
+    const bool f1 = rj_lane_longest<NQ>(F, text, n, s0, &e1, &o1);
+    const bool f2 = lw_longest<NQ, CTX>(WF, text, n, s0, &e2, &o2);
+    if (f1 != f2 || o1 != o2 || (f1 && e1 != e2)) bad++;
+    (*checked)++;
+  }
+  for (uint64_t p = 0; p < n; p++) {
+    for (int q = 0; q < P.n_pos; q++) {
+      bool o1 = false, o2 = false;
+      const bool r1 = rj_reaches_accept<NW>(F, text, n, p, q, &o1);
+      const bool r2 = lw_reaches_accept<NQ, CTX>(WF, text, n, p, q, &o2);
+      if (r1 != r2 || o1 != o2) bad++;
+      uint32_t S1[NW];
+      uint64_t S2[NQ];
+      for (int k = 0; k < NW; k++) S1[k] = 0;
+      for (int k = 0; k < NQ; k++) S2[k] = 0;
+      S1[q >> 5] = 1u << (q & 31);
+      S2[q >> 6] = 1ull << (q & 63);
+      uint64_t b1 = 0, b2 = 0;
+      o1 = o2 = false;
+      const bool l1 = rj_leftmost_start<NW>(R, text, n, p, S1, F.max_walk, &b1, &o1);
+      const bool l2 = lw_leftmost_start<NQ, CTX>(WR, text, n, p, S2, F.max_walk, &b2, &o2);
+      if (l1 != l2 || o1 != o2 || (l1 && b1 != b2)) bad++;
+      (*checked) += 2;
+    }
+    if (P.behind) {
+      uint64_t b1 = 0, e1 = 0, b2 = 0, e2 = 0;
+      bool o1 = false, o2 = false;
+      const bool c1 = rj_behind_candidate<NW, NQ>(F, R, text, n, p, &b1, &e1, &o1);
+      const bool c2 = lw_behind_candidate<NQ, CTX>(F, WF, WR, text, n, p, &b2, &e2, &o2);
+      if (c1 != c2 || o1 != o2 || (c1 && (b1 != b2 || e1 != e2))) bad++;
+      (*checked)++;
+    }
+  }
+  return bad;
+}
+
+extern "C" {
+
+long ce_lds_walk_check(const char* re, const uint8_t* text, uint64_t n, uint32_t max_walk, uint64_t* checked) {
+  LowerResult lr = lower(re);
+  if (lr.status != 0) return lr.status;
+  const Program& P = *lr.program;
+  if (P.n_words > 4) return -9;
+  const TableBlob fb = make_table_blob(P, P.n_pos, P.n_words, P.has_assertions);
+  const TableBlob rb = make_table_blob(P.rev, P.n_pos, P.n_words, P.has_assertions);
+  DevProgram F{}, R{};
+  point_tables(&F, fb.words.data(), fb, P.n_pos);
+  point_tables(&R, rb.words.data(), rb, P.n_pos);
+  F.nullable = R.nullable = nullable_bits(P);
+  F.max_walk = R.max_walk = max_walk;
+  fill_windows(&F, P);
+  const int nq = P.n_words <= 2 ? 1 : 2;
+  const std::vector<uint64_t> wf = make_walk_blob(fb, P.n_pos, nq), wr = make_walk_blob(rb, P.n_pos, nq);
+  if (nq == 1) {
+    const WalkTab<1> WF = lw_point<1>(wf.data(), fb.C, P.n_pos, F.nullable, max_walk), WR = lw_point<1>(wr.data(), rb.C, P.n_pos, R.nullable, max_walk);
+    if (fb.C > 1) return P.n_words <= 1 ? lds_walk_check<1, 1, true>(P, F, R, WF, WR, text, n, checked) : lds_walk_check<1, 2, true>(P, F, R, WF, WR, text, n, checked);
+    return P.n_words <= 1 ? lds_walk_check<1, 1, false>(P, F, R, WF, WR, text, n, checked) : lds_walk_check<1, 2, false>(P, F, R, WF, WR, text, n, checked);
+  }
+  const WalkTab<2> WF = lw_point<2>(wf.data(), fb.C, P.n_pos, F.nullable, max_walk), WR = lw_point<2>(wr.data(), rb.C, P.n_pos, R.nullable, max_walk);
+  return fb.C > 1 ? lds_walk_check<2, 4, true>(P, F, R, WF, WR, text, n, checked) : lds_walk_check<2, 4, false>(P, F, R, WF, WR, text, n, checked);
+}
+
+}  // extern "C"

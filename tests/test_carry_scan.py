@@ -23,7 +23,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(ROOT, "rejit_amd", "csrc")
 SO = os.path.join(HERE, "support", "libcarry_exec.so")
 SRCS = [os.path.join(HERE, "support", "carry_exec.cc"), os.path.join(CSRC, "parser.cc"), os.path.join(CSRC, "lowering.cc")]
-DEPS = SRCS + [os.path.join(CSRC, h) for h in ("carry_scan.h", "device_program.h", "lowering.h", "table_layout.h", "behind_walk.h")]
+DEPS = SRCS + [os.path.join(CSRC, h) for h in ("carry_scan.h", "device_program.h", "lowering.h", "table_layout.h", "behind_walk.h", "lds_walk.h")]
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 
 
@@ -37,6 +37,8 @@ def ce():
                                    ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, _u64p, ctypes.c_uint64]
     lib.ce_match_all_behind.restype = ctypes.c_long
     lib.ce_match_all_behind.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, _u64p, ctypes.c_uint64]
+    lib.ce_lds_walk_check.restype = ctypes.c_long
+    lib.ce_lds_walk_check.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, _u64p]
     return lib
 
 
@@ -144,3 +146,33 @@ def test_behind_walk_device_code_vs_oracle(ce):
                         assert got == oracle.match_all_spec(rx, t2), (rx, t2, walk)
                         used += 1
     assert used > 500, (used, flagged)
+
+
+def test_lds_walkers_equal_the_walkers_they_replace(ce):
+    """rejit_amd/csrc/lds_walk.h (padded tables, rows by position: what verify_lds.hip walks in LDS) against
+    device_program.h / behind_walk.h: the longest match from every start, the forward check and the backward walk from
+    every (text position, automaton position), the behind candidate of every text position -- found / begin / end /
+    overrun flags all equal, with and without a short walk limit, automata of one to four 32-bit words, with assertions."""
+    rng = random.Random(41)
+    pats = [b"regexp", b"[cgt]gggtaaa|tttaccc[acg]", b"([complex]|(regexp)){2,7}abcdefgh(at|the|[e-nd]as well)", b"[a-z]+abcdefgh", b".*regexp",
+            b"^ab+c$", b"(^|x)a*b$", b"\\d+regexp", b"[ab]*abb", b"a+(bc|bd)e*", b"(abcdefghijklmnopqrstuvwxyz0123456789)+x*", b"(ab|ba)+", b"x*",
+            b"(abc|abd|b+c?)(de)?$", b"^$", b"[a-f]+[0-9]", b"(a|b|c|d)(e|f)(g|h)+", b"(some|[stuff])((other|regexps)? bla root blah | (abcdefgh)+)"]
+    total = 0
+    for rx in pats:
+        for alphabet in (b"ab", b"abcdegxprt\n", b"abcdefgh xy01\n\r"):
+            for n in (0, 1, 48):
+                tx = bytes(rng.choices(alphabet, k=n))
+                for plant in (b"", b"regexpregexpabcdefghthe", b"abb", b"abcdefghat"):
+                    t2 = tx[:n // 2] + plant + tx[n // 2:]
+                    for walk in (1 << 20, 7):
+                        checked = ctypes.c_uint64(0)
+                        bad = ce.ce_lds_walk_check(rx, t2, len(t2), walk, ctypes.byref(checked))
+                        assert bad == 0, (rx, t2, walk, bad)
+                        total += checked.value
+    # (lowering these takes 0.03-0.7 s each -- the ring-artefact analysis -- so one text apiece: 3 and 4 words, rows)
+    for rx in (b"([ab]{3}c){12,}xy", b"[ab]{30,40}cd", b"[ab]{70,90}c"):
+        tx = bytes(rng.choices(b"ab", k=150)) + b"cdxy"
+        checked = ctypes.c_uint64(0)
+        assert ce.ce_lds_walk_check(rx, tx, len(tx), 1 << 20, ctypes.byref(checked)) == 0, rx
+        total += checked.value
+    assert total > 300_000, total

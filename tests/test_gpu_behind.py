@@ -86,3 +86,21 @@ def test_large_random_ascii_vs_oracle(rj, rx, lo, hi, plant):
         i = int(np.searchsorted(begins, o, side="right")) - 1
         covered += i >= 0 and int(spans[i, 1]) >= o + len(plant)
     assert covered == len(offs), (rx, covered, len(offs), st)
+
+
+def test_many_hits_per_region_matches_before_line_breaks(rj):
+    """Dozens of window hits in one region (every lane of the verify wave busy, walks of very different lengths) with
+    matches that end right before a line break or at the end of the text: the case in which a run-time "has
+    contexts" flag, kept by the compiler as a lane mask of the lanes still inside ONE walk's loop, sent the longest
+    walkers of the NEXT walk down the context path of an automaton without contexts (rejit_amd/csrc/lds_walk.h: CTX is a
+    template parameter since).  1 text in 750 showed it."""
+    oracle = Oracle()
+    rng = random.Random(5)
+    for rx, plant in ((b"[a-z]+@[a-z]+", b"Ad@abcdefgh"), (b"[a-z]+abcdefgh", b"0qqabcdefgh"), (b"\\d+x[a-f]+", b"A12xabcdefabc")):
+        p = rj.Program(rx)
+        for trial in range(700):
+            n = rng.randrange(20, 700)
+            alphabet = b"abcdx \nAB@" if trial % 2 else b"ABCDEFGH0123 x\n"
+            t2 = bytes(rng.choices(alphabet, k=n)) + plant
+            got = p.match_all(t2)
+            assert got in (oracle.match_all_spec(rx, t2), oracle.match_all(rx, t2)), (rx, trial, len(t2))

@@ -26,6 +26,6 @@ for src in srcs:
         def g(key):
             m = re.search(key + r": (\d+)", b)
             return int(m.group(1)) if m else -1
-        short = re.sub(r"\(.*", "", name).replace("rejit_amd::", "").replace("void ", "").replace("(anonymous namespace)::", "")
+        short = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", "")).replace("rejit_amd::", "").replace("void ", "")
         scratch, occ, lds = g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]"), g(r"LDS Size \[bytes/block\]")
         print(f"{short[:72]:72s} {g('VGPRs'):5d} {g('TotalSGPRs'):5d} {g('SGPRs Spill'):7d} {g('VGPRs Spill'):7d} {scratch:7d} {occ:3d} {lds:6d}")
