@@ -31,6 +31,120 @@ RJ_HD uint32_t lw_blob_words(int nq, int n_ctx, int n_pos) {
   return static_cast<uint32_t>(nq) * static_cast<uint32_t>(2 * n_ctx + 1 + n_ctx * (n_pos + 1) + 256);
 }
 
+// The text as the walks read it: `t[p]` for single bytes, and for the tight loops
+//   span(p, &ptr)       k >= 0 bytes text[p .. p + k) readable as ptr[0 .. k)   (never beyond the end of the text)
+//   span_back(p, &ptr)  k >= 0 bytes text[p - 1], text[p - 2], ... readable as ptr[0], ptr[-1], ...
+// This one is plain memory (CPU tests; verify_lds.hip has the LDS-window versions).
+struct PlainText {
+  const uint8_t* t;
+  uint64_t n;
+  RJ_HD PlainText(const uint8_t* text, uint64_t len) : t(text), n(len) {}
+  RJ_HD uint8_t operator[](uint64_t p) const { return t[p]; }
+  RJ_HD uint32_t span(uint64_t p, const uint8_t** ptr) const {
+    *ptr = t + p;
+    const uint64_t k = p < n ? n - p : 0;
+    return k > 0x40000000u ? 0x40000000u : static_cast<uint32_t>(k);
+  }
+  RJ_HD uint32_t span_back(uint64_t p, const uint8_t** ptr) const {
+    *ptr = t + p - 1;
+    return p > 0x40000000u ? 0x40000000u : static_cast<uint32_t>(p);
+  }
+};
+
+// The two LDS-window texts of verify_lds.hip.  `Loader::block16(dst, text, n, at)` puts text[at .. at + 16) (bytes at
+// or beyond n as 0) at dst; on the GPU dst is LDS, the CPU tests run the same index arithmetic over plain arrays
+// with every access checked (tests/support/carry_exec.cc).
+//
+// Floating windows: a window shared by the wave (every lane walks a start of the same hit); a walk that leaves it
+// -- a match of several hundred bytes -- goes on through 16 bytes of its own, refilled as it moves.
+template <class Loader>
+struct WaveWindowText {
+  const uint8_t* win;
+  uint8_t* slot;  // 16 bytes of this lane
+  uint64_t base;
+  uint32_t len;
+  const uint8_t* text;
+  uint64_t n;
+  mutable uint64_t slot_base;
+  RJ_HD WaveWindowText(const uint8_t* w, uint8_t* own, uint64_t b, uint32_t l, const uint8_t* t, uint64_t tn)
+      : win(w), slot(own), base(b), len(l), text(t), n(tn), slot_base(~0ull) {}
+  RJ_HD const uint8_t* far(uint64_t p) const {
+    const uint64_t b = p & ~15ull;
+    if (b != slot_base) {
+      slot_base = b;
+      Loader::block16(slot, text, n, b);
+    }
+    return slot + (static_cast<uint32_t>(p) & 15u);
+  }
+  // (plain 64-bit comparisons: the wrap-around forms `uint32(p - base) < len`, `d - 1u < len` went wrong in the
+  // device build of LaneWindowText below -- a backward walk read on past the window's first byte and past text[0])
+  RJ_HD bool holds(uint64_t p) const { return p >= base && p - base < len; }
+  RJ_HD uint8_t operator[](uint64_t p) const { return holds(p) ? win[static_cast<uint32_t>(p - base)] : *far(p); }
+  RJ_HD uint32_t span(uint64_t p, const uint8_t** ptr) const {
+    if (holds(p)) {
+      const uint32_t d = static_cast<uint32_t>(p - base);
+      *ptr = win + d;
+      return len - d;
+    }
+    if (p >= n) return 0;
+    *ptr = far(p);
+    const uint32_t k = 16u - (static_cast<uint32_t>(p) & 15u);
+    return n - p < k ? static_cast<uint32_t>(n - p) : k;
+  }
+  RJ_HD uint32_t span_back(uint64_t p, const uint8_t** ptr) const {
+    if (p > base && p - base <= len) {
+      const uint32_t d = static_cast<uint32_t>(p - base);
+      *ptr = win + d - 1;
+      return d;
+    }
+    if (p == 0) return 0;
+    *ptr = far(p - 1);
+    return (static_cast<uint32_t>(p - 1) & 15u) + 1u;
+  }
+};
+
+// Behind an unbounded prefix: a lane per hit, so the window (WIN bytes, a multiple of 16) is the lane's own and
+// simply moves when a walk leaves it.
+template <class Loader, uint32_t WIN>
+struct LaneWindowText {
+  uint8_t* win;
+  mutable uint64_t base;
+  mutable uint32_t len;
+  const uint8_t* text;
+  uint64_t n;
+  RJ_HD LaneWindowText(uint8_t* w, uint64_t b, uint32_t l, const uint8_t* t, uint64_t tn) : win(w), base(b), len(l), text(t), n(tn) {}
+  RJ_HD void move(uint64_t nb) const {  // (rare: block by block)
+    base = nb;
+    len = n - nb < WIN ? static_cast<uint32_t>(n - nb) : WIN;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (uint32_t k = 0; k < WIN / 16; k++) Loader::block16(win + 16 * k, text, n, nb + 16 * k);
+  }
+  RJ_HD bool holds(uint64_t p) const { return p >= base && p - base < len; }
+  RJ_HD uint8_t operator[](uint64_t p) const {
+    if (!holds(p)) move(p & ~15ull);
+    return win[static_cast<uint32_t>(p - base)];
+  }
+  RJ_HD uint32_t span(uint64_t p, const uint8_t** ptr) const {
+    if (p >= n) return 0;
+    if (!holds(p)) move(p & ~15ull);
+    const uint32_t d = static_cast<uint32_t>(p - base);
+    *ptr = win + d;
+    return len - d;
+  }
+  RJ_HD uint32_t span_back(uint64_t p, const uint8_t** ptr) const {
+    if (p == 0) return 0;
+    if (!holds(p - 1)) {  // put text[p - 1] into the window's last block
+      const uint64_t blk = (p - 1) & ~15ull;
+      move(blk >= WIN - 16 ? blk - (WIN - 16) : 0ull);
+    }
+    const uint32_t d = static_cast<uint32_t>(p - base);
+    *ptr = win + d - 1;
+    return d;
+  }
+};
+
 template <int NQ>
 struct WalkTab {
   const uint64_t* first;
@@ -129,6 +243,49 @@ RJ_HD bool lw_longest(const WalkTab<NQ>& T, const Text& t, uint64_t n, uint64_t 
 #pragma unroll
     for (int q = 0; q < NQ; q++) alive |= S[q];
     if (!alive) break;
+    {
+      // The boundaries at which nothing but a step can happen -- inside the text, below the walk limit, not a
+      // poll boundary, bytes at hand -- in a loop with ONE exit: the general iteration below spends most of its
+      // ~150 instructions on the masks of its five exits, and a lone wave pays every instruction in full.
+      const uint64_t k = p - s;
+      uint64_t m = (k & 255u) != 0 ? 256u - (k & 255u) : 0u;
+      if (k >= T.max_walk) m = 0;
+      else if (T.max_walk - k < m) m = T.max_walk - k;
+      const uint8_t* ptr = nullptr;
+      const uint32_t at_hand = m != 0 ? t.span(p, &ptr) : 0u;  // (never beyond the end of the text)
+      if (at_hand < m) m = at_hand;
+      if (m != 0) {
+        uint32_t i = 0, hit = ~0u, prev = cur;
+        uint64_t live;
+        do {
+          const uint32_t c = ptr[i];
+          const int cx = ctxed ? lw_ctx(false, prev, false, c) : 0;
+          const uint64_t* lr = T.last + cx * NQ;
+          uint64_t acc = 0;
+#pragma unroll
+          for (int q = 0; q < NQ; q++) acc |= S[q] & lr[q];
+          hit = acc != 0 ? i : hit;
+          uint64_t N[NQ];
+          lw_follow<NQ>(T, S, cx, N);
+          const uint64_t* cr = T.cls + c * NQ;
+          live = 0;
+#pragma unroll
+          for (int q = 0; q < NQ; q++) {
+            S[q] = N[q] & cr[q];
+            live |= S[q];
+          }
+          prev = c;
+          i++;
+        } while (i < m && live != 0);
+        if (hit != ~0u) {
+          found = true;
+          *end = p + hit;
+        }
+        cur = prev;
+        p += i;
+        continue;
+      }
+    }
     const uint32_t prev = cur;
     cur = p < n ? t[p] : 0u;
     ctx = ctxed ? lw_ctx(false, prev, p == n, cur) : 0;
@@ -178,7 +335,46 @@ RJ_HD bool lw_reaches_accept(const WalkTab<NQ>& T, const Text& t, uint64_t n, ui
   for (int k = 0; k < NQ; k++) S[k] = 0;
   S[q >> 6] = 1ull << (q & 63);
   uint32_t cur = t[p];
-  for (uint64_t at = p + 1;; at++) {  // S = positions that have consumed text[at - 1]
+  uint64_t at = p + 1;
+  for (;;) {  // S = positions that have consumed text[at - 1]
+    {
+      // (the plain steps in a tight loop, see lw_longest)
+      const uint64_t k = at - p;
+      uint64_t m = (k & 255u) != 0 ? 256u - (k & 255u) : 0u;
+      if (k >= T.max_walk) m = 0;
+      else if (T.max_walk - k < m) m = T.max_walk - k;
+      const uint8_t* ptr = nullptr;
+      const uint32_t at_hand = m != 0 ? t.span(at, &ptr) : 0u;
+      if (at_hand < m) m = at_hand;
+      if (m != 0) {
+        uint32_t i = 0, prev = cur;
+        int state = 0;  // 1: accepted, 2: dead
+        do {
+          const uint32_t c = ptr[i];
+          const int cx = ctxed ? lw_ctx(false, prev, false, c) : 0;
+          const uint64_t* lr = T.last + cx * NQ;
+          uint64_t acc = 0, live = 0;
+#pragma unroll
+          for (int j = 0; j < NQ; j++) acc |= S[j] & lr[j];
+          uint64_t N[NQ];
+          lw_follow<NQ>(T, S, cx, N);
+          const uint64_t* cr = T.cls + c * NQ;
+#pragma unroll
+          for (int j = 0; j < NQ; j++) {
+            S[j] = N[j] & cr[j];
+            live |= S[j];
+          }
+          state = acc != 0 ? 1 : live == 0 ? 2 : 0;
+          prev = c;
+          i++;
+        } while (i < m && state == 0);
+        if (state == 1) return true;
+        if (state == 2) return false;
+        cur = prev;
+        at += i;
+        continue;
+      }
+    }
     const uint32_t prev = cur;
     cur = at < n ? t[at] : 0u;
     const int ctx = ctxed ? lw_ctx(false, prev, at == n, cur) : 0;
@@ -202,6 +398,7 @@ RJ_HD bool lw_reaches_accept(const WalkTab<NQ>& T, const Text& t, uint64_t n, ui
       alive |= S[k];
     }
     if (!alive) return false;
+    at++;
   }
 }
 
@@ -213,7 +410,50 @@ RJ_HD bool lw_leftmost_start(const WalkTab<NQ>& R, const Text& t, uint64_t n, ui
   constexpr bool ctxed = CTX;
   bool found = false;
   uint32_t cur = t[p];  // text[at]
-  for (uint64_t at = p;; at--) {  // S = reverse positions that have consumed text[at]
+  uint64_t at = p;
+  for (;;) {  // S = reverse positions that have consumed text[at]
+    {
+      // (the plain steps in a tight loop, see lw_longest: boundaries at, at - 1, ... that are >= 1, below the walk
+      // limit, not a poll boundary, their byte before at hand)
+      const uint64_t k = p - at;
+      uint64_t m = (k & 255u) != 0 ? 256u - (k & 255u) : 0u;
+      if (k >= max_walk) m = 0;
+      else if (max_walk - k < m) m = max_walk - k;
+      const uint8_t* ptr = nullptr;
+      const uint32_t at_hand = m != 0 ? t.span_back(at, &ptr) : 0u;  // text[at - 1], text[at - 2], ... = ptr[0], ptr[-1], ...
+      if (at_hand < m) m = at_hand;
+      if (m != 0) {
+        uint32_t i = 0, hit = ~0u;
+        uint64_t live;
+        do {
+          const uint32_t before = *(ptr - i);
+          const int cx = ctxed ? lw_ctx(false, before, false, cur) : 0;
+          const uint64_t* lr = R.last + cx * NQ;
+          uint64_t acc = 0;
+#pragma unroll
+          for (int j = 0; j < NQ; j++) acc |= S[j] & lr[j];
+          hit = acc != 0 ? i : hit;
+          uint64_t N[NQ];
+          lw_follow<NQ>(R, S, cx, N);
+          const uint64_t* cr = R.cls + before * NQ;
+          live = 0;
+#pragma unroll
+          for (int j = 0; j < NQ; j++) {
+            S[j] = N[j] & cr[j];
+            live |= S[j];
+          }
+          cur = before;
+          i++;
+        } while (i < m && live != 0);
+        if (hit != ~0u) {
+          found = true;
+          *start = at - hit;
+        }
+        if (live == 0) break;
+        at -= i;
+        continue;
+      }
+    }
     const uint32_t before = at > 0 ? t[at - 1] : 0u;
     const int ctx = ctxed ? lw_ctx(at == 0, before, at == n, cur) : 0;
     const uint64_t* lr = R.last + ctx * NQ;
@@ -240,6 +480,7 @@ RJ_HD bool lw_leftmost_start(const WalkTab<NQ>& R, const Text& t, uint64_t n, ui
     }
     if (!alive) break;
     cur = before;
+    at--;
   }
   return found;
 }

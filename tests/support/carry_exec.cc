@@ -346,15 +346,45 @@ long ce_short_check(const char* re, const uint8_t* text, uint64_t n, uint64_t* c
 //   lw_leftmost_start == rj_leftmost_start from the single reverse position of q;
 //   behind patterns, every text position: lw_behind_candidate == rj_behind_candidate.
 // Returns the number of disagreements (-9: wider than 128 positions); *checked = comparisons made.
-template <int NQ, int NW, bool CTX>
-static long lds_walk_check(const Program& P, const DevProgram& F, const DevProgram& R, const WalkTab<NQ>& WF, const WalkTab<NQ>& WR,
-                           const uint8_t* text, uint64_t n, uint64_t* checked) {
+// text that hands out its bytes in aligned blocks of B at most: the tight loops of the walkers then run in many
+// short pieces, like a walk that leaves its LDS window on the GPU
+template <unsigned B>
+struct BlockText {
+  const uint8_t* t;
+  uint64_t n;
+  uint8_t operator[](uint64_t p) const { return t[p]; }
+  uint32_t span(uint64_t p, const uint8_t** ptr) const {
+    *ptr = t + p;
+    if (p >= n) return 0;
+    const uint64_t k = B - (p % B);
+    return static_cast<uint32_t>(std::min<uint64_t>(k, n - p));
+  }
+  uint32_t span_back(uint64_t p, const uint8_t** ptr) const {
+    *ptr = t + p - 1;
+    if (p == 0) return 0;
+    return static_cast<uint32_t>((p - 1) % B + 1);
+  }
+};
+
+// The GPU's window texts (lds_walk.h) over plain arrays: the loader checks every block it is asked for, and the
+// windows sit between guard bytes that must stay untouched.
+static long g_loader_violations = 0;
+struct CheckedLoader {
+  static void block16(uint8_t* dst, const uint8_t* text, uint64_t n, uint64_t at) {
+    if ((at & 15u) != 0 || at > n + 4096) g_loader_violations++;
+    for (uint64_t k = 0; k < 16; k++) dst[k] = at + k < n ? text[at + k] : 0;
+  }
+};
+
+template <int NQ, int NW, bool CTX, class WText>
+static long lds_walk_check_with(const Program& P, const DevProgram& F, const DevProgram& R, const WalkTab<NQ>& WF, const WalkTab<NQ>& WR,
+                                const uint8_t* text, const WText& wtext, uint64_t n, uint64_t* checked) {
   long bad = 0;
   for (uint64_t s0 = 0; s0 <= n; s0++) {
     uint64_t e1 = 0, e2 = 0;
     bool o1 = false, o2 = false;
     const bool f1 = rj_lane_longest<NQ>(F, text, n, s0, &e1, &o1);
-    const bool f2 = lw_longest<NQ, CTX>(WF, text, n, s0, &e2, &o2);
+    const bool f2 = lw_longest<NQ, CTX>(WF, wtext, n, s0, &e2, &o2);
     if (f1 != f2 || o1 != o2 || (f1 && e1 != e2)) bad++;
     (*checked)++;
   }
@@ -362,7 +392,7 @@ static long lds_walk_check(const Program& P, const DevProgram& F, const DevProgr
     for (int q = 0; q < P.n_pos; q++) {
       bool o1 = false, o2 = false;
       const bool r1 = rj_reaches_accept<NW>(F, text, n, p, q, &o1);
-      const bool r2 = lw_reaches_accept<NQ, CTX>(WF, text, n, p, q, &o2);
+      const bool r2 = lw_reaches_accept<NQ, CTX>(WF, wtext, n, p, q, &o2);
       if (r1 != r2 || o1 != o2) bad++;
       uint32_t S1[NW];
       uint64_t S2[NQ];
@@ -373,7 +403,7 @@ static long lds_walk_check(const Program& P, const DevProgram& F, const DevProgr
       uint64_t b1 = 0, b2 = 0;
       o1 = o2 = false;
       const bool l1 = rj_leftmost_start<NW>(R, text, n, p, S1, F.max_walk, &b1, &o1);
-      const bool l2 = lw_leftmost_start<NQ, CTX>(WR, text, n, p, S2, F.max_walk, &b2, &o2);
+      const bool l2 = lw_leftmost_start<NQ, CTX>(WR, wtext, n, p, S2, F.max_walk, &b2, &o2);
       if (l1 != l2 || o1 != o2 || (l1 && b1 != b2)) bad++;
       (*checked) += 2;
     }
@@ -381,12 +411,60 @@ static long lds_walk_check(const Program& P, const DevProgram& F, const DevProgr
       uint64_t b1 = 0, e1 = 0, b2 = 0, e2 = 0;
       bool o1 = false, o2 = false;
       const bool c1 = rj_behind_candidate<NW, NQ>(F, R, text, n, p, &b1, &e1, &o1);
-      const bool c2 = lw_behind_candidate<NQ, CTX>(F, WF, WR, text, n, p, &b2, &e2, &o2);
+      const bool c2 = lw_behind_candidate<NQ, CTX>(F, WF, WR, wtext, n, p, &b2, &e2, &o2);
       if (c1 != c2 || o1 != o2 || (c1 && (b1 != b2 || e1 != e2))) bad++;
       (*checked)++;
     }
   }
   return bad;
+}
+
+template <int NQ, int NW, bool CTX>
+static long lds_walk_check(const Program& P, const DevProgram& F, const DevProgram& R, const WalkTab<NQ>& WF, const WalkTab<NQ>& WR,
+                           const uint8_t* text, uint64_t n, uint64_t* checked) {
+  long extra = 0;
+  {
+    // a lane window of 48 bytes and a wave window of 64 bytes + a 16-byte slot, placed around every 7th position:
+    // walks from there leave the windows in both directions
+    std::vector<uint8_t> arena(16 + 64 + 16 + 16 + 16, 0xEE);
+    for (uint64_t c = 0; c <= n; c += 7) {
+      const uint64_t wb = c >= 16 ? (c - 16) & ~15ull : 0;
+      uint8_t* lane_win = arena.data() + 16;
+      LaneWindowText<CheckedLoader, 48> lt(lane_win, wb, 0, text, n);
+      lt.move(wb);
+      uint64_t e1 = 0, e2 = 0, b1 = 0, b2 = 0;
+      bool o1 = false, o2 = false;
+      const bool f1 = rj_lane_longest<NQ>(F, text, n, c, &e1, &o1), f2 = lw_longest<NQ, CTX>(WF, lt, n, c, &e2, &o2);
+      if (f1 != f2 || o1 != o2 || (f1 && e1 != e2)) extra++;
+      for (int q = 0; q < P.n_pos && c < n; q += 3) {
+        uint32_t S1[NW];
+        uint64_t S2[NQ];
+        for (int k = 0; k < NW; k++) S1[k] = 0;
+        for (int k = 0; k < NQ; k++) S2[k] = 0;
+        S1[q >> 5] = 1u << (q & 31);
+        S2[q >> 6] = 1ull << (q & 63);
+        o1 = o2 = false;
+        const bool l1 = rj_leftmost_start<NW>(R, text, n, c, S1, F.max_walk, &b1, &o1);
+        const bool l2 = lw_leftmost_start<NQ, CTX>(WR, lt, n, c, S2, F.max_walk, &b2, &o2);
+        if (l1 != l2 || o1 != o2 || (l1 && b1 != b2)) extra++;
+      }
+      uint8_t* wave_win = arena.data() + 16;
+      for (uint64_t k = 0; k < 64; k += 16) CheckedLoader::block16(wave_win + k, text, n, wb + k);
+      const uint64_t avail = n - wb;
+      WaveWindowText<CheckedLoader> wt(wave_win, arena.data() + 16 + 64 + 16, wb, avail < 64 ? static_cast<uint32_t>(avail) : 64u, text, n);
+      o2 = false;
+      const bool f3 = lw_longest<NQ, CTX>(WF, wt, n, c, &e2, &o2);
+      if (f1 != f3 || (f1 && e1 != e2)) extra++;
+      for (size_t g = 0; g < 16; g++)
+        if (arena[g] != 0xEE || arena[16 + 64 + g] != 0xEE || arena[16 + 64 + 32 + g] != 0xEE) extra++;
+      (*checked) += 3;
+    }
+    extra += g_loader_violations;
+    g_loader_violations = 0;
+  }
+  return extra + lds_walk_check_with<NQ, NW, CTX>(P, F, R, WF, WR, text, PlainText(text, n), n, checked) +
+         lds_walk_check_with<NQ, NW, CTX>(P, F, R, WF, WR, text, BlockText<16>{text, n}, n, checked) +
+         lds_walk_check_with<NQ, NW, CTX>(P, F, R, WF, WR, text, BlockText<3>{text, n}, n, checked);
 }
 
 extern "C" {
