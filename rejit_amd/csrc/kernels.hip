@@ -1224,11 +1224,17 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
   const uint32_t cnt = r < n_regions ? counts[r] : 0u;
   const uint64_t src = static_cast<uint64_t>(r) * region_cap;
   uint64_t hb[kHeld], he[kHeld];
+  // (loaded whatever the count says -- the slots exist, an empty region's hold rubbish that is zeroed below -- so
+  // that they leave together with the count instead of a trip behind it)
 #pragma unroll
   for (int k = 0; k < kHeld; k++) {
-    hb[k] = static_cast<uint32_t>(k) < cnt ? region_begins[src + k] : 0;
-    he[k] = static_cast<uint32_t>(k) < cnt ? region_ends[src + k] : 0;
+    const bool slot = r < n_regions && static_cast<uint32_t>(k) < region_cap;
+    hb[k] = slot ? region_begins[src + k] : 0;
+    he[k] = slot ? region_ends[src + k] : 0;
   }
+#pragma unroll
+  for (int k = 0; k < kHeld; k++)
+    if (static_cast<uint32_t>(k) >= cnt) hb[k] = he[k] = 0;
   // the region's largest end: the held ones and the LAST one.  (Exact whenever the region is
   // ordered inside, and when it is not the copy below flags the list anyway.)
   uint64_t my_end = 0;

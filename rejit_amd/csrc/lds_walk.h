@@ -13,7 +13,9 @@
 // each a single ds_read of 8 or 16 bytes.  Results are identical to the old walkers by construction
 // (same recurrence S' = follow_ctx(S) & cls[byte]); tests/test_carry_scan.py::test_lds_walkers_* checks it.
 //
-// Blob layout (uint64 words):  first [C][NQ]  last [C][NQ]  linear [NQ]  rows [C][n_pos + 1][NQ]  cls [256][NQ]
+// Blob layout (uint64 words):  first [C][NQ]  last [C][NQ]  linear [NQ]  loops [NQ]  rows [C][n_pos + 1][NQ]  cls [256][NQ]
+// (loops: non-linear positions whose follow set is {i, i + 1} in every context -- x+, x*, .* -- stepped with two
+// shifts instead of a row read: the commonest kind, and the read was the one LDS trip left in a step's chain)
 #ifndef REJIT_AMD_LDS_WALK_H_
 #define REJIT_AMD_LDS_WALK_H_
 
@@ -28,7 +30,7 @@
 namespace rejit_amd {
 
 RJ_HD uint32_t lw_blob_words(int nq, int n_ctx, int n_pos) {
-  return static_cast<uint32_t>(nq) * static_cast<uint32_t>(2 * n_ctx + 1 + n_ctx * (n_pos + 1) + 256);
+  return static_cast<uint32_t>(nq) * static_cast<uint32_t>(2 * n_ctx + 2 + n_ctx * (n_pos + 1) + 256);
 }
 
 // The text as the walks read it: `t[p]` for single bytes, and for the tight loops
@@ -152,6 +154,7 @@ struct WalkTab {
   const uint64_t* rows;
   const uint64_t* cls;
   uint64_t linear[NQ];
+  uint64_t loops[NQ];
   int32_t n_ctx, n_pos;
   uint32_t nullable;  // DevProgram::nullable
   uint32_t max_walk;  // DevProgram::max_walk
@@ -164,8 +167,11 @@ RJ_HD WalkTab<NQ> lw_point(const uint64_t* blob, int n_ctx, int n_pos, uint32_t 
   T.last = blob + n_ctx * NQ;
   const uint64_t* lin = blob + 2 * n_ctx * NQ;
 #pragma unroll
-  for (int q = 0; q < NQ; q++) T.linear[q] = lin[q];
-  T.rows = lin + NQ;
+  for (int q = 0; q < NQ; q++) {
+    T.linear[q] = lin[q];
+    T.loops[q] = lin[NQ + q];
+  }
+  T.rows = lin + 2 * NQ;
   T.cls = T.rows + static_cast<uint32_t>(n_ctx * (n_pos + 1)) * NQ;
   T.n_ctx = n_ctx;
   T.n_pos = n_pos;
@@ -181,14 +187,14 @@ RJ_HD void lw_follow(const WalkTab<NQ>& T, const uint64_t (&S)[NQ], int ctx, uin
   uint64_t carry = 0;
 #pragma unroll
   for (int q = 0; q < NQ; q++) {
-    const uint64_t x = S[q] & T.linear[q];
-    out[q] = (x << 1) | carry;
+    const uint64_t l = S[q] & T.loops[q], x = (S[q] & T.linear[q]) | l;  // (disjoint masks)
+    out[q] = (x << 1) | carry | l;
     carry = x >> 63;
   }
   const uint64_t* rows = T.rows + static_cast<uint32_t>(ctx * (T.n_pos + 1)) * NQ;
 #pragma unroll
   for (int q = 0; q < NQ; q++) {
-    uint64_t sp = S[q] & ~T.linear[q];
+    uint64_t sp = S[q] & ~(T.linear[q] | T.loops[q]);
     while (sp) {
       const int i0 = q * 64 + __builtin_ctzll(sp);
       sp &= sp - 1;
@@ -255,10 +261,27 @@ RJ_HD bool lw_longest(const WalkTab<NQ>& T, const Text& t, uint64_t n, uint64_t 
       const uint32_t at_hand = m != 0 ? t.span(p, &ptr) : 0u;  // (never beyond the end of the text)
       if (at_hand < m) m = at_hand;
       if (m != 0) {
+        // The byte two steps ahead and the class row one step ahead are fetched while the current step runs:
+        // neither depends on the automaton state, and read on demand they were two LDS round trips in every
+        // step's dependent chain.  (Indices are clamped to the span: the extra reads repeat its last byte.)
         uint32_t i = 0, hit = ~0u, prev = cur;
         uint64_t live;
+        const uint32_t last_i = static_cast<uint32_t>(m) - 1u;
+        uint32_t c = ptr[0], c1 = ptr[last_i < 1u ? last_i : 1u];
+        uint64_t row[NQ];
+        {
+          const uint64_t* cr = T.cls + c * NQ;
+#pragma unroll
+          for (int q = 0; q < NQ; q++) row[q] = cr[q];
+        }
         do {
-          const uint32_t c = ptr[i];
+          const uint32_t c2 = ptr[i + 2u < last_i ? i + 2u : last_i];
+          uint64_t row1[NQ];
+          {
+            const uint64_t* cr = T.cls + c1 * NQ;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) row1[q] = cr[q];
+          }
           const int cx = ctxed ? lw_ctx(false, prev, false, c) : 0;
           const uint64_t* lr = T.last + cx * NQ;
           uint64_t acc = 0;
@@ -267,14 +290,16 @@ RJ_HD bool lw_longest(const WalkTab<NQ>& T, const Text& t, uint64_t n, uint64_t 
           hit = acc != 0 ? i : hit;
           uint64_t N[NQ];
           lw_follow<NQ>(T, S, cx, N);
-          const uint64_t* cr = T.cls + c * NQ;
           live = 0;
 #pragma unroll
           for (int q = 0; q < NQ; q++) {
-            S[q] = N[q] & cr[q];
+            S[q] = N[q] & row[q];
             live |= S[q];
+            row[q] = row1[q];
           }
           prev = c;
+          c = c1;
+          c1 = c2;
           i++;
         } while (i < m && live != 0);
         if (hit != ~0u) {
@@ -423,10 +448,25 @@ RJ_HD bool lw_leftmost_start(const WalkTab<NQ>& R, const Text& t, uint64_t n, ui
       const uint32_t at_hand = m != 0 ? t.span_back(at, &ptr) : 0u;  // text[at - 1], text[at - 2], ... = ptr[0], ptr[-1], ...
       if (at_hand < m) m = at_hand;
       if (m != 0) {
+        // (bytes two steps ahead, class rows one step ahead: see lw_longest)
         uint32_t i = 0, hit = ~0u;
         uint64_t live;
+        const uint32_t last_i = static_cast<uint32_t>(m) - 1u;
+        uint32_t before = *ptr, before1 = *(ptr - (last_i < 1u ? last_i : 1u));
+        uint64_t row[NQ];
+        {
+          const uint64_t* cr = R.cls + before * NQ;
+#pragma unroll
+          for (int j = 0; j < NQ; j++) row[j] = cr[j];
+        }
         do {
-          const uint32_t before = *(ptr - i);
+          const uint32_t before2 = *(ptr - (i + 2u < last_i ? i + 2u : last_i));
+          uint64_t row1[NQ];
+          {
+            const uint64_t* cr = R.cls + before1 * NQ;
+#pragma unroll
+            for (int j = 0; j < NQ; j++) row1[j] = cr[j];
+          }
           const int cx = ctxed ? lw_ctx(false, before, false, cur) : 0;
           const uint64_t* lr = R.last + cx * NQ;
           uint64_t acc = 0;
@@ -435,14 +475,16 @@ RJ_HD bool lw_leftmost_start(const WalkTab<NQ>& R, const Text& t, uint64_t n, ui
           hit = acc != 0 ? i : hit;
           uint64_t N[NQ];
           lw_follow<NQ>(R, S, cx, N);
-          const uint64_t* cr = R.cls + before * NQ;
           live = 0;
 #pragma unroll
           for (int j = 0; j < NQ; j++) {
-            S[j] = N[j] & cr[j];
+            S[j] = N[j] & row[j];
             live |= S[j];
+            row[j] = row1[j];
           }
           cur = before;
+          before = before1;
+          before1 = before2;
           i++;
         } while (i < m && live != 0);
         if (hit != ~0u) {

@@ -61,7 +61,7 @@ inline std::vector<uint64_t> make_walk_blob(const TableBlob& b, int n_pos, int n
   auto pack = [&](size_t dst, size_t src) {  // W 32-bit words at b.words[src] -> NQ 64-bit words at out[dst]
     for (size_t k = 0; k < W && k < 2 * NQ; k++) out[dst + k / 2] |= static_cast<uint64_t>(b.words[src + k]) << (32 * (k & 1));
   };
-  const size_t o_first = 0, o_last = C * NQ, o_lin = 2 * C * NQ, o_rows = o_lin + NQ, o_cls = o_rows + C * (P + 1) * NQ;
+  const size_t o_first = 0, o_last = C * NQ, o_lin = 2 * C * NQ, o_loop = o_lin + NQ, o_rows = o_loop + NQ, o_cls = o_rows + C * (P + 1) * NQ;
   for (size_t c = 0; c < C; c++) {
     pack(o_first + c * NQ, b.off_first + c * W);
     pack(o_last + c * NQ, b.off_last + c * W);
@@ -72,6 +72,19 @@ inline std::vector<uint64_t> make_walk_blob(const TableBlob& b, int n_pos, int n
   }
   pack(o_lin, b.off_linear);
   for (size_t v = 0; v < 256; v++) pack(o_cls + v * NQ, b.off_cls + v * W);
+  // loops: rows that are exactly {i, i + 1} in every context (position i + 1 exists)
+  for (size_t i = 0; i + 1 < P; i++) {
+    if (static_cast<int32_t>(b.words[b.off_rowof + i]) < 0) continue;
+    bool loop = true;
+    for (size_t c = 0; c < C && loop; c++)
+      for (size_t q = 0; q < NQ && loop; q++) {
+        uint64_t want = 0;
+        if (i / 64 == q) want |= 1ull << (i % 64);
+        if ((i + 1) / 64 == q) want |= 1ull << ((i + 1) % 64);
+        loop = out[o_rows + (c * (P + 1) + i) * NQ + q] == want;
+      }
+    if (loop) out[o_loop + i / 64] |= 1ull << (i % 64);
+  }
   return out;
 }
 

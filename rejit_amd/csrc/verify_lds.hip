@@ -41,7 +41,7 @@ namespace rejit_amd {
 namespace {
 
 constexpr int kWave = 64;
-constexpr uint32_t kRegionsPerBlock = 64;
+constexpr uint32_t kRegionsPerBlock = 32;  // (64: a fifth of the workgroups of a 1000-hit run had more regions with hits than waves; 16: no faster)
 constexpr uint32_t kWinBytes = 1024;      // floating: text window of a wave (64 lanes x 16 B)
 constexpr uint32_t kLaneWin = 128;        // behind: text window of a lane ...
 constexpr uint32_t kLaneWinStride = 144;  // ... at this stride (16-byte aligned slots, 8 banks apart)
@@ -92,20 +92,42 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ void copy_blob(uint64_t* dst, const uint64_t* src, uint32_t words) {
+// The table copy in two halves: the loads leave with the workgroup's first trip (before it is known whether any of
+// its regions has a hit -- the tables are a few KiB that every workgroup finds in L2), the LDS stores follow once
+// one has.  kBlobRegs x 256 lanes x 16 bytes are held in registers, a longer blob's rest is copied the plain way.
+constexpr uint32_t kBlobRegs = 3;
+struct BlobRegs {
+  uint4 v[kBlobRegs];
+};
+__device__ __forceinline__ BlobRegs blob_fetch(const uint64_t* src, uint32_t words) {
+  BlobRegs b;
+  const uint4* s4 = reinterpret_cast<const uint4*>(src);
+#pragma unroll
+  for (uint32_t k = 0; k < kBlobRegs; k++) {
+    const uint32_t i = threadIdx.x + k * 256u;
+    b.v[k] = i < words / 2 ? s4[i] : make_uint4(0u, 0u, 0u, 0u);
+  }
+  return b;
+}
+__device__ __forceinline__ void blob_store(uint64_t* dst, const uint64_t* src, uint32_t words, const BlobRegs& b) {
   const uint4* s4 = reinterpret_cast<const uint4*>(src);
   uint4* d4 = reinterpret_cast<uint4*>(dst);
-  for (uint32_t i = threadIdx.x; i < words / 2; i += blockDim.x) d4[i] = s4[i];
+#pragma unroll
+  for (uint32_t k = 0; k < kBlobRegs; k++) {
+    const uint32_t i = threadIdx.x + k * 256u;
+    if (i < words / 2) d4[i] = b.v[k];
+  }
+  for (uint32_t i = threadIdx.x + kBlobRegs * 256u; i < words / 2; i += 256u) d4[i] = s4[i];
 }
 
 __device__ __forceinline__ uint64_t window_base(uint64_t lo) { return lo >= 16 ? (lo - 16) & ~15ull : 0ull; }
 
 // What a workgroup knows about its 64 regions after the first trip (one region per lane of wave 0).
 struct BlockRegions {
-  uint32_t raw[kRegionsPerBlock];   // hit counts as the scan left them
-  uint64_t first[kRegionsPerBlock]; // the region's first hit (rubbish when the region is empty)
-  uint64_t before[kRegionsPerBlock];// floating: 1 + the last hit of the region right before, 0 when that one is empty
-  uint64_t todo;                    // bit k: region k has hits
+  uint32_t raw[kWave];     // hit counts as the scan left them (a region per lane of the first wave)
+  uint64_t first[kWave];   // the region's first hit (rubbish when the region is empty)
+  uint64_t before[kWave];  // floating: 1 + the last hit of the region right before, 0 when that one is empty
+  uint64_t todo;           // bit k: region k has hits
 };
 
 // Floating windows: a hit at w makes every s in [w - float_max, w - float_min] a candidate start.  A wave per
@@ -121,44 +143,46 @@ __global__ __launch_bounds__(256) void verify_floating_lds(VerifyParams a, WalkD
   uint8_t* win = reinterpret_cast<uint8_t*>(lds + d.words) + static_cast<uint32_t>(wave) * kWinBytes;
   uint8_t* slot = reinterpret_cast<uint8_t*>(lds + d.words) + 4 * kWinBytes + (static_cast<uint32_t>(wave) * kWave + static_cast<uint32_t>(sub)) * 16;
   const uint64_t r0 = static_cast<uint64_t>(blockIdx.x) * kRegionsPerBlock;
-  if (blockIdx.x == 0 && threadIdx.x == 0) RJ_STAMP(0);
+  if (threadIdx.x == 0) RJ_STAMP(0);
+  const BlobRegs tables = blob_fetch(d.blob, d.words);
   // trip 1 (wave 0, a region per lane): the count, the count of the region before, and -- speculatively -- the first hit
   bool any = false;
+  uint64_t pw = 0;     // wave 0: the last hit of the region before this lane's region ...
+  bool has_pw = false; // ... when both have hits (trip 2, in flight across the first barrier)
   if (wave == 0) {
     const uint64_t r = r0 + static_cast<uint64_t>(sub);
-    const bool mine = r < a.n_regions;
+    const bool mine = r < a.n_regions && static_cast<uint32_t>(sub) < kRegionsPerBlock;
     const uint32_t raw = mine ? hit_counts[r] : 0u;
     const uint32_t prev_raw = mine && r > 0 ? hit_counts[r - 1] : 0u;
     const uint64_t w0 = mine ? a.hits[r * a.region_cap] : 0ull;
     br.raw[sub] = raw;
     br.first[sub] = w0;
-    // trip 2 for the few: the last hit of the region before a region with hits
-    uint64_t pw = 0;
-    if (raw != 0 && prev_raw != 0) pw = a.hits[(r - 1) * a.region_cap + (prev_raw < a.region_cap ? prev_raw : a.region_cap) - 1];
-    br.before[sub] = raw != 0 && prev_raw != 0 ? pw + 1 : 0;  // (+ 1: 0 means none)
+    has_pw = raw != 0 && prev_raw != 0;
+    if (has_pw) pw = a.hits[(r - 1) * a.region_cap + (prev_raw < a.region_cap ? prev_raw : a.region_cap) - 1];
     if (mine && raw == 0) valid_counts[r] = 0;
     any = raw != 0;
     const uint64_t mask = __ballot(any);
     if (sub == 0) br.todo = mask;
   }
-  if (!__syncthreads_or(any)) return;  // nothing to verify in these 64 regions
-  copy_blob(lds, d.blob, d.words);
+  if (!__syncthreads_or(any)) return;  // nothing to verify in these regions
+  blob_store(lds, d.blob, d.words, tables);
   const uint64_t todo = br.todo;  // the regions with hits, shared out among the four waves
   // this wave's first region: its text window can leave together with the table copy
   uint32_t mine_k = 0;
   {
     uint64_t m = todo;
     for (int skip = 0; skip < wave && m != 0; skip++) m &= m - 1;
-    mine_k = m != 0 ? static_cast<uint32_t>(__builtin_ctzll(m)) : kRegionsPerBlock;
+    mine_k = m != 0 ? static_cast<uint32_t>(__builtin_ctzll(m)) : kWave;
   }
   uint64_t w = 0, wbase = 0;
-  if (mine_k < kRegionsPerBlock) {
+  if (mine_k < kWave) {
     w = br.first[mine_k];
     wbase = window_base(w >= a.float_max ? w - a.float_max : 0);
     stage16(win + 16 * sub, a.text, a.n, wbase + 16 * static_cast<uint64_t>(sub));
   }
+  if (wave == 0) br.before[sub] = has_pw ? pw + 1 : 0;  // (+ 1: 0 means none)
   __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x == 0) RJ_STAMP(1);
+  if (threadIdx.x == 0) RJ_STAMP(1);
   const WalkTab<NQ> T = lw_point<NQ>(lds, d.n_ctx, d.n_pos, d.nullable, d.max_walk);
   uint32_t nth = static_cast<uint32_t>(wave);  // this wave takes the nth, (nth + 4)th, ... region with hits
   for (uint64_t m = todo; m != 0; m &= m - 1, nth--) {
@@ -256,11 +280,12 @@ __global__ __launch_bounds__(256) void verify_behind_lds(VerifyParams a, DevProg
   const int wave = static_cast<int>(threadIdx.x) >> 6, sub = lane_id();
   uint8_t* win = reinterpret_cast<uint8_t*>(lds + 2 * d.words) + (static_cast<uint32_t>(wave) * kWave + static_cast<uint32_t>(sub)) * kLaneWinStride;
   const uint64_t r0 = static_cast<uint64_t>(blockIdx.x) * kRegionsPerBlock;
-  if (blockIdx.x == 0 && threadIdx.x == 0) RJ_STAMP(0);
+  if (threadIdx.x == 0) RJ_STAMP(0);
+  const BlobRegs fwd_tables = blob_fetch(d.blob, d.words), rev_tables = blob_fetch(d.rev_blob, d.words);
   bool any = false;
   if (wave == 0) {
     const uint64_t r = r0 + static_cast<uint64_t>(sub);
-    const bool mine = r < a.n_regions;
+    const bool mine = r < a.n_regions && static_cast<uint32_t>(sub) < kRegionsPerBlock;
     const uint32_t raw = mine ? hit_counts[r] : 0u;
     const uint64_t w0 = mine ? a.hits[r * a.region_cap] : 0ull;
     br.raw[sub] = raw;
@@ -271,11 +296,11 @@ __global__ __launch_bounds__(256) void verify_behind_lds(VerifyParams a, DevProg
     if (sub == 0) br.todo = mask;
   }
   if (!__syncthreads_or(any)) return;
-  copy_blob(lds, d.blob, d.words);
-  copy_blob(lds + d.words, d.rev_blob, d.words);
+  blob_store(lds, d.blob, d.words, fwd_tables);
+  blob_store(lds + d.words, d.rev_blob, d.words, rev_tables);
   const uint64_t todo = br.todo;
   __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x == 0) RJ_STAMP(1);
+  if (threadIdx.x == 0) RJ_STAMP(1);
   const WalkTab<NQ> F = lw_point<NQ>(lds, d.n_ctx, d.n_pos, d.nullable, d.max_walk);
   const WalkTab<NQ> R = lw_point<NQ>(lds + d.words, d.n_ctx, d.n_pos, d.nullable, d.max_walk);
   uint32_t nth = static_cast<uint32_t>(wave);
