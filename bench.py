@@ -11,8 +11,9 @@ BASELINE's metric is quoted on, configs[2]): the nine regex-dna patterns (refere
 sample/regexdna.cc:51-67), one MatchAllCount each, over the stripped 50M-line FASTA text (500 MB per
 GPU), resident in HBM when the timed region starts.  With N GPUs the text is N x 500 MB (weak
 scaling), cut into contiguous byte ranges with a halo of max_match_len-1 bytes; the exchange step is
-one RCCL all_gather of 5 integers per pattern (count + first / last match, which carries the
-left-most-longest selection over the cuts).  Rank 0 prints ONE JSON line.
+one RCCL all_gather of 8 integers per pattern written on the device (count + first / last match, which
+carries the left-most-longest selection over the cuts; sharding.CarryExchange).  Rank 0 prints ONE JSON
+line.  Without a launcher, --gpus N > 1 spawns the N ranks itself.
 
 Other workloads (same contract; what an 8-GPU run of BASELINE configs[3] / [4] / [1] uses):
   --workload complex   ([complex]|(regexp)){2,7}abcdefgh(...) MatchAll, --literal-bytes per GPU
@@ -22,17 +23,22 @@ Other workloads (same contract; what an 8-GPU run of BASELINE configs[3] / [4] /
                        with matches, output gathered to rank 0
   --workload literal   literal `regexp` MatchAll over --literal-bytes per GPU
 
-Besides the contract fields the regexdna line carries
-  roofline      -- the dominant kernel (the fast-forward window scan): algorithmic bytes per launch
-                   (1 byte read per text byte per MatchAll call) / average
-                   launch duration from the kernels' own dispatch timestamps on the run's stream
-  cpu_baseline  -- the REAL reference (oracle/_ref, built from /root/reference) on the host: one core
-                   and all cores (threads stated), on a bounded sample of the same text
-  fused         -- the same nine counts in ONE pass over the text (the fastest way to do the job), with
-                   its HBM and VALU rooflines
-  hbm_not_cache -- the headline kernel on a 2.5 GB text (10x the 256 MiB Infinity Cache)
-  literal_scan / literal_50gb / complex_scan -- BASELINE configs[1] (5 GB and the north star's 50 GB)
-                   and configs[3]'s shape on one GPU, each with its own roofline and CPU baseline
+The headline step is ONE pass over the text for all nine patterns (rj_multi_run mode 0: plane_scan +
+classify_shared_multi + offsets_gather_check_multi, one synchronise).  Besides the contract fields the line carries
+  roofline      -- the dominant kernel (plane_scan<2>): the text's bytes (1 byte read per text byte and pass,
+                   SURVEY.md section 8d) / the launch's average duration from HIP events on the run's stream,
+                   traffic = FETCH_SIZE x 2 per launch from profiles/pmc_traffic.json
+  roofline_valu -- the same launch against the VALU peak (SQ_INSTS_VALU per byte from profiles/)
+  cpu_baseline  -- the REAL reference (oracle/_ref, built from /root/reference) on the host: one core (>= 0.5 s of
+                   work) and all cores over disjoint slices, on a bounded sample of the same text
+  train / separate_launches / serial_calls / interleaved / overlapped -- the other ways to get the nine counts
+  hbm_not_cache / one_pass_2p5gb -- per-pattern kernels and the one pass on a 2.5 GB text (10x the Infinity Cache)
+  literal_scan / literal_50gb / complex_scan / behind_scan / dense_scan / line_table -- BASELINE configs[1] (5 GB and
+                   the north star's 50 GB), configs[3]'s shape on one GPU and the other scan modes, each with
+                   median / min of >= 10 calls, the first call, its roofline and CPU baseline
+  jrep_10gb / end_to_end -- BASELINE configs[4] at full size on one GPU (host buffers, PCIe included) and the
+                   reference's regexdna.cc unchanged on the library next to the published number
+  parity_full_size -- the GPU's answers == the real reference's at BASELINE size (tests/golden/fullsize_vectors.json)
 """
 import argparse
 import json
@@ -603,7 +609,7 @@ def literal_and_complex_extras(args, c, out):
         c, rejit_amd, t, n, rx, "%s MatchAll over %d bytes random ASCII, %d planted (BASELINE configs[3] shape, 1 GPU)" % (rx, n, len(offs2)),
         "scan_windows<1> (floating window)", 5, check_complex, "complex", True, args)
     # a required literal BEHIND an unbounded prefix (the reference's backward pass from the fast-forward hit,
-    # src/x64/codegen-x64.cc:643-650): the window scan finds `abcdefgh`, verify_behind_in_regions walks the
+    # src/x64/codegen-x64.cc:643-650): the window scan finds `abcdefgh`, verify_behind_lds (verify_lds.hip) walks the
     # reverse automaton to the start.  Round 1 ran these patterns in dense mode (0.6 TB/s).
     rxb = "[a-z]+abcdefgh"
 
@@ -613,7 +619,7 @@ def literal_and_complex_extras(args, c, out):
 
     out["behind_scan"] = single_pattern_extra(
         c, rejit_amd, t, n, rxb, "%s MatchAll over the same %d bytes (window behind an unbounded prefix)" % (rxb, n),
-        "scan_windows<1> + verify_behind_in_regions", 5, check_behind, "behind", True, args)
+        "scan_windows<1> + verify_behind_lds", 5, check_behind, "behind", True, args)
     # Patterns WITHOUT a fast-forward window (the NFA half of the north star): scan_dense_walk finds, walks and
     # compacts the candidates in one kernel.  `[a-f]+[0-9]`: a start at 8 % of the bytes of this text (only the
     # first byte of every run of [a-f] is taken, DevProgram::loop_first); the first four automaton steps of all
