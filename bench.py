@@ -308,26 +308,79 @@ def run_regexdna(args, c):
 
     exchange = sharding.CarryExchange(len(patterns), rank, world, dist, dev, c.cdev) if (world > 1 and use_multi) else None
 
-    def rerun_local(i, cur, prev_end, have):
-        sep_scans[i].run(text_ptr, n_local, own_begin=own_lo, own_end=own_hi, carry_cur=cur, carry_prev_end=prev_end, have_prev=have, stream=stream)
+    # Two steps in flight (rj_multi_start / rj_multi_finish on two rj_multi objects used alternately): while the host
+    # collects step k's counts -- and, with several ranks, runs its carry exchange on a side stream -- the kernels of
+    # step k + 1 are already queued, so the device never waits for the host's turn-around (~25 us of a 170 us step).
+    # Every step still is one complete pass of the path over the batch with its own result; the synchronous call is
+    # reported as `call_latency`.
+    def two_in_flight(own_streams):
+        """(step, drain, scan times) of a loop that keeps two steps in flight on two rj_multi objects.  own_streams:
+        each object on its own stream, the scan kernels ordered one behind the other (rj_multi_order_after), so that the
+        tails of step k run under the scan of step k + 1."""
+        multis = [rejit_amd.MultiScan(progs), rejit_amd.MultiScan(progs)]
+        for mm in multis:
+            mm.set_mode(0)
+        second = torch.cuda.Stream(dev) if own_streams else None
+        streams = [stream, second.cuda_stream if own_streams else stream]
+        if own_streams:
+            multis[0].order_after(multis[1])
+            multis[1].order_after(multis[0])
+        side = torch.cuda.Stream(dev) if exchange is not None else None
+        fly = {"k": 0, "busy": [False, False], "keep": (second, side)}
+        times = []
 
-    def step(record):
-        if exchange is not None:
-            # exchange step of the path: per pattern 8 integers per rank (count, first / last match, carry used) written by a
-            # kernel, one all_gather over RCCL/xGMI, the decision taken by a kernel: no host tensors, one extra synchronise
-            counts = exchange.counts(multi_sep, local_counts, rerun_local, vis_lo, stream)
-        elif world > 1:
-            counts = sharding.multi_pattern_counts(run_local, rerun_one, len(patterns), rank, world, dist, c.cdev)
-        else:
-            counts = local_counts()
-        if record:
-            if use_multi:
-                scan_ms.append(multi_sep.scan_ms())     # ONE launch scans the nine patterns (scan_windows_train)
-            else:
+        def collect(j, record):
+            local = multis[j].finish()
+            fly["busy"][j] = False
+            if record:
+                times.append(multis[j].scan_ms())         # ONE launch scans the nine patterns (plane_scan)
+            if exchange is None:
+                return local
+            # exchange step of the path: per pattern 8 integers per rank (count, first / last match, carry used) written by
+            # a kernel, one all_gather over RCCL/xGMI, the decision taken by a kernel: no host tensors, one synchronise of
+            # the side stream; the other object's step runs on the main stream meanwhile
+            def rerun_j(i, cur, prev_end, have):
+                multis[j].scan(i).run(text_ptr, n_local, own_begin=own_lo, own_end=own_hi, carry_cur=cur, carry_prev_end=prev_end,
+                                      have_prev=have, stream=side.cuda_stream)
+            with torch.cuda.stream(side):
+                return exchange.counts(multis[j], lambda: None, rerun_j, vis_lo, side.cuda_stream)
+
+        def step(record):
+            j = fly["k"] % 2
+            fly["k"] += 1
+            res = collect(j, record) if fly["busy"][j] else None
+            multis[j].start(text_ptr, n_local, stream=streams[j], own_begin=own_lo, own_end=own_hi)
+            fly["busy"][j] = True
+            return res
+
+        def drain():
+            res = None
+            for j in (fly["k"] % 2, (fly["k"] + 1) % 2):   # the older of the two first
+                if fly["busy"][j]:
+                    res = collect(j, True)
+            return res
+
+        return step, drain, times
+
+    # Two steps in flight (rj_multi_start / rj_multi_finish on two rj_multi objects used alternately): while the host
+    # collects step k's counts -- and, with several ranks, runs its carry exchange on a side stream -- the kernels of
+    # step k + 1 are already queued, so the device never waits for the host's turn-around (~15 us of a 170 us step).
+    # Every step still is one complete pass of the path over the batch with its own result; the synchronous call is
+    # reported as `call_latency` / `synchronous_calls`, the variant with a stream per object as `overlapped_tails`.
+    if use_multi:
+        step, drain, scan_ms = two_in_flight(False)
+    else:
+        drain = None
+
+        def step(record):
+            counts = [run_one(i) for i in range(len(scans))]
+            if world > 1:
+                counts = sharding.multi_pattern_counts(run_local, rerun_one, len(patterns), rank, world, dist, c.cdev)
+            if record:
                 scan_ms.extend(sc.stats()["scan_ms"] for sc in scans)
-        return counts
+            return counts
 
-    elapsed, counts = timed(c, args, step)
+    elapsed, counts = timed(c, args, step, drain)
     total_matches = int(sum(counts))
     scanned = len(patterns) * n_total * args.steps          # bytes of text scanned by the whole job
     avg_scan_ms = sum(scan_ms) / max(len(scan_ms), 1)
@@ -337,12 +390,13 @@ def run_regexdna(args, c):
                      "fasta_n_per_gpu": args.fasta_n, "text_bytes_per_gpu": int(own_bytes), "patterns": len(patterns),
                      "sharding": "contiguous byte ranges + %d-byte halo; all_gather of 8 integers per pattern (count, first / last match, carry used) per step, rows and decision on the device"
                                  % (max_len - 1),
-                     "calls": "rj_multi_run mode 0: one pass over the text for the nine patterns (plane_scan) + classify + gather, one synchronise" if use_multi else "9 x rj_scan_run per step"})
+                     "calls": "rj_multi_start / rj_multi_finish, mode 0, two steps in flight on two rj_multi objects: one pass over the text for the nine patterns (plane_scan) + classify + gather per step" if use_multi else "9 x rj_scan_run per step"})
     out["matches_per_s"] = round(total_matches * args.steps / elapsed, 1)
     out["matches_per_pass"] = counts
     if use_multi:
         # the dominant kernel: plane_scan reads every text byte ONCE for all nine patterns: algorithmic bytes per
         # launch = text bytes (for a fused pass quote n / t_fused, never 9 n / t_fused, against HBM)
+        assert multi_sep.run(text_ptr, n_local, stream=stream, own_begin=own_lo, own_end=own_hi) == (counts if world == 1 else multi_sep.run(text_ptr, n_local, stream=stream, own_begin=own_lo, own_end=own_hi))
         one_pass = multi_sep.how == 1
         out["roofline"] = hbm_roofline("plane_scan<2> (one pass, nine patterns)" if one_pass else "scan kernels of rj_multi_run", own_bytes, avg_scan_ms,
                                        pmc_traffic("plane", fasta_n=args.fasta_n) if world == 1 else None, len(scan_ms))
@@ -379,6 +433,21 @@ def run_regexdna(args, c):
     if extras and use_multi:
         ek0, ck0 = time_steps(lambda: multi_sep.run(text_ptr, n_local, stream=stream, own_begin=own_lo, own_end=own_hi), key="headline")
         out["call_latency"] = call_times["headline"]
+        assert ck0 == counts, (ck0, counts)
+        if world == 1:
+            # the same loop with a stream per object: the tails of step k (classify + gather, latency-bound) run under the
+            # scan of step k + 1 -- more steps per second, but the scan kernel shares the device with them and takes
+            # longer, which is why the headline (and its roofline) keeps both objects on one stream
+            o_step, o_drain, o_times = two_in_flight(True)
+            eo, co = timed(c, args, o_step, o_drain)
+            assert co == counts, (co, counts)
+            out["overlapped_tails"] = {"calls": "two steps in flight, a stream per rj_multi object, scans ordered (rj_multi_order_after)",
+                                       "ms_per_step": round(eo / args.steps * 1e3, 4),
+                                       "value": round(len(patterns) * n_total * args.steps / eo / 1e9, 3), "unit": "GB/s",
+                                       "scan_kernel_ms": round(sum(o_times) / max(len(o_times), 1), 5)}
+        out["synchronous_calls"] = {"calls": "rj_multi_run mode 0, one call after the other (one step in flight): what rounds 1-2 timed",
+                                    "ms_per_step": round(ek0 / args.steps * 1e3, 4),
+                                    "value": round(len(patterns) * n_total * args.steps / ek0 / 1e9, 3), "unit": "GB/s"}
         # The nine per-pattern scans as ONE launch (rj_multi mode 1, round 2's headline): a wave runs its own 32 KB
         # span through pattern after pattern, so passes 2..9 are served by the 256 MiB Infinity Cache -- 9 n / t of
         # that launch is a rate of algorithmic bytes, not an HBM rate, and is reported as such.

@@ -171,6 +171,19 @@ int rj_multi_run(rj_multi* multi, const void* d_text, uint64_t n, uint64_t* coun
  * [0, n), as for rj_scan_run; no selection state is carried in (first shard / independent ranges) */
 int rj_multi_run_range(rj_multi* multi, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end,
                        uint64_t* counts, void* hip_stream);
+/* rj_multi_run in two halves: rj_multi_start enqueues the run's kernels on hip_stream and returns, rj_multi_finish
+ * waits for them and collects the counts (its return value is rj_multi_run's).  One run in flight per rj_multi; a
+ * caller that alternates between TWO rj_multi objects of the same patterns keeps the device busy while the host
+ * turns a result around (the reference's counterpart: regexdna-multithread.cc keeps one thread per pattern busy,
+ * sample/regexdna-multithread.cc:65-78) -- bench.py's headline loop does that.  The text must stay unchanged until
+ * rj_multi_finish.  [own_begin, own_end) as for rj_multi_run_range (0, n + 1: the whole text). */
+int rj_multi_start(rj_multi* multi, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end, void* hip_stream);
+int rj_multi_finish(rj_multi* multi, uint64_t* counts);
+/* For two rj_multi objects run alternately on two streams: the scan kernel of `multi`'s runs is queued behind the
+ * scan kernel of `before`'s run in flight (a stream-wait on that kernel's end), so that the two HBM-bound scans never
+ * share the memory system while the latency-bound tails of one run execute under the scan of the other.  before =
+ * NULL removes the order.  The objects must outlive each other's runs. */
+int rj_multi_order_after(rj_multi* multi, rj_multi* before);
 rj_scan* rj_multi_scan(rj_multi* multi, int i);
 /* First and last match of every pattern's result after rj_multi_run / _run_range: bounds[4*i .. 4*i+3] =
  * first begin, first end, last begin, last end (all UINT64_MAX when pattern i has no match).  This is what

@@ -124,7 +124,7 @@ C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_er
                  "rj_match_all_batch", "rj_multi_create", "rj_multi_destroy", "rj_multi_run", "rj_multi_scan",
                  "rj_multi_scan_ms", "rj_scan_start", "rj_scan_finish", "rj_multi_set_mode", "rj_multi_run_range",
                  "rj_multi_bounds", "rj_batch_separator", "rj_match_all_packed", "rj_host_alloc", "rj_host_free",
-                 "rj_multi_bounds_device", "rj_carry_decide"]
+                 "rj_multi_bounds_device", "rj_carry_decide", "rj_multi_start", "rj_multi_finish", "rj_multi_order_after"]
 
 
 def load_library():
@@ -161,6 +161,9 @@ def load_library():
     L.rj_multi_destroy.argtypes = [vp]
     L.rj_multi_run.argtypes = [vp, vp, u64, _u64p, vp]
     L.rj_multi_run_range.argtypes = [vp, vp, u64, u64, u64, _u64p, vp]
+    L.rj_multi_start.argtypes = [vp, vp, u64, u64, u64, vp]
+    L.rj_multi_finish.argtypes = [vp, _u64p]
+    L.rj_multi_order_after.argtypes = [vp, vp]
     L.rj_multi_scan.restype = vp
     L.rj_multi_scan.argtypes = [vp, ctypes.c_int]
     L.rj_multi_scan_ms.restype = ctypes.c_float
@@ -411,6 +414,24 @@ class MultiScan:
         r = _check(self._lib.rj_multi_run_range(self._h, ctypes.c_void_p(d_text_ptr), n, own_begin,
                                                 n + 1 if own_end is None else own_end, counts, ctypes.c_void_p(stream)))
         self.how = int(r)          # 1 fused scan, 2 separate scans + batched tails, 0 one by one
+        self.fused = r == 1
+        return [int(c) for c in counts]
+
+    def start(self, d_text_ptr: int, n: int, stream: int = 0, own_begin: int = 0, own_end: Optional[int] = None) -> None:
+        """Enqueue a run; finish() collects its counts.  Two MultiScan objects of the same patterns used alternately
+        keep the device busy while the host turns a result around."""
+        _check(self._lib.rj_multi_start(self._h, ctypes.c_void_p(d_text_ptr), n, own_begin, n + 1 if own_end is None else own_end,
+                                        ctypes.c_void_p(stream)))
+
+    def order_after(self, other: Optional["MultiScan"]) -> None:
+        """This object's scan kernels wait for the scan kernel of `other`'s run in flight (two objects, two streams)."""
+        self._after = other   # (keeps it alive)
+        _check(self._lib.rj_multi_order_after(self._h, other._h if other is not None else None))
+
+    def finish(self) -> List[int]:
+        counts = (ctypes.c_uint64 * len(self.programs))()
+        r = _check(self._lib.rj_multi_finish(self._h, counts))
+        self.how = int(r)
         self.fused = r == 1
         return [int(c) for c in counts]
 

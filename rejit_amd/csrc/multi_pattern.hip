@@ -162,6 +162,20 @@ struct rj_multi {
   bool batchable = false; // every pattern takes the in-region pipeline: scans back to back, tails together
   int mode = 0;           // rj_multi_set_mode
   float scan_ms = 0.f;
+  // rj_multi_start / rj_multi_finish: a run whose kernels are enqueued and whose results have not been collected
+  struct Pending {
+    bool active = false;
+    int kind = 0;  // rj_multi_run's return value: 1 one pass, 2 separate scans + batched tails, 0 one pipeline after the other
+    const uint8_t* text = nullptr;
+    uint64_t n = 0, sb = 0, se = 0;
+    hipStream_t st = nullptr;
+    bool fuse = false;
+    std::vector<uint64_t> caps;
+    uint32_t shared_cap = 0;
+    hipEvent_t done = nullptr;  // behind the run's last kernel: rj_multi_finish waits for THIS run, not for the stream
+  } pending;
+  rj_multi* scan_after = nullptr;  // rj_multi_order_after: this object's scan kernel waits for that one's
+
 };
 
 namespace {
@@ -230,7 +244,10 @@ int classify_blob(rj_multi* m, hipStream_t st) {
 
 // The scans of all patterns (ONE fused kernel, or one kernel per pattern back to back) + the tails of
 // all patterns in two launches + one synchronise.  Whole text, starts [0, n].
-int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, hipStream_t st, bool fuse) {
+// phase 0: the whole run (enqueue, synchronise, collect; repeated with larger regions when one overflowed).
+// phase 1 (rj_multi_start): enqueue the first attempt and return.  phase 2 (rj_multi_finish): synchronise and collect
+// what phase 1 enqueued -- same arguments --, and carry on like phase 0 when a region overflowed.
+int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, hipStream_t st, bool fuse, int phase = 0) {
   const int P = static_cast<int>(m->scans.size());
   // chunks that can hold a window of a start in [sb, se): a window begins at most 7 bytes after its start
   const uint64_t end_byte = std::min<uint64_t>(n, se + 8);
@@ -249,7 +266,14 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
   }
   // (plane scan, 500 MB: 96 chunks per workgroup measured best -- 92 us against 98 at 128, 96 at 64)
   const ScanGeometry geo = scan_geometry(chunks, plane ? 96 : 128);
+  rj_scan* const s0 = m->scans[0];
+  std::vector<uint64_t> caps(static_cast<size_t>(P));
+  uint32_t shared_cap = 0;
   for (int attempt = 0; attempt < 6; attempt++) {
+   if (phase == 2 && attempt == 0) {
+    caps = m->pending.caps;
+    shared_cap = m->pending.shared_cap;
+   } else {
     FusedParams fp{};
     fp.text = d_text;
     fp.n = n;
@@ -258,7 +282,6 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     fp.span_chunks = geo.span_chunks;
     fp.n_patterns = static_cast<uint32_t>((P + kFuseGroup - 1) / kFuseGroup * kFuseGroup);
     RJ_HIP(m->dummy_counts.reserve(static_cast<size_t>(geo.n_regions) * sizeof(uint32_t)));
-    std::vector<uint64_t> caps(static_cast<size_t>(P));
     for (int p = 0; p < static_cast<int>(fp.n_patterns); p++) {
       const int q = p < P ? p : 0;  // padding repeats pattern 0 with no room for hits
       rj_scan* s = m->scans[static_cast<size_t>(q)];
@@ -287,7 +310,6 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
         fp.zero_counters[p] = nullptr;
       }
     }
-    rj_scan* s0 = m->scans[0];
     fp.n_bases = 0;
     static const bool no_prefilter = getenv("RJ_NO_FUSED_PREFILTER") != nullptr;  // measurement override
     if (fuse && m->mode == 0 && !no_prefilter) {
@@ -329,7 +351,12 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
           }
       }
     }
-    uint32_t shared_cap = 0;
+    shared_cap = 0;
+    if (m->scan_after != nullptr && m->scan_after != m && m->scan_after->scans[0]->ev[2] != nullptr) {
+      // two objects on two streams (rj_multi_order_after): the scan kernels -- both HBM-bound -- stay one behind the
+      // other, only the other run's latency-bound tails overlap this scan
+      RJ_HIP(hipStreamWaitEvent(st, m->scan_after->scans[0]->ev[2], 0));
+    }
     if (plane) {
       PlaneParams pp{};
       pp.text = d_text;
@@ -492,7 +519,17 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     } else {
       launch_tails_multi(m->tails.as<MultiTail>(), P, geo.n_regions, st);
     }
-    RJ_HIP(hipStreamSynchronize(st));
+   }
+    if (phase == 1) {
+      m->pending.caps = caps;
+      m->pending.shared_cap = shared_cap;
+      if (!m->pending.done) RJ_HIP(hipEventCreateWithFlags(&m->pending.done, hipEventDisableTiming));
+      RJ_HIP(hipEventRecord(m->pending.done, st));
+      return RJ_OK;
+    }
+    // (phase 2: the stream may already hold the NEXT run of another rj_multi -- wait for this one only)
+    if (phase == 2 && attempt == 0) RJ_HIP(hipEventSynchronize(m->pending.done));
+    else RJ_HIP(hipStreamSynchronize(st));
     RJ_HIP(hipGetLastError());
     bool again = false;
     if (plane && s0->host_counters[kCntSharedMax] != 0) {
@@ -603,6 +640,7 @@ void rj_multi_destroy(rj_multi* m) {
   if (m->second) (void)hipStreamDestroy(m->second);
   if (m->fork) (void)hipEventDestroy(m->fork);
   if (m->join) (void)hipEventDestroy(m->join);
+  if (m->pending.done) (void)hipEventDestroy(m->pending.done);
   delete m;
 }
 
@@ -614,6 +652,7 @@ int rj_multi_run_range(rj_multi* m, const void* d_text, uint64_t n, uint64_t own
                        void* hip_stream) {
   ErrnoGuard errno_guard;
   if (!m || (!d_text && n) || !counts) return fail(RJ_BAD_ARGUMENT, "null argument");
+  if (m->pending.active) return fail(RJ_BAD_ARGUMENT, "rj_multi_run: a run started with rj_multi_start has not been finished");
   if (own_end > n + 1) own_end = n + 1;
   if (own_begin >= own_end) {
     for (size_t i = 0; i < m->scans.size(); i++) counts[i] = 0;
@@ -639,6 +678,58 @@ int rj_multi_run_range(rj_multi* m, const void* d_text, uint64_t n, uint64_t own
   }
   for (size_t i = 0; i < m->scans.size(); i++) counts[i] = m->scans[i]->result_count;
   return fused;
+}
+
+int rj_multi_start(rj_multi* m, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end, void* hip_stream) {
+  ErrnoGuard errno_guard;
+  if (!m || (!d_text && n)) return fail(RJ_BAD_ARGUMENT, "null argument");
+  if (m->pending.active) return fail(RJ_BAD_ARGUMENT, "rj_multi_start: the previous run has not been finished");
+  if ((reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) return fail(RJ_BAD_ARGUMENT, "device text must be 16-byte aligned");
+  if (own_end > n + 1) own_end = n + 1;
+  rj_multi::Pending& q = m->pending;
+  q.text = static_cast<const uint8_t*>(d_text);
+  q.n = n;
+  q.sb = own_begin;
+  q.se = own_end;
+  q.st = static_cast<hipStream_t>(hip_stream);
+  m->scan_ms = 0.f;
+  q.kind = own_begin >= own_end ? -1 : (m->fused && m->mode == 0 && n >= 16) ? 1 : (m->batchable && n >= 16) ? 2 : 0;
+  q.fuse = q.kind == 1;
+  if (q.kind > 0) {
+    int rc = run_batched(m, q.text, n, q.sb, q.se, q.st, q.fuse, 1);
+    if (rc != RJ_OK) return rc;
+  }  // (kind 0: pattern sets that take one pipeline after the other run in rj_multi_finish)
+  q.active = true;
+  return RJ_OK;
+}
+
+int rj_multi_finish(rj_multi* m, uint64_t* counts) {
+  ErrnoGuard errno_guard;
+  if (!m || !counts) return fail(RJ_BAD_ARGUMENT, "null argument");
+  rj_multi::Pending& q = m->pending;
+  if (!q.active) return fail(RJ_BAD_ARGUMENT, "rj_multi_finish without rj_multi_start");
+  q.active = false;
+  if (q.kind < 0) {  // an empty range
+    for (size_t i = 0; i < m->scans.size(); i++) counts[i] = 0;
+    return 0;
+  }
+  if (q.kind != 0) {
+    int rc = run_batched(m, q.text, q.n, q.sb, q.se, q.st, q.fuse, 2);
+    if (rc != RJ_OK) return rc;
+  } else {
+    for (rj_scan* s : m->scans) {
+      int rc = run_pipeline(s, q.text, q.n, q.sb, q.se, 0, 0, 0, q.st);
+      if (rc != RJ_OK) return rc;
+    }
+  }
+  for (size_t i = 0; i < m->scans.size(); i++) counts[i] = m->scans[i]->result_count;
+  return q.kind;
+}
+
+int rj_multi_order_after(rj_multi* m, rj_multi* before) {
+  if (!m) return fail(RJ_BAD_ARGUMENT, "null argument");
+  m->scan_after = before;
+  return RJ_OK;
 }
 
 rj_scan* rj_multi_scan(rj_multi* m, int i) {

@@ -658,3 +658,36 @@ def test_random_patterns_through_the_general_pipeline():
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     last = out.strip().splitlines()[-1]
     assert last.startswith("checked 700") and last.endswith("mismatches 0"), out[-2000:]
+
+
+@pytest.mark.gpu
+def test_multi_start_finish_two_in_flight():
+    """rj_multi_start / rj_multi_finish: two rj_multi objects of the nine regexdna patterns used alternately over two
+    different texts give, step by step, the counts of rj_multi_run; a second start before finish is refused; ranges."""
+    import torch
+    import rejit_amd
+    from rejit_amd import workloads as W
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    progs = [rejit_amd.Program(rx) for rx in W.REGEXDNA_PATTERNS]
+    texts = [torch.from_numpy(W.fasta_stripped_numpy(n).copy()).to(dev) for n in (30000, 47000)]
+    ref = rejit_amd.MultiScan(progs)
+    want = [ref.run(t.data_ptr(), t.numel(), stream=st) for t in texts]
+    a, b = rejit_amd.MultiScan(progs), rejit_amd.MultiScan(progs)
+    objs, got = [a, b], []
+    a.start(texts[0].data_ptr(), texts[0].numel(), stream=st)          # step 0
+    with pytest.raises(rejit_amd.RejitError):
+        a.start(texts[0].data_ptr(), texts[0].numel(), stream=st)
+    for k in range(1, 9):                                               # step k runs on object k % 2 over text k % 2
+        objs[k % 2].start(texts[k % 2].data_ptr(), texts[k % 2].numel(), stream=st)
+        got.append(objs[(k - 1) % 2].finish())                          # ... while step k - 1 is collected
+    got.append(objs[8 % 2].finish())
+    assert got == [want[k % 2] for k in range(9)]
+    # a shard's own range
+    n = texts[1].numel()
+    lo, hi = n // 3, 2 * n // 3
+    want_r = ref.run(texts[1].data_ptr(), n, stream=st, own_begin=lo, own_end=hi)
+    a.start(texts[1].data_ptr(), n, stream=st, own_begin=lo, own_end=hi)
+    assert a.finish() == want_r
+    with pytest.raises(rejit_amd.RejitError):
+        a.finish()
