@@ -1202,20 +1202,34 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
   __shared__ uint64_t wave_sum[kWaves], wave_before[kWaves], wave_end[kWaves];
   __shared__ int64_t wave_last[kWaves];
   const int lane = lane_id(), wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) RJ_STAMP(0);
   const uint32_t first = blockIdx.x * kOgcThreads;  // a multiple of 4
   // 1. everything before this workgroup: candidate count, nearest non-empty region (its index and
   //    count packed in one word so that the maximum carries both)
   uint64_t before = 0;
   int64_t last = -1;
   const uint4* counts4 = reinterpret_cast<const uint4*>(counts);
-  for (uint32_t q = threadIdx.x; q < first / 4; q += kOgcThreads) {
-    const uint4 c = counts4[q];
-    before += static_cast<uint64_t>(c.x) + c.y + c.z + c.w;
-    const uint32_t i = 4 * q;
-    if (c.x) last = (static_cast<int64_t>(i) << 32) | c.x;  // q grows along the loop
-    if (c.y) last = (static_cast<int64_t>(i + 1) << 32) | c.y;
-    if (c.z) last = (static_cast<int64_t>(i + 2) << 32) | c.z;
-    if (c.w) last = (static_cast<int64_t>(i + 3) << 32) | c.w;
+  // (eight loads in flight per lane instead of one consumed before the next is issued: the last workgroup of a
+  // 20 000-region run makes 20 of them per lane.  Measured: no change of the kernel's 21-23 us -- kept because it is
+  // not slower; the stamps of tools/ogc_trace.py put most of the kernel before the first barrier, but their
+  // atomics perturb exactly that part)
+  constexpr uint32_t kBatch = 8;
+  for (uint32_t q0 = threadIdx.x; q0 < first / 4; q0 += kOgcThreads * kBatch) {
+    uint4 c[kBatch];
+#pragma unroll
+    for (uint32_t j = 0; j < kBatch; j++) {
+      const uint32_t q = q0 + j * kOgcThreads;
+      c[j] = q < first / 4 ? counts4[q] : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kBatch; j++) {
+      before += static_cast<uint64_t>(c[j].x) + c[j].y + c[j].z + c[j].w;
+      const uint32_t i = 4 * (q0 + j * kOgcThreads);
+      if (c[j].x) last = (static_cast<int64_t>(i) << 32) | c[j].x;  // q grows along the loop
+      if (c[j].y) last = (static_cast<int64_t>(i + 1) << 32) | c[j].y;
+      if (c[j].z) last = (static_cast<int64_t>(i + 2) << 32) | c[j].z;
+      if (c[j].w) last = (static_cast<int64_t>(i + 3) << 32) | c[j].w;
+    }
   }
   // 2. own region: the first kHeld entries are loaded at once and kept in registers (regions hold
   //    a few candidates; one round trip instead of one per entry), the largest end
@@ -1224,17 +1238,13 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
   const uint32_t cnt = r < n_regions ? counts[r] : 0u;
   const uint64_t src = static_cast<uint64_t>(r) * region_cap;
   uint64_t hb[kHeld], he[kHeld];
-  // (loaded whatever the count says -- the slots exist, an empty region's hold rubbish that is zeroed below -- so
-  // that they leave together with the count instead of a trip behind it)
+  // (only the regions with survivors: loading the slots of ALL regions ahead of the count -- one trip less -- was
+  // measured slower, 160 000 scattered loads against a thousand)
 #pragma unroll
   for (int k = 0; k < kHeld; k++) {
-    const bool slot = r < n_regions && static_cast<uint32_t>(k) < region_cap;
-    hb[k] = slot ? region_begins[src + k] : 0;
-    he[k] = slot ? region_ends[src + k] : 0;
+    hb[k] = static_cast<uint32_t>(k) < cnt ? region_begins[src + k] : 0;
+    he[k] = static_cast<uint32_t>(k) < cnt ? region_ends[src + k] : 0;
   }
-#pragma unroll
-  for (int k = 0; k < kHeld; k++)
-    if (static_cast<uint32_t>(k) >= cnt) hb[k] = he[k] = 0;
   // the region's largest end: the held ones and the LAST one.  (Exact whenever the region is
   // ordered inside, and when it is not the copy below flags the list anyway.)
   uint64_t my_end = 0;
@@ -1266,6 +1276,7 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
     wave_last[wv] = last;
   }
   __syncthreads();
+  if (threadIdx.x == 0) RJ_STAMP(1);
   uint64_t base = 0, own_before = 0, own_total = 0, end_before = 0;
   int64_t nearest = -1;
 #pragma unroll
@@ -1287,6 +1298,7 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
   prev = end_before > prev ? end_before : prev;
   const uint64_t up = __shfl_up(inc_end, 1);  // inclusive maximum of the lanes below
   if (lane > 0) prev = up > prev ? up : prev;
+  if (threadIdx.x == 0 && prev != ~0ull) RJ_STAMP(2);
   // 3. copy + check
   const uint64_t off = base + own_before + inc - cnt;
   bool ok = true;
@@ -1335,6 +1347,7 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
     prev = e > prev ? e : prev;
     if (off + k < out_cap) *reinterpret_cast<ulonglong2*>(out + 2 * (off + k)) = make_ulonglong2(b, e);
   }
+  if (threadIdx.x == 0) RJ_STAMP(3);
   if (!ok) {
     counters[kCntUnordered] = 1;
     if (host_counters) host_counters[kCntUnordered] = 1;
@@ -1344,6 +1357,7 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
     if (host_counters) host_counters[kCntAdjacent] = 1;
   }
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    RJ_STAMP(4);
     counters[kCntHits] = base + own_total;
     counters[kCntCands] = base + own_total;
     if (host_counters) {
