@@ -894,7 +894,8 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
 }
 
 static int scan_init(rj_scan* s) {
-  RJ_HIP(s->counters.reserve(kCntSize * sizeof(unsigned long long)));
+  RJ_HIP(s->counters.reserve(kCounterBlockWords * sizeof(unsigned long long)));
+  RJ_HIP(hipMemset(s->counters.p, 0, kCounterBlockWords * sizeof(unsigned long long)));
   RJ_HIP(s->flag.reserve(16));
   RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->host_counters), kCntSize * sizeof(unsigned long long)));
   RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->host_flag), 16));

@@ -16,6 +16,10 @@ enum { kCntCands = 0, kCntFinal = 1, kCntOverflow = 2, kCntAdjacent = 3, kCntHit
   kCntSharedMax = 9,  // plane scan (plane_scan.hip): fullest SHARED candidate region when one overflowed, else 0
   kCntLongWalks = 10, // walks of the run that went past kLongWalk bytes (device_program.h: rj_lane_longest)
   kCntSize = 11 };
+// offsets_gather_check keeps 2 x kOgcMaxBlocks granules behind the counters of a scan (kernels.hip): a counter block is
+// kCntSize + 2 * kOgcMaxBlocks words, zeroed when it is allocated
+constexpr uint32_t kOgcMaxBlocks = 256;
+constexpr size_t kCounterBlockWords = kCntSize + 2 * kOgcMaxBlocks;
 static_assert(kCntLongWalks - kCntOverrun == kLongWalksAfterOverrun, "rj_lane_longest finds the long-walk counter behind the overrun flag");
 
 constexpr uint64_t kNoMatch = ~0ull;  // cand_end of a hit at which nothing matches

@@ -42,6 +42,7 @@
 // No MFMA: there is no contraction anywhere on this path (integer compares on a byte stream);
 // the roofline is HBM read bandwidth.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -1192,7 +1193,7 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
                                                           const uint64_t* region_ends, uint32_t n_regions,
                                                           uint32_t region_cap, uint64_t carry_cur, uint64_t* out,
                                                           uint64_t out_cap, unsigned long long* counters,
-                                                          unsigned long long* host_counters, uint64_t carry_pe,
+                                                          unsigned long long* host_counters, uint64_t carry_pe, uint32_t epoch,
                                                           uint64_t* offsets_out = nullptr, uint64_t* prev_out = nullptr) {
   // Adjacency (a candidate begins exactly where an earlier one ends) is wanted for the Q8 check.
   // When the list is ordered and disjoint -- the only case in which this kernel's verdict is
@@ -1202,35 +1203,42 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
   __shared__ uint64_t wave_sum[kWaves], wave_before[kWaves], wave_end[kWaves];
   __shared__ int64_t wave_last[kWaves];
   const int lane = lane_id(), wv = threadIdx.x >> 6;
-  if (threadIdx.x == 0) RJ_STAMP(0);
+  if (threadIdx.x == 0) RJ_STAMP_AT(blockIdx.x, 0);
   const uint32_t first = blockIdx.x * kOgcThreads;  // a multiple of 4
-  // 1. everything before this workgroup: candidate count, nearest non-empty region (its index and
-  //    count packed in one word so that the maximum carries both)
+  // 1. everything before this workgroup: candidate count, nearest non-empty region (its index and count packed in
+  //    one word so that the maximum carries both).  Every workgroup used to add up the counts of ALL regions before its
+  //    own: the last workgroup of a 65 536-region run (a 5 GB text) made 63 dependent trips per lane, 22 of the kernel's
+  //    25 us (tools/ogc_trace.py: per-workgroup stamps).  Now a workgroup publishes the total and the last non-empty
+  //    region of ITS 256 regions in two 8-byte granules {epoch, value} (relaxed agent-scope stores into the tail of the
+  //    scan's counter block; the epoch is this launch's number, so nothing needs clearing) and reads the granules of
+  //    the workgroups before it, one per lane: one trip.  It waits for lower-numbered workgroups only -- dispatched no
+  //    later than itself -- and a lane whose granule does not show up in time adds that workgroup's counts up itself.
   uint64_t before = 0;
   int64_t last = -1;
   const uint4* counts4 = reinterpret_cast<const uint4*>(counts);
-  // (eight loads in flight per lane instead of one consumed before the next is issued: the last workgroup of a
-  // 20 000-region run makes 20 of them per lane.  Measured: no change of the kernel's 21-23 us -- kept because it is
-  // not slower; the stamps of tools/ogc_trace.py put most of the kernel before the first barrier, but their
-  // atomics perturb exactly that part)
-  constexpr uint32_t kBatch = 8;
-  for (uint32_t q0 = threadIdx.x; q0 < first / 4; q0 += kOgcThreads * kBatch) {
-    uint4 c[kBatch];
+  const bool exchange = gridDim.x <= kOgcMaxBlocks && gridDim.x > 1;
+  unsigned long long* granules = counters + kCntSize;  // [kOgcMaxBlocks] totals, [kOgcMaxBlocks] last non-empty regions
+  auto sum_counts = [&](uint32_t q_begin, uint32_t q_end, uint32_t stride) {  // uint4 indices
+    constexpr uint32_t kBatch = 8;
+    for (uint32_t q0 = q_begin; q0 < q_end; q0 += stride * kBatch) {
+      uint4 c[kBatch];
 #pragma unroll
-    for (uint32_t j = 0; j < kBatch; j++) {
-      const uint32_t q = q0 + j * kOgcThreads;
-      c[j] = q < first / 4 ? counts4[q] : make_uint4(0u, 0u, 0u, 0u);
-    }
+      for (uint32_t j = 0; j < kBatch; j++) {
+        const uint32_t q = q0 + j * stride;
+        c[j] = q < q_end ? counts4[q] : make_uint4(0u, 0u, 0u, 0u);
+      }
 #pragma unroll
-    for (uint32_t j = 0; j < kBatch; j++) {
-      before += static_cast<uint64_t>(c[j].x) + c[j].y + c[j].z + c[j].w;
-      const uint32_t i = 4 * (q0 + j * kOgcThreads);
-      if (c[j].x) last = (static_cast<int64_t>(i) << 32) | c[j].x;  // q grows along the loop
-      if (c[j].y) last = (static_cast<int64_t>(i + 1) << 32) | c[j].y;
-      if (c[j].z) last = (static_cast<int64_t>(i + 2) << 32) | c[j].z;
-      if (c[j].w) last = (static_cast<int64_t>(i + 3) << 32) | c[j].w;
+      for (uint32_t j = 0; j < kBatch; j++) {
+        before += static_cast<uint64_t>(c[j].x) + c[j].y + c[j].z + c[j].w;
+        const uint32_t i = 4 * (q0 + j * stride);
+        if (c[j].x) last = (static_cast<int64_t>(i) << 32) | c[j].x;  // q grows along the loop
+        if (c[j].y) last = (static_cast<int64_t>(i + 1) << 32) | c[j].y;
+        if (c[j].z) last = (static_cast<int64_t>(i + 2) << 32) | c[j].z;
+        if (c[j].w) last = (static_cast<int64_t>(i + 3) << 32) | c[j].w;
+      }
     }
-  }
+  };
+  if (!exchange) sum_counts(threadIdx.x, first / 4, kOgcThreads);
   // 2. own region: the first kHeld entries are loaded at once and kept in registers (regions hold
   //    a few candidates; one round trip instead of one per entry), the largest end
   constexpr int kHeld = 4;
@@ -1255,6 +1263,7 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
     my_end = e > my_end ? e : my_end;
   }
   uint64_t inc = cnt, inc_end = my_end;
+  int64_t own_last = cnt ? ((static_cast<int64_t>(r) << 32) | cnt) : -1;  // this workgroup's last non-empty region
 #pragma unroll
   for (int o = 1; o < kWave; o <<= 1) {
     const uint64_t v = __shfl_up(inc, o);
@@ -1263,31 +1272,73 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
       inc += v;
       inc_end = ve > inc_end ? ve : inc_end;
     }
-    before += __shfl_xor(before, o);
-    const int64_t l2 = __shfl_xor(last, o);
-    last = l2 > last ? l2 : last;
+    const int64_t ol = __shfl_xor(own_last, o);
+    own_last = ol > own_last ? ol : own_last;
   }
+  __shared__ int64_t wave_own_last[kWaves];
   if (lane == kWave - 1) {
     wave_sum[wv] = inc;
     wave_end[wv] = inc_end;
+  }
+  if (lane == 0) wave_own_last[wv] = own_last;
+  __syncthreads();
+  if (threadIdx.x == 0) RJ_STAMP_AT(blockIdx.x, 1);
+  uint64_t own_before = 0, own_total = 0, end_before = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) {
+    if (w < wv) {
+      own_before += wave_sum[w];
+      end_before = wave_end[w] > end_before ? wave_end[w] : end_before;
+    }
+    own_total += wave_sum[w];
+  }
+  const unsigned long long tag = static_cast<unsigned long long>(epoch & 0xFFFFFFu) << 40;
+  if (exchange) {
+    if (threadIdx.x == 0) {
+      int64_t bl = -1;
+#pragma unroll
+      for (int w = 0; w < kWaves; w++) bl = wave_own_last[w] > bl ? wave_own_last[w] : bl;
+      // (region index + 1 in 17 bits, count in 21: a region holds at most 2^20 candidates; 0 = none)
+      const unsigned long long packed = bl < 0 ? 0ull : ((static_cast<unsigned long long>(bl >> 32) + 1) << 21) | static_cast<unsigned long long>(bl & 0x1FFFFF);
+      __hip_atomic_store(&granules[blockIdx.x], tag | own_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&granules[kOgcMaxBlocks + blockIdx.x], tag | packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x < blockIdx.x) {  // lane t: the workgroup t before this one
+      unsigned long long gs = 0, gl = 0;
+      bool have = false;
+      for (int spin = 0; spin < 4096 && !have; spin++) {
+        gs = __hip_atomic_load(&granules[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gl = __hip_atomic_load(&granules[kOgcMaxBlocks + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        have = (gs >> 40) == (tag >> 40) && (gl >> 40) == (tag >> 40);
+        if (!have) __builtin_amdgcn_s_sleep(1);
+      }
+      if (have) {
+        before = gs & 0xFFFFFFFFFFull;
+        const unsigned long long pk = gl & 0xFFFFFFFFFFull;
+        last = pk == 0 ? -1 : ((static_cast<int64_t>((pk >> 21) - 1) << 32) | static_cast<int64_t>(pk & 0x1FFFFF));
+      } else {
+        sum_counts(threadIdx.x * (kOgcThreads / 4), (threadIdx.x + 1) * (kOgcThreads / 4), 1);  // that workgroup's 256 counts
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    before += __shfl_xor(before, o);
+    const int64_t l2 = __shfl_xor(last, o);
+    last = l2 > last ? l2 : last;
   }
   if (lane == 0) {
     wave_before[wv] = before;
     wave_last[wv] = last;
   }
   __syncthreads();
-  if (threadIdx.x == 0) RJ_STAMP(1);
-  uint64_t base = 0, own_before = 0, own_total = 0, end_before = 0;
+  if (threadIdx.x == 0) RJ_STAMP_AT(blockIdx.x, 2);
+  uint64_t base = 0;
   int64_t nearest = -1;
 #pragma unroll
   for (int w = 0; w < kWaves; w++) {
     base += wave_before[w];
     nearest = wave_last[w] > nearest ? wave_last[w] : nearest;
-    if (w < wv) {
-      own_before += wave_sum[w];
-      end_before = wave_end[w] > end_before ? wave_end[w] : end_before;
-    }
-    own_total += wave_sum[w];
   }
   // running maximum of the ends before this thread's first candidate
   uint64_t prev = carry_cur;
@@ -1298,7 +1349,7 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
   prev = end_before > prev ? end_before : prev;
   const uint64_t up = __shfl_up(inc_end, 1);  // inclusive maximum of the lanes below
   if (lane > 0) prev = up > prev ? up : prev;
-  if (threadIdx.x == 0 && prev != ~0ull) RJ_STAMP(2);
+  if (threadIdx.x == 0 && prev != ~0ull) RJ_STAMP_AT(blockIdx.x, 3);
   // 3. copy + check
   const uint64_t off = base + own_before + inc - cnt;
   bool ok = true;
@@ -1347,7 +1398,7 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
     prev = e > prev ? e : prev;
     if (off + k < out_cap) *reinterpret_cast<ulonglong2*>(out + 2 * (off + k)) = make_ulonglong2(b, e);
   }
-  if (threadIdx.x == 0) RJ_STAMP(3);
+  if (threadIdx.x == 0) RJ_STAMP_AT(blockIdx.x, 4);
   if (!ok) {
     counters[kCntUnordered] = 1;
     if (host_counters) host_counters[kCntUnordered] = 1;
@@ -1357,7 +1408,6 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
     if (host_counters) host_counters[kCntAdjacent] = 1;
   }
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-    RJ_STAMP(4);
     counters[kCntHits] = base + own_total;
     counters[kCntCands] = base + own_total;
     if (host_counters) {
@@ -1372,6 +1422,7 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
       host_counters[kCntSharedMax] = counters[kCntSharedMax];
       host_counters[kCntFinal] = 0;
     }
+    RJ_STAMP_AT(blockIdx.x, 5);
   }
 }
 
@@ -1380,9 +1431,9 @@ __global__ __launch_bounds__(kOgcThreads) void offsets_gather_check(const uint32
                                                                     uint32_t region_cap, uint64_t carry_cur, uint64_t* out,
                                                                     uint64_t out_cap, unsigned long long* counters,
                                                                     unsigned long long* host_counters, uint64_t carry_pe,
-                                                                    uint64_t* offsets_out, uint64_t* prev_out) {
+                                                                    uint64_t* offsets_out, uint64_t* prev_out, uint32_t epoch) {
   offsets_gather_check_body(counts, region_begins, region_ends, n_regions, region_cap, carry_cur, out, out_cap, counters,
-                            host_counters, carry_pe, offsets_out, prev_out);
+                            host_counters, carry_pe, epoch, offsets_out, prev_out);
 }
 
 // Second half of the two-launch form used when regions hold many candidates (tens and more each:
@@ -1419,10 +1470,10 @@ __global__ __launch_bounds__(256) void gather_regions_by_wave(const uint32_t* co
   }
 }
 
-__global__ __launch_bounds__(kOgcThreads) void offsets_gather_check_multi(const MultiTail* tails) {
+__global__ __launch_bounds__(kOgcThreads) void offsets_gather_check_multi(const MultiTail* tails, uint32_t epoch) {
   const MultiTail t = tails[blockIdx.y];  // by value, see verify_in_regions_multi
   offsets_gather_check_body(t.valid_counts, t.verify.hits, t.region_ends, t.verify.n_regions, t.verify.region_cap, 0, t.out,
-                            t.out_cap, t.verify.counters, t.host_counters, ~0ull);
+                            t.out_cap, t.verify.counters, t.host_counters, ~0ull, epoch);
 }
 
 // First and last match of up to kMaxFused result lists (rj_multi_bounds: what a shard exchanges with
@@ -3000,6 +3051,13 @@ void launch_verify_in_regions(const VerifyParams& a, const DevProgram& P, const 
                           valid_counts, region_ends);
 }
 
+// a number per launch of the gather kernels (24 bits used: a granule left by an earlier launch never matches)
+static uint32_t next_ogc_epoch() {
+  static std::atomic<uint32_t> epoch{0};
+  uint32_t e = epoch.fetch_add(1, std::memory_order_relaxed) + 1;
+  return (e & 0xFFFFFFu) == 0 ? next_ogc_epoch() : e;  // (0 is what a fresh counter block holds)
+}
+
 void launch_offsets_gather_check(const uint32_t* counts, const uint64_t* region_begins, const uint64_t* region_ends,
                                  uint32_t n_regions, uint32_t region_cap, uint64_t carry_cur, uint64_t* out, uint64_t out_cap,
                                  unsigned long long* counters, unsigned long long* host_counters, uint64_t* offsets_scratch,
@@ -3007,7 +3065,7 @@ void launch_offsets_gather_check(const uint32_t* counts, const uint64_t* region_
   const uint64_t carry_pe = have_prev ? carry_prev_end : ~0ull;
   const unsigned blocks = n_regions ? (n_regions + kOgcThreads - 1) / kOgcThreads : 1u;
   hipLaunchKernelGGL(offsets_gather_check, dim3(blocks), dim3(kOgcThreads), 0, st, counts, region_begins, region_ends, n_regions,
-                     region_cap, carry_cur, out, out_cap, counters, host_counters, carry_pe, offsets_scratch, prev_scratch);
+                     region_cap, carry_cur, out, out_cap, counters, host_counters, carry_pe, offsets_scratch, prev_scratch, next_ogc_epoch());
   if (offsets_scratch != nullptr) {
     uint64_t wblocks = (static_cast<uint64_t>(n_regions) + 3) / 4;
     wblocks = wblocks < 1 ? 1 : wblocks > 16384 ? 16384 : wblocks;
@@ -3053,7 +3111,7 @@ void launch_tails_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_reg
 
 void launch_offsets_gather_check_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_regions, hipStream_t st) {
   const unsigned gblocks = n_regions ? (n_regions + kOgcThreads - 1) / kOgcThreads : 1u;
-  hipLaunchKernelGGL(offsets_gather_check_multi, dim3(gblocks, n_patterns), dim3(kOgcThreads), 0, st, d_tails);
+  hipLaunchKernelGGL(offsets_gather_check_multi, dim3(gblocks, n_patterns), dim3(kOgcThreads), 0, st, d_tails, next_ogc_epoch());
 }
 
 void launch_split_pairs(const uint64_t* pairs, const unsigned long long* n_ptr, uint64_t n_upper, uint64_t* keys, uint64_t* vals,

@@ -10,7 +10,11 @@
 static __device__ unsigned long long rj_trace_buf[64];  // wall_clock64(): 10 ns units
 #define RJ_STAMP(i) ((i) == 0 ? atomicMin(&rj_trace_buf[0], static_cast<unsigned long long>(wall_clock64())) \
                               : atomicMax(&rj_trace_buf[i], static_cast<unsigned long long>(wall_clock64())))
+// per-workgroup stamps with plain stores (no atomics: nothing for a lane to wait for): slot = blockIdx.x, i < 8
+static __device__ unsigned long long rj_trace_wide[8 * 4096];
+#define RJ_STAMP_AT(slot, i) (rj_trace_wide[((slot) & 4095u) * 8u + (i)] = wall_clock64())
 #define RJ_TRACE_EXPORT(name)                                                                                        \
+  extern "C" int name##_wide(unsigned long long* out) { return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(rj_trace_wide), sizeof(rj_trace_wide))); } \
   extern "C" int name(unsigned long long* out) { return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(rj_trace_buf), sizeof(rj_trace_buf))); } \
   extern "C" int name##_reset() {                                                                                    \
     unsigned long long z[64] = {~0ull};                                                                              \
@@ -18,6 +22,7 @@ static __device__ unsigned long long rj_trace_buf[64];  // wall_clock64(): 10 ns
   }
 #else
 #define RJ_STAMP(i) ((void)0)
+#define RJ_STAMP_AT(slot, i) ((void)0)
 #define RJ_TRACE_EXPORT(name)
 #endif
 #endif

@@ -17,15 +17,19 @@ st = torch.cuda.current_stream(dev).cuda_stream
 t = W.random_ascii_torch(n, 0xC0FFEE, dev)
 W.plant(t, W.plant_offsets(n, 6, 1000, seed=7), b"regexp")
 sc = rejit_amd.Scan(rejit_amd.Program("regexp"))
-NAMES = {0: "first workgroup starts", 1: "counts of all earlier regions + own entries read (last workgroup)", 2: "nearest earlier end read",
-         3: "copied and checked", 4: "last block: host counters"}
+lib.rj_debug_trace_wide.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+NAMES = ["workgroup starts", "counts of all earlier regions summed (thread 0)", "own count + entries read, wave sums exchanged", "nearest earlier end read",
+         "copied and checked", "last block: host counters written"]
 for rep in range(5):
-    lib.rj_debug_trace_reset()
     k = sc.run(t.data_ptr(), n, stream=st)
     torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * 64)()
-    lib.rj_debug_trace(buf)
+    buf = (ctypes.c_ulonglong * (8 * 4096))()
+    lib.rj_debug_trace_wide(buf)
     if rep >= 3:
-        print(k, "matches; call", round(sc.stats()["total_ms"], 3), "scan", round(sc.stats()["scan_ms"], 3))
-        for i in sorted(NAMES):
-            print("   %-70s %+8.2f us" % (NAMES[i], (buf[i] - buf[0]) / 100.0))
+        blocks = [b for b in range(4096) if buf[8 * b]]
+        t0 = min(buf[8 * b] for b in blocks)
+        print(k, "matches; call", round(sc.stats()["total_ms"], 3), "scan", round(sc.stats()["scan_ms"], 3), "; workgroups", len(blocks))
+        for i, name in enumerate(NAMES):
+            vals = [(buf[8 * b + i] - t0) / 100.0 for b in blocks if buf[8 * b + i]]
+            if vals:
+                print("   %-62s first %+7.2f  last %+7.2f us (workgroup %d)" % (name, min(vals), max(vals), max(blocks, key=lambda b: buf[8 * b + i])))
