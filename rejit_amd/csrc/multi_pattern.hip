@@ -265,7 +265,8 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     chunks = std::max<uint64_t>(plane_pairs * 2, 1);
   }
   // (plane scan, 500 MB: 96 chunks per workgroup measured best -- 92 us against 98 at 128, 96 at 64)
-  const ScanGeometry geo = scan_geometry(chunks, plane ? 96 : 128);
+  static const int plane_chunks = getenv("RJ_PLANE_CHUNKS") ? atoi(getenv("RJ_PLANE_CHUNKS")) : 96;  // measurement override
+  const ScanGeometry geo = scan_geometry(chunks, plane ? static_cast<uint64_t>(plane_chunks > 0 ? plane_chunks : 96) : 128);
   rj_scan* const s0 = m->scans[0];
   std::vector<uint64_t> caps(static_cast<size_t>(P));
   uint32_t shared_cap = 0;

@@ -36,6 +36,9 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include "trace_stamp.h"
+RJ_TRACE_EXPORT(rj_debug_trace_plane)
+
 #include <type_traits>
 
 #include "device_program.h"
@@ -344,6 +347,7 @@ __global__ __launch_bounds__(256) void classify_shared_multi(SharedHits sh, unsi
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int lane = lane_id();
   const int half = lane >> 5, sub = lane & 31;
+  if (threadIdx.x == 0) RJ_STAMP_AT(blockIdx.x, 0);
   const uint64_t wave = __builtin_amdgcn_readfirstlane(
       static_cast<uint32_t>((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6));
   const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
@@ -360,6 +364,7 @@ __global__ __launch_bounds__(256) void classify_shared_multi(SharedHits sh, unsi
     for (uint32_t i = threadIdx.x; i < sh.blob_words / 4; i += blockDim.x) dst[i] = src[i];
   }
   __syncthreads();
+  if (threadIdx.x == 0) RJ_STAMP_AT(blockIdx.x, 1);
   const ClassifyDesc* desc = reinterpret_cast<const ClassifyDesc*>(lds);
   const uint32_t* tab = lds + sh.desc_words;
   for (uint64_t r0 = wave * 2; r0 < sh.n_regions; r0 += n_waves * 2) {
@@ -389,6 +394,7 @@ __global__ __launch_bounds__(256) void classify_shared_multi(SharedHits sh, unsi
         rj_load16(text, n, s, &t_lo, &t_hi);
       }
       const uint32_t avail = n - s < 16 ? static_cast<uint32_t>(n - s) : 16u;
+      if (threadIdx.x == 0 && (t_lo | lo) != 0x123456789ull) RJ_STAMP_AT(blockIdx.x, r0 == wave * 2 ? 2 : 4);
       for (uint32_t p = 0; p < sh.n_patterns; p++) {
         const ClassifyDesc& d = desc[p];
         bool win = (((lo ^ d.v0[0]) & d.m0[0]) | ((hi ^ d.v1[0]) & d.m1[0])) == 0;
@@ -426,7 +432,9 @@ __global__ __launch_bounds__(256) void classify_shared_multi(SharedHits sh, unsi
       }
       d.valid_counts[r] = c < cap_p ? c : cap_p;
     }
+    if (threadIdx.x == 0) RJ_STAMP_AT(blockIdx.x, r0 == wave * 2 ? 3 : 5);
   }
+  if (threadIdx.x == 0) RJ_STAMP_AT(blockIdx.x, 6);
 }
 
 void launch_tails_shared(const MultiTail* d_tails, const SharedHits& sh, int max_words, uint32_t max_short, unsigned long long* counters0,
