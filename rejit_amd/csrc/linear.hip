@@ -40,7 +40,10 @@ int run_linear(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint6
   // sub-chunk = what one lane walks sequentially: large enough that the summaries stay small next to
   // the text, small enough that a modest text still fills the GPU
   uint64_t sub = 4096;
-  while (sub > 256 && (n - sb) / sub < 32768) sub >>= 1;
+  static const uint64_t want_lanes = getenv("RJ_CS_LANES") ? static_cast<uint64_t>(atoll(getenv("RJ_CS_LANES"))) : 131072;  // measurement override
+  // (131072 lanes = two waves per SIMD: `a.*b` over a 64 MiB line 8.8 -> 5.6 ms, `[acgt]+` 5.2 -> 4.3 against 32768;
+  // 262144 and more: slower again -- sub-chunks of 256 bytes, the per-sub-chunk work of resolve and the chains grows)
+  while (sub > 256 && (n - sb) / sub < want_lanes) sub >>= 1;
   while ((n - sb) / sub > (16u << 20)) sub <<= 1;
   const int np = std::max(R.n_pos, 1), W = R.n_words;
   // ... and the summaries (np * (8 + 4 W) bytes per sub-chunk: 10 KiB for a 256-position automaton) stay below half
