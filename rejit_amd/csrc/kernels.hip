@@ -1193,7 +1193,7 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
                                                           const uint64_t* region_ends, uint32_t n_regions,
                                                           uint32_t region_cap, uint64_t carry_cur, uint64_t* out,
                                                           uint64_t out_cap, unsigned long long* counters,
-                                                          unsigned long long* host_counters, uint64_t carry_pe, uint32_t epoch,
+                                                          unsigned long long* host_counters, uint64_t carry_pe, uint64_t epoch,
                                                           uint64_t* offsets_out = nullptr, uint64_t* prev_out = nullptr) {
   // Adjacency (a candidate begins exactly where an earlier one ends) is wanted for the Q8 check.
   // When the list is ordered and disjoint -- the only case in which this kernel's verdict is
@@ -1292,7 +1292,9 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
     }
     own_total += wave_sum[w];
   }
-  const unsigned long long tag = static_cast<unsigned long long>(epoch & 0xFFFFFFu) << 40;
+  // (the launch number is 58 bits, split over the two granules: 32 beside the total -- a workgroup's own 256 regions hold
+  // < 2^28 candidates -- and 26 beside the packed last region; a stale pair would have to match both)
+  const unsigned long long tag_sum = (epoch & 0xFFFFFFFFull) << 32, tag_last = ((epoch >> 32) & 0x3FFFFFFull) << 38;
   if (exchange) {
     if (threadIdx.x == 0) {
       int64_t bl = -1;
@@ -1300,8 +1302,8 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
       for (int w = 0; w < kWaves; w++) bl = wave_own_last[w] > bl ? wave_own_last[w] : bl;
       // (region index + 1 in 17 bits, count in 21: a region holds at most 2^20 candidates; 0 = none)
       const unsigned long long packed = bl < 0 ? 0ull : ((static_cast<unsigned long long>(bl >> 32) + 1) << 21) | static_cast<unsigned long long>(bl & 0x1FFFFF);
-      __hip_atomic_store(&granules[blockIdx.x], tag | own_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&granules[kOgcMaxBlocks + blockIdx.x], tag | packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&granules[blockIdx.x], tag_sum | (own_total & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&granules[kOgcMaxBlocks + blockIdx.x], tag_last | packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (threadIdx.x < blockIdx.x) {  // lane t: the workgroup t before this one
       unsigned long long gs = 0, gl = 0;
@@ -1309,12 +1311,12 @@ __device__ __forceinline__ void offsets_gather_check_body(const uint32_t* counts
       for (int spin = 0; spin < 4096 && !have; spin++) {
         gs = __hip_atomic_load(&granules[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         gl = __hip_atomic_load(&granules[kOgcMaxBlocks + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        have = (gs >> 40) == (tag >> 40) && (gl >> 40) == (tag >> 40);
+        have = (gs >> 32) == (tag_sum >> 32) && (gl >> 38) == (tag_last >> 38);
         if (!have) __builtin_amdgcn_s_sleep(1);
       }
       if (have) {
-        before = gs & 0xFFFFFFFFFFull;
-        const unsigned long long pk = gl & 0xFFFFFFFFFFull;
+        before = gs & 0xFFFFFFFFull;
+        const unsigned long long pk = gl & 0x3FFFFFFFFFull;
         last = pk == 0 ? -1 : ((static_cast<int64_t>((pk >> 21) - 1) << 32) | static_cast<int64_t>(pk & 0x1FFFFF));
       } else {
         sum_counts(threadIdx.x * (kOgcThreads / 4), (threadIdx.x + 1) * (kOgcThreads / 4), 1);  // that workgroup's 256 counts
@@ -1431,7 +1433,7 @@ __global__ __launch_bounds__(kOgcThreads) void offsets_gather_check(const uint32
                                                                     uint32_t region_cap, uint64_t carry_cur, uint64_t* out,
                                                                     uint64_t out_cap, unsigned long long* counters,
                                                                     unsigned long long* host_counters, uint64_t carry_pe,
-                                                                    uint64_t* offsets_out, uint64_t* prev_out, uint32_t epoch) {
+                                                                    uint64_t* offsets_out, uint64_t* prev_out, uint64_t epoch) {
   offsets_gather_check_body(counts, region_begins, region_ends, n_regions, region_cap, carry_cur, out, out_cap, counters,
                             host_counters, carry_pe, epoch, offsets_out, prev_out);
 }
@@ -1470,7 +1472,7 @@ __global__ __launch_bounds__(256) void gather_regions_by_wave(const uint32_t* co
   }
 }
 
-__global__ __launch_bounds__(kOgcThreads) void offsets_gather_check_multi(const MultiTail* tails, uint32_t epoch) {
+__global__ __launch_bounds__(kOgcThreads) void offsets_gather_check_multi(const MultiTail* tails, uint64_t epoch) {
   const MultiTail t = tails[blockIdx.y];  // by value, see verify_in_regions_multi
   offsets_gather_check_body(t.valid_counts, t.verify.hits, t.region_ends, t.verify.n_regions, t.verify.region_cap, 0, t.out,
                             t.out_cap, t.verify.counters, t.host_counters, ~0ull, epoch);
@@ -3051,11 +3053,12 @@ void launch_verify_in_regions(const VerifyParams& a, const DevProgram& P, const 
                           valid_counts, region_ends);
 }
 
-// a number per launch of the gather kernels (24 bits used: a granule left by an earlier launch never matches)
-static uint32_t next_ogc_epoch() {
-  static std::atomic<uint32_t> epoch{0};
-  uint32_t e = epoch.fetch_add(1, std::memory_order_relaxed) + 1;
-  return (e & 0xFFFFFFu) == 0 ? next_ogc_epoch() : e;  // (0 is what a fresh counter block holds)
+// a number per launch of the gather kernels (58 bits used: a granule pair left by an earlier launch never matches; the
+// low 32 bits are never 0, which is what a fresh counter block holds)
+static uint64_t next_ogc_epoch() {
+  static std::atomic<uint64_t> epoch{0};
+  uint64_t e = epoch.fetch_add(1, std::memory_order_relaxed) + 1;
+  return (e & 0xFFFFFFFFull) == 0 ? next_ogc_epoch() : e;
 }
 
 void launch_offsets_gather_check(const uint32_t* counts, const uint64_t* region_begins, const uint64_t* region_ends,
