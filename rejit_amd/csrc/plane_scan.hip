@@ -395,22 +395,43 @@ __global__ __launch_bounds__(256) void classify_shared_multi(SharedHits sh, unsi
       }
       const uint32_t avail = n - s < 16 ? static_cast<uint32_t>(n - s) : 16u;
       if (threadIdx.x == 0 && (t_lo | lo) != 0x123456789ull) RJ_STAMP_AT(blockIdx.x, r0 == wave * 2 ? 2 : 4);
+      // 1. every pattern's exact window test: a bit per pattern that this candidate may match
+      uint32_t todo = 0;
       for (uint32_t p = 0; p < sh.n_patterns; p++) {
         const ClassifyDesc& d = desc[p];
         bool win = (((lo ^ d.v0[0]) & d.m0[0]) | ((hi ^ d.v1[0]) & d.m1[0])) == 0;
         if (d.n_windows > 1) win = win || ((((lo ^ d.v0[1]) & d.m0[1]) | ((hi ^ d.v1[1]) & d.m1[1])) == 0);
-        const bool active = in_range && win;
-        if (__ballot(active) == 0) continue;
+        todo |= (in_range && win) ? 1u << p : 0u;
+      }
+      // 2. the automata: in pass r every lane runs the r-th pattern whose window test ITS candidate passed (tables and
+      //    descriptor addressed per lane).  A candidate passes one or two tests, so this is two passes where the loop
+      //    over the patterns -- the automaton whenever ANY of the 64 candidates passed the pattern's test -- made nine.
+      uint32_t matched = 0;  // bit p: pattern p matches at this candidate ...
+      uint64_t lens[2] = {0, 0};  // ... with this length (5 bits per pattern, <= 16: twelve patterns per word)
+      static_assert(kMaxFused <= 24, "two words of twelve lengths");
+      while (__ballot(todo != 0) != 0) {
+        const bool act = todo != 0;
+        const uint32_t p = act ? static_cast<uint32_t>(__builtin_ctz(todo)) : 0u;
+        todo &= todo - 1;
+        const ClassifyDesc& d = desc[p];
+        const uint32_t* t0 = tab + d.tab;
         uint32_t len = 0;
-        bool found = false;
-        {
-          const uint32_t* t0 = tab + d.tab;
-          if (W == 1 || d.n_words <= 1) found = short_longest_lds<1, MAXK>(t0, d, t_lo, t_hi, avail, &len);
-          else found = short_longest_lds<W, MAXK>(t0, d, t_lo, t_hi, avail, &len);
+        bool found;
+        if (W == 1 || d.n_words <= 1) found = short_longest_lds<1, MAXK>(t0, d, t_lo, t_hi, avail, &len);
+        else found = short_longest_lds<W, MAXK>(t0, d, t_lo, t_hi, avail, &len);
+        if (found && act) {
+          matched |= 1u << p;
+          if (p < 12) lens[0] |= static_cast<uint64_t>(len) << (5 * p);
+          else lens[1] |= static_cast<uint64_t>(len) << (5 * (p - 12));
         }
-        found = found && active;
-        const uint64_t e = s + len;
+      }
+      // 3. the survivors of every pattern, in position order, to the pattern's own region
+      for (uint32_t p = 0; p < sh.n_patterns; p++) {
+        const bool found = ((matched >> p) & 1u) != 0;
         const uint64_t mine = __ballot(found);
+        if (mine == 0) continue;
+        const ClassifyDesc& d = desc[p];
+        const uint64_t e = s + (((p < 12 ? lens[0] >> (5 * p) : lens[1] >> (5 * (p - 12)))) & 31u);
         const uint32_t mine_half = static_cast<uint32_t>(mine >> (32 * half));
         const uint32_t b0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(kept), static_cast<int>(p)));
         const uint32_t b1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(kept), static_cast<int>(32 + p)));
