@@ -204,6 +204,24 @@ int rj_multi_bounds_device(rj_multi* multi, int64_t offset, int first_round, int
  * the pattern again | the (cur, prev_end) to select it under | 1 when any rank re-runs anything.  One kernel on
  * hip_stream; the caller synchronises once per round. */
 int rj_carry_decide(const int64_t* d_all, int world, int rank, int n_patterns, int64_t* out, void* hip_stream);
+/* The whole exchange step behind one call, for C++ callers with one process (or thread) per GPU and one shard of the
+ * text resident on each (the reference's counterpart is the per-pattern thread pool of sample/regexdna-multithread.cc:
+ * 65-78; across devices the unit is the byte range): runs the patterns over this rank's shard (arguments as for
+ * rj_multi_run_range; `offset` = the position of d_text[0] in the whole text), then carries the left-most-longest
+ * selection over the cuts -- per round one all-gather of 8 integers per pattern, written and evaluated by kernels on
+ * hip_stream, one synchronise -- re-running the (rare) pattern whose first match begins inside its left neighbour's
+ * last one.  counts[i] = matches of pattern i over the WHOLE text, on every rank; rj_multi_scan(m, i) holds this
+ * shard's final spans.  rccl_comm is the caller's ncclComm_t (RCCL is bound with dlopen at the first call: the copy
+ * the process has loaded already, else librccl.so.1 / $RJ_RCCL_LIBRARY); every rank of the communicator must call.
+ * Ring-artefact-risk patterns need their shard's buffer to reach the end of the text (rj_program_info). */
+int rj_multi_device_counts(rj_multi* multi, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end,
+                           int64_t offset, void* rccl_comm, int rank, int world, uint64_t* counts, void* hip_stream);
+/* The same over any all-gather: d_send (bytes_per_rank bytes, device) of every rank, in rank order, into d_recv
+ * (world * bytes_per_rank bytes, device), queued on hip_stream or complete on return; 0 = success. */
+typedef int (*rj_allgather_fn)(void* ctx, const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* hip_stream);
+int rj_multi_device_counts_via(rj_multi* multi, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end,
+                               int64_t offset, rj_allgather_fn allgather, void* ctx, int rank, int world, uint64_t* counts,
+                               void* hip_stream);
 /* mode 0 (default): fuse when possible; mode 1: never fuse -- every pattern scans the whole text on its own,
  * all of them in ONE launch when the patterns have the regexdna shape (scan_windows_train), else one kernel
  * per pattern back to back on the caller's stream; mode 2: one kernel per pattern, alternating between the

@@ -117,6 +117,9 @@ class _Stats(ctypes.Structure):
 _lib = None
 
 # every symbol include/rejit_hip.h declares
+# rj_allgather_fn (include/rejit_hip.h): ctx, d_send, d_recv, bytes per rank, hip stream -> 0 on success
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p)
+
 C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_error", "rj_match_full",
                  "rj_match_anywhere", "rj_match_first", "rj_match_all", "rj_free_spans", "rj_scan_create",
                  "rj_scan_destroy", "rj_scan_run", "rj_scan_device_spans", "rj_scan_copy_spans", "rj_scan_stats",
@@ -124,7 +127,8 @@ C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_er
                  "rj_match_all_batch", "rj_multi_create", "rj_multi_destroy", "rj_multi_run", "rj_multi_scan",
                  "rj_multi_scan_ms", "rj_scan_start", "rj_scan_finish", "rj_multi_set_mode", "rj_multi_run_range",
                  "rj_multi_bounds", "rj_batch_separator", "rj_match_all_packed", "rj_host_alloc", "rj_host_free",
-                 "rj_multi_bounds_device", "rj_carry_decide", "rj_multi_start", "rj_multi_finish", "rj_multi_order_after"]
+                 "rj_multi_bounds_device", "rj_carry_decide", "rj_multi_start", "rj_multi_finish", "rj_multi_order_after",
+                 "rj_multi_device_counts", "rj_multi_device_counts_via"]
 
 
 def load_library():
@@ -172,6 +176,8 @@ def load_library():
     L.rj_multi_bounds.argtypes = [vp, _u64p, vp]
     L.rj_multi_bounds_device.argtypes = [vp, ctypes.c_int64, ctypes.c_int, vp, vp]
     L.rj_carry_decide.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
+    L.rj_multi_device_counts.argtypes = [vp, vp, u64, u64, u64, ctypes.c_int64, vp, ctypes.c_int, ctypes.c_int, _u64p, vp]
+    L.rj_multi_device_counts_via.argtypes = [vp, vp, u64, u64, u64, ctypes.c_int64, ALLGATHER_FN, vp, ctypes.c_int, ctypes.c_int, _u64p, vp]
     L.rj_scan_destroy.argtypes = [vp]
     L.rj_scan_run.restype = i64
     L.rj_scan_run.argtypes = [vp, vp, u64, u64, u64, u64, u64, ctypes.c_int, vp]
@@ -431,6 +437,22 @@ class MultiScan:
     def finish(self) -> List[int]:
         counts = (ctypes.c_uint64 * len(self.programs))()
         r = _check(self._lib.rj_multi_finish(self._h, counts))
+        self.how = int(r)
+        self.fused = r == 1
+        return [int(c) for c in counts]
+
+    def device_counts(self, d_text_ptr: int, n: int, offset: int, rank: int, world: int, comm: Optional[int] = None, allgather=None,
+                      own_begin: int = 0, own_end: Optional[int] = None, stream: int = 0) -> List[int]:
+        """rj_multi_device_counts: run over this rank's shard, then the carry exchange between the shards, behind one call.
+        `comm` = an ncclComm_t (integer handle) of RCCL, or `allgather` = an ALLGATHER_FN(ctx, d_send, d_recv, bytes, stream)
+        callable.  Returns the job-wide counts (the same on every rank)."""
+        counts = (ctypes.c_uint64 * len(self.programs))()
+        args = (self._h, ctypes.c_void_p(d_text_ptr), n, own_begin, n + 1 if own_end is None else own_end, ctypes.c_int64(offset))
+        if allgather is not None:
+            fn = allgather if isinstance(allgather, ALLGATHER_FN) else ALLGATHER_FN(allgather)
+            r = _check(self._lib.rj_multi_device_counts_via(*args, fn, None, rank, world, counts, ctypes.c_void_p(stream)))
+        else:
+            r = _check(self._lib.rj_multi_device_counts(*args, ctypes.c_void_p(comm), rank, world, counts, ctypes.c_void_p(stream)))
         self.how = int(r)
         self.fused = r == 1
         return [int(c) for c in counts]

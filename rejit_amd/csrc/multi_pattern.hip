@@ -6,6 +6,7 @@
 // through run_pipeline (engine.hip).
 
 #include <cstring>
+#include <dlfcn.h>
 
 #include <hip/hip_runtime.h>
 
@@ -14,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -175,6 +177,9 @@ struct rj_multi {
     hipEvent_t done = nullptr;  // behind the run's last kernel: rj_multi_finish waits for THIS run, not for the stream
   } pending;
   rj_multi* scan_after = nullptr;  // rj_multi_order_after: this object's scan kernel waits for that one's
+  // rj_multi_device_counts: this rank's rows [P][8] followed by every rank's [world][P][8]; the decision (pinned)
+  DeviceBuffer exchange_rows;
+  int64_t* host_decision = nullptr;
 
 };
 
@@ -642,6 +647,7 @@ void rj_multi_destroy(rj_multi* m) {
   if (m->fork) (void)hipEventDestroy(m->fork);
   if (m->join) (void)hipEventDestroy(m->join);
   if (m->pending.done) (void)hipEventDestroy(m->pending.done);
+  if (m->host_decision) (void)hipHostFree(m->host_decision);
   delete m;
 }
 
@@ -780,6 +786,89 @@ int rj_carry_decide(const int64_t* d_all, int world, int rank, int n_patterns, i
   launch_carry_decide(d_all, world, rank, n_patterns, out, static_cast<hipStream_t>(hip_stream));
   RJ_HIP(hipGetLastError());
   return RJ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The exchange step of a sharded multi-pattern count behind ONE call, for C++ callers with one process (or thread)
+// per GPU: what rejit_amd/sharding.py's CarryExchange does over torch.distributed, here over the collective the
+// caller hands in -- RCCL's all-gather on the caller's communicator (rj_multi_device_counts), or any function of
+// that shape (rj_multi_device_counts_via: MPI, a test harness with several shards on one device).
+//   per round: rows of this rank (kernel) -> all-gather of 8 integers per pattern -> decision (kernel) -> ONE
+//   synchronise -> the (rare) patterns whose selection has to be repeated under the left neighbour's last match.
+// Rounds end when no rank repeats anything: at most `world` of them (a carry travels one shard per round).
+int rj_multi_device_counts_via(rj_multi* m, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end, int64_t offset,
+                               rj_allgather_fn allgather, void* ctx, int rank, int world, uint64_t* counts, void* hip_stream) {
+  ErrnoGuard errno_guard;
+  if (!m || !allgather || !counts || world < 1 || rank < 0 || rank >= world) return fail(RJ_BAD_ARGUMENT, "bad argument");
+  const int P = static_cast<int>(m->scans.size());
+  if (P < 1 || P > 64) return fail(RJ_BAD_ARGUMENT, "rj_multi_device_counts: 1..64 patterns");
+  const int kind = rj_multi_run_range(m, d_text, n, own_begin, own_end, counts, hip_stream);
+  if (kind < 0) return kind;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const size_t row_words = static_cast<size_t>(P) * 8;
+  RJ_HIP(m->exchange_rows.reserve(sizeof(int64_t) * row_words * static_cast<size_t>(world + 1)));
+  if (!m->host_decision) RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&m->host_decision), sizeof(int64_t) * (4 * 64 + 1)));
+  int64_t* mine = m->exchange_rows.as<int64_t>();
+  int64_t* all = mine + row_words;
+  int64_t* out = m->host_decision;
+  for (int round = 0; round <= world; round++) {
+    const int e = rj_multi_bounds_device(m, offset, round == 0, mine, hip_stream);
+    if (e < 0) return e;
+    if (allgather(ctx, mine, all, sizeof(int64_t) * row_words, hip_stream) != 0)
+      return fail(RJ_DEVICE_ERROR, "rj_multi_device_counts: the all-gather failed (round %d)", round);
+    const int d = rj_carry_decide(all, world, rank, P, out, hip_stream);
+    if (d < 0) return d;
+    RJ_HIP(hipStreamSynchronize(st));
+    if (out[4 * P] == 0) {
+      for (int i = 0; i < P; i++) counts[i] = static_cast<uint64_t>(out[i]);
+      return kind;
+    }
+    for (int i = 0; i < P; i++) {
+      if (!out[P + i]) continue;
+      // (global offsets in the rows; the shard's own run takes them relative to its buffer)
+      const int64_t cur = out[2 * P + 2 * i], pe = out[2 * P + 2 * i + 1];
+      const int have = (cur != 0 || pe != 0) ? 1 : 0;
+      const uint64_t lc = cur > offset ? static_cast<uint64_t>(cur - offset) : 0, lp = pe > offset ? static_cast<uint64_t>(pe - offset) : 0;
+      const int64_t k = rj_scan_run(m->scans[static_cast<size_t>(i)], d_text, n, own_begin, own_end, lc, lp, have, hip_stream);
+      if (k < 0) return static_cast<int>(k);
+      const int64_t used[3] = {cur, pe, have};  // the carry this result was selected under: part of the next round's row
+      RJ_HIP(hipMemcpyAsync(mine + 8 * i + 5, used, sizeof(used), hipMemcpyHostToDevice, st));
+      RJ_HIP(hipStreamSynchronize(st));  // (`used` is on the stack)
+    }
+  }
+  return fail(RJ_DEVICE_ERROR, "rj_multi_device_counts: the carry exchange did not converge in %d rounds", world + 1);
+}
+
+namespace {
+// RCCL, bound at the first call: the library is an optional companion of this one (a single-GPU caller never
+// needs it), and a process that has loaded RCCL already -- through PyTorch, say -- must get THAT copy.
+using AllGatherFn = int (*)(const void*, void*, size_t, int, void*, hipStream_t);
+AllGatherFn rccl_all_gather() {
+  static AllGatherFn fn = nullptr;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {std::getenv("RJ_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* name : names) {
+      if (!name || !*name) continue;
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+        fn = reinterpret_cast<AllGatherFn>(dlsym(h, "ncclAllGather"));
+        if (fn) return;
+      }
+    }
+  });
+  return fn;
+}
+int rccl_gather(void* comm, const void* send, void* recv, uint64_t bytes, void* stream) {
+  constexpr int kNcclInt64 = 4;  // ncclDataType_t (rccl.h)
+  return rccl_all_gather()(send, recv, bytes / sizeof(int64_t), kNcclInt64, comm, static_cast<hipStream_t>(stream));
+}
+}  // namespace
+
+int rj_multi_device_counts(rj_multi* m, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end, int64_t offset,
+                           void* rccl_comm, int rank, int world, uint64_t* counts, void* hip_stream) {
+  if (!rccl_comm) return fail(RJ_BAD_ARGUMENT, "rj_multi_device_counts: no communicator");
+  if (!rccl_all_gather()) return fail(RJ_DEVICE_ERROR, "rj_multi_device_counts: librccl.so not found (set RJ_RCCL_LIBRARY)");
+  return rj_multi_device_counts_via(m, d_text, n, own_begin, own_end, offset, rccl_gather, rccl_comm, rank, world, counts, hip_stream);
 }
 
 int rj_multi_set_mode(rj_multi* m, int mode) {
