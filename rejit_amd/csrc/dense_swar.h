@@ -29,13 +29,26 @@ RJ_HD void rj_swar_rows5(const SwarPlan& pl, const uint32_t (&x)[5], uint32_t (&
 #pragma unroll
   for (int i = 0; i < 5; i++) {
     x7[i] = x[i] & 0x7f7f7f7fu;
-    highh[i] = x[i] & 0x80808080u;
-    lowh[i] = highh[i] ^ 0x80808080u;
+    lowh[i] = ~x[i] & 0x80808080u;
     rows[i] = 0;
   }
+  if (pl.n_ranges <= 4 && pl.n_low == pl.n_ranges) {
+    // the usual pattern: a few ranges, all of them ASCII -- no choice between the halves per range and word, and
+    // unrolled, so that the constants are loop-invariant scalars of the caller's chunk loop instead of three scalar
+    // loads (and a wait) per range and chunk
+#pragma unroll
+    for (uint32_t r = 0; r < 4; r++) {
+      if (r < pl.n_ranges) {
+        const uint32_t lo = pl.add_lo[r], hi = pl.add_hi[r], sh = pl.shift[r];
+#pragma unroll
+        for (int i = 0; i < 5; i++) rows[i] |= ((x7[i] + lo) & ~(x7[i] + hi) & lowh[i]) >> sh;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 5; i++) highh[i] = x[i] & 0x80808080u;
   if (pl.n_ranges <= 4) {
-    // the usual few ranges: unrolled, so that the constants are loop-invariant scalars of the caller's chunk
-    // loop instead of three scalar loads (and a wait) per range and chunk
 #pragma unroll
     for (uint32_t r = 0; r < 4; r++) {
       if (r < pl.n_ranges) {
@@ -100,6 +113,15 @@ RJ_HD uint32_t rj_swar_f_to_starts(uint32_t f) {
 RJ_HD uint32_t rj_swar_f_next(uint32_t f, uint32_t carry_in) { return (f << 8) | ((f >> 23) & 0xEu) | carry_in; }
 RJ_HD uint32_t rj_swar_f_last(uint32_t f) { return (f >> 27) & 1u; }  // the flag of start 15
 
+RJ_HD uint32_t rj_rotr(uint32_t x, uint32_t r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(x, x, r);
+#else
+  r &= 31u;
+  return r ? (x >> r) | (x << (32u - r)) : x;
+#endif
+}
+
 // The first D steps of the 16 starts whose bytes are rows[0..3] (rows[4]: the four bytes after them).
 // All masks in F layout:
 //   *walk     the start is still alive after D + 1 bytes, or passed through a position whose follow set
@@ -107,10 +129,21 @@ RJ_HD uint32_t rj_swar_f_last(uint32_t f) { return (f >> 27) & 1u; }  // the fla
 //   *matched  some prefix of at most D bytes matched; H[g] byte k bit t - 1: start 4g + k matched t bytes.
 //             A start that is not in *walk is decided: its longest match is the highest t.
 //   *in_first (FIRST only) the start's byte can begin a match (DevProgram::loop_first: one first position)
-template <int D, bool FIRST>
-RJ_HD void rj_swar_presteps(const SwarPlan& pl, const uint32_t (&rows)[5], uint32_t* walk, uint32_t* matched, uint32_t (&H)[4],
-                            uint32_t* in_first) {
+// TWO_LAST: there are two accepting positions (else last_shift[1] == last_shift[0]); GEN: some position has a
+// general follow row (pl.gen != 0) -- wave-uniform facts of the pattern, template parameters so that the steps of
+// the common pattern (one accepting position, shifts and loops only) carry neither.
+// The flag "accepting after t bytes" goes from bit 8k + last to bit 8k + t - 1 of h with ONE rotation (by
+// last - t + 1 mod 32: the bit stays in its byte whichever way it moves) and one and-or.
+template <int D, bool FIRST, bool TWO_LAST, bool GEN>
+RJ_HD void rj_swar_presteps_as(const SwarPlan& pl, const uint32_t (&rows)[5], uint32_t* walk, uint32_t* matched, uint32_t (&H)[4],
+                               uint32_t* in_first) {
   uint32_t w = 0, m = 0, inf = 0;
+  uint32_t rot0[D], rot1[D];
+#pragma unroll
+  for (int t = 1; t <= D; t++) {
+    rot0[t - 1] = (pl.last_shift[0] + 33u - static_cast<uint32_t>(t)) & 31u;
+    rot1[t - 1] = (pl.last_shift[1] + 33u - static_cast<uint32_t>(t)) & 31u;
+  }
 #pragma unroll
   for (int g = 0; g < 4; g++) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -123,18 +156,26 @@ RJ_HD void rj_swar_presteps(const SwarPlan& pl, const uint32_t (&rows)[5], uint3
     uint32_t gen = 0, h = 0;
 #pragma unroll
     for (int t = 1; t <= D; t++) {
-      h |= (((S >> pl.last_shift[0]) | (S >> pl.last_shift[1])) & 0x01010101u) << (t - 1);
-      gen |= S & pl.gen;
+      h |= rj_rotr(S, rot0[t - 1]) & (0x01010101u << (t - 1));
+      if (TWO_LAST) h |= rj_rotr(S, rot1[t - 1]) & (0x01010101u << (t - 1));
+      if (GEN) gen |= S & pl.gen;
       const uint32_t rt = t < 4 ? rj_alignbyte(rows[g + 1], rows[g], t) : rows[g + 1];
       S = (((S & pl.step1) << 1) | (S & pl.loopm)) & rt;
     }
-    w |= (rj_swar_nz(S | gen) >> 7) << g;
+    w |= (rj_swar_nz(GEN ? (S | gen) : S) >> 7) << g;
     m |= (((h + 0x7f7f7f7fu) & 0x80808080u) >> 7) << g;  // (h < 0x10 in every byte)
     H[g] = h;
   }
   *walk = w;
   *matched = m;
   *in_first = inf;
+}
+
+template <int D, bool FIRST>
+RJ_HD void rj_swar_presteps(const SwarPlan& pl, const uint32_t (&rows)[5], uint32_t* walk, uint32_t* matched, uint32_t (&H)[4],
+                            uint32_t* in_first) {
+  if (pl.last_shift[0] == pl.last_shift[1] && pl.gen == 0) rj_swar_presteps_as<D, FIRST, false, false>(pl, rows, walk, matched, H, in_first);
+  else rj_swar_presteps_as<D, FIRST, true, true>(pl, rows, walk, matched, H, in_first);
 }
 
 }  // namespace rejit_amd

@@ -2512,21 +2512,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   uint4 pre_v = make_uint4(0, 0, 0, 0);
   unsigned long long pre_flag = 0;
   bool pre_valid = false;  // (wave-uniform)
+  // packed pre-steps of `X+...`: is the last byte of the span's chunk tail_it - 1 in X (both wave-uniform)
+  uint32_t tail_in_x = 0;
+  uint32_t tail_it = ~0u;
   // (a relaxed atomic load at device scope: fresh data, but -- unlike a volatile access -- nothing to wait for
   // until the value is used, an iteration later)
   auto load_flag = [&]() { return __hip_atomic_load(counters + kCntOverrun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  for (uint64_t c = span.c0; c < span.c1; c++) {
+  // The loop's wave-uniform tests as 32-bit chunk counts relative to the span: a 64-bit ordering of two uniform
+  // values has no scalar instruction -- the compiler copies both to vector registers and compares there, three VALU
+  // instructions apiece in a kernel that is bound by exactly those.
+  const uint32_t n_iter = static_cast<uint32_t>(span.c1 - span.c0);
+  auto rel = [&](uint64_t chunk) -> uint32_t {
+    return chunk <= span.c0 ? 0u : (chunk - span.c0 >= n_iter ? n_iter : static_cast<uint32_t>(chunk - span.c0));
+  };
+  const uint64_t own_lim = a.se < a.n ? a.se : a.n;
+  const uint32_t full_until = rel(a.n / kChunk);                       // [0, full_until): base + kChunk <= n
+  const uint32_t plus4_until = rel(a.n >= 4 ? (a.n - 4) / kChunk : 0);  // base + kChunk + 4 <= n
+  const uint32_t clip_below = rel((a.sb + kChunk - 1) / kChunk);       // base < sb
+  const uint32_t clip_from = rel(own_lim / kChunk);                    // base + kChunk > min(se, n)
+  for (uint32_t it = 0; it < n_iter; it++) {
+    const uint64_t c = span.c0 + it;
     const uint64_t base = c * kChunk;
     const uint64_t at = base + static_cast<uint64_t>(lane) * 16;
     const uint8_t* tbase = a.text + base;
-    const bool full = base + kChunk <= a.n;
+    const bool full = it < full_until;
     uint4 v = pre_v;
     unsigned long long stop = pre_flag;
     if (!pre_valid) {
       stop = load_flag();
       if (full) v = *reinterpret_cast<const uint4*>(a.text + at);
     }
-    pre_valid = c + 1 < span.c1 && base + 2 * kChunk <= a.n;
+    pre_valid = it + 1 < full_until;  // (the next chunk belongs to the span and lies inside the text)
     if (pre_valid) {
       pre_v = *reinterpret_cast<const uint4*>(a.text + at + kChunk);
       pre_flag = load_flag();
@@ -2546,7 +2562,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     uint32_t cand = 0;
     uint32_t fin = 0, flen = 0;  // starts already decided by the pre-steps, 2 bits of length each
     uint32_t Hs[4] = {0, 0, 0, 0};  // packed pre-steps: per start the lengths that matched (dense_swar.h)
-    const bool packed = PD > 0 && base + kChunk + 4 <= a.n;  // (wave-uniform)
+    const bool packed = PD > 0 && it < plus4_until;  // (wave-uniform)
     if (packed) {
       // Pre-steps, four starts per register (dense_swar.h): class rows by byte-parallel range tests, the
       // first `depth` automaton steps of all 16 starts, no lookups and no divergence.  A start that is
@@ -2560,8 +2576,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       else rj_swar_presteps<(PD > 0 ? PD : 1), false>(P.swar, rows, &walk, &matched, Hs, &in_x);
       fin = matched & ~walk;
       cand = walk | fin;
-      const uint64_t lim = a.se < a.n ? a.se : a.n;
-      if (at < a.sb || at + 16 > lim) {  // the ends of the own range
+      const uint64_t lim = own_lim;
+      if (it < clip_below || it >= clip_from) {  // the chunks at the ends of the own range (a scalar test)
         const uint32_t hi = lim > at ? (lim - at < 16 ? static_cast<uint32_t>(lim - at) : 16u) : 0u;
         const uint32_t lo = a.sb > at ? (a.sb - at < 16 ? static_cast<uint32_t>(a.sb - at) : 16u) : 0u;
         const uint32_t range = rj_swar_f_from_starts(((1u << hi) - 1u) & ~((1u << lo) - 1u));
@@ -2569,12 +2585,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         cand &= range;
       }
       if (P.loop_first) {
-        // `X+...`: a start whose previous byte is in X too is never selected (see DevProgram::loop_first)
+        // `X+...`: a start whose previous byte is in X too is never selected (see DevProgram::loop_first).  The byte
+        // before the chunk: the last lane's flag of the chunk before, when this wave has just been through it --
+        // else one byte from the text
         uint32_t prev_in = wave_from_lane_below(rj_swar_f_last(in_x));
-        if (lane == 0) prev_in = base > 0 ? ((fb[a.text[base - 1] >> 5] >> (a.text[base - 1] & 31)) & 1u) : 0u;
+        uint32_t before = tail_in_x;
+        if (tail_it != it) before = base > 0 ? ((fb[a.text[base - 1] >> 5] >> (a.text[base - 1] & 31)) & 1u) : 0u;
+        if (lane == 0) prev_in = before;
         cand &= ~rj_swar_f_next(in_x, prev_in);
+        tail_in_x = wave_last_lane(rj_swar_f_last(in_x));
+        tail_it = it + 1;
       }
-    } else if (PD == 0 && NW == 1 && !CTX && P.nullable == 0 && base + kChunk + 4 <= a.n) {
+    } else if (PD == 0 && NW == 1 && !CTX && P.nullable == 0 && it < plus4_until) {
       // Pre-steps: the first kPre automaton steps of ALL 16 starts of the lane, in registers, with
       // no divergence.  Most starts die within a few bytes (a walk on random text is ~1.5 steps
       // long), and those never reach the walkers: a start that is dead after kPre + 1 bytes is
