@@ -39,6 +39,7 @@ def test_one_rank_rccl_communicator():
     assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
     rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
     assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    ctypes.CDLL(None).fflush(None)   # (RCCL's version banner sits in C stdio's buffer: out now, inside this test's capture, not at exit)
     try:
         rng = random.Random(3)
         text = bytes(rng.choices(b"acgt", k=400_000)) + b"agggtaaa" * 3 + b"tttaccct"
