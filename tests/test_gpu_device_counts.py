@@ -54,6 +54,7 @@ def test_one_rank_rccl_communicator():
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
+        ctypes.CDLL(None).fflush(None)
 
 
 @pytest.mark.parametrize("world", [2, 3, 5])
