@@ -421,28 +421,53 @@ class Automaton {
   // most `target` remain; returns the number of wildcards introduced, or -1
   static int merge_patterns(std::vector<Pattern>* ps, int len, size_t target) {
     int wilds = 0;
+    // 0: keep both, 1: the same pattern twice, 2: merge j into i
+    const auto verdict = [&](size_t i, size_t j, int max_dist) {
+      const int dist = distance((*ps)[i], (*ps)[j], len);
+      if (dist == 0) return 1;
+      return dist <= max_dist && fixed_after_merge((*ps)[i], (*ps)[j], len) >= std::max(1, len - 2) ? 2 : 0;
+    };
     // distance-1 merges are always worth it (one class position)
+    //
+    // The rule: take the FIRST pair (i, j), i < j, in lexicographic order that can be merged, merge it, start
+    // again -- until nothing merges (or, at distance 2, until `target` is reached).  Starting again from (0, 1)
+    // made this cubic: 256 patterns ([ab]{8}) at 40 window offsets were half a second of compile time.  After a
+    // merge at (i, j) the only pairs before (i, j) whose answer can have changed are (a, i), a < i -- every other
+    // one holds the same two patterns as when it was refused -- so the next first pair is the smallest such a,
+    // else whatever a scan resumed at (i, i + 1) finds.  Same merges in the same order, quadratic.
     for (int max_dist = 1; max_dist <= 2; max_dist++) {
-      bool merged = true;
-      while (merged && (max_dist == 1 || ps->size() > target)) {
-        merged = false;
-        for (size_t i = 0; i < ps->size() && !merged; i++)
-          for (size_t j = i + 1; j < ps->size() && !merged; j++) {
-            int dist = distance((*ps)[i], (*ps)[j], len);
-            if (dist == 0) {
-              ps->erase(ps->begin() + static_cast<long>(j));
-              merged = true;
-            } else if (dist <= max_dist && fixed_after_merge((*ps)[i], (*ps)[j], len) >= std::max(1, len - 2)) {
-              for (int k = 0; k < len; k++)
-                if ((*ps)[i].wild[k] != (*ps)[j].wild[k] || (*ps)[i].byte[k] != (*ps)[j].byte[k]) {
-                  if (!(*ps)[i].wild[k]) wilds++;
-                  (*ps)[i].wild[k] = true;
-                  (*ps)[i].byte[k] = 0;
-                }
-              ps->erase(ps->begin() + static_cast<long>(j));
-              merged = true;
-            }
+      size_t i = 0, j = 1;  // the scan resumes here
+      while (max_dist == 1 || ps->size() > target) {
+        int what = 0;
+        for (; i < ps->size(); i++, j = i + 1) {
+          for (; j < ps->size(); j++)
+            if ((what = verdict(i, j, max_dist)) != 0) break;
+          if (what != 0) break;
+        }
+        if (what == 0) break;
+        for (;;) {
+          if (what == 2) {
+            for (int k = 0; k < len; k++)
+              if ((*ps)[i].wild[k] != (*ps)[j].wild[k] || (*ps)[i].byte[k] != (*ps)[j].byte[k]) {
+                if (!(*ps)[i].wild[k]) wilds++;
+                (*ps)[i].wild[k] = true;
+                (*ps)[i].byte[k] = 0;
+              }
           }
+          ps->erase(ps->begin() + static_cast<long>(j));
+          if (what == 1) break;  // (pattern i is what it was: no earlier pair has changed)
+          if (!(max_dist == 1 || ps->size() > target)) break;
+          // pattern i changed: an earlier pattern may merge with it now
+          what = 0;
+          for (size_t a = 0; a < i; a++)
+            if ((what = verdict(a, i, max_dist)) != 0) {
+              j = i;
+              i = a;
+              break;
+            }
+          if (what == 0) break;
+        }
+        j = what == 1 ? j : i + 1;  // a duplicate removed: go on where the scan was; else pattern i meets everyone again
       }
     }
     return ps->size() <= target ? wilds : -1;
@@ -704,18 +729,27 @@ class Automaton {
       if (found->size() > kMaxEnumerated) *overflow = true;
       return;
     }
-    std::vector<std::pair<int, Bits>> branches;
-    for (int b = 0; b < 256; b++) {
+    // the byte values some position of the level consumes (no set is built for the others, nor for any once there
+    // are more than 16: this loop was most of the compile time of patterns with wide repetitions)
+    int values[17];
+    size_t n_values = 0;
+    for (int b = 0; b < 256 && n_values <= 16; b++) {
       const uint32_t* row = &p_->cls[static_cast<size_t>(b) * W_];
-      Bits hit(W_);
-      bool any = false;
-      for (int k = 0; k < W_; k++) {
-        hit.w[static_cast<size_t>(k)] = level.w[static_cast<size_t>(k)] & row[k];
-        any |= hit.w[static_cast<size_t>(k)] != 0;
-      }
-      if (any) branches.emplace_back(b, std::move(hit));
+      uint32_t any = 0;
+      for (int k = 0; k < W_; k++) any |= level.w[static_cast<size_t>(k)] & row[k];
+      if (any) values[n_values++] = b;
     }
-    if (branches.size() > 16) {  // a wide class ('.', [a-z], ...): do not split on it
+    std::vector<std::pair<int, Bits>> branches;
+    if (n_values <= 16) {
+      branches.reserve(n_values);
+      for (size_t v = 0; v < n_values; v++) {
+        const uint32_t* row = &p_->cls[static_cast<size_t>(values[v]) * W_];
+        Bits hit(W_);
+        for (int k = 0; k < W_; k++) hit.w[static_cast<size_t>(k)] = level.w[static_cast<size_t>(k)] & row[k];
+        branches.emplace_back(values[v], std::move(hit));
+      }
+    }
+    if (n_values > 16) {  // a wide class ('.', [a-z], ...): do not split on it
       cur->byte[depth] = 0;
       cur->wild[depth] = true;
       Bits next = depth + 1 < len ? step_any(level) : level;

@@ -193,3 +193,16 @@ def test_run_start_rule_is_sound(pe):
             for _ in range(40):
                 tx = bytes(rng.choice(alphabet) for _ in range(rng.choice([7, 30, 120])))
                 assert match_all(pe, rx, tx) == oracle.match_all_spec(rx, tx), (rx, tx)
+
+
+def test_compile_time_of_wide_repetitions(pe):
+    """The window search merges candidate strings pairwise; done naively that was cubic and `[ab]{30,40}cd` took half a
+    second to compile ([ab]{8} = 256 strings at 40 window offsets).  Generous bounds: the point is the order of growth."""
+    import time
+    for rx, limit in ((b"[ab]{30,40}cd", 0.25), (b"[ab]{100}", 0.4), (b"([complex]|(regexp)){2,7}abcdefgh(at|the|[e-nd]as well)", 0.1),
+                      (b"[acgt]{12}x", 0.25)):
+        t0 = time.perf_counter()
+        p = plan(pe, rx)
+        dt = time.perf_counter() - t0
+        assert dt < limit, (rx, dt)
+        assert p["n_pos"] > 0
