@@ -296,7 +296,18 @@ class Automaton {
   Closure closure(int q, int ctx) {
     Closure c;
     std::vector<int> stack{q};
-    std::set<int> seen{q};
+    // (visited marks by epoch: a std::set here was 40 % of the compile time of automata with thousands of states)
+    if (mark_.size() != static_cast<size_t>(g_.n_states)) mark_.assign(static_cast<size_t>(g_.n_states), 0u);
+    if (++mark_epoch_ == 0) {
+      std::fill(mark_.begin(), mark_.end(), 0u);
+      mark_epoch_ = 1;
+    }
+    const auto first_visit = [&](int st) {
+      if (mark_[static_cast<size_t>(st)] == mark_epoch_) return false;
+      mark_[static_cast<size_t>(st)] = mark_epoch_;
+      return true;
+    };
+    first_visit(q);
     while (!stack.empty()) {
       int s = stack.back();
       stack.pop_back();
@@ -305,7 +316,7 @@ class Automaton {
       for (const ControlEdge* e : ctrl_[static_cast<size_t>(s)]) {
         bool ok = e->kind == ControlKind::Epsilon || (e->kind == ControlKind::StartOfLine && (ctx & 1)) ||
                   (e->kind == ControlKind::EndOfLine && (ctx & 2));
-        if (ok && seen.insert(e->dst).second) stack.push_back(e->dst);
+        if (ok && first_visit(e->dst)) stack.push_back(e->dst);
       }
     }
     return c;
@@ -332,7 +343,15 @@ class Automaton {
 
   Bits step_any(const Bits& s) const {
     Bits out(W_);
-    s.for_each([&](int i) { out |= follow_any(i); });
+    s.for_each([&](int i) {  // out |= follow_any(i), without a set per position
+      if ((p_->linear[static_cast<size_t>(i) >> 5] >> (i & 31)) & 1u) {
+        out.set(i + 1);
+        return;
+      }
+      const int r = p_->row_of[static_cast<size_t>(i)];
+      for (int ctx = 0; ctx < kNumCtx; ctx++)
+        for (int k = 0; k < W_; k++) out.w[static_cast<size_t>(k)] |= p_->rows[ctx][static_cast<size_t>(r) * W_ + k];
+    });
     return out;
   }
 
@@ -483,13 +502,25 @@ class Automaton {
     int best_fixed = -1;  // exact (non-wildcard) bytes of the weakest window
     uint64_t best_d = 0;
     Bits level = first_any;
+    std::vector<Pattern> last_raw, last_merged;
+    bool last_ok = false;
     for (uint64_t d = 0; d <= max_d; d++) {
       std::vector<Pattern> ps;
       Pattern cur{};
       bool overflow = false;
       enumerate(level, 0, wl, &cur, &ps, &overflow);
       if (!overflow && !ps.empty()) {
-        if (merge_patterns(&ps, wl, kMaxWindows) >= 0) {
+        // (a repetition offers the same strings at one offset after the other: merge them once)
+        const bool same = ps.size() == last_raw.size() &&
+                          std::memcmp(ps.data(), last_raw.data(), ps.size() * sizeof(Pattern)) == 0;
+        if (same) {
+          ps = last_merged;
+        } else {
+          last_raw = ps;
+          last_ok = merge_patterns(&ps, wl, kMaxWindows) >= 0;
+          last_merged = ps;
+        }
+        if (last_ok) {
           int weakest = wl;
           for (const Pattern& pt : ps) {
             int fixed = 0;
@@ -836,6 +867,8 @@ class Automaton {
   const Graph& g_;
   Program* p_;
   int P_ = 0, W_ = 1;
+  std::vector<uint32_t> mark_;  // closure(): visited marks
+  uint32_t mark_epoch_ = 0;
   std::vector<int> edge_first_;
   std::vector<std::vector<int>> out_edges_;
   std::vector<std::vector<const ControlEdge*>> ctrl_;
