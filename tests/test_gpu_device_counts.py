@@ -122,3 +122,29 @@ def test_shards_on_one_device_over_a_callers_all_gather(world):
     for i, p in enumerate(patterns):
         joined = [s for rank in range(world) for s in results[rank][1][i]]
         assert joined == o.match_all(p, text), p
+
+
+def test_native_sample_over_every_gpu_of_the_node(tmp_path):
+    """samples/regexdna_rccl.cc: one process, a thread + shard + RCCL rank per visible device (here: one), the exchange
+    behind rj_multi_device_counts -- its nine count lines against the oracle over the stripped sequence."""
+    import os
+    import subprocess
+    import rejit_amd
+    from rejit_amd import workloads as W
+    from checkers import Oracle
+    rejit_amd.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "samples"), "rccl"], stdout=subprocess.DEVNULL)
+    nf = 300000
+    raw = W.fasta_raw_numpy(nf).tobytes()
+    seq = W.fasta_stripped_numpy(nf).tobytes()
+    r = subprocess.run([os.path.join(root, "samples", "regexdna_rccl")], input=raw, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = r.stdout.decode().splitlines()
+    o = Oracle()
+    pats = [rx for rx in lines if "|" in rx]
+    assert len(pats) == 9
+    for line in pats:
+        rx, cnt = line.rsplit(" ", 1)
+        assert int(cnt) == len(o.match_all(rx.encode(), seq)), line
+    assert lines[-2:] == [str(len(raw)), str(len(seq))]
