@@ -92,7 +92,8 @@ class Regej {
   Status last_status_;
 };
 
-// One-shot helpers: each builds a temporary Regej (there is no compiled-pattern cache).
+// One-shot helpers.  The reference builds a temporary Regej per call (no cache, its include/rejit.h:48-50); here the 32
+// most recent patterns stay compiled (a compile also fills device tables) -- same results, the second call is cheap.
 bool MatchFull(const char* regexp, const string& text);
 bool MatchFull(const char* regexp, const char* text, size_t text_size);
 bool MatchAnywhere(const char* regexp, const string& text);
