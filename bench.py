@@ -43,6 +43,7 @@ classify_shared_multi + offsets_gather_check_multi, one synchronise).  Besides t
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -80,6 +81,7 @@ def parse_args():
     ap.add_argument("--jrep-files", type=int, default=100_000, help="jrep_10gb extra: files (BASELINE configs[4]: 100 000)")
     ap.add_argument("--jrep-bytes", type=int, default=10_000_000_000, help="jrep_10gb extra: total bytes (BASELINE configs[4]: 10 GB)")
     ap.add_argument("--no-extra", action="store_true", help="headline only")
+    ap.add_argument("--tail-streams-probe", action="store_true", help="internal: the child process of the tails_on_own_streams extra")
     ap.add_argument("--no-big", action="store_true", help="skip the 50 GB and 2.5 GB extras")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial-calls", action="store_true", help="headline with nine synchronous rj_scan_run calls per step "
@@ -313,13 +315,17 @@ def run_regexdna(args, c):
     # step k + 1 are already queued, so the device never waits for the host's turn-around (~25 us of a 170 us step).
     # Every step still is one complete pass of the path over the batch with its own result; the synchronous call is
     # reported as `call_latency`.
-    def two_in_flight(own_streams):
+    def two_in_flight(own_streams, tail_streams=False):
         """(step, drain, scan times) of a loop that keeps two steps in flight on two rj_multi objects.  own_streams:
         each object on its own stream, the scan kernels ordered one behind the other (rj_multi_order_after), so that the
-        tails of step k run under the scan of step k + 1."""
+        tails of step k run under the scan of step k + 1.  tail_streams: both objects on ONE stream, but each queues its
+        tails on a stream of its own (rj_multi_set_tail_stream): the scan kernels then follow each other in order on the
+        one stream, with no cross-stream wait between them."""
         multis = [rejit_amd.MultiScan(progs), rejit_amd.MultiScan(progs)]
         for mm in multis:
             mm.set_mode(0)
+            if tail_streams:
+                mm.set_tail_stream(True)
         second = torch.cuda.Stream(dev) if own_streams else None
         streams = [stream, second.cuda_stream if own_streams else stream]
         if own_streams:
@@ -381,6 +387,16 @@ def run_regexdna(args, c):
             return counts
 
     elapsed, counts = timed(c, args, step, drain)
+    if args.tail_streams_probe:
+        # child process of the `tails_on_own_streams` extra (see below): this one variant, one JSON line, nothing else
+        p_step, p_drain, p_times = two_in_flight(False, tail_streams=True)
+        ep, cp = timed(c, args, p_step, p_drain)
+        print(json.dumps({"tail_streams_probe": {"ms_per_step": round(ep / args.steps * 1e3, 4),
+                                                 "value": round(len(patterns) * n_total * args.steps / ep / 1e9, 3), "unit": "GB/s",
+                                                 "scan_kernel_ms": round(sum(p_times) / max(len(p_times), 1), 5),
+                                                 "counts_equal_headline": cp == counts,
+                                                 "headline_ms_per_step_in_this_process": round(elapsed / args.steps * 1e3, 4)}}))
+        return None, False
     total_matches = int(sum(counts))
     scanned = len(patterns) * n_total * args.steps          # bytes of text scanned by the whole job
     avg_scan_ms = sum(scan_ms) / max(len(scan_ms), 1)
@@ -445,6 +461,20 @@ def run_regexdna(args, c):
                                        "ms_per_step": round(eo / args.steps * 1e3, 4),
                                        "value": round(len(patterns) * n_total * args.steps / eo / 1e9, 3), "unit": "GB/s",
                                        "scan_kernel_ms": round(sum(o_times) / max(len(o_times), 1), 5)}
+            # Untested on a GPU when it was written (the round's GPU minutes were spent), hence in a process of its own:
+            # whatever happens there, this process's line is printed.  Both objects on one stream, each with its tails on
+            # a stream of its own (rj_multi_set_tail_stream): scan kernels back to back in order, tails under the next scan.
+            try:
+                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--tail-streams-probe", "--fasta-n", str(args.fasta_n),
+                                        "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-extra", "--no-cpu-baseline"],
+                                       capture_output=True, timeout=240)
+                probe = None
+                for line in child.stdout.decode(errors="replace").splitlines():
+                    if line.startswith('{"tail_streams_probe"'):
+                        probe = json.loads(line)["tail_streams_probe"]
+                out["tails_on_own_streams"] = probe if probe is not None else {"error": "exit %d: %s" % (child.returncode, child.stderr.decode(errors="replace")[-300:])}
+            except Exception as e:  # noqa: BLE001 (an extra must never cost the line)
+                out["tails_on_own_streams"] = {"error": repr(e)[:300]}
         out["synchronous_calls"] = {"calls": "rj_multi_run mode 0, one call after the other (one step in flight): what rounds 1-2 timed",
                                     "ms_per_step": round(ek0 / args.steps * 1e3, 4),
                                     "value": round(len(patterns) * n_total * args.steps / ek0 / 1e9, 3), "unit": "GB/s"}
@@ -1047,6 +1077,8 @@ def main():
     rejit_amd.build()
     if args.workload == "regexdna":
         out, extras = run_regexdna(args, c)
+        if out is None:
+            return
         if extras:
             literal_and_complex_extras(args, c, out)
             if not args.no_big:

@@ -184,6 +184,12 @@ int rj_multi_finish(rj_multi* multi, uint64_t* counts);
  * share the memory system while the latency-bound tails of one run execute under the scan of the other.  before =
  * NULL removes the order.  The objects must outlive each other's runs. */
 int rj_multi_order_after(rj_multi* multi, rj_multi* before);
+/* on != 0: rj_multi_start queues only the scan kernel on the caller's stream and everything behind it (the
+ * latency-bound classify / gather tails) on a stream of the object's own, ordered by the scan kernel's end event.  A
+ * caller that alternates two rj_multi objects on ONE stream then has the HBM-bound scan kernels back to back on that
+ * stream -- in order, no cross-stream wait between them -- while each run's tails execute under the next scan.
+ * rj_multi_finish is unchanged (it waits for the run's last kernel, wherever it is).  Not with mode 2. */
+int rj_multi_set_tail_stream(rj_multi* multi, int on);
 rj_scan* rj_multi_scan(rj_multi* multi, int i);
 /* First and last match of every pattern's result after rj_multi_run / _run_range: bounds[4*i .. 4*i+3] =
  * first begin, first end, last begin, last end (all UINT64_MAX when pattern i has no match).  This is what

@@ -128,7 +128,7 @@ C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_er
                  "rj_multi_scan_ms", "rj_scan_start", "rj_scan_finish", "rj_multi_set_mode", "rj_multi_run_range",
                  "rj_multi_bounds", "rj_batch_separator", "rj_match_all_packed", "rj_host_alloc", "rj_host_free",
                  "rj_multi_bounds_device", "rj_carry_decide", "rj_multi_start", "rj_multi_finish", "rj_multi_order_after",
-                 "rj_multi_device_counts", "rj_multi_device_counts_via"]
+                 "rj_multi_device_counts", "rj_multi_device_counts_via", "rj_multi_set_tail_stream"]
 
 
 def load_library():
@@ -173,6 +173,7 @@ def load_library():
     L.rj_multi_scan_ms.restype = ctypes.c_float
     L.rj_multi_scan_ms.argtypes = [vp]
     L.rj_multi_set_mode.argtypes = [vp, ctypes.c_int]
+    L.rj_multi_set_tail_stream.argtypes = [vp, ctypes.c_int]
     L.rj_multi_bounds.argtypes = [vp, _u64p, vp]
     L.rj_multi_bounds_device.argtypes = [vp, ctypes.c_int64, ctypes.c_int, vp, vp]
     L.rj_carry_decide.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
@@ -428,6 +429,10 @@ class MultiScan:
         keep the device busy while the host turns a result around."""
         _check(self._lib.rj_multi_start(self._h, ctypes.c_void_p(d_text_ptr), n, own_begin, n + 1 if own_end is None else own_end,
                                         ctypes.c_void_p(stream)))
+
+    def set_tail_stream(self, on: bool = True) -> None:
+        """start() queues only the scan kernel on the caller's stream, the tails on a stream of the object's own."""
+        _check(self._lib.rj_multi_set_tail_stream(self._h, int(on)))
 
     def order_after(self, other: Optional["MultiScan"]) -> None:
         """This object's scan kernels wait for the scan kernel of `other`'s run in flight (two objects, two streams)."""

@@ -177,6 +177,9 @@ struct rj_multi {
     hipEvent_t done = nullptr;  // behind the run's last kernel: rj_multi_finish waits for THIS run, not for the stream
   } pending;
   rj_multi* scan_after = nullptr;  // rj_multi_order_after: this object's scan kernel waits for that one's
+  // rj_multi_set_tail_stream: rj_multi_start queues the tails on this stream, behind the scan kernel's end event
+  hipStream_t tail_stream = nullptr;
+  bool tails_own_stream = false;
   // rj_multi_device_counts: this rank's rows [P][8] followed by every rank's [world][P][8]; the decision (pinned)
   DeviceBuffer exchange_rows;
   int64_t* host_decision = nullptr;
@@ -466,6 +469,13 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
         RJ_HIP(hipEventRecord(s0->ev[2], st));  // end of the train: both streams have drained
       }
     }
+    // rj_multi_set_tail_stream: everything behind the scan goes to the object's own stream, ordered by the scan's end
+    // event -- the caller's stream is free for the next scan kernel (of another rj_multi) at once
+    hipStream_t ts = st;
+    if (phase == 1 && m->tails_own_stream && m->tail_stream != nullptr && m->mode != 2) {
+      ts = m->tail_stream;
+      RJ_HIP(hipStreamWaitEvent(ts, s0->ev[2], 0));
+    }
     // the single-pattern tails (verify inside the regions, offsets + gather + check) of all patterns
     // in two launches; their parameters travel as one small array
     for (int p = 0; p < P; p++) {
@@ -494,7 +504,7 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     }
     if (m->uploaded.size() != static_cast<size_t>(P) ||
         memcmp(m->uploaded.data(), m->host_tails, sizeof(MultiTail) * static_cast<size_t>(P)) != 0) {
-      RJ_HIP(hipMemcpyAsync(m->tails.p, m->host_tails, sizeof(MultiTail) * P, hipMemcpyHostToDevice, st));
+      RJ_HIP(hipMemcpyAsync(m->tails.p, m->host_tails, sizeof(MultiTail) * P, hipMemcpyHostToDevice, ts));
       m->uploaded.assign(m->host_tails, m->host_tails + P);
     }
     if (plane) {
@@ -509,7 +519,7 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       sh.n = n;
       sh.sb = sb;
       sh.se = se;
-      int rc = classify_blob(m, st);
+      int rc = classify_blob(m, ts);
       if (rc != RJ_OK) return rc;
       sh.blob = m->classify_blob.as<uint32_t>();
       sh.desc_words = m->desc_words;
@@ -521,17 +531,19 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
         max_words = std::max(max_words, static_cast<int>(D.n_words));
         max_short = std::max(max_short, D.short_max);
       }
-      launch_tails_shared(m->tails.as<MultiTail>(), sh, max_words, max_short, s0->counters.as<unsigned long long>(), st);
+      launch_tails_shared(m->tails.as<MultiTail>(), sh, max_words, max_short, s0->counters.as<unsigned long long>(), ts);
     } else {
-      launch_tails_multi(m->tails.as<MultiTail>(), P, geo.n_regions, st);
+      launch_tails_multi(m->tails.as<MultiTail>(), P, geo.n_regions, ts);
+    }
+    if (phase == 1) {
+      if (!m->pending.done) RJ_HIP(hipEventCreateWithFlags(&m->pending.done, hipEventDisableTiming));
+      RJ_HIP(hipEventRecord(m->pending.done, ts));
     }
    }
     if (phase == 1) {
       m->pending.caps = caps;
       m->pending.shared_cap = shared_cap;
-      if (!m->pending.done) RJ_HIP(hipEventCreateWithFlags(&m->pending.done, hipEventDisableTiming));
-      RJ_HIP(hipEventRecord(m->pending.done, st));
-      return RJ_OK;
+      return RJ_OK;  // (pending.done was recorded behind the tails, on the stream that holds them)
     }
     // (phase 2: the stream may already hold the NEXT run of another rj_multi -- wait for this one only)
     if (phase == 2 && attempt == 0) RJ_HIP(hipEventSynchronize(m->pending.done));
@@ -648,6 +660,7 @@ void rj_multi_destroy(rj_multi* m) {
   if (m->join) (void)hipEventDestroy(m->join);
   if (m->pending.done) (void)hipEventDestroy(m->pending.done);
   if (m->host_decision) (void)hipHostFree(m->host_decision);
+  if (m->tail_stream) (void)hipStreamDestroy(m->tail_stream);
   delete m;
 }
 
@@ -869,6 +882,15 @@ int rj_multi_device_counts(rj_multi* m, const void* d_text, uint64_t n, uint64_t
   if (!rccl_comm) return fail(RJ_BAD_ARGUMENT, "rj_multi_device_counts: no communicator");
   if (!rccl_all_gather()) return fail(RJ_DEVICE_ERROR, "rj_multi_device_counts: librccl.so not found (set RJ_RCCL_LIBRARY)");
   return rj_multi_device_counts_via(m, d_text, n, own_begin, own_end, offset, rccl_gather, rccl_comm, rank, world, counts, hip_stream);
+}
+
+int rj_multi_set_tail_stream(rj_multi* m, int on) {
+  ErrnoGuard errno_guard;
+  if (!m) return fail(RJ_BAD_ARGUMENT, "null argument");
+  if (m->pending.active) return fail(RJ_BAD_ARGUMENT, "rj_multi_set_tail_stream: a run is in flight");
+  if (on && !m->tail_stream) RJ_HIP(hipStreamCreateWithFlags(&m->tail_stream, hipStreamNonBlocking));
+  m->tails_own_stream = on != 0;
+  return RJ_OK;
 }
 
 int rj_multi_set_mode(rj_multi* m, int mode) {
