@@ -17,6 +17,7 @@ FUSED_VALU_OPS_PER_BYTE = 15.5
 # 500 MB launch x 64 lanes / 5e8 bytes (profiles/r03_pmc_sq_counters.txt) -- 4.2 in the streaming loop (135 per
 # 2-KiB pair and wave), the rest appends the candidates (about four pairs in five hold one on DNA)
 PLANE_VALU_OPS_PER_BYTE = 5.56
-# scan_dense_walk<1,false,4> on `[a-f]+[0-9]` over random ASCII: SQ_INSTS_VALU 2.233e9 wave instructions per 5 GB launch
-# x 64 lanes / 5e9 bytes (profiles/r02_pmc_sq_counters.txt); 59 before the lane-packed pre-steps
-DENSE_VALU_OPS_PER_BYTE = 28.6
+# scan_dense_walk<1,false,4> on `[a-f]+[0-9]` over random ASCII: SQ_INSTS_VALU 1.835e9 wave instructions per 5 GB launch
+# x 64 lanes / 5e9 bytes (profiles/r03_pmc_sq_counters.txt); 28.6 before round 3's instruction diet, 59 before the
+# lane-packed pre-steps
+DENSE_VALU_OPS_PER_BYTE = 23.5
