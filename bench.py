@@ -691,6 +691,32 @@ def literal_and_complex_extras(args, c, out):
         "literal 'regexp' MatchAll over %d bytes random ASCII ['0','z'), %d planted (BASELINE configs[1])" % (n, len(offs)),
         "scan_windows<1>", max(5, min(args.steps, 20)), check_literal, "literal", True, args)
 
+    # The same literal scan with two calls in flight (rj_scan_start / rj_scan_finish on two rj_scan objects: the scan
+    # kernel on the caller's stream, the latency-bound tail on the scan's own): the whole-call rate when the caller has
+    # the next text ready -- what a reader thread feeding a scanner does.  Guarded: an extra must never cost the line.
+    try:
+        prog_p = rejit_amd.Program("regexp")
+        pair = [rejit_amd.Scan(prog_p), rejit_amd.Scan(prog_p)]
+        want_p = [sc.run(t.data_ptr(), n, stream=c.stream) for sc in pair][0]
+        calls_p = 20
+        torch.cuda.synchronize(dev)
+        t0p = time.perf_counter()
+        pair[0].start(t.data_ptr(), n, stream=c.stream)
+        got_p = []
+        for k in range(1, calls_p):
+            pair[k & 1].start(t.data_ptr(), n, stream=c.stream)
+            got_p.append(pair[(k - 1) & 1].finish())
+        got_p.append(pair[(calls_p - 1) & 1].finish())
+        torch.cuda.synchronize(dev)
+        dtp = (time.perf_counter() - t0p) / calls_p
+        out["literal_scan"]["two_in_flight"] = {"calls": "rj_scan_start / rj_scan_finish, two rj_scan objects, %d calls" % calls_p,
+                                                "ms_per_call": round(dtp * 1e3, 4), "value": round(n / dtp / 1e9, 1), "unit": "GB/s",
+                                                "frac_of_hbm_peak": round(n / dtp / 1e9 / HBM_PEAK_GBS, 4),
+                                                "counts_equal": all(g == want_p for g in got_p)}
+        del pair, prog_p
+    except Exception as e:  # noqa: BLE001
+        out["literal_scan"]["two_in_flight"] = {"error": repr(e)[:300]}
+
     # BASELINE configs[3] shape on one GPU: the complex benchmark regex (floating fast-forward window
     # `abcdefgh`) over the same text with strings of its language planted
     rx = W.BENCH_REGEXES[3][0]
