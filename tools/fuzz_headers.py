@@ -7,7 +7,9 @@
   swar   dense_swar.h against the scalar automaton, rj_lane_longest_short against rj_lane_longest, random patterns
          (round 2: 6600 + 6500 plans, 0 mismatches)
 
-usage: fuzz_headers.py exact|swar [seed] [cases]"""
+  lds    lds_walk.h against the walkers it replaces (device_program.h, behind_walk.h), random patterns
+
+usage: fuzz_headers.py exact|swar|lds [seed] [cases]"""
 import ctypes, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -88,4 +90,36 @@ def fuzz_swar():
 
 
 
-(fuzz_exact if mode == "exact" else fuzz_swar)()
+def fuzz_lds():
+    """lds_walk.h (what verify_lds.hip walks in LDS: padded tables, rows by position, text through block / lane / wave
+    windows with guard bytes) against device_program.h / behind_walk.h on random patterns: longest match from every
+    start, forward check and backward walk from every (text position, automaton position), behind candidates."""
+    from checkers import Oracle
+    from make_golden import RegexGen, ALPHABETS
+    o = Oracle()
+    lib = ctypes.CDLL(SO)
+    lib.ce_lds_walk_check.restype = ctypes.c_long
+    lib.ce_lds_walk_check.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+    seed = int(sys.argv[1]); N = int(sys.argv[2]); rng = random.Random(seed)
+    ALPH = ALPHABETS + ["ab\n\r", "abcdefgh12 \n"]
+    used = bad = 0; total = 0; t0 = time.time()
+    for it in range(N):
+        alphabet = rng.choice(ALPH)
+        rx = RegexGen(rng, alphabet).alt(3)
+        if rng.random() < 0.4:
+            rx = rng.choice(["", ".*", "[a-z]+", "^"]) + rx + rng.choice(["", "{2,5}", "+", "abc", "$"])
+        rx = rx.encode("latin1")
+        if b"\0" in rx or o.status(rx) != 0: continue
+        tx = "".join(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 17, 48, 130]))).encode("latin1")
+        for walk in (1 << 20, rng.choice([3, 7, 19])):
+            c = ctypes.c_uint64(0)
+            r = lib.ce_lds_walk_check(rx, tx, len(tx), walk, ctypes.byref(c))
+            if r < 0: break           # (the pattern does not take these walkers: > 4 words, or no tables)
+            used += 1; total += c.value
+            if r != 0:
+                print("LDS WALK MISMATCH", rx, tx, walk, r); bad += 1
+        if bad > 5: break
+    print(f"seed {seed}: lds-walk runs {used}, comparisons {total}, mismatches {bad}, {time.time()-t0:.0f}s")
+
+
+{"exact": fuzz_exact, "swar": fuzz_swar, "lds": fuzz_lds}[mode]()
