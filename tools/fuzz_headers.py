@@ -9,7 +9,9 @@
 
   lds    lds_walk.h against the walkers it replaces (device_program.h, behind_walk.h), random patterns
 
-usage: fuzz_headers.py exact|swar|lds [seed] [cases]"""
+  carry  carry_scan.h against the oracle's documented semantics, whole texts and two ranges with the carry over a cut
+
+usage: fuzz_headers.py exact|swar|lds|carry [seed] [cases]"""
 import ctypes, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -122,4 +124,50 @@ def fuzz_lds():
     print(f"seed {seed}: lds-walk runs {used}, comparisons {total}, mismatches {bad}, {time.time()-t0:.0f}s")
 
 
-{"exact": fuzz_exact, "swar": fuzz_swar, "lds": fuzz_lds}[mode]()
+def fuzz_carry():
+    """carry_scan.h (the linear-time matcher) against the oracle's documented semantics on random patterns: whole texts
+    with random sub-chunk sizes, and two ranges with the selection state carried over a random cut."""
+    from checkers import Oracle
+    from make_golden import RegexGen, ALPHABETS
+    o = Oracle()
+    lib = ctypes.CDLL(SO)
+    _u64p = ctypes.POINTER(ctypes.c_uint64)
+    lib.ce_match_range.restype = ctypes.c_long
+    lib.ce_match_range.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                   ctypes.c_uint64, ctypes.c_int, _u64p, ctypes.c_uint64]
+    def carry(rx, tx, sub, sb=0, se=None, cur=0, prev_end=0, have=False):
+        se = len(tx) + 1 if se is None else se
+        cap = len(tx) + 2; buf = (ctypes.c_uint64 * (2 * cap))()
+        n = lib.ce_match_range(rx, tx, len(tx), sub, sb, se, cur, prev_end, int(have), buf, cap)
+        return int(n) if n < 0 else [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n)]
+    seed = int(sys.argv[1]); N = int(sys.argv[2]); rng = random.Random(seed)
+    ALPH = ALPHABETS + ["ab\n\r", "xyz ^$", "acgt"]
+    used = bad = 0; t0 = time.time()
+    for it in range(N):
+        alphabet = rng.choice(ALPH)
+        rx = RegexGen(rng, alphabet).alt(3)
+        if rng.random() < 0.3:
+            rx = rng.choice(["", ".*", "[a-z]+"]) + rx + rng.choice(["", "+", "*", "{2,}"])
+        rx = rx.encode("latin1")
+        if b"\0" in rx or o.status(rx) != 0: continue
+        tx = "".join(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 9, 70, 300, 900]))).encode("latin1")
+        spec = o.match_all_spec(rx, tx)
+        if isinstance(spec, int): continue
+        got = carry(rx, tx, rng.choice([1, 3, 16, 64, 4096]))
+        if isinstance(got, int): continue      # (wider than the driver's limit)
+        used += 1
+        ok = got == spec
+        if ok and len(tx) > 1:
+            cut = rng.randrange(1, len(tx) + 1)
+            first = carry(rx, tx, 32, 0, cut)
+            state = (0, 0, False)
+            if first:
+                b, e = first[-1]; state = (e if e > b else b + 1, e, True)
+            ok = first + carry(rx, tx, 32, cut, len(tx) + 1, *state) == spec
+        if not ok:
+            print("CARRY MISMATCH", rx, tx[:60]); bad += 1
+            if bad > 5: break
+    print(f"seed {seed}: carry-scan cases {used}, mismatches {bad}, {time.time()-t0:.0f}s")
+
+
+{"exact": fuzz_exact, "swar": fuzz_swar, "lds": fuzz_lds, "carry": fuzz_carry}[mode]()
