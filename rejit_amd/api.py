@@ -197,6 +197,13 @@ def load_library():
     L.rj_scan_replace.restype = i64
     L.rj_scan_replace.argtypes = [vp, vp, u64, cp, u64, vp, u64, vp]
     L.rj_device_count.restype = ctypes.c_int
+    L.rj_batch_separator.restype = ctypes.c_int
+    L.rj_batch_separator.argtypes = [vp]
+    L.rj_match_all_packed.restype = i64
+    L.rj_match_all_packed.argtypes = [vp, vp, _u64p, ctypes.POINTER(sz), sz, u64, _u64p, ctypes.POINTER(_u64p)]
+    L.rj_host_alloc.restype = vp
+    L.rj_host_alloc.argtypes = [sz]
+    L.rj_host_free.argtypes = [vp]
     _lib = L
     return L
 
@@ -281,6 +288,29 @@ class Program:
         if total:
             self._lib.rj_free_spans(spans)
         return [int(counts[i]) for i in range(k)]
+
+    def batch_separator(self) -> int:
+        """The byte that ends a text inside a packed batch, or -1 (the pattern is matched text by text)."""
+        return int(self._lib.rj_batch_separator(self._h))
+
+    def match_all_packed(self, buf_ptr: int, offsets: List[int], sizes: List[int], total_bytes: int) -> List[List[Tuple[int, int]]]:
+        """rj_match_all_packed over a buffer the caller laid out (a raw pointer: rj_host_alloc'ed or ordinary memory):
+        per text the spans relative to the text."""
+        k = len(offsets)
+        off = (ctypes.c_uint64 * max(k, 1))(*offsets)
+        sz_ = (ctypes.c_size_t * max(k, 1))(*sizes)
+        counts = (ctypes.c_uint64 * max(k, 1))()
+        spans = _u64p()
+        total = _check(self._lib.rj_match_all_packed(self._h, ctypes.c_void_p(buf_ptr), off, sz_, k, total_bytes, counts, ctypes.byref(spans)))
+        out, at = [], 0
+        for i in range(k):
+            c = int(counts[i])
+            out.append([(int(spans[2 * (at + j)]), int(spans[2 * (at + j) + 1])) for j in range(c)])
+            at += c
+        assert at == total, (at, total)
+        if total:
+            self._lib.rj_free_spans(spans)
+        return out
 
     def count(self, text: bytes) -> int:
         return int(_check(self._lib.rj_match_all(self._h, text, len(text), None)))

@@ -235,7 +235,9 @@ int64_t finish_packed(rj_scan* s, const uint64_t* off, const size_t* sizes, size
   for (uint64_t k = 0; k < m; k++) {
     const uint64_t b = pairs[2 * k], e = pairs[2 * k + 1];
     while (t + 1 < n_texts && b >= off[t + 1]) t++;
-    if (b > off[t] + sizes[t]) continue;  // (an empty match between the separators of a gap: belongs to no text)
+    // an empty match between the separators of a gap -- before the first text (offsets[0] > 0), or behind a text's
+    // own end -- belongs to no text
+    if (b < off[t] || b > off[t] + sizes[t]) continue;
     if (e > off[t] + sizes[t]) return fail(RJ_DEVICE_ERROR, "internal: a match crosses a text boundary in a batch");
     counts[t]++;
     pairs[2 * kept] = b - off[t];

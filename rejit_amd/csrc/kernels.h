@@ -261,6 +261,14 @@ struct SharedHits {
 void launch_tails_shared(const MultiTail* d_tails, const SharedHits& sh, int max_words, uint32_t max_short, unsigned long long* counters0,
                          hipStream_t st);
 void launch_offsets_gather_check_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_regions, hipStream_t st);
+// plane_scan + classify_shared_multi as ONE kernel (plane_scan.hip, round 4): a wave keeps its span's candidates in LDS and
+// classifies them at the end of the span; sh.hits / sh.counts / sh.cap are unused.  The kernel does not clear the
+// counters it may set (kCntOverflow, kCntMaxRegion of every pattern, kCntSharedMax of pattern 0): the caller keeps them
+// zero.  kCntSharedMax != 0 afterwards: a span held more candidates than the LDS slots, the run is void.  Returns
+// false (nothing launched) when the pattern set's shape has no instantiation: then launch_plane_scan + launch_tails_shared.
+constexpr uint32_t kFusedMaxBlobWords = 4096;  // 16 KiB of descriptors + tables per workgroup
+bool launch_plane_scan_classify(const PlaneParams& a, const SharedHits& sh, int max_words, uint32_t max_short, unsigned long long* counters0,
+                                int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 
 // windows mode, lane-sized automaton: verify + compact inside every region (16 lanes each), then
 // offsets_gather_check lays the survivors out

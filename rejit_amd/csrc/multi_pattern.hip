@@ -147,6 +147,11 @@ struct rj_multi {
   PlanePlan plane;             // mode 0: the one-pass bit-plane scan with a shared candidate list
   DeviceBuffer shared_hits, shared_counts;
   uint32_t shared_cap_hint = 128;
+  // round 4: scan + classification in one kernel (plane_scan_classify); off after a run whose span overflowed the
+  // kernel's LDS candidate slots (then the two kernels with shared regions in device memory), or RJ_NO_FUSED_CLASSIFY
+  bool fused_classify = true;
+  bool flags_clean = false;   // the counters that kernel may set but does not clear are zero on the device
+  bool last_was_fused_classify = false;
   // what classify_shared_multi copies into LDS: ClassifyDesc[P] + the patterns' tables (kernels.h)
   DeviceBuffer classify_blob;
   ClassifyDesc* host_desc = nullptr;   // pinned
@@ -187,6 +192,21 @@ struct rj_multi {
 };
 
 namespace {
+
+SharedHits shared_hits_of(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, uint32_t shared_cap, uint32_t n_regions, int P) {
+  SharedHits sh{};
+  sh.hits = m->shared_hits.as<uint64_t>();
+  sh.counts = m->shared_counts.as<uint32_t>();
+  sh.cap = shared_cap;
+  sh.n_regions = n_regions;
+  sh.n_patterns = static_cast<uint32_t>(P);
+  sh.win_offset = m->plane.offset;
+  sh.text = d_text;
+  sh.n = n;
+  sh.sb = sb;
+  sh.se = se;
+  return sh;
+}
 
 // The blob classify_shared_multi stages in LDS (kernels.h): the tables are copied once, device to device; the
 // descriptors hold this run's output pointers and are uploaded when they changed (host_tails is filled already).
@@ -278,10 +298,12 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
   rj_scan* const s0 = m->scans[0];
   std::vector<uint64_t> caps(static_cast<size_t>(P));
   uint32_t shared_cap = 0;
+  bool fused_launched = false;  // this attempt's scan kernel classified its own candidates (plane_scan_classify)
   for (int attempt = 0; attempt < 6; attempt++) {
    if (phase == 2 && attempt == 0) {
     caps = m->pending.caps;
     shared_cap = m->pending.shared_cap;
+    fused_launched = m->last_was_fused_classify;
    } else {
     FusedParams fp{};
     fp.text = d_text;
@@ -360,6 +382,37 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
           }
       }
     }
+    // the single-pattern tails (verify inside the regions, offsets + gather + check) of all patterns
+    // in two launches; their parameters travel as one small array
+    for (int p = 0; p < P; p++) {
+      rj_scan* s = m->scans[static_cast<size_t>(p)];
+      MultiTail& t = m->host_tails[p];
+      t = MultiTail{};
+      t.verify.text = d_text;
+      t.verify.n = n;
+      t.verify.hits = s->hits.as<uint64_t>();
+      t.verify.n_regions = geo.n_regions;
+      t.verify.region_cap = static_cast<uint32_t>(caps[static_cast<size_t>(p)]);
+      t.verify.counters = s->counters.as<unsigned long long>();
+      t.verify.sb = sb;
+      t.verify.se = se;
+      t.verify.expand = 1;
+      t.verify.float_max = s->prog->dev.float_max;
+      t.program = s->prog->dev;
+      t.hit_counts = s->hit_counts.as<uint32_t>();
+      t.valid_counts = s->valid_counts.as<uint32_t>();
+      t.region_ends = s->cand_end.as<uint64_t>();
+      t.out = s->out.as<uint64_t>();
+      t.out_cap = s->out_cap;
+      t.host_counters = s->host_counters;
+      s->host_counters[kCntUnordered] = 0;
+      s->host_counters[kCntAdjacent] = 0;
+    }
+    if (m->uploaded.size() != static_cast<size_t>(P) ||
+        memcmp(m->uploaded.data(), m->host_tails, sizeof(MultiTail) * static_cast<size_t>(P)) != 0) {
+      RJ_HIP(hipMemcpyAsync(m->tails.p, m->host_tails, sizeof(MultiTail) * P, hipMemcpyHostToDevice, st));
+      m->uploaded.assign(m->host_tails, m->host_tails + P);
+    }
     shared_cap = 0;
     if (m->scan_after != nullptr && m->scan_after != m && m->scan_after->scans[0]->ev[2] != nullptr) {
       // two objects on two streams (rj_multi_order_after): the scan kernels -- both HBM-bound -- stay one behind the
@@ -390,7 +443,40 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       pp.hit_counts = m->shared_counts.as<uint32_t>();
       pp.n_zero = static_cast<uint32_t>(P);
       for (int p = 0; p < P; p++) pp.zero_counters[p] = m->scans[static_cast<size_t>(p)]->counters.as<unsigned long long>();
-      launch_plane_scan(pp, geo.grid, s0->ev[1], s0->ev[2], st);
+      // plane_scan_classify (scan + classification in one kernel): correct, but measured no faster than the two kernels
+      // -- its classification is VALU work inside a kernel that is VALU co-limited (scan 99 -> 119 us per 500 MB, step
+      // 0.152 ms either way) -- so it is opt-in (tests run both)
+      static const bool want_fused_classify = getenv("RJ_FUSED_CLASSIFY") != nullptr;
+      fused_launched = false;
+      if (m->fused_classify && want_fused_classify) {
+        const SharedHits sh = shared_hits_of(m, d_text, n, sb, se, 0, geo.n_regions, P);
+        int rc = classify_blob(m, st);
+        if (rc != RJ_OK) return rc;
+        SharedHits shb = sh;
+        shb.blob = m->classify_blob.as<uint32_t>();
+        shb.desc_words = m->desc_words;
+        shb.blob_words = m->blob_words;
+        if (shb.blob_words <= kFusedMaxBlobWords) {
+          if (!m->flags_clean) {
+            for (int p = 0; p < P; p++)
+              RJ_HIP(hipMemsetAsync(m->scans[static_cast<size_t>(p)]->counters.p, 0, kCntSize * sizeof(unsigned long long), st));
+            m->flags_clean = true;
+          }
+          int max_words = 1;
+          uint32_t max_short = 0;
+          for (int p = 0; p < P; p++) {
+            const DevProgram& D = m->scans[static_cast<size_t>(p)]->prog->dev;
+            max_words = std::max(max_words, static_cast<int>(D.n_words));
+            max_short = std::max(max_short, D.short_max);
+          }
+          fused_launched = launch_plane_scan_classify(pp, shb, max_words, max_short, s0->counters.as<unsigned long long>(), geo.grid,
+                                                      s0->ev[1], s0->ev[2], st);
+        }
+      }
+      if (!fused_launched) {
+        m->flags_clean = false;
+        launch_plane_scan(pp, geo.grid, s0->ev[1], s0->ev[2], st);
+      }
     } else if (fuse) {
       launch_scan_windows_fused(fp, geo.grid, s0->ev[1], s0->ev[2], st);
     } else {
@@ -476,49 +562,10 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       ts = m->tail_stream;
       RJ_HIP(hipStreamWaitEvent(ts, s0->ev[2], 0));
     }
-    // the single-pattern tails (verify inside the regions, offsets + gather + check) of all patterns
-    // in two launches; their parameters travel as one small array
-    for (int p = 0; p < P; p++) {
-      rj_scan* s = m->scans[static_cast<size_t>(p)];
-      MultiTail& t = m->host_tails[p];
-      t = MultiTail{};
-      t.verify.text = d_text;
-      t.verify.n = n;
-      t.verify.hits = s->hits.as<uint64_t>();
-      t.verify.n_regions = geo.n_regions;
-      t.verify.region_cap = static_cast<uint32_t>(caps[static_cast<size_t>(p)]);
-      t.verify.counters = s->counters.as<unsigned long long>();
-      t.verify.sb = sb;
-      t.verify.se = se;
-      t.verify.expand = 1;
-      t.verify.float_max = s->prog->dev.float_max;
-      t.program = s->prog->dev;
-      t.hit_counts = s->hit_counts.as<uint32_t>();
-      t.valid_counts = s->valid_counts.as<uint32_t>();
-      t.region_ends = s->cand_end.as<uint64_t>();
-      t.out = s->out.as<uint64_t>();
-      t.out_cap = s->out_cap;
-      t.host_counters = s->host_counters;
-      s->host_counters[kCntUnordered] = 0;
-      s->host_counters[kCntAdjacent] = 0;
-    }
-    if (m->uploaded.size() != static_cast<size_t>(P) ||
-        memcmp(m->uploaded.data(), m->host_tails, sizeof(MultiTail) * static_cast<size_t>(P)) != 0) {
-      RJ_HIP(hipMemcpyAsync(m->tails.p, m->host_tails, sizeof(MultiTail) * P, hipMemcpyHostToDevice, ts));
-      m->uploaded.assign(m->host_tails, m->host_tails + P);
-    }
-    if (plane) {
-      SharedHits sh{};
-      sh.hits = m->shared_hits.as<uint64_t>();
-      sh.counts = m->shared_counts.as<uint32_t>();
-      sh.cap = shared_cap;
-      sh.n_regions = geo.n_regions;
-      sh.n_patterns = static_cast<uint32_t>(P);
-      sh.win_offset = m->plane.offset;
-      sh.text = d_text;
-      sh.n = n;
-      sh.sb = sb;
-      sh.se = se;
+    if (plane && fused_launched) {
+      launch_offsets_gather_check_multi(m->tails.as<MultiTail>(), P, geo.n_regions, ts);
+    } else if (plane) {
+      SharedHits sh = shared_hits_of(m, d_text, n, sb, se, shared_cap, geo.n_regions, P);
       int rc = classify_blob(m, ts);
       if (rc != RJ_OK) return rc;
       sh.blob = m->classify_blob.as<uint32_t>();
@@ -543,6 +590,7 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     if (phase == 1) {
       m->pending.caps = caps;
       m->pending.shared_cap = shared_cap;
+      m->last_was_fused_classify = fused_launched;
       return RJ_OK;  // (pending.done was recorded behind the tails, on the stream that holds them)
     }
     // (phase 2: the stream may already hold the NEXT run of another rj_multi -- wait for this one only)
@@ -550,7 +598,19 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     else RJ_HIP(hipStreamSynchronize(st));
     RJ_HIP(hipGetLastError());
     bool again = false;
-    if (plane && s0->host_counters[kCntSharedMax] != 0) {
+    if (plane && fused_launched) {
+      // the flags plane_scan_classify sets but does not clear: dirty when any of them is up
+      for (int p = 0; p < P; p++)
+        if (m->scans[static_cast<size_t>(p)]->host_counters[kCntOverflow] != 0) m->flags_clean = false;
+      if (s0->host_counters[kCntSharedMax] != 0) {
+        // a span with more candidates than the kernel's LDS slots: the two kernels with shared regions in device memory
+        m->flags_clean = false;
+        m->fused_classify = false;
+        m->shared_cap_hint = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(s0->host_counters[kCntSharedMax] * 2, m->shared_cap_hint), 1u << 20));
+        s0->stats.retries++;
+        continue;
+      }
+    } else if (plane && s0->host_counters[kCntSharedMax] != 0) {
       // a shared candidate region overflowed: size them all for the fullest one seen (x2) and run again
       const uint64_t want = std::max<uint64_t>(s0->host_counters[kCntSharedMax] * 2, static_cast<uint64_t>(shared_cap) * 2);
       if (shared_cap >= 2048 * std::max<uint64_t>((plane_pairs + geo.n_regions - 1) / geo.n_regions, 1))
@@ -610,6 +670,18 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
 
 }  // namespace
 
+namespace {
+// the live rj_multi objects (rj_multi_destroy clears the scan_after pointers that name the object it frees)
+std::mutex& live_multi_mutex() {
+  static std::mutex mu;
+  return mu;
+}
+std::vector<rj_multi*>& live_multi() {
+  static std::vector<rj_multi*> v;
+  return v;
+}
+}  // namespace
+
 extern "C" {
 
 int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out) {
@@ -644,6 +716,10 @@ int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out)
   m->fused = all && n_progs > 1 && getenv("RJ_NO_FUSION") == nullptr;
   if (m->fused) m->plane = plan_plane(m->scans);
   m->batchable = all_batchable && n_progs > 1;
+  {
+    std::lock_guard<std::mutex> lock(live_multi_mutex());
+    live_multi().push_back(m.get());
+  }
   *out = m.release();
   return RJ_OK;
 }
@@ -651,6 +727,14 @@ int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out)
 void rj_multi_destroy(rj_multi* m) {
   ErrnoGuard errno_guard;
   if (!m) return;
+  {
+    // rj_multi_order_after keeps a raw pointer: objects that wait for this one's scans stop doing so
+    std::lock_guard<std::mutex> lock(live_multi_mutex());
+    auto& live = live_multi();
+    live.erase(std::remove(live.begin(), live.end(), m), live.end());
+    for (rj_multi* other : live)
+      if (other->scan_after == m) other->scan_after = nullptr;
+  }
   for (rj_scan* s : m->scans) rj_scan_destroy(s);
   if (m->host_tails) (void)hipHostFree(m->host_tails);
   if (m->host_bounds) (void)hipHostFree(m->host_bounds);
@@ -748,6 +832,7 @@ int rj_multi_finish(rj_multi* m, uint64_t* counts) {
 
 int rj_multi_order_after(rj_multi* m, rj_multi* before) {
   if (!m) return fail(RJ_BAD_ARGUMENT, "null argument");
+  std::lock_guard<std::mutex> lock(live_multi_mutex());
   m->scan_after = before;
   return RJ_OK;
 }

@@ -458,6 +458,239 @@ __global__ __launch_bounds__(256) void classify_shared_multi(SharedHits sh, unsi
   if (threadIdx.x == 0) RJ_STAMP_AT(blockIdx.x, 6);
 }
 
+// ---------------------------------------------------------------------------------------
+// Round 4: scan and classification in ONE kernel.  The step of round 3 was plane_scan (97 us) -> gap ->
+// classify_shared_multi (24 us) -> gap -> offsets_gather_check_multi (20 us): a third of it latency-bound tails on
+// the same stream.  A wave's span holds two dozen candidates, so the wave that found them can classify them
+// itself at the end of its span: candidates stay in LDS (32-bit window positions relative to the span, never
+// written to HBM), their text is still in L2, the blob of descriptors and tables is staged once per workgroup
+// while the first text loads are in flight, and the prefetch registers of the scan loop are dead by then (no
+// more registers than the scan alone).  One launch and one gap less per step; the shared candidate regions in
+// device memory and their counts are gone from this path.  A span with more than kFusedCap candidates (13 x the
+// density of DNA) flags the run (kCntSharedMax) and the host repeats it with the two kernels above, whose shared
+// regions grow.
+constexpr uint32_t kFusedCap = 256;  // candidate slots per wave (LDS)
+
+namespace {
+
+struct LdsRegion {
+  uint32_t* slots;
+  uint32_t count;  // wave-uniform; keeps counting past kFusedCap
+};
+
+// push_pair with the slots in LDS: `rel` = offset of the lane's 16 bytes of chunk A from the span's first byte
+__device__ __forceinline__ void push_pair_lds(LdsRegion& r, uint32_t hm, uint32_t rel) {
+  const uint32_t hA = hm & 0x55555555u, hB = hm & 0xAAAAAAAAu;
+  const uint64_t mA = __ballot(hA != 0), mB = __ballot(hB != 0);
+  const uint64_t several = __ballot(((hA & (hA - 1)) | (hB & (hB - 1))) != 0);
+  if (several == 0) {
+    const uint32_t nA = __popcll(mA), nB = __popcll(mB);
+    if (hA != 0) {
+      const uint32_t idx = r.count + lanes_below(mA);
+      if (idx < kFusedCap) r.slots[idx] = rel + (static_cast<uint32_t>(__builtin_ctz(hA)) >> 1);
+    }
+    if (hB != 0) {
+      const uint32_t idx = r.count + nA + lanes_below(mB);
+      if (idx < kFusedCap) r.slots[idx] = rel + static_cast<uint32_t>(kChunk) + (static_cast<uint32_t>(__builtin_ctz(hB)) >> 1);
+    }
+    r.count += nA + nB;
+    return;
+  }
+  const uint32_t cA = __popc(hA), cB = __popc(hB);
+  const uint32_t incA = wave_inclusive_sum(cA), incB = wave_inclusive_sum(cB);
+  const uint32_t totA = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incA), kWave - 1));
+  const uint32_t totB = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incB), kWave - 1));
+  uint32_t idx = r.count + incA - cA;
+  for (uint32_t m = hA; m; m &= m - 1, idx++)
+    if (idx < kFusedCap) r.slots[idx] = rel + (static_cast<uint32_t>(__builtin_ctz(m)) >> 1);
+  idx = r.count + totA + incB - cB;
+  for (uint32_t m = hB; m; m &= m - 1, idx++)
+    if (idx < kFusedCap) r.slots[idx] = rel + static_cast<uint32_t>(kChunk) + (static_cast<uint32_t>(__builtin_ctz(m)) >> 1);
+  r.count += totA + totB;
+}
+
+template <int NB>
+__device__ __forceinline__ void plane_pair_lds(const uint32_t (&dA)[6], const uint32_t (&dB)[6], uint32_t rel, const PlaneConsts& k,
+                                               const PlaneParams& a, LdsRegion& region) {
+  const uint32_t hm = plane_candidates<NB>(dA, dB, k, a);
+  if (__ballot(hm != 0) == 0) return;  // wave-uniform
+  push_pair_lds(region, hm, rel);
+}
+
+// The wave's candidates (window positions span_base + slots[k], in position order) against every pattern: exact
+// window test, short automaton from the LDS tables, survivors in position order into the pattern's own region
+// `r` -- what classify_shared_multi does for half a wave per region, here for the whole wave and ONE region.
+template <int W, int MAXK>
+__device__ __forceinline__ void classify_own_region(const uint32_t* lds, const SharedHits& sh, const uint32_t* slots, uint32_t cnt,
+                                                    uint64_t span_base, uint64_t r) {
+  const int lane = lane_id();
+  const ClassifyDesc* desc = reinterpret_cast<const ClassifyDesc*>(lds);
+  const uint32_t* tab = lds + sh.desc_words;
+  const uint8_t* text = sh.text;
+  const uint64_t n = sh.n, sb = sh.sb, se = sh.se;
+  uint32_t kept = 0;  // lane p: survivors of pattern p so far
+  for (uint32_t base = 0; base < cnt; base += kWave) {
+    const uint32_t k = base + static_cast<uint32_t>(lane);
+    const bool have = k < cnt;
+    const uint64_t w = span_base + (have ? slots[k] : 0u);
+    const uint64_t s = w - sh.win_offset;  // (wraps for a window before the offset: dropped by `s < se`)
+    const bool in_range = have && s >= sb && s < se && w + 8 <= n;
+    uint32_t lo = 0, hi = 0;
+    uint64_t t_lo = 0, t_hi = 0;
+    if (in_range) {
+      __builtin_memcpy(&lo, text + w, 4);
+      __builtin_memcpy(&hi, text + w + 4, 4);
+      rj_load16(text, n, s, &t_lo, &t_hi);
+    }
+    const uint32_t avail = n - s < 16 ? static_cast<uint32_t>(n - s) : 16u;
+    uint32_t todo = 0;
+    for (uint32_t p = 0; p < sh.n_patterns; p++) {
+      const ClassifyDesc& d = desc[p];
+      bool win = (((lo ^ d.v0[0]) & d.m0[0]) | ((hi ^ d.v1[0]) & d.m1[0])) == 0;
+      if (d.n_windows > 1) win = win || ((((lo ^ d.v0[1]) & d.m0[1]) | ((hi ^ d.v1[1]) & d.m1[1])) == 0);
+      todo |= (in_range && win) ? 1u << p : 0u;
+    }
+    uint32_t matched = 0;
+    uint64_t lens[2] = {0, 0};
+    while (__ballot(todo != 0) != 0) {
+      const bool act = todo != 0;
+      const uint32_t p = act ? static_cast<uint32_t>(__builtin_ctz(todo)) : 0u;
+      todo &= todo - 1;
+      const ClassifyDesc& d = desc[p];
+      const uint32_t* t0 = tab + d.tab;
+      uint32_t len = 0;
+      bool found;
+      if (W == 1 || d.n_words <= 1) found = short_longest_lds<1, MAXK>(t0, d, t_lo, t_hi, avail, &len);
+      else found = short_longest_lds<W, MAXK>(t0, d, t_lo, t_hi, avail, &len);
+      if (found && act) {
+        matched |= 1u << p;
+        if (p < 12) lens[0] |= static_cast<uint64_t>(len) << (5 * p);
+        else lens[1] |= static_cast<uint64_t>(len) << (5 * (p - 12));
+      }
+    }
+    for (uint32_t p = 0; p < sh.n_patterns; p++) {
+      const bool found = ((matched >> p) & 1u) != 0;
+      const uint64_t mine = __ballot(found);
+      if (mine == 0) continue;
+      const ClassifyDesc& d = desc[p];
+      const uint64_t e = s + (((p < 12 ? lens[0] >> (5 * p) : lens[1] >> (5 * (p - 12)))) & 31u);
+      const uint32_t b0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(kept), static_cast<int>(p)));
+      const uint32_t pos = b0 + lanes_below(mine);
+      const uint32_t cap_p = d.region_cap;
+      if (found && pos < cap_p) {
+        d.begins[r * cap_p + pos] = s;
+        d.ends[r * cap_p + pos] = e;
+      }
+      if (lane == static_cast<int>(p)) kept += __popcll(mine);
+    }
+  }
+  if (lane < static_cast<int>(sh.n_patterns)) {
+    const ClassifyDesc& d = desc[lane];
+    const uint32_t c = kept, cap_p = d.region_cap;
+    if (c > cap_p) {  // the host grows this pattern's regions and runs again
+      d.counters[kCntOverflow] = 1;
+      atomicMax(&d.counters[kCntMaxRegion], static_cast<unsigned long long>(c));
+    }
+    d.valid_counts[r] = c < cap_p ? c : cap_p;
+  }
+}
+
+}  // namespace
+
+// sh.hits / sh.counts / sh.cap are unused here (no shared regions in device memory); sh.n_regions = the grid's waves.
+// The counters this kernel may SET (kCntOverflow, kCntMaxRegion of a pattern, kCntSharedMax of pattern 0) are not
+// among those it clears -- a wave may finish before wave 0 has run: the host keeps them clean (multi_pattern.hip).
+template <int NB, int W, int MAXK>
+__global__ __launch_bounds__(256) void plane_scan_classify(PlaneParams a, SharedHits sh, unsigned long long* counters0) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int lane = lane_id();
+  const uint64_t wave = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6));
+  if (wave == 0 && lane < kCntSize && lane != kCntOverflow && lane != kCntMaxRegion && lane != kCntSharedMax)
+    for (uint32_t p = 0; p < a.n_zero; p++) a.zero_counters[p][lane] = 0;
+  PlaneConsts k;
+  k.shift = a.code_shift;
+  k.cmask = 0x03030303u << a.code_shift;
+  LdsRegion region{lds + sh.blob_words + (threadIdx.x >> 6) * kFusedCap, 0u};
+  const uint64_t wlo = a.sb + a.offset;
+  const uint64_t last_w = a.n >= 8 ? a.n - 8 + 1 : 0;
+  uint64_t whi = a.se + a.offset;
+  if (whi > last_w) whi = last_w;
+  const uint64_t first_pair = wlo / kPair;
+  const uint64_t end_pair = whi > wlo ? (whi + kPair - 1) / kPair : first_pair;
+  uint64_t c0 = first_pair + wave * a.span_pairs, c1 = c0 + a.span_pairs;
+  if (c0 > end_pair) c0 = end_pair;
+  if (c1 > end_pair) c1 = end_pair;
+  uint64_t fast_end = a.n >= kPair + 8 ? (a.n - 8) / kPair : 0;
+  if (fast_end > c1) fast_end = c1;
+  if (fast_end < c0) fast_end = c0;
+  const uint64_t lane_off = static_cast<uint64_t>(lane) * 16;
+  const uint64_t span_base = c0 * kPair;
+  const uint32_t lane_rel = static_cast<uint32_t>(lane) * 16u;
+  uint32_t a0[6], b0[6], a1[6], b1[6];
+  uint64_t c = c0;
+  const bool piped = c + 3 < fast_end;  // (wave-uniform)
+  if (piped) {
+    load_chunk24(a.text, c * kPair + lane_off, a0);
+    load_chunk24(a.text, c * kPair + kChunk + lane_off, b0);
+    load_chunk24(a.text, (c + 1) * kPair + lane_off, a1);
+    load_chunk24(a.text, (c + 1) * kPair + kChunk + lane_off, b1);
+  }
+  {
+    // the blob of descriptors + tables, while the first pairs are on their way
+    const uint4* src = reinterpret_cast<const uint4*>(sh.blob);
+    uint4* dst = reinterpret_cast<uint4*>(lds);
+    for (uint32_t i = threadIdx.x; i < sh.blob_words / 4; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  if (piped) {
+    while (c + 3 < fast_end) {
+      plane_pair_lds<NB>(a0, b0, static_cast<uint32_t>((c - c0) * kPair) + lane_rel, k, a, region);
+      load_chunk24(a.text, (c + 2) * kPair + lane_off, a0);
+      load_chunk24(a.text, (c + 2) * kPair + kChunk + lane_off, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      plane_pair_lds<NB>(a1, b1, static_cast<uint32_t>((c + 1 - c0) * kPair) + lane_rel, k, a, region);
+      load_chunk24(a.text, (c + 3) * kPair + lane_off, a1);
+      load_chunk24(a.text, (c + 3) * kPair + kChunk + lane_off, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      c += 2;
+    }
+    plane_pair_lds<NB>(a0, b0, static_cast<uint32_t>((c - c0) * kPair) + lane_rel, k, a, region);
+    plane_pair_lds<NB>(a1, b1, static_cast<uint32_t>((c + 1 - c0) * kPair) + lane_rel, k, a, region);
+    c += 2;
+  }
+  for (; c < fast_end; c++) {
+    load_chunk24(a.text, c * kPair + lane_off, a0);
+    load_chunk24(a.text, c * kPair + kChunk + lane_off, b0);
+    plane_pair_lds<NB>(a0, b0, static_cast<uint32_t>((c - c0) * kPair) + lane_rel, k, a, region);
+  }
+  for (uint64_t t = fast_end; t < c1; t++) {
+    load_guarded24(a.text, a.n, t * kPair + lane_off, a0);
+    load_guarded24(a.text, a.n, t * kPair + kChunk + lane_off, b0);
+    plane_pair_lds<NB>(a0, b0, static_cast<uint32_t>((t - c0) * kPair) + lane_rel, k, a, region);
+  }
+  // the wave's own LDS stores, then its own LDS loads: in order on the LDS queue, no barrier
+  uint32_t cnt = region.count;
+  if (cnt > kFusedCap) {  // the run is void: the host repeats it with regions in device memory
+    if (lane == 0) atomicMax(&counters0[kCntSharedMax], static_cast<unsigned long long>(cnt));
+    cnt = kFusedCap;
+  }
+  classify_own_region<W, MAXK>(lds, sh, region.slots, cnt, span_base, wave);
+}
+
+size_t plane_fused_lds_bytes(uint32_t blob_words) { return (static_cast<size_t>(blob_words) + 4u * kFusedCap) * sizeof(uint32_t); }
+
+// false: no instantiation for this shape / blob too large for a resident workgroup mix (the caller takes the two kernels)
+bool launch_plane_scan_classify(const PlaneParams& a, const SharedHits& sh, int max_words, uint32_t max_short, unsigned long long* counters0,
+                                int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+  if (max_words > 1 || max_short > 8 || sh.blob_words > kFusedMaxBlobWords) return false;
+  const size_t lds = plane_fused_lds_bytes(sh.blob_words);
+  if (a.n_bases <= 1) hipExtLaunchKernelGGL((plane_scan_classify<1, 1, 8>), dim3(grid), dim3(256), lds, st, t0, t1, 0, a, sh, counters0);
+  else hipExtLaunchKernelGGL((plane_scan_classify<2, 1, 8>), dim3(grid), dim3(256), lds, st, t0, t1, 0, a, sh, counters0);
+  return true;
+}
+
+
 void launch_tails_shared(const MultiTail* d_tails, const SharedHits& sh, int max_words, uint32_t max_short, unsigned long long* counters0,
                          hipStream_t st) {
   // half a wave per region; every workgroup copies the blob into LDS first

@@ -691,3 +691,45 @@ def test_multi_start_finish_two_in_flight():
     assert a.finish() == want_r
     with pytest.raises(rejit_amd.RejitError):
         a.finish()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["tails_on_own_streams", "stream_per_object"])
+def test_multi_two_in_flight_on_tail_streams(variant):
+    """The two other ways to keep two steps in flight (bench.py's headline loop and its extras): every run's tails on a
+    stream of the object's own behind the scan's end event (rj_multi_set_tail_stream), and an object per stream with the
+    scans ordered by rj_multi_order_after -- step by step the counts and the spans of rj_multi_run, on texts of
+    different sizes so that a run that overtook its predecessor would show."""
+    import torch
+    import rejit_amd
+    from rejit_amd import workloads as W
+    dev = torch.device("cuda:0")
+    main = torch.cuda.current_stream(dev).cuda_stream
+    second = torch.cuda.Stream(dev)
+    progs = [rejit_amd.Program(rx) for rx in W.REGEXDNA_PATTERNS]
+    texts = [torch.from_numpy(W.fasta_stripped_numpy(n).copy()).to(dev) for n in (30000, 470000, 2000000)]
+    ref = rejit_amd.MultiScan(progs)
+    want, want_spans = [], []
+    for t in texts:
+        want.append(ref.run(t.data_ptr(), t.numel(), stream=main))
+        want_spans.append([ref.scan(i).spans() for i in range(len(progs))])
+    objs = [rejit_amd.MultiScan(progs), rejit_amd.MultiScan(progs)]
+    streams = [main, main]
+    if variant == "tails_on_own_streams":
+        for m in objs:
+            m.set_tail_stream(True)
+    else:
+        streams = [main, second.cuda_stream]
+        objs[0].order_after(objs[1]); objs[1].order_after(objs[0])
+    steps, got = 13, []
+    for k in range(steps):
+        j = k & 1
+        if k >= 2:
+            got.append(objs[j].finish())
+            assert [objs[j].scan(i).spans() for i in range(len(progs))] == want_spans[(k - 2) % 3], (variant, k)
+        objs[j].start(texts[k % 3].data_ptr(), texts[k % 3].numel(), stream=streams[j])
+    for k in (steps - 2, steps - 1):
+        got.append(objs[k & 1].finish())
+    assert got == [want[k % 3] for k in range(steps)], variant
+    for m in objs:                       # (the raw pointers of order_after must not outlive their targets)
+        m.order_after(None)
