@@ -68,6 +68,8 @@ typedef struct {
   int32_t large_path;      /* 1 when the rocPRIM sort path was taken                 */
   int32_t exact_path;      /* 1 when the one-lane exact kernel replaced the result   */
   int32_t linear_path;    /* 1 when a candidate outlived the parallel verifier's walk and the linear-time carry scan ran */
+  int32_t stream_path;    /* 1 when the bit-stream dense kernel produced the result (one pass, pairs written once) */
+  int32_t slow_starts;    /* that kernel: starts that outlived its register steps and took the scalar walk (saturating) */
 } rj_stats;
 
 /* ---- compile (replaces Regej::Regej + Regej::Compile, src/rejit.cc:127-137,229-267) */
@@ -232,7 +234,8 @@ int rj_multi_device_counts_via(rj_multi* multi, const void* d_text, uint64_t n, 
  * all of them in ONE launch when the patterns have the regexdna shape (scan_windows_train), else one kernel
  * per pattern back to back on the caller's stream; mode 2: one kernel per pattern, alternating between the
  * caller's stream and a second one so that consecutive kernels overlap at their boundaries; mode 3: one
- * kernel per pattern back to back (measurement: the per-kernel HBM roofline) */
+ * kernel per pattern back to back (measurement: the per-kernel HBM roofline); mode 4: mode 0 with the scan and
+ * the classification of its candidates in ONE kernel (round 4: measured no faster, kept selectable) */
 int rj_multi_set_mode(rj_multi* multi, int mode);
 /* duration of the last run's scan kernel(s) in ms, summed (0 when the patterns ran one by one) */
 float rj_multi_scan_ms(const rj_multi* multi);

@@ -197,6 +197,7 @@ int upload_program(rj_program* rp) {
   // (patterns at risk of the ring artefact keep every start as a candidate: the test "a candidate begins where
   // another one ends" that sends a text to the exact replay is made on the candidates)
   D.loop_first = run_start_rule(P) && !P.q8_risk && getenv("RJ_NO_LOOP_FIRST") == nullptr ? 1u : 0u;  // (env: measurement override)
+  rp->stream = getenv("RJ_NO_STREAMS") == nullptr ? make_stream_plan(P, D.loop_first != 0, P.q8_risk) : StreamPlan{};  // (env: measurement override)
   D.float_range = P.floating ? P.float_max - P.float_min + 1 : 1;
   D.float_max = P.floating ? P.float_max : 0;
   for (int k = 0; k < 8; k++) D.first_bytes[k] = P.first_bytes.w[k];
@@ -209,6 +210,10 @@ int upload_program(rj_program* rp) {
   D.cls = base + off_cls;
   rp->walk.nullable = D.nullable;
   rp->walk.max_walk = D.max_walk;
+  if (rp->stream.n_pos != 0) {
+    RJ_HIP(rp->dev_struct.reserve(sizeof(DevProgram)));
+    RJ_HIP(hipMemcpy(rp->dev_struct.p, &D, sizeof(DevProgram), hipMemcpyHostToDevice));
+  }
   if (P.q8_risk) {
     // graph for the exact replay kernels (table_layout.h: int32 arrays, class bitmaps, literal bytes)
     const GraphBlob gb = make_graph_blob(P.graph);
@@ -467,6 +472,74 @@ static int run_assertions(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_
   return 0;
 }
 
+// Dense patterns whose candidates cannot overlap (make_stream_plan) from the beginning of a selection: one pass, the pairs
+// written once, in place (dense_streams.hip).  1 = done, 0 = not applicable / void run (the caller takes scan_dense_walk,
+// and from there the carry scan), < 0 = error.
+static int run_streams(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, hipStream_t st) {
+  const rj_program* rp = s->prog;
+  if (rp->stream.n_pos == 0 || s->streams_off || se <= sb) return 0;
+  StreamParams a{};
+  a.text = d_text;
+  a.n = n;
+  a.sb = sb;
+  a.se = se;
+  a.n_tiles = stream_tiles(sb, se, n, &a.first_tile);
+  if (a.n_tiles == 0) {
+    s->result_count = 0;
+    s->result = s->out.as<uint64_t>();
+    return 1;
+  }
+  a.plan = rp->stream;
+  uint64_t cap = std::max<uint64_t>(s->hits_hint + s->hits_hint / 8 + 1024, (se - sb) / 64 + 1024);
+  RJ_HIP(s->scan_a.reserve(stream_scratch_bytes(a.n_tiles)));
+  for (int attempt = 0; attempt < 3; attempt++) {
+    if (cap > s->out_cap) {
+      RJ_HIP(s->out.reserve(cap * 2 * sizeof(uint64_t)));
+      s->out_cap = cap;
+    }
+    RJ_HIP(hipMemsetAsync(s->counters.p, 0, kCntSize * sizeof(unsigned long long), st));
+    s->host_counters[kCntOverrun] = 0;
+    s->host_counters[kCntFinal] = 0;
+    a.out = s->out.as<uint64_t>();
+    a.out_cap = s->out_cap;
+    a.counters = s->counters.as<unsigned long long>();
+    a.host_counters = s->host_counters;
+    launch_dense_streams(a, rp->dev_struct.as<DevProgram>(), s->scan_a.as<unsigned long long>(), s->ev[1], s->ev[2], st);
+    unsigned long long slow = 0;
+    RJ_HIP(hipMemcpyAsync(&s->host_counters[kCntSlowStarts], s->counters.as<unsigned long long>() + kCntSlowStarts, sizeof(unsigned long long),
+                          hipMemcpyDeviceToHost, st));
+    RJ_HIP(hipStreamSynchronize(st));
+    RJ_HIP(hipGetLastError());
+    slow = s->host_counters[kCntSlowStarts];
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, s->ev[1], s->ev[2]);
+    s->stats.scan_ms += ms;
+    if (s->host_counters[kCntOverrun] != 0) {
+      s->streams_off = true;  // (a long-lived thread or a time-out: this text is not for the register steps)
+      s->stats.retries++;
+      return 0;
+    }
+    // a text on which many starts outlive the register steps (long runs of the loop's class): the scalar walks are
+    // chains of loads from device memory; scan_dense_walk's LDS walkers do that better -- from the next call on
+    if (slow > (se - sb) / 512) s->streams_off = true;
+    const uint64_t cnt = s->host_counters[kCntFinal];
+    if (cnt > s->out_cap) {  // more matches than room: once more with room for all of them
+      s->stats.retries++;
+      cap = cnt + cnt / 16 + 1024;
+      continue;
+    }
+    s->result_count = cnt;
+    s->result = s->out.as<uint64_t>();
+    s->hits_hint = cnt;
+    s->stats.n_hits += cnt;
+    s->stats.n_candidates += cnt;
+    s->stats.stream_path = 1;
+    s->stats.slow_starts = static_cast<int32_t>(std::min<unsigned long long>(slow, 0x7fffffffull));
+    return 1;
+  }
+  return 0;
+}
+
 constexpr uint64_t kExactLimit = 1u << 20;  // bytes the one-lane exact kernel is allowed to walk
 constexpr uint64_t kDenseSegment = 1ull << 27;  // dense mode: starts per pipeline run (bounds the lists)
 
@@ -496,7 +569,9 @@ static int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb,
   // when the text turns out not to need it)
   if (s->linear_hint && linear_path_fits(rp)) return run_linear(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
   if (!windows && carry_cur == 0 && !have_prev) {
-    const int rc = run_assertions(s, d_text, n, sb, se, st);
+    int rc = run_assertions(s, d_text, n, sb, se, st);
+    if (rc != 0) return rc < 0 ? rc : RJ_OK;
+    rc = run_streams(s, d_text, n, sb, se, st);
     if (rc != 0) return rc < 0 ? rc : RJ_OK;
   }
 

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "dense_streams.h"
 #include "device_program.h"
 
 namespace rejit_amd {
@@ -15,7 +16,8 @@ enum { kCntCands = 0, kCntFinal = 1, kCntOverflow = 2, kCntAdjacent = 3, kCntHit
   kCntConflict = 8,   // behind mode: a candidate hidden by an earlier match ends after it (the run is repeated dense)
   kCntSharedMax = 9,  // plane scan (plane_scan.hip): fullest SHARED candidate region when one overflowed, else 0
   kCntLongWalks = 10, // walks of the run that went past kLongWalk bytes (device_program.h: rj_lane_longest)
-  kCntSize = 11 };
+  kCntSlowStarts = 11, // dense_streams.hip: starts that outlived the register steps and took the scalar walk
+  kCntSize = 12 };
 // offsets_gather_check keeps 2 x kOgcMaxBlocks granules behind the counters of a scan (kernels.hip): a counter block is
 // kCntSize + 2 * kOgcMaxBlocks words, zeroed when it is allocated
 constexpr uint32_t kOgcMaxBlocks = 256;
@@ -180,6 +182,27 @@ struct PlaneParams {
   unsigned long long* zero_counters[kMaxFused];  // counter blocks the kernel clears (one per pattern)
 };
 void launch_plane_scan(const PlaneParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
+
+// Dense mode as bit streams (dense_streams.h / dense_streams.hip): patterns whose candidates cannot overlap, one pass, the
+// pairs written once at their final place (tiles of 32 KiB, decoupled look-back).  counters[kCntFinal] = the number of
+// matches (also beyond out_cap: the host grows `out` and runs again); counters[kCntOverrun] = 1: a walk beyond max_walk
+// or a look-back time-out, the run is void; counters[kCntSlowStarts] = starts that took the scalar walk.
+struct StreamParams {
+  const uint8_t* text;   // 16-byte aligned
+  uint64_t n;
+  uint64_t sb, se;       // starts [sb, se), se <= n + 1
+  uint64_t first_tile, n_tiles;   // stream_tiles()
+  unsigned long long* granules;   // set by the launcher
+  unsigned long long* ticket;
+  uint64_t* out;
+  uint64_t out_cap;
+  unsigned long long* counters;
+  unsigned long long* host_counters;
+  StreamPlan plan;
+};
+uint64_t stream_tiles(uint64_t sb, uint64_t se, uint64_t n, uint64_t* first_tile);
+size_t stream_scratch_bytes(uint64_t n_tiles);
+void launch_dense_streams(StreamParams a, const DevProgram* d_program, unsigned long long* scratch, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 
 struct ScanGeometry {
   int grid;

@@ -150,6 +150,7 @@ struct rj_multi {
   // round 4: scan + classification in one kernel (plane_scan_classify); off after a run whose span overflowed the
   // kernel's LDS candidate slots (then the two kernels with shared regions in device memory), or RJ_NO_FUSED_CLASSIFY
   bool fused_classify = true;
+  bool want_fused_classify = false;  // rj_multi_set_mode(m, 4): mode 0 with the one-kernel form
   bool flags_clean = false;   // the counters that kernel may set but does not clear are zero on the device
   bool last_was_fused_classify = false;
   // what classify_shared_multi copies into LDS: ClassifyDesc[P] + the patterns' tables (kernels.h)
@@ -448,7 +449,7 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       // 0.152 ms either way) -- so it is opt-in (tests run both)
       static const bool want_fused_classify = getenv("RJ_FUSED_CLASSIFY") != nullptr;
       fused_launched = false;
-      if (m->fused_classify && want_fused_classify) {
+      if (m->fused_classify && (want_fused_classify || m->want_fused_classify)) {
         const SharedHits sh = shared_hits_of(m, d_text, n, sb, se, 0, geo.n_regions, P);
         int rc = classify_blob(m, st);
         if (rc != RJ_OK) return rc;
@@ -979,8 +980,9 @@ int rj_multi_set_tail_stream(rj_multi* m, int on) {
 }
 
 int rj_multi_set_mode(rj_multi* m, int mode) {
-  if (!m || mode < 0 || mode > 3) return fail(RJ_BAD_ARGUMENT, "bad argument");
-  m->mode = mode;
+  if (!m || mode < 0 || mode > 4) return fail(RJ_BAD_ARGUMENT, "bad argument");
+  m->want_fused_classify = mode == 4;
+  m->mode = mode == 4 ? 0 : mode;
   return RJ_OK;
 }
 

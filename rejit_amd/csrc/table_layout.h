@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "dense_streams.h"
 #include "device_program.h"
 #include "lds_walk.h"
 #include "lowering.h"
@@ -265,6 +266,105 @@ inline SwarPlan make_swar_plan(const Program& P) {
   pl.gen = gen * rep;
   pl.depth = P.max_len <= 1 ? 1 : P.max_len <= 2 ? 2 : 4;
   pl.n_ranges = n;
+  return pl;
+}
+
+// The plan of the bit-stream dense kernel (dense_streams.h: StreamPlan), n_pos = 0 when the pattern does not qualify:
+// <= 8 positions in one word, no assertions, not nullable, every follow set a subset of {i, i + 1}, <= 8 byte ranges in
+// all, not at risk of the ring artefact, and -- decided here on the automaton -- NO TWO CANDIDATES CAN OVERLAP, so that
+// the candidates are the reference's selection (src/codegen.cc:36-86) and can be written once, in place.
+//   Candidates: every start with a match; under `loop_first` (DevProgram::loop_first, `X+ rest`) the first byte of every
+//   run of X.  Two candidates s < s' overlap when the thread of s consumes the byte at s'.  Sufficient for "never": over
+//   all thread states reachable after >= 1 consumed bytes (<= 256 position sets x "was the last byte in X"), no state can
+//   consume a byte at which a candidate may begin (a byte of a first position's class; under loop_first: a byte of X
+//   that follows a byte outside X).
+inline StreamPlan make_stream_plan(const Program& P, bool loop_first, bool q8_risk) {
+  StreamPlan pl{};
+  if (P.n_pos < 1 || P.n_pos > kStreamMaxPos || P.has_assertions || P.any_nullable || P.n_words != 1 || q8_risk) return pl;
+  const uint32_t all = (1u << P.n_pos) - 1u;
+  const uint32_t first = P.first[0][0] & all, last = P.last[0][0] & all;
+  if (first == 0 || last == 0) return pl;
+  uint32_t step = 0, loop = 0;
+  for (int k = 0; k < P.n_pos; k++) {
+    const int r = P.row_of[static_cast<size_t>(k)];
+    const uint32_t F = (r < 0 ? (1u << (k + 1)) : P.rows[0][static_cast<size_t>(r)]) & all;
+    const uint32_t allowed = (1u << k) | (k + 1 < P.n_pos ? 1u << (k + 1) : 0u);
+    if (F & ~allowed) return pl;  // a general follow set (alternation inside a repetition, optional positions)
+    if ((F >> k) & 1u) loop |= 1u << k;
+    if (k + 1 < P.n_pos && ((F >> (k + 1)) & 1u)) step |= 1u << k;
+  }
+  // the byte ranges of all positions, identical ranges shared
+  uint32_t n = 0;
+  for (int half = 0; half < 2; half++)
+    for (int k = 0; k < P.n_pos; k++) {
+      int b = 0;
+      while (b < 128) {
+        while (b < 128 && !((P.cls[static_cast<size_t>(half * 128 + b)] >> k) & 1u)) b++;
+        if (b >= 128) break;
+        int e = b;
+        while (e + 1 < 128 && ((P.cls[static_cast<size_t>(half * 128 + e + 1)] >> k) & 1u)) e++;
+        const uint32_t lo = static_cast<uint32_t>(0x80 - b) * 0x01010101u, hi = static_cast<uint32_t>(0x7f - e) * 0x01010101u;
+        uint32_t r = 0;
+        while (r < n && !(pl.add_lo[r] == lo && pl.add_hi[r] == hi && ((pl.high_half >> r) & 1u) == static_cast<uint32_t>(half))) r++;
+        if (r == n) {
+          if (n >= static_cast<uint32_t>(kStreamMaxRanges)) return StreamPlan{};
+          pl.add_lo[n] = lo;
+          pl.add_hi[n] = hi;
+          pl.high_half |= static_cast<uint32_t>(half) << n;
+          n++;
+        }
+        pl.range_pos[r] |= 1u << k;
+        b = e + 1;
+      }
+    }
+  if (n == 0) return StreamPlan{};
+  const uint32_t first_pos = static_cast<uint32_t>(__builtin_ctz(first));
+  if (loop_first && (__builtin_popcount(first) != 1 || !((loop >> first_pos) & 1u))) loop_first = false;
+  // can two candidates overlap?
+  auto follow = [&](uint32_t S) {
+    uint32_t T = 0;
+    for (int k = 0; k < P.n_pos; k++)
+      if ((S >> k) & 1u) T |= (((step >> k) & 1u) << (k + 1)) | (((loop >> k) & 1u) << k);
+    return T;
+  };
+  std::vector<uint8_t> seen(512, 0);
+  std::vector<uint32_t> todo;
+  for (int b = 0; b < 256; b++) {
+    const uint32_t S = first & P.cls[static_cast<size_t>(b)] & all;
+    if (S == 0) continue;
+    const uint32_t in_x = loop_first ? 1u : 0u;  // (under loop_first the first byte is in X by definition)
+    if (!seen[S * 2 + in_x]) {
+      seen[S * 2 + in_x] = 1;
+      todo.push_back(S * 2 + in_x);
+    }
+  }
+  while (!todo.empty()) {
+    const uint32_t st = todo.back();
+    todo.pop_back();
+    const uint32_t S = st >> 1, prev_in_x = st & 1u, T = follow(S);
+    for (int c = 0; c < 256; c++) {
+      const uint32_t cls = P.cls[static_cast<size_t>(c)] & all;
+      const uint32_t S2 = T & cls;
+      if (S2 == 0) continue;  // the thread does not consume this byte
+      const bool in_x = loop_first && ((cls >> first_pos) & 1u);
+      const bool may_begin = loop_first ? (in_x && !prev_in_x) : (first & cls) != 0;
+      if (may_begin) return StreamPlan{};
+      const uint32_t nx = S2 * 2 + (in_x ? 1u : 0u);
+      if (!seen[nx]) {
+        seen[nx] = 1;
+        todo.push_back(nx);
+      }
+    }
+  }
+  pl.n_pos = static_cast<uint32_t>(P.n_pos);
+  pl.n_ranges = n;
+  pl.depth = P.max_len == Program::kUnboundedLen || P.max_len > kStreamShift ? kStreamShift : static_cast<uint32_t>(std::max<uint64_t>(P.max_len, 1));
+  pl.loop_first = loop_first ? 1u : 0u;
+  pl.first_pos = first_pos;
+  pl.first = first;
+  pl.last = last;
+  pl.step = step;
+  pl.loop = loop;
   return pl;
 }
 

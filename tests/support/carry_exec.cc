@@ -11,6 +11,7 @@
 
 #include "../../rejit_amd/csrc/behind_walk.h"
 #include "../../rejit_amd/csrc/carry_scan.h"
+#include "../../rejit_amd/csrc/dense_streams.h"
 #include "../../rejit_amd/csrc/dense_swar.h"
 #include "../../rejit_amd/csrc/exact_replay.h"
 #include "../../rejit_amd/csrc/lowering.h"
@@ -238,6 +239,115 @@ static long swar_check(const Program& P, const SwarPlan& pl, const uint8_t* t, u
   }
   stats[3] = D;
   return bad;
+}
+
+// dense_streams.h, lane by lane on the CPU: MatchAll of the starts [sb, se) exactly as dense_streams.hip computes it --
+// 32 bytes per lane, the start frame kStreamShift bytes back, class streams, position-major steps, the scalar walk for
+// the starts still alive after the plan's depth -- the pairs in order.  Returns the count, -101 when the pattern does
+// not qualify (make_stream_plan), a negative lowering status; stats: [0] starts decided in registers with a match,
+// [1] starts handed to the scalar walk, [2] disagreements between the register steps and the scalar automaton
+// (start by start: candidate flag, "alive after depth bytes", longest length), [3] the plan's depth, [4] loop_first.
+template <int NP>
+static long stream_run(const Program& P, const DevProgram& F, const StreamPlan& pl, const uint8_t* t, uint64_t n, uint64_t sb, uint64_t se,
+                       uint64_t* out, uint64_t cap, uint64_t* stats) {
+  const StreamMasks<NP> mk = rj_stream_masks<NP>(pl);
+  uint64_t k = 0;
+  if (se > n + 1) se = n + 1;
+  const uint64_t lim = se < n ? se : n;  // starts s < lim
+  uint32_t Sb[NP];
+  for (int q = 0; q < NP; q++) Sb[q] = 0;
+  auto any = [](uint32_t x) { return x != 0; };
+  for (uint64_t at = 0; lim > 0 && at <= lim - 1 + kStreamShift; at += 32) {
+    uint32_t x[8] = {0, 0, 0, 0, 0, 0, 0, 0}, valid = 0, S[NP];
+    for (int j = 0; j < 32; j++)
+      if (at + j < n) {
+        x[j >> 2] |= static_cast<uint32_t>(t[at + j]) << (8 * (j & 3));
+        valid |= 1u << j;
+      }
+    rj_stream_classes<NP>(pl, x, valid, S);
+    uint32_t start_mask = 0;
+    for (int j = 0; j < 32; j++) {
+      const uint64_t p = at + j;  // start p - kStreamShift
+      if (p >= kStreamShift && p - kStreamShift >= sb && p - kStreamShift < lim) start_mask |= 1u << j;
+    }
+    uint32_t matched, alive, len[4], cand;
+    rj_stream_steps<NP>(pl, mk, S, Sb, start_mask, any, &matched, &alive, len, &cand);
+    for (int j = 0; j < 32; j++) {
+      if (!((start_mask >> j) & 1u)) {
+        if ((cand >> j) & 1u) stats[2]++;
+        continue;
+      }
+      const uint64_t s = at + j - kStreamShift;
+      // the scalar truth for this start
+      uint32_t St = P.first[0][0] & P.cls[t[s]];
+      bool is_cand = St != 0;
+      if (pl.loop_first && s > 0 && (P.first[0][0] & P.cls[t[s - 1]]) != 0) is_cand = false;
+      uint32_t longest = 0;
+      for (uint32_t d = 1; d <= pl.depth && St; d++) {
+        if (St & P.last[0][0]) longest = d;
+        uint32_t T = 0;
+        for (int q = 0; q < P.n_pos; q++)
+          if ((St >> q) & 1u) {
+            const int r = P.row_of[static_cast<size_t>(q)];
+            T |= r < 0 ? 1u << (q + 1) : P.rows[0][static_cast<size_t>(r)];
+          }
+        St = s + d < n ? (T & P.cls[t[s + d]]) : 0u;
+      }
+      if (((cand >> j) & 1u) != (is_cand ? 1u : 0u)) stats[2]++;
+      if (!is_cand) continue;
+      if (((alive >> j) & 1u) != (St != 0 ? 1u : 0u)) stats[2]++;
+      if ((alive >> j) & 1u) {
+        stats[1]++;
+        uint64_t e = 0;
+        bool overrun = false;
+        if (rj_lane_longest<1>(F, t, n, s, &e, &overrun)) {
+          if (k < cap) {
+            out[2 * k] = s;
+            out[2 * k + 1] = e;
+          }
+          k++;
+        }
+        continue;
+      }
+      if (((matched >> j) & 1u) != (longest != 0 ? 1u : 0u)) stats[2]++;
+      if ((matched >> j) & 1u) {
+        const uint32_t l = rj_stream_len(len, j);
+        if (l != longest) stats[2]++;
+        stats[0]++;
+        if (k < cap) {
+          out[2 * k] = s;
+          out[2 * k + 1] = s + l;
+        }
+        k++;
+      }
+    }
+    for (int q = 0; q < NP; q++) Sb[q] = S[q];
+  }
+  return static_cast<long>(k);
+}
+
+extern "C" long ce_stream_match_all(const char* re, const uint8_t* text, uint64_t n, uint64_t sb, uint64_t se, uint64_t* out, uint64_t cap,
+                                    uint64_t* stats) {
+  LowerResult lr = lower(re);
+  if (lr.status != 0) return lr.status;
+  const Program& P = *lr.program;
+  const StreamPlan pl = make_stream_plan(P, run_start_rule(P) && !P.q8_risk, P.q8_risk);
+  if (pl.n_pos == 0) return -101;
+  const TableBlob fb = make_table_blob(P, P.n_pos, P.n_words, P.has_assertions);
+  DevProgram F{};
+  point_tables(&F, fb.words.data(), fb, P.n_pos);
+  F.nullable = nullable_bits(P);
+  F.max_walk = 1u << 20;
+  stats[3] = pl.depth;
+  stats[4] = pl.loop_first;
+  switch (pl.n_pos) {
+    case 1: return stream_run<1>(P, F, pl, text, n, sb, se, out, cap, stats);
+    case 2: return stream_run<2>(P, F, pl, text, n, sb, se, out, cap, stats);
+    case 3: return stream_run<3>(P, F, pl, text, n, sb, se, out, cap, stats);
+    case 4: return stream_run<4>(P, F, pl, text, n, sb, se, out, cap, stats);
+    case 5: case 6: return stream_run<6>(P, F, pl, text, n, sb, se, out, cap, stats);
+    default: return stream_run<8>(P, F, pl, text, n, sb, se, out, cap, stats);
+  }
 }
 
 extern "C" {

@@ -346,6 +346,22 @@ def test_fused_multi_pattern_equals_single_runs(rj):
         t = texts[1][1000:1000 + max(n, 1)].clone()
         counts = multi.run(t.data_ptr(), n, stream=st)
         assert counts == [sc.run(t.data_ptr(), n, stream=st) for sc in singles], n
+    # mode 4: the scan kernel classifies its own candidates (plane_scan_classify); the text made of hits only overflows
+    # its LDS candidate slots and falls back to the two kernels
+    one = rj.MultiScan(progs)
+    one.set_mode(4)
+    t = texts[1]
+    for lo, hi in ((0, 1000000), (999999, 2000001), (1234567, int(t.numel()) + 1)):
+        counts = one.run(t.data_ptr(), int(t.numel()), stream=st, own_begin=lo, own_end=hi)
+        assert counts == [sc.run(t.data_ptr(), int(t.numel()), own_begin=lo, own_end=hi, stream=st) for sc in singles], (lo, hi)
+    for t in [texts[0], texts[1], texts[1][784:784 + 100001].clone(), texts[1][16:16 + 2047].clone(), texts[2], texts[0]]:
+        n = int(t.numel())
+        for _ in range(2):
+            counts = one.run(t.data_ptr(), n, stream=st)
+            assert one.fused
+            for i, sc in enumerate(singles):
+                assert counts[i] == sc.run(t.data_ptr(), n, stream=st), i
+                assert one.scan(i).spans() == sc.spans(), i
     # the same nine patterns with separate scan kernels and batched tails (mode 1)
     sep = rj.MultiScan(progs)
     sep.set_mode(1)
