@@ -85,35 +85,75 @@ RJ_HD uint32_t rj_stream_range(const uint32_t (&x7)[8], const uint32_t (&half)[8
   return (m[0] >> 7) | (m[1] << 1) | (m[2] << 9) | (m[3] << 17);
 }
 
-// the streams S_k of all positions over the lane's 32 bytes x[0..7]; `valid` = bit j: byte j lies inside the text
+// the streams S_k of all positions over the lane's 32 bytes x[0..7]; `valid` = bit j: byte j lies inside the text.
 // NR = the loop's compile-time bound: the plan's n_ranges <= NR (the constants of ranges beyond it are never touched, so
-// they take no scalar registers in the kernel's chunk loop)
-template <int NP, int NR = kStreamMaxRanges>
-RJ_HD void rj_stream_classes(const StreamPlan& pl, const uint32_t (&x)[8], uint32_t valid, uint32_t (&S)[NP]) {
+// they take no scalar registers in the kernel's chunk loop); HIGH = some range lies in 0x80..0xff (else the high-half
+// flags are never formed -- the usual pattern is ASCII); rm[r][k] = 0 / ~0: position k reads range r.
+template <int NP, int NR>
+struct StreamRangeMasks {
+  uint32_t m[NR][NP];
+};
+template <int NP, int NR>
+RJ_HD StreamRangeMasks<NP, NR> rj_stream_range_masks(const StreamPlan& pl) {
+  StreamRangeMasks<NP, NR> rm;
+#pragma unroll
+  for (int r = 0; r < NR; r++)
+#pragma unroll
+    for (int k = 0; k < NP; k++) rm.m[r][k] = static_cast<uint32_t>(r) < pl.n_ranges ? 0u - ((pl.range_pos[r] >> k) & 1u) : 0u;
+  return rm;
+}
+
+template <int NP, int NR, bool HIGH>
+RJ_HD void rj_stream_classes(const StreamPlan& pl, const StreamRangeMasks<NP, NR>& rm, const uint32_t (&x)[8], uint32_t valid, uint32_t (&S)[NP]) {
   uint32_t x7[8], lowh[8], highh[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     x7[i] = x[i] & 0x7f7f7f7fu;
     lowh[i] = ~x[i] & 0x80808080u;
+    highh[i] = HIGH ? (x[i] & 0x80808080u) : 0u;
   }
 #pragma unroll
   for (int k = 0; k < NP; k++) S[k] = 0;
-  if (pl.high_half != 0) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) highh[i] = x[i] & 0x80808080u;
-  }
 #pragma unroll
   for (int r = 0; r < NR; r++) {
-    if (static_cast<uint32_t>(r) < pl.n_ranges) {  // (wave-uniform)
-      uint32_t T;
-      if ((pl.high_half >> r) & 1u) T = rj_stream_range(x7, highh, pl.add_lo[r], pl.add_hi[r]);
-      else T = rj_stream_range(x7, lowh, pl.add_lo[r], pl.add_hi[r]);
-      T &= valid;
+    // (ranges beyond the plan's n_ranges have zero masks: computed and dropped, at most NR / 2 - 1 of them)
+    uint32_t T;
+    if (HIGH && ((pl.high_half >> r) & 1u)) T = rj_stream_range(x7, highh, pl.add_lo[r], pl.add_hi[r]);
+    else T = rj_stream_range(x7, lowh, pl.add_lo[r], pl.add_hi[r]);
 #pragma unroll
-      for (int k = 0; k < NP; k++)
-        if ((pl.range_pos[r] >> k) & 1u) S[k] |= T;
-    }
+    for (int k = 0; k < NP; k++) S[k] |= T & rm.m[r][k];
   }
+#pragma unroll
+  for (int k = 0; k < NP; k++) S[k] &= valid;
+}
+
+// The scalar walk of ONE start with nothing but the plan (no tables): the chain automaton's state in a register, the
+// class of a byte from the plan's ranges.  For the rare start that outlives the register steps.  Returns the longest
+// match's length (0: none); *overrun when the walk reached max_walk bytes.
+RJ_HD uint32_t rj_stream_cls(const StreamPlan& pl, uint32_t b) {
+  uint32_t c = 0;
+  const uint32_t b7 = b & 0x7fu, high = b >> 7;
+  for (uint32_t r = 0; r < pl.n_ranges; r++) {
+    const uint32_t lo = 0x80u - (pl.add_lo[r] & 0xFFu), hi = 0x7fu - (pl.add_hi[r] & 0xFFu);
+    if (((pl.high_half >> r) & 1u) == high && b7 >= lo && b7 <= hi) c |= pl.range_pos[r];
+  }
+  return c;
+}
+RJ_HD uint32_t rj_stream_walk(const StreamPlan& pl, const uint8_t* t, uint64_t n, uint64_t s, uint32_t max_walk, bool* overrun) {
+  uint32_t S = pl.first & rj_stream_cls(pl, t[s]);
+  uint32_t longest = 0, d = 1;
+  while (S != 0) {
+    if (S & pl.last) longest = d;
+    if (s + d >= n) break;
+    if (d >= max_walk) {
+      *overrun = true;
+      break;
+    }
+    const uint32_t T = ((S & pl.step) << 1) | (S & pl.loop);
+    S = T & rj_stream_cls(pl, t[s + d]);
+    d++;
+  }
+  return longest;
 }
 
 // 0 / ~0 per position: the plan's bit masks as operands (scalars of the kernel's chunk loop)
@@ -140,7 +180,7 @@ RJ_HD StreamMasks<NP> rj_stream_masks(const StreamPlan& pl) {
 //   any(x)      is x != 0 in any lane of the wave (device: a ballot; host: the lane itself) -- the steps stop when
 //               every thread of the wave has died
 // Out: *matched  starts with a match of at most pl.depth bytes; len[b] = bit b of (its longest length - 1)
-//      *alive    starts whose thread is still alive after pl.depth bytes: NOT decided (matched / len then hold the
+//      *alive    starts whose thread is still alive after kStreamShift (16) bytes: NOT decided (matched / len then hold the
 //                longest match so far); empty when the longest possible match is pl.depth bytes
 //      *cand     the candidate starts themselves (first byte fits; run starts only under loop_first)
 template <int NP, typename Any>
@@ -153,11 +193,12 @@ RJ_HD void rj_stream_steps(const StreamPlan& pl, const StreamMasks<NP>& mk, cons
     c0 |= A[k];
   }
   if (pl.loop_first) {
-    // `X+ rest`: a start whose previous byte is in X too is never selected (DevProgram::loop_first)
+    // `X+ rest`: a start whose previous byte is in X too is never selected (DevProgram::loop_first; X = the class of the
+    // one first position, picked by its mask -- no comparison of position numbers, each of which the compiler keeps as a
+    // 64-bit lane mask in scalar registers)
     uint32_t prev = 0;
 #pragma unroll
-    for (int k = 0; k < NP; k++)
-      if (static_cast<uint32_t>(k) == pl.first_pos) prev = rj_alignbit(S[k], Sb[k], 32u - kStreamShift - 1u);
+    for (int k = 0; k < NP; k++) prev |= rj_alignbit(S[k], Sb[k], 32u - kStreamShift - 1u) & mk.first[k];
     c0 &= ~prev;
   }
   c0 &= start_mask;
@@ -185,11 +226,10 @@ RJ_HD void rj_stream_steps(const StreamPlan& pl, const StreamMasks<NP>& mk, cons
       N[k] = (((k > 0 ? A[k > 0 ? k - 1 : 0] & mk.step[k > 0 ? k - 1 : 0] : 0u)) | (A[k] & mk.loop[k])) & w;
       live |= N[k];
     }
-    if (static_cast<uint32_t>(t) + 1u == pl.depth) {  // (wave-uniform)
-      al = live;
-      break;
-    }
-    if (!any(live)) break;
+    // (no test for the plan's depth: a bounded pattern's threads are dead after its longest match, which is <= 16 bytes
+    // whenever the plan's depth is below 16 -- sixteen uniform comparisons cost 32 scalar registers as lane masks)
+    al = live;
+    if (t + 1 == static_cast<int>(kStreamShift) || !any(live)) break;
 #pragma unroll
     for (int k = 0; k < NP; k++) A[k] = N[k];
   }

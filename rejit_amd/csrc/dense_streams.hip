@@ -10,7 +10,7 @@
 //   * the starts of a lane lie 16 bytes BEFORE its bytes, so every shifted stream comes from the lane's own word and the
 //     word of the lane below (DPP; lane 0: the last lane of the iteration before, a scalar) -- no halo loads;
 //   * a start still alive after the plan's depth (16 bytes for patterns with a loop) is walked by its lane with the
-//     scalar walker (rj_lane_longest): rare on random text, counted (kCntSlowStarts) -- the host goes back to
+//     plan's own scalar walk (rj_stream_walk): rare on random text, counted (kCntSlowStarts) -- the host goes back to
 //     scan_dense_walk for a scan object whose text makes it common;
 //   * output as in emit_scan.hip: a wave owns a TILE of 32 KiB (16 iterations), stages its pairs in LDS (4 bytes each:
 //     begin relative to the tile | length), publishes the tile's count as a {status, value} granule, finds the count of
@@ -26,6 +26,7 @@
 #include "dense_streams.h"
 #include "device_program.h"
 #include "kernels.h"
+#include "tile_lookback.h"
 
 namespace rejit_amd {
 
@@ -38,8 +39,6 @@ constexpr uint64_t kTile = kIter * kTileIters;      // 32 KiB: a wave's unit of 
 constexpr uint32_t kStage = 1024;                   // staged pairs per wave
 constexpr uint32_t kLenBits = 17;                   // staged entry: begin - tile start (15 bits) << 17 | length
 constexpr int kTilesPerTicket = 4;
-constexpr unsigned long long kStatusAggregate = 1ull << 62, kStatusInclusive = 2ull << 62, kValueMask = (1ull << 62) - 1;
-constexpr uint32_t kSpinLimit = 1u << 22;
 
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & (kWave - 1); }
 
@@ -84,26 +83,6 @@ __device__ __forceinline__ void load32_guarded(const uint8_t* text, uint64_t n, 
   *valid = v;
 }
 
-// The scalar walk of a start that outlived the register steps: its own function, so that the program descriptor (122
-// dwords, loaded from device memory here) does not compete for the scalar registers of the kernel's chunk loop.
-// Returns the longest match's length (0: none) in the low kLenBits bits, bit 31 when the walk hit max_walk.
-constexpr uint32_t kSlowOverrun = 1u << 31;
-__device__ __attribute__((noinline)) uint32_t slow_longest(const DevProgram* Pd, const uint8_t* text, uint64_t n, uint64_t s,
-                                                           unsigned long long* counters) {
-  const DevProgram P = *Pd;
-  uint64_t e = 0;
-  bool ov = false;
-  const bool found = rj_lane_longest<1>(P, text, n, s, &e, &ov, counters + kCntOverrun);
-  uint32_t r = ov ? kSlowOverrun : 0u;
-  if (!found) return r;
-  uint64_t l = e - s;
-  if (l >= (1u << kLenBits)) {  // (beyond what a staged entry holds: the run goes to the carry scan like an overrun)
-    r |= kSlowOverrun;
-    l = (1u << kLenBits) - 1u;
-  }
-  return r | static_cast<uint32_t>(l);
-}
-
 struct TileOut {
   uint32_t* stage;        // the wave's kStage staged entries (LDS)
   uint64_t* out;
@@ -113,8 +92,8 @@ struct TileOut {
 
 // One tile: its matches counted and (DIRECT) written at direct_base onwards / (not DIRECT) staged in LDS.  Returns the
 // tile's count (wave-uniform); *slow = starts that took the scalar walk; *overrun = a walk hit max_walk.
-template <int NP, int NR, bool DIRECT>
-__device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const DevProgram* Pd, const StreamMasks<NP>& mk, uint64_t base,
+template <int NP, int NR, bool HIGH, bool DIRECT>
+__device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const StreamMasks<NP>& mk, const StreamRangeMasks<NP, NR>& rm, uint64_t base,
                                                 const TileOut& o, uint32_t* slow, bool* overrun) {
   const int lane = lane_id();
   const StreamPlan& pl = a.plan;
@@ -127,7 +106,7 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Dev
 #pragma unroll
     for (int q = 0; q < 8; q++) x[q] = 0;
     if (base >= 32) load32_guarded(a.text, a.n, base - 32, x, &valid);
-    rj_stream_classes<NP, NR>(pl, x, valid, carry);
+    rj_stream_classes<NP, NR, HIGH>(pl, rm, x, valid, carry);
 #pragma unroll
     for (int k = 0; k < NP; k++) carry[k] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(carry[k])));
   }
@@ -162,7 +141,7 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Dev
       start_mask = below_hi & ~below_lo;
     }
     uint32_t S[NP], Sb[NP];
-    rj_stream_classes<NP, NR>(pl, x, valid, S);
+    rj_stream_classes<NP, NR, HIGH>(pl, rm, x, valid, S);
 #pragma unroll
     for (int k = 0; k < NP; k++) {
       const uint32_t below = wave_from_lane_below(S[k]);
@@ -174,13 +153,14 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Dev
     uint32_t fin = matched & ~alive;
     uint32_t walked = 0;  // alive starts whose scalar walk found a match
     if (__ballot(alive != 0) != 0) {
-      // starts that outlived the register steps: the scalar walk, once now for "does it match" (the ranks below need the
-      // count) and once more when the pair is written (no per-start storage)
+      // starts that outlived the register steps: the scalar walk (dense_streams.h: state in a register, classes from the
+      // plan's ranges, a byte load per step), once now for "does it match" (the ranks below need the count) and once more
+      // when the pair is written (no per-start storage)
       for (uint32_t m = alive; m; m &= m - 1) {
         const int j = __builtin_ctz(m);
-        const uint32_t r = slow_longest(Pd, a.text, a.n, at + static_cast<uint64_t>(j) - kStreamShift, a.counters);
-        if ((r & ~kSlowOverrun) != 0) walked |= 1u << j;
-        if (r & kSlowOverrun) *overrun = true;
+        bool ov = false;
+        if (rj_stream_walk(pl, a.text, a.n, at + static_cast<uint64_t>(j) - kStreamShift, a.max_walk, &ov) != 0) walked |= 1u << j;
+        if (ov) *overrun = true;
         (*slow)++;
       }
     }
@@ -194,7 +174,8 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Dev
       const int j = __builtin_ctz(m);
       uint32_t l;
       if ((walked >> j) & 1u) {
-        l = slow_longest(Pd, a.text, a.n, at + static_cast<uint64_t>(j) - kStreamShift, a.counters) & ~kSlowOverrun;
+        bool ov = false;
+        l = rj_stream_walk(pl, a.text, a.n, at + static_cast<uint64_t>(j) - kStreamShift, a.max_walk, &ov);
       } else {
         l = rj_stream_len(len, j);
       }
@@ -211,93 +192,77 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Dev
   return count;
 }
 
-// the tile's count published, the count of everything before it from the look-back (emit_scan.hip: emit_tile)
-__device__ __forceinline__ bool look_back(unsigned long long* granules, uint64_t t, unsigned long long k, unsigned long long* before) {
-  const int lane = lane_id();
-  unsigned long long before_tile = 0;
-  if (t == 0) {
-    if (lane == 0) __hip_atomic_store(&granules[0], kStatusInclusive | k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *before = 0;
-    return true;
-  }
-  if (lane == 0) __hip_atomic_store(&granules[t], kStatusAggregate | k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  uint64_t window_end = t;  // tiles [window_end - 64, window_end) are looked at, lane l reads tile window_end - 1 - l
-  for (;;) {
-    const bool valid = window_end >= static_cast<uint64_t>(lane) + 1;
-    const uint64_t tile = valid ? window_end - 1 - static_cast<uint64_t>(lane) : 0;
-    unsigned long long g = 0;
-    uint32_t spins = 0;
-    for (;;) {
-      g = valid ? __hip_atomic_load(&granules[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kStatusInclusive;
-      const uint64_t inclusive = __ballot((g >> 62) == 2);
-      const uint64_t missing = __ballot((g >> 62) == 0);
-      const uint64_t upto = inclusive ? (inclusive & (0 - inclusive)) : 0;
-      const uint64_t needed = upto ? (upto | (upto - 1)) : ~0ull;
-      if ((missing & needed) == 0) break;
-      if (++spins > kSpinLimit) return false;
-      __builtin_amdgcn_s_sleep(2);
-    }
-    const uint64_t inclusive = __ballot((g >> 62) == 2);
-    const int stop = inclusive ? __builtin_ctzll(inclusive) : kWave;
-    unsigned long long part = lane <= stop ? (g & kValueMask) : 0ull;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-    before_tile += part;
-    if (inclusive) break;
-    window_end -= kWave;
-  }
-  if (lane == 0) __hip_atomic_store(&granules[t], kStatusInclusive | (before_tile + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  *before = before_tile;
-  return true;
-}
-
 }  // namespace
 
-template <int NP, int NR>
-__global__ __launch_bounds__(256) void dense_streams(StreamParams a, const DevProgram* Pd) {
-  __shared__ unsigned long long s_ticket;
-  __shared__ uint32_t s_stage[4][kStage];
+// One granule per WORKGROUP and round (its four tiles), not per tile: the four waves add their counts up in LDS and wave 0
+// looks back over the tickets before it.  With a granule per tile the look-back itself set the pace: a window step is a
+// trip to L2 (~0.5 us) and covers 64 granules, so the resolved prefix advances by ~100 tiles = 3-4 MB per microsecond at
+// best -- the rate these kernels ran at whatever their instruction count (`[@#]`, one step, took as long as
+// `[a-f]+[0-9]`).  A quarter of the granules, four times the headroom.
+template <int NP, int NR, bool HIGH>
+__global__ __launch_bounds__(256) void dense_streams(StreamParams a) {
+  __shared__ unsigned long long s_ticket, s_before;
+  __shared__ uint32_t s_count[kTilesPerTicket], s_bad;
+  __shared__ uint32_t s_stage[kTilesPerTicket][kStage];
   const int wv = static_cast<int>(threadIdx.x) >> 6;
   const int lane = lane_id();
   const StreamMasks<NP> mk = rj_stream_masks<NP>(a.plan);
+  const StreamRangeMasks<NP, NR> rm = rj_stream_range_masks<NP, NR>(a.plan);
+  const uint64_t n_tickets = (a.n_tiles + kTilesPerTicket - 1) / kTilesPerTicket;
   for (;;) {
-    if (threadIdx.x == 0) s_ticket = atomicAdd(a.ticket, 1ull);
+    if (threadIdx.x == 0) {
+      s_ticket = atomicAdd(a.ticket, 1ull);
+      s_bad = 0;
+    }
     __syncthreads();
     const uint64_t tk = s_ticket;
-    __syncthreads();
-    if (tk * kTilesPerTicket >= a.n_tiles) return;
+    if (tk >= n_tickets) return;
     const uint64_t t = tk * kTilesPerTicket + static_cast<uint64_t>(wv);
-    if (t >= a.n_tiles) continue;
     const uint64_t base = (a.first_tile + t) * kTile;
-    // the run is void already (a time-out or an overrun elsewhere): publish a count so that nobody waits for this tile
+    // the run is void already (a time-out or an overrun elsewhere): publish a count so that nobody waits for this ticket
     const bool void_run = __hip_atomic_load(a.counters + kCntOverrun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     TileOut o{s_stage[wv], a.out, a.out_cap, 0};
     uint32_t slow = 0;
     bool overrun = false;
-    unsigned long long k = 0;
-    if (!void_run) k = stream_tile<NP, NR, false>(a, Pd, mk, base, o, &slow, &overrun);
+    uint32_t k = 0;
+    if (!void_run && t < a.n_tiles) k = stream_tile<NP, NR, HIGH, false>(a, mk, rm, base, o, &slow, &overrun);
     overrun = __ballot(overrun) != 0;
-    unsigned long long before = 0;
-    bool ok = !void_run && !overrun;
-    if (ok) ok = look_back(a.granules, t, k, &before);
-    if (!ok) {
+    if (lane == 0) {
+      s_count[wv] = k;
+      if (void_run || overrun) s_bad = 1;
+    }
+    __syncthreads();
+    if (wv == 0) {
+      unsigned long long total = 0, before = 0;
+#pragma unroll
+      for (int w = 0; w < kTilesPerTicket; w++) total += s_count[w];
+      bool ok = s_bad == 0;
+      if (ok) ok = lookback::look_back(a.granules, tk, total, &before);
       if (lane == 0) {
-        __hip_atomic_store(&a.granules[t], kStatusInclusive | 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.counters[kCntOverrun] = 1;
-        if (a.host_counters) a.host_counters[kCntOverrun] = 1;
+        if (!ok) {
+          lookback::publish_void(a.granules, tk);
+          a.counters[kCntOverrun] = 1;
+          if (a.host_counters) a.host_counters[kCntOverrun] = 1;
+          s_bad = 1;
+        } else if (tk == n_tickets - 1) {
+          a.counters[kCntFinal] = before + total;
+          a.counters[kCntCands] = before + total;
+          a.counters[kCntHits] = before + total;
+          if (a.host_counters) {
+            a.host_counters[kCntFinal] = before + total;
+            a.host_counters[kCntCands] = before + total;
+            a.host_counters[kCntHits] = before + total;
+          }
+        }
+        s_before = before;
       }
-      continue;
     }
-    if (t == a.n_tiles - 1 && lane == 0) {
-      a.counters[kCntFinal] = before + k;
-      a.counters[kCntCands] = before + k;
-      a.counters[kCntHits] = before + k;
-      if (a.host_counters) {
-        a.host_counters[kCntFinal] = before + k;
-        a.host_counters[kCntCands] = before + k;
-        a.host_counters[kCntHits] = before + k;
-      }
-    }
+    __syncthreads();
+    const bool bad = s_bad != 0;
+    unsigned long long before = s_before;
+    for (int w = 0; w < wv; w++) before += s_count[w];
+    __syncthreads();  // (s_ticket, s_bad, s_count are rewritten at the top of the next round)
+    if (bad || t >= a.n_tiles) continue;
     if (slow != 0) {
       uint32_t total = slow;
 #pragma unroll
@@ -307,7 +272,7 @@ __global__ __launch_bounds__(256) void dense_streams(StreamParams a, const DevPr
     if (k <= kStage) {
       // the staged pairs to their final place: lane i takes pair i, 16 bytes each -- one KiB per wave store
       const uint64_t tile_start = base - kStreamShift;
-      for (uint32_t i = static_cast<uint32_t>(lane); i < static_cast<uint32_t>(k); i += kWave) {
+      for (uint32_t i = static_cast<uint32_t>(lane); i < k; i += kWave) {
         const uint32_t e = o.stage[i];
         const uint64_t b = tile_start + (e >> kLenBits);
         const uint64_t pos = before + i;
@@ -318,7 +283,7 @@ __global__ __launch_bounds__(256) void dense_streams(StreamParams a, const DevPr
       o.direct_base = before;
       uint32_t slow2 = 0;
       bool ov2 = false;
-      (void)stream_tile<NP, NR, true>(a, Pd, mk, base, o, &slow2, &ov2);
+      (void)stream_tile<NP, NR, HIGH, true>(a, mk, rm, base, o, &slow2, &ov2);
     }
   }
 }
@@ -330,23 +295,27 @@ uint64_t stream_tiles(uint64_t sb, uint64_t se, uint64_t n, uint64_t* first_tile
   return (lim - 1 + kStreamShift) / kTile - *first_tile + 1;
 }
 
-size_t stream_scratch_bytes(uint64_t n_tiles) { return (n_tiles + 1) * sizeof(unsigned long long); }
+size_t stream_scratch_bytes(uint64_t n_tiles) { return ((n_tiles + kTilesPerTicket - 1) / kTilesPerTicket + 1) * sizeof(unsigned long long); }
 
-// scratch: [0] the ticket counter, [1 ..] one granule per tile; cleared here
+// scratch: [0] the ticket counter, [1 ..] one granule per ticket (four tiles); cleared here
 namespace {
-template <int NP>
-void launch_np(const StreamParams& a, const DevProgram* Pd, dim3 g, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+template <int NP, int NR>
+void launch_nr(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
   const dim3 b(256);
+  if (a.plan.high_half == 0) hipExtLaunchKernelGGL((dense_streams<NP, NR, false>), g, b, 0, st, t0, t1, 0, a);
+  else hipExtLaunchKernelGGL((dense_streams<NP, NR, true>), g, b, 0, st, t0, t1, 0, a);
+}
+template <int NP>
+void launch_np(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
   const uint32_t nr = a.plan.n_ranges;
-  if (nr <= 1) hipExtLaunchKernelGGL((dense_streams<NP, 1>), g, b, 0, st, t0, t1, 0, a, Pd);
-  else if (nr <= 2) hipExtLaunchKernelGGL((dense_streams<NP, 2>), g, b, 0, st, t0, t1, 0, a, Pd);
-  else if (nr <= 4) hipExtLaunchKernelGGL((dense_streams<NP, 4>), g, b, 0, st, t0, t1, 0, a, Pd);
-  else hipExtLaunchKernelGGL((dense_streams<NP, 8>), g, b, 0, st, t0, t1, 0, a, Pd);
+  if (nr <= 1) launch_nr<NP, 1>(a, g, t0, t1, st);
+  else if (nr <= 2) launch_nr<NP, 2>(a, g, t0, t1, st);
+  else if (nr <= 4) launch_nr<NP, 4>(a, g, t0, t1, st);
+  else launch_nr<NP, 8>(a, g, t0, t1, st);
 }
 }  // namespace
 
-// d_program: the pattern's DevProgram in device memory (the scalar walk of the rare long-lived start reads it there)
-void launch_dense_streams(StreamParams a, const DevProgram* d_program, unsigned long long* scratch, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+void launch_dense_streams(StreamParams a, unsigned long long* scratch, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
   (void)hipMemsetAsync(scratch, 0, stream_scratch_bytes(a.n_tiles), st);
   a.ticket = scratch;
   a.granules = scratch + 1;
@@ -354,12 +323,12 @@ void launch_dense_streams(StreamParams a, const DevProgram* d_program, unsigned 
   blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;  // persistent: workgroups take tickets until none is left
   const dim3 g(static_cast<unsigned>(blocks));
   const uint32_t np = a.plan.n_pos;
-  if (np <= 1) launch_np<1>(a, d_program, g, t0, t1, st);
-  else if (np <= 2) launch_np<2>(a, d_program, g, t0, t1, st);
-  else if (np <= 3) launch_np<3>(a, d_program, g, t0, t1, st);
-  else if (np <= 4) launch_np<4>(a, d_program, g, t0, t1, st);
-  else if (np <= 6) launch_np<6>(a, d_program, g, t0, t1, st);
-  else launch_np<8>(a, d_program, g, t0, t1, st);
+  if (np <= 1) launch_np<1>(a, g, t0, t1, st);
+  else if (np <= 2) launch_np<2>(a, g, t0, t1, st);
+  else if (np <= 3) launch_np<3>(a, g, t0, t1, st);
+  else if (np <= 4) launch_np<4>(a, g, t0, t1, st);
+  else if (np <= 6) launch_np<6>(a, g, t0, t1, st);
+  else launch_np<8>(a, g, t0, t1, st);
 }
 
 }  // namespace rejit_amd

@@ -24,6 +24,7 @@
 #include "dense_swar.h"
 #include "device_program.h"
 #include "kernels.h"
+#include "tile_lookback.h"
 
 namespace rejit_amd {
 
@@ -34,8 +35,6 @@ constexpr uint64_t kChunk = 1024;
 constexpr int kTileChunks = 32;                        // chunks per tile (a wave's unit of look-back)
 constexpr uint64_t kTile = kChunk * kTileChunks;       // 32 KiB
 constexpr int kDepth = 8;                              // chunk loads in flight per wave
-constexpr unsigned long long kStatusAggregate = 1ull << 62, kStatusInclusive = 2ull << 62, kValueMask = (1ull << 62) - 1;
-constexpr uint32_t kSpinLimit = 1u << 22;
 
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & (kWave - 1); }
 
@@ -126,21 +125,25 @@ __device__ __forceinline__ uint32_t chunk_mask(const uint4& v, uint64_t at, uint
 namespace {
 
 // one tile: masks, count, look-back, pairs
+// `resolve(k, &before)`: the tile's count -> the count of everything before the tile (false: the run is void); called by
+// all four waves of the workgroup together (it synchronises them: one granule per workgroup and round, see the kernel)
+template <typename Resolve>
 __device__ __forceinline__ void emit_tile(const uint8_t* __restrict__ text, uint64_t n, uint64_t sb, uint64_t se, uint32_t nullable,
-                                          unsigned long long* granules, uint64_t n_tiles, uint64_t first_tile, uint64_t t, uint64_t* out,
-                                          uint64_t out_cap, unsigned long long* counters, unsigned long long* host_counters) {
+                                          uint64_t n_tiles, uint64_t first_tile, uint64_t t, uint64_t* out,
+                                          uint64_t out_cap, Resolve resolve) {
   const int lane = lane_id();
+  const bool live = t < n_tiles;  // (wave-uniform: a wave beyond the last tile only takes part in the workgroup's sums)
   const uint64_t base = (first_tile + t) * kTile;
   // ---- the tile's candidate masks: bit j of chunk c's mask = position base + 1024 c + 16 lane + j is a match
   uint32_t mask[kTileChunks / 2];  // two chunks per register
   uint32_t mine = 0;
   uint32_t carry_lb = 1u;          // was the byte before the chunk a line break (the start of the text counts as one)
-  if (base > 0) {
+  if (live && base > 0) {
     const uint8_t c = text[base - 1];
     carry_lb = (c == '\n' || c == '\r') ? 1u : 0u;
   }
   // a tile strictly inside the text and the own range needs no guards (wave-uniform)
-  const bool inner = base >= sb && base + kTile + 16 <= n && base + kTile <= se;
+  const bool inner = live && base >= sb && base + kTile + 16 <= n && base + kTile <= se;
   const uint8_t* lane_text = text + base + static_cast<uint64_t>(lane) * 16;
   if (inner) {
 #pragma unroll
@@ -167,7 +170,7 @@ __device__ __forceinline__ void emit_tile(const uint8_t* __restrict__ text, uint
         const uint64_t at = base + static_cast<uint64_t>(2 * h + q) * kChunk + static_cast<uint64_t>(lane) * 16;
         const uint64_t chunk_at = base + static_cast<uint64_t>(2 * h + q) * kChunk;
         uint32_t m = 0;
-        if (chunk_at <= n && chunk_at < se) {  // (wave-uniform; chunks behind the end of the text or the range hold nothing)
+        if (live && chunk_at <= n && chunk_at < se) {  // (wave-uniform; chunks behind the end of the text or the range hold nothing)
           const uint4 v = load16_guarded(text, n, at);
           m = chunk_mask(v, at, n, sb, se, nullable, false, &carry_lb);
         } else {
@@ -179,67 +182,11 @@ __device__ __forceinline__ void emit_tile(const uint8_t* __restrict__ text, uint
       mask[h] = both;
     }
   }
-  // ---- the tile's count, published; look back for the count of everything before the tile
+  // ---- the tile's count; the count of everything before the tile
   const uint32_t inc_all = wave_inclusive_sum(mine);
   const unsigned long long k = wave_last_lane(inc_all);
   unsigned long long before_tile = 0;
-  bool timed_out = false;
-  if (t == 0) {
-    if (lane == 0) __hip_atomic_store(&granules[0], kStatusInclusive | k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    if (lane == 0) __hip_atomic_store(&granules[t], kStatusAggregate | k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint64_t window_end = t;  // tiles [window_end - 64, window_end) are looked at, lane l reads tile window_end - 1 - l
-    for (;;) {
-      const bool valid = window_end >= static_cast<uint64_t>(lane) + 1;
-      const uint64_t tile = valid ? window_end - 1 - static_cast<uint64_t>(lane) : 0;
-      unsigned long long g = 0;
-      uint32_t spins = 0;
-      for (;;) {
-        g = valid ? __hip_atomic_load(&granules[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kStatusInclusive;
-        const uint64_t inclusive = __ballot((g >> 62) == 2);
-        const uint64_t missing = __ballot((g >> 62) == 0);
-        // the chain is usable up to the nearest tile with an inclusive prefix when no tile before it is missing
-        const uint64_t upto = inclusive ? (inclusive & (0 - inclusive)) : 0;  // lowest set bit
-        const uint64_t needed = upto ? (upto | (upto - 1)) : ~0ull;
-        if ((missing & needed) == 0) break;
-        if (++spins > kSpinLimit) {
-          timed_out = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(2);
-      }
-      if (timed_out) break;
-      const uint64_t inclusive = __ballot((g >> 62) == 2);
-      const int stop = inclusive ? __builtin_ctzll(inclusive) : kWave;  // lanes 0 .. stop take part
-      unsigned long long part = lane <= stop ? (g & kValueMask) : 0ull;
-      // wave sum of 64-bit values (two 32-bit halves through DPP would need carries: 6 xor-shuffles are fine here)
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-      before_tile += part;
-      if (inclusive) break;
-      window_end -= kWave;  // 64 aggregates and no inclusive prefix among them: further back
-    }
-    if (!timed_out && lane == 0) __hip_atomic_store(&granules[t], kStatusInclusive | (before_tile + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (timed_out) {
-    // (publish something so that nobody behind this tile waits for ever; the run is void)
-    if (lane == 0) {
-      __hip_atomic_store(&granules[t], kStatusInclusive | 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      counters[kCntOverrun] = 1;
-      if (host_counters) host_counters[kCntOverrun] = 1;
-    }
-    return;
-  }
-  if (t == n_tiles - 1 && lane == 0) {
-    counters[kCntFinal] = before_tile + k;
-    counters[kCntCands] = before_tile + k;
-    counters[kCntHits] = before_tile + k;
-    if (host_counters) {
-      host_counters[kCntFinal] = before_tile + k;
-      host_counters[kCntCands] = before_tile + k;
-      host_counters[kCntHits] = before_tile + k;
-    }
-  }
+  if (!resolve(k, &before_tile) || !live) return;
   // ---- the pairs, at their final place
   uint64_t pos = before_tile;
 #pragma unroll
@@ -273,22 +220,63 @@ __device__ __forceinline__ void emit_tile(const uint8_t* __restrict__ text, uint
 // What is left is instruction count (6.4 VALU operations per text byte at ~25 % VALU utilisation).
 constexpr int kTilesPerTicket = 4;
 
-__global__ __launch_bounds__(256) void emit_assertions(const uint8_t* __restrict__ text, uint64_t n, uint64_t sb, uint64_t se, uint32_t nullable,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void emit_assertions(const uint8_t* __restrict__ text, uint64_t n, uint64_t sb, uint64_t se, uint32_t nullable,
                                                        unsigned long long* granules, unsigned long long* ticket, uint64_t n_tiles,
                                                        uint64_t* out, uint64_t out_cap, unsigned long long* counters,
                                                        unsigned long long* host_counters) {
-  __shared__ unsigned long long s_ticket;
+  __shared__ unsigned long long s_ticket, s_before;
+  __shared__ unsigned long long s_count[kTilesPerTicket];
+  __shared__ uint32_t s_bad;
   const int wv = static_cast<int>(threadIdx.x) >> 6;
+  const int lane = lane_id();
   const uint64_t first_tile = sb / kTile;
+  const uint64_t n_tickets = (n_tiles + kTilesPerTicket - 1) / kTilesPerTicket;
   for (;;) {
     // ---- a ticket per workgroup and round, in arrival order
     if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1ull);
     __syncthreads();
     const uint64_t tk = s_ticket;
-    __syncthreads();
-    if (tk * kTilesPerTicket >= n_tiles) return;
+    if (tk >= n_tickets) return;
     const uint64_t t = tk * kTilesPerTicket + static_cast<uint64_t>(wv);
-    if (t < n_tiles) emit_tile(text, n, sb, se, nullable, granules, n_tiles, first_tile, t, out, out_cap, counters, host_counters);
+    // ONE granule per workgroup and round (round 4; a granule per tile before): the four waves add their counts up in
+    // LDS, wave 0 looks back over the tickets before this one (tile_lookback.h), every wave adds the waves below it
+    auto resolve = [&](unsigned long long k, unsigned long long* before) -> bool {
+      if (lane == 0) s_count[wv] = k;
+      __syncthreads();
+      if (wv == 0) {
+        unsigned long long total = 0, b = 0;
+#pragma unroll
+        for (int w = 0; w < kTilesPerTicket; w++) total += s_count[w];
+        const bool ok = lookback::look_back(granules, tk, total, &b);
+        if (lane == 0) {
+          s_bad = ok ? 0u : 1u;
+          s_before = b;
+          if (!ok) {
+            // (publish something so that nobody behind this ticket waits for ever; the run is void)
+            lookback::publish_void(granules, tk);
+            counters[kCntOverrun] = 1;
+            if (host_counters) host_counters[kCntOverrun] = 1;
+          } else if (tk == n_tickets - 1) {
+            counters[kCntFinal] = b + total;
+            counters[kCntCands] = b + total;
+            counters[kCntHits] = b + total;
+            if (host_counters) {
+              host_counters[kCntFinal] = b + total;
+              host_counters[kCntCands] = b + total;
+              host_counters[kCntHits] = b + total;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      unsigned long long b = s_before;
+      for (int w = 0; w < wv; w++) b += s_count[w];
+      const bool ok = s_bad == 0;
+      __syncthreads();  // (the shared words are rewritten in the next round)
+      *before = b;
+      return ok;
+    };
+    emit_tile(text, n, sb, se, nullable, n_tiles, first_tile, t, out, out_cap, resolve);
   }
 }
 
@@ -308,6 +296,6 @@ uint64_t emit_tiles(uint64_t sb, uint64_t se) {
   return (se + kTile - 1) / kTile - sb / kTile;  // tiles that hold a start in [sb, se)
 }
 
-size_t emit_scratch_bytes(uint64_t sb, uint64_t se) { return (emit_tiles(sb, se) + 1) * sizeof(unsigned long long); }
+size_t emit_scratch_bytes(uint64_t sb, uint64_t se) { return ((emit_tiles(sb, se) + 3) / 4 + 1) * sizeof(unsigned long long); }
 
 }  // namespace rejit_amd

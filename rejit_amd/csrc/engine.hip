@@ -210,10 +210,6 @@ int upload_program(rj_program* rp) {
   D.cls = base + off_cls;
   rp->walk.nullable = D.nullable;
   rp->walk.max_walk = D.max_walk;
-  if (rp->stream.n_pos != 0) {
-    RJ_HIP(rp->dev_struct.reserve(sizeof(DevProgram)));
-    RJ_HIP(hipMemcpy(rp->dev_struct.p, &D, sizeof(DevProgram), hipMemcpyHostToDevice));
-  }
   if (P.q8_risk) {
     // graph for the exact replay kernels (table_layout.h: int32 arrays, class bitmaps, literal bytes)
     const GraphBlob gb = make_graph_blob(P.graph);
@@ -490,6 +486,7 @@ static int run_streams(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t s
     return 1;
   }
   a.plan = rp->stream;
+  a.max_walk = rp->dev.max_walk;
   uint64_t cap = std::max<uint64_t>(s->hits_hint + s->hits_hint / 8 + 1024, (se - sb) / 64 + 1024);
   RJ_HIP(s->scan_a.reserve(stream_scratch_bytes(a.n_tiles)));
   for (int attempt = 0; attempt < 3; attempt++) {
@@ -504,7 +501,7 @@ static int run_streams(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t s
     a.out_cap = s->out_cap;
     a.counters = s->counters.as<unsigned long long>();
     a.host_counters = s->host_counters;
-    launch_dense_streams(a, rp->dev_struct.as<DevProgram>(), s->scan_a.as<unsigned long long>(), s->ev[1], s->ev[2], st);
+    launch_dense_streams(a, s->scan_a.as<unsigned long long>(), s->ev[1], s->ev[2], st);
     unsigned long long slow = 0;
     RJ_HIP(hipMemcpyAsync(&s->host_counters[kCntSlowStarts], s->counters.as<unsigned long long>() + kCntSlowStarts, sizeof(unsigned long long),
                           hipMemcpyDeviceToHost, st));

@@ -95,7 +95,6 @@ struct rj_program {
   bool window_nibbles = false;  // those values differ in their low nibble (nibble filter usable)
   int batch_separator = -1;  // byte that ends a text inside a concatenated batch, -1: none exists
   rejit_amd::StreamPlan stream{};  // dense mode as bit streams (dense_streams.h): n_pos == 0 when the pattern does not qualify
-  rejit_amd::DeviceBuffer dev_struct;  // `dev` itself in device memory (patterns with a stream plan: the kernel's rare scalar walk)
   std::string pattern;
 };
 

@@ -198,11 +198,12 @@ struct StreamParams {
   uint64_t out_cap;
   unsigned long long* counters;
   unsigned long long* host_counters;
+  uint32_t max_walk;     // DevProgram::max_walk: a walk this long voids the run (the carry scan takes it)
   StreamPlan plan;
 };
 uint64_t stream_tiles(uint64_t sb, uint64_t se, uint64_t n, uint64_t* first_tile);
 size_t stream_scratch_bytes(uint64_t n_tiles);
-void launch_dense_streams(StreamParams a, const DevProgram* d_program, unsigned long long* scratch, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
+void launch_dense_streams(StreamParams a, unsigned long long* scratch, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 
 struct ScanGeometry {
   int grid;

@@ -251,6 +251,7 @@ template <int NP>
 static long stream_run(const Program& P, const DevProgram& F, const StreamPlan& pl, const uint8_t* t, uint64_t n, uint64_t sb, uint64_t se,
                        uint64_t* out, uint64_t cap, uint64_t* stats) {
   const StreamMasks<NP> mk = rj_stream_masks<NP>(pl);
+  const StreamRangeMasks<NP, kStreamMaxRanges> rm = rj_stream_range_masks<NP, kStreamMaxRanges>(pl);
   uint64_t k = 0;
   if (se > n + 1) se = n + 1;
   const uint64_t lim = se < n ? se : n;  // starts s < lim
@@ -264,7 +265,8 @@ static long stream_run(const Program& P, const DevProgram& F, const StreamPlan& 
         x[j >> 2] |= static_cast<uint32_t>(t[at + j]) << (8 * (j & 3));
         valid |= 1u << j;
       }
-    rj_stream_classes<NP>(pl, x, valid, S);
+    if (pl.high_half) rj_stream_classes<NP, kStreamMaxRanges, true>(pl, rm, x, valid, S);
+    else rj_stream_classes<NP, kStreamMaxRanges, false>(pl, rm, x, valid, S);
     uint32_t start_mask = 0;
     for (int j = 0; j < 32; j++) {
       const uint64_t p = at + j;  // start p - kStreamShift
@@ -283,7 +285,7 @@ static long stream_run(const Program& P, const DevProgram& F, const StreamPlan& 
       bool is_cand = St != 0;
       if (pl.loop_first && s > 0 && (P.first[0][0] & P.cls[t[s - 1]]) != 0) is_cand = false;
       uint32_t longest = 0;
-      for (uint32_t d = 1; d <= pl.depth && St; d++) {
+      for (uint32_t d = 1; d <= kStreamShift && St; d++) {
         if (St & P.last[0][0]) longest = d;
         uint32_t T = 0;
         for (int q = 0; q < P.n_pos; q++)
@@ -299,11 +301,14 @@ static long stream_run(const Program& P, const DevProgram& F, const StreamPlan& 
       if ((alive >> j) & 1u) {
         stats[1]++;
         uint64_t e = 0;
-        bool overrun = false;
-        if (rj_lane_longest<1>(F, t, n, s, &e, &overrun)) {
+        bool overrun = false, ov2 = false;
+        const bool f1 = rj_lane_longest<1>(F, t, n, s, &e, &overrun);
+        const uint32_t l = rj_stream_walk(pl, t, n, s, 1u << 20, &ov2);   // the kernel's own walk == the general walker
+        if ((l != 0) != f1 || (f1 && s + l != e)) stats[2]++;
+        if (l != 0) {
           if (k < cap) {
             out[2 * k] = s;
-            out[2 * k + 1] = e;
+            out[2 * k + 1] = s + l;
           }
           k++;
         }
