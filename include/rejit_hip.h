@@ -230,6 +230,28 @@ typedef int (*rj_allgather_fn)(void* ctx, const void* d_send, void* d_recv, uint
 int rj_multi_device_counts_via(rj_multi* multi, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end,
                                int64_t offset, rj_allgather_fn allgather, void* ctx, int rank, int world, uint64_t* counts,
                                void* hip_stream);
+
+/* MatchAll of ONE pattern over a text that is sharded across ranks (one process or thread per GPU, a shard of the text
+ * resident on each), the ordered match list gathered on `root` -- SURVEY 8e / BASELINE configs[3] (the complex regex
+ * over 50 GB on 8 GPUs); the reference's result is that list (src/codegen.cc:36-86, include/rejit.h:65-68).  Arguments
+ * as for rj_multi_device_counts: this rank owns the match begins [own_begin, own_end) of its buffer d_text[0..n), which
+ * starts at `offset` of the whole text and holds a halo of max_len - 1 bytes behind own_end.  Runs the shard, carries
+ * the left-most-longest selection over the cuts (rounds of one 64-byte all-gather), then every rank sends its pairs --
+ * as GLOBAL offsets -- straight to their place in the root's list (ncclSend / ncclRecv in one group: peer -> root, no
+ * ring).  Returns the job-wide number of matches on every rank (or rj_status); on `root`
+ * rj_scan_gathered_spans(scan, &count) is the device pointer to the 2 * count offsets in text order (valid until the
+ * scan's next run), NULL elsewhere.  rj_scan_device_spans(scan) stays this shard's own (local) result. */
+int64_t rj_scan_gather_spans(rj_scan* scan, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end, int64_t offset,
+                             void* rccl_comm, int rank, int world, int root, void* hip_stream);
+/* The same over any pair of collectives (MPI, a test harness with several shards on one device): the all-gather of
+ * rj_multi_device_counts_via, and a gather of byte ranges to the root -- d_send[0..send_bytes) of every rank to
+ * d_recv + recv_offsets[rank] on the root (d_recv is NULL elsewhere; recv_offsets / recv_bytes list all ranks, on all
+ * ranks), queued on hip_stream or complete on return; 0 = success. */
+typedef int (*rj_gatherv_fn)(void* ctx, const void* d_send, uint64_t send_bytes, void* d_recv, const uint64_t* recv_offsets,
+                             const uint64_t* recv_bytes, int root, void* hip_stream);
+int64_t rj_scan_gather_spans_via(rj_scan* scan, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end, int64_t offset,
+                                 rj_allgather_fn allgather, rj_gatherv_fn gatherv, void* ctx, int rank, int world, int root, void* hip_stream);
+const uint64_t* rj_scan_gathered_spans(const rj_scan* scan, uint64_t* count);
 /* mode 0 (default): fuse when possible; mode 1: never fuse -- every pattern scans the whole text on its own,
  * all of them in ONE launch when the patterns have the regexdna shape (scan_windows_train), else one kernel
  * per pattern back to back on the caller's stream; mode 2: one kernel per pattern, alternating between the

@@ -120,6 +120,9 @@ _lib = None
 # every symbol include/rejit_hip.h declares
 # rj_allgather_fn (include/rejit_hip.h): ctx, d_send, d_recv, bytes per rank, hip stream -> 0 on success
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p)
+# rj_gatherv_fn: ctx, d_send, send_bytes, d_recv (root only), recv_offsets[world], recv_bytes[world], root, hip stream -> 0 on success
+GATHERV_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64),
+                              ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_void_p)
 
 C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_error", "rj_match_full",
                  "rj_match_anywhere", "rj_match_first", "rj_match_all", "rj_free_spans", "rj_scan_create",
@@ -129,7 +132,8 @@ C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_er
                  "rj_multi_scan_ms", "rj_scan_start", "rj_scan_finish", "rj_multi_set_mode", "rj_multi_run_range",
                  "rj_multi_bounds", "rj_batch_separator", "rj_match_all_packed", "rj_host_alloc", "rj_host_free",
                  "rj_multi_bounds_device", "rj_carry_decide", "rj_multi_start", "rj_multi_finish", "rj_multi_order_after",
-                 "rj_multi_device_counts", "rj_multi_device_counts_via", "rj_multi_set_tail_stream"]
+                 "rj_multi_device_counts", "rj_multi_device_counts_via", "rj_multi_set_tail_stream",
+                 "rj_scan_gather_spans", "rj_scan_gather_spans_via", "rj_scan_gathered_spans"]
 
 
 def load_library():
@@ -181,6 +185,12 @@ def load_library():
     L.rj_multi_device_counts.argtypes = [vp, vp, u64, u64, u64, ctypes.c_int64, vp, ctypes.c_int, ctypes.c_int, _u64p, vp]
     L.rj_multi_device_counts_via.argtypes = [vp, vp, u64, u64, u64, ctypes.c_int64, ALLGATHER_FN, vp, ctypes.c_int, ctypes.c_int, _u64p, vp]
     L.rj_scan_destroy.argtypes = [vp]
+    L.rj_scan_gather_spans.restype = i64
+    L.rj_scan_gather_spans.argtypes = [vp, vp, u64, u64, u64, ctypes.c_int64, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+    L.rj_scan_gather_spans_via.restype = i64
+    L.rj_scan_gather_spans_via.argtypes = [vp, vp, u64, u64, u64, ctypes.c_int64, ALLGATHER_FN, GATHERV_FN, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+    L.rj_scan_gathered_spans.restype = vp
+    L.rj_scan_gathered_spans.argtypes = [vp, _u64p]
     L.rj_scan_run.restype = i64
     L.rj_scan_run.argtypes = [vp, vp, u64, u64, u64, u64, u64, ctypes.c_int, vp]
     L.rj_scan_start.argtypes = [vp, vp, u64, vp]
@@ -359,6 +369,28 @@ class Scan:
             own_end = n + 1
         return int(_check(self._lib.rj_scan_run(self._h, ctypes.c_void_p(d_text_ptr), n, own_begin, own_end, carry_cur,
                                                 carry_prev_end, int(have_prev), ctypes.c_void_p(stream))))
+
+    def gather_spans(self, d_text_ptr: int, n: int, offset: int, rank: int, world: int, root: int = 0, comm: Optional[int] = None,
+                     allgather=None, gatherv=None, own_begin: int = 0, own_end: Optional[int] = None, stream: int = 0):
+        """rj_scan_gather_spans: this rank's shard, the carry over the cuts, every rank's pairs (global offsets) gathered on
+        `root` in text order.  Returns (job-wide count, the list on root / None elsewhere)."""
+        args = (self._h, ctypes.c_void_p(d_text_ptr), n, own_begin, n + 1 if own_end is None else own_end, ctypes.c_int64(offset))
+        if allgather is not None:
+            total = _check(self._lib.rj_scan_gather_spans_via(*args, allgather, gatherv, None, rank, world, root, ctypes.c_void_p(stream)))
+        else:
+            total = _check(self._lib.rj_scan_gather_spans(*args, ctypes.c_void_p(comm), rank, world, root, ctypes.c_void_p(stream)))
+        cnt = ctypes.c_uint64()
+        ptr = self._lib.rj_scan_gathered_spans(self._h, ctypes.byref(cnt))
+        if not ptr:
+            return int(total), None
+        import torch
+        host = torch.empty(2 * int(cnt.value), dtype=torch.int64)
+        if cnt.value:
+            hip = ctypes.CDLL("libamdhip64.so.7")
+            hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+            assert hip.hipMemcpy(ctypes.c_void_p(host.data_ptr()), ctypes.c_void_p(ptr), 16 * int(cnt.value), 2) == 0   # DeviceToHost
+        v = host.tolist()
+        return int(total), [(v[2 * i], v[2 * i + 1]) for i in range(int(cnt.value))]
 
     def start(self, d_text_ptr: int, n: int, stream: int = 0) -> None:
         """Enqueue a whole-text run; finish() returns its count (several scans can be in flight)."""

@@ -1056,6 +1056,7 @@ void rj_scan_destroy(rj_scan* s) {
   if (s->small_out) (void)hipHostFree(s->small_out);
   if (s->small_hdr) (void)hipHostFree(s->small_hdr);
   if (s->small_text) (void)hipHostFree(s->small_text);
+  if (s->gx_host) (void)hipHostFree(s->gx_host);
   for (auto& e : s->ev)
     if (e) (void)hipEventDestroy(e);
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);

@@ -139,6 +139,12 @@ struct rj_scan {
   char* pinned = nullptr;  // staging for rj_match_all_batch
   size_t pinned_cap = 0;
   hipStream_t own_stream = nullptr;
+  // rj_scan_gather_spans: carry rows (this rank's 8 integers + every rank's), the pinned decision + rows copy, the
+  // shard's pairs as global offsets, and (root) the whole list
+  rejit_amd::DeviceBuffer gx_rows, gx_send, gx_out;
+  int64_t* gx_host = nullptr;
+  const uint64_t* gathered = nullptr;
+  uint64_t gathered_count = 0;
 };
 
 namespace rejit_amd {

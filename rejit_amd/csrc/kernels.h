@@ -156,6 +156,8 @@ struct BoundsParams {
 void launch_first_last(const BoundsParams& a, uint64_t* pinned_bounds, hipStream_t st);
 void launch_bounds_rows(const BoundsParams& a, int64_t offset, int first_round, int64_t* d_rows, hipStream_t st);
 void launch_carry_decide(const int64_t* d_all, int world, int rank, int n_patterns, int64_t* out, hipStream_t st);
+// out[i] = local[i] + offset for the 2 * count offsets of a shard's result (rj_scan_gather_spans: local -> global)
+void launch_globalize_spans(const uint64_t* local, uint64_t count, int64_t offset, uint64_t* out, hipStream_t st);
 void launch_scan_windows_fused(const FusedParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 
 // ---- plane scan (plane_scan.hip): the one-pass scan for SEVERAL patterns whose 8-byte windows all lie within

@@ -1583,6 +1583,16 @@ void launch_carry_decide(const int64_t* d_all, int world, int rank, int n_patter
   hipLaunchKernelGGL(carry_decide_kernel, dim3(1), dim3(64), 0, st, d_all, world, rank, n_patterns, out);
 }
 
+__global__ void globalize_spans(const uint64_t* local, uint64_t n2, uint64_t offset, uint64_t* out) {
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n2; i += stride) out[i] = local[i] + offset;
+}
+void launch_globalize_spans(const uint64_t* local, uint64_t count, int64_t offset, uint64_t* out, hipStream_t st) {
+  const uint64_t n2 = 2 * count;
+  const unsigned blocks = static_cast<unsigned>(std::min<uint64_t>((n2 + 255) / 256, 4096));
+  hipLaunchKernelGGL(globalize_spans, dim3(blocks ? blocks : 1), dim3(256), 0, st, local, n2, static_cast<uint64_t>(offset), out);
+}
+
 // pairs -> begin[] / end[] for the selection kernels (only when the pairs are not the result yet)
 __global__ void split_pairs(const uint64_t* pairs, const unsigned long long* n_ptr, uint64_t* keys, uint64_t* vals) {
   const uint64_t n = *n_ptr;

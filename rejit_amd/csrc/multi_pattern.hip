@@ -927,8 +927,11 @@ int rj_multi_device_counts_via(rj_multi* m, const void* d_text, uint64_t n, uint
       // (global offsets in the rows; the shard's own run takes them relative to its buffer)
       const int64_t cur = out[2 * P + 2 * i], pe = out[2 * P + 2 * i + 1];
       const int have = (cur != 0 || pe != 0) ? 1 : 0;
-      const uint64_t lc = cur > offset ? static_cast<uint64_t>(cur - offset) : 0, lp = pe > offset ? static_cast<uint64_t>(pe - offset) : 0;
-      const int64_t k = rj_scan_run(m->scans[static_cast<size_t>(i)], d_text, n, own_begin, own_end, lc, lp, have, hip_stream);
+      // in the shard's own coordinates; a previous match that ENDS before the buffer begins cannot touch anything in it
+      // (clamping its end to 0 would suppress a legitimate empty match at local position 0): no carry then
+      const int have_local = have && pe >= offset ? 1 : 0;
+      const uint64_t lc = have_local && cur > offset ? static_cast<uint64_t>(cur - offset) : 0, lp = have_local ? static_cast<uint64_t>(pe - offset) : 0;
+      const int64_t k = rj_scan_run(m->scans[static_cast<size_t>(i)], d_text, n, own_begin, own_end, lc, lp, have_local, hip_stream);
       if (k < 0) return static_cast<int>(k);
       const int64_t used[3] = {cur, pe, have};  // the carry this result was selected under: part of the next round's row
       RJ_HIP(hipMemcpyAsync(mine + 8 * i + 5, used, sizeof(used), hipMemcpyHostToDevice, st));
@@ -941,33 +944,154 @@ int rj_multi_device_counts_via(rj_multi* m, const void* d_text, uint64_t n, uint
 namespace {
 // RCCL, bound at the first call: the library is an optional companion of this one (a single-GPU caller never
 // needs it), and a process that has loaded RCCL already -- through PyTorch, say -- must get THAT copy.
-using AllGatherFn = int (*)(const void*, void*, size_t, int, void*, hipStream_t);
-AllGatherFn rccl_all_gather() {
-  static AllGatherFn fn = nullptr;
+struct Rccl {
+  int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*group_start)() = nullptr;
+  int (*group_end)() = nullptr;
+};
+const Rccl& rccl() {
+  static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
     const char* names[] = {std::getenv("RJ_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (const char* name : names) {
       if (!name || !*name) continue;
       if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
-        fn = reinterpret_cast<AllGatherFn>(dlsym(h, "ncclAllGather"));
-        if (fn) return;
+        r.all_gather = reinterpret_cast<decltype(r.all_gather)>(dlsym(h, "ncclAllGather"));
+        r.send = reinterpret_cast<decltype(r.send)>(dlsym(h, "ncclSend"));
+        r.recv = reinterpret_cast<decltype(r.recv)>(dlsym(h, "ncclRecv"));
+        r.group_start = reinterpret_cast<decltype(r.group_start)>(dlsym(h, "ncclGroupStart"));
+        r.group_end = reinterpret_cast<decltype(r.group_end)>(dlsym(h, "ncclGroupEnd"));
+        if (r.all_gather && r.send && r.recv && r.group_start && r.group_end) return;
+        r = Rccl{};
       }
     }
   });
-  return fn;
+  return r;
 }
+constexpr int kNcclInt64 = 4, kNcclUint64 = 5;  // ncclDataType_t (rccl.h)
 int rccl_gather(void* comm, const void* send, void* recv, uint64_t bytes, void* stream) {
-  constexpr int kNcclInt64 = 4;  // ncclDataType_t (rccl.h)
-  return rccl_all_gather()(send, recv, bytes / sizeof(int64_t), kNcclInt64, comm, static_cast<hipStream_t>(stream));
+  return rccl().all_gather(send, recv, bytes / sizeof(int64_t), kNcclInt64, comm, static_cast<hipStream_t>(stream));
+}
+// every rank's pairs straight to their place in the root's list: point to point, root <- rank, one group (SURVEY 8e:
+// "direct peer -> root transfers, not a ring")
+struct RcclGatherCtx {
+  void* comm;
+  int rank, world;
+};
+int rccl_gatherv(void* ctx, const void* d_send, uint64_t send_bytes, void* d_recv, const uint64_t* recv_offsets, const uint64_t* recv_bytes, int root,
+                 void* stream) {
+  const RcclGatherCtx* c = static_cast<const RcclGatherCtx*>(ctx);
+  const Rccl& R = rccl();
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = R.group_start();
+  if (c->rank == root)
+    for (int r = 0; r < c->world && rc == 0; r++)
+      if (recv_bytes[r]) rc = R.recv(static_cast<char*>(d_recv) + recv_offsets[r], recv_bytes[r] / 8, kNcclUint64, r, c->comm, st);
+  if (rc == 0 && send_bytes) rc = R.send(d_send, send_bytes / 8, kNcclUint64, root, c->comm, st);
+  const int rc2 = R.group_end();
+  return rc ? rc : rc2;
+}
+int rccl_allgather_ctx(void* ctx, const void* send, void* recv, uint64_t bytes, void* stream) {
+  return rccl_gather(static_cast<const RcclGatherCtx*>(ctx)->comm, send, recv, bytes, stream);
 }
 }  // namespace
 
 int rj_multi_device_counts(rj_multi* m, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end, int64_t offset,
                            void* rccl_comm, int rank, int world, uint64_t* counts, void* hip_stream) {
   if (!rccl_comm) return fail(RJ_BAD_ARGUMENT, "rj_multi_device_counts: no communicator");
-  if (!rccl_all_gather()) return fail(RJ_DEVICE_ERROR, "rj_multi_device_counts: librccl.so not found (set RJ_RCCL_LIBRARY)");
+  if (!rccl().all_gather) return fail(RJ_DEVICE_ERROR, "rj_multi_device_counts: librccl.so not found (set RJ_RCCL_LIBRARY)");
   return rj_multi_device_counts_via(m, d_text, n, own_begin, own_end, offset, rccl_gather, rccl_comm, rank, world, counts, hip_stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// MatchAll of ONE pattern over a text sharded across ranks, the (begin, end) pairs gathered on `root` in text order
+// (BASELINE configs[3]: the complex regex over 50 GB on 8 GPUs; the reference's result IS the ordered
+// match list, src/codegen.cc:36-86): the shard's run, the carry rounds of rj_multi_device_counts for one pattern
+// (the left-most-longest selection crosses a cut when a match of the left neighbour reaches over it), then every
+// rank's pairs -- global offsets -- straight to their place in the root's list.  Rank order = text order, and the
+// carry has removed what overlapped a cut, so the concatenation is the reference's list.
+int64_t rj_scan_gather_spans_via(rj_scan* s, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end, int64_t offset,
+                                 rj_allgather_fn allgather, rj_gatherv_fn gatherv, void* ctx, int rank, int world, int root, void* hip_stream) {
+  ErrnoGuard errno_guard;
+  if (!s || !allgather || !gatherv || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world) return fail(RJ_BAD_ARGUMENT, "bad argument");
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  s->gathered = nullptr;
+  s->gathered_count = 0;
+  int64_t k = rj_scan_run(s, d_text, n, own_begin, own_end, 0, 0, 0, hip_stream);
+  if (k < 0) return k;
+  RJ_HIP(s->gx_rows.reserve(sizeof(int64_t) * 8 * static_cast<size_t>(world + 1)));
+  if (!s->gx_host) RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->gx_host), sizeof(int64_t) * (8 + 8 * 1024)));
+  if (world > 1024) return fail(RJ_BAD_ARGUMENT, "rj_scan_gather_spans: at most 1024 ranks");
+  int64_t* mine = s->gx_rows.as<int64_t>();
+  int64_t* all = mine + 8;
+  int64_t* out = s->gx_host;
+  bool converged = false;
+  for (int round = 0; round <= world && !converged; round++) {
+    BoundsParams bp{};
+    bp.n_lists = 1;
+    bp.spans[0] = s->result;
+    bp.count[0] = s->result ? s->result_count : 0;
+    launch_bounds_rows(bp, offset, round == 0, mine, st);
+    if (allgather(ctx, mine, all, sizeof(int64_t) * 8, hip_stream) != 0)
+      return fail(RJ_DEVICE_ERROR, "rj_scan_gather_spans: the all-gather failed (round %d)", round);
+    launch_carry_decide(all, world, rank, 1, out, st);
+    RJ_HIP(hipMemcpyAsync(out + 8, all, sizeof(int64_t) * 8 * static_cast<size_t>(world), hipMemcpyDeviceToHost, st));
+    RJ_HIP(hipStreamSynchronize(st));
+    RJ_HIP(hipGetLastError());
+    if (out[4] == 0) {
+      converged = true;
+      break;
+    }
+    if (out[1]) {
+      const int64_t cur = out[2], pe = out[3];
+      const int have = (cur != 0 || pe != 0) ? 1 : 0;
+      const int have_local = have && pe >= offset ? 1 : 0;
+      const uint64_t lc = have_local && cur > offset ? static_cast<uint64_t>(cur - offset) : 0, lp = have_local ? static_cast<uint64_t>(pe - offset) : 0;
+      k = rj_scan_run(s, d_text, n, own_begin, own_end, lc, lp, have_local, hip_stream);
+      if (k < 0) return k;
+      const int64_t used[3] = {cur, pe, have};
+      RJ_HIP(hipMemcpyAsync(mine + 5, used, sizeof(used), hipMemcpyHostToDevice, st));
+      RJ_HIP(hipStreamSynchronize(st));  // (`used` is on the stack)
+    }
+  }
+  if (!converged) return fail(RJ_DEVICE_ERROR, "rj_scan_gather_spans: the carry exchange did not converge in %d rounds", world + 1);
+  // every rank knows every rank's count (the rows of the last round)
+  std::vector<uint64_t> offs(static_cast<size_t>(world)), bytes(static_cast<size_t>(world));
+  uint64_t total = 0;
+  for (int r = 0; r < world; r++) {
+    const uint64_t c = static_cast<uint64_t>(out[8 + 8 * r]);
+    offs[static_cast<size_t>(r)] = total * 16;
+    bytes[static_cast<size_t>(r)] = c * 16;
+    total += c;
+  }
+  const uint64_t my = s->result ? s->result_count : 0;
+  if (my * 16 != bytes[static_cast<size_t>(rank)]) return fail(RJ_DEVICE_ERROR, "rj_scan_gather_spans: internal: the rows disagree with the shard's count");
+  RJ_HIP(s->gx_send.reserve(std::max<uint64_t>(my, 1) * 16));
+  if (my) launch_globalize_spans(s->result, my, offset, s->gx_send.as<uint64_t>(), st);
+  if (rank == root) RJ_HIP(s->gx_out.reserve(std::max<uint64_t>(total, 1) * 16));
+  if (gatherv(ctx, s->gx_send.p, my * 16, rank == root ? s->gx_out.p : nullptr, offs.data(), bytes.data(), root, hip_stream) != 0)
+    return fail(RJ_DEVICE_ERROR, "rj_scan_gather_spans: the gather failed");
+  RJ_HIP(hipStreamSynchronize(st));
+  RJ_HIP(hipGetLastError());
+  s->gathered = rank == root ? s->gx_out.as<uint64_t>() : nullptr;
+  s->gathered_count = total;
+  return static_cast<int64_t>(total);
+}
+
+int64_t rj_scan_gather_spans(rj_scan* s, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end, int64_t offset, void* rccl_comm, int rank,
+                             int world, int root, void* hip_stream) {
+  if (!rccl_comm) return fail(RJ_BAD_ARGUMENT, "rj_scan_gather_spans: no communicator");
+  if (!rccl().all_gather) return fail(RJ_DEVICE_ERROR, "rj_scan_gather_spans: librccl.so not found (set RJ_RCCL_LIBRARY)");
+  RcclGatherCtx c{rccl_comm, rank, world};
+  return rj_scan_gather_spans_via(s, d_text, n, own_begin, own_end, offset, rccl_allgather_ctx, rccl_gatherv, &c, rank, world, root, hip_stream);
+}
+
+const uint64_t* rj_scan_gathered_spans(const rj_scan* s, uint64_t* count) {
+  if (count) *count = s ? s->gathered_count : 0;
+  return s ? s->gathered : nullptr;
 }
 
 int rj_multi_set_tail_stream(rj_multi* m, int on) {

@@ -5,7 +5,7 @@
 // answers all nine patterns over its part in one pass, and the left-most-longest selection is carried over the cuts
 // by an all-gather of 8 integers per pattern.
 //
-//   regexdna_rccl < fasta.txt          (make -C samples rccl; with one GPU visible: a one-rank communicator)
+//   regexdna_rccl [--devices N] < fasta.txt     (make -C samples rccl; with one GPU visible: a one-rank communicator)
 //
 // Output: the nine "pattern count" lines of the Benchmarks-Game program (sample/regexdna.cc:56-70) and the
 // lengths of the input and of the stripped sequence.
@@ -93,7 +93,10 @@ void run_rank(int rank, int world, ncclComm_t comm, const char* seq, uint64_t n,
 
 }  // namespace
 
-int main() {
+int main(int argc, char** argv) {
+  int want_devices = 0;  // --devices N: at most N of the visible devices (default: all of them)
+  for (int i = 1; i < argc; i++)
+    if (std::string(argv[i]) == "--devices" && i + 1 < argc) want_devices = atoi(argv[++i]);
   std::string input;
   {
     char buf[1 << 16];
@@ -120,7 +123,10 @@ int main() {
     fprintf(stderr, "no GPU\n");
     return 2;
   }
+  const int visible = world;
+  if (want_devices > 0) world = std::min(world, want_devices);
   if (n < static_cast<size_t>(world) * (1u << 20)) world = 1;  // (a shard per device only pays from megabytes up)
+  fprintf(stderr, "regexdna_rccl: %d device(s) of %d visible\n", world, visible);
   std::vector<ncclComm_t> comms(static_cast<size_t>(world));
   std::vector<int> devs(static_cast<size_t>(world));
   for (int r = 0; r < world; r++) devs[static_cast<size_t>(r)] = r;
