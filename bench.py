@@ -300,11 +300,13 @@ def run_regexdna(args, c):
                 bounds.append(to_global((sp[0][0], sp[0][1], sp[-1][0], sp[-1][1])) if sp else None)
         return cnt, bounds
 
-    def rerun_one(i, cur, prev_end):
-        # (rare) the left neighbour's last match reaches into this shard's first one
+    def rerun_one(i, cur, prev_end, have=True):
+        # (rare) the left neighbour's last match reaches into this shard's first one; a previous match that ends before
+        # this shard's buffer is no carry for it
         sc = sep_scans[i] if use_multi else scans[i]
-        k = sc.run(text_ptr, n_local, own_begin=own_lo, own_end=own_hi, carry_cur=max(cur - vis_lo, 0),
-                   carry_prev_end=max(prev_end - vis_lo, 0), have_prev=True, stream=stream)
+        have = bool(have) and prev_end >= vis_lo
+        k = sc.run(text_ptr, n_local, own_begin=own_lo, own_end=own_hi, carry_cur=max(cur - vis_lo, 0) if have else 0,
+                   carry_prev_end=prev_end - vis_lo if have else 0, have_prev=have, stream=stream)
         sp = sc.spans()
         return k, (to_global((sp[0][0], sp[0][1], sp[-1][0], sp[-1][1])) if sp else None)
 

@@ -287,11 +287,16 @@ class CarryExchange:
             self.all_c = torch.zeros((world, n_patterns, 8), dtype=torch.int64, device=self.cdev)
 
     def counts(self, multi, run_local, rerun_one, offset: int, stream: int):
-        """run_local() -> local counts (rj_multi_run over this rank's range, empty carry); rerun_one(i, cur, prev_end)
-        re-runs pattern i of `multi` under the true carry (offsets LOCAL to the shard).  Returns the job-wide counts."""
+        """run_local() -> local counts (rj_multi_run over this rank's range, empty carry); rerun_one(i, cur, prev_end, have)
+        re-runs pattern i of `multi` under the true carry (offsets LOCAL to the shard).  Returns the job-wide counts.
+        `stream` must be torch's CURRENT stream of the device (the collective, the row update and the synchronise below
+        run there; bench.py wraps the call in `torch.cuda.stream(...)`): a kernel queued on another stream would race
+        with them."""
         import torch
         from . import api
 
+        if stream != torch.cuda.current_stream(self.device).cuda_stream:
+            raise ValueError("CarryExchange.counts: `stream` must be the device's current torch stream")
         run_local()
         first = True
         for _ in range(self.world + 1):
@@ -312,14 +317,21 @@ class CarryExchange:
                 if out[P + i]:
                     cur, pe = out[2 * P + 2 * i], out[2 * P + 2 * i + 1]
                     have = cur != 0 or pe != 0
-                    rerun_one(i, max(cur - offset, 0), max(pe - offset, 0), have)
+                    # in the shard's own coordinates; a previous match that ends before the buffer begins cannot touch
+                    # anything in it (clamping its end to 0 would suppress a legitimate empty match at local 0): no carry
+                    have_local = have and pe >= offset
+                    rerun_one(i, max(cur - offset, 0) if have_local else 0, pe - offset if have_local else 0, have_local)
                     self.mine[i, 5:8] = torch.tensor([cur, pe, int(have)], dtype=torch.int64)
         raise RuntimeError("carry exchange did not converge")
 
 
 def _rerun_empty(rerun_one, i):
-    # (a carry that went back to "no earlier match": select again from an empty carry)
-    return rerun_one(i, 0, 0)
+    # (a carry that went back to "no earlier match": select again from an empty carry -- have = False when the callback
+    # takes the flag)
+    try:
+        return rerun_one(i, 0, 0, False)
+    except TypeError:
+        return rerun_one(i, 0, 0)
 
 
 def _device_for(dist):
