@@ -78,6 +78,7 @@ def parse_args():
     ap.add_argument("--literal-bytes", type=int, default=5_000_000_000, help="text bytes per GPU of the literal / complex workloads")
     ap.add_argument("--big-literal-bytes", type=int, default=50_000_000_000, help="the north star's 50 GB single-GPU scan (extra)")
     ap.add_argument("--tree-files", type=int, default=12_500, help="jrep workload: files per GPU (~20 KB each)")
+    ap.add_argument("--one-stream", action="store_true", help="headline loop as in round 3: both rj_multi objects and their tails on one stream")
     ap.add_argument("--jrep-files", type=int, default=100_000, help="jrep_10gb extra: files (BASELINE configs[4]: 100 000)")
     ap.add_argument("--jrep-bytes", type=int, default=10_000_000_000, help="jrep_10gb extra: total bytes (BASELINE configs[4]: 10 GB)")
     ap.add_argument("--no-extra", action="store_true", help="headline only")
@@ -375,8 +376,13 @@ def run_regexdna(args, c):
     # step k + 1 are already queued, so the device never waits for the host's turn-around (~15 us of a 170 us step).
     # Every step still is one complete pass of the path over the batch with its own result; the synchronous call is
     # reported as `call_latency` / `synchronous_calls`, the variant with a stream per object as `overlapped_tails`.
+    # Round 4: the headline loop keeps both objects on ONE stream and queues every run's tails (classify + gather,
+    # latency-bound) on a stream of the object's own (rj_multi_set_tail_stream): the scan kernels follow each other in
+    # order, the tails of step k run under the scan of step k + 1.  The scan kernel then shares the device with them,
+    # so its duration inside this loop is longer than alone: `roofline` is measured in this loop (as the contract asks),
+    # `roofline_kernel_alone` in the one-stream loop of round 3 (`one_stream`).
     if use_multi:
-        step, drain, scan_ms = two_in_flight(False)
+        step, drain, scan_ms = two_in_flight(False, tail_streams=not args.one_stream)
     else:
         drain = None
 
@@ -408,9 +414,14 @@ def run_regexdna(args, c):
                      "fasta_n_per_gpu": args.fasta_n, "text_bytes_per_gpu": int(own_bytes), "patterns": len(patterns),
                      "sharding": "contiguous byte ranges + %d-byte halo; all_gather of 8 integers per pattern (count, first / last match, carry used) per step, rows and decision on the device"
                                  % (max_len - 1),
-                     "calls": "rj_multi_start / rj_multi_finish, mode 0, two steps in flight on two rj_multi objects: one pass over the text for the nine patterns (plane_scan) + classify + gather per step" if use_multi else "9 x rj_scan_run per step"})
+                     "calls": ("rj_multi_start / rj_multi_finish, mode 0, two steps in flight on two rj_multi objects on one stream%s: one pass over the text for the nine patterns (plane_scan) + classify + gather per step"
+                               % ("" if args.one_stream else ", each run's tails on a stream of the object's own (rj_multi_set_tail_stream)")) if use_multi else "9 x rj_scan_run per step"})
     out["matches_per_s"] = round(total_matches * args.steps / elapsed, 1)
     out["matches_per_pass"] = counts
+    # the physical rate of a step: every text byte crosses the HBM interface ONCE per step whatever the number of patterns
+    # (`value` counts it once per pattern, the reference's convention for nine MatchAllCount calls)
+    out["physical_GBps"] = round(n_total * args.steps / elapsed / 1e9, 1)
+    out["step_frac"] = round(n_total * args.steps / elapsed / 1e9 / HBM_PEAK_GBS / world, 4)
     if use_multi:
         # the dominant kernel: plane_scan reads every text byte ONCE for all nine patterns: algorithmic bytes per
         # launch = text bytes (for a fused pass quote n / t_fused, never 9 n / t_fused, against HBM)
@@ -463,20 +474,18 @@ def run_regexdna(args, c):
                                        "ms_per_step": round(eo / args.steps * 1e3, 4),
                                        "value": round(len(patterns) * n_total * args.steps / eo / 1e9, 3), "unit": "GB/s",
                                        "scan_kernel_ms": round(sum(o_times) / max(len(o_times), 1), 5)}
-            # Untested on a GPU when it was written (the round's GPU minutes were spent), hence in a process of its own:
-            # whatever happens there, this process's line is printed.  Both objects on one stream, each with its tails on
-            # a stream of its own (rj_multi_set_tail_stream): scan kernels back to back in order, tails under the next scan.
-            try:
-                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--tail-streams-probe", "--fasta-n", str(args.fasta_n),
-                                        "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-extra", "--no-cpu-baseline"],
-                                       capture_output=True, timeout=240)
-                probe = None
-                for line in child.stdout.decode(errors="replace").splitlines():
-                    if line.startswith('{"tail_streams_probe"'):
-                        probe = json.loads(line)["tail_streams_probe"]
-                out["tails_on_own_streams"] = probe if probe is not None else {"error": "exit %d: %s" % (child.returncode, child.stderr.decode(errors="replace")[-300:])}
-            except Exception as e:  # noqa: BLE001 (an extra must never cost the line)
-                out["tails_on_own_streams"] = {"error": repr(e)[:300]}
+            # the loop of round 3's headline: both objects AND their tails on one stream -- the scan kernel alone on the device
+            s_step, s_drain, s_times = two_in_flight(False, tail_streams=args.one_stream)
+            es1, cs1 = timed(c, args, s_step, s_drain)
+            assert cs1 == counts, (cs1, counts)
+            key = "tails_on_own_streams" if args.one_stream else "one_stream"
+            out[key] = {"calls": "two steps in flight on one stream, tails %s" % ("on a stream per object" if args.one_stream else "on the same stream (round 3's headline loop)"),
+                        "ms_per_step": round(es1 / args.steps * 1e3, 4),
+                        "value": round(len(patterns) * n_total * args.steps / es1 / 1e9, 3), "unit": "GB/s",
+                        "scan_kernel_ms": round(sum(s_times) / max(len(s_times), 1), 5)}
+            if not args.one_stream and s_times:
+                out["roofline_kernel_alone"] = hbm_roofline("plane_scan<2> with nothing else on the device (the one-stream loop)", own_bytes,
+                                                            sum(s_times) / len(s_times), pmc_traffic("plane", fasta_n=args.fasta_n), len(s_times))
         out["synchronous_calls"] = {"calls": "rj_multi_run mode 0, one call after the other (one step in flight): what rounds 1-2 timed",
                                     "ms_per_step": round(ek0 / args.steps * 1e3, 4),
                                     "value": round(len(patterns) * n_total * args.steps / ek0 / 1e9, 3), "unit": "GB/s"}
@@ -752,16 +761,18 @@ def literal_and_complex_extras(args, c, out):
     # first byte of every run of [a-f] is taken, DevProgram::loop_first); the first four automaton steps of all
     # starts run lane-packed, four starts per register (dense_swar.h).
     def check_dense(sc):
-        assert sc.stats()["n_matches"] > 1000
+        st_d = sc.stats()
+        assert st_d["n_matches"] > 1000
+        out["dense_path"] = {"stream_path": st_d["stream_path"], "slow_starts": st_d["slow_starts"]}
 
     out["dense_scan"] = single_pattern_extra(
         c, rejit_amd, t, n, "[a-f]+[0-9]", "[a-f]+[0-9] MatchAll over the same %d bytes (no fast-forward window: dense mode)" % n,
-        "scan_dense_walk<1,false,4> (lane-packed pre-steps)", 5, check_dense, "dense", True, args)
+        "dense_streams<2,2> (bit streams, position-major steps, pairs written once)", 5, check_dense, "dense", True, args)
     # (the dense kernel is issue-bound, not HBM-bound: its VALU roofline says how close to the other ceiling it runs)
     _dl = out["dense_scan"]["roofline"]["avg_launch_ms"]
     if _dl:
         _valu = n * rejit_amd.DENSE_VALU_OPS_PER_BYTE / (_dl * 1e-3) / 1e12
-        out["dense_scan"]["roofline_valu"] = {"bound": "valu", "kernel": "scan_dense_walk<1,false,4>",
+        out["dense_scan"]["roofline_valu"] = {"bound": "valu", "kernel": "dense_streams<2,2>",
                                               "ops_per_text_byte": rejit_amd.DENSE_VALU_OPS_PER_BYTE, "achieved": round(_valu, 2),
                                               "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s", "frac": round(_valu / VALU_PEAK_TOPS, 4)}
     # The line table of a grep-like caller (sample/jrep.cc:294: MatchAll of "^"): a class scan whose OUTPUT is
@@ -1011,6 +1022,11 @@ def end_to_end_extra(args, c, out):
 
     try:
         got = run([exe_hip], "reference_regexdna_on_librejit_hip", "sample/regexdna.cc unchanged, linked against librejit_hip.so; process wall time, 2 runs, best")
+        native_exe = os.path.join(ROOT, "samples", "regexdna_gpu")
+        native = None
+        if os.path.exists(native_exe):
+            native = run([native_exe], "regexdna_gpu_native", "samples/regexdna_gpu (C++ over the C ABI): one upload, strip + nine counts in one pass + eleven "
+                         "replacements on the device, the counts and the replacements in flight together; process wall time, 2 runs, best")
         gpu = run([sys.executable, os.path.join(ROOT, "samples", "regexdna_gpu.py")], "regexdna_gpu_py",
                   "samples/regexdna_gpu.py: one upload, text stays in HBM; process wall time incl. the Python / torch start-up")
         if os.path.exists(exe_ref):
@@ -1025,25 +1041,25 @@ def end_to_end_extra(args, c, out):
             if gpu:
                 assert gpu == got, "regexdna_gpu.py and regexdna_hip print different results"
                 rec["parity"] += "; regexdna_gpu.py prints the same 12 lines"
+            if native:
+                assert native == got, "samples/regexdna_gpu and regexdna_hip print different results"
+                rec["parity"] += "; so does the native samples/regexdna_gpu"
     finally:
         os.unlink(path)
     out["end_to_end"] = rec
 
 
-def jrep_extra(args, c, out):
-    """BASELINE configs[4] at its size on ONE GPU: 100 000 source-like files, 10 GB, log-normal sizes with a heavy tail,
-    1 % hold the needle -- host buffers through rj_match_all_batch (packing, PCIe and result copies included) + the `^`
-    line tables of the files with matches, in batches of 256 MiB like samples/jrep_gpu.  The reference on the host: its own
-    jrep loop (one MatchAll per file + `^` for the files with a match) over a bounded sample of the same files, one core."""
+def jrep_tree(n_files, total_bytes):
+    """The synthetic tree of the jrep_10gb extra (BASELINE configs[4]: 100 000 files, 10 GB): log-normal sizes with a heavy
+    tail, bodies cut from a ~12 MB corpus of source-like lines, ` regexp ` planted in every hundredth file.  Deterministic
+    (tests/golden/make_fullsize.py runs the real reference over the same files)."""
     import numpy as np
-    import rejit_amd
     rng = np.random.default_rng(5)
-    n_files = args.jrep_files
     corpus = b"".join(synthetic_tree(600, 77))                       # ~12 MB of source-like lines without the needle
     corpus = corpus.replace(b"regexp", b"regexq")
     cn = len(corpus)
     sizes = np.clip(rng.lognormal(np.log(20000), 1.8, n_files), 200, 64 << 20).astype(np.int64)
-    sizes = (sizes * (args.jrep_bytes / sizes.sum())).astype(np.int64) + 1
+    sizes = (sizes * (total_bytes / sizes.sum())).astype(np.int64) + 1
     starts = rng.integers(0, cn, n_files)
     files = []
     for i in range(n_files):
@@ -1054,30 +1070,59 @@ def jrep_extra(args, c, out):
             at = (i * 7919) % max(1, k - 8)
             body = body[:at] + b" regexp " + body[at + 8:]
         files.append(body)
+    return files
+
+
+def jrep_digest(rows):
+    """rows: (file index, matches in the file, line starts of the file) of every file with a match, in file order."""
+    import hashlib
+    h = hashlib.sha256()
+    for i, k, l in rows:
+        h.update(b"%d:%d:%d\n" % (i, k, l))
+    return h.hexdigest()
+
+
+def jrep_extra(args, c, out):
+    """BASELINE configs[4] at its size on ONE GPU: 100 000 source-like files, 10 GB, log-normal sizes with a heavy tail,
+    1 % hold the needle -- host buffers through rj_match_all_batch (packing, PCIe and result copies included) + the `^`
+    line tables of the files with matches, in batches of 256 MiB like samples/jrep_gpu.  The reference on the host: its own
+    jrep loop (one MatchAll per file + `^` for the files with a match) over a bounded sample of the same files, one core."""
+    import rejit_amd
+    n_files = args.jrep_files
+    files = jrep_tree(n_files, args.jrep_bytes)
     total = sum(len(f) for f in files)
     prog, sol = rejit_amd.Program(b"regexp"), rejit_amd.Program(b"^")
 
     def one_pass():
-        hits, lines, at = 0, 0, 0
+        hits, lines, at, rows = 0, 0, 0, []
         while at < n_files:
             b, size = at, 0
             while at < n_files and (at == b or size + len(files[at]) <= (256 << 20)):
                 size += len(files[at])
                 at += 1
             res = prog.match_all_batch_counts(files[b:at])
-            hit = [files[b + i] for i, k in enumerate(res) if k]
-            hits += len(hit)
-            if hit:
-                lines += sum(sol.match_all_batch_counts(hit))
-        return hits, lines
+            idx = [b + i for i, k in enumerate(res) if k]
+            hits += len(idx)
+            if idx:
+                lc = sol.match_all_batch_counts([files[i] for i in idx])
+                lines += sum(lc)
+                rows.extend((i, res[i - b], l) for i, l in zip(idx, lc))
+        return hits, lines, rows
 
     one_pass()
     t0 = time.perf_counter()
-    hits, lines = one_pass()
+    hits, lines, rows = one_pass()
     dt = time.perf_counter() - t0
     rec = {"workload": "jrep shape at BASELINE size: %d files, %d bytes (log-normal sizes, sigma 1.8), needle in 1 %% of them; rj_match_all_batch in "
                        "256 MiB batches + `^` line tables of the files with matches; host buffers, PCIe included" % (n_files, total),
            "value": round(total / dt / 1e9, 2), "unit": "GB/s end to end", "seconds": round(dt, 3), "files_with_matches": hits, "line_starts": lines}
+    fx = fullsize_fixture()
+    if fx and "c5" in fx and fx["c5"]["files"] == n_files and fx["c5"]["bytes_asked"] == args.jrep_bytes:
+        c5 = fx["c5"]
+        assert (hits, lines, sum(k for _, k, _ in rows)) == (c5["files_with_matches"], c5["line_starts"], c5["matches"]), \
+            ("jrep_10gb differs from the real reference's answer", hits, lines, c5)
+        assert jrep_digest(rows) == c5["sha256"], "jrep_10gb: per-file counts differ from the real reference's"
+        rec["parity_full_size"] = "files with matches, matches and line starts per file == the real reference's over the same 100 000 files (sha256 of the rows)"
     ref, _ = _ref()
     if ref is not None and not args.no_cpu_baseline:
         ref.set_flags(1, 1, 0, 1)

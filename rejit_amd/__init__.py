@@ -20,4 +20,7 @@ PLANE_VALU_OPS_PER_BYTE = 5.56
 # scan_dense_walk<1,false,4> on `[a-f]+[0-9]` over random ASCII: SQ_INSTS_VALU 1.835e9 wave instructions per 5 GB launch
 # x 64 lanes / 5e9 bytes (profiles/r03_pmc_sq_counters.txt); 28.6 before round 3's instruction diet, 59 before the
 # lane-packed pre-steps
-DENSE_VALU_OPS_PER_BYTE = 23.5
+# round 4: dense_streams<2,2> (bit streams, dense_streams.hip) on the same pattern and text: SQ_INSTS_VALU 144.6 M wave
+# instructions per 1 GB launch x 64 lanes / 1e9 bytes (gpurun_out/r04_stream_pmc2.txt; profiles/r04_pmc_sq_counters.txt
+# holds the 5 GB launch)
+DENSE_VALU_OPS_PER_BYTE = 9.3

@@ -3,7 +3,7 @@
 and span digests (rejit_amd.workloads.span_digest_numpy) -- run ONLY in the build container, where /root/reference
 exists and oracle/_ref has been built, and needs ~20 GB of RAM and a few minutes:
 
-    make -C oracle ref && python tests/golden/make_fullsize.py [c3] [c2] [c4]
+    make -C oracle ref && python tests/golden/make_fullsize.py [c3] [c2] [c4] [c4all] [c5]
 
   C3  regexdna: the nine patterns over the stripped 50M-line FASTA (500 000 000 bytes, rejit_amd.workloads), reference
       with use_fast_forward=1 / use_ff_reduce=0 (its correct fast configuration) AND with
@@ -13,6 +13,11 @@ exists and oracle/_ref has been built, and needs ~20 GB of RAM and a few minutes
   C4  the complex benchmark regex over rank 0's shard of bench.py --workload complex --gpus 8 --literal-bytes 6250000000:
       the bytes [0, 6 250 000 057) of the stream with the job's planted samples, matches that BEGIN before the cut;
       use_fast_forward=0 (the fast path mis-places matches of this regex).
+
+  C4ALL every one of the eight shards of that job (round 4), each with 64 KiB of left context: the matches that begin in
+      the shard's own range, as global offsets; use_fast_forward=0.
+  C5  bench.py's jrep_10gb tree (100 000 files, 10 GB): per file the reference's MatchAll count of `regexp` and, for the
+      files with a match, of `^` -- what sample/jrep.cc:288-294 computes -- as totals and a sha256 of the rows.
 
 What is stored is data: the inputs' generator parameters and the expected counts / digests."""
 import ctypes
@@ -121,6 +126,73 @@ def main():
                      "world": world, "bytes_per_gpu": per, "visible_bytes": int(vis_hi), "own_end": int(own[1]), "regex": rx,
                      "reference_flags": "use_fast_forward=0", "digest": d}
         del text
+    if "c4all" in which:
+        # Every shard of the 8-GPU job (BASELINE configs[3]: 50 GB), one after the other: the reference over the shard's
+        # bytes plus 64 KiB of left context (a fresh run there agrees with the run over the whole text from the first gap
+        # without a match on -- asserted), matches that BEGIN in the shard's own range, as global offsets.  The digests
+        # are sums: the whole job's digest is the sum of the shards'.
+        world, per = 8, 6_250_000_000
+        rx = W.BENCH_REGEXES[3][0]
+        n_total = per * world
+        ranges = sharding.partition(n_total, world)
+        cuts = [r[0] for r in ranges[1:]]
+        rng = random.Random(7)
+        needles = [(o, W.complex_regex_sample(rng)) for o in W.plant_offsets(n_total, 64, 200 * world, seed=7, boundaries=cuts)]
+        left = 1 << 16
+        shards = []
+        for r in range(world):
+            own = ranges[r]
+            lo = max(0, own[0] - left)
+            hi = min(n_total, own[1] + 58)
+            t0 = time.time()
+            text = random_ascii_big(hi - lo, 0xC0FFEE, start=lo)
+            for o, smp in needles:
+                a, b = max(o, lo), min(o + len(smp), hi)
+                if a < b:
+                    W.plant(text, [a - lo], smp[a - o:b - o])
+            t1 = time.time()
+            sp = ref_spans(ref, FF0, rx.encode(), text) + np.uint64(lo)
+            before = sp[sp[:, 0] < np.uint64(own[0])]
+            if r > 0:
+                # a gap without a match between the fresh start and the own range: both runs agree from there on
+                edges = [lo] + [int(e) for e in before[:, 1]]
+                starts = [int(b) for b in before[:, 0]] + [own[0]]
+                assert any(s_ - e_ > 64 for e_, s_ in zip(edges, starts)), "no gap in the left context of shard %d" % r
+            mine = sp[(sp[:, 0] >= np.uint64(own[0])) & (sp[:, 0] < np.uint64(min(own[1], n_total + 1)))]
+            d = W.span_digest_numpy(mine)
+            carry = [int(before[-1, 0]), int(before[-1, 1])] if len(before) else None
+            print("  shard %d: bytes [%d, %d), %d matches begin in it (text %.0f s, reference ff off %.0f s)" % (r, own[0], own[1], d["count"], t1 - t0, time.time() - t1), flush=True)
+            shards.append({"rank": r, "own": [int(own[0]), int(min(own[1], n_total + 1))], "digest": d, "last_match_before": carry})
+            del text
+        doc["c4all"] = {"text": "bench.py --workload complex --gpus 8 --literal-bytes 6250000000: random_ascii(seed 0xC0FFEE) with the job's planted "
+                                "complex_regex_sample strings; per shard the matches that begin in its own range, global offsets",
+                        "world": world, "bytes_per_gpu": per, "regex": rx, "reference_flags": "use_fast_forward=0", "shards": shards,
+                        "total_count": sum(x["digest"]["count"] for x in shards)}
+    if "c5" in which:
+        # BASELINE configs[4] at its size: bench.py's jrep_10gb tree (100 000 files, 10 GB), the reference's own jrep logic
+        # (sample/jrep.cc:288-294: MatchAll per file, then `^` MatchAll of every file with a match), per file
+        import bench
+        n_files, total_bytes = 100_000, 10_000_000_000
+        t0 = time.time()
+        files = bench.jrep_tree(n_files, total_bytes)
+        print("C5 tree: %d files, %d bytes in %.0f s" % (n_files, sum(len(f) for f in files), time.time() - t0), flush=True)
+        ref.set_flags(*FAST)
+        t0 = time.time()
+        rows = []
+        for i, f in enumerate(files):
+            k = int(ref.lib.ref_match_all_repeat(b"regexp", f, len(f), 1))
+            if k:
+                l = int(ref.lib.ref_match_all_repeat(b"^", f, len(f), 1))
+                rows.append((i, k, l))
+        print("  %d files with matches, %d matches, %d line starts (reference, %.0f s)" % (len(rows), sum(r[1] for r in rows), sum(r[2] for r in rows), time.time() - t0), flush=True)
+        # cross-check of the literal with Python on a sample of the files
+        for i in range(0, n_files, 997):
+            assert (files[i].count(b"regexp") > 0) == any(r[0] == i for r in rows), i
+        doc["c5"] = {"text": "bench.jrep_tree(100000, 10000000000): log-normal file sizes, ` regexp ` in every hundredth file", "files": n_files,
+                     "bytes_asked": total_bytes, "bytes": int(sum(len(f) for f in files)), "regex": "regexp", "line_regex": "^",
+                     "reference_flags": "use_fast_forward=1,use_ff_reduce=0", "files_with_matches": len(rows), "matches": int(sum(r[1] for r in rows)),
+                     "line_starts": int(sum(r[2] for r in rows)), "sha256": bench.jrep_digest(rows)}
+        del files
     with open(OUT, "w") as fh:
         json.dump(doc, fh, indent=1)
     print("wrote", OUT)

@@ -143,6 +143,30 @@ def test_own_regexdna_counterpart(tmp_path):
     assert [int(x) for x in lines[-3:]] == [508411, 500000, 668262]
 
 
+@pytest.mark.parametrize("nf,mode", [(50000, "--timing"), (50000, "--serial"), (5000000, "--timing")])
+def test_native_regexdna_counterpart(tmp_path, nf, mode):
+    """samples/regexdna_gpu (C++ over the C ABI: one upload, strip / nine counts in one pass / eleven replacements all on the
+    device, the counts and the replacements in flight together) prints byte for byte what the reference's own program
+    prints on this library (oracle/_ref/regexdna_hip: sample/regexdna.cc unchanged) and the canonical answers."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "samples")], stdout=subprocess.DEVNULL)
+    fasta = tmp_path / "in.fasta"
+    fasta.write_bytes(W.fasta_raw_numpy(nf).tobytes())
+    with open(fasta, "rb") as f:
+        r = subprocess.run([os.path.join(ROOT, "samples", "regexdna_gpu"), mode], stdin=f, capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = r.stdout.decode()
+    lines = out.strip().split("\n")
+    assert [l.rsplit(" ", 1)[0] for l in lines[:9]] == W.REGEXDNA_PATTERNS
+    if nf == 50000:
+        assert [int(l.rsplit(" ", 1)[1]) for l in lines[:9]] == [3, 12, 43, 27, 58, 16, 15, 18, 20]
+        assert [int(x) for x in lines[-3:]] == [508411, 500000, 668262]
+    exe = os.path.join(ROOT, "oracle", "_ref", "regexdna_hip")
+    if os.path.exists(exe):
+        with open(fasta, "rb") as f:
+            want = subprocess.run([exe], stdin=f, capture_output=True, timeout=900, check=True).stdout.decode()
+        assert out == want
+
+
 REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 
 

@@ -3,7 +3,9 @@ inputs, stored as counts + span digests in tests/golden/fullsize_vectors.json (g
 tests/golden/make_fullsize.py from oracle/_ref, the reference compiled in place).
   C3  the nine regexdna patterns over the stripped 50M-line FASTA (500 MB): one-pass run (plane scan) and single runs
   C2  literal `regexp` over 5 GB of random ASCII with 1000 planted occurrences
-  C4  the complex benchmark regex over rank 0's 6.25 GB shard of the 8-GPU job (own range + 58-byte halo)"""
+  C4  the complex benchmark regex over rank 0's 6.25 GB shard of the 8-GPU job (own range + 58-byte halo), and (round 4)
+      ALL eight shards one after the other with the selection carried over the seven cuts
+  C5  bench.py's 100 000-file / 10 GB tree: per-file match and line-start counts against the reference's jrep logic"""
 import json
 import os
 import random
@@ -86,3 +88,78 @@ def test_c4_complex_shard_of_8(env):
     k = sc.run(t.data_ptr(), vis_hi, own_begin=0, own_end=own[1], stream=torch.cuda.current_stream(dev).cuda_stream)
     assert k == c4["digest"]["count"]
     assert digest_of(W, sc, dev) == c4["digest"]
+
+
+def test_c4_all_eight_shards_with_the_carry(env):
+    """BASELINE configs[3] at its size, the WHOLE job on one GPU, shard after shard: every one of the eight 6.25 GB shards
+    (own range + 58-byte halo, 64 bytes of left context) with the selection carried over the seven cuts exactly as the
+    multi-GPU run carries it (the last match before the cut: carry_cur / carry_prev_end), each shard's spans -- global
+    offsets -- against the real reference's answer for that shard, and the total against the sum."""
+    rj, W, torch, dev, doc = env
+    from rejit_amd import sharding
+    if "c4all" not in doc:
+        pytest.skip("tests/golden/fullsize_vectors.json has no c4all section (make_fullsize.py c4all)")
+    c4 = doc["c4all"]
+    world, per = c4["world"], c4["bytes_per_gpu"]
+    n_total = per * world
+    ranges = sharding.partition(n_total, world)
+    cuts = [r[0] for r in ranges[1:]]
+    rng = random.Random(7)
+    needles = [(o, W.complex_regex_sample(rng)) for o in W.plant_offsets(n_total, 64, 200 * world, seed=7, boundaries=cuts)]
+    sc = rj.Scan(rj.Program(c4["regex"]))
+    st = torch.cuda.current_stream(dev).cuda_stream
+    carry = (0, 0, False)   # (cur, prev_end, have) in GLOBAL offsets
+    total = 0
+    for shard in c4["shards"]:
+        r = shard["rank"]
+        own = ranges[r]
+        vis_lo, vis_hi = sharding.visible_range(n_total, own, 58)
+        vis_lo &= ~15
+        assert [own[0], min(own[1], n_total + 1)] == shard["own"]
+        t = W.random_ascii_torch(vis_hi - vis_lo, 0xC0FFEE, dev, start=vis_lo)
+        for o, s in needles:
+            lo, hi = max(o, vis_lo), min(o + len(s), vis_hi)
+            if lo < hi:
+                W.plant(t, [lo - vis_lo], s[lo - o:hi - o])
+        have = carry[2] and carry[1] >= vis_lo
+        k = sc.run(t.data_ptr(), vis_hi - vis_lo, own_begin=own[0] - vis_lo, own_end=min(own[1], n_total + 1) - vis_lo,
+                   carry_cur=max(carry[0] - vis_lo, 0) if have else 0, carry_prev_end=carry[1] - vis_lo if have else 0, have_prev=have, stream=st)
+        sp = sc.spans_tensor(dev) + vis_lo
+        assert k == shard["digest"]["count"], (r, k, shard["digest"]["count"])
+        assert W.span_digest_torch(sp) == shard["digest"], r
+        if k:
+            b, e = int(sp[-1, 0]), int(sp[-1, 1])
+            carry = (e if e > b else b + 1, e, True)
+        total += k
+        del t, sp
+        torch.cuda.empty_cache()
+    assert total == c4["total_count"]
+
+
+def test_c5_jrep_tree_at_baseline_size(env):
+    """BASELINE configs[4] at its size: bench.py's 100 000-file / 10 GB tree through rj_match_all_batch in 256 MiB batches
+    + the `^` line tables of the files with matches -- files with matches, matches and line starts PER FILE against the real
+    reference's jrep logic over the same files (sample/jrep.cc:288-294), as totals and a sha256 of the rows."""
+    rj, W, torch, dev, doc = env
+    if "c5" not in doc:
+        pytest.skip("tests/golden/fullsize_vectors.json has no c5 section (make_fullsize.py c5)")
+    import sys
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    c5 = doc["c5"]
+    files = bench.jrep_tree(c5["files"], c5["bytes_asked"])
+    assert sum(len(f) for f in files) == c5["bytes"]
+    prog, sol = rj.Program(c5["regex"].encode()), rj.Program(c5["line_regex"].encode())
+    rows, at, n_files = [], 0, len(files)
+    while at < n_files:
+        b, size = at, 0
+        while at < n_files and (at == b or size + len(files[at]) <= (256 << 20)):
+            size += len(files[at])
+            at += 1
+        res = prog.match_all_batch_counts(files[b:at])
+        idx = [b + i for i, k in enumerate(res) if k]
+        if idx:
+            lc = sol.match_all_batch_counts([files[i] for i in idx])
+            rows.extend((i, res[i - b], l) for i, l in zip(idx, lc))
+    assert (len(rows), sum(r[1] for r in rows), sum(r[2] for r in rows)) == (c5["files_with_matches"], c5["matches"], c5["line_starts"])
+    assert bench.jrep_digest(rows) == c5["sha256"]
