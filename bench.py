@@ -756,6 +756,32 @@ def literal_and_complex_extras(args, c, out):
     out["behind_scan"] = single_pattern_extra(
         c, rejit_amd, t, n, rxb, "%s MatchAll over the same %d bytes (window behind an unbounded prefix)" % (rxb, n),
         "scan_windows<1> + verify_behind_lds", 5, check_behind, "behind", True, args)
+    # A one-pass run of a pattern set that is NOT the regexdna shape (round 4: plane_scan_general): two literal alternations of
+    # the reference's benchmark regexes (tools/benchmarks/run.py:352,356), windows of 7 / 8 bytes at offsets 0 / 1, four
+    # base windows compared exactly as 2-bit codes over an alphabet of 74 symbols (codes alias: a filter).
+    try:
+        gset = ["alternation|strings", "prefix abcd|prefix 1234"]
+        for k, o in enumerate(W.plant_offsets(n, 32, 400, seed=11)):
+            W.plant(t, [o], [b"alternation", b"strings", b"prefix abcd", b"prefix 1234"][k % 4])
+        gprogs = [rejit_amd.Program(rx) for rx in gset]
+        gmulti = rejit_amd.MultiScan(gprogs)
+        gcounts = gmulti.run(t.data_ptr(), n, stream=c.stream)
+        ghow = gmulti.how
+        gsingle = [rejit_amd.Scan(p).run(t.data_ptr(), n, stream=c.stream) for p in gprogs]
+        gms, gwall = [], []
+        for _ in range(10):
+            t0g = time.perf_counter()
+            gmulti.run(t.data_ptr(), n, stream=c.stream)
+            gwall.append(time.perf_counter() - t0g)
+            gms.append(gmulti.scan_ms())
+        gmed = sorted(gwall)[len(gwall) // 2]
+        out["general_one_pass"] = {"workload": "%s over the same %d bytes in ONE pass (plane_scan_general: 4 exact base windows of 7 bytes, offsets 0 and 1)" % (" + ".join(gset), n),
+                                   "how": ghow, "counts": gcounts, "counts_equal_single_runs": gcounts == gsingle,
+                                   "latency_ms": round(gmed * 1e3, 4), "value": round(n / gmed / 1e9, 1), "unit": "GB/s of text (once for both patterns)",
+                                   "roofline": hbm_roofline("plane_scan_general<4,exact>", n, sum(gms) / len(gms), None, len(gms))}
+        del gmulti, gprogs
+    except Exception as e:  # noqa: BLE001 (an extra must never cost the line)
+        out["general_one_pass"] = {"error": repr(e)[:300]}
     # Patterns WITHOUT a fast-forward window (the NFA half of the north star): scan_dense_walk finds, walks and
     # compacts the candidates in one kernel.  `[a-f]+[0-9]`: a start at 8 % of the bytes of this text (only the
     # first byte of every run of [a-f] is taken, DevProgram::loop_first); the first four automaton steps of all

@@ -257,14 +257,16 @@ void launch_tails_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_reg
 // travels as ONE blob that every workgroup copies into LDS: ClassifyDesc[n_patterns] (padded to 16 bytes), then
 // the patterns' automaton tables one after the other (each padded to 4 words), <= kClassifyMaxTableWords in all.
 constexpr uint32_t kClassifyMaxTableWords = 12288;
+constexpr int kClassifyMaxWindows = 4;
 struct ClassifyDesc {
-  uint32_t n_windows;
-  uint32_t v0[2], m0[2], v1[2], m1[2];
+  uint32_t n_windows;   // <= kClassifyMaxWindows (classify_shared_multi, the regexdna shape, looks at the first two)
+  uint32_t v0[kClassifyMaxWindows], m0[kClassifyMaxWindows], v1[kClassifyMaxWindows], m1[kClassifyMaxWindows];
   uint32_t tab;         // the pattern's tables, word offset behind the descriptors
   uint32_t n_words, n_pos, n_rows, short_max, nullable;
   uint32_t rowbits[2];  // non-linear positions whose follow set is not empty
   uint32_t region_cap;
-  uint32_t pad[2];      // (the pointers below start on an 8-byte boundary without implicit padding)
+  uint32_t win_offset, win_len;  // classify_shared_general: the pattern's own window offset and length
+  // (28 32-bit words: the pointers below start on an 8-byte boundary without implicit padding)
   uint64_t* begins;     // the pattern's own regions
   uint64_t* ends;
   uint32_t* valid_counts;
@@ -286,6 +288,28 @@ struct SharedHits {
 // max_words / max_short: the largest n_words / short_max among the patterns (selects the kernel instantiation)
 void launch_tails_shared(const MultiTail* d_tails, const SharedHits& sh, int max_words, uint32_t max_short, unsigned long long* counters0,
                          hipStream_t st);
+// The general one-pass scan (round 4): any set of patterns with fixed-offset windows of >= 4 bytes and short bounded
+// automata.  The windows' first n_cmp bytes are compared, as 2-bit codes (byte >> code_shift) & 3 -- codes may alias:
+// a superset test like every fast-forward filter --, with <= kPlaneMaxBases base windows, exactly (tolerance 0) or up to
+// one differing code (tolerance 1: windows with a class byte).  Candidates are WINDOW POSITIONS (the patterns' offsets
+// differ); classify_shared_general applies every pattern's own offset, exact window test (<= 4 windows) and automaton.
+constexpr int kPlaneMaxBases = 4;  // (eight: 128 uniform masks no longer fit the scalar registers -- the compiler moved them to 254 VGPRs)
+struct PlaneGParams {
+  const uint8_t* text;
+  uint64_t n;
+  uint64_t wlo, whi;     // window positions to look at
+  uint64_t span_pairs;
+  uint32_t code_shift, n_bases, n_cmp, tolerance;
+  uint32_t lo[kPlaneMaxBases][8], hi[kPlaneMaxBases][8];
+  uint64_t* hits;
+  uint32_t region_cap;
+  uint32_t* hit_counts;
+  uint32_t n_zero;
+  unsigned long long* zero_counters[kMaxFused];
+};
+void launch_plane_scan_general(const PlaneGParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
+void launch_tails_shared_general(const MultiTail* d_tails, const SharedHits& sh, int max_words, uint32_t max_short, unsigned long long* counters0,
+                                 hipStream_t st);
 void launch_offsets_gather_check_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_regions, hipStream_t st);
 // plane_scan + classify_shared_multi as ONE kernel (plane_scan.hip, round 4): a wave keeps its span's candidates in LDS and
 // classifies them at the end of the span; sh.hits / sh.counts / sh.cap are unused.  The kernel does not clear the

@@ -63,7 +63,10 @@ void nibble_window(const DevProgram& D, int k, uint32_t* value, uint32_t* mask) 
 struct PlanePlan {
   bool ok = false;
   uint32_t code_shift = 0, n_bases = 0, offset = 0;
-  uint8_t base[2][8] = {};
+  uint8_t base[kPlaneMaxBases][8] = {};
+  // the general plan (plan_plane_general): windows of differing offsets / lengths, any alphabet, <= 4 bases
+  bool general = false;
+  uint32_t n_cmp = 8, tolerance = 1, min_offset = 0, max_offset = 0;
 };
 
 PlanePlan plan_plane(const std::vector<rj_scan*>& scans) {
@@ -137,6 +140,115 @@ PlanePlan plan_plane(const std::vector<rj_scan*>& scans) {
       return pl;
     }
   }
+  return pl;
+}
+
+// The general plan (plane_scan_general): every pattern has 1..4 fixed-offset windows of >= 4 bytes and a short bounded
+// automaton; the windows' first n_cmp bytes (n_cmp = the shortest window of the set) are covered by <= 4 base windows,
+// exactly (tolerance 0: all of them literals) or within one byte (a window with ONE class position).  Codes are
+// (byte >> shift) & 3 with the shift under which the bases' bytes take the most distinct codes; they may alias -- the
+// test is a filter.  Refused when the filter would pass more than one position in 128 of uniform codes.
+bool plane_general_ok(const rj_program* rp) {
+  const DevProgram& D = rp->dev;
+  return D.mode == 1 && D.float_range == 1 && !D.behind && !rp->host->q8_risk && D.short_max != 0 && D.n_words <= 2 && D.win_len >= 4 &&
+         D.n_windows >= 1 && D.n_windows <= kClassifyMaxWindows;
+}
+
+PlanePlan plan_plane_general(const std::vector<rj_scan*>& scans) {
+  PlanePlan pl;
+  struct Win {
+    uint8_t v[8];
+    bool fixed[8];
+  };
+  std::vector<Win> wins;
+  uint32_t table_words = 0, n_cmp = 8, min_off = ~0u, max_off = 0;
+  for (rj_scan* sc : scans) {
+    if (!plane_general_ok(sc->prog)) return pl;
+    const DevProgram& D = sc->prog->dev;
+    table_words += (D.table_words + 3u) & ~3u;
+    if (table_words > kClassifyMaxTableWords) return pl;
+    n_cmp = std::min<uint32_t>(n_cmp, D.win_len);
+    min_off = std::min(min_off, D.win_offset);
+    max_off = std::max(max_off, D.win_offset);
+  }
+  for (rj_scan* sc : scans) {
+    const DevProgram& D = sc->prog->dev;
+    for (int k = 0; k < D.n_windows; k++) {
+      Win w;
+      for (int i = 0; i < 8; i++) {
+        const uint32_t vb = (i < 4 ? (D.win_value0[k] >> (8 * i)) : (D.win_value1[k] >> (8 * (i - 4)))) & 0xFFu;
+        const uint32_t mb = (i < 4 ? (D.win_mask0[k] >> (8 * i)) : (D.win_mask1[k] >> (8 * (i - 4)))) & 0xFFu;
+        if (mb != 0 && mb != 0xFFu) return pl;
+        w.v[i] = static_cast<uint8_t>(vb);
+        w.fixed[i] = mb != 0 && static_cast<uint32_t>(i) < n_cmp;
+      }
+      wins.push_back(w);
+    }
+  }
+  auto off = [&](const Win& w, const uint8_t* base) {  // compared bytes in which w is free or differs from base
+    int d = 0;
+    for (uint32_t i = 0; i < n_cmp; i++) d += (!w.fixed[i] || w.v[i] != base[i]) ? 1 : 0;
+    return d;
+  };
+  auto exact = [&](const Win& w) {
+    for (uint32_t i = 0; i < n_cmp; i++)
+      if (!w.fixed[i]) return false;
+    return true;
+  };
+  int nb = 0;
+  uint32_t tol = 0;
+  for (uint32_t tol_try = 0; tol_try <= 1; tol_try++) {
+    nb = 0;
+    bool ok = true;
+    for (int pass = 0; pass < 2 && ok; pass++)
+      for (const Win& w : wins) {
+        bool covered = false;
+        for (int b = 0; b < nb; b++) covered = covered || off(w, pl.base[b]) <= static_cast<int>(tol_try);
+        if (covered) continue;
+        if (pass == 0 && exact(w) && nb < kPlaneMaxBases) memcpy(pl.base[nb++], w.v, 8);
+        else if (pass == 1) ok = false;
+      }
+    if (ok && nb > 0) {
+      tol = tol_try;
+      break;
+    }
+    nb = 0;
+  }
+  if (nb == 0) return pl;
+  // the shift under which the bases' bytes take the most distinct codes
+  int best_sh = -1, best_distinct = 0;
+  for (int sh = 0; sh <= 6; sh++) {
+    // per compared position the number of distinct codes would be ideal; the total over the bases' bytes is a good proxy
+    bool seen_pair[256][4] = {};
+    uint32_t codes_seen = 0;
+    int distinct_bytes_apart = 0;
+    for (int b = 0; b < nb; b++)
+      for (uint32_t i = 0; i < n_cmp; i++) {
+        const uint32_t c = (static_cast<uint32_t>(pl.base[b][i]) >> sh) & 3u;
+        if (!seen_pair[pl.base[b][i]][c]) {
+          seen_pair[pl.base[b][i]][c] = true;
+          if (!((codes_seen >> c) & 1u)) distinct_bytes_apart++;
+          codes_seen |= 1u << c;
+        }
+      }
+    if (distinct_bytes_apart > best_distinct) {
+      best_distinct = distinct_bytes_apart;
+      best_sh = sh;
+    }
+  }
+  if (best_sh < 0 || best_distinct < 2) return pl;
+  // expected pass rate over uniform codes: n_bases x (1 + 3 n_cmp tol) / 4^n_cmp
+  double rate = static_cast<double>(nb) * (1.0 + 3.0 * n_cmp * tol);
+  for (uint32_t i = 0; i < n_cmp; i++) rate /= 4.0;
+  if (rate > 1.0 / 128.0) return pl;
+  pl.ok = pl.general = true;
+  pl.code_shift = static_cast<uint32_t>(best_sh);
+  pl.n_bases = static_cast<uint32_t>(nb);
+  pl.n_cmp = n_cmp;
+  pl.tolerance = tol;
+  pl.min_offset = min_off;
+  pl.max_offset = max_off;
+  pl.offset = 0;
   return pl;
 }
 
@@ -221,13 +333,15 @@ int classify_blob(rj_multi* m, hipStream_t st) {
     const DevProgram& D = t.program;
     ClassifyDesc& d = m->host_desc[p];
     d = ClassifyDesc{};
-    d.n_windows = static_cast<uint32_t>(std::min(D.n_windows, 2));
-    for (int q = 0; q < 2; q++) {
+    d.n_windows = static_cast<uint32_t>(std::min(D.n_windows, kClassifyMaxWindows));
+    for (int q = 0; q < kClassifyMaxWindows; q++) {
       d.v0[q] = D.win_value0[q];
       d.m0[q] = D.win_mask0[q];
       d.v1[q] = D.win_value1[q];
       d.m1[q] = D.win_mask1[q];
     }
+    d.win_offset = D.win_offset;
+    d.win_len = D.win_len;
     d.tab = off;
     d.n_words = static_cast<uint32_t>(D.n_words);
     d.n_pos = static_cast<uint32_t>(D.n_pos);
@@ -285,12 +399,15 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
   // window positions [wlo, whi) in pairs of chunks
   static const bool no_plane = getenv("RJ_NO_PLANE") != nullptr;  // measurement override
   const bool plane = fuse && m->mode == 0 && m->plane.ok && !no_plane;
-  uint64_t plane_pairs = 0;
+  if (fuse && m->plane.general && !plane) fuse = false;  // (a general set has no other one-pass kernel: separate scans, batched tails)
+  uint64_t plane_pairs = 0, plane_wlo = 0, plane_whi = 0;
   if (plane) {
-    const uint64_t wlo = sb + m->plane.offset;
-    const uint64_t last_w = n >= 8 ? n - 8 + 1 : 0;
-    const uint64_t whi = std::min<uint64_t>(se + m->plane.offset, last_w);
-    plane_pairs = whi > wlo ? (whi + 2047) / 2048 - wlo / 2048 : 0;
+    // window positions that can belong to a start in [sb, se): the general plan's patterns have their own offsets
+    const uint32_t cmp = m->plane.general ? m->plane.n_cmp : 8u;
+    plane_wlo = sb + (m->plane.general ? m->plane.min_offset : m->plane.offset);
+    const uint64_t last_w = n >= cmp ? n - cmp + 1 : 0;
+    plane_whi = std::min<uint64_t>(se + (m->plane.general ? m->plane.max_offset : m->plane.offset), last_w);
+    plane_pairs = plane_whi > plane_wlo ? (plane_whi + 2047) / 2048 - plane_wlo / 2048 : 0;
     chunks = std::max<uint64_t>(plane_pairs * 2, 1);
   }
   // (plane scan, 500 MB: 96 chunks per workgroup measured best -- 92 us against 98 at 128, 96 at 64)
@@ -420,7 +537,35 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       // other, only the other run's latency-bound tails overlap this scan
       RJ_HIP(hipStreamWaitEvent(st, m->scan_after->scans[0]->ev[2], 0));
     }
-    if (plane) {
+    if (plane && m->plane.general) {
+      PlaneGParams pg{};
+      pg.text = d_text;
+      pg.n = n;
+      pg.wlo = plane_wlo;
+      pg.whi = plane_whi;
+      pg.span_pairs = std::max<uint64_t>((plane_pairs + geo.n_regions - 1) / geo.n_regions, 1);
+      pg.code_shift = m->plane.code_shift;
+      pg.n_bases = m->plane.n_bases;
+      pg.n_cmp = m->plane.n_cmp;
+      pg.tolerance = m->plane.tolerance;
+      for (uint32_t b = 0; b < kPlaneMaxBases; b++)
+        for (int i = 0; i < 8; i++) {
+          const uint32_t code = (static_cast<uint32_t>(m->plane.base[b < m->plane.n_bases ? b : 0][i]) >> m->plane.code_shift) & 3u;
+          pg.lo[b][i] = (code & 1u) ? 0u : ~0u;
+          pg.hi[b][i] = (code & 2u) ? 0u : ~0u;
+        }
+      shared_cap = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint32_t>(m->shared_cap_hint, 64), pg.span_pairs * 2048));
+      RJ_HIP(m->shared_hits.reserve(static_cast<size_t>(geo.n_regions) * shared_cap * sizeof(uint64_t)));
+      RJ_HIP(m->shared_counts.reserve(static_cast<size_t>(geo.n_regions) * sizeof(uint32_t)));
+      pg.hits = m->shared_hits.as<uint64_t>();
+      pg.region_cap = shared_cap;
+      pg.hit_counts = m->shared_counts.as<uint32_t>();
+      pg.n_zero = static_cast<uint32_t>(P);
+      for (int p = 0; p < P; p++) pg.zero_counters[p] = m->scans[static_cast<size_t>(p)]->counters.as<unsigned long long>();
+      fused_launched = false;
+      m->flags_clean = false;
+      launch_plane_scan_general(pg, geo.grid, s0->ev[1], s0->ev[2], st);
+    } else if (plane) {
       PlaneParams pp{};
       pp.text = d_text;
       pp.n = n;
@@ -579,7 +724,8 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
         max_words = std::max(max_words, static_cast<int>(D.n_words));
         max_short = std::max(max_short, D.short_max);
       }
-      launch_tails_shared(m->tails.as<MultiTail>(), sh, max_words, max_short, s0->counters.as<unsigned long long>(), ts);
+      if (m->plane.general) launch_tails_shared_general(m->tails.as<MultiTail>(), sh, max_words, max_short, s0->counters.as<unsigned long long>(), ts);
+      else launch_tails_shared(m->tails.as<MultiTail>(), sh, max_words, max_short, s0->counters.as<unsigned long long>(), ts);
     } else {
       launch_tails_multi(m->tails.as<MultiTail>(), P, geo.n_regions, ts);
     }
@@ -716,6 +862,14 @@ int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out)
   }
   m->fused = all && n_progs > 1 && getenv("RJ_NO_FUSION") == nullptr;
   if (m->fused) m->plane = plan_plane(m->scans);
+  if (!m->plane.ok && n_progs > 1 && getenv("RJ_NO_FUSION") == nullptr && getenv("RJ_NO_PLANE") == nullptr && getenv("RJ_NO_PLANE_GENERAL") == nullptr) {
+    // not the regexdna shape: the general one-pass plan (round 4)
+    const PlanePlan g = plan_plane_general(m->scans);
+    if (g.ok) {
+      m->plane = g;
+      m->fused = true;
+    }
+  }
   m->batchable = all_batchable && n_progs > 1;
   {
     std::lock_guard<std::mutex> lock(live_multi_mutex());

@@ -691,6 +691,250 @@ bool launch_plane_scan_classify(const PlaneParams& a, const SharedHits& sh, int 
 }
 
 
+// ---------------------------------------------------------------------------------------
+// The GENERAL one-pass scan (round 4; kernels.h: PlaneGParams): up to 4 base windows, their first n_cmp (4..8) bytes
+// compared exactly or with one differing code, any alphabet (codes alias), candidates = window positions.
+namespace {
+
+template <int NB, bool TOL>
+__device__ __forceinline__ uint32_t plane_candidates_general(const uint32_t (&dA)[6], const uint32_t (&dB)[6], const PlaneConsts& k,
+                                                             const PlaneGParams& a) {
+  const uint32_t s = k.shift;
+  const uint32_t ta = (codes4(dA[0], k) >> s) | (codes4(dA[1], k) << (8 - s)) | (codes4(dA[2], k) << (16 - s)) | (codes4(dA[3], k) << (24 - s));
+  const uint32_t tb = (codes4(dB[0], k) >> s) | (codes4(dB[1], k) << (8 - s)) | (codes4(dB[2], k) << (16 - s)) | (codes4(dB[3], k) << (24 - s));
+  const uint32_t ha = (codes4(dA[4], k) >> s) | (codes4(dA[5], k) << (8 - s));
+  const uint32_t hb = (codes4(dB[4], k) >> s) | (codes4(dB[5], k) << (8 - s));
+  constexpr uint32_t kEven = 0x55555555u;
+  const uint32_t L = (ta & kEven) | ((tb << 1) & ~kEven);
+  const uint32_t H = ((ta >> 1) & kEven) | (tb & ~kEven);
+  const uint32_t Ln = (ha & kEven) | ((hb << 1) & ~kEven);
+  const uint32_t Hn = ((ha >> 1) & kEven) | (hb & ~kEven);
+  uint32_t Z[NB], O[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    Z[b] = ~0u;
+    O[b] = ~0u;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    if (static_cast<uint32_t>(i) >= a.n_cmp) break;  // (wave-uniform: windows shorter than 8 bytes)
+    const uint32_t Li = i ? __builtin_amdgcn_alignbit(Ln, L, 2 * i) : L;
+    const uint32_t Hi = i ? __builtin_amdgcn_alignbit(Hn, H, 2 * i) : H;
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      const uint32_t E = (Li ^ a.lo[b][i]) & (Hi ^ a.hi[b][i]);
+      if (TOL) O[b] = i == 0 ? ~0u : (Z[b] | (O[b] & E));   // at most one code differs so far
+      Z[b] &= E;                                              // none differs so far
+    }
+  }
+  uint32_t c = 0;
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+    if (static_cast<uint32_t>(b) < a.n_bases) c |= TOL ? O[b] : Z[b];
+  return c;
+}
+
+}  // namespace
+
+template <int NB, bool TOL>
+__global__ __launch_bounds__(256) void plane_scan_general(PlaneGParams a) {
+  const int lane = lane_id();
+  const uint64_t wave = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6));
+  if (wave == 0 && lane < kCntSize)
+    for (uint32_t p = 0; p < a.n_zero; p++) a.zero_counters[p][lane] = 0;
+  PlaneConsts k;
+  k.shift = a.code_shift;
+  k.cmask = 0x03030303u << a.code_shift;
+  SharedRegion region{a.hits + wave * a.region_cap, a.region_cap, 0u};
+  const uint64_t first_pair = a.wlo / kPair;
+  const uint64_t end_pair = a.whi > a.wlo ? (a.whi + kPair - 1) / kPair : first_pair;
+  uint64_t c0 = first_pair + wave * a.span_pairs, c1 = c0 + a.span_pairs;
+  if (c0 > end_pair) c0 = end_pair;
+  if (c1 > end_pair) c1 = end_pair;
+  uint64_t fast_end = a.n >= kPair + 8 ? (a.n - 8) / kPair : 0;
+  if (fast_end > c1) fast_end = c1;
+  if (fast_end < c0) fast_end = c0;
+  const uint64_t lane_off = static_cast<uint64_t>(lane) * 16;
+  auto pair = [&](const uint32_t (&dA)[6], const uint32_t (&dB)[6], uint64_t at) {
+    const uint32_t hm = plane_candidates_general<NB, TOL>(dA, dB, k, a);
+    if (__ballot(hm != 0) == 0) return;
+    push_pair(region, hm, at, 0);   // (the slot holds the WINDOW position; classify_shared_general clips)
+  };
+  {
+    uint32_t a0[6], b0[6], a1[6], b1[6];
+    uint64_t c = c0;
+    if (c + 3 < fast_end) {
+      load_chunk24(a.text, c * kPair + lane_off, a0);
+      load_chunk24(a.text, c * kPair + kChunk + lane_off, b0);
+      load_chunk24(a.text, (c + 1) * kPair + lane_off, a1);
+      load_chunk24(a.text, (c + 1) * kPair + kChunk + lane_off, b1);
+      while (c + 3 < fast_end) {
+        pair(a0, b0, c * kPair + lane_off);
+        load_chunk24(a.text, (c + 2) * kPair + lane_off, a0);
+        load_chunk24(a.text, (c + 2) * kPair + kChunk + lane_off, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        pair(a1, b1, (c + 1) * kPair + lane_off);
+        load_chunk24(a.text, (c + 3) * kPair + lane_off, a1);
+        load_chunk24(a.text, (c + 3) * kPair + kChunk + lane_off, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        c += 2;
+      }
+      pair(a0, b0, c * kPair + lane_off);
+      pair(a1, b1, (c + 1) * kPair + lane_off);
+      c += 2;
+    }
+    for (; c < fast_end; c++) {
+      load_chunk24(a.text, c * kPair + lane_off, a0);
+      load_chunk24(a.text, c * kPair + kChunk + lane_off, b0);
+      pair(a0, b0, c * kPair + lane_off);
+    }
+  }
+  for (uint64_t t = fast_end; t < c1; t++) {
+    uint32_t dA[6], dB[6];
+    load_guarded24(a.text, a.n, t * kPair + lane_off, dA);
+    load_guarded24(a.text, a.n, t * kPair + kChunk + lane_off, dB);
+    pair(dA, dB, t * kPair + lane_off);
+  }
+  if (lane == 0) a.hit_counts[wave] = region.count;
+}
+
+void launch_plane_scan_general(const PlaneGParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+  const dim3 g(grid), b(256);
+#define RJ_LAUNCH_PG(NB)                                                                                       \
+  do {                                                                                                         \
+    if (a.tolerance) hipExtLaunchKernelGGL((plane_scan_general<NB, true>), g, b, 0, st, t0, t1, 0, a);        \
+    else hipExtLaunchKernelGGL((plane_scan_general<NB, false>), g, b, 0, st, t0, t1, 0, a);                   \
+  } while (0)
+  if (a.n_bases <= 1) RJ_LAUNCH_PG(1);
+  else if (a.n_bases <= 2) RJ_LAUNCH_PG(2);
+  else RJ_LAUNCH_PG(4);
+#undef RJ_LAUNCH_PG
+}
+
+// classify_shared_multi for candidates that are WINDOW positions of patterns with their own offsets, window lengths and
+// up to four windows each: per pattern the start s = w - offset is clipped to the own range, the exact window test runs on
+// the 8 bytes at w (masks cover the pattern's own window length), the automaton reads the 16 bytes at ITS start.
+template <int W, int MAXK>
+__global__ __launch_bounds__(256) void classify_shared_general(SharedHits sh, unsigned long long* counters0) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int lane = lane_id();
+  const int half = lane >> 5, sub = lane & 31;
+  const uint64_t wave = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6));
+  const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+  const uint8_t* text = sh.text;
+  const uint64_t n = sh.n, sb = sh.sb, se = sh.se;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(sh.blob);
+    uint4* dst = reinterpret_cast<uint4*>(lds);
+    for (uint32_t i = threadIdx.x; i < sh.blob_words / 4; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const ClassifyDesc* desc = reinterpret_cast<const ClassifyDesc*>(lds);
+  const uint32_t* tab = lds + sh.desc_words;
+  for (uint64_t r0 = wave * 2; r0 < sh.n_regions; r0 += n_waves * 2) {
+    const uint64_t r = r0 + half;
+    const bool live = r < sh.n_regions;
+    const uint32_t raw = live ? sh.counts[r] : 0u;
+    const uint32_t cnt = raw < sh.cap ? raw : sh.cap;
+    if (raw > sh.cap && sub == 0) atomicMax(&counters0[kCntSharedMax], static_cast<unsigned long long>(raw));
+    uint32_t kept = 0;  // lane 32 * half + p: survivors of pattern p in the half's region
+    const uint64_t* region = sh.hits + r * sh.cap;
+    for (uint32_t base = 0; __ballot(base < cnt) != 0; base += 32) {
+      const uint32_t k = base + sub;
+      const bool have = k < cnt;
+      const uint64_t w = have ? region[k] : 0;
+      uint32_t lo = 0, hi = 0;
+      if (have) {
+        if (w + 8 <= n) {
+          __builtin_memcpy(&lo, text + w, 4);
+          __builtin_memcpy(&hi, text + w + 4, 4);
+        } else {
+          for (uint32_t q = 0; q < 8 && w + q < n; q++) {
+            const uint32_t c = text[w + q];
+            if (q < 4) lo |= c << (8 * q);
+            else hi |= c << (8 * (q - 4));
+          }
+        }
+      }
+      // 1. per pattern: the start inside the own range, the window inside the text, one of its windows matches
+      uint32_t todo = 0;
+      for (uint32_t p = 0; p < sh.n_patterns; p++) {
+        const ClassifyDesc& d = desc[p];
+        const uint64_t s = w - d.win_offset;
+        const bool ok = have && w >= d.win_offset && s >= sb && s < se && w + d.win_len <= n;
+        bool win = false;
+        for (uint32_t q = 0; q < d.n_windows; q++) win = win || ((((lo ^ d.v0[q]) & d.m0[q]) | ((hi ^ d.v1[q]) & d.m1[q])) == 0);
+        todo |= (ok && win) ? 1u << p : 0u;
+      }
+      // 2. the automata: in pass r every lane runs the r-th pattern whose window test its candidate passed
+      uint32_t matched = 0;
+      uint64_t lens[2] = {0, 0};
+      while (__ballot(todo != 0) != 0) {
+        const bool act = todo != 0;
+        const uint32_t p = act ? static_cast<uint32_t>(__builtin_ctz(todo)) : 0u;
+        todo &= todo - 1;
+        const ClassifyDesc& d = desc[p];
+        const uint32_t* t0 = tab + d.tab;
+        const uint64_t s = w - d.win_offset;
+        uint64_t t_lo = 0, t_hi = 0;
+        if (act) rj_load16(text, n, s, &t_lo, &t_hi);
+        const uint32_t avail = act ? (n - s < 16 ? static_cast<uint32_t>(n - s) : 16u) : 0u;
+        uint32_t len = 0;
+        bool found;
+        if (W == 1 || d.n_words <= 1) found = short_longest_lds<1, MAXK>(t0, d, t_lo, t_hi, avail, &len);
+        else found = short_longest_lds<W, MAXK>(t0, d, t_lo, t_hi, avail, &len);
+        if (found && act) {
+          matched |= 1u << p;
+          if (p < 12) lens[0] |= static_cast<uint64_t>(len) << (5 * p);
+          else lens[1] |= static_cast<uint64_t>(len) << (5 * (p - 12));
+        }
+      }
+      // 3. the survivors of every pattern, in position order, to the pattern's own region
+      for (uint32_t p = 0; p < sh.n_patterns; p++) {
+        const bool found = ((matched >> p) & 1u) != 0;
+        const uint64_t mine = __ballot(found);
+        if (mine == 0) continue;
+        const ClassifyDesc& d = desc[p];
+        const uint64_t s = w - d.win_offset;
+        const uint64_t e = s + (((p < 12 ? lens[0] >> (5 * p) : lens[1] >> (5 * (p - 12)))) & 31u);
+        const uint32_t mine_half = static_cast<uint32_t>(mine >> (32 * half));
+        const uint32_t b0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(kept), static_cast<int>(p)));
+        const uint32_t b1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(kept), static_cast<int>(32 + p)));
+        const uint32_t pos = (half ? b1 : b0) + __popc(mine_half & ((1u << sub) - 1u));
+        const uint32_t cap_p = d.region_cap;
+        if (found && pos < cap_p) {
+          d.begins[r * cap_p + pos] = s;
+          d.ends[r * cap_p + pos] = e;
+        }
+        if (sub == static_cast<int>(p)) kept += __popc(mine_half);
+      }
+    }
+    if (live && sub < static_cast<int>(sh.n_patterns)) {
+      const ClassifyDesc& d = desc[sub];
+      const uint32_t c = kept, cap_p = d.region_cap;
+      if (c > cap_p) {
+        d.counters[kCntOverflow] = 1;
+        atomicMax(&d.counters[kCntMaxRegion], static_cast<unsigned long long>(c));
+      }
+      d.valid_counts[r] = c < cap_p ? c : cap_p;
+    }
+  }
+}
+
+void launch_tails_shared_general(const MultiTail* d_tails, const SharedHits& sh, int max_words, uint32_t max_short, unsigned long long* counters0,
+                                 hipStream_t st) {
+  uint64_t blocks = (static_cast<uint64_t>(sh.n_regions) + 7) / 8;
+  blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
+  const dim3 g(static_cast<unsigned>(blocks)), b(256);
+  const size_t lds = static_cast<size_t>(sh.blob_words) * sizeof(uint32_t);
+  if (max_words <= 1 && max_short <= 8) hipLaunchKernelGGL((classify_shared_general<1, 8>), g, b, lds, st, sh, counters0);
+  else if (max_words <= 1) hipLaunchKernelGGL((classify_shared_general<1, 16>), g, b, lds, st, sh, counters0);
+  else hipLaunchKernelGGL((classify_shared_general<2, 16>), g, b, lds, st, sh, counters0);
+  launch_offsets_gather_check_multi(d_tails, static_cast<int>(sh.n_patterns), sh.n_regions, st);
+}
+
 void launch_tails_shared(const MultiTail* d_tails, const SharedHits& sh, int max_words, uint32_t max_short, unsigned long long* counters0,
                          hipStream_t st) {
   // half a wave per region; every workgroup copies the blob into LDS first

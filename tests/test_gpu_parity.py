@@ -400,6 +400,57 @@ def test_fused_multi_pattern_equals_single_runs(rj):
     assert counts == [rj.Scan(p).run(t.data_ptr(), n, stream=st) for p in mixed]
 
 
+def test_general_one_pass_pattern_sets(rj, oracle):
+    """The general one-pass plan (plane_scan_general + classify_shared_general, round 4): pattern sets that are NOT the
+    regexdna shape -- literal alternations of the reference's benchmark regexes with windows at differing offsets and of
+    7 / 8 bytes, four 6-mers over [a-z] (codes alias), windows with a class byte (one code may differ) -- run in ONE pass
+    (how == 1) and give the spans of single runs and of the oracle; a set the plan refuses runs as separate scans."""
+    import torch
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    rng = random.Random(77)
+    sets = [
+        ([b"alternation|strings", b"prefix abcd|prefix 1234"], [b"alternation", b"strings", b"prefix abcd", b"prefix 1234", b"alternatiom", b"refix abcd"], 1),
+        ([b"qwerty", b"zxcvbn", b"plmokn", b"ijbuhv"], [b"qwerty", b"zxcvbn", b"plmokn", b"ijbuhv", b"qwertz", b"ijbuhw", b"uaivzr"], 1),
+        ([b"abc[de]fgh", b"abcdfgh[xy]", b"abcefgh"], [b"abcdfgh", b"abcefgh", b"abcdfghx", b"abcdfghz", b"abcffgh"], 1),
+        ([b"x[0-9]regexp", b"regexpyz", b"abcd suffix|1234 suffix"], [b"x7regexp", b"regexpyz", b"abcd suffix", b"1234 suffix", b"xxregexp"], 2),
+    ]
+    for patterns, needles, how in sets:
+        progs = [rj.Program(rx) for rx in patterns]
+        multi = rj.MultiScan(progs)
+        singles = [rj.Scan(p) for p in progs]
+        for n, alphabet in ((300_000, b"abcdefghijklmnopqrstuvwxyz 0123456789"), (2_000_000, b"abcdefghijklmnopqrstuvwxyz 0123456789"),
+                            (100_000, b"abcdefgh"), (40_000, b"qwertyzxcvbnplmokijuh"), (17, b"ab"), (5000, b"a")):
+            body = bytearray(rng.choices(alphabet, k=n))
+            for _ in range(n // 900):
+                nd = rng.choice(needles)
+                at = rng.randrange(0, max(1, n - len(nd)))
+                body[at:at + len(nd)] = nd
+            for nd in needles[:2]:                       # at the very beginning and end, and across 1-KiB / 2-KiB edges
+                if n > 4096:
+                    body[0:len(nd)] = nd
+                    body[n - len(nd):n] = nd
+                    body[1024 - 3:1024 - 3 + len(nd)] = nd
+                    body[2048 - 2:2048 - 2 + len(nd)] = nd
+            text = bytes(body)
+            t = torch.frombuffer(bytearray(text + bytes(16)), dtype=torch.uint8).to(dev)
+            counts = multi.run(t.data_ptr(), n, stream=st)
+            if n >= 16:
+                assert multi.how == how, (patterns, n, multi.how)
+            for i, sc in enumerate(singles):
+                want = oracle.match_all(patterns[i], text)
+                assert counts[i] == len(want), (patterns[i], n, counts[i], len(want))
+                assert multi.scan(i).spans() == want, (patterns[i], n)
+                assert sc.run(t.data_ptr(), n, stream=st) == len(want)
+            # a shard's own range
+            if n >= 100_000:
+                lo, hi = n // 3 + 1, 2 * n // 3
+                counts = multi.run(t.data_ptr(), n, stream=st, own_begin=lo, own_end=hi)
+                for i in range(len(patterns)):
+                    want = [m for m in oracle.match_all(patterns[i], text) if lo <= m[0] < hi]
+                    assert multi.scan(i).spans() == want, (patterns[i], n, "range")
+
+
 def test_concurrent_match_all_on_one_program(rj, oracle):
     """A compiled pattern is shared by worker threads that call MatchAll concurrently (jrep -j,
     sample/jrep.cc:461-493): scratch is per thread, results are those of serial calls."""
