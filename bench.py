@@ -138,6 +138,16 @@ def cpu_baseline(text_host: bytes, patterns, sample_desc: str, all_cores: bool =
     out = dict(value=passes * len(patterns) * n1 / dt / 1e9, unit="GB/s", cores=1, kind="reference", host_cores=host_threads,
                sample=sample_desc + "; first %d bytes, %d pass(es); reference flags use_fast_forward=1 use_ff_reduce=0" % (n1, passes),
                seconds=round(dt, 3))
+    # the same core over a sample that does NOT fit its caches (one pass over up to 1 GiB, from DRAM): the number the GPU's
+    # HBM-streaming figure sits beside; the 64 MiB sample above is L3-resident on this host and flatters the CPU
+    n_dram = min(total, 1 << 30)
+    if n_dram > 2 * n1:
+        t0 = time.perf_counter()
+        for rx in patterns:
+            fn(rx.encode(), addr, n_dram, 1)
+        dtd = time.perf_counter() - t0
+        out["one_core_dram_resident"] = dict(value=len(patterns) * n_dram / dtd / 1e9, unit="GB/s", cores=1,
+                                             sample="ONE pass over the first %d bytes of the same text, every pattern" % n_dram, seconds=round(dtd, 3))
     if all_cores and host_threads > 1:
         from concurrent.futures import ThreadPoolExecutor
         threads = host_threads
@@ -422,6 +432,7 @@ def run_regexdna(args, c):
     # (`value` counts it once per pattern, the reference's convention for nine MatchAllCount calls)
     out["physical_GBps"] = round(n_total * args.steps / elapsed / 1e9, 1)
     out["step_frac"] = round(n_total * args.steps / elapsed / 1e9 / HBM_PEAK_GBS / world, 4)
+    out["step_variants_ms"] = {"headline": round(elapsed / args.steps * 1e3, 4)}   # (filled in by the extras below; kept near the top of the line)
     if use_multi:
         # the dominant kernel: plane_scan reads every text byte ONCE for all nine patterns: algorithmic bytes per
         # launch = text bytes (for a fused pass quote n / t_fused, never 9 n / t_fused, against HBM)
@@ -483,9 +494,12 @@ def run_regexdna(args, c):
                         "ms_per_step": round(es1 / args.steps * 1e3, 4),
                         "value": round(len(patterns) * n_total * args.steps / es1 / 1e9, 3), "unit": "GB/s",
                         "scan_kernel_ms": round(sum(s_times) / max(len(s_times), 1), 5)}
+            out["step_variants_ms"][key] = out[key]["ms_per_step"]
+            out["step_variants_ms"]["overlapped_tails"] = out["overlapped_tails"]["ms_per_step"]
             if not args.one_stream and s_times:
                 out["roofline_kernel_alone"] = hbm_roofline("plane_scan<2> with nothing else on the device (the one-stream loop)", own_bytes,
                                                             sum(s_times) / len(s_times), pmc_traffic("plane", fasta_n=args.fasta_n), len(s_times))
+        out["step_variants_ms"]["synchronous_calls"] = round(ek0 / args.steps * 1e3, 4)
         out["synchronous_calls"] = {"calls": "rj_multi_run mode 0, one call after the other (one step in flight): what rounds 1-2 timed",
                                     "ms_per_step": round(ek0 / args.steps * 1e3, 4),
                                     "value": round(len(patterns) * n_total * args.steps / ek0 / 1e9, 3), "unit": "GB/s"}

@@ -57,6 +57,41 @@ def random_ascii_big(n, seed, start=0, chunk=1 << 27):
     return out
 
 
+def _c4_shard(job):
+    """One shard of the 8-GPU C4 job in its own process (the reference library keeps global flags: one instance per process)."""
+    r, world, per, left = job
+    ref = Ref(use_ff=0)
+    ref.lib.ref_match_all.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t]
+    rx = W.BENCH_REGEXES[3][0]
+    n_total = per * world
+    ranges = sharding.partition(n_total, world)
+    cuts = [q[0] for q in ranges[1:]]
+    rng = random.Random(7)
+    needles = [(o, W.complex_regex_sample(rng)) for o in W.plant_offsets(n_total, 64, 200 * world, seed=7, boundaries=cuts)]
+    own = ranges[r]
+    lo = max(0, own[0] - left)
+    hi = min(n_total, own[1] + 58)
+    t0 = time.time()
+    text = random_ascii_big(hi - lo, 0xC0FFEE, start=lo)
+    for o, smp in needles:
+        a, b = max(o, lo), min(o + len(smp), hi)
+        if a < b:
+            W.plant(text, [a - lo], smp[a - o:b - o])
+    t1 = time.time()
+    sp = ref_spans(ref, FF0, rx.encode(), text) + np.uint64(lo)
+    before = sp[sp[:, 0] < np.uint64(own[0])]
+    if r > 0:
+        # a gap without a match between the fresh start and the own range: both runs agree from there on
+        edges = [lo] + [int(e) for e in before[:, 1]]
+        starts = [int(b) for b in before[:, 0]] + [own[0]]
+        assert any(s_ - e_ > 64 for e_, s_ in zip(edges, starts)), "no gap in the left context of shard %d" % r
+    mine = sp[(sp[:, 0] >= np.uint64(own[0])) & (sp[:, 0] < np.uint64(min(own[1], n_total + 1)))]
+    d = W.span_digest_numpy(mine)
+    carry = [int(before[-1, 0]), int(before[-1, 1])] if len(before) else None
+    print("  shard %d done: text %.0f s, reference (ff off) %.0f s" % (r, t1 - t0, time.time() - t1), flush=True)
+    return {"rank": r, "own": [int(own[0]), int(min(own[1], n_total + 1))], "digest": d, "last_match_before": carry}
+
+
 def main():
     which = set(sys.argv[1:]) or {"c3", "c2", "c4"}
     doc = json.load(open(OUT)) if os.path.exists(OUT) else {}
@@ -139,31 +174,11 @@ def main():
         rng = random.Random(7)
         needles = [(o, W.complex_regex_sample(rng)) for o in W.plant_offsets(n_total, 64, 200 * world, seed=7, boundaries=cuts)]
         left = 1 << 16
-        shards = []
-        for r in range(world):
-            own = ranges[r]
-            lo = max(0, own[0] - left)
-            hi = min(n_total, own[1] + 58)
-            t0 = time.time()
-            text = random_ascii_big(hi - lo, 0xC0FFEE, start=lo)
-            for o, smp in needles:
-                a, b = max(o, lo), min(o + len(smp), hi)
-                if a < b:
-                    W.plant(text, [a - lo], smp[a - o:b - o])
-            t1 = time.time()
-            sp = ref_spans(ref, FF0, rx.encode(), text) + np.uint64(lo)
-            before = sp[sp[:, 0] < np.uint64(own[0])]
-            if r > 0:
-                # a gap without a match between the fresh start and the own range: both runs agree from there on
-                edges = [lo] + [int(e) for e in before[:, 1]]
-                starts = [int(b) for b in before[:, 0]] + [own[0]]
-                assert any(s_ - e_ > 64 for e_, s_ in zip(edges, starts)), "no gap in the left context of shard %d" % r
-            mine = sp[(sp[:, 0] >= np.uint64(own[0])) & (sp[:, 0] < np.uint64(min(own[1], n_total + 1)))]
-            d = W.span_digest_numpy(mine)
-            carry = [int(before[-1, 0]), int(before[-1, 1])] if len(before) else None
-            print("  shard %d: bytes [%d, %d), %d matches begin in it (text %.0f s, reference ff off %.0f s)" % (r, own[0], own[1], d["count"], t1 - t0, time.time() - t1), flush=True)
-            shards.append({"rank": r, "own": [int(own[0]), int(min(own[1], n_total + 1))], "digest": d, "last_match_before": carry})
-            del text
+        from concurrent.futures import ProcessPoolExecutor
+        with ProcessPoolExecutor(max_workers=int(os.environ.get("C4ALL_WORKERS", "4"))) as pool:
+            shards = list(pool.map(_c4_shard, [(r, world, per, left) for r in range(world)]))
+        for x in shards:
+            print("  shard %d: bytes [%d, %d), %d matches begin in it" % (x["rank"], x["own"][0], x["own"][1], x["digest"]["count"]), flush=True)
         doc["c4all"] = {"text": "bench.py --workload complex --gpus 8 --literal-bytes 6250000000: random_ascii(seed 0xC0FFEE) with the job's planted "
                                 "complex_regex_sample strings; per shard the matches that begin in its own range, global offsets",
                         "world": world, "bytes_per_gpu": per, "regex": rx, "reference_flags": "use_fast_forward=0", "shards": shards,

@@ -4,7 +4,7 @@ bench_engine.cc:177-249: random text in [low,high), sizes 2^3..2^21, bytes/s = s
 compile excluded) extended to GPU-sized inputs.  Device-resident text; `cpu` columns = the real
 reference (oracle/_ref, default flags) on one host core where the prebuilt library exists.
 
-    python tools/bench_sizes.py [regex_index ...]      # indices into workloads.BENCH_REGEXES
+    python tools/bench_sizes.py [all | regex_index ...]      # indices into workloads.BENCH_REGEXES (all: the twelve of run.py:347-360)
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +18,7 @@ dev = torch.device("cuda:0")
 st = torch.cuda.current_stream(dev).cuda_stream
 ref = checkers.Ref(use_ff=1, ff_early=1, ff_reduce=0, parser_opt=1) if checkers.have_ref() else None
 sizes = [1 << k for k in range(3, 22, 3)] + [1 << 24, 1 << 27, 1 << 30]
-which = [int(a) for a in sys.argv[1:]] or [1, 3, 4, 11]
+which = list(range(len(W.BENCH_REGEXES))) if sys.argv[1:] == ["all"] else ([int(a) for a in sys.argv[1:]] or [1, 3, 4, 11])
 print("%-58s %10s %12s %12s %12s" % ("regexp", "size", "gpu_us/call", "gpu_GB/s", "cpu1_GB/s"))
 for idx in which:
     rx, lo, hi = W.BENCH_REGEXES[idx]

@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (via gpurun): the bench line, kernel-trace stats of the headline run and of the full bench (incl.
 # the 50 GB and 2.5 GB runs), and the PMC passes (own runs, --kernel-trace only -- never combined with other trace
 # domains).  Summaries land in gpurun_out/prof_<tag>_*; tools/collect_profiles.py turns them into profiles/<tag>_*.
-tag=${1:-r03}
+tag=${1:-r04}
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out; mkdir -p $out
 make -C $root/samples > /dev/null 2>&1
@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o r -- python $root/bench.py -
 python $root/tools/rocpd_stats.py $(find /tmp/prof_kt -name "*.db" | head -1) 12 > $out/prof_${tag}_kernel_stats.txt
 # every extra of the bench line, the 50 GB literal scan and the 2.5 GB runs included: one table
 rocprofv3 --kernel-trace --stats -d /tmp/prof_full -o r -- python $root/bench.py --no-cpu-baseline --steps 5 --jrep-files 5000 --jrep-bytes 500000000 > /dev/null 2> /tmp/full.log
-python $root/tools/rocpd_stats.py $(find /tmp/prof_full -name "*.db" | head -1) 48 > $out/prof_${tag}_kernel_stats_full.txt
+python $root/tools/rocpd_stats.py $(find /tmp/prof_full -name "*.db" | head -1) 56 split > $out/prof_${tag}_kernel_stats_full.txt
 # the linear-time carry scan and the dense / class patterns, first and warm calls
 rocprofv3 --kernel-trace --stats -d /tmp/prof_lin -o r -- python $root/tools/linear_probe.py > $out/prof_${tag}_linear_probe.txt 2> /tmp/lin.log
 python $root/tools/rocpd_stats.py $(find /tmp/prof_lin -name "*.db" | head -1) 24 > $out/prof_${tag}_kernel_stats_linear.txt
@@ -30,7 +30,8 @@ for c in SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUS
 done > $out/prof_${tag}_pmc_sq.txt
 cd $root
 python tools/jrep_compare.py 2>&1 | grep -v amdgpu.ids > $out/prof_${tag}_jrep_compare.txt
-python tools/bench_sizes.py > $out/prof_${tag}_bench_sizes.txt 2>/dev/null
+python tools/bench_sizes.py all > $out/prof_${tag}_bench_sizes.txt 2>/dev/null
+python tools/dense_probe.py 1e9 > $out/prof_${tag}_dense_probe.txt 2>/dev/null
 tail -1 $out/prof_${tag}_bench.json | cut -c1-300
 head -6 $out/prof_${tag}_kernel_stats.txt | cut -c1-60,91-170
 head -14 $out/prof_${tag}_pmc_fetch.txt
