@@ -299,6 +299,7 @@ struct PendingCall {
   size_t n;
   bool want_spans;
   uint64_t off = 0;
+  bool retry_alone = false;  // the combined pass failed: this call runs again on its own
   uint64_t* spans = nullptr;
   int64_t result = 0;
   std::string error;
@@ -348,10 +349,10 @@ void run_combined(const rj_program* prog, rj_scan* scan, const char* packed, uin
   uint64_t* all = nullptr;
   const int64_t total = run_packed(prog, packed, off.data(), sizes.data(), batch.size(), used, counts.data(), &all, scan);
   if (total < 0) {
-    for (PendingCall* p : batch) {
-      p->result = total;
-      p->error = g_error;
-    }
+    // The pass over the concatenation failed (one member's text drove a walk into its limit, a device list could not
+    // grow, ...): the members are independent callers -- each of them repeats ITS call alone on the direct path (flagged
+    // here, done by the caller's own thread in combined_match_all), so that one text's failure is that text's alone.
+    for (PendingCall* p : batch) p->retry_alone = true;
     return;
   }
   uint64_t at = 0;
@@ -444,6 +445,10 @@ int combined_match_all(const rj_program* prog, const char* text, size_t n, uint6
     if (!c->calls.empty()) c->calls.front()->cv.notify_one();
   }
   lk.unlock();
+  if (me.retry_alone) {
+    *result = rj_match_range_host(prog, text, n, 0, n + 1, 0, 0, 0, spans);
+    return 1;
+  }
   if (me.result < 0) g_error = me.error;
   if (spans) *spans = me.spans;
   *result = me.result;

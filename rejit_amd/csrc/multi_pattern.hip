@@ -1252,6 +1252,8 @@ int rj_multi_set_tail_stream(rj_multi* m, int on) {
   ErrnoGuard errno_guard;
   if (!m) return fail(RJ_BAD_ARGUMENT, "null argument");
   if (m->pending.active) return fail(RJ_BAD_ARGUMENT, "rj_multi_set_tail_stream: a run is in flight");
+  // (a tail stream of the lowest OR of the highest priority was measured: 0.196 / 0.188 ms per step against 0.134 with an
+  // ordinary stream -- a priority queue is scheduled differently altogether, and worse for this)
   if (on && !m->tail_stream) RJ_HIP(hipStreamCreateWithFlags(&m->tail_stream, hipStreamNonBlocking));
   m->tails_own_stream = on != 0;
   return RJ_OK;
