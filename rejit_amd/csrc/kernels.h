@@ -293,7 +293,7 @@ void launch_tails_shared(const MultiTail* d_tails, const SharedHits& sh, int max
 // a superset test like every fast-forward filter --, with <= kPlaneMaxBases base windows, exactly (tolerance 0) or up to
 // one differing code (tolerance 1: windows with a class byte).  Candidates are WINDOW POSITIONS (the patterns' offsets
 // differ); classify_shared_general applies every pattern's own offset, exact window test (<= 4 windows) and automaton.
-constexpr int kPlaneMaxBases = 4;  // (eight: 128 uniform masks no longer fit the scalar registers -- the compiler moved them to 254 VGPRs)
+constexpr int kPlaneMaxBases = 12;  // (the kernel loops over the bases without unrolling: one base's masks in scalar registers at a time)
 struct PlaneGParams {
   const uint8_t* text;
   uint64_t n;

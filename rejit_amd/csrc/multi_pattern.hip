@@ -861,7 +861,7 @@ int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out)
     return fail(RJ_DEVICE_ERROR, "hipStreamCreate / hipEventCreate failed");
   }
   m->fused = all && n_progs > 1 && getenv("RJ_NO_FUSION") == nullptr;
-  if (m->fused) m->plane = plan_plane(m->scans);
+  if (m->fused && getenv("RJ_PLANE_GENERAL_ONLY") == nullptr) m->plane = plan_plane(m->scans);  // (env: measurement override)
   if (!m->plane.ok && n_progs > 1 && getenv("RJ_NO_FUSION") == nullptr && getenv("RJ_NO_PLANE") == nullptr && getenv("RJ_NO_PLANE_GENERAL") == nullptr) {
     // not the regexdna shape: the general one-pass plan (round 4)
     const PlanePlan g = plan_plane_general(m->scans);

@@ -692,7 +692,7 @@ bool launch_plane_scan_classify(const PlaneParams& a, const SharedHits& sh, int 
 
 
 // ---------------------------------------------------------------------------------------
-// The GENERAL one-pass scan (round 4; kernels.h: PlaneGParams): up to 4 base windows, their first n_cmp (4..8) bytes
+// The GENERAL one-pass scan (round 4; kernels.h: PlaneGParams): up to 12 base windows, their first n_cmp (4..8) bytes
 // compared exactly or with one differing code, any alphabet (codes alias), candidates = window positions.
 namespace {
 
@@ -709,28 +709,28 @@ __device__ __forceinline__ uint32_t plane_candidates_general(const uint32_t (&dA
   const uint32_t H = ((ta >> 1) & kEven) | (tb & ~kEven);
   const uint32_t Ln = (ha & kEven) | ((hb << 1) & ~kEven);
   const uint32_t Hn = ((ha >> 1) & kEven) | (hb & ~kEven);
-  uint32_t Z[NB], O[NB];
-#pragma unroll
-  for (int b = 0; b < NB; b++) {
-    Z[b] = ~0u;
-    O[b] = ~0u;
-  }
+  // the shifted planes of all compared offsets first (16 registers), then base after base in a loop that is NOT unrolled:
+  // one base's 16 masks live in scalar registers at a time (read from the kernel arguments per pair: scalar-cache hits).
+  // All bases unrolled kept 4 x 8 x 2 masks live and the compiler spilled ~100 of them to VGPR lanes, a v_readlane per use.
+  uint32_t Ls[8], Hs[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    if (static_cast<uint32_t>(i) >= a.n_cmp) break;  // (wave-uniform: windows shorter than 8 bytes)
-    const uint32_t Li = i ? __builtin_amdgcn_alignbit(Ln, L, 2 * i) : L;
-    const uint32_t Hi = i ? __builtin_amdgcn_alignbit(Hn, H, 2 * i) : H;
-#pragma unroll
-    for (int b = 0; b < NB; b++) {
-      const uint32_t E = (Li ^ a.lo[b][i]) & (Hi ^ a.hi[b][i]);
-      if (TOL) O[b] = i == 0 ? ~0u : (Z[b] | (O[b] & E));   // at most one code differs so far
-      Z[b] &= E;                                              // none differs so far
-    }
+    Ls[i] = i ? __builtin_amdgcn_alignbit(Ln, L, 2 * i) : L;
+    Hs[i] = i ? __builtin_amdgcn_alignbit(Hn, H, 2 * i) : H;
   }
   uint32_t c = 0;
+#pragma clang loop unroll(disable)
+  for (uint32_t b = 0; b < a.n_bases; b++) {
+    uint32_t Z = ~0u, O = ~0u;
 #pragma unroll
-  for (int b = 0; b < NB; b++)
-    if (static_cast<uint32_t>(b) < a.n_bases) c |= TOL ? O[b] : Z[b];
+    for (int i = 0; i < 8; i++) {
+      if (static_cast<uint32_t>(i) >= a.n_cmp) break;  // (wave-uniform: windows shorter than 8 bytes)
+      const uint32_t E = (Ls[i] ^ a.lo[b][i]) & (Hs[i] ^ a.hi[b][i]);
+      if (TOL) O = i == 0 ? ~0u : (Z | (O & E));   // at most one code differs so far
+      Z &= E;                                        // none differs so far
+    }
+    c |= TOL ? O : Z;
+  }
   return c;
 }
 
@@ -801,15 +801,9 @@ __global__ __launch_bounds__(256) void plane_scan_general(PlaneGParams a) {
 
 void launch_plane_scan_general(const PlaneGParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
   const dim3 g(grid), b(256);
-#define RJ_LAUNCH_PG(NB)                                                                                       \
-  do {                                                                                                         \
-    if (a.tolerance) hipExtLaunchKernelGGL((plane_scan_general<NB, true>), g, b, 0, st, t0, t1, 0, a);        \
-    else hipExtLaunchKernelGGL((plane_scan_general<NB, false>), g, b, 0, st, t0, t1, 0, a);                   \
-  } while (0)
-  if (a.n_bases <= 1) RJ_LAUNCH_PG(1);
-  else if (a.n_bases <= 2) RJ_LAUNCH_PG(2);
-  else RJ_LAUNCH_PG(4);
-#undef RJ_LAUNCH_PG
+  // (the kernel no longer depends on the number of bases at compile time: one instantiation per tolerance)
+  if (a.tolerance) hipExtLaunchKernelGGL((plane_scan_general<1, true>), g, b, 0, st, t0, t1, 0, a);
+  else hipExtLaunchKernelGGL((plane_scan_general<1, false>), g, b, 0, st, t0, t1, 0, a);
 }
 
 // classify_shared_multi for candidates that are WINDOW positions of patterns with their own offsets, window lengths and

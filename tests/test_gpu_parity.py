@@ -414,6 +414,9 @@ def test_general_one_pass_pattern_sets(rj, oracle):
         ([b"qwerty", b"zxcvbn", b"plmokn", b"ijbuhv"], [b"qwerty", b"zxcvbn", b"plmokn", b"ijbuhv", b"qwertz", b"ijbuhw", b"uaivzr"], 1),
         ([b"abc[de]fgh", b"abcdfgh[xy]", b"abcefgh"], [b"abcdfgh", b"abcefgh", b"abcdfghx", b"abcdfghz", b"abcffgh"], 1),
         ([b"x[0-9]regexp", b"regexpyz", b"abcd suffix|1234 suffix"], [b"x7regexp", b"regexpyz", b"abcd suffix", b"1234 suffix", b"xxregexp"], 2),
+        # nine 6-mers over [a-z]: nine bases (the scan loops over them; VERDICT r03's example)
+        ([b"qwerty", b"zxcvbn", b"plmokn", b"ijbuhv", b"ygctfx", b"rdzesw", b"aqmnbv", b"lkjhgf", b"poiuyt"],
+         [b"qwerty", b"zxcvbn", b"plmokn", b"ijbuhv", b"ygctfx", b"rdzesw", b"aqmnbv", b"lkjhgf", b"poiuyt", b"qwertz", b"poiuyr"], 1),
     ]
     for patterns, needles, how in sets:
         progs = [rj.Program(rx) for rx in patterns]

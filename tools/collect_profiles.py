@@ -60,7 +60,7 @@ for key, prefix, nbytes, extra in (
         ("literal_50gb", "scan_windows<1, true, true, true, false>", 50000000000, {}),
         ("complex", "scan_windows<1, true, false, true, false>", 5000000000, {}),
         ("dense", "dense_streams<2, 2, false>", 5000000000, {}),
-        ("general", "plane_scan_general<4, false>", 5000000000, {}),
+        ("general", "plane_scan_general<1, false>", 5000000000, {}),
         ("line_table", "emit_assertions", 5000000000, {})):
     try:
         j[key] = dict(kernel=prefix, hbm_read_bytes_per_launch=avg_of(f, prefix, nbytes) * 1024 * 2, bytes=nbytes, **extra)
