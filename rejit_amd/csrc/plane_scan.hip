@@ -39,6 +39,7 @@
 #include "trace_stamp.h"
 RJ_TRACE_EXPORT(rj_debug_trace_plane)
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "device_program.h"
@@ -262,8 +263,11 @@ __global__ __launch_bounds__(256) void plane_scan(PlaneParams a) {
 }
 
 void launch_plane_scan(const PlaneParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
-  if (a.n_bases <= 1) hipExtLaunchKernelGGL((plane_scan<1>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
-  else hipExtLaunchKernelGGL((plane_scan<2>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+  // RJ_PLANE_LDS (measurement): unused dynamic LDS per workgroup, to cap the kernel's residency (160 KiB per CU) and leave
+  // wave slots to the tails of the previous step that run beside it
+  static const size_t lds = getenv("RJ_PLANE_LDS") ? static_cast<size_t>(atoi(getenv("RJ_PLANE_LDS"))) : 0;
+  if (a.n_bases <= 1) hipExtLaunchKernelGGL((plane_scan<1>), dim3(grid), dim3(256), lds, st, t0, t1, 0, a);
+  else hipExtLaunchKernelGGL((plane_scan<2>), dim3(grid), dim3(256), lds, st, t0, t1, 0, a);
 }
 
 // ---------------------------------------------------------------------------------------
