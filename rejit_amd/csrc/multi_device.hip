@@ -156,7 +156,9 @@ void run_shard(const rj_program* prog, int shard, const char* text, size_t n, ui
     return;
   }
   const uint64_t vis_lo = lo > 64 ? (lo - 64) & ~static_cast<uint64_t>(15) : 0;
-  const uint64_t vis_hi = std::min<uint64_t>(n, hi + max_len);
+  // (max_len == ~0: a pattern at risk of the ring artefact -- its range owns whole segments between synchronisation points of
+  // the reference's loop, which the engine looks for in the buffer it is given: the shard sees the text up to its end)
+  const uint64_t vis_hi = max_len == ~0ull ? n : std::min<uint64_t>(n, hi + max_len);
   const uint64_t local_n = vis_hi - vis_lo;
   uint64_t* spans = nullptr;
   const int64_t c = rj_match_range_host(rp, text + vis_lo, local_n, lo - vis_lo, std::min<uint64_t>(hi, n + 1) - vis_lo,
@@ -180,9 +182,13 @@ bool multi_device_match_all(const rj_program* prog, const char* text, size_t n, 
   const int shards = shard_count();
   const uint64_t max_len = prog->host->max_len;
   if (shards < 2 || n < multi_device_min_bytes() || max_len == Program::kUnboundedLen || max_len > (1u << 20)) return false;
-  // (a pattern at risk of the ring artefact needs the text up to the next synchronisation point of the
-  // reference's loop, not a fixed halo -- exact_replay.h: one device)
-  if (prog->host->q8_risk) return false;
+  // A pattern at risk of the ring artefact is sharded by SEGMENT ownership (round 4; one device before):
+  // a range [lo, hi) owns the segments between synchronisation points of the reference's loop that begin in it, every shard
+  // gets the text from its range to the END (run_pipeline replays the reference's loop over the owned segments), the shards'
+  // results concatenate to the reference's answer and no carry crosses a cut.  More bytes over PCIe (shard r uploads the
+  // text from its cut on), all of them in parallel.
+  const bool to_the_end = prog->host->q8_risk;
+  const uint64_t halo = to_the_end ? ~0ull : max_len;
   // contiguous ranges of starts, cut at multiples of 4096; the last one owns the start n (the empty match at the end)
   std::vector<uint64_t> cuts(static_cast<size_t>(shards) + 1, 0);
   for (int r = 1; r < shards; r++) cuts[static_cast<size_t>(r)] = std::max(cuts[static_cast<size_t>(r) - 1], (n * r / shards) & ~static_cast<uint64_t>(4095));
@@ -193,7 +199,7 @@ bool multi_device_match_all(const rj_program* prog, const char* text, size_t n, 
     std::vector<std::function<void()>> tasks;
     for (int r = 0; r < shards; r++)
       tasks.emplace_back([=, &res, &cuts] {
-        run_shard(prog, r, text, n, cuts[static_cast<size_t>(r)], cuts[static_cast<size_t>(r) + 1], max_len, 0, 0, 0, &res[static_cast<size_t>(r)]);
+        run_shard(prog, r, text, n, cuts[static_cast<size_t>(r)], cuts[static_cast<size_t>(r) + 1], halo, 0, 0, 0, &res[static_cast<size_t>(r)]);
       });
     workers().run(tasks);
   }
@@ -207,11 +213,11 @@ bool multi_device_match_all(const rj_program* prog, const char* text, size_t n, 
       *result = s.rc;
       return true;
     }
-    if (r > 0 && have_prev && s.count > 0) {
+    if (r > 0 && have_prev && s.count > 0) {  // (segment ownership: never true when the replay ran; it guards the documented-semantics fallback)
       const uint64_t b = s.spans[0], e = s.spans[1];
       if (b < cur || (b == e && prev_end == b)) {  // the first match would change under the true carry-in
         ShardResult again;
-        run_shard(prog, r, text, n, cuts[static_cast<size_t>(r)], cuts[static_cast<size_t>(r) + 1], max_len, cur, prev_end, 1, &again);
+        run_shard(prog, r, text, n, cuts[static_cast<size_t>(r)], cuts[static_cast<size_t>(r) + 1], halo, cur, prev_end, 1, &again);
         if (again.rc != RJ_OK) {
           rj_fail(again.rc, "%s", again.error.c_str());
           *result = again.rc;
