@@ -78,6 +78,7 @@ def parse_args():
     ap.add_argument("--literal-bytes", type=int, default=5_000_000_000, help="text bytes per GPU of the literal / complex workloads")
     ap.add_argument("--big-literal-bytes", type=int, default=50_000_000_000, help="the north star's 50 GB single-GPU scan (extra)")
     ap.add_argument("--tree-files", type=int, default=12_500, help="jrep workload: files per GPU (~20 KB each)")
+    ap.add_argument("--in-flight", type=int, default=2, help="steps kept in flight by the headline loop (rj_multi objects used in turn)")
     ap.add_argument("--one-stream", action="store_true", help="headline loop as in round 3: both rj_multi objects and their tails on one stream")
     ap.add_argument("--jrep-files", type=int, default=100_000, help="jrep_10gb extra: files (BASELINE configs[4]: 100 000)")
     ap.add_argument("--jrep-bytes", type=int, default=10_000_000_000, help="jrep_10gb extra: total bytes (BASELINE configs[4]: 10 GB)")
@@ -334,18 +335,19 @@ def run_regexdna(args, c):
         tails of step k run under the scan of step k + 1.  tail_streams: both objects on ONE stream, but each queues its
         tails on a stream of its own (rj_multi_set_tail_stream): the scan kernels then follow each other in order on the
         one stream, with no cross-stream wait between them."""
-        multis = [rejit_amd.MultiScan(progs), rejit_amd.MultiScan(progs)]
+        depth = 2 if own_streams else max(2, args.in_flight)
+        multis = [rejit_amd.MultiScan(progs) for _ in range(depth)]
         for mm in multis:
             mm.set_mode(0)
             if tail_streams:
                 mm.set_tail_stream(True)
         second = torch.cuda.Stream(dev) if own_streams else None
-        streams = [stream, second.cuda_stream if own_streams else stream]
+        streams = [stream, second.cuda_stream] if own_streams else [stream] * depth
         if own_streams:
             multis[0].order_after(multis[1])
             multis[1].order_after(multis[0])
         side = torch.cuda.Stream(dev) if exchange is not None else None
-        fly = {"k": 0, "busy": [False, False], "keep": (second, side)}
+        fly = {"k": 0, "busy": [False] * depth, "keep": (second, side)}
         times = []
 
         def collect(j, record):
@@ -365,7 +367,7 @@ def run_regexdna(args, c):
                 return exchange.counts(multis[j], lambda: None, rerun_j, vis_lo, side.cuda_stream)
 
         def step(record):
-            j = fly["k"] % 2
+            j = fly["k"] % depth
             fly["k"] += 1
             res = collect(j, record) if fly["busy"][j] else None
             multis[j].start(text_ptr, n_local, stream=streams[j], own_begin=own_lo, own_end=own_hi)
@@ -374,7 +376,7 @@ def run_regexdna(args, c):
 
         def drain():
             res = None
-            for j in (fly["k"] % 2, (fly["k"] + 1) % 2):   # the older of the two first
+            for j in [(fly["k"] + d) % depth for d in range(depth)]:   # the oldest first
                 if fly["busy"][j]:
                     res = collect(j, True)
             return res

@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 #include "dense_streams.h"
 #include "device_program.h"
 #include "kernels.h"
@@ -36,7 +38,7 @@ constexpr int kWave = 64;
 constexpr uint64_t kIter = 2048;                    // bytes per wave iteration: 64 lanes x 32
 constexpr int kTileIters = 16;
 constexpr uint64_t kTile = kIter * kTileIters;      // 32 KiB: a wave's unit of look-back
-constexpr uint32_t kStage = 1024;                   // staged pairs per wave
+constexpr uint32_t kStage = 640;                    // staged pairs per wave and stage (two stages: 20 KiB per workgroup)
 constexpr uint32_t kLenBits = 17;                   // staged entry: begin - tile start (15 bits) << 17 | length
 constexpr int kTilesPerTicket = 4;
 
@@ -194,97 +196,118 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Str
 
 }  // namespace
 
-// One granule per WORKGROUP and round (its four tiles), not per tile: the four waves add their counts up in LDS and wave 0
-// looks back over the tickets before it.  With a granule per tile the look-back itself set the pace: a window step is a
-// trip to L2 (~0.5 us) and covers 64 granules, so the resolved prefix advances by ~100 tiles = 3-4 MB per microsecond at
-// best -- the rate these kernels ran at whatever their instruction count (`[@#]`, one step, took as long as
-// `[a-f]+[0-9]`).  A quarter of the granules, four times the headroom.
+// One unit of the prefix scan per WORKGROUP and round (its four tiles, one per wave), resolved ONE ROUND LATE
+// (tile_lookback.h): a round computes its tiles, stages their pairs in LDS and publishes their count; then the count of
+// everything before the PREVIOUS round's tiles is looked up -- published long ago by then, no waiting -- and that round's
+// staged pairs go out.  Two stages per wave, used alternately.  History: a granule per tile, resolved at once: the
+// look-back set the pace (`[@#]`, one step, took as long as `[a-f]+[0-9]`); a granule per workgroup: 1.62 ms per 5 GB;
+// two-level look-back: 1.53; with no look-back at all (wrong output) 1.17 -- the rest was waiting for the slowest of the
+// ~1800 units in flight, which this form no longer does.
 template <int NP, int NR, bool HIGH>
 __global__ __launch_bounds__(256) void dense_streams(StreamParams a) {
   __shared__ unsigned long long s_ticket, s_before;
-  __shared__ uint32_t s_count[kTilesPerTicket], s_bad;
-  __shared__ uint32_t s_stage[kTilesPerTicket][kStage];
+  __shared__ uint32_t s_count[2][kTilesPerTicket], s_bad;
+  __shared__ uint32_t s_stage[2][kTilesPerTicket][kStage];
   const int wv = static_cast<int>(threadIdx.x) >> 6;
   const int lane = lane_id();
   const StreamMasks<NP> mk = rj_stream_masks<NP>(a.plan);
   const StreamRangeMasks<NP, NR> rm = rj_stream_range_masks<NP, NR>(a.plan);
   const uint64_t n_tickets = (a.n_tiles + kTilesPerTicket - 1) / kTilesPerTicket;
+  if (threadIdx.x == 0) s_bad = 0;
+  uint64_t prev_tk = ~0ull;  // the round whose pairs wait in s_stage[cur ^ 1]
+  uint32_t prev_k = 0;
+  int cur = 0;
   for (;;) {
-    if (threadIdx.x == 0) {
-      s_ticket = atomicAdd(a.ticket, 1ull);
-      s_bad = 0;
-    }
+    if (threadIdx.x == 0) s_ticket = atomicAdd(a.ticket, 1ull);
     __syncthreads();
     const uint64_t tk = s_ticket;
-    if (tk >= n_tickets) return;
+    const bool have = tk < n_tickets;
     const uint64_t t = tk * kTilesPerTicket + static_cast<uint64_t>(wv);
     const uint64_t base = (a.first_tile + t) * kTile;
-    // the run is void already (a time-out or an overrun elsewhere): publish a count so that nobody waits for this ticket
-    const bool void_run = __hip_atomic_load(a.counters + kCntOverrun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    TileOut o{s_stage[wv], a.out, a.out_cap, 0};
-    uint32_t slow = 0;
-    bool overrun = false;
     uint32_t k = 0;
-    if (!void_run && t < a.n_tiles) k = stream_tile<NP, NR, HIGH, false>(a, mk, rm, base, o, &slow, &overrun);
-    overrun = __ballot(overrun) != 0;
-    if (lane == 0) {
-      s_count[wv] = k;
-      if (void_run || overrun) s_bad = 1;
-    }
-    __syncthreads();
-    if (wv == 0) {
-      unsigned long long total = 0, before = 0;
+    if (have) {
+      // (the run is void already -- a time-out or an overrun elsewhere: only publish a count so that nobody waits)
+      const bool void_run = __hip_atomic_load(a.counters + kCntOverrun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      const TileOut o{s_stage[cur][wv], a.out, a.out_cap, 0};
+      uint32_t slow = 0;
+      bool overrun = false;
+      if (!void_run && t < a.n_tiles) k = stream_tile<NP, NR, HIGH, false>(a, mk, rm, base, o, &slow, &overrun);
+      if (__ballot(overrun) != 0 && lane == 0) {
+        a.counters[kCntOverrun] = 1;
+        if (a.host_counters) a.host_counters[kCntOverrun] = 1;
+      }
+      if (slow != 0) {
+        uint32_t total = slow;
 #pragma unroll
-      for (int w = 0; w < kTilesPerTicket; w++) total += s_count[w];
-      bool ok = s_bad == 0;
-      if (ok) ok = lookback::look_back(a.granules, tk, total, &before);
+        for (int w = 32; w > 0; w >>= 1) total += __shfl_xor(total, w);
+        if (lane == 0) atomicAdd(a.counters + kCntSlowStarts, static_cast<unsigned long long>(total));
+      }
+      if (lane == 0) s_count[cur][wv] = k;
+    }
+    // wave 0, its own tile done, looks up the count of everything before the PREVIOUS round (the other waves are still at
+    // their tiles); behind the barrier it publishes this round's count
+    unsigned long long prev_total = 0;
+    if (wv == 0 && prev_tk != ~0ull) {
+      unsigned long long before = 0;
+      const bool ok = (a.debug & 1u) != 0 || lookback::resolve(a.granules, n_tickets, prev_tk, &before);
       if (lane == 0) {
+#pragma unroll
+        for (int w = 0; w < kTilesPerTicket; w++) prev_total += s_count[cur ^ 1][w];
         if (!ok) {
-          lookback::publish_void(a.granules, tk);
           a.counters[kCntOverrun] = 1;
           if (a.host_counters) a.host_counters[kCntOverrun] = 1;
           s_bad = 1;
-        } else if (tk == n_tickets - 1) {
-          a.counters[kCntFinal] = before + total;
-          a.counters[kCntCands] = before + total;
-          a.counters[kCntHits] = before + total;
+        } else if (prev_tk == n_tickets - 1) {
+          a.counters[kCntFinal] = before + prev_total;
+          a.counters[kCntCands] = before + prev_total;
+          a.counters[kCntHits] = before + prev_total;
           if (a.host_counters) {
-            a.host_counters[kCntFinal] = before + total;
-            a.host_counters[kCntCands] = before + total;
-            a.host_counters[kCntHits] = before + total;
+            a.host_counters[kCntFinal] = before + prev_total;
+            a.host_counters[kCntCands] = before + prev_total;
+            a.host_counters[kCntHits] = before + prev_total;
           }
         }
         s_before = before;
       }
     }
     __syncthreads();
-    const bool bad = s_bad != 0;
-    unsigned long long before = s_before;
-    for (int w = 0; w < wv; w++) before += s_count[w];
-    __syncthreads();  // (s_ticket, s_bad, s_count are rewritten at the top of the next round)
-    if (bad || t >= a.n_tiles) continue;
-    if (slow != 0) {
-      uint32_t total = slow;
+    if (have && threadIdx.x == 0) {
+      unsigned long long total = 0;
 #pragma unroll
-      for (int w = 32; w > 0; w >>= 1) total += __shfl_xor(total, w);
-      if (lane == 0) atomicAdd(a.counters + kCntSlowStarts, static_cast<unsigned long long>(total));
+      for (int w = 0; w < kTilesPerTicket; w++) total += s_count[cur][w];
+      lookback::publish(a.granules, n_tickets, tk, total);
     }
-    if (k <= kStage) {
-      // the staged pairs to their final place: lane i takes pair i, 16 bytes each -- one KiB per wave store
-      const uint64_t tile_start = base - kStreamShift;
-      for (uint32_t i = static_cast<uint32_t>(lane); i < k; i += kWave) {
-        const uint32_t e = o.stage[i];
-        const uint64_t b = tile_start + (e >> kLenBits);
-        const uint64_t pos = before + i;
-        if (pos < a.out_cap) *reinterpret_cast<ulonglong2*>(a.out + 2 * pos) = make_ulonglong2(b, b + (e & ((1u << kLenBits) - 1u)));
+    if (prev_tk != ~0ull && s_bad == 0 && !(a.debug & 2u)) {
+      const uint64_t pt = prev_tk * kTilesPerTicket + static_cast<uint64_t>(wv);
+      const uint64_t pbase = (a.first_tile + pt) * kTile;
+      unsigned long long before = s_before;
+      for (int w = 0; w < wv; w++) before += s_count[cur ^ 1][w];
+      if (pt >= a.n_tiles) {
+        // (a wave beyond the last tile)
+      } else if (prev_k <= kStage) {
+        // the staged pairs to their final place: lane i takes pair i, 16 bytes each -- one KiB per wave store
+        const uint32_t* stage = s_stage[cur ^ 1][wv];
+        const uint64_t tile_start = pbase - kStreamShift;
+        for (uint32_t i = static_cast<uint32_t>(lane); i < prev_k; i += kWave) {
+          const uint32_t e = stage[i];
+          const uint64_t b = tile_start + (e >> kLenBits);
+          const uint64_t pos = before + i;
+          if (pos < a.out_cap) *reinterpret_cast<ulonglong2*>(a.out + 2 * pos) = make_ulonglong2(b, b + (e & ((1u << kLenBits) - 1u)));
+        }
+      } else {
+        // more pairs than the stage holds: the tile once more, its base known now
+        const TileOut o{s_stage[cur ^ 1][wv], a.out, a.out_cap, before};
+        uint32_t slow2 = 0;
+        bool ov2 = false;
+        (void)stream_tile<NP, NR, HIGH, true>(a, mk, rm, pbase, o, &slow2, &ov2);
       }
-    } else {
-      // more pairs than the stage holds: the tile once more, its base known now
-      o.direct_base = before;
-      uint32_t slow2 = 0;
-      bool ov2 = false;
-      (void)stream_tile<NP, NR, HIGH, true>(a, mk, rm, base, o, &slow2, &ov2);
     }
+    if (!have) return;
+    // (two barriers per round: s_ticket is rewritten when every wave has read it -- before the second one --, s_count[cur ^ 1]
+    // and s_before behind the next round's first)
+    prev_tk = tk;
+    prev_k = k;
+    cur ^= 1;
   }
 }
 
@@ -295,9 +318,11 @@ uint64_t stream_tiles(uint64_t sb, uint64_t se, uint64_t n, uint64_t* first_tile
   return (lim - 1 + kStreamShift) / kTile - *first_tile + 1;
 }
 
-size_t stream_scratch_bytes(uint64_t n_tiles) { return ((n_tiles + kTilesPerTicket - 1) / kTilesPerTicket + 1) * sizeof(unsigned long long); }
+size_t stream_scratch_bytes(uint64_t n_tiles) {
+  return (lookback::granule_words((n_tiles + kTilesPerTicket - 1) / kTilesPerTicket) + 1) * sizeof(unsigned long long);
+}
 
-// scratch: [0] the ticket counter, [1 ..] one granule per ticket (four tiles); cleared here
+// scratch: [0] the ticket counter, [1 ..] one granule per ticket (four tiles), then one per group of tickets; cleared here
 namespace {
 template <int NP, int NR>
 void launch_nr(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
@@ -317,6 +342,8 @@ void launch_np(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipS
 
 void launch_dense_streams(StreamParams a, unsigned long long* scratch, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
   (void)hipMemsetAsync(scratch, 0, stream_scratch_bytes(a.n_tiles), st);
+  static const uint32_t debug = getenv("RJ_STREAM_DEBUG") ? static_cast<uint32_t>(atoi(getenv("RJ_STREAM_DEBUG"))) : 0u;
+  a.debug = debug;
   a.ticket = scratch;
   a.granules = scratch + 1;
   uint64_t blocks = (a.n_tiles + kTilesPerTicket - 1) / kTilesPerTicket;

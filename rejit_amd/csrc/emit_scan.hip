@@ -124,18 +124,11 @@ __device__ __forceinline__ uint32_t chunk_mask(const uint4& v, uint64_t at, uint
 // counters[kCntOverrun] = 1 when a spin timed out.
 namespace {
 
-// one tile: masks, count, look-back, pairs
-// `resolve(k, &before)`: the tile's count -> the count of everything before the tile (false: the run is void); called by
-// all four waves of the workgroup together (it synchronises them: one granule per workgroup and round, see the kernel)
-template <typename Resolve>
-__device__ __forceinline__ void emit_tile(const uint8_t* __restrict__ text, uint64_t n, uint64_t sb, uint64_t se, uint32_t nullable,
-                                          uint64_t n_tiles, uint64_t first_tile, uint64_t t, uint64_t* out,
-                                          uint64_t out_cap, Resolve resolve) {
+// One tile, first half: its candidate masks (bit j of chunk c's mask = position base + 1024 c + 16 lane + j is a match; two
+// chunks per register) and its count (wave-uniform).
+__device__ __forceinline__ uint32_t tile_masks(const uint8_t* __restrict__ text, uint64_t n, uint64_t sb, uint64_t se, uint32_t nullable,
+                                               bool live, uint64_t base, uint32_t (&mask)[kTileChunks / 2]) {
   const int lane = lane_id();
-  const bool live = t < n_tiles;  // (wave-uniform: a wave beyond the last tile only takes part in the workgroup's sums)
-  const uint64_t base = (first_tile + t) * kTile;
-  // ---- the tile's candidate masks: bit j of chunk c's mask = position base + 1024 c + 16 lane + j is a match
-  uint32_t mask[kTileChunks / 2];  // two chunks per register
   uint32_t mine = 0;
   uint32_t carry_lb = 1u;          // was the byte before the chunk a line break (the start of the text counts as one)
   if (live && base > 0) {
@@ -182,16 +175,16 @@ __device__ __forceinline__ void emit_tile(const uint8_t* __restrict__ text, uint
       mask[h] = both;
     }
   }
-  // ---- the tile's count; the count of everything before the tile
-  const uint32_t inc_all = wave_inclusive_sum(mine);
-  const unsigned long long k = wave_last_lane(inc_all);
-  unsigned long long before_tile = 0;
-  if (!resolve(k, &before_tile) || !live) return;
-  // ---- the pairs, at their final place
-  uint64_t pos = before_tile;
-#pragma unroll
+  return wave_last_lane(wave_inclusive_sum(mine));
+}
+
+// Second half, a round later: the pairs of the tile at `base`, whose masks wait in LDS (masks[h * 64 + lane]), at their
+// final place: `pos` = the count of everything before the tile.
+__device__ __forceinline__ void tile_pairs(const uint32_t* masks, uint64_t base, uint64_t pos, uint64_t* out, uint64_t out_cap) {
+  const int lane = lane_id();
+#pragma unroll 4
   for (int c = 0; c < kTileChunks; c++) {
-    uint32_t m = (mask[c >> 1] >> (16 * (c & 1))) & 0xFFFFu;
+    uint32_t m = (masks[(c >> 1) * kWave + lane] >> (16 * (c & 1))) & 0xFFFFu;
     const uint32_t cnt = __popc(m);
     const uint32_t inc = wave_inclusive_sum(cnt);
     uint64_t at_out = pos + inc - cnt;
@@ -225,58 +218,80 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                                                        uint64_t* out, uint64_t out_cap, unsigned long long* counters,
                                                        unsigned long long* host_counters) {
   __shared__ unsigned long long s_ticket, s_before;
-  __shared__ unsigned long long s_count[kTilesPerTicket];
+  __shared__ unsigned long long s_count[2][kTilesPerTicket];
   __shared__ uint32_t s_bad;
+  __shared__ uint32_t s_masks[kTilesPerTicket][(kTileChunks / 2) * kWave];  // the masks of the round that waits for its prefix: 16 KiB
   const int wv = static_cast<int>(threadIdx.x) >> 6;
   const int lane = lane_id();
   const uint64_t first_tile = sb / kTile;
   const uint64_t n_tickets = (n_tiles + kTilesPerTicket - 1) / kTilesPerTicket;
+  if (threadIdx.x == 0) s_bad = 0;
+  // One unit of the prefix scan per workgroup and round (four tiles, one per wave), resolved ONE ROUND LATE
+  // (tile_lookback.h): a round finds its tiles' masks and publishes their count; then the count of everything before the
+  // PREVIOUS round's tiles is looked up -- published long ago by then: no waiting -- and that round's pairs are written from
+  // the masks it left in LDS; then this round's masks take their place.
+  uint64_t prev_tk = ~0ull;
+  int cur = 0;
   for (;;) {
     // ---- a ticket per workgroup and round, in arrival order
     if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1ull);
     __syncthreads();
     const uint64_t tk = s_ticket;
-    if (tk >= n_tickets) return;
+    const bool have = tk < n_tickets;
     const uint64_t t = tk * kTilesPerTicket + static_cast<uint64_t>(wv);
-    // ONE granule per workgroup and round (round 4; a granule per tile before): the four waves add their counts up in
-    // LDS, wave 0 looks back over the tickets before this one (tile_lookback.h), every wave adds the waves below it
-    auto resolve = [&](unsigned long long k, unsigned long long* before) -> bool {
-      if (lane == 0) s_count[wv] = k;
-      __syncthreads();
-      if (wv == 0) {
-        unsigned long long total = 0, b = 0;
+    uint32_t mask[kTileChunks / 2];
+    if (have) {
+      const uint32_t k = tile_masks(text, n, sb, se, nullable, t < n_tiles, (first_tile + t) * kTile, mask);
+      if (lane == 0) s_count[cur][wv] = k;
+    }
+    // wave 0, its own tile done, looks up the count of everything before the PREVIOUS round (the other waves are still at
+    // their tiles); behind the barrier it publishes this round's count
+    if (wv == 0 && prev_tk != ~0ull) {
+      unsigned long long b = 0;
+      const bool ok = lookback::resolve(granules, n_tickets, prev_tk, &b);
+      if (lane == 0) {
+        unsigned long long total = 0;
 #pragma unroll
-        for (int w = 0; w < kTilesPerTicket; w++) total += s_count[w];
-        const bool ok = lookback::look_back(granules, tk, total, &b);
-        if (lane == 0) {
-          s_bad = ok ? 0u : 1u;
-          s_before = b;
-          if (!ok) {
-            // (publish something so that nobody behind this ticket waits for ever; the run is void)
-            lookback::publish_void(granules, tk);
-            counters[kCntOverrun] = 1;
-            if (host_counters) host_counters[kCntOverrun] = 1;
-          } else if (tk == n_tickets - 1) {
-            counters[kCntFinal] = b + total;
-            counters[kCntCands] = b + total;
-            counters[kCntHits] = b + total;
-            if (host_counters) {
-              host_counters[kCntFinal] = b + total;
-              host_counters[kCntCands] = b + total;
-              host_counters[kCntHits] = b + total;
-            }
+        for (int w = 0; w < kTilesPerTicket; w++) total += s_count[cur ^ 1][w];
+        s_before = b;
+        if (!ok) {
+          s_bad = 1;
+          counters[kCntOverrun] = 1;
+          if (host_counters) host_counters[kCntOverrun] = 1;
+        } else if (prev_tk == n_tickets - 1) {
+          counters[kCntFinal] = b + total;
+          counters[kCntCands] = b + total;
+          counters[kCntHits] = b + total;
+          if (host_counters) {
+            host_counters[kCntFinal] = b + total;
+            host_counters[kCntCands] = b + total;
+            host_counters[kCntHits] = b + total;
           }
         }
       }
-      __syncthreads();
+    }
+    __syncthreads();
+    if (have && threadIdx.x == 0) {
+      unsigned long long total = 0;
+#pragma unroll
+      for (int w = 0; w < kTilesPerTicket; w++) total += s_count[cur][w];
+      lookback::publish(granules, n_tickets, tk, total);
+    }
+    if (prev_tk != ~0ull && s_bad == 0) {
+      const uint64_t pt = prev_tk * kTilesPerTicket + static_cast<uint64_t>(wv);
       unsigned long long b = s_before;
-      for (int w = 0; w < wv; w++) b += s_count[w];
-      const bool ok = s_bad == 0;
-      __syncthreads();  // (the shared words are rewritten in the next round)
-      *before = b;
-      return ok;
-    };
-    emit_tile(text, n, sb, se, nullable, n_tiles, first_tile, t, out, out_cap, resolve);
+      for (int w = 0; w < wv; w++) b += s_count[cur ^ 1][w];
+      if (pt < n_tiles) tile_pairs(s_masks[wv], (first_tile + pt) * kTile, b, out, out_cap);
+    }
+    if (!have) return;
+    // (a wave reads and writes only its own s_masks row; the other shared words of this round are rewritten behind the
+    // next round's barriers)
+    if (t < n_tiles) {
+#pragma unroll
+      for (int h = 0; h < kTileChunks / 2; h++) s_masks[wv][h * kWave + lane] = mask[h];
+    }
+    prev_tk = tk;
+    cur ^= 1;
   }
 }
 
@@ -296,6 +311,6 @@ uint64_t emit_tiles(uint64_t sb, uint64_t se) {
   return (se + kTile - 1) / kTile - sb / kTile;  // tiles that hold a start in [sb, se)
 }
 
-size_t emit_scratch_bytes(uint64_t sb, uint64_t se) { return ((emit_tiles(sb, se) + 3) / 4 + 1) * sizeof(unsigned long long); }
+size_t emit_scratch_bytes(uint64_t sb, uint64_t se) { return (lookback::granule_words((emit_tiles(sb, se) + 3) / 4) + 1) * sizeof(unsigned long long); }
 
 }  // namespace rejit_amd

@@ -201,6 +201,7 @@ struct StreamParams {
   unsigned long long* counters;
   unsigned long long* host_counters;
   uint32_t max_walk;     // DevProgram::max_walk: a walk this long voids the run (the carry scan takes it)
+  uint32_t debug;        // measurement (RJ_STREAM_DEBUG): 1 = no look-back, 2 = no output stores, 4 = no steps
   StreamPlan plan;
 };
 uint64_t stream_tiles(uint64_t sb, uint64_t se, uint64_t n, uint64_t* first_tile);
@@ -284,6 +285,7 @@ struct SharedHits {
   const uint32_t* blob;   // descriptors + tables (device memory)
   uint32_t desc_words;    // words the descriptors take (a multiple of 4)
   uint32_t blob_words;    // descriptors + tables (a multiple of 4)
+  uint32_t reverse;       // classify_shared_multi: take the regions from the last one down
 };
 // max_words / max_short: the largest n_words / short_max among the patterns (selects the kernel instantiation)
 void launch_tails_shared(const MultiTail* d_tails, const SharedHits& sh, int max_words, uint32_t max_short, unsigned long long* counters0,

@@ -318,6 +318,8 @@ SharedHits shared_hits_of(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64
   sh.n = n;
   sh.sb = sb;
   sh.se = se;
+  static const bool forward = getenv("RJ_CLASSIFY_FORWARD") != nullptr;  // measurement override
+  sh.reverse = forward ? 0u : 1u;
   return sh;
 }
 

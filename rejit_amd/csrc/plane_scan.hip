@@ -359,7 +359,10 @@ __global__ __launch_bounds__(256) void classify_shared_multi(SharedHits sh, unsi
   const uint64_t n = sh.n, sb = sh.sb, se = sh.se;
   // the first region's count and candidates are on their way while the blob is copied (a region has at least
   // 64 slots: the first 32 are read whatever the count says)
+  // (regions are taken from the LAST one down: the scan read the text front to back, so the end of the text is what the
+  // caches still hold when this kernel starts)
   uint64_t r = wave * 2 + half;
+  if (sh.reverse && r < sh.n_regions) r = sh.n_regions - 1 - r;
   uint32_t raw = r < sh.n_regions ? sh.counts[r] : 0u;
   uint64_t s_first = r < sh.n_regions ? sh.hits[r * sh.cap + sub] : 0;
   {
@@ -374,6 +377,7 @@ __global__ __launch_bounds__(256) void classify_shared_multi(SharedHits sh, unsi
   for (uint64_t r0 = wave * 2; r0 < sh.n_regions; r0 += n_waves * 2) {
     r = r0 + half;
     const bool live = r < sh.n_regions;
+    if (sh.reverse && live) r = sh.n_regions - 1 - r;
     if (r0 != wave * 2) {
       raw = live ? sh.counts[r] : 0u;
       s_first = live ? sh.hits[r * sh.cap + sub] : 0;

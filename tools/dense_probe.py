@@ -12,7 +12,10 @@ calls = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 dev = torch.device("cuda:0")
 text = W.random_ascii_torch(n, 0xC0FFEE, dev)
 st = torch.cuda.current_stream(dev).cuda_stream
-for rx in (b"[a-f]+[0-9]", b"[~]", b"[@#]", b"[a-z]+", b"[0-9]+", b"[A-Z][a-z]+", b"[0-9][0-9][0-9]", b"^"):
+patterns = (b"[a-f]+[0-9]", b"[~]", b"[@#]", b"[a-z]+", b"[0-9]+", b"[A-Z][a-z]+", b"[0-9][0-9][0-9]", b"^")
+if os.environ.get("DENSE_PROBE_RX"):
+    patterns = tuple(x.encode() for x in os.environ["DENSE_PROBE_RX"].split(" "))
+for rx in patterns:
     p = rejit_amd.Program(rx)
     s = rejit_amd.Scan(p)
     times = []
