@@ -12,12 +12,12 @@
 //   * a start still alive after the plan's depth (16 bytes for patterns with a loop) is walked by its lane with the
 //     plan's own scalar walk (rj_stream_walk): rare on random text, counted (kCntSlowStarts) -- the host goes back to
 //     scan_dense_walk for a scan object whose text makes it common;
-//   * output as in emit_scan.hip: a wave owns a TILE of 32 KiB (16 iterations), stages its pairs in LDS (4 bytes each:
-//     begin relative to the tile | length), publishes the tile's count as a {status, value} granule, finds the count of
-//     everything before the tile by a decoupled look-back (Merrill & Garland) over tiles handed out in ARRIVAL order (a
-//     ticket per workgroup and round, so every tile a wave waits for belongs to a wave that has started), and then
-//     writes the staged pairs with coalesced 16-byte stores.  A tile with more pairs than the stage holds is computed a
-//     second time with its base known, writing directly (`[a-p]` on a text of a..p).
+//   * output as in emit_scan.hip: a wave owns a TILE of 32 KiB (16 iterations) and stages its pairs in LDS (4 bytes each:
+//     begin relative to the tile | length); the workgroup publishes the count of its four tiles (tiles are handed out in
+//     ARRIVAL order: a ticket per workgroup and round, so everything a wave waits for belongs to a wave that has started),
+//     computes its NEXT four tiles into the other stage, and only then looks up the count of everything before the staged
+//     ones (tile_lookback.h: published long ago by then) and writes them with coalesced 16-byte stores.  A tile with more
+//     pairs than a stage holds is computed a second time with its base known, writing directly (`[a-p]` on a text of a..p).
 // Every spin is bounded; a time-out or a walk beyond max_walk flags the run (kCntOverrun) and the engine repeats it on
 // scan_dense_walk (and, from there, the carry scan).
 #include <hip/hip_runtime.h>

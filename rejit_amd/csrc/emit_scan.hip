@@ -9,15 +9,17 @@
 // copies them -- every pair written twice and read once in between, 8.9 GB moved for 6.3 GB of algorithmic bytes
 // over a 5 GB text, 2.47 ms.
 //
-// Here the final position of a tile's matches comes from a DECOUPLED LOOK-BACK over the tiles before it (the
-// single-pass prefix scan of Merrill & Garland): a wave takes a tile of 32 KiB, finds the line breaks of its 32
-// chunks (16 bits per lane and chunk: the masks of the whole tile stay in 16 registers), counts, publishes the count
-// as an 8-byte {status, value} granule, reads the granules of the tiles before it until it meets one that
-// already knows its inclusive prefix, publishes its own, and writes the pairs where they belong.  Tiles are handed
-// out in the order in which workgroups ARRIVE (one ticket per workgroup and round, a tile per wave), so every tile a
-// wave waits for is owned by a wave that has started -- no assumption about dispatch order or residency.
-// Granules are written and read with relaxed agent-scope atomics (the data is the flag; MI355X guide, "R2");
-// every spin is bounded: on a time-out the kernel flags the run and the engine repeats it on the dense kernel.
+// Here the final position of a tile's matches comes from a single-pass prefix scan over the tiles before it (after
+// Merrill & Garland's decoupled look-back; tile_lookback.h): a wave takes a tile of 32 KiB, finds the line breaks of its
+// 32 chunks (16 bits per lane and chunk: the masks of the whole tile are 16 registers), counts, and the workgroup publishes
+// the count of its four tiles.  The masks then wait in LDS while the workgroup does its NEXT four tiles; only after that
+// is the count of everything before them looked up -- it was published long ago by then, nothing waits -- and the pairs are
+// written where they belong.  (Resolving at once, as round 3 did and the textbook does, cost a quarter of the kernel: the
+// ~1800 resident workgroups finish a round nearly in lock-step, and every one of them waited for the slowest.)  Tiles are
+// handed out in the order in which workgroups ARRIVE (one ticket per workgroup and round, a tile per wave), so everything a
+// wave waits for is owned by a wave that has started -- no assumption about dispatch order or residency.  The words of the
+// scan are written and read with relaxed agent-scope atomics (the data is the flag; MI355X guide, "R2"); every spin is
+// bounded: on a time-out the kernel flags the run and the engine repeats it on the dense kernel.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
