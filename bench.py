@@ -813,6 +813,10 @@ def literal_and_complex_extras(args, c, out):
     # (the dense kernel is issue-bound, not HBM-bound: its VALU roofline says how close to the other ceiling it runs)
     _dl = out["dense_scan"]["roofline"]["avg_launch_ms"]
     if _dl:
+        # (`frac` counts the text bytes only; the kernel also writes 16 B per match, once: both together)
+        _k = int(out["dense_scan"].get("matches", 0))
+        out["dense_scan"]["roofline"]["with_pairs_written"] = {"bytes_per_launch": n + 16 * _k, "achieved": round((n + 16 * _k) / (_dl * 1e-3) / 1e9, 1),
+                                                               "frac": round((n + 16 * _k) / (_dl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         _valu = n * rejit_amd.DENSE_VALU_OPS_PER_BYTE / (_dl * 1e-3) / 1e12
         out["dense_scan"]["roofline_valu"] = {"bound": "valu", "kernel": "dense_streams<2,2>",
                                               "ops_per_text_byte": rejit_amd.DENSE_VALU_OPS_PER_BYTE, "achieved": round(_valu, 2),
@@ -840,7 +844,7 @@ def literal_and_complex_extras(args, c, out):
                          "value": round(n / (sorted(ltot)[len(ltot) // 2] * 1e-3) / 1e9, 1), "unit": "GB/s of text",
                          "latency_ms": round(sorted(ltot)[len(ltot) // 2], 4), "latency_ms_min": round(min(ltot), 4), "cold_call_ms": round(cold_l * 1e3, 3),
                          "calls_timed": len(ltot), "write_bytes_per_launch": 16 * int(k),
-                         "roofline": hbm_roofline("emit_assertions (one pass, decoupled look-back: n text bytes read + 16 B written per match)", bytes_l, a_l,
+                         "roofline": hbm_roofline("emit_assertions (one pass, prefix scan resolved a round late: n text bytes read + 16 B written per match)", bytes_l, a_l,
                                                   pmc_traffic("line_table", bytes=n))}
     del t
     torch.cuda.empty_cache()

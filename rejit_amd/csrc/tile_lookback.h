@@ -57,35 +57,11 @@ __device__ __forceinline__ void publish(unsigned long long* units, uint64_t n_un
   __hip_atomic_fetch_add(&units[n_units + t / kGroup], (1ull << kArrivalShift) | k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ONE WAVE: the count of all units before t (every one of them has been, or will be, published).
-// Only a group's FIRST unit looks back over the groups (and leaves prefix[g] for the other 63, who read it in the same trip
-// as the words of their own group): when every unit did, ~1800 waves read the same 64 group words at the same moment --
-// eight cache lines behind ONE memory channel -- and the resolve took longer than the wait it was meant to avoid
-// (`[@#]` over 5 GB: 1.43 -> 1.93 ms).
-__device__ __forceinline__ bool resolve(unsigned long long* units, uint64_t n_units, uint64_t t, unsigned long long* before) {
+// ONE WAVE: the count of all groups before g: complete group words, nearest first (lane l: group window_end - 1 - l), back
+// to a group whose exclusive prefix is known; leaves prefix[g] behind.
+__device__ __forceinline__ bool groups_before(unsigned long long* groups, unsigned long long* prefix, uint64_t g, unsigned long long* out) {
   const int lane = lane_id();
-  unsigned long long* groups = units + n_units;
-  unsigned long long* prefix = groups + n_groups(n_units);
-  const uint64_t g = t / kGroup;
-  const uint32_t i = static_cast<uint32_t>(t % kGroup);
-  if (i != 0) {
-    // lane l < i: unit 64 g + l of the own group; lane 63: the group's exclusive prefix.  A lane whose word has arrived keeps it.
-    const bool unit_lane = static_cast<uint32_t>(lane) < i, prefix_lane = lane == kWave - 1;
-    unsigned long long v = prefix_lane && g == 0 ? kHave : 0ull;
-    const unsigned long long* at = unit_lane ? &units[g * kGroup + static_cast<uint64_t>(lane)] : &prefix[g];
-    uint32_t spins = 0;
-    for (;;) {
-      if ((unit_lane || prefix_lane) && v == 0) v = __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__ballot((unit_lane || prefix_lane) && v == 0) == 0) break;
-      if (++spins > kSpinLimit) return false;
-      __builtin_amdgcn_s_sleep(1);
-    }
-    *before = wave_sum((unit_lane || prefix_lane) ? (v & kValueMask) : 0ull);
-    return true;
-  }
-  // the group's first unit: the groups before g, nearest first (lane l: group window_end - 1 - l), back to one whose
-  // exclusive prefix is known
-  unsigned long long groups_before = 0;
+  unsigned long long total = 0;
   uint64_t window_end = g;
   while (window_end != 0) {
     const bool valid = window_end >= static_cast<uint64_t>(lane) + 1;
@@ -111,12 +87,50 @@ __device__ __forceinline__ bool resolve(unsigned long long* units, uint64_t n_un
     const int stop = known ? __builtin_ctzll(known) : kWave;
     unsigned long long part = valid && lane <= stop ? sum : 0ull;
     if (lane == stop) part += pre & kValueMask;
-    groups_before += wave_sum(part);
+    total += wave_sum(part);
     if (known) break;
     window_end = window_end > static_cast<uint64_t>(kWave) ? window_end - kWave : 0;
   }
-  if (lane == 0 && g != 0) __hip_atomic_store(&prefix[g], kHave | groups_before, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  *before = groups_before;
+  if (lane == 0 && g != 0) __hip_atomic_store(&prefix[g], kHave | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  *out = total;
+  return true;
+}
+
+// ONE WAVE: the count of all units before t (every one of them has been, or will be, published).
+// Only a group's FIRST unit looks back over the groups (and leaves prefix[g] for the other 63, who read it in the same trip
+// as the words of their own group): when every unit did, ~1800 waves read the same 64 group words at the same moment --
+// eight cache lines behind ONE memory channel -- and the resolve took longer than the wait it was meant to avoid
+// (`[@#]` over 5 GB: 1.43 -> 1.93 ms).  A unit that has its own group's words but still no prefix[g] after kPatience
+// polls works it out itself (the first unit's workgroup may be a round behind: at the end of the run, or when it was slow).
+constexpr uint32_t kPatience = 16;
+__device__ __forceinline__ bool resolve(unsigned long long* units, uint64_t n_units, uint64_t t, unsigned long long* before) {
+  const int lane = lane_id();
+  unsigned long long* groups = units + n_units;
+  unsigned long long* prefix = groups + n_groups(n_units);
+  const uint64_t g = t / kGroup;
+  const uint32_t i = static_cast<uint32_t>(t % kGroup);
+  if (i == 0) return groups_before(groups, prefix, g, before);
+  // lane l < i: unit 64 g + l of the own group; lane 63: the group's exclusive prefix.  A lane whose word has arrived keeps it.
+  const bool unit_lane = static_cast<uint32_t>(lane) < i, prefix_lane = lane == kWave - 1;
+  unsigned long long v = prefix_lane && g == 0 ? kHave : 0ull;
+  const unsigned long long* at = unit_lane ? &units[g * kGroup + static_cast<uint64_t>(lane)] : &prefix[g];
+  uint32_t spins = 0;
+  bool have_prefix = false;
+  for (;;) {
+    if ((unit_lane || prefix_lane) && v == 0) v = __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool units_here = __ballot(unit_lane && v == 0) == 0;
+    have_prefix = __ballot(prefix_lane && v == 0) == 0;
+    if (units_here && (have_prefix || spins >= kPatience)) break;
+    if (++spins > kSpinLimit) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  unsigned long long sum = wave_sum((unit_lane || (prefix_lane && have_prefix)) ? (v & kValueMask) : 0ull);
+  if (!have_prefix) {
+    unsigned long long gb = 0;
+    if (!groups_before(groups, prefix, g, &gb)) return false;
+    sum += gb;
+  }
+  *before = sum;
   return true;
 }
 
