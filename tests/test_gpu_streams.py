@@ -105,3 +105,31 @@ def test_stream_kernel_long_runs_fall_back(rj, oracle):
         got, st = run_scan(rj, scan2, long_text)
         assert got == want, call
         assert st["stream_path"] == 0
+
+
+def test_prefix_scan_across_unit_groups(rj, oracle):
+    """The single-write kernels place their pairs with a prefix scan over UNITS of 128 KiB (a workgroup's four tiles) that
+    form GROUPS of 64 (8 MiB), resolved a round late (rejit_amd/csrc/tile_lookback.h): texts around one, two and five
+    groups -- a last group that is partial, complete, or one unit long --, whole and as own ranges that begin inside a
+    group, for the bit-stream kernel (`[@#]`, `[a-f]+[0-9]`) and the line table (`^`, `$`), against the oracle."""
+    from rejit_amd import workloads as W
+    unit, group = 128 << 10, 8 << 20
+    base = W.random_ascii_numpy(5 * group + 3 * unit + 777, seed=123)
+    base[np.arange(60, base.size, 61)] = 10       # a line break every 61 bytes, like the bench's line table
+    base[np.arange(7000, base.size, 9973)] = 13
+    for n in (group - 1024, group, group + unit, group + unit + 1, 2 * group + 5, base.size):
+        text = base[:n].tobytes()
+        for rx in (b"[@#]", b"[a-f]+[0-9]", b"^", b"$"):
+            if n > 3 * group and rx in (b"[a-f]+[0-9]", b"$"):
+                continue                               # (the largest text once per kernel)
+            p = rj.Program(rx)
+            scan = rj.Scan(p)
+            want = oracle.match_all(rx, text)
+            got, st = run_scan(rj, scan, text)
+            assert got == want, (rx, n)
+            if rx in (b"[@#]", b"[a-f]+[0-9]"):
+                assert st["stream_path"] == 1, (rx, n)
+            if n == 2 * group + 5:
+                for lo, hi in ((group - 7, group + 3 * unit + 1), (group + 5 * unit + 17, n + 1), (3 * unit, 2 * group - unit)):
+                    got, st = run_scan(rj, scan, text, own_begin=lo, own_end=hi)
+                    assert got == [m for m in want if lo <= m[0] < hi], (rx, n, lo, hi)
