@@ -215,7 +215,7 @@ __device__ __forceinline__ void tile_pairs(const uint32_t* masks, uint64_t base,
 // What is left is instruction count (6.4 VALU operations per text byte at ~25 % VALU utilisation).
 constexpr int kTilesPerTicket = 4;
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void emit_assertions(const uint8_t* __restrict__ text, uint64_t n, uint64_t sb, uint64_t se, uint32_t nullable,
+__global__ __launch_bounds__(256) void emit_assertions(const uint8_t* __restrict__ text, uint64_t n, uint64_t sb, uint64_t se, uint32_t nullable,
                                                        unsigned long long* granules, unsigned long long* ticket, uint64_t n_tiles,
                                                        uint64_t* out, uint64_t out_cap, unsigned long long* counters,
                                                        unsigned long long* host_counters) {
