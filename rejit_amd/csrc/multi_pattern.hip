@@ -623,6 +623,9 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       }
       if (!fused_launched) {
         m->flags_clean = false;
+        static const bool plain = getenv("RJ_SCAN_PLAIN") != nullptr;  // measurement: no events at all (only with RJ_SKIP_TAILS=3)
+        if (plain) launch_plane_scan(pp, geo.grid, nullptr, nullptr, st);
+        else
         launch_plane_scan(pp, geo.grid, s0->ev[1], s0->ev[2], st);
       }
     } else if (fuse) {
@@ -708,6 +711,8 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     hipStream_t ts = st;
     if (phase == 1 && m->tails_own_stream && m->tail_stream != nullptr && m->mode != 2) {
       ts = m->tail_stream;
+      static const bool plain = getenv("RJ_SCAN_PLAIN") != nullptr;
+      if (!plain)
       RJ_HIP(hipStreamWaitEvent(ts, s0->ev[2], 0));
     }
     if (plane && fused_launched) {
@@ -777,7 +782,9 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
         again = true;
       }
     }
-    if (fuse) {
+    static const bool plain_scan = getenv("RJ_SCAN_PLAIN") != nullptr;
+    if (plain_scan) {
+    } else if (fuse) {
       (void)hipEventElapsedTime(&m->scan_ms, s0->ev[1], s0->ev[2]);
     } else {
       (void)hipEventElapsedTime(&m->scan_ms, s0->ev[1], s0->ev[2]);  // first start to last end, gaps included
