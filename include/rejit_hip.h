@@ -133,6 +133,14 @@ void rj_free_text(char* text);
  * selected before own_begin (0,0,0 for the first shard). */
 int rj_scan_create(const rj_program* prog, rj_scan** out);
 void rj_scan_destroy(rj_scan* scan);
+/* rj_stats.scan_ms (and rj_multi_scan_ms) is the scan kernel's own duration, from a start and an end event stamped by the
+ * launch.  The end event is free; the START event costs 6-9 us per call (measured, round 4: 32-37 -> 26-28 us for texts of
+ * 32 KB .. 16 MiB; ~6.5 us between two kernels of the regexdna step).  So it is OFF unless asked for -- per object, or for
+ * every object created from now on (rj_set_default_timing returns the previous default; environment RJ_KERNEL_TIMING=1 sets
+ * the initial one) -- and scan_ms reads 0 without it.  The Python binding (rejit_amd/api.py: bench.py, the tests and the
+ * tools read scan_ms) switches the default on when it loads the library. */
+int rj_scan_set_timing(rj_scan* scan, int on);
+int rj_set_default_timing(int on);
 int64_t rj_scan_run(rj_scan* scan, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end,
                     uint64_t carry_cur, uint64_t carry_prev_end, int have_prev, void* hip_stream);
 /* The same whole-text run in two halves, so that a caller with several patterns (or texts) in
@@ -192,6 +200,8 @@ int rj_multi_order_after(rj_multi* multi, rj_multi* before);
  * stream -- in order, no cross-stream wait between them -- while each run's tails execute under the next scan.
  * rj_multi_finish is unchanged (it waits for the run's last kernel, wherever it is).  Not with mode 2. */
 int rj_multi_set_tail_stream(rj_multi* multi, int on);
+/* rj_scan_set_timing for every pattern of the object (rj_multi_scan_ms reads 0 when off). */
+int rj_multi_set_timing(rj_multi* multi, int on);
 rj_scan* rj_multi_scan(rj_multi* multi, int i);
 /* First and last match of every pattern's result after rj_multi_run / _run_range: bounds[4*i .. 4*i+3] =
  * first begin, first end, last begin, last end (all UINT64_MAX when pattern i has no match).  This is what

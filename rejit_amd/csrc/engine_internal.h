@@ -120,6 +120,8 @@ struct rj_scan {
   unsigned long long* host_counters = nullptr;  // pinned
   int* host_flag = nullptr;                     // pinned
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool timing = false;             // rj_scan_set_timing: the scan kernel's START event (rj_stats.scan_ms); its end event is always recorded
+  hipEvent_t t0() const { return timing ? ev[1] : nullptr; }
   rj_stats stats{};
   const uint64_t* result = nullptr;  // device pointer to the final pairs
   uint64_t result_count = 0;

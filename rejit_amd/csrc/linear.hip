@@ -55,7 +55,7 @@ int run_linear(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint6
   RJ_HIP(s->cs_vals.reserve((m + 1) * np * sizeof(uint64_t)));
   RJ_HIP(s->cs_mats.reserve(m * static_cast<uint64_t>(np) * W * sizeof(uint32_t)));
   RJ_HIP(s->cs_scratch.reserve(std::max<size_t>(cs_scratch_bytes(R, m), 16)));
-  RJ_HIP(hipEventRecord(s->ev[1], st));
+  if (s->timing) RJ_HIP(hipEventRecord(s->ev[1], st));
   launch_cs_summarize(R, d_text, n, a0, sub, m, s->cs_vals.as<uint64_t>(), s->cs_mats.as<uint32_t>(), s->cs_scratch.as<uint8_t>(), st);
   RJ_HIP(s->cs_groups.reserve(cs_resolve_scratch_bytes(R, m)));
   launch_cs_resolve(R, m, s->cs_vals.as<uint64_t>(), s->cs_mats.as<uint32_t>(), s->cs_groups.as<uint8_t>(), st);
@@ -148,10 +148,10 @@ int run_linear(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint6
     first_segment = false;
     lo = hi;
   }
-  RJ_HIP(hipEventRecord(s->ev[2], st));
+  if (s->timing) RJ_HIP(hipEventRecord(s->ev[2], st));
   RJ_HIP(hipStreamSynchronize(st));
   float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, s->ev[1], s->ev[2]);
+  if (s->timing) (void)hipEventElapsedTime(&ms, s->ev[1], s->ev[2]);
   s->stats.scan_ms += ms;
   s->result_count = total;
   // every candidate would have fitted the parallel verifier's walk: the next text starts there again

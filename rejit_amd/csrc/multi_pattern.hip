@@ -566,7 +566,7 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       for (int p = 0; p < P; p++) pg.zero_counters[p] = m->scans[static_cast<size_t>(p)]->counters.as<unsigned long long>();
       fused_launched = false;
       m->flags_clean = false;
-      launch_plane_scan_general(pg, geo.grid, s0->ev[1], s0->ev[2], st);
+      launch_plane_scan_general(pg, geo.grid, s0->t0(), s0->ev[2], st);
     } else if (plane) {
       PlaneParams pp{};
       pp.text = d_text;
@@ -618,18 +618,21 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
             max_short = std::max(max_short, D.short_max);
           }
           fused_launched = launch_plane_scan_classify(pp, shb, max_words, max_short, s0->counters.as<unsigned long long>(), geo.grid,
-                                                      s0->ev[1], s0->ev[2], st);
+                                                      s0->t0(), s0->ev[2], st);
         }
       }
       if (!fused_launched) {
         m->flags_clean = false;
         static const bool plain = getenv("RJ_SCAN_PLAIN") != nullptr;  // measurement: no events at all (only with RJ_SKIP_TAILS=3)
-        if (plain) launch_plane_scan(pp, geo.grid, nullptr, nullptr, st);
-        else
-        launch_plane_scan(pp, geo.grid, s0->ev[1], s0->ev[2], st);
+        static const int plain_mode = getenv("RJ_SCAN_PLAIN") ? atoi(getenv("RJ_SCAN_PLAIN")) : 0;
+        if (plain) {
+          launch_plane_scan(pp, geo.grid, nullptr, plain_mode == 3 ? s0->ev[2] : nullptr, st);
+          if (plain_mode == 2) RJ_HIP(hipEventRecord(m->fork, st));  // (an event without timing behind the kernel)
+        } else
+        launch_plane_scan(pp, geo.grid, s0->t0(), s0->ev[2], st);
       }
     } else if (fuse) {
-      launch_scan_windows_fused(fp, geo.grid, s0->ev[1], s0->ev[2], st);
+      launch_scan_windows_fused(fp, geo.grid, s0->t0(), s0->ev[2], st);
     } else {
       // every pattern's own scan kernel (each at its full streaming rate), queued back to back on
       // the caller's stream -- or, mode 2, alternating between it and a second stream: kernels of ONE
@@ -671,7 +674,7 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
           tp.hit_counts[p] = s->hit_counts.as<uint32_t>();
           tp.zero_counters[p] = s->counters.as<unsigned long long>();
         }
-        launch_scan_windows_train(tp, masked, geo.grid, s0->ev[1], s0->ev[2], st);
+        launch_scan_windows_train(tp, masked, geo.grid, s0->t0(), s0->ev[2], st);
       }
       if (two_streams) {
         RJ_HIP(hipEventRecord(m->fork, st));
@@ -697,7 +700,7 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
         // one pair of timestamps around the whole train of scan kernels (first kernel's start, last
         // kernel's end): a pair per kernel puts a completion signal between consecutive kernels
         hipStream_t sp_stream = (two_streams && (p & 1)) ? m->second : st;
-        launch_scan_windows(sp, make_window_set(s->prog), D.n_windows, geo.grid, p == 0 ? s0->ev[1] : nullptr,
+        launch_scan_windows(sp, make_window_set(s->prog), D.n_windows, geo.grid, p == 0 ? s0->t0() : nullptr,
                             (!two_streams && p == P - 1) ? s0->ev[2] : nullptr, sp_stream);
       }
       if (two_streams) {
@@ -783,11 +786,12 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       }
     }
     static const bool plain_scan = getenv("RJ_SCAN_PLAIN") != nullptr;
-    if (plain_scan) {
+    if (plain_scan || !s0->timing) {
+      m->scan_ms = 0.f;
     } else if (fuse) {
-      (void)hipEventElapsedTime(&m->scan_ms, s0->ev[1], s0->ev[2]);
+      if (s0->timing) (void)hipEventElapsedTime(&m->scan_ms, s0->ev[1], s0->ev[2]);
     } else {
-      (void)hipEventElapsedTime(&m->scan_ms, s0->ev[1], s0->ev[2]);  // first start to last end, gaps included
+      if (s0->timing) (void)hipEventElapsedTime(&m->scan_ms, s0->ev[1], s0->ev[2]);  // first start to last end, gaps included
     }
     if (again) continue;
     for (int p = 0; p < P; p++) {
@@ -1265,6 +1269,12 @@ int rj_multi_set_tail_stream(rj_multi* m, int on) {
   // ordinary stream -- a priority queue is scheduled differently altogether, and worse for this)
   if (on && !m->tail_stream) RJ_HIP(hipStreamCreateWithFlags(&m->tail_stream, hipStreamNonBlocking));
   m->tails_own_stream = on != 0;
+  return RJ_OK;
+}
+
+int rj_multi_set_timing(rj_multi* m, int on) {
+  if (!m) return fail(RJ_BAD_ARGUMENT, "null argument");
+  for (rj_scan* s : m->scans) s->timing = on != 0;
   return RJ_OK;
 }
 

@@ -225,3 +225,44 @@ def test_native_jrep_equals_gnu_grep_and_reference_jrep(rj, tmp_path):
             assert sorted(l.rsplit(b":", 1)[0] for l in out.splitlines()) == sorted(gout.splitlines()), pattern
             checked += 1
     assert checked >= 6, "neither GNU grep nor oracle/_ref/jrep_ref on this box"
+
+
+def test_kernel_timing_switch(rj, oracle):
+    """rj_scan_set_timing / rj_multi_set_timing / rj_set_default_timing: without the scan kernel's start event the answers
+    are the same and scan_ms reads 0 (the C default; the Python binding switches the default on when it loads the library)."""
+    import torch
+    from rejit_amd import workloads as W
+    lib = rj.load_library()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    n = 3 << 20
+    t = W.random_ascii_numpy(n, seed=77)
+    W.plant(t, W.plant_offsets(n, 6, 40, seed=3, boundaries=[65536]), b"regexp")
+    d = torch.from_numpy(t).to(dev)
+    for rx in (b"regexp", b"[a-f]+[0-9]", b"^"):
+        p = rj.Program(rx)
+        a, b = rj.Scan(p), rj.Scan(p)
+        b.set_timing(False)
+        ca, cb = a.run(d.data_ptr(), n, stream=st), b.run(d.data_ptr(), n, stream=st)
+        assert ca == cb and a.spans() == b.spans(), rx
+        assert a.stats()["scan_ms"] > 0 and b.stats()["scan_ms"] == 0, rx
+        if rx == b"regexp":
+            assert a.spans() == oracle.match_all(rx, t.tobytes())
+    prev = lib.rj_set_default_timing(0)
+    try:
+        assert prev == 1                      # (the binding's default)
+        c = rj.Scan(rj.Program(b"regexp"))
+        c.run(d.data_ptr(), n, stream=st)
+        assert c.stats()["scan_ms"] == 0
+    finally:
+        lib.rj_set_default_timing(prev)
+    progs = [rj.Program(x) for x in W.REGEXDNA_PATTERNS]
+    f = W.fasta_stripped_torch(200_000, dev)
+    m1, m2 = rj.MultiScan(progs), rj.MultiScan(progs)
+    m2.set_timing(False)
+    c1 = m1.run(f.data_ptr(), f.numel(), stream=st)
+    c2 = m2.run(f.data_ptr(), f.numel(), stream=st)
+    assert c1 == c2 and m1.scan_ms() > 0 and m2.scan_ms() == 0
+    m2.set_tail_stream(True)
+    m2.start(f.data_ptr(), f.numel(), stream=st)
+    assert m2.finish() == c1
