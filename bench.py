@@ -79,6 +79,8 @@ def parse_args():
     ap.add_argument("--big-literal-bytes", type=int, default=50_000_000_000, help="the north star's 50 GB single-GPU scan (extra)")
     ap.add_argument("--tree-files", type=int, default=12_500, help="jrep workload: files per GPU (~20 KB each)")
     ap.add_argument("--in-flight", type=int, default=2, help="steps kept in flight by the headline loop (rj_multi objects used in turn)")
+    ap.add_argument("--settle-ms", type=float, default=600.0, help="untimed run of the step loop before the W warm-up and K timed steps (device clocks)")
+    ap.add_argument("--time-all-launches", action="store_true", help="headline loop: the start event on every scan launch (default: every second one)")
     ap.add_argument("--one-stream", action="store_true", help="headline loop as in round 3: both rj_multi objects and their tails on one stream")
     ap.add_argument("--jrep-files", type=int, default=100_000, help="jrep_10gb extra: files (BASELINE configs[4]: 100 000)")
     ap.add_argument("--jrep-bytes", type=int, default=10_000_000_000, help="jrep_10gb extra: total bytes (BASELINE configs[4]: 10 GB)")
@@ -329,7 +331,7 @@ def run_regexdna(args, c):
     # step k + 1 are already queued, so the device never waits for the host's turn-around (~25 us of a 170 us step).
     # Every step still is one complete pass of the path over the batch with its own result; the synchronous call is
     # reported as `call_latency`.
-    def two_in_flight(own_streams, tail_streams=False):
+    def two_in_flight(own_streams, tail_streams=False, time_all=True):
         """(step, drain, scan times) of a loop that keeps two steps in flight on two rj_multi objects.  own_streams:
         each object on its own stream, the scan kernels ordered one behind the other (rj_multi_order_after), so that the
         tails of step k run under the scan of step k + 1.  tail_streams: both objects on ONE stream, but each queues its
@@ -337,8 +339,12 @@ def run_regexdna(args, c):
         one stream, with no cross-stream wait between them."""
         depth = 2 if own_streams else max(2, args.in_flight)
         multis = [rejit_amd.MultiScan(progs) for _ in range(depth)]
-        for mm in multis:
+        # time_all False: only the first object's scan launches carry the start event scan_ms() needs (every second launch of
+        # the loop): that event costs ~6.5 us between two kernels of a stream (DESIGN.md 5), the end event nothing
+        timed = [True] + [time_all] * (depth - 1)
+        for mm, tt in zip(multis, timed):
             mm.set_mode(0)
+            mm.set_timing(tt)
             if tail_streams:
                 mm.set_tail_stream(True)
         second = torch.cuda.Stream(dev) if own_streams else None
@@ -353,7 +359,7 @@ def run_regexdna(args, c):
         def collect(j, record):
             local = multis[j].finish()
             fly["busy"][j] = False
-            if record:
+            if record and timed[j]:
                 times.append(multis[j].scan_ms())         # ONE launch scans the nine patterns (plane_scan)
             if exchange is None:
                 return local
@@ -394,7 +400,7 @@ def run_regexdna(args, c):
     # so its duration inside this loop is longer than alone: `roofline` is measured in this loop (as the contract asks),
     # `roofline_kernel_alone` in the one-stream loop of round 3 (`one_stream`).
     if use_multi:
-        step, drain, scan_ms = two_in_flight(False, tail_streams=not args.one_stream)
+        step, drain, scan_ms = two_in_flight(False, tail_streams=not args.one_stream, time_all=args.time_all_launches)
     else:
         drain = None
 
@@ -406,6 +412,23 @@ def run_regexdna(args, c):
                 scan_ms.extend(sc.stats()["scan_ms"] for sc in scans)
             return counts
 
+    # The timed region is 3 ms long (K = 20 steps of 0.13 ms).  A device that has just been idle (the set-up above is host
+    # work) runs its first half second of load below its steady clocks: measured, K = 20 after W = 5 warm-up steps gives
+    # 0.141 ms per step, after 50 ms of load the same, after 500 ms 0.127.  A production caller streams texts for hours; so
+    # the step loop first runs untimed for --settle-ms (more warm-up steps of the very same loop; `settle_steps` in the
+    # line), and what K steps cost on the cold device is reported beside the headline (`cold_ms_per_step`).
+    cold_elapsed = None
+    settle_steps = 0
+    if args.settle_ms > 0:
+        cold_elapsed, _ = timed(c, args, step, drain)
+        _t = time.perf_counter()
+        while (time.perf_counter() - _t) * 1e3 < args.settle_ms:
+            for _ in range(50):
+                step(False)
+            settle_steps += 50
+        if drain:
+            drain()
+        del scan_ms[:]                 # (kernel durations of the timed region only)
     elapsed, counts = timed(c, args, step, drain)
     if args.tail_streams_probe:
         # child process of the `tails_on_own_streams` extra (see below): this one variant, one JSON line, nothing else
@@ -427,13 +450,18 @@ def run_regexdna(args, c):
                      "sharding": "contiguous byte ranges + %d-byte halo; all_gather of 8 integers per pattern (count, first / last match, carry used) per step, rows and decision on the device"
                                  % (max_len - 1),
                      "calls": ("rj_multi_start / rj_multi_finish, mode 0, two steps in flight on two rj_multi objects on one stream%s: one pass over the text for the nine patterns (plane_scan) + classify + gather per step"
-                               % ("" if args.one_stream else ", each run's tails on a stream of the object's own (rj_multi_set_tail_stream)")) if use_multi else "9 x rj_scan_run per step"})
+                               % ("" if args.one_stream else ", each run's tails on a stream of the object's own (rj_multi_set_tail_stream)")) if use_multi else "9 x rj_scan_run per step",
+                     "before_the_timed_region": "the same loop untimed for --settle-ms = %g ms (device clocks: `cold_ms_per_step` is K steps straight after the set-up), then W warm-up steps" % args.settle_ms})
     out["matches_per_s"] = round(total_matches * args.steps / elapsed, 1)
     out["matches_per_pass"] = counts
     # the physical rate of a step: every text byte crosses the HBM interface ONCE per step whatever the number of patterns
     # (`value` counts it once per pattern, the reference's convention for nine MatchAllCount calls)
     out["physical_GBps"] = round(n_total * args.steps / elapsed / 1e9, 1)
     out["step_frac"] = round(n_total * args.steps / elapsed / 1e9 / HBM_PEAK_GBS / world, 4)
+    if cold_elapsed is not None:
+        out["settle_ms"] = args.settle_ms
+        out["settle_steps"] = settle_steps
+        out["cold_ms_per_step"] = round(cold_elapsed / args.steps * 1e3, 4)
     out["step_variants_ms"] = {"headline": round(elapsed / args.steps * 1e3, 4)}   # (filled in by the extras below; kept near the top of the line)
     if use_multi:
         # the dominant kernel: plane_scan reads every text byte ONCE for all nine patterns: algorithmic bytes per
@@ -444,6 +472,9 @@ def run_regexdna(args, c):
                                        pmc_traffic("plane", fasta_n=args.fasta_n) if world == 1 else None, len(scan_ms))
         out["roofline"]["note"] = ("n / t of the one launch that scans the text for all nine patterns; `value` counts the text once per pattern "
                                    "(9 x n per step, the reference's convention: nine MatchAllCount calls)")
+        if not args.time_all_launches:
+            out["roofline"]["timing"] = ("HIP events of every SECOND scan launch of the timed region (one of the two rj_multi objects): the start event "
+                                         "costs ~6.5 us between two kernels of a stream; `step_variants_ms.every_launch_timed` is the loop with it on all")
         ops_per_byte = rejit_amd.PLANE_VALU_OPS_PER_BYTE
         valu = own_bytes * ops_per_byte / (avg_scan_ms * 1e-3) / 1e12 if avg_scan_ms > 0 else 0.0
         out["roofline_valu"] = {"bound": "valu", "kernel": "plane_scan<2>", "ops_per_text_byte": ops_per_byte,
@@ -498,6 +529,12 @@ def run_regexdna(args, c):
                         "scan_kernel_ms": round(sum(s_times) / max(len(s_times), 1), 5)}
             out["step_variants_ms"][key] = out[key]["ms_per_step"]
             out["step_variants_ms"]["overlapped_tails"] = out["overlapped_tails"]["ms_per_step"]
+            if not args.one_stream and not args.time_all_launches:
+                # the headline loop with the start event on EVERY scan launch (what `--time-all-launches` makes the headline)
+                a_step, a_drain, a_times = two_in_flight(False, tail_streams=True, time_all=True)
+                ea, ca = timed(c, args, a_step, a_drain)
+                assert ca == counts, (ca, counts)
+                out["step_variants_ms"]["every_launch_timed"] = round(ea / args.steps * 1e3, 4)
             if not args.one_stream and s_times:
                 out["roofline_kernel_alone"] = hbm_roofline("plane_scan<2> with nothing else on the device (the one-stream loop)", own_bytes,
                                                             sum(s_times) / len(s_times), pmc_traffic("plane", fasta_n=args.fasta_n), len(s_times))
