@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void dense_streams(StreamParams a) {
     unsigned long long prev_total = 0;
     if (wv == 0 && prev_tk != ~0ull) {
       unsigned long long before = 0;
-      const bool ok = (a.debug & 1u) != 0 || lookback::resolve(a.granules, n_tickets, prev_tk, &before);
+      const bool ok = lookback::resolve(a.granules, n_tickets, prev_tk, &before);
       if (lane == 0) {
 #pragma unroll
         for (int w = 0; w < kTilesPerTicket; w++) prev_total += s_count[cur ^ 1][w];
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void dense_streams(StreamParams a) {
       for (int w = 0; w < kTilesPerTicket; w++) total += s_count[cur][w];
       lookback::publish(a.granules, n_tickets, tk, total);
     }
-    if (prev_tk != ~0ull && s_bad == 0 && !(a.debug & 2u)) {
+    if (prev_tk != ~0ull && s_bad == 0) {
       const uint64_t pt = prev_tk * kTilesPerTicket + static_cast<uint64_t>(wv);
       const uint64_t pbase = (a.first_tile + pt) * kTile;
       unsigned long long before = s_before;
@@ -342,8 +342,6 @@ void launch_np(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipS
 
 void launch_dense_streams(StreamParams a, unsigned long long* scratch, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
   (void)hipMemsetAsync(scratch, 0, stream_scratch_bytes(a.n_tiles), st);
-  static const uint32_t debug = getenv("RJ_STREAM_DEBUG") ? static_cast<uint32_t>(atoi(getenv("RJ_STREAM_DEBUG"))) : 0u;
-  a.debug = debug;
   a.ticket = scratch;
   a.granules = scratch + 1;
   uint64_t blocks = (a.n_tiles + kTilesPerTicket - 1) / kTilesPerTicket;

@@ -201,7 +201,6 @@ struct StreamParams {
   unsigned long long* counters;
   unsigned long long* host_counters;
   uint32_t max_walk;     // DevProgram::max_walk: a walk this long voids the run (the carry scan takes it)
-  uint32_t debug;        // measurement (RJ_STREAM_DEBUG): 1 = no look-back, 2 = no output stores, 4 = no steps
   StreamPlan plan;
 };
 uint64_t stream_tiles(uint64_t sb, uint64_t se, uint64_t n, uint64_t* first_tile);

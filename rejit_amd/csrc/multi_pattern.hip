@@ -623,12 +623,6 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       }
       if (!fused_launched) {
         m->flags_clean = false;
-        static const bool plain = getenv("RJ_SCAN_PLAIN") != nullptr;  // measurement: no events at all (only with RJ_SKIP_TAILS=3)
-        static const int plain_mode = getenv("RJ_SCAN_PLAIN") ? atoi(getenv("RJ_SCAN_PLAIN")) : 0;
-        if (plain) {
-          launch_plane_scan(pp, geo.grid, nullptr, plain_mode == 3 ? s0->ev[2] : nullptr, st);
-          if (plain_mode == 2) RJ_HIP(hipEventRecord(m->fork, st));  // (an event without timing behind the kernel)
-        } else
         launch_plane_scan(pp, geo.grid, s0->t0(), s0->ev[2], st);
       }
     } else if (fuse) {
@@ -714,8 +708,6 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     hipStream_t ts = st;
     if (phase == 1 && m->tails_own_stream && m->tail_stream != nullptr && m->mode != 2) {
       ts = m->tail_stream;
-      static const bool plain = getenv("RJ_SCAN_PLAIN") != nullptr;
-      if (!plain)
       RJ_HIP(hipStreamWaitEvent(ts, s0->ev[2], 0));
     }
     if (plane && fused_launched) {
@@ -785,8 +777,7 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
         again = true;
       }
     }
-    static const bool plain_scan = getenv("RJ_SCAN_PLAIN") != nullptr;
-    if (plain_scan || !s0->timing) {
+    if (!s0->timing) {
       m->scan_ms = 0.f;
     } else if (fuse) {
       if (s0->timing) (void)hipEventElapsedTime(&m->scan_ms, s0->ev[1], s0->ev[2]);

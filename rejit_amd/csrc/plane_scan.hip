@@ -941,16 +941,14 @@ void launch_tails_shared(const MultiTail* d_tails, const SharedHits& sh, int max
                          hipStream_t st) {
   // half a wave per region; every workgroup copies the blob into LDS first
   uint64_t blocks = (static_cast<uint64_t>(sh.n_regions) + 7) / 8;
+  // (at most 2048 workgroups, each taking its regions grid-stride; 1024 / 512 / 256 measured: +1 / +4 / +7 % on the regexdna step)
   blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
   const dim3 g(static_cast<unsigned>(blocks)), b(256);
   const size_t lds = static_cast<size_t>(sh.blob_words) * sizeof(uint32_t);
-  static const int skip = getenv("RJ_SKIP_TAILS") ? atoi(getenv("RJ_SKIP_TAILS")) : 0;  // measurement: 1 no classify, 2 no gather, 3 neither
-  if (skip & 1) {
-  } else
   if (max_words <= 1 && max_short <= 8) hipLaunchKernelGGL((classify_shared_multi<1, 8>), g, b, lds, st, sh, counters0);
   else if (max_words <= 1) hipLaunchKernelGGL((classify_shared_multi<1, 16>), g, b, lds, st, sh, counters0);
   else hipLaunchKernelGGL((classify_shared_multi<2, 16>), g, b, lds, st, sh, counters0);
-  if (!(skip & 2)) launch_offsets_gather_check_multi(d_tails, static_cast<int>(sh.n_patterns), sh.n_regions, st);
+  launch_offsets_gather_check_multi(d_tails, static_cast<int>(sh.n_patterns), sh.n_regions, st);
 }
 
 }  // namespace rejit_amd

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU: synchronous regexdna steps (rj_multi_run, 500 MB) on a settled device: ms per call under the environment's
-overrides (RJ_SKIP_TAILS, ...); with rocprofv3 --kernel-trace around it the tail kernels' own durations."""
+overrides (RJ_CLASSIFY_FORWARD, RJ_PLANE_LDS, ...); with rocprofv3 --kernel-trace around it the tail kernels' own durations."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, rejit_amd
