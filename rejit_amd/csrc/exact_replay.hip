@@ -13,7 +13,7 @@
 //
 // The text is taken in batches of 64 MiB so that the scratch is bounded (1 GiB); a batch ends at its last
 // synchronisation point, where the next one begins.  A stretch of more than kMaxSegment bytes without a
-// proven synchronisation point is not replayed (one lane, ~0.2-1 us per byte): run_exact reports "not
+// proven synchronisation point is not replayed (one lane: 2-6 us per byte, tools/replay_probe.py): run_exact reports "not
 // done" and the caller keeps the result of the parallel pipeline (documented semantics).
 #include <hip/hip_runtime.h>
 
