@@ -66,7 +66,7 @@ typedef struct {
   float total_ms;          /* host clock: first launch to final synchronise of the run */
   int32_t retries;         /* runs repeated because a device list had to grow        */
   int32_t large_path;      /* 1 when the rocPRIM sort path was taken                 */
-  int32_t exact_path;      /* 1 when the one-lane exact kernel replaced the result   */
+  int32_t exact_path;      /* 1 when the exact replay replaced the result, 2 when it took a long segment in parts */
   int32_t linear_path;    /* 1 when a candidate outlived the parallel verifier's walk and the linear-time carry scan ran */
   int32_t stream_path;    /* 1 when the bit-stream dense kernel produced the result (one pass, pairs written once) */
   int32_t slow_starts;    /* that kernel: starts that outlived its register steps and took the scalar walk (saturating) */

@@ -869,7 +869,7 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     int rc = run_exact(s, d_text, n, sb, se, st);
     if (rc < 0) return rc;
     if (rc == 1) {
-      s->stats.exact_path = 1;
+      s->stats.exact_path = s->xr_parts != 0 ? 2 : 1;
       s->stats.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
       s->stats.n_matches = s->result_count;
       return RJ_OK;
@@ -956,7 +956,7 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     if (exact_replay_fits(rp)) rc = run_exact(s, d_text, n, 0, n + 1, st);
     else if (n <= kExactLimit && rp->graph.n_states > 0) rc = run_exact_one_lane(s, d_text, n, st) == RJ_OK ? 1 : RJ_DEVICE_ERROR;
     if (rc < 0) return rc;
-    if (rc == 1) s->stats.exact_path = 1;
+    if (rc == 1) s->stats.exact_path = s->xr_parts != 0 ? 2 : 1;
   }
   // (every run_range ends with a stream synchronise, so the host clock covers the whole pipeline
   // and no event commands are needed on the stream)

@@ -105,6 +105,8 @@ struct rj_scan {
   rejit_amd::DeviceBuffer ring;                   // exact sequential kernel / exact replay with a ring too big for LDS
   rejit_amd::DeviceBuffer xr_state, xr_sync, xr_seg_end, xr_offs, xr_counts, xr_scratch, xr_out;  // exact replay (exact_replay.hip)
   uint64_t xr_out_cap = 0;
+  rejit_amd::DeviceBuffer xr_snaps, xr_raw_n, xr_fix_ring;  // long segments taken in parts (speculate and verify)
+  uint64_t xr_parts = 0, xr_rounds = 0;                     // of the last exact replay: parts of long segments, rounds beyond the first
   bool want_exact = false;         // the run just made may differ from the reference by the ring artefact (Q8)
   rejit_amd::DeviceBuffer with_buf, long_gaps, repl_out;  // replace_gather
   // carry scan (linear.hip): summaries (resolved in place), reachability matrices, E / G slabs,

@@ -143,10 +143,100 @@ RJ_HD uint64_t rj_chunk_first_sync(const DevProgram& P, const uint8_t* t, uint64
   return kNoSync;
 }
 
+// ---- the reference's loop, in pieces (rj_replay_segment puts them together; rj_replay_raw does so for a part of a segment)
+//
+// `ring(i)` is slot i of times x states start offsets (int64_t&, -1 = free); `base` = the time row of the current position.
+
+// Position p, first half: seed p's thread, close over the control edges; when the exit state is occupied report the match
+// (*pb .. p) and clear the threads that began inside it (CheckMatch + ClearStates, src/x64/codegen-x64.cc:401-466,
+// 1075-1097).
+template <class Ring>
+RJ_HD bool rj_ring_match(const DevGraph& G, const uint8_t* t, uint64_t n, uint64_t p, Ring ring, int base, int64_t* pb) {
+  const int S = G.n_states, slots = S * G.times;
+  const int t0 = base * S;
+  ring(t0 + G.entry) = static_cast<int64_t>(p);
+  bool changed = true;
+  while (changed) {
+    changed = false;
+    for (int i = 0; i < G.n_control_edges; i++) {
+      const int64_t v = ring(t0 + G.ce_src[i]);
+      if (v < 0) continue;
+      const int kind = G.ce_kind[i];
+      bool ok = true;
+      if (kind == 1) ok = p == 0 || rj_line_break(t[p - 1]);
+      else if (kind == 2) ok = p == n || rj_line_break(t[p]);
+      if (!ok) continue;
+      const int d = t0 + G.ce_dst[i];
+      const int64_t cur = ring(d);
+      if (cur < 0 || v < cur) {
+        ring(d) = v;
+        changed = true;
+      }
+    }
+  }
+  const int64_t xs = ring(t0 + G.exit);
+  if (xs < 0) return false;
+  const int64_t pe = static_cast<int64_t>(p);
+  for (int i = 0; i < slots; i++) {
+    const int64_t v = ring(i);
+    if (v > xs && v < pe) ring(i) = -1;
+  }
+  *pb = xs;
+  return true;
+}
+
+// Position p < n, second half: the byte edges out of the current row (SetState, :951-987), then the row is freed; returns
+// the next position's row.
+template <class Ring>
+RJ_HD int rj_ring_consume(const DevGraph& G, const uint8_t* t, uint64_t n, uint64_t p, Ring ring, int base) {
+  const int S = G.n_states, T = G.times;
+  const int t0 = base * S;
+  for (int i = 0; i < G.n_byte_edges; i++) {
+    const int64_t v = ring(t0 + G.be_src[i]);
+    if (v < 0) continue;
+    const int len = G.be_len[i];
+    int land = 0;
+    if (len > 0) {
+      if (p + static_cast<uint64_t>(len) <= n) {
+        const uint8_t* lit = G.lit + G.be_off[i];
+        bool eq = true;
+        for (int k = 0; k < len && eq; k++) eq = t[p + k] == lit[k];
+        if (eq) land = len;
+      }
+    } else {
+      const uint32_t c = t[p];
+      if ((G.cls[G.be_off[i] * 8 + (c >> 5)] >> (c & 31)) & 1u) land = 1;
+    }
+    if (land) {
+      int tt = base + land;
+      if (tt >= T) tt -= T;
+      const int d = tt * S + G.be_dst[i];
+      const int64_t cur = ring(d);
+      if (cur < 0 || v < cur) ring(d) = v;
+    }
+  }
+  for (int s = 0; s < S; s++) ring(t0 + s) = -1;
+  base++;
+  if (base >= T) base -= T;
+  return base;
+}
+
+// MatchAllAppendFilter (src/codegen.cc:36-86) for one reported match: it replaces those that begin at or after its begin;
+// an empty match right at the end of the previous one is dropped.  Returns the new number of pairs in out.
+RJ_HD uint64_t rj_sink_append(uint64_t* out, uint64_t out_n, int64_t pb, int64_t pe) {
+  while (out_n > 0 && static_cast<int64_t>(out[2 * (out_n - 1)]) >= pb) out_n--;
+  if (!(pb == pe && out_n > 0 && static_cast<int64_t>(out[2 * (out_n - 1) + 1]) == pb)) {
+    out[2 * out_n] = static_cast<uint64_t>(pb);
+    out[2 * out_n + 1] = static_cast<uint64_t>(pe);
+    out_n++;
+  }
+  return out_n;
+}
+
 // The reference's loop over one segment [a, b): a is a synchronisation point (the ring starts empty),
-// b the next one (b <= n), or n + 1 for the segment that runs to the end of the text.  `ring(i)` is slot
-// i of times x states start offsets (int64_t&).  Matches go to out[2*k], out[2*k+1]; begins are strictly
-// increasing and lie in [a, b), so b - a pairs of room suffice.  Returns the number of matches.
+// b the next one (b <= n), or n + 1 for the segment that runs to the end of the text.  Matches go to out[2*k],
+// out[2*k+1]; begins are strictly increasing and lie in [a, b), so b - a pairs of room suffice.  Returns the number
+// of matches.
 //
 // No state crosses b: nothing is alive there, a match found at b - 1 is emitted before the loop stops,
 // the sink can neither pop (begins before b are smaller than any later begin) nor filter (a match that
@@ -154,96 +244,83 @@ RJ_HD uint64_t rj_chunk_first_sync(const DevProgram& P, const uint8_t* t, uint64
 template <class Ring>
 RJ_HD uint64_t rj_replay_segment(const DevGraph& G, const uint8_t* t, uint64_t n, uint64_t a, uint64_t b, Ring ring,
                                  uint64_t* out) {
-  const int S = G.n_states, T = G.times;
-  const int slots = S * T;
+  const int slots = G.n_states * G.times;
   for (int i = 0; i < slots; i++) ring(i) = -1;
   int base = 0;
   uint64_t out_n = 0;
-  bool pending = false;
-  int64_t pb = 0, pe = 0;
-  for (uint64_t p = a;; p++) {
-    if (pending) {
-      // MatchAllAppendFilter: a match replaces those that begin at or after its begin; an empty match
-      // right at the end of the previous one is dropped
-      while (out_n > 0 && static_cast<int64_t>(out[2 * (out_n - 1)]) >= pb) out_n--;
-      if (!(pb == pe && out_n > 0 && static_cast<int64_t>(out[2 * (out_n - 1) + 1]) == pb)) {
-        out[2 * out_n] = static_cast<uint64_t>(pb);
-        out[2 * out_n + 1] = static_cast<uint64_t>(pe);
-        out_n++;
-      }
-      pending = false;
-      if (static_cast<uint64_t>(pe) == n) break;
+  for (uint64_t p = a; p != b; p++) {
+    int64_t pb = 0;
+    if (rj_ring_match(G, t, n, p, ring, base, &pb)) out_n = rj_sink_append(out, out_n, pb, static_cast<int64_t>(p));
+    if (p == n) break;
+    base = rj_ring_consume(G, t, n, p, ring, base);
+  }
+  return out_n;
+}
+
+// ---- long segments: speculate and verify (round 4).
+//
+// One lane replays a segment at 2-6 us per byte, so a stretch of megabytes without a synchronisation point took minutes.
+// The ring's evolution does not depend on the sink, and it is deterministic: from EQUAL rings at the same position on --
+// equal as AGES, position minus start offset -- two runs of the loop agree for ever, and report the same matches.  So a
+// long segment is cut into parts at c_1 < c_2 < ...:
+//   round 0      every part i is replayed from c_i - W bytes with a free ring (part 0 from the segment's beginning: exact),
+//                in parallel; it notes the ring on entering the part (E_i) and on leaving it (X_i^0);
+//   the walk     goes over the parts in order with the TRUE ring T (free at the segment's beginning): a part that has been
+//                replayed from T -- T == E_i, or T == a candidate ring C_k it was given in a later round -- hands on its exit
+//                ring; otherwise the walk stops, T becomes a new candidate, and
+//   round k      every part from there on is replayed from C_k, in parallel, noting X_i^k; the walk carries on.
+// The number of rounds is the number of different rings met at the cuts that the warm-up did not produce by itself.
+// Threads are short-lived and every match clears most of the ring, so usually none; a text that keeps a PHASE (`.{0,2}.`
+// over a run without line breaks: matches tile it in threes) needs one round per phase; a thread that outlives the warm-up
+// (`[xy]+z` inside a run of x: the match begins megabytes back) gives a different ring at every cut -- the answer really
+// does depend on the far past -- and after kReplayMaxRounds the segment is given up (the caller keeps the documented
+// semantics).  Then every part is replayed once more from its verified ring, reporting its matches RAW, and the sink
+// (rj_sink_append) is applied to them in order: cheap next to the ring.
+
+constexpr int kReplayMaxRounds = 12;
+
+// the ring as AGES in time order from the current row (what two runs at the same position must agree on):
+// snap[d * S + s] = p - start offset, or -1 for a free slot
+template <class Ring>
+RJ_HD void rj_ring_snapshot(const DevGraph& G, Ring ring, int base, uint64_t p, int64_t* snap) {
+  const int S = G.n_states, T = G.times;
+  for (int d = 0; d < T; d++) {
+    int row = base + d;
+    if (row >= T) row -= T;
+    for (int s = 0; s < S; s++) {
+      const int64_t v = ring(row * S + s);
+      snap[d * S + s] = v < 0 ? -1 : static_cast<int64_t>(p) - v;
     }
-    if (p == b) break;
-    const int t0 = base * S;
-    ring(t0 + G.entry) = static_cast<int64_t>(p);
-    bool changed = true;
-    while (changed) {
-      changed = false;
-      for (int i = 0; i < G.n_control_edges; i++) {
-        const int64_t v = ring(t0 + G.ce_src[i]);
-        if (v < 0) continue;
-        const int kind = G.ce_kind[i];
-        bool ok = true;
-        if (kind == 1) ok = p == 0 || rj_line_break(t[p - 1]);
-        else if (kind == 2) ok = p == n || rj_line_break(t[p]);
-        if (!ok) continue;
-        const int d = t0 + G.ce_dst[i];
-        const int64_t cur = ring(d);
-        if (cur < 0 || v < cur) {
-          ring(d) = v;
-          changed = true;
-        }
-      }
-    }
-    const int64_t xs = ring(t0 + G.exit);
-    if (xs >= 0) {
-      pending = true;
-      pb = xs;
-      pe = static_cast<int64_t>(p);
-      for (int i = 0; i < slots; i++) {
-        const int64_t v = ring(i);
-        if (v > xs && v < pe) ring(i) = -1;
-      }
-    }
-    if (p == n) {
-      if (pending) {
-        while (out_n > 0 && static_cast<int64_t>(out[2 * (out_n - 1)]) >= pb) out_n--;
-        if (!(pb == pe && out_n > 0 && static_cast<int64_t>(out[2 * (out_n - 1) + 1]) == pb)) {
-          out[2 * out_n] = static_cast<uint64_t>(pb);
-          out[2 * out_n + 1] = static_cast<uint64_t>(pe);
-          out_n++;
-        }
-      }
+  }
+}
+
+// Positions [start, stop) of a segment (stop <= n + 1; the loop also ends behind position n): from a free ring, or from
+// `init` (a snapshot taken at `start`: ages).  Matches that END at or after emit_from go to out as found (no sink; out may
+// be null: counted only); snapshots are taken on arriving at emit_from (snap_entry, if not null) and at stop (snap_exit,
+// if not null and reached).  Returns the number of raw matches.
+template <class Ring>
+RJ_HD uint64_t rj_replay_raw(const DevGraph& G, const uint8_t* t, uint64_t n, uint64_t start, const int64_t* init, uint64_t emit_from,
+                             uint64_t stop, Ring ring, int64_t* snap_entry, int64_t* snap_exit, uint64_t* out) {
+  const int slots = G.n_states * G.times;
+  for (int i = 0; i < slots; i++) ring(i) = init && init[i] >= 0 ? static_cast<int64_t>(start) - init[i] : -1;
+  int base = 0;
+  uint64_t out_n = 0;
+  for (uint64_t p = start;; p++) {
+    if (p == emit_from && snap_entry) rj_ring_snapshot(G, ring, base, p, snap_entry);
+    if (p == stop) {
+      if (snap_exit) rj_ring_snapshot(G, ring, base, p, snap_exit);
       break;
     }
-    for (int i = 0; i < G.n_byte_edges; i++) {
-      const int64_t v = ring(t0 + G.be_src[i]);
-      if (v < 0) continue;
-      const int len = G.be_len[i];
-      int land = 0;
-      if (len > 0) {
-        if (p + static_cast<uint64_t>(len) <= n) {
-          const uint8_t* lit = G.lit + G.be_off[i];
-          bool eq = true;
-          for (int k = 0; k < len && eq; k++) eq = t[p + k] == lit[k];
-          if (eq) land = len;
-        }
-      } else {
-        const uint32_t c = t[p];
-        if ((G.cls[G.be_off[i] * 8 + (c >> 5)] >> (c & 31)) & 1u) land = 1;
+    int64_t pb = 0;
+    if (rj_ring_match(G, t, n, p, ring, base, &pb) && p >= emit_from) {
+      if (out) {
+        out[2 * out_n] = static_cast<uint64_t>(pb);
+        out[2 * out_n + 1] = p;
       }
-      if (land) {
-        int tt = base + land;
-        if (tt >= T) tt -= T;
-        const int d = tt * S + G.be_dst[i];
-        const int64_t cur = ring(d);
-        if (cur < 0 || v < cur) ring(d) = v;
-      }
+      out_n++;
     }
-    for (int s = 0; s < S; s++) ring(t0 + s) = -1;
-    base++;
-    if (base >= T) base -= T;
+    if (p == n) break;
+    base = rj_ring_consume(G, t, n, p, ring, base);
   }
   return out_n;
 }

@@ -12,13 +12,29 @@
 //   xr_compact     scratch -> result pairs
 //
 // The text is taken in batches of 64 MiB so that the scratch is bounded (1 GiB); a batch ends at its last
-// synchronisation point, where the next one begins.  A stretch of more than kMaxSegment bytes without a
-// proven synchronisation point is not replayed (one lane: 2-6 us per byte, tools/replay_probe.py): run_exact reports "not
-// done" and the caller keeps the result of the parallel pipeline (documented semantics).
+// synchronisation point, where the next one begins.
+//
+// Round 4: LONG segments.  One lane replays a segment at 2-6 us per byte (tools/replay_probe.py: `.{0,2}.` over a text
+// without line breaks, 4 MiB = 25 s), so until round 4 a stretch of more than 16 MiB without a proven synchronisation point
+// was not replayed at all.  Now a segment of more than kLongSegment bytes is taken in parts (exact_replay.h, "speculate and
+// verify"):
+//   xr_round       lane per part of kPart bytes: round 0 replays it from kWarm bytes before with a free ring and notes the
+//                  ring (as ages) on entering and on leaving the part; round k replays the parts from candidate ring k
+//   xr_walk        one wave carries the TRUE ring over the parts: a part that was replayed from it hands on its exit ring;
+//                  a ring no part was replayed from stops the walk and becomes the next round's candidate
+//   xr_emit        lane per part: once more from its verified ring, the matches RAW (no sink)
+//   xr_sink        one wave: MatchAllAppendFilter over the parts' raw matches in order (64 at a time through LDS, the top
+//                  of the stack in an LDS window), in place at the segment's beginning
+// and xr_offsets / xr_compact carry on as for the other segments.  What remains: a segment must fit a batch (which grows
+// from 64 MiB to 1 GiB when it has to), its
+// text must not keep a thread alive across the parts (more than kReplayMaxRounds different rings at the cuts: `[xy]+z`
+// inside megabytes of x), and rings of more than kWalkSlots slots keep the one-lane replay (<= 16 MiB): otherwise run_exact
+// reports "not done" and the caller keeps the result of the parallel pipeline (documented semantics).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "engine_internal.h"
 #include "exact_replay.h"
@@ -27,13 +43,17 @@ namespace rejit_amd {
 namespace {
 
 constexpr uint64_t kChunk = 1024;
-constexpr uint64_t kBatchChunks = 65536;        // 64 MiB of text per batch
-constexpr uint64_t kMaxSegment = 16ull << 20;   // longest stretch one lane is asked to replay
+constexpr uint64_t kBatchChunks = 65536;        // 64 MiB of text per batch ...
+constexpr uint64_t kBigBatchChunks = 1u << 20;  // ... and up to 1 GiB (16 GiB of scratch) when a batch holds no second synchronisation point
+constexpr uint64_t kMaxSegment = 16ull << 20;   // longest stretch ONE lane is asked to replay (rings too large for the walk)
+constexpr uint64_t kLongSegment = 64ull << 10;  // a longer segment is taken in parts
+constexpr uint64_t kPart = 2048, kWarm = 512;   // bytes per part; bytes before a part its replay starts at
+constexpr int kWalkSlots = 448;                 // times x states up to this: xr_walk holds the true ring and the candidates in LDS
 constexpr int kReplayLanes = 64;                // lanes per workgroup of xr_replay
 constexpr int kLdsRingSlots = 96;               // times x states up to this: ring in LDS (64 lanes x 96 x 8 B = 48 KiB)
 
 // state words shared by the kernels of one run
-enum { kXrY0 = 0, kXrY1, kXrLastSync, kXrMaxGap, kXrTotal, kXrStateSize };
+enum { kXrY0 = 0, kXrY1, kXrLastSync, kXrMaxGap, kXrTotal, kXrRounds, kXrWalkNext, kXrWalkStuck, kXrStateSize };
 
 template <int NQ>
 __global__ void xr_lookup(DevProgram P, const uint8_t* t, uint64_t n, uint64_t sb, uint64_t se, unsigned long long* state) {
@@ -89,13 +109,14 @@ struct GlobalRing {
 template <bool LDS>
 __global__ void __launch_bounds__(kReplayLanes)
 xr_replay(DevGraph G, const uint8_t* t, uint64_t n, uint64_t ys, const uint64_t* sync, const uint64_t* seg_end, uint64_t n_chunks,
-          int64_t* ring_mem, uint64_t* scratch, uint32_t* counts) {
+          int64_t* ring_mem, uint64_t* scratch, uint32_t* counts, uint64_t max_len) {
   extern __shared__ int64_t lds_ring[];
   const uint64_t lanes = static_cast<uint64_t>(gridDim.x) * kReplayLanes;
   const uint64_t lane = static_cast<uint64_t>(blockIdx.x) * kReplayLanes + threadIdx.x;
   for (uint64_t c = lane; c < n_chunks; c += lanes) {
     const uint64_t a = sync[c], b = seg_end[c];
     uint32_t m = 0;
+    if (a != kNoSync && b != kNoSync && b - a > max_len) continue;  // (a long segment: xr_spec / xr_repair / xr_sink set its count)
     if (a != kNoSync && b != kNoSync) {
       uint64_t* out = scratch + 2 * (a - ys);
       if (LDS) m = static_cast<uint32_t>(rj_replay_segment(G, t, n, a, b, LdsRing{lds_ring + threadIdx.x}, out));
@@ -103,6 +124,184 @@ xr_replay(DevGraph G, const uint8_t* t, uint64_t n, uint64_t ys, const uint64_t*
     }
     counts[c] = m;
   }
+}
+
+// ---- long segments (exact_replay.h: speculate and verify)
+struct CandFrom {
+  uint64_t v[kReplayMaxRounds + 1];  // the first part that has been replayed from candidate k
+};
+
+__device__ __forceinline__ uint64_t part_warm_start(uint64_t a, uint64_t i) {
+  const uint64_t c0 = a + i * kPart;
+  return i == 0 ? a : std::max(a, c0 - std::min(c0, kWarm));
+}
+
+// exits: [n_parts][slots] of this round; entry0 (round 0 only): [n_parts][slots]
+template <bool LDS>
+__global__ void __launch_bounds__(kReplayLanes)
+xr_round(DevGraph G, const uint8_t* t, uint64_t n, uint64_t a, uint64_t b, uint64_t n_parts, uint64_t from, const int64_t* cand,
+         int64_t* ring_mem, int64_t* entry0, int64_t* exits) {
+  extern __shared__ int64_t lds_ring[];
+  const uint64_t lanes = static_cast<uint64_t>(gridDim.x) * kReplayLanes;
+  const uint64_t lane = static_cast<uint64_t>(blockIdx.x) * kReplayLanes + threadIdx.x;
+  const uint64_t slots = static_cast<uint64_t>(G.n_states) * G.times;
+  for (uint64_t i = from + lane; i < n_parts; i += lanes) {
+    const uint64_t c0 = a + i * kPart, c1 = i + 1 == n_parts ? b : c0 + kPart;
+    const uint64_t start = cand ? c0 : part_warm_start(a, i);
+    int64_t* entry = cand ? nullptr : entry0 + i * slots;
+    if (LDS) rj_replay_raw(G, t, n, start, cand, c0, c1, LdsRing{lds_ring + threadIdx.x}, entry, exits + i * slots, static_cast<uint64_t*>(nullptr));
+    else rj_replay_raw(G, t, n, start, cand, c0, c1, GlobalRing{ring_mem + lane, lanes}, entry, exits + i * slots, static_cast<uint64_t*>(nullptr));
+  }
+}
+
+// One wave.  cands: [kReplayMaxRounds + 1][slots] (row 0 unused: round 0's entry rings are the parts' own); exits:
+// [kReplayMaxRounds + 1][n_parts][slots]; walk_ring: the true ring at part state[kXrWalkNext] (in: where to carry on; out:
+// the ring that stopped the walk).  state[kXrWalkStuck] = 1 when it stopped before the last part.
+__global__ void __launch_bounds__(64) xr_walk(uint64_t slots, uint64_t n_parts, int n_cand, CandFrom cand_from, const int64_t* cands,
+                                              const int64_t* entry0, const int64_t* exits, int64_t* walk_ring, int32_t* chosen,
+                                              unsigned long long* state) {
+  extern __shared__ int64_t lds[];  // the true ring, then the candidates 1 .. n_cand - 1
+  int64_t* T = lds;
+  const uint32_t lane = threadIdx.x;
+  for (uint64_t k = lane; k < slots; k += 64) T[k] = walk_ring[k];
+  for (int c = 1; c < n_cand; c++)
+    for (uint64_t k = lane; k < slots; k += 64) lds[static_cast<uint64_t>(c) * slots + k] = cands[static_cast<uint64_t>(c) * slots + k];
+  __syncthreads();
+  uint64_t i = state[kXrWalkNext];
+  for (; i < n_parts; i++) {
+    int found = -1;
+    {
+      bool same = true;
+      for (uint64_t k = lane; k < slots; k += 64) same = same && T[k] == entry0[i * slots + k];
+      if (__ballot(!same) == 0) found = 0;
+    }
+    for (int c = 1; c < n_cand && found < 0; c++) {
+      if (i < cand_from.v[c]) continue;
+      bool same = true;
+      for (uint64_t k = lane; k < slots; k += 64) same = same && T[k] == lds[static_cast<uint64_t>(c) * slots + k];
+      if (__ballot(!same) == 0) found = c;
+    }
+    if (found < 0) break;
+    if (lane == 0) chosen[i] = found;
+    __syncthreads();
+    const int64_t* x = exits + (static_cast<uint64_t>(found) * n_parts + i) * slots;
+    for (uint64_t k = lane; k < slots; k += 64) T[k] = x[k];
+    __syncthreads();
+  }
+  for (uint64_t k = lane; k < slots; k += 64) walk_ring[k] = T[k];
+  if (lane == 0) {
+    state[kXrWalkNext] = i;
+    state[kXrWalkStuck] = i < n_parts ? 1 : 0;
+  }
+}
+
+// local_sink (patterns that cannot match the empty string): the sink over the part's own matches, in place, as if nothing came
+// before the part, and the smallest begin among its raw matches -- all a later part's matches do to the list before them is
+// "pop while begin >= that" (xr_join).  With empty matches the filter of MatchAllAppendFilter looks at the entry before,
+// which may belong to another part: raw matches then, and the sequential xr_sink.
+template <bool LDS>
+__global__ void __launch_bounds__(kReplayLanes)
+xr_emit(DevGraph G, const uint8_t* t, uint64_t n, uint64_t a, uint64_t b, uint64_t ys, uint64_t n_parts, const int32_t* chosen, const int64_t* cands,
+        int64_t* ring_mem, uint64_t* scratch, uint32_t* raw_n, int local_sink, uint64_t* min_begin) {
+  extern __shared__ int64_t lds_ring[];
+  const uint64_t lanes = static_cast<uint64_t>(gridDim.x) * kReplayLanes;
+  const uint64_t lane = static_cast<uint64_t>(blockIdx.x) * kReplayLanes + threadIdx.x;
+  const uint64_t slots = static_cast<uint64_t>(G.n_states) * G.times;
+  for (uint64_t i = lane; i < n_parts; i += lanes) {
+    const uint64_t c0 = a + i * kPart, c1 = i + 1 == n_parts ? b : c0 + kPart;
+    const int k = chosen[i];
+    const int64_t* init = k == 0 ? nullptr : cands + static_cast<uint64_t>(k) * slots;
+    const uint64_t start = k == 0 ? part_warm_start(a, i) : c0;
+    uint64_t* out = scratch + 2 * (c0 - ys);
+    uint64_t m;
+    if (LDS) m = rj_replay_raw(G, t, n, start, init, c0, c1, LdsRing{lds_ring + threadIdx.x}, static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr), out);
+    else m = rj_replay_raw(G, t, n, start, init, c0, c1, GlobalRing{ring_mem + lane, lanes}, static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr), out);
+    if (local_sink) {
+      uint64_t lowest = ~0ull, kept = 0;
+      for (uint64_t j = 0; j < m; j++) {
+        const uint64_t pb = out[2 * j], pe = out[2 * j + 1];
+        lowest = pb < lowest ? pb : lowest;
+        kept = rj_sink_append(out, kept, static_cast<int64_t>(pb), static_cast<int64_t>(pe));
+      }
+      min_begin[i] = lowest;
+      m = kept;
+    }
+    raw_n[i] = static_cast<uint32_t>(m);
+  }
+}
+
+// One lane: the parts' own lists (xr_emit, local_sink) joined in order: a part pops from the list before it while begin >= the
+// smallest begin among its raw matches.  What is left of part i is handed to xr_offsets / xr_compact as if the part were a
+// segment of its own: sync[] / counts[] of the chunk its first byte lies in (parts are two chunks long; a long segment has
+// no synchronisation point of its own inside).  keep / prev: n_parts words each.
+__global__ void xr_join(uint64_t a, uint64_t ys, uint64_t n_parts, const uint32_t* raw_n, const uint64_t* min_begin, const uint64_t* scratch,
+                        uint32_t* keep, int32_t* prev, uint64_t* sync, uint32_t* counts) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int64_t top_part = -1;
+  for (uint64_t i = 0; i < n_parts; i++) {
+    const uint32_t l = raw_n[i];
+    const uint64_t mb = min_begin[i];
+    while (top_part >= 0 && mb != ~0ull) {
+      const uint64_t* list = scratch + 2 * (a + static_cast<uint64_t>(top_part) * kPart - ys);
+      uint32_t k = keep[top_part];
+      while (k > 0 && list[2 * (k - 1)] >= mb) k--;
+      keep[top_part] = k;
+      if (k != 0) break;
+      top_part = prev[top_part];
+    }
+    keep[i] = l;
+    if (l != 0) {
+      prev[i] = static_cast<int32_t>(top_part);
+      top_part = static_cast<int64_t>(i);
+    }
+  }
+  for (uint64_t i = 0; i < n_parts; i++) {
+    const uint64_t c0 = a + i * kPart;
+    const uint64_t c = (c0 - ys) / kChunk;
+    if (i != 0) sync[c] = c0;
+    counts[c] = keep[i];
+  }
+}
+
+// one wave: the sink over the parts' raw matches, in place at the segment's beginning (the sunk list never overtakes the
+// raw matches still to be read: a part holds at most one per byte).  64 raw matches at a time go through LDS; the top 256
+// entries of the stack live in an LDS window beside their copy in device memory.
+__global__ void __launch_bounds__(64) xr_sink(uint64_t a, uint64_t ys, uint64_t n_parts, const uint32_t* raw_n, uint64_t* scratch,
+                                              uint32_t* count_out) {
+  constexpr uint32_t kWin = 256;
+  __shared__ uint64_t buf[128];
+  __shared__ uint64_t win[2 * kWin];
+  const uint32_t lane = threadIdx.x;
+  uint64_t* out = scratch + 2 * (a - ys);
+  uint64_t out_n = 0, hi = 0;  // hi: entries [hi - kWin, hi) of the stack are in the window (hi = 1 + the largest index pushed)
+  auto top = [&](uint64_t idx, int which) -> uint64_t { return idx + kWin >= hi ? win[2 * (idx % kWin) + which] : out[2 * idx + which]; };
+  for (uint64_t i = 0; i < n_parts; i++) {
+    const uint64_t cnt = raw_n[i];
+    const uint64_t* src = scratch + 2 * (a + i * kPart - ys);
+    for (uint64_t j0 = 0; j0 < cnt; j0 += 64) {
+      const uint32_t m = static_cast<uint32_t>(std::min<uint64_t>(64, cnt - j0));
+      if (lane < m) {
+        buf[2 * lane] = src[2 * (j0 + lane)];
+        buf[2 * lane + 1] = src[2 * (j0 + lane) + 1];
+      }
+      __syncthreads();
+      if (lane == 0) {
+        for (uint32_t k = 0; k < m; k++) {
+          const int64_t pb = static_cast<int64_t>(buf[2 * k]), pe = static_cast<int64_t>(buf[2 * k + 1]);
+          while (out_n > 0 && static_cast<int64_t>(top(out_n - 1, 0)) >= pb) out_n--;
+          if (pb == pe && out_n > 0 && static_cast<int64_t>(top(out_n - 1, 1)) == pb) continue;
+          out[2 * out_n] = static_cast<uint64_t>(pb);
+          out[2 * out_n + 1] = static_cast<uint64_t>(pe);
+          win[2 * (out_n % kWin)] = static_cast<uint64_t>(pb);
+          win[2 * (out_n % kWin) + 1] = static_cast<uint64_t>(pe);
+          out_n++;
+          if (out_n > hi) hi = out_n;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (lane == 0) *count_out = static_cast<uint32_t>(out_n);
 }
 
 // one workgroup: offs[c] = total so far + exclusive prefix of counts; total += sum
@@ -164,19 +363,22 @@ int run_exact_nq(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
   const bool lds = slots <= kLdsRingSlots;
   // (the pairs go to a buffer of their own: when a later batch turns out not to be replayable the caller
   // keeps the result it has)
-  for (int attempt = 0; attempt < 2; attempt++) {
+  uint64_t batch_chunks = kBatchChunks;
+  for (int attempt = 0; attempt < 8; attempt++) {
     if (y0 >= y1) {  // nothing begins in this range
       s->result_count = 0;
       s->result = s->out.as<uint64_t>();
       return 1;
     }
     RJ_HIP(hipMemsetAsync(state + kXrTotal, 0, sizeof(unsigned long long), st));
+    s->xr_parts = 0;
+    s->xr_rounds = 0;
     if (s->xr_out_cap < (y1 - y0) / 8 + 1024) {  // (a first guess; the count decides below)
       s->xr_out_cap = (y1 - y0) / 8 + 1024;
       RJ_HIP(s->xr_out.reserve(s->xr_out_cap * 2 * sizeof(uint64_t)));
     }
     const uint64_t all_chunks = (y1 - y0 + kChunk - 1) / kChunk;
-    const uint64_t cap_chunks = std::min(all_chunks, kBatchChunks);
+    const uint64_t cap_chunks = std::min(all_chunks, batch_chunks);
     RJ_HIP(s->xr_sync.reserve(cap_chunks * sizeof(uint64_t)));
     RJ_HIP(s->xr_seg_end.reserve(cap_chunks * sizeof(uint64_t)));
     RJ_HIP(s->xr_offs.reserve(cap_chunks * sizeof(uint64_t)));
@@ -184,8 +386,9 @@ int run_exact_nq(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     RJ_HIP(s->xr_scratch.reserve((cap_chunks * kChunk + 1) * 2 * sizeof(uint64_t)));
     const int replay_blocks = static_cast<int>(std::min<uint64_t>((cap_chunks + kReplayLanes - 1) / kReplayLanes, 2048));
     if (!lds) RJ_HIP(s->ring.reserve(static_cast<size_t>(replay_blocks) * kReplayLanes * slots * sizeof(int64_t)));
+    bool grow_batch = false;
     for (uint64_t ys = y0; ys < y1;) {
-      const uint64_t nb = std::min((y1 - ys + kChunk - 1) / kChunk, kBatchChunks);
+      const uint64_t nb = std::min((y1 - ys + kChunk - 1) / kChunk, batch_chunks);
       const int final = ys + nb * kChunk >= y1 ? 1 : 0;
       hipLaunchKernelGGL(xr_begin_batch, dim3(1), dim3(1), 0, st, state, ys);
       const int grid = static_cast<int>((nb + 255) / 256);
@@ -197,22 +400,106 @@ int run_exact_nq(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       const uint64_t last = h[kXrLastSync];
       // the batch's last point opens a segment that the next batch replays; when it is the batch's first
       // point as well, more than a batch of text has no synchronisation point
-      if (h[kXrMaxGap] > kMaxSegment || (!final && last == ys)) return 0;
+      const bool can_walk = slots <= kWalkSlots;
+      if (!final && last == ys) {
+        // (larger batches, from the beginning: the parts make a segment of a gigabyte a matter of seconds)
+        if (!can_walk || batch_chunks >= kBigBatchChunks) return 0;
+        batch_chunks *= 4;
+        grow_batch = true;
+        break;
+      }
+      if (!can_walk && h[kXrMaxGap] > kMaxSegment) return 0;  // (one lane would take minutes)
+      const bool has_long = can_walk && h[kXrMaxGap] > kLongSegment;
+      const uint64_t max_len = has_long ? kLongSegment : ~0ull;
       const int rb = static_cast<int>(std::min<uint64_t>((nb + kReplayLanes - 1) / kReplayLanes, static_cast<uint64_t>(replay_blocks)));
       if (lds)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(xr_replay<true>), dim3(rb), dim3(kReplayLanes),
                            static_cast<size_t>(slots) * kReplayLanes * sizeof(int64_t), st, G, d_text, n, ys, s->xr_sync.as<uint64_t>(),
-                           s->xr_seg_end.as<uint64_t>(), nb, nullptr, s->xr_scratch.as<uint64_t>(), s->xr_counts.as<uint32_t>());
+                           s->xr_seg_end.as<uint64_t>(), nb, nullptr, s->xr_scratch.as<uint64_t>(), s->xr_counts.as<uint32_t>(), max_len);
       else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(xr_replay<false>), dim3(rb), dim3(kReplayLanes), 0, st, G, d_text, n, ys,
                            s->xr_sync.as<uint64_t>(), s->xr_seg_end.as<uint64_t>(), nb, s->ring.as<int64_t>(),
-                           s->xr_scratch.as<uint64_t>(), s->xr_counts.as<uint32_t>());
+                           s->xr_scratch.as<uint64_t>(), s->xr_counts.as<uint32_t>(), max_len);
+      if (has_long) {
+        // the long segments, one after the other: rounds of parts in parallel, the walk, the raw matches, the sink
+        std::vector<uint64_t> h_sync(nb), h_end(nb);
+        RJ_HIP(hipMemcpyAsync(h_sync.data(), s->xr_sync.p, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        RJ_HIP(hipMemcpyAsync(h_end.data(), s->xr_seg_end.p, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        RJ_HIP(hipStreamSynchronize(st));
+        const size_t ring_bytes = static_cast<size_t>(slots) * sizeof(int64_t);
+        const size_t lds_bytes = lds ? ring_bytes * kReplayLanes : 0;
+        int64_t* ring_mem = lds ? nullptr : s->ring.as<int64_t>();
+        for (uint64_t c = 0; c < nb; c++) {
+          const uint64_t a = h_sync[c], b = h_end[c];
+          if (a == kNoSync || b == kNoSync || b - a <= kLongSegment) continue;
+          // (the last part takes the remainder, up to 2 kPart - 1 bytes: every part then begins at least kPart bytes before b, so
+          // the chunk its first byte lies in holds no synchronisation point of its own -- xr_join hands the part's list to
+          // xr_compact through that chunk's sync[] / counts[] words)
+          const uint64_t n_parts = (b - a) / kPart;
+          // snaps: the candidates' rings and the walk's [kReplayMaxRounds + 2][slots] | round 0's entry rings [n_parts][slots] |
+          // the exit rings [kReplayMaxRounds + 1][n_parts][slots]
+          RJ_HIP(s->xr_snaps.reserve((static_cast<size_t>(kReplayMaxRounds) + 2 + (static_cast<size_t>(kReplayMaxRounds) + 2) * n_parts) * ring_bytes));
+          RJ_HIP(s->xr_raw_n.reserve(n_parts * 2 * sizeof(uint32_t)));
+          int64_t* cands = s->xr_snaps.as<int64_t>();
+          int64_t* walk_ring = cands + static_cast<size_t>(kReplayMaxRounds + 1) * slots;
+          int64_t* entry0 = walk_ring + slots;
+          int64_t* exits = entry0 + n_parts * static_cast<size_t>(slots);
+          uint32_t* raw_n = s->xr_raw_n.as<uint32_t>();
+          int32_t* chosen = reinterpret_cast<int32_t*>(raw_n + n_parts);
+          const int blocks = static_cast<int>(std::min<uint64_t>((n_parts + kReplayLanes - 1) / kReplayLanes, static_cast<uint64_t>(replay_blocks)));
+          auto round = [&](uint64_t from, const int64_t* cand, int r) {
+            if (lds)
+              hipLaunchKernelGGL(HIP_KERNEL_NAME(xr_round<true>), dim3(blocks), dim3(kReplayLanes), lds_bytes, st, G, d_text, n, a, b, n_parts, from,
+                                 cand, ring_mem, entry0, exits + static_cast<size_t>(r) * n_parts * slots);
+            else
+              hipLaunchKernelGGL(HIP_KERNEL_NAME(xr_round<false>), dim3(blocks), dim3(kReplayLanes), 0, st, G, d_text, n, a, b, n_parts, from,
+                                 cand, ring_mem, entry0, exits + static_cast<size_t>(r) * n_parts * slots);
+          };
+          round(0, nullptr, 0);
+          RJ_HIP(hipMemsetAsync(walk_ring, 0xFF, ring_bytes, st));  // (the segment begins with a free ring: every slot -1)
+          RJ_HIP(hipMemsetAsync(state + kXrWalkNext, 0, 2 * sizeof(unsigned long long), st));
+          CandFrom cand_from{};
+          int n_cand = 1;
+          for (;;) {
+            hipLaunchKernelGGL(xr_walk, dim3(1), dim3(64), ring_bytes * static_cast<size_t>(n_cand), st, static_cast<uint64_t>(slots), n_parts, n_cand,
+                               cand_from, cands, entry0, exits, walk_ring, chosen, state);
+            RJ_HIP(hipMemcpyAsync(h, state, sizeof(h), hipMemcpyDeviceToHost, st));
+            RJ_HIP(hipStreamSynchronize(st));
+            if (h[kXrWalkStuck] == 0) break;
+            if (n_cand > kReplayMaxRounds) return 0;  // (a different ring at every cut: a thread older than the parts)
+            // the ring that stopped the walk becomes candidate n_cand: every part from there on is replayed from it
+            RJ_HIP(hipMemcpyAsync(cands + static_cast<size_t>(n_cand) * slots, walk_ring, ring_bytes, hipMemcpyDeviceToDevice, st));
+            cand_from.v[n_cand] = h[kXrWalkNext];
+            round(h[kXrWalkNext], cands + static_cast<size_t>(n_cand) * slots, n_cand);
+            n_cand++;
+            s->xr_rounds++;
+          }
+          const int local_sink = P.nullable == 0 ? 1 : 0;
+          uint64_t* min_begin = reinterpret_cast<uint64_t*>(exits);  // (the exit rings are done with: at least n_parts words)
+          if (lds)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(xr_emit<true>), dim3(blocks), dim3(kReplayLanes), lds_bytes, st, G, d_text, n, a, b, ys, n_parts, chosen,
+                               cands, ring_mem, s->xr_scratch.as<uint64_t>(), raw_n, local_sink, min_begin);
+          else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(xr_emit<false>), dim3(blocks), dim3(kReplayLanes), 0, st, G, d_text, n, a, b, ys, n_parts, chosen,
+                               cands, ring_mem, s->xr_scratch.as<uint64_t>(), raw_n, local_sink, min_begin);
+          if (local_sink) {
+            uint32_t* keep = reinterpret_cast<uint32_t*>(min_begin + n_parts);
+            int32_t* prev = reinterpret_cast<int32_t*>(keep + n_parts);
+            hipLaunchKernelGGL(xr_join, dim3(1), dim3(64), 0, st, a, ys, n_parts, raw_n, min_begin, s->xr_scratch.as<uint64_t>(), keep, prev,
+                               s->xr_sync.as<uint64_t>(), s->xr_counts.as<uint32_t>());
+          } else {
+            hipLaunchKernelGGL(xr_sink, dim3(1), dim3(64), 0, st, a, ys, n_parts, raw_n, s->xr_scratch.as<uint64_t>(), s->xr_counts.as<uint32_t>() + c);
+          }
+          s->xr_parts += n_parts;
+        }
+      }
       hipLaunchKernelGGL(xr_offsets, dim3(1), dim3(1024), 0, st, s->xr_counts.as<uint32_t>(), nb, s->xr_offs.as<uint64_t>(), state);
       hipLaunchKernelGGL(xr_compact, dim3(static_cast<int>((nb * 64 + 255) / 256)), dim3(256), 0, st, s->xr_sync.as<uint64_t>(),
                          s->xr_counts.as<uint32_t>(), s->xr_offs.as<uint64_t>(), nb, ys, s->xr_scratch.as<uint64_t>(),
                          s->xr_out.as<uint64_t>(), s->xr_out_cap);
       ys = final ? y1 : last;
     }
+    if (grow_batch) continue;
     RJ_HIP(hipMemcpyAsync(h, state, sizeof(h), hipMemcpyDeviceToHost, st));
     RJ_HIP(hipStreamSynchronize(st));
     RJ_HIP(hipGetLastError());

@@ -178,6 +178,132 @@ static long exact_run(const Program& P, const DevProgram& F, const DevGraph& G, 
 }
 
 
+// One segment [a, b) the way exact_replay.hip takes a LONG one (exact_replay.h, "speculate and verify"): parts of `sub`
+// bytes; round 0 replays each from `warm` bytes before its beginning with a free ring (the first from a); the walk carries
+// the true ring over the parts, a ring no part has been replayed from becomes a candidate and a new round; then the raw
+// matches of every part from its verified ring, and the sink.  *fixed = rounds beyond the first; returns ~0 when there
+// were more than kReplayMaxRounds (the device gives the segment up).
+static uint64_t replay_segment_speculatively(const DevGraph& G, const uint8_t* t, uint64_t n, uint64_t a, uint64_t b, uint64_t sub,
+                                             uint64_t warm, uint64_t* out, uint64_t* fixed, bool local_sink) {
+  const size_t slots = static_cast<size_t>(G.n_states) * G.times;
+  const uint64_t n_parts = (b - a + sub - 1) / sub;
+  typedef std::vector<int64_t> Snap;
+  std::vector<Snap> entry0(n_parts, Snap(slots, -1));
+  std::vector<std::vector<Snap>> exits(1, std::vector<Snap>(n_parts, Snap(slots, -1)));   // [round][part]
+  std::vector<Snap> cand(1);                                                               // candidate rings (0: the warm-up's own)
+  std::vector<uint64_t> cand_from(1, 0);
+  std::vector<int64_t> ring(slots);
+  int64_t* r = ring.data();
+  auto ring_fn = [r](int i) -> int64_t& { return r[i]; };
+  auto part_start = [&](uint64_t i) { return a + i * sub; };
+  auto part_stop = [&](uint64_t i) { return std::min(b, a + (i + 1) * sub); };
+  auto warm_start = [&](uint64_t i) { const uint64_t c0 = part_start(i); return i == 0 ? a : std::max(a, c0 > warm ? c0 - warm : 0); };
+  for (uint64_t i = 0; i < n_parts; i++)  // round 0 (in parallel on the device)
+    rj_replay_raw(G, t, n, warm_start(i), static_cast<const int64_t*>(nullptr), part_start(i), part_stop(i), ring_fn, entry0[i].data(),
+                  exits[0][i].data(), static_cast<uint64_t*>(nullptr));
+  std::vector<int> chosen(n_parts, -1);
+  Snap T(slots, -1);  // the true ring at the beginning of the part the walk stands at (free at a)
+  for (uint64_t i = 0; i < n_parts;) {
+    int k = -1;
+    if (T == entry0[i]) k = 0;
+    for (size_t c = 1; c < cand.size() && k < 0; c++)
+      if (i >= cand_from[c] && T == cand[c]) k = static_cast<int>(c);
+    if (k < 0) {  // a ring nobody has replayed this part from: a new candidate, a new round from here on
+      if (static_cast<int>(cand.size()) > kReplayMaxRounds) return ~0ull;
+      cand.push_back(T);
+      cand_from.push_back(i);
+      exits.push_back(std::vector<Snap>(n_parts, Snap(slots, -1)));
+      for (uint64_t j = i; j < n_parts; j++)
+        rj_replay_raw(G, t, n, part_start(j), T.data(), part_start(j), part_stop(j), ring_fn, static_cast<int64_t*>(nullptr),
+                      exits.back()[j].data(), static_cast<uint64_t*>(nullptr));
+      (*fixed)++;
+      continue;
+    }
+    chosen[i] = k;
+    T = exits[static_cast<size_t>(k)][i];
+    i++;
+  }
+  uint64_t out_n = 0;
+  std::vector<uint64_t> raw(2 * sub + 2);
+  std::vector<std::vector<uint64_t>> lists(n_parts);  // local_sink: every part's own list, then the join (xr_emit / xr_join)
+  std::vector<uint64_t> min_begin(n_parts, ~0ull);
+  for (uint64_t i = 0; i < n_parts; i++) {  // (in parallel on the device; then the sink, in order)
+    const int k = chosen[i];
+    const uint64_t m = k == 0 ? rj_replay_raw(G, t, n, warm_start(i), static_cast<const int64_t*>(nullptr), part_start(i), part_stop(i), ring_fn,
+                                              static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr), raw.data())
+                              : rj_replay_raw(G, t, n, part_start(i), cand[static_cast<size_t>(k)].data(), part_start(i), part_stop(i), ring_fn,
+                                              static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr), raw.data());
+    if (!local_sink) {
+      for (uint64_t j = 0; j < m; j++) out_n = rj_sink_append(out, out_n, static_cast<int64_t>(raw[2 * j]), static_cast<int64_t>(raw[2 * j + 1]));
+      continue;
+    }
+    uint64_t kept = 0;
+    for (uint64_t j = 0; j < m; j++) {
+      const uint64_t pb = raw[2 * j], pe = raw[2 * j + 1];
+      min_begin[i] = std::min(min_begin[i], pb);
+      kept = rj_sink_append(raw.data(), kept, static_cast<int64_t>(pb), static_cast<int64_t>(pe));
+    }
+    lists[i].assign(raw.begin(), raw.begin() + static_cast<long>(2 * kept));
+  }
+  if (!local_sink) return out_n;
+  std::vector<uint64_t> keep(n_parts, 0);
+  std::vector<int64_t> prev(n_parts, -1);
+  int64_t top_part = -1;
+  for (uint64_t i = 0; i < n_parts; i++) {  // xr_join
+    const uint64_t l = lists[i].size() / 2, mb = min_begin[i];
+    while (top_part >= 0 && mb != ~0ull) {
+      uint64_t kk = keep[static_cast<size_t>(top_part)];
+      while (kk > 0 && lists[static_cast<size_t>(top_part)][2 * (kk - 1)] >= mb) kk--;
+      keep[static_cast<size_t>(top_part)] = kk;
+      if (kk != 0) break;
+      top_part = prev[static_cast<size_t>(top_part)];
+    }
+    keep[i] = l;
+    if (l != 0) {
+      prev[i] = top_part;
+      top_part = static_cast<int64_t>(i);
+    }
+  }
+  for (uint64_t i = 0; i < n_parts; i++)
+    for (uint64_t j = 0; j < keep[i]; j++) {
+      out[2 * out_n] = lists[i][2 * j];
+      out[2 * out_n + 1] = lists[i][2 * j + 1];
+      out_n++;
+    }
+  return out_n;
+}
+
+template <int NQ>
+static long exact_run_spec(const DevProgram& F, const DevGraph& G, const uint8_t* t, uint64_t n, uint64_t chunk, uint64_t sb, uint64_t se,
+                           uint64_t sub, uint64_t warm, uint64_t* out, uint64_t cap, uint64_t* fixed) {
+  if (se > n + 1) se = n + 1;
+  const uint64_t y0 = rj_first_sync<NQ>(F, t, n, sb);
+  const uint64_t y1 = se > n ? n + 1 : rj_first_sync<NQ>(F, t, n, se);
+  std::vector<uint64_t> syncs;
+  for (uint64_t c0 = y0; c0 < y1; c0 += chunk) {
+    const uint64_t s = rj_chunk_first_sync<NQ>(F, t, n, c0, std::min(c0 + chunk, y1), c0 == y0);
+    if (s != kNoSync) syncs.push_back(s);
+  }
+  uint64_t k = 0;
+  for (size_t i = 0; i < syncs.size(); i++) {
+    const uint64_t a = syncs[i], b = i + 1 < syncs.size() ? syncs[i + 1] : y1;
+    std::vector<uint64_t> seg(2 * (b - a) + 2);
+    uint64_t m = replay_segment_speculatively(G, t, n, a, b, sub, warm, seg.data(), fixed, F.nullable == 0);
+    if (m == ~0ull) {  // (given up: the device keeps the documented semantics; here the one sequential replay)
+      std::vector<int64_t> ring(static_cast<size_t>(G.n_states) * G.times);
+      int64_t* r = ring.data();
+      m = rj_replay_segment(G, t, n, a, b, [r](int i2) -> int64_t& { return r[i2]; }, seg.data());
+      *fixed += 1000000;
+    }
+    for (uint64_t j = 0; j < m; j++, k++)
+      if (k < cap) {
+        out[2 * k] = seg[2 * j];
+        out[2 * k + 1] = seg[2 * j + 1];
+      }
+  }
+  return static_cast<long>(k);
+}
+
 // dense_swar.h against the scalar automaton: every 16-byte block of the text (with the 4 bytes after it),
 // every start of the block.  Returns the number of disagreements (0 expected), -101 when the pattern does
 // not qualify for the packed pre-steps; stats: [0] starts checked, [1] sent to the walkers, [2] decided with
@@ -414,6 +540,26 @@ long ce_exact_range(const char* re, const uint8_t* text, uint64_t n, uint64_t ch
   if (P.n_words <= 2) return exact_run<1>(P, F, G, text, n, chunk, sb, se, out, cap, n_segments, longest);
   if (P.n_words <= 4) return exact_run<2>(P, F, G, text, n, chunk, sb, se, out, cap, n_segments, longest);
   if (P.n_words <= 8) return exact_run<4>(P, F, G, text, n, chunk, sb, se, out, cap, n_segments, longest);
+  return -9;
+}
+
+// ce_exact_range with every segment taken in parts of `sub` bytes, speculatively (see replay_segment_speculatively)
+long ce_exact_range_spec(const char* re, const uint8_t* text, uint64_t n, uint64_t chunk, uint64_t sb, uint64_t se, uint64_t sub, uint64_t warm,
+                         uint64_t* out, uint64_t cap, uint64_t* fixed) {
+  LowerResult lr = lower(re);
+  if (lr.status != 0) return lr.status;
+  const Program& P = *lr.program;
+  const TableBlob fb = make_table_blob(P, P.n_pos, P.n_words, P.has_assertions);
+  DevProgram F{};
+  point_tables(&F, fb.words.data(), fb, P.n_pos);
+  F.nullable = nullable_bits(P);
+  const GraphBlob gb = make_graph_blob(P.graph);
+  DevGraph G{};
+  point_graph(&G, gb.bytes.data(), gb);
+  *fixed = 0;
+  if (P.n_words <= 2) return exact_run_spec<1>(F, G, text, n, chunk, sb, se, sub, warm, out, cap, fixed);
+  if (P.n_words <= 4) return exact_run_spec<2>(F, G, text, n, chunk, sb, se, sub, warm, out, cap, fixed);
+  if (P.n_words <= 8) return exact_run_spec<4>(F, G, text, n, chunk, sb, se, sub, warm, out, cap, fixed);
   return -9;
 }
 

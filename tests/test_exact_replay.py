@@ -160,3 +160,57 @@ def test_refined_risk_flag_is_sound(ce):
                 artefact += 1
                 assert risk, (rx, tx)
     assert checked > 2500 and 0 < flagged < checked * 0.6 and artefact > 20
+
+
+def test_long_segments_speculate_and_verify(ce):
+    """exact_replay.h, long segments: parts of a segment replayed from a few bytes earlier with a free ring, the true ring
+    walked over them, a ring no part was replayed from made a candidate and a further round, the sink applied afterwards --
+    the same answer as the one sequential replay (= the reference's, golden vectors), for parts of 1 .. 64 bytes and
+    warm-ups of 0 .. 64 bytes; with no warm-up at all further rounds are the rule (and tiny parts may be given up: the
+    driver then replays sequentially), with one they are the exception."""
+    ce.ce_exact_range_spec.restype = ctypes.c_long
+    ce.ce_exact_range_spec.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                       ctypes.c_uint64, ctypes.c_uint64, _u64p, ctypes.c_uint64, _u64p]
+
+    def spec(rx, tx, sub, warm, sb=0, se=None):
+        se = len(tx) + 1 if se is None else se
+        cap = len(tx) + 2
+        buf = (ctypes.c_uint64 * (2 * cap))()
+        fixed = ctypes.c_uint64()
+        n = ce.ce_exact_range_spec(rx, tx, len(tx), 4096, sb, se, sub, warm, buf, cap, ctypes.byref(fixed))
+        if n < 0:
+            return int(n), 0
+        return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n)], fixed.value
+
+    cases = rounds_cold = rounds_warm = given_up_warm = 0
+    for rx, tx, exp_all, _ in V.all_matchall_cases():
+        if len(rx) > 256:
+            continue
+        for sub, warm in ((1, 0), (2, 1), (3, 0), (5, 4), (7, 64), (64, 8)):
+            got, fixed = spec(rx, tx, sub, warm)       # fixed = rounds beyond the first + 10^6 per segment given up
+            if got == -9:
+                break
+            assert got == exp_all, (rx, tx, sub, warm, got, exp_all)
+            if warm == 0:
+                rounds_cold += fixed % 1000000
+            elif warm >= 8:
+                rounds_warm += fixed % 1000000
+                given_up_warm += fixed // 1000000
+        cases += 1
+    assert cases > 2500 and rounds_cold > 1000, (cases, rounds_cold)
+    # (with a warm-up the parts nearly always agree: further rounds are the exception, and no segment is given up)
+    assert rounds_warm * 20 < rounds_cold and given_up_warm == 0, (rounds_warm, rounds_cold, given_up_warm)
+    # longer texts, at-risk patterns, own ranges
+    rng = random.Random(17)
+    oracle = Oracle()
+    for rx in (b".{0,2}.", b"(a|ab)(c|bcd)(d*)", b"[ab]{1,3}b", b"a.{0,3}$", b"(x|xy|xyz)+z?"):
+        for _ in range(6):
+            tx = bytes(rng.choice(b"abcdxyz\n") for _ in range(rng.choice([50, 700, 3000])))
+            want = oracle.match_all(rx, tx)
+            for sub, warm in ((16, 0), (64, 16), (257, 32)):
+                got, _ = spec(rx, tx, sub, warm)
+                assert got == want, (rx, tx[:40], sub, warm)
+            lo = len(tx) // 3
+            got, _ = spec(rx, tx, 32, 8, lo, len(tx) + 1)
+            whole, _ = exact(ce, rx, tx, 4096, lo, len(tx) + 1)
+            assert got == whole, (rx, lo)

@@ -95,12 +95,12 @@ def test_several_batches_72mib(rj, oracle):
     import torch
     n = 72 << 20
     t = text_of(n, b"abcdefghijklmnopqrstuvwxyz0123456789  \n", 77)
-    t[(10 << 20):(10 << 20) + (1 << 19)] = ord("q")      # a 512 KiB stretch without a line break (one lane replays it: ~2 us per byte)
+    t[(10 << 20):(10 << 20) + (1 << 19)] = ord("q")      # a 512 KiB stretch without a line break (taken in parts since round 4)
     want = oracle_spans_np(oracle, b".{0,2}.", t)
     d = torch.from_numpy(t).cuda()
     scan = rj.Scan(rj.Program(b".{0,2}."))
     cnt = scan.run_tensor(d)
-    assert scan.stats()["exact_path"] == 1
+    assert scan.stats()["exact_path"] == 2   # (1: every segment by one lane; 2: a long one in parts)
     assert cnt == len(want) and np.array_equal(gpu_spans_np(rj, scan), want)
     got = run_ranges(rj, scan, d, n, [0, (64 << 20) + 3, n + 1])
     assert np.array_equal(got, want)
@@ -139,3 +139,40 @@ def test_match_first_of_an_at_risk_pattern_beyond_the_first_block(rj, oracle):
         assert prog.match_anywhere(text)
     assert prog.match_first(b"x" * 400000) is None
     assert not prog.match_anywhere(b"x" * 400000)
+
+
+def test_long_stretches_in_parts(rj, oracle):
+    """A stretch of megabytes without a synchronisation point (until round 4: one lane at 6 us per byte, and nothing beyond 16
+    MiB): replayed in parts -- speculate and verify, exact_replay.h -- with exact_path = 2.  `.{0,2}.` over text without line
+    breaks keeps a PHASE (the matches tile it in threes), so the walk needs a round per phase; the answer is the reference's
+    (Oracle.match_all), which on these texts differs from the documented semantics.  20 MiB whole and as ranges of a
+    sharded run, 66 MiB (the batch has to grow beyond 64 MiB), several long segments between a few line breaks, a pattern
+    that can match the empty string (the sequential sink instead of the parts' own lists), a wider ring."""
+    import torch
+    risky_nullable = 0
+    for rx, n, alphabet, breaks in ((b".{0,2}.", 20 << 20, b"abcde", ()), (b".{0,2}.", 66 << 20, b"ab", ()),
+                                    (b".{0,2}.", 9 << 20, b"abcdefgh", (1 << 20, (1 << 20) + 1, 5 << 20, (8 << 20) + 77)),
+                                    (b".{0,2}", 6 << 20, b"abc", (4 << 20,)), (b"(a|ab)(c|bcd)?(d*)", 6 << 20, b"abcd", ()),
+                                    (b"[ab]{1,3}b|.{1,4}c", 5 << 20, b"abcx", (3 << 20,))):
+        p = rj.Program(rx)
+        if not p.info()["ring_artefact_risk"]:
+            continue
+        t = text_of(n, alphabet, 1234 + n)
+        for b in breaks:
+            t[b] = 10
+        want = oracle_spans_np(oracle, rx, t)
+        d = torch.from_numpy(t).cuda()
+        scan = rj.Scan(p)
+        cnt = scan.run_tensor(d)
+        st = scan.stats()
+        assert cnt == len(want) and np.array_equal(gpu_spans_np(rj, scan), want), (rx, n, st)
+        assert st["exact_path"] == 2, (rx, n, st)
+        risky_nullable += 1 if p.info()["min_len"] == 0 else 0
+        if rx == b".{0,2}." and not breaks and n == 20 << 20:
+            spec = oracle.match_all_spec(rx, t[: 1 << 20].tobytes())
+            ref = oracle.match_all(rx, t[: 1 << 20].tobytes())
+            assert spec != ref, "the reference's answer should differ from the documented semantics on this text"
+            cuts = [0, 5 << 20, (5 << 20) + 1, 17 << 20, n + 1]
+            assert np.array_equal(run_ranges(rj, scan, d, n, cuts), want), rx
+    # (the sequential sink is for patterns that match the empty string: at least one of them must be at risk and have run)
+    assert risky_nullable >= 1 or not rj.Program(b".{0,2}").info()["ring_artefact_risk"]
