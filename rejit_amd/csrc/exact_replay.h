@@ -130,13 +130,14 @@ RJ_HD uint64_t rj_first_sync(const DevProgram& P, const uint8_t* t, uint64_t n, 
 // First proven synchronisation point in [c0, c1) (c1 <= n + 1), or kNoSync.  `exact_start`: c0 is known to
 // be a synchronisation point itself; otherwise the walk starts with every position alive, which can only
 // hide synchronisation points near the beginning of the chunk.
+// (from: only a point at or after it counts -- the ends of an ownership range, exact_replay.hip: xr_lookup)
 template <int NQ>
 RJ_HD uint64_t rj_chunk_first_sync(const DevProgram& P, const uint8_t* t, uint64_t n, uint64_t c0, uint64_t c1,
-                                   bool exact_start) {
+                                   bool exact_start, uint64_t from = 0) {
   RjAlive<NQ> A;
   rj_alive_init<NQ>(P, &A, !exact_start);
   for (uint64_t p = c0; p < c1; p++) {
-    if (rj_alive_empty<NQ>(A)) return p;
+    if (p >= from && rj_alive_empty<NQ>(A)) return p;
     if (p >= n) break;
     rj_alive_step<NQ>(P, t, n, p, &A);
   }

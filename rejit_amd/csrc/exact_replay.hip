@@ -2,7 +2,7 @@
 // size (exact_replay.h has the argument): synchronisation points from the all-starts position automaton,
 // then the reference's own loop per segment, one lane per segment.
 //
-//   xr_lookup      the two ends of the ownership range: first proven synchronisation point >= sb, >= se
+//   xr_lookup      the two ends of the ownership range: a proven synchronisation point >= sb, >= se (lane per chunk)
 //   xr_chunk_sync  per 1-KiB chunk the first proven synchronisation point (lane per chunk, early exit)
 //   xr_segments    per chunk that has one: where its segment ends; the last point and the longest segment
 //   xr_replay      lane per segment: rj_replay_segment, ring in LDS (lane-interleaved) when it fits, pairs
@@ -55,12 +55,20 @@ constexpr int kLdsRingSlots = 96;               // times x states up to this: ri
 // state words shared by the kernels of one run
 enum { kXrY0 = 0, kXrY1, kXrLastSync, kXrMaxGap, kXrTotal, kXrRounds, kXrWalkNext, kXrWalkStuck, kXrStateSize };
 
+// An end of the ownership range: the first PROVEN synchronisation point at or after x among the chunks [first_chunk,
+// first_chunk + n_chunks) of the text's own 1-KiB grid -- a lane per chunk walks it from its beginning with every position
+// alive (chunk 0: from nothing alive, exactly) and reports the first position >= x at which nothing is.  Any proven point
+// will do as a cut as long as the two ranges that share it compute it the same way: this is a function of the text and x
+// alone.  (Until round 4 ONE lane walked from x -- back and forth until its superset had died out -- to the next point: on a
+// text without synchronisation points that was the whole text at half a microsecond per byte, twice per call.)
 template <int NQ>
-__global__ void xr_lookup(DevProgram P, const uint8_t* t, uint64_t n, uint64_t sb, uint64_t se, unsigned long long* state) {
-  const int i = threadIdx.x;
-  if (blockIdx.x != 0 || i > 1) return;
-  const uint64_t x = i == 0 ? sb : se;
-  state[i == 0 ? kXrY0 : kXrY1] = x > n ? n + 1 : rj_first_sync<NQ>(P, t, n, x);
+__global__ void xr_lookup(DevProgram P, const uint8_t* t, uint64_t n, uint64_t x, uint64_t first_chunk, uint64_t n_chunks, unsigned long long* y) {
+  const uint64_t k = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (k >= n_chunks) return;
+  const uint64_t c0 = (first_chunk + k) * kChunk;
+  if (c0 > n) return;
+  const uint64_t p = rj_chunk_first_sync<NQ>(P, t, n, c0, std::min(c0 + kChunk, n + 1), c0 == 0, x);
+  if (p != kNoSync) atomicMin(y, static_cast<unsigned long long>(p));
 }
 
 template <int NQ>
@@ -353,11 +361,28 @@ int run_exact_nq(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
   unsigned long long h[kXrStateSize];
   uint64_t y0 = 0, y1 = n + 1;
   if (!(sb == 0 && se == n + 1)) {
-    hipLaunchKernelGGL(xr_lookup<NQ>, dim3(1), dim3(64), 0, st, P, d_text, n, sb, se, state);
-    RJ_HIP(hipMemcpyAsync(h, state, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    RJ_HIP(hipStreamSynchronize(st));
-    y0 = h[kXrY0];
-    y1 = h[kXrY1];
+    // the two ends, each in windows of 4096 chunks until a point shows up (on ordinary text: in the first)
+    auto first_point = [&](uint64_t x, uint64_t* out) -> int {
+      if (x == 0 || x > n) {
+        *out = x == 0 ? 0 : n + 1;
+        return RJ_OK;
+      }
+      constexpr uint64_t kWindow = 4096;
+      for (uint64_t c = x / kChunk; c * kChunk <= n; c += kWindow) {
+        h[0] = n + 1;
+        RJ_HIP(hipMemcpyAsync(state + kXrY0, h, sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(xr_lookup<NQ>, dim3(static_cast<unsigned>(kWindow / 256)), dim3(256), 0, st, P, d_text, n, x, c, kWindow, state + kXrY0);
+        RJ_HIP(hipMemcpyAsync(h, state + kXrY0, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        RJ_HIP(hipStreamSynchronize(st));
+        if (h[0] != n + 1) break;
+      }
+      *out = h[0];
+      return RJ_OK;
+    };
+    int rc = first_point(sb, &y0);
+    if (rc != RJ_OK) return rc;
+    rc = first_point(se, &y1);
+    if (rc != RJ_OK) return rc;
   }
   const int slots = G.n_states * G.times;
   const bool lds = slots <= kLdsRingSlots;
@@ -518,7 +543,8 @@ int run_exact_nq(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
 
 }  // namespace
 
-bool exact_replay_fits(const rj_program* rp) { return rp->host->q8_risk && rp->dev.n_words <= 8 && rp->graph.n_states > 0; }
+// (the position set of the synchronisation-point walk lives in registers: up to 1024 positions, 16 x 64 bits)
+bool exact_replay_fits(const rj_program* rp) { return rp->host->q8_risk && rp->dev.n_words <= 32 && rp->graph.n_states > 0; }
 
 int run_exact(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, hipStream_t st) {
   const rj_program* rp = s->prog;
@@ -526,7 +552,9 @@ int run_exact(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64
   if (se > n + 1) se = n + 1;
   if (rp->dev.n_words <= 2) return run_exact_nq<1>(s, d_text, n, sb, se, st);
   if (rp->dev.n_words <= 4) return run_exact_nq<2>(s, d_text, n, sb, se, st);
-  return run_exact_nq<4>(s, d_text, n, sb, se, st);
+  if (rp->dev.n_words <= 8) return run_exact_nq<4>(s, d_text, n, sb, se, st);
+  if (rp->dev.n_words <= 16) return run_exact_nq<8>(s, d_text, n, sb, se, st);
+  return run_exact_nq<16>(s, d_text, n, sb, se, st);
 }
 
 }  // namespace rejit_amd

@@ -540,6 +540,8 @@ long ce_exact_range(const char* re, const uint8_t* text, uint64_t n, uint64_t ch
   if (P.n_words <= 2) return exact_run<1>(P, F, G, text, n, chunk, sb, se, out, cap, n_segments, longest);
   if (P.n_words <= 4) return exact_run<2>(P, F, G, text, n, chunk, sb, se, out, cap, n_segments, longest);
   if (P.n_words <= 8) return exact_run<4>(P, F, G, text, n, chunk, sb, se, out, cap, n_segments, longest);
+  if (P.n_words <= 16) return exact_run<8>(P, F, G, text, n, chunk, sb, se, out, cap, n_segments, longest);
+  if (P.n_words <= 32) return exact_run<16>(P, F, G, text, n, chunk, sb, se, out, cap, n_segments, longest);
   return -9;
 }
 
@@ -560,6 +562,8 @@ long ce_exact_range_spec(const char* re, const uint8_t* text, uint64_t n, uint64
   if (P.n_words <= 2) return exact_run_spec<1>(F, G, text, n, chunk, sb, se, sub, warm, out, cap, fixed);
   if (P.n_words <= 4) return exact_run_spec<2>(F, G, text, n, chunk, sb, se, sub, warm, out, cap, fixed);
   if (P.n_words <= 8) return exact_run_spec<4>(F, G, text, n, chunk, sb, se, sub, warm, out, cap, fixed);
+  if (P.n_words <= 16) return exact_run_spec<8>(F, G, text, n, chunk, sb, se, sub, warm, out, cap, fixed);
+  if (P.n_words <= 32) return exact_run_spec<16>(F, G, text, n, chunk, sb, se, sub, warm, out, cap, fixed);
   return -9;
 }
 
