@@ -899,6 +899,30 @@ def literal_and_complex_extras(args, c, out):
     del t
     torch.cuda.empty_cache()
 
+    # The reference's ring artefact on a stretch WITHOUT a synchronisation point: `.{0,2}.` over 63 MiB
+    # without a line break -- every byte keeps a thread alive, so the whole text is ONE segment of the exact replay.  Until
+    # round 4 one lane replayed a segment (6 us per byte: minutes) and nothing beyond 16 MiB; now it is taken in parts.
+    try:
+        nx = 63 << 20
+        tx = W.random_ascii_torch(nx, 7, dev, ord("a"), ord("e"))
+        sx = rejit_amd.Scan(rejit_amd.Program(".{0,2}."))
+        sx.run(tx.data_ptr(), nx, stream=c.stream)
+        xs = []
+        for _ in range(3):
+            t0x = time.perf_counter()
+            kx = sx.run(tx.data_ptr(), nx, stream=c.stream)
+            xs.append(time.perf_counter() - t0x)
+        spans_x = sx.spans_tensor(dev)
+        # (without line breaks the reference's matches of this pattern tile the text: each begins where the one before ended)
+        tiles = bool((spans_x[1:, 0] == spans_x[:-1, 1]).all().item()) and int(spans_x[0, 0]) == 0 and int(spans_x[-1, 1]) == nx
+        out["exact_replay_long"] = {"workload": "`.{0,2}.` (at risk of the reference's ring artefact) MatchAll over %d bytes without a line break: one segment of the exact replay, in parts" % nx,
+                                    "seconds": round(sorted(xs)[1], 4), "matches": int(kx), "exact_path": sx.stats()["exact_path"],
+                                    "matches_tile_the_text": tiles}
+        del tx, sx, spans_x
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001  (an extra must not take the line down)
+        out["exact_replay_long"] = {"error": repr(e)[:300]}
+
     if not args.no_big:
         # the north star's target run: the fast-forward scan over a 50 GB synthetic text on ONE GPU
         nb = args.big_literal_bytes
