@@ -22,9 +22,9 @@
 //                  ring (as ages) on entering and on leaving the part; round k replays the parts from candidate ring k
 //   xr_walk        one wave carries the TRUE ring over the parts: a part that was replayed from it hands on its exit ring;
 //                  a ring no part was replayed from stops the walk and becomes the next round's candidate
-//   xr_emit        lane per part: once more from its verified ring, the matches RAW (no sink)
-//   xr_sink        one wave: MatchAllAppendFilter over the parts' raw matches in order (64 at a time through LDS, the top
-//                  of the stack in an LDS window), in place at the segment's beginning
+//   xr_emit        lane per part: once more from its verified ring, its matches through the sink as if nothing came before
+//   xr_join        one lane over the PARTS: a part pops from the lists before it while begin >= its smallest raw begin, and
+//                  drops its first entry when the sink's filter says so; the parts' lists then go to xr_compact as they are
 // and xr_offsets / xr_compact carry on as for the other segments.  What remains: a segment must fit a batch (which grows
 // from 64 MiB to 1 GiB when it has to), its
 // text must not keep a thread alive across the parts (more than kReplayMaxRounds different rings at the cuts: `[xy]+z`
@@ -124,7 +124,7 @@ xr_replay(DevGraph G, const uint8_t* t, uint64_t n, uint64_t ys, const uint64_t*
   for (uint64_t c = lane; c < n_chunks; c += lanes) {
     const uint64_t a = sync[c], b = seg_end[c];
     uint32_t m = 0;
-    if (a != kNoSync && b != kNoSync && b - a > max_len) continue;  // (a long segment: xr_spec / xr_repair / xr_sink set its count)
+    if (a != kNoSync && b != kNoSync && b - a > max_len) continue;  // (a long segment: xr_join sets the counts of its parts)
     if (a != kNoSync && b != kNoSync) {
       uint64_t* out = scratch + 2 * (a - ys);
       if (LDS) m = static_cast<uint32_t>(rj_replay_segment(G, t, n, a, b, LdsRing{lds_ring + threadIdx.x}, out));
@@ -203,14 +203,13 @@ __global__ void __launch_bounds__(64) xr_walk(uint64_t slots, uint64_t n_parts, 
   }
 }
 
-// local_sink (patterns that cannot match the empty string): the sink over the part's own matches, in place, as if nothing came
-// before the part, and the smallest begin among its raw matches -- all a later part's matches do to the list before them is
-// "pop while begin >= that" (xr_join).  With empty matches the filter of MatchAllAppendFilter looks at the entry before,
-// which may belong to another part: raw matches then, and the sequential xr_sink.
+// Then the sink over the part's own matches, in place, as if nothing came before the part, and the smallest begin among its
+// raw matches: all a later part's matches do to the list before them is "pop while begin >= that", and the one decision of
+// the sink's filter the part cannot take on its own is its list's first entry (xr_join).
 template <bool LDS>
 __global__ void __launch_bounds__(kReplayLanes)
 xr_emit(DevGraph G, const uint8_t* t, uint64_t n, uint64_t a, uint64_t b, uint64_t ys, uint64_t n_parts, const int32_t* chosen, const int64_t* cands,
-        int64_t* ring_mem, uint64_t* scratch, uint32_t* raw_n, int local_sink, uint64_t* min_begin) {
+        int64_t* ring_mem, uint64_t* scratch, uint32_t* raw_n, uint64_t* min_begin) {
   extern __shared__ int64_t lds_ring[];
   const uint64_t lanes = static_cast<uint64_t>(gridDim.x) * kReplayLanes;
   const uint64_t lane = static_cast<uint64_t>(blockIdx.x) * kReplayLanes + threadIdx.x;
@@ -224,26 +223,26 @@ xr_emit(DevGraph G, const uint8_t* t, uint64_t n, uint64_t a, uint64_t b, uint64
     uint64_t m;
     if (LDS) m = rj_replay_raw(G, t, n, start, init, c0, c1, LdsRing{lds_ring + threadIdx.x}, static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr), out);
     else m = rj_replay_raw(G, t, n, start, init, c0, c1, GlobalRing{ring_mem + lane, lanes}, static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr), out);
-    if (local_sink) {
-      uint64_t lowest = ~0ull, kept = 0;
-      for (uint64_t j = 0; j < m; j++) {
-        const uint64_t pb = out[2 * j], pe = out[2 * j + 1];
-        lowest = pb < lowest ? pb : lowest;
-        kept = rj_sink_append(out, kept, static_cast<int64_t>(pb), static_cast<int64_t>(pe));
-      }
-      min_begin[i] = lowest;
-      m = kept;
+    uint64_t lowest = ~0ull, kept = 0;
+    for (uint64_t j = 0; j < m; j++) {
+      const uint64_t pb = out[2 * j], pe = out[2 * j + 1];
+      lowest = pb < lowest ? pb : lowest;
+      kept = rj_sink_append(out, kept, static_cast<int64_t>(pb), static_cast<int64_t>(pe));
     }
-    raw_n[i] = static_cast<uint32_t>(m);
+    min_begin[i] = lowest;
+    raw_n[i] = static_cast<uint32_t>(kept);
   }
 }
 
-// One lane: the parts' own lists (xr_emit, local_sink) joined in order: a part pops from the list before it while begin >= the
-// smallest begin among its raw matches.  What is left of part i is handed to xr_offsets / xr_compact as if the part were a
-// segment of its own: sync[] / counts[] of the chunk its first byte lies in (parts are two chunks long; a long segment has
-// no synchronisation point of its own inside).  keep / prev: n_parts words each.
+// One lane: the parts' own lists (xr_emit) joined in order: a part pops from the list before it while begin >= the smallest
+// begin among its raw matches; and the filter of the sink for the one entry whose decision the part could not take on its
+// own -- its list's first, when that is an empty match right at the end of the entry before it (which belongs to an earlier
+// part): dropped (first[i] = 1).  Every later decision of the part came out the same with that entry standing in for the
+// one before it: both end where it begins.  What is left of part i is handed to xr_offsets / xr_compact as if the part were
+// a segment of its own: sync[] / counts[] of the chunk its first byte lies in (parts are two chunks long; a long segment has
+// no synchronisation point of its own inside).  keep / first / prev: n_parts words each.
 __global__ void xr_join(uint64_t a, uint64_t ys, uint64_t n_parts, const uint32_t* raw_n, const uint64_t* min_begin, const uint64_t* scratch,
-                        uint32_t* keep, int32_t* prev, uint64_t* sync, uint32_t* counts) {
+                        uint32_t* keep, uint32_t* first, int32_t* prev, uint64_t* sync, uint32_t* counts) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   int64_t top_part = -1;
   for (uint64_t i = 0; i < n_parts; i++) {
@@ -252,13 +251,21 @@ __global__ void xr_join(uint64_t a, uint64_t ys, uint64_t n_parts, const uint32_
     while (top_part >= 0 && mb != ~0ull) {
       const uint64_t* list = scratch + 2 * (a + static_cast<uint64_t>(top_part) * kPart - ys);
       uint32_t k = keep[top_part];
-      while (k > 0 && list[2 * (k - 1)] >= mb) k--;
+      const uint32_t f = first[top_part];
+      while (k > f && list[2 * (k - 1)] >= mb) k--;
       keep[top_part] = k;
-      if (k != 0) break;
+      if (k != f) break;
       top_part = prev[top_part];
     }
     keep[i] = l;
-    if (l != 0) {
+    uint32_t f = 0;
+    if (l != 0 && top_part >= 0) {
+      const uint64_t* mine = scratch + 2 * (a + i * kPart - ys);
+      const uint64_t* list = scratch + 2 * (a + static_cast<uint64_t>(top_part) * kPart - ys);
+      if (mine[0] == mine[1] && mine[0] == mb && list[2 * (keep[top_part] - 1) + 1] == mine[0]) f = 1;
+    }
+    first[i] = f;
+    if (l != f) {
       prev[i] = static_cast<int32_t>(top_part);
       top_part = static_cast<int64_t>(i);
     }
@@ -266,50 +273,10 @@ __global__ void xr_join(uint64_t a, uint64_t ys, uint64_t n_parts, const uint32_
   for (uint64_t i = 0; i < n_parts; i++) {
     const uint64_t c0 = a + i * kPart;
     const uint64_t c = (c0 - ys) / kChunk;
-    if (i != 0) sync[c] = c0;
-    counts[c] = keep[i];
+    // (xr_compact copies counts[c] pairs from scratch + 2 (sync[c] - ys): one pair further when the first entry is dropped)
+    if (i != 0 || first[i] != 0) sync[c] = c0 + first[i];
+    counts[c] = keep[i] - first[i];
   }
-}
-
-// one wave: the sink over the parts' raw matches, in place at the segment's beginning (the sunk list never overtakes the
-// raw matches still to be read: a part holds at most one per byte).  64 raw matches at a time go through LDS; the top 256
-// entries of the stack live in an LDS window beside their copy in device memory.
-__global__ void __launch_bounds__(64) xr_sink(uint64_t a, uint64_t ys, uint64_t n_parts, const uint32_t* raw_n, uint64_t* scratch,
-                                              uint32_t* count_out) {
-  constexpr uint32_t kWin = 256;
-  __shared__ uint64_t buf[128];
-  __shared__ uint64_t win[2 * kWin];
-  const uint32_t lane = threadIdx.x;
-  uint64_t* out = scratch + 2 * (a - ys);
-  uint64_t out_n = 0, hi = 0;  // hi: entries [hi - kWin, hi) of the stack are in the window (hi = 1 + the largest index pushed)
-  auto top = [&](uint64_t idx, int which) -> uint64_t { return idx + kWin >= hi ? win[2 * (idx % kWin) + which] : out[2 * idx + which]; };
-  for (uint64_t i = 0; i < n_parts; i++) {
-    const uint64_t cnt = raw_n[i];
-    const uint64_t* src = scratch + 2 * (a + i * kPart - ys);
-    for (uint64_t j0 = 0; j0 < cnt; j0 += 64) {
-      const uint32_t m = static_cast<uint32_t>(std::min<uint64_t>(64, cnt - j0));
-      if (lane < m) {
-        buf[2 * lane] = src[2 * (j0 + lane)];
-        buf[2 * lane + 1] = src[2 * (j0 + lane) + 1];
-      }
-      __syncthreads();
-      if (lane == 0) {
-        for (uint32_t k = 0; k < m; k++) {
-          const int64_t pb = static_cast<int64_t>(buf[2 * k]), pe = static_cast<int64_t>(buf[2 * k + 1]);
-          while (out_n > 0 && static_cast<int64_t>(top(out_n - 1, 0)) >= pb) out_n--;
-          if (pb == pe && out_n > 0 && static_cast<int64_t>(top(out_n - 1, 1)) == pb) continue;
-          out[2 * out_n] = static_cast<uint64_t>(pb);
-          out[2 * out_n + 1] = static_cast<uint64_t>(pe);
-          win[2 * (out_n % kWin)] = static_cast<uint64_t>(pb);
-          win[2 * (out_n % kWin) + 1] = static_cast<uint64_t>(pe);
-          out_n++;
-          if (out_n > hi) hi = out_n;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  if (lane == 0) *count_out = static_cast<uint32_t>(out_n);
 }
 
 // one workgroup: offs[c] = total so far + exclusive prefix of counts; total += sum
@@ -499,22 +466,18 @@ int run_exact_nq(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
             n_cand++;
             s->xr_rounds++;
           }
-          const int local_sink = P.nullable == 0 ? 1 : 0;
-          uint64_t* min_begin = reinterpret_cast<uint64_t*>(exits);  // (the exit rings are done with: at least n_parts words)
+          uint64_t* min_begin = reinterpret_cast<uint64_t*>(exits);  // (the exit rings are done with: at least 2 n_parts words)
           if (lds)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(xr_emit<true>), dim3(blocks), dim3(kReplayLanes), lds_bytes, st, G, d_text, n, a, b, ys, n_parts, chosen,
-                               cands, ring_mem, s->xr_scratch.as<uint64_t>(), raw_n, local_sink, min_begin);
+                               cands, ring_mem, s->xr_scratch.as<uint64_t>(), raw_n, min_begin);
           else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(xr_emit<false>), dim3(blocks), dim3(kReplayLanes), 0, st, G, d_text, n, a, b, ys, n_parts, chosen,
-                               cands, ring_mem, s->xr_scratch.as<uint64_t>(), raw_n, local_sink, min_begin);
-          if (local_sink) {
-            uint32_t* keep = reinterpret_cast<uint32_t*>(min_begin + n_parts);
-            int32_t* prev = reinterpret_cast<int32_t*>(keep + n_parts);
-            hipLaunchKernelGGL(xr_join, dim3(1), dim3(64), 0, st, a, ys, n_parts, raw_n, min_begin, s->xr_scratch.as<uint64_t>(), keep, prev,
-                               s->xr_sync.as<uint64_t>(), s->xr_counts.as<uint32_t>());
-          } else {
-            hipLaunchKernelGGL(xr_sink, dim3(1), dim3(64), 0, st, a, ys, n_parts, raw_n, s->xr_scratch.as<uint64_t>(), s->xr_counts.as<uint32_t>() + c);
-          }
+                               cands, ring_mem, s->xr_scratch.as<uint64_t>(), raw_n, min_begin);
+          uint32_t* keep = reinterpret_cast<uint32_t*>(min_begin + n_parts);
+          uint32_t* first = keep + n_parts;
+          int32_t* prev = reinterpret_cast<int32_t*>(first + n_parts);
+          hipLaunchKernelGGL(xr_join, dim3(1), dim3(64), 0, st, a, ys, n_parts, raw_n, min_begin, s->xr_scratch.as<uint64_t>(), keep, first, prev,
+                             s->xr_sync.as<uint64_t>(), s->xr_counts.as<uint32_t>());
           s->xr_parts += n_parts;
         }
       }

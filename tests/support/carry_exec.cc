@@ -246,26 +246,32 @@ static uint64_t replay_segment_speculatively(const DevGraph& G, const uint8_t* t
     lists[i].assign(raw.begin(), raw.begin() + static_cast<long>(2 * kept));
   }
   if (!local_sink) return out_n;
-  std::vector<uint64_t> keep(n_parts, 0);
+  std::vector<uint64_t> keep(n_parts, 0), first(n_parts, 0);
   std::vector<int64_t> prev(n_parts, -1);
   int64_t top_part = -1;
   for (uint64_t i = 0; i < n_parts; i++) {  // xr_join
     const uint64_t l = lists[i].size() / 2, mb = min_begin[i];
     while (top_part >= 0 && mb != ~0ull) {
-      uint64_t kk = keep[static_cast<size_t>(top_part)];
-      while (kk > 0 && lists[static_cast<size_t>(top_part)][2 * (kk - 1)] >= mb) kk--;
-      keep[static_cast<size_t>(top_part)] = kk;
-      if (kk != 0) break;
-      top_part = prev[static_cast<size_t>(top_part)];
+      const size_t tp = static_cast<size_t>(top_part);
+      uint64_t kk = keep[tp];
+      while (kk > first[tp] && lists[tp][2 * (kk - 1)] >= mb) kk--;
+      keep[tp] = kk;
+      if (kk != first[tp]) break;
+      top_part = prev[tp];
     }
     keep[i] = l;
-    if (l != 0) {
+    // the filter of the sink, for the one entry whose decision the part could not take on its own: its list's first, an empty
+    // match right at the end of the entry before it (which belongs to an earlier part)
+    if (l != 0 && top_part >= 0 && lists[i][0] == lists[i][1] && lists[i][0] == mb &&
+        lists[static_cast<size_t>(top_part)][2 * (keep[static_cast<size_t>(top_part)] - 1) + 1] == lists[i][0])
+      first[i] = 1;
+    if (l != first[i]) {
       prev[i] = top_part;
       top_part = static_cast<int64_t>(i);
     }
   }
   for (uint64_t i = 0; i < n_parts; i++)
-    for (uint64_t j = 0; j < keep[i]; j++) {
+    for (uint64_t j = first[i]; j < keep[i]; j++) {
       out[2 * out_n] = lists[i][2 * j];
       out[2 * out_n + 1] = lists[i][2 * j + 1];
       out_n++;
@@ -273,6 +279,7 @@ static uint64_t replay_segment_speculatively(const DevGraph& G, const uint8_t* t
   return out_n;
 }
 
+static bool local_sink_always = true;  // (the device: xr_join for every pattern since the filter's one cross-part case is handled there)
 template <int NQ>
 static long exact_run_spec(const DevProgram& F, const DevGraph& G, const uint8_t* t, uint64_t n, uint64_t chunk, uint64_t sb, uint64_t se,
                            uint64_t sub, uint64_t warm, uint64_t* out, uint64_t cap, uint64_t* fixed) {
@@ -288,7 +295,7 @@ static long exact_run_spec(const DevProgram& F, const DevGraph& G, const uint8_t
   for (size_t i = 0; i < syncs.size(); i++) {
     const uint64_t a = syncs[i], b = i + 1 < syncs.size() ? syncs[i + 1] : y1;
     std::vector<uint64_t> seg(2 * (b - a) + 2);
-    uint64_t m = replay_segment_speculatively(G, t, n, a, b, sub, warm, seg.data(), fixed, F.nullable == 0);
+    uint64_t m = replay_segment_speculatively(G, t, n, a, b, sub, warm, seg.data(), fixed, local_sink_always || F.nullable == 0);
     if (m == ~0ull) {  // (given up: the device keeps the documented semantics; here the one sequential replay)
       std::vector<int64_t> ring(static_cast<size_t>(G.n_states) * G.times);
       int64_t* r = ring.data();

@@ -147,7 +147,7 @@ def test_long_stretches_in_parts(rj, oracle):
     breaks keeps a PHASE (the matches tile it in threes), so the walk needs a round per phase; the answer is the reference's
     (Oracle.match_all), which on these texts differs from the documented semantics.  20 MiB whole and as ranges of a
     sharded run, 66 MiB (the batch has to grow beyond 64 MiB), several long segments between a few line breaks, a pattern
-    that can match the empty string (the sequential sink instead of the parts' own lists), a wider ring."""
+    that can match the empty string (the sink's filter at the junction of two parts), a wider ring."""
     import torch
     risky_nullable = 0
     for rx, n, alphabet, breaks in ((b".{0,2}.", 20 << 20, b"abcde", ()), (b".{0,2}.", 66 << 20, b"ab", ()),
@@ -186,7 +186,7 @@ def test_long_stretches_in_parts(rj, oracle):
             assert spec != ref, "the reference's answer should differ from the documented semantics on this text"
             cuts = [0, 5 << 20, (5 << 20) + 1, 17 << 20, n + 1]
             assert np.array_equal(run_ranges(rj, scan, d, n, cuts), want), rx
-    # (the sequential sink is for patterns that match the empty string: at least one of them must be at risk and have run)
+    # (the filter at a junction only matters for patterns that match the empty string: one of them must be at risk and have run)
     assert risky_nullable >= 1 or not rj.Program(b".{0,2}").info()["ring_artefact_risk"]
 
 
