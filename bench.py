@@ -421,11 +421,11 @@ def run_regexdna(args, c):
     settle_steps = 0
     if args.settle_ms > 0:
         cold_elapsed, _ = timed(c, args, step, drain)
-        _t = time.perf_counter()
-        while (time.perf_counter() - _t) * 1e3 < args.settle_ms:
-            for _ in range(50):
-                step(False)
-            settle_steps += 50
+        # (a step may hold a collective: every rank must run the SAME number of settle steps -- from the cold run's time per
+        # step, which timed() has already made the maximum over the ranks)
+        settle_steps = int(min(max(args.settle_ms / max(cold_elapsed / args.steps * 1e3, 1e-3), 1), 100000))
+        for _ in range(settle_steps):
+            step(False)
         if drain:
             drain()
         del scan_ms[:]                 # (kernel durations of the timed region only)
