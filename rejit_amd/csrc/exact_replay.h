@@ -261,60 +261,121 @@ RJ_HD uint64_t rj_replay_segment(const DevGraph& G, const uint8_t* t, uint64_t n
 // ---- long segments: speculate and verify (round 4).
 //
 // One lane replays a segment at 2-6 us per byte, so a stretch of megabytes without a synchronisation point took minutes.
-// The ring's evolution does not depend on the sink, and it is deterministic: from EQUAL rings at the same position on --
-// equal as AGES, position minus start offset -- two runs of the loop agree for ever, and report the same matches.  So a
-// long segment is cut into parts at c_1 < c_2 < ...:
+// Two facts make parts of it independent.  (1) The ring's evolution does not depend on the sink.  (2) It depends on the
+// start offsets in the ring only through their ORDER: "left-most start wins" is a minimum (SetState), ClearStates frees the
+// starts between a match's begin and its end -- comparisons, never arithmetic; the values themselves only come out as the
+// begins of matches.  So two runs of the loop that stand at the same position with rings of the same ORDER PATTERN -- the
+// same slots occupied, their distinct starts ranked the same way -- go through the same steps from there on, thread for
+// thread, and report the same matches, except that a match of a thread that was already there reports ITS start.
+// A long segment is cut into parts at c_1 < c_2 < ...:
 //   round 0      every part i is replayed from c_i - W bytes with a free ring (part 0 from the segment's beginning: exact),
-//                in parallel; it notes the ring on entering the part (E_i) and on leaving it (X_i^0);
-//   the walk     goes over the parts in order with the TRUE ring T (free at the segment's beginning): a part that has been
-//                replayed from T -- T == E_i, or T == a candidate ring C_k it was given in a later round -- hands on its exit
-//                ring; otherwise the walk stops, T becomes a new candidate, and
+//                in parallel.  On arriving at c_i it notes the ring's order pattern (E_i) and RELABELS the threads that
+//                are there, oldest first, c_i - cnt .. c_i - 1 (order kept; a start below c_i from then on means "the
+//                thread of that rank at the part's entry"); on leaving the part it notes the ring as it is (X_i^0);
+//   the walk     goes over the parts in order with the TRUE ring T (free at the segment's beginning, real start offsets): a
+//                part that has been replayed from T's order pattern -- it equals E_i, or a candidate pattern C_k the part
+//                was given in a later round -- hands on its exit ring, the inherited ranks replaced by T's real starts;
+//                otherwise the walk stops, T's pattern becomes a new candidate, and
 //   round k      every part from there on is replayed from C_k, in parallel, noting X_i^k; the walk carries on.
-// The number of rounds is the number of different rings met at the cuts that the warm-up did not produce by itself.
-// Threads are short-lived and every match clears most of the ring, so usually none; a text that keeps a PHASE (`.{0,2}.`
-// over a run without line breaks: matches tile it in threes) needs one round per phase; a thread that outlives the warm-up
-// (`[xy]+z` inside a run of x: the match begins megabytes back) gives a different ring at every cut -- the answer really
-// does depend on the far past -- and after kReplayMaxRounds the segment is given up (the caller keeps the documented
-// semantics).  Then every part is replayed once more from its verified ring, reporting its matches RAW, and the sink
-// (rj_sink_append) is applied to them in order: cheap next to the ring.
+// The number of rounds is the number of different ORDER PATTERNS met at the cuts that the warm-up did not produce by
+// itself: usually none -- also for a thread that lives for megabytes (`[xy]+z` inside a run of x: it holds its slot in
+// every part's warm-up just as in the true run, only under another start) --; a text that keeps a PHASE (`.{0,2}.` over a
+// run without line breaks: matches tile it in threes) needs one per phase.  After kReplayMaxRounds the segment is given up
+// (the caller keeps the documented semantics).  Then every part is replayed once more from its verified pattern,
+// reporting its matches RAW with the inherited begins replaced by the true starts the walk left for it, and the sink
+// (rj_sink_append) is applied to them: cheap next to the ring.
 
 constexpr int kReplayMaxRounds = 12;
 
-// the ring as AGES in time order from the current row (what two runs at the same position must agree on):
-// snap[d * S + s] = p - start offset, or -1 for a free slot
+// The ring's order pattern, slots in time order from the current row: pat[d * S + s] = the rank of the slot's start among
+// the ring's distinct starts (0 = oldest), -1 for a free slot; sorted[k] = the k-th smallest distinct start (room for one
+// per slot).  Returns their number.
 template <class Ring>
-RJ_HD void rj_ring_snapshot(const DevGraph& G, Ring ring, int base, uint64_t p, int64_t* snap) {
-  const int S = G.n_states, T = G.times;
+RJ_HD int rj_ring_pattern(const DevGraph& G, Ring ring, int base, int64_t* pat, int64_t* sorted) {
+  const int S = G.n_states, T = G.times, slots = S * T;
+  int cnt = 0;
+  for (int i = 0; i < slots; i++) {  // the distinct starts, ascending (insertion: a few dozen at most)
+    const int64_t v = ring(i);
+    if (v < 0) continue;
+    int k = 0;
+    while (k < cnt && sorted[k] < v) k++;
+    if (k < cnt && sorted[k] == v) continue;
+    for (int j = cnt; j > k; j--) sorted[j] = sorted[j - 1];
+    sorted[k] = v;
+    cnt++;
+  }
   for (int d = 0; d < T; d++) {
     int row = base + d;
     if (row >= T) row -= T;
     for (int s = 0; s < S; s++) {
       const int64_t v = ring(row * S + s);
-      snap[d * S + s] = v < 0 ? -1 : static_cast<int64_t>(p) - v;
+      int64_t rank = -1;
+      if (v >= 0) {
+        int k = 0;
+        while (sorted[k] != v) k++;
+        rank = k;
+      }
+      pat[d * S + s] = rank;
     }
+  }
+  return cnt;
+}
+
+// the ring as it is, slots in time order from the current row (start offsets, -1 free)
+template <class Ring>
+RJ_HD void rj_ring_values(const DevGraph& G, Ring ring, int base, int64_t* snap) {
+  const int S = G.n_states, T = G.times;
+  for (int d = 0; d < T; d++) {
+    int row = base + d;
+    if (row >= T) row -= T;
+    for (int s = 0; s < S; s++) snap[d * S + s] = ring(row * S + s);
   }
 }
 
-// Positions [start, stop) of a segment (stop <= n + 1; the loop also ends behind position n): from a free ring, or from
-// `init` (a snapshot taken at `start`: ages).  Matches that END at or after emit_from go to out as found (no sink; out may
-// be null: counted only); snapshots are taken on arriving at emit_from (snap_entry, if not null) and at stop (snap_exit,
-// if not null and reached).  Returns the number of raw matches.
+// Positions [start, stop) of a segment (stop <= n + 1; the loop also ends behind position n).
+//   init == null: from a free ring at `start` <= emit_from (the warm-up).  On arriving at emit_from the ring's order pattern
+//                 goes to entry_pat (if not null) and the threads that are there are relabelled emit_from - cnt + rank.
+//   init != null: start == emit_from, the ring is built from the order pattern `init` with the same labels.
+// A start below emit_from then means "the thread of rank start - (emit_from - cnt) at the part's entry".  On reaching
+// `stop` the ring's values go to exit_values (if not null).  Matches that END at or after emit_from go to out as found
+// (no sink; out may be null: counted only), an inherited begin replaced by true_starts[rank] (the real start offsets of
+// the entry's threads, oldest first) when that is given.  Returns the number of raw matches.
 template <class Ring>
 RJ_HD uint64_t rj_replay_raw(const DevGraph& G, const uint8_t* t, uint64_t n, uint64_t start, const int64_t* init, uint64_t emit_from,
-                             uint64_t stop, Ring ring, int64_t* snap_entry, int64_t* snap_exit, uint64_t* out) {
+                             uint64_t stop, Ring ring, int64_t* entry_pat, int64_t* exit_values, uint64_t* out, const int64_t* true_starts,
+                             int64_t* pattern_scratch) {
   const int slots = G.n_states * G.times;
-  for (int i = 0; i < slots; i++) ring(i) = init && init[i] >= 0 ? static_cast<int64_t>(start) - init[i] : -1;
+  int64_t cnt = 0;
+  if (init) {
+    for (int i = 0; i < slots; i++) cnt = init[i] + 1 > cnt ? init[i] + 1 : cnt;
+    for (int i = 0; i < slots; i++) ring(i) = init[i] >= 0 ? static_cast<int64_t>(emit_from) - cnt + init[i] : -1;
+  } else {
+    for (int i = 0; i < slots; i++) ring(i) = -1;
+  }
   int base = 0;
   uint64_t out_n = 0;
   for (uint64_t p = start;; p++) {
-    if (p == emit_from && snap_entry) rj_ring_snapshot(G, ring, base, p, snap_entry);
+    if (p == emit_from && !init) {
+      // (base rotates with p - start: the pattern is taken in time order, the relabelling done slot by slot)
+      // (pattern_scratch: 2 x slots words -- the pattern when the caller does not want it, and the distinct starts)
+      int64_t* pat = entry_pat ? entry_pat : pattern_scratch;
+      cnt = rj_ring_pattern(G, ring, base, pat, pattern_scratch + slots);
+      const int S = G.n_states, T = G.times;
+      for (int d = 0; d < T; d++) {
+        int row = base + d;
+        if (row >= T) row -= T;
+        for (int s = 0; s < S; s++)
+          if (pat[d * S + s] >= 0) ring(row * S + s) = static_cast<int64_t>(emit_from) - cnt + pat[d * S + s];
+      }
+    }
     if (p == stop) {
-      if (snap_exit) rj_ring_snapshot(G, ring, base, p, snap_exit);
+      if (exit_values) rj_ring_values(G, ring, base, exit_values);
       break;
     }
     int64_t pb = 0;
     if (rj_ring_match(G, t, n, p, ring, base, &pb) && p >= emit_from) {
       if (out) {
+        if (true_starts && pb < static_cast<int64_t>(emit_from)) pb = true_starts[pb - (static_cast<int64_t>(emit_from) - cnt)];
         out[2 * out_n] = static_cast<uint64_t>(pb);
         out[2 * out_n + 1] = p;
       }

@@ -19,16 +19,16 @@
 // was not replayed at all.  Now a segment of more than kLongSegment bytes is taken in parts (exact_replay.h, "speculate and
 // verify"):
 //   xr_round       lane per part of kPart bytes: round 0 replays it from kWarm bytes before with a free ring and notes the
-//                  ring (as ages) on entering and on leaving the part; round k replays the parts from candidate ring k
-//   xr_walk        one wave carries the TRUE ring over the parts: a part that was replayed from it hands on its exit ring;
-//                  a ring no part was replayed from stops the walk and becomes the next round's candidate
+//                  ring's ORDER PATTERN on entering the part and the ring on leaving it; round k replays the parts from
+//                  candidate pattern k
+//   xr_walk        one wave carries the TRUE ring over the parts: a part that was replayed from its order pattern hands on its
+//                  exit ring (inherited ranks replaced by the true starts); a pattern no part was replayed from stops the
+//                  walk and becomes the next round's candidate
 //   xr_emit        lane per part: once more from its verified ring, its matches through the sink as if nothing came before
 //   xr_join        one lane over the PARTS: a part pops from the lists before it while begin >= its smallest raw begin, and
 //                  drops its first entry when the sink's filter says so; the parts' lists then go to xr_compact as they are
 // and xr_offsets / xr_compact carry on as for the other segments.  What remains: a segment must fit a batch (which grows
-// from 64 MiB to 1 GiB when it has to), its
-// text must not keep a thread alive across the parts (more than kReplayMaxRounds different rings at the cuts: `[xy]+z`
-// inside megabytes of x), and rings of more than kWalkSlots slots keep the one-lane replay (<= 16 MiB): otherwise run_exact
+// from 64 MiB to 1 GiB when it has to), the cuts must not meet more than kReplayMaxRounds different order patterns, and rings of more than kWalkSlots slots keep the one-lane replay (<= 16 MiB): otherwise run_exact
 // reports "not done" and the caller keeps the result of the parallel pipeline (documented semantics).
 #include <hip/hip_runtime.h>
 
@@ -48,7 +48,7 @@ constexpr uint64_t kBigBatchChunks = 1u << 20;  // ... and up to 1 GiB (16 GiB o
 constexpr uint64_t kMaxSegment = 16ull << 20;   // longest stretch ONE lane is asked to replay (rings too large for the walk)
 constexpr uint64_t kLongSegment = 64ull << 10;  // a longer segment is taken in parts
 constexpr uint64_t kPart = 2048, kWarm = 512;   // bytes per part; bytes before a part its replay starts at
-constexpr int kWalkSlots = 448;                 // times x states up to this: xr_walk holds the true ring and the candidates in LDS
+constexpr int kWalkSlots = 448;                 // times x states up to this: xr_walk holds the true ring, its pattern and the candidates in LDS (16 x 448 x 8 B)
 constexpr int kReplayLanes = 64;                // lanes per workgroup of xr_replay
 constexpr int kLdsRingSlots = 96;               // times x states up to this: ring in LDS (64 lanes x 96 x 8 B = 48 KiB)
 
@@ -144,11 +144,12 @@ __device__ __forceinline__ uint64_t part_warm_start(uint64_t a, uint64_t i) {
   return i == 0 ? a : std::max(a, c0 - std::min(c0, kWarm));
 }
 
-// exits: [n_parts][slots] of this round; entry0 (round 0 only): [n_parts][slots]
+// exits: [n_parts][slots] of this round (ring values at the part's end); entry0 (round 0 only): [n_parts][slots] order
+// patterns; cand: the round's candidate pattern (null: round 0); pat_scratch: 2 x slots words per lane
 template <bool LDS>
 __global__ void __launch_bounds__(kReplayLanes)
 xr_round(DevGraph G, const uint8_t* t, uint64_t n, uint64_t a, uint64_t b, uint64_t n_parts, uint64_t from, const int64_t* cand,
-         int64_t* ring_mem, int64_t* entry0, int64_t* exits) {
+         int64_t* ring_mem, int64_t* entry0, int64_t* exits, int64_t* pat_scratch) {
   extern __shared__ int64_t lds_ring[];
   const uint64_t lanes = static_cast<uint64_t>(gridDim.x) * kReplayLanes;
   const uint64_t lane = static_cast<uint64_t>(blockIdx.x) * kReplayLanes + threadIdx.x;
@@ -157,59 +158,103 @@ xr_round(DevGraph G, const uint8_t* t, uint64_t n, uint64_t a, uint64_t b, uint6
     const uint64_t c0 = a + i * kPart, c1 = i + 1 == n_parts ? b : c0 + kPart;
     const uint64_t start = cand ? c0 : part_warm_start(a, i);
     int64_t* entry = cand ? nullptr : entry0 + i * slots;
-    if (LDS) rj_replay_raw(G, t, n, start, cand, c0, c1, LdsRing{lds_ring + threadIdx.x}, entry, exits + i * slots, static_cast<uint64_t*>(nullptr));
-    else rj_replay_raw(G, t, n, start, cand, c0, c1, GlobalRing{ring_mem + lane, lanes}, entry, exits + i * slots, static_cast<uint64_t*>(nullptr));
+    int64_t* scratch = pat_scratch + lane * 2 * slots;
+    if (LDS) rj_replay_raw(G, t, n, start, cand, c0, c1, LdsRing{lds_ring + threadIdx.x}, entry, exits + i * slots, static_cast<uint64_t*>(nullptr),
+                           static_cast<const int64_t*>(nullptr), scratch);
+    else rj_replay_raw(G, t, n, start, cand, c0, c1, GlobalRing{ring_mem + lane, lanes}, entry, exits + i * slots, static_cast<uint64_t*>(nullptr),
+                       static_cast<const int64_t*>(nullptr), scratch);
   }
 }
 
-// One wave.  cands: [kReplayMaxRounds + 1][slots] (row 0 unused: round 0's entry rings are the parts' own); exits:
-// [kReplayMaxRounds + 1][n_parts][slots]; walk_ring: the true ring at part state[kXrWalkNext] (in: where to carry on; out:
-// the ring that stopped the walk).  state[kXrWalkStuck] = 1 when it stopped before the last part.
-__global__ void __launch_bounds__(64) xr_walk(uint64_t slots, uint64_t n_parts, int n_cand, CandFrom cand_from, const int64_t* cands,
-                                              const int64_t* entry0, const int64_t* exits, int64_t* walk_ring, int32_t* chosen,
-                                              unsigned long long* state) {
-  extern __shared__ int64_t lds[];  // the true ring, then the candidates 1 .. n_cand - 1
+// One wave.  cands: [kReplayMaxRounds + 1][slots] order patterns (row 0 unused: round 0's entry patterns are the parts' own);
+// exits: [kReplayMaxRounds + 1][n_parts][slots]; walk_ring: the TRUE ring (start offsets, time order) at part
+// state[kXrWalkNext] -- in: where to carry on; out: where the walk stands; walk_pat (out): the pattern that stopped the walk;
+// true_starts: [n_parts][slots], row i = the real start offsets of the threads at part i's entry, oldest first (for xr_emit).
+// state[kXrWalkStuck] = 1 when it stopped before the last part.
+__global__ void __launch_bounds__(64) xr_walk(uint64_t slots, uint64_t a, uint64_t n_parts, int n_cand, CandFrom cand_from, const int64_t* cands,
+                                              const int64_t* entry0, const int64_t* exits, int64_t* walk_ring, int64_t* walk_pat,
+                                              int64_t* true_starts, int32_t* chosen, unsigned long long* state) {
+  extern __shared__ int64_t lds[];  // the true ring | its pattern | its distinct starts, ascending | first-slot flags | the candidates 1 .. n_cand - 1
   int64_t* T = lds;
+  int64_t* pat = lds + slots;
+  int64_t* sorted = lds + 2 * slots;
+  int64_t* first_slot = lds + 3 * slots;  // 1: the slot is the first one that holds its start
+  int64_t* cand_lds = lds + 4 * slots;    // candidate c at (c - 1) * slots
   const uint32_t lane = threadIdx.x;
   for (uint64_t k = lane; k < slots; k += 64) T[k] = walk_ring[k];
   for (int c = 1; c < n_cand; c++)
-    for (uint64_t k = lane; k < slots; k += 64) lds[static_cast<uint64_t>(c) * slots + k] = cands[static_cast<uint64_t>(c) * slots + k];
+    for (uint64_t k = lane; k < slots; k += 64) cand_lds[static_cast<uint64_t>(c - 1) * slots + k] = cands[static_cast<uint64_t>(c) * slots + k];
   __syncthreads();
   uint64_t i = state[kXrWalkNext];
   for (; i < n_parts; i++) {
+    // the true ring's order pattern: a slot's rank = the distinct starts below its own (each counted at its first slot)
+    for (uint64_t k = lane; k < slots; k += 64) {
+      const int64_t v = T[k];
+      bool first = v >= 0;
+      for (uint64_t q = 0; q < k && first; q++) first = T[q] != v;
+      first_slot[k] = first ? 1 : 0;
+    }
+    __syncthreads();
+    for (uint64_t k = lane; k < slots; k += 64) {
+      const int64_t v = T[k];
+      int64_t rank = -1;
+      if (v >= 0) {
+        rank = 0;
+        for (uint64_t j = 0; j < slots; j++) rank += (first_slot[j] != 0 && T[j] < v) ? 1 : 0;
+        if (first_slot[k] != 0) sorted[rank] = v;
+      }
+      pat[k] = rank;
+    }
+    __syncthreads();
     int found = -1;
     {
       bool same = true;
-      for (uint64_t k = lane; k < slots; k += 64) same = same && T[k] == entry0[i * slots + k];
+      for (uint64_t k = lane; k < slots; k += 64) same = same && pat[k] == entry0[i * slots + k];
       if (__ballot(!same) == 0) found = 0;
     }
     for (int c = 1; c < n_cand && found < 0; c++) {
       if (i < cand_from.v[c]) continue;
       bool same = true;
-      for (uint64_t k = lane; k < slots; k += 64) same = same && T[k] == lds[static_cast<uint64_t>(c) * slots + k];
+      for (uint64_t k = lane; k < slots; k += 64) same = same && pat[k] == cand_lds[static_cast<uint64_t>(c - 1) * slots + k];
       if (__ballot(!same) == 0) found = c;
     }
     if (found < 0) break;
+    // the number of distinct starts, the part's true starts for xr_emit, and the ring the part leaves
+    int64_t cnt = 0;
+    for (uint64_t k = lane; k < slots; k += 64) cnt = pat[k] + 1 > cnt ? pat[k] + 1 : cnt;
+    for (int o = 32; o > 0; o >>= 1) {
+      const int64_t other = __shfl_xor(cnt, o);
+      cnt = other > cnt ? other : cnt;
+    }
+    for (uint64_t k = lane; k < static_cast<uint64_t>(cnt); k += 64) true_starts[i * slots + k] = sorted[k];
     if (lane == 0) chosen[i] = found;
-    __syncthreads();
+    const int64_t c0 = static_cast<int64_t>(a + i * kPart);
     const int64_t* x = exits + (static_cast<uint64_t>(found) * n_parts + i) * slots;
-    for (uint64_t k = lane; k < slots; k += 64) T[k] = x[k];
+    int64_t next[(kWalkSlots + 63) / 64];
+    int u = 0;
+    for (uint64_t k = lane; k < slots; k += 64, u++) {
+      const int64_t v = x[k];
+      next[u] = v < 0 ? -1 : v < c0 ? sorted[v - (c0 - cnt)] : v;
+    }
+    __syncthreads();
+    u = 0;
+    for (uint64_t k = lane; k < slots; k += 64, u++) T[k] = next[u];
     __syncthreads();
   }
-  for (uint64_t k = lane; k < slots; k += 64) walk_ring[k] = T[k];
+  for (uint64_t k = lane; k < slots; k += 64) {
+    walk_ring[k] = T[k];
+    walk_pat[k] = pat[k];
+  }
   if (lane == 0) {
     state[kXrWalkNext] = i;
     state[kXrWalkStuck] = i < n_parts ? 1 : 0;
   }
 }
 
-// Then the sink over the part's own matches, in place, as if nothing came before the part, and the smallest begin among its
-// raw matches: all a later part's matches do to the list before them is "pop while begin >= that", and the one decision of
-// the sink's filter the part cannot take on its own is its list's first entry (xr_join).
 template <bool LDS>
 __global__ void __launch_bounds__(kReplayLanes)
 xr_emit(DevGraph G, const uint8_t* t, uint64_t n, uint64_t a, uint64_t b, uint64_t ys, uint64_t n_parts, const int32_t* chosen, const int64_t* cands,
-        int64_t* ring_mem, uint64_t* scratch, uint32_t* raw_n, uint64_t* min_begin) {
+        const int64_t* true_starts, int64_t* ring_mem, int64_t* pat_scratch, uint64_t* scratch, uint32_t* raw_n, uint64_t* min_begin) {
   extern __shared__ int64_t lds_ring[];
   const uint64_t lanes = static_cast<uint64_t>(gridDim.x) * kReplayLanes;
   const uint64_t lane = static_cast<uint64_t>(blockIdx.x) * kReplayLanes + threadIdx.x;
@@ -220,9 +265,11 @@ xr_emit(DevGraph G, const uint8_t* t, uint64_t n, uint64_t a, uint64_t b, uint64
     const int64_t* init = k == 0 ? nullptr : cands + static_cast<uint64_t>(k) * slots;
     const uint64_t start = k == 0 ? part_warm_start(a, i) : c0;
     uint64_t* out = scratch + 2 * (c0 - ys);
+    const int64_t* ts = true_starts + i * slots;
+    int64_t* ps = pat_scratch + lane * 2 * slots;
     uint64_t m;
-    if (LDS) m = rj_replay_raw(G, t, n, start, init, c0, c1, LdsRing{lds_ring + threadIdx.x}, static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr), out);
-    else m = rj_replay_raw(G, t, n, start, init, c0, c1, GlobalRing{ring_mem + lane, lanes}, static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr), out);
+    if (LDS) m = rj_replay_raw(G, t, n, start, init, c0, c1, LdsRing{lds_ring + threadIdx.x}, static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr), out, ts, ps);
+    else m = rj_replay_raw(G, t, n, start, init, c0, c1, GlobalRing{ring_mem + lane, lanes}, static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr), out, ts, ps);
     uint64_t lowest = ~0ull, kept = 0;
     for (uint64_t j = 0; j < m; j++) {
       const uint64_t pb = out[2 * j], pe = out[2 * j + 1];
@@ -428,24 +475,29 @@ int run_exact_nq(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
           // the chunk its first byte lies in holds no synchronisation point of its own -- xr_join hands the part's list to
           // xr_compact through that chunk's sync[] / counts[] words)
           const uint64_t n_parts = (b - a) / kPart;
-          // snaps: the candidates' rings and the walk's [kReplayMaxRounds + 2][slots] | round 0's entry rings [n_parts][slots] |
-          // the exit rings [kReplayMaxRounds + 1][n_parts][slots]
-          RJ_HIP(s->xr_snaps.reserve((static_cast<size_t>(kReplayMaxRounds) + 2 + (static_cast<size_t>(kReplayMaxRounds) + 2) * n_parts) * ring_bytes));
+          // snaps: the candidate patterns [kReplayMaxRounds + 1][slots] | the walk's ring and the pattern that stopped it [2][slots] |
+          // round 0's entry patterns [n_parts][slots] | the parts' true starts [n_parts][slots] | the exit rings
+          // [kReplayMaxRounds + 1][n_parts][slots] | pattern scratch [lanes][2 slots]
+          const int blocks = static_cast<int>(std::min<uint64_t>((n_parts + kReplayLanes - 1) / kReplayLanes, static_cast<uint64_t>(replay_blocks)));
+          const size_t lanes = static_cast<size_t>(blocks) * kReplayLanes;
+          RJ_HIP(s->xr_snaps.reserve((static_cast<size_t>(kReplayMaxRounds) + 3 + (static_cast<size_t>(kReplayMaxRounds) + 3) * n_parts + 2 * lanes) * ring_bytes));
           RJ_HIP(s->xr_raw_n.reserve(n_parts * 2 * sizeof(uint32_t)));
           int64_t* cands = s->xr_snaps.as<int64_t>();
           int64_t* walk_ring = cands + static_cast<size_t>(kReplayMaxRounds + 1) * slots;
-          int64_t* entry0 = walk_ring + slots;
-          int64_t* exits = entry0 + n_parts * static_cast<size_t>(slots);
+          int64_t* walk_pat = walk_ring + slots;
+          int64_t* entry0 = walk_pat + slots;
+          int64_t* true_starts = entry0 + n_parts * static_cast<size_t>(slots);
+          int64_t* exits = true_starts + n_parts * static_cast<size_t>(slots);
+          int64_t* pat_scratch = exits + static_cast<size_t>(kReplayMaxRounds + 1) * n_parts * slots;
           uint32_t* raw_n = s->xr_raw_n.as<uint32_t>();
           int32_t* chosen = reinterpret_cast<int32_t*>(raw_n + n_parts);
-          const int blocks = static_cast<int>(std::min<uint64_t>((n_parts + kReplayLanes - 1) / kReplayLanes, static_cast<uint64_t>(replay_blocks)));
           auto round = [&](uint64_t from, const int64_t* cand, int r) {
             if (lds)
               hipLaunchKernelGGL(HIP_KERNEL_NAME(xr_round<true>), dim3(blocks), dim3(kReplayLanes), lds_bytes, st, G, d_text, n, a, b, n_parts, from,
-                                 cand, ring_mem, entry0, exits + static_cast<size_t>(r) * n_parts * slots);
+                                 cand, ring_mem, entry0, exits + static_cast<size_t>(r) * n_parts * slots, pat_scratch);
             else
               hipLaunchKernelGGL(HIP_KERNEL_NAME(xr_round<false>), dim3(blocks), dim3(kReplayLanes), 0, st, G, d_text, n, a, b, n_parts, from,
-                                 cand, ring_mem, entry0, exits + static_cast<size_t>(r) * n_parts * slots);
+                                 cand, ring_mem, entry0, exits + static_cast<size_t>(r) * n_parts * slots, pat_scratch);
           };
           round(0, nullptr, 0);
           RJ_HIP(hipMemsetAsync(walk_ring, 0xFF, ring_bytes, st));  // (the segment begins with a free ring: every slot -1)
@@ -453,26 +505,26 @@ int run_exact_nq(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
           CandFrom cand_from{};
           int n_cand = 1;
           for (;;) {
-            hipLaunchKernelGGL(xr_walk, dim3(1), dim3(64), ring_bytes * static_cast<size_t>(n_cand), st, static_cast<uint64_t>(slots), n_parts, n_cand,
-                               cand_from, cands, entry0, exits, walk_ring, chosen, state);
+            hipLaunchKernelGGL(xr_walk, dim3(1), dim3(64), ring_bytes * static_cast<size_t>(n_cand + 3), st, static_cast<uint64_t>(slots), a, n_parts, n_cand,
+                               cand_from, cands, entry0, exits, walk_ring, walk_pat, true_starts, chosen, state);
             RJ_HIP(hipMemcpyAsync(h, state, sizeof(h), hipMemcpyDeviceToHost, st));
             RJ_HIP(hipStreamSynchronize(st));
             if (h[kXrWalkStuck] == 0) break;
-            if (n_cand > kReplayMaxRounds) return 0;  // (a different ring at every cut: a thread older than the parts)
-            // the ring that stopped the walk becomes candidate n_cand: every part from there on is replayed from it
-            RJ_HIP(hipMemcpyAsync(cands + static_cast<size_t>(n_cand) * slots, walk_ring, ring_bytes, hipMemcpyDeviceToDevice, st));
+            if (n_cand > kReplayMaxRounds) return 0;  // (more order patterns at the cuts than rounds: given up)
+            // the pattern that stopped the walk becomes candidate n_cand: every part from there on is replayed from it
+            RJ_HIP(hipMemcpyAsync(cands + static_cast<size_t>(n_cand) * slots, walk_pat, ring_bytes, hipMemcpyDeviceToDevice, st));
             cand_from.v[n_cand] = h[kXrWalkNext];
             round(h[kXrWalkNext], cands + static_cast<size_t>(n_cand) * slots, n_cand);
             n_cand++;
             s->xr_rounds++;
           }
-          uint64_t* min_begin = reinterpret_cast<uint64_t*>(exits);  // (the exit rings are done with: at least 2 n_parts words)
+          uint64_t* min_begin = reinterpret_cast<uint64_t*>(exits);  // (the exit rings are done with: at least 3 n_parts words)
           if (lds)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(xr_emit<true>), dim3(blocks), dim3(kReplayLanes), lds_bytes, st, G, d_text, n, a, b, ys, n_parts, chosen,
-                               cands, ring_mem, s->xr_scratch.as<uint64_t>(), raw_n, min_begin);
+                               cands, true_starts, ring_mem, pat_scratch, s->xr_scratch.as<uint64_t>(), raw_n, min_begin);
           else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(xr_emit<false>), dim3(blocks), dim3(kReplayLanes), 0, st, G, d_text, n, a, b, ys, n_parts, chosen,
-                               cands, ring_mem, s->xr_scratch.as<uint64_t>(), raw_n, min_begin);
+                               cands, true_starts, ring_mem, pat_scratch, s->xr_scratch.as<uint64_t>(), raw_n, min_begin);
           uint32_t* keep = reinterpret_cast<uint32_t*>(min_begin + n_parts);
           uint32_t* first = keep + n_parts;
           int32_t* prev = reinterpret_cast<int32_t*>(first + n_parts);

@@ -179,20 +179,21 @@ static long exact_run(const Program& P, const DevProgram& F, const DevGraph& G, 
 
 
 // One segment [a, b) the way exact_replay.hip takes a LONG one (exact_replay.h, "speculate and verify"): parts of `sub`
-// bytes; round 0 replays each from `warm` bytes before its beginning with a free ring (the first from a); the walk carries
-// the true ring over the parts, a ring no part has been replayed from becomes a candidate and a new round; then the raw
-// matches of every part from its verified ring, and the sink.  *fixed = rounds beyond the first; returns ~0 when there
-// were more than kReplayMaxRounds (the device gives the segment up).
+// bytes; round 0 replays each from `warm` bytes before its beginning with a free ring (the first from a) and notes the ring's
+// ORDER PATTERN on entering the part; the walk carries the true ring over the parts, a pattern no part has been replayed from
+// becomes a candidate and a new round; then the raw matches of every part from its verified pattern (inherited begins
+// replaced by the true starts), every part's own sunk list, and the join.  *fixed = rounds beyond the first; returns ~0
+// when there were more than kReplayMaxRounds (the device gives the segment up).
 static uint64_t replay_segment_speculatively(const DevGraph& G, const uint8_t* t, uint64_t n, uint64_t a, uint64_t b, uint64_t sub,
                                              uint64_t warm, uint64_t* out, uint64_t* fixed, bool local_sink) {
   const size_t slots = static_cast<size_t>(G.n_states) * G.times;
   const uint64_t n_parts = (b - a + sub - 1) / sub;
   typedef std::vector<int64_t> Snap;
-  std::vector<Snap> entry0(n_parts, Snap(slots, -1));
-  std::vector<std::vector<Snap>> exits(1, std::vector<Snap>(n_parts, Snap(slots, -1)));   // [round][part]
-  std::vector<Snap> cand(1);                                                               // candidate rings (0: the warm-up's own)
+  std::vector<Snap> entry0(n_parts, Snap(slots, -1));                                      // order patterns
+  std::vector<std::vector<Snap>> exits(1, std::vector<Snap>(n_parts, Snap(slots, -1)));   // [round][part]: ring values at the part's end
+  std::vector<Snap> cand(1);                                                               // candidate patterns (0: the warm-up's own)
   std::vector<uint64_t> cand_from(1, 0);
-  std::vector<int64_t> ring(slots);
+  std::vector<int64_t> ring(slots), scratch(2 * slots);
   int64_t* r = ring.data();
   auto ring_fn = [r](int i) -> int64_t& { return r[i]; };
   auto part_start = [&](uint64_t i) { return a + i * sub; };
@@ -200,27 +201,40 @@ static uint64_t replay_segment_speculatively(const DevGraph& G, const uint8_t* t
   auto warm_start = [&](uint64_t i) { const uint64_t c0 = part_start(i); return i == 0 ? a : std::max(a, c0 > warm ? c0 - warm : 0); };
   for (uint64_t i = 0; i < n_parts; i++)  // round 0 (in parallel on the device)
     rj_replay_raw(G, t, n, warm_start(i), static_cast<const int64_t*>(nullptr), part_start(i), part_stop(i), ring_fn, entry0[i].data(),
-                  exits[0][i].data(), static_cast<uint64_t*>(nullptr));
+                  exits[0][i].data(), static_cast<uint64_t*>(nullptr), static_cast<const int64_t*>(nullptr), scratch.data());
   std::vector<int> chosen(n_parts, -1);
-  Snap T(slots, -1);  // the true ring at the beginning of the part the walk stands at (free at a)
+  std::vector<Snap> true_starts(n_parts);  // the real start offsets of the threads at each part's entry, oldest first
+  Snap T(slots, -1);                       // the true ring at the beginning of the part the walk stands at (free at a)
   for (uint64_t i = 0; i < n_parts;) {
+    // T's order pattern
+    Snap sorted;
+    for (size_t k = 0; k < slots; k++)
+      if (T[k] >= 0) sorted.push_back(T[k]);
+    std::sort(sorted.begin(), sorted.end());
+    sorted.erase(std::unique(sorted.begin(), sorted.end()), sorted.end());
+    Snap pat(slots, -1);
+    for (size_t k = 0; k < slots; k++)
+      if (T[k] >= 0) pat[k] = std::lower_bound(sorted.begin(), sorted.end(), T[k]) - sorted.begin();
     int k = -1;
-    if (T == entry0[i]) k = 0;
+    if (pat == entry0[i]) k = 0;
     for (size_t c = 1; c < cand.size() && k < 0; c++)
-      if (i >= cand_from[c] && T == cand[c]) k = static_cast<int>(c);
-    if (k < 0) {  // a ring nobody has replayed this part from: a new candidate, a new round from here on
+      if (i >= cand_from[c] && pat == cand[c]) k = static_cast<int>(c);
+    if (k < 0) {  // a pattern nobody has replayed this part from: a new candidate, a new round from here on
       if (static_cast<int>(cand.size()) > kReplayMaxRounds) return ~0ull;
-      cand.push_back(T);
+      cand.push_back(pat);
       cand_from.push_back(i);
       exits.push_back(std::vector<Snap>(n_parts, Snap(slots, -1)));
       for (uint64_t j = i; j < n_parts; j++)
-        rj_replay_raw(G, t, n, part_start(j), T.data(), part_start(j), part_stop(j), ring_fn, static_cast<int64_t*>(nullptr),
-                      exits.back()[j].data(), static_cast<uint64_t*>(nullptr));
+        rj_replay_raw(G, t, n, part_start(j), pat.data(), part_start(j), part_stop(j), ring_fn, static_cast<int64_t*>(nullptr),
+                      exits.back()[j].data(), static_cast<uint64_t*>(nullptr), static_cast<const int64_t*>(nullptr), scratch.data());
       (*fixed)++;
       continue;
     }
     chosen[i] = k;
-    T = exits[static_cast<size_t>(k)][i];
+    true_starts[i] = sorted;
+    const int64_t c0 = static_cast<int64_t>(part_start(i)), cnt = static_cast<int64_t>(sorted.size());
+    const Snap& x = exits[static_cast<size_t>(k)][i];
+    for (size_t q = 0; q < slots; q++) T[q] = x[q] < 0 ? -1 : x[q] < c0 ? sorted[static_cast<size_t>(x[q] - (c0 - cnt))] : x[q];
     i++;
   }
   uint64_t out_n = 0;
@@ -229,10 +243,11 @@ static uint64_t replay_segment_speculatively(const DevGraph& G, const uint8_t* t
   std::vector<uint64_t> min_begin(n_parts, ~0ull);
   for (uint64_t i = 0; i < n_parts; i++) {  // (in parallel on the device; then the sink, in order)
     const int k = chosen[i];
+    const int64_t* ts = true_starts[i].empty() ? nullptr : true_starts[i].data();
     const uint64_t m = k == 0 ? rj_replay_raw(G, t, n, warm_start(i), static_cast<const int64_t*>(nullptr), part_start(i), part_stop(i), ring_fn,
-                                              static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr), raw.data())
+                                              static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr), raw.data(), ts, scratch.data())
                               : rj_replay_raw(G, t, n, part_start(i), cand[static_cast<size_t>(k)].data(), part_start(i), part_stop(i), ring_fn,
-                                              static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr), raw.data());
+                                              static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr), raw.data(), ts, scratch.data());
     if (!local_sink) {
       for (uint64_t j = 0; j < m; j++) out_n = rj_sink_append(out, out_n, static_cast<int64_t>(raw[2 * j]), static_cast<int64_t>(raw[2 * j + 1]));
       continue;

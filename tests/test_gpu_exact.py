@@ -77,18 +77,23 @@ def test_carry_scan_then_replay(rj, oracle, monkeypatch):
         assert st["linear_path"] == 1 and st["exact_path"] == 1, (rx, st)
 
 
-def test_stretch_too_long_to_replay_keeps_documented_semantics(rj, oracle):
+def test_thread_that_lives_for_megabytes_is_replayed_in_parts(rj, oracle):
+    """`[xy]+z[xy]` inside 20 MiB of x: ONE thread holds the loop's slot from the first byte to the last, the match begins
+    megabytes before it ends.  Until round 4 such a stretch was not replayed (more than 16 MiB without a synchronisation
+    point).  The parts only need the ring's ORDER PATTERN at their cuts (exact_replay.h): the old thread holds its slot in a
+    part's warm-up just as in the true run, under another start, and the walk puts the true one back."""
     import torch
     n = 20 << 20
     t = np.full(n, ord("x"), dtype=np.uint8)
     t[n - 6:] = np.frombuffer(b"zx xzy", dtype=np.uint8)
-    want = oracle_spans_np(oracle, b"[xy]+z[xy]", t)     # (reference == documented semantics on this text)
-    assert len(want) == 2
+    t[5 << 20] = ord("z")                                  # (and one in the middle: [0, 5 MiB + 2), then a second long run)
+    want = oracle_spans_np(oracle, b"[xy]+z[xy]", t)
+    assert len(want) == 3 and want[0][0] == 0 and want[0][1] == (5 << 20) + 2
     d = torch.from_numpy(t).cuda()
     scan = rj.Scan(rj.Program(b"[xy]+z[xy]"))
     cnt = scan.run_tensor(d)
-    assert cnt == len(want) and np.array_equal(gpu_spans_np(rj, scan), want)
-    assert scan.stats()["exact_path"] == 0
+    assert cnt == len(want) and np.array_equal(gpu_spans_np(rj, scan), want), scan.stats()
+    assert scan.stats()["exact_path"] == 2
 
 
 def test_several_batches_72mib(rj, oracle):
