@@ -214,6 +214,15 @@ def test_long_segments_speculate_and_verify(ce):
             got, _ = spec(rx, tx, 32, 8, lo, len(tx) + 1)
             whole, _ = exact(ce, rx, tx, 4096, lo, len(tx) + 1)
             assert got == whole, (rx, lo)
+    # a thread that lives for thousands of bytes (the match begins long before the part that reports it): the parts only need
+    # the ring's ORDER PATTERN -- no further rounds with a warm-up, a few without, never given up
+    for rx, tx in ((b"[xy]+z[xy]", b"x" * 5000 + b"zx xzy" + b"y" * 3000 + b"zy"), (b"[a-f]+[0-9][a-f]", b"abc" * 2000 + b"1cd2e"),
+                   (b"(ab|ba)+", b"ab" * 4000 + b"c" + b"ba" * 10)):
+        want = oracle.match_all(rx, tx)
+        for sub, warm in ((16, 0), (64, 8), (257, 32)):
+            got, fixed = spec(rx, tx, sub, warm)
+            assert got == want and fixed < 6, (rx, sub, warm, fixed)
+            assert warm == 0 or fixed <= 1, (rx, sub, warm, fixed)
     # patterns that match the empty string: the sink's filter looks at the entry before, which may belong to another part --
     # the join decides it for a part's first entry (xr_join); tiny parts put nearly every decision there
     for rx in (b".{0,2}", b"(a|ab)?(c|bcd)?", b"x*y?", b"[ab]{0,2}", b"(ab|b)*", b"a?$", b"^b?", b".{0,3}d?"):
