@@ -918,10 +918,23 @@ def literal_and_complex_extras(args, c, out):
         out["exact_replay_long"] = {"workload": "`.{0,2}.` (at risk of the reference's ring artefact) MatchAll over %d bytes without a line break: one segment of the exact replay, in parts" % nx,
                                     "seconds": round(sorted(xs)[1], 4), "matches": int(kx), "exact_path": sx.stats()["exact_path"],
                                     "matches_tile_the_text": tiles}
-        del tx, sx, spans_x
+        # ... and a thread that lives for megabytes: `[xy]+z[xy]` inside 63 MiB of x (one match from 0 to the z in the middle)
+        ty = torch.full((nx + 16,), ord("x"), dtype=torch.uint8, device=dev)
+        ty[nx // 2] = ord("z")
+        ty[nx - 6:nx] = torch.tensor(list(b"zx xzy"), dtype=torch.uint8, device=dev)
+        sy = rejit_amd.Scan(rejit_amd.Program("[xy]+z[xy]"))
+        sy.run(ty.data_ptr(), nx, stream=c.stream)
+        t0y = time.perf_counter()
+        ky = sy.run(ty.data_ptr(), nx, stream=c.stream)
+        dty = time.perf_counter() - t0y
+        first_y = sy.spans()[0] if ky else None
+        out["exact_replay_long"]["long_lived_thread"] = {"workload": "`[xy]+z[xy]` inside %d bytes of x, a z in the middle" % nx, "seconds": round(dty, 4),
+                                                         "matches": int(ky), "exact_path": sy.stats()["exact_path"],
+                                                         "first_match_is_the_whole_first_half": first_y == (0, nx // 2 + 2)}
+        del tx, sx, spans_x, ty, sy
         torch.cuda.empty_cache()
     except Exception as e:  # noqa: BLE001  (an extra must not take the line down)
-        out["exact_replay_long"] = {"error": repr(e)[:300]}
+        out.setdefault("exact_replay_long", {})["error"] = repr(e)[:300]
 
     if not args.no_big:
         # the north star's target run: the fast-forward scan over a 50 GB synthetic text on ONE GPU
