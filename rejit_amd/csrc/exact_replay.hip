@@ -480,8 +480,12 @@ int run_exact_nq(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
           // [kReplayMaxRounds + 1][n_parts][slots] | pattern scratch [lanes][2 slots]
           const int blocks = static_cast<int>(std::min<uint64_t>((n_parts + kReplayLanes - 1) / kReplayLanes, static_cast<uint64_t>(replay_blocks)));
           const size_t lanes = static_cast<size_t>(blocks) * kReplayLanes;
-          RJ_HIP(s->xr_snaps.reserve((static_cast<size_t>(kReplayMaxRounds) + 3 + (static_cast<size_t>(kReplayMaxRounds) + 3) * n_parts + 2 * lanes) * ring_bytes));
-          RJ_HIP(s->xr_raw_n.reserve(n_parts * 2 * sizeof(uint32_t)));
+          // (a wide ring over a gigabyte asks for tens of GB here: no room means "not replayed", not an error)
+          if (s->xr_snaps.reserve((static_cast<size_t>(kReplayMaxRounds) + 3 + (static_cast<size_t>(kReplayMaxRounds) + 3) * n_parts + 2 * lanes) * ring_bytes) != hipSuccess ||
+              s->xr_raw_n.reserve(n_parts * 2 * sizeof(uint32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+          }
           int64_t* cands = s->xr_snaps.as<int64_t>();
           int64_t* walk_ring = cands + static_cast<size_t>(kReplayMaxRounds + 1) * slots;
           int64_t* walk_pat = walk_ring + slots;
