@@ -422,7 +422,11 @@ int run_exact_nq(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     RJ_HIP(s->xr_seg_end.reserve(cap_chunks * sizeof(uint64_t)));
     RJ_HIP(s->xr_offs.reserve(cap_chunks * sizeof(uint64_t)));
     RJ_HIP(s->xr_counts.reserve(cap_chunks * sizeof(uint32_t)));
-    RJ_HIP(s->xr_scratch.reserve((cap_chunks * kChunk + 1) * 2 * sizeof(uint64_t)));
+    if (s->xr_scratch.reserve((cap_chunks * kChunk + 1) * 2 * sizeof(uint64_t)) != hipSuccess) {
+      (void)hipGetLastError();
+      if (batch_chunks > kBatchChunks) return 0;  // (a grown batch: 16 bytes of scratch per text byte did not fit -- not replayed)
+      return rj_fail(RJ_DEVICE_ERROR, "exact replay: out of device memory");
+    }
     const int replay_blocks = static_cast<int>(std::min<uint64_t>((cap_chunks + kReplayLanes - 1) / kReplayLanes, 2048));
     if (!lds) RJ_HIP(s->ring.reserve(static_cast<size_t>(replay_blocks) * kReplayLanes * slots * sizeof(int64_t)));
     bool grow_batch = false;
