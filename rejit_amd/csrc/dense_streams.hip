@@ -37,7 +37,7 @@ namespace {
 constexpr int kWave = 64;
 constexpr uint64_t kIter = 2048;                    // bytes per wave iteration: 64 lanes x 32
 constexpr int kTileIters = 16;
-constexpr uint64_t kTile = kIter * kTileIters;      // 32 KiB: a wave's unit of look-back
+constexpr uint64_t kTile = kIter * kTileIters;      // 32 KiB: a wave's tile (four of them are a unit of the prefix scan)
 constexpr uint32_t kStage = 640;                    // staged pairs per wave and stage (two stages: 20 KiB per workgroup)
 constexpr uint32_t kLenBits = 17;                   // staged entry: begin - tile start (15 bits) << 17 | length
 constexpr int kTilesPerTicket = 4;

@@ -34,7 +34,7 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr uint64_t kChunk = 1024;
-constexpr int kTileChunks = 32;                        // chunks per tile (a wave's unit of look-back)
+constexpr int kTileChunks = 32;                        // chunks per tile (four tiles, one per wave, are a unit of the prefix scan)
 constexpr uint64_t kTile = kChunk * kTileChunks;       // 32 KiB
 constexpr int kDepth = 8;                              // chunk loads in flight per wave
 

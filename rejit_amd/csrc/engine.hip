@@ -429,7 +429,7 @@ WindowSet make_window_set(const rj_program* rp) {
 
 // Assertion-only patterns (`^`, `$`: the line table of a grep-like caller) from the beginning of a selection: every
 // position in a matching context is a match, so the result is written once, in place (emit_scan.hip).
-// 1 = done, 0 = not applicable / look-back timed out (the caller takes the dense kernel), < 0 = error.
+// 1 = done, 0 = not applicable / the prefix scan timed out (the caller takes the dense kernel), < 0 = error.
 static int run_assertions(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, hipStream_t st) {
   const DevProgram& D = s->prog->dev;
   static const bool off = getenv("RJ_NO_EMIT") != nullptr;  // measurement override

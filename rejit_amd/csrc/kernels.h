@@ -186,9 +186,9 @@ struct PlaneParams {
 void launch_plane_scan(const PlaneParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 
 // Dense mode as bit streams (dense_streams.h / dense_streams.hip): patterns whose candidates cannot overlap, one pass, the
-// pairs written once at their final place (tiles of 32 KiB, decoupled look-back).  counters[kCntFinal] = the number of
+// pairs written once at their final place (tiles of 32 KiB, the prefix scan of tile_lookback.h).  counters[kCntFinal] = the number of
 // matches (also beyond out_cap: the host grows `out` and runs again); counters[kCntOverrun] = 1: a walk beyond max_walk
-// or a look-back time-out, the run is void; counters[kCntSlowStarts] = starts that took the scalar walk.
+// or a time-out of the prefix scan, the run is void; counters[kCntSlowStarts] = starts that took the scalar walk.
 struct StreamParams {
   const uint8_t* text;   // 16-byte aligned
   uint64_t n;
@@ -226,9 +226,9 @@ void launch_scan_dense_walk(const ScanParams& a, const DevProgram& P, int grid, 
                             unsigned long long* counters, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 void launch_scan_dense(const ScanParams& a, const DevProgram& P, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 // assertion-only patterns (n_pos == 0) in one pass, the pairs written once at their final place through a decoupled
-// look-back over 32-KiB tiles (emit_scan.hip).  scratch: emit_scratch_bytes(sb, se) bytes (zeroed by the launcher).
+// prefix scan over 32-KiB tiles (emit_scan.hip, tile_lookback.h).  scratch: emit_scratch_bytes(sb, se) bytes (zeroed by the launcher).
 // counters[kCntFinal] (and host_counters, pinned, when given) = the number of matches, also when it exceeds out_cap;
-// [kCntOverrun] = 1 when a look-back timed out (the caller takes the dense kernel instead).
+// [kCntOverrun] = 1 when the prefix scan timed out (the caller takes the dense kernel instead).
 uint64_t emit_tiles(uint64_t sb, uint64_t se);
 size_t emit_scratch_bytes(uint64_t sb, uint64_t se);
 void launch_emit_assertions(const uint8_t* text, uint64_t n, uint64_t sb, uint64_t se, uint32_t nullable, unsigned long long* scratch,
