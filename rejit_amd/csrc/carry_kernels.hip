@@ -121,8 +121,8 @@ __global__ __launch_bounds__(64) void cs_group_compose_kernel(int P, int W, uint
 __global__ __launch_bounds__(64) void cs_resolve_kernel(int P, int W, uint64_t m, uint64_t* vals, const uint32_t* mats) {
   const int np = P > 0 ? P : 1;
   const int lane = threadIdx.x;
-  __shared__ uint64_t dn[256];
-  for (int k = lane; k < 256; k += kCsWave) dn[k] = 0;
+  __shared__ uint64_t dn[1024];
+  for (int k = lane; k < 1024; k += kCsWave) dn[k] = 0;
   __syncthreads();
   for (uint64_t i = m; i-- > 0;) {
     uint64_t* D = vals + i * np;
@@ -249,7 +249,10 @@ __global__ __launch_bounds__(256) void cs_take_kernel(uint64_t* E, uint64_t* G, 
 }
 
 // ------------------------------------------------------------------------------------- launchers
-int cs_state_words(const DevProgram& R) { return R.n_words <= 1 ? 1 : R.n_words <= 2 ? 2 : R.n_words <= 4 ? 4 : R.n_words <= 8 ? 8 : 0; }
+// (round 4: up to 1024 positions -- 256 before, which left cyclic automata wider than that with RJ_TOO_LARGE at match time)
+int cs_state_words(const DevProgram& R) {
+  return R.n_words <= 1 ? 1 : R.n_words <= 2 ? 2 : R.n_words <= 4 ? 4 : R.n_words <= 8 ? 8 : R.n_words <= 16 ? 16 : R.n_words <= 32 ? 32 : 0;
+}
 
 namespace {
 struct CsLaunch {
@@ -289,7 +292,9 @@ void launch_cs_summarize(const DevProgram& R, const uint8_t* text, uint64_t n, u
     case 1: if (L.lds_state) RJ_CS_SUM(1, true); else RJ_CS_SUM(1, false); break;
     case 2: RJ_CS_SUM(2, false); break;
     case 4: RJ_CS_SUM(4, false); break;
-    default: RJ_CS_SUM(8, false); break;
+    case 8: RJ_CS_SUM(8, false); break;
+    case 16: RJ_CS_SUM(16, false); break;
+    default: RJ_CS_SUM(32, false); break;
   }
 #undef RJ_CS_SUM
 }
@@ -327,7 +332,9 @@ void launch_cs_emit(const DevProgram& R, const uint8_t* text, uint64_t n, uint64
     case 1: if (L.lds_state) RJ_CS_EMIT(1, true); else RJ_CS_EMIT(1, false); break;
     case 2: RJ_CS_EMIT(2, false); break;
     case 4: RJ_CS_EMIT(4, false); break;
-    default: RJ_CS_EMIT(8, false); break;
+    case 8: RJ_CS_EMIT(8, false); break;
+    case 16: RJ_CS_EMIT(16, false); break;
+    default: RJ_CS_EMIT(32, false); break;
   }
 #undef RJ_CS_EMIT
 }

@@ -406,7 +406,7 @@ void launch_compact_kept(const uint64_t* keys, const uint64_t* vals, const uint6
 // ---- the linear-time carry scan (carry_kernels.hip, carry_scan.h).  R = the REVERSE automaton.
 // A run covers the sub-chunks [a0 + i*sub, ..), i < m, up to the end of the text; the first m_own of
 // them hold the starts [sb, se).  vals [m][P] uint64 (summaries, resolved in place), mats [m][P*W].
-int cs_state_words(const DevProgram& R);                       // 1, 2, 4, 8; 0 = automaton too wide
+int cs_state_words(const DevProgram& R);                       // 1, 2, 4, 8, 16, 32; 0 = automaton too wide (> 1024 positions)
 size_t cs_scratch_bytes(const DevProgram& R, uint64_t lanes);  // global slab for the lanes' private state
 void launch_cs_summarize(const DevProgram& R, const uint8_t* text, uint64_t n, uint64_t a0, uint64_t sub, uint64_t m, uint64_t* vals,
                          uint32_t* mats, uint8_t* scratch, hipStream_t st);

@@ -32,7 +32,7 @@ int run_linear(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint6
   const DevProgram& R = rp->rev;
   if (!linear_path_fits(rp))
     return rj_fail(RJ_TOO_LARGE, "a match candidate runs longer than the parallel verifier walks and the automaton (%d positions) "
-                                 "is wider than the linear-time path takes (256)", R.n_pos);
+                                 "is wider than the linear-time path takes (1024)", R.n_pos);
   if (se > n + 1) se = n + 1;
   s->result_count = 0;
   s->stats.linear_path = 1;

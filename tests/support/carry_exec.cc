@@ -520,6 +520,8 @@ long ce_match_range(const char* re, const uint8_t* text, uint64_t n, uint64_t su
   if (P.n_words <= 2) return run<2>(P, R, text, n, sub, sb, se, carry_cur, carry_prev_end, have_prev, out, cap);
   if (P.n_words <= 4) return run<4>(P, R, text, n, sub, sb, se, carry_cur, carry_prev_end, have_prev, out, cap);
   if (P.n_words <= 8) return run<8>(P, R, text, n, sub, sb, se, carry_cur, carry_prev_end, have_prev, out, cap);
+  if (P.n_words <= 16) return run<16>(P, R, text, n, sub, sb, se, carry_cur, carry_prev_end, have_prev, out, cap);
+  if (P.n_words <= 32) return run<32>(P, R, text, n, sub, sb, se, carry_cur, carry_prev_end, have_prev, out, cap);
   return -9;
 }
 

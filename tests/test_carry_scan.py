@@ -118,6 +118,25 @@ def test_wide_automata(ce):
             assert carry(ce, rx, tx, sub) == want, (rx, sub)
 
 
+def test_automata_of_up_to_1024_positions(ce):
+    """More than 256 positions (16 and 32 state words; round 4 -- until then the one RJ_TOO_LARGE reachable at match time): cyclic
+    automata whose candidates live for the whole text."""
+    oracle = Oracle()
+    rng = random.Random(9)
+    words = ["".join(rng.choice("abcd") for _ in range(rng.randint(6, 10))) for _ in range(40)]
+    more = ["".join(rng.choice("abcd") for _ in range(rng.randint(7, 9))) for _ in range(110)]
+    for ws, lo, hi in ((words, 256, 512), (more, 512, 1024)):
+        rx = ("(" + "|".join(ws) + ")+").encode()
+        tx = "".join(rng.choice(ws) for _ in range(60)).encode() + b"x" + "".join(rng.choice(ws) for _ in range(25)).encode() + b"ab"
+        want = oracle.match_all_spec(rx, tx)
+        assert not isinstance(want, int) and len(want) >= 2 and want[0][1] - want[0][0] > 300
+        for sub in (7, 64, 4096):
+            got = carry(ce, rx, tx, sub)
+            assert got == want, (len(rx), sub)
+        cut = len(tx) // 2
+        assert carry(ce, rx, tx, 32, 0, cut) == [m for m in want if m[0] < cut]
+
+
 def test_behind_walk_device_code_vs_oracle(ce):
     """rejit_amd/csrc/behind_walk.h -- the per-hit procedure verify_behind_in_regions runs (forward check
     from the cut, reverse automaton to the left-most start, forward longest) -- compiled for the CPU:

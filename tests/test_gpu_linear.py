@@ -178,3 +178,25 @@ def test_fasta_500mb_runs(rj, rx):
     assert cnt == begins.numel() and cnt > 0
     assert torch.equal(got[:, 0], begins) and torch.equal(got[:, 1], ends)
     assert int((got[:, 1] - got[:, 0]).max()) > 200_000_000   # the 250 MB run is one match
+
+
+def test_wide_cyclic_automata_take_the_carry_scan(rj, oracle):
+    """`(w1|...|w40)+` and `(w1|...|w110)+` (330 and 900 positions) over a hundred kilobytes of their own words: one candidate lives for
+    the whole text.  Until round 4 this was the one RJ_TOO_LARGE reachable at match time (the carry scan took 256 positions);
+    it takes 1024 now (16 and 32 state words)."""
+    import torch
+    rng = random.Random(9)
+    for n_words, n_cat in ((40, 20_000), (110, 12_000)):
+        words = ["".join(rng.choice("abcd") for _ in range(rng.randint(6, 10))) for _ in range(n_words)]
+        rx = ("(" + "|".join(words) + ")+").encode()
+        p = rj.Program(rx)
+        assert p.info()["n_positions"] > 256
+        text = ("".join(rng.choice(words) for _ in range(n_cat)) + "x" + "".join(rng.choice(words) for _ in range(1000)) + "ab").encode()
+        t = np.frombuffer(text, dtype=np.uint8).copy()
+        want = oracle_spans_np(oracle, rx, t)
+        assert len(want) >= 2 and want[0][1] - want[0][0] > 90_000
+        d = torch.from_numpy(t).cuda()
+        scan = rj.Scan(p)
+        cnt = scan.run_tensor(d)
+        assert cnt == len(want) and np.array_equal(gpu_spans_np(rj, scan), want), (n_words, scan.stats())
+        assert scan.stats()["linear_path"] == 1, scan.stats()
