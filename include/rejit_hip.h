@@ -173,7 +173,7 @@ typedef struct rj_multi rj_multi;   /* like rj_scan: per caller, NOT thread-safe
 int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out);
 void rj_multi_destroy(rj_multi* multi);
 /* counts[i] = matches of pattern i over d_text[0..n).  Returns how the set was run: 1 = one fused scan
- * kernel for all patterns; 2 = one scan kernel per pattern queued back to back, then the verify /
+ * kernel for all patterns; 3 = scan + classification + counting in one kernel (rj_multi_set_counts_only); 2 = one scan kernel per pattern queued back to back, then the verify /
  * gather tails of all patterns in two launches and a single synchronise (any set of fixed-window
  * patterns); 0 = one complete pipeline after the other; <0 = rj_status */
 int rj_multi_run(rj_multi* multi, const void* d_text, uint64_t n, uint64_t* counts, void* hip_stream);
@@ -200,6 +200,18 @@ int rj_multi_order_after(rj_multi* multi, rj_multi* before);
  * stream -- in order, no cross-stream wait between them -- while each run's tails execute under the next scan.
  * rj_multi_finish is unchanged (it waits for the run's last kernel, wherever it is).  Not with mode 2. */
 int rj_multi_set_tail_stream(rj_multi* multi, int on);
+/* on != 0: the caller wants COUNTS -- what Regej::MatchAllCount answers (reference src/rejit.cc:203-208; regexdna asks
+ * nothing else of its nine patterns, sample/regexdna.cc:65).  For the pattern sets the one-pass scan takes AND whose
+ * patterns all match exactly 8 bytes within one byte of the scan's base windows (k-mers with one degenerate position,
+ * both strands: regexdna's nine) rj_multi_run / _run_range / _start + _finish then run ONE kernel (plane_count.hip): the
+ * text once, every candidate's eight bytes looked up in a table, nothing written but the counts.  Their return value is
+ * 3 for such a run.  Afterwards counts[] and rj_multi_bounds / _bounds_device / rj_multi_device_counts work as ever;
+ * rj_scan_device_spans(rj_multi_scan(m, i)) is NULL (no span list was made).  Exactness: the counts are those of the
+ * left-most-longest, non-overlapping selection; a text on which that differs from the number of matching positions (two
+ * matches of ONE pattern fewer than 8 bytes apart) makes the kernel void its run, and the call -- and every later one on
+ * this object -- is answered by the span pipeline (return value 1).  Any other pattern set ignores the switch.
+ * Returns 1 when runs will take the one-kernel path, 0 when the set does not have the shape, < 0 rj_status. */
+int rj_multi_set_counts_only(rj_multi* multi, int on);
 /* rj_scan_set_timing for every pattern of the object (rj_multi_scan_ms reads 0 when off). */
 int rj_multi_set_timing(rj_multi* multi, int on);
 rj_scan* rj_multi_scan(rj_multi* multi, int i);

@@ -8,8 +8,8 @@ from typing import List, Optional, Tuple
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-SOURCES = ["kernels.hip", "plane_scan.hip", "emit_scan.hip", "dense_streams.hip", "verify_lds.hip", "carry_kernels.hip", "engine.hip", "multi_pattern.hip", "host_api.hip", "linear.hip", "exact_replay.hip", "multi_device.hip", "parser.cc", "lowering.cc", "rejit_api.cc"]
-HEADERS = ["kernels.h", "device_program.h", "lowering.h", "carry_scan.h", "behind_walk.h", "exact_replay.h", "engine_internal.h", "table_layout.h", "lds_walk.h", "trace_stamp.h", "dense_swar.h", "dense_streams.h", "tile_lookback.h"]
+SOURCES = ["kernels.hip", "plane_scan.hip", "plane_count.hip", "emit_scan.hip", "dense_streams.hip", "verify_lds.hip", "carry_kernels.hip", "engine.hip", "multi_pattern.hip", "host_api.hip", "linear.hip", "exact_replay.hip", "multi_device.hip", "parser.cc", "lowering.cc", "rejit_api.cc"]
+HEADERS = ["kernels.h", "device_program.h", "lowering.h", "carry_scan.h", "behind_walk.h", "exact_replay.h", "engine_internal.h", "table_layout.h", "lds_walk.h", "trace_stamp.h", "dense_swar.h", "dense_streams.h", "tile_lookback.h", "exact_count.h"]
 LIB = os.path.join(PKG, "librejit_hip.so")
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -80,12 +80,34 @@ def _build_locked(verbose: bool) -> str:
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread"]
 
+    # an object is kept when it was compiled from this very source and these very headers (content hash beside it):
+    # kernels.hip alone takes about a minute, a change to one file should cost that file
+    import hashlib
+    hh = hashlib.sha256(" ".join(flags).encode())
+    for f in HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            hh.update(fh.read())
+    for f in ("rejit.h", "rejit_hip.h"):
+        with open(os.path.join(PKG, "..", "include", f), "rb") as fh:
+            hh.update(fh.read())
+    headers_hash = hh.hexdigest()
+
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        with open(os.path.join(CSRC, src), "rb") as fh:
+            want = hashlib.sha256(headers_hash.encode() + fh.read()).hexdigest()
+        stamp = obj + ".srchash"
+        try:
+            if os.path.exists(obj) and open(stamp).read().strip() == want:
+                return obj
+        except OSError:
+            pass
         cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        with open(stamp, "w") as fh:
+            fh.write(want + "\n")
         return obj
 
     from concurrent.futures import ThreadPoolExecutor
@@ -133,7 +155,7 @@ C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_er
                  "rj_multi_bounds", "rj_batch_separator", "rj_match_all_packed", "rj_host_alloc", "rj_host_free",
                  "rj_multi_bounds_device", "rj_carry_decide", "rj_multi_start", "rj_multi_finish", "rj_multi_order_after",
                  "rj_multi_device_counts", "rj_multi_device_counts_via", "rj_multi_set_tail_stream", "rj_multi_set_timing", "rj_scan_set_timing", "rj_set_default_timing",
-                 "rj_scan_gather_spans", "rj_scan_gather_spans_via", "rj_scan_gathered_spans"]
+                 "rj_scan_gather_spans", "rj_scan_gather_spans_via", "rj_scan_gathered_spans", "rj_multi_set_counts_only"]
 
 
 def load_library():
@@ -180,6 +202,7 @@ def load_library():
     L.rj_multi_set_mode.argtypes = [vp, ctypes.c_int]
     L.rj_multi_set_tail_stream.argtypes = [vp, ctypes.c_int]
     L.rj_multi_set_timing.argtypes = [vp, ctypes.c_int]
+    L.rj_multi_set_counts_only.argtypes = [vp, ctypes.c_int]
     L.rj_scan_set_timing.argtypes = [vp, ctypes.c_int]
     L.rj_set_default_timing.argtypes = [ctypes.c_int]
     L.rj_set_default_timing(1)   # bench.py, the tests and the tools read scan_ms: the scan kernel's start event is on for them
@@ -504,6 +527,11 @@ class MultiScan:
     def set_tail_stream(self, on: bool = True) -> None:
         """start() queues only the scan kernel on the caller's stream, the tails on a stream of the object's own."""
         _check(self._lib.rj_multi_set_tail_stream(self._h, int(on)))
+
+    def set_counts_only(self, on: bool = True) -> bool:
+        """rj_multi_set_counts_only: MatchAllCount semantics -- counts (and bounds) only, no span lists; True when the
+        pattern set takes the one-kernel path (plane_count.hip)."""
+        return bool(_check(self._lib.rj_multi_set_counts_only(self._h, int(on))))
 
     def set_timing(self, on: bool = True) -> None:
         """rj_multi_set_timing: without the scan kernel's start event scan_ms() reads 0 and consecutive kernels follow closer."""

@@ -185,6 +185,41 @@ struct PlaneParams {
 };
 void launch_plane_scan(const PlaneParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 
+// ---- plane count (plane_count.hip, exact_count.h): the same scan for callers that want COUNTS (MatchAllCount,
+// reference src/rejit.cc:203-208), scan + exact classification + counting in ONE kernel.  The caller zeroes `acc`
+// once (kPcAccWords words); a run leaves its results in `host_out` (pinned, kPcHostWords words) and a device copy in `acc`.
+enum { kPcConflict = 1,   // two matches of one pattern fewer than 8 bytes apart (the count needs the selection): run void
+       kPcVoid = 2 };     // a 2-KiB block held more candidates than a wave's ring: run void
+constexpr uint32_t kPcBounds = 0;                      // acc: [32][2] first / last match begin of the last run (device copy)
+constexpr uint32_t kPcTotals = kPcBounds + 64;         // [32]: the last run's counts (device copy)
+constexpr uint32_t kPcAccWords = kPcTotals + 32;
+constexpr uint32_t kPcHostCount = 0, kPcHostFlags = 32, kPcHostBounds = 40, kPcHostWords = 40 + 64;
+constexpr unsigned long long kPcNone = ~0ull, kPcUnknown = ~0ull - 1;   // bounds: no match / matches, but none in an edge wave's span
+struct PlaneCountParams {
+  const uint8_t* text;   // 16-byte aligned
+  uint64_t n;
+  uint64_t sb, se;       // match begins [sb, se)
+  uint64_t first_block, end_block;   // the 2-KiB blocks that hold their window positions
+  uint64_t span_blocks;  // wave w owns span_blocks blocks, the first span_extra waves one more, one after the other from first_block
+  uint32_t span_extra;
+  uint32_t code_shift, n_bases, n_patterns;
+  uint32_t edge_waves;   // the first and the last edge_waves waves of the grid record their first / last match per pattern
+  uint32_t debug;        // measurement only (RJ_COUNT_DEBUG): 1 no ticket / device atomics, 2 no classification, 4 no push
+  uint32_t lo[2][8], hi[2][8];       // as PlaneParams
+  uint32_t base_lo[2], base_hi[2];   // the bases' 8 bytes (ExactCountPlan)
+  const uint32_t* table;             // ExactCountPlan::table in device memory
+  unsigned long long* acc;
+  uint32_t* wg_rows;                 // [grid][32]: every workgroup's counts (slot 31: its flags)
+  unsigned long long* host_out;
+  unsigned long long* edge_rows;     // [2 * edge_waves][32][4]: count, first begin, last begin
+};
+void launch_plane_count(const PlaneCountParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
+// the rows of that launch (grid workgroups) added up: counts, flags, bounds -> a.host_out and a.acc
+void launch_plane_count_finish(const PlaneCountParams& a, int grid, hipStream_t st);
+// launch_bounds_rows after a counts run: a pattern without a list (spans[p] == nullptr) takes its count and first /
+// last match (8 bytes long) from the kernel's device copy in `acc`
+void launch_bounds_rows_counts(const BoundsParams& a, const unsigned long long* acc, int64_t offset, int first_round, int64_t* d_rows, hipStream_t st);
+
 // Dense mode as bit streams (dense_streams.h / dense_streams.hip): patterns whose candidates cannot overlap, one pass, the
 // pairs written once at their final place (tiles of 32 KiB, the prefix scan of tile_lookback.h).  counters[kCntFinal] = the number of
 // matches (also beyond out_cap: the host grows `out` and runs again); counters[kCntOverrun] = 1: a walk beyond max_walk

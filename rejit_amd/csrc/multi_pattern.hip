@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "engine_internal.h"
+#include "exact_count.h"
 
 using namespace rejit_amd;
 
@@ -301,6 +302,19 @@ struct rj_multi {
   // rj_multi_device_counts: this rank's rows [P][8] followed by every rank's [world][P][8]; the decision (pinned)
   DeviceBuffer exchange_rows;
   int64_t* host_decision = nullptr;
+  // rj_multi_set_counts_only: MatchAllCount in ONE kernel (plane_count.hip) for the sets exact_count.h takes
+  bool counts_only = false;
+  bool counts_off = false;     // a counts run was void (two matches of one pattern within 8 bytes, a block full of candidates): spans from now on
+  ExactCountPlan exact;
+  DeviceBuffer exact_table, count_acc, edge_rows, wg_rows;
+  unsigned long long* count_out = nullptr;   // pinned: counts, flags, first / last match begin per pattern
+  bool last_counts = false;    // the last run left counts (no span lists); the run's arguments, for a caller that then asks for more
+  struct LastRun {
+    const uint8_t* text = nullptr;
+    uint64_t n = 0, sb = 0, se = 0;
+    hipStream_t st = nullptr;
+  } last_run;
+  uint32_t counts_fallbacks = 0;
 
 };
 
@@ -819,6 +833,121 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
   return fail(RJ_DEVICE_ERROR, "hit regions kept overflowing");
 }
 
+
+constexpr uint32_t kEdgeWaves = 64;   // (<= 64: plane_count_finish reads a pattern's edge rows with one wave) waves at either end of the grid that record their first / last match (plane_count.hip)
+
+bool counts_path(const rj_multi* m) {
+  static const bool off = getenv("RJ_NO_COUNTS") != nullptr;  // measurement override
+  return m->counts_only && !m->counts_off && m->exact.ok && m->plane.ok && !m->plane.general && m->plane.offset == 0 && m->mode == 0 && !off;
+}
+
+// MatchAllCount of every pattern over the starts [sb, se) in one kernel.  phase as run_batched.  A void run (flags) is
+// repeated by the span pipeline, synchronously, and the object stays there.
+int run_counts(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, hipStream_t st, int phase) {
+  const int P = static_cast<int>(m->scans.size());
+  rj_scan* const s0 = m->scans[0];
+  if (phase != 2) {
+    const uint64_t last_w = n >= 8 ? n - 8 + 1 : 0;
+    const uint64_t wlo = sb, whi = std::min<uint64_t>(se, last_w);
+    const uint64_t first_block = wlo / 2048;
+    const uint64_t end_block = whi > wlo ? (whi + 2047) / 2048 : first_block;
+    const uint64_t blocks = end_block - first_block;
+    static const int plane_chunks = getenv("RJ_COUNT_CHUNKS") ? atoi(getenv("RJ_COUNT_CHUNKS")) : 96;  // measurement override
+    const ScanGeometry geo = scan_geometry(std::max<uint64_t>(blocks * 2, 1), static_cast<uint64_t>(plane_chunks > 0 ? plane_chunks : 96));
+    if (!m->count_out) {
+      RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&m->count_out), sizeof(unsigned long long) * kPcHostWords));
+      RJ_HIP(m->exact_table.reserve(sizeof(uint32_t) * kExactTabWords));
+      RJ_HIP(hipMemcpyAsync(m->exact_table.p, m->exact.table, sizeof(uint32_t) * kExactTabWords, hipMemcpyHostToDevice, st));
+      RJ_HIP(m->count_acc.reserve(sizeof(unsigned long long) * kPcAccWords));
+      RJ_HIP(hipMemsetAsync(m->count_acc.p, 0, sizeof(unsigned long long) * kPcAccWords, st));
+      RJ_HIP(m->edge_rows.reserve(sizeof(unsigned long long) * 2 * kEdgeWaves * kExactMaxPatterns * 4));
+      RJ_HIP(hipMemsetAsync(m->edge_rows.p, 0, sizeof(unsigned long long) * 2 * kEdgeWaves * kExactMaxPatterns * 4, st));
+    }
+    PlaneCountParams pc{};
+    pc.text = d_text;
+    pc.n = n;
+    pc.sb = sb;
+    pc.se = se;
+    pc.first_block = first_block;
+    pc.end_block = end_block;
+    pc.span_blocks = blocks / geo.n_regions;
+    pc.span_extra = static_cast<uint32_t>(blocks % geo.n_regions);
+    pc.code_shift = m->plane.code_shift;
+    pc.n_bases = m->plane.n_bases;
+    pc.n_patterns = static_cast<uint32_t>(P);
+    pc.edge_waves = kEdgeWaves;
+    static const uint32_t count_debug = getenv("RJ_COUNT_DEBUG") ? static_cast<uint32_t>(atoi(getenv("RJ_COUNT_DEBUG"))) : 0u;  // measurement only
+    pc.debug = count_debug;
+    for (uint32_t b = 0; b < 2; b++) {
+      const uint32_t bb = b < m->plane.n_bases ? b : 0;
+      for (int i = 0; i < 8; i++) {
+        const uint32_t code = (static_cast<uint32_t>(m->plane.base[bb][i]) >> m->plane.code_shift) & 3u;
+        pc.lo[b][i] = (code & 1u) ? 0u : ~0u;
+        pc.hi[b][i] = (code & 2u) ? 0u : ~0u;
+      }
+      pc.base_lo[b] = m->exact.base_lo[bb];
+      pc.base_hi[b] = m->exact.base_hi[bb];
+    }
+    pc.table = m->exact_table.as<uint32_t>();
+    pc.acc = m->count_acc.as<unsigned long long>();
+    pc.host_out = m->count_out;
+    RJ_HIP(m->wg_rows.reserve(sizeof(uint32_t) * kExactMaxPatterns * static_cast<size_t>(geo.grid)));
+    pc.wg_rows = m->wg_rows.as<uint32_t>();
+    pc.edge_rows = m->edge_rows.as<unsigned long long>();
+    if (m->scan_after != nullptr && m->scan_after != m && m->scan_after->scans[0]->ev[2] != nullptr)
+      RJ_HIP(hipStreamWaitEvent(st, m->scan_after->scans[0]->ev[2], 0));
+    launch_plane_count(pc, geo.grid, s0->t0(), s0->ev[2], st);
+    // the rows added up: behind the scan, on the object's own stream when the caller keeps runs in flight (rj_multi_start):
+    // the caller's stream is free for the next scan kernel at once
+    hipStream_t fs = st;
+    if (phase == 1) {
+      if (!m->tail_stream) RJ_HIP(hipStreamCreateWithFlags(&m->tail_stream, hipStreamNonBlocking));
+      fs = m->tail_stream;
+      RJ_HIP(hipStreamWaitEvent(fs, s0->ev[2], 0));
+    }
+    launch_plane_count_finish(pc, geo.grid, fs);
+    m->last_run.text = d_text;
+    m->last_run.n = n;
+    m->last_run.sb = sb;
+    m->last_run.se = se;
+    m->last_run.st = st;
+    if (phase == 1) {
+      if (!m->pending.done) RJ_HIP(hipEventCreateWithFlags(&m->pending.done, hipEventDisableTiming));
+      RJ_HIP(hipEventRecord(m->pending.done, fs));
+      return RJ_OK;
+    }
+  }
+  if (phase == 2) RJ_HIP(hipEventSynchronize(m->pending.done));
+  else RJ_HIP(hipStreamSynchronize(st));
+  RJ_HIP(hipGetLastError());
+  if (m->count_out[kPcHostFlags] != 0) {
+    m->counts_off = true;
+    m->counts_fallbacks++;
+    m->last_counts = false;
+    return run_batched(m, d_text, n, sb, se, st, true, 0);
+  }
+  m->scan_ms = 0.f;
+  if (s0->timing) (void)hipEventElapsedTime(&m->scan_ms, s0->ev[1], s0->ev[2]);
+  for (int p = 0; p < P; p++) {
+    rj_scan* s = m->scans[static_cast<size_t>(p)];
+    s->stats = rj_stats{};
+    s->result = nullptr;   // (no span list: rj_scan_device_spans reads NULL)
+    s->result_count = m->count_out[kPcHostCount + p];
+    s->stats.n_matches = s->result_count;
+    s->stats.scan_ms = m->scan_ms;
+  }
+  m->last_counts = true;
+  return RJ_OK;
+}
+
+// after a counts run, for a caller that asks for what only the span pipeline leaves behind
+int spans_after_counts(rj_multi* m) {
+  if (!m->last_counts) return RJ_OK;
+  m->last_counts = false;
+  const rj_multi::LastRun& r = m->last_run;
+  return run_batched(m, r.text, r.n, r.sb, r.se, r.st, true, 0);
+}
+
 }  // namespace
 
 namespace {
@@ -875,6 +1004,12 @@ int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out)
     }
   }
   m->batchable = all_batchable && n_progs > 1;
+  if (m->fused && m->plane.ok && !m->plane.general && m->plane.offset == 0) {
+    // the set's shape for MatchAllCount in one kernel (exact_count.h); used when the caller asks: rj_multi_set_counts_only
+    std::vector<const Program*> hosts;
+    for (rj_scan* s : m->scans) hosts.push_back(s->prog->host.get());
+    make_exact_count_plan(hosts, m->plane.base, m->plane.n_bases, &m->exact);
+  }
   {
     std::lock_guard<std::mutex> lock(live_multi_mutex());
     live_multi().push_back(m.get());
@@ -898,6 +1033,7 @@ void rj_multi_destroy(rj_multi* m) {
   if (m->host_tails) (void)hipHostFree(m->host_tails);
   if (m->host_bounds) (void)hipHostFree(m->host_bounds);
   if (m->host_desc) (void)hipHostFree(m->host_desc);
+  if (m->count_out) (void)hipHostFree(m->count_out);
   if (m->second) (void)hipStreamDestroy(m->second);
   if (m->fork) (void)hipEventDestroy(m->fork);
   if (m->join) (void)hipEventDestroy(m->join);
@@ -925,7 +1061,12 @@ int rj_multi_run_range(rj_multi* m, const void* d_text, uint64_t n, uint64_t own
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   m->scan_ms = 0.f;
   int fused = 0;
-  if (m->fused && m->mode == 0 && n >= 16) {
+  m->last_counts = false;
+  if (m->fused && n >= 16 && counts_path(m)) {
+    int rc = run_counts(m, static_cast<const uint8_t*>(d_text), n, own_begin, own_end, st, 0);
+    if (rc != RJ_OK) return rc;
+    fused = m->last_counts ? 3 : 1;
+  } else if (m->fused && m->mode == 0 && n >= 16) {
     int rc = run_batched(m, static_cast<const uint8_t*>(d_text), n, own_begin, own_end, st, true);
     if (rc != RJ_OK) return rc;
     fused = 1;
@@ -956,9 +1097,13 @@ int rj_multi_start(rj_multi* m, const void* d_text, uint64_t n, uint64_t own_beg
   q.se = own_end;
   q.st = static_cast<hipStream_t>(hip_stream);
   m->scan_ms = 0.f;
-  q.kind = own_begin >= own_end ? -1 : (m->fused && m->mode == 0 && n >= 16) ? 1 : (m->batchable && n >= 16) ? 2 : 0;
+  q.kind = own_begin >= own_end ? -1 : (m->fused && n >= 16 && counts_path(m)) ? 3 : (m->fused && m->mode == 0 && n >= 16) ? 1 : (m->batchable && n >= 16) ? 2 : 0;
   q.fuse = q.kind == 1;
-  if (q.kind > 0) {
+  m->last_counts = false;
+  if (q.kind == 3) {
+    int rc = run_counts(m, q.text, n, q.sb, q.se, q.st, 1);
+    if (rc != RJ_OK) return rc;
+  } else if (q.kind > 0) {
     int rc = run_batched(m, q.text, n, q.sb, q.se, q.st, q.fuse, 1);
     if (rc != RJ_OK) return rc;
   }  // (kind 0: pattern sets that take one pipeline after the other run in rj_multi_finish)
@@ -976,7 +1121,11 @@ int rj_multi_finish(rj_multi* m, uint64_t* counts) {
     for (size_t i = 0; i < m->scans.size(); i++) counts[i] = 0;
     return 0;
   }
-  if (q.kind != 0) {
+  if (q.kind == 3) {
+    int rc = run_counts(m, q.text, q.n, q.sb, q.se, q.st, 2);
+    if (rc != RJ_OK) return rc;
+    if (!m->last_counts) q.kind = 1;   // (a void run: the span pipeline answered)
+  } else if (q.kind != 0) {
     int rc = run_batched(m, q.text, q.n, q.sb, q.se, q.st, q.fuse, 2);
     if (rc != RJ_OK) return rc;
   } else {
@@ -1009,16 +1158,42 @@ int rj_multi_bounds(rj_multi* m, uint64_t* bounds, void* hip_stream) {
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const int P = static_cast<int>(m->scans.size());
   if (!m->host_bounds) RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&m->host_bounds), sizeof(uint64_t) * 4 * kMaxFused));
-  BoundsParams bp{};
-  bp.n_lists = P;
-  for (int p = 0; p < P; p++) {
-    bp.spans[p] = m->scans[static_cast<size_t>(p)]->result;
-    bp.count[p] = bp.spans[p] ? m->scans[static_cast<size_t>(p)]->result_count : 0;
+  // a counts run: the kernel's last workgroup left every pattern's first / last match begin in pinned memory (all
+  // matches are 8 bytes long); a pattern re-run under a carry since (rj_scan_run on rj_multi_scan) has its own list
+  bool listed = !m->last_counts;
+  if (m->last_counts) {
+    bool unknown = false;
+    for (int p = 0; p < P; p++) {
+      if (m->scans[static_cast<size_t>(p)]->result) listed = true;
+      else if (m->count_out[kPcHostBounds + 2 * p] == kPcUnknown || m->count_out[kPcHostBounds + 2 * p + 1] == kPcUnknown) unknown = true;
+    }
+    if (unknown) {  // matches, but none in the spans of the grid's edge waves: the span pipeline
+      int rc = spans_after_counts(m);
+      if (rc != RJ_OK) return rc;
+      listed = true;
+    }
   }
-  launch_first_last(bp, m->host_bounds, st);
-  RJ_HIP(hipStreamSynchronize(st));
-  RJ_HIP(hipGetLastError());
-  memcpy(bounds, m->host_bounds, sizeof(uint64_t) * 4 * static_cast<size_t>(P));
+  if (listed) {
+    BoundsParams bp{};
+    bp.n_lists = P;
+    for (int p = 0; p < P; p++) {
+      bp.spans[p] = m->scans[static_cast<size_t>(p)]->result;
+      bp.count[p] = bp.spans[p] ? m->scans[static_cast<size_t>(p)]->result_count : 0;
+    }
+    launch_first_last(bp, m->host_bounds, st);
+    RJ_HIP(hipStreamSynchronize(st));
+    RJ_HIP(hipGetLastError());
+    memcpy(bounds, m->host_bounds, sizeof(uint64_t) * 4 * static_cast<size_t>(P));
+  }
+  if (m->last_counts)
+    for (int p = 0; p < P; p++) {
+      if (m->scans[static_cast<size_t>(p)]->result) continue;
+      const unsigned long long f = m->count_out[kPcHostBounds + 2 * p], l = m->count_out[kPcHostBounds + 2 * p + 1];
+      bounds[4 * p + 0] = f;
+      bounds[4 * p + 1] = f == kPcNone ? kPcNone : f + 8;
+      bounds[4 * p + 2] = l;
+      bounds[4 * p + 3] = l == kPcNone ? kPcNone : l + 8;
+    }
   return RJ_OK;
 }
 
@@ -1026,13 +1201,23 @@ int rj_multi_bounds_device(rj_multi* m, int64_t offset, int first_round, int64_t
   ErrnoGuard errno_guard;
   if (!m || !d_rows) return fail(RJ_BAD_ARGUMENT, "null argument");
   const int P = static_cast<int>(m->scans.size());
+  if (m->last_counts)
+    for (int p = 0; p < P; p++)
+      if (!m->scans[static_cast<size_t>(p)]->result &&
+          (m->count_out[kPcHostBounds + 2 * p] == kPcUnknown || m->count_out[kPcHostBounds + 2 * p + 1] == kPcUnknown)) {
+        int rc = spans_after_counts(m);   // (matches, but none in the spans of the grid's edge waves)
+        if (rc != RJ_OK) return rc;
+        break;
+      }
   BoundsParams bp{};
   bp.n_lists = P;
   for (int p = 0; p < P; p++) {
     bp.spans[p] = m->scans[static_cast<size_t>(p)]->result;
     bp.count[p] = bp.spans[p] ? m->scans[static_cast<size_t>(p)]->result_count : 0;
   }
-  launch_bounds_rows(bp, offset, first_round, d_rows, static_cast<hipStream_t>(hip_stream));
+  // (after a counts run the patterns without a list take count and bounds from the kernel's device copy)
+  if (m->last_counts) launch_bounds_rows_counts(bp, m->count_acc.as<unsigned long long>(), offset, first_round, d_rows, static_cast<hipStream_t>(hip_stream));
+  else launch_bounds_rows(bp, offset, first_round, d_rows, static_cast<hipStream_t>(hip_stream));
   RJ_HIP(hipGetLastError());
   return RJ_OK;
 }
@@ -1267,6 +1452,15 @@ int rj_multi_set_timing(rj_multi* m, int on) {
   if (!m) return fail(RJ_BAD_ARGUMENT, "null argument");
   for (rj_scan* s : m->scans) s->timing = on != 0;
   return RJ_OK;
+}
+
+int rj_multi_set_counts_only(rj_multi* m, int on) {
+  ErrnoGuard errno_guard;
+  if (!m) return fail(RJ_BAD_ARGUMENT, "null argument");
+  if (m->pending.active) return fail(RJ_BAD_ARGUMENT, "rj_multi_set_counts_only: a run is in flight");
+  m->counts_only = on != 0;
+  if (on) m->counts_off = false;
+  return (m->counts_only && m->exact.ok && m->plane.ok && !m->plane.general && m->plane.offset == 0) ? 1 : 0;
 }
 
 int rj_multi_set_mode(rj_multi* m, int mode) {

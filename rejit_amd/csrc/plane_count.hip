@@ -1,0 +1,548 @@
+// rejit_amd/csrc/plane_count.hip -- MatchAllCount for SEVERAL patterns in ONE kernel: the nine counts of regexdna
+// (reference sample/regexdna.cc:51-67: one MatchAllCount per pattern, src/rejit.cc:203-208, each a run of
+// FastForwardGen's multi-literal scan, src/x64/codegen-x64.cc:1102-1252, plus the NFA loop on its hits).
+//
+// Round 5.  The span pipeline answers the same question with three kernels -- plane_scan (the text, once),
+// classify_shared_multi (an automaton walk per candidate), offsets_gather_check_multi (the (begin, end) lists laid
+// out) -- and 44 % of its step was the two tails.  A caller that asks for COUNTS needs neither the lists nor, for
+// the pattern sets this kernel takes (exact_count.h: fixed-length 8-byte patterns whose language lies within one byte
+// of the scan's base windows), the automaton: a candidate's eight bytes are looked up in a table.  So here a wave
+//   * streams its span of the text through the bit-plane test of plane_scan.hip, re-laid out so that a lane owns 32
+//     CONTIGUOUS bytes (two 16-byte loads; bit 2k of a plane = byte k, bit 2k + 1 = byte 16 + k): the 8 positions
+//     that follow a lane's first half are its own second half, those that follow the second half are the next lane's
+//     first -- one DPP move instead of two more loads and four more code conversions per 2 KiB --, and the codes of
+//     the NEXT block are computed one step ahead, so that lane 63 finds its neighbour (lane 0 of the next block) in
+//     a register;
+//   * keeps the candidates (one per 1.3 KiB on DNA) in an LDS ring of its own, as 32-bit offsets;
+//   * classifies them 64 at a time -- whenever the ring holds that many, and at the end of the span --: two loads of
+//     the candidate's text, exact_classify, a ballot per pattern;
+//   * adds its counts to the workgroup's; the workgroup stores a row of its own (no atomics: see the end of the kernel),
+//     and plane_count_finish -- one workgroup, queued behind the scan on a stream of the object's own, so that the next
+//     scan kernel starts at once -- adds the rows up and hands counts, flags and the first / last match of every pattern
+//     (what the carry exchange between shards needs, rj_multi_bounds) to pinned host memory.
+// Nothing else is written: no candidate list in HBM, no (begin, end) arrays, no second or third launch.
+//
+// Exactness.  The table answers "does pattern p match these 8 bytes" exactly (exact_count.h).  The reference's count
+// is that of the left-most-longest, non-overlapping selection (src/x64/codegen-x64.cc:401-466); with all matches 8
+// bytes long it differs from the number of matching positions only when two matches of ONE pattern begin fewer than
+// 8 bytes apart.  Candidates are classified in text order, so that needs two neighbours in the ring (or across a
+// batch, or across two waves' spans: the wave looks at the 7 positions before its span itself) closer than 8 bytes
+// with a pattern in common: the run is then flagged (kPcConflict) and the host repeats it with the span pipeline.
+// A block that holds more candidates than the ring can take (kPcVoid) is handled the same way.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "exact_count.h"
+#include "kernels.h"
+
+namespace rejit_amd {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr uint64_t kBlock = 2048;     // bytes a wave takes per iteration: 64 lanes x 32 B
+constexpr uint32_t kRing = 256;       // candidate slots per wave; consumed 64 at a time, looked at every second block
+
+__device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & (kWave - 1); }
+
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
+// lane i <- lane i + 1 (wave_shl:1); lane 63 keeps `last`
+__device__ __forceinline__ uint32_t from_lane_above(uint32_t v, uint32_t last) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(last), static_cast<int>(v), 0x130, 0xF, 0xF, false));
+}
+// lane i <- lane i - 1 (wave_shr:1); lane 0 keeps `first`
+__device__ __forceinline__ uint32_t from_lane_below(uint32_t v, uint32_t first) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(first), static_cast<int>(v), 0x138, 0xF, 0xF, false));
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t x) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+  x += dpp_or_zero<0x111, 0xF>(x);
+  x += dpp_or_zero<0x112, 0xF>(x);
+  x += dpp_or_zero<0x114, 0xF>(x);
+  x += dpp_or_zero<0x118, 0xF>(x);
+  x += dpp_or_zero<0x142, 0xA>(x);
+  x += dpp_or_zero<0x143, 0xC>(x);
+  return x;
+}
+
+struct Consts {
+  uint32_t cmask;   // 0x03030303 << code_shift
+  uint32_t shift;
+};
+
+// the 2-bit codes of a dword's four bytes as one byte (times 2^shift)
+__device__ __forceinline__ uint32_t codes4(uint32_t d, const Consts& k) { return __builtin_amdgcn_udot4(d & k.cmask, 0x40100401u, 0u, false); }
+
+// the codes of 16 bytes: bits 2k, 2k + 1 = byte k
+__device__ __forceinline__ uint32_t codes16(const uint4& v, const Consts& k) {
+  const uint32_t s = k.shift;
+  return (codes4(v.x, k) >> s) | (codes4(v.y, k) << (8 - s)) | (codes4(v.z, k) << (16 - s)) | (codes4(v.w, k) << (24 - s));
+}
+
+struct Raw {
+  uint4 a, b;   // the lane's 32 bytes
+};
+
+__device__ __forceinline__ void load_block(const uint8_t* text, uint64_t at, Raw& r) {
+  r.a = *reinterpret_cast<const uint4*>(text + at);
+  r.b = *reinterpret_cast<const uint4*>(text + at + 16);
+}
+
+__device__ __forceinline__ uint32_t guarded_dword(const uint8_t* text, uint64_t n, uint64_t at) {
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (at + k < n) v |= static_cast<uint32_t>(text[at + k]) << (8 * k);
+  return v;
+}
+
+// Window positions of the lane's 32 bytes that lie within one code of a base: bit 2k = byte k, bit 2k + 1 = byte
+// 16 + k.  ta / tb: the codes of the two halves; hb: the codes of the 8 bytes behind them (bits 0..15).
+template <int NB>
+__device__ __forceinline__ uint32_t plane_test(uint32_t ta, uint32_t tb, uint32_t hb, const PlaneCountParams& a) {
+  constexpr uint32_t kEven = 0x55555555u;
+  const uint32_t L = (ta & kEven) | ((tb << 1) & ~kEven);
+  const uint32_t H = ((ta >> 1) & kEven) | (tb & ~kEven);
+  const uint32_t Ln = (tb & kEven) | ((hb << 1) & ~kEven);   // what follows the first half is the second half
+  const uint32_t Hn = ((tb >> 1) & kEven) | (hb & ~kEven);
+  uint32_t Z[NB], O[NB];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint32_t Li = i ? __builtin_amdgcn_alignbit(Ln, L, 2 * i) : L;
+    const uint32_t Hi = i ? __builtin_amdgcn_alignbit(Hn, H, 2 * i) : H;
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      const uint32_t E = (Li ^ a.lo[b][i]) & (Hi ^ a.hi[b][i]);
+      if (i == 0) {
+        Z[b] = E;
+      } else if (i == 1) {
+        O[b] = Z[b] | E;
+        Z[b] &= E;
+      } else {
+        O[b] = Z[b] | (O[b] & E);
+        if (i < 7) Z[b] &= E;
+      }
+    }
+  }
+  return NB > 1 ? (O[0] | O[NB - 1]) : O[0];
+}
+
+// per wave: the ring, and what the classification carries from batch to batch
+struct WaveState {
+  uint32_t* ring;        // LDS, kRing slots: offsets from the span's first byte, in text order
+  uint32_t head, tail;   // wave-uniform, free-running
+  uint32_t acc;          // lane p: matches of pattern p so far
+  uint32_t flags;        // kPcConflict | kPcVoid (wave-uniform)
+  // the last candidate classified so far: its offset, patterns, and whether it was itself within 8 bytes of the one before
+  uint32_t prev_rel, prev_mask, prev_close, prev_valid;
+  // edge waves (the first / last a.edge_waves of the grid): first / last match offset of pattern p at edge[2 p], edge[2 p + 1]
+  // (LDS; kNoEdge: none yet)
+  uint32_t* edge;
+};
+constexpr uint32_t kNoEdge = 0xFFFFFFFFu;
+
+// the candidates of one block, in text order, to the ring
+__device__ __forceinline__ void push_block(WaveState& w, uint32_t hm, uint32_t rel_lane) {
+  const uint64_t any = __ballot(hm != 0);
+  if (any == 0) return;  // wave-uniform
+  const uint64_t several = __ballot((hm & (hm - 1)) != 0);
+  if (several == 0) {
+    // the usual case: no lane holds two candidates
+    if (hm != 0) {
+      const uint32_t bit = static_cast<uint32_t>(__builtin_ctz(hm));
+      const uint32_t idx = w.tail + lanes_below(any);
+      w.ring[idx & (kRing - 1)] = rel_lane + (bit >> 1) + ((bit & 1u) << 4);
+    }
+    w.tail += static_cast<uint32_t>(__popcll(any));
+    return;
+  }
+  const uint32_t c = __popc(hm);
+  const uint32_t inc = wave_inclusive_sum(c);
+  const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(inc), kWave - 1));
+  if (tot <= kRing) {   // (more: the caller's occupancy test voids the run; nothing is written)
+    uint32_t idx = w.tail + inc - c;
+    for (uint32_t m = hm & 0x55555555u; m; m &= m - 1, idx++) w.ring[idx & (kRing - 1)] = rel_lane + (static_cast<uint32_t>(__builtin_ctz(m)) >> 1);
+    for (uint32_t m = hm & 0xAAAAAAAAu; m; m &= m - 1, idx++) w.ring[idx & (kRing - 1)] = rel_lane + 16u + (static_cast<uint32_t>(__builtin_ctz(m)) >> 1);
+  }
+  w.tail += tot;
+}
+
+// The first m (<= 64) candidates of the ring against the table: counts, the overlap test, the edge rows.
+template <int NB>
+__device__ __forceinline__ void classify_batch(WaveState& w, uint32_t m, const uint32_t* table, const PlaneCountParams& a, uint64_t span_base,
+                                               bool edge) {
+  const int lane = lane_id();
+  const bool have = static_cast<uint32_t>(lane) < m;
+  const uint32_t rel = w.ring[(w.head + static_cast<uint32_t>(lane)) & (kRing - 1)];
+  const uint64_t pos = span_base + rel;
+  // (the scan does not clip: windows before the range, or with bytes beyond the end of the text, are dropped here)
+  const bool ok = have && pos >= a.sb && pos < a.se && pos + 8 <= a.n;
+  uint32_t lo = 0, hi = 0;
+  if (ok) {
+    __builtin_memcpy(&lo, a.text + pos, 4);
+    __builtin_memcpy(&hi, a.text + pos + 4, 4);
+  }
+  uint32_t mask = exact_classify<NB>(table, a.base_lo, a.base_hi, lo, hi);
+  mask = ok ? mask : 0u;
+  // counts: a ballot per pattern, lane p keeps pattern p's
+  for (uint32_t p = 0; p < a.n_patterns; p++) {
+    const uint64_t mine = __ballot(((mask >> p) & 1u) != 0);
+    if (lane == static_cast<int>(p)) w.acc += static_cast<uint32_t>(__popcll(mine));
+    if (edge && mine != 0) {  // (wave-uniform)
+      const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(rel), static_cast<int>(__builtin_ctzll(mine))));
+      const uint32_t last = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(rel), 63 - static_cast<int>(__builtin_clzll(mine))));
+      if (lane == static_cast<int>(p)) {
+        if (w.edge[2 * p] == kNoEdge) w.edge[2 * p] = first;
+        w.edge[2 * p + 1] = last;
+      }
+    }
+  }
+  // two matches of one pattern fewer than 8 bytes apart?  candidates are in text order: look at the one before
+  const uint32_t before = from_lane_below(rel, w.prev_rel);
+  const bool has_before = lane > 0 || w.prev_valid != 0;
+  const bool close = have && has_before && (rel - before) < 8u;
+  if (__ballot(close) != 0) {  // (wave-uniform; 0.6 % of the candidates on DNA)
+    const uint32_t mask_before = from_lane_below(mask, w.prev_mask);
+    const uint32_t close_before = from_lane_below(close ? 1u : 0u, w.prev_close);
+    // a pattern in common with the neighbour -- or three candidates in a row that close (the one before the neighbour is
+    // not looked at: flagged without asking for its patterns)
+    if (__ballot(close && ((mask & mask_before) != 0 || close_before != 0)) != 0) w.flags |= kPcConflict;
+  }
+  w.prev_rel = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(rel), static_cast<int>(m - 1)));
+  w.prev_mask = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mask), static_cast<int>(m - 1)));
+  w.prev_close = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(close ? 1u : 0u), static_cast<int>(m - 1)));
+  w.prev_valid = 1;
+  w.head += m;
+}
+
+// The first candidates of a span may lie within 8 bytes of a match that begins in the span before it (another wave's):
+// the wave classifies the 7 positions before its span itself.  Conservative: any pattern in common between those
+// positions and the span's candidates in its first 7 bytes flags the run.  (Those candidates are the ring's first
+// entries -- text order -- and at most 7: lanes 0..6 of the span's first batch.)
+template <int NB>
+__device__ __forceinline__ void check_span_start(WaveState& w, uint32_t m, const uint32_t* table, const PlaneCountParams& a, uint64_t span_base) {
+  const int lane = lane_id();
+  const uint32_t rel = w.ring[(w.head + static_cast<uint32_t>(lane)) & (kRing - 1)];
+  const bool near = static_cast<uint32_t>(lane) < m && lane < 7 && rel < 7u;
+  if (__ballot(near) == 0 || span_base == 0) return;  // (wave-uniform)
+  uint32_t any[2] = {0, 0};  // patterns that match at one of the 7 positions before the span / at a near candidate
+#pragma unroll
+  for (int round = 0; round < 2; round++) {
+    const uint64_t pos = round == 0 ? span_base + static_cast<uint64_t>(lane) - 7 : span_base + rel;
+    const bool mine = round == 0 ? (lane < 7 && span_base + static_cast<uint64_t>(lane) >= 7) : near;
+    const bool ok = mine && pos >= a.sb && pos < a.se && pos + 8 <= a.n;
+    uint32_t lo = 0, hi = 0;
+    if (ok) {
+      __builtin_memcpy(&lo, a.text + pos, 4);
+      __builtin_memcpy(&hi, a.text + pos + 4, 4);
+    }
+    uint32_t mask = exact_classify<NB>(table, a.base_lo, a.base_hi, lo, hi);
+    mask = ok ? mask : 0u;
+    for (uint32_t p = 0; p < a.n_patterns; p++)
+      if (__ballot(((mask >> p) & 1u) != 0) != 0) any[round] |= 1u << p;
+  }
+  if ((any[0] & any[1]) != 0) w.flags |= kPcConflict;
+}
+
+// after every second block: the run is void when a block overfilled the ring; else classify while 64 are held
+template <int NB>
+__device__ __forceinline__ void blocks_done(WaveState& w, const uint32_t* table, const PlaneCountParams& a, uint64_t span_base, bool edge, bool& first_batch) {
+  if (w.tail - w.head > kRing) {  // more candidates than the ring takes: the run is void
+    w.flags |= kPcVoid;
+    w.head = w.tail;
+    return;
+  }
+  if (a.debug & 2u) w.head = w.tail;
+  while (w.tail - w.head >= 64u) {
+    if (first_batch) check_span_start<NB>(w, 64u, table, a, span_base);
+    first_batch = false;
+    classify_batch<NB>(w, 64u, table, a, span_base, edge);
+  }
+}
+
+}  // namespace
+
+// (block indices are 32-bit inside the kernel: texts of up to 8 TiB)
+template <int NB>
+__global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
+  __shared__ __attribute__((aligned(16))) uint32_t table[kExactTabWords];
+  __shared__ uint32_t rings[4][kRing];
+  __shared__ uint32_t edges[4][2 * kExactMaxPatterns];
+  __shared__ uint32_t wave_counts[4][kExactMaxPatterns];
+  __shared__ uint32_t wave_flags[4];
+  const int lane = lane_id();
+  const uint32_t wid = threadIdx.x >> 6;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6));
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  Consts k;
+  k.shift = a.code_shift;
+  k.cmask = 0x03030303u << a.code_shift;
+  // the blocks are dealt out evenly: wave w takes span_blocks of them, the first span_extra waves one more (a rounded-up
+  // span for everybody left the last 8 % of the grid without work on the 500 MB text, and the others 13 blocks for 12)
+  const uint32_t c0 = static_cast<uint32_t>(a.first_block) + wave * static_cast<uint32_t>(a.span_blocks) + (wave < a.span_extra ? wave : a.span_extra);
+  const uint32_t c1 = c0 + static_cast<uint32_t>(a.span_blocks) + (wave < a.span_extra ? 1u : 0u);
+  // blocks below fast_end: the block and the one behind it lie inside the text (unguarded loads; the codes of the block
+  // behind feed lane 63)
+  const uint32_t full = static_cast<uint32_t>(a.n / kBlock);
+  uint32_t fast_end = full >= 1 ? full - 1 : 0;
+  if (fast_end > c1) fast_end = c1;
+  if (fast_end < c0) fast_end = c0;
+  const uint32_t last_full = full >= 1 ? full - 1 : 0;   // prefetches beyond the span are clamped to a block of the text
+  const uint8_t* lane_text = a.text + static_cast<uint32_t>(lane) * 32u;
+  const uint64_t span_base = static_cast<uint64_t>(c0) * kBlock;
+  const bool edge = wave < a.edge_waves || wave + a.edge_waves >= n_waves;
+  WaveState w;
+  w.ring = rings[wid];
+  w.edge = edges[wid];
+  w.head = w.tail = 0;
+  w.acc = 0;
+  w.flags = 0;
+  w.prev_rel = w.prev_mask = w.prev_close = w.prev_valid = 0;
+  if (edge) w.edge[lane] = kNoEdge;   // (2 x 32 entries: one per lane)
+  bool first_batch = true;
+
+  auto blk = [&](uint32_t c) { return static_cast<uint64_t>(c < last_full ? c : last_full) * kBlock; };
+  const uint32_t lane_rel = static_cast<uint32_t>(lane) * 32u;
+  Raw ra, rb;
+  uint32_t c = c0;
+  // the table (all waves), before the first wait for text
+  if (c < fast_end) {
+    load_block(lane_text, blk(c), ra);
+    load_block(lane_text, blk(c + 1), rb);
+  }
+  for (uint32_t i = threadIdx.x; i < kExactTabWords; i += blockDim.x) table[i] = a.table[i];
+  __syncthreads();
+  if (c < fast_end) {
+    uint32_t xa = codes16(ra.a, k), xb = codes16(ra.b, k);   // block c
+    load_block(lane_text, blk(c + 2), ra);
+    // two blocks per iteration: x = the codes of block c, rb = block c + 1, ra = block c + 2 (in flight)
+    while (c + 1 < fast_end) {
+      const uint32_t ya = codes16(rb.a, k), yb = codes16(rb.b, k);   // block c + 1
+      // (the codes must exist BEFORE the buffer is loaded again: when the compiler sinks their computation towards its
+      // use, the reload lands in other registers and is copied back at the loop's end -- behind a wait for it)
+      asm volatile("" ::"v"(ya), "v"(yb));
+      load_block(lane_text, blk(c + 3), rb);
+      {
+        const uint32_t hb = from_lane_above(xa, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ya))));
+        const uint32_t hm = plane_test<NB>(xa, xb, hb, a);
+        if (!(a.debug & 4u)) push_block(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
+        else if (hm == 0x12345678u) w.flags |= 4u;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      xa = codes16(ra.a, k);   // block c + 2
+      xb = codes16(ra.b, k);
+      asm volatile("" ::"v"(xa), "v"(xb));
+      load_block(lane_text, blk(c + 4), ra);
+      {
+        const uint32_t hb = from_lane_above(ya, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xa))));
+        const uint32_t hm = plane_test<NB>(ya, yb, hb, a);
+        if (!(a.debug & 4u)) push_block(w, hm, (c + 1 - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
+        else if (hm == 0x12345678u) w.flags |= 4u;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      c += 2;
+      if (w.tail - w.head >= 64u) blocks_done<NB>(w, table, a, span_base, edge, first_batch);
+    }
+    if (c + 1 == fast_end) {   // an odd block left: x holds its codes, rb the block behind it
+      const uint32_t ya = codes16(rb.a, k);
+      const uint32_t hb = from_lane_above(xa, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ya))));
+      const uint32_t hm = plane_test<NB>(xa, xb, hb, a);
+      if (!(a.debug & 4u)) push_block(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
+      c++;
+    }
+    blocks_done<NB>(w, table, a, span_base, edge, first_batch);
+  }
+  // the block(s) at the end of the text: guarded loads, the 8 bytes behind the lane's 32 read by the lane itself
+  for (; c < c1; c++) {
+    const uint64_t at = static_cast<uint64_t>(c) * kBlock + lane_rel;
+    uint4 va, vb;
+    va.x = guarded_dword(a.text, a.n, at);
+    va.y = guarded_dword(a.text, a.n, at + 4);
+    va.z = guarded_dword(a.text, a.n, at + 8);
+    va.w = guarded_dword(a.text, a.n, at + 12);
+    vb.x = guarded_dword(a.text, a.n, at + 16);
+    vb.y = guarded_dword(a.text, a.n, at + 20);
+    vb.z = guarded_dword(a.text, a.n, at + 24);
+    vb.w = guarded_dword(a.text, a.n, at + 28);
+    const uint32_t h0 = guarded_dword(a.text, a.n, at + 32), h1 = guarded_dword(a.text, a.n, at + 36);
+    const uint32_t hb = (codes4(h0, k) >> k.shift) | (codes4(h1, k) << (8 - k.shift));
+    const uint32_t hm = plane_test<NB>(codes16(va, k), codes16(vb, k), hb, a);
+    if (w.tail - w.head > kRing - 64u) blocks_done<NB>(w, table, a, span_base, edge, first_batch);   // (room for this block)
+    push_block(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
+  }
+  // what the ring still holds
+  if (w.tail - w.head > kRing) {
+    w.flags |= kPcVoid;
+    w.head = w.tail;
+  }
+  if (a.debug & 2u) w.head = w.tail;
+  while (w.tail != w.head) {
+    const uint32_t held = w.tail - w.head;
+    const uint32_t m = held < 64u ? held : 64u;
+    if (first_batch) check_span_start<NB>(w, m, table, a, span_base);
+    first_batch = false;
+    classify_batch<NB>(w, m, table, a, span_base, edge);
+  }
+  // edge waves: their own rows (count, first, last match of every pattern), read by the last workgroup
+  if (edge && lane < static_cast<int>(a.n_patterns)) {
+    unsigned long long* row = nullptr;
+    if (wave < a.edge_waves) row = a.edge_rows + (wave * kExactMaxPatterns + static_cast<uint64_t>(lane)) * 4;
+    const uint32_t ef = w.edge[2 * lane], el = w.edge[2 * lane + 1];
+    const unsigned long long first = ef != kNoEdge ? span_base + ef : ~0ull, last = ef != kNoEdge ? span_base + el : ~0ull;
+    if (row) {
+      row[0] = w.acc;
+      row[1] = first;
+      row[2] = last;
+    }
+    if (wave + a.edge_waves >= n_waves) {
+      row = a.edge_rows + ((a.edge_waves + (wave + a.edge_waves - n_waves)) * kExactMaxPatterns + static_cast<uint64_t>(lane)) * 4;
+      row[0] = w.acc;
+      row[1] = first;
+      row[2] = last;
+    }
+  }
+  // wave -> workgroup (LDS) -> a row of the workgroup's own in device memory: plain stores, read by plane_count_finish
+  // (the next kernel on the stream).  Measured alternatives, all inside this kernel: nine device-scope atomic adds and a
+  // ticket per workgroup (kernel 0.094 -> 0.159 ms: the memory side performs same-address atomics one after the other);
+  // rows + a ticket per group of 64 workgroups + a top ticket (0.183 ms: it is the atomic WITH RETURN that costs, ~18 us of
+  // device time per thousand of them, whatever the address; an acq_rel ticket -- L2 write-back + invalidate per
+  // workgroup -- 0.41 ms).
+  if (lane < kExactMaxPatterns) wave_counts[wid][lane] = lane < static_cast<int>(a.n_patterns) ? w.acc : 0u;
+  if (lane == 0) wave_flags[wid] = w.flags;
+  if (a.debug & 1u) return;
+  __syncthreads();
+  if (wid != 0 || lane >= kExactMaxPatterns) return;
+  uint32_t v = wave_counts[0][lane] + wave_counts[1][lane] + wave_counts[2][lane] + wave_counts[3][lane];
+  if (lane == kExactMaxPatterns - 1) v = wave_flags[0] | wave_flags[1] | wave_flags[2] | wave_flags[3];   // (slot 31: the flags)
+  a.wg_rows[static_cast<uint64_t>(blockIdx.x) * kExactMaxPatterns + lane] = v;
+}
+
+// The rows of plane_count added up: counts, flags and bounds to pinned host memory and to the device copy in `acc`
+// (rj_multi_bounds_device).  One workgroup of 1024 threads, and as few DEPENDENT trips to memory as possible -- a lone
+// workgroup pays ~2 us per trip, more under the next scan: thread t adds four patterns (t & 7) of the rows t >> 3,
+// + 128, ... with up to 14 16-byte loads in flight (three trips for 5000 rows); then every wave reads all edge rows of a
+// pattern in one trip (a row = count, first, last: 32 bytes).
+constexpr uint32_t kFinishBatch = 14;
+__global__ __launch_bounds__(1024) void plane_count_finish(PlaneCountParams a, uint32_t n_wg) {
+  __shared__ unsigned long long part[128][kExactMaxPatterns];
+  __shared__ unsigned long long bounds[kExactMaxPatterns][2];
+  const uint32_t p4 = threadIdx.x & 7u, q = threadIdx.x >> 3;
+  unsigned long long sum[4] = {0, 0, 0, 0};
+  const uint4* rows = reinterpret_cast<const uint4*>(a.wg_rows);
+  for (uint32_t r = q; r < ((a.debug & 64u) ? 0u : n_wg); r += 128 * kFinishBatch) {
+    uint4 v[kFinishBatch];
+#pragma unroll
+    for (uint32_t i = 0; i < kFinishBatch; i++) {
+      const uint32_t rr = r + 128 * i;
+      v[i] = rows[static_cast<uint64_t>(rr < n_wg ? rr : q) * 8 + p4];   // (clamped, not skipped: no branch between the loads)
+      if (rr >= n_wg) v[i] = uint4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kFinishBatch; i++) {
+      sum[0] += v[i].x;
+      sum[1] += v[i].y;
+      sum[2] += v[i].z;
+      sum[3] = p4 == 7 ? (sum[3] | v[i].w) : (sum[3] + v[i].w);   // (slot 31: the flags)
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) part[q][4 * p4 + i] = sum[i];
+  // the bounds: wave w takes the patterns w and w + 16, lane e the e-th edge row from the front and from the back -- every
+  // row in ONE trip (a rare pattern has no match in most of the edge waves' 24-KiB spans: rows looked at one after the
+  // other cost 2 us each), a ballot finds the first / last row that holds a match
+  const uint32_t lane = threadIdx.x & 63u, wave_id = threadIdx.x >> 6;
+  const uint64_t n_waves = static_cast<uint64_t>(n_wg) * 4;
+  const uint32_t n_front = static_cast<uint32_t>(n_waves < a.edge_waves ? n_waves : a.edge_waves);   // (edge_waves <= 64)
+  for (uint32_t p = wave_id; p < a.n_patterns; p += 16) {
+    ulonglong2 f{0, 0};
+    unsigned long long bc = 0, bl = 0;
+    if (lane < n_front) {
+      f = *reinterpret_cast<const ulonglong2*>(a.edge_rows + (static_cast<uint64_t>(lane) * kExactMaxPatterns + p) * 4);   // count, first
+      // back rows: slot edge_waves + q holds wave n_waves - edge_waves + q
+      const unsigned long long* br = a.edge_rows + ((static_cast<uint64_t>(a.edge_waves) + (a.edge_waves - n_front) + lane) * kExactMaxPatterns + p) * 4;
+      bc = br[0];
+      bl = br[2];
+    }
+    const uint64_t mf = __ballot(f.x != 0), mb = __ballot(bc != 0);
+    unsigned long long first = kPcNone, last = kPcNone;
+    if (mf) first = __shfl(f.y, __builtin_ctzll(mf));
+    if (mb) last = __shfl(bl, 63 - __builtin_clzll(mb));
+    if (lane == 0) {
+      bounds[p][0] = first;
+      bounds[p][1] = last;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x >= kExactMaxPatterns) return;
+  const uint32_t p = threadIdx.x;
+  unsigned long long total = 0;
+  for (uint32_t i = 0; i < 128; i++) total = p == kExactMaxPatterns - 1 ? (total | part[i][p]) : (total + part[i][p]);
+  if (a.debug & 256u) return;
+  if (p == kExactMaxPatterns - 1) a.host_out[kPcHostFlags] = total;
+  if (p >= a.n_patterns) return;
+  unsigned long long first = bounds[p][0], last = bounds[p][1];
+  // matches exist but none in the edge rows: the bounds are not known (the host runs the span pipeline if asked)
+  if (total != 0 && first == kPcNone) first = kPcUnknown;
+  if (total != 0 && last == kPcNone) last = kPcUnknown;
+  if (total == 0) first = last = kPcNone;
+  a.host_out[kPcHostCount + p] = total;
+  a.host_out[kPcHostBounds + 2 * p] = first;
+  a.host_out[kPcHostBounds + 2 * p + 1] = last;
+  a.acc[kPcBounds + 2 * p] = first;       // the device copy
+  a.acc[kPcBounds + 2 * p + 1] = last;
+  a.acc[kPcTotals + p] = total;
+}
+
+__global__ void bounds_rows_counts_kernel(BoundsParams a, const unsigned long long* acc, int64_t offset, int first_round, int64_t* rows) {
+  const int p = threadIdx.x;
+  if (p >= a.n_lists) return;
+  uint64_t n = a.count[p];
+  int64_t fb = -1, fe = -1, lb = -1, le = -1;
+  if (a.spans[p]) {
+    const uint64_t* r = a.spans[p];
+    if (n) {
+      fb = static_cast<int64_t>(r[0]) + offset;
+      fe = static_cast<int64_t>(r[1]) + offset;
+      lb = static_cast<int64_t>(r[2 * (n - 1)]) + offset;
+      le = static_cast<int64_t>(r[2 * (n - 1) + 1]) + offset;
+    }
+  } else {
+    n = acc[kPcTotals + p];
+    if (n) {
+      fb = static_cast<int64_t>(acc[kPcBounds + 2 * p]) + offset;
+      fe = fb + 8;
+      lb = static_cast<int64_t>(acc[kPcBounds + 2 * p + 1]) + offset;
+      le = lb + 8;
+    }
+  }
+  rows[8 * p + 0] = static_cast<int64_t>(n);
+  if (first_round) {
+    rows[8 * p + 1] = fb;
+    rows[8 * p + 2] = fe;
+    rows[8 * p + 5] = rows[8 * p + 6] = rows[8 * p + 7] = 0;
+  }
+  rows[8 * p + 3] = lb;
+  rows[8 * p + 4] = le;
+}
+
+void launch_bounds_rows_counts(const BoundsParams& a, const unsigned long long* acc, int64_t offset, int first_round, int64_t* d_rows, hipStream_t st) {
+  hipLaunchKernelGGL(bounds_rows_counts_kernel, dim3(1), dim3(64), 0, st, a, acc, offset, first_round, d_rows);
+}
+
+void launch_plane_count(const PlaneCountParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+  if (a.n_bases <= 1) hipExtLaunchKernelGGL((plane_count<1>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+  else hipExtLaunchKernelGGL((plane_count<2>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+}
+
+void launch_plane_count_finish(const PlaneCountParams& a, int grid, hipStream_t st) {
+  hipLaunchKernelGGL(plane_count_finish, dim3(1), dim3(1024), 0, st, a, static_cast<uint32_t>(grid));
+}
+
+}  // namespace rejit_amd

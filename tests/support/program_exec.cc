@@ -11,6 +11,7 @@
 #include <cstring>
 #include <vector>
 
+#include "../../rejit_amd/csrc/exact_count.h"
 #include "../../rejit_amd/csrc/lowering.h"
 #include "../../rejit_amd/csrc/table_layout.h"
 
@@ -368,6 +369,39 @@ int pe_plan(const char* re, uint64_t* info, uint32_t* window_values) {
     window_values[4 * i + 3] = P.windows[i].mask1;
   }
   return 0;
+}
+
+
+// exact_count.h: the plan of MatchAllCount-in-one-kernel for `n_rx` patterns and `n_bases` base windows (8 bytes each).
+// 1 = the set has the shape (table_out: kExactTabWords words, base_out: lo[2], hi[2]), 0 = refused, < 0 = a pattern
+// does not compile.
+int pe_exact_plan(const char* const* rxs, int n_rx, const uint8_t* bases, int n_bases, uint32_t* table_out, uint32_t* base_out) {
+  std::vector<LowerResult> lowered;
+  std::vector<const Program*> progs;
+  for (int i = 0; i < n_rx; i++) {
+    lowered.push_back(lower(rxs[i]));
+    if (lowered.back().status != 0) return -1 - i;
+  }
+  for (auto& l : lowered) progs.push_back(l.program.get());
+  uint8_t b[2][8] = {};
+  for (int k = 0; k < n_bases && k < 2; k++) memcpy(b[k], bases + 8 * k, 8);
+  ExactCountPlan plan;
+  make_exact_count_plan(progs, b, static_cast<uint32_t>(n_bases), &plan);
+  if (!plan.ok) return 0;
+  memcpy(table_out, plan.table, sizeof(plan.table));
+  base_out[0] = plan.base_lo[0];
+  base_out[1] = plan.base_lo[1];
+  base_out[2] = plan.base_hi[0];
+  base_out[3] = plan.base_hi[1];
+  return 1;
+}
+
+// the kernel's per-candidate code (exact_classify) on 8 bytes: bit p = pattern p matches them
+uint32_t pe_exact_classify(const uint32_t* table, const uint32_t* base, int n_bases, const uint8_t* bytes8) {
+  uint32_t lo, hi;
+  memcpy(&lo, bytes8, 4);
+  memcpy(&hi, bytes8 + 4, 4);
+  return n_bases > 1 ? exact_classify<2>(table, base, base + 2, lo, hi) : exact_classify<1>(table, base, base + 2, lo, hi);
 }
 
 }  // extern "C"
