@@ -23,11 +23,16 @@ Other workloads (same contract; what an 8-GPU run of BASELINE configs[3] / [4] /
                        with matches, output gathered to rank 0
   --workload literal   literal `regexp` MatchAll over --literal-bytes per GPU
 
-The headline step is ONE pass over the text for all nine patterns (rj_multi_run mode 0: plane_scan +
-classify_shared_multi + offsets_gather_check_multi, one synchronise).  Besides the contract fields the line carries
-  roofline      -- the dominant kernel (plane_scan<2>): the text's bytes (1 byte read per text byte and pass,
+The headline step is ONE kernel over the text for all nine patterns: regexdna asks MatchAllCount (reference
+sample/regexdna.cc:65), and for counts plane_count scans, classifies its candidates by table lookup and counts
+(rj_multi_set_counts_only; plane_count.hip), a small kernel on the object's own stream adds the workgroups' rows up.
+`--span-lists` / `step_variants_ms.span_lists`: round 4's loop, which lays out every pattern's (begin, end) list
+(plane_scan + classify_shared_multi + offsets_gather_check_multi).  Besides the contract fields the line carries
+  physical_GBps / step_frac -- n / t of the step: every text byte crosses the HBM interface once per step
+  roofline      -- the dominant kernel (plane_count<2>): the text's bytes (1 byte read per text byte and pass,
                    SURVEY.md section 8d) / the launch's average duration from HIP events on the run's stream,
-                   traffic = FETCH_SIZE x 2 per launch from profiles/pmc_traffic.json
+                   traffic = FETCH_SIZE x 2 per launch from profiles/pmc_traffic.json; read_only_ceiling /
+                   frac_of_ceiling: against a kernel that only reads the same bytes, measured in this run (`hbm_ceiling`)
   roofline_valu -- the same launch against the VALU peak (SQ_INSTS_VALU per byte from profiles/)
   cpu_baseline  -- the REAL reference (oracle/_ref, built from /root/reference) on the host: one core (>= 0.5 s of
                    work) and all cores over disjoint slices, on a bounded sample of the same text
@@ -81,6 +86,8 @@ def parse_args():
     ap.add_argument("--in-flight", type=int, default=2, help="steps kept in flight by the headline loop (rj_multi objects used in turn)")
     ap.add_argument("--settle-ms", type=float, default=600.0, help="untimed run of the step loop before the W warm-up and K timed steps (device clocks)")
     ap.add_argument("--time-all-launches", action="store_true", help="headline loop: the start event on every scan launch (default: every second one)")
+    ap.add_argument("--span-lists", action="store_true", help="headline loop as in round 4: the span pipeline (plane_scan + classify + gather: every "
+                    "pattern's (begin, end) list) instead of MatchAllCount in one kernel (plane_count)")
     ap.add_argument("--one-stream", action="store_true", help="headline loop as in round 3: both rj_multi objects and their tails on one stream")
     ap.add_argument("--jrep-files", type=int, default=100_000, help="jrep_10gb extra: files (BASELINE configs[4]: 100 000)")
     ap.add_argument("--jrep-bytes", type=int, default=10_000_000_000, help="jrep_10gb extra: total bytes (BASELINE configs[4]: 10 GB)")
@@ -244,13 +251,33 @@ def base_line(args, c, metric, value, elapsed, config):
             "scaling_measured": "no SCALE record exists yet: multi-GPU numbers are unmeasured until the driver runs N=1,2,4,8"}
 
 
-def hbm_roofline(kernel, bytes_per_launch, avg_ms, traffic=None, launches=None):
+_CEILING = {}
+
+
+def hbm_ceiling(ptr, n, stream):
+    """The achievable ceiling of a read-only stream over THIS text on THIS device in THIS run: a kernel that
+    only reads -- 16 bytes per lane and load, XOR-reduced (rj_stream_read_probe, plane_count.hip) --, GB/s, memoised per size."""
+    import rejit_amd
+    if n not in _CEILING:
+        try:
+            ms = rejit_amd.stream_read_probe(ptr, n, 10, stream)
+            _CEILING[n] = n / (ms * 1e-3) / 1e9 if ms > 0 else None
+        except Exception:
+            _CEILING[n] = None
+    return _CEILING[n]
+
+
+def hbm_roofline(kernel, bytes_per_launch, avg_ms, traffic=None, launches=None, ceiling=None):
     ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     r = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 5),
          "bytes_per_launch": int(bytes_per_launch)}
     if launches is not None:
         r["launches_timed"] = launches
+    if ceiling:
+        # beside the spec peak: what a kernel that does nothing but read the same bytes reaches here, now
+        r["read_only_ceiling"] = round(ceiling, 1)
+        r["frac_of_ceiling"] = round(ach / ceiling, 4)
     return r
 
 
@@ -331,7 +358,7 @@ def run_regexdna(args, c):
     # step k + 1 are already queued, so the device never waits for the host's turn-around (~25 us of a 170 us step).
     # Every step still is one complete pass of the path over the batch with its own result; the synchronous call is
     # reported as `call_latency`.
-    def two_in_flight(own_streams, tail_streams=False, time_all=True):
+    def two_in_flight(own_streams, tail_streams=False, time_all=True, counts_only=False):
         """(step, drain, scan times) of a loop that keeps two steps in flight on two rj_multi objects.  own_streams:
         each object on its own stream, the scan kernels ordered one behind the other (rj_multi_order_after), so that the
         tails of step k run under the scan of step k + 1.  tail_streams: both objects on ONE stream, but each queues its
@@ -345,7 +372,11 @@ def run_regexdna(args, c):
         for mm, tt in zip(multis, timed):
             mm.set_mode(0)
             mm.set_timing(tt)
-            if tail_streams:
+            if counts_only:
+                # MatchAllCount semantics (what regexdna asks, sample/regexdna.cc:65): scan + classification + counting in
+                # ONE kernel (plane_count.hip), its rows added up by a small kernel on the object's own stream
+                assert mm.set_counts_only(True), "the regexdna set must take the one-kernel counts path"
+            elif tail_streams:
                 mm.set_tail_stream(True)
         second = torch.cuda.Stream(dev) if own_streams else None
         streams = [stream, second.cuda_stream] if own_streams else [stream] * depth
@@ -399,8 +430,14 @@ def run_regexdna(args, c):
     # order, the tails of step k run under the scan of step k + 1.  The scan kernel then shares the device with them,
     # so its duration inside this loop is longer than alone: `roofline` is measured in this loop (as the contract asks),
     # `roofline_kernel_alone` in the one-stream loop of round 3 (`one_stream`).
+    # Round 5: regexdna asks for COUNTS (MatchAllCount, sample/regexdna.cc:65), and for counts the step is ONE kernel:
+    # plane_count (scan + exact classification of the candidates + counting; rj_multi_set_counts_only) followed by a
+    # small kernel that adds the workgroups' rows up, on the object's own stream.  Nothing shares the device with the
+    # scan but that small kernel.  `--span-lists` keeps round 4's loop (every pattern's (begin, end) list is laid out:
+    # plane_scan + classify + gather) as the headline; it is always reported as `step_variants_ms.span_lists`.
+    counts_headline = use_multi and not args.span_lists
     if use_multi:
-        step, drain, scan_ms = two_in_flight(False, tail_streams=not args.one_stream, time_all=args.time_all_launches)
+        step, drain, scan_ms = two_in_flight(False, tail_streams=not args.one_stream, time_all=args.time_all_launches, counts_only=counts_headline)
     else:
         drain = None
 
@@ -449,8 +486,11 @@ def run_regexdna(args, c):
                      "fasta_n_per_gpu": args.fasta_n, "text_bytes_per_gpu": int(own_bytes), "patterns": len(patterns),
                      "sharding": "contiguous byte ranges + %d-byte halo; all_gather of 8 integers per pattern (count, first / last match, carry used) per step, rows and decision on the device"
                                  % (max_len - 1),
-                     "calls": ("rj_multi_start / rj_multi_finish, mode 0, two steps in flight on two rj_multi objects on one stream%s: one pass over the text for the nine patterns (plane_scan) + classify + gather per step"
-                               % ("" if args.one_stream else ", each run's tails on a stream of the object's own (rj_multi_set_tail_stream)")) if use_multi else "9 x rj_scan_run per step",
+                     "calls": (("rj_multi_set_counts_only + rj_multi_start / rj_multi_finish, %d steps in flight on %d rj_multi objects on one stream: per step ONE pass over the text for the nine "
+                                "patterns that also classifies and counts (plane_count) + a small kernel adding up its rows on the object's own stream; MatchAllCount semantics, no span lists"
+                                % (max(2, args.in_flight), max(2, args.in_flight))) if counts_headline else
+                               ("rj_multi_start / rj_multi_finish, mode 0, %d steps in flight on rj_multi objects on one stream%s: one pass over the text for the nine patterns (plane_scan) + classify + gather per step"
+                                % (max(2, args.in_flight), "" if args.one_stream else ", each run's tails on a stream of the object's own (rj_multi_set_tail_stream)"))) if use_multi else "9 x rj_scan_run per step",
                      "before_the_timed_region": "the same loop untimed for --settle-ms = %g ms (device clocks: `cold_ms_per_step` is K steps straight after the set-up), then W warm-up steps" % args.settle_ms})
     out["matches_per_s"] = round(total_matches * args.steps / elapsed, 1)
     out["matches_per_pass"] = counts
@@ -468,19 +508,27 @@ def run_regexdna(args, c):
         # launch = text bytes (for a fused pass quote n / t_fused, never 9 n / t_fused, against HBM)
         assert multi_sep.run(text_ptr, n_local, stream=stream, own_begin=own_lo, own_end=own_hi) == (counts if world == 1 else multi_sep.run(text_ptr, n_local, stream=stream, own_begin=own_lo, own_end=own_hi))
         one_pass = multi_sep.how == 1
-        out["roofline"] = hbm_roofline("plane_scan<2> (one pass, nine patterns)" if one_pass else "scan kernels of rj_multi_run", own_bytes, avg_scan_ms,
-                                       pmc_traffic("plane", fasta_n=args.fasta_n) if world == 1 else None, len(scan_ms))
+        ceiling = hbm_ceiling(text_ptr, n_local, stream) if rank == 0 else None
+        kernel_name = ("plane_count<2> (one pass, nine patterns: scan + classification + counts)" if counts_headline else
+                       "plane_scan<2> (one pass, nine patterns)" if one_pass else "scan kernels of rj_multi_run")
+        out["roofline"] = hbm_roofline(kernel_name, own_bytes, avg_scan_ms,
+                                       pmc_traffic("plane_count" if counts_headline else "plane", fasta_n=args.fasta_n) if world == 1 else None, len(scan_ms),
+                                       ceiling=ceiling)
         out["roofline"]["note"] = ("n / t of the one launch that scans the text for all nine patterns; `value` counts the text once per pattern "
-                                   "(9 x n per step, the reference's convention: nine MatchAllCount calls)")
+                                   "(9 x n per step, the reference's convention: nine MatchAllCount calls); `physical_GBps` is n / t of the step")
+        if ceiling:
+            out["hbm_ceiling"] = {"what": "a kernel that only reads the same %d bytes (16 B per lane and load, XOR-reduced; rj_stream_read_probe), this device, this run" % n_local,
+                                  "GB_per_s": round(ceiling, 1), "frac_of_spec_peak": round(ceiling / HBM_PEAK_GBS, 4)}
         if not args.time_all_launches:
-            out["roofline"]["timing"] = ("HIP events of every SECOND scan launch of the timed region (one of the two rj_multi objects): the start event "
-                                         "costs ~6.5 us between two kernels of a stream; `step_variants_ms.every_launch_timed` is the loop with it on all")
-        ops_per_byte = rejit_amd.PLANE_VALU_OPS_PER_BYTE
+            out["roofline"]["timing"] = ("HIP events of one scan launch in %d of the timed region (the first of the rj_multi objects used in turn): the start event "
+                                         "costs ~6.5 us between two kernels of a stream; `step_variants_ms.every_launch_timed` is the loop with it on all"
+                                         % max(2, args.in_flight))
+        ops_per_byte = rejit_amd.PLANE_COUNT_VALU_OPS_PER_BYTE if counts_headline else rejit_amd.PLANE_VALU_OPS_PER_BYTE
         valu = own_bytes * ops_per_byte / (avg_scan_ms * 1e-3) / 1e12 if avg_scan_ms > 0 else 0.0
-        out["roofline_valu"] = {"bound": "valu", "kernel": "plane_scan<2>", "ops_per_text_byte": ops_per_byte,
+        out["roofline_valu"] = {"bound": "valu", "kernel": "plane_count<2>" if counts_headline else "plane_scan<2>", "ops_per_text_byte": ops_per_byte,
                                 "achieved": round(valu, 2), "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",
                                 "frac": round(valu / VALU_PEAK_TOPS, 4),
-                                "note": "SQ_INSTS_VALU x 64 / text bytes from profiles/r03_pmc_sq_counters.txt"}
+                                "note": "SQ_INSTS_VALU x 64 / text bytes from profiles/%s_pmc_sq_counters.txt" % ("r05" if counts_headline else "r03")}
     else:
         out["roofline"] = hbm_roofline("scan_windows<2,NIB>", own_bytes, avg_scan_ms, None, len(scan_ms))
     extras = rank == 0 and world == 1 and not args.no_extra
@@ -507,7 +555,47 @@ def run_regexdna(args, c):
         ek0, ck0 = time_steps(lambda: multi_sep.run(text_ptr, n_local, stream=stream, own_begin=own_lo, own_end=own_hi), key="headline")
         out["call_latency"] = call_times["headline"]
         assert ck0 == counts, (ck0, counts)
-        if world == 1:
+        if world == 1 and counts_headline:
+            # MatchAllCount in one kernel, one synchronous call after the other: the kernel with nothing else on the device
+            multi_c = rejit_amd.MultiScan(progs)
+            assert multi_c.set_counts_only(True)
+            c_ms = []
+
+            def counts_call():
+                r = multi_c.run(text_ptr, n_local, stream=stream, own_begin=own_lo, own_end=own_hi)
+                c_ms.append(multi_c.scan_ms())
+                return r
+
+            ec, cc = time_steps(counts_call, key="counts_only")
+            assert cc == counts and multi_c.how == 3, (cc, counts, multi_c.how)
+            c_ms = c_ms[2:]
+            out["counts_call_latency"] = call_times["counts_only"]
+            out["step_variants_ms"]["counts_synchronous_calls"] = round(ec / args.steps * 1e3, 4)
+            out["roofline_kernel_alone"] = hbm_roofline("plane_count<2> with nothing else on the device (synchronous calls)", own_bytes,
+                                                        sum(c_ms) / len(c_ms), pmc_traffic("plane_count", fasta_n=args.fasta_n), len(c_ms),
+                                                        ceiling=hbm_ceiling(text_ptr, n_local, stream))
+            # the first / last match per pattern the counts kernel leaves for the carry exchange == the span pipeline's
+            multi_sep.run(text_ptr, n_local, stream=stream, own_begin=own_lo, own_end=own_hi)
+            assert multi_c.bounds() == multi_sep.bounds(), "counts-mode bounds differ from the span pipeline's"
+            out["counts_bounds_equal_span_lists"] = True
+            del multi_c
+            # round 4's headline loop: the span pipeline, tails on a stream per object
+            l_step, l_drain, l_times = two_in_flight(False, tail_streams=True, time_all=args.time_all_launches)
+            el, cl = timed(c, args, l_step, l_drain)
+            assert cl == counts, (cl, counts)
+            out["span_lists"] = {"calls": "round 4's headline loop: every pattern's (begin, end) list laid out -- plane_scan + classify_shared_multi + offsets_gather_check_multi per step, "
+                                          "steps in flight on one stream, tails on a stream per object",
+                                 "ms_per_step": round(el / args.steps * 1e3, 4),
+                                 "value": round(len(patterns) * n_total * args.steps / el / 1e9, 3), "unit": "GB/s",
+                                 "roofline": hbm_roofline("plane_scan<2> inside that loop", own_bytes, sum(l_times) / max(len(l_times), 1),
+                                                          pmc_traffic("plane", fasta_n=args.fasta_n), len(l_times))}
+            out["step_variants_ms"]["span_lists"] = out["span_lists"]["ms_per_step"]
+            if not args.time_all_launches:
+                a_step, a_drain, a_times = two_in_flight(False, time_all=True, counts_only=True)
+                ea, ca = timed(c, args, a_step, a_drain)
+                assert ca == counts, (ca, counts)
+                out["step_variants_ms"]["every_launch_timed"] = round(ea / args.steps * 1e3, 4)
+        if world == 1 and not counts_headline:
             # the same loop with a stream per object: the tails of step k (classify + gather, latency-bound) run under the
             # scan of step k + 1 -- more steps per second, but the scan kernel shares the device with them and takes
             # longer, which is why the headline (and its roofline) keeps both objects on one stream
@@ -683,7 +771,24 @@ def run_regexdna(args, c):
                                  "value": round(9 * nb / (e0 / args.steps) / 1e9, 3), "unit": "GB/s",
                                  "ms_per_step": round(e0 / args.steps * 1e3, 4),
                                  "roofline": hbm_roofline("plane_scan<2>", nb, sum(ms0) / len(ms0), pmc_traffic("plane_2p5gb", bytes=nb), len(ms0))}
-        del big, m2, m0
+        mc = rejit_amd.MultiScan(progs)
+        assert mc.set_counts_only(True)
+        msc = []
+
+        def big_count_step():
+            r = mc.run(big.data_ptr(), nb, stream=stream)
+            msc.append(mc.scan_ms())
+            return r
+
+        ecb, ccb = time_steps(big_count_step, warm=1, steps=5)
+        assert ccb == cb and mc.how == 3, "the counts kernel and the per-pattern runs disagree on the 2.5 GB text"
+        msc = msc[1:]
+        out["counts_2p5gb"] = {"workload": "the headline's one-kernel MatchAllCount over the same 2.5 GB text",
+                               "value": round(9 * nb / (ecb / args.steps) / 1e9, 3), "unit": "GB/s",
+                               "ms_per_step": round(ecb / args.steps * 1e3, 4),
+                               "roofline": hbm_roofline("plane_count<2>", nb, sum(msc) / len(msc), pmc_traffic("plane_count_2p5gb", bytes=nb), len(msc),
+                                                        ceiling=hbm_ceiling(big.data_ptr(), nb, stream))}
+        del big, m2, m0, mc
         torch.cuda.empty_cache()
     return out, extras
 

@@ -5,7 +5,7 @@ include/rejit.h); this package only builds it (hipcc, gfx950) and binds it with 
 tests and bench.py.  There is no Python or CPU implementation of the matching path: if the
 library is missing, or no HIP device is present, every call fails loudly.
 """
-from .api import (RejitError, Program, Scan, MultiScan, build, library_path, load_library, device_count)  # noqa: F401
+from .api import (RejitError, Program, Scan, MultiScan, build, library_path, load_library, device_count, stream_read_probe)  # noqa: F401
 
 # VALU operations the fused nine-pattern scan kernel (scan_windows_fused, shared-prefilter form) spends per
 # text byte on the regexdna text: MEASURED (rocprofv3 --pmc SQ_INSTS_VALU, profiles/r02_pmc_sq.txt:
@@ -17,6 +17,9 @@ FUSED_VALU_OPS_PER_BYTE = 15.5
 # 500 MB launch x 64 lanes / 5e8 bytes (profiles/r03_pmc_sq_counters.txt) -- 4.2 in the streaming loop (135 per
 # 2-KiB pair and wave), the rest appends the candidates (about four pairs in five hold one on DNA)
 PLANE_VALU_OPS_PER_BYTE = 5.56
+# plane_count<2> (round 5: 32 contiguous bytes per lane, candidates in an LDS ring, classified by table lookup 64 at a time):
+# SQ_INSTS_VALU 33.46 M wave-instructions per 500 MB launch x 64 lanes / 5e8 bytes (profiles/r05_pmc_sq_counters.txt)
+PLANE_COUNT_VALU_OPS_PER_BYTE = 4.28
 # scan_dense_walk<1,false,4> on `[a-f]+[0-9]` over random ASCII: SQ_INSTS_VALU 1.835e9 wave instructions per 5 GB launch
 # x 64 lanes / 5e9 bytes (profiles/r03_pmc_sq_counters.txt); 28.6 before round 3's instruction diet, 59 before the
 # lane-packed pre-steps

@@ -155,7 +155,7 @@ C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_er
                  "rj_multi_bounds", "rj_batch_separator", "rj_match_all_packed", "rj_host_alloc", "rj_host_free",
                  "rj_multi_bounds_device", "rj_carry_decide", "rj_multi_start", "rj_multi_finish", "rj_multi_order_after",
                  "rj_multi_device_counts", "rj_multi_device_counts_via", "rj_multi_set_tail_stream", "rj_multi_set_timing", "rj_scan_set_timing", "rj_set_default_timing",
-                 "rj_scan_gather_spans", "rj_scan_gather_spans_via", "rj_scan_gathered_spans", "rj_multi_set_counts_only"]
+                 "rj_scan_gather_spans", "rj_scan_gather_spans_via", "rj_scan_gathered_spans", "rj_multi_set_counts_only", "rj_stream_read_probe"]
 
 
 def load_library():
@@ -203,6 +203,8 @@ def load_library():
     L.rj_multi_set_tail_stream.argtypes = [vp, ctypes.c_int]
     L.rj_multi_set_timing.argtypes = [vp, ctypes.c_int]
     L.rj_multi_set_counts_only.argtypes = [vp, ctypes.c_int]
+    L.rj_stream_read_probe.restype = ctypes.c_float
+    L.rj_stream_read_probe.argtypes = [vp, u64, ctypes.c_int, vp]
     L.rj_scan_set_timing.argtypes = [vp, ctypes.c_int]
     L.rj_set_default_timing.argtypes = [ctypes.c_int]
     L.rj_set_default_timing(1)   # bench.py, the tests and the tools read scan_ms: the scan kernel's start event is on for them
@@ -251,6 +253,14 @@ def carry_decide(all_rows, world: int, rank: int, n_patterns: int, out, stream: 
     lib = load_library()
     _check(lib.rj_carry_decide(ctypes.c_void_p(all_rows.data_ptr()), world, rank, n_patterns, ctypes.c_void_p(out.data_ptr()),
                                ctypes.c_void_p(stream)))
+
+
+def stream_read_probe(d_text_ptr: int, n: int, launches: int = 10, stream: int = 0) -> float:
+    """rj_stream_read_probe: average ms of a read-only kernel over device memory (the achievable ceiling of a scan)."""
+    ms = float(load_library().rj_stream_read_probe(ctypes.c_void_p(d_text_ptr), n, launches, ctypes.c_void_p(stream)))
+    if ms < 0:
+        raise RejitError(-3, load_library().rj_last_error().decode("latin1"))
+    return ms
 
 
 def device_count() -> int:

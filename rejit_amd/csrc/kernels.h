@@ -192,7 +192,10 @@ enum { kPcConflict = 1,   // two matches of one pattern fewer than 8 bytes apart
        kPcVoid = 2 };     // a 2-KiB block held more candidates than a wave's ring: run void
 constexpr uint32_t kPcBounds = 0;                      // acc: [32][2] first / last match begin of the last run (device copy)
 constexpr uint32_t kPcTotals = kPcBounds + 64;         // [32]: the last run's counts (device copy)
-constexpr uint32_t kPcAccWords = kPcTotals + 32;
+constexpr uint32_t kPcFinishGroups = 8;                // workgroups of plane_count_finish
+constexpr uint32_t kPcTicket = kPcTotals + 32;         // their ticket (zero between runs)
+constexpr uint32_t kPcGroupRows = kPcTicket + 16;      // [kPcFinishGroups][32]: their sums (slot 31: the flags)
+constexpr uint32_t kPcAccWords = kPcGroupRows + kPcFinishGroups * 32;
 constexpr uint32_t kPcHostCount = 0, kPcHostFlags = 32, kPcHostBounds = 40, kPcHostWords = 40 + 64;
 constexpr unsigned long long kPcNone = ~0ull, kPcUnknown = ~0ull - 1;   // bounds: no match / matches, but none in an edge wave's span
 struct PlaneCountParams {
@@ -204,7 +207,7 @@ struct PlaneCountParams {
   uint32_t span_extra;
   uint32_t code_shift, n_bases, n_patterns;
   uint32_t edge_waves;   // the first and the last edge_waves waves of the grid record their first / last match per pattern
-  uint32_t debug;        // measurement only (RJ_COUNT_DEBUG): 1 no ticket / device atomics, 2 no classification, 4 no push
+  uint32_t batch_at;     // a wave classifies what its ring holds (<= 64 at a time) when that many are waiting, 1..64
   uint32_t lo[2][8], hi[2][8];       // as PlaneParams
   uint32_t base_lo[2], base_hi[2];   // the bases' 8 bytes (ExactCountPlan)
   const uint32_t* table;             // ExactCountPlan::table in device memory
@@ -216,6 +219,8 @@ struct PlaneCountParams {
 void launch_plane_count(const PlaneCountParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 // the rows of that launch (grid workgroups) added up: counts, flags, bounds -> a.host_out and a.acc
 void launch_plane_count_finish(const PlaneCountParams& a, int grid, hipStream_t st);
+// measurement (rj_stream_read_probe): a read-only pass over d_text[0..n), 16 bytes per lane and load; d_out: grid * 4 words
+void launch_stream_read_probe(const void* d_text, uint64_t n, uint32_t* d_out, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 // launch_bounds_rows after a counts run: a pattern without a list (spans[p] == nullptr) takes its count and first /
 // last match (8 bytes long) from the kernel's device copy in `acc`
 void launch_bounds_rows_counts(const BoundsParams& a, const unsigned long long* acc, int64_t offset, int first_round, int64_t* d_rows, hipStream_t st);

@@ -852,8 +852,10 @@ int run_counts(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint
     const uint64_t first_block = wlo / 2048;
     const uint64_t end_block = whi > wlo ? (whi + 2047) / 2048 : first_block;
     const uint64_t blocks = end_block - first_block;
-    static const int plane_chunks = getenv("RJ_COUNT_CHUNKS") ? atoi(getenv("RJ_COUNT_CHUNKS")) : 96;  // measurement override
-    const ScanGeometry geo = scan_geometry(std::max<uint64_t>(blocks * 2, 1), static_cast<uint64_t>(plane_chunks > 0 ? plane_chunks : 96));
+    // (500 MB: 2048 .. 3584 workgroups measured equal, 0.094 ms; 5086 -- plane_scan's 96 KiB per workgroup -- 0.0985, 8192
+    // 0.101: a wave's fixed costs, the pipeline's first trip and the classification of its candidates, want long spans)
+    static const int count_chunks = getenv("RJ_COUNT_CHUNKS") ? atoi(getenv("RJ_COUNT_CHUNKS")) : 160;  // measurement override
+    const ScanGeometry geo = scan_geometry(std::max<uint64_t>(blocks * 2, 1), static_cast<uint64_t>(count_chunks > 0 ? count_chunks : 160));
     if (!m->count_out) {
       RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&m->count_out), sizeof(unsigned long long) * kPcHostWords));
       RJ_HIP(m->exact_table.reserve(sizeof(uint32_t) * kExactTabWords));
@@ -876,8 +878,8 @@ int run_counts(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint
     pc.n_bases = m->plane.n_bases;
     pc.n_patterns = static_cast<uint32_t>(P);
     pc.edge_waves = kEdgeWaves;
-    static const uint32_t count_debug = getenv("RJ_COUNT_DEBUG") ? static_cast<uint32_t>(atoi(getenv("RJ_COUNT_DEBUG"))) : 0u;  // measurement only
-    pc.debug = count_debug;
+    static const int batch_at = getenv("RJ_COUNT_BATCH") ? atoi(getenv("RJ_COUNT_BATCH")) : 64;  // measurement override
+    pc.batch_at = static_cast<uint32_t>(std::min(std::max(batch_at, 1), 64));
     for (uint32_t b = 0; b < 2; b++) {
       const uint32_t bb = b < m->plane.n_bases ? b : 0;
       for (int i = 0; i < 8; i++) {
@@ -1452,6 +1454,37 @@ int rj_multi_set_timing(rj_multi* m, int on) {
   if (!m) return fail(RJ_BAD_ARGUMENT, "null argument");
   for (rj_scan* s : m->scans) s->timing = on != 0;
   return RJ_OK;
+}
+
+float rj_stream_read_probe(const void* d_text, uint64_t n, int launches, void* hip_stream) {
+  ErrnoGuard errno_guard;
+  if (!d_text || n < (1u << 20) || launches < 1 || (reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) {
+    fail(RJ_BAD_ARGUMENT, "rj_stream_read_probe: >= 1 MiB of 16-byte aligned device memory");
+    return -1.f;
+  }
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const ScanGeometry geo = scan_geometry(n / 1024, 128);   // the scans' own launch shape
+  DeviceBuffer out;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (out.reserve(sizeof(uint32_t) * 4 * static_cast<size_t>(geo.grid)) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    fail(RJ_DEVICE_ERROR, "rj_stream_read_probe: out of memory");
+    return -1.f;
+  }
+  float total = 0.f;
+  for (int i = 0; i < launches + 2; i++) {   // (two untimed launches first)
+    launch_stream_read_probe(d_text, n, out.as<uint32_t>(), geo.grid, e0, e1, st);
+    if (hipStreamSynchronize(st) != hipSuccess) {
+      fail(RJ_DEVICE_ERROR, "rj_stream_read_probe: the kernel failed");
+      total = -1.f;
+      break;
+    }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (i >= 2) total += ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return total < 0.f ? -1.f : total / static_cast<float>(launches);
 }
 
 int rj_multi_set_counts_only(rj_multi* m, int on) {

@@ -259,11 +259,12 @@ __device__ __forceinline__ void blocks_done(WaveState& w, const uint32_t* table,
     w.head = w.tail;
     return;
   }
-  if (a.debug & 2u) w.head = w.tail;
-  while (w.tail - w.head >= 64u) {
-    if (first_batch) check_span_start<NB>(w, 64u, table, a, span_base);
+  while (w.tail - w.head >= a.batch_at) {
+    const uint32_t held = w.tail - w.head;
+    const uint32_t m = held < 64u ? held : 64u;
+    if (first_batch) check_span_start<NB>(w, m, table, a, span_base);
     first_batch = false;
-    classify_batch<NB>(w, 64u, table, a, span_base, edge);
+    classify_batch<NB>(w, m, table, a, span_base, edge);
   }
 }
 
@@ -288,13 +289,11 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
   // span for everybody left the last 8 % of the grid without work on the 500 MB text, and the others 13 blocks for 12)
   const uint32_t c0 = static_cast<uint32_t>(a.first_block) + wave * static_cast<uint32_t>(a.span_blocks) + (wave < a.span_extra ? wave : a.span_extra);
   const uint32_t c1 = c0 + static_cast<uint32_t>(a.span_blocks) + (wave < a.span_extra ? 1u : 0u);
-  // blocks below fast_end: the block and the one behind it lie inside the text (unguarded loads; the codes of the block
-  // behind feed lane 63)
+  // blocks below fast_end: the block and the one behind it lie inside the text (unguarded loads)
   const uint32_t full = static_cast<uint32_t>(a.n / kBlock);
   uint32_t fast_end = full >= 1 ? full - 1 : 0;
   if (fast_end > c1) fast_end = c1;
   if (fast_end < c0) fast_end = c0;
-  const uint32_t last_full = full >= 1 ? full - 1 : 0;   // prefetches beyond the span are clamped to a block of the text
   const uint8_t* lane_text = a.text + static_cast<uint32_t>(lane) * 32u;
   const uint64_t span_base = static_cast<uint64_t>(c0) * kBlock;
   const bool edge = wave < a.edge_waves || wave + a.edge_waves >= n_waves;
@@ -308,20 +307,28 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
   if (edge) w.edge[lane] = kNoEdge;   // (2 x 32 entries: one per lane)
   bool first_batch = true;
 
-  auto blk = [&](uint32_t c) { return static_cast<uint64_t>(c < last_full ? c : last_full) * kBlock; };
+  // A wave never loads a block that is not its own: prefetches beyond the span's last fast block are clamped to that
+  // block (cache hits), and what lane 63 needs of the block BEHIND the span -- the codes of its first 8 bytes -- comes
+  // from one 8-byte load, the same address in every lane.  (Clamped to the text's last block only, the prefetches ran
+  // three blocks into the neighbour's span: FETCH_SIZE 1.22 x the text on spans of 20 blocks.)
+  const uint32_t last_own = fast_end > c0 ? fast_end - 1 : c0;
+  auto blk = [&](uint32_t c) { return static_cast<uint64_t>(c < last_own ? c : last_own) * kBlock; };
   const uint32_t lane_rel = static_cast<uint32_t>(lane) * 32u;
   Raw ra, rb;
+  uint2 behind{0, 0};
   uint32_t c = c0;
-  // the table (all waves), before the first wait for text
   if (c < fast_end) {
     load_block(lane_text, blk(c), ra);
     load_block(lane_text, blk(c + 1), rb);
+    behind = *reinterpret_cast<const uint2*>(a.text + static_cast<uint64_t>(fast_end) * kBlock);   // (block fast_end lies inside the text)
   }
+  // the table (all waves), before the first wait for text
   for (uint32_t i = threadIdx.x; i < kExactTabWords; i += blockDim.x) table[i] = a.table[i];
   __syncthreads();
   if (c < fast_end) {
     uint32_t xa = codes16(ra.a, k), xb = codes16(ra.b, k);   // block c
     load_block(lane_text, blk(c + 2), ra);
+    const uint32_t behind_codes = (codes4(behind.x, k) >> k.shift) | (codes4(behind.y, k) << (8 - k.shift));
     // two blocks per iteration: x = the codes of block c, rb = block c + 1, ra = block c + 2 (in flight)
     while (c + 1 < fast_end) {
       const uint32_t ya = codes16(rb.a, k), yb = codes16(rb.b, k);   // block c + 1
@@ -332,29 +339,27 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
       {
         const uint32_t hb = from_lane_above(xa, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ya))));
         const uint32_t hm = plane_test<NB>(xa, xb, hb, a);
-        if (!(a.debug & 4u)) push_block(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
-        else if (hm == 0x12345678u) w.flags |= 4u;
+        push_block(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
       }
       __builtin_amdgcn_sched_barrier(0);
-      xa = codes16(ra.a, k);   // block c + 2
+      xa = codes16(ra.a, k);   // block c + 2 (the span's last fast block again when c + 2 == fast_end: not used then)
       xb = codes16(ra.b, k);
       asm volatile("" ::"v"(xa), "v"(xb));
       load_block(lane_text, blk(c + 4), ra);
       {
-        const uint32_t hb = from_lane_above(ya, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xa))));
+        const uint32_t next0 = c + 2 == fast_end ? behind_codes : static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xa)));
+        const uint32_t hb = from_lane_above(ya, next0);
         const uint32_t hm = plane_test<NB>(ya, yb, hb, a);
-        if (!(a.debug & 4u)) push_block(w, hm, (c + 1 - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
-        else if (hm == 0x12345678u) w.flags |= 4u;
+        push_block(w, hm, (c + 1 - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
       }
       __builtin_amdgcn_sched_barrier(0);
       c += 2;
-      if (w.tail - w.head >= 64u) blocks_done<NB>(w, table, a, span_base, edge, first_batch);
+      if (w.tail - w.head >= a.batch_at) blocks_done<NB>(w, table, a, span_base, edge, first_batch);
     }
-    if (c + 1 == fast_end) {   // an odd block left: x holds its codes, rb the block behind it
-      const uint32_t ya = codes16(rb.a, k);
-      const uint32_t hb = from_lane_above(xa, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ya))));
+    if (c + 1 == fast_end) {   // an odd block left: x holds its codes; behind it the span ends
+      const uint32_t hb = from_lane_above(xa, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(behind_codes))));
       const uint32_t hm = plane_test<NB>(xa, xb, hb, a);
-      if (!(a.debug & 4u)) push_block(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
+      push_block(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
       c++;
     }
     blocks_done<NB>(w, table, a, span_base, edge, first_batch);
@@ -382,7 +387,6 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
     w.flags |= kPcVoid;
     w.head = w.tail;
   }
-  if (a.debug & 2u) w.head = w.tail;
   while (w.tail != w.head) {
     const uint32_t held = w.tail - w.head;
     const uint32_t m = held < 64u ? held : 64u;
@@ -416,7 +420,6 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
   // workgroup -- 0.41 ms).
   if (lane < kExactMaxPatterns) wave_counts[wid][lane] = lane < static_cast<int>(a.n_patterns) ? w.acc : 0u;
   if (lane == 0) wave_flags[wid] = w.flags;
-  if (a.debug & 1u) return;
   __syncthreads();
   if (wid != 0 || lane >= kExactMaxPatterns) return;
   uint32_t v = wave_counts[0][lane] + wave_counts[1][lane] + wave_counts[2][lane] + wave_counts[3][lane];
@@ -425,24 +428,30 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
 }
 
 // The rows of plane_count added up: counts, flags and bounds to pinned host memory and to the device copy in `acc`
-// (rj_multi_bounds_device).  One workgroup of 1024 threads, and as few DEPENDENT trips to memory as possible -- a lone
-// workgroup pays ~2 us per trip, more under the next scan: thread t adds four patterns (t & 7) of the rows t >> 3,
-// + 128, ... with up to 14 16-byte loads in flight (three trips for 5000 rows); then every wave reads all edge rows of a
-// pattern in one trip (a row = count, first, last: 32 bytes).
+// (rj_multi_bounds_device).  kFinishGroups workgroups of the scan's own shape (4 waves, little LDS), so that they find a
+// place between the workgroups of the NEXT scan, which is running when a caller keeps steps in flight: ONE workgroup
+// of 1024 threads waited for 16 free wave slots on one CU -- until that scan had drained (93 us instead of 18).  As few
+// DEPENDENT trips to memory as possible (a lone workgroup pays ~2 us per trip, more under a scan): thread t adds four
+// patterns (t & 7) of its group's rows t >> 3, + 32, ... with up to 14 16-byte loads in flight; the group's sums go to
+// acc, a ticket (eight arrivals: the cost of an atomic with return does not matter here) finds the last group, which
+// adds them up and reads all edge rows of a pattern in one trip (a row = count, first, last: 32 bytes).
 constexpr uint32_t kFinishBatch = 14;
-__global__ __launch_bounds__(1024) void plane_count_finish(PlaneCountParams a, uint32_t n_wg) {
-  __shared__ unsigned long long part[128][kExactMaxPatterns];
+__global__ __launch_bounds__(256) void plane_count_finish(PlaneCountParams a, uint32_t n_wg) {
+  __shared__ unsigned long long part[32][kExactMaxPatterns];
   __shared__ unsigned long long bounds[kExactMaxPatterns][2];
+  __shared__ uint32_t is_last;
   const uint32_t p4 = threadIdx.x & 7u, q = threadIdx.x >> 3;
+  const uint32_t per = (n_wg + gridDim.x - 1) / gridDim.x;
+  const uint32_t r_lo = blockIdx.x * per, r_hi = r_lo + per < n_wg ? r_lo + per : n_wg;
   unsigned long long sum[4] = {0, 0, 0, 0};
   const uint4* rows = reinterpret_cast<const uint4*>(a.wg_rows);
-  for (uint32_t r = q; r < ((a.debug & 64u) ? 0u : n_wg); r += 128 * kFinishBatch) {
+  for (uint32_t r = r_lo + q; r < r_hi; r += 32 * kFinishBatch) {
     uint4 v[kFinishBatch];
 #pragma unroll
     for (uint32_t i = 0; i < kFinishBatch; i++) {
-      const uint32_t rr = r + 128 * i;
-      v[i] = rows[static_cast<uint64_t>(rr < n_wg ? rr : q) * 8 + p4];   // (clamped, not skipped: no branch between the loads)
-      if (rr >= n_wg) v[i] = uint4{0, 0, 0, 0};
+      const uint32_t rr = r + 32 * i;
+      v[i] = rows[static_cast<uint64_t>(rr < r_hi ? rr : r) * 8 + p4];   // (clamped, not skipped: no branch between the loads)
+      if (rr >= r_hi) v[i] = uint4{0, 0, 0, 0};
     }
 #pragma unroll
     for (uint32_t i = 0; i < kFinishBatch; i++) {
@@ -454,13 +463,29 @@ __global__ __launch_bounds__(1024) void plane_count_finish(PlaneCountParams a, u
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) part[q][4 * p4 + i] = sum[i];
-  // the bounds: wave w takes the patterns w and w + 16, lane e the e-th edge row from the front and from the back -- every
-  // row in ONE trip (a rare pattern has no match in most of the edge waves' 24-KiB spans: rows looked at one after the
-  // other cost 2 us each), a ballot finds the first / last row that holds a match
+  __syncthreads();
   const uint32_t lane = threadIdx.x & 63u, wave_id = threadIdx.x >> 6;
+  if (wave_id == 0) {
+    if (lane < kExactMaxPatterns) {
+      unsigned long long t = 0;
+      for (uint32_t i = 0; i < 32; i++) t = lane == kExactMaxPatterns - 1 ? (t | part[i][lane]) : (t + part[i][lane]);
+      __hip_atomic_store(&a.acc[kPcGroupRows + blockIdx.x * kExactMaxPatterns + lane], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the row is complete before the ticket that publishes it is drawn)
+    if (lane == 0) {
+      const unsigned long long t = __hip_atomic_fetch_add(&a.acc[kPcTicket], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      is_last = t + 1 == gridDim.x ? 1u : 0u;
+      if (t + 1 == gridDim.x) __hip_atomic_store(&a.acc[kPcTicket], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next run)
+    }
+  }
+  __syncthreads();
+  if (!is_last) return;
+  // the last group.  The bounds: wave w takes the patterns w, w + 4, ..., lane e the e-th edge row from the front and from the
+  // back -- every row in ONE trip (a rare pattern has no match in most of the edge waves' spans: rows looked at one after the
+  // other cost 2 us each), a ballot finds the first / last row that holds a match
   const uint64_t n_waves = static_cast<uint64_t>(n_wg) * 4;
   const uint32_t n_front = static_cast<uint32_t>(n_waves < a.edge_waves ? n_waves : a.edge_waves);   // (edge_waves <= 64)
-  for (uint32_t p = wave_id; p < a.n_patterns; p += 16) {
+  for (uint32_t p = wave_id; p < a.n_patterns; p += 4) {
     ulonglong2 f{0, 0};
     unsigned long long bc = 0, bl = 0;
     if (lane < n_front) {
@@ -483,8 +508,10 @@ __global__ __launch_bounds__(1024) void plane_count_finish(PlaneCountParams a, u
   if (threadIdx.x >= kExactMaxPatterns) return;
   const uint32_t p = threadIdx.x;
   unsigned long long total = 0;
-  for (uint32_t i = 0; i < 128; i++) total = p == kExactMaxPatterns - 1 ? (total | part[i][p]) : (total + part[i][p]);
-  if (a.debug & 256u) return;
+  for (uint32_t g = 0; g < gridDim.x; g++) {
+    const unsigned long long v = __hip_atomic_load(&a.acc[kPcGroupRows + g * kExactMaxPatterns + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    total = p == kExactMaxPatterns - 1 ? (total | v) : (total + v);
+  }
   if (p == kExactMaxPatterns - 1) a.host_out[kPcHostFlags] = total;
   if (p >= a.n_patterns) return;
   unsigned long long first = bounds[p][0], last = bounds[p][1];
@@ -536,13 +563,50 @@ void launch_bounds_rows_counts(const BoundsParams& a, const unsigned long long* 
   hipLaunchKernelGGL(bounds_rows_counts_kernel, dim3(1), dim3(64), 0, st, a, acc, offset, first_round, d_rows);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The achievable ceiling of a READ-ONLY stream on this device, measured in the run that quotes a scan against it
+// ("measure a plain device read-only kernel in the same run as the achievable ceiling"): every lane reads
+// 16 bytes per load, four loads in flight per lane, XORs them together and the wave leaves one word -- nothing else.
+// Same launch shape as the scans (workgroups of four waves over contiguous spans).
+__global__ __launch_bounds__(256) void stream_read_probe(const uint4* text, uint64_t n16, uint64_t span16, uint32_t* out) {
+  const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint64_t i = wave * span16 + lane, end = (wave + 1) * span16;
+  if (end > n16) end = n16;
+  uint4 acc{0, 0, 0, 0};
+  for (; i + 192 < end; i += 256) {
+    const uint4 a = text[i], b = text[i + 64], c = text[i + 128], d = text[i + 192];
+    acc.x ^= a.x ^ b.x ^ c.x ^ d.x;
+    acc.y ^= a.y ^ b.y ^ c.y ^ d.y;
+    acc.z ^= a.z ^ b.z ^ c.z ^ d.z;
+    acc.w ^= a.w ^ b.w ^ c.w ^ d.w;
+  }
+  for (; i < end; i += 64) {
+    const uint4 a = text[i];
+    acc.x ^= a.x;
+    acc.y ^= a.y;
+    acc.z ^= a.z;
+    acc.w ^= a.w;
+  }
+  uint32_t v = acc.x ^ acc.y ^ acc.z ^ acc.w;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o);
+  if (lane == 0) out[wave] = v;
+}
+
+void launch_stream_read_probe(const void* d_text, uint64_t n, uint32_t* d_out, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+  const uint64_t n16 = n / 16, waves = static_cast<uint64_t>(grid) * 4;
+  const uint64_t span16 = ((n16 + waves - 1) / waves + 63) / 64 * 64;
+  hipExtLaunchKernelGGL(stream_read_probe, dim3(grid), dim3(256), 0, st, t0, t1, 0, static_cast<const uint4*>(d_text), n16, span16, d_out);
+}
+
 void launch_plane_count(const PlaneCountParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
   if (a.n_bases <= 1) hipExtLaunchKernelGGL((plane_count<1>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
   else hipExtLaunchKernelGGL((plane_count<2>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
 }
 
 void launch_plane_count_finish(const PlaneCountParams& a, int grid, hipStream_t st) {
-  hipLaunchKernelGGL(plane_count_finish, dim3(1), dim3(1024), 0, st, a, static_cast<uint32_t>(grid));
+  hipLaunchKernelGGL(plane_count_finish, dim3(kPcFinishGroups), dim3(256), 0, st, a, static_cast<uint32_t>(grid));
 }
 
 }  // namespace rejit_amd
