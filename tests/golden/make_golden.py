@@ -23,6 +23,10 @@ text is stored):
                          the documented semantics were seen to differ, over texts of up to 600 bytes with many
                          adjacent candidates; reference(ff=0) outputs.  (The oracle's `match_all_spec` is used
                          only to SELECT inputs; every expectation stored is the real reference's.)
+  highbyte_vectors.json  bytes >= 0x80 in patterns and texts (round 5): signed bracket ranges around 0x7f / 0x80 (the
+                         reference compares bytes as signed chars), `.` / \\S / \\D / negated classes over Latin-1 and
+                         UTF-8 text, literal windows of high bytes, random patterns over alphabets with high bytes;
+                         texts of up to 5000 bytes; reference(ff=0) outputs.
   bench_vectors.json     the 12 benchmark regexps (tools/benchmarks/run.py:347-360) on
                          seeded random text with planted matches; regexdna patterns on the
                          FASTA n=50000 input; reference(ff=0) outputs (offsets or digest).
@@ -30,6 +34,7 @@ text is stored):
 The reference is driven in a child process with a timeout: it can abort or loop forever
 on inputs its own tests never exercise.
 """
+import base64
 import hashlib
 import json
 import multiprocessing as mp
@@ -365,6 +370,86 @@ def gen_fuzz(ref: RefProc, count=2500, seed=20260926):
 
 
 
+
+# --------------------------------------------------------------------------- bytes >= 0x80
+# The reference compares bracket ranges as SIGNED bytes (src/x64/codegen-x64.cc:902-907: greater_equal / less_equal on
+# movsx'd characters), its `.` / `\S` / `\D` / negated brackets take any byte, and its fast-forward literals are byte
+# strings: everything here holds bytes >= 0x80 in the pattern, in the text, or both.  Texts of up to 5000 bytes, so that
+# the engine's window scans (nibble filter, 2-bit codes: bytes >= 0x80 alias ASCII ones there) see them, not only its
+# small-text kernel.
+ALPHABETS_HI = ["a\xe9\xff", "ab\x80\x7f", "\x80\x81\xfe\xff", "a\x00\xff\x01", "ab\xc3\xa9 ", "az\x7e\x7f\x80\x81", "\n\xe9a\r",
+                "i\xe9\x69\x29\xa9", "\xe0\xe1\xe2abc", "0\xb0\xf09"]
+HIGH_PATTERNS = [
+    # signed ranges around the sign change, negations, classes of high bytes only
+    "[\x7e-\x81]", "[\x7e-\x81]+", "[^\x80]", "[^\x80]+", "[\x80-\xff]", "[\x80-\xff]+", "[^\x80-\xff]+", "[a-\xff]", "[a-\xff]+x",
+    "[\xf0-\x10]", "[\xf0-\x10]+", "[\x01-\x7f]+", "[\x80-\x8f\xe0-\xef]+", "[^a\xe9]", "[\xe9\xff]+a", "a[\x80-\xff]b", "[\xe0-\xe2]{2,3}",
+    "[\xfe-\xff][\x80-\x81]", "[^\xff]\xff", "[\x7f\x80]{2}",
+    # . \S \D \s \d over Latin-1 / UTF-8 text
+    ".", ".+", "\\S+", "\\D+", "\\S\\D", "a.b", "\xe9.\xe9", ".\xff", "\\D\xe9", "\\S{2}\xe9", "^.\xe9", "\xe9$", "^\xff+$", "(\xe9|\xff)+", "\xc3\xa9",
+    "\xc3[\x80-\xbf]", "(\xc3\xa9)+", "caf\xe9", "na\xefve|\xfcber", "\xe9t\xe9", "[a-z]*\xe9[a-z]*",
+    # literal windows of high bytes: 4, 5 and 8 bytes (window filters), alternations of them, with a prefix / suffix
+    "\x80\x81\x82\x83", "\xe0\xe1\xe2\xe0\xe1", "\x80\x81\x82\x83\x84\x85\x86\x87", "\xff\xfe\xfd\xfc\xfb\xfa\xf9\xf8", "\xe9\xe9\xe9\xe9\xe9\xe9",
+    "\x80\x81\x82\x83|\xff\xfe\xfd\xfc", "a\xe0\xe1\xe2\xe0|b\xe1\xe2\xe0\xe1", "[ab]\x80\x81\x82\x83", "\x80\x81\x82\x83[ab]", "x+\xe9\xe9\xe9\xe9", "\xe9\xe9\xe9\xe9x*",
+    "(\x80\x81){2,3}", "\xa9\x29\x69\xe9", "i\xe9i\xe9i\xe9i\xe9", "\xf0\xb0\xf0\xb0|0909",
+    # \xHH escapes (hex letters are mis-decoded by the reference: kept, whatever it answers)
+    "\\x80", "\\xe9+", "\\xff", "[\\x80-\\x8f]",
+]
+
+
+def gen_highbyte(ref: RefProc, seed=20260928):
+    rng = random.Random(seed)
+    out = []
+    bad = 0
+
+    def text_of(alphabet, n, plant=()):
+        t = [rng.choice(alphabet) for _ in range(n)]
+        for p in plant:
+            if n > len(p):
+                at = rng.randrange(0, n - len(p) + 1)
+                t[at:at + len(p)] = list(p)
+        return "".join(t)
+
+    def add(rx, text):
+        nonlocal bad
+        rxb, txb = rx.encode("latin1"), text.encode("latin1")
+        allm = ref.call("all", rxb, txb, timeout=10.0)
+        if not isinstance(allm, list):
+            bad += 1
+            return
+        full = ref.call("full", rxb, txb, timeout=10.0)
+        if full not in (0, 1):
+            bad += 1
+            return
+        # (texts as base64: a high byte costs six characters as a JSON escape; long match lists as count + digest)
+        v = dict(regex=rx, text_b64=base64.b64encode(txb).decode("ascii"), ref_full=full)
+        if len(allm) > 100:
+            v["ref_digest"] = dict(count=len(allm), sha256=hashlib.sha256(repr([tuple(p) for p in allm]).encode()).hexdigest())
+        else:
+            v["ref_all"] = pairs(allm)
+        out.append(v)
+
+    every_byte = "".join(chr(c) for c in range(256))
+    for rx in HIGH_PATTERNS:
+        # what a literal of the pattern looks like, planted into the random texts (patterns of literals and classes)
+        lits = [m for m in re.findall(r"(?:[^\\\[\]()|*+?{}.^$]){2,}", rx)]
+        add(rx, every_byte)
+        add(rx, every_byte[::-1] * 2)
+        for k, alphabet in enumerate(rng.sample(ALPHABETS_HI, 3)):
+            for n in (0, 1, 9, 33, 200) + ((1100,) if k < 2 else (5000,)):
+                add(rx, text_of(alphabet, n, plant=[rng.choice(lits) for _ in range(n // 40)] if lits else ()))
+    # random patterns over the high alphabets (the generator of gen_fuzz; its brackets then hold high bytes and signed ranges)
+    want = len(out) + 700
+    while len(out) < want:
+        alphabet = rng.choice(ALPHABETS_HI)
+        gen_alphabet = alphabet.replace("\x00", "")      # (a C string: no NUL in the pattern)
+        rx = RegexGen(rng, gen_alphabet).alt(2)
+        n = rng.choice([0, 1, 3, 8, 17, 33, 64, 100, 300, 1000])
+        add(rx, text_of(alphabet, n))
+    with_high = sum(1 for v in out if any(ord(c) >= 0x80 for c in v["regex"]) or any(c >= 0x80 for c in base64.b64decode(v["text_b64"])))
+    print(f"highbyte: {len(out)} vectors ({with_high} with a byte >= 0x80), {bad} skipped (reference crashed / timed out / parse error)")
+    return out
+
+
 # --------------------------------------------------------------------------- the ring artefact
 ARTEFACT_PATTERNS = [".{0,2}.", "[a-f]+[0-9][a-f]", "(ab|ba)+", "[xy]+z[xy]", "x+yx", "(aa|aaa)+", "[a-z]+@[a-z]+", "^.{0,2}.",
                      "[ab]+b[ab]", "a+(b|ca)", ".{1,3}b", "(a|bc){1,3}d?", "[a-c]+d[a-c]*"]
@@ -484,7 +569,7 @@ def dump(name, obj):
 
 def main():
     ref = RefProc()
-    which = sys.argv[1:] or ["testcc", "semantics", "fuzz", "artefact", "bench"]
+    which = sys.argv[1:] or ["testcc", "semantics", "fuzz", "artefact", "highbyte", "bench"]
     if "testcc" in which:
         dump("testcc_vectors.json", gen_testcc(ref))
     if "semantics" in which:
@@ -493,6 +578,8 @@ def main():
         dump("fuzz_vectors.json", gen_fuzz(ref))
     if "artefact" in which:
         dump("artefact_vectors.json", gen_artefact(ref))
+    if "highbyte" in which:
+        dump("highbyte_vectors.json", gen_highbyte(ref))
     if "bench" in which:
         dump("bench_vectors.json", gen_bench(ref))
 

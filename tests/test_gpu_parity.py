@@ -65,6 +65,39 @@ def test_golden_vectors(rj, oracle):
     assert n > 2500
 
 
+def test_high_byte_vectors(rj):
+    """The HIP path on bytes >= 0x80 (half the byte range was unpinned): the 1900 high-byte vectors with the
+    real reference's outputs -- signed bracket ranges around 0x7f / 0x80, `.` / \\S / \\D / negated classes over Latin-1
+    and UTF-8 text, literal windows of high bytes (nibble filter, 2-bit codes: they alias ASCII bytes there), texts of up
+    to 5000 bytes so that the window and dense scans run, not only the small-text kernel."""
+    n = high = 0
+    for rx, tx, exp_all, exp_full in V.highbyte_cases():
+        p = prog(rj, rx)
+        got = p.match_all(tx)
+        assert got == exp_all, (rx, tx[:80], got[:5])
+        assert p.match_full(tx) == bool(exp_full), (rx, tx[:80])
+        high += any(c >= 0x80 for c in rx + tx)
+        n += 1
+    assert n >= 1800 and high >= 400
+
+
+def test_high_byte_vectors_device_text(rj):
+    """The same vectors through the device-text entry points with the small-text kernel OFF (texts >= 200 bytes): the
+    general pipeline -- window scans with the nibble filter, dense kernels, verify tails -- on high bytes."""
+    import torch
+    n = 0
+    for rx, tx, exp_all, exp_full in V.highbyte_cases():
+        if len(tx) < 200:
+            continue
+        sc = rj.Scan(prog(rj, rx))
+        t = torch.frombuffer(bytearray(tx), dtype=torch.uint8).cuda()
+        k = sc.run_tensor(t)
+        got = sc.spans()
+        assert got == exp_all and k == len(got), (rx, tx[:60], got[:5])
+        n += 1
+    assert n >= 400
+
+
 def test_ring_artefact_vectors(rj):
     """The engine against the REAL reference's outputs where its ring artefact applies (263 of these 840 vectors
     differ from the documented semantics): host-text calls, i.e. the small-text kernel handing over to the
@@ -83,11 +116,11 @@ def test_fresh_random_vs_oracle(rj, oracle):
     the GPU result must equal the strict restatement of the reference bit for bit."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
-    from make_golden import RegexGen, ALPHABETS
+    from make_golden import RegexGen, ALPHABETS, ALPHABETS_HI
     rng = random.Random(4242)
     checked = exact = 0
-    for _ in range(1500):
-        alphabet = rng.choice(ALPHABETS)
+    for it in range(2100):
+        alphabet = rng.choice(ALPHABETS if it < 1500 else [a.replace("\x00", "") for a in ALPHABETS_HI])   # (then: bytes >= 0x80)
         rx = RegexGen(rng, alphabet).alt(2).encode("latin1")
         text = "".join(rng.choice(alphabet) for _ in range(rng.choice([5, 40, 150, 400]))).encode("latin1")
         want = oracle.match_all(rx, text)
@@ -97,7 +130,7 @@ def test_fresh_random_vs_oracle(rj, oracle):
         assert got == want, (rx, text)
         exact += want != oracle.match_all_spec(rx, text)
         checked += 1
-    assert checked > 1400
+    assert checked > 2000
     assert exact > 0   # the artefact does occur in this sample, and is reproduced
 
 
@@ -108,11 +141,11 @@ def test_fresh_random_multi_chunk_vs_oracle(rj, oracle):
     thousands of these; a lost pair of matches at every chunk edge was found that way.)"""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
-    from make_golden import RegexGen, ALPHABETS
+    from make_golden import RegexGen, ALPHABETS, ALPHABETS_HI
     rng = random.Random(90125)
     checked = 0
-    for _ in range(500):
-        alphabet = rng.choice(ALPHABETS)
+    for it in range(800):
+        alphabet = rng.choice(ALPHABETS if it < 500 else [a.replace("\x00", "") for a in ALPHABETS_HI])   # (then: bytes >= 0x80)
         rx = RegexGen(rng, alphabet).alt(2).encode("latin1")
         n = rng.choice([1500, 2047, 2048, 2053, 3100, 4096, 5000])
         text = "".join(rng.choice(alphabet) for _ in range(n)).encode("latin1")
@@ -121,7 +154,7 @@ def test_fresh_random_multi_chunk_vs_oracle(rj, oracle):
             continue
         assert prog(rj, rx).match_all(text) == want, (rx, n)
         checked += 1
-    assert checked > 450
+    assert checked > 720
 
 
 def test_testcc_expectations(rj):

@@ -80,7 +80,24 @@ def test_all_vectors_match_reference(pe):
         assert pe.pe_match_full(rx, tx, len(tx)) == exp_full, (rx, tx)
         n += 1
     assert n > 2500
-    assert q8 <= 19, q8   # 19 of 2500 fuzz vectors; none of the test.cc-derived vectors
+    assert q8 <= 25, q8   # 19 of the 2500 fuzz vectors (+ a few of the short high-byte ones); none of the test.cc-derived vectors
+
+
+def test_high_byte_vectors_match_reference(pe):
+    """The lowering (parser's signed bracket ranges, class tables, window plans over bytes >= 0x80) + the CPU mirror of
+    the device pipeline against the real reference's outputs on the high-byte vectors (texts up to 5000 bytes)."""
+    oracle = Oracle()
+    n = q8 = 0
+    for rx, tx, exp_all, exp_full in V.highbyte_cases():
+        got = match_all(pe, rx, tx)
+        if got != exp_all:
+            spec = oracle.match_all_spec(rx, tx)      # (the ring artefact: documented semantics != reference)
+            assert spec != exp_all and got == spec, (rx, tx[:80], got if isinstance(got, int) else got[:5])
+            q8 += 1
+        assert pe.pe_match_full(rx, tx, len(tx)) == exp_full, (rx, tx[:80])
+        n += 1
+    assert n >= 1800
+    assert q8 <= 40, q8
 
 
 def test_parse_errors(pe):

@@ -57,6 +57,19 @@ def test_against_reference_outputs(oracle):
     assert n > 2500
 
 
+def test_high_byte_vectors(oracle):
+    """Bytes >= 0x80 in patterns and texts -- signed bracket ranges (reference src/x64/codegen-x64.cc:902-907), `.` / \\S /
+    \\D / negations over Latin-1 and UTF-8 text, literals of high bytes -- against the real reference's outputs
+    (tests/golden/make_golden.py highbyte: 1900 vectors, 1800 of them with such a byte)."""
+    n = high = 0
+    for rx, tx, exp_all, exp_full in V.highbyte_cases():
+        assert oracle.match_all(rx, tx) == exp_all, (rx, tx[:80])
+        assert oracle.match_full(rx, tx) == exp_full, (rx, tx[:80])
+        high += any(c >= 0x80 for c in rx + tx)
+        n += 1
+    assert n >= 1800 and high >= 400
+
+
 def test_ring_artefact_vectors(oracle):
     """The oracle is the REFERENCE's loop, artefact included: 840 vectors on which the reference's ring artefact
      applies or nearly applies -- on 263 of them the reference differs from the documented
