@@ -155,10 +155,16 @@ void run_shard(const rj_program* prog, int shard, const char* text, size_t n, ui
     out->error = "no replica of the program on device " + std::to_string(dev);
     return;
   }
-  const uint64_t vis_lo = lo > 64 ? (lo - 64) & ~static_cast<uint64_t>(15) : 0;
-  // (max_len == ~0: a pattern at risk of the ring artefact -- its range owns whole segments between synchronisation points of
-  // the reference's loop, which the engine looks for in the buffer it is given: the shard sees the text up to its end)
-  const uint64_t vis_hi = max_len == ~0ull ? n : std::min<uint64_t>(n, hi + max_len);
+  // max_len == ~0: a pattern at risk of the ring artefact -- its range owns whole segments between synchronisation points of
+  // the reference's loop, which the engine looks for IN THE BUFFER IT IS GIVEN (exact_replay.hip: the points proven on the
+  // buffer's own 1-KiB chunk grid, its first chunk taken to start with nothing alive).  Two neighbours only agree on the
+  // point that separates them when they look at the same buffer: every shard gets the WHOLE text, as sharding.visible_range
+  // (whole_text) gives every rank.  (Round 4 gave shard r the text from its cut - 64 on: shard r looked for `cut` in a
+  // chunk with everything alive and ended later than shard r + 1, whose buffer began there with nothing alive, started --
+  // the matches in between came out twice.  ADVICE r04.)
+  const bool whole = max_len == ~0ull;
+  const uint64_t vis_lo = whole ? 0 : lo > 64 ? (lo - 64) & ~static_cast<uint64_t>(15) : 0;
+  const uint64_t vis_hi = whole ? n : std::min<uint64_t>(n, hi + max_len);
   const uint64_t local_n = vis_hi - vis_lo;
   uint64_t* spans = nullptr;
   const int64_t c = rj_match_range_host(rp, text + vis_lo, local_n, lo - vis_lo, std::min<uint64_t>(hi, n + 1) - vis_lo,
@@ -184,9 +190,9 @@ bool multi_device_match_all(const rj_program* prog, const char* text, size_t n, 
   if (shards < 2 || n < multi_device_min_bytes() || max_len == Program::kUnboundedLen || max_len > (1u << 20)) return false;
   // A pattern at risk of the ring artefact is sharded by SEGMENT ownership (round 4; one device before):
   // a range [lo, hi) owns the segments between synchronisation points of the reference's loop that begin in it, every shard
-  // gets the text from its range to the END (run_pipeline replays the reference's loop over the owned segments), the shards'
-  // results concatenate to the reference's answer and no carry crosses a cut.  More bytes over PCIe (shard r uploads the
-  // text from its cut on), all of them in parallel.
+  // gets the WHOLE text (run_shard: one buffer, one set of points for everybody; run_pipeline replays the reference's loop
+  // over the owned segments only), the shards' results concatenate to the reference's answer and no carry crosses a cut.
+  // More bytes over PCIe (every shard uploads the text), all of them in parallel.
   const bool to_the_end = prog->host->q8_risk;
   const uint64_t halo = to_the_end ? ~0ull : max_len;
   // contiguous ranges of starts, cut at multiples of 4096; the last one owns the start n (the empty match at the end)

@@ -25,6 +25,23 @@ text = bytes(rng.choices(b"aabbcx\n regexp", k=3_000_000)) + b"aaaa" * 1000
 for rx in [b"regexp", b"aa", b"ab|bcx", b"a{1,3}", b"^a", b"b$", b"(ab|ba)x?", b"[ab]{2,5}c", b"x", b"$", b".{0,2}.", b"[ab]{1,3}[ab]", b"(a|ab)(c|bcx)"]:
     p = rejit_amd.Program(rx)
     out[rx.decode()] = p.match_all(text)
+# Where the synchronisation points of the reference's loop lie depends on what is alive (ADVICE r04): a run of [ab] that
+# begins a few bytes before a shard's buffer would begin (cuts are multiples of 4096; round 4 gave a shard its text from
+# cut - 64 on) and crosses the cut makes `[ab]{1,3}[ab]` match every 4 bytes IN PHASE WITH THE RUN'S BEGIN; a shard that
+# took its buffer's first byte for a point found the phase of ITS buffer, and the two neighbours disagreed on the segment
+# at the cut (matches twice, or shifted).  Also: a point exactly at a cut with a match beginning there.
+seg = bytearray(rng.choices(b"abx", k=1_200_000))
+for k, cut in enumerate(range(4096, len(seg) - 4096, 4096)):
+    if k %% 2:
+        begin = cut - 64 - rng.choice([1, 2, 3, 5, 6, 7, 9, 30, 31, 33])
+        seg[begin - 1] = ord("x")
+        seg[begin:cut + 300] = bytes(rng.choices(b"ab", k=cut + 300 - begin))
+    else:
+        seg[cut - 1] = ord("x")
+        seg[cut:cut + 3] = rng.choice([b"aba", b"abb", b"bab"])
+seg = bytes(seg)
+for rx in [b"[ab]{1,3}[ab]", b".{0,2}.", b"(ab|ba)+", b"[ab]{2}[ab]?"]:
+    out["cut:" + rx.decode()] = rejit_amd.Program(rx).match_all(seg)
 files = [bytes(rng.choices(b"ab regexp\n", k=rng.choice([0, 5, 300, 4000, 70000]))) for _ in range(200)]
 p = rejit_amd.Program(b"regexp|^a")
 out["batch"] = p.match_all_batch(files)
