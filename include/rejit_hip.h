@@ -161,6 +161,11 @@ int64_t rj_scan_copy_spans(const rj_scan* scan, uint64_t* host_spans, uint64_t c
 int64_t rj_scan_replace(rj_scan* scan, const void* d_text, uint64_t n, const char* with, uint64_t with_len, void* d_out,
                         uint64_t out_cap, void* hip_stream);
 int rj_scan_stats(const rj_scan* scan, rj_stats* stats);
+/* rj_stats has grown (stream_path, slow_starts: round 4) and may grow again: rj_scan_stats writes sizeof(rj_stats) of the
+ * header the LIBRARY was built from.  A caller that may meet a newer library passes the size of ITS struct: at most
+ * struct_size bytes are written; returns the library's sizeof(rj_stats) (> struct_size: fields the caller does not know
+ * were left out) or rj_status. */
+int rj_scan_stats_sized(const rj_scan* scan, void* stats, size_t struct_size);
 /* 1 / 0 / <0: kMatchFull over device text */
 int rj_scan_match_full(rj_scan* scan, const void* d_text, uint64_t n, void* hip_stream);
 
@@ -274,6 +279,9 @@ typedef int (*rj_gatherv_fn)(void* ctx, const void* d_send, uint64_t send_bytes,
 int64_t rj_scan_gather_spans_via(rj_scan* scan, const void* d_text, uint64_t n, uint64_t own_begin, uint64_t own_end, int64_t offset,
                                  rj_allgather_fn allgather, rj_gatherv_fn gatherv, void* ctx, int rank, int world, int root, void* hip_stream);
 const uint64_t* rj_scan_gathered_spans(const rj_scan* scan, uint64_t* count);
+/* a copy of that list (host_spans: host or device memory, cap pairs at most); returns the number of pairs gathered (0 on a
+ * rank that is not the root) or rj_status */
+int64_t rj_scan_copy_gathered_spans(const rj_scan* scan, uint64_t* host_spans, uint64_t cap);
 /* mode 0 (default): fuse when possible; mode 1: never fuse -- every pattern scans the whole text on its own,
  * all of them in ONE launch when the patterns have the regexdna shape (scan_windows_train), else one kernel
  * per pattern back to back on the caller's stream; mode 2: one kernel per pattern, alternating between the

@@ -155,7 +155,7 @@ C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_er
                  "rj_multi_bounds", "rj_batch_separator", "rj_match_all_packed", "rj_host_alloc", "rj_host_free",
                  "rj_multi_bounds_device", "rj_carry_decide", "rj_multi_start", "rj_multi_finish", "rj_multi_order_after",
                  "rj_multi_device_counts", "rj_multi_device_counts_via", "rj_multi_set_tail_stream", "rj_multi_set_timing", "rj_scan_set_timing", "rj_set_default_timing",
-                 "rj_scan_gather_spans", "rj_scan_gather_spans_via", "rj_scan_gathered_spans", "rj_multi_set_counts_only", "rj_stream_read_probe"]
+                 "rj_scan_gather_spans", "rj_scan_gather_spans_via", "rj_scan_gathered_spans", "rj_multi_set_counts_only", "rj_stream_read_probe", "rj_scan_stats_sized", "rj_scan_copy_gathered_spans"]
 
 
 def load_library():
@@ -203,6 +203,9 @@ def load_library():
     L.rj_multi_set_tail_stream.argtypes = [vp, ctypes.c_int]
     L.rj_multi_set_timing.argtypes = [vp, ctypes.c_int]
     L.rj_multi_set_counts_only.argtypes = [vp, ctypes.c_int]
+    L.rj_scan_stats_sized.argtypes = [vp, vp, sz]
+    L.rj_scan_copy_gathered_spans.restype = i64
+    L.rj_scan_copy_gathered_spans.argtypes = [vp, _u64p, u64]
     L.rj_stream_read_probe.restype = ctypes.c_float
     L.rj_stream_read_probe.argtypes = [vp, u64, ctypes.c_int, vp]
     L.rj_scan_set_timing.argtypes = [vp, ctypes.c_int]
@@ -424,13 +427,12 @@ class Scan:
         ptr = self._lib.rj_scan_gathered_spans(self._h, ctypes.byref(cnt))
         if not ptr:
             return int(total), None
-        import torch
-        host = torch.empty(2 * int(cnt.value), dtype=torch.int64)
-        if cnt.value:
-            hip = ctypes.CDLL("libamdhip64.so.7")
-            hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-            assert hip.hipMemcpy(ctypes.c_void_p(host.data_ptr()), ctypes.c_void_p(ptr), 16 * int(cnt.value), 2) == 0   # DeviceToHost
-        v = host.tolist()
+        k = int(cnt.value)
+        buf = (ctypes.c_uint64 * max(2 * k, 1))()
+        got = _check(self._lib.rj_scan_copy_gathered_spans(self._h, buf, k))   # (through the library: no HIP binding of our own)
+        if got != k:
+            raise RejitError(-3, "rj_scan_copy_gathered_spans returned %d pairs, %d were gathered" % (got, k))
+        v = list(buf)
         return int(total), [(v[2 * i], v[2 * i + 1]) for i in range(int(cnt.value))]
 
     def start(self, d_text_ptr: int, n: int, stream: int = 0) -> None:

@@ -39,7 +39,7 @@ constexpr uint64_t kIter = 2048;                    // bytes per wave iteration:
 constexpr int kTileIters = 16;
 constexpr uint64_t kTile = kIter * kTileIters;      // 32 KiB: a wave's tile (four of them are a unit of the prefix scan)
 constexpr uint32_t kStage = 640;                    // staged pairs per wave and stage (two stages: 20 KiB per workgroup)
-constexpr uint32_t kLenBits = 17;                   // staged entry: begin - tile start (15 bits) << 17 | length
+constexpr uint32_t kLenBits = 17;                   // staged entry: begin - tile start (15 bits) << 17 | length (engine.hip caps max_walk below 2^17)
 constexpr int kTilesPerTicket = 4;
 
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & (kWave - 1); }

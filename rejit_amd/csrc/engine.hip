@@ -486,7 +486,8 @@ static int run_streams(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t s
     return 1;
   }
   a.plan = rp->stream;
-  a.max_walk = rp->dev.max_walk;
+  // (a staged pair keeps its length in 17 bits, dense_streams.hip: a longer walk must void the run, not wrap into the begin)
+  a.max_walk = std::min<uint32_t>(rp->dev.max_walk, (1u << 17) - 1u);
   uint64_t cap = std::max<uint64_t>(s->hits_hint + s->hits_hint / 8 + 1024, (se - sb) / 64 + 1024);
   RJ_HIP(s->scan_a.reserve(stream_scratch_bytes(a.n_tiles)));
   for (int attempt = 0; attempt < 3; attempt++) {
@@ -1224,6 +1225,18 @@ int64_t rj_scan_copy_spans(const rj_scan* s, uint64_t* host_spans, uint64_t cap)
   return static_cast<int64_t>(s->result_count);
 }
 
+int64_t rj_scan_copy_gathered_spans(const rj_scan* s, uint64_t* host_spans, uint64_t cap) {
+  ErrnoGuard errno_guard;
+  if (!s) return fail(RJ_BAD_ARGUMENT, "null scan");
+  if (!s->gathered) return 0;   // (not the root, or no gather yet)
+  const uint64_t k = std::min<uint64_t>(cap, s->gathered_count);
+  if (k) {
+    if (!host_spans) return fail(RJ_BAD_ARGUMENT, "null argument");
+    RJ_HIP(hipMemcpy(host_spans, s->gathered, k * 2 * sizeof(uint64_t), hipMemcpyDefault));
+  }
+  return static_cast<int64_t>(s->gathered_count);
+}
+
 int64_t rj_scan_replace(rj_scan* s, const void* d_text, uint64_t n, const char* with, uint64_t with_len, void* d_out,
                         uint64_t out_cap, void* hip_stream) {
   ErrnoGuard errno_guard;
@@ -1263,6 +1276,12 @@ int rj_scan_stats(const rj_scan* s, rj_stats* stats) {
   if (!s || !stats) return fail(RJ_BAD_ARGUMENT, "null argument");
   *stats = s->stats;
   return RJ_OK;
+}
+
+int rj_scan_stats_sized(const rj_scan* s, void* stats, size_t struct_size) {
+  if (!s || !stats) return fail(RJ_BAD_ARGUMENT, "null argument");
+  memcpy(stats, &s->stats, std::min(struct_size, sizeof(rj_stats)));   // (a caller built against an older header gets its own fields)
+  return static_cast<int>(sizeof(rj_stats));
 }
 
 int rj_scan_match_full(rj_scan* s, const void* d_text, uint64_t n, void* hip_stream) {

@@ -328,10 +328,12 @@ class CarryExchange:
 def _rerun_empty(rerun_one, i):
     # (a carry that went back to "no earlier match": select again from an empty carry -- have = False when the callback
     # takes the flag)
+    import inspect
     try:
-        return rerun_one(i, 0, 0, False)
-    except TypeError:
-        return rerun_one(i, 0, 0)
+        n_params = len(inspect.signature(rerun_one).parameters)
+    except (TypeError, ValueError):     # (a callable without a signature: take the current form)
+        n_params = 4
+    return rerun_one(i, 0, 0, False) if n_params >= 4 else rerun_one(i, 0, 0)
 
 
 def _device_for(dist):
