@@ -477,6 +477,37 @@ def run_regexdna(args, c):
                                                  "counts_equal_headline": cp == counts,
                                                  "headline_ms_per_step_in_this_process": round(elapsed / args.steps * 1e3, 4)}}))
         return None, False
+    # Absolute match latency at N ranks (BASELINE's north star: "GB/s scan throughput and absolute match latency reported
+    # at 1/2/4/8 GPUs"): ten synchronous steps -- one rj_multi_run over the rank's shard, then the exchange -- timed on every
+    # rank, the shard's run and the exchange apart; rank 0 reports every rank's medians.  (A step of the timed loop above
+    # overlaps these with the next step's kernels; this is what ONE call costs.)
+    per_rank = None
+    if use_multi and world > 1:
+        lat_multi = rejit_amd.MultiScan(progs)
+        lat_multi.set_mode(0)
+        if counts_headline:
+            lat_multi.set_counts_only(True)
+
+        def rerun_lat(i, cur, prev_end, have):
+            lat_multi.scan(i).run(text_ptr, n_local, own_begin=own_lo, own_end=own_hi, carry_cur=cur, carry_prev_end=prev_end,
+                                  have_prev=have, stream=stream)
+        t_run, t_xch, lat_counts = [], [], None
+        for it in range(12):
+            barrier(c)
+            t0 = time.perf_counter()
+            lat_multi.run(text_ptr, n_local, stream=stream, own_begin=own_lo, own_end=own_hi)
+            t1 = time.perf_counter()
+            lat_counts = exchange.counts(lat_multi, lambda: None, rerun_lat, vis_lo, stream)
+            t2 = time.perf_counter()
+            if it >= 2:
+                t_run.append(t1 - t0)
+                t_xch.append(t2 - t1)
+        assert lat_counts == counts, (lat_counts, counts)
+        mine = torch.tensor([sorted(t_run)[len(t_run) // 2] * 1e3, sorted(t_xch)[len(t_xch) // 2] * 1e3], dtype=torch.float64, device=c.cdev)
+        allr = [torch.zeros(2, dtype=torch.float64, device=c.cdev) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "shard_run_ms": round(float(v[0]), 4), "exchange_ms": round(float(v[1]), 4)} for r, v in enumerate(allr)]
+        del lat_multi
     total_matches = int(sum(counts))
     scanned = len(patterns) * n_total * args.steps          # bytes of text scanned by the whole job
     avg_scan_ms = sum(scan_ms) / max(len(scan_ms), 1)
@@ -492,6 +523,11 @@ def run_regexdna(args, c):
                                ("rj_multi_start / rj_multi_finish, mode 0, %d steps in flight on rj_multi objects on one stream%s: one pass over the text for the nine patterns (plane_scan) + classify + gather per step"
                                 % (max(2, args.in_flight), "" if args.one_stream else ", each run's tails on a stream of the object's own (rj_multi_set_tail_stream)"))) if use_multi else "9 x rj_scan_run per step",
                      "before_the_timed_region": "the same loop untimed for --settle-ms = %g ms (device clocks: `cold_ms_per_step` is K steps straight after the set-up), then W warm-up steps" % args.settle_ms})
+    if per_rank is not None:
+        out["latency"] = {"what": "one synchronous call per rank: rj_multi_run over the rank's shard (median of 10), then the carry exchange "
+                                  "(rows written by a kernel, one all_gather of 8 integers per pattern, decision kernel, one synchronise)",
+                          "latency_ms": round(max(r["shard_run_ms"] + r["exchange_ms"] for r in per_rank), 4),
+                          "per_rank": per_rank}
     out["matches_per_s"] = round(total_matches * args.steps / elapsed, 1)
     out["matches_per_pass"] = counts
     # the physical rate of a step: every text byte crosses the HBM interface ONCE per step whatever the number of patterns

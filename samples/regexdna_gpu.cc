@@ -123,6 +123,7 @@ int main(int argc, char** argv) {
   // ---- the nine counts: one pass over the sequence, queued on its own stream ...
   rj_multi* multi = nullptr;
   if (rj_multi_create(P.count, kN, &multi) != RJ_OK) die("multi");
+  (void)rj_multi_set_counts_only(multi, 1);   // regexdna asks MatchAllCount: scan + classification + counts in one kernel (plane_count.hip)
   uint64_t counts[kN] = {};
   if (serial) {
     if (rj_multi_run(multi, d_a, static_cast<uint64_t>(seq_size), counts, s_main) < 0) die("counts");

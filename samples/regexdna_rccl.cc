@@ -79,6 +79,7 @@ void run_rank(int rank, int world, ncclComm_t comm, const char* seq, uint64_t n,
     return;
   }
   // one pass over the shard for all nine patterns, then the exchange: every rank gets the counts over the WHOLE text
+  (void)rj_multi_set_counts_only(multi, 1);   // counts are all that is asked: one kernel per shard, rows of the exchange from its first / last match
   const int how = rj_multi_device_counts(multi, d_text, n_local, own_b - lo, std::min(own_e, n + 1) - lo, static_cast<int64_t>(lo), comm, rank,
                                          world, out->counts, stream);
   if (how < 0) {
