@@ -51,6 +51,8 @@ j = {"source": f"profiles/{tag}_pmc_hbm_traffic.txt",
              "run at two text sizes in the profiled command take the min / max launch"}
 FASTA = 500000000  # bytes of the stripped 50 M-base FASTA input (workloads.fasta_stripped_size)
 for key, prefix, nbytes, extra in (
+        ("plane_count", "plane_count<2>", FASTA, {"fasta_n": 50000000}),
+        ("plane_count_2p5gb", "plane_count<2>", 2500000000, {}),
         ("plane", "plane_scan<2>", FASTA, {"fasta_n": 50000000}),
         ("plane_2p5gb", "plane_scan<2>", 2500000000, {}),
         ("regexdna_single", "scan_windows<2, true, true, false, true>", FASTA, {"fasta_n": 50000000}),
@@ -75,7 +77,7 @@ open(P("bench_kernel_stats.txt"), "w").write(
     "# rocprofv3 --kernel-trace --stats -- python bench.py --no-extra --no-cpu-baseline   (MI355X)\n"
     "# = the headline run alone (default K/W; the extras and the CPU sample left out so that the per-kernel averages are\n"
     "# those of the timed region); summarised from the rocpd database by tools/rocpd_stats.py.  The un-profiled bench line\n"
-    f"# (profiles/{tag}_bench_line.json) reports roofline.avg_launch_ms, which agrees with plane_scan<2> avg_us below\n"
+    f"# (profiles/{tag}_bench_line.json) reports roofline.avg_launch_ms, which agrees with plane_count<2> avg_us below\n"
     "# (under the profiler the dispatch-timestamp time reads a few % higher):\n# " + prof_line + "\n" + open(g("kernel_stats.txt")).read())
 open(P("bench_full_kernel_stats.txt"), "w").write(
     "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 5 --jrep-files 5000 --jrep-bytes 500000000   (MI355X):\n"
