@@ -626,6 +626,46 @@ def run_regexdna(args, c):
                                  "roofline": hbm_roofline("plane_scan<2> inside that loop", own_bytes, sum(l_times) / max(len(l_times), 1),
                                                           pmc_traffic("plane", fasta_n=args.fasta_n), len(l_times))}
             out["step_variants_ms"]["span_lists"] = out["span_lists"]["ms_per_step"]
+            # Throughput with the scan kernels of consecutive steps OVERLAPPING: four rj_multi objects, a stream each, no order
+            # between them -- a caller with several texts in flight.  The next kernels' workgroups fill the wave slots that a
+            # kernel's last workgroups and the launch ramp leave idle (the 500 MB kernel loses ~13 us to them when it runs
+            # alone).  Not the headline: a kernel's own duration is then no roofline input (several share the device).
+            ov_depth = 4
+            ov = [rejit_amd.MultiScan(progs) for _ in range(ov_depth)]
+            ov_streams = [torch.cuda.Stream(dev) for _ in range(ov_depth)]
+            for mm in ov:
+                assert mm.set_counts_only(True)
+                mm.set_timing(False)
+            ov_state = {"k": 0, "busy": [False] * ov_depth}
+
+            def ov_step(record):
+                j = ov_state["k"] % ov_depth
+                ov_state["k"] += 1
+                res = ov[j].finish() if ov_state["busy"][j] else None
+                ov[j].start(text_ptr, n_local, stream=ov_streams[j].cuda_stream, own_begin=own_lo, own_end=own_hi)
+                ov_state["busy"][j] = True
+                return res
+
+            def ov_drain():
+                res = None
+                for j in [(ov_state["k"] + d) % ov_depth for d in range(ov_depth)]:
+                    if ov_state["busy"][j]:
+                        res = ov[j].finish()
+                        ov_state["busy"][j] = False
+                return res
+
+            for _ in range(40):
+                ov_step(False)
+            ov_drain()
+            eov, cov = timed(c, args, ov_step, ov_drain)
+            assert cov == counts, (cov, counts)
+            out["overlapped_scans"] = {"calls": "%d rj_multi objects (counts only), a stream each, no order between their kernels: the scan kernels of consecutive steps overlap" % ov_depth,
+                                       "ms_per_step": round(eov / args.steps * 1e3, 4),
+                                       "physical_GBps": round(n_total * args.steps / eov / 1e9, 1),
+                                       "step_frac": round(n_total * args.steps / eov / 1e9 / HBM_PEAK_GBS, 4),
+                                       "value": round(len(patterns) * n_total * args.steps / eov / 1e9, 3), "unit": "GB/s"}
+            out["step_variants_ms"]["overlapped_scans"] = out["overlapped_scans"]["ms_per_step"]
+            del ov, ov_streams
             if not args.time_all_launches:
                 a_step, a_drain, a_times = two_in_flight(False, time_all=True, counts_only=True)
                 ea, ca = timed(c, args, a_step, a_drain)

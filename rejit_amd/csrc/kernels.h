@@ -208,7 +208,7 @@ struct PlaneCountParams {
   uint32_t code_shift, n_bases, n_patterns;
   uint32_t edge_waves;   // the first and the last edge_waves waves of the grid record their first / last match per pattern
   uint32_t batch_at;     // a wave classifies what its ring holds (<= 64 at a time) when that many are waiting, 1..64
-  uint32_t lo[2][8], hi[2][8];       // as PlaneParams
+  uint32_t mask_bits;    // bit 16 b + 2 i / + 1: the low / high bit of the symbol code of base b's window byte i is 0
   uint32_t base_lo[2], base_hi[2];   // the bases' 8 bytes (ExactCountPlan)
   const uint32_t* table;             // ExactCountPlan::table in device memory
   unsigned long long* acc;

@@ -884,8 +884,8 @@ int run_counts(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint
       const uint32_t bb = b < m->plane.n_bases ? b : 0;
       for (int i = 0; i < 8; i++) {
         const uint32_t code = (static_cast<uint32_t>(m->plane.base[bb][i]) >> m->plane.code_shift) & 3u;
-        pc.lo[b][i] = (code & 1u) ? 0u : ~0u;
-        pc.hi[b][i] = (code & 2u) ? 0u : ~0u;
+        if (!(code & 1u)) pc.mask_bits |= 1u << (16 * b + 2 * i);
+        if (!(code & 2u)) pc.mask_bits |= 1u << (16 * b + 2 * i + 1);
       }
       pc.base_lo[b] = m->exact.base_lo[bb];
       pc.base_hi[b] = m->exact.base_hi[bb];

@@ -112,6 +112,12 @@ __device__ __forceinline__ uint32_t plane_test(uint32_t ta, uint32_t tb, uint32_
   const uint32_t H = ((ta >> 1) & kEven) | (tb & ~kEven);
   const uint32_t Ln = (tb & kEven) | ((hb << 1) & ~kEven);   // what follows the first half is the second half
   const uint32_t Hn = ((tb >> 1) & kEven) | (hb & ~kEven);
+  // The 32 masks (base b, window byte i: all ones when the low / high bit of its symbol code is 0) live as BITS of one
+  // scalar register and are widened where they are used (a scalar sign-extension each; the scalar unit has time): as 32
+  // registers they took the kernel to 106 SGPRs -- 7 waves per SIMD instead of 8, and spills.  (The empty asm keeps the
+  // compiler from widening them all ahead of the loop again.)
+  uint32_t bits = a.mask_bits;
+  asm volatile("" : "+s"(bits));
   uint32_t Z[NB], O[NB];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -119,7 +125,9 @@ __device__ __forceinline__ uint32_t plane_test(uint32_t ta, uint32_t tb, uint32_
     const uint32_t Hi = i ? __builtin_amdgcn_alignbit(Hn, H, 2 * i) : H;
 #pragma unroll
     for (int b = 0; b < NB; b++) {
-      const uint32_t E = (Li ^ a.lo[b][i]) & (Hi ^ a.hi[b][i]);
+      const uint32_t lo = static_cast<uint32_t>(static_cast<int32_t>(bits << (31 - (16 * b + 2 * i))) >> 31);
+      const uint32_t hi = static_cast<uint32_t>(static_cast<int32_t>(bits << (31 - (16 * b + 2 * i + 1))) >> 31);
+      const uint32_t E = (Li ^ lo) & (Hi ^ hi);
       if (i == 0) {
         Z[b] = E;
       } else if (i == 1) {
