@@ -13,6 +13,7 @@ import os
 import sys
 import time
 
+_T_PROCESS = time.perf_counter()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
@@ -25,13 +26,16 @@ def main():
     import torch
     import rejit_amd
     from rejit_amd import workloads as W
+    t_imports = time.perf_counter() - _T_PROCESS
 
     dev = torch.device("cuda:0")
+    t_in = time.perf_counter()
     raw_host = W.fasta_raw_numpy(args.n) if args.n else np.frombuffer(sys.stdin.buffer.read(), dtype=np.uint8)
+    t_read = time.perf_counter() - t_in
     t0 = time.perf_counter()
     text = torch.from_numpy(np.ascontiguousarray(raw_host)).to(dev)
     torch.cuda.synchronize()
-    t_up = time.perf_counter() - t0
+    t_up = time.perf_counter() - t0    # (the first device call of the process: includes the HIP context)
     stream = torch.cuda.current_stream(dev).cuda_stream
     raw_size = int(text.numel())
 
@@ -69,8 +73,9 @@ def main():
     print("\n".join(lines))
     print("\n%d\n%d\n%d" % (raw_size, text_size, n))
     if args.timing:
-        print("upload %.3f s, device pipeline (strip + 9 counts + 11 replaces) %.3f s" % (t_up, t_dev), file=sys.stderr)
         print("; ".join(phases), file=sys.stderr)
+        print("imports (numpy, torch, rejit_amd) %.3f s, input %.3f s, HIP context + upload %.3f s, device pipeline (strip + 9 counts + 11 replaces) %.3f s"
+              % (t_imports, t_read, t_up, t_dev), file=sys.stderr)
 
 
 if __name__ == "__main__":
