@@ -831,7 +831,8 @@ def run_regexdna(args, c):
         out["hbm_not_cache"] = {"workload": "the same nine patterns, one kernel per pattern (mode 3), over a 2.5 GB stripped FASTA (fasta_n 250M)",
                                 "value": round(9 * nb / (eb / args.steps) / 1e9, 3), "unit": "GB/s", "ms_per_step": round(eb / args.steps * 1e3, 4),
                                 "matches_per_pass": cb,
-                                "roofline": hbm_roofline("scan_windows<2,NIB>", nb, sum(ms2) / len(ms2), pmc_traffic("regexdna_single_2p5gb", bytes=nb), len(ms2))}
+                                "roofline": hbm_roofline("scan_windows<2,NIB>", nb, sum(ms2) / len(ms2), pmc_traffic("regexdna_single_2p5gb", bytes=nb), len(ms2),
+                                                         ceiling=hbm_ceiling(big.data_ptr(), nb, stream))}
         m0 = rejit_amd.MultiScan(progs)
         ms0 = []
 
@@ -846,7 +847,8 @@ def run_regexdna(args, c):
         out["one_pass_2p5gb"] = {"workload": "the headline's one-pass run over the same 2.5 GB text",
                                  "value": round(9 * nb / (e0 / args.steps) / 1e9, 3), "unit": "GB/s",
                                  "ms_per_step": round(e0 / args.steps * 1e3, 4),
-                                 "roofline": hbm_roofline("plane_scan<2>", nb, sum(ms0) / len(ms0), pmc_traffic("plane_2p5gb", bytes=nb), len(ms0))}
+                                 "roofline": hbm_roofline("plane_scan<2>", nb, sum(ms0) / len(ms0), pmc_traffic("plane_2p5gb", bytes=nb), len(ms0),
+                                                          ceiling=hbm_ceiling(big.data_ptr(), nb, stream))}
         mc = rejit_amd.MultiScan(progs)
         assert mc.set_counts_only(True)
         msc = []
@@ -909,7 +911,8 @@ def single_pattern_extra(c, rejit_amd, t, n, rx, label, kernel, steps, check, tr
     rec = {"workload": label, "value": round(n / dt / 1e9, 1), "unit": "GB/s", "matches": int(cnt),
            "latency_ms": round(dt * 1e3, 4), "latency_ms_min": round(min(wall) * 1e3, 4), "latency_ms_max": round(max(wall) * 1e3, 4),
            "cold_call_ms": round(cold * 1e3, 3), "calls_timed": steps,
-           "roofline": hbm_roofline(kernel, n, a_ms, pmc_traffic(traffic_key, bytes=n) if traffic_key else None)}
+           "roofline": hbm_roofline(kernel, n, a_ms, pmc_traffic(traffic_key, bytes=n) if traffic_key else None,
+                                    ceiling=hbm_ceiling(t.data_ptr(), n, stream))}
     if cpu and args is not None and not args.no_cpu_baseline:
         big = min(n, 4 << 30)                       # all cores: 4 GiB of the text in disjoint slices
         host = t[:big].cpu().numpy().tobytes()
@@ -1024,7 +1027,7 @@ def literal_and_complex_extras(args, c, out):
         out["general_one_pass"] = {"workload": "%s over the same %d bytes in ONE pass (plane_scan_general: 4 exact base windows of 7 bytes, offsets 0 and 1; the kernel loops over the bases)" % (" + ".join(gset), n),
                                    "how": ghow, "counts": gcounts, "counts_equal_single_runs": gcounts == gsingle,
                                    "latency_ms": round(gmed * 1e3, 4), "value": round(n / gmed / 1e9, 1), "unit": "GB/s of text (once for both patterns)",
-                                   "roofline": hbm_roofline("plane_scan_general<exact>", n, sum(gms) / len(gms), None, len(gms))}
+                                   "roofline": hbm_roofline("plane_scan_general<exact>", n, sum(gms) / len(gms), None, len(gms), ceiling=hbm_ceiling(t.data_ptr(), n, c.stream))}
         del gmulti, gprogs
     except Exception as e:  # noqa: BLE001 (an extra must never cost the line)
         out["general_one_pass"] = {"error": repr(e)[:300]}
@@ -1076,7 +1079,8 @@ def literal_and_complex_extras(args, c, out):
                          "latency_ms": round(sorted(ltot)[len(ltot) // 2], 4), "latency_ms_min": round(min(ltot), 4), "cold_call_ms": round(cold_l * 1e3, 3),
                          "calls_timed": len(ltot), "write_bytes_per_launch": 16 * int(k),
                          "roofline": hbm_roofline("emit_assertions (one pass, prefix scan resolved a round late: n text bytes read + 16 B written per match)", bytes_l, a_l,
-                                                  pmc_traffic("line_table", bytes=n))}
+                                                  pmc_traffic("line_table", bytes=n), ceiling=hbm_ceiling(t.data_ptr(), n, c.stream))}
+    out["line_table"]["roofline"]["ceiling_note"] = "the ceiling is a READ-only kernel over the text; this kernel also writes 16 B per match"
     del t
     torch.cuda.empty_cache()
 

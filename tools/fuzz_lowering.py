@@ -9,7 +9,7 @@ import ctypes, os, random, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 from checkers import Oracle
-from make_golden import RegexGen, ALPHABETS
+from make_golden import RegexGen, ALPHABETS, ALPHABETS_HI
 
 CSRC = os.path.join(ROOT, "rejit_amd", "csrc")
 so = "/tmp/libprogram_exec_fuzz.so"
@@ -34,6 +34,8 @@ cases = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 rng = random.Random(seed)
 o = Oracle()
 ALPH = ALPHABETS + ["ab\n\r", "xyz ^$", "aA0-", "abcdefgh12 "]
+if os.environ.get("FUZZ_HIGH_BYTES"):   # round 5: alphabets with bytes >= 0x80 (signed bracket ranges, Latin-1 / UTF-8 text)
+    ALPH = [a.replace("\x00", "") for a in ALPHABETS_HI] + ["ab\x80\xff\n", "\xe9\xe8 ^$"]
 checked = bad = q8 = behind = too_large = 0
 t0 = time.time()
 for it in range(cases):
