@@ -90,9 +90,11 @@ struct Raw {
   uint4 a, b;   // the lane's 32 bytes
 };
 
-__device__ __forceinline__ void load_block(const uint8_t* text, uint64_t at, Raw& r) {
-  r.a = *reinterpret_cast<const uint4*>(text + at);
-  r.b = *reinterpret_cast<const uint4*>(text + at + 16);
+// (a uniform base and a 32-bit lane offset: the load takes its address from a scalar pair + one register, no 64-bit
+// pointer per lane is kept alive across the loop)
+__device__ __forceinline__ void load_block(const uint8_t* block, uint32_t lane_off, Raw& r) {
+  r.a = *reinterpret_cast<const uint4*>(block + lane_off);
+  r.b = *reinterpret_cast<const uint4*>(block + lane_off + 16);
 }
 
 __device__ __forceinline__ uint32_t guarded_dword(const uint8_t* text, uint64_t n, uint64_t at) {
@@ -137,6 +139,13 @@ __device__ __forceinline__ uint32_t plane_test(uint32_t ta, uint32_t tb, uint32_
         O[b] = Z[b] | (O[b] & E);
         if (i < 7) Z[b] &= E;
       }
+    }
+    // (half way: the recurrence is brought up to date before the shifted planes of the last four window bytes are formed.
+    // Left alone the compiler forms all sixteen first and shares them between the bases: 65 registers with two bases, one
+    // more than eight waves per SIMD allow)
+    if (NB > 1 && i == 3) {
+#pragma unroll
+      for (int b = 0; b < NB; b++) asm volatile("" : "+v"(Z[b]), "+v"(O[b]));
     }
   }
   return NB > 1 ? (O[0] | O[NB - 1]) : O[0];
@@ -302,7 +311,6 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
   uint32_t fast_end = full >= 1 ? full - 1 : 0;
   if (fast_end > c1) fast_end = c1;
   if (fast_end < c0) fast_end = c0;
-  const uint8_t* lane_text = a.text + static_cast<uint32_t>(lane) * 32u;
   const uint64_t span_base = static_cast<uint64_t>(c0) * kBlock;
   const bool edge = wave < a.edge_waves || wave + a.edge_waves >= n_waves;
   WaveState w;
@@ -320,14 +328,14 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
   // from one 8-byte load, the same address in every lane.  (Clamped to the text's last block only, the prefetches ran
   // three blocks into the neighbour's span: FETCH_SIZE 1.22 x the text on spans of 20 blocks.)
   const uint32_t last_own = fast_end > c0 ? fast_end - 1 : c0;
-  auto blk = [&](uint32_t c) { return static_cast<uint64_t>(c < last_own ? c : last_own) * kBlock; };
+  auto blk = [&](uint32_t c) { return a.text + static_cast<uint64_t>(c < last_own ? c : last_own) * kBlock; };
   const uint32_t lane_rel = static_cast<uint32_t>(lane) * 32u;
   Raw ra, rb;
   uint2 behind{0, 0};
   uint32_t c = c0;
   if (c < fast_end) {
-    load_block(lane_text, blk(c), ra);
-    load_block(lane_text, blk(c + 1), rb);
+    load_block(blk(c), lane_rel, ra);
+    load_block(blk(c + 1), lane_rel, rb);
     behind = *reinterpret_cast<const uint2*>(a.text + static_cast<uint64_t>(fast_end) * kBlock);   // (block fast_end lies inside the text)
   }
   // the table (all waves), before the first wait for text
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
   __syncthreads();
   if (c < fast_end) {
     uint32_t xa = codes16(ra.a, k), xb = codes16(ra.b, k);   // block c
-    load_block(lane_text, blk(c + 2), ra);
+    load_block(blk(c + 2), lane_rel, ra);
     const uint32_t behind_codes = (codes4(behind.x, k) >> k.shift) | (codes4(behind.y, k) << (8 - k.shift));
     // two blocks per iteration: x = the codes of block c, rb = block c + 1, ra = block c + 2 (in flight)
     while (c + 1 < fast_end) {
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
       // (the codes must exist BEFORE the buffer is loaded again: when the compiler sinks their computation towards its
       // use, the reload lands in other registers and is copied back at the loop's end -- behind a wait for it)
       asm volatile("" ::"v"(ya), "v"(yb));
-      load_block(lane_text, blk(c + 3), rb);
+      load_block(blk(c + 3), lane_rel, rb);
       {
         const uint32_t hb = from_lane_above(xa, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ya))));
         const uint32_t hm = plane_test<NB>(xa, xb, hb, a);
@@ -353,7 +361,7 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
       xa = codes16(ra.a, k);   // block c + 2 (the span's last fast block again when c + 2 == fast_end: not used then)
       xb = codes16(ra.b, k);
       asm volatile("" ::"v"(xa), "v"(xb));
-      load_block(lane_text, blk(c + 4), ra);
+      load_block(blk(c + 4), lane_rel, ra);
       {
         const uint32_t next0 = c + 2 == fast_end ? behind_codes : static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xa)));
         const uint32_t hb = from_lane_above(ya, next0);
