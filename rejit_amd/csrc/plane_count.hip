@@ -32,6 +32,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 #include "exact_count.h"
 #include "kernels.h"
 
@@ -610,9 +612,36 @@ __global__ __launch_bounds__(256) void stream_read_probe(const uint4* text, uint
   if (lane == 0) out[wave] = v;
 }
 
+// (measurement only, RJ_PROBE_PATTERN=1: the same reads in plane_count's layout -- a lane takes 32 CONTIGUOUS bytes as two
+// 16-byte loads, so a load instruction of the wave touches every second 16 bytes of 2 KiB)
+__global__ __launch_bounds__(256) void stream_read_probe_pairs(const uint4* text, uint64_t n16, uint64_t span16, uint32_t* out) {
+  const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint64_t i = wave * span16 + 2 * lane, end = (wave + 1) * span16;
+  if (end > n16) end = n16;
+  uint4 acc{0, 0, 0, 0};
+  for (; i + 129 < end; i += 256) {
+    const uint4 a = text[i], b = text[i + 1], c = text[i + 128], d = text[i + 129];
+    acc.x ^= a.x ^ b.x ^ c.x ^ d.x;
+    acc.y ^= a.y ^ b.y ^ c.y ^ d.y;
+    acc.z ^= a.z ^ b.z ^ c.z ^ d.z;
+    acc.w ^= a.w ^ b.w ^ c.w ^ d.w;
+  }
+  uint32_t v = acc.x ^ acc.y ^ acc.z ^ acc.w;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o);
+  if (lane == 0) out[wave] = v;
+}
+
 void launch_stream_read_probe(const void* d_text, uint64_t n, uint32_t* d_out, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
   const uint64_t n16 = n / 16, waves = static_cast<uint64_t>(grid) * 4;
   const uint64_t span16 = ((n16 + waves - 1) / waves + 63) / 64 * 64;
+  static const bool pairs = getenv("RJ_PROBE_PATTERN") && atoi(getenv("RJ_PROBE_PATTERN")) == 1;
+  if (pairs) {
+    const uint64_t span = (span16 + 255) / 256 * 256;
+    hipExtLaunchKernelGGL(stream_read_probe_pairs, dim3(grid), dim3(256), 0, st, t0, t1, 0, static_cast<const uint4*>(d_text), n16, span, d_out);
+    return;
+  }
   hipExtLaunchKernelGGL(stream_read_probe, dim3(grid), dim3(256), 0, st, t0, t1, 0, static_cast<const uint4*>(d_text), n16, span16, d_out);
 }
 
