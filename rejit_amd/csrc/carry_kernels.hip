@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void cs_take_kernel(uint64_t* E, uint64_t* G, 
 // ------------------------------------------------------------------------------------- launchers
 // (round 4: up to 1024 positions -- 256 before, which left cyclic automata wider than that with RJ_TOO_LARGE at match time)
 int cs_state_words(const DevProgram& R) {
-  return R.n_words <= 1 ? 1 : R.n_words <= 2 ? 2 : R.n_words <= 4 ? 4 : R.n_words <= 8 ? 8 : R.n_words <= 16 ? 16 : R.n_words <= 32 ? 32 : 0;
+  return R.n_words <= 1 ? 1 : R.n_words <= 2 ? 2 : R.n_words <= 4 ? 4 : R.n_words <= 8 ? 8 : R.n_words <= 16 ? 16 : R.n_words <= 32 ? 32 : R.n_words <= 64 ? 64 : R.n_words <= 128 ? 128 : R.n_words <= 256 ? 256 : 0;
 }
 
 namespace {
@@ -294,7 +294,10 @@ void launch_cs_summarize(const DevProgram& R, const uint8_t* text, uint64_t n, u
     case 4: RJ_CS_SUM(4, false); break;
     case 8: RJ_CS_SUM(8, false); break;
     case 16: RJ_CS_SUM(16, false); break;
-    default: RJ_CS_SUM(32, false); break;
+    case 32: RJ_CS_SUM(32, false); break;
+    case 64: RJ_CS_SUM(64, false); break;
+    case 128: RJ_CS_SUM(128, false); break;
+    default: RJ_CS_SUM(256, false); break;
   }
 #undef RJ_CS_SUM
 }
@@ -334,7 +337,10 @@ void launch_cs_emit(const DevProgram& R, const uint8_t* text, uint64_t n, uint64
     case 4: RJ_CS_EMIT(4, false); break;
     case 8: RJ_CS_EMIT(8, false); break;
     case 16: RJ_CS_EMIT(16, false); break;
-    default: RJ_CS_EMIT(32, false); break;
+    case 32: RJ_CS_EMIT(32, false); break;
+    case 64: RJ_CS_EMIT(64, false); break;
+    case 128: RJ_CS_EMIT(128, false); break;
+    default: RJ_CS_EMIT(256, false); break;
   }
 #undef RJ_CS_EMIT
 }

@@ -191,7 +191,9 @@ int upload_program(rj_program* rp) {
   // (linear.hip).  Dense mode walks a start at a sizeable share of the bytes, so a long-lived
   // candidate means many of them: cut early.  Window hits are rare: a long line is cheaper to walk.
   D.max_walk = static_cast<uint32_t>(kMaxSimSteps);
-  if (linear_path_fits(rp)) D.max_walk = (D.mode == 0 || D.behind) ? 4096u : 65536u;  // (behind: three walks per hit, a step ~1 us)
+  // (automata of more than 1024 positions: the carry scan takes them since round 5, but its cost grows with the square of the
+  // width -- a start is walked for up to 2^20 bytes before a run goes there)
+  if (linear_path_cheap(rp)) D.max_walk = (D.mode == 0 || D.behind) ? 4096u : 65536u;  // (behind: three walks per hit, a step ~1 us)
   if (const char* mw = getenv("RJ_MAX_WALK"))  // test / measurement override
     if (atoi(mw) > 0) D.max_walk = static_cast<uint32_t>(std::min<long>(atol(mw), static_cast<long>(kMaxSimSteps)));
   // (patterns at risk of the ring artefact keep every start as a candidate: the test "a candidate begins where
@@ -556,7 +558,7 @@ static int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb,
     dense_copy = rp->dev;
     dense_copy.mode = 0;
     dense_copy.behind = 0;
-    if (linear_path_fits(rp)) dense_copy.max_walk = std::min<uint32_t>(dense_copy.max_walk, 4096u);
+    if (linear_path_cheap(rp)) dense_copy.max_walk = std::min<uint32_t>(dense_copy.max_walk, 4096u);
   }
   const DevProgram& D = (as_dense && rp->dev.mode == 1) ? dense_copy : rp->dev;
   const bool windows = D.mode == 1;

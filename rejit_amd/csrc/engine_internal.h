@@ -168,6 +168,7 @@ extern thread_local std::string g_error;   // engine.hip: the calling thread's r
 // after run_range (s->out, s->result_count).  RJ_TOO_LARGE when the automaton is wider than the
 // carry kernels take.
 bool linear_path_fits(const rj_program* rp);
+bool linear_path_cheap(const rj_program* rp);  // <= 1024 positions: state in registers
 int run_linear(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, uint64_t carry_cur,
                uint64_t carry_prev_end, int have_prev, hipStream_t st);
 

@@ -25,6 +25,7 @@ constexpr uint64_t kCsSegment = 256ull << 20;  // own starts per segment: 4 GiB 
 }
 
 bool linear_path_fits(const rj_program* rp) { return cs_state_words(rp->rev) != 0; }
+bool linear_path_cheap(const rj_program* rp) { const int w = cs_state_words(rp->rev); return w != 0 && w <= 32; }
 
 int run_linear(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, uint64_t carry_cur,
                uint64_t carry_prev_end, int have_prev, hipStream_t st) {
@@ -32,7 +33,7 @@ int run_linear(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint6
   const DevProgram& R = rp->rev;
   if (!linear_path_fits(rp))
     return rj_fail(RJ_TOO_LARGE, "a match candidate runs longer than the parallel verifier walks and the automaton (%d positions) "
-                                 "is wider than the linear-time path takes (1024)", R.n_pos);
+                                 "is wider than the linear-time path takes (8192)", R.n_pos);
   if (se > n + 1) se = n + 1;
   s->result_count = 0;
   s->stats.linear_path = 1;

@@ -522,6 +522,9 @@ long ce_match_range(const char* re, const uint8_t* text, uint64_t n, uint64_t su
   if (P.n_words <= 8) return run<8>(P, R, text, n, sub, sb, se, carry_cur, carry_prev_end, have_prev, out, cap);
   if (P.n_words <= 16) return run<16>(P, R, text, n, sub, sb, se, carry_cur, carry_prev_end, have_prev, out, cap);
   if (P.n_words <= 32) return run<32>(P, R, text, n, sub, sb, se, carry_cur, carry_prev_end, have_prev, out, cap);
+  if (P.n_words <= 64) return run<64>(P, R, text, n, sub, sb, se, carry_cur, carry_prev_end, have_prev, out, cap);
+  if (P.n_words <= 128) return run<128>(P, R, text, n, sub, sb, se, carry_cur, carry_prev_end, have_prev, out, cap);
+  if (P.n_words <= 256) return run<256>(P, R, text, n, sub, sb, se, carry_cur, carry_prev_end, have_prev, out, cap);
   return -9;
 }
 

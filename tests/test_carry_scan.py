@@ -137,6 +137,23 @@ def test_automata_of_up_to_1024_positions(ce):
         assert carry(ce, rx, tx, 32, 0, cut) == [m for m in want if m[0] < cut]
 
 
+def test_automata_beyond_1024_positions(ce):
+    """64, 128 and 256 state words (round 5: the carry scan takes every automaton the lowering accepts, 8192 positions; until then
+    a cyclic automaton of more than 1024 positions with a long-lived candidate was RJ_TOO_LARGE at match time)."""
+    oracle = Oracle()
+    rng = random.Random(17)
+    for n_words, subs in ((250, (64, 4096)), (480, (4096,)), (900, (4096,))):
+        ws = ["".join(rng.choice("abcd") for _ in range(rng.randint(7, 9))) for _ in range(n_words)]
+        rx = ("(" + "|".join(ws) + ")+").encode()
+        tx = "".join(rng.choice(ws) for _ in range(50)).encode() + b"x" + "".join(rng.choice(ws) for _ in range(20)).encode() + b"ab"
+        want = oracle.match_all_spec(rx, tx)
+        assert not isinstance(want, int) and len(want) >= 2 and want[0][1] - want[0][0] > 300
+        for sub in subs:
+            assert carry(ce, rx, tx, sub) == want, (n_words, sub)
+        cut = len(tx) // 2
+        assert carry(ce, rx, tx, 512, 0, cut) == [m for m in want if m[0] < cut]
+
+
 def test_behind_walk_device_code_vs_oracle(ce):
     """rejit_amd/csrc/behind_walk.h -- the per-hit procedure verify_behind_in_regions runs (forward check
     from the cut, reverse automaton to the left-most start, forward longest) -- compiled for the CPU:

@@ -200,3 +200,27 @@ def test_wide_cyclic_automata_take_the_carry_scan(rj, oracle):
         cnt = scan.run_tensor(d)
         assert cnt == len(want) and np.array_equal(gpu_spans_np(rj, scan), want), (n_words, scan.stats())
         assert scan.stats()["linear_path"] == 1, scan.stats()
+
+
+def test_automata_beyond_1024_positions_take_the_carry_scan(rj, oracle, monkeypatch):
+    """`(w1|...|w250)+`, `(w1|...|w480)+`, `(w1|...|w900)+` (2000, 3900 and 7200 positions: 64, 128 and 256 state words) over their own
+    words with a walk limit of 4096: one candidate lives for the whole text and the run goes to the carry scan.  Until round 5
+    this was RJ_TOO_LARGE at match time; the reference has no such error.  (Without the limit such a pattern
+    walks a start for up to 2^20 bytes first: the carry scan's cost grows with the square of the width.)"""
+    import torch
+    monkeypatch.setenv("RJ_MAX_WALK", "4096")
+    rng = random.Random(21)
+    for n_words, n_cat in ((250, 2000), (480, 800), (900, 600)):
+        words = ["".join(rng.choice("abcd") for _ in range(rng.randint(7, 9))) for _ in range(n_words)]
+        rx = ("(" + "|".join(words) + ")+").encode()
+        p = rj.Program(rx)
+        assert p.info()["n_positions"] > 1024 * (1 if n_words == 250 else 2 if n_words == 480 else 4)
+        text = ("".join(rng.choice(words) for _ in range(n_cat)) + "x" + "".join(rng.choice(words) for _ in range(300)) + "ab").encode()
+        t = np.frombuffer(text, dtype=np.uint8).copy()
+        want = oracle_spans_np(oracle, rx, t)
+        assert len(want) >= 2 and want[0][1] - want[0][0] > 4500
+        d = torch.from_numpy(t).cuda()
+        scan = rj.Scan(p)
+        cnt = scan.run_tensor(d)
+        assert cnt == len(want) and np.array_equal(gpu_spans_np(rj, scan), want), (n_words, scan.stats())
+        assert scan.stats()["linear_path"] == 1, scan.stats()
