@@ -1054,6 +1054,41 @@ def literal_and_complex_extras(args, c, out):
         out["dense_scan"]["roofline_valu"] = {"bound": "valu", "kernel": "dense_streams<2,2>",
                                               "ops_per_text_byte": rejit_amd.DENSE_VALU_OPS_PER_BYTE, "achieved": round(_valu, 2),
                                               "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s", "frac": round(_valu / VALU_PEAK_TOPS, 4)}
+    # Candidates that CAN overlap (`[0-9][0-9][0-9]`: VERDICT r04 item 4): the same kernel with the reference's left-most-longest
+    # selection made inside it (StreamPlan::select, round 5); until then this pattern took scan_dense_walk.  Parity at this size:
+    # the digest of all (begin, end) pairs against scan_dense_walk's over the same text (tests: both against the oracle).
+    try:
+        def spans_digest(sc):
+            x = sc.spans_tensor(dev)
+            return [int(x.shape[0]), int((x[:, 0] * 1000003 + x[:, 1]).sum().item()) & ((1 << 62) - 1)] if x.numel() else [0, 0]
+
+        sel_digest = []
+
+        def check_select(sc):
+            st_d = sc.stats()
+            assert st_d["n_matches"] > 1000
+            sel_digest.append(spans_digest(sc))
+            sel_digest.append(st_d["stream_path"])
+
+        out["dense_select"] = single_pattern_extra(
+            c, rejit_amd, t, n, "[0-9][0-9][0-9]", "[0-9][0-9][0-9] MatchAll over the same %d bytes (dense mode, candidates overlap: selection in the kernel)" % n,
+            "dense_streams<3,1,select> (bit streams, left-most-longest selection by lane speculation, pairs written once)", 5, check_select, None, False, args)
+        out["dense_select"]["stream_path"] = sel_digest[1]
+        os.environ["RJ_NO_STREAMS"] = "1"          # (read when a pattern is lowered)
+        try:
+            sc_w = rejit_amd.Scan(rejit_amd.Program("[0-9][0-9][0-9]"))
+        finally:
+            del os.environ["RJ_NO_STREAMS"]
+        sc_w.run(t.data_ptr(), n, stream=c.stream)
+        sc_w.run(t.data_ptr(), n, stream=c.stream)
+        t0w = time.perf_counter()
+        sc_w.run(t.data_ptr(), n, stream=c.stream)
+        walk_ms = (time.perf_counter() - t0w) * 1e3
+        out["dense_select"]["scan_dense_walk"] = {"latency_ms": round(walk_ms, 3), "kernel_ms": round(sc_w.stats()["scan_ms"], 3),
+                                                  "same_pairs": spans_digest(sc_w) == sel_digest[0], "pairs_digest": sel_digest[0]}
+        del sc_w
+    except Exception as e:  # noqa: BLE001 (an extra must never cost the line)
+        out["dense_select"] = {"error": repr(e)[:300]}
     # The line table of a grep-like caller (sample/jrep.cc:294: MatchAll of "^"): a class scan whose OUTPUT is
     # the traffic -- 16 bytes per line start next to 1 byte read per text byte.
     nl = torch.arange(60, n, 61, device=dev)

@@ -27,7 +27,8 @@
 // byte at which a candidate may begin).  Then the candidates (every start with a match; for `X+ rest` the first byte
 // of every run of X, DevProgram::loop_first) ARE the result of the reference's left-most-longest selection
 // (src/codegen.cc:36-86, src/x64/codegen-x64.cc:401-466), in order, and the kernel writes them once, at their
-// final place.
+// final place.  Round 5: candidates that CAN overlap are taken too when no match is longer than 16 bytes
+// (`[0-9][0-9][0-9]`, StreamPlan::select): the selection is then made in the kernel, rj_stream_select below.
 #ifndef REJIT_AMD_DENSE_STREAMS_H_
 #define REJIT_AMD_DENSE_STREAMS_H_
 
@@ -53,6 +54,8 @@ struct StreamPlan {
   uint32_t high_half;                    // bit r: the range lies in 0x80..0xff
   uint32_t range_pos[kStreamMaxRanges];  // bit k: position k consumes the bytes of range r
   uint32_t first, last, step, loop;      // bit k: may begin a match / accepts / passes to k + 1 / follows itself
+  uint32_t select;      // candidates MAY overlap (`[0-9][0-9][0-9]`) and no match is longer than kStreamShift bytes: the kernel
+                        // applies the reference's left-most-longest selection itself (rj_stream_select)
 };
 
 RJ_HD uint32_t rj_udot4(uint32_t a, uint32_t b, uint32_t acc) {
@@ -241,6 +244,26 @@ RJ_HD void rj_stream_steps(const StreamPlan& pl, const StreamMasks<NP>& mk, cons
 // longest length of start j from the bit-sliced registers
 RJ_HD uint32_t rj_stream_len(const uint32_t (&len)[4], int j) {
   return 1u + (((len[0] >> j) & 1u) | (((len[1] >> j) & 1u) << 1) | (((len[2] >> j) & 1u) << 2) | (((len[3] >> j) & 1u) << 3));
+}
+
+// The reference's selection (left-most start, longest match from it, the next match begins at or behind its end:
+// src/codegen.cc:36-86, src/x64/codegen-x64.cc:401-466, 494-500) among the 32 starts of one lane, for plans with
+// `select`: T = the starts with a match, len = their longest lengths (bit-sliced, <= kStreamShift), d = how many of the
+// lane's first starts lie inside a match selected in a lane below (0 .. kStreamShift - 1).  Returns the selected starts;
+// *out = the same count for the NEXT lane.  A lane without any match resets the chain (a match is at most 16 bytes long,
+// a lane 32 starts): the kernel resolves d lane by lane by speculation (d = 0, corrected from the lane below until
+// nothing changes) and finds a tile's entry state in the 2 KiB before the tile (dense_streams.hip).
+RJ_HD uint32_t rj_stream_select(uint32_t T, const uint32_t (&len)[4], uint32_t d, uint32_t* out) {
+  uint32_t sel = 0, pos = d;
+  uint32_t m = pos < 32u ? T & (~0u << pos) : 0u;
+  while (m != 0) {
+    const int j = __builtin_ctz(m);
+    sel |= 1u << j;
+    pos = static_cast<uint32_t>(j) + rj_stream_len(len, j);
+    m = pos < 32u ? T & (~0u << pos) : 0u;
+  }
+  *out = pos > 32u ? pos - 32u : 0u;
+  return sel;
 }
 
 }  // namespace rejit_amd

@@ -94,12 +94,24 @@ struct TileOut {
 
 // One tile: its matches counted and (DIRECT) written at direct_base onwards / (not DIRECT) staged in LDS.  Returns the
 // tile's count (wave-uniform); *slow = starts that took the scalar walk; *overrun = a walk hit max_walk.
-template <int NP, int NR, bool HIGH, bool DIRECT>
+//
+// SELECT (StreamPlan::select: candidates may overlap, matches of at most 16 bytes): the left-most-longest selection is made
+// here.  Inside a lane it is a short chain over the lane's matches (rj_stream_select); from lane to lane the one thing that
+// travels is d = how many of a lane's first starts lie inside a match selected below it.  Every lane first assumes d = 0,
+// then takes the d its neighbour below computed and repeats while anything changes (lane k is exact after k rounds; on
+// text whose matches are not packed, after one or two).  From iteration to iteration d is a scalar.  A TILE's entry state
+// comes from the 2 KiB before it (one iteration more, `it` = -1, nothing written): a lane without any match there resets
+// the chain whatever came before, so everything behind the LAST such lane is exact.  No such lane in 2 KiB (64 lanes each
+// with a match: a text packed with matches): *unsure -- the run is void and the engine repeats it on scan_dense_walk.
+template <int NP, int NR, bool HIGH, bool DIRECT, bool SELECT>
 __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const StreamMasks<NP>& mk, const StreamRangeMasks<NP, NR>& rm, uint64_t base,
                                                 const TileOut& o, uint32_t* slow, bool* overrun) {
   const int lane = lane_id();
   const StreamPlan& pl = a.plan;
   const uint64_t lim = a.se < a.n ? a.se : a.n;  // starts s in [sb, lim)
+  const int it0 = (SELECT && base >= kIter) ? -1 : 0;   // (tiles begin at multiples of 32 KiB: the first one of a text has nothing before it)
+  const uint64_t first_at = base - (it0 < 0 ? kIter : 0u);
+  uint32_t d_carry = 0;   // SELECT: starts at the beginning of the iteration that lie inside a selected match (uniform)
   // the streams of the 32 bytes before the tile: the "lane below" of lane 0 in the first iteration (every lane computes the
   // same words; a tile begins at a multiple of 32 KiB, so those bytes exist unless the tile is the text's first)
   uint32_t carry[NP];
@@ -107,33 +119,33 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Str
     uint32_t x[8], valid = 0;
 #pragma unroll
     for (int q = 0; q < 8; q++) x[q] = 0;
-    if (base >= 32) load32_guarded(a.text, a.n, base - 32, x, &valid);
+    if (first_at >= 32) load32_guarded(a.text, a.n, first_at - 32, x, &valid);
     rj_stream_classes<NP, NR, HIGH>(pl, rm, x, valid, carry);
 #pragma unroll
     for (int k = 0; k < NP; k++) carry[k] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(carry[k])));
   }
   // a tile whose bytes all lie inside the text and whose starts all lie inside the own range needs no guards (uniform)
-  const bool inner = base + kTile <= a.n && base >= a.sb + kStreamShift && base + kTile <= lim + kStreamShift;
+  const bool inner = base + kTile <= a.n && first_at >= a.sb + kStreamShift && base + kTile <= lim + kStreamShift;
   const uint8_t* lane_text = a.text + base + static_cast<uint64_t>(lane) * 32;
   uint4 n0 = make_uint4(0, 0, 0, 0), n1 = make_uint4(0, 0, 0, 0);
   if (inner) {
-    n0 = *reinterpret_cast<const uint4*>(lane_text);
-    n1 = *reinterpret_cast<const uint4*>(lane_text + 16);
+    n0 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it0) * static_cast<int64_t>(kIter));
+    n1 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it0) * static_cast<int64_t>(kIter) + 16);
   }
   uint32_t count = 0;
 #pragma unroll 1
-  for (int it = 0; it < kTileIters; it++) {
-    const uint64_t at = base + static_cast<uint64_t>(it) * kIter + static_cast<uint64_t>(lane) * 32;
+  for (int it = it0; it < kTileIters; it++) {
+    const uint64_t at = base + static_cast<uint64_t>(static_cast<int64_t>(it) * static_cast<int64_t>(kIter)) + static_cast<uint64_t>(lane) * 32;
     uint32_t x[8], valid = ~0u, start_mask = ~0u;
     if (inner) {
       x[0] = n0.x; x[1] = n0.y; x[2] = n0.z; x[3] = n0.w;
       x[4] = n1.x; x[5] = n1.y; x[6] = n1.z; x[7] = n1.w;
       if (it + 1 < kTileIters) {  // the next iteration's bytes, in flight while this one is evaluated
-        n0 = *reinterpret_cast<const uint4*>(lane_text + static_cast<uint64_t>(it + 1) * kIter);
-        n1 = *reinterpret_cast<const uint4*>(lane_text + static_cast<uint64_t>(it + 1) * kIter + 16);
+        n0 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it + 1) * static_cast<int64_t>(kIter));
+        n1 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it + 1) * static_cast<int64_t>(kIter) + 16);
       }
     } else {
-      if (base + static_cast<uint64_t>(it) * kIter >= lim + kStreamShift) break;  // (uniform: no start of the range reaches this far)
+      if (it >= 0 && base + static_cast<uint64_t>(it) * kIter >= lim + kStreamShift) break;  // (uniform: no start of the range reaches this far)
       load32_guarded(a.text, a.n, at, x, &valid);
       // starts p = at - 16 + j inside [sb, lim)
       const uint64_t lo_p = a.sb + kStreamShift, hi_p = lim + kStreamShift;  // bit j counts iff lo_p <= at + j < hi_p
@@ -166,7 +178,35 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Str
         (*slow)++;
       }
     }
-    const uint32_t take = fin | walked;
+    uint32_t take = fin | walked;
+    if (SELECT) {
+      if (it < 0) {
+        const uint64_t quiet = __ballot(take == 0);
+        if (quiet == 0) *overrun = true;   // (no lane resets the chain: the tile's entry state is not known)
+        const int last_quiet = quiet != 0 ? 63 - static_cast<int>(__builtin_clzll(quiet)) : 63;
+        if (lane <= last_quiet) take = 0;  // (what lies before the last reset does not matter)
+        d_carry = 0;
+      }
+      if (__ballot(take != 0) == 0) {
+        d_carry = 0;   // (2 KiB without a match)
+        continue;
+      }
+      uint32_t d_in = lane == 0 ? d_carry : 0u, d_out;
+      uint32_t sel = rj_stream_select(take, len, d_in, &d_out);
+      for (;;) {
+        uint32_t want = wave_from_lane_below(d_out);
+        if (lane == 0) want = d_carry;
+        const bool redo = want != d_in;
+        if (__ballot(redo) == 0) break;
+        if (redo) {
+          d_in = want;
+          sel = rj_stream_select(take, len, d_in, &d_out);
+        }
+      }
+      d_carry = wave_last_lane(d_out);
+      if (it < 0) continue;
+      take = sel;
+    }
     if (__ballot(take != 0) == 0) continue;
     const uint32_t mine = __popc(take);
     const uint32_t inc = wave_inclusive_sum(mine);
@@ -203,7 +243,7 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Str
 // look-back set the pace (`[@#]`, one step, took as long as `[a-f]+[0-9]`); a granule per workgroup: 1.62 ms per 5 GB;
 // two-level look-back: 1.53; with no look-back at all (wrong output) 1.17 -- the rest was waiting for the slowest of the
 // ~1800 units in flight, which this form no longer does.
-template <int NP, int NR, bool HIGH>
+template <int NP, int NR, bool HIGH, bool SELECT>
 __global__ __launch_bounds__(256) void dense_streams(StreamParams a) {
   __shared__ unsigned long long s_ticket, s_before;
   __shared__ uint32_t s_count[2][kTilesPerTicket], s_bad;
@@ -231,7 +271,7 @@ __global__ __launch_bounds__(256) void dense_streams(StreamParams a) {
       const TileOut o{s_stage[cur][wv], a.out, a.out_cap, 0};
       uint32_t slow = 0;
       bool overrun = false;
-      if (!void_run && t < a.n_tiles) k = stream_tile<NP, NR, HIGH, false>(a, mk, rm, base, o, &slow, &overrun);
+      if (!void_run && t < a.n_tiles) k = stream_tile<NP, NR, HIGH, false, SELECT>(a, mk, rm, base, o, &slow, &overrun);
       if (__ballot(overrun) != 0 && lane == 0) {
         a.counters[kCntOverrun] = 1;
         if (a.host_counters) a.host_counters[kCntOverrun] = 1;
@@ -299,7 +339,7 @@ __global__ __launch_bounds__(256) void dense_streams(StreamParams a) {
         const TileOut o{s_stage[cur ^ 1][wv], a.out, a.out_cap, before};
         uint32_t slow2 = 0;
         bool ov2 = false;
-        (void)stream_tile<NP, NR, HIGH, true>(a, mk, rm, pbase, o, &slow2, &ov2);
+        (void)stream_tile<NP, NR, HIGH, true, SELECT>(a, mk, rm, pbase, o, &slow2, &ov2);
       }
     }
     if (!have) return;
@@ -327,8 +367,13 @@ namespace {
 template <int NP, int NR>
 void launch_nr(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
   const dim3 b(256);
-  if (a.plan.high_half == 0) hipExtLaunchKernelGGL((dense_streams<NP, NR, false>), g, b, 0, st, t0, t1, 0, a);
-  else hipExtLaunchKernelGGL((dense_streams<NP, NR, true>), g, b, 0, st, t0, t1, 0, a);
+  if (a.plan.select) {
+    if (a.plan.high_half == 0) hipExtLaunchKernelGGL((dense_streams<NP, NR, false, true>), g, b, 0, st, t0, t1, 0, a);
+    else hipExtLaunchKernelGGL((dense_streams<NP, NR, true, true>), g, b, 0, st, t0, t1, 0, a);
+    return;
+  }
+  if (a.plan.high_half == 0) hipExtLaunchKernelGGL((dense_streams<NP, NR, false, false>), g, b, 0, st, t0, t1, 0, a);
+  else hipExtLaunchKernelGGL((dense_streams<NP, NR, true, false>), g, b, 0, st, t0, t1, 0, a);
 }
 template <int NP>
 void launch_np(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {

@@ -348,7 +348,14 @@ inline StreamPlan make_stream_plan(const Program& P, bool loop_first, bool q8_ri
       if (S2 == 0) continue;  // the thread does not consume this byte
       const bool in_x = loop_first && ((cls >> first_pos) & 1u);
       const bool may_begin = loop_first ? (in_x && !prev_in_x) : (first & cls) != 0;
-      if (may_begin) return StreamPlan{};
+      if (may_begin) {
+        // two candidates can overlap: the kernel makes the selection itself when every match ends within the register
+        // steps (StreamPlan::select, round 5); else this is scan_dense_walk's pattern
+        if (loop_first || P.max_len == Program::kUnboundedLen || P.max_len > kStreamShift) return StreamPlan{};
+        pl.select = 1;
+        todo.clear();
+        break;
+      }
       const uint32_t nx = S2 * 2 + (in_x ? 1u : 0u);
       if (!seen[nx]) {
         seen[nx] = 1;

@@ -406,6 +406,11 @@ static long stream_run(const Program& P, const DevProgram& F, const StreamPlan& 
   uint32_t Sb[NP];
   for (int q = 0; q < NP; q++) Sb[q] = 0;
   auto any = [](uint32_t x) { return x != 0; };
+  // plans with `select`: the lanes' matches are kept and the kernel's selection is replayed behind the loop
+  struct LaneMatches {
+    uint32_t take, len[4];
+  };
+  std::vector<LaneMatches> lanes;
   for (uint64_t at = 0; lim > 0 && at <= lim - 1 + kStreamShift; at += 32) {
     uint32_t x[8] = {0, 0, 0, 0, 0, 0, 0, 0}, valid = 0, S[NP];
     for (int j = 0; j < 32; j++)
@@ -422,6 +427,10 @@ static long stream_run(const Program& P, const DevProgram& F, const StreamPlan& 
     }
     uint32_t matched, alive, len[4], cand;
     rj_stream_steps<NP>(pl, mk, S, Sb, start_mask, any, &matched, &alive, len, &cand);
+    if (pl.select) {
+      if (alive != 0) stats[2]++;   // (no match of such a plan outlives the register steps)
+      lanes.push_back(LaneMatches{matched, {len[0], len[1], len[2], len[3]}});
+    }
     for (int j = 0; j < 32; j++) {
       if (!((start_mask >> j) & 1u)) {
         if ((cand >> j) & 1u) stats[2]++;
@@ -467,6 +476,7 @@ static long stream_run(const Program& P, const DevProgram& F, const StreamPlan& 
         const uint32_t l = rj_stream_len(len, j);
         if (l != longest) stats[2]++;
         stats[0]++;
+        if (pl.select) continue;
         if (k < cap) {
           out[2 * k] = s;
           out[2 * k + 1] = s + l;
@@ -476,6 +486,80 @@ static long stream_run(const Program& P, const DevProgram& F, const StreamPlan& 
     }
     for (int q = 0; q < NP; q++) Sb[q] = S[q];
   }
+  if (!pl.select) return static_cast<long>(k);
+  // The selection as dense_streams.hip makes it (stream_tile<.., SELECT>): tiles of 1024 lanes on their own, a tile's entry
+  // state from the 64 lanes before it (the last lane without a match resets the chain; none: the run is void, -103), inside
+  // an iteration of 64 lanes every lane assumes that nothing reaches into it and is corrected from the lane below until
+  // nothing changes, from iteration to iteration the state is carried.
+  const uint64_t n_lanes = lanes.size();
+  auto lane_at = [&](uint64_t i) { return i < n_lanes ? lanes[static_cast<size_t>(i)] : LaneMatches{0, {0, 0, 0, 0}}; };
+  bool unsure = false;
+  uint64_t rounds_max = 0;
+  auto resolve = [&](LaneMatches (&w)[64], uint32_t d_carry, uint32_t (&sel)[64]) {
+    uint32_t d_in[64], d_out[64];
+    for (int i = 0; i < 64; i++) {
+      d_in[i] = i == 0 ? d_carry : 0u;
+      sel[i] = rj_stream_select(w[i].take, w[i].len, d_in[i], &d_out[i]);
+    }
+    for (uint64_t rounds = 1;; rounds++) {
+      uint32_t want[64];
+      bool any_redo = false;
+      for (int i = 0; i < 64; i++) {
+        want[i] = i == 0 ? d_carry : d_out[i - 1];
+        any_redo = any_redo || want[i] != d_in[i];
+      }
+      if (rounds > rounds_max) rounds_max = rounds;
+      if (!any_redo) break;
+      for (int i = 0; i < 64; i++)
+        if (want[i] != d_in[i]) {
+          d_in[i] = want[i];
+          sel[i] = rj_stream_select(w[i].take, w[i].len, d_in[i], &d_out[i]);
+        }
+    }
+    return d_out[63];
+  };
+  const uint64_t tile_lanes = 1024, first_tile = (sb + kStreamShift) / (tile_lanes * 32);
+  for (uint64_t tile = first_tile; tile * tile_lanes < n_lanes; tile++) {
+    const uint64_t l0 = tile * tile_lanes;
+    uint32_t d_carry = 0;
+    for (int it = l0 >= 64 ? -1 : 0; it < 16; it++) {
+      const uint64_t i0 = l0 + static_cast<uint64_t>(static_cast<int64_t>(it) * 64);
+      LaneMatches w[64];
+      bool any_take = false;
+      for (int i = 0; i < 64; i++) w[i] = lane_at(i0 + i);
+      if (it < 0) {
+        int last_quiet = -1;
+        for (int i = 0; i < 64; i++)
+          if (w[i].take == 0) last_quiet = i;
+        if (last_quiet < 0) {
+          unsure = true;
+          last_quiet = 63;
+        }
+        for (int i = 0; i <= last_quiet; i++) w[i].take = 0;
+        d_carry = 0;
+      }
+      for (int i = 0; i < 64; i++) any_take = any_take || w[i].take != 0;
+      if (!any_take) {
+        d_carry = 0;
+        continue;
+      }
+      uint32_t sel[64];
+      d_carry = resolve(w, d_carry, sel);
+      if (it < 0) continue;
+      for (int i = 0; i < 64; i++)
+        for (uint32_t m = sel[i]; m; m &= m - 1) {
+          const int j = __builtin_ctz(m);
+          const uint64_t s0 = (i0 + i) * 32 + j - kStreamShift;
+          if (k < cap) {
+            out[2 * k] = s0;
+            out[2 * k + 1] = s0 + rj_stream_len(w[i].len, j);
+          }
+          k++;
+        }
+    }
+  }
+  stats[5] = rounds_max;
+  if (unsure) return -103;
   return static_cast<long>(k);
 }
 

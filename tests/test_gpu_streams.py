@@ -133,3 +133,41 @@ def test_prefix_scan_across_unit_groups(rj, oracle):
                 for lo, hi in ((group - 7, group + 3 * unit + 1), (group + 5 * unit + 17, n + 1), (3 * unit, 2 * group - unit)):
                     got, st = run_scan(rj, scan, text, own_begin=lo, own_end=hi)
                     assert got == [m for m in want if lo <= m[0] < hi], (rx, n, lo, hi)
+
+
+SELECT_SHAPES = [b"[0-9][0-9][0-9]", b"..", b"a.c", b"[a-c]{4}d", b"(ab|ba)", b"[a-z][a-z][0-9]", b"[ab][bc][cd]", b"[0-9]{8}", b"aa|aab", b"[ab]{2,3}"]
+
+
+def test_selection_in_the_stream_kernel_vs_oracle(rj, oracle):
+    """Candidates that CAN overlap (`[0-9][0-9][0-9]`): since round 5 the bit-stream kernel makes the
+    reference's left-most-longest selection itself (StreamPlan::select, rj_stream_select; src/codegen.cc:36-86,
+    src/x64/codegen-x64.cc:401-466).  Sizes around the lane / iteration / tile edges; sparse text (the kernel answers: every
+    tile finds a lane without a match before it), text packed with matches beyond one tile (the run is void and repeated on
+    scan_dense_walk: the answer is still the oracle's), a packed stretch across a tile edge inside sparse text, own ranges."""
+    rng = random.Random(61)
+    sparse_alphabet = bytes(range(0x30, 0x7a))
+    took = void = 0
+    for rx in SELECT_SHAPES:
+        p = rj.Program(rx)
+        for n in (17, 33, 2047, 2049, 20000, 32767, 32769, 34817, 70001, 300000, 1 << 20):
+            scan = rj.Scan(p)   # (a void run switches the stream kernel off for its scan object)
+            text = bytearray(rng.choice(sparse_alphabet) for _ in range(min(n, 200000)))
+            text = (text * (n // len(text) + 1))[:n]
+            for edge in range(32768, n - 100, 32768):
+                text[edge - 300:edge - 40] = bytes(rng.choice(b"0123456789ab") for _ in range(260))
+                text[edge - 9:edge + 9] = b"12ab34ba5678901234"
+            text = bytes(text)
+            got, st = run_scan(rj, scan, text)
+            assert got == oracle.match_all(rx, text), (rx, n, st)
+            took += st["stream_path"]
+            if n == 70001:
+                want = got
+                cut = 32768 + 5
+                first, _ = run_scan(rj, scan, text, own_begin=0, own_end=cut)
+                assert first == [m for m in want if m[0] < cut], (rx, cut)
+        scan = rj.Scan(p)
+        packed = bytes(rng.choice(b"0123456789ab") for _ in range(100000))
+        got, st = run_scan(rj, scan, packed)
+        assert got == oracle.match_all(rx, packed), (rx, "packed")
+        void += 1 - st["stream_path"]
+    assert took >= 30 and void >= 5, (took, void)
