@@ -127,25 +127,31 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Str
   // a tile whose bytes all lie inside the text and whose starts all lie inside the own range needs no guards (uniform)
   const bool inner = base + kTile <= a.n && first_at >= a.sb + kStreamShift && base + kTile <= lim + kStreamShift;
   const uint8_t* lane_text = a.text + base + static_cast<uint64_t>(lane) * 32;
-  uint4 n0 = make_uint4(0, 0, 0, 0), n1 = make_uint4(0, 0, 0, 0);
+  // The lane's 32 bytes are loaded one iteration ahead.  Where the load sits decides what the back edge of the loop costs:
+  // one buffer, reloaded AHEAD of its last readers (the class streams), lands in fresh registers and is copied twice -- 20
+  // moves per iteration, 7 % of the kernel's instructions.  Measured on one box, alternating builds (`[a-f]+[0-9]` /
+  // `[0-9][0-9][0-9]` over 5 GB): that form 1.25 / 1.20 ms; the reload BEHIND the class streams into the same registers
+  // (69 registers, 7 waves per SIMD) 1.20 / 1.29; two buffers used alternately, the loop unrolled by two (81 registers, 5
+  // waves) 1.25 / 1.15.  So: the plain kernels reload late into the one buffer, the SELECT kernels alternate two.
+  uint4 bufa0 = make_uint4(0, 0, 0, 0), bufa1 = make_uint4(0, 0, 0, 0), bufb0 = make_uint4(0, 0, 0, 0), bufb1 = make_uint4(0, 0, 0, 0);
   if (inner) {
-    n0 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it0) * static_cast<int64_t>(kIter));
-    n1 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it0) * static_cast<int64_t>(kIter) + 16);
+    bufa0 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it0) * static_cast<int64_t>(kIter));
+    bufa1 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it0) * static_cast<int64_t>(kIter) + 16);
   }
   uint32_t count = 0;
-#pragma unroll 1
-  for (int it = it0; it < kTileIters; it++) {
+  // one iteration (2 KiB of the tile); false: the tile ends here
+  auto iteration = [&](const int it, uint4& n0, uint4& n1, uint4& next0, uint4& next1) __attribute__((always_inline)) -> bool {
     const uint64_t at = base + static_cast<uint64_t>(static_cast<int64_t>(it) * static_cast<int64_t>(kIter)) + static_cast<uint64_t>(lane) * 32;
     uint32_t x[8], valid = ~0u, start_mask = ~0u;
     if (inner) {
       x[0] = n0.x; x[1] = n0.y; x[2] = n0.z; x[3] = n0.w;
       x[4] = n1.x; x[5] = n1.y; x[6] = n1.z; x[7] = n1.w;
-      if (it + 1 < kTileIters) {  // the next iteration's bytes, in flight while this one is evaluated
-        n0 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it + 1) * static_cast<int64_t>(kIter));
-        n1 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it + 1) * static_cast<int64_t>(kIter) + 16);
+      if (SELECT && it + 1 < kTileIters) {  // the next iteration's bytes, in flight while this one is evaluated
+        next0 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it + 1) * static_cast<int64_t>(kIter));
+        next1 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it + 1) * static_cast<int64_t>(kIter) + 16);
       }
     } else {
-      if (it >= 0 && base + static_cast<uint64_t>(it) * kIter >= lim + kStreamShift) break;  // (uniform: no start of the range reaches this far)
+      if (it >= 0 && base + static_cast<uint64_t>(it) * kIter >= lim + kStreamShift) return false;  // (uniform: no start of the range reaches this far)
       load32_guarded(a.text, a.n, at, x, &valid);
       // starts p = at - 16 + j inside [sb, lim)
       const uint64_t lo_p = a.sb + kStreamShift, hi_p = lim + kStreamShift;  // bit j counts iff lo_p <= at + j < hi_p
@@ -156,6 +162,12 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Str
     }
     uint32_t S[NP], Sb[NP];
     rj_stream_classes<NP, NR, HIGH>(pl, rm, x, valid, S);
+    if (!SELECT && inner && it + 1 < kTileIters) {  // (next0 / next1 ARE n0 / n1 here: the streams are pinned, then the reload)
+#pragma unroll
+      for (int k = 0; k < NP; k++) asm volatile("" : "+v"(S[k]));
+      next0 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it + 1) * static_cast<int64_t>(kIter));
+      next1 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it + 1) * static_cast<int64_t>(kIter) + 16);
+    }
 #pragma unroll
     for (int k = 0; k < NP; k++) {
       const uint32_t below = wave_from_lane_below(S[k]);
@@ -189,7 +201,7 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Str
       }
       if (__ballot(take != 0) == 0) {
         d_carry = 0;   // (2 KiB without a match)
-        continue;
+        return true;
       }
       uint32_t d_in = lane == 0 ? d_carry : 0u, d_out;
       uint32_t sel = rj_stream_select(take, len, d_in, &d_out);
@@ -204,10 +216,10 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Str
         }
       }
       d_carry = wave_last_lane(d_out);
-      if (it < 0) continue;
+      if (it < 0) return true;
       take = sel;
     }
-    if (__ballot(take != 0) == 0) continue;
+    if (__ballot(take != 0) == 0) return true;
     const uint32_t mine = __popc(take);
     const uint32_t inc = wave_inclusive_sum(mine);
     uint32_t idx = count + inc - mine;
@@ -230,6 +242,18 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Str
       }
     }
     count += wave_last_lane(inc);
+    return true;
+  };
+  if (SELECT) {
+#pragma unroll 1
+    for (int it = it0; it < kTileIters; it += 2) {
+      if (!iteration(it, bufa0, bufa1, bufb0, bufb1)) break;
+      if (it + 1 >= kTileIters || !iteration(it + 1, bufb0, bufb1, bufa0, bufa1)) break;
+    }
+  } else {
+#pragma unroll 1
+    for (int it = it0; it < kTileIters; it++)
+      if (!iteration(it, bufa0, bufa1, bufa0, bufa1)) break;
   }
   return count;
 }
