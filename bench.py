@@ -58,6 +58,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 VALU_PEAK_TOPS = 78.6        # 256 CUs x 4 SIMD-32 x 32 lanes/clk x 2.4 GHz simple 32-bit VALU lane-ops per second (same guide:
                              # a wave64 instruction issues over 2 cycles; = the 157.3 TFLOP/s FP32 vector peak / 2 flops per FMA)
+# ... and what this device issues when asked (round 5, tools/probes/valu_rate.hip, profiles/r05_valu_rate.txt: eight independent
+# chains per lane, 8 waves per SIMD): v_and / v_xor / v_add 3.1-3.3 cycles per wave64 instruction, v_alignbit / v_dot4_u32_u8 /
+# v_bitop3 / v_and_or / v_bfi / shifts / DPP moves 4.0-4.5 -- 35-39 T lane-ops/s for the mix these kernels are made of.
+VALU_MEASURED_TOPS = 37.0
 
 
 def pmc_traffic(key, **match):
@@ -564,6 +568,7 @@ def run_regexdna(args, c):
         out["roofline_valu"] = {"bound": "valu", "kernel": "plane_count<2>" if counts_headline else "plane_scan<2>", "ops_per_text_byte": ops_per_byte,
                                 "achieved": round(valu, 2), "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",
                                 "frac": round(valu / VALU_PEAK_TOPS, 4),
+                                "measured_issue_rate": VALU_MEASURED_TOPS, "frac_of_measured": round(valu / VALU_MEASURED_TOPS, 4),
                                 "note": "SQ_INSTS_VALU x 64 / text bytes from profiles/%s_pmc_sq_counters.txt" % ("r05" if counts_headline else "r03")}
     else:
         out["roofline"] = hbm_roofline("scan_windows<2,NIB>", own_bytes, avg_scan_ms, None, len(scan_ms))
@@ -1053,7 +1058,9 @@ def literal_and_complex_extras(args, c, out):
         _valu = n * rejit_amd.DENSE_VALU_OPS_PER_BYTE / (_dl * 1e-3) / 1e12
         out["dense_scan"]["roofline_valu"] = {"bound": "valu", "kernel": "dense_streams<2,2>",
                                               "ops_per_text_byte": rejit_amd.DENSE_VALU_OPS_PER_BYTE, "achieved": round(_valu, 2),
-                                              "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s", "frac": round(_valu / VALU_PEAK_TOPS, 4)}
+                                              "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s", "frac": round(_valu / VALU_PEAK_TOPS, 4),
+                                              "measured_issue_rate": VALU_MEASURED_TOPS, "frac_of_measured": round(_valu / VALU_MEASURED_TOPS, 4),
+                                              "note": "the issue rate measured for this kernel's instruction mix (profiles/r05_valu_rate.txt): the kernel is VALU-bound"}
     # Candidates that CAN overlap (`[0-9][0-9][0-9]`: VERDICT r04 item 4): the same kernel with the reference's left-most-longest
     # selection made inside it (StreamPlan::select, round 5); until then this pattern took scan_dense_walk.  Parity at this size:
     # the digest of all (begin, end) pairs against scan_dense_walk's over the same text (tests: both against the oracle).
