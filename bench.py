@@ -1079,7 +1079,7 @@ def literal_and_complex_extras(args, c, out):
 
         out["dense_select"] = single_pattern_extra(
             c, rejit_amd, t, n, "[0-9][0-9][0-9]", "[0-9][0-9][0-9] MatchAll over the same %d bytes (dense mode, candidates overlap: selection in the kernel)" % n,
-            "dense_streams<3,1,select> (bit streams, left-most-longest selection by lane speculation, pairs written once)", 5, check_select, None, False, args)
+            "dense_streams<3,1,select> (bit streams, left-most-longest selection by lane speculation, pairs written once)", 5, check_select, "dense_select", False, args)
         out["dense_select"]["stream_path"] = sel_digest[1]
         os.environ["RJ_NO_STREAMS"] = "1"          # (read when a pattern is lowered)
         try:

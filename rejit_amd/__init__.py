@@ -18,12 +18,15 @@ FUSED_VALU_OPS_PER_BYTE = 15.5
 # 2-KiB pair and wave), the rest appends the candidates (about four pairs in five hold one on DNA)
 PLANE_VALU_OPS_PER_BYTE = 5.56
 # plane_count<2> (round 5: 32 contiguous bytes per lane, candidates in an LDS ring, classified by table lookup 64 at a time):
-# SQ_INSTS_VALU 33.46 M wave-instructions per 500 MB launch x 64 lanes / 5e8 bytes (profiles/r05_pmc_sq_counters.txt)
-PLANE_COUNT_VALU_OPS_PER_BYTE = 4.28
+# SQ_INSTS_VALU 34.13 M wave-instructions per 500 MB launch x 64 lanes / 5e8 bytes (profiles/r05_pmc_sq_counters.txt; 33.46 M = 4.28
+# before the recurrence was pinned half way for 58 registers / 8 waves per SIMD -- same kernel time)
+PLANE_COUNT_VALU_OPS_PER_BYTE = 4.37
 # scan_dense_walk<1,false,4> on `[a-f]+[0-9]` over random ASCII: SQ_INSTS_VALU 1.835e9 wave instructions per 5 GB launch
 # x 64 lanes / 5e9 bytes (profiles/r03_pmc_sq_counters.txt); 28.6 before round 3's instruction diet, 59 before the
 # lane-packed pre-steps
 # round 4: dense_streams<2,2> (bit streams, dense_streams.hip) on the same pattern and text: SQ_INSTS_VALU 144.6 M wave
 # instructions per 1 GB launch x 64 lanes / 1e9 bytes (gpurun_out/r04_stream_pmc2.txt; profiles/r04_pmc_sq_counters.txt
 # holds the 5 GB launch)
-DENSE_VALU_OPS_PER_BYTE = 9.3
+# round 5: 651.6 M per 5 GB launch = 8.34 (profiles/r05_pmc_sq_counters.txt: the register copies at the loop's back edge are gone;
+# 8.64 at the start of the round on the same counter, 9.3 was the 1 GB launch of round 4)
+DENSE_VALU_OPS_PER_BYTE = 8.34

@@ -61,7 +61,8 @@ for key, prefix, nbytes, extra in (
         ("literal", "scan_windows<1, true, true, true, false>", 5000000000, {}),
         ("literal_50gb", "scan_windows<1, true, true, true, false>", 50000000000, {}),
         ("complex", "scan_windows<1, true, false, true, false>", 5000000000, {}),
-        ("dense", "dense_streams<2, 2, false>", 5000000000, {}),
+        ("dense", "dense_streams<2, 2, false, false>", 5000000000, {}),
+        ("dense_select", "dense_streams<3, 1, false, true>", 5000000000, {}),
         ("general", "plane_scan_general<1, false>", 5000000000, {}),
         ("line_table", "emit_assertions", 5000000000, {})):
     try:
