@@ -18,9 +18,10 @@ FUSED_VALU_OPS_PER_BYTE = 15.5
 # 2-KiB pair and wave), the rest appends the candidates (about four pairs in five hold one on DNA)
 PLANE_VALU_OPS_PER_BYTE = 5.56
 # plane_count<2> (round 5: 32 contiguous bytes per lane, candidates in an LDS ring, classified by table lookup 64 at a time):
-# SQ_INSTS_VALU 34.13 M wave-instructions per 500 MB launch x 64 lanes / 5e8 bytes (profiles/r05_pmc_sq_counters.txt; 33.46 M = 4.28
-# before the recurrence was pinned half way for 58 registers / 8 waves per SIMD -- same kernel time)
-PLANE_COUNT_VALU_OPS_PER_BYTE = 4.37
+# SQ_INSTS_VALU 28.27 M wave-instructions per 500 MB launch x 64 lanes / 5e8 bytes (profiles/r05_pmc_sq_counters.txt) with the four code
+# planes read through the VGPR index mode (plane_count.hip: plane_test); 34.13 M = 4.37 with two bit planes compared against the
+# bases' masks, 33.46 M = 4.28 before the recurrence was pinned half way for 8 waves per SIMD
+PLANE_COUNT_VALU_OPS_PER_BYTE = 3.62
 # scan_dense_walk<1,false,4> on `[a-f]+[0-9]` over random ASCII: SQ_INSTS_VALU 1.835e9 wave instructions per 5 GB launch
 # x 64 lanes / 5e9 bytes (profiles/r03_pmc_sq_counters.txt); 28.6 before round 3's instruction diet, 59 before the
 # lane-packed pre-steps

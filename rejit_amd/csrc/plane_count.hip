@@ -116,39 +116,119 @@ __device__ __forceinline__ uint32_t plane_test(uint32_t ta, uint32_t tb, uint32_
   const uint32_t H = ((ta >> 1) & kEven) | (tb & ~kEven);
   const uint32_t Ln = (tb & kEven) | ((hb << 1) & ~kEven);   // what follows the first half is the second half
   const uint32_t Hn = ((tb >> 1) & kEven) | (hb & ~kEven);
-  // The 32 masks (base b, window byte i: all ones when the low / high bit of its symbol code is 0) live as BITS of one
-  // scalar register and are widened where they are used (a scalar sign-extension each; the scalar unit has time): as 32
-  // registers they took the kernel to 106 SGPRs -- 7 waves per SIMD instead of 8, and spills.  (The empty asm keeps the
-  // compiler from widening them all ahead of the loop again.)
-  uint32_t bits = a.mask_bits;
-  asm volatile("" : "+s"(bits));
-  uint32_t Z[NB], O[NB];
+  // The four CODE planes (bit = the position's symbol has code c) of the 32 positions and of the 32 that follow.  "Window byte
+  // i of base b fits at position p" is then ONE shifted plane -- alignbit(next[c], here[c], 2 i), c = the code of the base's
+  // byte i -- where two bit planes compared against the base's masks took a shift each (shared by the bases), an XOR and a
+  // three-input operation per base: 110 instead of 137 instructions per lane and block, in a kernel that runs at two thirds of
+  // the VALU issue rate this device measures (profiles/r05_valu_rate.txt).  WHICH plane is a launch constant, and reading a
+  // register picked by a run-time value is what the VGPR index mode is for (s_set_gpr_idx_*: the index in M0 is added to the
+  // source registers of the VALU instructions that follow): the eight planes sit in FIXED registers v48..v51 (here) and
+  // v52..v55 (next), `v_alignbit_b32 e, v52, v48, 2 i` under index c reads next[c], here[c].  Measured before this: a uniform
+  // branch around four one-instruction arms per pick -- 0.101 ms per launch against 0.091 (taken branches cost the wave more
+  // than the instructions saved); as selects the picks cost more than they save.
+  register uint32_t q0 asm("v48") = ~(L | H);
+  register uint32_t q1 asm("v49") = L & ~H;
+  register uint32_t q2 asm("v50") = ~L & H;
+  register uint32_t q3 asm("v51") = L & H;
+  register uint32_t n0 asm("v52") = ~(Ln | Hn);
+  register uint32_t n1 asm("v53") = Ln & ~Hn;
+  register uint32_t n2 asm("v54") = ~Ln & Hn;
+  register uint32_t n3 asm("v55") = Ln & Hn;
+  uint32_t codes = ~a.mask_bits;   // (mask bit set = that bit of the code is 0)
+  asm volatile("" : "+s"(codes));
+  auto code = [&](int b, int i) { return (codes >> (16 * b + 2 * i)) & 3u; };   // (wave-uniform: a scalar bit-field extract)
+  uint32_t E[8][NB], Z[NB], O[NB];
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const uint32_t Li = i ? __builtin_amdgcn_alignbit(Ln, L, 2 * i) : L;
-    const uint32_t Hi = i ? __builtin_amdgcn_alignbit(Hn, H, 2 * i) : H;
-#pragma unroll
-    for (int b = 0; b < NB; b++) {
-      const uint32_t lo = static_cast<uint32_t>(static_cast<int32_t>(bits << (31 - (16 * b + 2 * i))) >> 31);
-      const uint32_t hi = static_cast<uint32_t>(static_cast<int32_t>(bits << (31 - (16 * b + 2 * i + 1))) >> 31);
-      const uint32_t E = (Li ^ lo) & (Hi ^ hi);
-      if (i == 0) {
-        Z[b] = E;
-      } else if (i == 1) {
-        O[b] = Z[b] | E;
-        Z[b] &= E;
+  for (int half = 0; half < 2; half++) {
+    // (the picks of four window bytes in one statement: nothing but the indexed reads runs under the index mode)
+    if (NB == 1) {
+      if (half == 0) {
+      asm volatile(
+          "s_set_gpr_idx_on %[c00], 0x3\n"
+          "v_mov_b32 %[e00], v48\n"
+          "s_set_gpr_idx_idx %[c10]\n"
+          "v_alignbit_b32 %[e10], v52, v48, 2\n"
+          "s_set_gpr_idx_idx %[c20]\n"
+          "v_alignbit_b32 %[e20], v52, v48, 4\n"
+          "s_set_gpr_idx_idx %[c30]\n"
+          "v_alignbit_b32 %[e30], v52, v48, 6\n"
+          "s_set_gpr_idx_off\n"
+          : [e00] "=&v"(E[0][0]), [e10] "=&v"(E[1][0]), [e20] "=&v"(E[2][0]), [e30] "=&v"(E[3][0])
+          : [c00] "s"(code(0, 0)), [c10] "s"(code(0, 1)), [c20] "s"(code(0, 2)), [c30] "s"(code(0, 3)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3));
       } else {
-        O[b] = Z[b] | (O[b] & E);
-        if (i < 7) Z[b] &= E;
+      asm volatile(
+          "s_set_gpr_idx_on %[c40], 0x3\n"
+          "v_alignbit_b32 %[e40], v52, v48, 8\n"
+          "s_set_gpr_idx_idx %[c50]\n"
+          "v_alignbit_b32 %[e50], v52, v48, 10\n"
+          "s_set_gpr_idx_idx %[c60]\n"
+          "v_alignbit_b32 %[e60], v52, v48, 12\n"
+          "s_set_gpr_idx_idx %[c70]\n"
+          "v_alignbit_b32 %[e70], v52, v48, 14\n"
+          "s_set_gpr_idx_off\n"
+          : [e40] "=&v"(E[4][0]), [e50] "=&v"(E[5][0]), [e60] "=&v"(E[6][0]), [e70] "=&v"(E[7][0])
+          : [c40] "s"(code(0, 4)), [c50] "s"(code(0, 5)), [c60] "s"(code(0, 6)), [c70] "s"(code(0, 7)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3));
+      }
+    } else {
+      if (half == 0) {
+      asm volatile(
+          "s_set_gpr_idx_on %[c00], 0x3\n"
+          "v_mov_b32 %[e00], v48\n"
+          "s_set_gpr_idx_idx %[c01]\n"
+          "v_mov_b32 %[e01], v48\n"
+          "s_set_gpr_idx_idx %[c10]\n"
+          "v_alignbit_b32 %[e10], v52, v48, 2\n"
+          "s_set_gpr_idx_idx %[c11]\n"
+          "v_alignbit_b32 %[e11], v52, v48, 2\n"
+          "s_set_gpr_idx_idx %[c20]\n"
+          "v_alignbit_b32 %[e20], v52, v48, 4\n"
+          "s_set_gpr_idx_idx %[c21]\n"
+          "v_alignbit_b32 %[e21], v52, v48, 4\n"
+          "s_set_gpr_idx_idx %[c30]\n"
+          "v_alignbit_b32 %[e30], v52, v48, 6\n"
+          "s_set_gpr_idx_idx %[c31]\n"
+          "v_alignbit_b32 %[e31], v52, v48, 6\n"
+          "s_set_gpr_idx_off\n"
+          : [e00] "=&v"(E[0][0]), [e01] "=&v"(E[0][1]), [e10] "=&v"(E[1][0]), [e11] "=&v"(E[1][1]), [e20] "=&v"(E[2][0]), [e21] "=&v"(E[2][1]), [e30] "=&v"(E[3][0]), [e31] "=&v"(E[3][1])
+          : [c00] "s"(code(0, 0)), [c01] "s"(code(1, 0)), [c10] "s"(code(0, 1)), [c11] "s"(code(1, 1)), [c20] "s"(code(0, 2)), [c21] "s"(code(1, 2)), [c30] "s"(code(0, 3)), [c31] "s"(code(1, 3)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3));
+      } else {
+      asm volatile(
+          "s_set_gpr_idx_on %[c40], 0x3\n"
+          "v_alignbit_b32 %[e40], v52, v48, 8\n"
+          "s_set_gpr_idx_idx %[c41]\n"
+          "v_alignbit_b32 %[e41], v52, v48, 8\n"
+          "s_set_gpr_idx_idx %[c50]\n"
+          "v_alignbit_b32 %[e50], v52, v48, 10\n"
+          "s_set_gpr_idx_idx %[c51]\n"
+          "v_alignbit_b32 %[e51], v52, v48, 10\n"
+          "s_set_gpr_idx_idx %[c60]\n"
+          "v_alignbit_b32 %[e60], v52, v48, 12\n"
+          "s_set_gpr_idx_idx %[c61]\n"
+          "v_alignbit_b32 %[e61], v52, v48, 12\n"
+          "s_set_gpr_idx_idx %[c70]\n"
+          "v_alignbit_b32 %[e70], v52, v48, 14\n"
+          "s_set_gpr_idx_idx %[c71]\n"
+          "v_alignbit_b32 %[e71], v52, v48, 14\n"
+          "s_set_gpr_idx_off\n"
+          : [e40] "=&v"(E[4][0]), [e41] "=&v"(E[4][1]), [e50] "=&v"(E[5][0]), [e51] "=&v"(E[5][1]), [e60] "=&v"(E[6][0]), [e61] "=&v"(E[6][1]), [e70] "=&v"(E[7][0]), [e71] "=&v"(E[7][1])
+          : [c40] "s"(code(0, 4)), [c41] "s"(code(1, 4)), [c50] "s"(code(0, 5)), [c51] "s"(code(1, 5)), [c60] "s"(code(0, 6)), [c61] "s"(code(1, 6)), [c70] "s"(code(0, 7)), [c71] "s"(code(1, 7)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3));
       }
     }
-    // (half way: the recurrence is brought up to date before the shifted planes of the last four window bytes are formed.
-    // Left alone the compiler forms all sixteen first and shares them between the bases: 65 registers with two bases, one
-    // more than eight waves per SIMD allow)
-    if (NB > 1 && i == 3) {
 #pragma unroll
-      for (int b = 0; b < NB; b++) asm volatile("" : "+v"(Z[b]), "+v"(O[b]));
-    }
+    for (int i = 4 * half; i < 4 * half + 4; i++)
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        const uint32_t e = E[i][b];
+        if (i == 0) {
+          Z[b] = e;
+        } else if (i == 1) {
+          O[b] = Z[b] | e;
+          Z[b] &= e;
+        } else {
+          O[b] = Z[b] | (O[b] & e);
+          if (i < 7) Z[b] &= e;
+        }
+      }
   }
   return NB > 1 ? (O[0] | O[NB - 1]) : O[0];
 }
