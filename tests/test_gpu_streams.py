@@ -146,7 +146,7 @@ def test_selection_in_the_stream_kernel_vs_oracle(rj, oracle):
     scan_dense_walk: the answer is still the oracle's), a packed stretch across a tile edge inside sparse text, own ranges."""
     rng = random.Random(61)
     sparse_alphabet = bytes(range(0x30, 0x7a))
-    took = void = 0
+    took = void = direct = 0
     for rx in SELECT_SHAPES:
         p = rj.Program(rx)
         for n in (17, 33, 2047, 2049, 20000, 32767, 32769, 34817, 70001, 300000, 1 << 20):
@@ -165,9 +165,16 @@ def test_selection_in_the_stream_kernel_vs_oracle(rj, oracle):
                 cut = 32768 + 5
                 first, _ = run_scan(rj, scan, text, own_begin=0, own_end=cut)
                 assert first == [m for m in want if m[0] < cut], (rx, cut)
+        # ONE tile packed with matches: more pairs than a stage holds, so the tile is computed a second time writing directly --
+        # with the selection made again (no tile before it: the kernel answers)
+        scan = rj.Scan(p)
+        one_tile = bytes(rng.choice(b"0123456789ab") for _ in range(30000))
+        got, st = run_scan(rj, scan, one_tile)
+        assert got == oracle.match_all(rx, one_tile), (rx, "one packed tile")
+        direct += st["stream_path"]
         scan = rj.Scan(p)
         packed = bytes(rng.choice(b"0123456789ab") for _ in range(100000))
         got, st = run_scan(rj, scan, packed)
         assert got == oracle.match_all(rx, packed), (rx, "packed")
         void += 1 - st["stream_path"]
-    assert took >= 30 and void >= 5, (took, void)
+    assert took >= 30 and void >= 5 and direct >= 5, (took, void, direct)
