@@ -375,6 +375,7 @@ __global__ __launch_bounds__(256) void dense_streams(StreamParams a) {
   }
 }
 
+#ifndef RJ_DENSE_SELECT_TU
 uint64_t stream_tiles(uint64_t sb, uint64_t se, uint64_t n, uint64_t* first_tile) {
   const uint64_t lim = se < n ? se : n;
   *first_tile = (sb + kStreamShift) / kTile;
@@ -385,19 +386,25 @@ uint64_t stream_tiles(uint64_t sb, uint64_t se, uint64_t n, uint64_t* first_tile
 size_t stream_scratch_bytes(uint64_t n_tiles) {
   return (lookback::granule_words((n_tiles + kTilesPerTicket - 1) / kTilesPerTicket) + 1) * sizeof(unsigned long long);
 }
+#endif
 
-// scratch: [0] the ticket counter, [1 ..] one granule per ticket (four tiles), then one per group of tickets; cleared here
+// The kernels are instantiated in TWO translation units that compile side by side: this file (the plain kernels) and
+// dense_streams_select.hip, which includes this file with RJ_DENSE_SELECT_TU defined (the SELECT kernels) -- 96 kernels in one unit
+// took 3.4 of a clean build's 4 minutes.
+void launch_dense_streams_shape(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipStream_t st);         // this unit
+void launch_dense_streams_select_shape(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipStream_t st);  // the other
+
 namespace {
+#ifdef RJ_DENSE_SELECT_TU
+constexpr bool kSelectUnit = true;
+#else
+constexpr bool kSelectUnit = false;
+#endif
 template <int NP, int NR>
 void launch_nr(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
   const dim3 b(256);
-  if (a.plan.select) {
-    if (a.plan.high_half == 0) hipExtLaunchKernelGGL((dense_streams<NP, NR, false, true>), g, b, 0, st, t0, t1, 0, a);
-    else hipExtLaunchKernelGGL((dense_streams<NP, NR, true, true>), g, b, 0, st, t0, t1, 0, a);
-    return;
-  }
-  if (a.plan.high_half == 0) hipExtLaunchKernelGGL((dense_streams<NP, NR, false, false>), g, b, 0, st, t0, t1, 0, a);
-  else hipExtLaunchKernelGGL((dense_streams<NP, NR, true, false>), g, b, 0, st, t0, t1, 0, a);
+  if (a.plan.high_half == 0) hipExtLaunchKernelGGL((dense_streams<NP, NR, false, kSelectUnit>), g, b, 0, st, t0, t1, 0, a);
+  else hipExtLaunchKernelGGL((dense_streams<NP, NR, true, kSelectUnit>), g, b, 0, st, t0, t1, 0, a);
 }
 template <int NP>
 void launch_np(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
@@ -407,15 +414,7 @@ void launch_np(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipS
   else if (nr <= 4) launch_nr<NP, 4>(a, g, t0, t1, st);
   else launch_nr<NP, 8>(a, g, t0, t1, st);
 }
-}  // namespace
-
-void launch_dense_streams(StreamParams a, unsigned long long* scratch, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
-  (void)hipMemsetAsync(scratch, 0, stream_scratch_bytes(a.n_tiles), st);
-  a.ticket = scratch;
-  a.granules = scratch + 1;
-  uint64_t blocks = (a.n_tiles + kTilesPerTicket - 1) / kTilesPerTicket;
-  blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;  // persistent: workgroups take tickets until none is left
-  const dim3 g(static_cast<unsigned>(blocks));
+void launch_shape(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
   const uint32_t np = a.plan.n_pos;
   if (np <= 1) launch_np<1>(a, g, t0, t1, st);
   else if (np <= 2) launch_np<2>(a, g, t0, t1, st);
@@ -424,5 +423,24 @@ void launch_dense_streams(StreamParams a, unsigned long long* scratch, hipEvent_
   else if (np <= 6) launch_np<6>(a, g, t0, t1, st);
   else launch_np<8>(a, g, t0, t1, st);
 }
+}  // namespace
+
+#ifdef RJ_DENSE_SELECT_TU
+void launch_dense_streams_select_shape(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipStream_t st) { launch_shape(a, g, t0, t1, st); }
+#else
+void launch_dense_streams_shape(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipStream_t st) { launch_shape(a, g, t0, t1, st); }
+
+// scratch: [0] the ticket counter, [1 ..] one granule per ticket (four tiles), then one per group of tickets; cleared here
+void launch_dense_streams(StreamParams a, unsigned long long* scratch, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+  (void)hipMemsetAsync(scratch, 0, stream_scratch_bytes(a.n_tiles), st);
+  a.ticket = scratch;
+  a.granules = scratch + 1;
+  uint64_t blocks = (a.n_tiles + kTilesPerTicket - 1) / kTilesPerTicket;
+  blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;  // persistent: workgroups take tickets until none is left
+  const dim3 g(static_cast<unsigned>(blocks));
+  if (a.plan.select) launch_dense_streams_select_shape(a, g, t0, t1, st);
+  else launch_dense_streams_shape(a, g, t0, t1, st);
+}
+#endif
 
 }  // namespace rejit_amd
