@@ -152,6 +152,10 @@ def test_selection_across_tiles(ce, oracle):
         k, got, st = stream_match_all(ce, rx, tx)
         assert k >= 0 and st[2] == 0, (rx, k)
         assert got == oracle.match_all(rx, tx), rx
+        # own ranges that begin inside the second tile / end inside the third (a sharded run: the selection restarts at `lo`)
+        for lo, hi in ((40000, 90000), (32768 - 5, 65536 + 5), (65536, n + 1)):
+            k, got, st = stream_match_all(ce, rx, tx, lo, hi)
+            assert k >= 0 and got == [(b + lo, e + lo) for b, e in oracle.match_all(rx, tx[lo:]) if b + lo < hi], (rx, lo, hi)
         packed = bytes(rng.choice(b"0123456789ab") for _ in range(n))
         k, got, st = stream_match_all(ce, rx, packed)
         assert k == -103 or got == oracle.match_all(rx, packed), (rx, k)
