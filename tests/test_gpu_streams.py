@@ -165,6 +165,10 @@ def test_selection_in_the_stream_kernel_vs_oracle(rj, oracle):
                 cut = 32768 + 5
                 first, _ = run_scan(rj, scan, text, own_begin=0, own_end=cut)
                 assert first == [m for m in want if m[0] < cut], (rx, cut)
+                # a range that begins inside the second tile: the selection restarts there (nothing carried in)
+                lo = 40000
+                rest, _ = run_scan(rj, scan, text, own_begin=lo, own_end=n + 1)
+                assert rest == [(b + lo, e + lo) for b, e in oracle.match_all(rx, text[lo:])], (rx, lo)
         # ONE tile packed with matches: more pairs than a stage holds, so the tile is computed a second time writing directly --
         # with the selection made again (no tile before it: the kernel answers)
         scan = rj.Scan(p)
