@@ -70,6 +70,7 @@ typedef struct {
   int32_t linear_path;    /* 1 when a candidate outlived the parallel verifier's walk and the linear-time carry scan ran */
   int32_t stream_path;    /* 1 when the bit-stream dense kernel produced the result (one pass, pairs written once) */
   int32_t slow_starts;    /* that kernel: starts that outlived its register steps and took the scalar walk (saturating) */
+  int32_t count_path;     /* 1 when the one-kernel count (plane_count.hip) answered: a count and bounds, no span list (round 6) */
 } rj_stats;
 
 /* ---- compile (replaces Regej::Regej + Regej::Compile, src/rejit.cc:127-137,229-267) */
@@ -91,6 +92,10 @@ int rj_match_first(const rj_program* prog, const char* text, size_t n, uint64_t*
  * to only count. */
 int64_t rj_match_all(const rj_program* prog, const char* text, size_t n, uint64_t** spans);
 void rj_free_spans(uint64_t* spans);
+/* rj_stats of the calling thread's last rj_match_all / rj_match_first / rj_replace_all ... of `prog` (which kernels answered:
+ * count_path, stream_path, linear_path, ...), as rj_scan_stats_sized.  RJ_BAD_ARGUMENT when this thread has made no such
+ * call (calls of several threads combined into one batch are accounted to the thread that led the batch). */
+int rj_host_stats(const rj_program* prog, void* stats, size_t struct_size);
 
 /* A batch of independent texts in ONE device pass -- replaces the per-file loop of a grep-like
  * caller (`for each file: re->MatchAll(file, size, &matches)`, sample/jrep.cc:261-313), whose
@@ -151,6 +156,14 @@ int64_t rj_scan_run(rj_scan* scan, const void* d_text, uint64_t n, uint64_t own_
  * earlier ones overlap them. */
 int rj_scan_start(rj_scan* scan, const void* d_text, uint64_t n, void* hip_stream);
 int64_t rj_scan_finish(rj_scan* scan);
+/* MatchAllCount over device text (Regej::MatchAllCount, reference src/rejit.cc:203-208, is MatchAll with a NULL vector: the
+ * caller wants the NUMBER of matches).  A pattern with the shape the one-kernel count takes (plane_count.hip; every regexdna
+ * pattern, sample/regexdna.cc:51-61) is answered by that kernel -- the text read once, nothing written but the count;
+ * rj_stats.count_path reads 1, rj_scan_device_spans NULL, and rj_scan_copy_spans / rj_scan_replace refuse with
+ * RJ_BAD_ARGUMENT (there is no list).  Any other pattern, and a text on which the kernel voids its run, takes rj_scan_run's
+ * pipeline (whole text, no carry).  rj_match_all(prog, text, n, NULL) does the same for host texts.  Returns the count or
+ * rj_status. */
+int64_t rj_scan_count(rj_scan* scan, const void* d_text, uint64_t n, void* hip_stream);
 /* results of the last run: device pointer to 2*count uint64 offsets, or a copy (host_spans may be host or
  * device memory; returns the number of matches, copies at most cap of them) */
 const uint64_t* rj_scan_device_spans(const rj_scan* scan);
@@ -210,11 +223,14 @@ int rj_multi_set_tail_stream(rj_multi* multi, int on);
  * patterns all match exactly 8 bytes within one byte of the scan's base windows (k-mers with one degenerate position,
  * both strands: regexdna's nine) rj_multi_run / _run_range / _start + _finish then run ONE kernel (plane_count.hip): the
  * text once, every candidate's eight bytes looked up in a table, nothing written but the counts.  Their return value is
- * 3 for such a run.  Afterwards counts[] and rj_multi_bounds / _bounds_device / rj_multi_device_counts work as ever;
- * rj_scan_device_spans(rj_multi_scan(m, i)) is NULL (no span list was made).  Exactness: the counts are those of the
- * left-most-longest, non-overlapping selection; a text on which that differs from the number of matching positions (two
- * matches of ONE pattern fewer than 8 bytes apart) makes the kernel void its run, and the call -- and every later one on
- * this object -- is answered by the span pipeline (return value 1).  Any other pattern set ignores the switch.
+ * 3 for such a run.  Afterwards counts[] and rj_multi_bounds / _bounds_device / rj_multi_device_counts work as ever (every
+ * workgroup of the kernel records its first / last match per pattern: nothing is read again, the text may be gone);
+ * rj_scan_device_spans(rj_multi_scan(m, i)) is NULL (no span list was made) and rj_scan_copy_spans / rj_scan_replace on it
+ * return RJ_BAD_ARGUMENT.  Exactness: the counts are those of the left-most-longest, non-overlapping selection.  Two matches
+ * of ONE pattern fewer than 8 bytes apart (`agggtaaagggtaaa`) are resolved inside the kernel when they form an isolated
+ * pair; a longer chain of such neighbours, or a pair across two waves' spans, makes the kernel void its run, and THAT call
+ * is answered by the span pipeline (return value 1) -- the next call tries the kernel again.  Any other pattern set ignores
+ * the switch.  An rj_multi of ONE pattern takes the switch too.
  * Returns 1 when runs will take the one-kernel path, 0 when the set does not have the shape, < 0 rj_status. */
 int rj_multi_set_counts_only(rj_multi* multi, int on);
 /* rj_scan_set_timing for every pattern of the object (rj_multi_scan_ms reads 0 when off). */

@@ -80,22 +80,33 @@ def _build_locked(verbose: bool) -> str:
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread"]
 
-    # an object is kept when it was compiled from this very source and these very headers (content hash beside it):
-    # kernels.hip alone takes about a minute, a change to one file should cost that file
+    # an object is kept when it was compiled from this very source and the very headers IT includes (content hash beside
+    # it): kernels.hip alone takes about a minute, a change to one file -- or to a header three sources use -- should cost
+    # those files only
     import hashlib
-    hh = hashlib.sha256(" ".join(flags).encode())
-    for f in HEADERS:
-        with open(os.path.join(CSRC, f), "rb") as fh:
-            hh.update(fh.read())
-    for f in ("rejit.h", "rejit_hip.h"):
-        with open(os.path.join(PKG, "..", "include", f), "rb") as fh:
-            hh.update(fh.read())
-    headers_hash = hh.hexdigest()
+    import re
+    inc_re = re.compile(rb'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+    def closure(path, seen):
+        path = os.path.normpath(path)
+        if path in seen or not os.path.exists(path):
+            return
+        seen.add(path)
+        with open(path, "rb") as fh:
+            body = fh.read()
+        for m in inc_re.finditer(body):
+            closure(os.path.join(os.path.dirname(path), m.group(1).decode()), seen)
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        with open(os.path.join(CSRC, src), "rb") as fh:
-            want = hashlib.sha256(headers_hash.encode() + fh.read()).hexdigest()
+        deps = set()
+        closure(os.path.join(CSRC, src), deps)
+        hh = hashlib.sha256(" ".join(flags).encode())
+        for d in sorted(deps):
+            hh.update(os.path.basename(d).encode())
+            with open(d, "rb") as fh:
+                hh.update(fh.read())
+        want = hh.hexdigest()
         stamp = obj + ".srchash"
         try:
             if os.path.exists(obj) and open(stamp).read().strip() == want:
@@ -134,7 +145,7 @@ class _Stats(ctypes.Structure):
     _fields_ = [("n_hits", ctypes.c_uint64), ("n_candidates", ctypes.c_uint64), ("n_matches", ctypes.c_uint64),
                 ("scan_ms", ctypes.c_float), ("total_ms", ctypes.c_float), ("retries", ctypes.c_int32),
                 ("large_path", ctypes.c_int32), ("exact_path", ctypes.c_int32), ("linear_path", ctypes.c_int32),
-                ("stream_path", ctypes.c_int32), ("slow_starts", ctypes.c_int32)]
+                ("stream_path", ctypes.c_int32), ("slow_starts", ctypes.c_int32), ("count_path", ctypes.c_int32)]
 
 
 _lib = None
@@ -155,7 +166,7 @@ C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_er
                  "rj_multi_bounds", "rj_batch_separator", "rj_match_all_packed", "rj_host_alloc", "rj_host_free",
                  "rj_multi_bounds_device", "rj_carry_decide", "rj_multi_start", "rj_multi_finish", "rj_multi_order_after",
                  "rj_multi_device_counts", "rj_multi_device_counts_via", "rj_multi_set_tail_stream", "rj_multi_set_timing", "rj_scan_set_timing", "rj_set_default_timing",
-                 "rj_scan_gather_spans", "rj_scan_gather_spans_via", "rj_scan_gathered_spans", "rj_multi_set_counts_only", "rj_stream_read_probe", "rj_scan_stats_sized", "rj_scan_copy_gathered_spans"]
+                 "rj_scan_gather_spans", "rj_scan_gather_spans_via", "rj_scan_gathered_spans", "rj_multi_set_counts_only", "rj_stream_read_probe", "rj_scan_stats_sized", "rj_scan_copy_gathered_spans", "rj_scan_count", "rj_host_stats"]
 
 
 def load_library():
@@ -224,6 +235,10 @@ def load_library():
     L.rj_scan_gathered_spans.restype = vp
     L.rj_scan_gathered_spans.argtypes = [vp, _u64p]
     L.rj_scan_run.restype = i64
+    L.rj_host_stats.restype = ctypes.c_int
+    L.rj_host_stats.argtypes = [vp, vp, sz]
+    L.rj_scan_count.restype = i64
+    L.rj_scan_count.argtypes = [vp, vp, u64, vp]
     L.rj_scan_run.argtypes = [vp, vp, u64, u64, u64, u64, u64, ctypes.c_int, vp]
     L.rj_scan_start.argtypes = [vp, vp, u64, vp]
     L.rj_scan_finish.restype = i64
@@ -364,7 +379,14 @@ class Program:
         return out
 
     def count(self, text: bytes) -> int:
+        """Regej::MatchAllCount: rj_match_all with a NULL span list."""
         return int(_check(self._lib.rj_match_all(self._h, text, len(text), None)))
+
+    def host_stats(self) -> dict:
+        """rj_host_stats: which kernels answered this thread's last host-text call of the pattern."""
+        s = _Stats()
+        _check(self._lib.rj_host_stats(self._h, ctypes.byref(s), ctypes.sizeof(s)))
+        return {k: (float(getattr(s, k)) if k.endswith("_ms") else int(getattr(s, k))) for k, _ in _Stats._fields_}
 
     def replace_all(self, text: bytes, repl: bytes) -> Tuple[int, bytes]:
         """(number of matches, new text): MatchAll + Replace, spliced on the GPU."""
@@ -413,6 +435,18 @@ class Scan:
             own_end = n + 1
         return int(_check(self._lib.rj_scan_run(self._h, ctypes.c_void_p(d_text_ptr), n, own_begin, own_end, carry_cur,
                                                 carry_prev_end, int(have_prev), ctypes.c_void_p(stream))))
+
+    def count(self, d_text_ptr: int, n: int, stream: int = 0) -> int:
+        """rj_scan_count: MatchAllCount over device text (the one-kernel count when the pattern has the shape:
+        stats()["count_path"] == 1, no span list)."""
+        return int(_check(self._lib.rj_scan_count(self._h, ctypes.c_void_p(d_text_ptr), n, ctypes.c_void_p(stream))))
+
+    def count_tensor(self, t, n: Optional[int] = None, stream=None) -> int:
+        import torch
+
+        assert t.dtype == torch.uint8 and t.is_contiguous() and t.is_cuda
+        st = torch.cuda.current_stream(t.device).cuda_stream if stream is None else stream
+        return self.count(t.data_ptr(), int(t.numel() if n is None else n), stream=st)
 
     def gather_spans(self, d_text_ptr: int, n: int, offset: int, rank: int, world: int, root: int = 0, comm: Optional[int] = None,
                      allgather=None, gatherv=None, own_begin: int = 0, own_end: Optional[int] = None, stream: int = 0):

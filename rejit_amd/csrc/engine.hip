@@ -1082,6 +1082,7 @@ void rj_scan_destroy(rj_scan* s) {
     if (e) (void)hipEventDestroy(e);
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
   if (s->tail_stream) (void)hipStreamDestroy(s->tail_stream);
+  if (s->counter) rj_multi_destroy(s->counter);
   delete s;
 }
 
@@ -1209,6 +1210,7 @@ int64_t rj_scan_copy_spans(const rj_scan* s, uint64_t* host_spans, uint64_t cap)
   ErrnoGuard errno_guard;
   if (!s) return fail(RJ_BAD_ARGUMENT, "null scan");
   const uint64_t k = std::min<uint64_t>(cap, s->result_count);
+  if (k && !s->result) return fail(RJ_BAD_ARGUMENT, "the last run was counts-only: there is no span list (rj_multi_set_counts_only / rj_scan_count)");
   if (k) {
     // (hipMemcpyDefault: the destination may be host or device memory.  The run has been synchronised
     // before it returned; the copy goes over a non-blocking stream of the calling thread -- hipMemcpy on the
@@ -1246,6 +1248,7 @@ int64_t rj_scan_replace(rj_scan* s, const void* d_text, uint64_t n, const char* 
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const uint64_t m = s->result_count;
   const uint64_t* spans = s->result;
+  if (m && !spans) return fail(RJ_BAD_ARGUMENT, "the last run was counts-only: there is no span list to replace (rj_multi_set_counts_only / rj_scan_count)");
   RJ_HIP(s->with_buf.reserve(std::max<uint64_t>(with_len, 16)));
   if (with_len) RJ_HIP(hipMemcpyAsync(s->with_buf.p, with, with_len, hipMemcpyHostToDevice, st));
   RJ_HIP(s->scan_a.reserve(std::max<uint64_t>(m, 1) * sizeof(uint64_t)));

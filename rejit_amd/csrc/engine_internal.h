@@ -149,6 +149,10 @@ struct rj_scan {
   int64_t* gx_host = nullptr;
   const uint64_t* gathered = nullptr;
   uint64_t gathered_count = 0;
+  // rj_scan_count / rj_match_all(..., NULL): a private rj_multi of this one pattern on the counts path (multi_pattern.hip:
+  // scan_count); state 0 not looked at yet, 1 the pattern has the shape, -1 it has not
+  struct rj_multi* counter = nullptr;
+  int counter_state = 0;
 };
 
 namespace rejit_amd {
@@ -160,6 +164,9 @@ int resolve_selection(rj_scan* s, const FinalizeParams& fp, hipStream_t st);
 WindowSet make_window_set(const rj_program* rp);
 int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, uint64_t carry_cur, uint64_t carry_prev_end,
                  int have_prev, hipStream_t st);
+// multi_pattern.hip: MatchAllCount of the scan's pattern over a device text -- the one-kernel count (plane_count.hip) when
+// the pattern has the shape, else the pipeline; the count or rj_status
+int64_t scan_count(rj_scan* s, const uint8_t* d_text, uint64_t n, hipStream_t st);
 // host_api.hip
 void forget_host_scans(uint64_t program_id);
 void forget_combiner(uint64_t program_id);

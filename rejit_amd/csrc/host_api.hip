@@ -198,6 +198,11 @@ int64_t rejit_amd::rj_match_range_host(const rj_program* prog, const char* text,
   const uint8_t* d_text = nullptr;
   rc = stage_text(s, text, n, &d_text);
   if (rc != RJ_OK) return rc;
+  if (!spans && own_begin == 0 && own_end >= n + 1 && !have_prev && d_text != reinterpret_cast<const uint8_t*>(s->small_text)) {
+    // the caller wants the NUMBER of matches (Regej::MatchAllCount, reference src/rejit.cc:203-208): the one-kernel count
+    // for the patterns that have the shape (plane_count.hip), the pipeline for the others
+    return scan_count(s, d_text, n, s->own_stream);
+  }
   rc = run_pipeline(s, d_text, n, own_begin, own_end, carry_cur, carry_prev_end, have_prev, s->own_stream);
   if (rc != RJ_OK) return rc;
   if (spans && s->result_count) {
@@ -589,6 +594,13 @@ int64_t rejit_amd::rj_match_all_batch_one_device(const rj_program* prog, const c
 extern "C" {
 
 int rj_batch_separator(const rj_program* prog) { return prog ? prog->batch_separator : -1; }
+
+int rj_host_stats(const rj_program* prog, void* stats, size_t struct_size) {
+  if (!prog || !stats) return fail(RJ_BAD_ARGUMENT, "null argument");
+  for (auto& p : g_host_scans.v)
+    if (p.first == prog->id) return rj_scan_stats_sized(p.second, stats, struct_size);
+  return fail(RJ_BAD_ARGUMENT, "rj_host_stats: this thread has made no host-text call of the pattern (or the call was combined with other threads')");
+}
 
 void* rj_host_alloc(size_t bytes) {
   ErrnoGuard errno_guard;

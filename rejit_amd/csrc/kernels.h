@@ -188,16 +188,18 @@ void launch_plane_scan(const PlaneParams& a, int grid, hipEvent_t t0, hipEvent_t
 // ---- plane count (plane_count.hip, exact_count.h): the same scan for callers that want COUNTS (MatchAllCount,
 // reference src/rejit.cc:203-208), scan + exact classification + counting in ONE kernel.  The caller zeroes `acc`
 // once (kPcAccWords words); a run leaves its results in `host_out` (pinned, kPcHostWords words) and a device copy in `acc`.
-enum { kPcConflict = 1,   // two matches of one pattern fewer than 8 bytes apart (the count needs the selection): run void
+enum { kPcConflict = 1,   // matches of one pattern that overlap in a way the kernel does not resolve itself (three candidates in a row, each
+                          // closer to its neighbour than a match is long, or a pair across two waves' spans): run void
        kPcVoid = 2 };     // a 2-KiB block held more candidates than a wave's ring: run void
-constexpr uint32_t kPcBounds = 0;                      // acc: [32][2] first / last match begin of the last run (device copy)
+constexpr uint32_t kPcBounds = 0;                      // acc: [32][2] first / last match (kPcNone, or begin | length << kPcLenShift) of the last run (device copy)
 constexpr uint32_t kPcTotals = kPcBounds + 64;         // [32]: the last run's counts (device copy)
 constexpr uint32_t kPcFinishGroups = 8;                // workgroups of plane_count_finish
 constexpr uint32_t kPcTicket = kPcTotals + 32;         // their ticket (zero between runs)
-constexpr uint32_t kPcGroupRows = kPcTicket + 16;      // [kPcFinishGroups][32]: their sums (slot 31: the flags)
-constexpr uint32_t kPcAccWords = kPcGroupRows + kPcFinishGroups * 32;
+constexpr uint32_t kPcGroupRows = kPcTicket + 16;      // [kPcFinishGroups][3][32]: their sums (slot 31: the flags) | first | last row + 1 with a match (0: none)
+constexpr uint32_t kPcAccWords = kPcGroupRows + kPcFinishGroups * 96;
 constexpr uint32_t kPcHostCount = 0, kPcHostFlags = 32, kPcHostBounds = 40, kPcHostWords = 40 + 64;
-constexpr unsigned long long kPcNone = ~0ull, kPcUnknown = ~0ull - 1;   // bounds: no match / matches, but none in an edge wave's span
+constexpr unsigned long long kPcNone = ~0ull;          // bounds: no match
+constexpr uint32_t kPcLenShift = 56;                   // a bound = begin | length << 56
 struct PlaneCountParams {
   const uint8_t* text;   // 16-byte aligned
   uint64_t n;
@@ -206,15 +208,14 @@ struct PlaneCountParams {
   uint64_t span_blocks;  // wave w owns span_blocks blocks, the first span_extra waves one more, one after the other from first_block
   uint32_t span_extra;
   uint32_t code_shift, n_bases, n_patterns;
-  uint32_t edge_waves;   // the first and the last edge_waves waves of the grid record their first / last match per pattern
   uint32_t batch_at;     // a wave classifies what its ring holds (<= 64 at a time) when that many are waiting, 1..64
   uint32_t mask_bits;    // bit 16 b + 2 i / + 1: the low / high bit of the symbol code of base b's window byte i is 0
   uint32_t base_lo[2], base_hi[2];   // the bases' 8 bytes (ExactCountPlan)
   const uint32_t* table;             // ExactCountPlan::table in device memory
   unsigned long long* acc;
   uint32_t* wg_rows;                 // [grid][32]: every workgroup's counts (slot 31: its flags)
+  unsigned long long* wg_bounds;     // [grid][32][2]: every workgroup's first / last match per pattern (as kPcBounds)
   unsigned long long* host_out;
-  unsigned long long* edge_rows;     // [2 * edge_waves][32][4]: count, first begin, last begin
 };
 void launch_plane_count(const PlaneCountParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 // the rows of that launch (grid workgroups) added up: counts, flags, bounds -> a.host_out and a.acc

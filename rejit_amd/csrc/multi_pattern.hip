@@ -104,16 +104,32 @@ PlanePlan plan_plane(const std::vector<rj_scan*>& scans) {
     for (int i = 0; i < 8; i++) d += (!w.fixed[i] || w.v[i] != base[i]) ? 1 : 0;
     return d;
   };
+  // pass 0: exact windows become bases; pass 1 (round 6: `[cgt]gggtaaa|tttaccc[acg]` ALONE has no exact window): a window
+  // with ONE free position becomes a base with one of its own fixed bytes there -- any byte will do, the window's strings
+  // all lie within one byte of it, and one of its own keeps the alphabet at <= 4 symbols; pass 2: everything is covered
   int nb = 0;
-  for (int pass = 0; pass < 2; pass++)
+  for (int pass = 0; pass < 3; pass++)
     for (const Win& w : wins) {
       bool covered = false;
       for (int b = 0; b < nb; b++) covered = covered || off(w, pl.base[b]) <= 1;
       if (covered) continue;
-      bool exact = true;
-      for (int i = 0; i < 8; i++) exact = exact && w.fixed[i];
-      if (pass == 0 && exact && nb < 2) memcpy(pl.base[nb++], w.v, 8);
-      else if (pass == 1) return pl;  // not within one byte of a base
+      int n_free = 0, free_at = 0, fixed_at = -1;
+      for (int i = 0; i < 8; i++) {
+        if (!w.fixed[i]) {
+          n_free++;
+          free_at = i;
+        } else if (fixed_at < 0) {
+          fixed_at = i;
+        }
+      }
+      if (pass == 0 && n_free == 0 && nb < 2) {
+        memcpy(pl.base[nb++], w.v, 8);
+      } else if (pass == 1 && n_free == 1 && nb < 2) {
+        memcpy(pl.base[nb], w.v, 8);
+        pl.base[nb++][free_at] = w.v[fixed_at];
+      } else if (pass == 2) {
+        return pl;  // not within one byte of a base
+      }
     }
   if (nb == 0) return pl;
   // symbol codes: the distinct bytes of the bases must get distinct codes (else the test loses its selectivity)
@@ -304,16 +320,11 @@ struct rj_multi {
   int64_t* host_decision = nullptr;
   // rj_multi_set_counts_only: MatchAllCount in ONE kernel (plane_count.hip) for the sets exact_count.h takes
   bool counts_only = false;
-  bool counts_off = false;     // a counts run was void (two matches of one pattern within 8 bytes, a block full of candidates): spans from now on
   ExactCountPlan exact;
-  DeviceBuffer exact_table, count_acc, edge_rows, wg_rows;
-  unsigned long long* count_out = nullptr;   // pinned: counts, flags, first / last match begin per pattern
-  bool last_counts = false;    // the last run left counts (no span lists); the run's arguments, for a caller that then asks for more
-  struct LastRun {
-    const uint8_t* text = nullptr;
-    uint64_t n = 0, sb = 0, se = 0;
-    hipStream_t st = nullptr;
-  } last_run;
+  DeviceBuffer exact_table, count_acc, wg_rows, wg_bounds;
+  unsigned long long* count_out = nullptr;   // pinned: counts, flags, first / last match per pattern
+  bool counts_ready = false;   // the buffers above are allocated and cleared
+  bool last_counts = false;    // the last run left counts (no span lists)
   uint32_t counts_fallbacks = 0;
 
 };
@@ -834,15 +845,32 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
 }
 
 
-constexpr uint32_t kEdgeWaves = 64;   // (<= 64: plane_count_finish reads a pattern's edge rows with one wave) waves at either end of the grid that record their first / last match (plane_count.hip)
-
 bool counts_path(const rj_multi* m) {
   static const bool off = getenv("RJ_NO_COUNTS") != nullptr;  // measurement override
-  return m->counts_only && !m->counts_off && m->exact.ok && m->plane.ok && !m->plane.general && m->plane.offset == 0 && m->mode == 0 && !off;
+  return m->counts_only && m->exact.ok && m->plane.ok && !m->plane.general && m->plane.offset == 0 && m->mode == 0 && !off;
+}
+
+// the span lists of every pattern over the starts [sb, se), synchronously: what rj_multi_run does without the counts switch
+// (1 one pass, 2 separate scans + batched tails, 0 one pipeline after the other; < 0 rj_status)
+int run_spans(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, hipStream_t st) {
+  if (m->fused && m->mode == 0 && n >= 16) {
+    int rc = run_batched(m, d_text, n, sb, se, st, true);
+    return rc != RJ_OK ? rc : 1;
+  }
+  if (m->batchable && n >= 16) {
+    int rc = run_batched(m, d_text, n, sb, se, st, false);
+    return rc != RJ_OK ? rc : 2;
+  }
+  for (rj_scan* s : m->scans) {
+    int rc = run_pipeline(s, d_text, n, sb, se, 0, 0, 0, st);
+    if (rc != RJ_OK) return rc;
+  }
+  return 0;
 }
 
 // MatchAllCount of every pattern over the starts [sb, se) in one kernel.  phase as run_batched.  A void run (flags) is
-// repeated by the span pipeline, synchronously, and the object stays there.
+// repeated by the span pipeline, synchronously -- THAT run: the next one tries the kernel again (round 5 left the object
+// on the span pipeline for good after one tandem repeat).
 int run_counts(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, hipStream_t st, int phase) {
   const int P = static_cast<int>(m->scans.size());
   rj_scan* const s0 = m->scans[0];
@@ -856,14 +884,13 @@ int run_counts(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint
     // 0.101: a wave's fixed costs, the pipeline's first trip and the classification of its candidates, want long spans)
     static const int count_chunks = getenv("RJ_COUNT_CHUNKS") ? atoi(getenv("RJ_COUNT_CHUNKS")) : 160;  // measurement override
     const ScanGeometry geo = scan_geometry(std::max<uint64_t>(blocks * 2, 1), static_cast<uint64_t>(count_chunks > 0 ? count_chunks : 160));
-    if (!m->count_out) {
-      RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&m->count_out), sizeof(unsigned long long) * kPcHostWords));
+    if (!m->counts_ready) {
+      if (!m->count_out) RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&m->count_out), sizeof(unsigned long long) * kPcHostWords));
       RJ_HIP(m->exact_table.reserve(sizeof(uint32_t) * kExactTabWords));
       RJ_HIP(hipMemcpyAsync(m->exact_table.p, m->exact.table, sizeof(uint32_t) * kExactTabWords, hipMemcpyHostToDevice, st));
       RJ_HIP(m->count_acc.reserve(sizeof(unsigned long long) * kPcAccWords));
       RJ_HIP(hipMemsetAsync(m->count_acc.p, 0, sizeof(unsigned long long) * kPcAccWords, st));
-      RJ_HIP(m->edge_rows.reserve(sizeof(unsigned long long) * 2 * kEdgeWaves * kExactMaxPatterns * 4));
-      RJ_HIP(hipMemsetAsync(m->edge_rows.p, 0, sizeof(unsigned long long) * 2 * kEdgeWaves * kExactMaxPatterns * 4, st));
+      m->counts_ready = true;   // (only now: a failure above leaves the next call to start over)
     }
     PlaneCountParams pc{};
     pc.text = d_text;
@@ -877,7 +904,6 @@ int run_counts(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint
     pc.code_shift = m->plane.code_shift;
     pc.n_bases = m->plane.n_bases;
     pc.n_patterns = static_cast<uint32_t>(P);
-    pc.edge_waves = kEdgeWaves;
     static const int batch_at = getenv("RJ_COUNT_BATCH") ? atoi(getenv("RJ_COUNT_BATCH")) : 64;  // measurement override
     pc.batch_at = static_cast<uint32_t>(std::min(std::max(batch_at, 1), 64));
     for (uint32_t b = 0; b < 2; b++) {
@@ -894,8 +920,9 @@ int run_counts(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint
     pc.acc = m->count_acc.as<unsigned long long>();
     pc.host_out = m->count_out;
     RJ_HIP(m->wg_rows.reserve(sizeof(uint32_t) * kExactMaxPatterns * static_cast<size_t>(geo.grid)));
+    RJ_HIP(m->wg_bounds.reserve(sizeof(unsigned long long) * 2 * kExactMaxPatterns * static_cast<size_t>(geo.grid)));
     pc.wg_rows = m->wg_rows.as<uint32_t>();
-    pc.edge_rows = m->edge_rows.as<unsigned long long>();
+    pc.wg_bounds = m->wg_bounds.as<unsigned long long>();
     if (m->scan_after != nullptr && m->scan_after != m && m->scan_after->scans[0]->ev[2] != nullptr)
       RJ_HIP(hipStreamWaitEvent(st, m->scan_after->scans[0]->ev[2], 0));
     launch_plane_count(pc, geo.grid, s0->t0(), s0->ev[2], st);
@@ -908,11 +935,6 @@ int run_counts(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint
       RJ_HIP(hipStreamWaitEvent(fs, s0->ev[2], 0));
     }
     launch_plane_count_finish(pc, geo.grid, fs);
-    m->last_run.text = d_text;
-    m->last_run.n = n;
-    m->last_run.sb = sb;
-    m->last_run.se = se;
-    m->last_run.st = st;
     if (phase == 1) {
       if (!m->pending.done) RJ_HIP(hipEventCreateWithFlags(&m->pending.done, hipEventDisableTiming));
       RJ_HIP(hipEventRecord(m->pending.done, fs));
@@ -923,31 +945,24 @@ int run_counts(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint
   else RJ_HIP(hipStreamSynchronize(st));
   RJ_HIP(hipGetLastError());
   if (m->count_out[kPcHostFlags] != 0) {
-    m->counts_off = true;
     m->counts_fallbacks++;
     m->last_counts = false;
-    return run_batched(m, d_text, n, sb, se, st, true, 0);
+    int kind = run_spans(m, d_text, n, sb, se, st);
+    return kind < 0 ? kind : RJ_OK;
   }
   m->scan_ms = 0.f;
   if (s0->timing) (void)hipEventElapsedTime(&m->scan_ms, s0->ev[1], s0->ev[2]);
   for (int p = 0; p < P; p++) {
     rj_scan* s = m->scans[static_cast<size_t>(p)];
     s->stats = rj_stats{};
-    s->result = nullptr;   // (no span list: rj_scan_device_spans reads NULL)
+    s->result = nullptr;   // (no span list: rj_scan_device_spans reads NULL, the readers of the list refuse)
     s->result_count = m->count_out[kPcHostCount + p];
     s->stats.n_matches = s->result_count;
     s->stats.scan_ms = m->scan_ms;
+    s->stats.count_path = 1;
   }
   m->last_counts = true;
   return RJ_OK;
-}
-
-// after a counts run, for a caller that asks for what only the span pipeline leaves behind
-int spans_after_counts(rj_multi* m) {
-  if (!m->last_counts) return RJ_OK;
-  m->last_counts = false;
-  const rj_multi::LastRun& r = m->last_run;
-  return run_batched(m, r.text, r.n, r.sb, r.se, r.st, true, 0);
 }
 
 }  // namespace
@@ -1006,7 +1021,12 @@ int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out)
     }
   }
   m->batchable = all_batchable && n_progs > 1;
-  if (m->fused && m->plane.ok && !m->plane.general && m->plane.offset == 0) {
+  if (n_progs == 1 && all && getenv("RJ_NO_PLANE") == nullptr) {
+    // ONE pattern: no fused span pipeline (its own pipeline is that already), but the plan of its windows is what the
+    // one-kernel count needs -- Regej::MatchAllCount of a regexdna pattern (reference sample/regexdna.cc:65, src/rejit.cc:203-208)
+    m->plane = plan_plane(m->scans);
+  }
+  if ((m->fused || n_progs == 1) && m->plane.ok && !m->plane.general && m->plane.offset == 0) {
     // the set's shape for MatchAllCount in one kernel (exact_count.h); used when the caller asks: rj_multi_set_counts_only
     std::vector<const Program*> hosts;
     for (rj_scan* s : m->scans) hosts.push_back(s->prog->host.get());
@@ -1064,23 +1084,13 @@ int rj_multi_run_range(rj_multi* m, const void* d_text, uint64_t n, uint64_t own
   m->scan_ms = 0.f;
   int fused = 0;
   m->last_counts = false;
-  if (m->fused && n >= 16 && counts_path(m)) {
+  if (n >= 16 && counts_path(m)) {
     int rc = run_counts(m, static_cast<const uint8_t*>(d_text), n, own_begin, own_end, st, 0);
     if (rc != RJ_OK) return rc;
-    fused = m->last_counts ? 3 : 1;
-  } else if (m->fused && m->mode == 0 && n >= 16) {
-    int rc = run_batched(m, static_cast<const uint8_t*>(d_text), n, own_begin, own_end, st, true);
-    if (rc != RJ_OK) return rc;
-    fused = 1;
-  } else if (m->batchable && n >= 16) {
-    int rc = run_batched(m, static_cast<const uint8_t*>(d_text), n, own_begin, own_end, st, false);
-    if (rc != RJ_OK) return rc;
-    fused = 2;
+    fused = m->last_counts ? 3 : (m->fused && m->mode == 0) ? 1 : m->batchable ? 2 : 0;
   } else {
-    for (rj_scan* s : m->scans) {
-      int rc = run_pipeline(s, static_cast<const uint8_t*>(d_text), n, own_begin, own_end, 0, 0, 0, st);
-      if (rc != RJ_OK) return rc;
-    }
+    fused = run_spans(m, static_cast<const uint8_t*>(d_text), n, own_begin, own_end, st);
+    if (fused < 0) return fused;
   }
   for (size_t i = 0; i < m->scans.size(); i++) counts[i] = m->scans[i]->result_count;
   return fused;
@@ -1099,7 +1109,7 @@ int rj_multi_start(rj_multi* m, const void* d_text, uint64_t n, uint64_t own_beg
   q.se = own_end;
   q.st = static_cast<hipStream_t>(hip_stream);
   m->scan_ms = 0.f;
-  q.kind = own_begin >= own_end ? -1 : (m->fused && n >= 16 && counts_path(m)) ? 3 : (m->fused && m->mode == 0 && n >= 16) ? 1 : (m->batchable && n >= 16) ? 2 : 0;
+  q.kind = own_begin >= own_end ? -1 : (n >= 16 && counts_path(m)) ? 3 : (m->fused && m->mode == 0 && n >= 16) ? 1 : (m->batchable && n >= 16) ? 2 : 0;
   q.fuse = q.kind == 1;
   m->last_counts = false;
   if (q.kind == 3) {
@@ -1126,7 +1136,7 @@ int rj_multi_finish(rj_multi* m, uint64_t* counts) {
   if (q.kind == 3) {
     int rc = run_counts(m, q.text, q.n, q.sb, q.se, q.st, 2);
     if (rc != RJ_OK) return rc;
-    if (!m->last_counts) q.kind = 1;   // (a void run: the span pipeline answered)
+    if (!m->last_counts) q.kind = (m->fused && m->mode == 0) ? 1 : m->batchable ? 2 : 0;   // (a void run: the span pipeline answered)
   } else if (q.kind != 0) {
     int rc = run_batched(m, q.text, q.n, q.sb, q.se, q.st, q.fuse, 2);
     if (rc != RJ_OK) return rc;
@@ -1160,21 +1170,12 @@ int rj_multi_bounds(rj_multi* m, uint64_t* bounds, void* hip_stream) {
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const int P = static_cast<int>(m->scans.size());
   if (!m->host_bounds) RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&m->host_bounds), sizeof(uint64_t) * 4 * kMaxFused));
-  // a counts run: the kernel's last workgroup left every pattern's first / last match begin in pinned memory (all
-  // matches are 8 bytes long); a pattern re-run under a carry since (rj_scan_run on rj_multi_scan) has its own list
+  // a counts run: plane_count_finish left every pattern's first / last match (begin | length << 56) in pinned memory; a
+  // pattern re-run under a carry since (rj_scan_run on rj_multi_scan) has its own list
   bool listed = !m->last_counts;
-  if (m->last_counts) {
-    bool unknown = false;
-    for (int p = 0; p < P; p++) {
+  if (m->last_counts)
+    for (int p = 0; p < P; p++)
       if (m->scans[static_cast<size_t>(p)]->result) listed = true;
-      else if (m->count_out[kPcHostBounds + 2 * p] == kPcUnknown || m->count_out[kPcHostBounds + 2 * p + 1] == kPcUnknown) unknown = true;
-    }
-    if (unknown) {  // matches, but none in the spans of the grid's edge waves: the span pipeline
-      int rc = spans_after_counts(m);
-      if (rc != RJ_OK) return rc;
-      listed = true;
-    }
-  }
   if (listed) {
     BoundsParams bp{};
     bp.n_lists = P;
@@ -1191,10 +1192,11 @@ int rj_multi_bounds(rj_multi* m, uint64_t* bounds, void* hip_stream) {
     for (int p = 0; p < P; p++) {
       if (m->scans[static_cast<size_t>(p)]->result) continue;
       const unsigned long long f = m->count_out[kPcHostBounds + 2 * p], l = m->count_out[kPcHostBounds + 2 * p + 1];
-      bounds[4 * p + 0] = f;
-      bounds[4 * p + 1] = f == kPcNone ? kPcNone : f + 8;
-      bounds[4 * p + 2] = l;
-      bounds[4 * p + 3] = l == kPcNone ? kPcNone : l + 8;
+      const unsigned long long at = (1ull << kPcLenShift) - 1;
+      bounds[4 * p + 0] = f == kPcNone ? kPcNone : (f & at);
+      bounds[4 * p + 1] = f == kPcNone ? kPcNone : (f & at) + (f >> kPcLenShift);
+      bounds[4 * p + 2] = l == kPcNone ? kPcNone : (l & at);
+      bounds[4 * p + 3] = l == kPcNone ? kPcNone : (l & at) + (l >> kPcLenShift);
     }
   return RJ_OK;
 }
@@ -1203,14 +1205,6 @@ int rj_multi_bounds_device(rj_multi* m, int64_t offset, int first_round, int64_t
   ErrnoGuard errno_guard;
   if (!m || !d_rows) return fail(RJ_BAD_ARGUMENT, "null argument");
   const int P = static_cast<int>(m->scans.size());
-  if (m->last_counts)
-    for (int p = 0; p < P; p++)
-      if (!m->scans[static_cast<size_t>(p)]->result &&
-          (m->count_out[kPcHostBounds + 2 * p] == kPcUnknown || m->count_out[kPcHostBounds + 2 * p + 1] == kPcUnknown)) {
-        int rc = spans_after_counts(m);   // (matches, but none in the spans of the grid's edge waves)
-        if (rc != RJ_OK) return rc;
-        break;
-      }
   BoundsParams bp{};
   bp.n_lists = P;
   for (int p = 0; p < P; p++) {
@@ -1492,8 +1486,54 @@ int rj_multi_set_counts_only(rj_multi* m, int on) {
   if (!m) return fail(RJ_BAD_ARGUMENT, "null argument");
   if (m->pending.active) return fail(RJ_BAD_ARGUMENT, "rj_multi_set_counts_only: a run is in flight");
   m->counts_only = on != 0;
-  if (on) m->counts_off = false;
   return (m->counts_only && m->exact.ok && m->plane.ok && !m->plane.general && m->plane.offset == 0) ? 1 : 0;
+}
+
+}  // extern "C"
+
+// MatchAllCount of ONE pattern over a device text (rj_scan_count; rj_match_all(..., NULL) for host texts): a private
+// rj_multi of the one pattern on the counts path, made at the first call; patterns without the shape (or a void run) are
+// answered by the scan's own pipeline.
+int64_t rejit_amd::scan_count(rj_scan* s, const uint8_t* d_text, uint64_t n, hipStream_t st) {
+  if (s->counter_state == 0) {
+    s->counter_state = -1;
+    const rj_program* progs[1] = {s->prog};
+    rj_multi* m = nullptr;
+    if (n >= 16 && fusable(s->prog) && rj_multi_create(progs, 1, &m) == RJ_OK) {
+      if (rj_multi_set_counts_only(m, 1) == 1) {
+        (void)rj_multi_set_timing(m, s->timing ? 1 : 0);
+        s->counter = m;
+        s->counter_state = 1;
+      } else {
+        rj_multi_destroy(m);
+      }
+    } else if (n < 16) {
+      s->counter_state = 0;   // (not decided on a text the kernel does not take)
+    }
+  }
+  if (s->counter_state == 1 && n >= 16 && (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0) {
+    uint64_t count = 0;
+    int how = rj_multi_run(s->counter, d_text, n, &count, st);
+    if (how < 0) return how;
+    rj_scan* inner = s->counter->scans[0];
+    s->stats = inner->stats;
+    s->result_count = inner->result_count;
+    // (a void run was answered by the inner scan's pipeline: its list stays the inner scan's -- this call counts)
+    s->result = nullptr;
+    if (how != 3) s->stats.count_path = 0;
+    return static_cast<int64_t>(count);
+  }
+  int rc = run_pipeline(s, d_text, n, 0, n + 1, 0, 0, 0, st);
+  if (rc != RJ_OK) return rc;
+  return static_cast<int64_t>(s->result_count);
+}
+
+extern "C" {
+
+int64_t rj_scan_count(rj_scan* s, const void* d_text, uint64_t n, void* hip_stream) {
+  ErrnoGuard errno_guard;
+  if (!s || (!d_text && n)) return fail(RJ_BAD_ARGUMENT, "null argument");
+  return scan_count(s, static_cast<const uint8_t*>(d_text), n, static_cast<hipStream_t>(hip_stream));
 }
 
 int rj_multi_set_mode(rj_multi* m, int mode) {

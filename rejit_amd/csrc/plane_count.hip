@@ -23,12 +23,16 @@
 // Nothing else is written: no candidate list in HBM, no (begin, end) arrays, no second or third launch.
 //
 // Exactness.  The table answers "does pattern p match these 8 bytes" exactly (exact_count.h).  The reference's count
-// is that of the left-most-longest, non-overlapping selection (src/x64/codegen-x64.cc:401-466); with all matches 8
-// bytes long it differs from the number of matching positions only when two matches of ONE pattern begin fewer than
-// 8 bytes apart.  Candidates are classified in text order, so that needs two neighbours in the ring (or across a
-// batch, or across two waves' spans: the wave looks at the 7 positions before its span itself) closer than 8 bytes
-// with a pattern in common: the run is then flagged (kPcConflict) and the host repeats it with the span pipeline.
-// A block that holds more candidates than the ring can take (kPcVoid) is handled the same way.
+// is that of the left-most-longest, non-overlapping selection (src/x64/codegen-x64.cc:401-466: a match that begins inside
+// the match selected before it is dropped, :448-460); with all matches 8 bytes long it differs from the number of matching
+// positions only when two matches of ONE pattern begin fewer than 8 bytes apart.  Candidates are classified in text
+// order, so that needs two neighbours in the ring closer than 8 bytes with a pattern in common.  An isolated PAIR of
+// such neighbours is resolved on the spot: the first stands (nothing overlaps it), the second is dropped for the patterns
+// they share -- `agggtaaagggtaaa` counts once for `agggtaaa|tttaccct`, as in the reference.  Three or more candidates in a
+// row, each closer than 8 bytes to the one before, would need the selection replayed along the chain: the run is flagged
+// (kPcConflict) when a pattern occurs twice in such a chain (or the chain is longer than three), as is a pair that lies
+// across two waves' spans (the wave looks at the 7 positions before its span itself), and the host repeats THAT run with
+// the span pipeline.  A block that holds more candidates than the ring can take (kPcVoid) is handled the same way.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -154,7 +158,8 @@ __device__ __forceinline__ uint32_t plane_test(uint32_t ta, uint32_t tb, uint32_
           "v_alignbit_b32 %[e30], v52, v48, 6\n"
           "s_set_gpr_idx_off\n"
           : [e00] "=&v"(E[0][0]), [e10] "=&v"(E[1][0]), [e20] "=&v"(E[2][0]), [e30] "=&v"(E[3][0])
-          : [c00] "s"(code(0, 0)), [c10] "s"(code(0, 1)), [c20] "s"(code(0, 2)), [c30] "s"(code(0, 3)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3));
+          : [c00] "s"(code(0, 0)), [c10] "s"(code(0, 1)), [c20] "s"(code(0, 2)), [c30] "s"(code(0, 3)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3)
+          : "m0");
       } else {
       asm volatile(
           "s_set_gpr_idx_on %[c40], 0x3\n"
@@ -167,7 +172,8 @@ __device__ __forceinline__ uint32_t plane_test(uint32_t ta, uint32_t tb, uint32_
           "v_alignbit_b32 %[e70], v52, v48, 14\n"
           "s_set_gpr_idx_off\n"
           : [e40] "=&v"(E[4][0]), [e50] "=&v"(E[5][0]), [e60] "=&v"(E[6][0]), [e70] "=&v"(E[7][0])
-          : [c40] "s"(code(0, 4)), [c50] "s"(code(0, 5)), [c60] "s"(code(0, 6)), [c70] "s"(code(0, 7)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3));
+          : [c40] "s"(code(0, 4)), [c50] "s"(code(0, 5)), [c60] "s"(code(0, 6)), [c70] "s"(code(0, 7)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3)
+          : "m0");
       }
     } else {
       if (half == 0) {
@@ -190,7 +196,8 @@ __device__ __forceinline__ uint32_t plane_test(uint32_t ta, uint32_t tb, uint32_
           "v_alignbit_b32 %[e31], v52, v48, 6\n"
           "s_set_gpr_idx_off\n"
           : [e00] "=&v"(E[0][0]), [e01] "=&v"(E[0][1]), [e10] "=&v"(E[1][0]), [e11] "=&v"(E[1][1]), [e20] "=&v"(E[2][0]), [e21] "=&v"(E[2][1]), [e30] "=&v"(E[3][0]), [e31] "=&v"(E[3][1])
-          : [c00] "s"(code(0, 0)), [c01] "s"(code(1, 0)), [c10] "s"(code(0, 1)), [c11] "s"(code(1, 1)), [c20] "s"(code(0, 2)), [c21] "s"(code(1, 2)), [c30] "s"(code(0, 3)), [c31] "s"(code(1, 3)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3));
+          : [c00] "s"(code(0, 0)), [c01] "s"(code(1, 0)), [c10] "s"(code(0, 1)), [c11] "s"(code(1, 1)), [c20] "s"(code(0, 2)), [c21] "s"(code(1, 2)), [c30] "s"(code(0, 3)), [c31] "s"(code(1, 3)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3)
+          : "m0");
       } else {
       asm volatile(
           "s_set_gpr_idx_on %[c40], 0x3\n"
@@ -211,7 +218,8 @@ __device__ __forceinline__ uint32_t plane_test(uint32_t ta, uint32_t tb, uint32_
           "v_alignbit_b32 %[e71], v52, v48, 14\n"
           "s_set_gpr_idx_off\n"
           : [e40] "=&v"(E[4][0]), [e41] "=&v"(E[4][1]), [e50] "=&v"(E[5][0]), [e51] "=&v"(E[5][1]), [e60] "=&v"(E[6][0]), [e61] "=&v"(E[6][1]), [e70] "=&v"(E[7][0]), [e71] "=&v"(E[7][1])
-          : [c40] "s"(code(0, 4)), [c41] "s"(code(1, 4)), [c50] "s"(code(0, 5)), [c51] "s"(code(1, 5)), [c60] "s"(code(0, 6)), [c61] "s"(code(1, 6)), [c70] "s"(code(0, 7)), [c71] "s"(code(1, 7)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3));
+          : [c40] "s"(code(0, 4)), [c41] "s"(code(1, 4)), [c50] "s"(code(0, 5)), [c51] "s"(code(1, 5)), [c60] "s"(code(0, 6)), [c61] "s"(code(1, 6)), [c70] "s"(code(0, 7)), [c71] "s"(code(1, 7)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3)
+          : "m0");
       }
     }
 #pragma unroll
@@ -239,13 +247,13 @@ struct WaveState {
   uint32_t head, tail;   // wave-uniform, free-running
   uint32_t acc;          // lane p: matches of pattern p so far
   uint32_t flags;        // kPcConflict | kPcVoid (wave-uniform)
-  // the last candidate classified so far: its offset, patterns, and whether it was itself within 8 bytes of the one before
+  // the last two candidates classified so far: offset, patterns, whether each was itself within 8 bytes of the one before it
   uint32_t prev_rel, prev_mask, prev_close, prev_valid;
-  // edge waves (the first / last a.edge_waves of the grid): first / last match offset of pattern p at edge[2 p], edge[2 p + 1]
-  // (LDS; kNoEdge: none yet)
-  uint32_t* edge;
+  uint32_t prev2_mask, prev2_close;
+  // the wave's first / last match of pattern p: its offset at ends[2 p], ends[2 p + 1] (LDS; kNoEnd: none yet)
+  uint32_t* ends;
 };
-constexpr uint32_t kNoEdge = 0xFFFFFFFFu;
+constexpr uint32_t kNoEnd = 0xFFFFFFFFu;
 
 // the candidates of one block, in text order, to the ring
 __device__ __forceinline__ void push_block(WaveState& w, uint32_t hm, uint32_t rel_lane) {
@@ -273,10 +281,9 @@ __device__ __forceinline__ void push_block(WaveState& w, uint32_t hm, uint32_t r
   w.tail += tot;
 }
 
-// The first m (<= 64) candidates of the ring against the table: counts, the overlap test, the edge rows.
+// The first m (<= 64) candidates of the ring against the table: the overlap rule, counts, the wave's first / last matches.
 template <int NB>
-__device__ __forceinline__ void classify_batch(WaveState& w, uint32_t m, const uint32_t* table, const PlaneCountParams& a, uint64_t span_base,
-                                               bool edge) {
+__device__ __forceinline__ void classify_batch(WaveState& w, uint32_t m, const uint32_t* table, const PlaneCountParams& a, uint64_t span_base) {
   const int lane = lane_id();
   const bool have = static_cast<uint32_t>(lane) < m;
   const uint32_t rel = w.ring[(w.head + static_cast<uint32_t>(lane)) & (kRing - 1)];
@@ -290,33 +297,47 @@ __device__ __forceinline__ void classify_batch(WaveState& w, uint32_t m, const u
   }
   uint32_t mask = exact_classify<NB>(table, a.base_lo, a.base_hi, lo, hi);
   mask = ok ? mask : 0u;
-  // counts: a ballot per pattern, lane p keeps pattern p's
-  for (uint32_t p = 0; p < a.n_patterns; p++) {
-    const uint64_t mine = __ballot(((mask >> p) & 1u) != 0);
-    if (lane == static_cast<int>(p)) w.acc += static_cast<uint32_t>(__popcll(mine));
-    if (edge && mine != 0) {  // (wave-uniform)
-      const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(rel), static_cast<int>(__builtin_ctzll(mine))));
-      const uint32_t last = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(rel), 63 - static_cast<int>(__builtin_clzll(mine))));
-      if (lane == static_cast<int>(p)) {
-        if (w.edge[2 * p] == kNoEdge) w.edge[2 * p] = first;
-        w.edge[2 * p + 1] = last;
-      }
-    }
-  }
   // two matches of one pattern fewer than 8 bytes apart?  candidates are in text order: look at the one before
   const uint32_t before = from_lane_below(rel, w.prev_rel);
   const bool has_before = lane > 0 || w.prev_valid != 0;
   const bool close = have && has_before && (rel - before) < 8u;
+  const uint32_t all_mask = mask;   // (what the NEXT candidate compares itself with: the patterns that match here, dropped or not)
   if (__ballot(close) != 0) {  // (wave-uniform; 0.6 % of the candidates on DNA)
-    const uint32_t mask_before = from_lane_below(mask, w.prev_mask);
-    const uint32_t close_before = from_lane_below(close ? 1u : 0u, w.prev_close);
-    // a pattern in common with the neighbour -- or three candidates in a row that close (the one before the neighbour is
-    // not looked at: flagged without asking for its patterns)
-    if (__ballot(close && ((mask & mask_before) != 0 || close_before != 0)) != 0) w.flags |= kPcConflict;
+    const uint32_t mask1 = from_lane_below(all_mask, w.prev_mask);
+    const uint32_t close1 = from_lane_below(close ? 1u : 0u, w.prev_close);
+    if (__ballot(close && close1 != 0) != 0) {
+      // three in a row: void when a fourth hangs on, or when a pattern occurs twice among the three (else nothing overlaps)
+      const uint32_t mask2 = from_lane_below(mask1, w.prev2_mask);
+      const uint32_t close2 = from_lane_below(close1, w.prev2_close);
+      const bool bad = close && close1 != 0 && (close2 != 0 || ((all_mask & mask1) | (all_mask & mask2) | (mask1 & mask2)) != 0);
+      if (__ballot(bad) != 0) w.flags |= kPcConflict;
+    }
+    // an isolated pair: the first stands, the second is no match of the patterns they share (codegen-x64.cc:448-460)
+    mask = close ? (mask & ~mask1) : mask;
+  }
+  // counts: a ballot per pattern, lane p keeps pattern p's
+  for (uint32_t p = 0; p < a.n_patterns; p++) {
+    const uint64_t mine = __ballot(((mask >> p) & 1u) != 0);
+    if (mine == 0) continue;  // (wave-uniform)
+    if (lane == static_cast<int>(p)) w.acc += static_cast<uint32_t>(__popcll(mine));
+    const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(rel), static_cast<int>(__builtin_ctzll(mine))));
+    const uint32_t last = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(rel), 63 - static_cast<int>(__builtin_clzll(mine))));
+    if (lane == static_cast<int>(p)) {
+      if (w.ends[2 * p] == kNoEnd) w.ends[2 * p] = first;
+      w.ends[2 * p + 1] = last;
+    }
+  }
+  const uint32_t close_u = close ? 1u : 0u;
+  if (m >= 2) {
+    w.prev2_mask = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(all_mask), static_cast<int>(m - 2)));
+    w.prev2_close = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(close_u), static_cast<int>(m - 2)));
+  } else {
+    w.prev2_mask = w.prev_mask;
+    w.prev2_close = w.prev_close;
   }
   w.prev_rel = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(rel), static_cast<int>(m - 1)));
-  w.prev_mask = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mask), static_cast<int>(m - 1)));
-  w.prev_close = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(close ? 1u : 0u), static_cast<int>(m - 1)));
+  w.prev_mask = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(all_mask), static_cast<int>(m - 1)));
+  w.prev_close = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(close_u), static_cast<int>(m - 1)));
   w.prev_valid = 1;
   w.head += m;
 }
@@ -352,7 +373,7 @@ __device__ __forceinline__ void check_span_start(WaveState& w, uint32_t m, const
 
 // after every second block: the run is void when a block overfilled the ring; else classify while 64 are held
 template <int NB>
-__device__ __forceinline__ void blocks_done(WaveState& w, const uint32_t* table, const PlaneCountParams& a, uint64_t span_base, bool edge, bool& first_batch) {
+__device__ __forceinline__ void blocks_done(WaveState& w, const uint32_t* table, const PlaneCountParams& a, uint64_t span_base, bool& first_batch) {
   if (w.tail - w.head > kRing) {  // more candidates than the ring takes: the run is void
     w.flags |= kPcVoid;
     w.head = w.tail;
@@ -363,7 +384,7 @@ __device__ __forceinline__ void blocks_done(WaveState& w, const uint32_t* table,
     const uint32_t m = held < 64u ? held : 64u;
     if (first_batch) check_span_start<NB>(w, m, table, a, span_base);
     first_batch = false;
-    classify_batch<NB>(w, m, table, a, span_base, edge);
+    classify_batch<NB>(w, m, table, a, span_base);
   }
 }
 
@@ -374,7 +395,8 @@ template <int NB>
 __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
   __shared__ __attribute__((aligned(16))) uint32_t table[kExactTabWords];
   __shared__ uint32_t rings[4][kRing];
-  __shared__ uint32_t edges[4][2 * kExactMaxPatterns];
+  __shared__ uint32_t ends[4][2 * kExactMaxPatterns];
+  __shared__ unsigned long long wave_bounds[4][kExactMaxPatterns][2];
   __shared__ uint32_t wave_counts[4][kExactMaxPatterns];
   __shared__ uint32_t wave_flags[4];
   const int lane = lane_id();
@@ -394,15 +416,15 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
   if (fast_end > c1) fast_end = c1;
   if (fast_end < c0) fast_end = c0;
   const uint64_t span_base = static_cast<uint64_t>(c0) * kBlock;
-  const bool edge = wave < a.edge_waves || wave + a.edge_waves >= n_waves;
   WaveState w;
   w.ring = rings[wid];
-  w.edge = edges[wid];
+  w.ends = ends[wid];
   w.head = w.tail = 0;
   w.acc = 0;
   w.flags = 0;
   w.prev_rel = w.prev_mask = w.prev_close = w.prev_valid = 0;
-  if (edge) w.edge[lane] = kNoEdge;   // (2 x 32 entries: one per lane)
+  w.prev2_mask = w.prev2_close = 0;
+  w.ends[lane] = kNoEnd;   // (2 x 32 entries: one per lane)
   bool first_batch = true;
 
   // A wave never loads a block that is not its own: prefetches beyond the span's last fast block are clamped to that
@@ -452,7 +474,7 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
       }
       __builtin_amdgcn_sched_barrier(0);
       c += 2;
-      if (w.tail - w.head >= a.batch_at) blocks_done<NB>(w, table, a, span_base, edge, first_batch);
+      if (w.tail - w.head >= a.batch_at) blocks_done<NB>(w, table, a, span_base, first_batch);
     }
     if (c + 1 == fast_end) {   // an odd block left: x holds its codes; behind it the span ends
       const uint32_t hb = from_lane_above(xa, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(behind_codes))));
@@ -460,7 +482,7 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
       push_block(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
       c++;
     }
-    blocks_done<NB>(w, table, a, span_base, edge, first_batch);
+    blocks_done<NB>(w, table, a, span_base, first_batch);
   }
   // the block(s) at the end of the text: guarded loads, the 8 bytes behind the lane's 32 read by the lane itself
   for (; c < c1; c++) {
@@ -477,7 +499,7 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
     const uint32_t h0 = guarded_dword(a.text, a.n, at + 32), h1 = guarded_dword(a.text, a.n, at + 36);
     const uint32_t hb = (codes4(h0, k) >> k.shift) | (codes4(h1, k) << (8 - k.shift));
     const uint32_t hm = plane_test<NB>(codes16(va, k), codes16(vb, k), hb, a);
-    if (w.tail - w.head > kRing - 64u) blocks_done<NB>(w, table, a, span_base, edge, first_batch);   // (room for this block)
+    if (w.tail - w.head > kRing - 64u) blocks_done<NB>(w, table, a, span_base, first_batch);   // (room for this block)
     push_block(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
   }
   // what the ring still holds
@@ -490,39 +512,40 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
     const uint32_t m = held < 64u ? held : 64u;
     if (first_batch) check_span_start<NB>(w, m, table, a, span_base);
     first_batch = false;
-    classify_batch<NB>(w, m, table, a, span_base, edge);
+    classify_batch<NB>(w, m, table, a, span_base);
   }
-  // edge waves: their own rows (count, first, last match of every pattern), read by the last workgroup
-  if (edge && lane < static_cast<int>(a.n_patterns)) {
-    unsigned long long* row = nullptr;
-    if (wave < a.edge_waves) row = a.edge_rows + (wave * kExactMaxPatterns + static_cast<uint64_t>(lane)) * 4;
-    const uint32_t ef = w.edge[2 * lane], el = w.edge[2 * lane + 1];
-    const unsigned long long first = ef != kNoEdge ? span_base + ef : ~0ull, last = ef != kNoEdge ? span_base + el : ~0ull;
-    if (row) {
-      row[0] = w.acc;
-      row[1] = first;
-      row[2] = last;
-    }
-    if (wave + a.edge_waves >= n_waves) {
-      row = a.edge_rows + ((a.edge_waves + (wave + a.edge_waves - n_waves)) * kExactMaxPatterns + static_cast<uint64_t>(lane)) * 4;
-      row[0] = w.acc;
-      row[1] = first;
-      row[2] = last;
-    }
-  }
-  // wave -> workgroup (LDS) -> a row of the workgroup's own in device memory: plain stores, read by plane_count_finish
+  // wave -> workgroup (LDS) -> rows of the workgroup's own in device memory: plain stores, read by plane_count_finish
   // (the next kernel on the stream).  Measured alternatives, all inside this kernel: nine device-scope atomic adds and a
   // ticket per workgroup (kernel 0.094 -> 0.159 ms: the memory side performs same-address atomics one after the other);
   // rows + a ticket per group of 64 workgroups + a top ticket (0.183 ms: it is the atomic WITH RETURN that costs, ~18 us of
   // device time per thousand of them, whatever the address; an acq_rel ticket -- L2 write-back + invalidate per
   // workgroup -- 0.41 ms).
-  if (lane < kExactMaxPatterns) wave_counts[wid][lane] = lane < static_cast<int>(a.n_patterns) ? w.acc : 0u;
+  // Every workgroup leaves its first / last match of every pattern beside its counts (round 6; round 5 kept them for the
+  // 64 waves at either end of the grid only, and a caller who asked for the bounds of a pattern without a match there had
+  // the span pipeline re-read a text that might be gone by then): plane_count_finish finds the first / last ROW with a
+  // count from the rows it adds up anyway and reads two bounds per pattern.
+  if (lane < kExactMaxPatterns) {
+    wave_counts[wid][lane] = lane < static_cast<int>(a.n_patterns) ? w.acc : 0u;
+    const uint32_t ef = w.ends[2 * lane], el = w.ends[2 * lane + 1];
+    wave_bounds[wid][lane][0] = ef != kNoEnd ? ((span_base + ef) | (8ull << kPcLenShift)) : kPcNone;
+    wave_bounds[wid][lane][1] = ef != kNoEnd ? ((span_base + el) | (8ull << kPcLenShift)) : kPcNone;
+  }
   if (lane == 0) wave_flags[wid] = w.flags;
   __syncthreads();
   if (wid != 0 || lane >= kExactMaxPatterns) return;
   uint32_t v = wave_counts[0][lane] + wave_counts[1][lane] + wave_counts[2][lane] + wave_counts[3][lane];
   if (lane == kExactMaxPatterns - 1) v = wave_flags[0] | wave_flags[1] | wave_flags[2] | wave_flags[3];   // (slot 31: the flags)
   a.wg_rows[static_cast<uint64_t>(blockIdx.x) * kExactMaxPatterns + lane] = v;
+  if (lane < static_cast<int>(a.n_patterns) && v != 0) {   // (the waves of a workgroup hold consecutive spans)
+    unsigned long long first = kPcNone, last = kPcNone;
+#pragma unroll
+    for (int q = 3; q >= 0; q--)
+      if (wave_bounds[q][lane][0] != kPcNone) first = wave_bounds[q][lane][0];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (wave_bounds[q][lane][1] != kPcNone) last = wave_bounds[q][lane][1];
+    *reinterpret_cast<ulonglong2*>(a.wg_bounds + (static_cast<uint64_t>(blockIdx.x) * kExactMaxPatterns + lane) * 2) = ulonglong2{first, last};
+  }
 }
 
 // The rows of plane_count added up: counts, flags and bounds to pinned host memory and to the device copy in `acc`
@@ -530,18 +553,20 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
 // place between the workgroups of the NEXT scan, which is running when a caller keeps steps in flight: ONE workgroup
 // of 1024 threads waited for 16 free wave slots on one CU -- until that scan had drained (93 us instead of 18).  As few
 // DEPENDENT trips to memory as possible (a lone workgroup pays ~2 us per trip, more under a scan): thread t adds four
-// patterns (t & 7) of its group's rows t >> 3, + 32, ... with up to 14 16-byte loads in flight; the group's sums go to
-// acc, a ticket (eight arrivals: the cost of an atomic with return does not matter here) finds the last group, which
-// adds them up and reads all edge rows of a pattern in one trip (a row = count, first, last: 32 bytes).
+// patterns (t & 7) of its group's rows t >> 3, + 32, ... with up to 14 16-byte loads in flight and remembers the first /
+// last row with a count; the group's sums go to acc, a ticket (eight arrivals: the cost of an atomic with return does not
+// matter here) finds the last group, which adds them up and reads, in one more trip, the first match of every pattern's
+// first row with a count and the last match of its last one.
 constexpr uint32_t kFinishBatch = 14;
 __global__ __launch_bounds__(256) void plane_count_finish(PlaneCountParams a, uint32_t n_wg) {
   __shared__ unsigned long long part[32][kExactMaxPatterns];
-  __shared__ unsigned long long bounds[kExactMaxPatterns][2];
+  __shared__ uint32_t part_first[32][kExactMaxPatterns], part_last[32][kExactMaxPatterns];   // row + 1; 0: none
   __shared__ uint32_t is_last;
   const uint32_t p4 = threadIdx.x & 7u, q = threadIdx.x >> 3;
   const uint32_t per = (n_wg + gridDim.x - 1) / gridDim.x;
   const uint32_t r_lo = blockIdx.x * per, r_hi = r_lo + per < n_wg ? r_lo + per : n_wg;
   unsigned long long sum[4] = {0, 0, 0, 0};
+  uint32_t first_row[4] = {0, 0, 0, 0}, last_row[4] = {0, 0, 0, 0};
   const uint4* rows = reinterpret_cast<const uint4*>(a.wg_rows);
   for (uint32_t r = r_lo + q; r < r_hi; r += 32 * kFinishBatch) {
     uint4 v[kFinishBatch];
@@ -553,70 +578,71 @@ __global__ __launch_bounds__(256) void plane_count_finish(PlaneCountParams a, ui
     }
 #pragma unroll
     for (uint32_t i = 0; i < kFinishBatch; i++) {
+      const uint32_t rr1 = r + 32 * i + 1;
+      const uint32_t c[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
       sum[0] += v[i].x;
       sum[1] += v[i].y;
       sum[2] += v[i].z;
       sum[3] = p4 == 7 ? (sum[3] | v[i].w) : (sum[3] + v[i].w);   // (slot 31: the flags)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        first_row[k] = (c[k] != 0 && first_row[k] == 0) ? rr1 : first_row[k];   // (rows in rising order)
+        last_row[k] = c[k] != 0 ? rr1 : last_row[k];
+      }
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; i++) part[q][4 * p4 + i] = sum[i];
+  for (int i = 0; i < 4; i++) {
+    part[q][4 * p4 + i] = sum[i];
+    part_first[q][4 * p4 + i] = first_row[i];
+    part_last[q][4 * p4 + i] = last_row[i];
+  }
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u, wave_id = threadIdx.x >> 6;
   if (wave_id == 0) {
     if (lane < kExactMaxPatterns) {
       unsigned long long t = 0;
-      for (uint32_t i = 0; i < 32; i++) t = lane == kExactMaxPatterns - 1 ? (t | part[i][lane]) : (t + part[i][lane]);
-      __hip_atomic_store(&a.acc[kPcGroupRows + blockIdx.x * kExactMaxPatterns + lane], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t f = 0, l = 0;
+      for (uint32_t i = 0; i < 32; i++) {
+        t = lane == kExactMaxPatterns - 1 ? (t | part[i][lane]) : (t + part[i][lane]);
+        const uint32_t pf = part_first[i][lane], pl = part_last[i][lane];
+        f = pf != 0 && (f == 0 || pf < f) ? pf : f;
+        l = pl > l ? pl : l;
+      }
+      unsigned long long* g = a.acc + kPcGroupRows + blockIdx.x * 96;
+      __hip_atomic_store(&g[lane], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&g[32 + lane], static_cast<unsigned long long>(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&g[64 + lane], static_cast<unsigned long long>(l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the row is complete before the ticket that publishes it is drawn)
+    // (eight arrivals per launch: a release / acquire ticket costs nothing measurable here -- it is what the memory model asks for)
     if (lane == 0) {
-      const unsigned long long t = __hip_atomic_fetch_add(&a.acc[kPcTicket], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long t = __hip_atomic_fetch_add(&a.acc[kPcTicket], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
       is_last = t + 1 == gridDim.x ? 1u : 0u;
-      if (t + 1 == gridDim.x) __hip_atomic_store(&a.acc[kPcTicket], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next run)
+      if (t + 1 == gridDim.x) __hip_atomic_store(&a.acc[kPcTicket], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next run: exactly gridDim.x arrivals per launch)
     }
   }
   __syncthreads();
-  if (!is_last) return;
-  // the last group.  The bounds: wave w takes the patterns w, w + 4, ..., lane e the e-th edge row from the front and from the
-  // back -- every row in ONE trip (a rare pattern has no match in most of the edge waves' spans: rows looked at one after the
-  // other cost 2 us each), a ballot finds the first / last row that holds a match
-  const uint64_t n_waves = static_cast<uint64_t>(n_wg) * 4;
-  const uint32_t n_front = static_cast<uint32_t>(n_waves < a.edge_waves ? n_waves : a.edge_waves);   // (edge_waves <= 64)
-  for (uint32_t p = wave_id; p < a.n_patterns; p += 4) {
-    ulonglong2 f{0, 0};
-    unsigned long long bc = 0, bl = 0;
-    if (lane < n_front) {
-      f = *reinterpret_cast<const ulonglong2*>(a.edge_rows + (static_cast<uint64_t>(lane) * kExactMaxPatterns + p) * 4);   // count, first
-      // back rows: slot edge_waves + q holds wave n_waves - edge_waves + q
-      const unsigned long long* br = a.edge_rows + ((static_cast<uint64_t>(a.edge_waves) + (a.edge_waves - n_front) + lane) * kExactMaxPatterns + p) * 4;
-      bc = br[0];
-      bl = br[2];
-    }
-    const uint64_t mf = __ballot(f.x != 0), mb = __ballot(bc != 0);
-    unsigned long long first = kPcNone, last = kPcNone;
-    if (mf) first = __shfl(f.y, __builtin_ctzll(mf));
-    if (mb) last = __shfl(bl, 63 - __builtin_clzll(mb));
-    if (lane == 0) {
-      bounds[p][0] = first;
-      bounds[p][1] = last;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x >= kExactMaxPatterns) return;
+  if (!is_last || threadIdx.x >= kExactMaxPatterns) return;
+  // the last group
   const uint32_t p = threadIdx.x;
   unsigned long long total = 0;
+  uint32_t f = 0, l = 0;
   for (uint32_t g = 0; g < gridDim.x; g++) {
-    const unsigned long long v = __hip_atomic_load(&a.acc[kPcGroupRows + g * kExactMaxPatterns + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long* row = a.acc + kPcGroupRows + g * 96;
+    const unsigned long long v = __hip_atomic_load(&row[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t pf = static_cast<uint32_t>(__hip_atomic_load(&row[32 + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const uint32_t pl = static_cast<uint32_t>(__hip_atomic_load(&row[64 + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     total = p == kExactMaxPatterns - 1 ? (total | v) : (total + v);
+    f = pf != 0 && (f == 0 || pf < f) ? pf : f;
+    l = pl > l ? pl : l;
   }
   if (p == kExactMaxPatterns - 1) a.host_out[kPcHostFlags] = total;
   if (p >= a.n_patterns) return;
-  unsigned long long first = bounds[p][0], last = bounds[p][1];
-  // matches exist but none in the edge rows: the bounds are not known (the host runs the span pipeline if asked)
-  if (total != 0 && first == kPcNone) first = kPcUnknown;
-  if (total != 0 && last == kPcNone) last = kPcUnknown;
-  if (total == 0) first = last = kPcNone;
+  unsigned long long first = kPcNone, last = kPcNone;
+  if (total != 0 && f != 0) {   // (the scan kernel's plain stores: complete before this kernel began)
+    first = a.wg_bounds[(static_cast<uint64_t>(f - 1) * kExactMaxPatterns + p) * 2];
+    last = a.wg_bounds[(static_cast<uint64_t>(l - 1) * kExactMaxPatterns + p) * 2 + 1];
+  }
   a.host_out[kPcHostCount + p] = total;
   a.host_out[kPcHostBounds + 2 * p] = first;
   a.host_out[kPcHostBounds + 2 * p + 1] = last;
@@ -641,10 +667,12 @@ __global__ void bounds_rows_counts_kernel(BoundsParams a, const unsigned long lo
   } else {
     n = acc[kPcTotals + p];
     if (n) {
-      fb = static_cast<int64_t>(acc[kPcBounds + 2 * p]) + offset;
-      fe = fb + 8;
-      lb = static_cast<int64_t>(acc[kPcBounds + 2 * p + 1]) + offset;
-      le = lb + 8;
+      const unsigned long long f = acc[kPcBounds + 2 * p], l = acc[kPcBounds + 2 * p + 1];
+      const unsigned long long at = (1ull << kPcLenShift) - 1;
+      fb = static_cast<int64_t>(f & at) + offset;
+      fe = fb + static_cast<int64_t>(f >> kPcLenShift);
+      lb = static_cast<int64_t>(l & at) + offset;
+      le = lb + static_cast<int64_t>(l >> kPcLenShift);
     }
   }
   rows[8 * p + 0] = static_cast<int64_t>(n);

@@ -6,9 +6,10 @@ the span pipeline of the same object --
   and own ranges, at sizes around the kernel's 2-KiB blocks and the end-of-text path;
 * matches that straddle block, span and text ends; the first / last match per pattern (rj_multi_bounds) that the carry
   exchange between shards needs, equal to the span pipeline's;
-* texts on which the count is NOT the number of matching positions (two matches of one pattern fewer than 8 bytes apart,
-  inside a span and across a span boundary) or on which a block overfills a wave's ring: the run must void itself and
-  the span pipeline answer (return value 1), with the oracle's counts;
+* texts on which the count is NOT the number of matching positions (two matches of one pattern fewer than 8 bytes apart):
+  an isolated pair inside a span is resolved by the kernel, a chain of three / a pair across two waves' spans / a block
+  that overfills a wave's ring make THAT run void and the span pipeline answer (return value 1), with the oracle's counts;
+* the reference's own entry point: MatchAllCount of ONE pattern (rj_match_all(..., NULL), rj_scan_count);
 * start / finish with two objects in flight; the sharded count (virtual shards + carry exchange) in counts mode.
 """
 import random
@@ -156,35 +157,135 @@ def test_counts_of_own_ranges(rj, oracle, W):
         assert bc == bs, (own, bc, bs)
 
 
-def test_overlapping_matches_void_the_counts_run(rj, oracle, W):
+def test_overlapping_pairs_are_resolved_in_the_kernel(rj, oracle, W):
     """`agggtaaagggtaaa`: two matches of pattern 0 seven bytes apart -- the reference selects the first only
-    (src/x64/codegen-x64.cc:401-466), the number of matching positions is one more.  The kernel must notice (inside a
-    span, across a batch, and across the boundary of two waves' spans) and the span pipeline must answer."""
+    (src/x64/codegen-x64.cc:401-466, :448-460), the number of matching positions is one more.  Round 6: an isolated pair
+    inside a wave's span is resolved by the kernel itself (return value 3, the oracle's counts), at any offset to the
+    2-KiB blocks and across the 64-candidate batches; pairs of DIFFERENT patterns that close both count."""
     progs = [rj.Program(rx) for rx in W.REGEXDNA_PATTERNS]
     rng = random.Random(13)
-    base = bytearray(rng.choice(b"acgt") for _ in range(400000))
+    # (5 MB: 2442 blocks over the 1024 waves of a 256-workgroup grid -- the first waves own three blocks each, so the block
+    # boundaries at 2048 and 4096 lie INSIDE wave 0's span and the one at 6144 between two spans.  Texts below 2 MiB give
+    # every wave one block: every block boundary is a span boundary there, see the next test.)
+    n = 5000000
+    base = bytearray(np.random.default_rng(13).choice(np.frombuffer(b"acgt", dtype=np.uint8), n).tobytes())
     overlap = b"agggtaaagggtaaa"
-    for at in [1000, 2048 - 7, 2048 - 3, 98304 - 7, 98304 - 1, 98304 * 2 - 5, 24576 - 4, 24576 * 3 - 7, 399000]:
+    for at in [1000, 2048 - 7, 2048 - 3, 4096 - 1, 4096 - 5, 3000000, n - 15]:
         t = bytearray(base)
         t[at:at + len(overlap)] = overlap
         data = bytes(t)
         want = oracle_counts(oracle, W.REGEXDNA_PATTERNS, data)
-        tt = device_text(data)
-        mc = rj.MultiScan(progs)
-        assert mc.set_counts_only(True)
-        c = mc.run(tt.data_ptr(), len(data))
-        assert c == want, (at, mc.how, c, want)
-        assert mc.how == 1, (at, "an overlapping pair must send the run to the span pipeline")
-        # ... and the object stays there
-        assert mc.run(tt.data_ptr(), len(data)) == want and mc.how == 1
-    # a pair 8 bytes apart does not overlap: counts mode stays
+        c, how, s, bc, bs = both_ways(rj, progs, data)
+        assert c == want and s == want, (at, how, c, want)
+        assert how == 3, (at, "an isolated overlapping pair inside a span is the kernel's own business")
+        assert bc == bs, (at, bc, bs)
+    base = base[:400000]
+    # many isolated pairs of random one-off strings at every distance 1..10, 40 bytes apart, on a background that cannot match
+    strings = regexdna_strings()
+    t = bytearray(b"c" * 300000)
+    at = 100
+    while at + 64 < len(t):
+        a, b2, d = rng.choice(strings), rng.choice(strings), rng.randrange(1, 11)
+        t[at:at + 8] = a
+        if rng.random() < 0.5:
+            t[at + d:at + d + 8] = b2          # (overwrites the tail of the first: whatever matches then, the oracle decides)
+        else:
+            keep = bytes(t[at:at + 8])
+            t[at + d:at + d + 8] = b2
+            t[at:at + 8] = keep                # ... or the head of the second
+        at += 40 + rng.randrange(0, 30)
+    data = bytes(t)
+    want = oracle_counts(oracle, W.REGEXDNA_PATTERNS, data)
+    c, how, s, bc, bs = both_ways(rj, progs, data)
+    assert c == want and s == want, (how, c, s, want)
+    assert bc == bs
+    # a pair 8 bytes apart does not overlap
     t = bytearray(base)
     t[5000:5016] = b"agggtaaaagggtaaa"
     data = bytes(t)
-    tt = device_text(data)
+    c, how, s, bc, bs = both_ways(rj, progs, data)
+    assert c == oracle_counts(oracle, W.REGEXDNA_PATTERNS, data) and how == 3
+
+
+def test_chains_and_cut_pairs_void_THAT_run_only(rj, oracle, W):
+    """Three matches in a row, each inside the one before (`agggtaaagggtaaagggtaaa`: the reference keeps the first and the
+    third), and a pair that lies across two waves' spans: the kernel flags the run and the span pipeline answers (return
+    value 1, the oracle's counts) -- and the NEXT run of the same object, on a clean text, is back on the counts path
+    (round 5 left the object on the span pipeline for good)."""
+    progs = [rj.Program(rx) for rx in W.REGEXDNA_PATTERNS]
+    rng = random.Random(23)
+    base = bytearray(rng.choice(b"acgt") for _ in range(400000))
+    clean = bytes(base)
+    want_clean = oracle_counts(oracle, W.REGEXDNA_PATTERNS, clean)
+    t_clean = device_text(clean)
     mc = rj.MultiScan(progs)
-    mc.set_counts_only(True)
-    assert mc.run(tt.data_ptr(), len(data)) == oracle_counts(oracle, W.REGEXDNA_PATTERNS, data) and mc.how == 3
+    assert mc.set_counts_only(True)
+    assert mc.run(t_clean.data_ptr(), len(clean)) == want_clean and mc.how == 3
+    t = bytearray(base)
+    t[7000:7022] = b"agggtaaagggtaaagggtaaa"
+    data = bytes(t)
+    want = oracle_counts(oracle, W.REGEXDNA_PATTERNS, data)
+    tt = device_text(data)
+    assert mc.run(tt.data_ptr(), len(data)) == want, mc.how
+    assert mc.how == 1, "a chain of three must send the run to the span pipeline"
+    assert mc.run(t_clean.data_ptr(), len(clean)) == want_clean and mc.how == 3, "the fallback is per run, not per object"
+    # a pair at EVERY block boundary: some of them lie across two waves' spans, whatever the launch geometry
+    t = bytearray(base)
+    for edge in range(2048, len(t) - 64, 2048):
+        t[edge - 4:edge + 11] = b"agggtaaagggtaaa"
+    data = bytes(t)
+    want = oracle_counts(oracle, W.REGEXDNA_PATTERNS, data)
+    tt = device_text(data)
+    assert mc.run(tt.data_ptr(), len(data)) == want, mc.how
+    assert mc.how == 1
+    bounds_counts = mc.bounds()
+    ms = rj.MultiScan(progs)
+    assert ms.run(tt.data_ptr(), len(data)) == want and ms.bounds() == bounds_counts
+    assert mc.run(t_clean.data_ptr(), len(clean)) == want_clean and mc.how == 3
+
+
+def test_match_all_count_of_one_pattern_takes_the_kernel(rj, oracle, W):
+    """The reference's own entry point: regexdna calls the single-pattern MatchAllCount nine times (sample/regexdna.cc:65,
+    src/rejit.cc:84-86,203-208).  rj_match_all(prog, text, n, NULL) -- host text -- and rj_scan_count -- device text --
+    must run plane_count for every one of the nine (rj_stats.count_path), with the oracle's counts; a pattern without the
+    shape takes the pipeline; there is no span list to copy or replace afterwards."""
+    data = W.fasta_stripped_numpy(50000).tobytes()
+    pair = b"agggtaaagggtaaa"
+    t2 = bytearray(data[:200000])
+    for at in (5000, 2048 * 20 + 700, 150000):      # (mid-block: texts this small give every wave ONE block)
+        t2[at:at + len(pair)] = pair
+    t2[70000:70022] = b"agggtaaagggtaaagggtaaa"        # a chain: this text takes the pipeline, with the same answer
+    texts = [data, bytes(t2[:60000]), bytes(t2)]
+    for k, text in enumerate(texts):
+        tt = device_text(text)
+        for rx in W.REGEXDNA_PATTERNS:
+            want = len(oracle.match_all(rx.encode(), text))
+            prog = rj.Program(rx)
+            assert prog.count(text) == want, (k, rx)
+            hs = prog.host_stats()
+            assert hs["n_matches"] == want
+            scan = rj.Scan(prog)
+            assert scan.count_tensor(tt) == want, (k, rx)
+            st = scan.stats()
+            chain_hits = k == 2 and rx == W.REGEXDNA_PATTERNS[0]
+            assert st["count_path"] == (0 if chain_hits else 1), (k, rx, st)
+            assert hs["count_path"] == st["count_path"], (k, rx, hs)
+            if st["count_path"] == 1 and want:
+                assert scan.device_spans_ptr() == 0
+                with pytest.raises(rj.RejitError):
+                    scan.spans()
+            # the ordinary run of the same scan object afterwards: lists again
+            assert scan.run_tensor(tt) == want and scan.spans() == oracle.match_all(rx.encode(), text)
+    # not the shape: the pipeline answers, count_path stays 0
+    for rx in (b"agggtaaac", b"[acgt]+x", b"regexp"):
+        prog = rj.Program(rx)
+        text = texts[1] + b"agggtaaacxx regexp acgtx"
+        assert prog.count(text) == len(oracle.match_all(rx, text))
+        assert prog.host_stats()["count_path"] == 0
+    # small and empty texts
+    prog = rj.Program(W.REGEXDNA_PATTERNS[0])
+    for text in (b"", b"agggtaaa", b"xxagggtaaaxxtttaccct", b"agggtaaagggtaaa"):
+        assert prog.count(text) == len(oracle.match_all(W.REGEXDNA_PATTERNS[0].encode(), text)), text
 
 
 def test_a_block_full_of_candidates_voids_the_run(rj, oracle, W):
