@@ -211,7 +211,8 @@ struct PlaneCountParams {
   uint32_t batch_at;     // a wave classifies what its ring holds (<= 64 at a time) when that many are waiting, 1..64
   uint32_t mask_bits;    // bit 16 b + 2 i / + 1: the low / high bit of the symbol code of base b's window byte i is 0
   uint32_t base_lo[2], base_hi[2];   // the bases' 8 bytes (ExactCountPlan)
-  const uint32_t* table;             // ExactCountPlan::table in device memory
+  const uint32_t* table;             // ExactCountPlan::table in device memory (the general shape: the blob of descriptors + automaton tables)
+  uint32_t table_words;              // the general shape: words of that blob (a multiple of 4), copied to LDS by every workgroup
   unsigned long long* acc;
   uint32_t* wg_rows;                 // [grid][32]: every workgroup's counts (slot 31: its flags)
   unsigned long long* wg_bounds;     // [grid][32][2]: every workgroup's first / last match per pattern (as kPcBounds)
@@ -350,6 +351,20 @@ struct PlaneGParams {
   unsigned long long* zero_counters[kMaxFused];
 };
 void launch_plane_scan_general(const PlaneGParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
+// MatchAllCount in one kernel for the sets the GENERAL plan takes (round 6; plane_count.hip: GeneralShape): the filter of
+// plane_scan_general in plane_count's 32-bytes-per-lane layout, candidates in the wave's LDS ring, every candidate
+// classified by the patterns' exact window tests + automata out of LDS (c.table = the blob classify_shared_general
+// stages: ClassifyDesc[n_patterns] padded to 16 bytes, then the tables; c.table_words of it), the left-most-longest
+// selection applied per pattern along its matches, nothing written but counts and first / last matches.
+struct PlaneCountGParams {
+  PlaneCountParams c;    // (c.mask_bits, c.base_lo / _hi unused)
+  uint32_t n_cmp, tolerance;
+  uint32_t lmax;         // the longest match of any pattern (<= 16)
+  uint32_t desc_words;   // words the descriptors take inside the blob
+  uint32_t lo[kPlaneMaxBases][8], hi[kPlaneMaxBases][8];
+};
+constexpr uint32_t kCountMaxBlobWords = 6144;   // 24 KiB of descriptors + tables per workgroup
+void launch_plane_count_general(const PlaneCountGParams& g, int max_words, uint32_t max_short, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 void launch_tails_shared_general(const MultiTail* d_tails, const SharedHits& sh, int max_words, uint32_t max_short, unsigned long long* counters0,
                                  hipStream_t st);
 void launch_offsets_gather_check_multi(const MultiTail* d_tails, int n_patterns, uint32_t n_regions, hipStream_t st);

@@ -217,13 +217,30 @@ PlanePlan plan_plane_general(const std::vector<rj_scan*>& scans) {
   for (uint32_t tol_try = 0; tol_try <= 1; tol_try++) {
     nb = 0;
     bool ok = true;
-    for (int pass = 0; pass < 2 && ok; pass++)
+    // pass 0: exact windows become bases; pass 1 (tolerance 1 only; round 6): a window with ONE free position among the compared
+    // bytes becomes a base with one of its own fixed bytes there (its strings all lie within one byte of it); pass 2: all covered
+    for (int pass = 0; pass < 3 && ok; pass++)
       for (const Win& w : wins) {
         bool covered = false;
         for (int b = 0; b < nb; b++) covered = covered || off(w, pl.base[b]) <= static_cast<int>(tol_try);
         if (covered) continue;
-        if (pass == 0 && exact(w) && nb < kPlaneMaxBases) memcpy(pl.base[nb++], w.v, 8);
-        else if (pass == 1) ok = false;
+        int n_free = 0, free_at = 0, fixed_at = -1;
+        for (uint32_t i = 0; i < n_cmp; i++) {
+          if (!w.fixed[i]) {
+            n_free++;
+            free_at = static_cast<int>(i);
+          } else if (fixed_at < 0) {
+            fixed_at = static_cast<int>(i);
+          }
+        }
+        if (pass == 0 && exact(w) && nb < kPlaneMaxBases) {
+          memcpy(pl.base[nb++], w.v, 8);
+        } else if (pass == 1 && tol_try == 1 && n_free == 1 && fixed_at >= 0 && nb < kPlaneMaxBases) {
+          memcpy(pl.base[nb], w.v, 8);
+          pl.base[nb++][free_at] = w.v[fixed_at];
+        } else if (pass == 2) {
+          ok = false;
+        }
       }
     if (ok && nb > 0) {
       tol = tol_try;
@@ -324,6 +341,14 @@ struct rj_multi {
   DeviceBuffer exact_table, count_acc, wg_rows, wg_bounds;
   unsigned long long* count_out = nullptr;   // pinned: counts, flags, first / last match per pattern
   bool counts_ready = false;   // the buffers above are allocated and cleared
+  // ... and for the sets the GENERAL plan takes (plane_count.hip: GeneralShape): the plan (== plane when that is the general
+  // one), whether every pattern can be classified inside the kernel, the blob of descriptors + tables
+  PlanePlan gplane;
+  bool general_counts = false;
+  DeviceBuffer count_blob;
+  uint32_t count_desc_words = 0, count_blob_words = 0, count_lmax = 0, count_max_short = 0;
+  int count_max_words = 1;
+  bool count_blob_ready = false;
   bool last_counts = false;    // the last run left counts (no span lists)
   uint32_t counts_fallbacks = 0;
 
@@ -417,6 +442,9 @@ int classify_blob(rj_multi* m, hipStream_t st) {
 // phase 0: the whole run (enqueue, synchronise, collect; repeated with larger regions when one overflowed).
 // phase 1 (rj_multi_start): enqueue the first attempt and return.  phase 2 (rj_multi_finish): synchronise and collect
 // what phase 1 enqueued -- same arguments --, and carry on like phase 0 when a region overflowed.
+// (internal) the batched pipeline's regions cannot hold this text's hits -- a text with a hit at (almost) every position:
+// the caller runs every pattern's own pipeline, which has the dense and the large paths for that
+constexpr int kRegionsFull = -100;
 int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, hipStream_t st, bool fuse, int phase = 0) {
   const int P = static_cast<int>(m->scans.size());
   // chunks that can hold a window of a start in [sb, se): a window begins at most 7 bytes after its start
@@ -788,7 +816,7 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       // a shared candidate region overflowed: size them all for the fullest one seen (x2) and run again
       const uint64_t want = std::max<uint64_t>(s0->host_counters[kCntSharedMax] * 2, static_cast<uint64_t>(shared_cap) * 2);
       if (shared_cap >= 2048 * std::max<uint64_t>((plane_pairs + geo.n_regions - 1) / geo.n_regions, 1))
-        return fail(RJ_DEVICE_ERROR, "candidate regions cannot grow further");
+        return kRegionsFull;   // (run_spans: one pipeline after the other)
       m->shared_cap_hint = static_cast<uint32_t>(std::min<uint64_t>(want, 1u << 20));
       again = true;
     }
@@ -797,7 +825,7 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       if (s->host_counters[kCntOverflow] != 0) {
         const uint64_t cap = caps[static_cast<size_t>(p)];
         const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(s->host_counters[kCntMaxRegion] * 2, cap * 4), geo.span_chunks * 1024);
-        if (want <= cap) return fail(RJ_DEVICE_ERROR, "hit regions cannot grow further");
+        if (want <= cap) return kRegionsFull;
         s->region_cap_hint = static_cast<uint32_t>(std::min<uint64_t>(want, 1u << 20));
         again = true;
       }
@@ -841,13 +869,64 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     }
     return RJ_OK;
   }
-  return fail(RJ_DEVICE_ERROR, "hit regions kept overflowing");
+  return kRegionsFull;
 }
 
 
+bool counts_shape(const rj_multi* m) {
+  return (m->exact.ok && m->plane.ok && !m->plane.general && m->plane.offset == 0) || m->general_counts;
+}
+
 bool counts_path(const rj_multi* m) {
   static const bool off = getenv("RJ_NO_COUNTS") != nullptr;  // measurement override
-  return m->counts_only && m->exact.ok && m->plane.ok && !m->plane.general && m->plane.offset == 0 && m->mode == 0 && !off;
+  return m->counts_only && counts_shape(m) && m->mode == 0 && !off;
+}
+
+// the blob the general count kernel stages in LDS: ClassifyDesc per pattern (window constants, table offsets; no output
+// pointers: nothing is written) + the automaton tables, copied device to device from the programs' own
+int count_blob(rj_multi* m, hipStream_t st) {
+  if (m->count_blob_ready) return RJ_OK;
+  const int P = static_cast<int>(m->scans.size());
+  std::vector<ClassifyDesc> desc(static_cast<size_t>(P));
+  RJ_HIP(m->count_blob.reserve(static_cast<size_t>(m->count_blob_words) * sizeof(uint32_t)));
+  RJ_HIP(hipMemsetAsync(m->count_blob.p, 0, static_cast<size_t>(m->count_blob_words) * sizeof(uint32_t), st));
+  uint32_t off = 0;
+  for (int p = 0; p < P; p++) {
+    const DevProgram& D = m->scans[static_cast<size_t>(p)]->prog->dev;
+    const Program& H = *m->scans[static_cast<size_t>(p)]->prog->host;
+    ClassifyDesc& d = desc[static_cast<size_t>(p)];
+    d = ClassifyDesc{};
+    d.n_windows = static_cast<uint32_t>(std::min(D.n_windows, kClassifyMaxWindows));
+    for (int q = 0; q < kClassifyMaxWindows; q++) {
+      d.v0[q] = D.win_value0[q];
+      d.m0[q] = D.win_mask0[q];
+      d.v1[q] = D.win_value1[q];
+      d.m1[q] = D.win_mask1[q];
+    }
+    d.win_offset = D.win_offset;
+    d.win_len = D.win_len;
+    d.tab = off;
+    d.n_words = static_cast<uint32_t>(D.n_words);
+    d.n_pos = static_cast<uint32_t>(D.n_pos);
+    d.n_rows = static_cast<uint32_t>(D.n_rows);
+    d.short_max = D.short_max;
+    d.nullable = D.nullable;
+    for (int pos = 0; pos < H.n_pos && pos < 64; pos++) {
+      const int row = H.row_of[static_cast<size_t>(pos)];
+      if (row < 0) continue;
+      bool any = false;
+      for (int k = 0; k < H.n_words; k++) any = any || H.rows[0][static_cast<size_t>(row) * H.n_words + k] != 0;
+      if (any) d.rowbits[pos >> 5] |= 1u << (pos & 31);
+    }
+    RJ_HIP(hipMemcpyAsync(m->count_blob.as<uint32_t>() + m->count_desc_words + off, D.first, static_cast<size_t>(D.table_words) * sizeof(uint32_t),
+                          hipMemcpyDeviceToDevice, st));
+    off += (D.table_words + 3u) & ~3u;
+  }
+  // (a pageable source: the runtime stages it before the call returns)
+  RJ_HIP(hipMemcpyAsync(m->count_blob.p, desc.data(), sizeof(ClassifyDesc) * static_cast<size_t>(P), hipMemcpyHostToDevice, st));
+  RJ_HIP(hipStreamSynchronize(st));
+  m->count_blob_ready = true;
+  return RJ_OK;
 }
 
 // the span lists of every pattern over the starts [sb, se), synchronously: what rj_multi_run does without the counts switch
@@ -855,11 +934,10 @@ bool counts_path(const rj_multi* m) {
 int run_spans(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, hipStream_t st) {
   if (m->fused && m->mode == 0 && n >= 16) {
     int rc = run_batched(m, d_text, n, sb, se, st, true);
-    return rc != RJ_OK ? rc : 1;
-  }
-  if (m->batchable && n >= 16) {
+    if (rc != kRegionsFull) return rc != RJ_OK ? rc : 1;
+  } else if (m->batchable && n >= 16) {
     int rc = run_batched(m, d_text, n, sb, se, st, false);
-    return rc != RJ_OK ? rc : 2;
+    if (rc != kRegionsFull) return rc != RJ_OK ? rc : 2;
   }
   for (rj_scan* s : m->scans) {
     int rc = run_pipeline(s, d_text, n, sb, se, 0, 0, 0, st);
@@ -875,8 +953,12 @@ int run_counts(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint
   const int P = static_cast<int>(m->scans.size());
   rj_scan* const s0 = m->scans[0];
   if (phase != 2) {
-    const uint64_t last_w = n >= 8 ? n - 8 + 1 : 0;
-    const uint64_t wlo = sb, whi = std::min<uint64_t>(se, last_w);
+    // window positions that can belong to a start in [sb, se): the general plan's patterns have their own offsets
+    const bool general = !(m->exact.ok && m->plane.ok && !m->plane.general && m->plane.offset == 0);
+    const PlanePlan& plan = general ? m->gplane : m->plane;
+    const uint32_t cmp = general ? plan.n_cmp : 8u;
+    const uint64_t last_w = n >= cmp ? n - cmp + 1 : 0;
+    const uint64_t wlo = sb + (general ? plan.min_offset : 0u), whi = std::min<uint64_t>(se + (general ? plan.max_offset : 0u), last_w);
     const uint64_t first_block = wlo / 2048;
     const uint64_t end_block = whi > wlo ? (whi + 2047) / 2048 : first_block;
     const uint64_t blocks = end_block - first_block;
@@ -886,8 +968,10 @@ int run_counts(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint
     const ScanGeometry geo = scan_geometry(std::max<uint64_t>(blocks * 2, 1), static_cast<uint64_t>(count_chunks > 0 ? count_chunks : 160));
     if (!m->counts_ready) {
       if (!m->count_out) RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&m->count_out), sizeof(unsigned long long) * kPcHostWords));
-      RJ_HIP(m->exact_table.reserve(sizeof(uint32_t) * kExactTabWords));
-      RJ_HIP(hipMemcpyAsync(m->exact_table.p, m->exact.table, sizeof(uint32_t) * kExactTabWords, hipMemcpyHostToDevice, st));
+      if (m->exact.ok) {
+        RJ_HIP(m->exact_table.reserve(sizeof(uint32_t) * kExactTabWords));
+        RJ_HIP(hipMemcpyAsync(m->exact_table.p, m->exact.table, sizeof(uint32_t) * kExactTabWords, hipMemcpyHostToDevice, st));
+      }
       RJ_HIP(m->count_acc.reserve(sizeof(unsigned long long) * kPcAccWords));
       RJ_HIP(hipMemsetAsync(m->count_acc.p, 0, sizeof(unsigned long long) * kPcAccWords, st));
       m->counts_ready = true;   // (only now: a failure above leaves the next call to start over)
@@ -901,22 +985,40 @@ int run_counts(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint
     pc.end_block = end_block;
     pc.span_blocks = blocks / geo.n_regions;
     pc.span_extra = static_cast<uint32_t>(blocks % geo.n_regions);
-    pc.code_shift = m->plane.code_shift;
-    pc.n_bases = m->plane.n_bases;
+    pc.code_shift = plan.code_shift;
+    pc.n_bases = plan.n_bases;
     pc.n_patterns = static_cast<uint32_t>(P);
     static const int batch_at = getenv("RJ_COUNT_BATCH") ? atoi(getenv("RJ_COUNT_BATCH")) : 64;  // measurement override
     pc.batch_at = static_cast<uint32_t>(std::min(std::max(batch_at, 1), 64));
-    for (uint32_t b = 0; b < 2; b++) {
-      const uint32_t bb = b < m->plane.n_bases ? b : 0;
-      for (int i = 0; i < 8; i++) {
-        const uint32_t code = (static_cast<uint32_t>(m->plane.base[bb][i]) >> m->plane.code_shift) & 3u;
-        if (!(code & 1u)) pc.mask_bits |= 1u << (16 * b + 2 * i);
-        if (!(code & 2u)) pc.mask_bits |= 1u << (16 * b + 2 * i + 1);
+    PlaneCountGParams pg{};
+    if (general) {
+      int rc = count_blob(m, st);
+      if (rc != RJ_OK) return rc;
+      pc.table = m->count_blob.as<uint32_t>();
+      pc.table_words = m->count_blob_words;
+      pg.n_cmp = plan.n_cmp;
+      pg.tolerance = plan.tolerance;
+      pg.lmax = m->count_lmax;
+      pg.desc_words = m->count_desc_words;
+      for (uint32_t b = 0; b < kPlaneMaxBases; b++)
+        for (int i = 0; i < 8; i++) {
+          const uint32_t code = (static_cast<uint32_t>(plan.base[b < plan.n_bases ? b : 0][i]) >> plan.code_shift) & 3u;
+          pg.lo[b][i] = (code & 1u) ? 0u : ~0u;
+          pg.hi[b][i] = (code & 2u) ? 0u : ~0u;
+        }
+    } else {
+      for (uint32_t b = 0; b < 2; b++) {
+        const uint32_t bb = b < plan.n_bases ? b : 0;
+        for (int i = 0; i < 8; i++) {
+          const uint32_t code = (static_cast<uint32_t>(plan.base[bb][i]) >> plan.code_shift) & 3u;
+          if (!(code & 1u)) pc.mask_bits |= 1u << (16 * b + 2 * i);
+          if (!(code & 2u)) pc.mask_bits |= 1u << (16 * b + 2 * i + 1);
+        }
+        pc.base_lo[b] = m->exact.base_lo[bb];
+        pc.base_hi[b] = m->exact.base_hi[bb];
       }
-      pc.base_lo[b] = m->exact.base_lo[bb];
-      pc.base_hi[b] = m->exact.base_hi[bb];
+      pc.table = m->exact_table.as<uint32_t>();
     }
-    pc.table = m->exact_table.as<uint32_t>();
     pc.acc = m->count_acc.as<unsigned long long>();
     pc.host_out = m->count_out;
     RJ_HIP(m->wg_rows.reserve(sizeof(uint32_t) * kExactMaxPatterns * static_cast<size_t>(geo.grid)));
@@ -925,7 +1027,12 @@ int run_counts(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint
     pc.wg_bounds = m->wg_bounds.as<unsigned long long>();
     if (m->scan_after != nullptr && m->scan_after != m && m->scan_after->scans[0]->ev[2] != nullptr)
       RJ_HIP(hipStreamWaitEvent(st, m->scan_after->scans[0]->ev[2], 0));
-    launch_plane_count(pc, geo.grid, s0->t0(), s0->ev[2], st);
+    if (general) {
+      pg.c = pc;
+      launch_plane_count_general(pg, m->count_max_words, m->count_max_short, geo.grid, s0->t0(), s0->ev[2], st);
+    } else {
+      launch_plane_count(pc, geo.grid, s0->t0(), s0->ev[2], st);
+    }
     // the rows added up: behind the scan, on the object's own stream when the caller keeps runs in flight (rj_multi_start):
     // the caller's stream is free for the next scan kernel at once
     hipStream_t fs = st;
@@ -1031,6 +1138,25 @@ int rj_multi_create(const rj_program* const* progs, int n_progs, rj_multi** out)
     std::vector<const Program*> hosts;
     for (rj_scan* s : m->scans) hosts.push_back(s->prog->host.get());
     make_exact_count_plan(hosts, m->plane.base, m->plane.n_bases, &m->exact);
+  }
+  if (!m->exact.ok && getenv("RJ_NO_PLANE") == nullptr && getenv("RJ_NO_PLANE_GENERAL") == nullptr && getenv("RJ_NO_COUNTS_GENERAL") == nullptr) {
+    // ... and for everything else the general plan takes (round 6): alternations of literals of any length, k-mers of any
+    // k, windows with a class position -- the reference's fast forward takes any such set, src/codegen.cc:327-393
+    m->gplane = m->plane.ok && m->plane.general ? m->plane : plan_plane_general(m->scans);
+    bool ok = m->gplane.ok;
+    uint32_t words = 0;
+    for (rj_scan* s : m->scans) {
+      const DevProgram& D = s->prog->dev;
+      const Program& H = *s->prog->host;
+      ok = ok && !H.has_assertions && !H.q8_risk && !H.any_nullable && H.min_len >= 1 && D.short_max >= 1 && D.short_max <= 16 && D.n_words <= 2;
+      words += (D.table_words + 3u) & ~3u;
+      m->count_lmax = std::max(m->count_lmax, D.short_max);
+      m->count_max_short = std::max(m->count_max_short, D.short_max);
+      m->count_max_words = std::max(m->count_max_words, static_cast<int>(D.n_words));
+    }
+    m->count_desc_words = static_cast<uint32_t>((sizeof(ClassifyDesc) * static_cast<size_t>(n_progs) + 15) / 16 * 4);
+    m->count_blob_words = m->count_desc_words + words;
+    m->general_counts = ok && m->count_blob_words <= kCountMaxBlobWords && n_progs < kExactMaxPatterns && m->count_lmax >= 2;
   }
   {
     std::lock_guard<std::mutex> lock(live_multi_mutex());
@@ -1139,6 +1265,13 @@ int rj_multi_finish(rj_multi* m, uint64_t* counts) {
     if (!m->last_counts) q.kind = (m->fused && m->mode == 0) ? 1 : m->batchable ? 2 : 0;   // (a void run: the span pipeline answered)
   } else if (q.kind != 0) {
     int rc = run_batched(m, q.text, q.n, q.sb, q.se, q.st, q.fuse, 2);
+    if (rc == kRegionsFull) {   // (a hit at almost every position: every pattern's own pipeline)
+      q.kind = 0;
+      for (rj_scan* s : m->scans) {
+        rc = run_pipeline(s, q.text, q.n, q.sb, q.se, 0, 0, 0, q.st);
+        if (rc != RJ_OK) return rc;
+      }
+    }
     if (rc != RJ_OK) return rc;
   } else {
     for (rj_scan* s : m->scans) {
@@ -1486,7 +1619,7 @@ int rj_multi_set_counts_only(rj_multi* m, int on) {
   if (!m) return fail(RJ_BAD_ARGUMENT, "null argument");
   if (m->pending.active) return fail(RJ_BAD_ARGUMENT, "rj_multi_set_counts_only: a run is in flight");
   m->counts_only = on != 0;
-  return (m->counts_only && m->exact.ok && m->plane.ok && !m->plane.general && m->plane.offset == 0) ? 1 : 0;
+  return (m->counts_only && counts_shape(m)) ? 1 : 0;
 }
 
 }  // extern "C"
@@ -1499,7 +1632,7 @@ int64_t rejit_amd::scan_count(rj_scan* s, const uint8_t* d_text, uint64_t n, hip
     s->counter_state = -1;
     const rj_program* progs[1] = {s->prog};
     rj_multi* m = nullptr;
-    if (n >= 16 && fusable(s->prog) && rj_multi_create(progs, 1, &m) == RJ_OK) {
+    if (n >= 16 && (fusable(s->prog) || plane_general_ok(s->prog)) && rj_multi_create(progs, 1, &m) == RJ_OK) {
       if (rj_multi_set_counts_only(m, 1) == 1) {
         (void)rj_multi_set_timing(m, s->timing ? 1 : 0);
         s->counter = m;

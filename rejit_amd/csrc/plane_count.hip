@@ -40,6 +40,7 @@
 
 #include "exact_count.h"
 #include "kernels.h"
+#include "short_walk.h"
 
 namespace rejit_amd {
 
@@ -241,16 +242,159 @@ __device__ __forceinline__ uint32_t plane_test(uint32_t ta, uint32_t tb, uint32_
   return NB > 1 ? (O[0] | O[NB - 1]) : O[0];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6: the kernel is a template over the SHAPE of the pattern set.  A shape says how a block's 32 positions per lane
+// are tested (the filter) and how a candidate is classified (the exact answer: which patterns match at it, how long):
+//   ExactShape<NB>        8-byte patterns within one byte of <= 2 bases: bit-plane test through the VGPR index mode, table
+//                         lookup per candidate (exact_count.h) -- regexdna's nine, the headline;
+//   GeneralShape<W, K, T> any set the general one-pass plan takes (multi_pattern.hip: plan_plane_general -- <= 12 base
+//                         windows of 4..8 compared bytes, exactly or within one code, windows at the patterns' own offsets,
+//                         short bounded automata of any length <= 16): the bases one after the other against sixteen
+//                         shifted planes, and per candidate every pattern's exact window test + its automaton from LDS
+//                         (short_walk.h) -- alternations of literals of any length, k-mers of any k (the reference's
+//                         FastForwardGen takes any alternation of literals: src/x64/codegen-x64.cc:1129-1252,
+//                         src/codegen.cc:327-393).
+// Everything else -- the streaming loop, the ring, the selection rule, the rows -- is shared.
+
+struct Lens {
+  uint64_t w[2];   // 5 bits per pattern (match length <= 16), twelve patterns per word
+};
+static_assert(kMaxFused <= 24, "two words of twelve lengths");
+__device__ __forceinline__ uint32_t len_of(const Lens& l, uint32_t p) {   // (p wave-uniform)
+  return static_cast<uint32_t>((p < 12 ? l.w[0] >> (5 * p) : l.w[1] >> (5 * (p - 12))) & 31u);
+}
+
+template <int NB>
+struct ExactShape {
+  using Args = PlaneCountParams;
+  static constexpr uint32_t kFixedLen = 8;
+  static constexpr bool kBlobInLds = false;
+  __device__ static __forceinline__ const PlaneCountParams& common(const Args& g) { return g; }
+  __device__ static __forceinline__ uint32_t lmax(const Args&) { return 8u; }
+  __device__ static __forceinline__ uint32_t offset_of(const Args&, const uint32_t*, uint32_t) { return 0u; }
+  __device__ static __forceinline__ uint32_t test(uint32_t ta, uint32_t tb, uint32_t hb, const Args& g) { return plane_test<NB>(ta, tb, hb, g); }
+  // the patterns that match the 8 bytes at window position `pos` (the scan does not clip: windows before the range, or
+  // with bytes beyond the end of the text, are dropped here)
+  __device__ static __forceinline__ void classify(const Args& a, const uint32_t* table, uint64_t pos, bool have, uint32_t& mask, Lens&) {
+    const bool ok = have && pos >= a.sb && pos < a.se && pos + 8 <= a.n;
+    uint32_t lo = 0, hi = 0;
+    if (ok) {
+      __builtin_memcpy(&lo, a.text + pos, 4);
+      __builtin_memcpy(&hi, a.text + pos + 4, 4);
+    }
+    mask = exact_classify<NB>(table, a.base_lo, a.base_hi, lo, hi);
+    mask = ok ? mask : 0u;
+  }
+};
+
+// the general test: bit 2k = byte k, bit 2k + 1 = byte 16 + k of the lane's 32 (plane_test's layout)
+template <bool TOL>
+__device__ __forceinline__ uint32_t general_test(uint32_t ta, uint32_t tb, uint32_t hb, const PlaneCountGParams& g) {
+  constexpr uint32_t kEven = 0x55555555u;
+  const uint32_t L = (ta & kEven) | ((tb << 1) & ~kEven);
+  const uint32_t H = ((ta >> 1) & kEven) | (tb & ~kEven);
+  const uint32_t Ln = (tb & kEven) | ((hb << 1) & ~kEven);
+  const uint32_t Hn = ((tb >> 1) & kEven) | (hb & ~kEven);
+  // the shifted planes of all compared offsets first (16 registers), then base after base in a loop that is NOT unrolled:
+  // one base's masks live in scalar registers at a time (kernel arguments: scalar-cache hits) -- plane_scan.hip:
+  // plane_candidates_general, in the 32-bytes-per-lane layout
+  uint32_t Ls[8], Hs[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    Ls[i] = i ? __builtin_amdgcn_alignbit(Ln, L, 2 * i) : L;
+    Hs[i] = i ? __builtin_amdgcn_alignbit(Hn, H, 2 * i) : H;
+  }
+  uint32_t c = 0;
+#pragma clang loop unroll(disable)
+  for (uint32_t b = 0; b < g.c.n_bases; b++) {
+    uint32_t Z = ~0u, O = ~0u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      if (static_cast<uint32_t>(i) >= g.n_cmp) break;  // (wave-uniform: windows shorter than 8 bytes)
+      const uint32_t E = (Ls[i] ^ g.lo[b][i]) & (Hs[i] ^ g.hi[b][i]);
+      if (TOL) O = i == 0 ? ~0u : (Z | (O & E));   // at most one code differs so far
+      Z &= E;                                        // none differs so far
+    }
+    c |= TOL ? O : Z;
+  }
+  return c;
+}
+
+template <int W, int MAXK, bool TOL>
+struct GeneralShape {
+  using Args = PlaneCountGParams;
+  static constexpr uint32_t kFixedLen = 0;
+  static constexpr bool kBlobInLds = true;
+  __device__ static __forceinline__ const PlaneCountParams& common(const Args& g) { return g.c; }
+  __device__ static __forceinline__ uint32_t lmax(const Args& g) { return g.lmax; }
+  __device__ static __forceinline__ uint32_t offset_of(const Args&, const uint32_t* blob, uint32_t p) {
+    return reinterpret_cast<const ClassifyDesc*>(blob)[p].win_offset;
+  }
+  __device__ static __forceinline__ uint32_t test(uint32_t ta, uint32_t tb, uint32_t hb, const Args& g) { return general_test<TOL>(ta, tb, hb, g); }
+  // per pattern: the start s = w - its window offset inside the own range, the window inside the text, one of its windows
+  // matches exactly -- then its automaton from s (classify_shared_general's steps 1 and 2, for 64 candidates at a time)
+  __device__ static __forceinline__ void classify(const Args& g, const uint32_t* blob, uint64_t w, bool have, uint32_t& mask, Lens& lens) {
+    const PlaneCountParams& a = g.c;
+    const ClassifyDesc* desc = reinterpret_cast<const ClassifyDesc*>(blob);
+    const uint32_t* tab = blob + g.desc_words;
+    uint32_t lo = 0, hi = 0;
+    if (have) {
+      if (w + 8 <= a.n) {
+        __builtin_memcpy(&lo, a.text + w, 4);
+        __builtin_memcpy(&hi, a.text + w + 4, 4);
+      } else {
+        for (uint32_t q = 0; q < 8 && w + q < a.n; q++) {
+          const uint32_t c = a.text[w + q];
+          if (q < 4) lo |= c << (8 * q);
+          else hi |= c << (8 * (q - 4));
+        }
+      }
+    }
+    uint32_t todo = 0;
+    for (uint32_t p = 0; p < a.n_patterns; p++) {
+      const ClassifyDesc& d = desc[p];
+      const uint64_t s = w - d.win_offset;
+      const bool ok = have && w >= d.win_offset && s >= a.sb && s < a.se && w + d.win_len <= a.n;
+      bool win = false;
+      for (uint32_t q = 0; q < d.n_windows; q++) win = win || ((((lo ^ d.v0[q]) & d.m0[q]) | ((hi ^ d.v1[q]) & d.m1[q])) == 0);
+      todo |= (ok && win) ? 1u << p : 0u;
+    }
+    // in pass r every lane runs the r-th pattern whose window test ITS candidate passed (tables addressed per lane)
+    mask = 0;
+    lens.w[0] = lens.w[1] = 0;
+    while (__ballot(todo != 0) != 0) {
+      const bool act = todo != 0;
+      const uint32_t p = act ? static_cast<uint32_t>(__builtin_ctz(todo)) : 0u;
+      todo &= todo - 1;
+      const ClassifyDesc& d = desc[p];
+      const uint32_t* t0 = tab + d.tab;
+      const uint64_t s = w - d.win_offset;
+      uint64_t t_lo = 0, t_hi = 0;
+      if (act) rj_load16(a.text, a.n, s, &t_lo, &t_hi);
+      const uint32_t avail = act ? (a.n - s < 16 ? static_cast<uint32_t>(a.n - s) : 16u) : 0u;
+      uint32_t len = 0;
+      bool found;
+      if (W == 1 || d.n_words <= 1) found = short_longest_lds<1, MAXK>(t0, d, t_lo, t_hi, avail, &len);
+      else found = short_longest_lds<W, MAXK>(t0, d, t_lo, t_hi, avail, &len);
+      if (found && act && len != 0) {
+        mask |= 1u << p;
+        if (p < 12) lens.w[0] |= static_cast<uint64_t>(len) << (5 * p);
+        else lens.w[1] |= static_cast<uint64_t>(len) << (5 * (p - 12));
+      }
+    }
+  }
+};
+
 // per wave: the ring, and what the classification carries from batch to batch
 struct WaveState {
-  uint32_t* ring;        // LDS, kRing slots: offsets from the span's first byte, in text order
+  uint32_t* ring;        // LDS, kRing slots: window positions as offsets from the span's first byte, in text order
   uint32_t head, tail;   // wave-uniform, free-running
   uint32_t acc;          // lane p: matches of pattern p so far
   uint32_t flags;        // kPcConflict | kPcVoid (wave-uniform)
-  // the last two candidates classified so far: offset, patterns, whether each was itself within 8 bytes of the one before it
-  uint32_t prev_rel, prev_mask, prev_close, prev_valid;
-  uint32_t prev2_mask, prev2_close;
-  // the wave's first / last match of pattern p: its offset at ends[2 p], ends[2 p + 1] (LDS; kNoEnd: none yet)
+  uint32_t prev_rel, prev_valid;   // the last candidate classified so far
+  // the wave's first / last match of pattern p (LDS): ends[4 p ..] = first offset, first length, last offset, last length
+  // (offsets of the candidate, i.e. of the window; kNoEnd: none yet).  The last one is also the selection's state: the
+  // match the next one of the pattern must not begin inside.
   uint32_t* ends;
 };
 constexpr uint32_t kNoEnd = 0xFFFFFFFFu;
@@ -281,90 +425,97 @@ __device__ __forceinline__ void push_block(WaveState& w, uint32_t hm, uint32_t r
   w.tail += tot;
 }
 
-// The first m (<= 64) candidates of the ring against the table: the overlap rule, counts, the wave's first / last matches.
-template <int NB>
-__device__ __forceinline__ void classify_batch(WaveState& w, uint32_t m, const uint32_t* table, const PlaneCountParams& a, uint64_t span_base) {
+// The first m (<= 64) candidates of the ring: classified, the selection rule applied, counted.
+//
+// The selection (reference src/x64/codegen-x64.cc:401-466: left-most-longest, non-overlapping; a match that begins inside
+// the one selected before it is dropped, :448-460) is per pattern a walk along its matches in text order -- keep one when
+// it begins at or behind the end of the last one KEPT.  A candidate whose distance to the candidate before it is at least
+// the longest match (lmax) cannot begin inside anything: kept without asking.  The others (0.6 % of the candidates on DNA)
+// are "suspects": for every pattern that matches at a suspect the wave walks that pattern's matches of the batch in order
+// -- a scalar loop of two v_readlanes per match, starting from the pattern's last kept match (its ends[] entry, which is
+// how the rule carries across batches) -- and drops what the walk drops.  Exact for pairs (`agggtaaagggtaaa` counts once)
+// and for chains of any length (`agggtaaagggtaaagggtaaa`: the first and the third); round 5 voided the run on every pair.
+template <class S>
+__device__ __forceinline__ void classify_batch(WaveState& w, uint32_t m, const uint32_t* tab, const typename S::Args& g, uint64_t span_base) {
+  const PlaneCountParams& a = S::common(g);
   const int lane = lane_id();
   const bool have = static_cast<uint32_t>(lane) < m;
   const uint32_t rel = w.ring[(w.head + static_cast<uint32_t>(lane)) & (kRing - 1)];
-  const uint64_t pos = span_base + rel;
-  // (the scan does not clip: windows before the range, or with bytes beyond the end of the text, are dropped here)
-  const bool ok = have && pos >= a.sb && pos < a.se && pos + 8 <= a.n;
-  uint32_t lo = 0, hi = 0;
-  if (ok) {
-    __builtin_memcpy(&lo, a.text + pos, 4);
-    __builtin_memcpy(&hi, a.text + pos + 4, 4);
-  }
-  uint32_t mask = exact_classify<NB>(table, a.base_lo, a.base_hi, lo, hi);
-  mask = ok ? mask : 0u;
-  // two matches of one pattern fewer than 8 bytes apart?  candidates are in text order: look at the one before
+  uint32_t mask;
+  Lens lens;
+  S::classify(g, tab, span_base + rel, have, mask, lens);
   const uint32_t before = from_lane_below(rel, w.prev_rel);
   const bool has_before = lane > 0 || w.prev_valid != 0;
-  const bool close = have && has_before && (rel - before) < 8u;
-  const uint32_t all_mask = mask;   // (what the NEXT candidate compares itself with: the patterns that match here, dropped or not)
-  if (__ballot(close) != 0) {  // (wave-uniform; 0.6 % of the candidates on DNA)
-    const uint32_t mask1 = from_lane_below(all_mask, w.prev_mask);
-    const uint32_t close1 = from_lane_below(close ? 1u : 0u, w.prev_close);
-    if (__ballot(close && close1 != 0) != 0) {
-      // three in a row: void when a fourth hangs on, or when a pattern occurs twice among the three (else nothing overlaps)
-      const uint32_t mask2 = from_lane_below(mask1, w.prev2_mask);
-      const uint32_t close2 = from_lane_below(close1, w.prev2_close);
-      const bool bad = close && close1 != 0 && (close2 != 0 || ((all_mask & mask1) | (all_mask & mask2) | (mask1 & mask2)) != 0);
-      if (__ballot(bad) != 0) w.flags |= kPcConflict;
+  const bool close = have && has_before && (rel - before) < S::lmax(g);
+  if (__ballot(close && mask != 0) != 0) {  // (wave-uniform)
+    const uint32_t all_mask = mask;
+    const uint32_t suspect = close ? all_mask : 0u;
+    for (uint32_t p = 0; p < a.n_patterns; p++) {
+      if (__ballot(((suspect >> p) & 1u) != 0) == 0) continue;  // (wave-uniform)
+      const uint64_t all = __ballot(((all_mask >> p) & 1u) != 0);
+      const uint32_t my_len = S::kFixedLen ? S::kFixedLen : len_of(lens, p);
+      // the pattern's last kept match before this batch (every lane reads the same LDS words)
+      const uint32_t last_rel = w.ends[4 * p + 2], last_len = w.ends[4 * p + 3];
+      uint32_t kept_end = w.ends[4 * p] == kNoEnd ? 0u : static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(last_rel + last_len)));
+      uint64_t kept = 0;
+      for (uint64_t mm = all; mm != 0; mm &= mm - 1) {
+        const int i = __builtin_ctzll(mm);
+        const uint32_t wi = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(rel), i));
+        const uint32_t li = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(my_len), i));
+        if (wi >= kept_end) {
+          kept |= 1ull << i;
+          kept_end = wi + li;
+        }
+      }
+      if ((((all & ~kept) >> lane) & 1ull) != 0) mask &= ~(1u << p);
     }
-    // an isolated pair: the first stands, the second is no match of the patterns they share (codegen-x64.cc:448-460)
-    mask = close ? (mask & ~mask1) : mask;
   }
-  // counts: a ballot per pattern, lane p keeps pattern p's
+  // counts: a ballot per pattern, lane p keeps pattern p's; the wave's first / last match of the pattern
   for (uint32_t p = 0; p < a.n_patterns; p++) {
     const uint64_t mine = __ballot(((mask >> p) & 1u) != 0);
     if (mine == 0) continue;  // (wave-uniform)
     if (lane == static_cast<int>(p)) w.acc += static_cast<uint32_t>(__popcll(mine));
-    const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(rel), static_cast<int>(__builtin_ctzll(mine))));
-    const uint32_t last = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(rel), 63 - static_cast<int>(__builtin_clzll(mine))));
+    const int fl = __builtin_ctzll(mine), ll = 63 - __builtin_clzll(mine);
+    const uint32_t my_len = S::kFixedLen ? S::kFixedLen : len_of(lens, p);
+    const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(rel), fl));
+    const uint32_t last = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(rel), ll));
+    const uint32_t first_len = S::kFixedLen ? S::kFixedLen : static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(my_len), fl));
+    const uint32_t last_len = S::kFixedLen ? S::kFixedLen : static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(my_len), ll));
     if (lane == static_cast<int>(p)) {
-      if (w.ends[2 * p] == kNoEnd) w.ends[2 * p] = first;
-      w.ends[2 * p + 1] = last;
+      if (w.ends[4 * p] == kNoEnd) {
+        w.ends[4 * p] = first;
+        w.ends[4 * p + 1] = first_len;
+      }
+      w.ends[4 * p + 2] = last;
+      w.ends[4 * p + 3] = last_len;
     }
   }
-  const uint32_t close_u = close ? 1u : 0u;
-  if (m >= 2) {
-    w.prev2_mask = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(all_mask), static_cast<int>(m - 2)));
-    w.prev2_close = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(close_u), static_cast<int>(m - 2)));
-  } else {
-    w.prev2_mask = w.prev_mask;
-    w.prev2_close = w.prev_close;
-  }
   w.prev_rel = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(rel), static_cast<int>(m - 1)));
-  w.prev_mask = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(all_mask), static_cast<int>(m - 1)));
-  w.prev_close = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(close_u), static_cast<int>(m - 1)));
   w.prev_valid = 1;
   w.head += m;
 }
 
-// The first candidates of a span may lie within 8 bytes of a match that begins in the span before it (another wave's):
-// the wave classifies the 7 positions before its span itself.  Conservative: any pattern in common between those
-// positions and the span's candidates in its first 7 bytes flags the run.  (Those candidates are the ring's first
-// entries -- text order -- and at most 7: lanes 0..6 of the span's first batch.)
-template <int NB>
-__device__ __forceinline__ void check_span_start(WaveState& w, uint32_t m, const uint32_t* table, const PlaneCountParams& a, uint64_t span_base) {
+// The first candidates of a span may lie inside a match that begins in the span before it (another wave's): the wave
+// classifies the lmax - 1 positions before its span itself.  Conservative: any pattern in common between those positions
+// and the span's candidates in its first lmax - 1 bytes flags the run (kPcConflict: the host repeats it with the span
+// pipeline).  (Those candidates are the ring's first entries -- text order -- and at most lmax - 1 <= 15: the low lanes of
+// the span's first batch.)
+template <class S>
+__device__ __forceinline__ void check_span_start(WaveState& w, uint32_t m, const uint32_t* tab, const typename S::Args& g, uint64_t span_base) {
+  const PlaneCountParams& a = S::common(g);
   const int lane = lane_id();
+  const uint32_t reach = S::lmax(g) - 1u;   // (<= 15)
   const uint32_t rel = w.ring[(w.head + static_cast<uint32_t>(lane)) & (kRing - 1)];
-  const bool near = static_cast<uint32_t>(lane) < m && lane < 7 && rel < 7u;
+  const bool near = static_cast<uint32_t>(lane) < m && static_cast<uint32_t>(lane) < reach && rel < reach;
   if (__ballot(near) == 0 || span_base == 0) return;  // (wave-uniform)
-  uint32_t any[2] = {0, 0};  // patterns that match at one of the 7 positions before the span / at a near candidate
+  uint32_t any[2] = {0, 0};  // patterns that match at one of the positions before the span / at a near candidate
 #pragma unroll
   for (int round = 0; round < 2; round++) {
-    const uint64_t pos = round == 0 ? span_base + static_cast<uint64_t>(lane) - 7 : span_base + rel;
-    const bool mine = round == 0 ? (lane < 7 && span_base + static_cast<uint64_t>(lane) >= 7) : near;
-    const bool ok = mine && pos >= a.sb && pos < a.se && pos + 8 <= a.n;
-    uint32_t lo = 0, hi = 0;
-    if (ok) {
-      __builtin_memcpy(&lo, a.text + pos, 4);
-      __builtin_memcpy(&hi, a.text + pos + 4, 4);
-    }
-    uint32_t mask = exact_classify<NB>(table, a.base_lo, a.base_hi, lo, hi);
-    mask = ok ? mask : 0u;
+    const uint64_t pos = round == 0 ? span_base + static_cast<uint64_t>(lane) - reach : span_base + rel;
+    const bool mine = round == 0 ? (static_cast<uint32_t>(lane) < reach && span_base + static_cast<uint64_t>(lane) >= reach) : near;
+    uint32_t mask;
+    Lens lens;
+    S::classify(g, tab, pos, mine, mask, lens);
     for (uint32_t p = 0; p < a.n_patterns; p++)
       if (__ballot(((mask >> p) & 1u) != 0) != 0) any[round] |= 1u << p;
   }
@@ -372,8 +523,9 @@ __device__ __forceinline__ void check_span_start(WaveState& w, uint32_t m, const
 }
 
 // after every second block: the run is void when a block overfilled the ring; else classify while 64 are held
-template <int NB>
-__device__ __forceinline__ void blocks_done(WaveState& w, const uint32_t* table, const PlaneCountParams& a, uint64_t span_base, bool& first_batch) {
+template <class S>
+__device__ __forceinline__ void blocks_done(WaveState& w, const uint32_t* tab, const typename S::Args& g, uint64_t span_base, bool& first_batch) {
+  const PlaneCountParams& a = S::common(g);
   if (w.tail - w.head > kRing) {  // more candidates than the ring takes: the run is void
     w.flags |= kPcVoid;
     w.head = w.tail;
@@ -382,27 +534,30 @@ __device__ __forceinline__ void blocks_done(WaveState& w, const uint32_t* table,
   while (w.tail - w.head >= a.batch_at) {
     const uint32_t held = w.tail - w.head;
     const uint32_t m = held < 64u ? held : 64u;
-    if (first_batch) check_span_start<NB>(w, m, table, a, span_base);
+    if (first_batch) check_span_start<S>(w, m, tab, g, span_base);
     first_batch = false;
-    classify_batch<NB>(w, m, table, a, span_base);
+    classify_batch<S>(w, m, tab, g, span_base);
   }
 }
 
 }  // namespace
 
 // (block indices are 32-bit inside the kernel: texts of up to 8 TiB)
-template <int NB>
-__global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
+template <class S>
+__global__ __launch_bounds__(256) void plane_count(typename S::Args g) {
+  // ExactShape: the table (exact_count.h); GeneralShape: the blob of descriptors + automaton tables (dynamic LDS)
   __shared__ __attribute__((aligned(16))) uint32_t table[kExactTabWords];
+  extern __shared__ __attribute__((aligned(16))) uint32_t blob[];
   __shared__ uint32_t rings[4][kRing];
-  __shared__ uint32_t ends[4][2 * kExactMaxPatterns];
+  __shared__ uint32_t ends[4][4 * kExactMaxPatterns];
   __shared__ unsigned long long wave_bounds[4][kExactMaxPatterns][2];
   __shared__ uint32_t wave_counts[4][kExactMaxPatterns];
   __shared__ uint32_t wave_flags[4];
+  const PlaneCountParams& a = S::common(g);
+  const uint32_t* tab = S::kBlobInLds ? blob : table;
   const int lane = lane_id();
   const uint32_t wid = threadIdx.x >> 6;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6));
-  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
   Consts k;
   k.shift = a.code_shift;
   k.cmask = 0x03030303u << a.code_shift;
@@ -422,9 +577,9 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
   w.head = w.tail = 0;
   w.acc = 0;
   w.flags = 0;
-  w.prev_rel = w.prev_mask = w.prev_close = w.prev_valid = 0;
-  w.prev2_mask = w.prev2_close = 0;
-  w.ends[lane] = kNoEnd;   // (2 x 32 entries: one per lane)
+  w.prev_rel = w.prev_valid = 0;
+  w.ends[lane] = kNoEnd;   // (4 x 32 entries: two per lane)
+  w.ends[lane + 64] = kNoEnd;
   bool first_batch = true;
 
   // A wave never loads a block that is not its own: prefetches beyond the span's last fast block are clamped to that
@@ -442,8 +597,14 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
     load_block(blk(c + 1), lane_rel, rb);
     behind = *reinterpret_cast<const uint2*>(a.text + static_cast<uint64_t>(fast_end) * kBlock);   // (block fast_end lies inside the text)
   }
-  // the table (all waves), before the first wait for text
-  for (uint32_t i = threadIdx.x; i < kExactTabWords; i += blockDim.x) table[i] = a.table[i];
+  // the table / the blob (all waves), before the first wait for text
+  if (S::kBlobInLds) {
+    const uint4* src = reinterpret_cast<const uint4*>(a.table);
+    uint4* dst = reinterpret_cast<uint4*>(blob);
+    for (uint32_t i = threadIdx.x; i < a.table_words / 4; i += blockDim.x) dst[i] = src[i];
+  } else {
+    for (uint32_t i = threadIdx.x; i < kExactTabWords; i += blockDim.x) table[i] = a.table[i];
+  }
   __syncthreads();
   if (c < fast_end) {
     uint32_t xa = codes16(ra.a, k), xb = codes16(ra.b, k);   // block c
@@ -458,7 +619,7 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
       load_block(blk(c + 3), lane_rel, rb);
       {
         const uint32_t hb = from_lane_above(xa, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ya))));
-        const uint32_t hm = plane_test<NB>(xa, xb, hb, a);
+        const uint32_t hm = S::test(xa, xb, hb, g);
         push_block(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -469,20 +630,20 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
       {
         const uint32_t next0 = c + 2 == fast_end ? behind_codes : static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xa)));
         const uint32_t hb = from_lane_above(ya, next0);
-        const uint32_t hm = plane_test<NB>(ya, yb, hb, a);
+        const uint32_t hm = S::test(ya, yb, hb, g);
         push_block(w, hm, (c + 1 - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
       }
       __builtin_amdgcn_sched_barrier(0);
       c += 2;
-      if (w.tail - w.head >= a.batch_at) blocks_done<NB>(w, table, a, span_base, first_batch);
+      if (w.tail - w.head >= a.batch_at) blocks_done<S>(w, tab, g, span_base, first_batch);
     }
     if (c + 1 == fast_end) {   // an odd block left: x holds its codes; behind it the span ends
       const uint32_t hb = from_lane_above(xa, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(behind_codes))));
-      const uint32_t hm = plane_test<NB>(xa, xb, hb, a);
+      const uint32_t hm = S::test(xa, xb, hb, g);
       push_block(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
       c++;
     }
-    blocks_done<NB>(w, table, a, span_base, first_batch);
+    blocks_done<S>(w, tab, g, span_base, first_batch);
   }
   // the block(s) at the end of the text: guarded loads, the 8 bytes behind the lane's 32 read by the lane itself
   for (; c < c1; c++) {
@@ -498,8 +659,8 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
     vb.w = guarded_dword(a.text, a.n, at + 28);
     const uint32_t h0 = guarded_dword(a.text, a.n, at + 32), h1 = guarded_dword(a.text, a.n, at + 36);
     const uint32_t hb = (codes4(h0, k) >> k.shift) | (codes4(h1, k) << (8 - k.shift));
-    const uint32_t hm = plane_test<NB>(codes16(va, k), codes16(vb, k), hb, a);
-    if (w.tail - w.head > kRing - 64u) blocks_done<NB>(w, table, a, span_base, first_batch);   // (room for this block)
+    const uint32_t hm = S::test(codes16(va, k), codes16(vb, k), hb, g);
+    if (w.tail - w.head > kRing - 64u) blocks_done<S>(w, tab, g, span_base, first_batch);   // (room for this block)
     push_block(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
   }
   // what the ring still holds
@@ -510,9 +671,9 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
   while (w.tail != w.head) {
     const uint32_t held = w.tail - w.head;
     const uint32_t m = held < 64u ? held : 64u;
-    if (first_batch) check_span_start<NB>(w, m, table, a, span_base);
+    if (first_batch) check_span_start<S>(w, m, tab, g, span_base);
     first_batch = false;
-    classify_batch<NB>(w, m, table, a, span_base);
+    classify_batch<S>(w, m, tab, g, span_base);
   }
   // wave -> workgroup (LDS) -> rows of the workgroup's own in device memory: plain stores, read by plane_count_finish
   // (the next kernel on the stream).  Measured alternatives, all inside this kernel: nine device-scope atomic adds and a
@@ -525,10 +686,12 @@ __global__ __launch_bounds__(256) void plane_count(PlaneCountParams a) {
   // the span pipeline re-read a text that might be gone by then): plane_count_finish finds the first / last ROW with a
   // count from the rows it adds up anyway and reads two bounds per pattern.
   if (lane < kExactMaxPatterns) {
-    wave_counts[wid][lane] = lane < static_cast<int>(a.n_patterns) ? w.acc : 0u;
-    const uint32_t ef = w.ends[2 * lane], el = w.ends[2 * lane + 1];
-    wave_bounds[wid][lane][0] = ef != kNoEnd ? ((span_base + ef) | (8ull << kPcLenShift)) : kPcNone;
-    wave_bounds[wid][lane][1] = ef != kNoEnd ? ((span_base + el) | (8ull << kPcLenShift)) : kPcNone;
+    const bool real = lane < static_cast<int>(a.n_patterns);
+    wave_counts[wid][lane] = real ? w.acc : 0u;
+    const uint32_t ef = w.ends[4 * lane], efl = w.ends[4 * lane + 1], el = w.ends[4 * lane + 2], ell = w.ends[4 * lane + 3];
+    const uint64_t off = real ? S::offset_of(g, tab, static_cast<uint32_t>(lane)) : 0u;   // the match begins `off` bytes before its window
+    wave_bounds[wid][lane][0] = ef != kNoEnd ? ((span_base + ef - off) | (static_cast<unsigned long long>(efl) << kPcLenShift)) : kPcNone;
+    wave_bounds[wid][lane][1] = ef != kNoEnd ? ((span_base + el - off) | (static_cast<unsigned long long>(ell) << kPcLenShift)) : kPcNone;
   }
   if (lane == 0) wave_flags[wid] = w.flags;
   __syncthreads();
@@ -754,8 +917,23 @@ void launch_stream_read_probe(const void* d_text, uint64_t n, uint32_t* d_out, i
 }
 
 void launch_plane_count(const PlaneCountParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
-  if (a.n_bases <= 1) hipExtLaunchKernelGGL((plane_count<1>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
-  else hipExtLaunchKernelGGL((plane_count<2>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+  if (a.n_bases <= 1) hipExtLaunchKernelGGL((plane_count<ExactShape<1>>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+  else hipExtLaunchKernelGGL((plane_count<ExactShape<2>>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+}
+
+// max_words / max_short: the largest n_words / short_max among the patterns (the instantiation)
+void launch_plane_count_general(const PlaneCountGParams& g, int max_words, uint32_t max_short, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+  const size_t lds = static_cast<size_t>(g.c.table_words) * sizeof(uint32_t);
+  const dim3 gr(grid), b(256);
+  if (g.tolerance) {
+    if (max_words <= 1 && max_short <= 8) hipExtLaunchKernelGGL((plane_count<GeneralShape<1, 8, true>>), gr, b, lds, st, t0, t1, 0, g);
+    else if (max_words <= 1) hipExtLaunchKernelGGL((plane_count<GeneralShape<1, 16, true>>), gr, b, lds, st, t0, t1, 0, g);
+    else hipExtLaunchKernelGGL((plane_count<GeneralShape<2, 16, true>>), gr, b, lds, st, t0, t1, 0, g);
+  } else {
+    if (max_words <= 1 && max_short <= 8) hipExtLaunchKernelGGL((plane_count<GeneralShape<1, 8, false>>), gr, b, lds, st, t0, t1, 0, g);
+    else if (max_words <= 1) hipExtLaunchKernelGGL((plane_count<GeneralShape<1, 16, false>>), gr, b, lds, st, t0, t1, 0, g);
+    else hipExtLaunchKernelGGL((plane_count<GeneralShape<2, 16, false>>), gr, b, lds, st, t0, t1, 0, g);
+  }
 }
 
 void launch_plane_count_finish(const PlaneCountParams& a, int grid, hipStream_t st) {

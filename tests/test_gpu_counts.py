@@ -207,11 +207,11 @@ def test_overlapping_pairs_are_resolved_in_the_kernel(rj, oracle, W):
     assert c == oracle_counts(oracle, W.REGEXDNA_PATTERNS, data) and how == 3
 
 
-def test_chains_and_cut_pairs_void_THAT_run_only(rj, oracle, W):
+def test_chains_are_walked_and_cut_pairs_void_THAT_run_only(rj, oracle, W):
     """Three matches in a row, each inside the one before (`agggtaaagggtaaagggtaaa`: the reference keeps the first and the
-    third), and a pair that lies across two waves' spans: the kernel flags the run and the span pipeline answers (return
-    value 1, the oracle's counts) -- and the NEXT run of the same object, on a clean text, is back on the counts path
-    (round 5 left the object on the span pipeline for good)."""
+    third): the kernel walks the pattern's matches itself (return value 3).  A pair that lies across two waves' spans makes
+    the kernel flag the run and the span pipeline answer (return value 1, the oracle's counts) -- and the NEXT run of the
+    same object, on a clean text, is back on the counts path (round 5 left the object on the span pipeline for good)."""
     progs = [rj.Program(rx) for rx in W.REGEXDNA_PATTERNS]
     rng = random.Random(23)
     base = bytearray(rng.choice(b"acgt") for _ in range(400000))
@@ -221,14 +221,14 @@ def test_chains_and_cut_pairs_void_THAT_run_only(rj, oracle, W):
     mc = rj.MultiScan(progs)
     assert mc.set_counts_only(True)
     assert mc.run(t_clean.data_ptr(), len(clean)) == want_clean and mc.how == 3
-    t = bytearray(base)
-    t[7000:7022] = b"agggtaaagggtaaagggtaaa"
-    data = bytes(t)
-    want = oracle_counts(oracle, W.REGEXDNA_PATTERNS, data)
-    tt = device_text(data)
-    assert mc.run(tt.data_ptr(), len(data)) == want, mc.how
-    assert mc.how == 1, "a chain of three must send the run to the span pipeline"
-    assert mc.run(t_clean.data_ptr(), len(clean)) == want_clean and mc.how == 3, "the fallback is per run, not per object"
+    for chain in (b"agggtaaagggtaaagggtaaa", b"agggtaaagggtaaagggtaaagggtaaagggtaaa", b"tttaccctttaccctttaccct"):
+        t = bytearray(base)
+        t[7000:7000 + len(chain)] = chain
+        data = bytes(t)
+        want = oracle_counts(oracle, W.REGEXDNA_PATTERNS, data)
+        c, how, s, bc, bs = both_ways(rj, progs, data)
+        assert c == want and s == want, (chain, how, c, s, want)
+        assert how == 3 and bc == bs, (chain, how)
     # a pair at EVERY block boundary: some of them lie across two waves' spans, whatever the launch geometry
     t = bytearray(base)
     for edge in range(2048, len(t) - 64, 2048):
@@ -254,7 +254,7 @@ def test_match_all_count_of_one_pattern_takes_the_kernel(rj, oracle, W):
     t2 = bytearray(data[:200000])
     for at in (5000, 2048 * 20 + 700, 150000):      # (mid-block: texts this small give every wave ONE block)
         t2[at:at + len(pair)] = pair
-    t2[70000:70022] = b"agggtaaagggtaaagggtaaa"        # a chain: this text takes the pipeline, with the same answer
+    t2[70000:70022] = b"agggtaaagggtaaagggtaaa"        # a chain: walked inside the kernel
     texts = [data, bytes(t2[:60000]), bytes(t2)]
     for k, text in enumerate(texts):
         tt = device_text(text)
@@ -267,8 +267,7 @@ def test_match_all_count_of_one_pattern_takes_the_kernel(rj, oracle, W):
             scan = rj.Scan(prog)
             assert scan.count_tensor(tt) == want, (k, rx)
             st = scan.stats()
-            chain_hits = k == 2 and rx == W.REGEXDNA_PATTERNS[0]
-            assert st["count_path"] == (0 if chain_hits else 1), (k, rx, st)
+            assert st["count_path"] == 1, (k, rx, st)
             assert hs["count_path"] == st["count_path"], (k, rx, hs)
             if st["count_path"] == 1 and want:
                 assert scan.device_spans_ptr() == 0
@@ -276,12 +275,12 @@ def test_match_all_count_of_one_pattern_takes_the_kernel(rj, oracle, W):
                     scan.spans()
             # the ordinary run of the same scan object afterwards: lists again
             assert scan.run_tensor(tt) == want and scan.spans() == oracle.match_all(rx.encode(), text)
-    # not the shape: the pipeline answers, count_path stays 0
-    for rx in (b"agggtaaac", b"[acgt]+x", b"regexp"):
+    # other literals take the general form of the kernel; unbounded patterns and assertions the pipeline (count_path 0)
+    for rx, path in ((b"agggtaaac", 1), (b"regexp", 1), (b"[acgt]+x", 0), (b"^agggtaaa", 0), (b"a.*b", 0), (b"agg", 0)):
         prog = rj.Program(rx)
-        text = texts[1] + b"agggtaaacxx regexp acgtx"
-        assert prog.count(text) == len(oracle.match_all(rx, text))
-        assert prog.host_stats()["count_path"] == 0
+        text = texts[1] + b"agggtaaacxx regexp acgtx\nagggtaaa"
+        assert prog.count(text) == len(oracle.match_all(rx, text)), rx
+        assert prog.host_stats()["count_path"] == path, rx
     # small and empty texts
     prog = rj.Program(W.REGEXDNA_PATTERNS[0])
     for text in (b"", b"agggtaaa", b"xxagggtaaaxxtttaccct", b"agggtaaagggtaaa"):
@@ -340,13 +339,20 @@ def test_other_set_shapes(rj, oracle):
     assert c == want, (took, mc.how, c, want)
     ms = rj.MultiScan(progs)
     assert ms.run(tt.data_ptr(), len(data)) == want
-    # a longer pattern in the set: not the shape
+    # a longer pattern in the set: not the 8-mer table's shape -- the general form of the kernel takes it (round 6)
     progs2 = [rj.Program(rx) for rx in (b"agggtaaa|tttaccct", b"agggtaaac")]
     m2 = rj.MultiScan(progs2)
-    assert not m2.set_counts_only(True)
+    assert m2.set_counts_only(True)
     data2 = b"xxagggtaaacxxtttaccctxx" * 100
     t2 = device_text(data2)
-    assert m2.run(t2.data_ptr(), len(data2)) == oracle_counts(oracle, [b"agggtaaa|tttaccct", b"agggtaaac"], data2)
+    assert m2.run(t2.data_ptr(), len(data2)) == oracle_counts(oracle, [b"agggtaaa|tttaccct", b"agggtaaac"], data2) and m2.how == 3
+    # an unbounded pattern in the set: the switch is ignored
+    progs3 = [rj.Program(rx) for rx in (b"agggtaaa|tttaccct", b"agggtaaa[acgt]+x")]
+    m3 = rj.MultiScan(progs3)
+    assert not m3.set_counts_only(True)
+    data3 = b"xxagggtaaacxxtttaccctxx" * 100
+    t3 = device_text(data3)
+    assert m3.run(t3.data_ptr(), len(data3)) == oracle_counts(oracle, [b"agggtaaa|tttaccct", b"agggtaaa[acgt]+x"], data3) and m3.how != 3
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -423,3 +429,132 @@ def test_sharded_counts_in_counts_mode(rj, oracle, W, world):
     for rank in range(world):
         assert results[rank] == want, (rank, results[rank], want)
         assert hows[rank] == 3, (rank, hows)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Round 6: MatchAllCount in one kernel for the sets the GENERAL plan takes (plane_count.hip: GeneralShape) -- alternations
+# of literals of any length, k-mers of any k, windows with a class position (the reference's fast forward takes any
+# alternation of <= 7 literals, src/x64/codegen-x64.cc:1129-1252, src/codegen.cc:327-393).
+
+def general_both_ways(rj, rxs, data, own=None, expect_how=3):
+    progs = [rj.Program(rx) for rx in rxs]
+    t = device_text(data)
+    kw = {} if own is None else {"own_begin": own[0], "own_end": own[1]}
+    mc = rj.MultiScan(progs)
+    took = mc.set_counts_only(True)
+    c = mc.run(t.data_ptr(), len(data), **kw)
+    how, bc = mc.how, mc.bounds()
+    ms = rj.MultiScan(progs)
+    s = ms.run(t.data_ptr(), len(data), **kw)
+    bs = ms.bounds()
+    if expect_how is not None:
+        assert took and how == expect_how, (rxs, took, how)
+    return c, how, s, bc, bs
+
+
+def random_kmers(rng, k, count, alphabet):
+    out = set()
+    while len(out) < count:
+        out.add(bytes(rng.choice(alphabet) for _ in range(k)))
+    return sorted(out)
+
+
+def test_general_counts_literal_sets(rj, oracle, W):
+    """bench.py's general_one_pass set, nine random 6-mers and 12-mers (DNA alphabet, DNA text: matches and close pairs
+    are common; lower-case letters over random ASCII with plants), mixed lengths -- counts == oracle, first / last matches
+    == the span pipeline's, return value 3."""
+    rng = random.Random(31)
+    ascii_bg = bytes(range(ord("0"), ord("z")))
+    cases = []
+    gset = [b"alternation|strings", b"prefix abcd|prefix 1234"]
+    gstrings = [b"alternation", b"strings", b"prefix abcd", b"prefix 1234", b"alternatio", b"prefix abc4", b"string", b"prefix 123"]
+    cases.append((gset, planted_text(rng, 300000, ascii_bg, gstrings, 0.002)))
+    for k in (6, 12):
+        dna = random_kmers(rng, k, 9, b"acgt")
+        text = bytearray(np.random.default_rng(k).choice(np.frombuffer(b"acgt", dtype=np.uint8), 400000).tobytes())
+        for s in dna:                                   # (12-mers do not occur by chance)
+            for _ in range(40):
+                p = rng.randrange(0, len(text) - k)
+                text[p:p + k] = s
+        cases.append((dna, text))
+        words = random_kmers(rng, k, 9, b"abcdefghijklmnopqrstuvwxyz")
+        cases.append((words, planted_text(rng, 300000, ascii_bg, words + [w[:-1] for w in words], 0.003)))
+    mixed = [b"needle", b"haystacks|haycart", b"pitchfork12", b"barn door"]   # (five bases of >= 6 compared bytes: the plan's filter is selective enough)
+    cases.append((mixed, planted_text(rng, 300000, ascii_bg, [b"needle", b"haystacks", b"haystack", b"haycart", b"pitchfork12", b"pitchfork1", b"barn door"], 0.003)))
+    for rxs, t in cases:
+        data = bytes(t)
+        want = oracle_counts(oracle, rxs, data)
+        c, how, s, bc, bs = general_both_ways(rj, rxs, data)
+        assert s == want, (rxs, s, want)
+        assert c == want, (rxs, how, c, want)
+        assert bc == bs, (rxs, bc, bs)
+        assert sum(want) > 0
+
+
+def test_general_counts_classes_offsets_and_prefixes(rj, oracle, W):
+    """Windows with a class position (tolerance 1), windows behind a class (their own offset inside the match), an
+    alternative that is a prefix of another (the longest wins and is what the next match must not begin inside), own ranges."""
+    rng = random.Random(32)
+    ascii_bg = bytes(range(ord("0"), ord("z")))
+    cases = [
+        ([b"ab[cx]defgh", b"zzz[0-9]yyyy"], [b"abcdefgh", b"abxdefgh", b"abydefgh", b"zzz5yyyy", b"zzzayyyy", b"zzz0yyy"]),
+        ([b"[ab]cdefghij", b"[xy]cdefghiq"], [b"acdefghij", b"bcdefghij", b"ccdefghij", b"xcdefghiq", b"ycdefghij"]),
+        ([b"abcd|abcdefgh", b"efgh1234"], [b"abcd", b"abcdefgh", b"abcdefgh1234", b"abcdabcd", b"efgh1234"]),
+        ([b"ab(cd|ef)ghij", b"abcdgh"], [b"abcdghij", b"abefghij", b"abcdgh", b"abcdghi"]),
+    ]
+    for rxs, strings in cases:
+        data = bytes(planted_text(rng, 250000, ascii_bg, strings, 0.004))
+        want = oracle_counts(oracle, rxs, data)
+        c, how, s, bc, bs = general_both_ways(rj, rxs, data, expect_how=None)
+        assert s == want and c == want, (rxs, how, c, s, want)
+        assert bc == bs, (rxs, how, bc, bs)
+        assert how == 3, (rxs, "the general plan takes this set: the count must be the kernel's")
+        for own in [(0, 100000), (100000, 250001), (2040, 2060), (123457, 123458)]:
+            want_own = oracle_counts(oracle, rxs, data, own)
+            c, how, s, bc, bs = general_both_ways(rj, rxs, data, own, expect_how=None)
+            assert c == want_own and s == want_own, (rxs, own, how, c, s, want_own)
+            assert bc == bs, (rxs, own)
+
+
+def test_general_counts_selection_along_chains(rj, oracle, W):
+    """Texts on which the count is far from the number of matching positions: `abab|baba` over `abababab...` (every position
+    matches, every second one overlaps the one before), runs of a 6-mer's period, and a dense mix -- the selection is walked
+    inside the kernel (a pair or a chain inside a span never voids the run; across two waves' spans it may)."""
+    rng = random.Random(33)
+    rxs = [b"abab|baba", b"ababab"]
+    data = b"ab" * 3000 + b"xx" + b"ba" * 1000 + b"x" * 2000 + b"abab" + b"y" * 100 + b"ababab" + b"z" * 3000
+    want = oracle_counts(oracle, rxs, data)
+    c, how, s, bc, bs = general_both_ways(rj, rxs, data, expect_how=None)
+    assert s == want, (s, want)
+    assert c == want, (how, c, want)
+    assert bc == bs
+    # bursts of `abab...` of every length up to 40 with fillers between them (a wave's ring takes 256 candidates per two
+    # blocks): pairs and chains inside a span are the kernel's own business
+    small = b"".join(b"ab" * (k % 20 + 1) + b"q" * 300 + b"ba" * (k % 7 + 2) + b"x" * 250 for k in range(40))
+    small = small[:2000]        # (texts below 2 MiB give every wave ONE block: stay inside the first)
+    want = oracle_counts(oracle, rxs, small)
+    c, how, s, bc, bs = general_both_ways(rj, rxs, small, expect_how=None)
+    assert c == want and s == want and how == 3 and bc == bs, (how, c, s, want)
+    # a dense mix over two letters: six patterns of 5..9 bytes
+    pats = [b"aabab", b"babbab", b"abbabba", b"bbbbbbbb", b"aaaaaaaab", b"abaab|baaba"]
+    data = bytes(rng.choice(b"ab") for _ in range(150000))
+    want = oracle_counts(oracle, pats, data)
+    c, how, s, bc, bs = general_both_ways(rj, pats, data, expect_how=None)
+    assert c == want and s == want, (how, c, s, want)
+    assert bc == bs
+
+
+def test_general_counts_single_pattern_and_host_entry(rj, oracle, W):
+    """MatchAllCount of ONE pattern of the general shape: `alternation|strings` through rj_scan_count and through
+    rj_match_all(..., NULL)."""
+    rng = random.Random(34)
+    ascii_bg = bytes(range(ord("0"), ord("z")))
+    for rx, strings in [(b"alternation|strings", [b"alternation", b"strings", b"string"]), (b"prefix abcd|prefix 1234", [b"prefix abcd", b"prefix 1234", b"prefix 12"]),
+                        (b"acgtacgtacgt", [b"acgtacgtacgt", b"acgtacgtacg"])]:
+        data = bytes(planted_text(rng, 200000, ascii_bg, strings, 0.003))
+        want = len(oracle.match_all(rx, data))
+        prog = rj.Program(rx)
+        assert prog.count(data) == want
+        assert prog.host_stats()["count_path"] == 1, rx
+        sc = rj.Scan(prog)
+        assert sc.count_tensor(device_text(data)) == want and sc.stats()["count_path"] == 1

@@ -1,7 +1,8 @@
 """GPU parity at BASELINE's FULL sizes (-m gpu): the engine's spans against the REAL reference's answers over the same
 inputs, stored as counts + span digests in tests/golden/fullsize_vectors.json (generated once in the build container by
 tests/golden/make_fullsize.py from oracle/_ref, the reference compiled in place).
-  C3  the nine regexdna patterns over the stripped 50M-line FASTA (500 MB): one-pass run (plane scan) and single runs
+  C3  the nine regexdna patterns over the stripped 50M-line FASTA (500 MB): one-pass run (plane scan) and single runs;
+      MatchAllCount in one kernel (what bench.py times), own ranges cut mid-block, and a 4.3 GB text (32-bit offsets)
   C2  literal `regexp` over 5 GB of random ASCII with 1000 planted occurrences
   C4  the complex benchmark regex over rank 0's 6.25 GB shard of the 8-GPU job (own range + 58-byte halo), and (round 4)
       ALL eight shards one after the other with the selection carried over the seven cuts
@@ -51,6 +52,93 @@ def test_c3_regexdna_50m_lines(env):
         sc = rj.Scan(progs[i])
         assert sc.run(text.data_ptr(), n, stream=st) == c3["patterns"][i]["digest"]["count"]
         assert digest_of(W, sc, dev) == c3["patterns"][i]["digest"]
+
+
+def test_c3_counts_only_50m_lines(env):
+    """The kernel bench.py times (plane_count: MatchAllCount of the nine patterns in one launch, rj_multi_set_counts_only)
+    at BASELINE's size, pinned by the suite and not by a benchmark assert: the real reference's nine counts, the span
+    pipeline's first / last match per pattern, own ranges that cut the 500 MB text in the middle of a 2-KiB block (the
+    sharded shape), and the same through the reference's own entry point -- MatchAllCount pattern by pattern."""
+    rj, W, torch, dev, doc = env
+    c3 = doc["c3"]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    text = W.fasta_stripped_torch(c3["fasta_n"], dev)
+    n = int(text.numel())
+    want = [p["digest"]["count"] for p in c3["patterns"]]
+    progs = [rj.Program(p["regex"]) for p in c3["patterns"]]
+    counting, listing = rj.MultiScan(progs), rj.MultiScan(progs)
+    assert counting.set_counts_only(True)
+    assert counting.run(text.data_ptr(), n, stream=st) == want
+    assert counting.how == 3, "the nine patterns must take the one-kernel count at 500 MB"
+    assert listing.run(text.data_ptr(), n, stream=st) == want and listing.how == 1
+    assert counting.bounds() == listing.bounds()
+    # two in flight, as the headline loop runs it
+    other = rj.MultiScan(progs)
+    assert other.set_counts_only(True)
+    counting.start(text.data_ptr(), n, stream=st)
+    other.start(text.data_ptr(), n, stream=st)
+    assert counting.finish() == want and other.finish() == want and counting.how == 3 and other.how == 3
+    # shards: cuts in the middle of a block, and one a few bytes before a block boundary
+    for cut in (250000123, 2048 * 100000 - 3, n - 1000):
+        total = [0] * len(progs)
+        for own in ((0, cut), (cut, n + 1)):
+            c = counting.run(text.data_ptr(), n, stream=st, own_begin=own[0], own_end=own[1])
+            assert counting.how == 3, (cut, own)
+            s = listing.run(text.data_ptr(), n, stream=st, own_begin=own[0], own_end=own[1])
+            assert c == s, (cut, own, c, s)
+            assert counting.bounds() == listing.bounds(), (cut, own)
+            total = [a + b for a, b in zip(total, c)]
+        # (no regexdna match overlaps another of its pattern in this text: the two ranges' counts add up)
+        assert total == want, (cut, total, want)
+    # the reference's own call: one MatchAllCount per pattern (sample/regexdna.cc:65) -- device text
+    for i, p in enumerate(progs):
+        sc = rj.Scan(p)
+        assert sc.count(text.data_ptr(), n, stream=st) == want[i], c3["patterns"][i]["regex"]
+        assert sc.stats()["count_path"] == 1
+
+
+def test_counts_only_beyond_4gib(env):
+    """32-bit arithmetic in the count kernel (block indices, the candidates' offsets inside a span, the workgroup rows)
+    on a text of 4.3 GB: the FASTA generator's random sections are periodic (the LCG's period is 139 968 characters), so
+    the 43M-line text is more of the same; counts and first / last matches must equal the span pipeline's, a match planted
+    in the last 8 bytes (offset > 2^32) must be the last one, and a range that begins beyond 4 GiB must count like the
+    span pipeline does."""
+    rj, W, torch, dev, doc = env
+    st = torch.cuda.current_stream(dev).cuda_stream
+    fasta_n = 430000000
+    text = W.fasta_stripped_torch(fasta_n, dev)
+    n = int(text.numel())
+    assert n == 4300000000 and n > (1 << 32)
+    W.plant(text, [n - 8], b"agggtaaa")
+    W.plant(text, [(1 << 32) - 4], b"tttaccct")     # across the 4 GiB line
+    progs = [rj.Program(rx) for rx in W.REGEXDNA_PATTERNS]
+    counting, listing = rj.MultiScan(progs), rj.MultiScan(progs)
+    assert counting.set_counts_only(True)
+    c = counting.run(text.data_ptr(), n, stream=st)
+    assert counting.how == 3
+    s = listing.run(text.data_ptr(), n, stream=st)
+    assert listing.how == 1
+    assert c == s, (c, s)
+    bc, bs = counting.bounds(), listing.bounds()
+    assert bc == bs, (bc, bs)
+    assert bc[0][2:] == (n - 8, n)
+    # the periodic structure: sequence THREE (the last 5 n characters) repeats every 139 968 characters, so a stretch of
+    # whole periods holds the same matches wherever it begins: 30 periods early in the sequence and 30 periods that begin
+    # beyond 4 GiB
+    period = 139968
+    a0 = 5 * fasta_n + 7 * period
+    a1 = a0 + (((1 << 32) - a0 + period - 1) // period) * period
+    assert a1 >= (1 << 32) and a1 + 30 * period < n - 8
+    stretch = [counting.run(text.data_ptr(), n, stream=st, own_begin=a, own_end=a + 30 * period) for a in (a0, a1)]
+    assert counting.how == 3
+    assert stretch[0] == stretch[1], stretch
+    assert sum(stretch[0]) > 0
+    # a range beyond 4 GiB
+    own = ((1 << 32) + 12345, n + 1)
+    assert counting.run(text.data_ptr(), n, stream=st, own_begin=own[0], own_end=own[1]) == listing.run(text.data_ptr(), n, stream=st, own_begin=own[0], own_end=own[1])
+    assert counting.how == 3 and counting.bounds() == listing.bounds()
+    sc = rj.Scan(progs[0])
+    assert sc.count(text.data_ptr(), n, stream=st) == c[0] and sc.stats()["count_path"] == 1
 
 
 def test_c2_literal_5gb(env):
