@@ -361,7 +361,7 @@ struct PlaneCountGParams {
   uint32_t n_cmp, tolerance;
   uint32_t lmax;         // the longest match of any pattern (<= 16)
   uint32_t desc_words;   // words the descriptors take inside the blob
-  uint32_t lo[kPlaneMaxBases][8], hi[kPlaneMaxBases][8];
+  uint32_t idx[kPlaneMaxBases][8];   // base b, compared byte i: its symbol code 0..3, or 4 for a byte beyond n_cmp (always fits)
 };
 constexpr uint32_t kCountMaxBlobWords = 6144;   // 24 KiB of descriptors + tables per workgroup
 void launch_plane_count_general(const PlaneCountGParams& g, int max_words, uint32_t max_short, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);

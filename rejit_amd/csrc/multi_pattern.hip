@@ -1001,11 +1001,8 @@ int run_counts(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint
       pg.lmax = m->count_lmax;
       pg.desc_words = m->count_desc_words;
       for (uint32_t b = 0; b < kPlaneMaxBases; b++)
-        for (int i = 0; i < 8; i++) {
-          const uint32_t code = (static_cast<uint32_t>(plan.base[b < plan.n_bases ? b : 0][i]) >> plan.code_shift) & 3u;
-          pg.lo[b][i] = (code & 1u) ? 0u : ~0u;
-          pg.hi[b][i] = (code & 2u) ? 0u : ~0u;
-        }
+        for (uint32_t i = 0; i < 8; i++)
+          pg.idx[b][i] = i < plan.n_cmp ? (static_cast<uint32_t>(plan.base[b < plan.n_bases ? b : 0][i]) >> plan.code_shift) & 3u : 4u;
     } else {
       for (uint32_t b = 0; b < 2; b++) {
         const uint32_t bb = b < plan.n_bases ? b : 0;

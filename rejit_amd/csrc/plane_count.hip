@@ -287,7 +287,14 @@ struct ExactShape {
   }
 };
 
-// the general test: bit 2k = byte k, bit 2k + 1 = byte 16 + k of the lane's 32 (plane_test's layout)
+// The general test: bit 2k = byte k, bit 2k + 1 = byte 16 + k of the lane's 32 (plane_test's layout).  Base after base in a
+// loop that is NOT unrolled (<= 12 bases), and per base what plane_test does for its two: "window byte i of the base fits at
+// position p" is ONE shifted code plane, picked by the VGPR index mode -- the four planes of the 32 positions sit in v48..v51,
+// an all-ones plane in v52 (a compared byte beyond the set's n_cmp: always fits), the same for the 32 positions that follow
+// in v56..v60, and `v_alignbit_b32 e, v56, v48, 2 i` under index idx[b][i] (0..3 the code, 4 don't care: a launch constant,
+// eight dwords per base from the kernel arguments) reads next[idx], here[idx].  8 picks + 4 three-input ANDs per base; the
+// first version of this function (two bit planes XORed with per-position masks, a scalar load + wait per mask pair) ran
+// general_one_pass' four bases at 0.55 of peak and nine 12-mers at 0.32.
 template <bool TOL>
 __device__ __forceinline__ uint32_t general_test(uint32_t ta, uint32_t tb, uint32_t hb, const PlaneCountGParams& g) {
   constexpr uint32_t kEven = 0x55555555u;
@@ -295,27 +302,63 @@ __device__ __forceinline__ uint32_t general_test(uint32_t ta, uint32_t tb, uint3
   const uint32_t H = ((ta >> 1) & kEven) | (tb & ~kEven);
   const uint32_t Ln = (tb & kEven) | ((hb << 1) & ~kEven);
   const uint32_t Hn = ((tb >> 1) & kEven) | (hb & ~kEven);
-  // the shifted planes of all compared offsets first (16 registers), then base after base in a loop that is NOT unrolled:
-  // one base's masks live in scalar registers at a time (kernel arguments: scalar-cache hits) -- plane_scan.hip:
-  // plane_candidates_general, in the 32-bytes-per-lane layout
-  uint32_t Ls[8], Hs[8];
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    Ls[i] = i ? __builtin_amdgcn_alignbit(Ln, L, 2 * i) : L;
-    Hs[i] = i ? __builtin_amdgcn_alignbit(Hn, H, 2 * i) : H;
-  }
+  register uint32_t q0 asm("v48") = ~(L | H);
+  register uint32_t q1 asm("v49") = L & ~H;
+  register uint32_t q2 asm("v50") = ~L & H;
+  register uint32_t q3 asm("v51") = L & H;
+  register uint32_t q4 asm("v52") = ~0u;
+  register uint32_t n0 asm("v56") = ~(Ln | Hn);
+  register uint32_t n1 asm("v57") = Ln & ~Hn;
+  register uint32_t n2 asm("v58") = ~Ln & Hn;
+  register uint32_t n3 asm("v59") = Ln & Hn;
+  register uint32_t n4 asm("v60") = ~0u;
   uint32_t c = 0;
 #pragma clang loop unroll(disable)
   for (uint32_t b = 0; b < g.c.n_bases; b++) {
-    uint32_t Z = ~0u, O = ~0u;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      if (static_cast<uint32_t>(i) >= g.n_cmp) break;  // (wave-uniform: windows shorter than 8 bytes)
-      const uint32_t E = (Ls[i] ^ g.lo[b][i]) & (Hs[i] ^ g.hi[b][i]);
-      if (TOL) O = i == 0 ? ~0u : (Z | (O & E));   // at most one code differs so far
-      Z &= E;                                        // none differs so far
+    const uint32_t* ix = g.idx[b];
+    uint32_t e0, e1, e2, e3, e4, e5, e6, e7;
+    asm volatile(
+        "s_set_gpr_idx_on %[i0], 0x3\n"
+        "v_mov_b32 %[e0], v48\n"
+        "s_set_gpr_idx_idx %[i1]\n"
+        "v_alignbit_b32 %[e1], v56, v48, 2\n"
+        "s_set_gpr_idx_idx %[i2]\n"
+        "v_alignbit_b32 %[e2], v56, v48, 4\n"
+        "s_set_gpr_idx_idx %[i3]\n"
+        "v_alignbit_b32 %[e3], v56, v48, 6\n"
+        "s_set_gpr_idx_idx %[i4]\n"
+        "v_alignbit_b32 %[e4], v56, v48, 8\n"
+        "s_set_gpr_idx_idx %[i5]\n"
+        "v_alignbit_b32 %[e5], v56, v48, 10\n"
+        "s_set_gpr_idx_idx %[i6]\n"
+        "v_alignbit_b32 %[e6], v56, v48, 12\n"
+        "s_set_gpr_idx_idx %[i7]\n"
+        "v_alignbit_b32 %[e7], v56, v48, 14\n"
+        "s_set_gpr_idx_off\n"
+        : [e0] "=&v"(e0), [e1] "=&v"(e1), [e2] "=&v"(e2), [e3] "=&v"(e3), [e4] "=&v"(e4), [e5] "=&v"(e5), [e6] "=&v"(e6), [e7] "=&v"(e7)
+        : [i0] "s"(ix[0]), [i1] "s"(ix[1]), [i2] "s"(ix[2]), [i3] "s"(ix[3]), [i4] "s"(ix[4]), [i5] "s"(ix[5]), [i6] "s"(ix[6]), [i7] "s"(ix[7]), "v"(q0), "v"(q1), "v"(q2),
+          "v"(q3), "v"(q4), "v"(n0), "v"(n1), "v"(n2), "v"(n3), "v"(n4)
+        : "m0");
+    if (TOL) {
+      // Z: no code differs so far; O: at most one does
+      uint32_t Z = e0, O = e0 | e1;
+      Z &= e1;
+      O = Z | (O & e2);
+      Z &= e2;
+      O = Z | (O & e3);
+      Z &= e3;
+      O = Z | (O & e4);
+      Z &= e4;
+      O = Z | (O & e5);
+      Z &= e5;
+      O = Z | (O & e6);
+      Z &= e6;
+      O = Z | (O & e7);
+      c |= O;
+    } else {
+      const uint32_t z0 = e0 & e1 & e2, z1 = e3 & e4 & e5;
+      c |= z0 & z1 & e6 & e7;
     }
-    c |= TOL ? O : Z;
   }
   return c;
 }
