@@ -1033,6 +1033,40 @@ def literal_and_complex_extras(args, c, out):
                                    "how": ghow, "counts": gcounts, "counts_equal_single_runs": gcounts == gsingle,
                                    "latency_ms": round(gmed * 1e3, 4), "value": round(n / gmed / 1e9, 1), "unit": "GB/s of text (once for both patterns)",
                                    "roofline": hbm_roofline("plane_scan_general<exact>", n, sum(gms) / len(gms), None, len(gms), ceiling=hbm_ceiling(t.data_ptr(), n, c.stream))}
+        # the same set as MatchAllCount in ONE kernel (round 6: plane_count<GeneralShape>, rj_multi_set_counts_only): the filter
+        # through code planes, every candidate classified by the patterns' automata out of LDS, nothing written but the counts;
+        # and nine random 12-mers (nine bases: the filter's cost grows with the bases)
+        import random as _r
+        r12 = _r.Random(3)
+        w12 = ["".join(r12.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(12)) for _ in range(9)]
+        for key, cset, plants in (("counts_general", gset, None), ("counts_nine_12mers", w12, [w.encode() for w in w12])):
+            if plants:
+                for k, o in enumerate(W.plant_offsets(n, 32, 450, seed=13)):
+                    W.plant(t, [o], plants[k % len(plants)])
+            cprogs = [rejit_amd.Program(rx) for rx in cset]
+            cm = rejit_amd.MultiScan(cprogs)
+            took = cm.set_counts_only(True)
+            ccounts = cm.run(t.data_ptr(), n, stream=c.stream)
+            chow = cm.how
+            lm = rejit_amd.MultiScan(cprogs)
+            lcounts = lm.run(t.data_ptr(), n, stream=c.stream)
+            same_bounds = cm.bounds() == lm.bounds()
+            del lm
+            settle_device(lambda: cm.run(t.data_ptr(), n, stream=c.stream), args.settle_ms)
+            cms, cwall = [], []
+            for _ in range(10):
+                t0g = time.perf_counter()
+                cm.run(t.data_ptr(), n, stream=c.stream)
+                cwall.append(time.perf_counter() - t0g)
+                cms.append(cm.scan_ms())
+            cmed = sorted(cwall)[len(cwall) // 2]
+            out[key] = {"workload": "MatchAllCount of %s over the same %d bytes in ONE kernel (%d base windows)" % (" + ".join(cset) if len(cset) < 4 else "nine random 12-mers", n, 4 if not plants else 9),
+                        "took_counts_path": bool(took), "how": chow, "counts": ccounts, "counts_equal_span_pipeline": ccounts == lcounts,
+                        "bounds_equal_span_pipeline": same_bounds,
+                        "latency_ms": round(cmed * 1e3, 4), "value": round(n / cmed / 1e9, 1), "unit": "GB/s of text (once for all patterns)",
+                        "roofline": hbm_roofline("plane_count<GeneralShape>", n, sum(cms) / len(cms), None, len(cms), ceiling=hbm_ceiling(t.data_ptr(), n, c.stream))}
+            assert ccounts == lcounts and same_bounds, (key, ccounts, lcounts)
+            del cm, cprogs
         del gmulti, gprogs
     except Exception as e:  # noqa: BLE001 (an extra must never cost the line)
         out["general_one_pass"] = {"error": repr(e)[:300]}
