@@ -129,6 +129,14 @@ void rj_host_free(void* p);
 int64_t rj_replace_all(const rj_program* prog, const char* text, size_t n, const char* with, size_t with_len, char** out,
                        size_t* out_len);
 void rj_free_text(char* text);
+/* The same in two steps, for a caller that owns the buffer the new text goes to (Regej::ReplaceAll rewrites its std::string:
+ * include/rejit.h; reference src/rejit.cc:220-226): _begin uploads, matches and replaces on the device and returns the number
+ * of matches (or rj_status) with the new text's length in *out_len; _fetch -- same thread, same program, once -- copies the
+ * new text into dst[0 .. out_len) (dst_cap >= out_len; no NUL is written).  dst may be the memory `text` pointed to: the
+ * device holds its own copy by then.  Measured on the GPU box (1 GB): malloc + download + free of the one-call form cost
+ * 50 + 80 ms, the download into pages the caller already owns 18 ms. */
+int64_t rj_replace_all_begin(const rj_program* prog, const char* text, size_t n, const char* with, size_t with_len, size_t* out_len);
+int rj_replace_all_fetch(const rj_program* prog, char* dst, size_t dst_cap);
 
 /* ---- device-resident text (what bench.py and the multi-GPU driver use; no copies).
  * d_text must be 16-byte aligned device memory with bytes [0, n) readable.  Matches whose

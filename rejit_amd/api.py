@@ -166,7 +166,7 @@ C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_er
                  "rj_multi_bounds", "rj_batch_separator", "rj_match_all_packed", "rj_host_alloc", "rj_host_free",
                  "rj_multi_bounds_device", "rj_carry_decide", "rj_multi_start", "rj_multi_finish", "rj_multi_order_after",
                  "rj_multi_device_counts", "rj_multi_device_counts_via", "rj_multi_set_tail_stream", "rj_multi_set_timing", "rj_scan_set_timing", "rj_set_default_timing",
-                 "rj_scan_gather_spans", "rj_scan_gather_spans_via", "rj_scan_gathered_spans", "rj_multi_set_counts_only", "rj_stream_read_probe", "rj_scan_stats_sized", "rj_scan_copy_gathered_spans", "rj_scan_count", "rj_host_stats"]
+                 "rj_scan_gather_spans", "rj_scan_gather_spans_via", "rj_scan_gathered_spans", "rj_multi_set_counts_only", "rj_stream_read_probe", "rj_scan_stats_sized", "rj_scan_copy_gathered_spans", "rj_scan_count", "rj_host_stats", "rj_replace_all_begin", "rj_replace_all_fetch"]
 
 
 def load_library():
@@ -249,6 +249,10 @@ def load_library():
     L.rj_scan_copy_spans.argtypes = [vp, _u64p, u64]
     L.rj_scan_stats.argtypes = [vp, ctypes.POINTER(_Stats)]
     L.rj_scan_match_full.argtypes = [vp, vp, u64, vp]
+    L.rj_replace_all_begin.restype = i64
+    L.rj_replace_all_begin.argtypes = [vp, cp, sz, cp, sz, ctypes.POINTER(sz)]
+    L.rj_replace_all_fetch.restype = ctypes.c_int
+    L.rj_replace_all_fetch.argtypes = [vp, vp, sz]
     L.rj_replace_all.restype = i64
     L.rj_replace_all.argtypes = [vp, cp, sz, cp, sz, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz)]
     L.rj_free_text.argtypes = [ctypes.c_void_p]
@@ -396,6 +400,16 @@ class Program:
         data = ctypes.string_at(out, out_len.value)
         self._lib.rj_free_text(out)
         return int(m), data
+
+    def replace_all_into(self, text: bytes, repl: bytes, dst: bytearray) -> Tuple[int, int]:
+        """rj_replace_all_begin + rj_replace_all_fetch: the new text into a buffer of the caller's (number of matches, new length)."""
+        out_len = ctypes.c_size_t()
+        m = _check(self._lib.rj_replace_all_begin(self._h, text, len(text), repl, len(repl), ctypes.byref(out_len)))
+        if out_len.value > len(dst):
+            raise RejitError(-4, "replace_all_into: the new text has %d bytes, the buffer %d" % (out_len.value, len(dst)))
+        buf = (ctypes.c_char * len(dst)).from_buffer(dst)
+        _check(self._lib.rj_replace_all_fetch(self._h, ctypes.addressof(buf), len(dst)))
+        return int(m), int(out_len.value)
 
     def match_first(self, text: bytes) -> Optional[Tuple[int, int]]:
         b, e = ctypes.c_uint64(), ctypes.c_uint64()

@@ -109,6 +109,8 @@ struct rj_scan {
   uint64_t xr_parts = 0, xr_rounds = 0;                     // of the last exact replay: parts of long segments, rounds beyond the first
   bool want_exact = false;         // the run just made may differ from the reference by the ring artefact (Q8)
   rejit_amd::DeviceBuffer with_buf, long_gaps, repl_out;  // replace_gather
+  uint64_t repl_len = 0;           // rj_replace_all_begin: the new text waits in repl_out for rj_replace_all_fetch
+  bool repl_valid = false;
   // carry scan (linear.hip): summaries (resolved in place), reachability matrices, E / G slabs,
   // entry points, per-sub-chunk counts, wide-automaton scratch
   rejit_amd::DeviceBuffer cs_vals, cs_mats, cs_e, cs_g, cs_entry, cs_counts, cs_scratch, cs_acc, cs_groups;

@@ -14,6 +14,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -102,6 +103,156 @@ hipError_t copy_result_pairs(rj_scan* s, uint64_t* dst, uint64_t first, uint64_t
   return e;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Large results on their way back to HOST memory (round 6).  A rejit.h caller's buffers are ordinary (pageable) memory
+// -- sample/regexdna.cc:41-47: a std::string of 500 MB that eleven ReplaceAll calls rewrite.  Measured on the GPU box
+// (tools/probes/repl_probe.py, 1 GB): the runtime uploads from pageable memory at the link's rate (56 GB/s), but a plain
+// download into freshly allocated pages takes 76-110 ms per GB (one thread faults the pages in) and free() of such a
+// buffer another 70-90 ms.  So (a) the download is the library's own: a ring of pinned slices per calling thread, the DMA
+// of slice k + 1 running while a few worker threads copy slice k into the caller's memory side by side (the box has 256
+// host threads); (b) rj_replace_all_begin / _fetch let the caller take the new text into a buffer it already owns
+// (Regej::ReplaceAll: the string itself -- no allocation, no free, pages already there).
+constexpr size_t kStageSlice = 16u << 20;      // bytes per pinned slice
+constexpr int kStageSlots = 6;                 // slices in the ring (96 MiB of pinned memory per calling thread that moves large buffers)
+constexpr size_t kStageMin = 32u << 20;        // buffers below this take the plain copy
+
+// a few persistent workers: run(parts, fn) executes fn(0) .. fn(parts - 1) on them and on the caller
+class CopyPool {
+ public:
+  static CopyPool& get() {
+    static CopyPool* pool = new CopyPool;   // (never destroyed: worker threads at process exit)
+    return *pool;
+  }
+  unsigned width() const { return n_workers_ + 1; }
+  void run(unsigned parts, const std::function<void(unsigned)>& fn) {
+    if (parts <= 1 || n_workers_ == 0) {
+      for (unsigned i = 0; i < parts; i++) fn(i);
+      return;
+    }
+    std::unique_lock<std::mutex> lk(mu_);   // (one parallel section at a time: concurrent callers take turns)
+    busy_.wait(lk, [&] { return !running_; });
+    running_ = true;
+    fn_ = &fn;
+    parts_ = parts;
+    next_ = 1;           // part 0 is the caller's
+    left_ = parts - 1;
+    generation_++;
+    lk.unlock();
+    work_.notify_all();
+    fn(0);
+    lk.lock();
+    // (the caller helps with what the workers have not picked up yet)
+    while (next_ < parts_) {
+      const unsigned part = next_++;
+      lk.unlock();
+      fn(part);
+      lk.lock();
+      --left_;
+    }
+    done_.wait(lk, [&] { return left_ == 0; });
+    running_ = false;
+    lk.unlock();
+    busy_.notify_one();
+  }
+  void parallel_copy(char* dst, const char* src, size_t bytes) {
+    const unsigned parts = static_cast<unsigned>(std::min<size_t>(width(), std::max<size_t>(bytes >> 20, 1)));
+    const size_t per = ((bytes + parts - 1) / parts + 4095) & ~static_cast<size_t>(4095);
+    run(parts, [&](unsigned part) {
+      const size_t lo = std::min(bytes, per * part), hi = std::min(bytes, lo + per);
+      if (hi > lo) memcpy(dst + lo, src + lo, hi - lo);
+    });
+  }
+
+ private:
+  CopyPool() {
+    static const int env = getenv("RJ_COPY_THREADS") ? atoi(getenv("RJ_COPY_THREADS")) : 0;  // measurement override
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned n = env > 0 ? static_cast<unsigned>(env) : std::min(24u, std::max(3u, hw / 8));
+    n_workers_ = n - 1;
+    for (unsigned i = 0; i < n_workers_; i++) std::thread([this] { worker(); }).detach();
+  }
+  void worker() {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      work_.wait(lk, [&] { return generation_ != seen && next_ < parts_; });
+      while (next_ < parts_) {
+        const unsigned part = next_++;
+        const std::function<void(unsigned)>* fn = fn_;
+        lk.unlock();
+        (*fn)(part);
+        lk.lock();
+        if (--left_ == 0) done_.notify_all();
+      }
+      seen = generation_;
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable work_, done_, busy_;
+  unsigned n_workers_ = 0;
+  bool running_ = false;
+  const std::function<void(unsigned)>* fn_ = nullptr;
+  unsigned parts_ = 0, next_ = 0, left_ = 0;
+  uint64_t generation_ = 0;
+};
+
+// the calling thread's ring of pinned slices (allocated at its first large copy, per device context the memory is
+// visible to all devices: hipHostMalloc's default is portable enough for the one-process-many-devices paths here)
+struct StageRing {
+  char* base = nullptr;
+  hipEvent_t ev[kStageSlots] = {};
+  bool ok = false;
+  ~StageRing() {
+    if (base) (void)hipHostFree(base);
+    for (auto& e : ev)
+      if (e) (void)hipEventDestroy(e);
+  }
+  bool ready() {
+    if (ok) return true;
+    if (base) return false;   // (a failed attempt is not repeated)
+    if (hipHostMalloc(reinterpret_cast<void**>(&base), kStageSlice * kStageSlots, hipHostMallocPortable) != hipSuccess) {
+      base = reinterpret_cast<char*>(1);
+      (void)hipGetLastError();
+      return false;
+    }
+    for (auto& e : ev)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+    ok = true;
+    return true;
+  }
+};
+thread_local StageRing g_stage;
+
+// device -> host, complete on return
+int staged_download(char* dst, const void* d_src, size_t n, hipStream_t st) {
+  static const bool off = getenv("RJ_NO_STAGED_COPY") != nullptr;  // measurement override
+  if (n < kStageMin || off || !g_stage.ready()) {
+    if (n) RJ_HIP(hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, st));
+    RJ_HIP(hipStreamSynchronize(st));
+    return RJ_OK;
+  }
+  CopyPool& pool = CopyPool::get();
+  const size_t slices = (n + kStageSlice - 1) / kStageSlice;
+  // DMAs run kStageSlots - 1 slices ahead of the host copies that empty the ring
+  auto queue = [&](size_t k) -> hipError_t {
+    const size_t lo = k * kStageSlice, len = std::min(kStageSlice, n - lo);
+    const int slot = static_cast<int>(k % kStageSlots);
+    hipError_t e = hipMemcpyAsync(g_stage.base + static_cast<size_t>(slot) * kStageSlice, static_cast<const char*>(d_src) + lo, len, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipEventRecord(g_stage.ev[slot], st);
+    return e;
+  };
+  size_t queued = 0;
+  for (; queued < slices && queued + 1 < static_cast<size_t>(kStageSlots); queued++) RJ_HIP(queue(queued));
+  for (size_t k = 0; k < slices; k++) {
+    const size_t lo = k * kStageSlice, len = std::min(kStageSlice, n - lo);
+    const int slot = static_cast<int>(k % kStageSlots);
+    RJ_HIP(hipEventSynchronize(g_stage.ev[slot]));
+    if (queued < slices) RJ_HIP(queue(queued++));   // (its slot is the one emptied LAST round: kStageSlots - 1 in flight)
+    pool.parallel_copy(dst + lo, g_stage.base + static_cast<size_t>(slot) * kStageSlice, len);
+  }
+  return RJ_OK;
+}
+
 int stage_text(rj_scan* s, const char* text, size_t n, const uint8_t** d_text) {
   static const bool no_small = getenv("RJ_NO_SMALL") != nullptr;
   const DevProgram& D = s->prog->dev;
@@ -116,6 +267,8 @@ int stage_text(rj_scan* s, const char* text, size_t n, const uint8_t** d_text) {
     return RJ_OK;
   }
   RJ_HIP(s->text.reserve(((n + 64 + 4095) / 4096) * 4096));
+  // (measured, round 6: the runtime's own pageable upload runs at the link's rate -- 56 GB/s for 2 GB; a pinned ring filled by
+  // 24 threads was no faster.  The way BACK is where the library's own staging pays: staged_download)
   if (n) RJ_HIP(hipMemcpyAsync(s->text.p, text, n, hipMemcpyHostToDevice, s->own_stream));
   *d_text = s->text.as<uint8_t>();
   return RJ_OK;
@@ -147,15 +300,16 @@ void rejit_amd::forget_host_scans(uint64_t program_id) {
 
 extern "C" {
 
-int64_t rj_replace_all(const rj_program* prog, const char* text, size_t n, const char* with, size_t with_len, char** out,
-                       size_t* out_len) {
+int64_t rj_replace_all_begin(const rj_program* prog, const char* text, size_t n, const char* with, size_t with_len, size_t* out_len) {
   ErrnoGuard errno_guard;
-  if (!prog || (!text && n) || !out || !out_len) return fail(RJ_BAD_ARGUMENT, "null argument");
-  *out = nullptr;
+  if (!prog || (!text && n) || !out_len) return fail(RJ_BAD_ARGUMENT, "null argument");
   *out_len = 0;
+  DeviceGuard on_device(prog->device);
   rj_scan* s = nullptr;
   int rc = host_scan_for(prog, &s);
   if (rc != RJ_OK) return rc;
+  s->repl_len = 0;
+  s->repl_valid = false;
   const uint8_t* d_text = nullptr;
   rc = stage_text(s, text, n, &d_text);
   if (rc != RJ_OK) return rc;
@@ -167,20 +321,45 @@ int64_t rj_replace_all(const rj_program* prog, const char* text, size_t n, const
   RJ_HIP(s->repl_out.reserve(cap));
   int64_t new_len = rj_scan_replace(s, d_text, n, with, with_len, s->repl_out.p, cap, s->own_stream);
   if (new_len < 0) return new_len;
-  char* h = static_cast<char*>(malloc(static_cast<size_t>(new_len) + 1));
+  s->repl_len = static_cast<uint64_t>(new_len);
+  s->repl_valid = true;
+  *out_len = static_cast<size_t>(new_len);
+  return static_cast<int64_t>(m);
+}
+
+int rj_replace_all_fetch(const rj_program* prog, char* dst, size_t dst_cap) {
+  ErrnoGuard errno_guard;
+  if (!prog || (!dst && dst_cap)) return fail(RJ_BAD_ARGUMENT, "null argument");
+  DeviceGuard on_device(prog->device);
+  rj_scan* s = nullptr;
+  for (auto& p : g_host_scans.v)
+    if (p.first == prog->id) s = p.second;
+  if (!s || !s->repl_valid) return fail(RJ_BAD_ARGUMENT, "rj_replace_all_fetch without rj_replace_all_begin on this thread");
+  if (dst_cap < s->repl_len) return fail(RJ_BAD_ARGUMENT, "rj_replace_all_fetch: the new text has %llu bytes", static_cast<unsigned long long>(s->repl_len));
+  s->repl_valid = false;
+  return staged_download(dst, s->repl_out.p, static_cast<size_t>(s->repl_len), s->own_stream);
+}
+
+int64_t rj_replace_all(const rj_program* prog, const char* text, size_t n, const char* with, size_t with_len, char** out,
+                       size_t* out_len) {
+  ErrnoGuard errno_guard;
+  if (!prog || (!text && n) || !out || !out_len) return fail(RJ_BAD_ARGUMENT, "null argument");
+  *out = nullptr;
+  *out_len = 0;
+  size_t new_len = 0;
+  const int64_t m = rj_replace_all_begin(prog, text, n, with, with_len, &new_len);
+  if (m < 0) return m;
+  char* h = static_cast<char*>(malloc(new_len + 1));
   if (!h) return fail(RJ_DEVICE_ERROR, "out of host memory");
-  if (new_len) {
-    hipError_t e = hipMemcpyAsync(h, s->repl_out.p, static_cast<size_t>(new_len), hipMemcpyDeviceToHost, s->own_stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(s->own_stream);
-    if (e != hipSuccess) {
-      free(h);
-      return fail(RJ_DEVICE_ERROR, "hipMemcpy failed: %s", hipGetErrorString(e));
-    }
+  int rc = rj_replace_all_fetch(prog, h, new_len);
+  if (rc != RJ_OK) {
+    free(h);
+    return rc;
   }
   h[new_len] = 0;
   *out = h;
-  *out_len = static_cast<size_t>(new_len);
-  return static_cast<int64_t>(m);
+  *out_len = new_len;
+  return m;
 }
 
 }  // extern "C"
@@ -555,14 +734,15 @@ int64_t rejit_amd::rj_match_all_batch_one_device(const rj_program* prog, const c
     // Packing is a host memcpy of the whole batch (one core moves ~10 GB/s, PCIe takes 50+): it is
     // spread over a few threads and done slice by slice, each slice's DMA starting as soon as it is
     // packed, so packing slice k+1 overlaps the upload of slice k.
-    const unsigned n_thr = total_bytes > (8u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    CopyPool& pool = CopyPool::get();
+    const unsigned n_thr = total_bytes > (8u << 20) ? pool.width() : 1u;
     auto pack = [&](size_t first, size_t last) {
       for (size_t i = first; i < last; i++) {
         if (sizes[i]) memcpy(s->pinned + off[i], texts[i], sizes[i]);
         s->pinned[off[i] + sizes[i]] = sep;
       }
     };
-    constexpr uint64_t kSlice = 64ull << 20;
+    constexpr uint64_t kSlice = 32ull << 20;
     size_t first = 0;
     while (first < n_texts) {
       // texts [first, last) make up about one slice
@@ -572,17 +752,16 @@ int64_t rejit_amd::rj_match_all_batch_one_device(const rj_program* prog, const c
       if (n_thr == 1 || hi - lo < (8u << 20)) {
         pack(first, last);
       } else {
-        std::vector<std::thread> pool;
+        // the slice's texts dealt out by bytes (persistent workers: round 5 started eight threads per slice)
+        std::vector<size_t> cut(n_thr + 1, last);
+        cut[0] = first;
         size_t f = first;
-        for (unsigned t = 0; t < n_thr; t++) {
+        for (unsigned t = 0; t + 1 < n_thr; t++) {
           const uint64_t upto = lo + (hi - lo) * (t + 1) / n_thr;
-          size_t l = f;
-          while (l < last && off[l] < upto) l++;
-          if (t + 1 == n_thr) l = last;
-          pool.emplace_back(pack, f, l);
-          f = l;
+          while (f < last && off[f] < upto) f++;
+          cut[t + 1] = f;
         }
-        for (auto& th : pool) th.join();
+        pool.run(n_thr, [&](unsigned t) { pack(cut[t], cut[t + 1]); });
       }
       RJ_HIP(hipMemcpyAsync(static_cast<char*>(s->text.p) + lo, s->pinned + lo, hi - lo, hipMemcpyHostToDevice, s->own_stream));
       first = last;

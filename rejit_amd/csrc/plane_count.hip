@@ -763,15 +763,17 @@ __global__ __launch_bounds__(256) void plane_count(typename S::Args g) {
 // last row with a count; the group's sums go to acc, a ticket (eight arrivals: the cost of an atomic with return does not
 // matter here) finds the last group, which adds them up and reads, in one more trip, the first match of every pattern's
 // first row with a count and the last match of its last one.
-constexpr uint32_t kFinishBatch = 14;
-__global__ __launch_bounds__(256) void plane_count_finish(PlaneCountParams a, uint32_t n_wg) {
+// (<= 64 VGPRs -- __launch_bounds__(256, 8), eight loads in flight instead of fourteen, the reduce loops not unrolled: a workgroup of this kernel starts under a
+// running scan as soon as ONE scan wave per SIMD has retired; with its 132 VGPRs of round 6's first version it waited for three)
+constexpr uint32_t kFinishBatch = 8;
+__global__ __launch_bounds__(256, 8) void plane_count_finish(PlaneCountParams a, uint32_t n_wg) {
   __shared__ unsigned long long part[32][kExactMaxPatterns];
   __shared__ uint32_t part_first[32][kExactMaxPatterns], part_last[32][kExactMaxPatterns];   // row + 1; 0: none
   __shared__ uint32_t is_last;
   const uint32_t p4 = threadIdx.x & 7u, q = threadIdx.x >> 3;
   const uint32_t per = (n_wg + gridDim.x - 1) / gridDim.x;
   const uint32_t r_lo = blockIdx.x * per, r_hi = r_lo + per < n_wg ? r_lo + per : n_wg;
-  unsigned long long sum[4] = {0, 0, 0, 0};
+  uint32_t sum[4] = {0, 0, 0, 0};   // (a thread adds <= n_wg / 256 rows of <= 163 840 matches each: 32 bits)
   uint32_t first_row[4] = {0, 0, 0, 0}, last_row[4] = {0, 0, 0, 0};
   const uint4* rows = reinterpret_cast<const uint4*>(a.wg_rows);
   for (uint32_t r = r_lo + q; r < r_hi; r += 32 * kFinishBatch) {
@@ -809,6 +811,7 @@ __global__ __launch_bounds__(256) void plane_count_finish(PlaneCountParams a, ui
     if (lane < kExactMaxPatterns) {
       unsigned long long t = 0;
       uint32_t f = 0, l = 0;
+#pragma unroll 4
       for (uint32_t i = 0; i < 32; i++) {
         t = lane == kExactMaxPatterns - 1 ? (t | part[i][lane]) : (t + part[i][lane]);
         const uint32_t pf = part_first[i][lane], pl = part_last[i][lane];
@@ -833,6 +836,7 @@ __global__ __launch_bounds__(256) void plane_count_finish(PlaneCountParams a, ui
   const uint32_t p = threadIdx.x;
   unsigned long long total = 0;
   uint32_t f = 0, l = 0;
+#pragma unroll 2
   for (uint32_t g = 0; g < gridDim.x; g++) {
     const unsigned long long* row = a.acc + kPcGroupRows + g * 96;
     const unsigned long long v = __hip_atomic_load(&row[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -660,6 +660,40 @@ def test_replace_all_vs_oracle(rj, oracle):
     assert len(text) == g["replaced_size"] and hashlib.sha256(text).hexdigest() == g["replaced_sha256"]
 
 
+def test_replace_all_in_two_steps_and_large(rj, oracle):
+    """rj_replace_all_begin / _fetch (round 6: Regej::ReplaceAll takes the new text straight into its own string) and the
+    library's own staging of large downloads (host_api.hip: staged_download, >= 32 MiB): the same bytes as rj_replace_all and
+    as the reference's Replace on the oracle's matches; growing, shrinking and unchanged texts; a buffer that is too small is
+    refused and a fetch without begin too."""
+    from rejit_amd import workloads as W
+    rng = random.Random(19)
+    for rx, repl in [(b"regexp", b"<<literal>>"), (b"\n", b""), (b"[0-9]+", b"#"), (b"zzzz", b"never")]:
+        text = bytes(rng.choice(b"ab\nx>1regexp z0") for _ in range(150000))
+        want = _splice(text, oracle.match_all(rx, text), repl)
+        p = prog(rj, rx)
+        dst = bytearray(len(want) + 100)
+        m, new_len = p.replace_all_into(text, repl, dst)
+        assert new_len == len(want) and bytes(dst[:new_len]) == want and m == len(oracle.match_all(rx, text)), rx
+        with pytest.raises(rj.RejitError):
+            p.replace_all_into(text, repl, bytearray(max(len(want) - 1, 0)))
+    lib = rj.load_library()
+    assert lib.rj_replace_all_fetch(prog(rj, b"never begun")._h, None, 0) < 0
+    # 100 MB: four slices of the pinned ring each way round, matches across slice boundaries
+    n = 100_000_000
+    big = W.random_ascii_numpy(n, 9)
+    offs = W.plant_offsets(n, 6, 2000, seed=9, boundaries=[16 << 20, 32 << 20, 48 << 20, (16 << 20) * 5])
+    W.plant(big, offs, b"regexp")
+    tb = big.tobytes()
+    want = tb.replace(b"regexp", b"<<regular expression>>")
+    m, got = prog(rj, b"regexp").replace_all(tb, b"<<regular expression>>")
+    assert m == tb.count(b"regexp") and got == want
+    dst = bytearray(len(want))
+    m2, new_len = prog(rj, b"regexp").replace_all_into(tb, b"<<regular expression>>", dst)
+    assert (m2, new_len) == (m, len(want)) and bytes(dst) == want
+    m3, shrunk = prog(rj, b"regexp").replace_all(tb, b"")
+    assert m3 == m and shrunk == tb.replace(b"regexp", b"")
+
+
 def test_device_replace_keeps_text_in_hbm(rj):
     import torch
     from rejit_amd import workloads as W
