@@ -5,6 +5,7 @@
 // texts read in place from pinned memory, large ones copied; then run_pipeline (engine.hip).
 
 #include <cstring>
+#include <emmintrin.h>
 
 #include <hip/hip_runtime.h>
 
@@ -29,6 +30,13 @@ using namespace rejit_amd;
 #define fail ::rejit_amd::rj_fail
 
 namespace {
+
+// RJ_TRACE_HOST=1: the phases of the host-text batch calls on stderr (packing, upload, device pipeline, results)
+bool trace_host() {
+  static const bool on = getenv("RJ_TRACE_HOST") != nullptr;
+  return on;
+}
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // one scratch per (thread, program) for the host-text entry points
 struct HostScans {
@@ -115,6 +123,34 @@ hipError_t copy_result_pairs(rj_scan* s, uint64_t* dst, uint64_t first, uint64_t
 constexpr size_t kStageSlice = 16u << 20;      // bytes per pinned slice
 constexpr int kStageSlots = 6;                 // slices in the ring (96 MiB of pinned memory per calling thread that moves large buffers)
 constexpr size_t kStageMin = 32u << 20;        // buffers below this take the plain copy
+
+// memcpy into a staging buffer nobody reads on this side: non-temporal stores (no read-for-ownership of the destination
+// lines, nothing of the destination left in the caches); SSE2, the x86-64 baseline
+inline void stream_copy(char* dst, const char* src, size_t n) {
+  static const bool off = getenv("RJ_NO_STREAM_COPY") != nullptr;  // measurement override
+  if (n < 4096 || off) {
+    memcpy(dst, src, n);
+    return;
+  }
+  const size_t head = (16 - (reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u;
+  if (head) memcpy(dst, src, head);
+  dst += head;
+  src += head;
+  n -= head;
+  const size_t blocks = n / 64;
+  for (size_t i = 0; i < blocks; i++) {
+    const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src) + 0), b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src) + 1);
+    const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src) + 2), d = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src) + 3);
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst) + 0, a);
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst) + 1, b);
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst) + 2, c);
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst) + 3, d);
+    src += 64;
+    dst += 64;
+  }
+  _mm_sfence();
+  if (n & 63) memcpy(dst, src, n & 63);
+}
 
 // a few persistent workers: run(parts, fn) executes fn(0) .. fn(parts - 1) on them and on the caller
 class CopyPool {
@@ -407,11 +443,18 @@ namespace {
 int64_t finish_packed(rj_scan* s, const uint64_t* off, const size_t* sizes, size_t n_texts, uint64_t total_bytes, uint64_t* counts,
                       uint64_t** spans) {
   const uint64_t n = total_bytes - 1;  // the last separator is the end of the buffer
+  const double t0 = trace_host() ? now_ms() : 0;
+  if (trace_host()) (void)hipStreamSynchronize(s->own_stream);
+  const double t1 = trace_host() ? now_ms() : 0;
   int rc = run_pipeline(s, s->text.as<uint8_t>(), n, 0, n + 1, 0, 0, 0, s->own_stream);
   if (rc != RJ_OK) return rc;
+  const double t2 = trace_host() ? now_ms() : 0;
   const uint64_t m = s->result_count;
   std::vector<uint64_t> pairs(2 * m);
   if (m) RJ_HIP(copy_result_pairs(s, pairs.data(), 0, m, s->own_stream));
+  if (trace_host())
+    fprintf(stderr, "rejit batch: %zu texts, %llu bytes: uploads still running %.3f ms, pipeline %.3f ms, %llu pairs back %.3f ms\n", n_texts,
+            static_cast<unsigned long long>(total_bytes), t1 - t0, t2 - t1, static_cast<unsigned long long>(m), now_ms() - t2);
   // the matches are ordered by begin: one merge pass assigns them to their texts
   for (size_t i = 0; i < n_texts; i++) counts[i] = 0;
   size_t t = 0;
@@ -730,42 +773,55 @@ int64_t rejit_amd::rj_match_all_batch_one_device(const rj_program* prog, const c
   }
   const char sep = static_cast<char>(prog->batch_separator);
   RJ_HIP(s->text.reserve(((total_bytes + 64 + 4095) / 4096) * 4096));
+  const double t_pack = trace_host() ? now_ms() : 0;
   {
     // Packing is a host memcpy of the whole batch (one core moves ~10 GB/s, PCIe takes 50+): it is
     // spread over a few threads and done slice by slice, each slice's DMA starting as soon as it is
     // packed, so packing slice k+1 overlaps the upload of slice k.
     CopyPool& pool = CopyPool::get();
     const unsigned n_thr = total_bytes > (8u << 20) ? pool.width() : 1u;
-    auto pack = [&](size_t first, size_t last) {
-      for (size_t i = first; i < last; i++) {
-        if (sizes[i]) memcpy(s->pinned + off[i], texts[i], sizes[i]);
-        s->pinned[off[i] + sizes[i]] = sep;
+    // bytes [a, b) of the packed buffer: the pieces of the texts that lie there, and the separators.  The work is dealt out
+    // by BYTES, not by texts: a tree's sizes have a heavy tail (bench.py's: log-normal, sigma 1.8), and a 20 MiB file copied
+    // by one thread held a whole 32 MiB slice up (round 6, RJ_TRACE_HOST: 7.5 ms to pack 256 MiB whatever the thread count).
+    auto pack_bytes = [&](uint64_t a, uint64_t b) {
+      size_t i = static_cast<size_t>(std::upper_bound(off.begin(), off.begin() + static_cast<long>(n_texts), a) - off.begin());
+      i = i > 0 ? i - 1 : 0;   // the text that holds byte a (or its separator)
+      for (; i < n_texts && off[i] < b; i++) {
+        const uint64_t t_lo = off[i], t_hi = off[i] + sizes[i];   // text bytes [t_lo, t_hi), separator at t_hi
+        const uint64_t lo = std::max(a, t_lo), hi = std::min(b, t_hi);
+        if (hi > lo) stream_copy(s->pinned + lo, texts[i] + (lo - t_lo), hi - lo);
+        if (t_hi >= a && t_hi < b) s->pinned[t_hi] = sep;
       }
     };
-    constexpr uint64_t kSlice = 32ull << 20;
+    static const uint64_t kSlice = (getenv("RJ_BATCH_SLICE_MB") ? static_cast<uint64_t>(atoi(getenv("RJ_BATCH_SLICE_MB"))) : 16ull) << 20;  // measurement override (jrep_10gb: 4 MiB 37.4, 8 38.7, 16 38.9, 32 35.5, 64 34.7 GB/s end to end)
     size_t first = 0;
+    double t_copy = 0, t_queue = 0;
     while (first < n_texts) {
       // texts [first, last) make up about one slice
       size_t last = first;
       while (last < n_texts && off[last] - off[first] < kSlice) last++;
       const uint64_t lo = off[first], hi = off[last];
-      if (n_thr == 1 || hi - lo < (8u << 20)) {
-        pack(first, last);
+      const double tp0 = trace_host() ? now_ms() : 0;
+      if (n_thr == 1 || hi - lo < (4u << 20)) {
+        pack_bytes(lo, hi);
       } else {
-        // the slice's texts dealt out by bytes (persistent workers: round 5 started eight threads per slice)
-        std::vector<size_t> cut(n_thr + 1, last);
-        cut[0] = first;
-        size_t f = first;
-        for (unsigned t = 0; t + 1 < n_thr; t++) {
-          const uint64_t upto = lo + (hi - lo) * (t + 1) / n_thr;
-          while (f < last && off[f] < upto) f++;
-          cut[t + 1] = f;
-        }
-        pool.run(n_thr, [&](unsigned t) { pack(cut[t], cut[t + 1]); });
+        const uint64_t per = ((hi - lo + n_thr - 1) / n_thr + 63) & ~63ull;
+        pool.run(n_thr, [&](unsigned t) {
+          const uint64_t a = std::min(hi, lo + per * t), b = std::min(hi, a + per);
+          if (b > a) pack_bytes(a, b);
+        });
       }
+      const double tp1 = trace_host() ? now_ms() : 0;
       RJ_HIP(hipMemcpyAsync(static_cast<char*>(s->text.p) + lo, s->pinned + lo, hi - lo, hipMemcpyHostToDevice, s->own_stream));
+      if (trace_host()) {
+        t_copy += tp1 - tp0;
+        t_queue += now_ms() - tp1;
+      }
       first = last;
     }
+    if (trace_host())
+      fprintf(stderr, "rejit batch: packed + queued %llu bytes in %.3f ms (host copies %.3f ms on %u threads, hipMemcpyAsync calls %.3f ms)\n",
+              static_cast<unsigned long long>(total_bytes), now_ms() - t_pack, t_copy, n_thr, t_queue);
   }
   return finish_packed(s, off.data(), sizes, n_texts, total_bytes, counts, spans);
 }
