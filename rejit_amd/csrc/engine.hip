@@ -200,6 +200,7 @@ int upload_program(rj_program* rp) {
   // another one ends" that sends a text to the exact replay is made on the candidates)
   D.loop_first = run_start_rule(P) && !P.q8_risk && getenv("RJ_NO_LOOP_FIRST") == nullptr ? 1u : 0u;  // (env: measurement override)
   rp->stream = getenv("RJ_NO_STREAMS") == nullptr ? make_stream_plan(P, D.loop_first != 0, P.q8_risk) : StreamPlan{};  // (env: measurement override)
+  rp->run = getenv("RJ_NO_RUNS") == nullptr ? make_run_plan(P) : RunPlan{};   // (env: measurement override)
   D.float_range = P.floating ? P.float_max - P.float_min + 1 : 1;
   D.float_max = P.floating ? P.float_max : 0;
   for (int k = 0; k < 8; k++) D.first_bytes[k] = P.first_bytes.w[k];
@@ -540,6 +541,70 @@ static int run_streams(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t s
   return 0;
 }
 
+// Patterns with one long-lived thread in one loop position (run_scan.h: `X+`, `A L*`, `A L* B`, `X+ B`): two passes over
+// the text from the tile of sb to its END (the segment that holds the range's last start closes at the first break behind
+// it, wherever that is) and a scan over tile summaries; linear in the text whatever the length of the runs.  1 = done
+// (s->out, s->result_count), 0 = not this path, < 0 = error.
+static int run_runs(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, uint64_t carry_cur, uint64_t carry_prev_end, int have_prev,
+                    hipStream_t st) {
+  const rj_program* rp = s->prog;
+  if (!rp->run.ok || se <= sb) return 0;
+  RunParams a{};
+  a.text = d_text;
+  a.n = n;
+  a.sb = sb;
+  a.se = std::min<uint64_t>(se, n);   // (a match consumes at least one byte: none begins at n)
+  a.min_start = std::max<uint64_t>(sb, have_prev ? carry_cur : 0);
+  a.plan = rp->run;
+  if (have_prev && rp->run.has_b && carry_prev_end >= 1 && carry_prev_end <= n) {
+    // the carried-in match ended behind its B at carry_prev_end - 1: when that byte is no break, the segment goes on and has
+    // had its match (run_scan.h)
+    uint8_t last = 0;
+    RJ_HIP(hipMemcpyAsync(&last, d_text + carry_prev_end - 1, 1, hipMemcpyDeviceToHost, st));
+    RJ_HIP(hipStreamSynchronize(st));
+    const Program& P = *rp->host;
+    const int l_pos = P.n_pos == 3 ? 1 : 0;
+    a.blocked_in = ((P.cls[last] >> l_pos) & 1u) ? 1u : 0u;
+  }
+  a.n_tiles = run_tiles(a.min_start, n, &a.first_tile);
+  RJ_HIP(s->run_summaries.reserve(sizeof(RunSummary) * a.n_tiles));
+  RJ_HIP(s->run_tile_in.reserve(sizeof(RunTileIn) * a.n_tiles));
+  a.summaries = s->run_summaries.as<RunSummary>();
+  a.tile_in = s->run_tile_in.as<RunTileIn>();
+  a.counters = s->counters.as<unsigned long long>();
+  a.host_counters = s->host_counters;
+  a.out = s->out.as<uint64_t>();
+  a.out_cap = s->out_cap;
+  RJ_HIP(hipMemsetAsync(s->counters.p, 0, kCntSize * sizeof(unsigned long long), st));
+  s->host_counters[kCntFinal] = 0;
+  launch_run_summary(a, s->t0(), nullptr, st);
+  launch_run_resolve(a, st);
+  RJ_HIP(hipStreamSynchronize(st));   // (the number of pairs sizes the output)
+  RJ_HIP(hipGetLastError());
+  const uint64_t cnt = s->host_counters[kCntFinal];
+  if (cnt > s->out_cap) {
+    const uint64_t cap = cnt + cnt / 16 + 1024;
+    RJ_HIP(s->out.reserve(cap * 2 * sizeof(uint64_t)));
+    s->out_cap = cap;
+  }
+  a.out = s->out.as<uint64_t>();
+  a.out_cap = s->out_cap;
+  if (cnt) launch_run_emit(a, s->ev[2], st);
+  else RJ_HIP(hipEventRecord(s->ev[2], st));
+  RJ_HIP(hipStreamSynchronize(st));
+  RJ_HIP(hipGetLastError());
+  float ms = 0.f;
+  if (s->timing) (void)hipEventElapsedTime(&ms, s->ev[1], s->ev[2]);
+  s->stats.scan_ms += ms;   // (first pass's start to the second pass's end, the scan between them included)
+  s->result_count = cnt;
+  s->result = s->out.as<uint64_t>();
+  s->hits_hint = cnt;
+  s->stats.n_hits += cnt;
+  s->stats.n_candidates += cnt;
+  s->stats.run_path = 1;
+  return 1;
+}
+
 constexpr uint64_t kExactLimit = 1u << 20;  // bytes the one-lane exact kernel is allowed to walk
 constexpr uint64_t kDenseSegment = 1ull << 27;  // dense mode: starts per pipeline run (bounds the lists)
 
@@ -567,12 +632,28 @@ static int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb,
   s->result = nullptr;
   // the previous text needed the linear-time path: go there directly (run_linear clears the hint
   // when the text turns out not to need it)
+  // one long-lived thread in one loop position (run_scan.h): the text's bit streams answer, whatever the runs' length --
+  // after dense_streams (faster where the runs are short) has given such a text up, or at once for the patterns that
+  // kernel does not take (`a.*b`) and for runs under a carry
+  static const bool runs_first = getenv("RJ_RUNS_FIRST") != nullptr;   // measurement override
+  const bool fresh = carry_cur == 0 && !have_prev;
+  // (a pattern with a fast-forward window -- `a.*b`, `<[^>]*>`: the window is their first byte -- goes there only once a walk
+  // has outlived max_walk on this scan's text: linear_hint.  NOTE: the hint is cleared by nobody on this path; a scan object
+  // whose texts stop having long runs keeps the run kernels, which are never wrong and never quadratic.)
+  if (rp->run.ok && (runs_first || s->linear_hint || (!windows && (!fresh || rp->stream.n_pos == 0 || s->streams_off)))) {
+    int rc = run_runs(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
+    if (rc != 0) return rc < 0 ? rc : RJ_OK;
+  }
   if (s->linear_hint && linear_path_fits(rp)) return run_linear(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
-  if (!windows && carry_cur == 0 && !have_prev) {
+  if (!windows && fresh) {
     int rc = run_assertions(s, d_text, n, sb, se, st);
     if (rc != 0) return rc < 0 ? rc : RJ_OK;
     rc = run_streams(s, d_text, n, sb, se, st);
     if (rc != 0) return rc < 0 ? rc : RJ_OK;
+    if (rp->run.ok && s->streams_off) {   // (dense_streams has just given this text up: long runs)
+      rc = run_runs(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
+      if (rc != 0) return rc < 0 ? rc : RJ_OK;
+    }
   }
 
   // what the scan kernel walks, in 1-KiB chunks
@@ -816,6 +897,10 @@ static int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb,
       // whatever the pattern, like the reference's loop (codegen-x64.cc:535-640).
       s->linear_hint = true;
       s->stats.retries++;
+      if (rp->run.ok) {   // one long-lived thread in one loop position: the run kernels (two passes over the text)
+        rc = run_runs(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
+        if (rc != 0) return rc < 0 ? rc : RJ_OK;
+      }
       return run_linear(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
     }
     if (in_regions) {

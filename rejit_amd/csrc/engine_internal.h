@@ -95,6 +95,7 @@ struct rj_program {
   bool window_nibbles = false;  // those values differ in their low nibble (nibble filter usable)
   int batch_separator = -1;  // byte that ends a text inside a concatenated batch, -1: none exists
   rejit_amd::StreamPlan stream{};  // dense mode as bit streams (dense_streams.h): n_pos == 0 when the pattern does not qualify
+  rejit_amd::RunPlan run{};        // one long-lived thread in one loop position (run_scan.h): ok == 0 when the pattern does not qualify
   std::string pattern;
 };
 
@@ -115,6 +116,7 @@ struct rj_scan {
   // entry points, per-sub-chunk counts, wide-automaton scratch
   rejit_amd::DeviceBuffer cs_vals, cs_mats, cs_e, cs_g, cs_entry, cs_counts, cs_scratch, cs_acc, cs_groups;
   bool linear_hint = false;        // the previous run needed the carry scan: go there directly
+  rejit_amd::DeviceBuffer run_summaries, run_tile_in;  // run_scan.hip
   bool streams_off = false;        // dense_streams ran into a void run or too many scalar walks on this scan's text: scan_dense_walk
   bool behind_conflicts = false;   // behind mode gave a conflict / overrun on this scan's text: stay dense
   bool no_local_select = false;    // floating windows: the in-region selection left overlapping candidates on this text

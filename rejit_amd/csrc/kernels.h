@@ -7,6 +7,7 @@
 
 #include "dense_streams.h"
 #include "device_program.h"
+#include "run_scan.h"
 
 namespace rejit_amd {
 
@@ -248,6 +249,41 @@ struct StreamParams {
 uint64_t stream_tiles(uint64_t sb, uint64_t se, uint64_t n, uint64_t* first_tile);
 size_t stream_scratch_bytes(uint64_t n_tiles);
 void launch_dense_streams(StreamParams a, unsigned long long* scratch, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
+
+// Patterns with ONE long-lived thread in one loop position (run_scan.h / run_scan.hip, round 6): tiles of kRunTile bytes,
+// run_summary -> run_resolve -> run_emit.  counters[kCntFinal] (and host_counters) = the number of matches after run_resolve.
+constexpr uint64_t kRunTile = 8192;
+struct RunSummary {
+  unsigned long long r1;             // the tile's first break (~0: none)
+  unsigned long long a1, b1, b1a;    // before it (or in the whole tile): the first A, the last B, the last B behind that A
+  unsigned long long open_s, open_q; // the segment open at the tile's end (tiles with a break)
+  unsigned long long cnt;            // matches closed by the tile's other breaks
+  unsigned long long pad;
+};
+struct RunTileIn {
+  unsigned long long s, q;           // the segment open at the tile's begin
+  unsigned long long off;            // the tile's first output pair
+  unsigned long long pad;
+};
+struct RunParams {
+  const uint8_t* text;   // 16-byte aligned
+  uint64_t n;
+  uint64_t sb, se;       // match begins [sb, se)
+  uint64_t min_start;    // starts below are not looked at (the own range's begin, or where a carried-in match ends)
+  uint32_t blocked_in;   // the segment that holds min_start has had its match (a carried-in match with a B that is no break)
+  uint64_t first_tile, n_tiles;
+  RunPlan plan;
+  RunSummary* summaries;
+  RunTileIn* tile_in;
+  uint64_t* out;
+  uint64_t out_cap;
+  unsigned long long* counters;
+  unsigned long long* host_counters;
+};
+uint64_t run_tiles(uint64_t sb, uint64_t n, uint64_t* first_tile);
+void launch_run_summary(const RunParams& a, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
+void launch_run_resolve(const RunParams& a, hipStream_t st);
+void launch_run_emit(const RunParams& a, hipEvent_t t1, hipStream_t st);
 
 struct ScanGeometry {
   int grid;

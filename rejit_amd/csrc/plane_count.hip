@@ -131,6 +131,9 @@ __device__ __forceinline__ uint32_t plane_test(uint32_t ta, uint32_t tb, uint32_
   // v52..v55 (next), `v_alignbit_b32 e, v52, v48, 2 i` under index c reads next[c], here[c].  Measured before this: a uniform
   // branch around four one-instruction arms per pick -- 0.101 ms per launch against 0.091 (taken branches cost the wave more
   // than the instructions saved); as selects the picks cost more than they save.
+  // (M0: the index mode writes it.  It is a register the compiler reserves for itself -- an asm clobber of it is ignored, clang
+  // says so -- and uses for LDS-DMA, s_movrel, GWS and messages only, none of which this file contains: tools/check_m0.py
+  // looks at the generated code for any other reader of M0 in these kernels.)
   register uint32_t q0 asm("v48") = ~(L | H);
   register uint32_t q1 asm("v49") = L & ~H;
   register uint32_t q2 asm("v50") = ~L & H;
@@ -159,8 +162,7 @@ __device__ __forceinline__ uint32_t plane_test(uint32_t ta, uint32_t tb, uint32_
           "v_alignbit_b32 %[e30], v52, v48, 6\n"
           "s_set_gpr_idx_off\n"
           : [e00] "=&v"(E[0][0]), [e10] "=&v"(E[1][0]), [e20] "=&v"(E[2][0]), [e30] "=&v"(E[3][0])
-          : [c00] "s"(code(0, 0)), [c10] "s"(code(0, 1)), [c20] "s"(code(0, 2)), [c30] "s"(code(0, 3)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3)
-          : "m0");
+          : [c00] "s"(code(0, 0)), [c10] "s"(code(0, 1)), [c20] "s"(code(0, 2)), [c30] "s"(code(0, 3)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3));
       } else {
       asm volatile(
           "s_set_gpr_idx_on %[c40], 0x3\n"
@@ -173,8 +175,7 @@ __device__ __forceinline__ uint32_t plane_test(uint32_t ta, uint32_t tb, uint32_
           "v_alignbit_b32 %[e70], v52, v48, 14\n"
           "s_set_gpr_idx_off\n"
           : [e40] "=&v"(E[4][0]), [e50] "=&v"(E[5][0]), [e60] "=&v"(E[6][0]), [e70] "=&v"(E[7][0])
-          : [c40] "s"(code(0, 4)), [c50] "s"(code(0, 5)), [c60] "s"(code(0, 6)), [c70] "s"(code(0, 7)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3)
-          : "m0");
+          : [c40] "s"(code(0, 4)), [c50] "s"(code(0, 5)), [c60] "s"(code(0, 6)), [c70] "s"(code(0, 7)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3));
       }
     } else {
       if (half == 0) {
@@ -197,8 +198,7 @@ __device__ __forceinline__ uint32_t plane_test(uint32_t ta, uint32_t tb, uint32_
           "v_alignbit_b32 %[e31], v52, v48, 6\n"
           "s_set_gpr_idx_off\n"
           : [e00] "=&v"(E[0][0]), [e01] "=&v"(E[0][1]), [e10] "=&v"(E[1][0]), [e11] "=&v"(E[1][1]), [e20] "=&v"(E[2][0]), [e21] "=&v"(E[2][1]), [e30] "=&v"(E[3][0]), [e31] "=&v"(E[3][1])
-          : [c00] "s"(code(0, 0)), [c01] "s"(code(1, 0)), [c10] "s"(code(0, 1)), [c11] "s"(code(1, 1)), [c20] "s"(code(0, 2)), [c21] "s"(code(1, 2)), [c30] "s"(code(0, 3)), [c31] "s"(code(1, 3)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3)
-          : "m0");
+          : [c00] "s"(code(0, 0)), [c01] "s"(code(1, 0)), [c10] "s"(code(0, 1)), [c11] "s"(code(1, 1)), [c20] "s"(code(0, 2)), [c21] "s"(code(1, 2)), [c30] "s"(code(0, 3)), [c31] "s"(code(1, 3)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3));
       } else {
       asm volatile(
           "s_set_gpr_idx_on %[c40], 0x3\n"
@@ -219,8 +219,7 @@ __device__ __forceinline__ uint32_t plane_test(uint32_t ta, uint32_t tb, uint32_
           "v_alignbit_b32 %[e71], v52, v48, 14\n"
           "s_set_gpr_idx_off\n"
           : [e40] "=&v"(E[4][0]), [e41] "=&v"(E[4][1]), [e50] "=&v"(E[5][0]), [e51] "=&v"(E[5][1]), [e60] "=&v"(E[6][0]), [e61] "=&v"(E[6][1]), [e70] "=&v"(E[7][0]), [e71] "=&v"(E[7][1])
-          : [c40] "s"(code(0, 4)), [c41] "s"(code(1, 4)), [c50] "s"(code(0, 5)), [c51] "s"(code(1, 5)), [c60] "s"(code(0, 6)), [c61] "s"(code(1, 6)), [c70] "s"(code(0, 7)), [c71] "s"(code(1, 7)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3)
-          : "m0");
+          : [c40] "s"(code(0, 4)), [c41] "s"(code(1, 4)), [c50] "s"(code(0, 5)), [c51] "s"(code(1, 5)), [c60] "s"(code(0, 6)), [c61] "s"(code(1, 6)), [c70] "s"(code(0, 7)), [c71] "s"(code(1, 7)), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(n0), "v"(n1), "v"(n2), "v"(n3));
       }
     }
 #pragma unroll
@@ -337,8 +336,7 @@ __device__ __forceinline__ uint32_t general_test(uint32_t ta, uint32_t tb, uint3
         "s_set_gpr_idx_off\n"
         : [e0] "=&v"(e0), [e1] "=&v"(e1), [e2] "=&v"(e2), [e3] "=&v"(e3), [e4] "=&v"(e4), [e5] "=&v"(e5), [e6] "=&v"(e6), [e7] "=&v"(e7)
         : [i0] "s"(ix[0]), [i1] "s"(ix[1]), [i2] "s"(ix[2]), [i3] "s"(ix[3]), [i4] "s"(ix[4]), [i5] "s"(ix[5]), [i6] "s"(ix[6]), [i7] "s"(ix[7]), "v"(q0), "v"(q1), "v"(q2),
-          "v"(q3), "v"(q4), "v"(n0), "v"(n1), "v"(n2), "v"(n3), "v"(n4)
-        : "m0");
+          "v"(q3), "v"(q4), "v"(n0), "v"(n1), "v"(n2), "v"(n3), "v"(n4));
     if (TOL) {
       // Z: no code differs so far; O: at most one does
       uint32_t Z = e0, O = e0 | e1;

@@ -1,0 +1,171 @@
+"""GPU parity tests (-m gpu) of the run kernels (rejit_amd/csrc/run_scan.h / run_scan.hip, round 6): patterns whose match is ONE
+long-lived thread in one loop position -- `X+`, `A L*`, `A L* B`, `X+ B` (reference: the NFA loop with one thread in the
+loop's state, src/x64/codegen-x64.cc:535-581, last accepting position :426-461, restart behind the match :487-503) -- against
+the oracle, through the C ABI:
+
+* texts of every break density: none at all (one match of the whole text), one break per tile, a break every few bytes;
+  runs that cross iteration (2 KiB), tile (8 KiB) and resolve-chunk boundaries; text sizes around those units;
+* own ranges and carried-in selection state (the sharded shape), bytes >= 0x80, the end of the text as the closing break;
+* 64 MiB single-run texts (what the carry scan took 4-6 ms for), bit-exact;
+* patterns that look alike but do NOT have the shape keep their paths (run_path == 0).
+"""
+import random
+
+import numpy as np
+import pytest
+
+from checkers import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rj():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import rejit_amd
+    rejit_amd.build()
+    rejit_amd.load_library()
+    return rejit_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return Oracle()
+
+
+def device_text(data: bytes):
+    import torch
+    return torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+
+
+SHAPES = [b"[acgt]+", b"[^>]+", b"x+", b"a[bc]*", b"a.*b", b"<[^>]*>", b"[a-f]+[0-9]", b"\"[^\"]*\"", b"a[^\\n]*z", b"[\\x80-\\xff]+", b"q[a-z]*[0-9]",
+          b"[ab]+b", b"a.*a"]
+
+
+def texts_for(rng, n):
+    """alphabets chosen so that breaks are absent, rare or dense for the shapes above"""
+    out = []
+    for alphabet in (b"acgt", b"ab", b"abcxz", b"acgt>\n", b"ab<>\"q0\n", bytes(range(256)), b"aaaaaaab\n", b"xyz09af"):
+        out.append(bytes(rng.choice(alphabet) for _ in range(n)))
+    # long runs with a break every ~10 KiB and every ~100 KiB
+    for every in (10000, 100000):
+        t = bytearray(rng.choice(b"acgtab") for _ in range(n))
+        for p in range(rng.randrange(every), n, every):
+            t[p] = rng.choice(b">\n0z\"")
+        out.append(bytes(t))
+    return out
+
+
+def check(rj, oracle, rx, data, **kw):
+    prog = rj.Program(rx)
+    sc = rj.Scan(prog)
+    t = device_text(data)
+    n = len(data)
+    got_n = sc.run(t.data_ptr(), n, **kw) if n else 0
+    got = sc.spans() if n else []
+    if "own_begin" in kw:
+        # an independent range: the selection starts afresh at own_begin (include/rejit_hip.h: no state is carried in) -- or,
+        # for the kernels that look at the byte before the range (dense_streams' run-start rule), as in the whole text: the
+        # carry exchange between shards copes with either (rejit_amd/sharding.py), both are accepted here
+        ob, oe = kw["own_begin"], kw.get("own_end", n + 1)
+        want = [(b + ob, e + ob) for b, e in oracle.match_all(rx, data[ob:]) if b + ob < oe]
+        if got != want:
+            want = [m for m in oracle.match_all(rx, data) if ob <= m[0] < oe]
+    else:
+        want = oracle.match_all(rx, data)
+    assert got == want and got_n == len(want), (rx, n, kw, got[:4], want[:4], len(got), len(want))
+    return sc.stats()
+
+
+def test_run_shapes_vs_oracle(rj, oracle):
+    rng = random.Random(41)
+    took = 0
+    for n in (1, 31, 2047, 2048, 2049, 8191, 8192, 8193, 20000, 70001, 300000):
+        for data in texts_for(rng, n):
+            for rx in SHAPES:
+                st = check(rj, oracle, rx, data)
+                took += st["run_path"]
+    assert took > 0, "no text took the run kernels"
+
+
+def test_run_kernels_are_forced_and_exact(rj, oracle, monkeypatch):
+    """RJ_RUNS_FIRST=1 (read once per process: set before the library's first run in a child) -- here the kernels are
+    reached through texts dense_streams gives up (one run of the whole text) and through patterns it does not take."""
+    rng = random.Random(42)
+    for rx, alphabet in [(b"[acgt]+", b"acgt"), (b"a.*b", b"abcdefgh"), (b"<[^>]*>", b"<abc"), (b"[^>]+", b"acgt"), (b"x+", b"x"), (b"a[bc]*", b"abc")]:
+        for n in (5000, 70000, 1 << 20):
+            data = bytes(rng.choice(alphabet) for _ in range(n))
+            if rx == b"a[bc]*":
+                data = b"xa" + data.replace(b"a", b"b")     # (ONE run behind the only `a`)
+            st = check(rj, oracle, rx, data)
+            if n > 65536:   # (texts of a few KiB are match_small's: one launch for the whole MatchAll)
+                assert st["run_path"] == 1, (rx, n, st)
+            assert st["linear_path"] == 0
+
+
+def test_run_own_ranges_and_carry(rj, oracle):
+    """A shard's run: begins in [own_begin, own_end) only; and the selection state carried in from the left neighbour (the
+    last match before own_begin): the run kernels must neither re-open the segment a carried match with a B has closed nor
+    start inside the carried match."""
+    rng = random.Random(43)
+    for rx, alphabet in [(b"[acgt]+", b"acgtN"), (b"a.*b", b"abcd\n"), (b"<[^>]*>", b"<ab>"), (b"[a-f]+[0-9]", b"abc19 ")]:
+        data = bytes(rng.choice(alphabet) for _ in range(120000))
+        n = len(data)
+        full = oracle.match_all(rx, data)
+        for own in [(0, 50000), (50000, n + 1), (8192, 16384), (33333, 33400), (119990, n + 1)]:
+            check(rj, oracle, rx, data, own_begin=own[0], own_end=own[1])
+        # with the carry: the shard's matches are the whole text's matches that begin in the range
+        for cut in (40000, 65536, 99999):
+            before = [m for m in full if m[0] < cut]
+            prog = rj.Program(rx)
+            sc = rj.Scan(prog)
+            t = device_text(data)
+            if before:
+                b, e = before[-1]
+                kw = dict(carry_cur=e if e > b else b + 1, carry_prev_end=e, have_prev=True)
+            else:
+                kw = {}
+            k = sc.run(t.data_ptr(), n, own_begin=cut, own_end=n + 1, **kw)
+            want = [m for m in full if m[0] >= cut]
+            assert sc.spans() == want and k == len(want), (rx, cut, sc.spans()[:3], want[:3])
+
+
+def test_run_64mib_single_run(rj, oracle):
+    """`[acgt]+` over 64 MiB of acgt and `a.*b` over 64 MiB without a line break: ONE match each (the carry scan's case,
+    tools/linear_probe.py), by the run kernels."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 64 << 20
+    for rx, alphabet in [(b"[acgt]+", b"acgt"), (b"a.*b", b"abcdefgh")]:
+        g = torch.Generator(device="cuda").manual_seed(1)
+        lut = torch.tensor(list(alphabet), dtype=torch.uint8, device=dev)
+        d = lut[torch.randint(0, len(alphabet), (n,), generator=g, device=dev)].contiguous()
+        host = d.cpu().numpy()
+        sc = rj.Scan(rj.Program(rx))
+        k = sc.run_tensor(d)
+        st = sc.stats()
+        if rx == b"[acgt]+":
+            want = [(0, n)]
+        else:
+            a = int(np.argmax(host == ord("a")))
+            b = n - 1 - int(np.argmax(host[::-1] == ord("b")))
+            want = [(a, b + 1)]
+        assert sc.spans() == want and k == 1, (rx, sc.spans(), want)
+        assert st["run_path"] == 1 and st["linear_path"] == 0, st
+        # a break in the middle and one near the end: three runs
+        d2 = d.clone()
+        d2[n // 2] = ord("\n")
+        d2[n - 3] = ord("\n")
+        k2 = sc.run_tensor(d2)
+        h2 = d2.cpu().numpy().tobytes()
+        # (the oracle takes ~1 s per 64 MiB pattern: once)
+        assert sc.spans() == oracle.match_all(rx, h2) and k2 == len(sc.spans())
+
+
+def test_patterns_without_the_shape_keep_their_paths(rj, oracle):
+    rng = random.Random(44)
+    data = bytes(rng.choice(b"abcxyz\n") for _ in range(30000))
+    for rx in (b"a.*b|c", b"(ab)+", b"a+b+", b"x*", b"^a.*b", b"[ab]+c|[bc]+d", b"a.+b", b"a.*\\n", b"abc"):
+        st = check(rj, oracle, rx, data)
+        assert st["run_path"] == 0, (rx, st)
