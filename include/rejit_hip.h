@@ -318,12 +318,6 @@ int rj_multi_set_mode(rj_multi* multi, int mode);
 /* duration of the last run's scan kernel(s) in ms, summed (0 when the patterns ran one by one) */
 float rj_multi_scan_ms(const rj_multi* multi);
 
-/* Measurement, not part of the matching path: the average duration in ms of `launches` launches of a READ-ONLY kernel over
- * d_text[0..n) (16 bytes per lane and load, XOR-reduced, nothing written but one word per wave; the scans' launch shape)
- * -- the achievable ceiling of a byte-stream scan on this device, for a caller that quotes a scan kernel against it in
- * the same run (bench.py: `hbm_ceiling`).  < 0: an error (rj_last_error). */
-float rj_stream_read_probe(const void* d_text, uint64_t n, int launches, void* hip_stream);
-
 /* number of visible HIP devices (0 when there is none), for callers that want to probe */
 int rj_device_count(void);
 

@@ -34,6 +34,7 @@ def _source_hash() -> str:
     h = hashlib.sha256()
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
     deps += [os.path.join(PKG, "..", "include", f) for f in ("rejit.h", "rejit_hip.h")]
+    deps += [os.path.join(PKG, "..", "tools", "probes", "read_probe.hip")]
     for d in deps:
         h.update(os.path.basename(d).encode())
         with open(d, "rb") as f:
@@ -44,7 +45,7 @@ def _source_hash() -> str:
 def _stale() -> bool:
     """The library is rebuilt when the CONTENT of a source differs from what it was built
     from (mtimes do not survive the copy to the GPU box)."""
-    if not os.path.exists(LIB) or not os.path.exists(HASH):
+    if not os.path.exists(LIB) or not os.path.exists(HASH) or not os.path.exists(os.path.join(PKG, "librejit_bench.so")):
         return True
     try:
         with open(HASH) as fh:
@@ -129,6 +130,13 @@ def _build_locked(verbose: bool) -> str:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
+    # the measurement library (bench.py's read-only ceiling): its own shared object, not part of the product's ABI
+    probe_src = os.path.join(PKG, "..", "tools", "probes", "read_probe.hip")
+    cmd = [hipcc] + flags + ["-shared", probe_src, "-o", BENCH_LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(BENCH_LIB + ".tmp", BENCH_LIB)
     with open(HASH, "w") as f:
         f.write(_source_hash() + "\n")
     return LIB
@@ -166,7 +174,7 @@ C_ABI_SYMBOLS = ["rj_compile", "rj_program_free", "rj_program_info", "rj_last_er
                  "rj_multi_bounds", "rj_batch_separator", "rj_match_all_packed", "rj_host_alloc", "rj_host_free",
                  "rj_multi_bounds_device", "rj_carry_decide", "rj_multi_start", "rj_multi_finish", "rj_multi_order_after",
                  "rj_multi_device_counts", "rj_multi_device_counts_via", "rj_multi_set_tail_stream", "rj_multi_set_timing", "rj_scan_set_timing", "rj_set_default_timing",
-                 "rj_scan_gather_spans", "rj_scan_gather_spans_via", "rj_scan_gathered_spans", "rj_multi_set_counts_only", "rj_stream_read_probe", "rj_scan_stats_sized", "rj_scan_copy_gathered_spans", "rj_scan_count", "rj_host_stats", "rj_replace_all_begin", "rj_replace_all_fetch"]
+                 "rj_scan_gather_spans", "rj_scan_gather_spans_via", "rj_scan_gathered_spans", "rj_multi_set_counts_only", "rj_scan_stats_sized", "rj_scan_copy_gathered_spans", "rj_scan_count", "rj_host_stats", "rj_replace_all_begin", "rj_replace_all_fetch"]
 
 
 def load_library():
@@ -217,8 +225,6 @@ def load_library():
     L.rj_scan_stats_sized.argtypes = [vp, vp, sz]
     L.rj_scan_copy_gathered_spans.restype = i64
     L.rj_scan_copy_gathered_spans.argtypes = [vp, _u64p, u64]
-    L.rj_stream_read_probe.restype = ctypes.c_float
-    L.rj_stream_read_probe.argtypes = [vp, u64, ctypes.c_int, vp]
     L.rj_scan_set_timing.argtypes = [vp, ctypes.c_int]
     L.rj_set_default_timing.argtypes = [ctypes.c_int]
     L.rj_set_default_timing(1)   # bench.py, the tests and the tools read scan_ms: the scan kernel's start event is on for them
@@ -277,11 +283,24 @@ def carry_decide(all_rows, world: int, rank: int, n_patterns: int, out, stream: 
                                ctypes.c_void_p(stream)))
 
 
+BENCH_LIB = os.path.join(PKG, "librejit_bench.so")
+_bench_lib = None
+
+
 def stream_read_probe(d_text_ptr: int, n: int, launches: int = 10, stream: int = 0) -> float:
-    """rj_stream_read_probe: average ms of a read-only kernel over device memory (the achievable ceiling of a scan)."""
-    ms = float(load_library().rj_stream_read_probe(ctypes.c_void_p(d_text_ptr), n, launches, ctypes.c_void_p(stream)))
+    """Average ms of a read-only kernel over device memory (the achievable ceiling of a scan): MEASUREMENT, from
+    rejit_amd/librejit_bench.so (tools/probes/read_probe.hip) -- not part of the product library or its C ABI."""
+    global _bench_lib
+    if _bench_lib is None:
+        load_library()   # (torch's copy of the HIP runtime first)
+        if not os.path.exists(BENCH_LIB):
+            raise FileNotFoundError(f"{BENCH_LIB} is missing: run rejit_amd.build()")
+        _bench_lib = ctypes.CDLL(BENCH_LIB)
+        _bench_lib.rjb_stream_read_probe.restype = ctypes.c_float
+        _bench_lib.rjb_stream_read_probe.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p]
+    ms = float(_bench_lib.rjb_stream_read_probe(ctypes.c_void_p(d_text_ptr), n, launches, ctypes.c_void_p(stream)))
     if ms < 0:
-        raise RejitError(-3, load_library().rj_last_error().decode("latin1"))
+        raise RejitError(-3, "rjb_stream_read_probe failed")
     return ms
 
 

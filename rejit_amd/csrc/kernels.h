@@ -222,8 +222,6 @@ struct PlaneCountParams {
 void launch_plane_count(const PlaneCountParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 // the rows of that launch (grid workgroups) added up: counts, flags, bounds -> a.host_out and a.acc
 void launch_plane_count_finish(const PlaneCountParams& a, int grid, hipStream_t st);
-// measurement (rj_stream_read_probe): a read-only pass over d_text[0..n), 16 bytes per lane and load; d_out: grid * 4 words
-void launch_stream_read_probe(const void* d_text, uint64_t n, uint32_t* d_out, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 // launch_bounds_rows after a counts run: a pattern without a list (spans[p] == nullptr) takes its count and first /
 // last match (8 bytes long) from the kernel's device copy in `acc`
 void launch_bounds_rows_counts(const BoundsParams& a, const unsigned long long* acc, int64_t offset, int first_round, int64_t* d_rows, hipStream_t st);

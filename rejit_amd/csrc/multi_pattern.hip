@@ -1580,37 +1580,6 @@ int rj_multi_set_timing(rj_multi* m, int on) {
   return RJ_OK;
 }
 
-float rj_stream_read_probe(const void* d_text, uint64_t n, int launches, void* hip_stream) {
-  ErrnoGuard errno_guard;
-  if (!d_text || n < (1u << 20) || launches < 1 || (reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) {
-    fail(RJ_BAD_ARGUMENT, "rj_stream_read_probe: >= 1 MiB of 16-byte aligned device memory");
-    return -1.f;
-  }
-  hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  const ScanGeometry geo = scan_geometry(n / 1024, 128);   // the scans' own launch shape
-  DeviceBuffer out;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (out.reserve(sizeof(uint32_t) * 4 * static_cast<size_t>(geo.grid)) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
-    fail(RJ_DEVICE_ERROR, "rj_stream_read_probe: out of memory");
-    return -1.f;
-  }
-  float total = 0.f;
-  for (int i = 0; i < launches + 2; i++) {   // (two untimed launches first)
-    launch_stream_read_probe(d_text, n, out.as<uint32_t>(), geo.grid, e0, e1, st);
-    if (hipStreamSynchronize(st) != hipSuccess) {
-      fail(RJ_DEVICE_ERROR, "rj_stream_read_probe: the kernel failed");
-      total = -1.f;
-      break;
-    }
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    if (i >= 2) total += ms;
-  }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  return total < 0.f ? -1.f : total / static_cast<float>(launches);
-}
-
 int rj_multi_set_counts_only(rj_multi* m, int on) {
   ErrnoGuard errno_guard;
   if (!m) return fail(RJ_BAD_ARGUMENT, "null argument");

@@ -263,6 +263,9 @@ __device__ __forceinline__ uint32_t len_of(const Lens& l, uint32_t p) {   // (p 
   return static_cast<uint32_t>((p < 12 ? l.w[0] >> (5 * p) : l.w[1] >> (5 * (p - 12))) & 31u);
 }
 
+}  // namespace
+
+// (the shapes are named types of rejit_amd: a profiler prints the kernels as plane_count<rejit_amd::ExactShape<2> > ...)
 template <int NB>
 struct ExactShape {
   using Args = PlaneCountParams;
@@ -285,6 +288,8 @@ struct ExactShape {
     mask = ok ? mask : 0u;
   }
 };
+
+namespace {
 
 // The general test: bit 2k = byte k, bit 2k + 1 = byte 16 + k of the lane's 32 (plane_test's layout).  Base after base in a
 // loop that is NOT unrolled (<= 12 bases), and per base what plane_test does for its two: "window byte i of the base fits at
@@ -361,6 +366,8 @@ __device__ __forceinline__ uint32_t general_test(uint32_t ta, uint32_t tb, uint3
   return c;
 }
 
+}  // namespace
+
 template <int W, int MAXK, bool TOL>
 struct GeneralShape {
   using Args = PlaneCountGParams;
@@ -425,6 +432,8 @@ struct GeneralShape {
     }
   }
 };
+
+namespace {
 
 // per wave: the ring, and what the classification carries from batch to batch
 struct WaveState {
@@ -895,70 +904,6 @@ __global__ void bounds_rows_counts_kernel(BoundsParams a, const unsigned long lo
 
 void launch_bounds_rows_counts(const BoundsParams& a, const unsigned long long* acc, int64_t offset, int first_round, int64_t* d_rows, hipStream_t st) {
   hipLaunchKernelGGL(bounds_rows_counts_kernel, dim3(1), dim3(64), 0, st, a, acc, offset, first_round, d_rows);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The achievable ceiling of a READ-ONLY stream on this device, measured in the run that quotes a scan against it
-// ("measure a plain device read-only kernel in the same run as the achievable ceiling"): every lane reads
-// 16 bytes per load, four loads in flight per lane, XORs them together and the wave leaves one word -- nothing else.
-// Same launch shape as the scans (workgroups of four waves over contiguous spans).
-__global__ __launch_bounds__(256) void stream_read_probe(const uint4* text, uint64_t n16, uint64_t span16, uint32_t* out) {
-  const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t lane = threadIdx.x & 63u;
-  uint64_t i = wave * span16 + lane, end = (wave + 1) * span16;
-  if (end > n16) end = n16;
-  uint4 acc{0, 0, 0, 0};
-  for (; i + 192 < end; i += 256) {
-    const uint4 a = text[i], b = text[i + 64], c = text[i + 128], d = text[i + 192];
-    acc.x ^= a.x ^ b.x ^ c.x ^ d.x;
-    acc.y ^= a.y ^ b.y ^ c.y ^ d.y;
-    acc.z ^= a.z ^ b.z ^ c.z ^ d.z;
-    acc.w ^= a.w ^ b.w ^ c.w ^ d.w;
-  }
-  for (; i < end; i += 64) {
-    const uint4 a = text[i];
-    acc.x ^= a.x;
-    acc.y ^= a.y;
-    acc.z ^= a.z;
-    acc.w ^= a.w;
-  }
-  uint32_t v = acc.x ^ acc.y ^ acc.z ^ acc.w;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o);
-  if (lane == 0) out[wave] = v;
-}
-
-// (measurement only, RJ_PROBE_PATTERN=1: the same reads in plane_count's layout -- a lane takes 32 CONTIGUOUS bytes as two
-// 16-byte loads, so a load instruction of the wave touches every second 16 bytes of 2 KiB)
-__global__ __launch_bounds__(256) void stream_read_probe_pairs(const uint4* text, uint64_t n16, uint64_t span16, uint32_t* out) {
-  const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t lane = threadIdx.x & 63u;
-  uint64_t i = wave * span16 + 2 * lane, end = (wave + 1) * span16;
-  if (end > n16) end = n16;
-  uint4 acc{0, 0, 0, 0};
-  for (; i + 129 < end; i += 256) {
-    const uint4 a = text[i], b = text[i + 1], c = text[i + 128], d = text[i + 129];
-    acc.x ^= a.x ^ b.x ^ c.x ^ d.x;
-    acc.y ^= a.y ^ b.y ^ c.y ^ d.y;
-    acc.z ^= a.z ^ b.z ^ c.z ^ d.z;
-    acc.w ^= a.w ^ b.w ^ c.w ^ d.w;
-  }
-  uint32_t v = acc.x ^ acc.y ^ acc.z ^ acc.w;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o);
-  if (lane == 0) out[wave] = v;
-}
-
-void launch_stream_read_probe(const void* d_text, uint64_t n, uint32_t* d_out, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
-  const uint64_t n16 = n / 16, waves = static_cast<uint64_t>(grid) * 4;
-  const uint64_t span16 = ((n16 + waves - 1) / waves + 63) / 64 * 64;
-  static const bool pairs = getenv("RJ_PROBE_PATTERN") && atoi(getenv("RJ_PROBE_PATTERN")) == 1;
-  if (pairs) {
-    const uint64_t span = (span16 + 255) / 256 * 256;
-    hipExtLaunchKernelGGL(stream_read_probe_pairs, dim3(grid), dim3(256), 0, st, t0, t1, 0, static_cast<const uint4*>(d_text), n16, span, d_out);
-    return;
-  }
-  hipExtLaunchKernelGGL(stream_read_probe, dim3(grid), dim3(256), 0, st, t0, t1, 0, static_cast<const uint4*>(d_text), n16, span16, d_out);
 }
 
 void launch_plane_count(const PlaneCountParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {

@@ -51,8 +51,9 @@ j = {"source": f"profiles/{tag}_pmc_hbm_traffic.txt",
              "run at two text sizes in the profiled command take the min / max launch"}
 FASTA = 500000000  # bytes of the stripped 50 M-base FASTA input (workloads.fasta_stripped_size)
 for key, prefix, nbytes, extra in (
-        ("plane_count", "plane_count<2>", FASTA, {"fasta_n": 50000000}),
-        ("plane_count_2p5gb", "plane_count<2>", 2500000000, {}),
+        ("plane_count", "plane_count<ExactShape<2> >", FASTA, {"fasta_n": 50000000}),
+        ("plane_count_2p5gb", "plane_count<ExactShape<2> >", 2500000000, {}),
+        ("counts_general", "plane_count<GeneralShape<1, 16, false> >", 5000000000, {}),
         ("plane", "plane_scan<2>", FASTA, {"fasta_n": 50000000}),
         ("plane_2p5gb", "plane_scan<2>", 2500000000, {}),
         ("regexdna_single", "scan_windows<2, true, true, false, true>", FASTA, {"fasta_n": 50000000}),
@@ -69,6 +70,26 @@ for key, prefix, nbytes, extra in (
         j[key] = dict(kernel=prefix, hbm_read_bytes_per_launch=avg_of(f, prefix, nbytes) * 1024 * 2, bytes=nbytes, **extra)
     except KeyError:
         pass
+# VALU lane-operations per text byte of the issue-bound kernels: SQ_INSTS_VALU (wave instructions per launch, the SQ pass of
+# tools/profile_round.sh: bench.py --no-big, so every kernel runs at ONE text size there) x 64 lanes / text bytes -- what
+# bench.py's roofline_valu quotes (round 5 typed these into rejit_amd/__init__.py by hand)
+try:
+    sq = open(g("pmc_sq.txt")).read().split("## SQ_INSTS_VALU")[1].split("## ")[0]
+    for key, prefix, nbytes in (("plane_count", "plane_count<ExactShape<2> >", FASTA), ("plane", "plane_scan<2>", FASTA),
+                                ("dense", "dense_streams<2, 2, false, false>", 5000000000), ("dense_select", "dense_streams<3, 1, false, true>", 5000000000),
+                                ("counts_general", "plane_count<GeneralShape<1, 16, false> >", 5000000000), ("general", "plane_scan_general<1, false>", 5000000000)):
+        ops = None
+        for line in sq.splitlines():
+            if line.startswith(prefix):
+                # (the launch group nearest to what the kernel's instruction count per byte of the OTHER launches says is not known
+                # here: take the largest group -- the full-size text; the small calls of the latency sweeps are far below it)
+                groups = [float(x.split("x")[0]) for x in line[60:].split()[4:]]
+                ops = max(groups) * 64 / nbytes
+        if ops is not None and key in j:
+            j[key]["valu_ops_per_text_byte"] = round(ops, 3)
+            j[key]["valu_source"] = f"profiles/{tag}_pmc_sq_counters.txt: SQ_INSTS_VALU x 64 / {nbytes}"
+except (OSError, IndexError):
+    pass
 # (behind: the same scan kernel as `complex`, over the same text)
 if "complex" in j:
     j["behind"] = dict(j["complex"], note="same kernel and text as `complex`")
@@ -78,7 +99,7 @@ open(P("bench_kernel_stats.txt"), "w").write(
     "# rocprofv3 --kernel-trace --stats -- python bench.py --no-extra --no-cpu-baseline   (MI355X)\n"
     "# = the headline run alone (default K/W; the extras and the CPU sample left out so that the per-kernel averages are\n"
     "# those of the timed region); summarised from the rocpd database by tools/rocpd_stats.py.  The un-profiled bench line\n"
-    f"# (profiles/{tag}_bench_line.json) reports roofline.avg_launch_ms, which agrees with plane_count<2> avg_us below\n"
+    f"# (profiles/{tag}_bench_line.json) reports roofline.avg_launch_ms, which agrees with plane_count<ExactShape<2> > avg_us below\n"
     "# (under the profiler the dispatch-timestamp time reads a few % higher):\n# " + prof_line + "\n" + open(g("kernel_stats.txt")).read())
 open(P("bench_full_kernel_stats.txt"), "w").write(
     "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 5 --jrep-files 5000 --jrep-bytes 500000000   (MI355X):\n"
@@ -86,8 +107,8 @@ open(P("bench_full_kernel_stats.txt"), "w").write(
     "# (floating), behind, dense, line table (emit_assertions), batches, tails\n"
     + open(g("kernel_stats_full.txt")).read())
 open(P("linear_path_kernel_stats.txt"), "w").write(
-    "# rocprofv3 --kernel-trace --stats -- python tools/linear_probe.py   (MI355X): the linear-time carry scan (cs_*), the blocked\n"
-    "# chain selection (chain_*) and the dense kernel on `[acgt]+` / `a.*b` 64 MiB single-line, `x*` 16 MiB, `[ab]{40}c*` 4 MiB\n"
+    "# rocprofv3 --kernel-trace --stats -- python tools/linear_probe.py   (MI355X): `[acgt]+` / `a.*b` 64 MiB single-line (round 6: the run\n"
+    "# kernels run_summary / run_resolve / run_emit; until round 5 the carry scan cs_*), `x*` 16 MiB, `[ab]{40}c*` 4 MiB (carry scan / chain selection)\n"
     + "\n".join(l for l in open(g("linear_probe.txt")).read().splitlines() if " run " in l) + "\n" + open(g("kernel_stats_linear.txt")).read())
 open(P("pmc_sq_counters.txt"), "w").write(
     "# rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY\n"
