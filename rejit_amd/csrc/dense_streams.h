@@ -56,6 +56,7 @@ struct StreamPlan {
   uint32_t first, last, step, loop;      // bit k: may begin a match / accepts / passes to k + 1 / follows itself
   uint32_t select;      // candidates MAY overlap (`[0-9][0-9][0-9]`) and no match is longer than kStreamShift bytes: the kernel
                         // applies the reference's left-most-longest selection itself (rj_stream_select)
+  uint32_t run_shape;   // 1: `X+`, 2: `X+ Y` with X and Y disjoint -- the run form of the steps (rj_stream_runs, round 6); 0: neither
 };
 
 RJ_HD uint32_t rj_udot4(uint32_t a, uint32_t b, uint32_t acc) {
@@ -239,6 +240,39 @@ RJ_HD void rj_stream_steps(const StreamPlan& pl, const StreamMasks<NP>& mk, cons
   *matched = m;
   *alive = al;
   *cand = c0;
+}
+
+// `X+` and `X+ Y` (StreamPlan::run_shape; X, Y disjoint): the steps as ARITHMETIC on the lane's 64-byte window instead of one
+// automaton step per consumed byte (round 6).  W = the X stream of the 32 bytes before the lane's own (low word) and of its own
+// (high word); a lane's starts are the window bits 16 .. 47 (kStreamShift), so every start has at least 16 bytes of its run in
+// the window.  The candidates are the run starts (bit set, the bit below clear); adding them to W carries each through its
+// run and leaves a bit at the first byte behind it -- the run's END --, all runs at once, in one 64-bit addition: what sixteen
+// steps of four operations per position did.  A match is a run whose end holds Y (`X+`: every run); its length is the
+// distance of the two bits.  A run that reaches the window's top is not decided here (*alive: the scalar walk, as before).
+//   *starts  the candidates (window bits 16 .. 47, under start_mask)      *ends  the END bits of the runs that match
+RJ_HD void rj_stream_runs(uint32_t run_shape, uint32_t S0, uint32_t Sb0, uint32_t S1, uint32_t Sb1, uint32_t start_mask, uint64_t* starts, uint64_t* ends,
+                          uint32_t* alive) {
+  const uint64_t W = (static_cast<uint64_t>(S0) << 32) | Sb0;
+  const uint64_t c = W & ~(W << 1) & (static_cast<uint64_t>(start_mask) << kStreamShift);
+  const uint64_t T = W + c;               // (a carry out of bit 63 is the undecided run's)
+  uint64_t end = T & ~W;
+  if (run_shape == 2) end &= (static_cast<uint64_t>(S1) << 32) | Sb1;
+  // the run that reaches bit 63: its start is the bit above the window's highest zero
+  const uint64_t zeros = ~W;
+  const uint32_t lead = zeros == 0 ? 64u : static_cast<uint32_t>(__builtin_clzll(zeros));
+  const uint64_t top = (lead > 0 && lead < 64u) ? (1ull << (64u - lead)) : 0ull;   // (lead == 64: the run began before the window)
+  *alive = static_cast<uint32_t>((c & top) >> kStreamShift);
+  *starts = c;
+  *ends = end;
+}
+
+// the next match of the lane, in text order: takes the lowest bit of *ends; j = its start (0 .. 31), the match's length
+RJ_HD uint32_t rj_stream_run_next(uint32_t run_shape, uint64_t starts, uint64_t* ends, int* j) {
+  const int e = __builtin_ctzll(*ends);
+  *ends &= *ends - 1;
+  const int s = 63 - __builtin_clzll(starts & ((1ull << e) - 1ull));   // (the run's own start: the highest candidate below its end)
+  *j = s - static_cast<int>(kStreamShift);
+  return static_cast<uint32_t>(e - s) + (run_shape == 2 ? 1u : 0u);
 }
 
 // longest length of start j from the bit-sliced registers

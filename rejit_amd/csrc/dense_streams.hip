@@ -103,7 +103,9 @@ struct TileOut {
 // comes from the 2 KiB before it (one iteration more, `it` = -1, nothing written): a lane without any match there resets
 // the chain whatever came before, so everything behind the LAST such lane is exact.  No such lane in 2 KiB (64 lanes each
 // with a match: a text packed with matches): *unsure -- the run is void and the engine repeats it on scan_dense_walk.
-template <int NP, int NR, bool HIGH, bool DIRECT, bool SELECT>
+// RUN (StreamPlan::run_shape: `X+`, `X+ Y`; round 6): the steps are ONE 64-bit addition per lane (dense_streams.h: rj_stream_runs)
+// -- `[a-f]+[0-9]` spent 75 of its 267 instructions per lane and 32 bytes in the generic steps, at the VALU issue rate.
+template <int NP, int NR, bool HIGH, bool DIRECT, bool SELECT, bool RUN>
 __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const StreamMasks<NP>& mk, const StreamRangeMasks<NP, NR>& rm, uint64_t base,
                                                 const TileOut& o, uint32_t* slow, bool* overrun) {
   const int lane = lane_id();
@@ -174,6 +176,40 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Str
       Sb[k] = lane == 0 ? carry[k] : below;
       carry[k] = wave_last_lane(S[k]);
     }
+    const uint32_t rel0 = static_cast<uint32_t>(it) * static_cast<uint32_t>(kIter) + static_cast<uint32_t>(lane) * 32u;
+    auto put = [&](int j, uint32_t l, uint32_t idx) {
+      if (DIRECT) {
+        const uint64_t s = at + static_cast<uint64_t>(j) - kStreamShift;
+        const uint64_t pos = o.direct_base + idx;
+        if (pos < o.out_cap) *reinterpret_cast<ulonglong2*>(o.out + 2 * pos) = make_ulonglong2(s, s + l);
+      } else if (idx < kStage) {
+        o.stage[idx] = ((rel0 + static_cast<uint32_t>(j)) << kLenBits) | l;
+      }
+    };
+    if (RUN) {
+      uint64_t starts, ends;
+      uint32_t alive_r;
+      rj_stream_runs(pl.run_shape, S[0], Sb[0], NP > 1 ? S[NP > 1 ? 1 : 0] : 0u, NP > 1 ? Sb[NP > 1 ? 1 : 0] : 0u, start_mask, &starts, &ends, &alive_r);
+      uint32_t walked_l = 0;   // the run that reaches the window's top (at most one per lane): its scalar walk
+      if (__ballot(alive_r != 0) != 0 && alive_r != 0) {
+        bool ov = false;
+        walked_l = rj_stream_walk(pl, a.text, a.n, at + static_cast<uint64_t>(__builtin_ctz(alive_r)) - kStreamShift, a.max_walk, &ov);
+        if (ov) *overrun = true;
+        (*slow)++;
+      }
+      const uint32_t mine = static_cast<uint32_t>(__popcll(ends)) + (walked_l != 0 ? 1u : 0u);
+      if (__ballot(mine != 0) == 0) return true;
+      const uint32_t inc = wave_inclusive_sum(mine);
+      uint32_t idx = count + inc - mine;
+      while (ends != 0) {
+        int j;
+        const uint32_t l = rj_stream_run_next(pl.run_shape, starts, &ends, &j);
+        put(j, l, idx++);
+      }
+      if (walked_l != 0) put(__builtin_ctz(alive_r), walked_l, idx);   // (the top run is the lane's last)
+      count += wave_last_lane(inc);
+      return true;
+    }
     uint32_t matched, alive, len[4], cand;
     rj_stream_steps<NP>(pl, mk, S, Sb, start_mask, AnyLane(), &matched, &alive, len, &cand);
     uint32_t fin = matched & ~alive;
@@ -223,7 +259,6 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Str
     const uint32_t mine = __popc(take);
     const uint32_t inc = wave_inclusive_sum(mine);
     uint32_t idx = count + inc - mine;
-    const uint32_t rel0 = static_cast<uint32_t>(it) * static_cast<uint32_t>(kIter) + static_cast<uint32_t>(lane) * 32u;
     for (uint32_t m = take; m; m &= m - 1, idx++) {
       const int j = __builtin_ctz(m);
       uint32_t l;
@@ -233,13 +268,7 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Str
       } else {
         l = rj_stream_len(len, j);
       }
-      if (DIRECT) {
-        const uint64_t s = at + static_cast<uint64_t>(j) - kStreamShift;
-        const uint64_t pos = o.direct_base + idx;
-        if (pos < o.out_cap) *reinterpret_cast<ulonglong2*>(o.out + 2 * pos) = make_ulonglong2(s, s + l);
-      } else if (idx < kStage) {
-        o.stage[idx] = ((rel0 + static_cast<uint32_t>(j)) << kLenBits) | l;
-      }
+      put(j, l, idx);
     }
     count += wave_last_lane(inc);
     return true;
@@ -267,7 +296,7 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Str
 // look-back set the pace (`[@#]`, one step, took as long as `[a-f]+[0-9]`); a granule per workgroup: 1.62 ms per 5 GB;
 // two-level look-back: 1.53; with no look-back at all (wrong output) 1.17 -- the rest was waiting for the slowest of the
 // ~1800 units in flight, which this form no longer does.
-template <int NP, int NR, bool HIGH, bool SELECT>
+template <int NP, int NR, bool HIGH, bool SELECT, bool RUN = false>
 __global__ __launch_bounds__(256) void dense_streams(StreamParams a) {
   __shared__ unsigned long long s_ticket, s_before;
   __shared__ uint32_t s_count[2][kTilesPerTicket], s_bad;
@@ -295,7 +324,7 @@ __global__ __launch_bounds__(256) void dense_streams(StreamParams a) {
       const TileOut o{s_stage[cur][wv], a.out, a.out_cap, 0};
       uint32_t slow = 0;
       bool overrun = false;
-      if (!void_run && t < a.n_tiles) k = stream_tile<NP, NR, HIGH, false, SELECT>(a, mk, rm, base, o, &slow, &overrun);
+      if (!void_run && t < a.n_tiles) k = stream_tile<NP, NR, HIGH, false, SELECT, RUN>(a, mk, rm, base, o, &slow, &overrun);
       if (__ballot(overrun) != 0 && lane == 0) {
         a.counters[kCntOverrun] = 1;
         if (a.host_counters) a.host_counters[kCntOverrun] = 1;
@@ -363,7 +392,7 @@ __global__ __launch_bounds__(256) void dense_streams(StreamParams a) {
         const TileOut o{s_stage[cur ^ 1][wv], a.out, a.out_cap, before};
         uint32_t slow2 = 0;
         bool ov2 = false;
-        (void)stream_tile<NP, NR, HIGH, true, SELECT>(a, mk, rm, pbase, o, &slow2, &ov2);
+        (void)stream_tile<NP, NR, HIGH, true, SELECT, RUN>(a, mk, rm, pbase, o, &slow2, &ov2);
       }
     }
     if (!have) return;
@@ -414,13 +443,35 @@ void launch_np(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipS
   else if (nr <= 4) launch_nr<NP, 4>(a, g, t0, t1, st);
   else launch_nr<NP, 8>(a, g, t0, t1, st);
 }
+#ifndef RJ_DENSE_SELECT_TU
+// the run form (`X+`, `X+ Y`): NP 1 / 2, ranges rounded up to 2 / 8 -- eight kernels; the six-position instantiations of both
+// units went in exchange (plans of five and six positions take the eight-position kernels): 96 -> 88 kernels in all
+template <int NP, int NR>
+void launch_run_nr(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+  const dim3 b(256);
+  if (a.plan.high_half == 0) hipExtLaunchKernelGGL((dense_streams<NP, NR, false, false, true>), g, b, 0, st, t0, t1, 0, a);
+  else hipExtLaunchKernelGGL((dense_streams<NP, NR, true, false, true>), g, b, 0, st, t0, t1, 0, a);
+}
+void launch_run_shape(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+  const bool few = a.plan.n_ranges <= 2;
+  if (a.plan.n_pos <= 1) {
+    if (few) launch_run_nr<1, 2>(a, g, t0, t1, st);
+    else launch_run_nr<1, 8>(a, g, t0, t1, st);
+  } else {
+    if (few) launch_run_nr<2, 2>(a, g, t0, t1, st);
+    else launch_run_nr<2, 8>(a, g, t0, t1, st);
+  }
+}
+#endif
 void launch_shape(const StreamParams& a, dim3 g, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
   const uint32_t np = a.plan.n_pos;
+#ifndef RJ_DENSE_SELECT_TU
+  if (a.plan.run_shape != 0 && !a.plan.select && np <= 2) return launch_run_shape(a, g, t0, t1, st);
+#endif
   if (np <= 1) launch_np<1>(a, g, t0, t1, st);
   else if (np <= 2) launch_np<2>(a, g, t0, t1, st);
   else if (np <= 3) launch_np<3>(a, g, t0, t1, st);
   else if (np <= 4) launch_np<4>(a, g, t0, t1, st);
-  else if (np <= 6) launch_np<6>(a, g, t0, t1, st);
   else launch_np<8>(a, g, t0, t1, st);
 }
 }  // namespace

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -372,6 +373,17 @@ inline StreamPlan make_stream_plan(const Program& P, bool loop_first, bool q8_ri
   pl.last = last;
   pl.step = step;
   pl.loop = loop;
+  // the run form of the steps (dense_streams.h: rj_stream_runs): `X+`, or `X+ Y` with no byte in both classes
+  if (pl.loop_first && !pl.select && first == 1u) {
+    if (P.n_pos == 1 && last == 1u && loop == 1u) {
+      pl.run_shape = 1;
+    } else if (P.n_pos == 2 && last == 2u && loop == 1u && step == 1u) {
+      bool disjoint = true;
+      for (int c = 0; c < 256; c++) disjoint = disjoint && (P.cls[static_cast<size_t>(c)] & 3u) != 3u;
+      if (disjoint) pl.run_shape = 2;
+    }
+  }
+  if (getenv("RJ_NO_RUN_STEPS") != nullptr) pl.run_shape = 0;   // measurement override
   return pl;
 }
 

@@ -427,6 +427,38 @@ static long stream_run(const Program& P, const DevProgram& F, const StreamPlan& 
     }
     uint32_t matched, alive, len[4], cand;
     rj_stream_steps<NP>(pl, mk, S, Sb, start_mask, any, &matched, &alive, len, &cand);
+    if (pl.run_shape != 0) {
+      // the run form of the steps (rj_stream_runs, round 6) against the generic steps: the same candidates, the same undecided
+      // starts, the same matches with the same lengths
+      uint64_t starts = 0, ends = 0;
+      uint32_t alive_r = 0;
+      rj_stream_runs(pl.run_shape, S[0], Sb[0], NP > 1 ? S[NP > 1 ? 1 : 0] : 0u, NP > 1 ? Sb[NP > 1 ? 1 : 0] : 0u, start_mask, &starts, &ends, &alive_r);
+      if (static_cast<uint32_t>(starts >> kStreamShift) != cand || (starts & ~(0xFFFFFFFFull << kStreamShift)) != 0) stats[2]++;
+      // (a run of more than 16 bytes that ends inside the window is decided by the run form and undecided -- alive -- by the
+      // sixteen steps: such starts are checked against the scalar walk)
+      if ((alive_r & ~alive) != 0) stats[2]++;
+      uint32_t matched_r = 0;
+      while (ends != 0) {
+        int j = 0;
+        const uint32_t l = rj_stream_run_next(pl.run_shape, starts, &ends, &j);
+        if (j < 0 || j > 31 || ((matched_r >> j) & 1u) || ((alive_r >> j) & 1u)) {
+          stats[2]++;
+          break;
+        }
+        matched_r |= 1u << j;
+        bool ov = false;
+        const uint32_t want = ((alive >> j) & 1u) ? rj_stream_walk(pl, t, n, at + static_cast<uint64_t>(j) - kStreamShift, 1u << 20, &ov)
+                                                  : (((matched >> j) & 1u) ? rj_stream_len(len, j) : 0u);
+        if (l != want) stats[2]++;
+      }
+      for (int j = 0; j < 32; j++) {
+        if (((matched_r | alive_r) >> j) & 1u) continue;
+        // not matched by the run form and decided: the steps (or the walk) must not have a match either
+        bool ov = false;
+        const bool has = ((alive >> j) & 1u) ? rj_stream_walk(pl, t, n, at + static_cast<uint64_t>(j) - kStreamShift, 1u << 20, &ov) != 0 : ((matched >> j) & 1u) != 0;
+        if (has && ((start_mask >> j) & 1u)) stats[2]++;
+      }
+    }
     if (pl.select) {
       if (alive != 0) stats[2]++;   // (no match of such a plan outlives the register steps)
       lanes.push_back(LaneMatches{matched, {len[0], len[1], len[2], len[3]}});

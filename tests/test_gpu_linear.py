@@ -67,7 +67,7 @@ def test_forced_carry_scan_vs_oracle(rj, oracle, monkeypatch):
     import torch
     monkeypatch.setenv("RJ_MAX_WALK", "8")
     rng = random.Random(99)
-    took = 0
+    took = took_runs = 0
     for rx in HARD:
         p = rj.Program(rx)
         sc = rj.Scan(p)
@@ -83,6 +83,7 @@ def test_forced_carry_scan_vs_oracle(rj, oracle, monkeypatch):
             d = torch.frombuffer(bytearray(tx), dtype=torch.uint8).cuda()
             cnt = sc.run_tensor(d)
             took += sc.stats()["linear_path"]
+            took_runs += sc.stats()["run_path"]
             assert cnt == len(want) and sc.spans() == want, (rx, alphabet, n)
             # two own ranges with the selection state carried over the cut
             cut = n // 3 + 17
@@ -95,12 +96,14 @@ def test_forced_carry_scan_vs_oracle(rj, oracle, monkeypatch):
                 state = dict(carry_cur=e if e > b else b + 1, carry_prev_end=e, have_prev=True)
             sc.run_tensor(d, own_begin=cut, own_end=n + 1, **state)
             assert first + sc.spans() == want, (rx, alphabet, n, cut)
-    assert took > 20   # the carry scan did run
+    # the carry scan did run -- and (round 6) the run kernels took the texts of the patterns with ONE long-lived thread in one loop
+    # position (`[acgt]+`, `[^>]+`, `a.*b`: run_scan.hip), which the carry scan answered until then
+    assert took > 10 and took_runs > 0 and took + took_runs > 20, (took, took_runs)
 
 
 @pytest.mark.parametrize("rx,alphabet,mib,linear", [
-    (b"[acgt]+", b"acgtacgtacgtN", 64, True), (b"[^>]+", b"abc>", 64, True), (b"(ab|ba)+", b"ab", 64, False),
-    (b"a.*b", b"abcdefgh", 64, True), (b"x*", b"xy", 64, False), (b"[a-z]+@[a-z]+", b"abcdefghij@", 8, None),
+    (b"[acgt]+", b"acgtacgtacgtN", 64, "run"), (b"[^>]+", b"abc>", 64, "run"), (b"(ab|ba)+", b"ab", 64, False),
+    (b"a.*b", b"abcdefgh", 64, "run"), (b"x*", b"xy", 64, False), (b"[a-z]+@[a-z]+", b"abcdefghij@", 8, None),
     (b"(a|b)*abb", b"abc", 8, None), (b"[ab]{40}c*", b"ab", 8, None)])
 def test_long_single_line(rj, oracle, rx, alphabet, mib, linear):
     """64 MiB without a line break: candidates of tens of MiB (a.*b: ONE match over the whole text),
@@ -125,7 +128,9 @@ def test_long_single_line(rj, oracle, rx, alphabet, mib, linear):
     got = gpu_spans_np(rj, sc)
     assert cnt == len(want)
     assert np.array_equal(got, want), (rx, got[:3], want[:3])
-    if linear is not None:
+    if linear == "run":     # (round 6: one long-lived thread in one loop position -- the run kernels, not the carry scan)
+        assert st["run_path"] == 1 and st["linear_path"] == 0, st
+    elif linear is not None:
         assert st["linear_path"] == int(linear), st
 
 
@@ -173,7 +178,8 @@ def test_fasta_500mb_runs(rj, rx):
     del inside, prev, nxt
     sc = rj.Scan(rj.Program(rx))
     cnt = sc.run_tensor(text)
-    assert sc.stats()["linear_path"] == 1
+    st = sc.stats()
+    assert st["run_path"] == 1 and st["linear_path"] == 0, st     # (round 6: the run kernels; until then the carry scan)
     got = torch.from_numpy(gpu_spans_np(rj, sc).astype(np.int64)).to(dev)
     assert cnt == begins.numel() and cnt > 0
     assert torch.equal(got[:, 0], begins) and torch.equal(got[:, 1], ends)

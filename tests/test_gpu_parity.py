@@ -446,7 +446,10 @@ def test_general_one_pass_pattern_sets(rj, oracle):
         ([b"alternation|strings", b"prefix abcd|prefix 1234"], [b"alternation", b"strings", b"prefix abcd", b"prefix 1234", b"alternatiom", b"refix abcd"], 1),
         ([b"qwerty", b"zxcvbn", b"plmokn", b"ijbuhv"], [b"qwerty", b"zxcvbn", b"plmokn", b"ijbuhv", b"qwertz", b"ijbuhw", b"uaivzr"], 1),
         ([b"abc[de]fgh", b"abcdfgh[xy]", b"abcefgh"], [b"abcdfgh", b"abcefgh", b"abcdfghx", b"abcdfghz", b"abcffgh"], 1),
-        ([b"x[0-9]regexp", b"regexpyz", b"abcd suffix|1234 suffix"], [b"x7regexp", b"regexpyz", b"abcd suffix", b"1234 suffix", b"xxregexp"], 2),
+        # (round 6: a window with ONE class position becomes a base of its own under tolerance 1 -- this set ran as separate scans until then)
+        ([b"x[0-9]regexp", b"regexpyz", b"abcd suffix|1234 suffix"], [b"x7regexp", b"regexpyz", b"abcd suffix", b"1234 suffix", b"xxregexp"], 1),
+        # two class positions inside the compared bytes: no base within one byte -- refused, separate scans + batched tails
+        ([b"ab[cd][ef]ghij", b"klmnopqr"], [b"abceghij", b"abdfghij", b"abcgghij", b"klmnopqr", b"klmnopqs"], 2),
         # nine 6-mers over [a-z]: nine bases (the scan loops over them; VERDICT r03's example)
         ([b"qwerty", b"zxcvbn", b"plmokn", b"ijbuhv", b"ygctfx", b"rdzesw", b"aqmnbv", b"lkjhgf", b"poiuyt"],
          [b"qwerty", b"zxcvbn", b"plmokn", b"ijbuhv", b"ygctfx", b"rdzesw", b"aqmnbv", b"lkjhgf", b"poiuyt", b"qwertz", b"poiuyr"], 1),

@@ -18,7 +18,12 @@ hdr = f"""# rocprofv3 PMC passes, one counter group per pass (MI355X, gfx950, RO
 
 """
 f, w = open(g("pmc_fetch.txt")).read(), open(g("pmc_write.txt")).read()
-open(P("pmc_hbm_traffic.txt"), "w").write(hdr + "## FETCH_SIZE (KiB per launch)\n" + f + "\n## WRITE_SIZE (KiB per launch, raw)\n" + w)
+lin = ""
+if os.path.exists(g("pmc_fetch_linear.txt")):
+    lin = ("\n## FETCH_SIZE (KiB per launch) of tools/linear_probe.py '[acgt]+' 'a.*b' (64 MiB = 65536 KiB single-run texts; x 2 for HBM bytes):\n"
+           "## run_summary + run_emit read the text once each (round 5's carry scan: cs_emit_kernel 4 581 077 KiB, cs_local_chain_kernel 3 717 552 KiB per launch)\n"
+           + open(g("pmc_fetch_linear.txt")).read())
+open(P("pmc_hbm_traffic.txt"), "w").write(hdr + "## FETCH_SIZE (KiB per launch)\n" + f + "\n## WRITE_SIZE (KiB per launch, raw)\n" + w + lin)
 
 
 def avg(txt, prefix):
@@ -115,7 +120,8 @@ open(P("pmc_sq_counters.txt"), "w").write(
     "#           --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-big   (MI355X)\n"
     "# per kernel: calls, avg / min / max of the counter per launch.  SQ_INSTS_VALU are WAVE instructions: / (text bytes / 1024) = per\n"
     "# 1-KiB chunk and wave = per 16 bytes and lane.\n" + open(g("pmc_sq.txt")).read())
-for src, dst in (("dense_probe.txt", "dense_probe.txt"), ("jrep_compare.txt", "jrep_compare.txt"), ("bench_sizes.txt", "bench_sizes.txt")):
+for src, dst in (("dense_probe.txt", "dense_probe.txt"), ("jrep_compare.txt", "jrep_compare.txt"), ("bench_sizes.txt", "bench_sizes.txt"),
+                 ("count_general_probe.txt", "count_general_probe.txt"), ("e2e_probe.txt", "e2e_probe.txt"), ("host_copy_probe.txt", "host_copy_probe.txt")):
     if os.path.exists(g(src)):
         shutil.copy(g(src), P(dst))
 open(P("bench_line.json"), "w").write(open(g("bench.json")).read().strip().splitlines()[-1] + "\n")

@@ -18,6 +18,10 @@ python $root/tools/rocpd_stats.py $(find /tmp/prof_full -name "*.db" | head -1) 
 # the linear-time carry scan and the dense / class patterns, first and warm calls
 rocprofv3 --kernel-trace --stats -d /tmp/prof_lin -o r -- python $root/tools/linear_probe.py > $out/prof_${tag}_linear_probe.txt 2> /tmp/lin.log
 python $root/tools/rocpd_stats.py $(find /tmp/prof_lin -name "*.db" | head -1) 24 > $out/prof_${tag}_kernel_stats_linear.txt
+# ... and what the run kernels fetch on `[acgt]+` / `a.*b` over 64 MiB (round 5's carry scan: 70-140 x the text)
+rm -rf /tmp/prof_linf
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_linf -o r -- python $root/tools/linear_probe.py "[acgt]+" "a.*b" > /dev/null 2> /tmp/linf.log
+python $root/tools/pmc_summary.py /tmp/prof_linf FETCH_SIZE > $out/prof_${tag}_pmc_fetch_linear.txt
 # PMC passes: one counter group per run (the big runs included: no more `traffic: null`)
 PMC_CMD="python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --jrep-files 2000 --jrep-bytes 200000000"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_f -o r -- $PMC_CMD > /dev/null 2> /tmp/f.log
@@ -32,6 +36,9 @@ cd $root
 python tools/jrep_compare.py 2>&1 | grep -v amdgpu.ids > $out/prof_${tag}_jrep_compare.txt
 python tools/bench_sizes.py all > $out/prof_${tag}_bench_sizes.txt 2>/dev/null
 python tools/dense_probe.py 1e9 > $out/prof_${tag}_dense_probe.txt 2>/dev/null
+python tools/count_general_probe.py 1000000000 30 2>/dev/null | grep -v amdgpu.ids > $out/prof_${tag}_count_general_probe.txt
+python tools/e2e_probe.py 50000000 3 2>/dev/null | grep -v amdgpu.ids > $out/prof_${tag}_e2e_probe.txt
+python tools/probes/repl_probe.py 2>/dev/null | grep -v amdgpu.ids > $out/prof_${tag}_host_copy_probe.txt
 tail -1 $out/prof_${tag}_bench.json | cut -c1-300
 head -6 $out/prof_${tag}_kernel_stats.txt | cut -c1-60,91-170
 head -14 $out/prof_${tag}_pmc_fetch.txt
