@@ -220,6 +220,20 @@ struct PlaneCountParams {
   unsigned long long* host_out;
 };
 void launch_plane_count(const PlaneCountParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
+// The same streaming loop and test with the candidates written to the shared candidate regions of the span pipeline instead of
+// classified in place (round 6: plane_scan<NB>'s successor -- 32 contiguous bytes per lane, code planes through the VGPR index
+// mode; region w = wave w, in text order; c.first_block / span_blocks / span_extra deal the blocks out, c.text / n / code_shift /
+// n_bases / mask_bits as for the count).  What plane_scan leaves behind, for classify_shared_multi.
+struct PlaneListParams {
+  PlaneCountParams c;
+  uint64_t* hits;        // shared candidate regions (starts s = w - offset)
+  uint32_t region_cap;
+  uint32_t offset;       // window offset inside a match (the same for all patterns)
+  uint32_t* hit_counts;  // [n_regions]
+  uint32_t n_zero;
+  unsigned long long* zero_counters[kMaxFused];  // counter blocks the kernel clears (one per pattern)
+};
+void launch_plane_list(const PlaneListParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 // the rows of that launch (grid workgroups) added up: counts, flags, bounds -> a.host_out and a.acc
 void launch_plane_count_finish(const PlaneCountParams& a, int grid, hipStream_t st);
 // launch_bounds_rows after a counts run: a pattern without a list (spans[p] == nullptr) takes its count and first /

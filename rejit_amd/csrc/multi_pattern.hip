@@ -676,7 +676,41 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       }
       if (!fused_launched) {
         m->flags_clean = false;
-        launch_plane_scan(pp, geo.grid, s0->t0(), s0->ev[2], st);
+        // round 6: plane_count's streaming loop (32 contiguous bytes per lane, code planes through the VGPR index mode, the
+        // blocks dealt out evenly) with the candidates written to the shared regions: plane_scan<NB> is kept behind RJ_PLANE_SCAN_V1
+        static const bool v1 = getenv("RJ_PLANE_SCAN_V1") != nullptr;   // measurement override
+        if (v1) {
+          launch_plane_scan(pp, geo.grid, s0->t0(), s0->ev[2], st);
+        } else {
+          PlaneListParams pl{};
+          pl.c.text = d_text;
+          pl.c.n = n;
+          pl.c.sb = sb;
+          pl.c.se = se;
+          pl.c.first_block = plane_wlo / 2048;
+          pl.c.end_block = pl.c.first_block + plane_pairs;
+          pl.c.span_blocks = plane_pairs / geo.n_regions;
+          pl.c.span_extra = static_cast<uint32_t>(plane_pairs % geo.n_regions);
+          pl.c.code_shift = m->plane.code_shift;
+          pl.c.n_bases = m->plane.n_bases;
+          pl.c.n_patterns = static_cast<uint32_t>(P);
+          pl.c.batch_at = 64;
+          for (uint32_t b = 0; b < 2; b++) {
+            const uint32_t bb = b < m->plane.n_bases ? b : 0;
+            for (int i = 0; i < 8; i++) {
+              const uint32_t code = (static_cast<uint32_t>(m->plane.base[bb][i]) >> m->plane.code_shift) & 3u;
+              if (!(code & 1u)) pl.c.mask_bits |= 1u << (16 * b + 2 * i);
+              if (!(code & 2u)) pl.c.mask_bits |= 1u << (16 * b + 2 * i + 1);
+            }
+          }
+          pl.hits = pp.hits;
+          pl.region_cap = pp.region_cap;
+          pl.offset = pp.offset;
+          pl.hit_counts = pp.hit_counts;
+          pl.n_zero = pp.n_zero;
+          for (uint32_t p = 0; p < pp.n_zero; p++) pl.zero_counters[p] = pp.zero_counters[p];
+          launch_plane_list(pl, geo.grid, s0->t0(), s0->ev[2], st);
+        }
       }
     } else if (fuse) {
       launch_scan_windows_fused(fp, geo.grid, s0->t0(), s0->ev[2], st);

@@ -271,6 +271,7 @@ struct ExactShape {
   using Args = PlaneCountParams;
   static constexpr uint32_t kFixedLen = 8;
   static constexpr bool kBlobInLds = false;
+  static constexpr bool kList = false;
   __device__ static __forceinline__ const PlaneCountParams& common(const Args& g) { return g; }
   __device__ static __forceinline__ uint32_t lmax(const Args&) { return 8u; }
   __device__ static __forceinline__ uint32_t offset_of(const Args&, const uint32_t*, uint32_t) { return 0u; }
@@ -287,6 +288,21 @@ struct ExactShape {
     mask = exact_classify<NB>(table, a.base_lo, a.base_hi, lo, hi);
     mask = ok ? mask : 0u;
   }
+};
+
+// ListShape<NB>: ExactShape's test, the candidates not classified but written, in text order, to the wave's region of the
+// span pipeline's shared candidate list (kernels.h: PlaneListParams) -- plane_scan<NB> in this kernel's layout.
+template <int NB>
+struct ListShape {
+  using Args = PlaneListParams;
+  static constexpr uint32_t kFixedLen = 8;
+  static constexpr bool kBlobInLds = false;
+  static constexpr bool kList = true;
+  __device__ static __forceinline__ const PlaneCountParams& common(const Args& g) { return g.c; }
+  __device__ static __forceinline__ uint32_t lmax(const Args&) { return 8u; }
+  __device__ static __forceinline__ uint32_t offset_of(const Args&, const uint32_t*, uint32_t) { return 0u; }
+  __device__ static __forceinline__ uint32_t test(uint32_t ta, uint32_t tb, uint32_t hb, const Args& g) { return plane_test<NB>(ta, tb, hb, g.c); }
+  __device__ static __forceinline__ void classify(const Args&, const uint32_t*, uint64_t, bool, uint32_t& mask, Lens&) { mask = 0; }
 };
 
 namespace {
@@ -373,6 +389,7 @@ struct GeneralShape {
   using Args = PlaneCountGParams;
   static constexpr uint32_t kFixedLen = 0;
   static constexpr bool kBlobInLds = true;
+  static constexpr bool kList = false;
   __device__ static __forceinline__ const PlaneCountParams& common(const Args& g) { return g.c; }
   __device__ static __forceinline__ uint32_t lmax(const Args& g) { return g.lmax; }
   __device__ static __forceinline__ uint32_t offset_of(const Args&, const uint32_t* blob, uint32_t p) {
@@ -446,20 +463,31 @@ struct WaveState {
   // (offsets of the candidate, i.e. of the window; kNoEnd: none yet).  The last one is also the selection's state: the
   // match the next one of the pattern must not begin inside.
   uint32_t* ends;
+  // ListShape: the wave's region in device memory (slot = the candidate's start as an absolute offset), its capacity
+  uint64_t* list;
+  uint32_t list_cap;
+  uint64_t list_base;    // the span's first byte minus the windows' offset inside a match
 };
 constexpr uint32_t kNoEnd = 0xFFFFFFFFu;
 
-// the candidates of one block, in text order, to the ring
+// the candidates of one block, in text order, to the ring (LIST: to the wave's region in device memory; w.tail counts them)
+template <bool LIST>
 __device__ __forceinline__ void push_block(WaveState& w, uint32_t hm, uint32_t rel_lane) {
   const uint64_t any = __ballot(hm != 0);
   if (any == 0) return;  // wave-uniform
+  auto put = [&](uint32_t idx, uint32_t rel) {
+    if (LIST) {
+      if (idx < w.list_cap) w.list[idx] = w.list_base + rel;
+    } else {
+      w.ring[idx & (kRing - 1)] = rel;
+    }
+  };
   const uint64_t several = __ballot((hm & (hm - 1)) != 0);
   if (several == 0) {
     // the usual case: no lane holds two candidates
     if (hm != 0) {
       const uint32_t bit = static_cast<uint32_t>(__builtin_ctz(hm));
-      const uint32_t idx = w.tail + lanes_below(any);
-      w.ring[idx & (kRing - 1)] = rel_lane + (bit >> 1) + ((bit & 1u) << 4);
+      put(w.tail + lanes_below(any), rel_lane + (bit >> 1) + ((bit & 1u) << 4));
     }
     w.tail += static_cast<uint32_t>(__popcll(any));
     return;
@@ -467,10 +495,10 @@ __device__ __forceinline__ void push_block(WaveState& w, uint32_t hm, uint32_t r
   const uint32_t c = __popc(hm);
   const uint32_t inc = wave_inclusive_sum(c);
   const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(inc), kWave - 1));
-  if (tot <= kRing) {   // (more: the caller's occupancy test voids the run; nothing is written)
+  if (LIST || tot <= kRing) {   // (ring: more -- the caller's occupancy test voids the run; nothing is written)
     uint32_t idx = w.tail + inc - c;
-    for (uint32_t m = hm & 0x55555555u; m; m &= m - 1, idx++) w.ring[idx & (kRing - 1)] = rel_lane + (static_cast<uint32_t>(__builtin_ctz(m)) >> 1);
-    for (uint32_t m = hm & 0xAAAAAAAAu; m; m &= m - 1, idx++) w.ring[idx & (kRing - 1)] = rel_lane + 16u + (static_cast<uint32_t>(__builtin_ctz(m)) >> 1);
+    for (uint32_t m = hm & 0x55555555u; m; m &= m - 1, idx++) put(idx, rel_lane + (static_cast<uint32_t>(__builtin_ctz(m)) >> 1));
+    for (uint32_t m = hm & 0xAAAAAAAAu; m; m &= m - 1, idx++) put(idx, rel_lane + 16u + (static_cast<uint32_t>(__builtin_ctz(m)) >> 1));
   }
   w.tail += tot;
 }
@@ -630,6 +658,16 @@ __global__ __launch_bounds__(256) void plane_count(typename S::Args g) {
   w.prev_rel = w.prev_valid = 0;
   w.ends[lane] = kNoEnd;   // (4 x 32 entries: two per lane)
   w.ends[lane + 64] = kNoEnd;
+  w.list = nullptr;
+  w.list_cap = 0;
+  w.list_base = 0;
+  if constexpr (S::kList) {
+    if (wave == 0 && lane < kCntSize)
+      for (uint32_t p = 0; p < g.n_zero; p++) g.zero_counters[p][lane] = 0;
+    w.list = g.hits + static_cast<uint64_t>(wave) * g.region_cap;
+    w.list_cap = g.region_cap;
+    w.list_base = span_base - g.offset;   // (a window before `offset` wraps to a start beyond every range: dropped by the classification)
+  }
   bool first_batch = true;
 
   // A wave never loads a block that is not its own: prefetches beyond the span's last fast block are clamped to that
@@ -648,7 +686,9 @@ __global__ __launch_bounds__(256) void plane_count(typename S::Args g) {
     behind = *reinterpret_cast<const uint2*>(a.text + static_cast<uint64_t>(fast_end) * kBlock);   // (block fast_end lies inside the text)
   }
   // the table / the blob (all waves), before the first wait for text
-  if (S::kBlobInLds) {
+  if (S::kList) {
+    // (nothing to stage: the candidates are classified by the next kernel)
+  } else if (S::kBlobInLds) {
     const uint4* src = reinterpret_cast<const uint4*>(a.table);
     uint4* dst = reinterpret_cast<uint4*>(blob);
     for (uint32_t i = threadIdx.x; i < a.table_words / 4; i += blockDim.x) dst[i] = src[i];
@@ -670,7 +710,7 @@ __global__ __launch_bounds__(256) void plane_count(typename S::Args g) {
       {
         const uint32_t hb = from_lane_above(xa, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ya))));
         const uint32_t hm = S::test(xa, xb, hb, g);
-        push_block(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
+        push_block<S::kList>(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
       }
       __builtin_amdgcn_sched_barrier(0);
       xa = codes16(ra.a, k);   // block c + 2 (the span's last fast block again when c + 2 == fast_end: not used then)
@@ -681,19 +721,19 @@ __global__ __launch_bounds__(256) void plane_count(typename S::Args g) {
         const uint32_t next0 = c + 2 == fast_end ? behind_codes : static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xa)));
         const uint32_t hb = from_lane_above(ya, next0);
         const uint32_t hm = S::test(ya, yb, hb, g);
-        push_block(w, hm, (c + 1 - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
+        push_block<S::kList>(w, hm, (c + 1 - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
       }
       __builtin_amdgcn_sched_barrier(0);
       c += 2;
-      if (w.tail - w.head >= a.batch_at) blocks_done<S>(w, tab, g, span_base, first_batch);
+      if (!S::kList && w.tail - w.head >= a.batch_at) blocks_done<S>(w, tab, g, span_base, first_batch);
     }
     if (c + 1 == fast_end) {   // an odd block left: x holds its codes; behind it the span ends
       const uint32_t hb = from_lane_above(xa, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(behind_codes))));
       const uint32_t hm = S::test(xa, xb, hb, g);
-      push_block(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
+      push_block<S::kList>(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
       c++;
     }
-    blocks_done<S>(w, tab, g, span_base, first_batch);
+    if (!S::kList) blocks_done<S>(w, tab, g, span_base, first_batch);
   }
   // the block(s) at the end of the text: guarded loads, the 8 bytes behind the lane's 32 read by the lane itself
   for (; c < c1; c++) {
@@ -710,8 +750,12 @@ __global__ __launch_bounds__(256) void plane_count(typename S::Args g) {
     const uint32_t h0 = guarded_dword(a.text, a.n, at + 32), h1 = guarded_dword(a.text, a.n, at + 36);
     const uint32_t hb = (codes4(h0, k) >> k.shift) | (codes4(h1, k) << (8 - k.shift));
     const uint32_t hm = S::test(codes16(va, k), codes16(vb, k), hb, g);
-    if (w.tail - w.head > kRing - 64u) blocks_done<S>(w, tab, g, span_base, first_batch);   // (room for this block)
-    push_block(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
+    if (!S::kList && w.tail - w.head > kRing - 64u) blocks_done<S>(w, tab, g, span_base, first_batch);   // (room for this block)
+    push_block<S::kList>(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
+  }
+  if constexpr (S::kList) {
+    if (lane == 0) g.hit_counts[wave] = w.tail;   // (also beyond the region's capacity: the classification reports the overflow)
+    return;
   }
   // what the ring still holds
   if (w.tail - w.head > kRing) {
@@ -909,6 +953,11 @@ void launch_bounds_rows_counts(const BoundsParams& a, const unsigned long long* 
 void launch_plane_count(const PlaneCountParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
   if (a.n_bases <= 1) hipExtLaunchKernelGGL((plane_count<ExactShape<1>>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
   else hipExtLaunchKernelGGL((plane_count<ExactShape<2>>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+}
+
+void launch_plane_list(const PlaneListParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+  if (a.c.n_bases <= 1) hipExtLaunchKernelGGL((plane_count<ListShape<1>>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+  else hipExtLaunchKernelGGL((plane_count<ListShape<2>>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
 }
 
 // max_words / max_short: the largest n_words / short_max among the patterns (the instantiation)
