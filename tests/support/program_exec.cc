@@ -13,6 +13,7 @@
 
 #include "../../rejit_amd/csrc/exact_count.h"
 #include "../../rejit_amd/csrc/lowering.h"
+#include "../../rejit_amd/csrc/run_scan.h"
 #include "../../rejit_amd/csrc/table_layout.h"
 
 using namespace rejit_amd;
@@ -402,6 +403,58 @@ uint32_t pe_exact_classify(const uint32_t* table, const uint32_t* base, int n_ba
   memcpy(&lo, bytes8, 4);
   memcpy(&hi, bytes8 + 4, 4);
   return n_bases > 1 ? exact_classify<2>(table, base, base + 2, lo, hi) : exact_classify<1>(table, base, base + 2, lo, hi);
+}
+
+// run_scan.h on the CPU: the plan (make_run_plan: which patterns have ONE long-lived thread in one loop position; its classes as
+// byte ranges or complements) and the segment rule the kernels implement -- per segment between two breaks the first A and the
+// last B behind it -- walked byte by byte.  Returns the number of matches, -101 when the pattern does not have the shape, a
+// negative lowering status; shape[0..3]: has_b, n_ranges, the three classes' complement flags packed, 0.
+long pe_run_match_all(const char* re, const uint8_t* text, uint64_t n, uint64_t* out, uint64_t cap, uint32_t* shape) {
+  LowerResult lr = lower(re);
+  if (lr.status != 0) return lr.status;
+  const RunPlan pl = make_run_plan(*lr.program);
+  if (!pl.ok) return -101;
+  shape[0] = pl.has_b;
+  shape[1] = pl.n_ranges;
+  shape[2] = pl.a_neg | (pl.l_neg << 1) | (pl.b_neg << 2);
+  shape[3] = 0;
+  // a byte's membership from the plan's encoding (what rj_stream_range computes in the kernel)
+  auto in_class = [&](uint8_t c, uint32_t ranges, uint32_t neg) {
+    bool in = false;
+    for (uint32_t r = 0; r < pl.n_ranges; r++) {
+      if (!((ranges >> r) & 1u)) continue;
+      const uint32_t lo = 0x80u - (pl.add_lo[r] & 0xFFu), hi = 0x7fu - (pl.add_hi[r] & 0xFFu);
+      const uint32_t half = (pl.high_half >> r) & 1u;
+      if ((static_cast<uint32_t>(c) >> 7) == half && (c & 0x7fu) >= lo && (c & 0x7fu) <= hi) in = true;
+    }
+    return in != (neg != 0);
+  };
+  uint64_t k = 0;
+  const uint64_t none = ~0ull;
+  uint64_t s1 = none, q = none;
+  for (uint64_t p = 0; p <= n; p++) {
+    const bool at_end = p == n;
+    const uint8_t c = at_end ? 0 : text[p];
+    const bool brk = at_end || !in_class(c, pl.l_ranges, pl.l_neg);
+    if (brk) {
+      // B may be the break itself; a start lies before it
+      if (!at_end && pl.has_b && s1 != none && in_class(c, pl.b_ranges, pl.b_neg)) q = p;
+      if (s1 != none && (!pl.has_b || q != none)) {
+        if (k < cap) {
+          out[2 * k] = s1;
+          out[2 * k + 1] = pl.has_b ? q + 1 : p;
+        }
+        k++;
+      }
+      s1 = none;
+      q = none;
+      if (!at_end && in_class(c, pl.a_ranges, pl.a_neg)) s1 = p;   // the next segment's starts begin AT the break
+      continue;
+    }
+    if (pl.has_b && s1 != none && in_class(c, pl.b_ranges, pl.b_neg)) q = p;
+    if (s1 == none && in_class(c, pl.a_ranges, pl.a_neg)) s1 = p;
+  }
+  return static_cast<long>(k);
 }
 
 }  // extern "C"

@@ -1,0 +1,92 @@
+"""CPU test of the run plan (rejit_amd/csrc/run_scan.h; kernels: run_scan.hip, `-m gpu`: tests/test_gpu_runs.py): which patterns have
+ONE long-lived thread in one loop position (`X+`, `A L*`, `X+ B`, `A L* B`), the encoding of their classes as byte ranges or
+complements, and the rule the kernels implement -- every segment between two breaks holds at most one match, (its first A, the last
+B behind it) -- walked byte by byte on the CPU against the oracle (the strict restatement of the reference's NFA loop,
+src/x64/codegen-x64.cc:535-640) on random patterns of the four shapes and texts of every break density."""
+import ctypes
+import os
+import random
+import subprocess
+
+import pytest
+
+from checkers import Oracle
+from test_lowering import SO, SRCS, ROOT
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+@pytest.fixture(scope="module")
+def pe():
+    deps = SRCS + [os.path.join(ROOT, "rejit_amd", "csrc", h) for h in ("lowering.h", "exact_count.h", "table_layout.h", "run_scan.h", "dense_streams.h")]
+    if not os.path.exists(SO) or any(os.path.getmtime(SO) < os.path.getmtime(s) for s in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", SO] + SRCS)
+    lib = ctypes.CDLL(SO)
+    lib.pe_run_match_all.restype = ctypes.c_long
+    lib.pe_run_match_all.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, _u64p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
+    return lib
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return Oracle()
+
+
+def run(pe, rx, text):
+    cap = len(text) + 2
+    out = (ctypes.c_uint64 * (2 * cap))()
+    shape = (ctypes.c_uint32 * 4)()
+    k = pe.pe_run_match_all(rx, text, len(text), out, cap, shape)
+    if k < 0:
+        return k, None, None
+    return k, [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(k)], list(shape)
+
+
+def test_shapes_taken_and_refused(pe):
+    for rx in (b"[acgt]+", b"[^>]+", b"x+", b"a[bc]*", b"a.*b", b"<[^>]*>", b"[a-f]+[0-9]", b"[\\x80-\\xff]+", b"q[a-z]*[0-9]", b"[ab]+b", b"a.*a"):
+        k, spans, shape = run(pe, rx, b"")
+        assert k == 0, (rx, k)
+    # `.` is "not \\n, not \\r": the complement of two ranges, not the four ranges of its members
+    k, _, shape = run(pe, b"a.*b", b"")
+    assert shape[0] == 1 and (shape[2] >> 1) & 1 == 1 and shape[1] <= 4, shape
+    # (`"[^"]*"`: the closing quote is a break AND may open the next match -- whether it does depends on the match before it:
+    # the one byte class run_scan.h excludes)
+    for rx in (b"\"[^\"]*\"", b"a.*b|c", b"(ab)+", b"a+b+", b"x*", b"^a.*b", b"a.+b", b"abc", b"[ab]+c|[bc]+d", b"a.*bc"):
+        k, _, _ = run(pe, rx, b"")
+        assert k == -101, (rx, k)
+
+
+def test_segment_rule_equals_oracle(pe, oracle):
+    rng = random.Random(5)
+    pool = list(b"abcdxyz019<>\"\n ") + [0x80, 0xa5, 0xff]
+
+    def cls(alphabet):
+        members = sorted(set(rng.sample(alphabet, rng.randint(1, min(4, len(alphabet))))))
+
+        def esc(c):
+            return b"\\x%02x" % c if (c >= 0x7f or c < 0x20 or chr(c) in "\\[]^-") else bytes([c])
+        if rng.random() < 0.75:
+            return b"[" + b"".join(esc(c) for c in members) + b"]"
+        return b"[^" + b"".join(esc(c) for c in members) + b"]"
+
+    taken = 0
+    for case in range(1500):
+        alphabet = rng.sample(pool, rng.randint(2, 7))
+        a, l, b = cls(alphabet), cls(alphabet), cls(alphabet)
+        rx = rng.choice([a + b"+", a + l + b"*", a + l + b"*" + b, a + b"+" + b, a + b".*" + b])
+        n = rng.choice([0, 1, 2, 17, 300, 5000])
+        if rng.random() < 0.5:
+            text = bytes(rng.choices(alphabet, k=n))
+        else:
+            text = bytearray(rng.choices(alphabet[:2], k=n))
+            for _ in range(rng.choice([0, 1, 5])):
+                if n:
+                    text[rng.randrange(n)] = rng.choice(alphabet)
+            text = bytes(text)
+        k, spans, _ = run(pe, rx, text)
+        if k == -101:
+            continue
+        assert k >= 0, (rx, k)
+        taken += 1
+        assert spans == oracle.match_all(rx, text), (rx, text[:80], spans[:4])
+    assert taken > 700
