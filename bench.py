@@ -105,6 +105,7 @@ def parse_args():
     ap.add_argument("--one-stream", action="store_true", help="headline loop as in round 3: both rj_multi objects and their tails on one stream")
     ap.add_argument("--jrep-files", type=int, default=100_000, help="jrep_10gb extra: files (BASELINE configs[4]: 100 000)")
     ap.add_argument("--jrep-bytes", type=int, default=10_000_000_000, help="jrep_10gb extra: total bytes (BASELINE configs[4]: 10 GB)")
+    ap.add_argument("--jrep-threads", type=int, default=1, help="jrep_10gb extra: caller threads, each with its own batches (the reference's jrep -j)")
     ap.add_argument("--no-extra", action="store_true", help="headline only")
     ap.add_argument("--tail-streams-probe", action="store_true", help="internal: the child process of the tails_on_own_streams extra")
     ap.add_argument("--no-big", action="store_true", help="skip the 50 GB and 2.5 GB extras")
@@ -1510,28 +1511,42 @@ def jrep_extra(args, c, out):
     total = sum(len(f) for f in files)
     prog, sol = rejit_amd.Program(b"regexp"), rejit_amd.Program(b"^")
 
+    # the batches of one pass: files [b, e) of at most 256 MiB
+    batches, at = [], 0
+    while at < n_files:
+        b, size = at, 0
+        while at < n_files and (at == b or size + len(files[at]) <= (256 << 20)):
+            size += len(files[at])
+            at += 1
+        batches.append((b, at))
+    n_threads = max(1, int(getattr(args, "jrep_threads", 1)))
+
+    def one_batch(be):
+        b, e = be
+        res = prog.match_all_batch_counts(files[b:e])
+        idx = [b + i for i, k in enumerate(res) if k]
+        lc = sol.match_all_batch_counts([files[i] for i in idx]) if idx else []
+        return [(i, res[i - b], l) for i, l in zip(idx, lc)]
+
     def one_pass():
-        hits, lines, at, rows = 0, 0, 0, []
-        while at < n_files:
-            b, size = at, 0
-            while at < n_files and (at == b or size + len(files[at]) <= (256 << 20)):
-                size += len(files[at])
-                at += 1
-            res = prog.match_all_batch_counts(files[b:at])
-            idx = [b + i for i, k in enumerate(res) if k]
-            hits += len(idx)
-            if idx:
-                lc = sol.match_all_batch_counts([files[i] for i in idx])
-                lines += sum(lc)
-                rows.extend((i, res[i - b], l) for i, l in zip(idx, lc))
-        return hits, lines, rows
+        # (--jrep-threads N: caller threads as the reference's jrep has them, sample/jrep.cc:408-493, each with its own batches and
+        # its own scratch below the boundary.  Measured, round 6: 1 thread 41 GB/s, 2: 37, 3: 33, 4: 29 -- the batches' packing and
+        # uploads contend for the same host memory and the same link; one caller is the default)
+        if n_threads == 1:
+            parts = [one_batch(be) for be in batches]
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=n_threads) as pool:
+                parts = list(pool.map(one_batch, batches))
+        rows = [r for part in parts for r in part]
+        return len(rows), sum(r[2] for r in rows), rows
 
     one_pass()
     t0 = time.perf_counter()
     hits, lines, rows = one_pass()
     dt = time.perf_counter() - t0
     rec = {"workload": "jrep shape at BASELINE size: %d files, %d bytes (log-normal sizes, sigma 1.8), needle in 1 %% of them; rj_match_all_batch in "
-                       "256 MiB batches + `^` line tables of the files with matches; host buffers, PCIe included" % (n_files, total),
+                       "256 MiB batches + `^` line tables of the files with matches, %d caller thread(s) (the reference's jrep: a worker pool, sample/jrep.cc:408-493); host buffers, PCIe included" % (n_files, total, n_threads),
            "value": round(total / dt / 1e9, 2), "unit": "GB/s end to end", "seconds": round(dt, 3), "files_with_matches": hits, "line_starts": lines}
     fx = fullsize_fixture()
     if fx and "c5" in fx and fx["c5"]["files"] == n_files and fx["c5"]["bytes_asked"] == args.jrep_bytes:

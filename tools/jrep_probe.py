@@ -12,8 +12,8 @@ if sweep and "RJ_COPY_THREADS" not in os.environ:
         subprocess.call([sys.executable, __file__, str(files), str(nbytes)], env=dict(os.environ, RJ_COPY_THREADS=th))
     sys.exit(0)
 import bench
-args = types.SimpleNamespace(jrep_files=files, jrep_bytes=nbytes, no_cpu_baseline=True)
+args = types.SimpleNamespace(jrep_files=files, jrep_bytes=nbytes, no_cpu_baseline=True, jrep_threads=int(os.environ.get("JREP_THREADS", "1")))
 out = {}
 bench.jrep_extra(args, None, out)
 r = out["jrep_10gb"]
-print("RJ_COPY_THREADS=%s: %s GB/s end to end, %s s, parity: %s" % (os.environ.get("RJ_COPY_THREADS", "default"), r["value"], r["seconds"], "parity_full_size" in r), flush=True)
+print("JREP_THREADS=%s RJ_COPY_THREADS=%s: %s GB/s end to end, %s s, parity: %s" % (os.environ.get("JREP_THREADS", "1"), os.environ.get("RJ_COPY_THREADS", "default"), r["value"], r["seconds"], "parity_full_size" in r), flush=True)
