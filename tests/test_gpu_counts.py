@@ -355,34 +355,17 @@ def test_other_set_shapes(rj, oracle):
     assert m3.run(t3.data_ptr(), len(data3)) == oracle_counts(oracle, [b"agggtaaa|tttaccct", b"agggtaaa[acgt]+x"], data3) and m3.how != 3
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_counts_in_counts_mode(rj, oracle, W, world):
-    """rj_multi_device_counts_via over shards of one text on the one device (a thread, a stream and an rj_multi per shard,
-    the all-gather played by a barrier and device-to-device copies, as tests/test_gpu_device_counts.py), every shard's
-    object in counts mode: the rows of the carry exchange come from the kernel's first / last match per pattern.  One
-    cut has a pair of overlapping matches of pattern 0 across it (the right shard must re-select under the carry), one
-    cut goes through a match."""
+def _sharded_counts(rj, oracle, patterns, text, world, halo, cut_align=1024):
+    """rj_multi_device_counts_via over `world` shards of one text on the one device (a thread, a stream and an rj_multi per shard,
+    the all-gather played by a barrier and device-to-device copies, as tests/test_gpu_device_counts.py), every shard's object in
+    counts mode; returns (per-rank counts, per-rank `how`)."""
     import ctypes
     import threading
     import torch
     from rejit_amd import api, sharding
     dev = torch.device("cuda:0")
-    rng = random.Random(15 + world)
-    n = 300000
-    t = spaced_text(rng, n, b"ac", regexdna_strings())   # (background of a / c only: no match outside the planted strings)
-    ranges = sharding.partition(n, world, align=1024)
-    cut1 = ranges[0][1]
-    t[cut1 - 4:cut1 - 4 + 15] = b"agggtaaagggtaaa"          # first match begins left of the cut, the second right of it
-    for i in range(cut1 - 60, cut1 - 4):                      # (keep other matches of pattern 0 away from the pair)
-        t[i] = ord("c")
-    for i in range(cut1 + 11, cut1 + 60):
-        t[i] = ord("c")
-    if world > 2:
-        cut2 = ranges[1][1]
-        t[cut2 - 3:cut2 + 5] = b"tttaccct"
-    text = bytes(t)
-    patterns = W.REGEXDNA_PATTERNS
-    want = oracle_counts(oracle, patterns, text)
+    n = len(text)
+    ranges = sharding.partition(n, world, align=cut_align)
     hip = ctypes.CDLL("libamdhip64.so.7")
     hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
     hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
@@ -393,7 +376,7 @@ def test_sharded_counts_in_counts_mode(rj, oracle, W, world):
     def rank_main(rank):
         try:
             own = ranges[rank]
-            lo, hi = sharding.visible_range(n, own, 8)
+            lo, hi = sharding.visible_range(n, own, halo)
             shard = torch.frombuffer(bytearray(text[lo:hi]), dtype=torch.uint8).to(dev)
             stream = torch.cuda.Stream(dev)
             multi = rj.MultiScan([rj.Program(p) for p in patterns])
@@ -426,6 +409,61 @@ def test_sharded_counts_in_counts_mode(rj, oracle, W, world):
     for th in threads:
         th.join(timeout=300)
     assert not errors, errors
+    return results, hows, ranges
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_counts_in_counts_mode(rj, oracle, W, world):
+    """Every shard's object in counts mode: the rows of the carry exchange come from the kernel's first / last match per pattern.
+    One cut has a pair of overlapping matches of pattern 0 across it (the right shard must re-select under the carry), one
+    cut goes through a match."""
+    from rejit_amd import sharding
+    rng = random.Random(15 + world)
+    n = 300000
+    t = spaced_text(rng, n, b"ac", regexdna_strings())   # (background of a / c only: no match outside the planted strings)
+    ranges = sharding.partition(n, world, align=1024)
+    cut1 = ranges[0][1]
+    t[cut1 - 4:cut1 - 4 + 15] = b"agggtaaagggtaaa"          # first match begins left of the cut, the second right of it
+    for i in range(cut1 - 60, cut1 - 4):                      # (keep other matches of pattern 0 away from the pair)
+        t[i] = ord("c")
+    for i in range(cut1 + 11, cut1 + 60):
+        t[i] = ord("c")
+    if world > 2:
+        cut2 = ranges[1][1]
+        t[cut2 - 3:cut2 + 5] = b"tttaccct"
+    text = bytes(t)
+    patterns = W.REGEXDNA_PATTERNS
+    want = oracle_counts(oracle, patterns, text)
+    results, hows, _ = _sharded_counts(rj, oracle, patterns, text, world, 8)
+    for rank in range(world):
+        assert results[rank] == want, (rank, results[rank], want)
+        assert hows[rank] == 3, (rank, hows)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_counts_of_a_general_set(rj, oracle, W, world):
+    """The same exchange with the GENERAL form of the count kernel (round 6): literals of different lengths, so the rows carry
+    first / last matches with their own lengths; one cut goes through a long match, one has two overlapping matches of one pattern
+    (`abcabcabc` inside `abcabcabcabc...`) across it -- the right shard's first match begins inside the left shard's last."""
+    from rejit_amd import sharding
+    rng = random.Random(25 + world)
+    patterns = ["alternation|strings", "prefix abcd|prefix 1234", "abcabcabc"]
+    strings = [b"alternation", b"strings", b"prefix abcd", b"prefix 1234", b"abcabcabc", b"alternatio", b"prefix 12"]
+    n = 300000
+    t = spaced_text(rng, n, b"xyz 09", strings)
+    ranges = sharding.partition(n, world, align=1024)
+    cut1 = ranges[0][1]
+    for i in range(cut1 - 80, cut1 + 80):
+        t[i] = ord("x")
+    t[cut1 - 5:cut1 - 5 + 15] = b"abcabcabcabcabc"            # matches of `abcabcabc` at -5 (kept), -2 and +1 (inside it)
+    if world > 2:
+        cut2 = ranges[1][1]
+        for i in range(cut2 - 40, cut2 + 40):
+            t[i] = ord("y")
+        t[cut2 - 6:cut2 + 5] = b"alternation"
+    text = bytes(t)
+    want = oracle_counts(oracle, patterns, text)
+    results, hows, _ = _sharded_counts(rj, oracle, patterns, text, world, 16)
     for rank in range(world):
         assert results[rank] == want, (rank, results[rank], want)
         assert hows[rank] == 3, (rank, hows)

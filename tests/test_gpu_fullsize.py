@@ -141,6 +141,67 @@ def test_counts_only_beyond_4gib(env):
     assert sc.count(text.data_ptr(), n, stream=st) == c[0] and sc.stats()["count_path"] == 1
 
 
+def test_run_kernels_beyond_4gib(env):
+    """The run kernels (run_scan.hip: `[acgt]+`, one long-lived thread in one loop position) on the 4.3 GB FASTA text: its last
+    2.15 GB are ONE run of acgt, sequence TWO (1.29 GB) is runs of acgt between IUB codes, sequence ONE is upper case.  The runs are
+    computed independently with torch, chunk by chunk (count, sum of begins, sum of lengths, the longest), and a range that begins
+    beyond 4 GiB must give the tail of the one long run's ... nothing: the run began before the range, so a fresh start at the range's
+    begin reports (begin, n) -- the independent-range semantics of include/rejit_hip.h."""
+    rj, W, torch, dev, doc = env
+    fasta_n = 430000000
+    text = W.fasta_stripped_torch(fasta_n, dev)
+    n = int(text.numel())
+    assert n > (1 << 32)
+    lut = torch.zeros(256, dtype=torch.uint8, device=dev)
+    lut[torch.tensor(list(b"acgt"), device=dev)] = 1
+    count, sum_begin, sum_len, longest, prev_inside, open_begin = 0, 0, 0, 0, False, 0
+    step = 1 << 28
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        inside = lut[text[lo:hi].long()].bool()
+        prev = torch.cat([torch.tensor([prev_inside], device=dev), inside[:-1]])
+        begins = torch.nonzero(inside & ~prev).flatten() + lo
+        nxt_zero = torch.nonzero(~inside & prev).flatten() + lo        # ends: the first byte outside a run
+        count += int(begins.numel())
+        sum_begin += int(begins.sum().item())
+        # lengths: pair the ends with the begins in order (a run open at the chunk's begin closes with the first end)
+        b_list = ([open_begin] if prev_inside else []) + begins.tolist() if begins.numel() < 2_000_000 else None
+        if b_list is None:
+            # (sequence TWO: millions of short runs per chunk -- pair them on the device)
+            bb = torch.cat([torch.tensor([open_begin], device=dev, dtype=begins.dtype), begins]) if prev_inside else begins
+            k = int(nxt_zero.numel())
+            lens = nxt_zero - bb[:k]
+            sum_len += int(lens.sum().item())
+            longest = max(longest, int(lens.max().item()) if k else 0)
+            prev_inside = bool(inside[-1].item())
+            open_begin = int(bb[k].item()) if prev_inside else 0
+        else:
+            e_list = nxt_zero.tolist()
+            for b, e in zip(b_list, e_list):
+                sum_len += e - b
+                longest = max(longest, e - b)
+            prev_inside = bool(inside[-1].item())
+            open_begin = b_list[len(e_list)] if prev_inside else 0
+        del inside, prev, begins, nxt_zero
+    if prev_inside:
+        sum_len += n - open_begin
+        longest = max(longest, n - open_begin)
+    sc = rj.Scan(rj.Program(b"[acgt]+"))
+    cnt = sc.run_tensor(text)
+    st = sc.stats()
+    assert st["run_path"] == 1 and st["linear_path"] == 0, st
+    sp = sc.spans_tensor(dev)
+    assert cnt == count == int(sp.shape[0])
+    assert int(sp[:, 0].sum().item()) == sum_begin
+    lens = sp[:, 1] - sp[:, 0]
+    assert int(lens.sum().item()) == sum_len and int(lens.max().item()) == longest and longest > 2_000_000_000
+    assert int(sp[-1, 1].item()) == n                                   # the last run ends with the text
+    # a range that begins beyond 4 GiB, inside the long run
+    ob = (1 << 32) + 4097
+    k = sc.run_tensor(text, own_begin=ob, own_end=n + 1)
+    assert k == 1 and sc.spans() == [(ob, n)]
+
+
 def test_c2_literal_5gb(env):
     rj, W, torch, dev, doc = env
     c2 = doc["c2"]
