@@ -8,8 +8,8 @@ from typing import List, Optional, Tuple
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-SOURCES = ["kernels.hip", "plane_scan.hip", "plane_count.hip", "run_scan.hip", "emit_scan.hip", "dense_streams.hip", "dense_streams_select.hip", "verify_lds.hip", "carry_kernels.hip", "engine.hip", "multi_pattern.hip", "host_api.hip", "linear.hip", "exact_replay.hip", "multi_device.hip", "parser.cc", "lowering.cc", "rejit_api.cc"]
-HEADERS = ["kernels.h", "device_program.h", "lowering.h", "carry_scan.h", "behind_walk.h", "exact_replay.h", "engine_internal.h", "table_layout.h", "lds_walk.h", "trace_stamp.h", "dense_swar.h", "dense_streams.h", "tile_lookback.h", "exact_count.h", "short_walk.h", "run_scan.h", "dense_streams.hip"]  # (dense_streams_select.hip includes dense_streams.hip)
+SOURCES = ["kernels.hip", "scan_windows.hip", "dense_walk.hip", "select_kernels.hip", "plane_scan.hip", "plane_count.hip", "run_scan.hip", "emit_scan.hip", "dense_streams.hip", "dense_streams_select.hip", "verify_lds.hip", "carry_kernels.hip", "engine.hip", "multi_pattern.hip", "host_api.hip", "linear.hip", "exact_replay.hip", "multi_device.hip", "parser.cc", "lowering.cc", "rejit_api.cc"]
+HEADERS = ["kernels.h", "device_program.h", "lowering.h", "carry_scan.h", "behind_walk.h", "exact_replay.h", "engine_internal.h", "table_layout.h", "lds_walk.h", "trace_stamp.h", "dense_swar.h", "dense_streams.h", "tile_lookback.h", "exact_count.h", "short_walk.h", "run_scan.h", "kernel_util.h", "dense_streams.hip"]  # (dense_streams_select.hip includes dense_streams.hip)
 LIB = os.path.join(PKG, "librejit_hip.so")
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)

@@ -56,688 +56,12 @@ RJ_TRACE_EXPORT(rj_debug_trace)
 #include "behind_walk.h"
 #include "dense_swar.h"
 #include "device_program.h"
+#include "kernel_util.h"
 #include "kernels.h"
 
 namespace rejit_amd {
 
-namespace {
-
-constexpr int kWave = 64;
-constexpr int kChunk = 1024;  // bytes per wave iteration: 64 lanes x 16 B
-
-__device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & (kWave - 1); }
-
-// Cross-lane moves of the dense kernel through DPP (data-parallel primitives: the operand of a VALU
-// instruction comes from another lane of the wave, no LDS crossbar round trip as with ds_bpermute, which
-// is what __shfl_up / __shfl_down compile to).  gfx9 family: row_shr within rows of 16 lanes, row_bcast:15 /
-// row_bcast:31 to carry a row's total into the next rows, wave_shl / wave_shr by one lane.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t x) {
-  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, ROW_MASK, 0xF, true));
-}
-// inclusive prefix sum over the 64 lanes
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
-  x += dpp_or_zero<0x111, 0xF>(x);  // row_shr:1
-  x += dpp_or_zero<0x112, 0xF>(x);  // row_shr:2
-  x += dpp_or_zero<0x114, 0xF>(x);  // row_shr:4
-  x += dpp_or_zero<0x118, 0xF>(x);  // row_shr:8
-  x += dpp_or_zero<0x142, 0xA>(x);  // row_bcast:15 into rows 1 and 3
-  x += dpp_or_zero<0x143, 0xC>(x);  // row_bcast:31 into rows 2 and 3
-  return x;
-}
-__device__ __forceinline__ uint32_t wave_from_lane_below(uint32_t x) { return dpp_or_zero<0x138, 0xF>(x); }  // wave_shr:1, lane 0 gets 0
-__device__ __forceinline__ uint32_t wave_from_lane_above(uint32_t x) { return dpp_or_zero<0x130, 0xF>(x); }  // wave_shl:1, lane 63 gets 0
-__device__ __forceinline__ uint32_t wave_last_lane(uint32_t x) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(x), kWave - 1)); }
-
-// Hit offsets of one wave go to the wave's own REGION of the hit list: region w = wave w,
-// `cap` entries, filled in position order, no atomics.  Every wave owns a contiguous span of
-// the text, so the regions concatenated in wave order are globally sorted by offset -- which
-// is what lets the rest of the pipeline run without a sort.
-//
-// History (all measured, tools/ab_probe.py): appending chunk by chunk to one global counter ran
-// into the ~90 atomics/us limit of a single address (11 ns per chunk-with-hits); staging 256
-// hits per wave in LDS fixed that but cost one returning atomic per wave, whose latency under
-// a saturated memory pipeline (~20 us) made the kernel slower the more waves it had; 16 sharded
-// counters helped little.  Regions need no atomic at all.
-struct RegionHits {
-  uint64_t* slots;   // this wave's region
-  uint32_t cap;
-  uint32_t count;    // wave-uniform; keeps counting past cap so the host can size a retry
-
-  // bit j of mask16 <-> offset at + j - bias; appended in position order
-  __device__ __forceinline__ void push_bits(uint32_t mask16, uint64_t at, uint64_t bias) {
-    const int lane = lane_id();
-    const uint32_t cnt = __popc(mask16);
-    uint32_t inc, total;
-    uint64_t hitters = __ballot(cnt != 0);
-    if (__popcll(hitters) <= 4) {
-      // the usual case in window scans: a handful of lanes hold hits -- walk them (scalar loop,
-      // v_readlane) instead of a 6-step wave scan
-      uint32_t before = 0;
-      total = 0;
-      while (hitters) {
-        const int l = __builtin_ctzll(hitters);
-        hitters &= hitters - 1;
-        const uint32_t c = __builtin_amdgcn_readlane(cnt, l);
-        before += lane > l ? c : 0u;
-        total += c;
-      }
-      inc = before + cnt;
-    } else {
-      inc = cnt;
-#pragma unroll
-      for (int o = 1; o < kWave; o <<= 1) {
-        const uint32_t v = __shfl_up(inc, o);
-        if (lane >= o) inc += v;
-      }
-      total = __shfl(inc, kWave - 1);
-    }
-    uint32_t idx = count + inc - cnt;
-    while (mask16) {
-      const int j = __ffs(static_cast<int>(mask16)) - 1;
-      mask16 &= mask16 - 1;
-      if (idx < cap) slots[idx] = at + j - bias;
-      idx++;
-    }
-    count += total;
-  }
-};
-
-// geometry shared by the scan kernels: wave w owns chunks [c0, c1)
-struct WaveSpan {
-  uint64_t c0, c1;
-};
-
-__device__ __forceinline__ uint64_t scalar_wave_index() {
-  // as a scalar, so that chunk addresses and loop branches are wave-uniform
-  return __builtin_amdgcn_readfirstlane(
-      static_cast<uint32_t>((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6));
-}
-
-__device__ __forceinline__ WaveSpan wave_span(const ScanParams& a, uint64_t wave, uint64_t first_chunk,
-                                              uint64_t end_chunk) {
-  WaveSpan w;
-  w.c0 = first_chunk + wave * a.span_chunks;
-  w.c1 = w.c0 + a.span_chunks;
-  if (w.c0 > end_chunk) w.c0 = end_chunk;
-  if (w.c1 > end_chunk) w.c1 = end_chunk;
-  return w;
-}
-
-// 16 B of the lane + the 8 B that follow, guarded against the end of the text (tail chunk).
-__device__ __forceinline__ void load_guarded(const uint8_t* text, uint64_t n, uint64_t at, uint32_t d[6]) {
-#pragma unroll
-  for (int q = 0; q < 6; q++) {
-    uint32_t v = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const uint64_t p = at + 4 * q + k;
-      if (p < n) v |= static_cast<uint32_t>(text[p]) << (8 * k);
-    }
-    d[q] = v;
-  }
-}
-
-}  // namespace
-
-// ---------------------------------------------------------------------------------------
-// Fast-forward window scan.
-//
-// Window position w is a hit iff for some k < K
-//     (load32(text + w) & mask0[k]) == value0[k]  and, when TWO,
-//     (load32(text + w + 4) & mask1[k]) == value1[k];
-// the candidate start is s = w - offset.  Scanned w range: [wlo, whi).
-// One chunk: d[0..3] = the lane's 16 bytes, d[4..5] = the 8 bytes that follow.
-template <int K, bool TWO, bool MASKED, bool TWOLEVEL, bool NIB>
-__device__ __forceinline__ void windows_chunk(const uint32_t (&d)[6], uint64_t at, const ScanParams& a,
-                                              const WindowSet& ws, RegionHits& hits) {
-  if (NIB) {
-    // Nibble filter: keep only the low nibble of every byte, so that the 8 bytes of a window pack
-    // into ONE dword -- byte i of pk[j] = nibble of text byte j+i | nibble of text byte j+4+i << 4 --
-    // and a window costs one v_bitop3 ((pk ^ value) & mask) instead of three VALU ops.  The packing
-    // is done on the ALIGNED dwords first (z[q] = nib(d[q]) | nib(d[q+1]) << 4: 6 v_and + 5
-    // v_lshl_or) and the unaligned positions are v_alignbyte of neighbouring z: 26 VALU per chunk
-    // for all 16 pk[j] (packing after the alignment took 37).  With two masked 8-byte windows
-    // (regexdna) the exact form needs ~8.5 VALU per text byte, which bounds the kernel at ~4.6 TB/s
-    // on 256 CUs; this form needs ~4.6.
-    uint32_t nib[6], z[5], pk[16];
-#pragma unroll
-    for (int q = 0; q < 6; q++) nib[q] = d[q] & 0x0F0F0F0Fu;
-#pragma unroll
-    for (int q = 0; q < 5; q++) z[q] = nib[q] | (nib[q + 1] << 4);  // v_lshl_or_b32
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      pk[4 * q] = z[q];
-      pk[4 * q + 1] = __builtin_amdgcn_alignbyte(z[q + 1], z[q], 1);
-      pk[4 * q + 2] = __builtin_amdgcn_alignbyte(z[q + 1], z[q], 2);
-      pk[4 * q + 3] = __builtin_amdgcn_alignbyte(z[q + 1], z[q], 3);
-    }
-    uint32_t accs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-#pragma unroll
-      for (int k = 0; k + 1 < K; k += 2) {  // two windows per v_min3_u32
-        uint32_t t0 = pk[j] ^ ws.value0[k], t1 = pk[j] ^ ws.value0[k + 1];
-        if (MASKED) {
-          t0 &= ws.mask0[k];
-          t1 &= ws.mask0[k + 1];
-        }
-        const uint32_t ab = accs[j & 3] < t0 ? accs[j & 3] : t0;
-        accs[j & 3] = ab < t1 ? ab : t1;
-      }
-      if (K & 1) {
-        uint32_t t = pk[j] ^ ws.value0[K - 1];
-        if (MASKED) t &= ws.mask0[K - 1];
-        accs[j & 3] = accs[j & 3] < t ? accs[j & 3] : t;
-      }
-    }
-    const uint32_t m01 = accs[0] < accs[1] ? accs[0] : accs[1];
-    const uint32_t m23 = accs[2] < accs[3] ? accs[2] : accs[3];
-    const uint32_t acc = m01 < m23 ? m01 : m23;
-    if (__ballot(acc == 0) == 0) return;
-    uint32_t hm = 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      uint32_t best = 0xFFFFFFFFu;
-#pragma unroll
-      for (int k = 0; k < K; k++) {
-        uint32_t t = pk[j] ^ ws.value0[k];
-        if (MASKED) t &= ws.mask0[k];
-        best = best < t ? best : t;
-      }
-      hm |= static_cast<uint32_t>(best == 0) << j;
-    }
-    const uint64_t chunk_base = at - static_cast<uint64_t>(lane_id()) * 16;
-    if (chunk_base < a.wlo || chunk_base + kChunk > a.whi) {
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
-        const uint64_t w = at + j;
-        if (w < a.wlo || w >= a.whi) hm &= ~(1u << j);
-      }
-    }
-    hits.push_bits(hm, at, ws.offset);
-    return;
-  }
-  constexpr int NX = TWO ? 20 : 16;  // windows needed: 16 positions (+4 for the second dword)
-  // the unaligned 4-byte windows of this lane: x[j] = bytes [at+j, at+j+4)
-  uint32_t x[NX];
-#pragma unroll
-  for (int q = 0; q < NX / 4; q++) {
-    x[4 * q] = d[q];
-    x[4 * q + 1] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1);
-    x[4 * q + 2] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2);
-    x[4 * q + 3] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 3);
-  }
-  // Streaming test, VALU only.  For window k at position j
-  //     t = ((x[j] ^ value0[k]) & mask0[k]) | ((x[j+4] ^ value1[k]) & mask1[k])
-  // is zero iff the window matches; the minimum over all (j,k) is zero iff the lane has a
-  // hit.  (The obvious form -- v_cmp per dword and s_and/s_or of the lane masks -- put ~130
-  // scalar instructions per chunk on the CU's single scalar unit and ran at 2.9 TB/s.)
-  if (TWO && TWOLEVEL) {
-    // Two-level test for 5..8-byte windows over a large alphabet: the first dword alone is
-    // already a strong filter (e.g. 74^-4 on random ASCII), so test it for all 16 positions
-    // first and leave, wave-uniformly, when no lane has a first-dword hit.  Over a small
-    // alphabet (DNA) some lane always has one and this level would be pure overhead, which is
-    // why the host enables it only when the window bytes span more than 4 distinct values.
-    uint32_t acc1 = 0xFFFFFFFFu;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-#pragma unroll
-      for (int k = 0; k < K; k++) {
-        uint32_t t = x[j] ^ ws.value0[k];
-        if (MASKED) t &= ws.mask0[k];
-        acc1 = acc1 < t ? acc1 : t;
-      }
-    }
-    if (__ballot(acc1 == 0) == 0) return;
-  }
-  // four independent min chains (the single chain of 16*K dependent v_min was latency-bound:
-  // 2 chains 0.144 -> 0.139 ms although they cost 16 more VGPRs and one wave of occupancy)
-  uint32_t accs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-#pragma unroll
-  for (int j = 0; j < 16; j++) {
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      uint32_t t = x[j] ^ ws.value0[k];
-      if (MASKED) t &= ws.mask0[k];
-      if (TWO) {
-        uint32_t u = x[j + 4] ^ ws.value1[k];
-        t = MASKED ? ((u & ws.mask1[k]) | t) : (u | t);  // v_and_or_b32
-      }
-      accs[j & 3] = accs[j & 3] < t ? accs[j & 3] : t;
-    }
-  }
-  const uint32_t m01 = accs[0] < accs[1] ? accs[0] : accs[1];
-  const uint32_t m23 = accs[2] < accs[3] ? accs[2] : accs[3];
-  const uint32_t acc = m01 < m23 ? m01 : m23;
-  if (__ballot(acc == 0) == 0) return;  // wave-uniform: the common case leaves here
-
-  // rare path: per-lane 16-bit hit mask -> the wave's region of the hit list
-  uint32_t hm = 0;
-#pragma unroll
-  for (int j = 0; j < 16; j++) {
-    uint32_t best = 0xFFFFFFFFu;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      uint32_t t = x[j] ^ ws.value0[k];
-      if (MASKED) t &= ws.mask0[k];
-      if (TWO) {
-        uint32_t u = x[j + 4] ^ ws.value1[k];
-        t = MASKED ? ((u & ws.mask1[k]) | t) : (u | t);
-      }
-      best = best < t ? best : t;
-    }
-    hm |= static_cast<uint32_t>(best == 0) << j;
-  }
-  // positions outside [wlo, whi) only exist in the first / last chunk of the range
-  const uint64_t chunk_base = at - static_cast<uint64_t>(lane_id()) * 16;
-  if (chunk_base < a.wlo || chunk_base + kChunk > a.whi) {
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const uint64_t w = at + j;
-      if (w < a.wlo || w >= a.whi) hm &= ~(1u << j);
-    }
-  }
-  hits.push_bits(hm, at, ws.offset);
-}
-
-template <bool TWO>
-__device__ __forceinline__ void load_chunk(const uint8_t* text, uint64_t at, uint32_t (&d)[6]) {
-  const uint4 v = *reinterpret_cast<const uint4*>(text + at);
-  d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-  if (TWO) {  // the neighbour's first 8 bytes (same cache lines: L1 hits, no extra HBM traffic)
-    const uint2 h = *reinterpret_cast<const uint2*>(text + at + 16);
-    d[4] = h.x; d[5] = h.y;
-  } else {
-    d[4] = *reinterpret_cast<const uint32_t*>(text + at + 16);
-    d[5] = 0;
-  }
-}
-
-template <int K, bool TWO, bool MASKED, bool TWOLEVEL, bool NIB>
-__device__ __forceinline__ void scan_windows_body(const ScanParams& a, const WindowSet& ws) {
-  const int lane = lane_id();
-  const uint64_t wave = scalar_wave_index();
-  if (a.zero_counters != nullptr && wave == 0 && lane < kCntSize) a.zero_counters[lane] = 0;
-  RegionHits hits{a.hits + wave * a.region_cap, a.region_cap, 0u};
-  const uint64_t first_chunk = a.wlo / kChunk;
-  const uint64_t end_chunk = (a.whi + kChunk - 1) / kChunk;
-  const WaveSpan span = wave_span(a, wave, first_chunk, end_chunk);
-  // chunks below fast_end can be loaded without guards (16 B + 8 B halo stay < n)
-  uint64_t fast_end = a.n >= kChunk + 8 ? (a.n - 8) / kChunk : 0;
-  if (fast_end > span.c1) fast_end = span.c1;
-  if (fast_end < span.c0) fast_end = span.c0;
-  const uint64_t lane_off = static_cast<uint64_t>(lane) * 16;
-
-  // Software-pipelined streaming loop, three register buffers deep: while chunk c is compared
-  // the loads of chunks c+1 and c+2 are in flight (3 KiB per wave).  The prologue and the steady
-  // loop run only when all their loads exist, so every load is unconditional and the compiler can
-  // count them: it waits for exactly the buffer it needs (vmcnt(4)).  A conditional prologue
-  // ("load b1 if it exists") made the count at the loop head ambiguous and the compiler waited for
-  // ALL loads there -- including the one issued just before the back edge, i.e. a full memory
-  // latency exposed every third chunk.  Spans shorter than 6 chunks and the last <= 2 chunks of a
-  // span take the plain loop below; no byte is loaded twice.
-  {
-    uint32_t b0[6], b1[6], b2[6];
-    uint64_t c = span.c0;
-    if (c + 5 < fast_end) {
-      load_chunk<TWO>(a.text, c * kChunk + lane_off, b0);
-      load_chunk<TWO>(a.text, (c + 1) * kChunk + lane_off, b1);
-      load_chunk<TWO>(a.text, (c + 2) * kChunk + lane_off, b2);
-      while (c + 5 < fast_end) {
-        windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b0, c * kChunk + lane_off, a, ws, hits);
-        load_chunk<TWO>(a.text, (c + 3) * kChunk + lane_off, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b1, (c + 1) * kChunk + lane_off, a, ws, hits);
-        load_chunk<TWO>(a.text, (c + 4) * kChunk + lane_off, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b2, (c + 2) * kChunk + lane_off, a, ws, hits);
-        load_chunk<TWO>(a.text, (c + 5) * kChunk + lane_off, b2);
-        __builtin_amdgcn_sched_barrier(0);
-        c += 3;
-      }
-      // b0..b2 hold chunks c, c+1, c+2 (the loads of the last iteration, all inside the span)
-      windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b0, c * kChunk + lane_off, a, ws, hits);
-      windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b1, (c + 1) * kChunk + lane_off, a, ws, hits);
-      windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b2, (c + 2) * kChunk + lane_off, a, ws, hits);
-      c += 3;
-    }
-    for (; c < fast_end; c++) {
-      load_chunk<TWO>(a.text, c * kChunk + lane_off, b0);
-      windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b0, c * kChunk + lane_off, a, ws, hits);
-    }
-  }
-  // tail: the chunk(s) that touch the end of the text use guarded byte loads
-  for (uint64_t t = fast_end; t < span.c1; t++) {
-    uint32_t d[6];
-    load_guarded(a.text, a.n, t * kChunk + lane_off, d);
-    windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(d, t * kChunk + lane_off, a, ws, hits);
-  }
-  if (lane == 0) a.hit_counts[wave] = hits.count;
-}
-
-template <int K, bool TWO, bool MASKED, bool TWOLEVEL, bool NIB>
-__global__ __launch_bounds__(256) void scan_windows(ScanParams a, WindowSet ws) {
-  scan_windows_body<K, TWO, MASKED, TWOLEVEL, NIB>(a, ws);
-}
-
-// A TRAIN of scans in one launch: the same streaming scan for several patterns, one after the other, every
-// wave over its own span -- pattern p + 1 starts in a wave as soon as that wave is done with pattern p.
-// Launched one by one (rj_multi mode 1 of round 1) every kernel boundary cost the drain of the last
-// workgroups and the ramp-up of the next grid: 94-96 us per 500 MB pattern against 88 us in the
-// kernel's steady state.  More than the boundaries is saved: a wave's passes 2..P run over the 32 KB span it
-// has just read, and the spans of all resident waves (~150 MB) fit the 256 MiB Infinity Cache, so only the
-// first pass of a span comes from HBM -- 77 us per 500 MB pattern.  (On a text several times the cache --
-// bench.py `hbm_not_cache`, 2.5 GB -- the spans are 5 x larger and the passes stream from HBM again.)  The
-// launch's algorithmic bytes are patterns x text bytes.  Two 5..8-byte nibble-form windows per pattern
-// (regexdna's shape); every other set of patterns gets one launch per pattern.
-template <bool MASKED>
-__global__ __launch_bounds__(256) void scan_windows_train(TrainParams t) {
-  for (uint32_t p = 0; p < t.n_patterns; p++) {
-    ScanParams a;
-    a.text = t.text;
-    a.n = t.n;
-    a.sb = t.sb;
-    a.se = t.se;
-    a.wlo = t.wlo[p];
-    a.whi = t.whi[p];
-    a.span_chunks = t.span_chunks;
-    a.hits = t.hits[p];
-    a.region_cap = t.region_cap[p];
-    a.hit_counts = t.hit_counts[p];
-    a.zero_counters = t.zero_counters[p];
-    WindowSet ws;
-    ws.value0[0] = t.value[p][0];
-    ws.value0[1] = t.value[p][1];
-    ws.mask0[0] = t.mask[p][0];
-    ws.mask0[1] = t.mask[p][1];
-    ws.offset = t.offset[p];
-    ws.len = t.len[p];
-    scan_windows_body<2, true, MASKED, false, true>(a, ws);
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// Fused fast-forward scan: P patterns in ONE pass over the text (regexdna's nine patterns read the
-// same 500 MB nine times otherwise).  The nibble-packed dwords pk[j] of a chunk are built once;
-// each pattern then costs two v_bitop3 + one v_min3 per position.  29 VALU per text byte for 9
-// patterns makes this kernel VALU-bound (~1.3 TB/s of text, i.e. ~12 TB/s of "pattern-bytes"),
-// but it moves 1/9 of the HBM bytes of nine separate scans.  Hits go to per-pattern regions, so
-// everything downstream is the single-pattern pipeline (its kernels take grid.y = pattern).
-__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
-  const uint32_t ab = a < b ? a : b;
-  return ab < c ? ab : c;
-}
-
-__device__ __forceinline__ void fused_chunk(const uint32_t (&d)[6], uint64_t at, const FusedParams& a, uint32_t* counts,
-                                            uint64_t wave) {
-  uint32_t nib[6], z[5], pk[16];  // packed on the aligned dwords first, see windows_chunk
-#pragma unroll
-  for (int q = 0; q < 6; q++) nib[q] = d[q] & 0x0F0F0F0Fu;
-#pragma unroll
-  for (int q = 0; q < 5; q++) z[q] = nib[q] | (nib[q + 1] << 4);
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    pk[4 * q] = z[q];
-    pk[4 * q + 1] = __builtin_amdgcn_alignbyte(z[q + 1], z[q], 1);
-    pk[4 * q + 2] = __builtin_amdgcn_alignbyte(z[q + 1], z[q], 2);
-    pk[4 * q + 3] = __builtin_amdgcn_alignbyte(z[q + 1], z[q], 3);
-  }
-  for (uint32_t g = 0; g < a.n_patterns; g += kFuseGroup) {
-    uint32_t acc[kFuseGroup];
-#pragma unroll
-    for (int u = 0; u < kFuseGroup; u++) {
-      const uint32_t v0 = a.value[g + u][0], m0 = a.mask[g + u][0], v1 = a.value[g + u][1], m1 = a.mask[g + u][1];
-      uint32_t c[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // independent chains
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
-        const uint32_t t0 = (pk[j] ^ v0) & m0, t1 = (pk[j] ^ v1) & m1;
-        c[j & 3] = umin3(c[j & 3], t0, t1);  // one v_min3_u32 per position
-      }
-      acc[u] = umin3(c[0], c[1], c[2] < c[3] ? c[2] : c[3]);
-    }
-    uint32_t any = acc[0];
-#pragma unroll
-    for (int u = 1; u < kFuseGroup; u++) any = any < acc[u] ? any : acc[u];
-    if (__ballot(any == 0) == 0) continue;  // wave-uniform: no pattern of the group hits in this chunk
-    // rare path, pattern by pattern
-#pragma unroll
-    for (int u = 0; u < kFuseGroup; u++) {
-      if (__ballot(acc[u] == 0) == 0) continue;  // this pattern has no hit in the chunk
-      const uint32_t p = g + u;
-      const uint32_t v0 = a.value[p][0], m0 = a.mask[p][0], v1 = a.value[p][1], m1 = a.mask[p][1];
-      uint32_t hm = 0;
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
-        const uint32_t t0 = (pk[j] ^ v0) & m0, t1 = (pk[j] ^ v1) & m1;
-        hm |= static_cast<uint32_t>((t0 < t1 ? t0 : t1) == 0) << j;
-      }
-      // window positions of pattern p: w = s + offset, sb <= s < se, and the window must fit
-      const uint64_t wlo = a.sb + a.offset[p];
-      const uint64_t last_w = a.n >= a.len[p] ? a.n - a.len[p] + 1 : 0;
-      uint64_t whi = a.se + a.offset[p];
-      if (whi > last_w) whi = last_w;
-      const uint64_t chunk_base = at - static_cast<uint64_t>(lane_id()) * 16;
-      if (chunk_base < wlo || chunk_base + kChunk > whi) {  // only the first / last chunks of the range
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-          const uint64_t w = at + j;
-          if (w < wlo || w >= whi) hm &= ~(1u << j);
-        }
-      }
-      RegionHits hits{a.hits[p] + wave * a.region_cap[p], a.region_cap[p], counts[p]};
-      hits.push_bits(hm, at, a.offset[p]);
-      counts[p] = hits.count;  // wave-uniform, every lane stores the same value
-    }
-  }
-}
-
-// The same with a SHARED prefilter (FusedParams::n_bases > 0): when every window of every pattern is
-// within one nibble of one of NB base windows -- regexdna: all 18 windows are `agggtaaa` or `tttaccct`
-// with at most one position turned into a class -- a text position can only hit if it differs from a
-// base in at most ONE nibble.  That test is shared by all patterns and costs, per position and base,
-//     u = (pk ^ base) + 0x77777777      bit 3 of a nibble <=> that nibble differs       (v_xad_u32)
-//     c = popcount(u & 0x88888888)      differing nibbles                              (v_and, v_bcnt)
-// plus one v_min3 for both bases: 7 VALU per position instead of 3 per position AND PATTERN (27 for
-// regexdna's nine).  Nibbles are compared on their low 3 bits (bit 3 must be free for the carry-less
-// add): one more superset step, removed like every alias by the exact verification downstream.
-// Only chunks in which some lane passes the prefilter (about every second one on DNA: the true match
-// density is one per 2.4 KiB) run the exact per-pattern tests, and only for the hit positions' chains.
-template <int NB>
-__device__ __forceinline__ void fused_chunk_d1(const uint32_t (&d)[6], uint64_t at, const FusedParams& a, uint32_t* counts,
-                                               uint64_t wave) {
-  uint32_t nib[6], z[5], pk[16];
-#pragma unroll
-  for (int q = 0; q < 6; q++) nib[q] = d[q] & 0x07070707u;
-#pragma unroll
-  for (int q = 0; q < 5; q++) z[q] = nib[q] | (nib[q + 1] << 4);
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    pk[4 * q] = z[q];
-    pk[4 * q + 1] = __builtin_amdgcn_alignbyte(z[q + 1], z[q], 1);
-    pk[4 * q + 2] = __builtin_amdgcn_alignbyte(z[q + 1], z[q], 2);
-    pk[4 * q + 3] = __builtin_amdgcn_alignbyte(z[q + 1], z[q], 3);
-  }
-  const uint32_t b0 = a.base[0], b1 = a.base[NB > 1 ? 1 : 0];
-  const uint32_t c77 = 0x77777777u;
-  // (pk ^ base) + 0x77777777 in ONE instruction: the compiler emits v_xor + v_add for the C expression
-  auto xad = [&](uint32_t x, uint32_t base) -> uint32_t {
-    uint32_t u;
-    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(u) : "v"(x), "s"(base), "v"(c77));
-    return u;
-  };
-  uint32_t acc[8];  // chain q holds the positions q and q + 8
-#pragma unroll
-  for (int q = 0; q < 8; q++) acc[q] = 8;
-#pragma unroll
-  for (int j = 0; j < 16; j++) {
-    const uint32_t c0 = __builtin_popcount(xad(pk[j], b0) & 0x88888888u);
-    if (NB > 1) {
-      const uint32_t c1 = __builtin_popcount(xad(pk[j], b1) & 0x88888888u);
-      acc[j & 7] = umin3(acc[j & 7], c0, c1);
-    } else {
-      acc[j & 7] = acc[j & 7] < c0 ? acc[j & 7] : c0;
-    }
-  }
-  const uint32_t m0 = umin3(acc[0], acc[1], acc[2]), m1 = umin3(acc[3], acc[4], acc[5]);
-  const uint32_t best = umin3(m0, m1, acc[6] < acc[7] ? acc[6] : acc[7]);
-  if (__ballot(best <= 1) == 0) return;  // wave-uniform: no position of the chunk is near a base
-  // which chains hold a hit (wave-uniform mask)
-  uint32_t chains = 0;
-#pragma unroll
-  for (int q = 0; q < 8; q++) chains |= (__ballot(acc[q] <= 1) != 0 ? 1u : 0u) << q;
-  const uint64_t chunk_base = at - static_cast<uint64_t>(lane_id()) * 16;
-  for (uint32_t p = 0; p < a.n_patterns; p++) {
-    if (a.region_cap[p] == 0) continue;  // padding entry
-    const uint32_t v0 = a.value[p][0], k0 = a.mask[p][0], v1 = a.value[p][1], k1 = a.mask[p][1];
-    uint32_t hm = 0;
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      if (((chains >> q) & 1u) == 0) continue;  // uniform
-      {
-        const uint32_t t0 = (pk[q] ^ v0) & k0, t1 = (pk[q] ^ v1) & k1;
-        hm |= static_cast<uint32_t>((t0 < t1 ? t0 : t1) == 0) << q;
-      }
-      {
-        const uint32_t t0 = (pk[q + 8] ^ v0) & k0, t1 = (pk[q + 8] ^ v1) & k1;
-        hm |= static_cast<uint32_t>((t0 < t1 ? t0 : t1) == 0) << (q + 8);
-      }
-    }
-    if (__ballot(hm != 0) == 0) continue;
-    const uint64_t wlo = a.sb + a.offset[p];
-    const uint64_t last_w = a.n >= a.len[p] ? a.n - a.len[p] + 1 : 0;
-    uint64_t whi = a.se + a.offset[p];
-    if (whi > last_w) whi = last_w;
-    if (chunk_base < wlo || chunk_base + kChunk > whi) {  // only the first / last chunks of the range
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
-        const uint64_t w = at + j;
-        if (w < wlo || w >= whi) hm &= ~(1u << j);
-      }
-    }
-    RegionHits hits{a.hits[p] + wave * a.region_cap[p], a.region_cap[p], counts[p]};
-    hits.push_bits(hm, at, a.offset[p]);
-    counts[p] = hits.count;
-  }
-}
-
-template <int NB>
-__device__ __forceinline__ void fused_any(const uint32_t (&d)[6], uint64_t at, const FusedParams& a, uint32_t* counts, uint64_t wave) {
-  if (NB == 0) fused_chunk(d, at, a, counts, wave);
-  else fused_chunk_d1<NB>(d, at, a, counts, wave);
-}
-
-template <int NB>
-__global__ __launch_bounds__(256) void scan_windows_fused(FusedParams a) {
-  __shared__ uint32_t region_count[4][kMaxFused];
-  const int lane = lane_id();
-  const uint64_t wave = scalar_wave_index();
-  uint32_t* counts = region_count[threadIdx.x >> 6];
-  if (lane < kMaxFused) counts[lane] = 0;
-  if (wave == 0 && lane < kCntSize)
-    for (uint32_t p = 0; p < a.n_patterns; p++)
-      if (a.zero_counters[p] != nullptr) a.zero_counters[p][lane] = 0;
-  const uint64_t first_chunk = a.sb / kChunk;
-  // a window may begin up to 7 bytes after its start
-  const uint64_t end_byte = a.se + 8 < a.n ? a.se + 8 : a.n;
-  const uint64_t end_chunk = (end_byte + kChunk - 1) / kChunk;
-  WaveSpan span;
-  span.c0 = first_chunk + wave * a.span_chunks;
-  span.c1 = span.c0 + a.span_chunks;
-  if (span.c0 > end_chunk) span.c0 = end_chunk;
-  if (span.c1 > end_chunk) span.c1 = end_chunk;
-  uint64_t fast_end = a.n >= kChunk + 8 ? (a.n - 8) / kChunk : 0;
-  if (fast_end > span.c1) fast_end = span.c1;
-  if (fast_end < span.c0) fast_end = span.c0;
-  const uint64_t lane_off = static_cast<uint64_t>(lane) * 16;
-  {
-    // the same 3-deep register pipeline as scan_windows (unconditional prologue, see there)
-    uint32_t b0[6], b1[6], b2[6];
-    uint64_t c = span.c0;
-    if (c + 5 < fast_end) {
-      load_chunk<true>(a.text, c * kChunk + lane_off, b0);
-      load_chunk<true>(a.text, (c + 1) * kChunk + lane_off, b1);
-      load_chunk<true>(a.text, (c + 2) * kChunk + lane_off, b2);
-      while (c + 5 < fast_end) {
-        fused_any<NB>(b0, c * kChunk + lane_off, a, counts, wave);
-        load_chunk<true>(a.text, (c + 3) * kChunk + lane_off, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        fused_any<NB>(b1, (c + 1) * kChunk + lane_off, a, counts, wave);
-        load_chunk<true>(a.text, (c + 4) * kChunk + lane_off, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        fused_any<NB>(b2, (c + 2) * kChunk + lane_off, a, counts, wave);
-        load_chunk<true>(a.text, (c + 5) * kChunk + lane_off, b2);
-        __builtin_amdgcn_sched_barrier(0);
-        c += 3;
-      }
-      fused_any<NB>(b0, c * kChunk + lane_off, a, counts, wave);
-      fused_any<NB>(b1, (c + 1) * kChunk + lane_off, a, counts, wave);
-      fused_any<NB>(b2, (c + 2) * kChunk + lane_off, a, counts, wave);
-      c += 3;
-    }
-    for (; c < fast_end; c++) {
-      load_chunk<true>(a.text, c * kChunk + lane_off, b0);
-      fused_any<NB>(b0, c * kChunk + lane_off, a, counts, wave);
-    }
-  }
-  for (uint64_t t = fast_end; t < span.c1; t++) {
-    uint32_t d[6];
-    load_guarded(a.text, a.n, t * kChunk + lane_off, d);
-    fused_any<NB>(d, t * kChunk + lane_off, a, counts, wave);
-  }
-  if (lane < static_cast<int>(a.n_patterns) && a.region_cap[lane] != 0) a.hit_counts[lane][wave] = counts[lane];
-}
-
-// ---------------------------------------------------------------------------------------
-// Dense scan: every position s in [sb, se) that can start a match goes to the hit list.
-__global__ __launch_bounds__(256) void scan_dense(ScanParams a, DevProgram P) {
-  __shared__ uint32_t fb[8];
-  if (threadIdx.x < 8) fb[threadIdx.x] = P.first_bytes[threadIdx.x];
-  __syncthreads();
-  const int lane = lane_id();
-  const uint64_t wave = scalar_wave_index();
-  RegionHits hits{a.hits + wave * a.region_cap, a.region_cap, 0u};
-  const uint64_t first_chunk = a.sb / kChunk;
-  const uint64_t end_chunk = (a.se + kChunk - 1) / kChunk;  // se <= n + 1
-  const WaveSpan span = wave_span(a, wave, first_chunk, end_chunk);
-  const bool ctxed = P.n_ctx > 1;
-
-  for (uint64_t c = span.c0; c < span.c1; c++) {
-    const uint64_t base = c * kChunk;
-    const uint64_t at = base + static_cast<uint64_t>(lane) * 16;
-    uint32_t d[6];
-    if (base + kChunk <= a.n) {
-      const uint4 v = *reinterpret_cast<const uint4*>(a.text + at);
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    } else {
-      load_guarded(a.text, a.n, at, d);
-    }
-    uint32_t prev = '\n';  // byte before the lane's first byte ('\n' stands for "start of text")
-    if (at > 0 && at <= a.n) prev = a.text[at - 1];
-    uint32_t cand = 0;  // bit j: position at + j is a candidate start
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const uint32_t cur = (d[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-      const uint64_t s = at + j;
-      bool ok = false;
-      if (s < a.n) ok = (fb[cur >> 5] >> (cur & 31)) & 1u;
-      if (P.nullable && s <= a.n) {
-        int ctx = 0;
-        if (ctxed) {
-          if (s == 0 || rj_line_break(prev)) ctx |= 1;
-          if (s == a.n || rj_line_break(cur)) ctx |= 2;
-        }
-        ok = ok || ((P.nullable >> ctx) & 1u);
-      }
-      ok = ok && s >= a.sb && s < a.se;
-      cand |= static_cast<uint32_t>(ok) << j;
-      prev = cur;
-    }
-    if (__ballot(cand != 0) == 0) continue;
-    hits.push_bits(cand, at, 0);
-  }
-  if (lane == 0) a.hit_counts[wave] = hits.count;
-}
+// (the shared wave-level helpers: kernel_util.h)
 
 // ---------------------------------------------------------------------------------------
 // Region bookkeeping: offsets[r] = sum of min(count, cap) of the regions before r (so hit i of
@@ -1779,116 +1103,6 @@ __global__ __launch_bounds__(64) void match_full(const uint8_t* text, uint64_t n
 }
 
 // ---------------------------------------------------------------------------------------
-// Finalize (small): sort by begin, drop duplicates, left-most-longest selection.
-// One workgroup; cands are read from HBM once, everything else happens in LDS.
-__global__ __launch_bounds__(1024) void finalize_small(FinalizeParams a) {
-  __shared__ uint64_t key[kFinalizeCap];
-  __shared__ uint64_t val[kFinalizeCap];
-  __shared__ int all_disjoint;
-  __shared__ int n_valid;
-  const unsigned long long n_raw = a.counters[kCntHits] * a.expand;  // candidate slots
-  if (n_raw > a.cands_cap || a.counters[kCntOverflow] != 0) {
-    if (threadIdx.x == 0) {  // a list overflowed: the host grows it and retries
-      a.counters[kCntOverflow] = 1;
-      a.counters[kCntFinal] = ~0ull;
-    }
-    return;
-  }
-  if (n_raw > kFinalizeCap) {  // too many for LDS: the host takes the large path
-    if (threadIdx.x == 0) a.counters[kCntFinal] = ~0ull;
-    return;
-  }
-  const int n_slots = static_cast<int>(n_raw);
-  int m = 1;
-  while (m < n_slots) m <<= 1;
-  if (threadIdx.x == 0) {
-    all_disjoint = 1;
-    n_valid = 0;
-  }
-  __syncthreads();
-  int mine = 0;
-  for (int i = threadIdx.x; i < m; i += blockDim.x) {
-    // starts without a match sort to the end (the input is already ordered by begin; the sort is
-    // kept because it also serves callers that pass unordered candidates, and costs ~3 us)
-    const bool ok = i < n_slots && a.cand_end[i] != kNoMatch;
-    key[i] = ok ? a.cand_begin[i] : ~0ull;
-    val[i] = ok ? a.cand_end[i] : ~0ull;
-    mine += ok;
-  }
-  if (mine) atomicAdd(&n_valid, mine);
-  __syncthreads();
-  const int n = n_valid;
-  if (threadIdx.x == 0) a.counters[kCntCands] = static_cast<unsigned long long>(n);
-  // bitonic sort on (key, val)
-  for (int k = 2; k <= m; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < m; i += blockDim.x) {
-        const int l = i ^ j;
-        if (l > i) {
-          const bool up = (i & k) == 0;
-          const uint64_t ki = key[i], kl = key[l];
-          if ((ki > kl) == up && ki != kl) {
-            key[i] = kl; key[l] = ki;
-            const uint64_t vi = val[i];
-            val[i] = val[l]; val[l] = vi;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
-  if (a.detect_adjacent) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      const uint64_t e = val[i];
-      if (e <= key[i]) continue;
-      int lo = 0, hi = n;  // first index with key >= e
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (key[mid] < e) lo = mid + 1; else hi = mid;
-      }
-      if (lo < n && key[lo] == e) a.counters[kCntAdjacent] = 1;
-    }
-  }
-  // fast exit: pairwise disjoint, no duplicates, no empty matches -> selection is the identity
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const bool ok = val[i] > key[i] && (i == 0 || key[i] >= val[i - 1]);
-    if (!ok) all_disjoint = 0;
-  }
-  __syncthreads();
-  if (all_disjoint && (n == 0 || key[0] >= a.carry_cur)) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      if (static_cast<uint64_t>(i) < a.out_cap) {
-        a.out[2 * i] = key[i];
-        a.out[2 * i + 1] = val[i];
-      }
-    }
-    if (threadIdx.x == 0) a.counters[kCntFinal] = static_cast<unsigned long long>(n);
-    return;
-  }
-  // general case: sequential definition (clusters of overlapping candidates are tiny in practice)
-  if (threadIdx.x == 0) {
-    RjSelectState st;
-    st.cur = a.carry_cur;
-    st.prev_end = a.carry_prev_end;
-    st.have_prev = a.have_prev != 0;
-    unsigned long long out_n = 0;
-    for (int i = 0; i < n; i++) {
-      if (i > 0 && key[i] == key[i - 1]) continue;  // duplicate begin
-      if (a.detect_conflict && key[i] < st.cur && val[i] > st.cur) a.counters[kCntConflict] = 1;
-      bool taken;
-      if (rj_select_step(&st, key[i], val[i], &taken)) {
-        if (out_n < a.out_cap) {
-          a.out[2 * out_n] = key[i];
-          a.out[2 * out_n + 1] = val[i];
-        }
-        out_n++;
-      }
-    }
-    a.counters[kCntFinal] = out_n;
-  }
-}
-
-// ---------------------------------------------------------------------------------------
 // Small texts in ONE launch.  The general pipeline is three kernels and one synchronise -- ~35 us per call
 // however small the text, ~60 us with the copies of a host text -- which a caller that matches file by
 // file (the reference's sample/jrep.cc:261-313 does one MatchAll per file, and a second one for the line
@@ -2061,208 +1275,6 @@ void launch_match_small(const SmallParams& a, const DevProgram& P, hipStream_t s
   const size_t lds = small_lds_bytes(P, a.n);
   if (P.n_words <= 2) hipLaunchKernelGGL((match_small<1>), dim3(1), dim3(1024), lds, st, a, P);
   else hipLaunchKernelGGL((match_small<2>), dim3(1), dim3(1024), lds, st, a, P);
-}
-
-// Selection over a sorted candidate list of any size (large path).
-//
-// The greedy rule (reference: MatchAllAppendFilter + CheckMatch, src/codegen.cc:36-86,
-// codegen-x64.cc:401-466) is a CHAIN over the candidates: after taking i the next one taken is
-//     nxt[i] = the first j > i with begin[j] >= max(end[i], begin[i] + 1).
-// With M[i] = max end of the candidates before i (exclusive prefix max, computed by the caller)
-// candidate i is a HEAD iff begin[i] >= max(M[i], carry_cur) and begin[i] > begin[i-1]: nothing
-// before it can overlap it, so every chain passes through it.  Round 1 let the thread of a head walk
-// its whole cluster, which is sequential in the cluster's size -- `[ab]{40}c*` over 4 MiB of a/b is
-// ONE cluster of 4 M overlapping candidates: 1.05 s in that kernel.  Now the list is cut into blocks:
-//   chain_next    nxt[] by (galloping) binary search, one thread per candidate
-//   chain_local   per block, right to left: G[i] = where a chain that stands at i leaves the block
-//   chain_hop     from every block that holds a head (and from the chain's first candidate) hop block
-//                 to block through G until a block with a head of its own: the entry points
-//   chain_mark    per block: follow nxt[] from the entry point (or the first head) to the block's end
-// Sequential depth: block + (largest cluster / block) + block instead of the largest cluster.
-constexpr uint64_t kChainNone = ~0ull;
-
-// the block size balances the three sequential stretches (block + cluster / block + block): about
-// sqrt(n), so that a few thousand candidates are not walked by a handful of lanes for half a millisecond
-static uint64_t chain_block(uint64_t n) {
-  uint64_t b = 32;
-  while (b < 1024 && b * b < n) b <<= 1;
-  return b;
-}
-
-__global__ void chain_next(const uint64_t* keys, const uint64_t* vals, uint64_t n, uint64_t carry_cur, uint64_t* nxt, uint64_t* i0_out) {
-  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i == 0) {  // the chain's first candidate: the first index with begin >= carry_cur
-    uint64_t lo = 0, hi = n;
-    while (lo < hi) {
-      const uint64_t mid = (lo + hi) >> 1;
-      if (keys[mid] < carry_cur) lo = mid + 1; else hi = mid;
-    }
-    *i0_out = lo;
-  }
-  if (i >= n) return;
-  const uint64_t b = keys[i], e = vals[i];
-  const uint64_t cur = e > b ? e : b + 1;
-  uint64_t lo = i + 1, hi = n;  // first index in (i, n] with key >= cur
-  // the next candidate usually is close: gallop before bisecting
-  uint64_t step = 1;
-  while (lo + step < n && keys[lo + step] < cur) {
-    lo += step + 1;
-    step <<= 1;
-  }
-  if (lo + step < hi) hi = lo + step;
-  while (lo < hi) {
-    const uint64_t mid = (lo + hi) >> 1;
-    if (keys[mid] < cur) lo = mid + 1; else hi = mid;
-  }
-  nxt[i] = lo;
-}
-
-// One WAVE per block of B <= 1024 candidates: the block's `nxt` is staged in LDS (coalesced), lane 0 resolves
-// G back to front there (a dependent step per candidate costs an LDS access, not a round trip to L2 as when one
-// lane walked a block in global memory -- that was 125 us of the complex-regex tail), the heads are found by
-// all lanes, G goes back coalesced.
-__global__ __launch_bounds__(64) void chain_local(const uint64_t* keys, const uint64_t* pmax, const uint64_t* nxt, uint64_t n,
-                                                  uint64_t carry_cur, uint64_t B, const uint64_t* i0_ptr, uint64_t* G,
-                                                  uint64_t* first_head, uint64_t* entry) {
-  __shared__ uint64_t s_nxt[1024];
-  __shared__ uint64_t s_g[1024];
-  const uint64_t blk = blockIdx.x;
-  const uint64_t lo = blk * B;
-  if (lo >= n) return;
-  const uint64_t hi = lo + B < n ? lo + B : n;
-  const uint32_t len = static_cast<uint32_t>(hi - lo), lane = threadIdx.x;
-  uint64_t head = kChainNone;
-  for (uint32_t k = lane; k < len; k += 64) {
-    const uint64_t i = lo + k;
-    s_nxt[k] = nxt[i];
-    const uint64_t floor_i = pmax[i] > carry_cur ? pmax[i] : carry_cur;
-    if (head == kChainNone && keys[i] >= floor_i && (i == 0 || keys[i] > keys[i - 1])) head = i;  // (the lane's first: k ascends)
-  }
-  __syncthreads();
-  if (lane == 0)
-    for (uint32_t k = len; k-- > 0;) {
-      const uint64_t t = s_nxt[k];
-      s_g[k] = t >= hi ? t : s_g[t - lo];
-    }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {  // the block's first head = the minimum over the lanes
-    const uint64_t other = __shfl_xor(head, o);
-    head = other < head ? other : head;
-  }
-  __syncthreads();
-  for (uint32_t k = lane; k < len; k += 64) G[lo + k] = s_g[k];
-  if (lane == 0) {
-    first_head[blk] = head;
-    const uint64_t i0 = *i0_ptr;
-    entry[blk] = (i0 < n && i0 / B == blk) ? i0 : kChainNone;
-  }
-}
-
-__global__ __launch_bounds__(64) void chain_hop(const uint64_t* G, const uint64_t* first_head, const uint64_t* i0_ptr, uint64_t n,
-                                                uint64_t B, uint64_t* entry) {
-  const uint64_t blk = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (blk * B >= n) return;
-  const uint64_t i0 = *i0_ptr;
-  uint64_t start = first_head[blk];
-  if (i0 < n && i0 / B == blk) start = i0;  // (a head of this block, if any, lies at or after i0)
-  else if (start == kChainNone || start < i0) return;
-  uint64_t idx = G[start];
-  while (idx < n) {
-    const uint64_t b2 = idx / B;
-    entry[b2] = idx;
-    if (first_head[b2] != kChainNone) break;  // that block's own thread goes on from its head
-    idx = G[idx];
-  }
-}
-
-// (a wave per block as well: the chain through the block is followed in LDS)
-__global__ __launch_bounds__(64) void chain_mark(const uint64_t* nxt, const uint64_t* first_head, const uint64_t* entry,
-                                                 const uint64_t* i0_ptr, uint64_t n, uint64_t B, uint8_t* taken) {
-  __shared__ uint64_t s_nxt[1024];
-  __shared__ uint8_t s_taken[1024];
-  const uint64_t blk = blockIdx.x;
-  const uint64_t lo = blk * B;
-  if (lo >= n) return;
-  const uint64_t hi = lo + B < n ? lo + B : n;
-  uint64_t i = entry[blk];
-  if (i == kChainNone) {
-    i = first_head[blk];
-    if (i == kChainNone || i < *i0_ptr) return;  // no chain comes through this block (wave-uniform)
-  }
-  const uint32_t len = static_cast<uint32_t>(hi - lo), lane = threadIdx.x;
-  for (uint32_t k = lane; k < len; k += 64) {
-    s_nxt[k] = nxt[lo + k];
-    s_taken[k] = 0;
-  }
-  __syncthreads();
-  if (lane == 0)
-    while (i < hi) {
-      s_taken[i - lo] = 1;
-      i = s_nxt[i - lo];
-    }
-  __syncthreads();
-  for (uint32_t k = lane; k < len; k += 64)
-    if (s_taken[k]) taken[lo + k] = 1;
-}
-
-// idx[i] = i + 1 if candidate i was taken else 0 (input of the "last taken before i" max-scan)
-__global__ void taken_index(const uint8_t* taken, uint64_t n, uint64_t* idx) {
-  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < n) idx[i] = taken[i] ? i + 1 : 0;
-}
-
-// zero-length rule (reference src/codegen.cc:65-73): a taken empty match that begins where the
-// previously taken match ended is not reported.  keep[i] in {0,1} as uint64 for the sum-scan.
-__global__ void apply_zero_length_rule(const uint64_t* keys, const uint64_t* vals, const uint8_t* taken,
-                                       const uint64_t* last_taken, uint64_t n, uint64_t carry_prev_end,
-                                       int have_prev, uint64_t* keep, unsigned long long* conflict) {
-  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  bool k = taken[i] != 0;
-  if (conflict != nullptr && !k && last_taken[i] > 0) {
-    // behind mode: a candidate hidden by the match taken before it must not reach beyond that match
-    const uint64_t lb = keys[last_taken[i] - 1], le = vals[last_taken[i] - 1];
-    const uint64_t cur = le > lb ? le : lb + 1;
-    if (keys[i] != lb && keys[i] < cur && vals[i] > cur) *conflict = 1;
-  }
-  if (k && keys[i] == vals[i]) {
-    const uint64_t lt = last_taken[i];  // 1-based index of the last taken candidate before i
-    if (lt > 0) {
-      if (vals[lt - 1] == keys[i]) k = false;
-    } else if (have_prev && carry_prev_end == keys[i]) {
-      k = false;
-    }
-  }
-  keep[i] = k ? 1 : 0;
-}
-
-__global__ void compact_kept(const uint64_t* keys, const uint64_t* vals, const uint64_t* keep, const uint64_t* pos,
-                             uint64_t n, uint64_t* out, uint64_t out_cap, unsigned long long* counters) {
-  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (keep[i]) {
-    const uint64_t o = pos[i];
-    if (o < out_cap) {
-      out[2 * o] = keys[i];
-      out[2 * o + 1] = vals[i];
-    }
-  }
-  if (i == n - 1) counters[kCntFinal] = pos[i] + keep[i];
-}
-
-__global__ void detect_adjacent(const uint64_t* keys, const uint64_t* vals, unsigned long long* counters) {
-  const uint64_t n = counters[kCntCands];
-  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const uint64_t e = vals[i];
-    if (e <= keys[i]) continue;
-    uint64_t lo = 0, hi = n;
-    while (lo < hi) {
-      const uint64_t mid = (lo + hi) >> 1;
-      if (keys[mid] < e) lo = mid + 1; else hi = mid;
-    }
-    if (lo < n && keys[lo] == e) counters[kCntAdjacent] = 1;
-  }
 }
 
 // The reference's no-fast-forward kMatchAll loop, restated for ONE lane: a ring of
@@ -2454,589 +1466,13 @@ __global__ __launch_bounds__(256) void copy_long_gaps(const uint8_t* text, const
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// Dense mode, lane-sized automaton, everything in one kernel: find the candidate starts of a
-// 1-KiB chunk, walk them, keep only the starts at which something matched.
-//
-// The list-based dense pipeline (scan_dense -> region_offsets -> verify -> mark/scan/compact)
-// moves ~100 bytes of list traffic per candidate START; `[A-Z][a-z]+ [A-Z][a-z]+` over random
-// ASCII has a start at 35% of the bytes, so 1 GB of text cost 35 GB of traffic (13.6 ms) for
-// zero matches.  Here a start that does not match leaves no trace in HBM:
-//   1. each lane tests its 16 bytes (first-byte bitmap / nullable contexts) -> 16-bit mask;
-//      a wave scan ranks the chunk's candidates and their in-chunk offsets go to an LDS list;
-//   2. persistent walkers (see verify_walkers) run the automaton from every listed start and
-//      put the match length back into the candidate's LDS slot;
-//   3. the slots are compacted in order and the survivors appended to the wave's region as
-//      (begin -> region, end -> region_ends).
-// Downstream is the windows pipeline's offsets_gather_check.  Tables and the next text byte as
-// in verify_walkers.
-// NW = 32-bit words of automaton state per lane (1, 2 or 4); CTX = the pattern has ^ / $.
-// Positions inside the kernel are 32-bit offsets from the chunk base.
-constexpr int kHalo = 64;                    // bytes after the chunk kept in LDS for the walkers
-constexpr int kTextWindow = kChunk + kHalo;  // per wave
 
-// PD = depth of the lane-packed pre-steps (dense_swar.h), 0: the pattern does not qualify.
-// (amdgpu_waves_per_eu(6, 8): 80 instead of 90 VGPRs, six waves per SIMD instead of five -- measured 6 % on
-// `[a-f]+[0-9]`, 10 % on `[@#]`; seven waves need scratch and are slower again.)
-template <int NW, bool CTX, int PD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void scan_dense_walk(ScanParams a, DevProgram P, uint64_t* region_ends,
-                                                       unsigned long long* counters) {
-  extern __shared__ uint32_t tab[];
-  __shared__ uint32_t fb[8];  // first-byte bitmap (indexed by data: LDS, not registers)
-  if (threadIdx.x < 8) fb[threadIdx.x] = P.first_bytes[threadIdx.x];
-  const int W = P.n_words, C = P.n_ctx, NP = P.n_pos > 0 ? P.n_pos : 1;
-  const int o_last = C * W, o_lin = 2 * C * W, o_rowof = o_lin + W, o_rows = o_rowof + NP, o_cls = o_rows + C * P.n_rows * W;
-  for (uint32_t i = threadIdx.x; i < P.table_words; i += blockDim.x) tab[i] = P.first[i];
-  __syncthreads();
-  const int lane = lane_id();
-  // candidate slots of this wave: bits 0..9 offset inside the chunk, bits 10.. match length + 1
-  uint32_t* slot = tab + ((P.table_words + 3u) & ~3u) + (threadIdx.x >> 6) * kChunk;
-  // the chunk's text for the walkers (+ kHalo bytes after it): a global byte load per step made
-  // every step wait a full memory latency -- the one-ahead prefetch cannot be waited for
-  // separately (vmcnt counts in order) -- and the kernel was bound by exactly that
-  uint8_t* txt = reinterpret_cast<uint8_t*>(tab + ((P.table_words + 3u) & ~3u) + 4 * kChunk) + (threadIdx.x >> 6) * kTextWindow;
-  const uint64_t wave = scalar_wave_index();
-  uint64_t* region = a.hits + wave * a.region_cap;
-  uint64_t* ends = region_ends + wave * a.region_cap;
-  uint32_t count = 0;  // survivors of this wave so far (wave-uniform)
-  const uint64_t first_chunk = a.sb / kChunk;
-  const uint64_t end_chunk = (a.se + kChunk - 1) / kChunk;  // se <= n + 1
-  const WaveSpan span = wave_span(a, wave, first_chunk, end_chunk);
-  // per-word constants: linear / loop / skip masks; first and last rows of context 0 (all there is
-  // without assertions)
-  uint32_t step1[NW], loopm[NW], skipm[NW], first0[NW], last0[NW];
-#pragma unroll
-  for (int q = 0; q < NW; q++) {
-    const bool in = q < W;
-    loopm[q] = in ? P.loop_mask[q] : 0u;
-    skipm[q] = in ? P.skip_mask[q] : 0u;
-    step1[q] = (in ? tab[o_lin + q] : 0u) | loopm[q] | skipm[q];  // positions that pass to i + 1
-    first0[q] = in ? tab[q] : 0u;
-    last0[q] = in ? tab[o_last + q] : 0u;
-  }
-  // contexts in which a non-empty match can start at all (bit c: first[c] is not empty)
-  uint32_t first_ctx = 0;
-  for (int c = 0; c < C; c++)
-    for (int q = 0; q < W; q++)
-      if (tab[c * W + q] != 0) first_ctx |= 1u << c;
-  if (C == 1) first_ctx = 0xFu;
 
-  // The lane's 16 bytes of the NEXT chunk and the run's "void" flag are loaded one iteration ahead: a load
-  // at the top of the iteration that needs it put a full memory latency (two, with the flag) on every
-  // wave's critical path.
-  uint4 pre_v = make_uint4(0, 0, 0, 0);
-  unsigned long long pre_flag = 0;
-  bool pre_valid = false;  // (wave-uniform)
-  // packed pre-steps of `X+...`: is the last byte of the span's chunk tail_it - 1 in X (both wave-uniform)
-  uint32_t tail_in_x = 0;
-  uint32_t tail_it = ~0u;
-  // (a relaxed atomic load at device scope: fresh data, but -- unlike a volatile access -- nothing to wait for
-  // until the value is used, an iteration later)
-  auto load_flag = [&]() { return __hip_atomic_load(counters + kCntOverrun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  // The loop's wave-uniform tests as 32-bit chunk counts relative to the span: a 64-bit ordering of two uniform
-  // values has no scalar instruction -- the compiler copies both to vector registers and compares there, three VALU
-  // instructions apiece in a kernel that is bound by exactly those.
-  const uint32_t n_iter = static_cast<uint32_t>(span.c1 - span.c0);
-  auto rel = [&](uint64_t chunk) -> uint32_t {
-    return chunk <= span.c0 ? 0u : (chunk - span.c0 >= n_iter ? n_iter : static_cast<uint32_t>(chunk - span.c0));
-  };
-  const uint64_t own_lim = a.se < a.n ? a.se : a.n;
-  const uint32_t full_until = rel(a.n / kChunk);                       // [0, full_until): base + kChunk <= n
-  const uint32_t plus4_until = rel(a.n >= 4 ? (a.n - 4) / kChunk : 0);  // base + kChunk + 4 <= n
-  const uint32_t clip_below = rel((a.sb + kChunk - 1) / kChunk);       // base < sb
-  const uint32_t clip_from = rel(own_lim / kChunk);                    // base + kChunk > min(se, n)
-  for (uint32_t it = 0; it < n_iter; it++) {
-    const uint64_t c = span.c0 + it;
-    const uint64_t base = c * kChunk;
-    const uint64_t at = base + static_cast<uint64_t>(lane) * 16;
-    const uint8_t* tbase = a.text + base;
-    const bool full = it < full_until;
-    uint4 v = pre_v;
-    unsigned long long stop = pre_flag;
-    if (!pre_valid) {
-      stop = load_flag();
-      if (full) v = *reinterpret_cast<const uint4*>(a.text + at);
-    }
-    pre_valid = it + 1 < full_until;  // (the next chunk belongs to the span and lies inside the text)
-    if (pre_valid) {
-      pre_v = *reinterpret_cast<const uint4*>(a.text + at + kChunk);
-      pre_flag = load_flag();
-    }
-    // some walk of this run has hit P.max_walk: the run is void (the engine repeats it on the carry
-    // scan), no point in finishing it
-    if (stop != 0) break;
-    // text length as seen from the chunk (a walk is cut at 2^20 bytes, so clamping is exact)
-    const uint32_t n_rel = a.n - base < 0x7FFFFFFFull ? static_cast<uint32_t>(a.n - base) : 0x7FFFFFFFu;
-    // ---- 1. candidate mask of the lane's 16 positions
-    uint32_t d[6];
-    if (full) {
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    } else {
-      load_guarded(a.text, a.n, at, d);
-    }
-    uint32_t cand = 0;
-    uint32_t fin = 0, flen = 0;  // starts already decided by the pre-steps, 2 bits of length each
-    uint32_t Hs[4] = {0, 0, 0, 0};  // packed pre-steps: per start the lengths that matched (dense_swar.h)
-    const bool packed = PD > 0 && it < plus4_until;  // (wave-uniform)
-    if (packed) {
-      // Pre-steps, four starts per register (dense_swar.h): class rows by byte-parallel range tests, the
-      // first `depth` automaton steps of all 16 starts, no lookups and no divergence.  A start that is
-      // dead after depth + 1 bytes is decided here; the others go to the walkers.
-      uint32_t x[5] = {d[0], d[1], d[2], d[3], wave_from_lane_above(d[0])};
-      if (lane == kWave - 1) x[4] = *reinterpret_cast<const uint32_t*>(a.text + base + kChunk);  // (in the text: see `packed`)
-      uint32_t rows[5], walk, matched, in_x;
-      rj_swar_rows5(P.swar, x, rows);
-      // (masks in F layout from here on: bit 8k + g = the lane's start 4g + k, dense_swar.h)
-      if (P.loop_first) rj_swar_presteps<(PD > 0 ? PD : 1), true>(P.swar, rows, &walk, &matched, Hs, &in_x);
-      else rj_swar_presteps<(PD > 0 ? PD : 1), false>(P.swar, rows, &walk, &matched, Hs, &in_x);
-      fin = matched & ~walk;
-      cand = walk | fin;
-      const uint64_t lim = own_lim;
-      if (it < clip_below || it >= clip_from) {  // the chunks at the ends of the own range (a scalar test)
-        const uint32_t hi = lim > at ? (lim - at < 16 ? static_cast<uint32_t>(lim - at) : 16u) : 0u;
-        const uint32_t lo = a.sb > at ? (a.sb - at < 16 ? static_cast<uint32_t>(a.sb - at) : 16u) : 0u;
-        const uint32_t range = rj_swar_f_from_starts(((1u << hi) - 1u) & ~((1u << lo) - 1u));
-        fin &= range;
-        cand &= range;
-      }
-      if (P.loop_first) {
-        // `X+...`: a start whose previous byte is in X too is never selected (see DevProgram::loop_first).  The byte
-        // before the chunk: the last lane's flag of the chunk before, when this wave has just been through it --
-        // else one byte from the text
-        uint32_t prev_in = wave_from_lane_below(rj_swar_f_last(in_x));
-        uint32_t before = tail_in_x;
-        if (tail_it != it) before = base > 0 ? ((fb[a.text[base - 1] >> 5] >> (a.text[base - 1] & 31)) & 1u) : 0u;
-        if (lane == 0) prev_in = before;
-        cand &= ~rj_swar_f_next(in_x, prev_in);
-        tail_in_x = wave_last_lane(rj_swar_f_last(in_x));
-        tail_it = it + 1;
-      }
-    } else if (PD == 0 && NW == 1 && !CTX && P.nullable == 0 && it < plus4_until) {
-      // Pre-steps: the first kPre automaton steps of ALL 16 starts of the lane, in registers, with
-      // no divergence.  Most starts die within a few bytes (a walk on random text is ~1.5 steps
-      // long), and those never reach the walkers: a start that is dead after kPre + 1 bytes is
-      // decided here (its longest match, if any, has length <= kPre).  Positions with a general
-      // follow row are not stepped here: a state that holds one keeps the start for the walkers.
-      constexpr int kPre = 2;
-      uint32_t r[16 + kPre];  // class rows of the lane's bytes and of the kPre bytes after them
-      const uint32_t nx = wave_from_lane_above(d[0]);
-#pragma unroll
-      for (int k = 0; k < 16 + kPre; k++) {
-        const uint32_t byte = ((k < 16 ? d[k >> 2] : nx) >> (8 * (k & 3))) & 0xFFu;
-        r[k] = tab[o_cls + byte];
-      }
-      // (all flags as 0/1 integers: comparisons would go through the scalar unit)
-      auto nz = [](uint32_t x) -> uint32_t { return x < 1u ? x : 1u; };
-      uint32_t walk = 0;
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
-        uint32_t S = first0[0] & r[j];
-        uint32_t f = 0, gen = 0;
-#pragma unroll
-        for (int t = 1; t <= kPre; t++) {
-          const uint32_t hit = nz(S & last0[0]);
-          f = hit * t > f ? hit * t : f;
-          gen |= S & ~step1[0];
-          S = ((((S & step1[0]) << 1) | ((S & skipm[0]) << 2) | (S & loopm[0]))) & r[j + t];
-        }
-        const uint32_t alive = nz(S | gen);  // alive or decided, a start has a first byte
-        walk |= alive << j;
-        fin |= (nz(f) & (alive ^ 1u)) << j;
-        flen |= f << (2 * j);
-      }
-      if (lane == kWave - 1) {  // no neighbour: the rows past the lane's bytes are not valid
-        constexpr uint32_t tail = ((1u << kPre) - 1u) << (16 - kPre);
-        uint32_t starts = 0;
-#pragma unroll
-        for (int j = 16 - kPre; j < 16; j++) starts |= static_cast<uint32_t>((first0[0] & r[j]) != 0) << j;
-        walk = (walk & ~tail) | starts;
-        fin &= ~tail;
-      }
-      const uint64_t lim = a.se < a.n ? a.se : a.n;
-      const uint32_t hi = lim > at ? (lim - at < 16 ? static_cast<uint32_t>(lim - at) : 16u) : 0u;
-      const uint32_t lo = a.sb > at ? (a.sb - at < 16 ? static_cast<uint32_t>(a.sb - at) : 16u) : 0u;
-      const uint32_t range = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-      fin &= range;
-      cand = (walk & range) | fin;
-      if (P.loop_first) {
-        // `X+...`: a start whose previous byte is in X too is never selected (see DevProgram::loop_first)
-        uint32_t in_x = 0;
-#pragma unroll
-        for (int j = 0; j < 16; j++) in_x |= static_cast<uint32_t>((first0[0] & r[j]) != 0) << j;
-        uint32_t prev_in = wave_from_lane_below(in_x >> 15);
-        if (lane == 0) prev_in = base > 0 ? ((fb[a.text[base - 1] >> 5] >> (a.text[base - 1] & 31)) & 1u) : 0u;
-        cand &= ~((in_x << 1) | prev_in);
-      }
-    } else {
-      // General form.  A position starts a candidate when its byte can begin a match in the
-      // position's context, or (nullable patterns: x*, ^, $, ...) when the empty string matches
-      // there.  Contexts (bit0: start of line, bit1: end of line) of all 16 positions come from one
-      // line-break bitmask of the lane's bytes: sol = that mask shifted by one with the neighbour's
-      // last byte shifted in, eol = the mask itself plus the end of the text.  Patterns that begin
-      // with an assertion (`^[a-z]+:`) have an EMPTY first set outside their context: without the
-      // context filter every [a-z] byte of the text was a candidate for the walkers.
-      uint32_t lb = 0, first16 = 0;
-      if (CTX) {
-        // line breaks of the 16 bytes, four bytes per operation (a byte is \n or \r when one of the two
-        // differences is zero)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const uint32_t both = rj_swar_nz(d[q] ^ 0x0a0a0a0au) & rj_swar_nz(d[q] ^ 0x0d0d0d0du);
-          lb |= rj_swar_movemask(both ^ 0x80808080u) << (4 * q);
-        }
-      }
-      if (P.n_pos != 0) {  // (only assertions: no byte begins a match)
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-          const uint32_t cur = (d[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-          first16 |= ((fb[cur >> 5] >> (cur & 31)) & 1u) << j;
-        }
-      }
-      // positions with a byte (s < n) / positions at all (s <= n)
-      const uint32_t lt_n = a.n > at ? (a.n - at < 16 ? (1u << (a.n - at)) - 1u : 0xFFFFu) : 0u;
-      const uint32_t le_n = a.n >= at ? (a.n - at < 15 ? (2u << (a.n - at)) - 1u : 0xFFFFu) : 0u;
-      uint32_t null16 = P.nullable ? 0xFFFFu : 0u, allowed16 = 0xFFFFu;
-      if (CTX) {
-        lb &= lt_n;
-        uint32_t prev_lb = wave_from_lane_below(lb >> 15);  // the neighbour's last byte
-        if (lane == 0) prev_lb = base > 0 ? static_cast<uint32_t>(rj_line_break(a.text[base - 1])) : 1u;  // text start
-        const uint32_t sol = ((lb << 1) | prev_lb) & 0xFFFFu;
-        uint32_t eol = lb;
-        if (a.n >= at && a.n - at < 16) eol |= 1u << (a.n - at);  // the end of the text
-        const uint32_t in_ctx[4] = {~sol & ~eol, sol & ~eol, ~sol & eol, sol & eol};
-        null16 = 0;
-        allowed16 = 0;
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          if ((P.nullable >> c) & 1u) null16 |= in_ctx[c];
-          if ((first_ctx >> c) & 1u) allowed16 |= in_ctx[c];
-        }
-      }
-      const uint32_t hi = a.se > at ? (a.se - at < 16 ? static_cast<uint32_t>(a.se - at) : 16u) : 0u;
-      const uint32_t lo = a.sb > at ? (a.sb - at < 16 ? static_cast<uint32_t>(a.sb - at) : 16u) : 0u;
-      const uint32_t range = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-      cand = ((first16 & allowed16 & lt_n) | (null16 & le_n)) & 0xFFFFu & range;
-      if (P.loop_first) {  // (no assertions, not nullable: first16 is membership in X)
-        const uint32_t in_x = first16 & lt_n;
-        uint32_t prev_in = wave_from_lane_below(in_x >> 15);
-        if (lane == 0) prev_in = base > 0 ? ((fb[a.text[base - 1] >> 5] >> (a.text[base - 1] & 31)) & 1u) : 0u;
-        cand &= ~((in_x << 1) | prev_in);
-      }
-      if (P.n_pos == 0) {
-        // only assertions (^, $, ^$): every candidate IS a match, the empty one -- no walk at all
-        // (the line table of a grep-like caller is a MatchAll of "^", sample/jrep.cc:294)
-        fin = cand;
-        flen = 0;
-      }
-    }
-    if (__ballot(cand != 0) == 0) continue;
-    if ((packed || P.n_pos == 0) && __ballot((cand & ~fin) != 0) == 0) {
-      // Every candidate of the chunk is decided already (the common chunk of `[a-f]+[0-9]`, every chunk of
-      // `^`): no walkers, so no text window, no slots -- the lanes put their matches straight into the region
-      const uint32_t mine = __popc(cand);
-      const uint32_t inc = wave_inclusive_sum(mine);
-      uint32_t pos = count + inc - mine;
-      if (packed) {
-#pragma unroll
-        for (int g = 0; g < 4; g++) {  // (text order: group by group, byte by byte)
-          uint32_t m = (cand >> g) & 0x01010101u;
-          while (m) {
-            const int b = __ffs(static_cast<int>(m)) - 1;  // 8k
-            m &= m - 1;
-            const uint32_t hb = (Hs[g] >> b) & 0xFu;
-            if (pos < a.region_cap) {
-              const uint64_t s = at + static_cast<uint64_t>(4 * g + (b >> 3));
-              region[pos] = s;
-              ends[pos] = s + (32u - static_cast<uint32_t>(__clz(static_cast<int>(hb))));
-            }
-            pos++;
-          }
-        }
-      } else {
-        uint32_t m = cand;
-        while (m) {  // (only assertions: the empty match)
-          const int j = __ffs(static_cast<int>(m)) - 1;
-          m &= m - 1;
-          if (pos < a.region_cap) {
-            region[pos] = at + static_cast<uint64_t>(j);
-            ends[pos] = at + static_cast<uint64_t>(j);
-          }
-          pos++;
-        }
-      }
-      count += wave_last_lane(inc);
-      continue;
-    }
-    *reinterpret_cast<uint4*>(txt + lane * 16) = make_uint4(d[0], d[1], d[2], d[3]);
-    if (lane < kHalo / 4) {
-      const uint64_t hp = base + kChunk + 4 * lane;
-      uint32_t hv = 0;
-      if (hp + 4 <= a.n) {
-        hv = *reinterpret_cast<const uint32_t*>(a.text + hp);
-      } else {
-        for (int q = 0; q < 4; q++)
-          if (hp + q < a.n) hv |= static_cast<uint32_t>(a.text[hp + q]) << (8 * q);
-      }
-      *reinterpret_cast<uint32_t*>(txt + kChunk + 4 * lane) = hv;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    // byte at chunk offset x < n_rel
-    auto tb = [&](uint32_t x) -> uint32_t { return x < kChunk + kHalo ? txt[x] : tbase[x]; };
-    const uint32_t mine = __popc(cand);
-    const uint32_t inc = wave_inclusive_sum(mine);
-    const uint32_t total = wave_last_lane(inc);
-    if (packed) {
-      uint32_t idx = inc - mine;
-#pragma unroll
-      for (int g = 0; g < 4; g++) {  // (text order: group by group, byte by byte; Hs[] stays in registers)
-        uint32_t m = (cand >> g) & 0x01010101u;
-        while (m) {
-          const int b = __ffs(static_cast<int>(m)) - 1;  // 8k
-          m &= m - 1;
-          const int j = 4 * g + (b >> 3);
-          // decided starts carry their length already (bits 10..: length + 1): the longest prefix that matched
-          const uint32_t hb = (Hs[g] >> b) & 0xFu;
-          const uint32_t len1 = (fin >> (b + g)) & 1u ? (32u - static_cast<uint32_t>(__clz(static_cast<int>(hb)))) + 1u : 0u;
-          slot[idx++] = static_cast<uint32_t>(lane * 16 + j) | (len1 << 10);
-        }
-      }
-    } else {
-      uint32_t idx = inc - mine, m = cand;
-      while (m) {
-        const int j = __ffs(static_cast<int>(m)) - 1;
-        m &= m - 1;
-        // decided starts carry their length already (bits 10..: length + 1), the others go to the walkers
-        const uint32_t len1 = (fin >> j) & 1u ? ((flen >> (2 * j)) & 3u) + 1u : 0u;
-        slot[idx++] = static_cast<uint32_t>(lane * 16 + j) | (len1 << 10);
-      }
-    }
-    // ---- 2. persistent walkers over slot[0 .. total)
-    {
-      uint32_t cursor = 0;
-      bool active = false, found = false;
-      uint32_t my_k = 0, prevb = 0, curb = 0;
-      uint32_t s = 0, p = 0, e = 0, S[NW];  // offsets from the chunk base
-#pragma unroll
-      for (int q = 0; q < NW; q++) S[q] = 0;
-      for (;;) {
-        const uint64_t idle = __ballot(!active);
-        if (idle != 0 && cursor < total) {
-          const uint32_t k = cursor + __popcll(idle & ((1ull << lane) - 1ull));
-          const uint32_t entry = !active && k < total ? slot[k] : 1u << 10;
-          if ((entry >> 10) == 0) {  // (an entry decided by the pre-steps is left as it is)
-            my_k = k;
-            s = entry;
-            active = true;
-            found = false;
-            e = 0;
-            curb = s < n_rel ? tb(s) : '\n';
-            int ctx = 0;
-            if (CTX) {
-              prevb = (base + s) > 0 ? *(tbase + s - 1) : '\n';  // s <= n here
-              if (base + s == 0 || rj_line_break(prevb)) ctx |= 1;
-              if (s == n_rel || rj_line_break(curb)) ctx |= 2;
-            }
-            if ((P.nullable >> ctx) & 1u) {
-              found = true;
-              e = s;
-            }
-            const bool can_start = s < n_rel && P.n_pos != 0;
-            const int crow = o_cls + static_cast<int>(curb) * W;
-#pragma unroll
-            for (int q = 0; q < NW; q++) {
-              const uint32_t f = CTX ? (q < W ? tab[ctx * W + q] : 0u) : first0[q];
-              S[q] = can_start && q < W ? (f & tab[crow + q]) : 0u;
-            }
-            p = s + 1;
-            prevb = curb;
-            curb = p < n_rel ? tb(p) : '\n';
-          }
-          cursor += __popcll(idle);
-          if (cursor > total) cursor = total;
-        }
-        if (__ballot(active) == 0) {
-          if (cursor >= total) break;
-          continue;  // a whole round of entries was already decided by the pre-steps: hand out the next
-        }
-        if (active) {
-          uint32_t alive = 0;
-#pragma unroll
-          for (int q = 0; q < NW; q++) alive |= S[q];
-          bool done = alive == 0;
-          if (!done) {
-            int ctx = 0;
-            if (CTX) {
-              if (rj_line_break(prevb)) ctx |= 1;  // p >= 1 here
-              if (p == n_rel || rj_line_break(curb)) ctx |= 2;
-            }
-            uint32_t acc = 0;
-#pragma unroll
-            for (int q = 0; q < NW; q++) acc |= S[q] & (CTX ? (q < W ? tab[o_last + ctx * W + q] : 0u) : last0[q]);
-            if (acc) {
-              found = true;
-              e = p;
-            }
-            if (p == n_rel) {
-              done = true;
-            } else if (p - s >= P.max_walk) {
-              counters[kCntOverrun] = 1;
-              done = true;
-            } else {
-              const uint32_t nextb = p + 1 < n_rel ? tb(p + 1) : '\n';
-              uint32_t T[NW];
-              uint32_t c1 = 0, c2 = 0;
-#pragma unroll
-              for (int q = 0; q < NW; q++) {
-                const uint32_t x = S[q] & step1[q], y = S[q] & skipm[q];
-                T[q] = (x << 1) | c1 | (y << 2) | c2 | (S[q] & loopm[q]);
-                c1 = x >> 31;
-                c2 = y >> 30;
-              }
-#pragma unroll
-              for (int q = 0; q < NW; q++) {
-                uint32_t sp = S[q] & ~step1[q];  // positions with a general follow set: OR their rows in
-                while (sp) {
-                  const int b = __ffs(static_cast<int>(sp)) - 1;
-                  sp &= sp - 1;
-                  const int row = o_rows + (ctx * P.n_rows + static_cast<int>(tab[o_rowof + q * 32 + b])) * W;
-#pragma unroll
-                  for (int j = 0; j < NW; j++)
-                    if (j < W) T[j] |= tab[row + j];
-                }
-              }
-              const int crow = o_cls + static_cast<int>(curb) * W;
-#pragma unroll
-              for (int q = 0; q < NW; q++) S[q] = q < W ? (T[q] & tab[crow + q]) : 0u;
-              p++;
-              prevb = curb;
-              curb = nextb;
-            }
-          }
-          if (done) {
-            // length + 1 in bits 10..31 (a walk is cut at kMaxSimSteps = 2^20 bytes), 0 = no match
-            slot[my_k] = s | (found ? (e - s + 1) << 10 : 0u);
-            active = false;
-          }
-        }
-      }
-    }
-    // ---- 3. ordered compaction into the region
-    for (uint32_t kb = 0; kb < total; kb += kWave) {
-      const uint32_t k = kb + lane;
-      const uint32_t v = k < total ? slot[k] : 0u;
-      const bool keep = (v >> 10) != 0;
-      const uint64_t kept = __ballot(keep);
-      const uint32_t pos = count + __popcll(kept & ((1ull << lane) - 1ull));
-      if (keep && pos < a.region_cap) {
-        const uint64_t s = base + (v & 1023u);
-        region[pos] = s;
-        ends[pos] = s + (v >> 10) - 1;
-      }
-      count += __popcll(kept);
-    }
-  }
-  if (lane == 0) {
-    if (count > a.region_cap) {  // the host grows the regions and runs again
-      counters[kCntOverflow] = 1;
-      atomicMax(&counters[kCntMaxRegion], static_cast<unsigned long long>(count));
-    }
-    a.hit_counts[wave] = count < a.region_cap ? count : a.region_cap;
-  }
-}
 
-// ---------------------------------------------------------------------------------------
-// Launchers (host side of the <<< >>> syntax lives here so engine.cc stays plain C++).
-ScanGeometry scan_geometry(uint64_t chunks, uint64_t chunks_per_block) {
-  // Measured on MI355X (tools/ab_probe.py): a grid of exactly the resident workgroups loses
-  // ~12% to the partially filled last round; large texts stream best with >= 16 Ki workgroups
-  // (6.2-6.4 TB/s) while tiny spans waste the pipeline prologue, so aim at >= 32 chunks per
-  // wave and cap at 16 Ki workgroups.
-  uint64_t blocks = chunks / chunks_per_block;
-  if (blocks > 16384) blocks = 16384;
-  if (blocks < 256) blocks = (chunks + 3) / 4 < 256 ? (chunks + 3) / 4 : 256;
-  if (blocks == 0) blocks = 1;
-  static const char* env_grid = getenv("RJ_SCAN_GRID");  // measurement override
-  if (env_grid && atoi(env_grid) > 0) blocks = static_cast<uint64_t>(atoi(env_grid));
-  ScanGeometry g;
-  g.grid = static_cast<int>(blocks);
-  g.n_regions = static_cast<uint32_t>(blocks * 4);
-  g.span_chunks = (chunks + g.n_regions - 1) / g.n_regions;
-  if (g.span_chunks == 0) g.span_chunks = 1;
-  return g;
-}
 
-template <bool TWO, bool MASKED, bool TWOLEVEL, bool NIB>
-static void launch_windows_k(int k, const ScanParams& a, const WindowSet& ws, int grid, hipEvent_t t0, hipEvent_t t1,
-                             hipStream_t st) {
-  // K is rounded up to an instantiated size; the host pads the window set with copies
-  if (k <= 1) hipExtLaunchKernelGGL((scan_windows<1, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a, ws);
-  else if (k == 2) hipExtLaunchKernelGGL((scan_windows<2, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a, ws);
-  else if (k == 3) hipExtLaunchKernelGGL((scan_windows<3, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a, ws);
-  else if (k == 4) hipExtLaunchKernelGGL((scan_windows<4, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a, ws);
-  else if (k <= 6) hipExtLaunchKernelGGL((scan_windows<6, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a, ws);
-  else hipExtLaunchKernelGGL((scan_windows<8, TWO, MASKED, TWOLEVEL, NIB>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a, ws);
-}
 
-void launch_scan_windows(const ScanParams& a, const WindowSet& ws, int n_windows, int grid, hipEvent_t t0, hipEvent_t t1,
-                         hipStream_t st) {
-  const bool two = ws.len > 4;
-  if (two) {
-    if (ws.two_level) {
-      if (ws.masked) launch_windows_k<true, true, true, false>(n_windows, a, ws, grid, t0, t1, st);
-      else launch_windows_k<true, false, true, false>(n_windows, a, ws, grid, t0, t1, st);
-    } else if (ws.nibble) {
-      if (ws.masked) launch_windows_k<true, true, false, true>(n_windows, a, ws, grid, t0, t1, st);
-      else launch_windows_k<true, false, false, true>(n_windows, a, ws, grid, t0, t1, st);
-    } else {
-      if (ws.masked) launch_windows_k<true, true, false, false>(n_windows, a, ws, grid, t0, t1, st);
-      else launch_windows_k<true, false, false, false>(n_windows, a, ws, grid, t0, t1, st);
-    }
-  } else {
-    if (ws.masked) launch_windows_k<false, true, false, false>(n_windows, a, ws, grid, t0, t1, st);
-    else launch_windows_k<false, false, false, false>(n_windows, a, ws, grid, t0, t1, st);
-  }
-}
 
-void launch_scan_windows_train(const TrainParams& t, bool masked, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
-  if (masked) hipExtLaunchKernelGGL((scan_windows_train<true>), dim3(grid), dim3(256), 0, st, t0, t1, 0, t);
-  else hipExtLaunchKernelGGL((scan_windows_train<false>), dim3(grid), dim3(256), 0, st, t0, t1, 0, t);
-}
 
-void launch_scan_windows_fused(const FusedParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
-  if (a.n_bases == 0) hipExtLaunchKernelGGL((scan_windows_fused<0>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
-  else if (a.n_bases == 1) hipExtLaunchKernelGGL((scan_windows_fused<1>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
-  else hipExtLaunchKernelGGL((scan_windows_fused<2>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
-}
-
-void launch_scan_dense(const ScanParams& a, const DevProgram& P, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
-  hipExtLaunchKernelGGL(scan_dense, dim3(grid), dim3(256), 0, st, t0, t1, 0, a, P);
-}
-
-bool dense_walk_fits(const DevProgram& P) { return P.n_words <= 4 && P.table_words <= 8192; }
-
-void launch_scan_dense_walk(const ScanParams& a, const DevProgram& P, int grid, uint64_t* region_ends,
-                            unsigned long long* counters, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
-  const size_t lds = (((static_cast<size_t>(P.table_words) + 3) & ~size_t{3}) + 4 * kChunk) * sizeof(uint32_t) + 4 * kTextWindow;
-  const dim3 g(grid), b(256);
-  const bool ctx = P.n_ctx > 1;
-  const int pd = (P.n_words <= 1 && !ctx && P.swar.n_ranges != 0) ? static_cast<int>(P.swar.depth) : 0;
-  if (pd == 1) {
-    hipExtLaunchKernelGGL((scan_dense_walk<1, false, 1>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
-  } else if (pd == 2) {
-    hipExtLaunchKernelGGL((scan_dense_walk<1, false, 2>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
-  } else if (pd == 4) {
-    hipExtLaunchKernelGGL((scan_dense_walk<1, false, 4>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
-  } else if (P.n_words <= 1) {
-    if (ctx) hipExtLaunchKernelGGL((scan_dense_walk<1, true, 0>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
-    else hipExtLaunchKernelGGL((scan_dense_walk<1, false, 0>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
-  } else if (P.n_words == 2) {
-    if (ctx) hipExtLaunchKernelGGL((scan_dense_walk<2, true, 0>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
-    else hipExtLaunchKernelGGL((scan_dense_walk<2, false, 0>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
-  } else {
-    if (ctx) hipExtLaunchKernelGGL((scan_dense_walk<4, true, 0>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
-    else hipExtLaunchKernelGGL((scan_dense_walk<4, false, 0>), g, b, lds, st, t0, t1, 0, a, P, region_ends, counters);
-  }
-}
 
 void launch_region_offsets(const uint32_t* counts, uint32_t n_regions, uint32_t cap, uint64_t* offsets,
                            unsigned long long* counters, hipStream_t st) {
@@ -3184,9 +1620,6 @@ void launch_match_full(const uint8_t* text, uint64_t n, const DevProgram& P, int
   else hipLaunchKernelGGL((match_full<4>), dim3(1), dim3(64), 0, st, text, n, P, result);
 }
 
-void launch_finalize_small(const FinalizeParams& a, hipStream_t st) {
-  hipLaunchKernelGGL(finalize_small, dim3(1), dim3(1024), 0, st, a);
-}
 
 void launch_check_and_interleave(const uint64_t* keys, const uint64_t* vals, const unsigned long long* n_ptr,
                                  uint64_t n_upper, uint64_t carry_cur, uint64_t* out, uint64_t cap, unsigned long long* unordered,
@@ -3197,12 +1630,6 @@ void launch_check_and_interleave(const uint64_t* keys, const uint64_t* vals, con
                      n_ptr, carry_cur, out, cap, unordered);
 }
 
-void launch_detect_adjacent(const uint64_t* keys, const uint64_t* vals, uint64_t n_upper, unsigned long long* counters,
-                            hipStream_t st) {
-  uint64_t blocks = (n_upper + 255) / 256;
-  blocks = blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks;
-  hipLaunchKernelGGL(detect_adjacent, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, keys, vals, counters);
-}
 
 void launch_exact_sequential(const uint8_t* text, uint64_t n, const DevGraph& G, int64_t* ring, uint64_t* out,
                              uint64_t out_cap, unsigned long long* counters, hipStream_t st) {
@@ -3224,41 +1651,10 @@ void launch_replace_gather(const uint8_t* text, uint64_t n, const uint64_t* span
   hipLaunchKernelGGL(copy_long_gaps, dim3(2048), dim3(256), 0, st, text, long_gaps, counters, out, out_cap);
 }
 
-static unsigned blocks_for(uint64_t n) { return static_cast<unsigned>((n + 255) / 256); }
 
-size_t chain_select_scratch_bytes(uint64_t n) { return ((n + 31) / 32 * 2 + 2) * sizeof(uint64_t); }
 
-void launch_chain_select(const uint64_t* keys, const uint64_t* vals, const uint64_t* pmax, uint64_t n, uint64_t carry_cur,
-                         uint8_t* taken, uint64_t* nxt, uint64_t* G, uint64_t* blocks_scratch, hipStream_t st) {
-  const uint64_t B = chain_block(n);
-  const uint64_t nb = (n + B - 1) / B;
-  uint64_t* first_head = blocks_scratch;
-  uint64_t* entry = blocks_scratch + nb;
-  uint64_t* i0 = blocks_scratch + 2 * nb;
-  (void)hipMemsetAsync(taken, 0, n, st);
-  hipLaunchKernelGGL(chain_next, dim3(blocks_for(n)), dim3(256), 0, st, keys, vals, n, carry_cur, nxt, i0);
-  const unsigned lb = static_cast<unsigned>((nb + 63) / 64);
-  const unsigned wb = static_cast<unsigned>(nb);  // a wave per block of candidates
-  hipLaunchKernelGGL(chain_local, dim3(wb), dim3(64), 0, st, keys, pmax, nxt, n, carry_cur, B, i0, G, first_head, entry);
-  hipLaunchKernelGGL(chain_hop, dim3(lb), dim3(64), 0, st, G, first_head, i0, n, B, entry);
-  hipLaunchKernelGGL(chain_mark, dim3(wb), dim3(64), 0, st, nxt, first_head, entry, i0, n, B, taken);
-}
 
-void launch_taken_index(const uint8_t* taken, uint64_t n, uint64_t* idx, hipStream_t st) {
-  hipLaunchKernelGGL(taken_index, dim3(blocks_for(n)), dim3(256), 0, st, taken, n, idx);
-}
 
-void launch_zero_length_rule(const uint64_t* keys, const uint64_t* vals, const uint8_t* taken,
-                             const uint64_t* last_taken, uint64_t n, uint64_t carry_prev_end, int have_prev,
-                             uint64_t* keep, unsigned long long* conflict, hipStream_t st) {
-  hipLaunchKernelGGL(apply_zero_length_rule, dim3(blocks_for(n)), dim3(256), 0, st, keys, vals, taken, last_taken, n,
-                     carry_prev_end, have_prev, keep, conflict);
-}
 
-void launch_compact_kept(const uint64_t* keys, const uint64_t* vals, const uint64_t* keep, const uint64_t* pos,
-                         uint64_t n, uint64_t* out, uint64_t out_cap, unsigned long long* counters, hipStream_t st) {
-  hipLaunchKernelGGL(compact_kept, dim3(blocks_for(n)), dim3(256), 0, st, keys, vals, keep, pos, n, out, out_cap,
-                     counters);
-}
 
 }  // namespace rejit_amd

@@ -13,7 +13,7 @@ TRACE_LIB = os.path.join(api.PKG, "librejit_hip_trace.so")
 if "--build" in sys.argv:
     api.build()
     objdir = os.path.join(api.PKG, "build")
-    traced = ("kernels.hip", "verify_lds.hip", "plane_scan.hip")
+    traced = ("kernels.hip", "verify_lds.hip", "plane_scan.hip")   # (round 6: the window scans, scan_dense_walk and the selection kernels left kernels.hip; none of them carries stamps)
     objs = []
     for src in traced:
         objs.append(os.path.join(objdir, os.path.splitext(src)[0] + "_trace.o"))
