@@ -237,7 +237,7 @@ class CopyPool {
 struct StageRing {
   char* base = nullptr;
   hipEvent_t ev[kStageSlots] = {};
-  bool ok = false;
+  bool ok = false, failed = false;
   ~StageRing() {
     if (base) (void)hipHostFree(base);
     for (auto& e : ev)
@@ -245,14 +245,16 @@ struct StageRing {
   }
   bool ready() {
     if (ok) return true;
-    if (base) return false;   // (a failed attempt is not repeated)
+    if (failed) return false;   // (a failed attempt is not repeated: the plain copy serves)
+    failed = true;
     if (hipHostMalloc(reinterpret_cast<void**>(&base), kStageSlice * kStageSlots, hipHostMallocPortable) != hipSuccess) {
-      base = reinterpret_cast<char*>(1);
+      base = nullptr;
       (void)hipGetLastError();
       return false;
     }
     for (auto& e : ev)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+    failed = false;
     ok = true;
     return true;
   }

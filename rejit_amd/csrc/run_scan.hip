@@ -271,10 +271,17 @@ __global__ __launch_bounds__(1024) void run_resolve(RunParams a) {
   const uint64_t C = (a.n_tiles + 1023) / 1024;
   const uint64_t lo = static_cast<uint64_t>(t) * C, hi = lo + C < a.n_tiles ? lo + C : a.n_tiles;
   const Elem identity{0, kNone, kNone, kNone, kNone, kNone};   // (a stretch without a break, an A or a B hands every state on)
+  // (the loops over a thread's tiles load four summaries at a time: one thread's loads, issued one after the other and each
+  // waited for, were most of this kernel -- 58 us for the 8192 tiles of a 64 MiB text, three passes of eight dependent trips)
+  constexpr int kBatch = 4;
   Elem e = identity;
-  for (uint64_t i = lo; i < hi; i++) {
-    const Elem g = elem_of(a.summaries[i]);
-    e = i == lo ? g : compose(e, g);
+  for (uint64_t i = lo; i < hi; i += kBatch) {
+    RunSummary sm[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) sm[k] = a.summaries[i + k < hi ? i + k : i];
+#pragma unroll
+    for (int k = 0; k < kBatch; k++)
+      if (i + k < hi) e = (i + k == lo) ? elem_of(sm[k]) : compose(e, elem_of(sm[k]));
   }
   int cur = 0;
   chunk[0][t] = e;
@@ -290,17 +297,23 @@ __global__ __launch_bounds__(1024) void run_resolve(RunParams a) {
   bool emits;
   Open st = t == 0 ? initial : apply(a, chunk[cur][t - 1], initial, &emits);
   unsigned long long total = 0;
-  for (uint64_t i = lo; i < hi; i++) {
-    const RunSummary s = a.summaries[i];
-    const Open next = apply(a, elem_of(s), st, &emits);
-    RunTileIn ti;
-    ti.s = st.s;
-    ti.q = st.q;
-    ti.off = s.cnt + (emits ? 1ull : 0ull);   // (the tile's count for now: turned into its offset below)
-    ti.pad = 0;
-    a.tile_in[i] = ti;
-    total += ti.off;
-    st = next;
+  for (uint64_t i = lo; i < hi; i += kBatch) {
+    RunSummary sm[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) sm[k] = a.summaries[i + k < hi ? i + k : i];
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) {
+      if (i + k >= hi) break;
+      const Open next = apply(a, elem_of(sm[k]), st, &emits);
+      RunTileIn ti;
+      ti.s = st.s;
+      ti.q = st.q;
+      ti.off = sm[k].cnt + (emits ? 1ull : 0ull);   // (the tile's count for now: turned into its offset below)
+      ti.pad = 0;
+      a.tile_in[i + k] = ti;
+      total += ti.off;
+      st = next;
+    }
   }
   int sc = 0;
   sums[0][t] = total;
@@ -320,10 +333,16 @@ __global__ __launch_bounds__(1024) void run_resolve(RunParams a) {
     if (a.host_counters) a.host_counters[kCntFinal] = run;
   }
   unsigned long long off = sums[sc][t] - total;
-  for (uint64_t i = lo; i < hi; i++) {
-    const unsigned long long c = a.tile_in[i].off;
-    a.tile_in[i].off = off;
-    off += c;
+  for (uint64_t i = lo; i < hi; i += kBatch) {
+    unsigned long long c[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) c[k] = a.tile_in[i + k < hi ? i + k : i].off;
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) {
+      if (i + k >= hi) break;
+      a.tile_in[i + k].off = off;
+      off += c[k];
+    }
   }
 }
 

@@ -48,16 +48,18 @@ for case in range(cases):
             else:
                 branches.append(s)
         patterns.append(b"|".join(branches))
-    n = rng.choice([3000, 33000, 70001, 200000])
+    n = rng.choice([16, 17, 24, 40, 100, 2047, 2048, 2049, 2056, 3000, 4095, 4097, 33000, 70001, 200000])
     if dense:
         t = bytearray(rng.choices(alphabet, k=n))
     else:
         t = bytearray(rng.choices(ASCII, k=n))
-    for _ in range(n // 200):
+    for _ in range(n // 200 + 2):
         s = bytearray(rng.choice(lits))
+        if len(s) > n:
+            continue
         if rng.random() < 0.3:
             s[rng.randrange(len(s))] = rng.choice(alphabet)
-        at = rng.randrange(0, n - len(s))
+        at = rng.choice([0, n - len(s), rng.randrange(0, n - len(s) + 1)])     # (also at the very begin and end of the text)
         t[at:at + len(s)] = s
     text = bytes(t)
     own = None if rng.random() < 0.7 else tuple(sorted((rng.randrange(0, n + 1), rng.randrange(0, n + 1))))
