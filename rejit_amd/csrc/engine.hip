@@ -567,8 +567,8 @@ static int run_runs(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, 
     a.blocked_in = ((P.cls[last] >> l_pos) & 1u) ? 1u : 0u;
   }
   a.n_tiles = run_tiles(a.min_start, n, &a.first_tile);
-  RJ_HIP(s->run_summaries.reserve(sizeof(RunSummary) * a.n_tiles));
-  RJ_HIP(s->run_tile_in.reserve(sizeof(RunTileIn) * a.n_tiles));
+  RJ_HIP(s->run_summaries.reserve(sizeof(RunSummary) * run_resolve_slots(a.n_tiles)));
+  RJ_HIP(s->run_tile_in.reserve(sizeof(RunTileIn) * run_resolve_slots(a.n_tiles)));
   a.summaries = s->run_summaries.as<RunSummary>();
   a.tile_in = s->run_tile_in.as<RunTileIn>();
   a.counters = s->counters.as<unsigned long long>();

@@ -275,7 +275,7 @@ struct RunSummary {
 struct RunTileIn {
   unsigned long long s, q;           // the segment open at the tile's begin
   unsigned long long off;            // the tile's first output pair
-  unsigned long long pad;
+  unsigned long long cnt;            // the pairs it writes (0: run_emit skips the tile)
 };
 struct RunParams {
   const uint8_t* text;   // 16-byte aligned
@@ -284,6 +284,7 @@ struct RunParams {
   uint64_t min_start;    // starts below are not looked at (the own range's begin, or where a carried-in match ends)
   uint32_t blocked_in;   // the segment that holds min_start has had its match (a carried-in match with a B that is no break)
   uint64_t first_tile, n_tiles;
+  uint64_t block_tiles;  // (set by launch_run_resolve: tiles per block of the two-level resolve)
   RunPlan plan;
   RunSummary* summaries;
   RunTileIn* tile_in;
@@ -293,6 +294,7 @@ struct RunParams {
   unsigned long long* host_counters;
 };
 uint64_t run_tiles(uint64_t sb, uint64_t n, uint64_t* first_tile);
+uint64_t run_resolve_slots(uint64_t n_tiles);   // elements of `summaries` and of `tile_in`: the tiles + the blocks of the two-level resolve
 void launch_run_summary(const RunParams& a, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 void launch_run_resolve(const RunParams& a, hipStream_t st);
 void launch_run_emit(const RunParams& a, hipEvent_t t1, hipStream_t st);

@@ -9,13 +9,16 @@
 //                scalar registers; an iteration without a break costs two ballots, a break one trip round a loop.  Leaves
 //                the tile's summary: its first break, the first A / last B before it, the matches closed by its other
 //                breaks (they depend on nothing outside the tile), the segment open at its end.
-//   run_resolve  ONE workgroup: the summaries composed (tiles without a break hand the pending thread on, tiles with one
-//                replace it: associative), every tile's incoming state and the number of its first output pair.
-//   run_emit     run_summary's walk again with the incoming state known: the pairs at their final place.
-// Cost: the streams (~36 VALU per range and 32 bytes) twice; FETCH_SIZE 2 x the text.  Texts with a break every few bytes
+//   run_resolve  the summaries composed (tiles without a break hand the pending thread on, tiles with one replace it:
+//                associative), every tile's incoming state and the number of its first output pair: ONE workgroup up to
+//                32 MiB of text, beyond that two levels over blocks of 1024 tiles (run_reduce, run_resolve_blocks, run_apply).
+//   run_emit     run_summary's walk again with the incoming state known, over the tiles that close a match: the pairs at
+//                their final place.
+// Cost: the streams (~36 VALU per range and 32 bytes) once or twice; FETCH_SIZE 1-2 x the text.  Texts with a break every few bytes
 // take one loop trip per break -- slower than dense_streams, which is tried first for the patterns it takes.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <stdlib.h>
 
 #include "kernels.h"
 #include "run_scan.h"
@@ -205,12 +208,27 @@ __global__ __launch_bounds__(256) void run_summary(RunParams a) {
 
 namespace {
 
-// a tile (or a run of tiles) as a function on the open segment's state
+// a tile (or a run of tiles) as a function on the open segment's state.  cnt: the matches closed by its breaks other than the
+// first (what the first closes depends on the state that comes in)
 struct Elem {
   unsigned long long hb;   // holds a break
-  unsigned long long a1, b1, b1a, open_s, open_q;
+  unsigned long long a1, b1, b1a, open_s, open_q, cnt;
 };
-__device__ __forceinline__ Elem elem_of(const RunSummary& s) { return Elem{s.r1 != kNone ? 1ull : 0ull, s.a1, s.b1, s.b1a, s.open_s, s.open_q}; }
+__device__ __forceinline__ Elem elem_of(const RunSummary& s) { return Elem{s.r1 != kNone ? 1ull : 0ull, s.a1, s.b1, s.b1a, s.open_s, s.open_q, s.cnt}; }
+__device__ __forceinline__ RunSummary summary_of(const Elem& e) {   // (a block of tiles in the tiles' own format: r1 is a flag only)
+  RunSummary s;
+  s.r1 = e.hb ? 0ull : kNone;
+  s.a1 = e.a1;
+  s.b1 = e.b1;
+  s.b1a = e.b1a;
+  s.open_s = e.open_s;
+  s.open_q = e.open_q;
+  s.cnt = e.cnt;
+  s.pad = 0;
+  return s;
+}
+// the segment closed in state o holds a match that counts
+__device__ __forceinline__ bool counted(const RunParams& a, const Open& o) { return real(o.s) && (!a.plan.has_b || o.q != kNone) && o.s >= a.sb && o.s < a.se; }
 // the state behind a stretch without a break
 __device__ __forceinline__ Open pass_on(const Elem& g, Open in) {
   Open o;
@@ -224,7 +242,7 @@ __device__ __forceinline__ Open pass_on(const Elem& g, Open in) {
   return o;
 }
 // f, then g
-__device__ __forceinline__ Elem compose(const Elem& f, const Elem& g) {
+__device__ __forceinline__ Elem compose(const RunParams& a, const Elem& f, const Elem& g) {
   Elem e;
   if (!f.hb) {   // the stretch before the composite's first break: f's whole, then g's beginning
     e.a1 = f.a1 != kNone ? f.a1 : g.a1;
@@ -236,7 +254,9 @@ __device__ __forceinline__ Elem compose(const Elem& f, const Elem& g) {
     e.b1a = f.b1a;
   }
   e.hb = (f.hb | g.hb) ? 1ull : 0ull;
+  e.cnt = f.cnt + g.cnt;
   if (g.hb) {
+    if (f.hb && counted(a, pass_on(g, Open{f.open_s, f.open_q}))) e.cnt++;   // g's first break is not the composite's first
     e.open_s = g.open_s;
     e.open_q = g.open_q;
   } else if (f.hb) {
@@ -252,55 +272,64 @@ __device__ __forceinline__ Elem compose(const Elem& f, const Elem& g) {
 __device__ __forceinline__ Open apply(const RunParams& a, const Elem& g, Open in, bool* emits) {
   *emits = false;
   if (!g.hb) return pass_on(g, in);
-  const Open at_break = pass_on(g, in);
-  *emits = real(at_break.s) && (!a.plan.has_b || at_break.q != kNone) && at_break.s >= a.sb && at_break.s < a.se;
+  *emits = counted(a, pass_on(g, in));
   return Open{g.open_s, g.open_q};
 }
 
-}  // namespace
+constexpr uint64_t kBlockTiles = 1024;     // tiles per workgroup of the two-level resolve (RunParams::block_tiles)
+constexpr uint64_t kOneLevelTiles = 4096;  // up to here ONE workgroup resolves everything
 
-// ONE workgroup of 1024 threads: thread t owns the tiles [t C, (t + 1) C).  Its tiles composed into one element; an inclusive
-// scan of the 1024 elements in LDS (ten rounds: the composition is associative; the first version let thread 0 walk them one after
-// the other -- 197 us of the 280 us a 64 MiB text took); the element BEFORE a thread's chunk applied to the run's initial state is
-// the chunk's incoming state; the chunk walked again with it: every tile's incoming state and count; the counts' prefix sums the
-// same way.
-__global__ __launch_bounds__(1024) void run_resolve(RunParams a) {
-  __shared__ Elem chunk[2][1024];
-  __shared__ unsigned long long sums[2][1024];
+// T threads over the n elements src[0 .. n): thread t owns [t C, (t + 1) C).  Its elements composed into one; an inclusive scan
+// of the T composites in LDS (log2 T rounds: the composition is associative -- the first version let thread 0 walk them one
+// after the other: 197 us of the 280 us a 64 MiB text took).  Then either the whole span's composite goes to *whole (the
+// reduce step of the two-level resolve), or: the composite BEFORE a thread's chunk applied to the span's incoming state
+// (initial, off0) is the chunk's incoming state and first output pair; the chunk walked again with it leaves every element's
+// incoming state and offset in dst; *total (thread T - 1) = off0 + the span's matches.
+// (The loops over a thread's elements load four at a time: one thread's loads, issued one after the other and each waited
+// for, were most of this kernel.)
+template <int T>
+__device__ __forceinline__ void resolve_span(const RunParams& a, const RunSummary* src, RunTileIn* dst, uint64_t n, Open initial, unsigned long long off0,
+                                             Elem (*chunk)[T], RunSummary* whole, unsigned long long* total) {
   const uint32_t t = threadIdx.x;
-  const uint64_t C = (a.n_tiles + 1023) / 1024;
-  const uint64_t lo = static_cast<uint64_t>(t) * C, hi = lo + C < a.n_tiles ? lo + C : a.n_tiles;
-  const Elem identity{0, kNone, kNone, kNone, kNone, kNone};   // (a stretch without a break, an A or a B hands every state on)
-  // (the loops over a thread's tiles load four summaries at a time: one thread's loads, issued one after the other and each
-  // waited for, were most of this kernel -- 58 us for the 8192 tiles of a 64 MiB text, three passes of eight dependent trips)
+  const uint64_t C = (n + T - 1) / T;
+  const uint64_t lo = static_cast<uint64_t>(t) * C < n ? static_cast<uint64_t>(t) * C : n, hi = lo + C < n ? lo + C : n;
+  const Elem identity{0, kNone, kNone, kNone, kNone, kNone, 0};   // (a stretch without a break, an A or a B hands every state on)
   constexpr int kBatch = 4;
   Elem e = identity;
   for (uint64_t i = lo; i < hi; i += kBatch) {
     RunSummary sm[kBatch];
 #pragma unroll
-    for (int k = 0; k < kBatch; k++) sm[k] = a.summaries[i + k < hi ? i + k : i];
+    for (int k = 0; k < kBatch; k++) sm[k] = src[i + k < hi ? i + k : i];
 #pragma unroll
     for (int k = 0; k < kBatch; k++)
-      if (i + k < hi) e = (i + k == lo) ? elem_of(sm[k]) : compose(e, elem_of(sm[k]));
+      if (i + k < hi) e = (i + k == lo) ? elem_of(sm[k]) : compose(a, e, elem_of(sm[k]));
   }
   int cur = 0;
   chunk[0][t] = e;
   __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {
+  for (uint32_t d = 1; d < T; d <<= 1) {
     Elem v = chunk[cur][t];
-    if (t >= d) v = compose(chunk[cur][t - d], v);
+    if (t >= d) v = compose(a, chunk[cur][t - d], v);
     chunk[cur ^ 1][t] = v;
     cur ^= 1;
     __syncthreads();
   }
-  const Open initial{a.blocked_in ? kBlocked : kNone, kNone};
-  bool emits;
-  Open st = t == 0 ? initial : apply(a, chunk[cur][t - 1], initial, &emits);
-  unsigned long long total = 0;
+  if (whole) {
+    if (t == T - 1) *whole = summary_of(chunk[cur][T - 1]);
+    return;
+  }
+  bool emits = false;
+  Open st = initial;
+  unsigned long long off = off0;
+  if (t != 0) {
+    const Elem before = chunk[cur][t - 1];
+    st = apply(a, before, initial, &emits);
+    off += before.cnt + (emits ? 1ull : 0ull);
+  }
   for (uint64_t i = lo; i < hi; i += kBatch) {
     RunSummary sm[kBatch];
 #pragma unroll
-    for (int k = 0; k < kBatch; k++) sm[k] = a.summaries[i + k < hi ? i + k : i];
+    for (int k = 0; k < kBatch; k++) sm[k] = src[i + k < hi ? i + k : i];
 #pragma unroll
     for (int k = 0; k < kBatch; k++) {
       if (i + k >= hi) break;
@@ -308,42 +337,57 @@ __global__ __launch_bounds__(1024) void run_resolve(RunParams a) {
       RunTileIn ti;
       ti.s = st.s;
       ti.q = st.q;
-      ti.off = sm[k].cnt + (emits ? 1ull : 0ull);   // (the tile's count for now: turned into its offset below)
-      ti.pad = 0;
-      a.tile_in[i + k] = ti;
-      total += ti.off;
+      ti.off = off;
+      ti.cnt = sm[k].cnt + (emits ? 1ull : 0ull);
+      dst[i + k] = ti;
+      off += ti.cnt;
       st = next;
     }
   }
-  int sc = 0;
-  sums[0][t] = total;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {
-    unsigned long long v = sums[sc][t];
-    if (t >= d) v += sums[sc][t - d];
-    sums[sc ^ 1][t] = v;
-    sc ^= 1;
-    __syncthreads();
-  }
-  if (t == 1023) {
-    const unsigned long long run = sums[sc][1023];
-    a.counters[kCntFinal] = run;
-    a.counters[kCntCands] = run;
-    a.counters[kCntHits] = run;
-    if (a.host_counters) a.host_counters[kCntFinal] = run;
-  }
-  unsigned long long off = sums[sc][t] - total;
-  for (uint64_t i = lo; i < hi; i += kBatch) {
-    unsigned long long c[kBatch];
-#pragma unroll
-    for (int k = 0; k < kBatch; k++) c[k] = a.tile_in[i + k < hi ? i + k : i].off;
-#pragma unroll
-    for (int k = 0; k < kBatch; k++) {
-      if (i + k >= hi) break;
-      a.tile_in[i + k].off = off;
-      off += c[k];
-    }
-  }
+  if (t == T - 1) *total = off;
+}
+
+__device__ __forceinline__ void leave_total(const RunParams& a, unsigned long long run) {
+  a.counters[kCntFinal] = run;
+  a.counters[kCntCands] = run;
+  a.counters[kCntHits] = run;
+  if (a.host_counters) a.host_counters[kCntFinal] = run;
+}
+
+}  // namespace
+
+// Texts of up to kOneLevelTiles tiles (32 MiB): ONE workgroup composes the tiles' summaries -- every tile's incoming state and
+// the number of its first output pair.
+__global__ __launch_bounds__(1024) void run_resolve(RunParams a) {
+  __shared__ Elem chunk[2][1024];
+  unsigned long long total = 0;
+  resolve_span<1024>(a, a.summaries, a.tile_in, a.n_tiles, Open{a.blocked_in ? kBlocked : kNone, kNone}, 0, chunk, nullptr, &total);
+  if (threadIdx.x == 1023) leave_total(a, total);
+}
+// Longer texts, two levels (one workgroup alone took half of a 4 GiB call: 512 tiles per thread, walked twice): a workgroup
+// per block of kBlockTiles tiles composes its block into ONE element behind the tiles' summaries (run_reduce); one workgroup
+// resolves the blocks (run_resolve_blocks: their incoming states and offsets behind the tiles' own); a workgroup per block
+// resolves its tiles from there (run_apply).
+__global__ __launch_bounds__(256) void run_reduce(RunParams a) {
+  __shared__ Elem chunk[2][256];
+  const uint64_t b = blockIdx.x, first = b * a.block_tiles;
+  const uint64_t n = a.n_tiles - first < a.block_tiles ? a.n_tiles - first : a.block_tiles;
+  resolve_span<256>(a, a.summaries + first, nullptr, n, Open{kNone, kNone}, 0, chunk, a.summaries + a.n_tiles + b, nullptr);
+}
+__global__ __launch_bounds__(1024) void run_resolve_blocks(RunParams a) {
+  __shared__ Elem chunk[2][1024];
+  const uint64_t n_blocks = (a.n_tiles + a.block_tiles - 1) / a.block_tiles;
+  unsigned long long total = 0;
+  resolve_span<1024>(a, a.summaries + a.n_tiles, a.tile_in + a.n_tiles, n_blocks, Open{a.blocked_in ? kBlocked : kNone, kNone}, 0, chunk, nullptr, &total);
+  if (threadIdx.x == 1023) leave_total(a, total);
+}
+__global__ __launch_bounds__(256) void run_apply(RunParams a) {
+  __shared__ Elem chunk[2][256];
+  const uint64_t b = blockIdx.x, first = b * a.block_tiles;
+  const uint64_t n = a.n_tiles - first < a.block_tiles ? a.n_tiles - first : a.block_tiles;
+  const RunTileIn in = a.tile_in[a.n_tiles + b];
+  unsigned long long total = 0;
+  resolve_span<256>(a, a.summaries + first, a.tile_in + first, n, Open{in.s, in.q}, in.off, chunk, nullptr, &total);
 }
 
 __global__ __launch_bounds__(256) void run_emit(RunParams a) {
@@ -352,6 +396,7 @@ __global__ __launch_bounds__(256) void run_emit(RunParams a) {
   if (tile >= a.n_tiles) return;
   const uint64_t base = (a.first_tile + tile) * kRunTile;
   const RunTileIn in = a.tile_in[tile];
+  if (in.cnt == 0) return;   // (no pair ends here: a text of long runs is read ONCE)
   Open st{in.s, in.q};
   unsigned long long pos = in.off;
   bool no_track = false;
@@ -392,7 +437,31 @@ void launch_run_summary(const RunParams& a, hipEvent_t t0, hipEvent_t t1, hipStr
   const unsigned grid = static_cast<unsigned>((a.n_tiles + 3) / 4);
   hipExtLaunchKernelGGL(run_summary, dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
 }
-void launch_run_resolve(const RunParams& a, hipStream_t st) { hipLaunchKernelGGL(run_resolve, dim3(1), dim3(1024), 0, st, a); }
+// RJ_RUN_TWO_LEVELS=<tiles per block>: every text through the two-level kernels, in blocks of that many tiles (tests)
+static uint64_t forced_block_tiles() {
+  static const uint64_t v = [] {
+    const char* e = getenv("RJ_RUN_TWO_LEVELS");
+    const long x = e ? atol(e) : 0;
+    return static_cast<uint64_t>(x > 0 ? x : 0);
+  }();
+  return v;
+}
+uint64_t run_resolve_slots(uint64_t n_tiles) {
+  const uint64_t bt = forced_block_tiles() ? forced_block_tiles() : kBlockTiles;
+  return n_tiles + (n_tiles + bt - 1) / bt;
+}
+void launch_run_resolve(const RunParams& a0, hipStream_t st) {
+  RunParams a = a0;
+  a.block_tiles = forced_block_tiles() ? forced_block_tiles() : kBlockTiles;
+  if (a.n_tiles <= kOneLevelTiles && !forced_block_tiles()) {
+    hipLaunchKernelGGL(run_resolve, dim3(1), dim3(1024), 0, st, a);
+    return;
+  }
+  const unsigned blocks = static_cast<unsigned>((a.n_tiles + a.block_tiles - 1) / a.block_tiles);
+  hipLaunchKernelGGL(run_reduce, dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(run_resolve_blocks, dim3(1), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(run_apply, dim3(blocks), dim3(256), 0, st, a);
+}
 void launch_run_emit(const RunParams& a, hipEvent_t t1, hipStream_t st) {
   const unsigned grid = static_cast<unsigned>((a.n_tiles + 3) / 4);
   hipExtLaunchKernelGGL(run_emit, dim3(grid), dim3(256), 0, st, nullptr, t1, 0, a);
