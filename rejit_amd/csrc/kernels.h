@@ -285,6 +285,7 @@ struct RunParams {
   uint32_t blocked_in;   // the segment that holds min_start has had its match (a carried-in match with a B that is no break)
   uint64_t first_tile, n_tiles;
   uint64_t block_tiles;  // (set by launch_run_resolve: tiles per block of the two-level resolve)
+  uint32_t seq_max;      // (set by the launchers: iterations with at most this many breaks take the sequential machine)
   RunPlan plan;
   RunSummary* summaries;
   RunTileIn* tile_in;

@@ -1,21 +1,23 @@
-// rejit_amd/csrc/run_scan.hip -- the kernels of run_scan.h: MatchAll of `X+` / `A L*` / `A L* B` / `X+ B` patterns in two
+// rejit_amd/csrc/run_scan.hip -- the kernels of run_scan.h: MatchAll of `X+` / `A L*` / `A L* B` / `X+ B` patterns in one or two
 // passes over the text and one small scan over tile summaries, whatever the length of the runs (reference: the NFA loop's
 // one long-lived thread, src/x64/codegen-x64.cc:535-581, its last accepting position :426-461, the restart behind the
 // match :487-503).
 //
 //   run_summary  a wave per tile of 8 KiB (four iterations of 2 KiB: a lane owns 32 bytes, the next iteration's in flight):
-//                the class streams of A, B and the breaks (dense_streams.h: rj_stream_range), then the tile's events in
-//                text order with the wave as ONE sequential machine -- its state is the open segment's (s1, q), kept in
-//                scalar registers; an iteration without a break costs two ballots, a break one trip round a loop.  Leaves
-//                the tile's summary: its first break, the first A / last B before it, the matches closed by its other
-//                breaks (they depend on nothing outside the tile), the segment open at its end.
+//                the class streams of A, B and the breaks (dense_streams.h: rj_stream_range); the wave's state is the open
+//                segment's (s1, q) in scalar registers.  An iteration without a break costs two ballots; one with breaks is
+//                settled by all lanes at once (run_iteration_par: segments inside a lane's word by the lane, the segment a
+//                lane's first break closes through two prefix maxima over the wave; the sequential machine -- a trip per
+//                break -- is kept for iterations with one break).  Leaves the tile's summary: its first break, the first A /
+//                last B before it, the matches closed by its other breaks (they depend on nothing outside the tile), the
+//                segment open at its end.
 //   run_resolve  the summaries composed (tiles without a break hand the pending thread on, tiles with one replace it:
 //                associative), every tile's incoming state and the number of its first output pair: ONE workgroup up to
 //                32 MiB of text, beyond that two levels over blocks of 1024 tiles (run_reduce, run_resolve_blocks, run_apply).
 //   run_emit     run_summary's walk again with the incoming state known, over the tiles that close a match: the pairs at
 //                their final place.
-// Cost: the streams (~36 VALU per range and 32 bytes) once or twice; FETCH_SIZE 1-2 x the text.  Texts with a break every few bytes
-// take one loop trip per break -- slower than dense_streams, which is tried first for the patterns it takes.
+// Cost: the streams (~36 VALU per range and 32 bytes) once or twice; FETCH_SIZE 1-2 x the text; 1.1 TB/s (a break every 33
+// bytes) to 3.3 TB/s (none) for a whole call.  dense_streams (one pass) is tried first for the patterns it takes.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdlib.h>
@@ -106,6 +108,8 @@ struct Open {
 };
 
 __device__ __forceinline__ bool real(unsigned long long s) { return s < kBlocked; }
+// the segment closed in state o holds a match that counts
+__device__ __forceinline__ bool counted(const RunParams& a, const Open& o) { return real(o.s) && (!a.plan.has_b || o.q != kNone) && o.s >= a.sb && o.s < a.se; }
 
 // The events of one iteration in text order.  on_close(state, r): the break at absolute position r closes the segment.
 // any_b (may be null): the last B position met before the first close of this call chain (the caller resets it).
@@ -147,6 +151,133 @@ __device__ __forceinline__ void run_iteration(const RunParams& a, uint64_t it_ba
   part(kIterBytes, kIterBytes);
 }
 
+
+// ---- the iteration's breaks in parallel (round 6, second form).  The sequential machine above takes one trip per break: a text
+// with a break every 33 bytes ran at 236 GB/s.  Here every lane settles what lies between the breaks of its own 32 bytes
+// by itself, and what crosses lanes comes from two prefix maxima over the wave:
+//   * the segment closed by a lane's FIRST break began in a lane below (or before the iteration): its first A is the
+//     smallest "A at or behind the last break" of the lanes since the last lane with a break, its last B the largest "B
+//     behind the last break" of those lanes -- keys (breaks so far << 12 | position) make a plain prefix maximum of both;
+//   * the segments between two breaks of one lane (for_inner) need nothing from outside.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t x) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ uint32_t umax(uint32_t x, uint32_t y) { return x > y ? x : y; }
+__device__ __forceinline__ uint32_t wave_prefix_max(uint32_t x) {   // (inclusive; keys are >= 0: the zero a DPP move leaves is neutral)
+  x = umax(x, dpp0<0x111, 0xF>(x));  // row_shr:1
+  x = umax(x, dpp0<0x112, 0xF>(x));  // row_shr:2
+  x = umax(x, dpp0<0x114, 0xF>(x));  // row_shr:4
+  x = umax(x, dpp0<0x118, 0xF>(x));  // row_shr:8
+  x = umax(x, dpp0<0x142, 0xA>(x));  // row_bcast:15 into rows 1 and 3
+  x = umax(x, dpp0<0x143, 0xC>(x));  // row_bcast:31 into rows 2 and 3
+  return x;
+}
+__device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t x) {
+  x += dpp0<0x111, 0xF>(x);
+  x += dpp0<0x112, 0xF>(x);
+  x += dpp0<0x114, 0xF>(x);
+  x += dpp0<0x118, 0xF>(x);
+  x += dpp0<0x142, 0xA>(x);
+  x += dpp0<0x143, 0xC>(x);
+  return x;
+}
+__device__ __forceinline__ uint32_t lane_below(uint32_t x) { return dpp0<0x138, 0xF>(x); }   // wave_shr:1, lane 0 gets 0
+__device__ __forceinline__ uint32_t last_lane(uint32_t x) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(x), kWave - 1)); }
+__device__ __forceinline__ unsigned long long lane_value(unsigned long long x, int l) {
+  const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(x)), l));
+  const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(x >> 32)), l));
+  return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+__device__ __forceinline__ uint32_t bits_below(uint32_t b) { return (1u << b) - 1u; }        // b in 0 .. 31
+__device__ __forceinline__ uint32_t bits_upto(uint32_t b) { return (2u << b) - 1u; }         // bits 0 .. b, b in 0 .. 31
+
+// SA with the starts below min_start taken out (the sequential machine does that where it picks a start)
+__device__ __forceinline__ uint32_t clip_starts(const RunParams& a, uint64_t it_base, uint32_t SA) {
+  if (a.min_start <= it_base) return SA;
+  const uint32_t a_lo = a.min_start - it_base < kIterBytes ? static_cast<uint32_t>(a.min_start - it_base) : kIterBytes;
+  return clip(SA, lane_id(), a_lo, kIterBytes);
+}
+
+struct LaneClose {
+  unsigned long long s, q;   // the state the lane's first break closes (lanes with a break)
+  unsigned long long b_any;  // the last B of the iteration at or before that break (kNone: none)
+};
+
+// An iteration that holds a break (brm = ballot(BR != 0) != 0).  SA: clipped.  Leaves what every lane's first break closes and
+// the state behind the iteration's last break in st.
+__device__ __forceinline__ LaneClose run_iteration_par(const RunParams& a, uint64_t it_base, uint32_t SA, uint32_t SB, uint32_t BR, uint64_t brm, Open& st) {
+  const int lane = lane_id();
+  const uint32_t pbase = static_cast<uint32_t>(lane) * 32u;
+  const bool hb = BR != 0;
+  const uint32_t fb = hb ? static_cast<uint32_t>(__builtin_ctz(BR)) : 0u, lb = hb ? 31u - static_cast<uint32_t>(__builtin_clz(BR)) : 0u;
+  const uint32_t headA = hb ? SA & bits_below(fb) : SA;      // starts before the first break
+  const uint32_t headB = hb ? SB & bits_upto(fb) : SB;       // (B may be the break itself)
+  const uint32_t tailA = hb ? SA & ~bits_below(lb) : SA;     // (a start may sit ON the break that opens its segment)
+  const uint32_t tailB = hb ? SB & ~bits_upto(lb) : SB;
+  const uint32_t seg_excl = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(brm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(brm), 0u));
+  const uint32_t seg_incl = seg_excl + (hb ? 1u : 0u);
+  const uint32_t keyA = (seg_incl << 12) | (tailA ? 0xfffu - (pbase + static_cast<uint32_t>(__builtin_ctz(tailA))) : 0u);
+  const uint32_t inclA = wave_prefix_max(keyA);
+  const uint32_t exclA = lane_below(inclA) & 0xfffu;
+  uint32_t inclB = 0, exclB = 0;
+  if (a.plan.has_b) {   // (uniform)
+    const uint32_t keyB = (seg_incl << 12) | (tailB ? pbase + 32u - static_cast<uint32_t>(__builtin_clz(tailB)) : 0u);   // position + 1
+    inclB = wave_prefix_max(keyB);
+    exclB = lane_below(inclB) & 0xfffu;
+  }
+  LaneClose c;
+  c.s = c.q = c.b_any = kNone;
+  const bool carried = seg_excl == 0 && st.s != kNone;   // the segment was open, with its start, when the iteration began
+  bool s_here = false;
+  if (carried) {
+    c.s = st.s;
+  } else if (exclA != 0) {
+    c.s = it_base + (0xfffu - exclA);
+  } else if (headA != 0) {
+    c.s = it_base + pbase + static_cast<uint32_t>(__builtin_ctz(headA));
+    s_here = true;
+  }
+  if (a.plan.has_b) {
+    if (headB != 0) c.b_any = it_base + pbase + 31u - static_cast<uint32_t>(__builtin_clz(headB));
+    else if (exclB != 0 && seg_excl == 0) c.b_any = it_base + (exclB - 1u);
+    if (real(c.s)) {
+      const uint32_t hbm = s_here ? headB & ~bits_upto(static_cast<uint32_t>(__builtin_ctz(headA))) : headB;
+      if (hbm != 0) {
+        c.q = it_base + pbase + 31u - static_cast<uint32_t>(__builtin_clz(hbm));
+      } else if (!s_here) {
+        if (exclB != 0 && (carried || it_base + (exclB - 1u) > c.s)) c.q = it_base + (exclB - 1u);
+        else if (carried) c.q = st.q;
+      }
+    }
+  }
+  // behind the iteration's last break
+  const uint32_t endA = last_lane(inclA) & 0xfffu, endB = last_lane(inclB) & 0xfffu;
+  st.s = endA != 0 ? it_base + (0xfffu - endA) : kNone;
+  st.q = (endA != 0 && endB != 0 && it_base + (endB - 1u) > st.s) ? it_base + (endB - 1u) : kNone;
+  return c;
+}
+
+// the segments between two breaks of the lane's own word, in text order: f(s, q, r) -- positions relative to the word; q = 32: no B
+template <class F>
+__device__ __forceinline__ void for_inner(const RunParams& a, uint32_t SA, uint32_t SB, uint32_t BR, F f) {
+  if (BR == 0) return;
+  uint32_t prev = static_cast<uint32_t>(__builtin_ctz(BR));
+  uint32_t rest = BR & (BR - 1u);
+  while (rest != 0) {
+    const uint32_t r = static_cast<uint32_t>(__builtin_ctz(rest));
+    rest &= rest - 1u;
+    const uint32_t am = SA & bits_below(r) & ~bits_below(prev);
+    if (am != 0) {
+      const uint32_t s = static_cast<uint32_t>(__builtin_ctz(am));
+      const uint32_t bm = SB & bits_upto(r) & ~bits_upto(s);
+      if (!a.plan.has_b) f(s, 32u, r);
+      else if (bm != 0) f(s, 31u - static_cast<uint32_t>(__builtin_clz(bm)), r);
+    }
+    prev = r;
+  }
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(256) void run_summary(RunParams a) {
@@ -182,17 +313,43 @@ __global__ __launch_bounds__(256) void run_summary(RunParams a) {
     uint32_t SA, SB, BR;
     run_streams_of(a, it_base + static_cast<uint64_t>(lane) * 32, v0, v1, loaded, &SA, &SB, &BR);
     if (it + 1 < kIters) fetch(it + 1);
-    run_iteration(a, it_base, SA, SB, BR, st, &any_b, &before_first, [&](const Open& o, uint64_t r) {
-      if (before_first) {   // the tile's first break: what it closes depends on the tiles before
-        sum.r1 = r;
-        sum.a1 = o.s;
-        sum.b1a = o.q;
-        sum.b1 = any_b;
-        before_first = false;
-      } else if (real(o.s) && (!a.plan.has_b || o.q != kNone) && o.s >= a.sb && o.s < a.se) {
-        cnt++;
-      }
-    });
+    const uint64_t brm = __ballot(BR != 0), multi = __ballot((BR & (BR - 1u)) != 0);
+    if (brm == 0 || (multi == 0 && static_cast<uint32_t>(__popcll(brm)) <= a.seq_max)) {
+      run_iteration(a, it_base, SA, SB, BR, st, &any_b, &before_first, [&](const Open& o, uint64_t r) {
+        if (before_first) {   // the tile's first break: what it closes depends on the tiles before
+          sum.r1 = r;
+          sum.a1 = o.s;
+          sum.b1a = o.q;
+          sum.b1 = any_b;
+          before_first = false;
+        } else if (counted(a, o)) {
+          cnt++;
+        }
+      });
+      continue;
+    }
+    const uint32_t SAc = clip_starts(a, it_base, SA);
+    const LaneClose c = run_iteration_par(a, it_base, SAc, SB, BR, brm, st);
+    bool first = BR != 0 && counted(a, Open{c.s, c.q});
+    if (before_first) {
+      const int l1 = __builtin_ctzll(brm);
+      sum.r1 = it_base + static_cast<uint64_t>(l1) * 32u + static_cast<uint32_t>(__builtin_ctz(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(BR), l1))));
+      sum.a1 = lane_value(c.s, l1);
+      sum.b1a = lane_value(c.q, l1);
+      const unsigned long long b = lane_value(c.b_any, l1);
+      sum.b1 = b != kNone ? b : any_b;
+      before_first = false;
+      if (lane == l1) first = false;
+    }
+    cnt += static_cast<unsigned long long>(__popcll(__ballot(first)));
+    if (multi != 0) {
+      uint32_t inner = 0;
+      for_inner(a, SAc, SB, BR, [&](uint32_t s, uint32_t, uint32_t) {
+        const uint64_t at = it_base + static_cast<uint64_t>(lane) * 32u + s;
+        if (at >= a.sb && at < a.se) inner++;
+      });
+      cnt += last_lane(wave_prefix_sum(inner));
+    }
   }
   if (before_first) {   // no break in the tile
     sum.a1 = st.s;
@@ -227,8 +384,6 @@ __device__ __forceinline__ RunSummary summary_of(const Elem& e) {   // (a block 
   s.pad = 0;
   return s;
 }
-// the segment closed in state o holds a match that counts
-__device__ __forceinline__ bool counted(const RunParams& a, const Open& o) { return real(o.s) && (!a.plan.has_b || o.q != kNone) && o.s >= a.sb && o.s < a.se; }
 // the state behind a stretch without a break
 __device__ __forceinline__ Open pass_on(const Elem& g, Open in) {
   Open o;
@@ -419,12 +574,40 @@ __global__ __launch_bounds__(256) void run_emit(RunParams a) {
     uint32_t SA, SB, BR;
     run_streams_of(a, it_base + static_cast<uint64_t>(lane) * 32, v0, v1, loaded, &SA, &SB, &BR);
     if (it + 1 < kIters) fetch(it + 1);
-    run_iteration(a, it_base, SA, SB, BR, st, nullptr, &no_track, [&](const Open& o, uint64_t r) {
-      if (real(o.s) && (!a.plan.has_b || o.q != kNone) && o.s >= a.sb && o.s < a.se) {
-        if (lane == 0 && pos < a.out_cap) *reinterpret_cast<ulonglong2*>(a.out + 2 * pos) = make_ulonglong2(o.s, a.plan.has_b ? o.q + 1 : r);
-        pos++;
-      }
-    });
+    const uint64_t brm = __ballot(BR != 0), multi = __ballot((BR & (BR - 1u)) != 0);
+    if (brm == 0 || (multi == 0 && static_cast<uint32_t>(__popcll(brm)) <= a.seq_max)) {
+      run_iteration(a, it_base, SA, SB, BR, st, nullptr, &no_track, [&](const Open& o, uint64_t r) {
+        if (counted(a, o)) {
+          if (lane == 0 && pos < a.out_cap) *reinterpret_cast<ulonglong2*>(a.out + 2 * pos) = make_ulonglong2(o.s, a.plan.has_b ? o.q + 1 : r);
+          pos++;
+        }
+      });
+      continue;
+    }
+    const uint32_t SAc = clip_starts(a, it_base, SA);
+    const LaneClose c = run_iteration_par(a, it_base, SAc, SB, BR, brm, st);
+    const uint64_t word = it_base + static_cast<uint64_t>(lane) * 32u;
+    const bool first = BR != 0 && counted(a, Open{c.s, c.q});
+    uint32_t mine = first ? 1u : 0u;
+    if (multi != 0)
+      for_inner(a, SAc, SB, BR, [&](uint32_t s, uint32_t, uint32_t) {
+        if (word + s >= a.sb && word + s < a.se) mine++;
+      });
+    if (__ballot(mine != 0) == 0) continue;
+    const uint32_t inc = wave_prefix_sum(mine);
+    unsigned long long idx = pos + inc - mine;
+    if (first) {
+      if (idx < a.out_cap) *reinterpret_cast<ulonglong2*>(a.out + 2 * idx) = make_ulonglong2(c.s, a.plan.has_b ? c.q + 1 : word + static_cast<uint32_t>(__builtin_ctz(BR)));
+      idx++;
+    }
+    if (multi != 0)
+      for_inner(a, SAc, SB, BR, [&](uint32_t s, uint32_t q, uint32_t r) {
+        if (word + s >= a.sb && word + s < a.se) {
+          if (idx < a.out_cap) *reinterpret_cast<ulonglong2*>(a.out + 2 * idx) = make_ulonglong2(word + s, word + (a.plan.has_b ? q + 1u : r));
+          idx++;
+        }
+      });
+    pos += last_lane(inc);
   }
 }
 
@@ -433,7 +616,17 @@ uint64_t run_tiles(uint64_t sb, uint64_t n, uint64_t* first_tile) {
   return n / kRunTile - *first_tile + 1;   // (the tile that holds position n -- the text's end -- is the last)
 }
 
-void launch_run_summary(const RunParams& a, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+// iterations with at most this many breaks, each in a lane of its own, take the sequential machine (RJ_RUN_SEQ_MAX: measurements)
+static uint32_t seq_max_breaks() {
+  static const uint32_t v = [] {
+    const char* e = getenv("RJ_RUN_SEQ_MAX");
+    return e ? static_cast<uint32_t>(atol(e)) : 1u;
+  }();
+  return v;
+}
+void launch_run_summary(const RunParams& a0, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+  RunParams a = a0;
+  a.seq_max = seq_max_breaks();
   const unsigned grid = static_cast<unsigned>((a.n_tiles + 3) / 4);
   hipExtLaunchKernelGGL(run_summary, dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
 }
@@ -462,7 +655,9 @@ void launch_run_resolve(const RunParams& a0, hipStream_t st) {
   hipLaunchKernelGGL(run_resolve_blocks, dim3(1), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(run_apply, dim3(blocks), dim3(256), 0, st, a);
 }
-void launch_run_emit(const RunParams& a, hipEvent_t t1, hipStream_t st) {
+void launch_run_emit(const RunParams& a0, hipEvent_t t1, hipStream_t st) {
+  RunParams a = a0;
+  a.seq_max = seq_max_breaks();
   const unsigned grid = static_cast<unsigned>((a.n_tiles + 3) / 4);
   hipExtLaunchKernelGGL(run_emit, dim3(grid), dim3(256), 0, st, nullptr, t1, 0, a);
 }

@@ -104,6 +104,24 @@ def test_run_kernels_are_forced_and_exact(rj, oracle, monkeypatch):
             assert st["linear_path"] == 0
 
 
+def test_run_kernels_on_break_dense_text(rj, oracle):
+    """A text with a break every few bytes AND one run of 300 KB (dense_streams gives the text up, the run kernels take the
+    whole of it): the iterations with breaks go through the lane-parallel form (run_scan.hip: run_iteration_par -- segments
+    inside a lane's 32 bytes, segments across lanes by two prefix maxima, segments across iterations and tiles)."""
+    rng = random.Random(47)
+    for rx, alphabet, run in [(b"[acgt]+", b"acgtacgtacgtacgtN", b"acgt"), (b"a.*b", b"abcdefgh" * 6 + b"\n", b"acdefgh"), (b"<[^>]*>", b"<ab cd>", b"abcd "),
+                              (b"[a-f]+[0-9]", b"abcdef01 ", b"abcdef"), (b"a[bc]*", b"abcbcbcbcx", b"bc"), (b"[^>]+", b"ab>", b"ab"), (b"x+", b"xy", b"x")]:
+        for n in (300000, 2 << 20):
+            t = bytearray(rng.choice(alphabet) for _ in range(n))
+            at = rng.randrange(n // 4, n // 2)
+            t[at:at + 300000] = bytes(rng.choice(run) for _ in range(min(300000, n - at)))
+            if rx == b"a[bc]*":
+                t[at] = ord("a")
+            st = check(rj, oracle, rx, bytes(t))
+            # (`<[^>]*>` is a windows-mode pattern: its candidates are the `<`, and a walk of 300 KB stays under that path's limit)
+            assert (st["run_path"] == 1 or rx == b"<[^>]*>") and st["linear_path"] == 0, (rx, n, st)
+
+
 def test_run_own_ranges_and_carry(rj, oracle):
     """A shard's run: begins in [own_begin, own_end) only; and the selection state carried in from the left neighbour (the
     last match before own_begin): the run kernels must neither re-open the segment a carried match with a B has closed nor
