@@ -566,7 +566,8 @@ static int run_runs(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, 
     const int l_pos = P.n_pos == 3 ? 1 : 0;
     a.blocked_in = ((P.cls[last] >> l_pos) & 1u) ? 1u : 0u;
   }
-  a.n_tiles = run_tiles(a.min_start, n, &a.first_tile);
+  a.tile_bytes = run_tile_bytes(n - std::min<uint64_t>(a.min_start, n));
+  a.n_tiles = run_tiles(a.min_start, n, a.tile_bytes, &a.first_tile);
   RJ_HIP(s->run_summaries.reserve(sizeof(RunSummary) * run_resolve_slots(a.n_tiles)));
   RJ_HIP(s->run_tile_in.reserve(sizeof(RunTileIn) * run_resolve_slots(a.n_tiles)));
   a.summaries = s->run_summaries.as<RunSummary>();

@@ -284,8 +284,8 @@ struct RunParams {
   uint64_t min_start;    // starts below are not looked at (the own range's begin, or where a carried-in match ends)
   uint32_t blocked_in;   // the segment that holds min_start has had its match (a carried-in match with a B that is no break)
   uint64_t first_tile, n_tiles;
+  uint64_t tile_bytes;   // a wave's share of the text (run_tile_bytes)
   uint64_t block_tiles;  // (set by launch_run_resolve: tiles per block of the two-level resolve)
-  uint32_t seq_max;      // (set by the launchers: iterations with at most this many breaks take the sequential machine)
   RunPlan plan;
   RunSummary* summaries;
   RunTileIn* tile_in;
@@ -294,7 +294,8 @@ struct RunParams {
   unsigned long long* counters;
   unsigned long long* host_counters;
 };
-uint64_t run_tiles(uint64_t sb, uint64_t n, uint64_t* first_tile);
+uint64_t run_tile_bytes(uint64_t span);   // bytes per tile for a run over `span` bytes (kRunTile or a multiple)
+uint64_t run_tiles(uint64_t sb, uint64_t n, uint64_t tile_bytes, uint64_t* first_tile);
 uint64_t run_resolve_slots(uint64_t n_tiles);   // elements of `summaries` and of `tile_in`: the tiles + the blocks of the two-level resolve
 void launch_run_summary(const RunParams& a, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 void launch_run_resolve(const RunParams& a, hipStream_t st);

@@ -7,8 +7,7 @@
 //                the class streams of A, B and the breaks (dense_streams.h: rj_stream_range); the wave's state is the open
 //                segment's (s1, q) in scalar registers.  An iteration without a break costs two ballots; one with breaks is
 //                settled by all lanes at once (run_iteration_par: segments inside a lane's word by the lane, the segment a
-//                lane's first break closes through two prefix maxima over the wave; the sequential machine -- a trip per
-//                break -- is kept for iterations with one break).  Leaves the tile's summary: its first break, the first A /
+//                lane's first break closes through two prefix maxima over the wave).  Leaves the tile's summary: its first break, the first A /
 //                last B before it, the matches closed by its other breaks (they depend on nothing outside the tile), the
 //                segment open at its end.
 //   run_resolve  the summaries composed (tiles without a break hand the pending thread on, tiles with one replace it:
@@ -17,7 +16,7 @@
 //   run_emit     run_summary's walk again with the incoming state known, over the tiles that close a match: the pairs at
 //                their final place.
 // Cost: the streams (~36 VALU per range and 32 bytes) once or twice; FETCH_SIZE 1-2 x the text; 1.1 TB/s (a break every 33
-// bytes) to 3.3 TB/s (none) for a whole call.  dense_streams (one pass) is tried first for the patterns it takes.
+// bytes) to 3.9 TB/s (none) for a whole call.  dense_streams (one pass) is tried first for the patterns it takes.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdlib.h>
@@ -35,21 +34,43 @@ constexpr unsigned long long kNone = ~0ull, kBlocked = ~0ull - 1;
 
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & (kWave - 1); }
 
+// which class reads which range, as AND masks in scalar registers (0 / ~0); NR = the compile-time bound of the loop over the
+// plan's ranges (ranges beyond n_ranges are computed and dropped: at most NR / 2 - 1 of them)
+template <int NR>
+struct RunMasks {
+  uint32_t a[NR], l[NR], b[NR];
+};
+template <int NR>
+__device__ __forceinline__ RunMasks<NR> run_masks(const RunPlan& pl) {
+  RunMasks<NR> m;
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    const bool in = static_cast<uint32_t>(r) < pl.n_ranges;
+    m.a[r] = in ? 0u - ((pl.a_ranges >> r) & 1u) : 0u;
+    m.l[r] = in ? 0u - ((pl.l_ranges >> r) & 1u) : 0u;
+    m.b[r] = in ? 0u - ((pl.b_ranges >> r) & 1u) : 0u;
+  }
+  return m;
+}
+
 // the three streams of the lane's 32 bytes at `at`: A, B, breaks (a byte outside L; the text's end is one)
-__device__ __forceinline__ void run_streams_of(const RunParams& a, uint64_t at, const uint4& v0, const uint4& v1, bool loaded, uint32_t* SA, uint32_t* SB,
-                                               uint32_t* BR) {
+template <int NR, bool HAS_B>
+__device__ __forceinline__ void run_streams_of(const RunParams& a, const RunMasks<NR>& mk, uint64_t at, const uint4& v0, const uint4& v1, bool loaded,
+                                               uint32_t* SA, uint32_t* SB, uint32_t* BR) {
   uint32_t x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
   uint32_t valid = ~0u;
   if (!loaded) {   // (an iteration that touches the end of the text: byte by byte)
     valid = 0;
 #pragma unroll
     for (int q = 0; q < 8; q++) x[q] = 0;
-#pragma unroll 1
-    for (int j = 0; j < 32; j++)
-      if (at + j < a.n) {
-        x[j >> 2] |= static_cast<uint32_t>(a.text[at + j]) << (8 * (j & 3));
-        valid |= 1u << j;
-      }
+#pragma unroll
+    for (int q = 0; q < 8; q++)   // (constant indices: a run-time index would put x[] in scratch memory)
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+        if (at + static_cast<uint64_t>(4 * q + b) < a.n) {
+          x[q] |= static_cast<uint32_t>(a.text[at + static_cast<uint64_t>(4 * q + b)]) << (8 * b);
+          valid |= 1u << (4 * q + b);
+        }
   }
   uint32_t x7[8], lowh[8], highh[8];
 #pragma unroll
@@ -61,18 +82,17 @@ __device__ __forceinline__ void run_streams_of(const RunParams& a, uint64_t at, 
   const RunPlan& pl = a.plan;
   uint32_t sa = 0, sl = 0, sb = 0;
 #pragma unroll
-  for (int r = 0; r < kRunMaxRanges; r++) {
-    if (static_cast<uint32_t>(r) >= pl.n_ranges) break;   // (wave-uniform)
+  for (int r = 0; r < NR; r++) {
     uint32_t T;
-    if ((pl.high_half >> r) & 1u) T = rj_stream_range(x7, highh, pl.add_lo[r], pl.add_hi[r]);
+    if ((pl.high_half >> r) & 1u) T = rj_stream_range(x7, highh, pl.add_lo[r], pl.add_hi[r]);   // (wave-uniform)
     else T = rj_stream_range(x7, lowh, pl.add_lo[r], pl.add_hi[r]);
-    sa |= ((pl.a_ranges >> r) & 1u) ? T : 0u;
-    sl |= ((pl.l_ranges >> r) & 1u) ? T : 0u;
-    sb |= ((pl.b_ranges >> r) & 1u) ? T : 0u;
+    sa |= T & mk.a[r];
+    sl |= T & mk.l[r];
+    if (HAS_B) sb |= T & mk.b[r];
   }
   sa = (pl.a_neg ? ~sa : sa) & valid;
   sl = (pl.l_neg ? ~sl : sl) & valid;
-  sb = pl.has_b ? ((pl.b_neg ? ~sb : sb) & valid) : 0u;
+  sb = HAS_B ? ((pl.b_neg ? ~sb : sb) & valid) : 0u;
   uint32_t br = ~sl & valid;
   if (a.n >= at && a.n - at < 32) br |= 1u << static_cast<uint32_t>(a.n - at);   // the end of the text closes the last segment
   *SA = sa;
@@ -87,20 +107,11 @@ __device__ __forceinline__ uint32_t clip(uint32_t m, int lane, uint32_t lo, uint
   const uint32_t below_h = h >= 32u ? ~0u : ((1u << h) - 1u), below_l = l >= 32u ? ~0u : ((1u << l) - 1u);
   return m & below_h & ~below_l;
 }
-// index of the first / last set bit over the wave (kIterBytes: none)
-__device__ __forceinline__ uint32_t first_set(uint32_t m) {
-  const uint64_t b = __ballot(m != 0);
-  if (b == 0) return kIterBytes;
-  const int l = __builtin_ctzll(b);
-  const uint32_t w = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(m), l));
-  return static_cast<uint32_t>(l) * 32u + static_cast<uint32_t>(__builtin_ctz(w));
-}
-__device__ __forceinline__ uint32_t last_set(uint32_t m) {
-  const uint64_t b = __ballot(m != 0);
-  if (b == 0) return kIterBytes;
-  const int l = 63 - __builtin_clzll(b);
-  const uint32_t w = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(m), l));
-  return static_cast<uint32_t>(l) * 32u + 31u - static_cast<uint32_t>(__builtin_clz(w));
+// SA with the starts below min_start taken out
+__device__ __forceinline__ uint32_t clip_starts(const RunParams& a, uint64_t it_base, uint32_t SA) {
+  if (a.min_start <= it_base) return SA;   // (wave-uniform: all but the run's first iteration)
+  const uint32_t a_lo = a.min_start - it_base < kIterBytes ? static_cast<uint32_t>(a.min_start - it_base) : kIterBytes;
+  return clip(SA, lane_id(), a_lo, kIterBytes);
 }
 
 struct Open {
@@ -109,52 +120,41 @@ struct Open {
 
 __device__ __forceinline__ bool real(unsigned long long s) { return s < kBlocked; }
 // the segment closed in state o holds a match that counts
-__device__ __forceinline__ bool counted(const RunParams& a, const Open& o) { return real(o.s) && (!a.plan.has_b || o.q != kNone) && o.s >= a.sb && o.s < a.se; }
-
-// The events of one iteration in text order.  on_close(state, r): the break at absolute position r closes the segment.
-// any_b (may be null): the last B position met before the first close of this call chain (the caller resets it).
-template <class Close>
-__device__ __forceinline__ void run_iteration(const RunParams& a, uint64_t it_base, uint32_t SA, uint32_t SB, uint32_t BR, Open& st, unsigned long long* any_b,
-                                              bool* track_any, Close on_close) {
-  const int lane = lane_id();
-  const uint32_t a_lo = a.min_start > it_base ? (a.min_start - it_base < kIterBytes ? static_cast<uint32_t>(a.min_start - it_base) : kIterBytes) : 0u;
-  uint32_t lo = 0;
-  auto part = [&](uint32_t hi_a, uint32_t hi_b) {   // A in [lo, hi_a), B in (s1, hi_b)
-    if (any_b && *track_any && a.plan.has_b) {
-      const uint32_t p = last_set(clip(SB, lane, lo, hi_b));
-      if (p != kIterBytes) *any_b = it_base + p;
-    }
-    if (st.s == kNone) {
-      const uint32_t p = first_set(clip(SA, lane, lo > a_lo ? lo : a_lo, hi_a));
-      if (p != kIterBytes) st.s = it_base + p;
-    }
-    if (a.plan.has_b && real(st.s)) {
-      const uint32_t from = st.s >= it_base ? static_cast<uint32_t>(st.s - it_base) + 1u : 0u;
-      const uint32_t p = last_set(clip(SB, lane, from > lo ? from : lo, hi_b));
-      if (p != kIterBytes) st.q = it_base + p;
-    }
-  };
-  uint32_t brw = BR;
-  uint64_t brm = __ballot(brw != 0);
-  while (brm != 0) {
-    const int l = __builtin_ctzll(brm);
-    const uint32_t w = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(brw), l));
-    const uint32_t r = static_cast<uint32_t>(l) * 32u + static_cast<uint32_t>(__builtin_ctz(w));
-    part(r, r + 1);          // a start lies before the break, B may be the break itself
-    on_close(st, it_base + r);
-    st.s = kNone;
-    st.q = kNone;
-    lo = r;                  // (the next segment's starts begin AT the break)
-    if (lane == l) brw &= brw - 1;
-    if ((w & (w - 1)) == 0) brm &= brm - 1;
-  }
-  part(kIterBytes, kIterBytes);
+template <bool HAS_B>
+__device__ __forceinline__ bool counted(const RunParams& a, const Open& o) {
+  return real(o.s) && (!HAS_B || o.q != kNone) && o.s >= a.sb && o.s < a.se;
 }
 
+// An iteration WITHOUT a break (the usual one in a text of long runs): the open segment takes the iteration's first A if it
+// has no start yet, and the iteration's last B if that lies behind its start -- two ballots, the rest is scalar.
+// SA: clipped.  any_b (may be null): the last B met so far.
+template <bool HAS_B>
+__device__ __forceinline__ void run_iteration_quiet(uint64_t it_base, uint32_t SA, uint32_t SB, Open& st, unsigned long long* any_b) {
+  unsigned long long last_b = kNone;
+  if (HAS_B) {
+    const uint64_t bm = __ballot(SB != 0);
+    if (bm != 0) {
+      const int l = 63 - __builtin_clzll(bm);
+      const uint32_t w = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(SB), l));
+      last_b = it_base + static_cast<uint32_t>(l) * 32u + 31u - static_cast<uint32_t>(__builtin_clz(w));
+      if (any_b) *any_b = last_b;
+    }
+  }
+  if (st.s == kNone) {
+    const uint64_t am = __ballot(SA != 0);
+    if (am != 0) {
+      const int l = __builtin_ctzll(am);
+      const uint32_t w = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(SA), l));
+      st.s = it_base + static_cast<uint32_t>(l) * 32u + static_cast<uint32_t>(__builtin_ctz(w));
+    }
+  }
+  if (HAS_B && last_b != kNone && real(st.s) && last_b > st.s) st.q = last_b;
+}
 
-// ---- the iteration's breaks in parallel (round 6, second form).  The sequential machine above takes one trip per break: a text
-// with a break every 33 bytes ran at 236 GB/s.  Here every lane settles what lies between the breaks of its own 32 bytes
-// by itself, and what crosses lanes comes from two prefix maxima over the wave:
+// ---- An iteration WITH breaks, settled by all lanes at once.  (The first form walked the breaks one after the other, the wave
+// as ONE sequential machine, ~100 instructions a trip: a text with a break every 33 bytes ran at 236 GB/s.)  Every lane
+// settles what lies between the breaks of its own 32 bytes by itself, and what crosses lanes comes from two prefix maxima
+// over the wave:
 //   * the segment closed by a lane's FIRST break began in a lane below (or before the iteration): its first A is the
 //     smallest "A at or behind the last break" of the lanes since the last lane with a break, its last B the largest "B
 //     behind the last break" of those lanes -- keys (breaks so far << 12 | position) make a plain prefix maximum of both;
@@ -192,21 +192,15 @@ __device__ __forceinline__ unsigned long long lane_value(unsigned long long x, i
 __device__ __forceinline__ uint32_t bits_below(uint32_t b) { return (1u << b) - 1u; }        // b in 0 .. 31
 __device__ __forceinline__ uint32_t bits_upto(uint32_t b) { return (2u << b) - 1u; }         // bits 0 .. b, b in 0 .. 31
 
-// SA with the starts below min_start taken out (the sequential machine does that where it picks a start)
-__device__ __forceinline__ uint32_t clip_starts(const RunParams& a, uint64_t it_base, uint32_t SA) {
-  if (a.min_start <= it_base) return SA;
-  const uint32_t a_lo = a.min_start - it_base < kIterBytes ? static_cast<uint32_t>(a.min_start - it_base) : kIterBytes;
-  return clip(SA, lane_id(), a_lo, kIterBytes);
-}
-
 struct LaneClose {
   unsigned long long s, q;   // the state the lane's first break closes (lanes with a break)
   unsigned long long b_any;  // the last B of the iteration at or before that break (kNone: none)
 };
 
-// An iteration that holds a break (brm = ballot(BR != 0) != 0).  SA: clipped.  Leaves what every lane's first break closes and
-// the state behind the iteration's last break in st.
-__device__ __forceinline__ LaneClose run_iteration_par(const RunParams& a, uint64_t it_base, uint32_t SA, uint32_t SB, uint32_t BR, uint64_t brm, Open& st) {
+// brm = ballot(BR != 0) != 0.  SA: clipped.  Leaves what every lane's first break closes and the state behind the iteration's
+// last break in st.
+template <bool HAS_B>
+__device__ __forceinline__ LaneClose run_iteration_par(uint64_t it_base, uint32_t SA, uint32_t SB, uint32_t BR, uint64_t brm, Open& st) {
   const int lane = lane_id();
   const uint32_t pbase = static_cast<uint32_t>(lane) * 32u;
   const bool hb = BR != 0;
@@ -221,7 +215,7 @@ __device__ __forceinline__ LaneClose run_iteration_par(const RunParams& a, uint6
   const uint32_t inclA = wave_prefix_max(keyA);
   const uint32_t exclA = lane_below(inclA) & 0xfffu;
   uint32_t inclB = 0, exclB = 0;
-  if (a.plan.has_b) {   // (uniform)
+  if (HAS_B) {
     const uint32_t keyB = (seg_incl << 12) | (tailB ? pbase + 32u - static_cast<uint32_t>(__builtin_clz(tailB)) : 0u);   // position + 1
     inclB = wave_prefix_max(keyB);
     exclB = lane_below(inclB) & 0xfffu;
@@ -238,7 +232,7 @@ __device__ __forceinline__ LaneClose run_iteration_par(const RunParams& a, uint6
     c.s = it_base + pbase + static_cast<uint32_t>(__builtin_ctz(headA));
     s_here = true;
   }
-  if (a.plan.has_b) {
+  if (HAS_B) {
     if (headB != 0) c.b_any = it_base + pbase + 31u - static_cast<uint32_t>(__builtin_clz(headB));
     else if (exclB != 0 && seg_excl == 0) c.b_any = it_base + (exclB - 1u);
     if (real(c.s)) {
@@ -259,8 +253,8 @@ __device__ __forceinline__ LaneClose run_iteration_par(const RunParams& a, uint6
 }
 
 // the segments between two breaks of the lane's own word, in text order: f(s, q, r) -- positions relative to the word; q = 32: no B
-template <class F>
-__device__ __forceinline__ void for_inner(const RunParams& a, uint32_t SA, uint32_t SB, uint32_t BR, F f) {
+template <bool HAS_B, class F>
+__device__ __forceinline__ void for_inner(uint32_t SA, uint32_t SB, uint32_t BR, F f) {
   if (BR == 0) return;
   uint32_t prev = static_cast<uint32_t>(__builtin_ctz(BR));
   uint32_t rest = BR & (BR - 1u);
@@ -271,7 +265,7 @@ __device__ __forceinline__ void for_inner(const RunParams& a, uint32_t SA, uint3
     if (am != 0) {
       const uint32_t s = static_cast<uint32_t>(__builtin_ctz(am));
       const uint32_t bm = SB & bits_upto(r) & ~bits_upto(s);
-      if (!a.plan.has_b) f(s, 32u, r);
+      if (!HAS_B) f(s, 32u, r);
       else if (bm != 0) f(s, 31u - static_cast<uint32_t>(__builtin_clz(bm)), r);
     }
     prev = r;
@@ -280,21 +274,24 @@ __device__ __forceinline__ void for_inner(const RunParams& a, uint32_t SA, uint3
 
 }  // namespace
 
+template <int NR, bool HAS_B>
 __global__ __launch_bounds__(256) void run_summary(RunParams a) {
   const int lane = lane_id();
   const uint64_t tile = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
   if (tile >= a.n_tiles) return;
-  const uint64_t base = (a.first_tile + tile) * kRunTile;
+  const RunMasks<NR> mk = run_masks<NR>(a.plan);
+  const uint64_t base = (a.first_tile + tile) * a.tile_bytes;
   RunSummary sum;
   sum.r1 = kNone;
   sum.a1 = sum.b1 = sum.b1a = kNone;
   sum.open_s = sum.open_q = kNone;
   sum.cnt = 0;
+  sum.pad = 0;
   Open st{kNone, kNone};
   unsigned long long any_b = kNone;
   bool before_first = true;
   unsigned long long cnt = 0;
-  constexpr int kIters = static_cast<int>(kRunTile / kIterBytes);
+  const int kIters = static_cast<int>(a.tile_bytes / kIterBytes);
   uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
   bool loaded = false;
   auto fetch = [&](int it) {
@@ -311,27 +308,17 @@ __global__ __launch_bounds__(256) void run_summary(RunParams a) {
     const uint64_t it_base = base + static_cast<uint64_t>(it) * kIterBytes;
     if (it_base > a.n) break;   // (nothing here, not even the text's end)
     uint32_t SA, SB, BR;
-    run_streams_of(a, it_base + static_cast<uint64_t>(lane) * 32, v0, v1, loaded, &SA, &SB, &BR);
+    run_streams_of<NR, HAS_B>(a, mk, it_base + static_cast<uint64_t>(lane) * 32, v0, v1, loaded, &SA, &SB, &BR);
     if (it + 1 < kIters) fetch(it + 1);
-    const uint64_t brm = __ballot(BR != 0), multi = __ballot((BR & (BR - 1u)) != 0);
-    if (brm == 0 || (multi == 0 && static_cast<uint32_t>(__popcll(brm)) <= a.seq_max)) {
-      run_iteration(a, it_base, SA, SB, BR, st, &any_b, &before_first, [&](const Open& o, uint64_t r) {
-        if (before_first) {   // the tile's first break: what it closes depends on the tiles before
-          sum.r1 = r;
-          sum.a1 = o.s;
-          sum.b1a = o.q;
-          sum.b1 = any_b;
-          before_first = false;
-        } else if (counted(a, o)) {
-          cnt++;
-        }
-      });
+    SA = clip_starts(a, it_base, SA);
+    const uint64_t brm = __ballot(BR != 0);
+    if (brm == 0) {
+      run_iteration_quiet<HAS_B>(it_base, SA, SB, st, before_first ? &any_b : nullptr);
       continue;
     }
-    const uint32_t SAc = clip_starts(a, it_base, SA);
-    const LaneClose c = run_iteration_par(a, it_base, SAc, SB, BR, brm, st);
-    bool first = BR != 0 && counted(a, Open{c.s, c.q});
-    if (before_first) {
+    const LaneClose c = run_iteration_par<HAS_B>(it_base, SA, SB, BR, brm, st);
+    bool first = BR != 0 && counted<HAS_B>(a, Open{c.s, c.q});
+    if (before_first) {   // the tile's first break: what it closes depends on the tiles before
       const int l1 = __builtin_ctzll(brm);
       sum.r1 = it_base + static_cast<uint64_t>(l1) * 32u + static_cast<uint32_t>(__builtin_ctz(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(BR), l1))));
       sum.a1 = lane_value(c.s, l1);
@@ -342,9 +329,9 @@ __global__ __launch_bounds__(256) void run_summary(RunParams a) {
       if (lane == l1) first = false;
     }
     cnt += static_cast<unsigned long long>(__popcll(__ballot(first)));
-    if (multi != 0) {
+    if (__ballot((BR & (BR - 1u)) != 0) != 0) {   // (some lane holds two breaks)
       uint32_t inner = 0;
-      for_inner(a, SAc, SB, BR, [&](uint32_t s, uint32_t, uint32_t) {
+      for_inner<HAS_B>(SA, SB, BR, [&](uint32_t s, uint32_t, uint32_t) {
         const uint64_t at = it_base + static_cast<uint64_t>(lane) * 32u + s;
         if (at >= a.sb && at < a.se) inner++;
       });
@@ -364,6 +351,9 @@ __global__ __launch_bounds__(256) void run_summary(RunParams a) {
 }
 
 namespace {
+
+// (the resolve kernels are not templated: the plan says whether a B exists)
+__device__ __forceinline__ bool counted(const RunParams& a, const Open& o) { return a.plan.has_b ? counted<true>(a, o) : counted<false>(a, o); }
 
 // a tile (or a run of tiles) as a function on the open segment's state.  cnt: the matches closed by its breaks other than the
 // first (what the first closes depends on the state that comes in)
@@ -545,17 +535,18 @@ __global__ __launch_bounds__(256) void run_apply(RunParams a) {
   resolve_span<256>(a, a.summaries + first, a.tile_in + first, n, Open{in.s, in.q}, in.off, chunk, nullptr, &total);
 }
 
+template <int NR, bool HAS_B>
 __global__ __launch_bounds__(256) void run_emit(RunParams a) {
   const int lane = lane_id();
   const uint64_t tile = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
   if (tile >= a.n_tiles) return;
-  const uint64_t base = (a.first_tile + tile) * kRunTile;
   const RunTileIn in = a.tile_in[tile];
   if (in.cnt == 0) return;   // (no pair ends here: a text of long runs is read ONCE)
+  const RunMasks<NR> mk = run_masks<NR>(a.plan);
+  const uint64_t base = (a.first_tile + tile) * a.tile_bytes;
   Open st{in.s, in.q};
   unsigned long long pos = in.off;
-  bool no_track = false;
-  constexpr int kIters = static_cast<int>(kRunTile / kIterBytes);
+  const int kIters = static_cast<int>(a.tile_bytes / kIterBytes);
   uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
   bool loaded = false;
   auto fetch = [&](int it) {
@@ -572,38 +563,34 @@ __global__ __launch_bounds__(256) void run_emit(RunParams a) {
     const uint64_t it_base = base + static_cast<uint64_t>(it) * kIterBytes;
     if (it_base > a.n) break;
     uint32_t SA, SB, BR;
-    run_streams_of(a, it_base + static_cast<uint64_t>(lane) * 32, v0, v1, loaded, &SA, &SB, &BR);
+    run_streams_of<NR, HAS_B>(a, mk, it_base + static_cast<uint64_t>(lane) * 32, v0, v1, loaded, &SA, &SB, &BR);
     if (it + 1 < kIters) fetch(it + 1);
-    const uint64_t brm = __ballot(BR != 0), multi = __ballot((BR & (BR - 1u)) != 0);
-    if (brm == 0 || (multi == 0 && static_cast<uint32_t>(__popcll(brm)) <= a.seq_max)) {
-      run_iteration(a, it_base, SA, SB, BR, st, nullptr, &no_track, [&](const Open& o, uint64_t r) {
-        if (counted(a, o)) {
-          if (lane == 0 && pos < a.out_cap) *reinterpret_cast<ulonglong2*>(a.out + 2 * pos) = make_ulonglong2(o.s, a.plan.has_b ? o.q + 1 : r);
-          pos++;
-        }
-      });
+    SA = clip_starts(a, it_base, SA);
+    const uint64_t brm = __ballot(BR != 0);
+    if (brm == 0) {
+      run_iteration_quiet<HAS_B>(it_base, SA, SB, st, nullptr);
       continue;
     }
-    const uint32_t SAc = clip_starts(a, it_base, SA);
-    const LaneClose c = run_iteration_par(a, it_base, SAc, SB, BR, brm, st);
+    const LaneClose c = run_iteration_par<HAS_B>(it_base, SA, SB, BR, brm, st);
     const uint64_t word = it_base + static_cast<uint64_t>(lane) * 32u;
-    const bool first = BR != 0 && counted(a, Open{c.s, c.q});
+    const bool first = BR != 0 && counted<HAS_B>(a, Open{c.s, c.q});
+    const bool multi = __ballot((BR & (BR - 1u)) != 0) != 0;
     uint32_t mine = first ? 1u : 0u;
-    if (multi != 0)
-      for_inner(a, SAc, SB, BR, [&](uint32_t s, uint32_t, uint32_t) {
+    if (multi)
+      for_inner<HAS_B>(SA, SB, BR, [&](uint32_t s, uint32_t, uint32_t) {
         if (word + s >= a.sb && word + s < a.se) mine++;
       });
     if (__ballot(mine != 0) == 0) continue;
     const uint32_t inc = wave_prefix_sum(mine);
     unsigned long long idx = pos + inc - mine;
     if (first) {
-      if (idx < a.out_cap) *reinterpret_cast<ulonglong2*>(a.out + 2 * idx) = make_ulonglong2(c.s, a.plan.has_b ? c.q + 1 : word + static_cast<uint32_t>(__builtin_ctz(BR)));
+      if (idx < a.out_cap) *reinterpret_cast<ulonglong2*>(a.out + 2 * idx) = make_ulonglong2(c.s, HAS_B ? c.q + 1 : word + static_cast<uint32_t>(__builtin_ctz(BR)));
       idx++;
     }
-    if (multi != 0)
-      for_inner(a, SAc, SB, BR, [&](uint32_t s, uint32_t q, uint32_t r) {
+    if (multi)
+      for_inner<HAS_B>(SA, SB, BR, [&](uint32_t s, uint32_t q, uint32_t r) {
         if (word + s >= a.sb && word + s < a.se) {
-          if (idx < a.out_cap) *reinterpret_cast<ulonglong2*>(a.out + 2 * idx) = make_ulonglong2(word + s, word + (a.plan.has_b ? q + 1u : r));
+          if (idx < a.out_cap) *reinterpret_cast<ulonglong2*>(a.out + 2 * idx) = make_ulonglong2(word + s, word + (HAS_B ? q + 1u : r));
           idx++;
         }
       });
@@ -611,25 +598,35 @@ __global__ __launch_bounds__(256) void run_emit(RunParams a) {
   }
 }
 
-uint64_t run_tiles(uint64_t sb, uint64_t n, uint64_t* first_tile) {
-  *first_tile = sb / kRunTile;
-  return n / kRunTile - *first_tile + 1;   // (the tile that holds position n -- the text's end -- is the last)
+// Bytes per tile (a wave's share, a multiple of the 2-KiB iteration).  A wave pays one exposed trip to memory for its first
+// iteration whatever its tile: 8 KiB keeps enough waves for texts of a few MiB, longer texts take 32 KiB (RJ_RUN_TILE_KB: measurements).
+uint64_t run_tile_bytes(uint64_t span) {
+  static const uint64_t forced = [] {
+    const char* e = getenv("RJ_RUN_TILE_KB");
+    const long x = e ? atol(e) : 0;
+    return static_cast<uint64_t>(x >= 2 ? (x / 2) * 2048 : 0);
+  }();
+  if (forced) return forced;
+  return span <= (256ull << 20) ? kRunTile : 4 * kRunTile;
+}
+uint64_t run_tiles(uint64_t sb, uint64_t n, uint64_t tile_bytes, uint64_t* first_tile) {
+  *first_tile = sb / tile_bytes;
+  return n / tile_bytes - *first_tile + 1;   // (the tile that holds position n -- the text's end -- is the last)
 }
 
-// iterations with at most this many breaks, each in a lane of its own, take the sequential machine (RJ_RUN_SEQ_MAX: measurements)
-static uint32_t seq_max_breaks() {
-  static const uint32_t v = [] {
-    const char* e = getenv("RJ_RUN_SEQ_MAX");
-    return e ? static_cast<uint32_t>(atol(e)) : 1u;
-  }();
-  return v;
+namespace {
+template <int NR>
+void launch_summary_nr(const RunParams& a, unsigned grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+  if (a.plan.has_b) hipExtLaunchKernelGGL((run_summary<NR, true>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+  else hipExtLaunchKernelGGL((run_summary<NR, false>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
 }
-void launch_run_summary(const RunParams& a0, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
-  RunParams a = a0;
-  a.seq_max = seq_max_breaks();
-  const unsigned grid = static_cast<unsigned>((a.n_tiles + 3) / 4);
-  hipExtLaunchKernelGGL(run_summary, dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+template <int NR>
+void launch_emit_nr(const RunParams& a, unsigned grid, hipEvent_t t1, hipStream_t st) {
+  if (a.plan.has_b) hipExtLaunchKernelGGL((run_emit<NR, true>), dim3(grid), dim3(256), 0, st, nullptr, t1, 0, a);
+  else hipExtLaunchKernelGGL((run_emit<NR, false>), dim3(grid), dim3(256), 0, st, nullptr, t1, 0, a);
 }
+}  // namespace
+
 // RJ_RUN_TWO_LEVELS=<tiles per block>: every text through the two-level kernels, in blocks of that many tiles (tests)
 static uint64_t forced_block_tiles() {
   static const uint64_t v = [] {
@@ -655,11 +652,23 @@ void launch_run_resolve(const RunParams& a0, hipStream_t st) {
   hipLaunchKernelGGL(run_resolve_blocks, dim3(1), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(run_apply, dim3(blocks), dim3(256), 0, st, a);
 }
-void launch_run_emit(const RunParams& a0, hipEvent_t t1, hipStream_t st) {
-  RunParams a = a0;
-  a.seq_max = seq_max_breaks();
+
+// (eight kernels each: the ranges rounded up to 1 / 2 / 4 / 8, with and without a B position)
+void launch_run_summary(const RunParams& a, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
   const unsigned grid = static_cast<unsigned>((a.n_tiles + 3) / 4);
-  hipExtLaunchKernelGGL(run_emit, dim3(grid), dim3(256), 0, st, nullptr, t1, 0, a);
+  const uint32_t nr = a.plan.n_ranges;
+  if (nr <= 1) launch_summary_nr<1>(a, grid, t0, t1, st);
+  else if (nr <= 2) launch_summary_nr<2>(a, grid, t0, t1, st);
+  else if (nr <= 4) launch_summary_nr<4>(a, grid, t0, t1, st);
+  else launch_summary_nr<8>(a, grid, t0, t1, st);
+}
+void launch_run_emit(const RunParams& a, hipEvent_t t1, hipStream_t st) {
+  const unsigned grid = static_cast<unsigned>((a.n_tiles + 3) / 4);
+  const uint32_t nr = a.plan.n_ranges;
+  if (nr <= 1) launch_emit_nr<1>(a, grid, t1, st);
+  else if (nr <= 2) launch_emit_nr<2>(a, grid, t1, st);
+  else if (nr <= 4) launch_emit_nr<4>(a, grid, t1, st);
+  else launch_emit_nr<8>(a, grid, t1, st);
 }
 
 }  // namespace rejit_amd

@@ -1,5 +1,5 @@
 """The run kernels over texts with a break every ~k bytes (`[acgt]+` over acgt with an N now and then; `a.*b` over lines of k bytes):
-wall time of a whole call.  usage: run_density.py [MiB]   (RJ_RUN_SEQ_MAX: iterations with that many breaks or fewer take the sequential machine)"""
+wall time of a whole call.  usage: run_density.py [MiB]"""
 import os, sys, time; sys.path.insert(0, "/root/repo")
 os.environ["RJ_RUNS_FIRST"] = "1"
 import torch, rejit_amd
