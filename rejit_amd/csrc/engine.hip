@@ -583,6 +583,15 @@ static int run_runs(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, 
   RJ_HIP(hipStreamSynchronize(st));   // (the number of pairs sizes the output)
   RJ_HIP(hipGetLastError());
   const uint64_t cnt = s->host_counters[kCntFinal];
+  if (s->count_only_run && sb == 0 && se > n) {   // MatchAllCount of the whole text: one pass over it
+    s->result_count = cnt;
+    s->result = nullptr;
+    s->hits_hint = cnt;
+    s->stats.n_hits += cnt;
+    s->stats.n_candidates += cnt;
+    s->stats.run_path = 1;
+    return 1;
+  }
   if (cnt > s->out_cap) {
     const uint64_t cap = cnt + cnt / 16 + 1024;
     RJ_HIP(s->out.reserve(cap * 2 * sizeof(uint64_t)));
@@ -1008,7 +1017,8 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
   if (single_run) {
     int rc = run_range(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
     if (rc != RJ_OK) return rc;
-    if (s->result == nullptr) s->result = s->out.as<uint64_t>();  // (the carry scan may have accumulated segments elsewhere)
+    // (the carry scan may have accumulated segments elsewhere; a count-only run of the run kernels leaves no list)
+    if (s->result == nullptr && !(s->count_only_run && s->stats.run_path)) s->result = s->out.as<uint64_t>();
   } else {
     // Dense mode over a long range: a hit slot for a sizeable fraction of the bytes would not
     // fit, so the starts are walked in segments; the selection state is carried from one

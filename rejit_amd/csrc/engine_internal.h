@@ -117,6 +117,7 @@ struct rj_scan {
   rejit_amd::DeviceBuffer cs_vals, cs_mats, cs_e, cs_g, cs_entry, cs_counts, cs_scratch, cs_acc, cs_groups;
   bool linear_hint = false;        // the previous run needed the carry scan: go there directly
   rejit_amd::DeviceBuffer run_summaries, run_tile_in;  // run_scan.hip
+  bool count_only_run = false;   // (scan_count: this run's pairs are not wanted -- the run kernels stop behind their resolve)
   bool streams_off = false;        // dense_streams ran into a void run or too many scalar walks on this scan's text: scan_dense_walk
   bool behind_conflicts = false;   // behind mode gave a conflict / overrun on this scan's text: stay dense
   bool no_local_select = false;    // floating windows: the in-region selection left overlapping candidates on this text

@@ -1656,7 +1656,9 @@ int64_t rejit_amd::scan_count(rj_scan* s, const uint8_t* d_text, uint64_t n, hip
     if (how != 3) s->stats.count_path = 0;
     return static_cast<int64_t>(count);
   }
+  s->count_only_run = true;
   int rc = run_pipeline(s, d_text, n, 0, n + 1, 0, 0, 0, st);
+  s->count_only_run = false;
   if (rc != RJ_OK) return rc;
   return static_cast<int64_t>(s->result_count);
 }

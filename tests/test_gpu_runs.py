@@ -122,6 +122,26 @@ def test_run_kernels_on_break_dense_text(rj, oracle):
             assert (st["run_path"] == 1 or rx == b"<[^>]*>") and st["linear_path"] == 0, (rx, n, st)
 
 
+def test_run_kernels_count_only(rj, oracle):
+    """rj_scan_count (MatchAllCount over device text) of a run shape: the run kernels stop behind their resolve -- the count
+    without the second pass; a span list is not left behind (copy_spans refuses), the next full run has one again."""
+    rng = random.Random(48)
+    for rx, alphabet in [(b"[acgt]+", b"acgtacgtN"), (b"a.*b", b"abcdefgh\n"), (b"x+", b"x")]:
+        data = bytes(rng.choice(alphabet) for _ in range(3 << 20))
+        if rx != b"x+":
+            data = data[:1 << 20] + bytes(rng.choice(b"acgt") for _ in range(1 << 20)) + data[2 << 20:]   # (a run of 1 MiB: dense_streams gives up)
+        want = oracle.match_all(rx, data)
+        sc = rj.Scan(rj.Program(rx))
+        t = device_text(data)
+        assert sc.run(t.data_ptr(), len(data)) == len(want) and sc.stats()["run_path"] == 1
+        assert sc.count(t.data_ptr(), len(data)) == len(want)
+        st = sc.stats()
+        assert st["run_path"] == 1, st
+        with pytest.raises(Exception):
+            sc.spans()
+        assert sc.run(t.data_ptr(), len(data)) == len(want) and sc.spans() == want
+
+
 def test_run_own_ranges_and_carry(rj, oracle):
     """A shard's run: begins in [own_begin, own_end) only; and the selection state carried in from the left neighbour (the
     last match before own_begin): the run kernels must neither re-open the segment a carried match with a B has closed nor
