@@ -1047,10 +1047,10 @@ def literal_and_complex_extras(args, c, out):
             gwall.append(time.perf_counter() - t0g)
             gms.append(gmulti.scan_ms())
         gmed = sorted(gwall)[len(gwall) // 2]
-        out["general_one_pass"] = {"workload": "%s over the same %d bytes in ONE pass (plane_scan_general: 4 exact base windows of 7 bytes, offsets 0 and 1; the kernel loops over the bases)" % (" + ".join(gset), n),
+        out["general_one_pass"] = {"workload": "%s over the same %d bytes in ONE pass (plane_count<GeneralListShape>: 4 exact base windows of 7 bytes, offsets 0 and 1; round 4-5: plane_scan_general)" % (" + ".join(gset), n),
                                    "how": ghow, "counts": gcounts, "counts_equal_single_runs": gcounts == gsingle,
                                    "latency_ms": round(gmed * 1e3, 4), "value": round(n / gmed / 1e9, 1), "unit": "GB/s of text (once for both patterns)",
-                                   "roofline": hbm_roofline("plane_scan_general<exact>", n, sum(gms) / len(gms), None, len(gms), ceiling=hbm_ceiling(t.data_ptr(), n, c.stream))}
+                                   "roofline": hbm_roofline("plane_count<GeneralListShape<false>> (the span pipeline's scan kernel)", n, sum(gms) / len(gms), None, len(gms), ceiling=hbm_ceiling(t.data_ptr(), n, c.stream))}
         # the same set as MatchAllCount in ONE kernel (round 6: plane_count<GeneralShape>, rj_multi_set_counts_only): the filter
         # through code planes, every candidate classified by the patterns' automata out of LDS, nothing written but the counts;
         # and nine random 12-mers (nine bases: the filter's cost grows with the bases)

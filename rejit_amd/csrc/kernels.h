@@ -415,6 +415,18 @@ struct PlaneCountGParams {
   uint32_t desc_words;   // words the descriptors take inside the blob
   uint32_t idx[kPlaneMaxBases][8];   // base b, compared byte i: its symbol code 0..3, or 4 for a byte beyond n_cmp (always fits)
 };
+// plane_count<GeneralListShape>: the general test, the candidates (WINDOW positions: every pattern has its own offset, the
+// classification subtracts it) written to the shared regions -- plane_scan_general in plane_count's layout (round 6).
+struct PlaneListGParams {
+  PlaneCountGParams g;   // (g.c.table, g.lmax, g.desc_words unused)
+  uint64_t* hits;
+  uint32_t region_cap;
+  uint32_t offset;       // 0: the slots hold window positions
+  uint32_t* hit_counts;
+  uint32_t n_zero;
+  unsigned long long* zero_counters[kMaxFused];
+};
+void launch_plane_list_general(const PlaneListGParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 constexpr uint32_t kCountMaxBlobWords = 6144;   // 24 KiB of descriptors + tables per workgroup
 void launch_plane_count_general(const PlaneCountGParams& g, int max_words, uint32_t max_short, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 void launch_tails_shared_general(const MultiTail* d_tails, const SharedHits& sh, int max_words, uint32_t max_short, unsigned long long* counters0,

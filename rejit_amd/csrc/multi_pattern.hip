@@ -619,7 +619,39 @@ int run_batched(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
       for (int p = 0; p < P; p++) pg.zero_counters[p] = m->scans[static_cast<size_t>(p)]->counters.as<unsigned long long>();
       fused_launched = false;
       m->flags_clean = false;
-      launch_plane_scan_general(pg, geo.grid, s0->t0(), s0->ev[2], st);
+      // round 6: plane_count's streaming loop with the general test (code planes through the VGPR index mode), the candidates
+      // written to the shared regions; plane_scan_general is kept behind RJ_PLANE_SCAN_V1
+      static const bool v1g = getenv("RJ_PLANE_SCAN_V1") != nullptr;   // measurement override
+      if (v1g) {
+        launch_plane_scan_general(pg, geo.grid, s0->t0(), s0->ev[2], st);
+      } else {
+        PlaneListGParams pl{};
+        PlaneCountParams& c = pl.g.c;
+        c.text = d_text;
+        c.n = n;
+        c.sb = sb;
+        c.se = se;
+        c.first_block = plane_wlo / 2048;
+        c.end_block = c.first_block + plane_pairs;
+        c.span_blocks = plane_pairs / geo.n_regions;
+        c.span_extra = static_cast<uint32_t>(plane_pairs % geo.n_regions);
+        c.code_shift = m->plane.code_shift;
+        c.n_bases = m->plane.n_bases;
+        c.n_patterns = static_cast<uint32_t>(P);
+        c.batch_at = 64;
+        pl.g.n_cmp = m->plane.n_cmp;
+        pl.g.tolerance = m->plane.tolerance;
+        for (uint32_t b = 0; b < kPlaneMaxBases; b++)
+          for (uint32_t i = 0; i < 8; i++)
+            pl.g.idx[b][i] = i < m->plane.n_cmp ? (static_cast<uint32_t>(m->plane.base[b < m->plane.n_bases ? b : 0][i]) >> m->plane.code_shift) & 3u : 4u;
+        pl.hits = pg.hits;
+        pl.region_cap = pg.region_cap;
+        pl.offset = 0;
+        pl.hit_counts = pg.hit_counts;
+        pl.n_zero = pg.n_zero;
+        for (uint32_t p = 0; p < pg.n_zero; p++) pl.zero_counters[p] = pg.zero_counters[p];
+        launch_plane_list_general(pl, geo.grid, s0->t0(), s0->ev[2], st);
+      }
     } else if (plane) {
       PlaneParams pp{};
       pp.text = d_text;

@@ -450,6 +450,21 @@ struct GeneralShape {
   }
 };
 
+// GeneralListShape<TOL>: GeneralShape's test, the candidates written to the span pipeline's shared regions (kernels.h:
+// PlaneListGParams) for classify_shared_general -- what ListShape is to ExactShape.
+template <bool TOL>
+struct GeneralListShape {
+  using Args = PlaneListGParams;
+  static constexpr uint32_t kFixedLen = 0;
+  static constexpr bool kBlobInLds = false;
+  static constexpr bool kList = true;
+  __device__ static __forceinline__ const PlaneCountParams& common(const Args& g) { return g.g.c; }
+  __device__ static __forceinline__ uint32_t lmax(const Args& g) { return g.g.lmax; }
+  __device__ static __forceinline__ uint32_t offset_of(const Args&, const uint32_t*, uint32_t) { return 0u; }
+  __device__ static __forceinline__ uint32_t test(uint32_t ta, uint32_t tb, uint32_t hb, const Args& g) { return general_test<TOL>(ta, tb, hb, g.g); }
+  __device__ static __forceinline__ void classify(const Args&, const uint32_t*, uint64_t, bool, uint32_t& mask, Lens&) { mask = 0; }
+};
+
 namespace {
 
 // per wave: the ring, and what the classification carries from batch to batch
@@ -958,6 +973,11 @@ void launch_plane_count(const PlaneCountParams& a, int grid, hipEvent_t t0, hipE
 void launch_plane_list(const PlaneListParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
   if (a.c.n_bases <= 1) hipExtLaunchKernelGGL((plane_count<ListShape<1>>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
   else hipExtLaunchKernelGGL((plane_count<ListShape<2>>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+}
+
+void launch_plane_list_general(const PlaneListGParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+  if (a.g.tolerance) hipExtLaunchKernelGGL((plane_count<GeneralListShape<true>>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+  else hipExtLaunchKernelGGL((plane_count<GeneralListShape<false>>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
 }
 
 // max_words / max_short: the largest n_words / short_max among the patterns (the instantiation)

@@ -69,7 +69,7 @@ for key, prefix, nbytes, extra in (
         ("complex", "scan_windows<1, true, false, true, false>", 5000000000, {}),
         ("dense", "dense_streams<2, 2, false, false>", 5000000000, {}),
         ("dense_select", "dense_streams<3, 1, false, true>", 5000000000, {}),
-        ("general", "plane_scan_general<1, false>", 5000000000, {}),
+        ("general", "plane_count<GeneralListShape<false> >", 5000000000, {}),
         ("line_table", "emit_assertions", 5000000000, {})):
     try:
         j[key] = dict(kernel=prefix, hbm_read_bytes_per_launch=avg_of(f, prefix, nbytes) * 1024 * 2, bytes=nbytes, **extra)
@@ -82,7 +82,7 @@ try:
     sq = open(g("pmc_sq.txt")).read().split("## SQ_INSTS_VALU")[1].split("## ")[0]
     for key, prefix, nbytes in (("plane_count", "plane_count<ExactShape<2> >", FASTA), ("plane", "plane_scan<2>", FASTA),
                                 ("dense", "dense_streams<2, 2, false, false>", 5000000000), ("dense_select", "dense_streams<3, 1, false, true>", 5000000000),
-                                ("counts_general", "plane_count<GeneralShape<1, 16, false> >", 5000000000), ("general", "plane_scan_general<1, false>", 5000000000)):
+                                ("counts_general", "plane_count<GeneralShape<1, 16, false> >", 5000000000), ("general", "plane_count<GeneralListShape<false> >", 5000000000)):
         ops = None
         for line in sq.splitlines():
             if line.startswith(prefix):
@@ -121,7 +121,7 @@ open(P("pmc_sq_counters.txt"), "w").write(
     "# per kernel: calls, avg / min / max of the counter per launch.  SQ_INSTS_VALU are WAVE instructions: / (text bytes / 1024) = per\n"
     "# 1-KiB chunk and wave = per 16 bytes and lane.\n" + open(g("pmc_sq.txt")).read())
 for src, dst in (("dense_probe.txt", "dense_probe.txt"), ("jrep_compare.txt", "jrep_compare.txt"), ("bench_sizes.txt", "bench_sizes.txt"),
-                 ("count_general_probe.txt", "count_general_probe.txt"), ("e2e_probe.txt", "e2e_probe.txt"), ("host_copy_probe.txt", "host_copy_probe.txt")):
+                 ("count_general_probe.txt", "count_general_probe.txt"), ("e2e_probe.txt", "e2e_probe.txt"), ("host_copy_probe.txt", "host_copy_probe.txt"), ("run_probe.txt", "run_probe.txt")):
     if os.path.exists(g(src)):
         shutil.copy(g(src), P(dst))
 open(P("bench_line.json"), "w").write(open(g("bench.json")).read().strip().splitlines()[-1] + "\n")

@@ -39,6 +39,9 @@ python tools/dense_probe.py 1e9 > $out/prof_${tag}_dense_probe.txt 2>/dev/null
 python tools/count_general_probe.py 1000000000 30 2>/dev/null | grep -v amdgpu.ids > $out/prof_${tag}_count_general_probe.txt
 python tools/e2e_probe.py 50000000 3 2>/dev/null | grep -v amdgpu.ids > $out/prof_${tag}_e2e_probe.txt
 python tools/probes/repl_probe.py 2>/dev/null | grep -v amdgpu.ids > $out/prof_${tag}_host_copy_probe.txt
+# the run kernels over single runs (64 MiB, 4 GiB) and over 1 GiB with a break every ~33 ... 30 000 bytes: whole calls
+{ echo "# tools/probes/run_time.py + tools/probes/run_density.py (MI355X): the run kernels (run_scan.hip), wall time of whole calls, device texts"
+  python tools/probes/run_time.py 2>/dev/null | grep -v amdgpu.ids; python tools/probes/run_density.py 1024 2>/dev/null | grep -v amdgpu.ids; } > $out/prof_${tag}_run_probe.txt
 tail -1 $out/prof_${tag}_bench.json | cut -c1-300
 head -6 $out/prof_${tag}_kernel_stats.txt | cut -c1-60,91-170
 head -14 $out/prof_${tag}_pmc_fetch.txt
