@@ -642,11 +642,11 @@ def run_regexdna(args, c):
             l_step, l_drain, l_times = two_in_flight(False, tail_streams=True, time_all=args.time_all_launches)
             el, cl = timed(c, args, l_step, l_drain)
             assert cl == counts, (cl, counts)
-            out["span_lists"] = {"calls": "round 4's headline loop: every pattern's (begin, end) list laid out -- plane_scan + classify_shared_multi + offsets_gather_check_multi per step, "
+            out["span_lists"] = {"calls": "round 4's headline loop: every pattern's (begin, end) list laid out -- plane_count<ListShape<2>> (rounds 3-5: plane_scan<2>) + classify_shared_multi + offsets_gather_check_multi per step, "
                                           "steps in flight on one stream, tails on a stream per object",
                                  "ms_per_step": round(el / args.steps * 1e3, 4),
                                  "value": round(len(patterns) * n_total * args.steps / el / 1e9, 3), "unit": "GB/s",
-                                 "roofline": hbm_roofline("plane_scan<2> inside that loop", own_bytes, sum(l_times) / max(len(l_times), 1),
+                                 "roofline": hbm_roofline("plane_count<ListShape<2>> inside that loop", own_bytes, sum(l_times) / max(len(l_times), 1),
                                                           pmc_traffic("plane", fasta_n=args.fasta_n), len(l_times))}
             out["step_variants_ms"]["span_lists"] = out["span_lists"]["ms_per_step"]
             # Throughput with the scan kernels of consecutive steps OVERLAPPING: four rj_multi objects, a stream each, no order
@@ -723,7 +723,7 @@ def run_regexdna(args, c):
                 assert ca == counts, (ca, counts)
                 out["step_variants_ms"]["every_launch_timed"] = round(ea / args.steps * 1e3, 4)
             if not args.one_stream and s_times:
-                out["roofline_kernel_alone"] = hbm_roofline("plane_scan<2> with nothing else on the device (the one-stream loop)", own_bytes,
+                out["roofline_kernel_alone"] = hbm_roofline("plane_count<ListShape<2>> with nothing else on the device (the one-stream loop)", own_bytes,
                                                             sum(s_times) / len(s_times), pmc_traffic("plane", fasta_n=args.fasta_n), len(s_times))
         out["step_variants_ms"]["synchronous_calls"] = round(ek0 / args.steps * 1e3, 4)
         out["synchronous_calls"] = {"calls": "rj_multi_run mode 0, one call after the other (one step in flight): what rounds 1-2 timed",
@@ -867,10 +867,10 @@ def run_regexdna(args, c):
         e0, c0 = time_steps(big_plane_step, warm=1, steps=5)
         assert c0 == cb, "one-pass and per-pattern runs disagree on the 2.5 GB text"
         ms0 = ms0[1:]
-        out["one_pass_2p5gb"] = {"workload": "the headline's one-pass run over the same 2.5 GB text",
+        out["one_pass_2p5gb"] = {"workload": "the span-list pipeline's one-pass run (round 4's headline) over the same 2.5 GB text",
                                  "value": round(9 * nb / (e0 / args.steps) / 1e9, 3), "unit": "GB/s",
                                  "ms_per_step": round(e0 / args.steps * 1e3, 4),
-                                 "roofline": hbm_roofline("plane_scan<2>", nb, sum(ms0) / len(ms0), pmc_traffic("plane_2p5gb", bytes=nb), len(ms0),
+                                 "roofline": hbm_roofline("plane_count<ListShape<2>>", nb, sum(ms0) / len(ms0), pmc_traffic("plane_2p5gb", bytes=nb), len(ms0),
                                                           ceiling=hbm_ceiling(big.data_ptr(), nb, stream))}
         mc = rejit_amd.MultiScan(progs)
         assert mc.set_counts_only(True)
@@ -1050,7 +1050,7 @@ def literal_and_complex_extras(args, c, out):
         out["general_one_pass"] = {"workload": "%s over the same %d bytes in ONE pass (plane_count<GeneralListShape>: 4 exact base windows of 7 bytes, offsets 0 and 1; round 4-5: plane_scan_general)" % (" + ".join(gset), n),
                                    "how": ghow, "counts": gcounts, "counts_equal_single_runs": gcounts == gsingle,
                                    "latency_ms": round(gmed * 1e3, 4), "value": round(n / gmed / 1e9, 1), "unit": "GB/s of text (once for both patterns)",
-                                   "roofline": hbm_roofline("plane_count<GeneralListShape<false>> (the span pipeline's scan kernel)", n, sum(gms) / len(gms), None, len(gms), ceiling=hbm_ceiling(t.data_ptr(), n, c.stream))}
+                                   "roofline": hbm_roofline("plane_count<GeneralListShape<false>> (the span pipeline's scan kernel)", n, sum(gms) / len(gms), pmc_traffic("general", bytes=n), len(gms), ceiling=hbm_ceiling(t.data_ptr(), n, c.stream))}
         # the same set as MatchAllCount in ONE kernel (round 6: plane_count<GeneralShape>, rj_multi_set_counts_only): the filter
         # through code planes, every candidate classified by the patterns' automata out of LDS, nothing written but the counts;
         # and nine random 12-mers (nine bases: the filter's cost grows with the bases)
@@ -1082,7 +1082,7 @@ def literal_and_complex_extras(args, c, out):
                         "took_counts_path": bool(took), "how": chow, "counts": ccounts, "counts_equal_span_pipeline": ccounts == lcounts,
                         "bounds_equal_span_pipeline": same_bounds,
                         "latency_ms": round(cmed * 1e3, 4), "value": round(n / cmed / 1e9, 1), "unit": "GB/s of text (once for all patterns)",
-                        "roofline": hbm_roofline("plane_count<GeneralShape>", n, sum(cms) / len(cms), None, len(cms), ceiling=hbm_ceiling(t.data_ptr(), n, c.stream))}
+                        "roofline": hbm_roofline("plane_count<GeneralShape>", n, sum(cms) / len(cms), pmc_traffic("counts_general", bytes=n) if not plants else None, len(cms), ceiling=hbm_ceiling(t.data_ptr(), n, c.stream))}
             assert ccounts == lcounts and same_bounds, (key, ccounts, lcounts)
             del cm, cprogs
         del gmulti, gprogs

@@ -59,16 +59,16 @@ for key, prefix, nbytes, extra in (
         ("plane_count", "plane_count<ExactShape<2> >", FASTA, {"fasta_n": 50000000}),
         ("plane_count_2p5gb", "plane_count<ExactShape<2> >", 2500000000, {}),
         ("counts_general", "plane_count<GeneralShape<1, 16, false> >", 5000000000, {}),
-        ("plane", "plane_scan<2>", FASTA, {"fasta_n": 50000000}),
-        ("plane_2p5gb", "plane_scan<2>", 2500000000, {}),
+        ("plane", "plane_count<ListShape<2> >", FASTA, {"fasta_n": 50000000}),
+        ("plane_2p5gb", "plane_count<ListShape<2> >", 2500000000, {}),
         ("regexdna_single", "scan_windows<2, true, true, false, true>", FASTA, {"fasta_n": 50000000}),
         ("regexdna_single_2p5gb", "scan_windows<2, true, true, false, true>", 2500000000, {}),
         # (`regexp` is a 6-byte window: the MASKED instantiation; `abcdefgh` of the complex / behind patterns fills its 8 bytes)
         ("literal", "scan_windows<1, true, true, true, false>", 5000000000, {}),
         ("literal_50gb", "scan_windows<1, true, true, true, false>", 50000000000, {}),
         ("complex", "scan_windows<1, true, false, true, false>", 5000000000, {}),
-        ("dense", "dense_streams<2, 2, false, false>", 5000000000, {}),
-        ("dense_select", "dense_streams<3, 1, false, true>", 5000000000, {}),
+        ("dense", "dense_streams<2, 2, false, false, true>", 5000000000, {}),
+        ("dense_select", "dense_streams<3, 1, false, true, false>", 5000000000, {}),
         ("general", "plane_count<GeneralListShape<false> >", 5000000000, {}),
         ("line_table", "emit_assertions", 5000000000, {})):
     try:
@@ -80,8 +80,8 @@ for key, prefix, nbytes, extra in (
 # bench.py's roofline_valu quotes (round 5 typed these into rejit_amd/__init__.py by hand)
 try:
     sq = open(g("pmc_sq.txt")).read().split("## SQ_INSTS_VALU")[1].split("## ")[0]
-    for key, prefix, nbytes in (("plane_count", "plane_count<ExactShape<2> >", FASTA), ("plane", "plane_scan<2>", FASTA),
-                                ("dense", "dense_streams<2, 2, false, false>", 5000000000), ("dense_select", "dense_streams<3, 1, false, true>", 5000000000),
+    for key, prefix, nbytes in (("plane_count", "plane_count<ExactShape<2> >", FASTA), ("plane", "plane_count<ListShape<2> >", FASTA),
+                                ("dense", "dense_streams<2, 2, false, false, true>", 5000000000), ("dense_select", "dense_streams<3, 1, false, true, false>", 5000000000),
                                 ("counts_general", "plane_count<GeneralShape<1, 16, false> >", 5000000000), ("general", "plane_count<GeneralListShape<false> >", 5000000000)):
         ops = None
         for line in sq.splitlines():
