@@ -9,7 +9,7 @@ from typing import List, Optional, Tuple
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 SOURCES = ["kernels.hip", "scan_windows.hip", "dense_walk.hip", "select_kernels.hip", "plane_scan.hip", "plane_count.hip", "run_scan.hip", "emit_scan.hip", "dense_streams.hip", "dense_streams_select.hip", "verify_lds.hip", "carry_kernels.hip", "engine.hip", "multi_pattern.hip", "host_api.hip", "linear.hip", "exact_replay.hip", "multi_device.hip", "parser.cc", "lowering.cc", "rejit_api.cc"]
-HEADERS = ["kernels.h", "device_program.h", "lowering.h", "carry_scan.h", "behind_walk.h", "exact_replay.h", "engine_internal.h", "table_layout.h", "lds_walk.h", "trace_stamp.h", "dense_swar.h", "dense_streams.h", "tile_lookback.h", "exact_count.h", "short_walk.h", "run_scan.h", "kernel_util.h", "dense_streams.hip"]  # (dense_streams_select.hip includes dense_streams.hip)
+HEADERS = ["kernels.h", "device_program.h", "lowering.h", "carry_scan.h", "behind_walk.h", "exact_replay.h", "engine_internal.h", "table_layout.h", "lds_walk.h", "trace_stamp.h", "dense_swar.h", "dense_streams.h", "tile_lookback.h", "exact_count.h", "short_walk.h", "run_scan.h", "kernel_util.h", "stream_load.h", "dense_streams.hip"]  # (dense_streams_select.hip includes dense_streams.hip)
 LIB = os.path.join(PKG, "librejit_hip.so")
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -287,18 +287,20 @@ BENCH_LIB = os.path.join(PKG, "librejit_bench.so")
 _bench_lib = None
 
 
-def stream_read_probe(d_text_ptr: int, n: int, launches: int = 10, stream: int = 0) -> float:
+def stream_read_probe(d_text_ptr: int, n: int, launches: int = 10, stream: int = 0, default_policy: bool = False) -> float:
     """Average ms of a read-only kernel over device memory (the achievable ceiling of a scan): MEASUREMENT, from
-    rejit_amd/librejit_bench.so (tools/probes/read_probe.hip) -- not part of the product library or its C ABI."""
+    rejit_amd/librejit_bench.so (tools/probes/read_probe.hip) -- not part of the product library or its C ABI.
+    The probe loads with the scans' own non-temporal policy (csrc/stream_load.h); default_policy=True: plain loads,
+    what rounds 1-5 quoted as the ceiling."""
     global _bench_lib
     if _bench_lib is None:
         load_library()   # (torch's copy of the HIP runtime first)
         if not os.path.exists(BENCH_LIB):
             raise FileNotFoundError(f"{BENCH_LIB} is missing: run rejit_amd.build()")
         _bench_lib = ctypes.CDLL(BENCH_LIB)
-        _bench_lib.rjb_stream_read_probe.restype = ctypes.c_float
-        _bench_lib.rjb_stream_read_probe.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p]
-    ms = float(_bench_lib.rjb_stream_read_probe(ctypes.c_void_p(d_text_ptr), n, launches, ctypes.c_void_p(stream)))
+        _bench_lib.rjb_stream_read_probe_policy.restype = ctypes.c_float
+        _bench_lib.rjb_stream_read_probe_policy.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    ms = float(_bench_lib.rjb_stream_read_probe_policy(ctypes.c_void_p(d_text_ptr), n, launches, ctypes.c_void_p(stream), 1 if default_policy else 0))
     if ms < 0:
         raise RejitError(-3, "rjb_stream_read_probe failed")
     return ms

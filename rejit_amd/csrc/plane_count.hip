@@ -7,12 +7,14 @@
 // out) -- and 44 % of its step was the two tails.  A caller that asks for COUNTS needs neither the lists nor, for
 // the pattern sets this kernel takes (exact_count.h: fixed-length 8-byte patterns whose language lies within one byte
 // of the scan's base windows), the automaton: a candidate's eight bytes are looked up in a table.  So here a wave
-//   * streams its span of the text through the bit-plane test of plane_scan.hip, re-laid out so that a lane owns 32
-//     CONTIGUOUS bytes (two 16-byte loads; bit 2k of a plane = byte k, bit 2k + 1 = byte 16 + k): the 8 positions
-//     that follow a lane's first half are its own second half, those that follow the second half are the next lane's
-//     first -- one DPP move instead of two more loads and four more code conversions per 2 KiB --, and the codes of
-//     the NEXT block are computed one step ahead, so that lane 63 finds its neighbour (lane 0 of the next block) in
-//     a register;
+//   * streams its span of the text through the bit-plane test of plane_scan.hip in blocks of 2 KiB, of which a lane owns
+//     TWO 16-byte pieces -- piece A at 16 * lane, piece B at 1024 + 16 * lane; bit 2k of a plane = byte k of A, bit
+//     2k + 1 = byte k of B --: each of the wave's two loads covers one contiguous KiB, every cache line is asked for by
+//     ONE instruction, and that is what lets the loads be non-temporal (stream_load.h: 6.9 instead of 6.0 TB/s for a
+//     read-only stream; rounds 5-6 had a lane own 32 contiguous bytes, two loads per line, and the nt policy made that
+//     form 19 % SLOWER).  The 8 positions that follow a piece are the first 8 of the same piece one lane up -- two DPP
+//     moves, no load --, lane 63's piece A is followed by lane 0's piece B, and the codes of the NEXT block are computed
+//     one step ahead, so that lane 63's piece B finds its neighbour (lane 0's piece A of the next block) in a register;
 //   * keeps the candidates (one per 1.3 KiB on DNA) in an LDS ring of its own, as 32-bit offsets;
 //   * classifies them 64 at a time -- whenever the ring holds that many, and at the end of the span --: two loads of
 //     the candidate's text, exact_classify, a ballot per pattern;
@@ -41,13 +43,15 @@
 #include "exact_count.h"
 #include "kernels.h"
 #include "short_walk.h"
+#include "stream_load.h"
 
 namespace rejit_amd {
 
 namespace {
 
 constexpr int kWave = 64;
-constexpr uint64_t kBlock = 2048;     // bytes a wave takes per iteration: 64 lanes x 32 B
+constexpr uint64_t kBlock = 2048;     // bytes a wave takes per iteration: 64 lanes x 2 pieces of 16 B
+constexpr uint32_t kPieceB = 1024;    // a lane's piece B begins this far behind its piece A
 constexpr uint32_t kRing = 256;       // candidate slots per wave; consumed 64 at a time, looked at every second block
 
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & (kWave - 1); }
@@ -94,14 +98,14 @@ __device__ __forceinline__ uint32_t codes16(const uint4& v, const Consts& k) {
 }
 
 struct Raw {
-  uint4 a, b;   // the lane's 32 bytes
+  uint4 a, b;   // the lane's two pieces
 };
 
 // (a uniform base and a 32-bit lane offset: the load takes its address from a scalar pair + one register, no 64-bit
 // pointer per lane is kept alive across the loop)
 __device__ __forceinline__ void load_block(const uint8_t* block, uint32_t lane_off, Raw& r) {
-  r.a = *reinterpret_cast<const uint4*>(block + lane_off);
-  r.b = *reinterpret_cast<const uint4*>(block + lane_off + 16);
+  r.a = stream_load16(block + lane_off);
+  r.b = stream_load16(block + lane_off + kPieceB);
 }
 
 __device__ __forceinline__ uint32_t guarded_dword(const uint8_t* text, uint64_t n, uint64_t at) {
@@ -112,15 +116,15 @@ __device__ __forceinline__ uint32_t guarded_dword(const uint8_t* text, uint64_t 
   return v;
 }
 
-// Window positions of the lane's 32 bytes that lie within one code of a base: bit 2k = byte k, bit 2k + 1 = byte
-// 16 + k.  ta / tb: the codes of the two halves; hb: the codes of the 8 bytes behind them (bits 0..15).
+// Window positions of the lane's two pieces that lie within one code of a base: bit 2k = byte k of piece A, bit 2k + 1 =
+// byte k of piece B.  ta / tb: the codes of the pieces; ha / hb: the codes of the 8 bytes behind each of them (bits 0..15).
 template <int NB>
-__device__ __forceinline__ uint32_t plane_test(uint32_t ta, uint32_t tb, uint32_t hb, const PlaneCountParams& a) {
+__device__ __forceinline__ uint32_t plane_test(uint32_t ta, uint32_t tb, uint32_t ha, uint32_t hb, const PlaneCountParams& a) {
   constexpr uint32_t kEven = 0x55555555u;
   const uint32_t L = (ta & kEven) | ((tb << 1) & ~kEven);
   const uint32_t H = ((ta >> 1) & kEven) | (tb & ~kEven);
-  const uint32_t Ln = (tb & kEven) | ((hb << 1) & ~kEven);   // what follows the first half is the second half
-  const uint32_t Hn = ((tb >> 1) & kEven) | (hb & ~kEven);
+  const uint32_t Ln = (ha & kEven) | ((hb << 1) & ~kEven);
+  const uint32_t Hn = ((ha >> 1) & kEven) | (hb & ~kEven);
   // The four CODE planes (bit = the position's symbol has code c) of the 32 positions and of the 32 that follow.  "Window byte
   // i of base b fits at position p" is then ONE shifted plane -- alignbit(next[c], here[c], 2 i), c = the code of the base's
   // byte i -- where two bit planes compared against the base's masks took a shift each (shared by the bases), an XOR and a
@@ -275,7 +279,7 @@ struct ExactShape {
   __device__ static __forceinline__ const PlaneCountParams& common(const Args& g) { return g; }
   __device__ static __forceinline__ uint32_t lmax(const Args&) { return 8u; }
   __device__ static __forceinline__ uint32_t offset_of(const Args&, const uint32_t*, uint32_t) { return 0u; }
-  __device__ static __forceinline__ uint32_t test(uint32_t ta, uint32_t tb, uint32_t hb, const Args& g) { return plane_test<NB>(ta, tb, hb, g); }
+  __device__ static __forceinline__ uint32_t test(uint32_t ta, uint32_t tb, uint32_t ha, uint32_t hb, const Args& g) { return plane_test<NB>(ta, tb, ha, hb, g); }
   // the patterns that match the 8 bytes at window position `pos` (the scan does not clip: windows before the range, or
   // with bytes beyond the end of the text, are dropped here)
   __device__ static __forceinline__ void classify(const Args& a, const uint32_t* table, uint64_t pos, bool have, uint32_t& mask, Lens&) {
@@ -301,13 +305,13 @@ struct ListShape {
   __device__ static __forceinline__ const PlaneCountParams& common(const Args& g) { return g.c; }
   __device__ static __forceinline__ uint32_t lmax(const Args&) { return 8u; }
   __device__ static __forceinline__ uint32_t offset_of(const Args&, const uint32_t*, uint32_t) { return 0u; }
-  __device__ static __forceinline__ uint32_t test(uint32_t ta, uint32_t tb, uint32_t hb, const Args& g) { return plane_test<NB>(ta, tb, hb, g.c); }
+  __device__ static __forceinline__ uint32_t test(uint32_t ta, uint32_t tb, uint32_t ha, uint32_t hb, const Args& g) { return plane_test<NB>(ta, tb, ha, hb, g.c); }
   __device__ static __forceinline__ void classify(const Args&, const uint32_t*, uint64_t, bool, uint32_t& mask, Lens&) { mask = 0; }
 };
 
 namespace {
 
-// The general test: bit 2k = byte k, bit 2k + 1 = byte 16 + k of the lane's 32 (plane_test's layout).  Base after base in a
+// The general test: bit 2k = byte k of the lane's piece A, bit 2k + 1 = byte k of its piece B (plane_test's layout).  Base after base in a
 // loop that is NOT unrolled (<= 12 bases), and per base what plane_test does for its two: "window byte i of the base fits at
 // position p" is ONE shifted code plane, picked by the VGPR index mode -- the four planes of the 32 positions sit in v48..v51,
 // an all-ones plane in v52 (a compared byte beyond the set's n_cmp: always fits), the same for the 32 positions that follow
@@ -316,12 +320,12 @@ namespace {
 // first version of this function (two bit planes XORed with per-position masks, a scalar load + wait per mask pair) ran
 // general_one_pass' four bases at 0.55 of peak and nine 12-mers at 0.32.
 template <bool TOL>
-__device__ __forceinline__ uint32_t general_test(uint32_t ta, uint32_t tb, uint32_t hb, const PlaneCountGParams& g) {
+__device__ __forceinline__ uint32_t general_test(uint32_t ta, uint32_t tb, uint32_t ha, uint32_t hb, const PlaneCountGParams& g) {
   constexpr uint32_t kEven = 0x55555555u;
   const uint32_t L = (ta & kEven) | ((tb << 1) & ~kEven);
   const uint32_t H = ((ta >> 1) & kEven) | (tb & ~kEven);
-  const uint32_t Ln = (tb & kEven) | ((hb << 1) & ~kEven);
-  const uint32_t Hn = ((tb >> 1) & kEven) | (hb & ~kEven);
+  const uint32_t Ln = (ha & kEven) | ((hb << 1) & ~kEven);
+  const uint32_t Hn = ((ha >> 1) & kEven) | (hb & ~kEven);
   register uint32_t q0 asm("v48") = ~(L | H);
   register uint32_t q1 asm("v49") = L & ~H;
   register uint32_t q2 asm("v50") = ~L & H;
@@ -395,7 +399,7 @@ struct GeneralShape {
   __device__ static __forceinline__ uint32_t offset_of(const Args&, const uint32_t* blob, uint32_t p) {
     return reinterpret_cast<const ClassifyDesc*>(blob)[p].win_offset;
   }
-  __device__ static __forceinline__ uint32_t test(uint32_t ta, uint32_t tb, uint32_t hb, const Args& g) { return general_test<TOL>(ta, tb, hb, g); }
+  __device__ static __forceinline__ uint32_t test(uint32_t ta, uint32_t tb, uint32_t ha, uint32_t hb, const Args& g) { return general_test<TOL>(ta, tb, ha, hb, g); }
   // per pattern: the start s = w - its window offset inside the own range, the window inside the text, one of its windows
   // matches exactly -- then its automaton from s (classify_shared_general's steps 1 and 2, for 64 candidates at a time)
   __device__ static __forceinline__ void classify(const Args& g, const uint32_t* blob, uint64_t w, bool have, uint32_t& mask, Lens& lens) {
@@ -461,7 +465,7 @@ struct GeneralListShape {
   __device__ static __forceinline__ const PlaneCountParams& common(const Args& g) { return g.g.c; }
   __device__ static __forceinline__ uint32_t lmax(const Args& g) { return g.g.lmax; }
   __device__ static __forceinline__ uint32_t offset_of(const Args&, const uint32_t*, uint32_t) { return 0u; }
-  __device__ static __forceinline__ uint32_t test(uint32_t ta, uint32_t tb, uint32_t hb, const Args& g) { return general_test<TOL>(ta, tb, hb, g.g); }
+  __device__ static __forceinline__ uint32_t test(uint32_t ta, uint32_t tb, uint32_t ha, uint32_t hb, const Args& g) { return general_test<TOL>(ta, tb, ha, hb, g.g); }
   __device__ static __forceinline__ void classify(const Args&, const uint32_t*, uint64_t, bool, uint32_t& mask, Lens&) { mask = 0; }
 };
 
@@ -497,23 +501,31 @@ __device__ __forceinline__ void push_block(WaveState& w, uint32_t hm, uint32_t r
       w.ring[idx & (kRing - 1)] = rel;
     }
   };
+  // text order: the pieces A of lanes 0..63 (the block's first KiB), then the pieces B
+  const uint32_t hm_a = hm & 0x55555555u, hm_b = hm & 0xAAAAAAAAu;
   const uint64_t several = __ballot((hm & (hm - 1)) != 0);
   if (several == 0) {
     // the usual case: no lane holds two candidates
+    const uint64_t any_a = __ballot(hm_a != 0);
     if (hm != 0) {
       const uint32_t bit = static_cast<uint32_t>(__builtin_ctz(hm));
-      put(w.tail + lanes_below(any), rel_lane + (bit >> 1) + ((bit & 1u) << 4));
+      const uint32_t at = hm_a != 0 ? lanes_below(any_a) : static_cast<uint32_t>(__popcll(any_a)) + lanes_below(any & ~any_a);
+      put(w.tail + at, rel_lane + (bit >> 1) + ((bit & 1u) ? kPieceB : 0u));
     }
     w.tail += static_cast<uint32_t>(__popcll(any));
     return;
   }
-  const uint32_t c = __popc(hm);
+  // (one prefix sum for both: piece A's count in the low half of the word, piece B's in the high half; <= 16 per lane and piece)
+  const uint32_t c = __popc(hm_a) | (__popc(hm_b) << 16);
   const uint32_t inc = wave_inclusive_sum(c);
-  const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(inc), kWave - 1));
+  const uint32_t tots = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(inc), kWave - 1));
+  const uint32_t tot_a = tots & 0xFFFFu, tot = tot_a + (tots >> 16);
   if (LIST || tot <= kRing) {   // (ring: more -- the caller's occupancy test voids the run; nothing is written)
-    uint32_t idx = w.tail + inc - c;
-    for (uint32_t m = hm & 0x55555555u; m; m &= m - 1, idx++) put(idx, rel_lane + (static_cast<uint32_t>(__builtin_ctz(m)) >> 1));
-    for (uint32_t m = hm & 0xAAAAAAAAu; m; m &= m - 1, idx++) put(idx, rel_lane + 16u + (static_cast<uint32_t>(__builtin_ctz(m)) >> 1));
+    const uint32_t before = inc - c;
+    uint32_t idx = w.tail + (before & 0xFFFFu);
+    for (uint32_t m = hm_a; m; m &= m - 1, idx++) put(idx, rel_lane + (static_cast<uint32_t>(__builtin_ctz(m)) >> 1));
+    idx = w.tail + tot_a + (before >> 16);
+    for (uint32_t m = hm_b; m; m &= m - 1, idx++) put(idx, rel_lane + kPieceB + (static_cast<uint32_t>(__builtin_ctz(m)) >> 1));
   }
   w.tail += tot;
 }
@@ -685,13 +697,16 @@ __global__ __launch_bounds__(256) void plane_count(typename S::Args g) {
   }
   bool first_batch = true;
 
-  // A wave never loads a block that is not its own: prefetches beyond the span's last fast block are clamped to that
-  // block (cache hits), and what lane 63 needs of the block BEHIND the span -- the codes of its first 8 bytes -- comes
-  // from one 8-byte load, the same address in every lane.  (Clamped to the text's last block only, the prefetches ran
-  // three blocks into the neighbour's span: FETCH_SIZE 1.22 x the text on spans of 20 blocks.)
+  // A wave never loads a block that is not its own: prefetches beyond the span's last fast block are left out inside the
+  // loop (wave-uniform branches; the buffers then keep codes nobody uses), and what lane 63 needs of the block BEHIND the
+  // span -- the codes of its first 8 bytes -- comes from one 8-byte load, the same address in every lane.  History: clamped
+  // to the text's last block only, the prefetches ran three blocks into the neighbour's span (FETCH_SIZE 1.22 x the text
+  // on spans of 20 blocks); clamped to the span's own last block they were cache hits under the default load policy, but
+  // a non-temporal line does not wait in the cache to be hit: with nt loads the clamped form cost the list kernel 9 %
+  // (0.0867 -> 0.0790 ms per 500 MB without them, A/B in one gpurun call).
   const uint32_t last_own = fast_end > c0 ? fast_end - 1 : c0;
   auto blk = [&](uint32_t c) { return a.text + static_cast<uint64_t>(c < last_own ? c : last_own) * kBlock; };
-  const uint32_t lane_rel = static_cast<uint32_t>(lane) * 32u;
+  const uint32_t lane_rel = static_cast<uint32_t>(lane) * 16u;   // piece A; piece B kPieceB behind it
   Raw ra, rb;
   uint2 behind{0, 0};
   uint32_t c = c0;
@@ -721,21 +736,24 @@ __global__ __launch_bounds__(256) void plane_count(typename S::Args g) {
       // (the codes must exist BEFORE the buffer is loaded again: when the compiler sinks their computation towards its
       // use, the reload lands in other registers and is copied back at the loop's end -- behind a wait for it)
       asm volatile("" ::"v"(ya), "v"(yb));
-      load_block(blk(c + 3), lane_rel, rb);
+      if (c + 3 <= last_own) load_block(blk(c + 3), lane_rel, rb);
       {
-        const uint32_t hb = from_lane_above(xa, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ya))));
-        const uint32_t hm = S::test(xa, xb, hb, g);
+        // (behind lane 63's piece A: lane 0's piece B; behind its piece B: lane 0's piece A of the next block)
+        const uint32_t ha = from_lane_above(xa, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xb))));
+        const uint32_t hb = from_lane_above(xb, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ya))));
+        const uint32_t hm = S::test(xa, xb, ha, hb, g);
         push_block<S::kList>(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
       }
       __builtin_amdgcn_sched_barrier(0);
       xa = codes16(ra.a, k);   // block c + 2 (the span's last fast block again when c + 2 == fast_end: not used then)
       xb = codes16(ra.b, k);
       asm volatile("" ::"v"(xa), "v"(xb));
-      load_block(blk(c + 4), lane_rel, ra);
+      if (c + 4 <= last_own) load_block(blk(c + 4), lane_rel, ra);
       {
         const uint32_t next0 = c + 2 == fast_end ? behind_codes : static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xa)));
-        const uint32_t hb = from_lane_above(ya, next0);
-        const uint32_t hm = S::test(ya, yb, hb, g);
+        const uint32_t ha = from_lane_above(ya, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(yb))));
+        const uint32_t hb = from_lane_above(yb, next0);
+        const uint32_t hm = S::test(ya, yb, ha, hb, g);
         push_block<S::kList>(w, hm, (c + 1 - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -743,28 +761,31 @@ __global__ __launch_bounds__(256) void plane_count(typename S::Args g) {
       if (!S::kList && w.tail - w.head >= a.batch_at) blocks_done<S>(w, tab, g, span_base, first_batch);
     }
     if (c + 1 == fast_end) {   // an odd block left: x holds its codes; behind it the span ends
-      const uint32_t hb = from_lane_above(xa, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(behind_codes))));
-      const uint32_t hm = S::test(xa, xb, hb, g);
+      const uint32_t ha = from_lane_above(xa, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xb))));
+      const uint32_t hb = from_lane_above(xb, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(behind_codes))));
+      const uint32_t hm = S::test(xa, xb, ha, hb, g);
       push_block<S::kList>(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
       c++;
     }
     if (!S::kList) blocks_done<S>(w, tab, g, span_base, first_batch);
   }
-  // the block(s) at the end of the text: guarded loads, the 8 bytes behind the lane's 32 read by the lane itself
+  // the block(s) at the end of the text: guarded loads, the 8 bytes behind each of the lane's pieces read by the lane itself
   for (; c < c1; c++) {
-    const uint64_t at = static_cast<uint64_t>(c) * kBlock + lane_rel;
+    const uint64_t at = static_cast<uint64_t>(c) * kBlock + lane_rel, bt = at + kPieceB;
     uint4 va, vb;
     va.x = guarded_dword(a.text, a.n, at);
     va.y = guarded_dword(a.text, a.n, at + 4);
     va.z = guarded_dword(a.text, a.n, at + 8);
     va.w = guarded_dword(a.text, a.n, at + 12);
-    vb.x = guarded_dword(a.text, a.n, at + 16);
-    vb.y = guarded_dword(a.text, a.n, at + 20);
-    vb.z = guarded_dword(a.text, a.n, at + 24);
-    vb.w = guarded_dword(a.text, a.n, at + 28);
-    const uint32_t h0 = guarded_dword(a.text, a.n, at + 32), h1 = guarded_dword(a.text, a.n, at + 36);
+    vb.x = guarded_dword(a.text, a.n, bt);
+    vb.y = guarded_dword(a.text, a.n, bt + 4);
+    vb.z = guarded_dword(a.text, a.n, bt + 8);
+    vb.w = guarded_dword(a.text, a.n, bt + 12);
+    const uint32_t g0 = guarded_dword(a.text, a.n, at + 16), g1 = guarded_dword(a.text, a.n, at + 20);
+    const uint32_t h0 = guarded_dword(a.text, a.n, bt + 16), h1 = guarded_dword(a.text, a.n, bt + 20);
+    const uint32_t ha = (codes4(g0, k) >> k.shift) | (codes4(g1, k) << (8 - k.shift));
     const uint32_t hb = (codes4(h0, k) >> k.shift) | (codes4(h1, k) << (8 - k.shift));
-    const uint32_t hm = S::test(codes16(va, k), codes16(vb, k), hb, g);
+    const uint32_t hm = S::test(codes16(va, k), codes16(vb, k), ha, hb, g);
     if (!S::kList && w.tail - w.head > kRing - 64u) blocks_done<S>(w, tab, g, span_base, first_batch);   // (room for this block)
     push_block<S::kList>(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
   }

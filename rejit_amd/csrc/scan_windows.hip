@@ -13,6 +13,7 @@
 #include "dense_swar.h"
 #include "device_program.h"
 #include "kernel_util.h"
+#include "stream_load.h"
 #include "kernels.h"
 
 namespace rejit_amd {
@@ -178,9 +179,14 @@ __device__ __forceinline__ void windows_chunk(const uint32_t (&d)[6], uint64_t a
   hits.push_bits(hm, at, ws.offset);
 }
 
+// lane i <- lane i + 1 (wave_shl:1); lane 63 keeps `last`
+__device__ __forceinline__ uint32_t lane_above_or(uint32_t v, uint32_t last) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(last), static_cast<int>(v), 0x130, 0xF, 0xF, false));
+}
+
 template <bool TWO>
 __device__ __forceinline__ void load_chunk(const uint8_t* text, uint64_t at, uint32_t (&d)[6]) {
-  const uint4 v = *reinterpret_cast<const uint4*>(text + at);
+  const uint4 v = *reinterpret_cast<const uint4*>(text + at);   // (default policy: the halo load below asks for the same lines)
   d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
   if (TWO) {  // the neighbour's first 8 bytes (same cache lines: L1 hits, no extra HBM traffic)
     const uint2 h = *reinterpret_cast<const uint2*>(text + at + 16);
@@ -191,7 +197,10 @@ __device__ __forceinline__ void load_chunk(const uint8_t* text, uint64_t at, uin
   }
 }
 
-template <int K, bool TWO, bool MASKED, bool TWOLEVEL, bool NIB>
+// NT: the text is loaded with the non-temporal policy (stream_load.h) -- a kernel that reads its text ONCE.  The train reads a
+// wave's span once per pattern and lives on passes 2..P finding it in the Infinity Cache: default policy there (measured with nt:
+// 0.72 -> 0.83 ms per nine-pattern launch over 500 MB).
+template <int K, bool TWO, bool MASKED, bool TWOLEVEL, bool NIB, bool NT = true>
 __device__ __forceinline__ void scan_windows_body(const ScanParams& a, const WindowSet& ws) {
   const int lane = lane_id();
   const uint64_t wave = scalar_wave_index();
@@ -206,42 +215,65 @@ __device__ __forceinline__ void scan_windows_body(const ScanParams& a, const Win
   if (fast_end < span.c0) fast_end = span.c0;
   const uint64_t lane_off = static_cast<uint64_t>(lane) * 16;
 
-  // Software-pipelined streaming loop, three register buffers deep: while chunk c is compared
-  // the loads of chunks c+1 and c+2 are in flight (3 KiB per wave).  The prologue and the steady
-  // loop run only when all their loads exist, so every load is unconditional and the compiler can
-  // count them: it waits for exactly the buffer it needs (vmcnt(4)).  A conditional prologue
-  // ("load b1 if it exists") made the count at the loop head ambiguous and the compiler waited for
-  // ALL loads there -- including the one issued just before the back edge, i.e. a full memory
-  // latency exposed every third chunk.  Spans shorter than 6 chunks and the last <= 2 chunks of a
-  // span take the plain loop below; no byte is loaded twice.
+  // Software-pipelined streaming loop, FOUR register buffers of 16 bytes per lane: while chunk c is compared the loads of
+  // chunks c+2 and c+3 are in flight (2 KiB per wave), and chunk c+1 has landed -- lane 63 takes the bytes that follow its
+  // own 16 from there (lane 0's first dwords, a v_readfirstlane), every other lane from the lane above it (DPP): NO halo load.
+  // Round 6: with the halo loaded (rounds 1-5: 8 bytes at +16, "the same cache lines: L1 hits") every line of the text was
+  // asked for by two instructions, and a line loaded with the non-temporal policy does not wait in the cache for the second
+  // one -- the nt loads (stream_load.h) bought nothing until the halo load was gone.  The prologue and the steady loop run
+  // only when all their loads exist, so every load is unconditional and the compiler can count them (it waits for exactly the
+  // buffer it needs); a conditional prologue made the count at the loop head ambiguous and the compiler waited for ALL loads
+  // there.  Short spans and the last chunks of a span take the plain loop below (lane 63 loads its 8 bytes); no chunk is
+  // loaded twice.
   {
-    uint32_t b0[6], b1[6], b2[6];
+    auto ld = [&](uint64_t c) { return NT ? stream_load16(a.text + c * kChunk + lane_off) : *reinterpret_cast<const uint4*>(a.text + c * kChunk + lane_off); };
+    // chunk c = q, the chunk behind it begins with the dwords (nx, ny) (wave-uniform)
+    auto proc = [&](const uint4& q, uint32_t nx, uint32_t ny, uint64_t c) __attribute__((always_inline)) {
+      uint32_t d[6];
+      d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+      d[4] = lane_above_or(q.x, nx);
+      d[5] = TWO ? lane_above_or(q.y, ny) : 0u;
+      windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(d, c * kChunk + lane_off, a, ws, hits);
+    };
+    auto first_of = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
+    uint4 q0, q1, q2, q3;
     uint64_t c = span.c0;
-    if (c + 5 < fast_end) {
-      load_chunk<TWO>(a.text, c * kChunk + lane_off, b0);
-      load_chunk<TWO>(a.text, (c + 1) * kChunk + lane_off, b1);
-      load_chunk<TWO>(a.text, (c + 2) * kChunk + lane_off, b2);
-      while (c + 5 < fast_end) {
-        windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b0, c * kChunk + lane_off, a, ws, hits);
-        load_chunk<TWO>(a.text, (c + 3) * kChunk + lane_off, b0);
+    if (c + 7 < fast_end) {
+      q0 = ld(c);
+      q1 = ld(c + 1);
+      q2 = ld(c + 2);
+      q3 = ld(c + 3);
+      while (c + 7 < fast_end) {
+        proc(q0, first_of(q1.x), first_of(q1.y), c);
+        q0 = ld(c + 4);
         __builtin_amdgcn_sched_barrier(0);
-        windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b1, (c + 1) * kChunk + lane_off, a, ws, hits);
-        load_chunk<TWO>(a.text, (c + 4) * kChunk + lane_off, b1);
+        proc(q1, first_of(q2.x), first_of(q2.y), c + 1);
+        q1 = ld(c + 5);
         __builtin_amdgcn_sched_barrier(0);
-        windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b2, (c + 2) * kChunk + lane_off, a, ws, hits);
-        load_chunk<TWO>(a.text, (c + 5) * kChunk + lane_off, b2);
+        proc(q2, first_of(q3.x), first_of(q3.y), c + 2);
+        q2 = ld(c + 6);
         __builtin_amdgcn_sched_barrier(0);
-        c += 3;
+        proc(q3, first_of(q0.x), first_of(q0.y), c + 3);
+        q3 = ld(c + 7);
+        __builtin_amdgcn_sched_barrier(0);
+        c += 4;
       }
-      // b0..b2 hold chunks c, c+1, c+2 (the loads of the last iteration, all inside the span)
-      windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b0, c * kChunk + lane_off, a, ws, hits);
-      windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b1, (c + 1) * kChunk + lane_off, a, ws, hits);
-      windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b2, (c + 2) * kChunk + lane_off, a, ws, hits);
+      // q0..q3 hold chunks c .. c+3 (the loads of the last iteration, all inside the span); what follows c+3 is not loaded
+      proc(q0, first_of(q1.x), first_of(q1.y), c);
+      proc(q1, first_of(q2.x), first_of(q2.y), c + 1);
+      proc(q2, first_of(q3.x), first_of(q3.y), c + 2);
+      q0 = q3;
       c += 3;
+    } else if (c < fast_end) {
+      q0 = ld(c);
     }
+    // chunk c in q0; the 8 bytes behind it from one load of lane 63's (chunks below fast_end: they lie inside the text)
     for (; c < fast_end; c++) {
-      load_chunk<TWO>(a.text, c * kChunk + lane_off, b0);
-      windows_chunk<K, TWO, MASKED, TWOLEVEL, NIB>(b0, c * kChunk + lane_off, a, ws, hits);
+      uint2 h = make_uint2(0, 0);
+      if (lane == kWave - 1) h = *reinterpret_cast<const uint2*>(a.text + (c + 1) * kChunk);
+      const uint4 cur = q0;
+      if (c + 1 < fast_end) q0 = ld(c + 1);
+      proc(cur, h.x, h.y, c);   // (lane 63 keeps its own h: lane_above_or's `last` is per lane)
     }
   }
   // tail: the chunk(s) that touch the end of the text use guarded byte loads
@@ -290,7 +322,7 @@ __global__ __launch_bounds__(256) void scan_windows_train(TrainParams t) {
     ws.mask0[1] = t.mask[p][1];
     ws.offset = t.offset[p];
     ws.len = t.len[p];
-    scan_windows_body<2, true, MASKED, false, true>(a, ws);
+    scan_windows_body<2, true, MASKED, false, true, false>(a, ws);
   }
 }
 
