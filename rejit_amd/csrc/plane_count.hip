@@ -52,6 +52,9 @@ namespace {
 constexpr int kWave = 64;
 constexpr uint64_t kBlock = 2048;     // bytes a wave takes per iteration: 64 lanes x 2 pieces of 16 B
 constexpr uint32_t kPieceB = 1024;    // a lane's piece B begins this far behind its piece A
+// Capture (ExactShape): a wave keeps the raw bytes of the last two blocks in LDS -- a block's 2 KiB in text order and, behind
+// them, the first 8 bytes of the block that follows -- and a candidate takes its 8 bytes from there when it enters the ring.
+constexpr uint32_t kStashWords = (2048 + 16) / 4;
 constexpr uint32_t kRing = 256;       // candidate slots per wave; consumed 64 at a time, looked at every second block
 
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & (kWave - 1); }
@@ -276,6 +279,7 @@ struct ExactShape {
   static constexpr uint32_t kFixedLen = 8;
   static constexpr bool kBlobInLds = false;
   static constexpr bool kList = false;
+  static constexpr bool kCapture = true;   // a candidate's 8 bytes ride in the ring (taken from the wave's stash of the block)
   __device__ static __forceinline__ const PlaneCountParams& common(const Args& g) { return g; }
   __device__ static __forceinline__ uint32_t lmax(const Args&) { return 8u; }
   __device__ static __forceinline__ uint32_t offset_of(const Args&, const uint32_t*, uint32_t) { return 0u; }
@@ -292,6 +296,12 @@ struct ExactShape {
     mask = exact_classify<NB>(table, a.base_lo, a.base_hi, lo, hi);
     mask = ok ? mask : 0u;
   }
+  // ... the same with the window's bytes at hand (lo = bytes 0..3, hi = bytes 4..7)
+  __device__ static __forceinline__ void classify_bytes(const Args& a, const uint32_t* table, uint64_t pos, bool have, uint32_t lo, uint32_t hi, uint32_t& mask) {
+    const bool ok = have && pos >= a.sb && pos < a.se && pos + 8 <= a.n;
+    mask = exact_classify<NB>(table, a.base_lo, a.base_hi, lo, hi);
+    mask = ok ? mask : 0u;
+  }
 };
 
 // ListShape<NB>: ExactShape's test, the candidates not classified but written, in text order, to the wave's region of the
@@ -302,6 +312,8 @@ struct ListShape {
   static constexpr uint32_t kFixedLen = 8;
   static constexpr bool kBlobInLds = false;
   static constexpr bool kList = true;
+  static constexpr bool kCapture = false;
+  __device__ static __forceinline__ void classify_bytes(const Args&, const uint32_t*, uint64_t, bool, uint32_t, uint32_t, uint32_t& mask) { mask = 0; }
   __device__ static __forceinline__ const PlaneCountParams& common(const Args& g) { return g.c; }
   __device__ static __forceinline__ uint32_t lmax(const Args&) { return 8u; }
   __device__ static __forceinline__ uint32_t offset_of(const Args&, const uint32_t*, uint32_t) { return 0u; }
@@ -394,6 +406,8 @@ struct GeneralShape {
   static constexpr uint32_t kFixedLen = 0;
   static constexpr bool kBlobInLds = true;
   static constexpr bool kList = false;
+  static constexpr bool kCapture = false;
+  __device__ static __forceinline__ void classify_bytes(const Args&, const uint32_t*, uint64_t, bool, uint32_t, uint32_t, uint32_t& mask) { mask = 0; }
   __device__ static __forceinline__ const PlaneCountParams& common(const Args& g) { return g.c; }
   __device__ static __forceinline__ uint32_t lmax(const Args& g) { return g.lmax; }
   __device__ static __forceinline__ uint32_t offset_of(const Args&, const uint32_t* blob, uint32_t p) {
@@ -462,6 +476,8 @@ struct GeneralListShape {
   static constexpr uint32_t kFixedLen = 0;
   static constexpr bool kBlobInLds = false;
   static constexpr bool kList = true;
+  static constexpr bool kCapture = false;
+  __device__ static __forceinline__ void classify_bytes(const Args&, const uint32_t*, uint64_t, bool, uint32_t, uint32_t, uint32_t& mask) { mask = 0; }
   __device__ static __forceinline__ const PlaneCountParams& common(const Args& g) { return g.g.c; }
   __device__ static __forceinline__ uint32_t lmax(const Args& g) { return g.g.lmax; }
   __device__ static __forceinline__ uint32_t offset_of(const Args&, const uint32_t*, uint32_t) { return 0u; }
@@ -474,6 +490,8 @@ namespace {
 // per wave: the ring, and what the classification carries from batch to batch
 struct WaveState {
   uint32_t* ring;        // LDS, kRing slots: window positions as offsets from the span's first byte, in text order
+                         // (capture: the window's bytes 0..3 in ring[kRing + slot], 4..7 in ring[2 kRing + slot])
+  uint32_t* stash;       // LDS, capture: two slots of kStashWords
   uint32_t head, tail;   // wave-uniform, free-running
   uint32_t acc;          // lane p: matches of pattern p so far
   uint32_t flags;        // kPcConflict | kPcVoid (wave-uniform)
@@ -490,8 +508,9 @@ struct WaveState {
 constexpr uint32_t kNoEnd = 0xFFFFFFFFu;
 
 // the candidates of one block, in text order, to the ring (LIST: to the wave's region in device memory; w.tail counts them)
-template <bool LIST>
-__device__ __forceinline__ void push_block(WaveState& w, uint32_t hm, uint32_t rel_lane) {
+// (CAPTURE: block_rel = the block's first byte as an offset from the span's, slot = the block's stash slot)
+template <bool LIST, bool CAPTURE>
+__device__ __forceinline__ void push_block(WaveState& w, uint32_t hm, uint32_t rel_lane, uint32_t block_rel = 0, uint32_t slot = 0) {
   const uint64_t any = __ballot(hm != 0);
   if (any == 0) return;  // wave-uniform
   auto put = [&](uint32_t idx, uint32_t rel) {
@@ -499,6 +518,14 @@ __device__ __forceinline__ void push_block(WaveState& w, uint32_t hm, uint32_t r
       if (idx < w.list_cap) w.list[idx] = w.list_base + rel;
     } else {
       w.ring[idx & (kRing - 1)] = rel;
+      if (CAPTURE) {
+        // the window's 8 bytes: three aligned words of the stash, shifted (bytes 2048..2055 = the next block's first 8)
+        const uint32_t o = rel - block_rel;
+        const uint32_t* sw = w.stash + slot * kStashWords + (o >> 2);
+        const uint32_t s0 = sw[0], s1 = sw[1], s2 = sw[2];
+        w.ring[kRing + (idx & (kRing - 1))] = __builtin_amdgcn_alignbyte(s1, s0, o & 3u);
+        w.ring[2 * kRing + (idx & (kRing - 1))] = __builtin_amdgcn_alignbyte(s2, s1, o & 3u);
+      }
     }
   };
   // text order: the pieces A of lanes 0..63 (the block's first KiB), then the pieces B
@@ -548,7 +575,13 @@ __device__ __forceinline__ void classify_batch(WaveState& w, uint32_t m, const u
   const uint32_t rel = w.ring[(w.head + static_cast<uint32_t>(lane)) & (kRing - 1)];
   uint32_t mask;
   Lens lens;
-  S::classify(g, tab, span_base + rel, have, mask, lens);
+  if constexpr (S::kCapture) {
+    const uint32_t lo = w.ring[kRing + ((w.head + static_cast<uint32_t>(lane)) & (kRing - 1))];
+    const uint32_t hi = w.ring[2 * kRing + ((w.head + static_cast<uint32_t>(lane)) & (kRing - 1))];
+    S::classify_bytes(g, tab, span_base + rel, have, lo, hi, mask);
+  } else {
+    S::classify(g, tab, span_base + rel, have, mask, lens);
+  }
   const uint32_t before = from_lane_below(rel, w.prev_rel);
   const bool has_before = lane > 0 || w.prev_valid != 0;
   const bool close = have && has_before && (rel - before) < S::lmax(g);
@@ -653,7 +686,8 @@ __global__ __launch_bounds__(256) void plane_count(typename S::Args g) {
   // ExactShape: the table (exact_count.h); GeneralShape: the blob of descriptors + automaton tables (dynamic LDS)
   __shared__ __attribute__((aligned(16))) uint32_t table[kExactTabWords];
   extern __shared__ __attribute__((aligned(16))) uint32_t blob[];
-  __shared__ uint32_t rings[4][kRing];
+  __shared__ uint32_t rings[4][kRing * (S::kCapture ? 3 : 1)];
+  __shared__ __attribute__((aligned(16))) uint32_t stashes[4][S::kCapture ? 2 * kStashWords : 4];
   __shared__ uint32_t ends[4][4 * kExactMaxPatterns];
   __shared__ unsigned long long wave_bounds[4][kExactMaxPatterns][2];
   __shared__ uint32_t wave_counts[4][kExactMaxPatterns];
@@ -678,6 +712,7 @@ __global__ __launch_bounds__(256) void plane_count(typename S::Args g) {
   const uint64_t span_base = static_cast<uint64_t>(c0) * kBlock;
   WaveState w;
   w.ring = rings[wid];
+  w.stash = stashes[wid];
   w.ends = ends[wid];
   w.head = w.tail = 0;
   w.acc = 0;
@@ -710,6 +745,20 @@ __global__ __launch_bounds__(256) void plane_count(typename S::Args g) {
   Raw ra, rb;
   uint2 behind{0, 0};
   uint32_t c = c0;
+  // capture: block ci's bytes to its stash slot (text order: piece A of lane L at 16 L, piece B at 1024 + 16 L) ...
+  auto stash_put = [&](uint32_t ci, const Raw& r) __attribute__((always_inline)) {
+    if constexpr (S::kCapture) {
+      uint32_t* sl = w.stash + (ci & 1u) * kStashWords;
+      *reinterpret_cast<uint4*>(sl + lane * 4) = r.a;
+      *reinterpret_cast<uint4*>(sl + kPieceB / 4 + lane * 4) = r.b;
+    }
+  };
+  // ... and behind them the first 8 bytes of the block that follows (lane 0's x, y)
+  auto spill_put = [&](uint32_t ci, uint32_t x, uint32_t y) __attribute__((always_inline)) {
+    if constexpr (S::kCapture) {
+      if (lane == 0) *reinterpret_cast<uint2*>(w.stash + (ci & 1u) * kStashWords + kBlock / 4) = make_uint2(x, y);
+    }
+  };
   if (c < fast_end) {
     load_block(blk(c), lane_rel, ra);
     load_block(blk(c + 1), lane_rel, rb);
@@ -728,6 +777,8 @@ __global__ __launch_bounds__(256) void plane_count(typename S::Args g) {
   __syncthreads();
   if (c < fast_end) {
     uint32_t xa = codes16(ra.a, k), xb = codes16(ra.b, k);   // block c
+    stash_put(c, ra);
+    if (S::kCapture) __builtin_amdgcn_sched_barrier(0);   // (the stash is written before the buffer is loaded again)
     load_block(blk(c + 2), lane_rel, ra);
     const uint32_t behind_codes = (codes4(behind.x, k) >> k.shift) | (codes4(behind.y, k) << (8 - k.shift));
     // two blocks per iteration: x = the codes of block c, rb = block c + 1, ra = block c + 2 (in flight)
@@ -736,25 +787,35 @@ __global__ __launch_bounds__(256) void plane_count(typename S::Args g) {
       // (the codes must exist BEFORE the buffer is loaded again: when the compiler sinks their computation towards its
       // use, the reload lands in other registers and is copied back at the loop's end -- behind a wait for it)
       asm volatile("" ::"v"(ya), "v"(yb));
+      stash_put(c + 1, rb);
+      spill_put(c, rb.a.x, rb.a.y);
+      if (S::kCapture) __builtin_amdgcn_sched_barrier(0);
       if (c + 3 <= last_own) load_block(blk(c + 3), lane_rel, rb);
       {
         // (behind lane 63's piece A: lane 0's piece B; behind its piece B: lane 0's piece A of the next block)
         const uint32_t ha = from_lane_above(xa, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xb))));
         const uint32_t hb = from_lane_above(xb, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ya))));
         const uint32_t hm = S::test(xa, xb, ha, hb, g);
-        push_block<S::kList>(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
+        push_block<S::kList, S::kCapture>(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel, (c - c0) * static_cast<uint32_t>(kBlock), c & 1u);
       }
       __builtin_amdgcn_sched_barrier(0);
-      xa = codes16(ra.a, k);   // block c + 2 (the span's last fast block again when c + 2 == fast_end: not used then)
+      xa = codes16(ra.a, k);   // block c + 2 (stale bytes when c + 2 == fast_end: not used then)
       xb = codes16(ra.b, k);
       asm volatile("" ::"v"(xa), "v"(xb));
+      if (c + 2 < fast_end) {
+        stash_put(c + 2, ra);
+        spill_put(c + 1, ra.a.x, ra.a.y);
+      } else {
+        spill_put(c + 1, behind.x, behind.y);
+      }
+      if (S::kCapture) __builtin_amdgcn_sched_barrier(0);
       if (c + 4 <= last_own) load_block(blk(c + 4), lane_rel, ra);
       {
         const uint32_t next0 = c + 2 == fast_end ? behind_codes : static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xa)));
         const uint32_t ha = from_lane_above(ya, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(yb))));
         const uint32_t hb = from_lane_above(yb, next0);
         const uint32_t hm = S::test(ya, yb, ha, hb, g);
-        push_block<S::kList>(w, hm, (c + 1 - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
+        push_block<S::kList, S::kCapture>(w, hm, (c + 1 - c0) * static_cast<uint32_t>(kBlock) + lane_rel, (c + 1 - c0) * static_cast<uint32_t>(kBlock), (c + 1) & 1u);
       }
       __builtin_amdgcn_sched_barrier(0);
       c += 2;
@@ -764,7 +825,8 @@ __global__ __launch_bounds__(256) void plane_count(typename S::Args g) {
       const uint32_t ha = from_lane_above(xa, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xb))));
       const uint32_t hb = from_lane_above(xb, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(behind_codes))));
       const uint32_t hm = S::test(xa, xb, ha, hb, g);
-      push_block<S::kList>(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
+      spill_put(c, behind.x, behind.y);
+      push_block<S::kList, S::kCapture>(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel, (c - c0) * static_cast<uint32_t>(kBlock), c & 1u);
       c++;
     }
     if (!S::kList) blocks_done<S>(w, tab, g, span_base, first_batch);
@@ -787,7 +849,15 @@ __global__ __launch_bounds__(256) void plane_count(typename S::Args g) {
     const uint32_t hb = (codes4(h0, k) >> k.shift) | (codes4(h1, k) << (8 - k.shift));
     const uint32_t hm = S::test(codes16(va, k), codes16(vb, k), ha, hb, g);
     if (!S::kList && w.tail - w.head > kRing - 64u) blocks_done<S>(w, tab, g, span_base, first_batch);   // (room for this block)
-    push_block<S::kList>(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel);
+    if constexpr (S::kCapture) {
+      Raw gr;
+      gr.a = va;
+      gr.b = vb;
+      stash_put(c, gr);
+      const uint64_t nb = (static_cast<uint64_t>(c) + 1) * kBlock;
+      spill_put(c, guarded_dword(a.text, a.n, nb), guarded_dword(a.text, a.n, nb + 4));
+    }
+    push_block<S::kList, S::kCapture>(w, hm, (c - c0) * static_cast<uint32_t>(kBlock) + lane_rel, (c - c0) * static_cast<uint32_t>(kBlock), c & 1u);
   }
   if constexpr (S::kList) {
     if (lane == 0) g.hit_counts[wave] = w.tail;   // (also beyond the region's capacity: the classification reports the overflow)
@@ -987,8 +1057,9 @@ void launch_bounds_rows_counts(const BoundsParams& a, const unsigned long long* 
 }
 
 void launch_plane_count(const PlaneCountParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
-  if (a.n_bases <= 1) hipExtLaunchKernelGGL((plane_count<ExactShape<1>>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
-  else hipExtLaunchKernelGGL((plane_count<ExactShape<2>>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+  static const size_t pad = getenv("RJ_COUNT_LDS_PAD") ? static_cast<size_t>(atoi(getenv("RJ_COUNT_LDS_PAD"))) : 0;   // measurement: fewer workgroups per CU
+  if (a.n_bases <= 1) hipExtLaunchKernelGGL((plane_count<ExactShape<1>>), dim3(grid), dim3(256), pad, st, t0, t1, 0, a);
+  else hipExtLaunchKernelGGL((plane_count<ExactShape<2>>), dim3(grid), dim3(256), pad, st, t0, t1, 0, a);
 }
 
 void launch_plane_list(const PlaneListParams& a, int grid, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
