@@ -271,7 +271,8 @@ _CEILING = {}
 
 def hbm_ceiling(ptr, n, stream):
     """The achievable ceiling of a read-only stream over THIS text on THIS device in THIS run: a kernel that
-    only reads -- 16 bytes per lane and load, XOR-reduced (tools/probes/read_probe.hip: librejit_bench.so, not the product library) --, GB/s, memoised per size."""
+    only reads -- 16 bytes per lane and load, non-temporal policy (csrc/stream_load.h: what the scans use), XOR-reduced
+    (tools/probes/read_probe.hip: librejit_bench.so, not the product library) --, GB/s, memoised per size."""
     import rejit_amd
     if n not in _CEILING:
         try:
@@ -573,8 +574,14 @@ def run_regexdna(args, c):
         out["roofline"]["note"] = ("n / t of the one launch that scans the text for all nine patterns; `value` counts the text once per pattern "
                                    "(9 x n per step, the reference's convention: nine MatchAllCount calls); `physical_GBps` is n / t of the step")
         if ceiling:
-            out["hbm_ceiling"] = {"what": "a kernel that only reads the same %d bytes (16 B per lane and load, XOR-reduced; tools/probes/read_probe.hip), this device, this run" % n_local,
+            out["hbm_ceiling"] = {"what": "a kernel that only reads the same %d bytes (16 B per lane and load, NON-TEMPORAL loads as the scans use since round 6, XOR-reduced; tools/probes/read_probe.hip), this device, this run" % n_local,
                                   "GB_per_s": round(ceiling, 1), "frac_of_spec_peak": round(ceiling / HBM_PEAK_GBS, 4)}
+            try:
+                # what rounds 1-5 quoted as the ceiling: the same kernel with default-policy loads
+                dms = rejit_amd.stream_read_probe(text_ptr, n_local, 10, stream, default_policy=True)
+                out["hbm_ceiling"]["default_policy_GB_per_s"] = round(n_local / (dms * 1e-3) / 1e9, 1)
+            except Exception:
+                pass
         if not args.time_all_launches:
             out["roofline"]["timing"] = ("HIP events of one scan launch in %d of the timed region (the first of the rj_multi objects used in turn): the start event "
                                          "costs ~6.5 us between two kernels of a stream; `step_variants_ms.every_launch_timed` is the loop with it on all"
