@@ -1028,10 +1028,13 @@ int run_counts(rj_multi* m, const uint8_t* d_text, uint64_t n, uint64_t sb, uint
     const uint64_t first_block = wlo / 2048;
     const uint64_t end_block = whi > wlo ? (whi + 2047) / 2048 : first_block;
     const uint64_t blocks = end_block - first_block;
-    // (500 MB: 2048 .. 3584 workgroups measured equal, 0.094 ms; 5086 -- plane_scan's 96 KiB per workgroup -- 0.0985, 8192
-    // 0.101: a wave's fixed costs, the pipeline's first trip and the classification of its candidates, want long spans)
-    static const int count_chunks = getenv("RJ_COUNT_CHUNKS") ? atoi(getenv("RJ_COUNT_CHUNKS")) : 160;  // measurement override
-    const ScanGeometry geo = scan_geometry(std::max<uint64_t>(blocks * 2, 1), static_cast<uint64_t>(count_chunks > 0 ? count_chunks : 160));
+    // (500 MB, rounds 5-6 before the stash: 2048 .. 3584 workgroups measured equal, 0.094 ms; 5086 0.0985, 8192 0.101: a wave's
+    // fixed costs want long spans.  With the stash four workgroups of ExactShape are resident per CU (35 KB of LDS each) and the
+    // grid matters: KiB per workgroup 64 / 96 / 112 / 120 / 128 / 136 / 144 / 160 / 240 / 320 / 440 / 480 / 520 -> the kernel inside
+    // the two-in-flight loop 0.0915 / 0.0869 / 0.0879 / 0.0895 / 0.0851 / 0.0860 / 0.0867 / 0.0870 / 0.0875 / 0.0906 / 0.1064 / 0.0860 /
+    // 0.0915 ms -- 440 is 1109 workgroups, a second round of 85 behind the 1024 resident ones; 128 is the generic scans' share too)
+    static const int count_chunks = getenv("RJ_COUNT_CHUNKS") ? atoi(getenv("RJ_COUNT_CHUNKS")) : 128;  // measurement override
+    const ScanGeometry geo = scan_geometry(std::max<uint64_t>(blocks * 2, 1), static_cast<uint64_t>(count_chunks > 0 ? count_chunks : 128));
     if (!m->counts_ready) {
       if (!m->count_out) RJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&m->count_out), sizeof(unsigned long long) * kPcHostWords));
       if (m->exact.ok) {
