@@ -624,6 +624,43 @@ def test_planted_literal_large(rj):
     assert st["n_matches"] == count and st["scan_ms"] > 0
 
 
+@pytest.mark.parametrize("needle", [b"qz", b"qzv", b"qzvwx", b"regexpqz"])
+def test_literal_across_every_lane_and_chunk_edge(rj, needle):
+    """The streaming loop of scan_windows takes the bytes behind a lane's 16 from the lane above and, for lane 63, from the
+    NEXT chunk's buffer (round 6: no halo load).  A needle planted at every offset around 16-byte lane edges, 1-KiB chunk
+    edges and the edges of the waves' spans of a 64 MiB device text (steady loop, the loop's last three chunks, the plain
+    loop, the guarded tail): exactly the planted occurrences come back (checked with a torch sliding compare)."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = (64 << 20) + 777
+    g = torch.Generator(device="cpu").manual_seed(len(needle))
+    d = torch.randint(ord("a"), ord("p"), (n,), dtype=torch.uint8, generator=g).to(dev)   # (no q, z, r ... in the filler)
+    L = len(needle)
+    offs = []
+    for base in list(range(1 << 20, n - (2 << 20), (5 << 20) + 1024 * 37)) + [0, n - 4096]:
+        k = base // 1024 * 1024
+        for edge in (k + 1024, k + 2048 + 16 * 17, k + 5 * 1024 + 16 * 63, k + 9 * 1024):
+            offs.append(edge - L - 1 + (len(offs) % (L + 3)))     # ends before, on and behind the edge in turn
+    offs += [n - L, n - L - 1024, 16 - L // 2]
+    offs = sorted(set(o for o in offs if 0 <= o <= n - L))
+    kept, last = [], -100
+    for o in offs:                                              # (apart: no planted needle overwrites another)
+        if o >= last + L + 1:
+            kept.append(o)
+            last = o
+    nd = torch.tensor(list(needle), dtype=torch.uint8, device=dev)
+    for o in kept:
+        d[o:o + L] = nd
+    scan = rj.Scan(rj.Program(needle.decode()))
+    count = scan.run_tensor(d)
+    hit = torch.ones(n - L + 1, dtype=torch.bool, device=dev)
+    for j in range(L):
+        hit &= d[j:n - L + 1 + j] == nd[j]
+    truth = torch.nonzero(hit).flatten().cpu().tolist()
+    assert truth == kept
+    assert count == len(truth) and [b_ for b_, _ in scan.spans()] == truth
+
+
 def _splice(text: bytes, spans, repl: bytes) -> bytes:
     out, p = bytearray(), 0
     for b_, e_ in spans:
