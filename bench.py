@@ -32,7 +32,9 @@ sample/regexdna.cc:65), and for counts plane_count scans, classifies its candida
   roofline      -- the dominant kernel (plane_count<ExactShape<2>>): the text's bytes (1 byte read per text byte and pass,
                    SURVEY.md section 8d) / the launch's average duration from HIP events on the run's stream,
                    traffic = FETCH_SIZE x 2 per launch from profiles/pmc_traffic.json; read_only_ceiling /
-                   frac_of_ceiling: against a kernel that only reads the same bytes, measured in this run (`hbm_ceiling`)
+                   frac_of_ceiling: against a kernel that only reads the same bytes, measured in this run (`hbm_ceiling`;
+                   since round 6 with non-temporal loads, as the scans load: 6.9 TB/s; `default_policy_GB_per_s` beside it
+                   is what rounds 1-5 quoted, 6.0-6.3)
   roofline_valu -- the same launch against the VALU peak (SQ_INSTS_VALU per byte from profiles/)
   cpu_baseline  -- the REAL reference (oracle/_ref, built from /root/reference) on the host: one core (>= 0.5 s of
                    work) and all cores over disjoint slices, on a bounded sample of the same text
