@@ -376,7 +376,7 @@ def run_regexdna(args, c):
     # step k + 1 are already queued, so the device never waits for the host's turn-around (~25 us of a 170 us step).
     # Every step still is one complete pass of the path over the batch with its own result; the synchronous call is
     # reported as `call_latency`.
-    def two_in_flight(own_streams, tail_streams=False, time_all=True, counts_only=False):
+    def two_in_flight(own_streams, tail_streams=False, time_all=True, counts_only=False, time_first=True):
         """(step, drain, scan times) of a loop that keeps two steps in flight on two rj_multi objects.  own_streams:
         each object on its own stream, the scan kernels ordered one behind the other (rj_multi_order_after), so that the
         tails of step k run under the scan of step k + 1.  tail_streams: both objects on ONE stream, but each queues its
@@ -386,7 +386,7 @@ def run_regexdna(args, c):
         multis = [rejit_amd.MultiScan(progs) for _ in range(depth)]
         # time_all False: only the first object's scan launches carry the start event scan_ms() needs (every second launch of
         # the loop): that event costs ~6.5 us between two kernels of a stream, the end event nothing
-        timed = [True] + [time_all] * (depth - 1)
+        timed = [time_first] + [time_all] * (depth - 1)
         for mm, tt in zip(multis, timed):
             mm.set_mode(0)
             mm.set_timing(tt)
@@ -703,6 +703,11 @@ def run_regexdna(args, c):
                 ea, ca = timed(c, args, a_step, a_drain)
                 assert ca == counts, (ca, counts)
                 out["step_variants_ms"]["every_launch_timed"] = round(ea / args.steps * 1e3, 4)
+                # ... and with it on NO launch: the step of a caller who does not time kernels (nothing to quote a roofline from)
+                u_step, u_drain, _ = two_in_flight(False, time_all=False, counts_only=True, time_first=False)
+                eu, cu = timed(c, args, u_step, u_drain)
+                assert cu == counts, (cu, counts)
+                out["step_variants_ms"]["no_launch_timed"] = round(eu / args.steps * 1e3, 4)
         if world == 1 and not counts_headline:
             # the same loop with a stream per object: the tails of step k (classify + gather, latency-bound) run under the
             # scan of step k + 1 -- more steps per second, but the scan kernel shares the device with them and takes

@@ -41,6 +41,10 @@ constexpr uint64_t kTile = kIter * kTileIters;      // 32 KiB: a wave's tile (fo
 constexpr uint32_t kStage = 640;                    // staged pairs per wave and stage (two stages: 20 KiB per workgroup)
 constexpr uint32_t kLenBits = 17;                   // staged entry: begin - tile start (15 bits) << 17 | length (engine.hip caps max_walk below 2^17)
 constexpr int kTilesPerTicket = 4;
+#ifndef RJ_DS_AHEAD
+#define RJ_DS_AHEAD 1
+#endif
+constexpr int kAhead = RJ_DS_AHEAD;                 // iterations of text in flight per wave (2: two buffers, each reloaded behind its class streams)
 
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & (kWave - 1); }
 
@@ -139,6 +143,10 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Str
   if (inner) {
     bufa0 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it0) * static_cast<int64_t>(kIter));
     bufa1 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it0) * static_cast<int64_t>(kIter) + 16);
+    if (kAhead == 2) {
+      bufb0 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it0 + 1) * static_cast<int64_t>(kIter));
+      bufb1 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it0 + 1) * static_cast<int64_t>(kIter) + 16);
+    }
   }
   uint32_t count = 0;
   // one iteration (2 KiB of the tile); false: the tile ends here
@@ -148,7 +156,7 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Str
     if (inner) {
       x[0] = n0.x; x[1] = n0.y; x[2] = n0.z; x[3] = n0.w;
       x[4] = n1.x; x[5] = n1.y; x[6] = n1.z; x[7] = n1.w;
-      if (SELECT && it + 1 < kTileIters) {  // the next iteration's bytes, in flight while this one is evaluated
+      if (SELECT && kAhead == 1 && it + 1 < kTileIters) {  // the next iteration's bytes, in flight while this one is evaluated
         next0 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it + 1) * static_cast<int64_t>(kIter));
         next1 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it + 1) * static_cast<int64_t>(kIter) + 16);
       }
@@ -164,11 +172,11 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Str
     }
     uint32_t S[NP], Sb[NP];
     rj_stream_classes<NP, NR, HIGH>(pl, rm, x, valid, S);
-    if (!SELECT && inner && it + 1 < kTileIters) {  // (next0 / next1 ARE n0 / n1 here: the streams are pinned, then the reload)
+    if ((!SELECT || kAhead == 2) && inner && it + kAhead < kTileIters) {  // (next0 / next1 ARE n0 / n1 here: the streams are pinned, then the reload)
 #pragma unroll
       for (int k = 0; k < NP; k++) asm volatile("" : "+v"(S[k]));
-      next0 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it + 1) * static_cast<int64_t>(kIter));
-      next1 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it + 1) * static_cast<int64_t>(kIter) + 16);
+      next0 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it + kAhead) * static_cast<int64_t>(kIter));
+      next1 = *reinterpret_cast<const uint4*>(lane_text + static_cast<int64_t>(it + kAhead) * static_cast<int64_t>(kIter) + 16);
     }
 #pragma unroll
     for (int k = 0; k < NP; k++) {
@@ -273,7 +281,13 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Str
     count += wave_last_lane(inc);
     return true;
   };
-  if (SELECT) {
+  if (kAhead == 2) {
+#pragma unroll 1
+    for (int it = it0; it < kTileIters; it += 2) {
+      if (!iteration(it, bufa0, bufa1, bufa0, bufa1)) break;
+      if (it + 1 >= kTileIters || !iteration(it + 1, bufb0, bufb1, bufb0, bufb1)) break;
+    }
+  } else if (SELECT) {
 #pragma unroll 1
     for (int it = it0; it < kTileIters; it += 2) {
       if (!iteration(it, bufa0, bufa1, bufb0, bufb1)) break;
@@ -296,8 +310,13 @@ __device__ __forceinline__ uint32_t stream_tile(const StreamParams& a, const Str
 // look-back set the pace (`[@#]`, one step, took as long as `[a-f]+[0-9]`); a granule per workgroup: 1.62 ms per 5 GB;
 // two-level look-back: 1.53; with no look-back at all (wrong output) 1.17 -- the rest was waiting for the slowest of the
 // ~1800 units in flight, which this form no longer does.
+#ifdef RJ_DS_WAVES
+#define RJ_DS_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RJ_DS_WAVES, RJ_DS_WAVES)))
+#else
+#define RJ_DS_WAVES_ATTR
+#endif
 template <int NP, int NR, bool HIGH, bool SELECT, bool RUN = false>
-__global__ __launch_bounds__(256) void dense_streams(StreamParams a) {
+__global__ __launch_bounds__(256) RJ_DS_WAVES_ATTR void dense_streams(StreamParams a) {
   __shared__ unsigned long long s_ticket, s_before;
   __shared__ uint32_t s_count[2][kTilesPerTicket], s_bad;
   __shared__ uint32_t s_stage[2][kTilesPerTicket][kStage];

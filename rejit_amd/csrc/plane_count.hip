@@ -55,7 +55,10 @@ constexpr uint32_t kPieceB = 1024;    // a lane's piece B begins this far behind
 // Capture (ExactShape): a wave keeps the raw bytes of the last two blocks in LDS -- a block's 2 KiB in text order and, behind
 // them, the first 8 bytes of the block that follows -- and a candidate takes its 8 bytes from there when it enters the ring.
 constexpr uint32_t kStashWords = (2048 + 16) / 4;
-constexpr uint32_t kRing = 256;       // candidate slots per wave; consumed 64 at a time, looked at every second block
+#ifndef RJ_PC_RING
+#define RJ_PC_RING 256
+#endif
+constexpr uint32_t kRing = RJ_PC_RING;       // candidate slots per wave; consumed 64 at a time, looked at every second block
 
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & (kWave - 1); }
 
