@@ -72,7 +72,8 @@ typedef struct {
   int32_t slow_starts;    /* that kernel: starts that outlived its register steps and took the scalar walk (saturating) */
   int32_t count_path;     /* 1 when the one-kernel count (plane_count.hip) answered: a count and bounds, no span list (round 6) */
   int32_t run_path;       /* 1 when the run kernels (run_scan.hip: one long-lived thread in one loop position -- `[acgt]+`, `a.*b`)
-                           * produced the result: two passes over the text, linear whatever the runs' length (round 6) */
+                           * produced the result: two passes over the text, linear whatever the runs' length (round 6); 2: the pair
+                           * kernels of the same file (`"[^"]*"`: the same class at both ends, none of it inside the loop) */
 } rj_stats;
 
 /* ---- compile (replaces Regej::Regej + Regej::Compile, src/rejit.cc:127-137,229-267) */

@@ -615,6 +615,60 @@ static int run_runs(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, 
   return 1;
 }
 
+// The PAIR shape (run_scan.h: `"[^"]*"`, `'[^'\n]*'`): the same three steps with the pair kernels -- whole texts without a
+// carried-in state only (what crosses a cut is the parity of the Q bytes since the last reset, which a shard does not know).
+// 1 = done, 0 = not this path, < 0 = error.
+static int run_pairs(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uint64_t se, hipStream_t st) {
+  const rj_program* rp = s->prog;
+  if (!rp->run.pair || sb != 0 || se < n || n == 0) return 0;
+  RunParams a{};
+  a.text = d_text;
+  a.n = n;
+  a.sb = 0;
+  a.se = n;
+  a.plan = rp->run;
+  a.tile_bytes = run_tile_bytes(n);
+  a.n_tiles = run_tiles(0, n, a.tile_bytes, &a.first_tile);
+  RJ_HIP(s->run_summaries.reserve(sizeof(RunSummary) * run_resolve_slots(a.n_tiles)));
+  RJ_HIP(s->run_tile_in.reserve(sizeof(RunTileIn) * run_resolve_slots(a.n_tiles)));
+  a.summaries = s->run_summaries.as<RunSummary>();
+  a.tile_in = s->run_tile_in.as<RunTileIn>();
+  a.counters = s->counters.as<unsigned long long>();
+  a.host_counters = s->host_counters;
+  a.out = s->out.as<uint64_t>();
+  a.out_cap = s->out_cap;
+  RJ_HIP(hipMemsetAsync(s->counters.p, 0, kCntSize * sizeof(unsigned long long), st));
+  s->host_counters[kCntFinal] = 0;
+  launch_pair_summary(a, s->t0(), nullptr, st);
+  launch_pair_resolve(a, st);
+  RJ_HIP(hipStreamSynchronize(st));   // (the number of pairs sizes the output)
+  RJ_HIP(hipGetLastError());
+  const uint64_t cnt = s->host_counters[kCntFinal];
+  if (!s->count_only_run) {
+    if (cnt > s->out_cap) {
+      const uint64_t cap = cnt + cnt / 16 + 1024;
+      RJ_HIP(s->out.reserve(cap * 2 * sizeof(uint64_t)));
+      s->out_cap = cap;
+    }
+    a.out = s->out.as<uint64_t>();
+    a.out_cap = s->out_cap;
+    if (cnt) launch_pair_emit(a, s->ev[2], st);
+    else RJ_HIP(hipEventRecord(s->ev[2], st));
+    RJ_HIP(hipStreamSynchronize(st));
+    RJ_HIP(hipGetLastError());
+    float ms = 0.f;
+    if (s->timing) (void)hipEventElapsedTime(&ms, s->ev[1], s->ev[2]);
+    s->stats.scan_ms += ms;
+  }
+  s->result_count = cnt;
+  s->result = s->count_only_run ? nullptr : s->out.as<uint64_t>();
+  s->hits_hint = cnt;
+  s->stats.n_hits += cnt;
+  s->stats.n_candidates += cnt;
+  s->stats.run_path = 2;
+  return 1;
+}
+
 constexpr uint64_t kExactLimit = 1u << 20;  // bytes the one-lane exact kernel is allowed to walk
 constexpr uint64_t kDenseSegment = 1ull << 27;  // dense mode: starts per pipeline run (bounds the lists)
 
@@ -650,6 +704,11 @@ static int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb,
   // (a pattern with a fast-forward window -- `a.*b`, `<[^>]*>`: the window is their first byte -- goes there only once a walk
   // has outlived max_walk on this scan's text: linear_hint.  NOTE: the hint is cleared by nobody on this path; a scan object
   // whose texts stop having long runs keeps the run kernels, which are never wrong and never quadratic.)
+  static const bool no_pairs = getenv("RJ_NO_PAIRS") != nullptr;   // measurement override
+  if (rp->run.pair && fresh && !no_pairs) {   // (`"[^"]*"`: every Q byte is a window hit and a walk; the pair kernels are two streaming passes)
+    int rc = run_pairs(s, d_text, n, sb, se, st);
+    if (rc != 0) return rc < 0 ? rc : RJ_OK;
+  }
   if (rp->run.ok && (runs_first || s->linear_hint || (!windows && (!fresh || rp->stream.n_pos == 0 || s->streams_off)))) {
     int rc = run_runs(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
     if (rc != 0) return rc < 0 ? rc : RJ_OK;

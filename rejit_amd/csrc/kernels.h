@@ -300,6 +300,10 @@ uint64_t run_resolve_slots(uint64_t n_tiles);   // elements of `summaries` and o
 void launch_run_summary(const RunParams& a, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 void launch_run_resolve(const RunParams& a, hipStream_t st);
 void launch_run_emit(const RunParams& a, hipEvent_t t1, hipStream_t st);
+// the PAIR shape (`"[^"]*"`: run_scan.h), the same three steps over the same buffers
+void launch_pair_summary(const RunParams& a, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
+void launch_pair_resolve(const RunParams& a, hipStream_t st);
+void launch_pair_emit(const RunParams& a, hipEvent_t t1, hipStream_t st);
 
 struct ScanGeometry {
   int grid;

@@ -42,6 +42,7 @@ struct RunPlan {
   uint32_t high_half;           // bit r: the range lies in 0x80..0xff
   uint32_t a_ranges, l_ranges, b_ranges;   // bit r: the class (or its complement) holds range r
   uint32_t a_neg, l_neg, b_neg;            // 1: the class is the complement of its ranges
+  uint32_t pair;                // the PAIR shape (`"[^"]*"`; below): ok stays 0, the pair kernels of run_scan.hip take the pattern
 };
 
 }  // namespace rejit_amd
@@ -129,13 +130,29 @@ inline RunPlan make_run_plan(const Program& P) {
   } else {
     return pl;
   }
-  bool A[256], L[256], B[256];
+  bool A[256], L[256], B[256], clash = false;
   for (int c = 0; c < 256; c++) {
     const uint32_t cls = P.cls[static_cast<size_t>(c)];
     A[c] = ((cls >> a) & 1u) != 0;
     L[c] = ((cls >> l) & 1u) != 0;
     B[c] = b >= 0 && ((cls >> b) & 1u) != 0;
-    if (A[c] && B[c] && !L[c]) return pl;   // (the B of one match could be the A of the next: the general paths)
+    if (A[c] && B[c] && !L[c]) clash = true;   // (the B of one match could be the A of the next)
+  }
+  if (clash) {
+    // The PAIR shape: `Q L* Q` with the same class Q at both ends and no byte of Q inside L -- `"[^"]*"`, `'[^'\n]*'`, `%[a-z]*%`.
+    // Every Q byte is a break, and whether it OPENS a match depends on the match before it: a Q closes the match its predecessor
+    // opened, the next Q opens again; a break that is no Q (a RESET: `\n` for `"[^"\n]*"`, the text's end) drops an open Q.  So
+    // the matches are the pairs (1st, 2nd), (3rd, 4th) ... of the Q bytes since the last reset: a parity per segment, carried
+    // from tile to tile as a function on one bit (run_scan.hip: pair_summary / pair_resolve / pair_emit).
+    if (b < 0 || a == l) return pl;
+    for (int c = 0; c < 256; c++)
+      if (A[c] != B[c] || (A[c] && L[c])) return pl;
+    if (!run_detail::add_class(&pl, A, &pl.a_ranges, &pl.a_neg) || !run_detail::add_class(&pl, L, &pl.l_ranges, &pl.l_neg)) return RunPlan{};
+    pl.b_ranges = pl.a_ranges;
+    pl.b_neg = pl.a_neg;
+    pl.has_b = 1;
+    pl.pair = 1;
+    return pl;   // (ok == 0: the run kernels' segment rule does not hold)
   }
   if (!run_detail::add_class(&pl, A, &pl.a_ranges, &pl.a_neg) || !run_detail::add_class(&pl, L, &pl.l_ranges, &pl.l_neg)) return RunPlan{};
   if (b >= 0 && !run_detail::add_class(&pl, B, &pl.b_ranges, &pl.b_neg)) return RunPlan{};

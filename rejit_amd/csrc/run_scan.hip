@@ -598,6 +598,369 @@ __global__ __launch_bounds__(256) void run_emit(RunParams a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The PAIR shape (run_scan.h: `Q L* Q`, the same class at both ends, no Q inside L -- `"[^"]*"`, `'[^'\n]*'`): the matches are
+// the pairs (1st, 2nd), (3rd, 4th) ... of the Q bytes since the last RESET (a break that is no Q; the text's end).  Reference:
+// the thread a Q opens lives until the next break (src/x64/codegen-x64.cc:535-581); when that break is a Q the match ends behind
+// it (:426-461) and the scan restarts behind the match (:487-503) -- so that Q opens nothing --, when it is not the thread dies.
+//   pair_summary  a wave per tile: the Q stream and the reset stream; the tile as a FUNCTION on one bit (is a Q open when the
+//                 tile begins?): the matches it closes, whether a Q is open behind it and where that Q sits.  Everything
+//                 behind the tile's first reset does not depend on the bit; before it, c + k1 Q bytes make (c + k1) / 2 pairs.
+//   pair_resolve  the functions composed (associative): every tile's incoming bit, open position and first output pair.
+//   pair_emit     the tiles that close a match once more, the incoming state known: a Q is a CLOSER when an odd number of Q
+//                 bytes lies between the last reset (or the tile's begin, the incoming bit counted) and itself -- a prefix
+//                 parity inside the lane's word, the lane's own incoming parity from two ballots --; its opener is the Q before it.
+// Whole texts only (own ranges and carried-in states keep the other paths).
+namespace {
+
+struct PairElem {               // 64 bytes: the slot of a RunSummary
+  unsigned long long m[2];      // matches closed, by the incoming bit
+  unsigned long long pos[2];    // where the open Q sits behind the element (kind bit set)
+  uint32_t oo;                  // bit c: a Q is open behind the element
+  uint32_t kind;                // bit c: 1 = that Q lies inside the element (pos[c]), 0 = it is the one that came in
+  unsigned long long pad[3];
+};
+static_assert(sizeof(PairElem) == sizeof(RunSummary), "the pair kernels use the run kernels' buffers");
+
+__device__ __forceinline__ PairElem pair_compose(const PairElem& f, const PairElem& g) {   // f, then g
+  PairElem e;
+  e.oo = e.kind = 0;
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    const uint32_t c2 = (f.oo >> c) & 1u;
+    const bool inside = ((g.kind >> c2) & 1u) != 0;
+    e.m[c] = f.m[c] + g.m[c2];
+    e.pos[c] = inside ? g.pos[c2] : f.pos[c];
+    e.oo |= ((g.oo >> c2) & 1u) << c;
+    e.kind |= (inside ? 1u : ((f.kind >> c) & 1u)) << c;
+  }
+  e.pad[0] = e.pad[1] = e.pad[2] = 0;
+  return e;
+}
+
+struct PairState {
+  uint32_t open;
+  unsigned long long at;
+};
+__device__ __forceinline__ PairState pair_apply(const PairElem& g, PairState in, unsigned long long* closes) {
+  *closes = g.m[in.open];
+  PairState o;
+  o.open = (g.oo >> in.open) & 1u;
+  o.at = ((g.kind >> in.open) & 1u) ? g.pos[in.open] : in.at;
+  return o;
+}
+
+// resolve_span for PairElem (see there): T threads over n elements; `whole`: only the span's composite (the reduce step)
+template <int T>
+__device__ __forceinline__ void pair_resolve_span(const PairElem* src, RunTileIn* dst, uint64_t n, PairState initial, unsigned long long off0,
+                                                  PairElem (*chunk)[T], PairElem* whole, unsigned long long* total) {
+  const uint32_t t = threadIdx.x;
+  const uint64_t C = (n + T - 1) / T;
+  const uint64_t lo = static_cast<uint64_t>(t) * C < n ? static_cast<uint64_t>(t) * C : n, hi = lo + C < n ? lo + C : n;
+  PairElem identity;
+  identity.m[0] = identity.m[1] = 0;
+  identity.pos[0] = identity.pos[1] = kNone;
+  identity.oo = 2u;    // (the bit is handed on)
+  identity.kind = 0u;
+  identity.pad[0] = identity.pad[1] = identity.pad[2] = 0;
+  constexpr int kBatch = 4;
+  PairElem e = identity;
+  for (uint64_t i = lo; i < hi; i += kBatch) {
+    PairElem sm[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) sm[k] = src[i + k < hi ? i + k : i];
+#pragma unroll
+    for (int k = 0; k < kBatch; k++)
+      if (i + k < hi) e = (i + k == lo) ? sm[k] : pair_compose(e, sm[k]);
+  }
+  int cur = 0;
+  chunk[0][t] = e;
+  __syncthreads();
+  for (uint32_t d = 1; d < T; d <<= 1) {
+    PairElem v = chunk[cur][t];
+    if (t >= d) v = pair_compose(chunk[cur][t - d], v);
+    chunk[cur ^ 1][t] = v;
+    cur ^= 1;
+    __syncthreads();
+  }
+  if (whole) {
+    if (t == T - 1) *whole = chunk[cur][T - 1];
+    return;
+  }
+  PairState st = initial;
+  unsigned long long off = off0, closes = 0;
+  if (t != 0) {
+    st = pair_apply(chunk[cur][t - 1], initial, &closes);
+    off += closes;
+  }
+  for (uint64_t i = lo; i < hi; i += kBatch) {
+    PairElem sm[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) sm[k] = src[i + k < hi ? i + k : i];
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) {
+      if (i + k >= hi) break;
+      const PairState next = pair_apply(sm[k], st, &closes);
+      RunTileIn ti;
+      ti.s = st.open ? st.at : kNone;
+      ti.q = kNone;
+      ti.off = off;
+      ti.cnt = closes;
+      dst[i + k] = ti;
+      off += closes;
+      st = next;
+    }
+  }
+  if (t == T - 1) *total = off;
+}
+
+// the Q stream and the reset stream of the lane's 32 bytes
+template <int NR>
+__device__ __forceinline__ void pair_streams_of(const RunParams& a, const RunMasks<NR>& mk, uint64_t at, const uint4& v0, const uint4& v1, bool loaded,
+                                                uint32_t* SQ, uint32_t* RS) {
+  uint32_t sa, sb, br;
+  run_streams_of<NR, false>(a, mk, at, v0, v1, loaded, &sa, &sb, &br);
+  *SQ = sa;
+  *RS = br & ~sa;   // (every Q is a break: no Q lies inside L)
+}
+__device__ __forceinline__ uint64_t lanes_below(int lane) { return (1ull << lane) - 1ull; }
+__device__ __forceinline__ uint32_t wave_total(uint32_t x) { return last_lane(wave_prefix_sum(x)); }
+
+}  // namespace
+
+template <int NR>
+__global__ __launch_bounds__(256) void pair_summary(RunParams a) {
+  const int lane = lane_id();
+  const uint64_t tile = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  if (tile >= a.n_tiles) return;
+  const RunMasks<NR> mk = run_masks<NR>(a.plan);
+  const uint64_t base = (a.first_tile + tile) * a.tile_bytes;
+  bool seen = false;                    // a reset has been met
+  unsigned long long cur = 0;           // Q bytes since the last reset (or the tile's begin)
+  unsigned long long k1 = 0, fixed = 0; // Q bytes before the first reset; pairs closed behind it
+  unsigned long long last_q = kNone;
+  const int kIters = static_cast<int>(a.tile_bytes / kIterBytes);
+  uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+  bool loaded = false;
+  auto fetch = [&](int it) {
+    const uint64_t at = base + static_cast<uint64_t>(it) * kIterBytes + static_cast<uint64_t>(lane) * 32;
+    loaded = base + static_cast<uint64_t>(it + 1) * kIterBytes <= a.n;   // (wave-uniform)
+    if (loaded) {
+      v0 = *reinterpret_cast<const uint4*>(a.text + at);
+      v1 = *reinterpret_cast<const uint4*>(a.text + at + 16);
+    }
+  };
+  fetch(0);
+#pragma unroll 1
+  for (int it = 0; it < kIters; it++) {
+    const uint64_t it_base = base + static_cast<uint64_t>(it) * kIterBytes;
+    if (it_base > a.n) break;
+    uint32_t SQ, RS;
+    pair_streams_of<NR>(a, mk, it_base + static_cast<uint64_t>(lane) * 32, v0, v1, loaded, &SQ, &RS);
+    if (it + 1 < kIters) fetch(it + 1);
+    const uint64_t qm = __ballot(SQ != 0), rm = __ballot(RS != 0);
+    if ((qm | rm) == 0) continue;
+    const uint32_t nq = static_cast<uint32_t>(__popc(SQ));
+    if (qm != 0) {
+      const int l = 63 - __builtin_clzll(qm);
+      const uint32_t w = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(SQ), l));
+      last_q = it_base + static_cast<uint32_t>(l) * 32u + 31u - static_cast<uint32_t>(__builtin_clz(w));
+    }
+    if (rm == 0) {
+      cur += wave_total(nq);
+      continue;
+    }
+    // resets: F = the Q bytes of the iteration below its first reset, Lq = below its last one; between the two every
+    // segment (from one reset to the next) closes n / 2 pairs: (Lq - F - the number of odd segments) / 2 in all
+    const uint32_t inc = wave_prefix_sum(nq);
+    const uint32_t T = last_lane(inc);
+    const int j1 = __builtin_ctzll(rm), jl = 63 - __builtin_clzll(rm);
+    const bool hr = RS != 0;
+    const uint32_t fr = hr ? static_cast<uint32_t>(__builtin_ctz(RS)) : 0u, lr = hr ? 31u - static_cast<uint32_t>(__builtin_clz(RS)) : 0u;
+    const uint32_t qb = hr ? static_cast<uint32_t>(__popc(SQ & bits_below(fr))) : 0u;   // before the lane's first reset
+    const uint32_t qa = hr ? static_cast<uint32_t>(__popc(SQ & ~bits_upto(lr))) : nq;   // behind its last one
+    const uint32_t ev = inc - nq + qb, sv = inc - qa;
+    const uint32_t F = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ev), j1));
+    const uint32_t Lq = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(sv), jl));
+    const uint64_t S = __ballot(hr && (sv & 1u) != 0);
+    const uint64_t lower = rm & lanes_below(lane);
+    bool odd = false;
+    if (hr && lower != 0) {   // the segment the lane's first reset closes began behind the last reset of lane i
+      const int i = 63 - __builtin_clzll(lower);
+      odd = ((ev ^ static_cast<uint32_t>(S >> i)) & 1u) != 0;
+    }
+    uint32_t n_odd = static_cast<uint32_t>(__popcll(__ballot(odd)));
+    if (__ballot((RS & (RS - 1u)) != 0) != 0) {   // (some lane holds two resets: the segments inside its word)
+      uint32_t inner = 0;
+      if (hr) {
+        uint32_t prev = fr, rest = RS & (RS - 1u);
+        while (rest != 0) {
+          const uint32_t r = static_cast<uint32_t>(__builtin_ctz(rest));
+          rest &= rest - 1u;
+          inner += static_cast<uint32_t>(__popc(SQ & bits_below(r) & ~bits_upto(prev))) & 1u;
+          prev = r;
+        }
+      }
+      n_odd += wave_total(inner);
+    }
+    const unsigned long long first_n = cur + F;
+    if (!seen) {
+      k1 = first_n;
+      seen = true;
+    } else {
+      fixed += first_n / 2;
+    }
+    fixed += (Lq - F - n_odd) / 2;
+    cur = T - Lq;
+  }
+  PairElem e;
+  e.pad[0] = e.pad[1] = e.pad[2] = 0;
+  e.pos[0] = e.pos[1] = last_q;
+  if (!seen) {   // no reset: the tile's Q bytes pair up from the incoming bit on
+    k1 = cur;
+    e.m[0] = k1 / 2;
+    e.m[1] = (k1 + 1) / 2;
+    e.oo = static_cast<uint32_t>(k1 & 1u) | (static_cast<uint32_t>((k1 + 1) & 1u) << 1);
+    e.kind = k1 != 0 ? 3u : 0u;
+  } else {
+    fixed += cur / 2;
+    e.m[0] = k1 / 2 + fixed;
+    e.m[1] = (k1 + 1) / 2 + fixed;
+    e.oo = (cur & 1u) ? 3u : 0u;
+    e.kind = 3u;
+  }
+  if (lane == 0) reinterpret_cast<PairElem*>(a.summaries)[tile] = e;
+}
+
+__global__ __launch_bounds__(1024) void pair_resolve(RunParams a) {
+  __shared__ PairElem chunk[2][1024];
+  unsigned long long total = 0;
+  pair_resolve_span<1024>(reinterpret_cast<const PairElem*>(a.summaries), a.tile_in, a.n_tiles, PairState{0u, kNone}, 0, chunk, nullptr, &total);
+  if (threadIdx.x == 1023) leave_total(a, total);
+}
+__global__ __launch_bounds__(256) void pair_reduce(RunParams a) {
+  __shared__ PairElem chunk[2][256];
+  const uint64_t b = blockIdx.x, first = b * a.block_tiles;
+  const uint64_t n = a.n_tiles - first < a.block_tiles ? a.n_tiles - first : a.block_tiles;
+  PairElem* all = reinterpret_cast<PairElem*>(a.summaries);
+  pair_resolve_span<256>(all + first, nullptr, n, PairState{0u, kNone}, 0, chunk, all + a.n_tiles + b, nullptr);
+}
+__global__ __launch_bounds__(1024) void pair_resolve_blocks(RunParams a) {
+  __shared__ PairElem chunk[2][1024];
+  const uint64_t n_blocks = (a.n_tiles + a.block_tiles - 1) / a.block_tiles;
+  unsigned long long total = 0;
+  pair_resolve_span<1024>(reinterpret_cast<const PairElem*>(a.summaries) + a.n_tiles, a.tile_in + a.n_tiles, n_blocks, PairState{0u, kNone}, 0, chunk, nullptr, &total);
+  if (threadIdx.x == 1023) leave_total(a, total);
+}
+__global__ __launch_bounds__(256) void pair_apply_blocks(RunParams a) {
+  __shared__ PairElem chunk[2][256];
+  const uint64_t b = blockIdx.x, first = b * a.block_tiles;
+  const uint64_t n = a.n_tiles - first < a.block_tiles ? a.n_tiles - first : a.block_tiles;
+  const RunTileIn in = a.tile_in[a.n_tiles + b];
+  unsigned long long total = 0;
+  pair_resolve_span<256>(reinterpret_cast<const PairElem*>(a.summaries) + first, a.tile_in + first, n, PairState{in.s != kNone ? 1u : 0u, in.s}, in.off, chunk, nullptr, &total);
+}
+
+template <int NR>
+__global__ __launch_bounds__(256) void pair_emit(RunParams a) {
+  const int lane = lane_id();
+  const uint64_t tile = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  if (tile >= a.n_tiles) return;
+  const RunTileIn in = a.tile_in[tile];
+  if (in.cnt == 0) return;
+  const RunMasks<NR> mk = run_masks<NR>(a.plan);
+  const uint64_t base = (a.first_tile + tile) * a.tile_bytes;
+  bool open = in.s != kNone;            // a Q is open; it sits at open_at
+  unsigned long long open_at = in.s;
+  unsigned long long pos = in.off;
+  const int kIters = static_cast<int>(a.tile_bytes / kIterBytes);
+  uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+  bool loaded = false;
+  auto fetch = [&](int it) {
+    const uint64_t at = base + static_cast<uint64_t>(it) * kIterBytes + static_cast<uint64_t>(lane) * 32;
+    loaded = base + static_cast<uint64_t>(it + 1) * kIterBytes <= a.n;
+    if (loaded) {
+      v0 = *reinterpret_cast<const uint4*>(a.text + at);
+      v1 = *reinterpret_cast<const uint4*>(a.text + at + 16);
+    }
+  };
+  fetch(0);
+#pragma unroll 1
+  for (int it = 0; it < kIters; it++) {
+    const uint64_t it_base = base + static_cast<uint64_t>(it) * kIterBytes;
+    if (it_base > a.n) break;
+    uint32_t SQ, RS;
+    pair_streams_of<NR>(a, mk, it_base + static_cast<uint64_t>(lane) * 32, v0, v1, loaded, &SQ, &RS);
+    if (it + 1 < kIters) fetch(it + 1);
+    const uint64_t qm = __ballot(SQ != 0), rm = __ballot(RS != 0);
+    if (qm == 0) {
+      if (rm != 0) open = false;
+      continue;
+    }
+    const uint32_t nq = static_cast<uint32_t>(__popc(SQ));
+    const uint32_t inc = wave_prefix_sum(nq);
+    const uint32_t T = last_lane(inc);
+    // the lane's incoming parity: the Q bytes between the last reset below its word (or the iteration's begin, the carried
+    // bit counted) and its word
+    uint32_t ip = ((inc - nq) ^ (open ? 1u : 0u)) & 1u;
+    uint32_t Lq = 0;
+    if (rm != 0) {
+      const bool hr = RS != 0;
+      const uint32_t lr = hr ? 31u - static_cast<uint32_t>(__builtin_clz(RS)) : 0u;
+      const uint32_t qa = hr ? static_cast<uint32_t>(__popc(SQ & ~bits_upto(lr))) : nq;
+      const uint32_t sv = inc - qa;
+      const uint64_t S = __ballot(hr && (sv & 1u) != 0);
+      const uint64_t lower = rm & lanes_below(lane);
+      if (lower != 0) {
+        const int i = 63 - __builtin_clzll(lower);
+        ip = ((inc - nq) ^ static_cast<uint32_t>(S >> i)) & 1u;
+      }
+      Lq = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(sv), 63 - __builtin_clzll(rm)));
+    }
+    // inside the word: the parity of the Q bytes below every bit; a reset makes what follows it start even
+    uint32_t px = SQ;
+    px ^= px << 1;
+    px ^= px << 2;
+    px ^= px << 4;
+    px ^= px << 8;
+    px ^= px << 16;
+    const uint32_t before = px << 1;
+    uint32_t flip = ip ? ~0u : 0u;
+    for (uint32_t rs = RS; rs != 0; rs &= rs - 1u) {
+      const uint32_t r = static_cast<uint32_t>(__builtin_ctz(rs));
+      if (((before ^ flip) >> r) & 1u) flip ^= ~0u << r;
+    }
+    const uint32_t closers = SQ & (before ^ flip);
+    const uint32_t mine = static_cast<uint32_t>(__popc(closers));
+    // behind the iteration
+    const unsigned long long carried_at = open_at;
+    {
+      const int l = 63 - __builtin_clzll(qm);
+      const uint32_t w = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(SQ), l));
+      open_at = it_base + static_cast<uint32_t>(l) * 32u + 31u - static_cast<uint32_t>(__builtin_clz(w));   // (read only while `open`)
+    }
+    open = rm != 0 ? ((T - Lq) & 1u) != 0 : (open != ((T & 1u) != 0));
+    if (__ballot(mine != 0) == 0) continue;
+    // the opener of a lane's first closer, when it lies below the lane's word: the last Q of the lanes below, else the carried one
+    const uint32_t topq = SQ != 0 ? 31u - static_cast<uint32_t>(__builtin_clz(SQ)) : 0u;
+    const uint64_t lowerq = qm & lanes_below(lane);
+    const int pl = lowerq != 0 ? 63 - __builtin_clzll(lowerq) : 0;
+    const uint32_t tq = static_cast<uint32_t>(__shfl(static_cast<int>(topq), pl));
+    const unsigned long long below_at = lowerq != 0 ? it_base + static_cast<uint32_t>(pl) * 32u + tq : carried_at;
+    const uint64_t word = it_base + static_cast<uint64_t>(lane) * 32u;
+    const uint32_t incm = wave_prefix_sum(mine);
+    unsigned long long idx = pos + incm - mine;
+    for (uint32_t m = closers; m != 0; m &= m - 1u) {
+      const uint32_t b = static_cast<uint32_t>(__builtin_ctz(m));
+      const uint32_t under = SQ & bits_below(b);
+      const unsigned long long begin = under != 0 ? word + 31u - static_cast<uint32_t>(__builtin_clz(under)) : below_at;
+      if (idx < a.out_cap) *reinterpret_cast<ulonglong2*>(a.out + 2 * idx) = make_ulonglong2(begin, word + b + 1u);
+      idx++;
+    }
+    pos += last_lane(incm);
+  }
+}
+
 // Bytes per tile (a wave's share, a multiple of the 2-KiB iteration).  A wave pays one exposed trip to memory for its first
 // iteration whatever its tile: 8 KiB keeps enough waves for texts of a few MiB, longer texts take 32 KiB (RJ_RUN_TILE_KB: measurements).
 uint64_t run_tile_bytes(uint64_t span) {
@@ -669,6 +1032,36 @@ void launch_run_emit(const RunParams& a, hipEvent_t t1, hipStream_t st) {
   else if (nr <= 2) launch_emit_nr<2>(a, grid, t1, st);
   else if (nr <= 4) launch_emit_nr<4>(a, grid, t1, st);
   else launch_emit_nr<8>(a, grid, t1, st);
+}
+
+// ---- the pair shape
+void launch_pair_summary(const RunParams& a, hipEvent_t t0, hipEvent_t t1, hipStream_t st) {
+  const unsigned grid = static_cast<unsigned>((a.n_tiles + 3) / 4);
+  const uint32_t nr = a.plan.n_ranges;
+  if (nr <= 1) hipExtLaunchKernelGGL((pair_summary<1>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+  else if (nr <= 2) hipExtLaunchKernelGGL((pair_summary<2>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+  else if (nr <= 4) hipExtLaunchKernelGGL((pair_summary<4>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+  else hipExtLaunchKernelGGL((pair_summary<8>), dim3(grid), dim3(256), 0, st, t0, t1, 0, a);
+}
+void launch_pair_resolve(const RunParams& a0, hipStream_t st) {
+  RunParams a = a0;
+  a.block_tiles = forced_block_tiles() ? forced_block_tiles() : kBlockTiles;
+  if (a.n_tiles <= kOneLevelTiles && !forced_block_tiles()) {
+    hipLaunchKernelGGL(pair_resolve, dim3(1), dim3(1024), 0, st, a);
+    return;
+  }
+  const unsigned blocks = static_cast<unsigned>((a.n_tiles + a.block_tiles - 1) / a.block_tiles);
+  hipLaunchKernelGGL(pair_reduce, dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(pair_resolve_blocks, dim3(1), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(pair_apply_blocks, dim3(blocks), dim3(256), 0, st, a);
+}
+void launch_pair_emit(const RunParams& a, hipEvent_t t1, hipStream_t st) {
+  const unsigned grid = static_cast<unsigned>((a.n_tiles + 3) / 4);
+  const uint32_t nr = a.plan.n_ranges;
+  if (nr <= 1) hipExtLaunchKernelGGL((pair_emit<1>), dim3(grid), dim3(256), 0, st, nullptr, t1, 0, a);
+  else if (nr <= 2) hipExtLaunchKernelGGL((pair_emit<2>), dim3(grid), dim3(256), 0, st, nullptr, t1, 0, a);
+  else if (nr <= 4) hipExtLaunchKernelGGL((pair_emit<4>), dim3(grid), dim3(256), 0, st, nullptr, t1, 0, a);
+  else hipExtLaunchKernelGGL((pair_emit<8>), dim3(grid), dim3(256), 0, st, nullptr, t1, 0, a);
 }
 
 }  // namespace rejit_amd

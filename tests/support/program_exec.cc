@@ -457,4 +457,46 @@ long pe_run_match_all(const char* re, const uint8_t* text, uint64_t n, uint64_t*
   return static_cast<long>(k);
 }
 
+// The PAIR shape of run_scan.h (`"[^"]*"`: the same class Q at both ends, no Q inside L) on the CPU: the plan's class encoding and the
+// rule the pair kernels implement -- the matches are the pairs (1st, 2nd), (3rd, 4th) ... of the Q bytes since the last RESET (a
+// break that is no Q; the text's end) -- walked byte by byte.  -101: the pattern does not have the shape.
+long pe_pair_match_all(const char* re, const uint8_t* text, uint64_t n, uint64_t* out, uint64_t cap) {
+  LowerResult lr = lower(re);
+  if (lr.status != 0) return lr.status;
+  const RunPlan pl = make_run_plan(*lr.program);
+  if (!pl.pair || pl.ok) return -101;
+  auto in_class = [&](uint8_t c, uint32_t ranges, uint32_t neg) {
+    bool in = false;
+    for (uint32_t r = 0; r < pl.n_ranges; r++) {
+      if (!((ranges >> r) & 1u)) continue;
+      const uint32_t lo = 0x80u - (pl.add_lo[r] & 0xFFu), hi = 0x7fu - (pl.add_hi[r] & 0xFFu);
+      const uint32_t half = (pl.high_half >> r) & 1u;
+      if ((static_cast<uint32_t>(c) >> 7) == half && (c & 0x7fu) >= lo && (c & 0x7fu) <= hi) in = true;
+    }
+    return in != (neg != 0);
+  };
+  uint64_t k = 0;
+  bool open = false;
+  uint64_t at = 0;
+  for (uint64_t p = 0; p < n; p++) {
+    const uint8_t c = text[p];
+    if (in_class(c, pl.a_ranges, pl.a_neg)) {
+      if (open) {
+        if (k < cap) {
+          out[2 * k] = at;
+          out[2 * k + 1] = p + 1;
+        }
+        k++;
+        open = false;
+      } else {
+        open = true;
+        at = p;
+      }
+    } else if (!in_class(c, pl.l_ranges, pl.l_neg)) {
+      open = false;
+    }
+  }
+  return static_cast<long>(k);
+}
+
 }  // extern "C"

@@ -90,3 +90,61 @@ def test_segment_rule_equals_oracle(pe, oracle):
         taken += 1
         assert spans == oracle.match_all(rx, text), (rx, text[:80], spans[:4])
     assert taken > 700
+
+
+def pair_run(pe, rx, text):
+    pe.pe_pair_match_all.restype = ctypes.c_long
+    pe.pe_pair_match_all.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, _u64p, ctypes.c_uint64]
+    cap = len(text) + 2
+    out = (ctypes.c_uint64 * (2 * cap))()
+    k = pe.pe_pair_match_all(rx, text, len(text), out, cap)
+    return k, ([(int(out[2 * i]), int(out[2 * i + 1])) for i in range(k)] if k >= 0 else None)
+
+
+def test_pair_shape_taken_and_refused(pe):
+    """`Q L* Q` with the same class at both ends and no Q inside L (run_scan.h: the PAIR shape) -- and its look-alikes."""
+    for rx in (b"\"[^\"]*\"", b"'[^'\\n]*'", b"%[a-z]*%", b"[\"'][^\"']*[\"']", b"[\\x80][^\\x80]*[\\x80]", b"\\|[^|\\r\\n]*\\|"):
+        k, _ = pair_run(pe, rx, b"")
+        assert k == 0, (rx, k)
+    # different classes at the ends / a Q inside L (the last Q wins: the run kernels' shape) / more positions / plain run shapes
+    for rx in (b"\"[^\"]*'", b"\"[^x]*\"", b"a.*a", b"\"[^\"]*\"\"", b"\"[^\"]+\"", b"[ab][^a]*[ab]", b"<[^>]*>", b"[acgt]+"):
+        k, _ = pair_run(pe, rx, b"")
+        assert k == -101, (rx, k)
+
+
+def test_pair_rule_equals_oracle(pe, oracle):
+    """The pairs of Q bytes since the last reset ARE the reference's left-most-longest matches (oracle: src/x64/codegen-x64.cc:535-640)."""
+    rng = random.Random(11)
+    pool = list(b"abxy01\"'%|\n ") + [0x80, 0xfe]
+
+    def esc(c):
+        return b"\\x%02x" % c if (c >= 0x7f or c < 0x20 or chr(c) in "\\[]^-|%\"'") else bytes([c])
+    taken = 0
+    for case in range(1200):
+        alphabet = rng.sample(pool, rng.randint(2, 7))
+        q = sorted(set(rng.sample(alphabet, rng.randint(1, 2))))
+        rest = [c for c in alphabet if c not in q]
+        qcls = b"[" + b"".join(esc(c) for c in q) + b"]"
+        if rng.random() < 0.5 or not rest:
+            # L = everything but Q and some resets
+            resets = sorted(set(rng.sample(rest, rng.randint(0, min(2, len(rest)))))) if rest else []
+            lcls = b"[^" + b"".join(esc(c) for c in q + resets) + b"]"
+        else:
+            lcls = b"[" + b"".join(esc(c) for c in sorted(set(rng.sample(rest, rng.randint(1, len(rest)))))) + b"]"
+        rx = qcls + lcls + b"*" + qcls
+        n = rng.choice([0, 1, 2, 3, 17, 300, 5000])
+        if rng.random() < 0.5:
+            text = bytes(rng.choices(alphabet, k=n))
+        else:   # long stretches of L with a few other bytes
+            text = bytearray(rng.choices(rest[:2] if rest else alphabet, k=n))
+            for _ in range(rng.choice([0, 1, 2, 5, 40])):
+                if n:
+                    text[rng.randrange(n)] = rng.choice(alphabet)
+            text = bytes(text)
+        k, spans = pair_run(pe, rx, text)
+        if k == -101:   # (the reference parser's bracket quirks make a few of these another pattern: L1, tests/test_lowering.py)
+            continue
+        assert k >= 0, (rx, k)
+        taken += 1
+        assert spans == oracle.match_all(rx, text), (rx, text[:80], spans[:4])
+    assert taken > 700, taken

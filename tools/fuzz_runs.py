@@ -86,8 +86,8 @@ for case in range(cases):
         print("ERROR", rx, e, flush=True)
         bad += 1
         continue
-    took += st["run_path"]
-    refused += 1 - st["run_path"]
+    took += 1 if st["run_path"] else 0
+    refused += 0 if st["run_path"] else 1
     if got != want and "own_begin" in kw and "have_prev" not in kw and not st["run_path"]:
         # (an independent range through a kernel that looks at the byte before the range -- match_small, dense_streams: the
         # whole text's matches that begin in the range; tests/test_gpu_runs.py accepts both)
