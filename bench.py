@@ -1231,6 +1231,59 @@ def literal_and_complex_extras(args, c, out):
     except Exception as e:  # noqa: BLE001  (an extra must not take the line down)
         out.setdefault("exact_replay_long", {})["error"] = repr(e)[:300]
 
+    # Quoted strings: `"[^"]*"` over 1 GiB of JSON-like text (a quote every ~32 bytes) and over 1 GiB holding a few long strings --
+    # the PAIR kernels of run_scan.hip (the matches are the pairs of the quotes since the last reset: a parity per segment carried
+    # from tile to tile).  Before them every quote was a window hit and a walk (41 ms per GiB) and long strings took
+    # the carry scan (130 ms per GiB): profiles/r06_pair_probe.txt.  Checked here by properties (every match begins and ends on a
+    # quote and holds no other; matches == quotes / 2), against the oracle in tests/test_gpu_pairs.py.
+    try:
+        nq = 1 << 30
+        g = torch.Generator(device=dev)
+        g.manual_seed(3)
+        letters = torch.tensor(list((b"\"\"\n" + b"abcdefghijklmnopqrstuvwxyz0123456789 ,:{}[]_-.ABCDEFGHIJKLMNOPQRS")[:64]), device=dev, dtype=torch.uint8)
+        tq = letters[torch.randint(0, 64, (nq,), device=dev, generator=g).long()].contiguous()
+        sq_ = rejit_amd.Scan(rejit_amd.Program("\"[^\"]*\""))
+        sq_.run(tq.data_ptr(), nq, stream=c.stream)
+        qs, qk = [], []
+        for _ in range(5):
+            t0q = time.perf_counter()
+            kq = sq_.run(tq.data_ptr(), nq, stream=c.stream)
+            qs.append(time.perf_counter() - t0q)
+            qk.append(sq_.stats()["scan_ms"])
+        spans_q = sq_.spans_tensor(dev)
+        is_q = tq == ord("\"")
+        csum = torch.cumsum(is_q.to(torch.int32), 0)
+        ok_q = bool(is_q[spans_q[:, 0]].all().item()) and bool(is_q[spans_q[:, 1] - 1].all().item()) and \
+            bool(((csum[spans_q[:, 1] - 1] - csum[spans_q[:, 0]]) == 1).all().item()) and int(kq) == int(is_q.sum().item()) // 2
+        t0q = time.perf_counter()
+        kc = sq_.count(tq.data_ptr(), nq, stream=c.stream)
+        dtc = time.perf_counter() - t0q
+        out["quoted_strings"] = {"workload": "`\"[^\"]*\"` MatchAll over %d bytes of JSON-like text (64 letters, 2 of them quotes, 1 a line break)" % nq,
+                                 "matches": int(kq), "latency_ms": round(sorted(qs)[len(qs) // 2] * 1e3, 4), "latency_ms_min": round(min(qs) * 1e3, 4),
+                                 "value": round(nq / sorted(qs)[len(qs) // 2] / 1e9, 1), "unit": "GB/s of text",
+                                 "kernels_ms": round(sorted(qk)[len(qk) // 2], 4), "run_path": sq_.stats()["run_path"],
+                                 "pairs_are_the_quotes_in_twos": ok_q,
+                                 "count_only": {"call": "rj_scan_count (MatchAllCount): one pass, no list", "matches": int(kc), "latency_ms": round(dtc * 1e3, 4),
+                                                "value": round(nq / dtc / 1e9, 1), "unit": "GB/s of text"},
+                                 "algorithmic_bytes": "2 x the text read (summary + emit) + 16 B written per match = %d" % (2 * nq + 16 * int(kq)),
+                                 "before": "profiles/r06_pair_probe.txt: 41 ms for this text (every quote a window hit and a walk), 130 ms for 1 GiB of long strings (carry scan)"}
+        del spans_q, is_q, csum
+        tl = torch.full((nq,), ord("x"), dtype=torch.uint8, device=dev)
+        tl[torch.randint(0, nq, (nq // 30000,), device=dev, generator=g)] = ord("\"")
+        sq_.run(tl.data_ptr(), nq, stream=c.stream)
+        ls = []
+        for _ in range(5):
+            t0q = time.perf_counter()
+            kl = sq_.run(tl.data_ptr(), nq, stream=c.stream)
+            ls.append(time.perf_counter() - t0q)
+        out["quoted_strings"]["long_strings"] = {"workload": "the same pattern over %d bytes with a quote every ~30 000 bytes" % nq, "matches": int(kl),
+                                                 "latency_ms": round(sorted(ls)[len(ls) // 2] * 1e3, 4), "value": round(nq / sorted(ls)[len(ls) // 2] / 1e9, 1),
+                                                 "unit": "GB/s of text", "run_path": sq_.stats()["run_path"], "linear_path": sq_.stats()["linear_path"]}
+        del tq, tl, sq_
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001
+        out.setdefault("quoted_strings", {})["error"] = repr(e)[:300]
+
     if not args.no_big:
         # the north star's target run: the fast-forward scan over a 50 GB synthetic text on ONE GPU
         nb = args.big_literal_bytes

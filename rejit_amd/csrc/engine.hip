@@ -1072,7 +1072,9 @@ int run_pipeline(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, uin
     // too many candidates, a long walk, or a Q8-sensitive adjacency: the general pipeline
   }
   const bool windows = rp->dev.mode == 1;
-  const bool single_run = windows || dense_walk_fits(rp->dev) || se - sb <= kDenseSegment || (s->linear_hint && linear_path_fits(rp));
+  // (the pair kernels take whole texts only: a dense-mode pair pattern -- `["'][^"']*["']` -- must not be cut into segments)
+  const bool single_run = windows || dense_walk_fits(rp->dev) || se - sb <= kDenseSegment || (s->linear_hint && linear_path_fits(rp)) ||
+                          (rp->run.pair != 0 && whole_text);
   if (single_run) {
     int rc = run_range(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
     if (rc != RJ_OK) return rc;
@@ -1197,13 +1199,13 @@ int rj_program_info(const rj_program* prog, rj_info* info) {
 namespace {
 // rj_set_default_timing: whether NEW rj_scan objects take the scan kernel's start event (rj_stats.scan_ms).  Measured on the
 // regexdna step: the start event of hipExtLaunchKernelGGL costs ~6.5 us between two kernels of a stream, the end event nothing.
-std::atomic<int>& default_timing() {
+std::atomic<int>* default_timing() {   // (a pointer: this sits inside the extern "C" block, a reference to a class type draws a warning)
   static std::atomic<int> v{getenv("RJ_KERNEL_TIMING") && atoi(getenv("RJ_KERNEL_TIMING")) != 0 ? 1 : 0};
-  return v;
+  return &v;
 }
 }  // namespace
 
-int rj_set_default_timing(int on) { return default_timing().exchange(on != 0 ? 1 : 0); }
+int rj_set_default_timing(int on) { return default_timing()->exchange(on != 0 ? 1 : 0); }
 
 int rj_scan_set_timing(rj_scan* s, int on) {
   if (!s) return fail(RJ_BAD_ARGUMENT, "null scan");
@@ -1216,7 +1218,7 @@ int rj_scan_create(const rj_program* prog, rj_scan** out) {
   if (!prog || !out) return fail(RJ_BAD_ARGUMENT, "null argument");
   auto s = std::make_unique<rj_scan>();
   s->prog = prog;
-  s->timing = default_timing().load() != 0;
+  s->timing = default_timing()->load() != 0;
   int rc = scan_init(s.get());
   if (rc != RJ_OK) return rc;
   *out = s.release();

@@ -613,28 +613,25 @@ __global__ __launch_bounds__(256) void run_emit(RunParams a) {
 // Whole texts only (own ranges and carried-in states keep the other paths).
 namespace {
 
-struct PairElem {               // 64 bytes: the slot of a RunSummary
-  unsigned long long m[2];      // matches closed, by the incoming bit
-  unsigned long long pos[2];    // where the open Q sits behind the element (kind bit set)
-  uint32_t oo;                  // bit c: a Q is open behind the element
-  uint32_t kind;                // bit c: 1 = that Q lies inside the element (pos[c]), 0 = it is the one that came in
-  unsigned long long pad[3];
+struct alignas(64) PairElem {    // 64 bytes: the slot of a RunSummary.  (Scalars, no arrays: an array member put the element in scratch memory
+                                 // -- the first version's resolve took 120 us per GiB of text)
+  unsigned long long m0, m1;     // matches closed, by the incoming bit
+  unsigned long long pos0, pos1; // where the open Q sits behind the element (kind bit set)
+  uint32_t oo;                   // bit c: a Q is open behind the element
+  uint32_t kind;                 // bit c: 1 = that Q lies inside the element (pos), 0 = it is the one that came in
 };
 static_assert(sizeof(PairElem) == sizeof(RunSummary), "the pair kernels use the run kernels' buffers");
 
 __device__ __forceinline__ PairElem pair_compose(const PairElem& f, const PairElem& g) {   // f, then g
   PairElem e;
-  e.oo = e.kind = 0;
-#pragma unroll
-  for (int c = 0; c < 2; c++) {
-    const uint32_t c2 = (f.oo >> c) & 1u;
-    const bool inside = ((g.kind >> c2) & 1u) != 0;
-    e.m[c] = f.m[c] + g.m[c2];
-    e.pos[c] = inside ? g.pos[c2] : f.pos[c];
-    e.oo |= ((g.oo >> c2) & 1u) << c;
-    e.kind |= (inside ? 1u : ((f.kind >> c) & 1u)) << c;
-  }
-  e.pad[0] = e.pad[1] = e.pad[2] = 0;
+  const bool a0 = (f.oo & 1u) != 0, a1 = (f.oo & 2u) != 0;            // the bit g sees, by the bit f saw
+  const bool in0 = ((a0 ? g.kind >> 1 : g.kind) & 1u) != 0, in1 = ((a1 ? g.kind >> 1 : g.kind) & 1u) != 0;
+  e.m0 = f.m0 + (a0 ? g.m1 : g.m0);
+  e.m1 = f.m1 + (a1 ? g.m1 : g.m0);
+  e.pos0 = in0 ? (a0 ? g.pos1 : g.pos0) : f.pos0;
+  e.pos1 = in1 ? (a1 ? g.pos1 : g.pos0) : f.pos1;
+  e.oo = ((a0 ? g.oo >> 1 : g.oo) & 1u) | (((a1 ? g.oo >> 1 : g.oo) & 1u) << 1);
+  e.kind = (in0 ? 1u : (f.kind & 1u)) | ((in1 ? 1u : ((f.kind >> 1) & 1u)) << 1);
   return e;
 }
 
@@ -643,10 +640,11 @@ struct PairState {
   unsigned long long at;
 };
 __device__ __forceinline__ PairState pair_apply(const PairElem& g, PairState in, unsigned long long* closes) {
-  *closes = g.m[in.open];
+  const bool c = in.open != 0;
+  *closes = c ? g.m1 : g.m0;
   PairState o;
-  o.open = (g.oo >> in.open) & 1u;
-  o.at = ((g.kind >> in.open) & 1u) ? g.pos[in.open] : in.at;
+  o.open = (c ? g.oo >> 1 : g.oo) & 1u;
+  o.at = ((c ? g.kind >> 1 : g.kind) & 1u) ? (c ? g.pos1 : g.pos0) : in.at;
   return o;
 }
 
@@ -658,11 +656,10 @@ __device__ __forceinline__ void pair_resolve_span(const PairElem* src, RunTileIn
   const uint64_t C = (n + T - 1) / T;
   const uint64_t lo = static_cast<uint64_t>(t) * C < n ? static_cast<uint64_t>(t) * C : n, hi = lo + C < n ? lo + C : n;
   PairElem identity;
-  identity.m[0] = identity.m[1] = 0;
-  identity.pos[0] = identity.pos[1] = kNone;
+  identity.m0 = identity.m1 = 0;
+  identity.pos0 = identity.pos1 = kNone;
   identity.oo = 2u;    // (the bit is handed on)
   identity.kind = 0u;
-  identity.pad[0] = identity.pad[1] = identity.pad[2] = 0;
   constexpr int kBatch = 4;
   PairElem e = identity;
   for (uint64_t i = lo; i < hi; i += kBatch) {
@@ -814,18 +811,17 @@ __global__ __launch_bounds__(256) void pair_summary(RunParams a) {
     cur = T - Lq;
   }
   PairElem e;
-  e.pad[0] = e.pad[1] = e.pad[2] = 0;
-  e.pos[0] = e.pos[1] = last_q;
+  e.pos0 = e.pos1 = last_q;
   if (!seen) {   // no reset: the tile's Q bytes pair up from the incoming bit on
     k1 = cur;
-    e.m[0] = k1 / 2;
-    e.m[1] = (k1 + 1) / 2;
+    e.m0 = k1 / 2;
+    e.m1 = (k1 + 1) / 2;
     e.oo = static_cast<uint32_t>(k1 & 1u) | (static_cast<uint32_t>((k1 + 1) & 1u) << 1);
     e.kind = k1 != 0 ? 3u : 0u;
   } else {
     fixed += cur / 2;
-    e.m[0] = k1 / 2 + fixed;
-    e.m[1] = (k1 + 1) / 2 + fixed;
+    e.m0 = k1 / 2 + fixed;
+    e.m1 = (k1 + 1) / 2 + fixed;
     e.oo = (cur & 1u) ? 3u : 0u;
     e.kind = 3u;
   }
@@ -845,12 +841,14 @@ __global__ __launch_bounds__(256) void pair_reduce(RunParams a) {
   PairElem* all = reinterpret_cast<PairElem*>(a.summaries);
   pair_resolve_span<256>(all + first, nullptr, n, PairState{0u, kNone}, 0, chunk, all + a.n_tiles + b, nullptr);
 }
-__global__ __launch_bounds__(1024) void pair_resolve_blocks(RunParams a) {
-  __shared__ PairElem chunk[2][1024];
+// (T = 256 up to 1024 blocks -- 32 GiB of text --: the scan's rounds over 1024 mostly idle threads were 35 us of a 1 GiB call)
+template <int T>
+__global__ __launch_bounds__(T) void pair_resolve_blocks(RunParams a) {
+  __shared__ PairElem chunk[2][T];
   const uint64_t n_blocks = (a.n_tiles + a.block_tiles - 1) / a.block_tiles;
   unsigned long long total = 0;
-  pair_resolve_span<1024>(reinterpret_cast<const PairElem*>(a.summaries) + a.n_tiles, a.tile_in + a.n_tiles, n_blocks, PairState{0u, kNone}, 0, chunk, nullptr, &total);
-  if (threadIdx.x == 1023) leave_total(a, total);
+  pair_resolve_span<T>(reinterpret_cast<const PairElem*>(a.summaries) + a.n_tiles, a.tile_in + a.n_tiles, n_blocks, PairState{0u, kNone}, 0, chunk, nullptr, &total);
+  if (threadIdx.x == T - 1) leave_total(a, total);
 }
 __global__ __launch_bounds__(256) void pair_apply_blocks(RunParams a) {
   __shared__ PairElem chunk[2][256];
@@ -1052,7 +1050,8 @@ void launch_pair_resolve(const RunParams& a0, hipStream_t st) {
   }
   const unsigned blocks = static_cast<unsigned>((a.n_tiles + a.block_tiles - 1) / a.block_tiles);
   hipLaunchKernelGGL(pair_reduce, dim3(blocks), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(pair_resolve_blocks, dim3(1), dim3(1024), 0, st, a);
+  if (blocks <= 1024) hipLaunchKernelGGL(pair_resolve_blocks<256>, dim3(1), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(pair_resolve_blocks<1024>, dim3(1), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(pair_apply_blocks, dim3(blocks), dim3(256), 0, st, a);
 }
 void launch_pair_emit(const RunParams& a, hipEvent_t t1, hipStream_t st) {

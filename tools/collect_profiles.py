@@ -124,6 +124,16 @@ for src, dst in (("dense_probe.txt", "dense_probe.txt"), ("jrep_compare.txt", "j
                  ("count_general_probe.txt", "count_general_probe.txt"), ("e2e_probe.txt", "e2e_probe.txt"), ("host_copy_probe.txt", "host_copy_probe.txt"), ("run_probe.txt", "run_probe.txt")):
     if os.path.exists(g(src)):
         shutil.copy(g(src), P(dst))
+# the pair kernels (tools/probes/pair_profile.sh)
+if os.path.exists(g("pair_probe.txt")):
+    shutil.copy(g("pair_probe.txt"), P("pair_probe.txt"))
+    open(P("pair_kernel_stats.txt"), "w").write(
+        "# rocprofv3 --kernel-trace --stats -- python tools/probes/pair_time.py 1024   (MI355X): `\"[^\"]*\"` (pair_*<1>) and `\"[^\"\\n]*\"` (pair_*<4>)\n"
+        "# over 1 GiB of JSON-like text and 1 GiB of long strings; the at::native kernels build the texts\n" + open(g("pair_kernel_stats.txt")).read())
+    open(P("pair_pmc_fetch.txt"), "w").write(
+        "# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace -- python tools/probes/pair_time.py 1024 (own passes): KiB per launch; x 2 for HBM\n"
+        "# read bytes (gfx950: MI355X_MICROARCH.md) -- pair_summary reads the 1 GiB text once; pair_emit once more where tiles close a match\n"
+        "## FETCH_SIZE\n" + open(g("pair_pmc_fetch.txt")).read() + "## WRITE_SIZE (raw)\n" + open(g("pair_pmc_write.txt")).read())
 open(P("bench_line.json"), "w").write(open(g("bench.json")).read().strip().splitlines()[-1] + "\n")
 d = json.load(open(P("bench_line.json")))
 print("value", d["value"], "ms/step", d["ms_per_step"], "roofline", d["roofline"]["frac"])

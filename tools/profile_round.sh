@@ -42,6 +42,7 @@ python tools/probes/repl_probe.py 2>/dev/null | grep -v amdgpu.ids > $out/prof_$
 # the run kernels over single runs (64 MiB, 4 GiB) and over 1 GiB with a break every ~33 ... 30 000 bytes: whole calls
 { echo "# tools/probes/run_time.py + tools/probes/run_density.py (MI355X): the run kernels (run_scan.hip), wall time of whole calls, device texts"
   python tools/probes/run_time.py 2>/dev/null | grep -v amdgpu.ids; python tools/probes/run_density.py 1024 2>/dev/null | grep -v amdgpu.ids; } > $out/prof_${tag}_run_probe.txt
+bash tools/probes/pair_profile.sh $tag > /dev/null 2>&1
 tail -1 $out/prof_${tag}_bench.json | cut -c1-300
 head -6 $out/prof_${tag}_kernel_stats.txt | cut -c1-60,91-170
 head -14 $out/prof_${tag}_pmc_fetch.txt
