@@ -139,7 +139,8 @@ inline RunPlan make_run_plan(const Program& P) {
     if (A[c] && B[c] && !L[c]) clash = true;   // (the B of one match could be the A of the next)
   }
   if (clash) {
-    // The PAIR shape: `Q L* Q` with the same class Q at both ends and no byte of Q inside L -- `"[^"]*"`, `'[^'\n]*'`, `%[a-z]*%`.
+    // The PAIR shape: `Q L* Q` with the same class Q at both ends and no byte of Q inside L -- `"[^"]*"`, `%[a-z]*%`, `"[^"<LF>]*"` (the
+    // line-break byte itself: this dialect has no escapes inside brackets).
     // Every Q byte is a break, and whether it OPENS a match depends on the match before it: a Q closes the match its predecessor
     // opened, the next Q opens again; a break that is no Q (a RESET: `\n` for `"[^"\n]*"`, the text's end) drops an open Q.  So
     // the matches are the pairs (1st, 2nd), (3rd, 4th) ... of the Q bytes since the last reset: a parity per segment, carried

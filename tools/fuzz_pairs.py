@@ -16,8 +16,8 @@ oracle = Oracle()
 pool = list(b"abxy01\"'%|\n ,") + [0x80, 0xfe]
 
 
-def esc(c):
-    return b"\\x%02x" % c if (c >= 0x7f or c < 0x20 or chr(c) in "\\[]^-|%\"'") else bytes([c])
+def esc(c):   # (the reference's dialect has no escapes inside brackets: the byte itself; the pool holds none of `\\ [ ] ^ -`)
+    return bytes([c])
 
 
 bad = took = other = 0

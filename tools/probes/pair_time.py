@@ -20,7 +20,7 @@ json_like = alphabet[torch.randint(0, 64, (n,), device=dev, generator=g).long()]
 sparse = torch.full((n,), ord("x"), dtype=torch.uint8, device=dev)
 sparse[torch.randint(0, n, (n // 30000,), device=dev, generator=g)] = ord("\"")
 for name, d in (("json-like", json_like), ("long strings", sparse)):
-    for rx in (b"\"[^\"]*\"", b"\"[^\"\\n]*\""):
+    for rx in (b"\"[^\"]*\"", b"\"[^\"\n]*\""):
         sc = rejit_amd.Scan(rejit_amd.Program(rx))
         k = sc.run_tensor(d)
         ts = []
@@ -33,5 +33,5 @@ for name, d in (("json-like", json_like), ("long strings", sparse)):
         kc = sc.count_tensor(d)
         tc = time.perf_counter() - t0
         st = sc.stats()
-        print(f"{name:13s} {rx.decode():14s} {mib} MiB: {k} matches, best call {min(ts) * 1e3:8.3f} ms = {n / min(ts) / 1e9:7.1f} GB/s; count {kc} in {tc * 1e3:8.3f} ms; "
+        print(f"{name:13s} {rx.decode().replace(chr(10), '<LF>'):14s} {mib} MiB: {k} matches, best call {min(ts) * 1e3:8.3f} ms = {n / min(ts) / 1e9:7.1f} GB/s; count {kc} in {tc * 1e3:8.3f} ms; "
               f"run_path {st['run_path']} linear {st['linear_path']} stream {st['stream_path']}", flush=True)
