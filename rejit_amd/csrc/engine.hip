@@ -709,9 +709,20 @@ static int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb,
     int rc = run_pairs(s, d_text, n, sb, se, st);
     if (rc != 0) return rc < 0 ? rc : RJ_OK;
   }
-  if (rp->run.ok && (runs_first || s->linear_hint || (!windows && (!fresh || rp->stream.n_pos == 0 || s->streams_off)))) {
+  // A WINDOWS-mode run shape -- its window is the ONE byte of A: `a.*b`, `#.*`, `<[^>]*>`, `\([^)]*\)`, ` +` -- over a range that reaches the
+  // text's end: the run kernels first.  On everyday text such a byte is everywhere, every hit is a walk, and the window path ran 1 GiB
+  // of log-like text at 32-155 GB/s (`a.*b` 33.8 ms, `<[^>]*>` 22.7, `#.*` 6.9, ` +` 8.0) where the run kernels take 0.55-1.5 ms
+  // (tools/probes/zoo.py).  Where the byte is RARE the window scan is ~1.6 x faster (one pass at the literal scan's rate): a run
+  // that found few matches sends the next one there, and a window scan that meets dense hits sends the scan object back for good.
+  static const bool no_window_runs = getenv("RJ_NO_WINDOW_RUNS") != nullptr;   // measurement override
+  const bool window_runs = windows && se >= n && n - std::min(sb, n) >= (256u << 10) && (!s->runs_sparse || s->window_dense) && !no_window_runs;
+  if (rp->run.ok && (runs_first || s->linear_hint || window_runs || (!windows && (!fresh || rp->stream.n_pos == 0 || s->streams_off)))) {
     int rc = run_runs(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
-    if (rc != 0) return rc < 0 ? rc : RJ_OK;
+    if (rc != 0) {
+      // (fewer than a match per 64 KiB: at ~11 ns per hit the window path wins below a hit per ~32 KiB)
+      if (rc == 1 && windows && !s->linear_hint) s->runs_sparse = s->result_count * 65536 < n - std::min(sb, n);
+      return rc < 0 ? rc : RJ_OK;
+    }
   }
   if (s->linear_hint && linear_path_fits(rp)) return run_linear(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
   if (!windows && fresh) {
@@ -960,6 +971,7 @@ static int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb,
       continue;
     }
     s->hits_hint = n_hits;
+    if (windows && rp->run.ok && n_hits * 32768 > se - sb) s->window_dense = true;   // (a hit every 32 KiB or denser: the run kernels from now on)
     if (s->host_counters[kCntOverrun] != 0) {
       // some start was still alive after max_walk bytes (an unbounded repetition over a long run):
       // walking every start on its own is quadratic there.  The carry scan is linear in the text

@@ -118,6 +118,10 @@ struct rj_scan {
   bool linear_hint = false;        // the previous run needed the carry scan: go there directly
   rejit_amd::DeviceBuffer run_summaries, run_tile_in;  // run_scan.hip
   bool count_only_run = false;   // (scan_count: this run's pairs are not wanted -- the run kernels stop behind their resolve)
+  // a WINDOWS-mode run shape (`a.*b`, `#.*`, `<[^>]*>`, ` +`: the window is one byte) takes the run kernels first; runs_sparse: they
+  // found few matches on this scan's text, the next run tries the window scan (faster when its hits are rare); window_dense: that
+  // scan met dense hits on this scan's text (every hit a walk: 20-40 x slower than the run kernels) -- the run kernels for good
+  bool runs_sparse = false, window_dense = false;
   bool streams_off = false;        // dense_streams ran into a void run or too many scalar walks on this scan's text: scan_dense_walk
   bool behind_conflicts = false;   // behind mode gave a conflict / overrun on this scan's text: stay dense
   bool no_local_select = false;    // floating windows: the in-region selection left overlapping candidates on this text

@@ -207,3 +207,37 @@ def test_patterns_without_the_shape_keep_their_paths(rj, oracle):
     for rx in (b"a.*b|c", b"(ab)+", b"a+b+", b"x*", b"^a.*b", b"[ab]+c|[bc]+d", b"a.+b", b"a.*\\n", b"abc"):
         st = check(rj, oracle, rx, data)
         assert st["run_path"] == 0, (rx, st)
+
+
+def test_window_mode_run_shapes_take_the_run_kernels_first(rj, oracle):
+    """`a.*b`, `#.*`, `<[^>]*>`, ` +`: the fast-forward window is the ONE byte of A.  On everyday text that byte is everywhere and every hit
+    is a walk (1 GiB of log-like text: 7-34 ms), so a range that reaches the text's end takes the run kernels first (0.5-1.5 ms); a run
+    that found few matches sends the next one to the window scan, and a window scan that meets dense hits sends the scan object back for
+    good (engine.hip: window_runs).  The answers are the oracle's on every path."""
+    rng = random.Random(48)
+    n = 400000
+    dense = bytes(rng.choice(b"abcdefgh <>#()\n ") for _ in range(n))
+    sparse = bytearray(rng.choice(b"cdefgh\n") for _ in range(n))
+    for rx, plant in ((b"a.*b", b"a cd b"), (b"#.*", b"# x"), (b"<[^>]*>", b"<cd>"), (b"\\([^)]*\\)", b"(e)"), (b" +", b"  ")):
+        sp = bytearray(sparse)
+        sp[n // 2:n // 2 + len(plant)] = plant
+        sp = bytes(sp)
+        sc = rj.Scan(rj.Program(rx))
+
+        def run(data):
+            t = device_text(data)
+            k = sc.run(t.data_ptr(), len(data))
+            assert sc.spans() == oracle.match_all(rx, data) and k == len(sc.spans()), (rx, len(data))
+            return sc.stats()["run_path"]
+        assert run(dense) == 1, rx                 # no history: the run kernels
+        assert run(dense) == 1, rx                 # dense matches: they stay
+        assert run(sp) == 1, rx                    # ... and find one match in 400 KB
+        assert run(sp) == 0, rx                    # few matches: the window scan (rare hits: faster)
+        assert run(sp) == 0, rx
+        assert run(dense) == 0, rx                 # the window scan meets dense hits once ...
+        assert run(dense) == 1 and run(sp) == 1 and run(sp) == 1, rx    # ... and the scan object keeps the run kernels for good
+        # an own range that ends before the text does keeps the window path (the run kernels read to the text's end)
+        sc2 = rj.Scan(rj.Program(rx))
+        t = device_text(dense)
+        sc2.run(t.data_ptr(), n, own_begin=0, own_end=n // 2)
+        assert sc2.stats()["run_path"] == 0 and sc2.spans() == [m for m in oracle.match_all(rx, dense) if m[0] < n // 2], rx
