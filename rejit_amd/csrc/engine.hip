@@ -522,7 +522,11 @@ static int run_streams(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t s
     }
     // a text on which many starts outlive the register steps (long runs of the loop's class): the scalar walks are
     // chains of loads from device memory; scan_dense_walk's LDS walkers do that better -- from the next call on
-    if (slow > (se - sb) / 512) s->streams_off = true;
+    // ... and a run shape (`[A-Z][a-z]+` over words longer than the steps' 16 bytes) has the run kernels behind it, which take the
+    // text at 1.0-1.5 ms per GiB whatever the runs' length.  A scalar walk holds its whole wave up: 37 600 of them per GiB (one per
+    // 28 KiB) made this kernel 5.2 ms where the run kernels take 1.05 (tools/probes/zoo.py) -- ~100 ns apiece: they pay from a walk
+    // per ~256 KiB on
+    if (slow > (se - sb) / (rp->run.ok ? 262144 : 512)) s->streams_off = true;
     const uint64_t cnt = s->host_counters[kCntFinal];
     if (cnt > s->out_cap) {  // more matches than room: once more with room for all of them
       s->stats.retries++;
@@ -552,9 +556,11 @@ static int run_runs(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, 
   RunParams a{};
   a.text = d_text;
   a.n = n;
-  a.sb = sb;
-  a.se = std::min<uint64_t>(se, n);   // (a match consumes at least one byte: none begins at n)
-  a.min_start = std::max<uint64_t>(sb, have_prev ? carry_cur : 0);
+  // (`A L+` plans: the kernels' starts are the marks one byte behind a match's begin -- the three positions move with them)
+  const uint64_t lag = rp->run.lag;
+  a.sb = sb + lag;
+  a.se = std::min<uint64_t>(se, n) + lag;   // (a match consumes at least one byte: none begins at n)
+  a.min_start = std::max<uint64_t>(sb, have_prev ? carry_cur : 0) + lag;
   a.plan = rp->run;
   if (have_prev && rp->run.has_b && carry_prev_end >= 1 && carry_prev_end <= n) {
     // the carried-in match ended behind its B at carry_prev_end - 1: when that byte is no break, the segment goes on and has
@@ -583,7 +589,8 @@ static int run_runs(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, 
   RJ_HIP(hipStreamSynchronize(st));   // (the number of pairs sizes the output)
   RJ_HIP(hipGetLastError());
   const uint64_t cnt = s->host_counters[kCntFinal];
-  if (s->count_only_run && sb == 0 && se > n) {   // MatchAllCount of the whole text: one pass over it
+  const bool line_filter = rp->run.bol != 0 || rp->run.eol != 0;   // (`^#.*`, `#.*$`: every match is looked at once more)
+  if (s->count_only_run && sb == 0 && se > n && !line_filter) {   // MatchAllCount of the whole text: one pass over it
     s->result_count = cnt;
     s->result = nullptr;
     s->hits_hint = cnt;
@@ -606,8 +613,35 @@ static int run_runs(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, 
   float ms = 0.f;
   if (s->timing) (void)hipEventElapsedTime(&ms, s->ev[1], s->ev[2]);
   s->stats.scan_ms += ms;   // (first pass's start to the second pass's end, the scan between them included)
-  s->result_count = cnt;
-  s->result = s->out.as<uint64_t>();
+  uint64_t kept = cnt;
+  const uint64_t* result = s->out.as<uint64_t>();
+  if (line_filter && cnt) {
+    // `^` / `$` around the shape (run_scan.h: RunPlan::bol / eol): of these matches, the ones that begin at a line start / end at
+    // a line end -- counted per group of pairs, the groups' offsets by the region scan, the survivors moved in order
+    LineFilterParams f{};
+    f.text = d_text;
+    f.n = n;
+    f.bol = rp->run.bol;
+    f.eol = rp->run.eol;
+    f.in = s->out.as<uint64_t>();
+    f.cnt = cnt;
+    f.n_groups = line_filter_groups(cnt, &f.per);
+    RJ_HIP(s->hit_counts.reserve(sizeof(uint32_t) * static_cast<size_t>(f.n_groups)));
+    RJ_HIP(s->hit_offsets.reserve(sizeof(uint64_t) * (static_cast<size_t>(f.n_groups) + 1)));
+    RJ_HIP(s->run_filtered.reserve(cnt * 2 * sizeof(uint64_t)));
+    f.counts = s->hit_counts.as<uint32_t>();
+    f.offsets = s->hit_offsets.as<uint64_t>();
+    f.out = s->run_filtered.as<uint64_t>();
+    f.counters = s->counters.as<unsigned long long>();
+    f.host_counters = s->host_counters;
+    launch_line_filter(f, st);
+    RJ_HIP(hipStreamSynchronize(st));
+    RJ_HIP(hipGetLastError());
+    kept = s->host_counters[kCntFinal];
+    result = s->run_filtered.as<uint64_t>();
+  }
+  s->result_count = kept;
+  s->result = (s->count_only_run && sb == 0 && se > n) ? nullptr : result;
   s->hits_hint = cnt;
   s->stats.n_hits += cnt;
   s->stats.n_candidates += cnt;
@@ -716,7 +750,10 @@ static int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb,
   // that found few matches sends the next one there, and a window scan that meets dense hits sends the scan object back for good.
   static const bool no_window_runs = getenv("RJ_NO_WINDOW_RUNS") != nullptr;   // measurement override
   const bool window_runs = windows && se >= n && n - std::min(sb, n) >= (256u << 10) && (!s->runs_sparse || s->window_dense) && !no_window_runs;
-  if (rp->run.ok && (runs_first || s->linear_hint || window_runs || (!windows && (!fresh || rp->stream.n_pos == 0 || s->streams_off)))) {
+  // (`^[A-Z][a-z]+`: a dense-mode shape behind `^` -- its candidates are the line starts, few and cheap on the general path (1.2 ms per
+  // GiB of log-like text), where the run kernels would write every capitalised word and filter 98 % of them away again (1.8 ms))
+  const bool bol_dense = rp->run.bol != 0 && !windows && !runs_first;
+  if (rp->run.ok && (runs_first || s->linear_hint || window_runs || (!windows && !bol_dense && (!fresh || rp->stream.n_pos == 0 || s->streams_off)))) {
     int rc = run_runs(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
     if (rc != 0) {
       // (fewer than a match per 64 KiB: at ~11 ns per hit the window path wins below a hit per ~32 KiB)

@@ -42,6 +42,9 @@ struct RunPlan {
   uint32_t high_half;           // bit r: the range lies in 0x80..0xff
   uint32_t a_ranges, l_ranges, b_ranges;   // bit r: the class (or its complement) holds range r
   uint32_t a_neg, l_neg, b_neg;            // 1: the class is the complement of its ranges
+  uint32_t lag;                 // 1: `A L+` / `A L+ B` -- the kernels' start stream is "A at p - 1 and L at p" (below), a match begins one byte before its start
+  uint32_t bol, eol;            // `^...` / `...$` around a shape: the kernels run as without them, run_line_filter keeps the matches that begin at a
+                                // line start / end at a line end (below)
   uint32_t pair;                // the PAIR shape (`"[^"]*"`; below): ok stays 0, the pair kernels of run_scan.hip take the pattern
 };
 
@@ -104,17 +107,43 @@ inline bool add_class(RunPlan* pl, const bool (&set)[256], uint32_t* mask, uint3
 //   A L*    2 positions  first {0}  last {0,1}  0 -> {1}    1 -> {1}
 //   X+ B    2 positions  first {0}  last {1}    0 -> {0,1}  1 -> {}
 //   A L* B  3 positions  first {0}  last {2}    0 -> {1,2}  1 -> {1,2}  2 -> {}
+//   A L+    2 positions  first {0}  last {1}    0 -> {1}    1 -> {1}              (lag: see below)
+//   A L+ B  3 positions  first {0}  last {2}    0 -> {1}    1 -> {1,2}  2 -> {}   (lag)
 inline RunPlan make_run_plan(const Program& P) {
   RunPlan pl{};
-  if (P.n_pos < 1 || P.n_pos > 3 || P.n_words != 1 || P.has_assertions || P.any_nullable || P.q8_risk) return pl;
+  if (P.n_pos < 1 || P.n_pos > 3 || P.n_words != 1 || P.any_nullable || P.q8_risk) return pl;
   const uint32_t all = (1u << P.n_pos) - 1u;
-  const uint32_t first = P.first[0][0] & all, last = P.last[0][0] & all;
+  // `^` in front / `$` behind (contexts: lowering.h -- bit 0 = the boundary is a line start, bit 1 = a line end): the first set
+  // exists only at a line start / the last set only at a line end, nothing else depends on the context.  Then the matches are
+  // those of the pattern WITHOUT the assertions that begin at a line start / end at a line end, provided no line break is in A
+  // or L (and, for `$`, there is no B position): only a segment's FIRST A can follow a line break, and a match without B ends
+  // at its segment's break -- the filter cannot turn the selection of another start into a match.
+  uint32_t bol = 0, eol = 0;
+  const int cx = P.has_assertions ? 3 : 0;
+  if (P.has_assertions) {
+    auto f = [&](int c) { return P.first[c][0] & all; };
+    auto la = [&](int c) { return P.last[c][0] & all; };
+    if (f(1) != f(3) || f(0) != f(2) || la(2) != la(3) || la(0) != la(1)) return pl;
+    if (f(0) != f(3)) {
+      if (f(0) != 0) return pl;
+      bol = 1;
+    }
+    if (la(0) != la(3)) {
+      if (la(0) != 0) return pl;
+      eol = 1;
+    }
+    for (int c = 0; c < 3; c++)
+      if (P.rows[c] != P.rows[3]) return pl;
+    if (!bol && !eol) return pl;
+  }
+  const uint32_t first = P.first[cx][0] & all, last = P.last[cx][0] & all;
   uint32_t F[3] = {0, 0, 0};
   for (int k = 0; k < P.n_pos; k++) {
     const int r = P.row_of[static_cast<size_t>(k)];
-    F[k] = (r < 0 ? (1u << (k + 1)) : P.rows[0][static_cast<size_t>(r)]) & all;   // (no row: the follow set is {k + 1})
+    F[k] = (r < 0 ? (1u << (k + 1)) : P.rows[cx][static_cast<size_t>(r)]) & all;   // (no row: the follow set is {k + 1})
   }
   int a = -1, l = -1, b = -1;
+  uint32_t lag = 0;
   if (P.n_pos == 1 && first == 1 && last == 1 && F[0] == 1) {
     a = l = 0;
   } else if (P.n_pos == 2 && first == 1 && last == 3 && F[0] == 2 && F[1] == 2) {
@@ -127,6 +156,20 @@ inline RunPlan make_run_plan(const Program& P) {
     a = 0;
     l = 1;
     b = 2;
+  } else if (P.n_pos == 2 && first == 1 && last == 2 && F[0] == 2 && F[1] == 2) {
+    // `A L+` (`[A-Z][a-z]+`, `#.+`, `@[a-z]+`): `A L*` whose loop runs at least once.  The kernels take as START stream the marks
+    // "A at p - 1 and L at p" (one shift of the A stream, the carry from the lane below / the iteration before): the left-most
+    // mark of a segment sits one byte behind the left-most A that has an L byte behind it, the thread lives until the break as
+    // before, and with a B position "the last B BEHIND the start" is exactly "at least one L byte between A and B".  A match
+    // begins one byte before its mark (lag).
+    a = 0;
+    l = 1;
+    lag = 1;
+  } else if (P.n_pos == 3 && first == 1 && last == 4 && F[0] == 2 && F[1] == 6 && F[2] == 0) {
+    a = 0;     // `A L+ B` (`a.+b`, `<[^>]+>`)
+    l = 1;
+    b = 2;
+    lag = 1;
   } else {
     return pl;
   }
@@ -138,6 +181,9 @@ inline RunPlan make_run_plan(const Program& P) {
     B[c] = b >= 0 && ((cls >> b) & 1u) != 0;
     if (A[c] && B[c] && !L[c]) clash = true;   // (the B of one match could be the A of the next)
   }
+  if (bol || eol) {
+    if ((eol && b >= 0) || A['\n'] || A['\r'] || L['\n'] || L['\r']) return pl;
+  }
   if (clash) {
     // The PAIR shape: `Q L* Q` with the same class Q at both ends and no byte of Q inside L -- `"[^"]*"`, `%[a-z]*%`, `"[^"<LF>]*"` (the
     // line-break byte itself: this dialect has no escapes inside brackets).
@@ -145,7 +191,7 @@ inline RunPlan make_run_plan(const Program& P) {
     // opened, the next Q opens again; a break that is no Q (a RESET: `\n` for `"[^"\n]*"`, the text's end) drops an open Q.  So
     // the matches are the pairs (1st, 2nd), (3rd, 4th) ... of the Q bytes since the last reset: a parity per segment, carried
     // from tile to tile as a function on one bit (run_scan.hip: pair_summary / pair_resolve / pair_emit).
-    if (b < 0 || a == l) return pl;
+    if (b < 0 || a == l || lag || bol || eol) return pl;
     for (int c = 0; c < 256; c++)
       if (A[c] != B[c] || (A[c] && L[c])) return pl;
     if (!run_detail::add_class(&pl, A, &pl.a_ranges, &pl.a_neg) || !run_detail::add_class(&pl, L, &pl.l_ranges, &pl.l_neg)) return RunPlan{};
@@ -158,6 +204,9 @@ inline RunPlan make_run_plan(const Program& P) {
   if (!run_detail::add_class(&pl, A, &pl.a_ranges, &pl.a_neg) || !run_detail::add_class(&pl, L, &pl.l_ranges, &pl.l_neg)) return RunPlan{};
   if (b >= 0 && !run_detail::add_class(&pl, B, &pl.b_ranges, &pl.b_neg)) return RunPlan{};
   pl.has_b = b >= 0 ? 1u : 0u;
+  pl.lag = lag;
+  pl.bol = bol;
+  pl.eol = eol;
   pl.ok = 1;
   return pl;
 }

@@ -1,4 +1,4 @@
-// rejit_amd/csrc/run_scan.hip -- the kernels of run_scan.h: MatchAll of `X+` / `A L*` / `A L* B` / `X+ B` patterns in one or two
+// rejit_amd/csrc/run_scan.hip -- the kernels of run_scan.h: MatchAll of `X+` / `A L*` / `A L* B` / `X+ B` (/ `A L+` / `A L+ B`: lag_marks) patterns in one or two
 // passes over the text and one small scan over tile summaries, whatever the length of the runs (reference: the NFA loop's
 // one long-lived thread, src/x64/codegen-x64.cc:535-581, its last accepting position :426-461, the restart behind the
 // match :487-503).
@@ -184,6 +184,23 @@ __device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t x) {
 }
 __device__ __forceinline__ uint32_t lane_below(uint32_t x) { return dpp0<0x138, 0xF>(x); }   // wave_shr:1, lane 0 gets 0
 __device__ __forceinline__ uint32_t last_lane(uint32_t x) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(x), kWave - 1)); }
+// RunPlan::lag (`A L+`, `A L+ B`): the start stream becomes the marks "A at p - 1 and L at p"; prev_a = the A bit of the byte before
+// the iteration (in: of this one, out: of the next)
+__device__ __forceinline__ uint32_t lag_marks(uint32_t SA, uint32_t BR, uint32_t& prev_a) {
+  const uint32_t below = lane_below(SA) >> 31;
+  const uint32_t cin = lane_id() == 0 ? prev_a : below;
+  prev_a = last_lane(SA) >> 31;
+  return ((SA << 1) | cin) & ~BR;   // (BR holds the text's end: no mark there or beyond)
+}
+// ... and at a tile's begin: the A bit of the byte before the tile (every lane reads the same 32 bytes, once per tile)
+template <int NR, bool HAS_B>
+__device__ __forceinline__ uint32_t lag_entry(const RunParams& a, const RunMasks<NR>& mk, uint64_t base) {
+  if (!a.plan.lag || base == 0) return 0u;
+  uint32_t sa, sb, br;
+  const uint4 none = make_uint4(0, 0, 0, 0);
+  run_streams_of<NR, HAS_B>(a, mk, base - 1, none, none, false, &sa, &sb, &br);
+  return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(sa))) & 1u;
+}
 __device__ __forceinline__ unsigned long long lane_value(unsigned long long x, int l) {
   const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(x)), l));
   const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(x >> 32)), l));
@@ -303,6 +320,7 @@ __global__ __launch_bounds__(256) void run_summary(RunParams a) {
     }
   };
   fetch(0);
+  uint32_t prev_a = lag_entry<NR, HAS_B>(a, mk, base);
 #pragma unroll 1
   for (int it = 0; it < kIters; it++) {
     const uint64_t it_base = base + static_cast<uint64_t>(it) * kIterBytes;
@@ -310,6 +328,7 @@ __global__ __launch_bounds__(256) void run_summary(RunParams a) {
     uint32_t SA, SB, BR;
     run_streams_of<NR, HAS_B>(a, mk, it_base + static_cast<uint64_t>(lane) * 32, v0, v1, loaded, &SA, &SB, &BR);
     if (it + 1 < kIters) fetch(it + 1);
+    if (a.plan.lag) SA = lag_marks(SA, BR, prev_a);
     SA = clip_starts(a, it_base, SA);
     const uint64_t brm = __ballot(BR != 0);
     if (brm == 0) {
@@ -558,6 +577,7 @@ __global__ __launch_bounds__(256) void run_emit(RunParams a) {
     }
   };
   fetch(0);
+  uint32_t prev_a = lag_entry<NR, HAS_B>(a, mk, base);
 #pragma unroll 1
   for (int it = 0; it < kIters; it++) {
     const uint64_t it_base = base + static_cast<uint64_t>(it) * kIterBytes;
@@ -565,6 +585,7 @@ __global__ __launch_bounds__(256) void run_emit(RunParams a) {
     uint32_t SA, SB, BR;
     run_streams_of<NR, HAS_B>(a, mk, it_base + static_cast<uint64_t>(lane) * 32, v0, v1, loaded, &SA, &SB, &BR);
     if (it + 1 < kIters) fetch(it + 1);
+    if (a.plan.lag) SA = lag_marks(SA, BR, prev_a);
     SA = clip_starts(a, it_base, SA);
     const uint64_t brm = __ballot(BR != 0);
     if (brm == 0) {
@@ -584,13 +605,13 @@ __global__ __launch_bounds__(256) void run_emit(RunParams a) {
     const uint32_t inc = wave_prefix_sum(mine);
     unsigned long long idx = pos + inc - mine;
     if (first) {
-      if (idx < a.out_cap) *reinterpret_cast<ulonglong2*>(a.out + 2 * idx) = make_ulonglong2(c.s, HAS_B ? c.q + 1 : word + static_cast<uint32_t>(__builtin_ctz(BR)));
+      if (idx < a.out_cap) *reinterpret_cast<ulonglong2*>(a.out + 2 * idx) = make_ulonglong2(c.s - a.plan.lag, HAS_B ? c.q + 1 : word + static_cast<uint32_t>(__builtin_ctz(BR)));
       idx++;
     }
     if (multi)
       for_inner<HAS_B>(SA, SB, BR, [&](uint32_t s, uint32_t q, uint32_t r) {
         if (word + s >= a.sb && word + s < a.se) {
-          if (idx < a.out_cap) *reinterpret_cast<ulonglong2*>(a.out + 2 * idx) = make_ulonglong2(word + s, word + (HAS_B ? q + 1u : r));
+          if (idx < a.out_cap) *reinterpret_cast<ulonglong2*>(a.out + 2 * idx) = make_ulonglong2(word + s - a.plan.lag, word + (HAS_B ? q + 1u : r));
           idx++;
         }
       });
@@ -1030,6 +1051,70 @@ void launch_run_emit(const RunParams& a, hipEvent_t t1, hipStream_t st) {
   else if (nr <= 2) launch_emit_nr<2>(a, grid, t1, st);
   else if (nr <= 4) launch_emit_nr<4>(a, grid, t1, st);
   else launch_emit_nr<8>(a, grid, t1, st);
+}
+
+// ---- `^` / `$` around a run shape: the line filter (RunPlan::bol / eol, run_scan.h)
+namespace {
+__device__ __forceinline__ bool line_break(uint8_t c) { return c == 0x0a || c == 0x0d; }
+__device__ __forceinline__ bool line_keep(const LineFilterParams& a, uint64_t i) {
+  const ulonglong2 m = *reinterpret_cast<const ulonglong2*>(a.in + 2 * i);
+  bool ok = true;
+  if (a.bol) ok = m.x == 0 || line_break(a.text[m.x - 1]);       // codegen-x64.cc:686-708: a line starts behind \n / \r and at 0
+  if (ok && a.eol) ok = m.y >= a.n || line_break(a.text[m.y]);
+  return ok;
+}
+}  // namespace
+__global__ __launch_bounds__(256) void line_filter_count(LineFilterParams a) {
+  __shared__ uint32_t wave_n[4];
+  const uint64_t lo = static_cast<uint64_t>(blockIdx.x) * a.per, hi = lo + a.per < a.cnt ? lo + a.per : a.cnt;
+  uint32_t mine = 0;
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) mine += line_keep(a, i) ? 1u : 0u;
+  const uint32_t w = wave_total(mine);
+  if (lane_id() == 0) wave_n[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) a.counts[blockIdx.x] = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+}
+__global__ __launch_bounds__(256) void line_filter_scatter(LineFilterParams a) {
+  __shared__ uint32_t wave_n[2][4];
+  const uint64_t lo = static_cast<uint64_t>(blockIdx.x) * a.per, hi = lo + a.per < a.cnt ? lo + a.per : a.cnt;
+  const int wv = static_cast<int>(threadIdx.x) >> 6;
+  uint64_t at = a.offsets[blockIdx.x];
+  int cur = 0;
+  for (uint64_t base = lo; base < hi; base += 256, cur ^= 1) {
+    const uint64_t i = base + threadIdx.x;
+    const bool keep = i < hi && line_keep(a, i);
+    const uint64_t bal = __ballot(keep);
+    if (lane_id() == 0) wave_n[cur][wv] = static_cast<uint32_t>(__popcll(bal));
+    __syncthreads();   // (two sets of wave counts used alternately: one barrier per round)
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      before += q < wv ? wave_n[cur][q] : 0u;
+      all += wave_n[cur][q];
+    }
+    if (keep) {
+      const uint64_t rank = at + before + static_cast<uint32_t>(__popcll(bal & lanes_below(lane_id())));
+      *reinterpret_cast<ulonglong2*>(a.out + 2 * rank) = *reinterpret_cast<const ulonglong2*>(a.in + 2 * i);
+    }
+    at += all;
+  }
+  if (blockIdx.x == a.n_groups - 1 && threadIdx.x == 0) {
+    const unsigned long long total = a.offsets[a.n_groups];
+    a.counters[kCntFinal] = total;
+    if (a.host_counters) a.host_counters[kCntFinal] = total;
+  }
+}
+// at most 64 Ki workgroups (launch_region_offsets' limit), 4096 pairs each or more
+uint32_t line_filter_groups(uint64_t cnt, uint32_t* per) {
+  uint64_t p = 4096;
+  while ((cnt + p - 1) / p > 65536) p *= 2;
+  *per = static_cast<uint32_t>(p);
+  return static_cast<uint32_t>((cnt + p - 1) / p);
+}
+void launch_line_filter(const LineFilterParams& a, hipStream_t st) {
+  hipLaunchKernelGGL(line_filter_count, dim3(a.n_groups), dim3(256), 0, st, a);
+  launch_region_offsets(a.counts, a.n_groups, 0xffffffffu, a.offsets, a.counters, st);
+  hipLaunchKernelGGL(line_filter_scatter, dim3(a.n_groups), dim3(256), 0, st, a);
 }
 
 // ---- the pair shape

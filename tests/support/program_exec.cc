@@ -432,27 +432,38 @@ long pe_run_match_all(const char* re, const uint8_t* text, uint64_t n, uint64_t*
   uint64_t k = 0;
   const uint64_t none = ~0ull;
   uint64_t s1 = none, q = none;
+  bool prev_a = false;   // lag plans (`A L+`): a start is the MARK "A at p - 1 and L at p"; the match begins one byte before it
+  shape[3] = pl.lag;
   for (uint64_t p = 0; p <= n; p++) {
     const bool at_end = p == n;
     const uint8_t c = at_end ? 0 : text[p];
     const bool brk = at_end || !in_class(c, pl.l_ranges, pl.l_neg);
+    const bool is_a = !at_end && in_class(c, pl.a_ranges, pl.a_neg);
+    const bool start_here = pl.lag ? (prev_a && !brk) : is_a;
+    prev_a = is_a;
     if (brk) {
       // B may be the break itself; a start lies before it
       if (!at_end && pl.has_b && s1 != none && in_class(c, pl.b_ranges, pl.b_neg)) q = p;
       if (s1 != none && (!pl.has_b || q != none)) {
-        if (k < cap) {
-          out[2 * k] = s1;
-          out[2 * k + 1] = pl.has_b ? q + 1 : p;
+        const uint64_t mb = s1 - pl.lag, me = pl.has_b ? q + 1 : p;
+        // `^` / `$` (RunPlan::bol / eol): the match stays when it begins at a line start / ends at a line end
+        const bool at_bol = mb == 0 || text[mb - 1] == '\n' || text[mb - 1] == '\r';
+        const bool at_eol = me == n || text[me] == '\n' || text[me] == '\r';
+        if ((!pl.bol || at_bol) && (!pl.eol || at_eol)) {
+          if (k < cap) {
+            out[2 * k] = mb;
+            out[2 * k + 1] = me;
+          }
+          k++;
         }
-        k++;
       }
       s1 = none;
       q = none;
-      if (!at_end && in_class(c, pl.a_ranges, pl.a_neg)) s1 = p;   // the next segment's starts begin AT the break
+      if (start_here) s1 = p;   // the next segment's starts begin AT the break (never a mark: a mark is an L byte)
       continue;
     }
     if (pl.has_b && s1 != none && in_class(c, pl.b_ranges, pl.b_neg)) q = p;
-    if (s1 == none && in_class(c, pl.a_ranges, pl.a_neg)) s1 = p;
+    if (s1 == none && start_here) s1 = p;
   }
   return static_cast<long>(k);
 }

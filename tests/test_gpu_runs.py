@@ -40,13 +40,13 @@ def device_text(data: bytes):
 
 
 SHAPES = [b"[acgt]+", b"[^>]+", b"x+", b"a[bc]*", b"a.*b", b"<[^>]*>", b"[a-f]+[0-9]", b"\"[^\"]*\"", b"a[^\\n]*z", b"[\\x80-\\xff]+", b"q[a-z]*[0-9]",
-          b"[ab]+b", b"a.*a"]
+          b"[ab]+b", b"a.*a", b"[A-Z][a-z]+", b"a.+b", b"<[^>]+>", b"#.+", b"a[bc]+", b"q[a-z]+[0-9]", b"a.+a"]   # (`A L+` / `A L+ B`: lag)
 
 
 def texts_for(rng, n):
     """alphabets chosen so that breaks are absent, rare or dense for the shapes above"""
     out = []
-    for alphabet in (b"acgt", b"ab", b"abcxz", b"acgt>\n", b"ab<>\"q0\n", bytes(range(256)), b"aaaaaaab\n", b"xyz09af"):
+    for alphabet in (b"acgt", b"ab", b"abcxz", b"acgt>\n", b"ab<>\"q0\n", bytes(range(256)), b"aaaaaaab\n", b"xyz09af", b"ABab#<> \n"):
         out.append(bytes(rng.choice(alphabet) for _ in range(n)))
     # long runs with a break every ~10 KiB and every ~100 KiB
     for every in (10000, 100000):
@@ -241,3 +241,29 @@ def test_window_mode_run_shapes_take_the_run_kernels_first(rj, oracle):
         t = device_text(dense)
         sc2.run(t.data_ptr(), n, own_begin=0, own_end=n // 2)
         assert sc2.stats()["run_path"] == 0 and sc2.spans() == [m for m in oracle.match_all(rx, dense) if m[0] < n // 2], rx
+
+
+def test_line_assertions_around_run_shapes(rj, oracle):
+    """`^#.*`, `#.*$`, `^a.*b`, `^[A-Z][a-z]+$`: `^` in front / `$` behind a run shape whose classes hold no line break (run_scan.h:
+    RunPlan::bol / eol) -- the run kernels as without them, then the line filter (line_filter_count -> region scan ->
+    line_filter_scatter) keeps the matches that begin at a line start / end at a line end (reference: the contexts of
+    src/x64/codegen-x64.cc:686-708).  `X+` with an assertion is at risk of the reference's ring artefact and keeps the exact replay."""
+    rng = random.Random(49)
+    took = 0
+    for n in (70001, 300000, 1 << 20):
+        for alphabet in (b"ab# \n", b"abAB#<>\n\r ", b"#a\n", b"ab cd#\n" * 3 + b"AB"):
+            data = bytes(rng.choice(alphabet) for _ in range(n))
+            for rx in (b"^#.*", b"#.*$", b"^a.*b", b"^[AB][ab]+$", b"^#.+", b"a[b ]*$", b"^<[^>\n]*>", b"[AB][ab]+$", b"^a[b ]*$"):
+                st = check(rj, oracle, rx, data)
+                took += st["run_path"]
+                if rx == b"^#.*":
+                    check(rj, oracle, rx, data, own_begin=n // 3, own_end=n + 1)
+                    sc = rj.Scan(rj.Program(rx))
+                    t = device_text(data)
+                    assert sc.count(t.data_ptr(), n) == len(oracle.match_all(rx, data))
+    assert took > 40, took   # (dense-mode shapes behind `^` keep the general path: their candidates are the line starts)
+    # look-alikes: the ring artefact's (`X+` with an assertion), `$` behind a B position, a line break inside L
+    data = bytes(rng.choice(b"ab# \n") for _ in range(100000))
+    for rx in (b"^[ab]+", b"[ab]+$", b"a.*b$", b"^a[^b]*"):
+        st = check(rj, oracle, rx, data)
+        assert st["run_path"] == 0, (rx, st)

@@ -43,7 +43,9 @@ def run(pe, rx, text):
 
 
 def test_shapes_taken_and_refused(pe):
-    for rx in (b"[acgt]+", b"[^>]+", b"x+", b"a[bc]*", b"a.*b", b"<[^>]*>", b"[a-f]+[0-9]", b"[\\x80-\\xff]+", b"q[a-z]*[0-9]", b"[ab]+b", b"a.*a"):
+    for rx in (b"[acgt]+", b"[^>]+", b"x+", b"a[bc]*", b"a.*b", b"<[^>]*>", b"[a-f]+[0-9]", b"[\\x80-\\xff]+", b"q[a-z]*[0-9]", b"[ab]+b", b"a.*a",
+               b"[A-Z][a-z]+", b"a.+b", b"<[^>]+>", b"#.+", b"a.+a",    # (these five: `A L+` / `A L+ B`, round 6 last session -- lag)
+               b"^#.*", b"#.*$", b"^a.*b", b"^[A-Z][a-z]+$", b"^#.+", b"a[bc]*$"):   # (`^` / `$` around a shape: the line filter)
         k, spans, shape = run(pe, rx, b"")
         assert k == 0, (rx, k)
     # `.` is "not \\n, not \\r": the complement of two ranges, not the four ranges of its members
@@ -51,7 +53,7 @@ def test_shapes_taken_and_refused(pe):
     assert shape[0] == 1 and (shape[2] >> 1) & 1 == 1 and shape[1] <= 4, shape
     # (`"[^"]*"`: the closing quote is a break AND may open the next match -- whether it does depends on the match before it:
     # the one byte class run_scan.h excludes)
-    for rx in (b"\"[^\"]*\"", b"a.*b|c", b"(ab)+", b"a+b+", b"x*", b"^a.*b", b"a.+b", b"abc", b"[ab]+c|[bc]+d", b"a.*bc"):
+    for rx in (b"\"[^\"]*\"", b"a.*b|c", b"(ab)+", b"a+b+", b"x*", b"a.*b$", b"^a[^b]*", b"q[^a]*$", b"^[a-z]+", b" +$", b"a.+b+", b"abc", b"[ab]+c|[bc]+d", b"a.*bc", b"\"[^\"]+\"", b"ab+c+"):
         k, _, _ = run(pe, rx, b"")
         assert k == -101, (rx, k)
 
@@ -70,10 +72,12 @@ def test_segment_rule_equals_oracle(pe, oracle):
         return b"[^" + b"".join(esc(c) for c in members) + b"]"
 
     taken = 0
-    for case in range(1500):
+    for case in range(3600):
         alphabet = rng.sample(pool, rng.randint(2, 7))
         a, l, b = cls(alphabet), cls(alphabet), cls(alphabet)
-        rx = rng.choice([a + b"+", a + l + b"*", a + l + b"*" + b, a + b"+" + b, a + b".*" + b])
+        rx = rng.choice([a + b"+", a + l + b"*", a + l + b"*" + b, a + b"+" + b, a + b".*" + b, a + l + b"+", a + l + b"+" + b, a + b".+" + b])
+        if rng.random() < 0.3:
+            rx = rng.choice([b"^" + rx, rx + b"$", b"^" + rx + b"$"])
         n = rng.choice([0, 1, 2, 17, 300, 5000])
         if rng.random() < 0.5:
             text = bytes(rng.choices(alphabet, k=n))
@@ -89,7 +93,7 @@ def test_segment_rule_equals_oracle(pe, oracle):
         assert k >= 0, (rx, k)
         taken += 1
         assert spans == oracle.match_all(rx, text), (rx, text[:80], spans[:4])
-    assert taken > 700
+    assert taken > 1100, taken
 
 
 def pair_run(pe, rx, text):

@@ -32,7 +32,7 @@ def cls(alphabet):
 bad = took = refused = 0
 for case in range(cases):
     alphabet = rng.sample(POOL, rng.randint(2, 7))
-    shape = rng.choice(["X+", "AL*", "AL*B", "X+B", "A.*B"])
+    shape = rng.choice(["X+", "AL*", "AL*B", "X+B", "A.*B", "AL+", "AL+B", "A.+B"])
     a, aset = cls(alphabet)
     l, lset = cls(alphabet)
     b, bset = cls(alphabet)
@@ -44,8 +44,16 @@ for case in range(cases):
         rx = a + l + b"*" + b
     elif shape == "X+B":
         rx = a + b"+" + b
+    elif shape == "AL+":
+        rx = a + l + b"+"
+    elif shape == "AL+B":
+        rx = a + l + b"+" + b
+    elif shape == "A.+B":
+        rx = a + b".+" + b
     else:
         rx = a + b".*" + b
+    if rng.random() < 0.25:   # `^` / `$` around the shape (RunPlan::bol / eol: the line filter)
+        rx = rng.choice([b"^" + rx, rx + b"$", b"^" + rx + b"$"])
     n = rng.choice([17, 100, 2048, 2049, 8192, 8200, 16384, 40000, 70001, 300000])
     dense = rng.random()
     if dense < 0.3:
@@ -88,7 +96,9 @@ for case in range(cases):
         continue
     took += 1 if st["run_path"] else 0
     refused += 0 if st["run_path"] else 1
-    if got != want and "own_begin" in kw and "have_prev" not in kw and not st["run_path"]:
+    # (`^` / `$`: the line filter reads the byte before the range -- a range that begins inside a line has no line start there, the
+    # whole text's answer; an independent run of the suffix would see one)
+    if got != want and "own_begin" in kw and "have_prev" not in kw and (not st["run_path"] or rx.startswith(b"^") or rx.endswith(b"$")):
         # (an independent range through a kernel that looks at the byte before the range -- match_small, dense_streams: the
         # whole text's matches that begin in the range; tests/test_gpu_runs.py accepts both)
         want = [m for m in full if kw["own_begin"] <= m[0] < kw["own_end"]]

@@ -42,6 +42,6 @@ for rx in PATTERNS:
             ts.append(time.perf_counter() - t0)
         st = sc.stats()
         path = "run" if st["run_path"] == 1 else "pair" if st["run_path"] == 2 else "stream" if st["stream_path"] else "linear" if st["linear_path"] else "exact" if st["exact_path"] else "general"
-        print(f"{rx.decode():28s} {k:>10d} matches  first {first * 1e3:9.3f} ms  best {min(ts) * 1e3:9.3f} ms = {n / min(ts) / 1e9:8.1f} GB/s  {path}  retries {st['retries']}", flush=True)
+        print(f"{rx.decode():28s} {k:>10d} matches  first {first * 1e3:9.3f} ms  best {min(ts) * 1e3:9.3f} ms = {n / min(ts) / 1e9:8.1f} GB/s  {path}  retries {st['retries']} slow {st['slow_starts']} kernels {st['scan_ms']:.3f} ms", flush=True)
     except Exception as e:  # noqa: BLE001
         print(f"{rx.decode():28s} ERROR {e!r}"[:200], flush=True)
