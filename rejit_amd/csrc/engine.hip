@@ -752,6 +752,12 @@ static int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb,
   const bool window_runs = windows && se >= n && n - std::min(sb, n) >= (256u << 10) && (!s->runs_sparse || s->window_dense) && !no_window_runs;
   // (`^[A-Z][a-z]+`: a dense-mode shape behind `^` -- its candidates are the line starts, few and cheap on the general path (1.2 ms per
   // GiB of log-like text), where the run kernels would write every capitalised word and filter 98 % of them away again (1.8 ms))
+  // (... and where the shape is `X+` / `X+ Y` -- ` +`, `=+`, `-+>` -- dense_streams decides runs of up to 47 bytes in registers in ONE pass:
+  // ` +` over the same text 0.7 ms against the run kernels' 1.5; texts of longer runs send it back through streams_off, as in dense mode)
+  if (window_runs && fresh && rp->stream.n_pos != 0 && rp->stream.run_shape != 0 && !rp->stream.select && !s->streams_off && !s->linear_hint && !runs_first) {
+    int rc = run_streams(s, d_text, n, sb, se, st);
+    if (rc != 0) return rc < 0 ? rc : RJ_OK;
+  }
   const bool bol_dense = rp->run.bol != 0 && !windows && !runs_first;
   if (rp->run.ok && (runs_first || s->linear_hint || window_runs || (!windows && !bol_dense && (!fresh || rp->stream.n_pos == 0 || s->streams_off)))) {
     int rc = run_runs(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);

@@ -218,7 +218,12 @@ def test_window_mode_run_shapes_take_the_run_kernels_first(rj, oracle):
     n = 400000
     dense = bytes(rng.choice(b"abcdefgh <>#()\n ") for _ in range(n))
     sparse = bytearray(rng.choice(b"cdefgh\n") for _ in range(n))
-    for rx, plant in ((b"a.*b", b"a cd b"), (b"#.*", b"# x"), (b"<[^>]*>", b"<cd>"), (b"\\([^)]*\\)", b"(e)"), (b" +", b"  ")):
+    # (` +` -- `X+`: dense_streams first, one pass with the runs decided in registers; the run kernels behind it)
+    sc = rj.Scan(rj.Program(b" +"))
+    t = device_text(dense)
+    assert sc.run(t.data_ptr(), n) == len(oracle.match_all(b" +", dense)) and sc.spans() == oracle.match_all(b" +", dense)
+    assert sc.stats()["stream_path"] == 1 and sc.stats()["run_path"] == 0
+    for rx, plant in ((b"a.*b", b"a cd b"), (b"#.*", b"# x"), (b"<[^>]*>", b"<cd>"), (b"\\([^)]*\\)", b"(e)"), (b"#.+", b"# x")):
         sp = bytearray(sparse)
         sp[n // 2:n // 2 + len(plant)] = plant
         sp = bytes(sp)
