@@ -310,9 +310,11 @@ def test_match_first_and_anywhere_early_exit(rj, oracle):
     tb = t.tobytes()
     p = prog(rj, b"regexp")
     p.match_first(tb)
-    t0 = time.perf_counter(); p.match_first(tb); early = time.perf_counter() - t0
-    t0 = time.perf_counter(); p.match_all(tb); full = time.perf_counter() - t0
-    assert early < full / 2, (early, full)
+    early, full = [], []
+    for _ in range(5):   # (wall clock on a shared host: the best of five each -- one descheduled call failed this once in ten suite runs)
+        t0 = time.perf_counter(); p.match_first(tb); early.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); p.match_all(tb); full.append(time.perf_counter() - t0)
+    assert min(early) < min(full) / 2, (early, full)
     # small texts vs the oracle (all block logic collapses to one run)
     rng = random.Random(3)
     for rx in (b"a+b", b"^b", b"b$", b"x*", b"(ab|ba)+"):
