@@ -1284,6 +1284,63 @@ def literal_and_complex_extras(args, c, out):
     except Exception as e:  # noqa: BLE001
         out.setdefault("quoted_strings", {})["error"] = repr(e)[:300]
 
+    # Everyday patterns on everyday text: `#.*` (a comment to the end of its line) and `a.*b` over 1 GiB of synthetic log-like text
+    # (letters, digits, punctuation, a line break every ~70 bytes: tools/probes/zoo.py's text).  Their fast-forward window is ONE byte that
+    # such a text holds everywhere; until the last session of round 6 every hit was a walk (`#.*` 6.9 ms, `a.*b` 33.7 ms:
+    # profiles/r06_zoo.txt), now windows-mode run shapes take the run kernels first (DESIGN.md 4.11 "When").  `#.*` is checked in
+    # full against torch (the first `#` of every line that holds one, to the line's end), `a.*b` by properties.
+    try:
+        nz = 1 << 30
+        gz = torch.Generator(device=dev)
+        gz.manual_seed(5)
+        weights = {ch: 30 for ch in b"etaoinshrdlucmfwypvbgkqjxz"}
+        weights.update({ch: 6 for ch in b"0123456789"})
+        weights[ord(" ")] = 60
+        weights.update({ch: 4 for ch in b".,:;=-_/@()<>\"'#"})
+        weights.update({ch: 8 for ch in b"ETAOINSHR"})
+        weights[10] = 16
+        syms = torch.tensor(list(weights.keys()), dtype=torch.uint8, device=dev)
+        wz = torch.tensor([float(v) for v in weights.values()], device=dev)
+        tz = syms[torch.multinomial(wz, nz, replacement=True, generator=gz)].contiguous()
+        rec = {"workload": "MatchAll over %d bytes of synthetic log-like text (tools/probes/zoo.py)" % nz, "patterns": {}}
+        nl_pos = torch.nonzero(tz == 10).flatten()
+        for rx in ("#.*", "a.*b"):
+            sz = rejit_amd.Scan(rejit_amd.Program(rx))
+            sz.run(tz.data_ptr(), nz, stream=c.stream)
+            zs = []
+            for _ in range(5):
+                t0z = time.perf_counter()
+                kz = sz.run(tz.data_ptr(), nz, stream=c.stream)
+                zs.append(time.perf_counter() - t0z)
+            spz = sz.spans_tensor(dev)
+            first_byte = ord(rx[0])
+            # per line: the first position of the pattern's first byte; the match ends at the line's end (`#.*`) / behind the line's last b
+            hp = torch.nonzero(tz == first_byte).flatten()
+            line_of = torch.searchsorted(nl_pos, hp)                      # the number of line breaks before the position
+            firsts = hp[torch.cat([torch.ones(1, dtype=torch.bool, device=dev), line_of[1:] != line_of[:-1]])]
+            ends_of_line = torch.cat([nl_pos, torch.tensor([nz], device=dev)])[torch.searchsorted(nl_pos, firsts)]
+            if rx == "#.*":
+                ok = int(kz) == int(firsts.numel()) and bool((spz[:, 0] == firsts).all().item()) and bool((spz[:, 1] == ends_of_line).all().item())
+            else:
+                # every match begins at its line's first a, ends behind a b inside the line, and no b lies between its end and the line's end
+                sel = torch.searchsorted(firsts, spz[:, 0].contiguous())
+                on_first = bool((firsts[sel.clamp(max=firsts.numel() - 1)] == spz[:, 0]).all().item())
+                eol = ends_of_line[sel.clamp(max=firsts.numel() - 1)]
+                bcs = torch.cumsum((tz == ord("b")).to(torch.int32), 0)
+                no_b_behind = bool((bcs[(eol - 1).clamp(min=0)] == bcs[spz[:, 1] - 1]).all().item())
+                ok = on_first and bool((tz[spz[:, 1] - 1] == ord("b")).all().item()) and bool((spz[:, 1] <= eol).all().item()) and no_b_behind
+                del bcs
+            st_z = sz.stats()
+            rec["patterns"][rx] = {"matches": int(kz), "latency_ms": round(sorted(zs)[len(zs) // 2] * 1e3, 4), "value": round(nz / sorted(zs)[len(zs) // 2] / 1e9, 1),
+                                   "unit": "GB/s of text", "kernels_ms": round(st_z["scan_ms"], 4), "run_path": st_z["run_path"], "checked_against_torch": ok}
+            del spz, hp, line_of, firsts, ends_of_line, sz
+        rec["before"] = "profiles/r06_zoo.txt (RJ_NO_RUNS=1): `#.*` 6.9 ms, `a.*b` 33.8 ms -- the window scan + a walk per hit"
+        out["everyday_patterns"] = rec
+        del tz, nl_pos
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001
+        out.setdefault("everyday_patterns", {})["error"] = repr(e)[:300]
+
     if not args.no_big:
         # the north star's target run: the fast-forward scan over a 50 GB synthetic text on ONE GPU
         nb = args.big_literal_bytes
