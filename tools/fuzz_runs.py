@@ -67,14 +67,23 @@ for case in range(cases):
     full = oracle.match_all(rx, text)
     mode = rng.random()
     kw = {}
+    asserted = rx.startswith(b"^") or rx.endswith(b"$")
+
+    def line_start(p):
+        # A range begins afresh (no selection state is carried in) but its CONTEXT is the real text's: the byte before it says whether
+        # it begins at a line start.  The oracle knows "the whole text" and "the suffix as a text of its own"; the two agree with the
+        # engine on `^` patterns when the range begins at a line start, so such ranges are moved to one.
+        while asserted and 0 < p < n and text[p - 1] not in b"\n\r":
+            p += 1
+        return min(p, n - 1) if n else 0
     if mode < 0.5:
         want = full
     elif mode < 0.75:
-        ob = rng.randrange(0, n); oe = rng.randrange(ob, n + 2)
+        ob = line_start(rng.randrange(0, n)); oe = rng.randrange(ob, n + 2)
         kw = dict(own_begin=ob, own_end=oe)
         want = [(x + ob, y + ob) for x, y in oracle.match_all(rx, text[ob:]) if x + ob < oe]
     else:
-        cut = rng.randrange(0, n)
+        cut = line_start(rng.randrange(0, n))
         before = [m for m in full if m[0] < cut]
         kw = dict(own_begin=cut, own_end=n + 1)
         if before:
