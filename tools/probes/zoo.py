@@ -27,7 +27,7 @@ text = syms[torch.multinomial(w, n, replacement=True, generator=g)].contiguous()
 PATTERNS = [b"[a-z]+@[a-z]+", b"[0-9]+\\.[0-9]+", b"[A-Za-z_][A-Za-z0-9_]*", b"//.*", b"#.*", b"[0-9]+-[0-9]+", b"\\([^)]*\\)", b"[a-z]+ing", b" +",
             b"\"[^\"]*\"", b"<[a-z]+>", b"[0-9][0-9]:[0-9][0-9]", b"[a-z]+=[a-z0-9]+", b"error", b"(error|warning|fatal)", b"[A-Z][a-z]+", b"[a-z]+\\.[a-z]+",
             b"^[a-z]+", b"[a-z]+$", b"the [a-z]+", b"[0-9]+", b"0x[0-9a-f]+", b"[a-z]+[0-9]+[a-z]+", b".*error.*", b"[^ ]+@[^ ]+",
-            b"a.*b", b"<[^>]*>", b"a.+b", b"<[^>]+>", b"#.+", b"@[a-z]+", b"[a-z][a-z0-9]+", b"^#.*", b"#.*$", b"^a.*b", b"[A-Z][a-z]+$", b"^[A-Z][a-z]+"]
+            b"a.*b", b"<[^>]*>", b"a.+b", b"<[^>]+>", b"#.+", b"@[a-z]+", b"[a-z][a-z0-9]+", b"^#.*", b"#.*$", b"^a.*b", b"[A-Z][a-z]+$", b"^[A-Z][a-z]+", b" +$", b"^ +", b"^[a-z]+$"]
 if len(sys.argv) > 2:
     PATTERNS = [p.encode() for p in sys.argv[2:]]
 for rx in PATTERNS:
