@@ -589,7 +589,7 @@ static int run_runs(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, 
   RJ_HIP(hipStreamSynchronize(st));   // (the number of pairs sizes the output)
   RJ_HIP(hipGetLastError());
   const uint64_t cnt = s->host_counters[kCntFinal];
-  const bool line_filter = rp->run.bol != 0 || rp->run.eol != 0;   // (`^#.*`, `#.*$`: every match is looked at once more)
+  const bool line_filter = rp->run.eol != 0;   // (`#.*$`: every match is looked at once more; `^` is a mask on the kernels' start stream)
   if (s->count_only_run && sb == 0 && se > n && !line_filter) {   // MatchAllCount of the whole text: one pass over it
     s->result_count = cnt;
     s->result = nullptr;
@@ -621,7 +621,7 @@ static int run_runs(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, 
     LineFilterParams f{};
     f.text = d_text;
     f.n = n;
-    f.bol = rp->run.bol;
+    f.bol = 0;   // (in the kernels: run_scan.hip, bol_stream)
     f.eol = rp->run.eol;
     f.in = s->out.as<uint64_t>();
     f.cnt = cnt;
@@ -758,7 +758,8 @@ static int run_range(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb,
     int rc = run_streams(s, d_text, n, sb, se, st);
     if (rc != 0) return rc < 0 ? rc : RJ_OK;
   }
-  const bool bol_dense = rp->run.bol != 0 && !windows && !runs_first;
+  static const bool bol_dense_general = getenv("RJ_BOL_DENSE_GENERAL") != nullptr;   // measurement override: the policy before the in-kernel `^`
+  const bool bol_dense = rp->run.bol != 0 && !windows && !runs_first && bol_dense_general;
   if (rp->run.ok && (runs_first || s->linear_hint || window_runs || (!windows && !bol_dense && (!fresh || rp->stream.n_pos == 0 || s->streams_off)))) {
     int rc = run_runs(s, d_text, n, sb, se, carry_cur, carry_prev_end, have_prev, st);
     if (rc != 0) {

@@ -54,9 +54,10 @@ __device__ __forceinline__ RunMasks<NR> run_masks(const RunPlan& pl) {
 }
 
 // the three streams of the lane's 32 bytes at `at`: A, B, breaks (a byte outside L; the text's end is one)
+// SNL (RunPlan::bol: `^` in front of the shape): the stream of the line breaks \n / \r
 template <int NR, bool HAS_B>
 __device__ __forceinline__ void run_streams_of(const RunParams& a, const RunMasks<NR>& mk, uint64_t at, const uint4& v0, const uint4& v1, bool loaded,
-                                               uint32_t* SA, uint32_t* SB, uint32_t* BR) {
+                                               uint32_t* SA, uint32_t* SB, uint32_t* BR, uint32_t* SNL = nullptr) {
   uint32_t x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
   uint32_t valid = ~0u;
   if (!loaded) {   // (an iteration that touches the end of the text: byte by byte)
@@ -98,6 +99,9 @@ __device__ __forceinline__ void run_streams_of(const RunParams& a, const RunMask
   *SA = sa;
   *SB = sb;
   *BR = br;
+  if (SNL) {   // (0x0a / 0x0d as ranges of one byte: add constants as run_detail::add_class makes them)
+    *SNL = a.plan.bol ? (rj_stream_range(x7, lowh, 0x76767676u, 0x75757575u) | rj_stream_range(x7, lowh, 0x73737373u, 0x72727272u)) & valid : 0u;
+  }
 }
 
 // bits of the lane's word whose index lane * 32 + bit lies in [lo, hi)
@@ -192,14 +196,29 @@ __device__ __forceinline__ uint32_t lag_marks(uint32_t SA, uint32_t BR, uint32_t
   prev_a = last_lane(SA) >> 31;
   return ((SA << 1) | cin) & ~BR;   // (BR holds the text's end: no mark there or beyond)
 }
-// ... and at a tile's begin: the A bit of the byte before the tile (every lane reads the same 32 bytes, once per tile)
+// RunPlan::bol (`^` in front): "the byte before p is a line break, or p is the text's begin"; prev_nl as prev_a
+__device__ __forceinline__ uint32_t bol_stream(uint32_t SNL, uint32_t& prev_nl) {
+  const uint32_t below = lane_below(SNL) >> 31;
+  const uint32_t cin = lane_id() == 0 ? prev_nl : below;
+  prev_nl = last_lane(SNL) >> 31;
+  return (SNL << 1) | cin;
+}
+// ... and at a tile's begin: the two carries from the two bytes before the tile (every lane reads the same 32 bytes, once per tile;
+// tiles begin at multiples of 2 KiB: base >= 2 unless it is 0)
 template <int NR, bool HAS_B>
-__device__ __forceinline__ uint32_t lag_entry(const RunParams& a, const RunMasks<NR>& mk, uint64_t base) {
-  if (!a.plan.lag || base == 0) return 0u;
-  uint32_t sa, sb, br;
+__device__ __forceinline__ void run_entry(const RunParams& a, const RunMasks<NR>& mk, uint64_t base, uint32_t& prev_a, uint32_t& prev_nl) {
+  prev_a = 0u;
+  prev_nl = base == 0 ? 1u : 0u;   // (the text's begin is a line start)
+  if ((!a.plan.lag && !a.plan.bol) || base == 0) return;
+  uint32_t sa, sb, br, snl;
   const uint4 none = make_uint4(0, 0, 0, 0);
-  run_streams_of<NR, HAS_B>(a, mk, base - 1, none, none, false, &sa, &sb, &br);
-  return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(sa))) & 1u;
+  run_streams_of<NR, HAS_B>(a, mk, base - 2, none, none, false, &sa, &sb, &br, &snl);
+  sa = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(sa)));
+  snl = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(snl)));
+  uint32_t a1 = (sa >> 1) & 1u;                 // A at base - 1 ...
+  if (a.plan.bol) a1 &= snl & 1u;               // ... a start only behind a line break (base - 2)
+  prev_a = a.plan.lag ? a1 : 0u;
+  prev_nl = a.plan.bol ? (snl >> 1) & 1u : 0u;
 }
 __device__ __forceinline__ unsigned long long lane_value(unsigned long long x, int l) {
   const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(x)), l));
@@ -320,14 +339,16 @@ __global__ __launch_bounds__(256) void run_summary(RunParams a) {
     }
   };
   fetch(0);
-  uint32_t prev_a = lag_entry<NR, HAS_B>(a, mk, base);
+  uint32_t prev_a, prev_nl;
+  run_entry<NR, HAS_B>(a, mk, base, prev_a, prev_nl);
 #pragma unroll 1
   for (int it = 0; it < kIters; it++) {
     const uint64_t it_base = base + static_cast<uint64_t>(it) * kIterBytes;
     if (it_base > a.n) break;   // (nothing here, not even the text's end)
-    uint32_t SA, SB, BR;
-    run_streams_of<NR, HAS_B>(a, mk, it_base + static_cast<uint64_t>(lane) * 32, v0, v1, loaded, &SA, &SB, &BR);
+    uint32_t SA, SB, BR, SNL;
+    run_streams_of<NR, HAS_B>(a, mk, it_base + static_cast<uint64_t>(lane) * 32, v0, v1, loaded, &SA, &SB, &BR, &SNL);
     if (it + 1 < kIters) fetch(it + 1);
+    if (a.plan.bol) SA &= bol_stream(SNL, prev_nl);   // `^`: an A counts only at a line start (before the shift of `A L+`)
     if (a.plan.lag) SA = lag_marks(SA, BR, prev_a);
     SA = clip_starts(a, it_base, SA);
     const uint64_t brm = __ballot(BR != 0);
@@ -577,14 +598,16 @@ __global__ __launch_bounds__(256) void run_emit(RunParams a) {
     }
   };
   fetch(0);
-  uint32_t prev_a = lag_entry<NR, HAS_B>(a, mk, base);
+  uint32_t prev_a, prev_nl;
+  run_entry<NR, HAS_B>(a, mk, base, prev_a, prev_nl);
 #pragma unroll 1
   for (int it = 0; it < kIters; it++) {
     const uint64_t it_base = base + static_cast<uint64_t>(it) * kIterBytes;
     if (it_base > a.n) break;
-    uint32_t SA, SB, BR;
-    run_streams_of<NR, HAS_B>(a, mk, it_base + static_cast<uint64_t>(lane) * 32, v0, v1, loaded, &SA, &SB, &BR);
+    uint32_t SA, SB, BR, SNL;
+    run_streams_of<NR, HAS_B>(a, mk, it_base + static_cast<uint64_t>(lane) * 32, v0, v1, loaded, &SA, &SB, &BR, &SNL);
     if (it + 1 < kIters) fetch(it + 1);
+    if (a.plan.bol) SA &= bol_stream(SNL, prev_nl);   // `^`: an A counts only at a line start (before the shift of `A L+`)
     if (a.plan.lag) SA = lag_marks(SA, BR, prev_a);
     SA = clip_starts(a, it_base, SA);
     const uint64_t brm = __ballot(BR != 0);
