@@ -589,8 +589,8 @@ static int run_runs(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, 
   RJ_HIP(hipStreamSynchronize(st));   // (the number of pairs sizes the output)
   RJ_HIP(hipGetLastError());
   const uint64_t cnt = s->host_counters[kCntFinal];
-  const bool line_filter = rp->run.eol != 0;   // (`#.*$`: every match is looked at once more; `^` is a mask on the kernels' start stream)
-  if (s->count_only_run && sb == 0 && se > n && !line_filter) {   // MatchAllCount of the whole text: one pass over it
+  // (`^` in front of the shape is a mask on the kernels' start stream, `$` behind it a test of the closing break: run_scan.hip)
+  if (s->count_only_run && sb == 0 && se > n) {   // MatchAllCount of the whole text: one pass over it
     s->result_count = cnt;
     s->result = nullptr;
     s->hits_hint = cnt;
@@ -613,35 +613,8 @@ static int run_runs(rj_scan* s, const uint8_t* d_text, uint64_t n, uint64_t sb, 
   float ms = 0.f;
   if (s->timing) (void)hipEventElapsedTime(&ms, s->ev[1], s->ev[2]);
   s->stats.scan_ms += ms;   // (first pass's start to the second pass's end, the scan between them included)
-  uint64_t kept = cnt;
-  const uint64_t* result = s->out.as<uint64_t>();
-  if (line_filter && cnt) {
-    // `^` / `$` around the shape (run_scan.h: RunPlan::bol / eol): of these matches, the ones that begin at a line start / end at
-    // a line end -- counted per group of pairs, the groups' offsets by the region scan, the survivors moved in order
-    LineFilterParams f{};
-    f.text = d_text;
-    f.n = n;
-    f.bol = 0;   // (in the kernels: run_scan.hip, bol_stream)
-    f.eol = rp->run.eol;
-    f.in = s->out.as<uint64_t>();
-    f.cnt = cnt;
-    f.n_groups = line_filter_groups(cnt, &f.per);
-    RJ_HIP(s->hit_counts.reserve(sizeof(uint32_t) * static_cast<size_t>(f.n_groups)));
-    RJ_HIP(s->hit_offsets.reserve(sizeof(uint64_t) * (static_cast<size_t>(f.n_groups) + 1)));
-    RJ_HIP(s->run_filtered.reserve(cnt * 2 * sizeof(uint64_t)));
-    f.counts = s->hit_counts.as<uint32_t>();
-    f.offsets = s->hit_offsets.as<uint64_t>();
-    f.out = s->run_filtered.as<uint64_t>();
-    f.counters = s->counters.as<unsigned long long>();
-    f.host_counters = s->host_counters;
-    launch_line_filter(f, st);
-    RJ_HIP(hipStreamSynchronize(st));
-    RJ_HIP(hipGetLastError());
-    kept = s->host_counters[kCntFinal];
-    result = s->run_filtered.as<uint64_t>();
-  }
-  s->result_count = kept;
-  s->result = (s->count_only_run && sb == 0 && se > n) ? nullptr : result;
+  s->result_count = cnt;
+  s->result = s->out.as<uint64_t>();
   s->hits_hint = cnt;
   s->stats.n_hits += cnt;
   s->stats.n_candidates += cnt;

@@ -117,7 +117,6 @@ struct rj_scan {
   rejit_amd::DeviceBuffer cs_vals, cs_mats, cs_e, cs_g, cs_entry, cs_counts, cs_scratch, cs_acc, cs_groups;
   bool linear_hint = false;        // the previous run needed the carry scan: go there directly
   rejit_amd::DeviceBuffer run_summaries, run_tile_in;  // run_scan.hip
-  rejit_amd::DeviceBuffer run_filtered;                // ... `^` / `$` around a run shape: the matches the line filter keeps
   bool count_only_run = false;   // (scan_count: this run's pairs are not wanted -- the run kernels stop behind their resolve)
   // a WINDOWS-mode run shape (`a.*b`, `#.*`, `<[^>]*>`, ` +`: the window is one byte) takes the run kernels first; runs_sparse: they
   // found few matches on this scan's text, the next run tries the window scan (faster when its hits are rare); window_dense: that

@@ -300,24 +300,6 @@ uint64_t run_resolve_slots(uint64_t n_tiles);   // elements of `summaries` and o
 void launch_run_summary(const RunParams& a, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 void launch_run_resolve(const RunParams& a, hipStream_t st);
 void launch_run_emit(const RunParams& a, hipEvent_t t1, hipStream_t st);
-// `^` / `$` around a run shape (RunPlan::bol / eol): of the matches of the shape without them, those that begin at a line start / end at a
-// line end, in order (run_scan.hip: line_filter_count -> region_offsets -> line_filter_scatter; the number left in counters[kCntFinal])
-struct LineFilterParams {
-  const uint8_t* text;
-  uint64_t n;
-  uint32_t bol, eol;
-  const uint64_t* in;      // cnt (begin, end) pairs
-  uint64_t cnt;
-  uint32_t per;            // pairs per workgroup
-  uint32_t n_groups;
-  uint32_t* counts;        // [n_groups]
-  uint64_t* offsets;       // [n_groups + 1]
-  uint64_t* out;
-  unsigned long long* counters;
-  unsigned long long* host_counters;
-};
-uint32_t line_filter_groups(uint64_t cnt, uint32_t* per);
-void launch_line_filter(const LineFilterParams& a, hipStream_t st);
 // the PAIR shape (`"[^"]*"`: run_scan.h), the same three steps over the same buffers
 void launch_pair_summary(const RunParams& a, hipEvent_t t0, hipEvent_t t1, hipStream_t st);
 void launch_pair_resolve(const RunParams& a, hipStream_t st);

@@ -43,8 +43,8 @@ struct RunPlan {
   uint32_t a_ranges, l_ranges, b_ranges;   // bit r: the class (or its complement) holds range r
   uint32_t a_neg, l_neg, b_neg;            // 1: the class is the complement of its ranges
   uint32_t lag;                 // 1: `A L+` / `A L+ B` -- the kernels' start stream is "A at p - 1 and L at p" (below), a match begins one byte before its start
-  uint32_t bol, eol;            // `^...` / `...$` around a shape: the kernels run as without them, run_line_filter keeps the matches that begin at a
-                                // line start / end at a line end (below)
+  uint32_t bol, eol;            // `^...` / `...$` around a shape: a start counts at a line start only (a mask on the start stream) / a match when its
+                                // closing break is a line end (below; run_scan.hip: bol_stream, the SNL bit at the break)
   uint32_t pair;                // the PAIR shape (`"[^"]*"`; below): ok stays 0, the pair kernels of run_scan.hip take the pattern
 };
 

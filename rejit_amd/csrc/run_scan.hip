@@ -100,7 +100,10 @@ __device__ __forceinline__ void run_streams_of(const RunParams& a, const RunMask
   *SB = sb;
   *BR = br;
   if (SNL) {   // (0x0a / 0x0d as ranges of one byte: add constants as run_detail::add_class makes them)
-    *SNL = a.plan.bol ? (rj_stream_range(x7, lowh, 0x76767676u, 0x75757575u) | rj_stream_range(x7, lowh, 0x73737373u, 0x72727272u)) & valid : 0u;
+    // (RunPlan::eol reads it at the closing breaks: the text's end closes a line too)
+    uint32_t snl = (a.plan.bol | a.plan.eol) ? (rj_stream_range(x7, lowh, 0x76767676u, 0x75757575u) | rj_stream_range(x7, lowh, 0x73737373u, 0x72727272u)) & valid : 0u;
+    if (a.plan.eol && a.n >= at && a.n - at < 32) snl |= 1u << static_cast<uint32_t>(a.n - at);
+    *SNL = snl;
   }
 }
 
@@ -357,9 +360,13 @@ __global__ __launch_bounds__(256) void run_summary(RunParams a) {
       continue;
     }
     const LaneClose c = run_iteration_par<HAS_B>(it_base, SA, SB, BR, brm, st);
-    bool first = BR != 0 && counted<HAS_B>(a, Open{c.s, c.q});
+    // RunPlan::eol (`$` behind a shape without B): a match ends at its segment's closing break, and counts when that break is a line end
+    const bool eol = a.plan.eol != 0;
+    const bool first_at_eol = !eol || (BR != 0 && ((SNL >> static_cast<uint32_t>(__builtin_ctz(BR | 0x80000000u))) & 1u) != 0);
+    bool first = BR != 0 && first_at_eol && counted<HAS_B>(a, Open{c.s, c.q});
     if (before_first) {   // the tile's first break: what it closes depends on the tiles before
       const int l1 = __builtin_ctzll(brm);
+      sum.pad = __builtin_amdgcn_readlane(static_cast<int>(first_at_eol ? 0 : 1), l1) != 0 ? 1ull : 0ull;   // (1: whatever it closes does not count)
       sum.r1 = it_base + static_cast<uint64_t>(l1) * 32u + static_cast<uint32_t>(__builtin_ctz(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(BR), l1))));
       sum.a1 = lane_value(c.s, l1);
       sum.b1a = lane_value(c.q, l1);
@@ -371,9 +378,9 @@ __global__ __launch_bounds__(256) void run_summary(RunParams a) {
     cnt += static_cast<unsigned long long>(__popcll(__ballot(first)));
     if (__ballot((BR & (BR - 1u)) != 0) != 0) {   // (some lane holds two breaks)
       uint32_t inner = 0;
-      for_inner<HAS_B>(SA, SB, BR, [&](uint32_t s, uint32_t, uint32_t) {
+      for_inner<HAS_B>(SA, SB, BR, [&](uint32_t s, uint32_t, uint32_t r) {
         const uint64_t at = it_base + static_cast<uint64_t>(lane) * 32u + s;
-        if (at >= a.sb && at < a.se) inner++;
+        if (at >= a.sb && at < a.se && (!eol || ((SNL >> r) & 1u) != 0)) inner++;
       });
       cnt += last_lane(wave_prefix_sum(inner));
     }
@@ -401,7 +408,8 @@ struct Elem {
   unsigned long long hb;   // holds a break
   unsigned long long a1, b1, b1a, open_s, open_q, cnt;
 };
-__device__ __forceinline__ Elem elem_of(const RunSummary& s) { return Elem{s.r1 != kNone ? 1ull : 0ull, s.a1, s.b1, s.b1a, s.open_s, s.open_q, s.cnt}; }
+// hb: 0 = no break; 1 = the first break closes what came in; 2 (RunPlan::eol) = it is no line end: whatever it closes does not count
+__device__ __forceinline__ Elem elem_of(const RunSummary& s) { return Elem{s.r1 != kNone ? (s.pad ? 2ull : 1ull) : 0ull, s.a1, s.b1, s.b1a, s.open_s, s.open_q, s.cnt}; }
 __device__ __forceinline__ RunSummary summary_of(const Elem& e) {   // (a block of tiles in the tiles' own format: r1 is a flag only)
   RunSummary s;
   s.r1 = e.hb ? 0ull : kNone;
@@ -411,7 +419,7 @@ __device__ __forceinline__ RunSummary summary_of(const Elem& e) {   // (a block 
   s.open_s = e.open_s;
   s.open_q = e.open_q;
   s.cnt = e.cnt;
-  s.pad = 0;
+  s.pad = e.hb == 2 ? 1ull : 0ull;
   return s;
 }
 // the state behind a stretch without a break
@@ -438,10 +446,10 @@ __device__ __forceinline__ Elem compose(const RunParams& a, const Elem& f, const
     e.b1 = f.b1;
     e.b1a = f.b1a;
   }
-  e.hb = (f.hb | g.hb) ? 1ull : 0ull;
+  e.hb = f.hb ? f.hb : g.hb;   // (the composite's first break)
   e.cnt = f.cnt + g.cnt;
   if (g.hb) {
-    if (f.hb && counted(a, pass_on(g, Open{f.open_s, f.open_q}))) e.cnt++;   // g's first break is not the composite's first
+    if (f.hb && g.hb == 1 && counted(a, pass_on(g, Open{f.open_s, f.open_q}))) e.cnt++;   // g's first break is not the composite's first
     e.open_s = g.open_s;
     e.open_q = g.open_q;
   } else if (f.hb) {
@@ -457,7 +465,7 @@ __device__ __forceinline__ Elem compose(const RunParams& a, const Elem& f, const
 __device__ __forceinline__ Open apply(const RunParams& a, const Elem& g, Open in, bool* emits) {
   *emits = false;
   if (!g.hb) return pass_on(g, in);
-  *emits = counted(a, pass_on(g, in));
+  *emits = g.hb == 1 && counted(a, pass_on(g, in));
   return Open{g.open_s, g.open_q};
 }
 
@@ -617,12 +625,13 @@ __global__ __launch_bounds__(256) void run_emit(RunParams a) {
     }
     const LaneClose c = run_iteration_par<HAS_B>(it_base, SA, SB, BR, brm, st);
     const uint64_t word = it_base + static_cast<uint64_t>(lane) * 32u;
-    const bool first = BR != 0 && counted<HAS_B>(a, Open{c.s, c.q});
+    const bool eol = a.plan.eol != 0;   // (`$`: the closing break must be a line end -- as run_summary counted)
+    const bool first = BR != 0 && (!eol || ((SNL >> static_cast<uint32_t>(__builtin_ctz(BR | 0x80000000u))) & 1u) != 0) && counted<HAS_B>(a, Open{c.s, c.q});
     const bool multi = __ballot((BR & (BR - 1u)) != 0) != 0;
     uint32_t mine = first ? 1u : 0u;
     if (multi)
-      for_inner<HAS_B>(SA, SB, BR, [&](uint32_t s, uint32_t, uint32_t) {
-        if (word + s >= a.sb && word + s < a.se) mine++;
+      for_inner<HAS_B>(SA, SB, BR, [&](uint32_t s, uint32_t, uint32_t r) {
+        if (word + s >= a.sb && word + s < a.se && (!eol || ((SNL >> r) & 1u) != 0)) mine++;
       });
     if (__ballot(mine != 0) == 0) continue;
     const uint32_t inc = wave_prefix_sum(mine);
@@ -633,7 +642,7 @@ __global__ __launch_bounds__(256) void run_emit(RunParams a) {
     }
     if (multi)
       for_inner<HAS_B>(SA, SB, BR, [&](uint32_t s, uint32_t q, uint32_t r) {
-        if (word + s >= a.sb && word + s < a.se) {
+        if (word + s >= a.sb && word + s < a.se && (!eol || ((SNL >> r) & 1u) != 0)) {
           if (idx < a.out_cap) *reinterpret_cast<ulonglong2*>(a.out + 2 * idx) = make_ulonglong2(word + s - a.plan.lag, word + (HAS_B ? q + 1u : r));
           idx++;
         }
@@ -1074,70 +1083,6 @@ void launch_run_emit(const RunParams& a, hipEvent_t t1, hipStream_t st) {
   else if (nr <= 2) launch_emit_nr<2>(a, grid, t1, st);
   else if (nr <= 4) launch_emit_nr<4>(a, grid, t1, st);
   else launch_emit_nr<8>(a, grid, t1, st);
-}
-
-// ---- `^` / `$` around a run shape: the line filter (RunPlan::bol / eol, run_scan.h)
-namespace {
-__device__ __forceinline__ bool line_break(uint8_t c) { return c == 0x0a || c == 0x0d; }
-__device__ __forceinline__ bool line_keep(const LineFilterParams& a, uint64_t i) {
-  const ulonglong2 m = *reinterpret_cast<const ulonglong2*>(a.in + 2 * i);
-  bool ok = true;
-  if (a.bol) ok = m.x == 0 || line_break(a.text[m.x - 1]);       // codegen-x64.cc:686-708: a line starts behind \n / \r and at 0
-  if (ok && a.eol) ok = m.y >= a.n || line_break(a.text[m.y]);
-  return ok;
-}
-}  // namespace
-__global__ __launch_bounds__(256) void line_filter_count(LineFilterParams a) {
-  __shared__ uint32_t wave_n[4];
-  const uint64_t lo = static_cast<uint64_t>(blockIdx.x) * a.per, hi = lo + a.per < a.cnt ? lo + a.per : a.cnt;
-  uint32_t mine = 0;
-  for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) mine += line_keep(a, i) ? 1u : 0u;
-  const uint32_t w = wave_total(mine);
-  if (lane_id() == 0) wave_n[threadIdx.x >> 6] = w;
-  __syncthreads();
-  if (threadIdx.x == 0) a.counts[blockIdx.x] = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
-}
-__global__ __launch_bounds__(256) void line_filter_scatter(LineFilterParams a) {
-  __shared__ uint32_t wave_n[2][4];
-  const uint64_t lo = static_cast<uint64_t>(blockIdx.x) * a.per, hi = lo + a.per < a.cnt ? lo + a.per : a.cnt;
-  const int wv = static_cast<int>(threadIdx.x) >> 6;
-  uint64_t at = a.offsets[blockIdx.x];
-  int cur = 0;
-  for (uint64_t base = lo; base < hi; base += 256, cur ^= 1) {
-    const uint64_t i = base + threadIdx.x;
-    const bool keep = i < hi && line_keep(a, i);
-    const uint64_t bal = __ballot(keep);
-    if (lane_id() == 0) wave_n[cur][wv] = static_cast<uint32_t>(__popcll(bal));
-    __syncthreads();   // (two sets of wave counts used alternately: one barrier per round)
-    uint32_t before = 0, all = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      before += q < wv ? wave_n[cur][q] : 0u;
-      all += wave_n[cur][q];
-    }
-    if (keep) {
-      const uint64_t rank = at + before + static_cast<uint32_t>(__popcll(bal & lanes_below(lane_id())));
-      *reinterpret_cast<ulonglong2*>(a.out + 2 * rank) = *reinterpret_cast<const ulonglong2*>(a.in + 2 * i);
-    }
-    at += all;
-  }
-  if (blockIdx.x == a.n_groups - 1 && threadIdx.x == 0) {
-    const unsigned long long total = a.offsets[a.n_groups];
-    a.counters[kCntFinal] = total;
-    if (a.host_counters) a.host_counters[kCntFinal] = total;
-  }
-}
-// at most 64 Ki workgroups (launch_region_offsets' limit), 4096 pairs each or more
-uint32_t line_filter_groups(uint64_t cnt, uint32_t* per) {
-  uint64_t p = 4096;
-  while ((cnt + p - 1) / p > 65536) p *= 2;
-  *per = static_cast<uint32_t>(p);
-  return static_cast<uint32_t>((cnt + p - 1) / p);
-}
-void launch_line_filter(const LineFilterParams& a, hipStream_t st) {
-  hipLaunchKernelGGL(line_filter_count, dim3(a.n_groups), dim3(256), 0, st, a);
-  launch_region_offsets(a.counts, a.n_groups, 0xffffffffu, a.offsets, a.counters, st);
-  hipLaunchKernelGGL(line_filter_scatter, dim3(a.n_groups), dim3(256), 0, st, a);
 }
 
 // ---- the pair shape

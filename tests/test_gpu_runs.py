@@ -250,9 +250,10 @@ def test_window_mode_run_shapes_take_the_run_kernels_first(rj, oracle):
 
 def test_line_assertions_around_run_shapes(rj, oracle):
     """`^#.*`, `#.*$`, `^a.*b`, `^[A-Z][a-z]+$`: `^` in front / `$` behind a run shape whose classes hold no line break (run_scan.h:
-    RunPlan::bol / eol) -- the run kernels as without them, then the line filter (line_filter_count -> region scan ->
-    line_filter_scatter) keeps the matches that begin at a line start / end at a line end (reference: the contexts of
-    src/x64/codegen-x64.cc:686-708).  `X+` with an assertion is at risk of the reference's ring artefact and keeps the exact replay."""
+    RunPlan::bol / eol) -- in the run kernels `^` is a mask on the start stream (a start counts at a line start only) and `$` a test of the
+    closing break (a match counts when its segment's break is a line end), so that the matches are those of the shape that begin at a line
+    start / end at a line end (reference: the contexts of
+    src/x64/codegen-x64.cc:686-708).  `X+` with an assertion: the second half of this test."""
     rng = random.Random(49)
     took = 0
     for n in (70001, 300000, 1 << 20):

@@ -45,7 +45,7 @@ def run(pe, rx, text):
 def test_shapes_taken_and_refused(pe):
     for rx in (b"[acgt]+", b"[^>]+", b"x+", b"a[bc]*", b"a.*b", b"<[^>]*>", b"[a-f]+[0-9]", b"[\\x80-\\xff]+", b"q[a-z]*[0-9]", b"[ab]+b", b"a.*a",
                b"[A-Z][a-z]+", b"a.+b", b"<[^>]+>", b"#.+", b"a.+a",    # (these five: `A L+` / `A L+ B`, round 6 last session -- lag)
-               b"^#.*", b"#.*$", b"^a.*b", b"^[A-Z][a-z]+$", b"^#.+", b"a[bc]*$",    # (`^` / `$` around a shape: the line filter)
+               b"^#.*", b"#.*$", b"^a.*b", b"^[A-Z][a-z]+$", b"^#.+", b"a[bc]*$",    # (`^` / `$` around a shape)
                b"^[a-z]+", b"[a-z]+$", b" +$", b"^x+$"):   # (`X+` between them: at risk of the ring artefact by the static analysis, but see run_scan.h)
         k, spans, shape = run(pe, rx, b"")
         assert k == 0, (rx, k)

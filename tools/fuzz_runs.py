@@ -52,7 +52,7 @@ for case in range(cases):
         rx = a + b".+" + b
     else:
         rx = a + b".*" + b
-    if rng.random() < 0.25:   # `^` / `$` around the shape (RunPlan::bol / eol: the line filter)
+    if rng.random() < 0.25:   # `^` / `$` around the shape (RunPlan::bol / eol)
         rx = rng.choice([b"^" + rx, rx + b"$", b"^" + rx + b"$"])
     n = rng.choice([17, 100, 2048, 2049, 8192, 8200, 16384, 40000, 70001, 300000])
     dense = rng.random()
@@ -105,7 +105,7 @@ for case in range(cases):
         continue
     took += 1 if st["run_path"] else 0
     refused += 0 if st["run_path"] else 1
-    # (`^` / `$`: the line filter reads the byte before the range -- a range that begins inside a line has no line start there, the
+    # (`^` / `$`: the kernels read the byte before the range -- a range that begins inside a line has no line start there, the
     # whole text's answer; an independent run of the suffix would see one)
     if got != want and "own_begin" in kw and "have_prev" not in kw and (not st["run_path"] or rx.startswith(b"^") or rx.endswith(b"$")):
         # (an independent range through a kernel that looks at the byte before the range -- match_small, dense_streams: the
