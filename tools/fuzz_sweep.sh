@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 seed=${1:-1}; lim=${2:-150}
 out=gpurun_out/fuzz_sweep_$seed.txt; : > $out
-run() { echo "== $*" >> $out; timeout $lim "$@" 2>&1 | tail -4 >> $out; echo "rc=$?" >> $out; }   # (VAR=x run ...: the environment reaches the command)
+run() { echo "== $*" >> $out; timeout $lim "$@" > $out.one 2>&1; rc=$?; tail -4 $out.one >> $out; [ $rc -eq 124 ] && echo "TIMED OUT after $lim s (no summary)" >> $out; echo "rc=$rc" >> $out; rm -f $out.one; }   # (VAR=x run ...: the environment reaches the command)
 run python tools/fuzz_counts.py 300 $((seed + 100))
 run python tools/fuzz_counts_general.py 400 $((seed + 200))
 run python tools/fuzz_runs.py 1500 $((seed + 300))
